@@ -1,0 +1,143 @@
+"""ctypes wrapper around oracle/_build/liboracle.so  (TEST INFRASTRUCTURE ONLY).
+
+The oracle is the CPU restatement of the reference algorithm
+(/root/reference/src/osqppurepy/_osqp.py, see osqp_oracle.c for per-function citations).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+import scipy.sparse as sp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, '_build', 'liboracle.so')
+
+# status values (v1.0.0 enum order, bindings.cpp.in:349-361)
+SOLVED, SOLVED_INACCURATE, PRIMAL_INFEASIBLE, PRIMAL_INFEASIBLE_INACCURATE, DUAL_INFEASIBLE, \
+    DUAL_INFEASIBLE_INACCURATE, MAX_ITER_REACHED, TIME_LIMIT_REACHED, NON_CVX, SIGINT, UNSOLVED = range(1, 12)
+INFTY = 1e30
+
+
+class Settings(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ('rho', 'sigma', 'alpha', 'eps_abs', 'eps_rel', 'eps_prim_inf',
+                                           'eps_dual_inf', 'adaptive_rho_tolerance', 'pcg_tol')] + \
+               [(k, C.c_int) for k in ('scaling', 'max_iter', 'scaled_termination', 'check_termination',
+                                       'warm_start', 'adaptive_rho', 'adaptive_rho_interval', 'linsys',
+                                       'ordering', 'pcg_max_iter', 'c_core_warm_start')]
+
+
+class Info(C.Structure):
+    _fields_ = [('iter', C.c_int), ('status_val', C.c_int), ('rho_updates', C.c_int)] + \
+               [(k, C.c_double) for k in ('obj_val', 'pri_res', 'dua_res', 'rho_estimate', 'setup_time',
+                                          'solve_time', 'lnz', 'pcg_iters')]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, 'osqp_oracle.c')):
+        subprocess.check_call(['make', '-C', _HERE, '-s', '-B'])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.oracle_setup.restype = C.c_void_p
+        _lib.oracle_solve.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.POINTER(Info)]
+        for f in ('oracle_update_lin_cost', 'oracle_update_bounds', 'oracle_update_matrices', 'oracle_warm_start',
+                  'oracle_free', 'oracle_set_trace', 'oracle_update_settings', 'oracle_get_scaling'):
+            getattr(_lib, f).argtypes = None
+        _lib.oracle_update_rho.argtypes = [C.c_void_p, C.c_double]
+    return _lib
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Oracle:
+    """Mirrors the setup/solve/update/warm_start surface of osqppurepy.OSQP (interface.py:18-292)."""
+
+    def __init__(self):
+        self._h = None
+
+    def setup(self, P, q, A, l, u, **stg):
+        L = lib()
+        n = len(q)
+        m = A.shape[0] if A is not None else 0
+        if P is None:
+            P = sp.csc_matrix((n, n))
+        if A is None:
+            A = sp.csc_matrix((0, n)); l = np.zeros(0); u = np.zeros(0)
+        P = sp.triu(sp.csc_matrix(P), format='csc'); P.sort_indices()
+        A = sp.csc_matrix(A); A.sort_indices()
+        self.n, self.m = n, m
+        self._keep = [np.ascontiguousarray(P.indptr, np.int32), np.ascontiguousarray(P.indices, np.int32), _f64(P.data),
+                      _f64(q), np.ascontiguousarray(A.indptr, np.int32), np.ascontiguousarray(A.indices, np.int32),
+                      _f64(A.data), _f64(np.maximum(l, -INFTY)), _f64(np.minimum(u, INFTY))]
+        s = Settings(); L.oracle_default_settings(C.byref(s))
+        for k, v in stg.items():
+            if not hasattr(s, k):
+                raise ValueError('unknown oracle setting ' + k)
+            setattr(s, k, type(getattr(s, k))(v))
+        self.settings = s
+        err = C.c_int(0)
+        L.oracle_setup.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.POINTER(Settings), C.POINTER(C.c_int)]
+        self._h = L.oracle_setup(n, m, *[_dp(a) for a in self._keep], C.byref(s), C.byref(err))
+        self.setup_error = err.value
+        if err.value:
+            raise ValueError('oracle setup error %d' % err.value)
+        return self
+
+    def set_trace(self, cap):
+        self._tp = np.full(cap, np.nan); self._td = np.full(cap, np.nan)
+        lib().oracle_set_trace(C.c_void_p(self._h), _dp(self._tp), _dp(self._td), C.c_int(cap))
+        return self._tp, self._td
+
+    def solve(self):
+        x = np.empty(self.n); y = np.empty(self.m); cert = np.zeros(max(self.n, self.m, 1)); info = Info()
+        lib().oracle_solve(C.c_void_p(self._h), _dp(x), _dp(y), _dp(cert), C.byref(info))
+        self.cert = cert
+        return x, y, info
+
+    def update(self, q=None, l=None, u=None, Px=None, Ax=None):
+        L = lib(); h = C.c_void_p(self._h)
+        if q is not None:
+            self._keep[3] = _f64(q); L.oracle_update_lin_cost(h, _dp(self._keep[3]))
+        if l is not None or u is not None:
+            if l is not None:
+                self._keep[7] = _f64(np.maximum(l, -INFTY))
+            if u is not None:
+                self._keep[8] = _f64(np.minimum(u, INFTY))
+            if L.oracle_update_bounds(h, _dp(self._keep[7]), _dp(self._keep[8])):
+                raise ValueError('lower bound must not exceed upper bound')
+        if Px is not None or Ax is not None:
+            L.oracle_update_matrices(h, _dp(_f64(Px)), _dp(_f64(Ax)))
+
+    def warm_start(self, x=None, y=None):
+        lib().oracle_warm_start(C.c_void_p(self._h), _dp(_f64(x)), _dp(_f64(y)))
+
+    def update_rho(self, rho):
+        lib().oracle_update_rho(C.c_void_p(self._h), float(rho))
+
+    def update_settings(self, **kw):
+        for k, v in kw.items():
+            setattr(self.settings, k, type(getattr(self.settings, k))(v))
+        lib().oracle_update_settings(C.c_void_p(self._h), C.byref(self.settings))
+
+    def scaling(self):
+        D = np.empty(self.n); E = np.empty(self.m); c = C.c_double()
+        lib().oracle_get_scaling(C.c_void_p(self._h), _dp(D), _dp(E), C.byref(c))
+        return D, E, c.value
+
+    def __del__(self):
+        if self._h is not None and _lib is not None:
+            _lib.oracle_free(C.c_void_p(self._h)); self._h = None
