@@ -1,0 +1,201 @@
+/*
+ * osqp_hip.h -- C ABI of libosqp_hip.so, the MI355X-native OSQP ADMM engine.
+ *
+ * Drop-in boundary: these are the entry points the reference's pybind11 layer
+ * binds from the un-vendored osqp C core ("osqp_api_functions.h" / "osqp_api_types.h",
+ * /root/reference/src/bindings.cpp.in:9-10).  Each declaration cites the call site it replaces.
+ * The struct members are the ones the reference reads or writes through its bindings
+ * (bindings.cpp.in:405-447 settings, :473-492 info, :64-105 solution, :41-48 CSC matrix).
+ *
+ * Plain pointers and sizes only: no torch / pybind / HIP types cross this boundary.
+ * All functions return an osqp_error_type value (0 = OSQP_NO_ERROR) unless stated otherwise.
+ * A solver handle is not thread-safe; distinct handles may be used from distinct threads
+ * (bindings.cpp.in:196-201 releases the GIL around osqp_solve; multithread_test.py:38-53).
+ */
+#ifndef OSQP_HIP_H
+#define OSQP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int    OSQPInt;    /* OSQP_USE_LONG OFF  (reference CMakeLists.txt:9, interface.py:153) */
+typedef double OSQPFloat;  /* OSQP_USE_FLOAT OFF (interface.py:152)                              */
+
+#define OSQP_INFTY ((OSQPFloat)1e30)   /* bindings.cpp.in:340 */
+
+/* bindings.cpp.in:343-346 */
+enum osqp_linsys_solver_type { OSQP_UNKNOWN_SOLVER = 0, OSQP_DIRECT_SOLVER, OSQP_INDIRECT_SOLVER };
+
+/* bindings.cpp.in:349-361 (same member order) */
+enum osqp_status_type {
+  OSQP_SOLVED = 1, OSQP_SOLVED_INACCURATE, OSQP_PRIMAL_INFEASIBLE, OSQP_PRIMAL_INFEASIBLE_INACCURATE,
+  OSQP_DUAL_INFEASIBLE, OSQP_DUAL_INFEASIBLE_INACCURATE, OSQP_MAX_ITER_REACHED, OSQP_TIME_LIMIT_REACHED,
+  OSQP_NON_CVX, OSQP_SIGINT, OSQP_UNSOLVED
+};
+
+/* bindings.cpp.in:364-375 (same member order) */
+enum osqp_error_type {
+  OSQP_NO_ERROR = 0, OSQP_DATA_VALIDATION_ERROR, OSQP_SETTINGS_VALIDATION_ERROR, OSQP_LINSYS_SOLVER_INIT_ERROR,
+  OSQP_NONCVX_ERROR, OSQP_MEM_ALLOC_ERROR, OSQP_WORKSPACE_NOT_INIT_ERROR, OSQP_ALGEBRA_LOAD_ERROR,
+  OSQP_CODEGEN_DEFINES_ERROR, OSQP_DATA_NOT_INITIALIZED, OSQP_FUNC_NOT_IMPLEMENTED
+};
+
+/* bindings.cpp.in:378-381 */
+enum osqp_precond_type { OSQP_NO_PRECONDITIONER = 0, OSQP_DIAGONAL_PRECONDITIONER };
+
+/* bindings.cpp.in:395-400 */
+enum osqp_capabilities_type {
+  OSQP_CAPABILITY_DIRECT_SOLVER = 0x01, OSQP_CAPABILITY_INDIRECT_SOLVER = 0x02, OSQP_CAPABILITY_CODEGEN = 0x04,
+  OSQP_CAPABILITY_UPDATE_MATRICES = 0x08, OSQP_CAPABILITY_DERIVATIVES = 0x10
+};
+
+/* Compressed-sparse-column matrix, borrowed zero-copy from the caller (bindings.cpp.in:41-48). */
+typedef struct {
+  OSQPInt    m;      /* rows */
+  OSQPInt    n;      /* columns */
+  OSQPInt   *p;      /* column pointers (n+1) */
+  OSQPInt   *i;      /* row indices (nzmax), sorted within a column (interface.py:232-235) */
+  OSQPFloat *x;      /* values (nzmax) */
+  OSQPInt    nzmax;  /* number of stored entries */
+  OSQPInt    nz;     /* -1 for CSC (bindings.cpp.in:48) */
+} OSQPCscMatrix;
+
+/* The 29 fields bound at bindings.cpp.in:409-447, in that order. */
+typedef struct {
+  OSQPInt device;                         /* HIP device ordinal */
+  enum osqp_linsys_solver_type linsys_solver;   /* only OSQP_INDIRECT_SOLVER is implemented */
+  OSQPInt verbose;
+  OSQPInt warm_starting;
+  OSQPInt scaling;                        /* Ruiz iterations, 0 = off */
+  OSQPInt polishing;                      /* accepted, not implemented in this round (info.status_polish = 0) */
+  OSQPFloat rho;
+  OSQPInt   rho_is_vec;
+  OSQPFloat sigma;
+  OSQPFloat alpha;
+  OSQPInt   cg_max_iter;                  /* cap on PCG iterations per ADMM iteration */
+  OSQPInt   cg_tol_reduction;             /* first-chunk PCG tolerance = ||rhs||_inf / cg_tol_reduction */
+  OSQPFloat cg_tol_fraction;              /* PCG tolerance = fraction * sqrt(prim_res * dual_res) (scaled) */
+  enum osqp_precond_type cg_precond;
+  OSQPInt   adaptive_rho;
+  OSQPInt   adaptive_rho_interval;        /* 0 = automatic (2 * check_termination, or 50) */
+  OSQPFloat adaptive_rho_fraction;        /* accepted for API parity; the automatic interval is not time-based */
+  OSQPFloat adaptive_rho_tolerance;
+  OSQPInt   max_iter;
+  OSQPFloat eps_abs;
+  OSQPFloat eps_rel;
+  OSQPFloat eps_prim_inf;
+  OSQPFloat eps_dual_inf;
+  OSQPInt   scaled_termination;
+  OSQPInt   check_termination;            /* interval; 0 = only at max_iter */
+  OSQPInt   check_dualgap;
+  OSQPFloat time_limit;
+  OSQPFloat delta;
+  OSQPInt   polish_refine_iter;
+} OSQPSettings;
+
+/* bindings.cpp.in:473-492 */
+typedef struct {
+  char      status[32];
+  OSQPInt   status_val;
+  OSQPInt   status_polish;
+  OSQPFloat obj_val;
+  OSQPFloat dual_obj_val;
+  OSQPFloat prim_res;
+  OSQPFloat dual_res;
+  OSQPFloat duality_gap;
+  OSQPInt   iter;
+  OSQPInt   rho_updates;
+  OSQPFloat rho_estimate;
+  OSQPFloat setup_time;
+  OSQPFloat solve_time;
+  OSQPFloat update_time;
+  OSQPFloat polish_time;
+  OSQPFloat run_time;
+  OSQPFloat primdual_int;
+  OSQPFloat rel_kkt_error;
+} OSQPInfo;
+
+/* bindings.cpp.in:64-105: host arrays owned by the solver, refreshed by osqp_solve */
+typedef struct {
+  OSQPFloat *x;               /* n */
+  OSQPFloat *y;               /* m */
+  OSQPFloat *prim_inf_cert;   /* m */
+  OSQPFloat *dual_inf_cert;   /* n */
+} OSQPSolution;
+
+typedef struct OSQPWorkspace_ OSQPWorkspace;   /* opaque */
+
+/* bindings.cpp.in:163-176 dereferences solver->settings / ->solution / ->info */
+typedef struct {
+  OSQPSettings  *settings;
+  OSQPSolution  *solution;
+  OSQPInfo      *info;
+  OSQPWorkspace *work;
+} OSQPSolver;
+
+/* bindings.cpp.in:452-463 (codegen is out of scope: the struct exists so the binding compiles) */
+typedef struct {
+  OSQPInt embedded_mode, float_type, printing_enable, profiling_enable, interrupt_enable, derivatives_enable;
+} OSQPCodegenDefines;
+
+/* ---- core API ---- */
+OSQPInt osqp_capabilities(void);                                        /* bindings.cpp.in:402 */
+void    osqp_set_default_settings(OSQPSettings *settings);              /* bindings.cpp.in:449 */
+const char *osqp_version(void);
+
+/* bindings.cpp.in:153.  P: upper-triangular CSC (interface.py:221-222); A: CSC; l/u clamped to
+   +-OSQP_INFTY by the caller (interface.py:237-238).  Inputs are copied; nothing is retained. */
+OSQPInt osqp_setup(OSQPSolver **solverp, const OSQPCscMatrix *P, const OSQPFloat *q, const OSQPCscMatrix *A,
+                   const OSQPFloat *l, const OSQPFloat *u, OSQPInt m, OSQPInt n, const OSQPSettings *settings);
+OSQPInt osqp_solve(OSQPSolver *solver);                                 /* bindings.cpp.in:198 */
+OSQPInt osqp_cleanup(OSQPSolver *solver);                               /* bindings.cpp.in:160 */
+OSQPInt osqp_warm_start(OSQPSolver *solver, const OSQPFloat *x, const OSQPFloat *y);   /* :193, NULL-able */
+OSQPInt osqp_cold_start(OSQPSolver *solver);
+OSQPInt osqp_update_data_vec(OSQPSolver *solver, const OSQPFloat *q_new, const OSQPFloat *l_new,
+                             const OSQPFloat *u_new);                   /* bindings.cpp.in:237, NULL-able */
+/* bindings.cpp.in:280: *_new_idx == NULL means "all entries, in CSC order"; Px refers to the upper triangle */
+OSQPInt osqp_update_data_mat(OSQPSolver *solver, const OSQPFloat *Px_new, const OSQPInt *Px_new_idx, OSQPInt P_new_n,
+                             const OSQPFloat *Ax_new, const OSQPInt *Ax_new_idx, OSQPInt A_new_n);
+OSQPInt osqp_update_settings(OSQPSolver *solver, const OSQPSettings *new_settings);    /* bindings.cpp.in:204 */
+OSQPInt osqp_update_rho(OSQPSolver *solver, OSQPFloat rho_new);         /* bindings.cpp.in:213 */
+void    osqp_get_dimensions(OSQPSolver *solver, OSQPInt *m, OSQPInt *n);   /* codegen/pywrapper/bindings.cpp.jinja:21 */
+
+/* Out of scope (derivatives / codegen): present so the reference binding links; return OSQP_FUNC_NOT_IMPLEMENTED. */
+OSQPInt osqp_adjoint_derivative_compute(OSQPSolver *solver, OSQPFloat *dx, OSQPFloat *dy);            /* :302 */
+OSQPInt osqp_adjoint_derivative_get_mat(OSQPSolver *solver, OSQPCscMatrix *dP, OSQPCscMatrix *dA);    /* :310 */
+OSQPInt osqp_adjoint_derivative_get_vec(OSQPSolver *solver, OSQPFloat *dq, OSQPFloat *dl, OSQPFloat *du);   /* :318 */
+OSQPInt osqp_codegen(OSQPSolver *solver, const char *output_dir, const char *prefix, OSQPCodegenDefines *defines);   /* :322 */
+void    osqp_set_default_codegen_defines(OSQPCodegenDefines *defines);  /* bindings.cpp.in:463 */
+
+/* ---- extensions of this engine (no reference analogue) ---- */
+
+/* Engine statistics of the last osqp_solve. */
+typedef struct {
+  double pcg_iters_total;     /* PCG iterations summed over all ADMM iterations           */
+  double pcg_iters_max;       /* largest per-ADMM-iteration PCG count                     */
+  double pcg_unconverged;     /* ADMM iterations whose PCG hit the budget                 */
+  double kernel_launches;     /* kernels enqueued (graph nodes included)                  */
+  double graph_launches;      /* hipGraphLaunch calls                                     */
+  double gpu_solve_ms;        /* hipEvent time around the ADMM loop                       */
+  double nnzA, nnzB;          /* stored entries of A (CSR) and B = [P+sigma I | A'] (CSR) */
+} OSQPHipStats;
+OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
+
+/* Re-launch one hot-path kernel `reps` times on the solver's stream with the solver's current device state and
+   return its mean duration in milliseconds (hipEvent pair on that stream).  which: 0 = SpMV A (K1),
+   1 = SpMV B (K2), 2 = PCG vector update (Kv), 3 = rhs kernel (KB), 4 = A x~ + z,y,x update (KA).
+   The kernels run in a side-effect-free "probe" mode; solver state is unchanged. */
+OSQPInt osqp_hip_time_kernel(OSQPSolver *solver, OSQPInt which, OSQPInt reps, double *mean_ms);
+
+/* Test hooks (used by tests/ only): y = A x, y = B [xn; xm] on the device with the scaled matrices. */
+OSQPInt osqp_hip_test_spmv(OSQPSolver *solver, OSQPInt which, const OSQPFloat *in, OSQPFloat *out);
+/* copy out internal scaling D (n), E (m), c */
+OSQPInt osqp_hip_get_scaling(OSQPSolver *solver, OSQPFloat *D, OSQPFloat *E, OSQPFloat *c);
+/* name of the compute backend compiled into this library: "hip-gfx950" for the product */
+const char *osqp_hip_backend(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSQP_HIP_H */

@@ -1,0 +1,137 @@
+// backend.h -- device-op interface between the host ADMM driver (engine.cpp) and the compute backend.
+//
+// Two implementations exist:
+//   backend_hip.hip   hand-written gfx950 kernels; the ONLY backend linked into libosqp_hip.so (the product)
+//   backend_host.cpp  plain loops with identical semantics; built ONLY by tests/ into tests/_build/ so that the
+//                     driver logic (termination, adaptive rho, PCG budget, updates) can be exercised on machines
+//                     without a GPU.  It is never shipped, never loaded by the package, and is not a fallback.
+//
+// Every ADMM quantity lives in SCALED space (Appendix A of SURVEY.md); formulas cite
+// /root/reference/src/osqppurepy/_osqp.py ("_osqp.py:LINE").
+//
+// Matrices on the device (fp64 values, int32 indices):
+//   A : m x n      CSR of the scaled constraint matrix
+//   B : n x (n+m)  CSR of [ P + sigma I | A' ]  (P full symmetric; column n+i is constraint i)
+// so that the reduced KKT operator of the PCG  K = P + sigma I + A' diag(rho) A  is applied as
+//   t = rho .* (A p)   (kernel K1, m rows)      Kp = B [p; t]   (kernel K2, n rows).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace osqp_hip {
+
+constexpr int kBlock = 256;        // threads per workgroup (4 wave64)
+constexpr int kGrid = 1024;        // workgroups per launch = number of partial-reduction slots
+constexpr int kChunk = 1024;       // nnz staged through LDS per row-block (4 per thread)
+constexpr int kLongRow = 128;      // rows with more nnz get a workgroup of their own (block-wide reduction)
+constexpr int kMaxRowsPerBlock = 1024;
+constexpr int kMaxCg = 1024;       // hard cap on the PCG budget (size of the alpha/gamma history)
+
+struct DevCsr {
+  int nrows = 0, ncols = 0, nnz = 0, nblk = 0;
+  int *rowptr = nullptr, *col = nullptr, *rowblk = nullptr;
+  double *val = nullptr;
+};
+
+// indices into Dev::res (results of the residual kernels, reduced on the device)
+enum ResId {
+  R_PRI_U = 0, R_AX_U, R_Z_U, R_PRI_S, R_AX_S, R_Z_S, R_DY_U, R_DY_S, R_PINF_LHS, R_SUPP,   // m-side
+  R_DUA_U, R_PX_U, R_ATY_U, R_DUA_S, R_PX_S, R_ATY_S, R_DX_U, R_DX_S, R_XPX, R_QX, R_QDX,    // n-side
+  R_ATDY_U, R_ATDY_S, R_PDX_U, R_PDX_S, R_ADX_VIOL,                                          // infeasibility 2nd stage
+  R_COUNT
+};
+// indices into the int32 status block
+enum FlagId { F_DONE = 0, F_ITERS, F_STAT_SUM, F_STAT_MAX, F_STAT_UNCONV, F_COUNT };
+// indices into the fp64 scalar block
+enum ScalId { S_TOL_REL = 0, S_TOL_ABS, S_HIST = 8 /* gamma[kMaxCg+1], then alpha[kMaxCg+1] */ };
+
+struct Dev {
+  int n = 0, m = 0, device = 0;
+  double sigma = 0, alpha = 0;
+  DevCsr A, B;
+  int *Bdiag = nullptr;          // position of the diagonal entry of row j inside B.val
+  // problem data (scaled) and scaling
+  double *q = nullptr, *l = nullptr, *u = nullptr, *D = nullptr, *Dinv = nullptr, *E = nullptr, *Einv = nullptr;
+  double *rho = nullptr, *rho_inv = nullptr;
+  int *ctype = nullptr;          // -1 loose, 0 inequality, 1 equality (_osqp.py:516-518)
+  // ADMM iterates
+  double *x = nullptr, *z = nullptr, *y = nullptr, *dx = nullptr, *dy = nullptr;
+  double *xs = nullptr;          // x~ : PCG solution, kept as warm start for the next ADMM iteration
+  double *zt = nullptr;          // z~ = A x~
+  double *t0 = nullptr;          // rho .* z~  (so K x~ = B [x~; t0] needs no extra SpMV)
+  double *v = nullptr;           // rho .* z - y
+  // PCG (Chronopoulos-Gear single-reduction form)
+  double *r = nullptr, *uu = nullptr, *p = nullptr, *s = nullptr, *w = nullptr, *t = nullptr, *Minv = nullptr;
+  // reductions
+  double *part = nullptr;        // [slot][kGrid] partial results, slots see backend implementation
+  double *res = nullptr;         // [R_COUNT]
+  double *scal = nullptr;        // [S_HIST + 2*(kMaxCg+1)]
+  int *flags = nullptr;          // [F_COUNT]
+  void *stream = nullptr;        // hipStream_t (product) / unused (host simulator)
+  void *impl = nullptr;          // backend private (events, graphs, pinned staging)
+};
+
+namespace be {
+
+const char *name();
+int init(Dev &d, int device);            // select device, create stream; returns 0 or osqp_error_type
+void destroy(Dev &d);
+void *alloc(Dev &d, size_t bytes);       // zero-initialised device memory
+void dfree(Dev &d, void *p);
+void h2d(Dev &d, void *dst, const void *src, size_t bytes);
+void d2h(Dev &d, void *dst, const void *src, size_t bytes);   // synchronous w.r.t. the solver stream
+void zero(Dev &d, void *dst, size_t bytes);
+void sync(Dev &d);
+void activate(Dev &d);                  // make d.device current for the calling thread (HIP's current device is thread-local)
+
+// ---- ADMM hot path (all asynchronous on d.stream) ----
+// KB: x-part of the rhs and the PCG start, one pass over B (two sums per row):
+//   rhs_j = sigma x_j - q_j + (A' v)_j                         (_osqp.py:649-650 folded into the reduced system)
+//   r_j   = rhs_j - (B [xs; t0])_j ;  u_j = Minv_j r_j
+//   partials: gamma0 = <r,u>, ||r||_inf, ||rhs||_inf ; resets F_DONE/F_ITERS
+void kb_rhs(Dev &d);
+// K1_i: if PCG already converged -> no-op.  Else test ||r_i||_inf <= max(tol_rel*||rhs||_inf, tol_abs); on success set
+//   F_DONE, F_ITERS = i and return; otherwise t = rho .* (A u).
+void k1(Dev &d, int i);
+// K2_i: if !done: w = B [u; t] ; partial delta = <w,u>
+void k2(Dev &d, int i);
+// Kv_i: if !done: alpha_i,beta_i from (gamma_i, delta_i, gamma_{i-1}, alpha_{i-1});
+//   p = u + beta p ; s = w + beta s ; xs += alpha p ; r -= alpha s ; u = Minv r ; partials gamma_{i+1}, ||r||_inf
+void kv(Dev &d, int i);
+// KA: after the PCG (budget = number of (K1,K2,Kv) triples that were enqueued):
+//   z~ = A xs ; z,y update (_osqp.py:682-703) ; v = rho z - y ; t0 = rho z~ ; dy ; and, on extra workgroups,
+//   x = alpha xs + (1-alpha) x ; dx (_osqp.py:660-668).  Also folds the PCG statistics of this ADMM iteration.
+void ka(Dev &d, int budget);
+
+// ---- every check_termination iterations ----
+// residual norms / objective pieces of (x,z,y) -> d.res[0 .. R_QDX]   (_osqp.py:705-794, 880-908)
+void residuals(Dev &d);
+void infeas_primal(Dev &d);                         // d.res[R_ATDY_*] = || (Dinv) A' dy ||_inf      (_osqp.py:815-818)
+void infeas_dual(Dev &d, double thr, int unscaled);               // d.res[R_PDX_*], d.res[R_ADX_VIOL]              (_osqp.py:846-872)
+void fetch_res(Dev &d, double *host_res);           // D2H of d.res + stream sync
+void fetch_flags(Dev &d, int *host_flags);          // D2H of d.flags (+ reset of the F_STAT_* counters)
+
+// ---- rho / preconditioner ----
+// rho_i by constraint type (_osqp.py:1590-1594), rho_inv, v = rho z - y, t0 = rho z~
+void set_rho(Dev &d, double rho_bar);
+// Minv_j = 1 / (B_jj + sum_i rho_i A_ij^2)   (diag of K; B_jj already contains sigma).  precond==0 -> Minv = 1
+void precond(Dev &d, int diagonal);
+void set_pcg_tol(Dev &d, double tol_rel, double tol_abs);
+
+// full != 0 (after warm_start / cold_start, _osqp.py:1493-1509):  z = A x ; xs = x ; dx = dy = 0, then the refresh;
+// refresh (always):  zt = A xs ; t0 = rho zt ; v = rho z - y   (state the PCG start of kb_rhs relies on)
+void init_iterates(Dev &d, int full);
+
+// ---- launch batching ----
+bool graphs_supported();
+void graph_begin(Dev &d);                 // start capturing d.stream
+void *graph_end(Dev &d);                  // stop capturing, instantiate; returns executable-graph handle
+void graph_launch(Dev &d, void *g);
+void graph_free(Dev &d, void *g);
+
+// ---- probes / tests ----
+void test_spmv(Dev &d, int which, const double *in_dev, double *out_dev);   // 0: out = A in ; 1: out = B in
+float time_kernel(Dev &d, int which, int reps);                             // mean ms per launch
+
+}  // namespace be
+}  // namespace osqp_hip

@@ -1,0 +1,637 @@
+// backend_hip.hip -- gfx950 (MI355X / CDNA4) implementation of the device-op interface in backend.h.
+//
+// Everything on the ADMM / PCG hot path is a hand-written HIP kernel; there is no rocSPARSE / hipBLAS call and no
+// CPU path.  The path is sparse and bandwidth-bound (~0.17 flop/byte), so no MFMA: the design goals are
+//   * coalesced streaming of the CSR value/index arrays (12 B per stored entry) -- "CSR-stream": a workgroup stages
+//     a contiguous chunk of <= kChunk products val*x[col] in LDS with unit-stride global loads (4 independent
+//     loads + 4 independent gathers in flight per lane), then one lane per row sums its LDS segment.  Rows longer
+//     than kLongRow get a workgroup of their own and are reduced with wave64 __shfl_down + an LDS cross-wave step;
+//   * as few launches as possible per PCG iteration: the Chronopoulos-Gear single-reduction form of PCG needs only
+//     three kernels per iteration (K1: t = rho.*(A u), K2: w = B[u;t] + <w,u>, Kv: fused 5-vector update + <r,u> +
+//     ||r||_inf), every dot product / norm is fused into the kernel that produces its operands;
+//   * no host round trip inside a chunk of ADMM iterations: alpha/beta, the PCG stopping test and the PCG statistics
+//     live in device memory; a converged PCG turns the remaining (K1,K2,Kv) launches of that ADMM iteration into
+//     immediate returns;
+//   * deterministic reductions: every kernel runs with exactly kGrid workgroups; a workgroup writes ONE partial per
+//     reduced quantity (slot[blockIdx.x]) and the consumer kernel sums the kGrid partials in a fixed order
+//     (no atomics), so iteration counts are reproducible run to run;
+//   * launch batching with hipGraph (one graph per (ADMM iterations, PCG budget) pair, see engine.cpp).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/osqp_hip.h"
+#include "backend.h"
+
+namespace osqp_hip {
+namespace be {
+
+#define HIP_CHECK(expr)                                                                                       \
+  do {                                                                                                        \
+    hipError_t e_ = (expr);                                                                                   \
+    if (e_ != hipSuccess) {                                                                                   \
+      std::fprintf(stderr, "osqp_hip: HIP error %s at %s:%d (%s)\n", hipGetErrorString(e_), __FILE__, __LINE__, #expr); \
+      std::abort();                                                                                           \
+    }                                                                                                         \
+  } while (0)
+
+namespace {
+
+// partial-reduction slots inside Dev::part (each kGrid doubles)
+enum Slot { SL_GAMMA0 = 0, SL_GAMMA1, SL_RN0, SL_RN1, SL_BN, SL_DELTA, SL_RES0 /* .. SL_RES0 + R_COUNT - 1 */ };
+static_assert(SL_RES0 + R_COUNT <= 32, "Dev::part holds 32 slots");
+
+struct Impl {
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double *pin_res = nullptr;
+  int *pin_flags = nullptr;
+};
+inline Impl &im(Dev &d) { return *static_cast<Impl *>(d.impl); }
+inline hipStream_t st(Dev &d) { return static_cast<hipStream_t>(d.stream); }
+
+// ---------------------------------------------------------------------------------------------- device helpers
+__device__ __forceinline__ double nanmax(double r, double a) { return (a > r || a != a) ? a : r; }
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = nanmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+// all threads receive the block total; sred needs >= 4 doubles
+__device__ __forceinline__ double block_sum(double v, double *sred) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  __syncthreads();
+  return t;
+}
+__device__ __forceinline__ double block_max(double v, double *sred) {
+  v = wave_max(v);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = nanmax(nanmax(sred[0], sred[1]), nanmax(sred[2], sred[3]));
+  __syncthreads();
+  return t;
+}
+__device__ __forceinline__ double partial_sum(const double *slot, double *sred) {
+  double v = 0;
+#pragma unroll
+  for (int k = 0; k < kGrid / kBlock; k++) v += slot[threadIdx.x + k * kBlock];
+  return block_sum(v, sred);
+}
+__device__ __forceinline__ double partial_max(const double *slot, double *sred) {
+  double v = 0;
+#pragma unroll
+  for (int k = 0; k < kGrid / kBlock; k++) v = nanmax(v, slot[threadIdx.x + k * kBlock]);
+  return block_max(v, sred);
+}
+__device__ __forceinline__ void put_partial(double *part, int slot, double v) {
+  if (threadIdx.x == 0) part[slot * kGrid + blockIdx.x] = v;
+}
+
+// CSR-stream / CSR-vector row processing shared by every sparse kernel.
+//   G: gather functor   void operator()(int col, double val, double (&prod)[NS])
+//   E: row epilogue     void operator()(int row, const double (&sum)[NS])   (called by exactly one lane per row)
+template <int NS>
+struct StreamLds { double prod[2][NS][kChunk]; double red[8]; };
+
+template <int NS, class G, class E>
+__device__ __forceinline__ void process_rows(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds) {
+  int buf = 0;
+  for (int b = blockIdx.x; b < M.nblk; b += gridDim.x) {
+    const int r0 = M.rowblk[b], r1 = M.rowblk[b + 1];
+    const int k0 = M.rowptr[r0], k1 = M.rowptr[r1];
+    const int cnt = k1 - k0;
+    if (r1 - r0 == 1 && cnt > kLongRow) {                       // one long row: whole workgroup reduces it
+      double acc[NS];
+#pragma unroll
+      for (int s = 0; s < NS; s++) acc[s] = 0.0;
+      for (int k = k0 + threadIdx.x; k < k1; k += kBlock) {
+        double pr[NS];
+        g(M.col[k], M.val[k], pr);
+#pragma unroll
+        for (int s = 0; s < NS; s++) acc[s] += pr[s];
+      }
+#pragma unroll
+      for (int s = 0; s < NS; s++) acc[s] = block_sum(acc[s], lds.red);
+      if (threadIdx.x == 0) e(r0, acc);
+    } else {                                                    // many short rows: stage products in LDS
+      int cc[kChunk / kBlock];
+      double vv[kChunk / kBlock];
+#pragma unroll
+      for (int u = 0; u < kChunk / kBlock; u++) {                // unit-stride loads first (all in flight together)
+        const int k = threadIdx.x + u * kBlock;
+        cc[u] = k < cnt ? M.col[k0 + k] : -1;
+        vv[u] = k < cnt ? M.val[k0 + k] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kChunk / kBlock; u++) {                // then the gathers
+        const int k = threadIdx.x + u * kBlock;
+        if (cc[u] >= 0) {
+          double pr[NS];
+          g(cc[u], vv[u], pr);
+#pragma unroll
+          for (int s = 0; s < NS; s++) lds.prod[buf][s][k] = pr[s];
+        }
+      }
+      __syncthreads();
+      for (int r = r0 + threadIdx.x; r < r1; r += kBlock) {
+        const int a = M.rowptr[r] - k0, z = M.rowptr[r + 1] - k0;
+        double acc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) acc[s] = 0.0;
+        for (int k = a; k < z; k++) {
+#pragma unroll
+          for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
+        }
+        e(r, acc);
+      }
+      buf ^= 1;   // the next row block fills the other buffer, so one barrier per block suffices
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- hot-path kernels
+// KB ------------------------------------------------------------------------------------------
+struct GKb {
+  const double *xs, *v, *t0; int n;
+  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[2]) const {
+    if (c < n) { pr[0] = 0.0; pr[1] = a * xs[c]; }
+    else { pr[0] = a * v[c - n]; pr[1] = a * t0[c - n]; }
+  }
+};
+struct EKb {
+  const double *x, *q, *Minv; double *r, *uu; double sigma; double g = 0, rn = 0, bn = 0;
+  __device__ __forceinline__ void operator()(int j, const double (&s)[2]) {
+    const double rhs = sigma * x[j] - q[j] + s[0];
+    const double rr = rhs - s[1], u = Minv[j] * rr;
+    r[j] = rr; uu[j] = u;
+    g += rr * u; rn = nanmax(rn, fabs(rr)); bn = nanmax(bn, fabs(rhs));
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_kb(Dev d) {
+  __shared__ StreamLds<2> lds;
+  GKb g{d.xs, d.v, d.t0, d.n};
+  EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma};
+  process_rows<2>(d.B, g, e, lds);
+  __syncthreads();
+  const double G = block_sum(e.g, lds.red), RN = block_max(e.rn, lds.red), BN = block_max(e.bn, lds.red);
+  put_partial(d.part, SL_GAMMA0, G); put_partial(d.part, SL_RN0, RN); put_partial(d.part, SL_BN, BN);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
+}
+
+// K1 ------------------------------------------------------------------------------------------
+struct GVec { const double *x; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * x[c]; } };
+struct EK1 { const double *rho; double *t; __device__ __forceinline__ void operator()(int i, const double (&s)[1]) { t[i] = rho[i] * s[0]; } };
+__global__ __launch_bounds__(kBlock) void k_k1(Dev d, int i, int probe) {
+  __shared__ StreamLds<1> lds;
+  if (!probe) {
+    if (d.flags[F_DONE]) return;
+    const double rn = partial_max(d.part + (SL_RN0 + (i & 1)) * kGrid, lds.red);
+    const double bn = partial_max(d.part + SL_BN * kGrid, lds.red);
+    const double tol = fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS]);
+    if (!(rn > tol)) {            // converged (a NaN residual also stops the inner loop; the ADMM residuals will flag it)
+      if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = i; }
+      return;
+    }
+  }
+  GVec g{d.uu};
+  EK1 e{d.rho, d.t};
+  process_rows<1>(d.A, g, e, lds);
+}
+
+// K2 ------------------------------------------------------------------------------------------
+struct GSplit {      // [pn; pm] indexed by a B column
+  const double *pn, *pm; int n;
+  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * (c < n ? pn[c] : pm[c - n]); }
+};
+struct EK2 { const double *uu; double *w; double dl = 0; __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { w[j] = s[0]; dl += s[0] * uu[j]; } };
+__global__ __launch_bounds__(kBlock) void k_k2(Dev d, int probe) {
+  __shared__ StreamLds<1> lds;
+  if (!probe && d.flags[F_DONE]) return;
+  GSplit g{d.uu, d.t, d.n};
+  EK2 e{d.uu, d.w};
+  process_rows<1>(d.B, g, e, lds);
+  __syncthreads();
+  const double DL = block_sum(e.dl, lds.red);
+  put_partial(d.part, SL_DELTA, DL);
+}
+
+// Kv ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_kv(Dev d, int i, int probe) {
+  __shared__ double sred[8];
+  if (!probe && d.flags[F_DONE]) return;
+  double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
+  double alpha, beta;
+  if (probe) { alpha = 0.0; beta = 0.0; }
+  else {
+    const double gamma = partial_sum(d.part + (SL_GAMMA0 + (i & 1)) * kGrid, sred);
+    const double delta = partial_sum(d.part + SL_DELTA * kGrid, sred);
+    if (i == 0) { beta = 0.0; alpha = gamma / delta; }
+    else { beta = gamma / gam[i - 1]; alpha = gamma / (delta - beta * gamma / alp[i - 1]); }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { gam[i] = gamma; alp[i] = alpha; }
+  }
+  const bool first = (i == 0) && !probe;
+  double g = 0, rn = 0;
+  const int n2 = d.n >> 1;
+  const int stride = gridDim.x * kBlock;
+  double2 *p2 = reinterpret_cast<double2 *>(d.p), *s2 = reinterpret_cast<double2 *>(d.s), *x2 = reinterpret_cast<double2 *>(d.xs),
+          *r2 = reinterpret_cast<double2 *>(d.r), *u2 = reinterpret_cast<double2 *>(d.uu);
+  const double2 *w2 = reinterpret_cast<const double2 *>(d.w), *m2 = reinterpret_cast<const double2 *>(d.Minv);
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < n2; j += stride) {
+    double2 u = u2[j], w = w2[j], x = x2[j], r = r2[j], mi = m2[j], p, s;
+    if (first) { p = u; s = w; }
+    else { p = p2[j]; s = s2[j]; p.x = u.x + beta * p.x; p.y = u.y + beta * p.y; s.x = w.x + beta * s.x; s.y = w.y + beta * s.y; }
+    x.x += alpha * p.x; x.y += alpha * p.y;
+    r.x -= alpha * s.x; r.y -= alpha * s.y;
+    u.x = mi.x * r.x; u.y = mi.y * r.y;
+    p2[j] = p; s2[j] = s; x2[j] = x; r2[j] = r; u2[j] = u;
+    g += r.x * u.x + r.y * u.y;
+    rn = nanmax(nanmax(rn, fabs(r.x)), fabs(r.y));
+  }
+  if ((d.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {      // odd tail element
+    const int j = d.n - 1;
+    double p = first ? d.uu[j] : d.uu[j] + beta * d.p[j], s = first ? d.w[j] : d.w[j] + beta * d.s[j];
+    d.p[j] = p; d.s[j] = s; d.xs[j] += alpha * p;
+    const double r = d.r[j] - alpha * s, u = d.Minv[j] * r;
+    d.r[j] = r; d.uu[j] = u;
+    g += r * u; rn = nanmax(rn, fabs(r));
+  }
+  const double G = block_sum(g, sred), RN = block_max(rn, sred);
+  if (!probe) { put_partial(d.part, SL_GAMMA0 + ((i + 1) & 1), G); put_partial(d.part, SL_RN0 + ((i + 1) & 1), RN); }
+}
+
+// KA ------------------------------------------------------------------------------------------
+struct EKa {
+  const double *l, *u, *rho, *rho_inv; double *z, *y, *zt, *t0, *v, *dy; double alpha;
+  __device__ __forceinline__ void operator()(int i, const double (&s)[1]) {
+    const double ztil = s[0], rh = rho[i], yi = y[i];
+    const double zr = alpha * ztil + (1.0 - alpha) * z[i];                 // _osqp.py:686-690
+    const double zn = fmin(fmax(zr + rho_inv[i] * yi, l[i]), u[i]);          // :674
+    const double dyi = rh * (zr - zn), yn = yi + dyi;                        // :698-703
+    y[i] = yn; dy[i] = dyi; z[i] = zn; zt[i] = ztil; v[i] = rh * zn - yn; t0[i] = rh * ztil;
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
+  __shared__ StreamLds<1> lds;
+  GVec g{d.xs};
+  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha};
+  process_rows<1>(d.A, g, e, lds);
+  const int stride = gridDim.x * kBlock;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) {    // _osqp.py:664-668
+    const double xo = d.x[j], xn = d.alpha * d.xs[j] + (1.0 - d.alpha) * xo;
+    d.dx[j] = xn - xo; d.x[j] = xn;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {                                 // PCG statistics of this ADMM iteration
+    const int done = d.flags[F_DONE], used = done ? d.flags[F_ITERS] : budget;
+    d.flags[F_STAT_SUM] += used;
+    if (used > d.flags[F_STAT_MAX]) d.flags[F_STAT_MAX] = used;
+    if (!done) d.flags[F_STAT_UNCONV] += 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- residual kernels
+struct EKr1 {
+  const double *z, *y, *dy, *l, *u, *E, *Einv;
+  double pu = 0, au = 0, zu = 0, ps = 0, as = 0, zs = 0, du = 0, ds = 0, lhs = 0, sup = 0;
+  __device__ __forceinline__ void operator()(int i, const double (&s)[1]) {
+    const double ax = s[0], zi = z[i], pr = ax - zi, ei = Einv[i], dyi = dy[i], yi = y[i], li = l[i], ui = u[i];
+    pu = nanmax(pu, fabs(ei * pr)); au = nanmax(au, fabs(ei * ax)); zu = nanmax(zu, fabs(ei * zi));
+    ps = nanmax(ps, fabs(pr)); as = nanmax(as, fabs(ax)); zs = nanmax(zs, fabs(zi));
+    du = nanmax(du, fabs(E[i] * dyi)); ds = nanmax(ds, fabs(dyi));
+    lhs += ui * fmax(dyi, 0.0) + li * fmin(dyi, 0.0);                        // _osqp.py:811-813
+    if (yi > 0.0 && ui < OSQP_INFTY * 1e-4) sup += ui * yi;
+    else if (yi < 0.0 && li > -OSQP_INFTY * 1e-4) sup += li * yi;
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_res_m(Dev d) {
+  __shared__ StreamLds<1> lds;
+  GVec g{d.x};
+  EKr1 e{d.z, d.y, d.dy, d.l, d.u, d.E, d.Einv};
+  process_rows<1>(d.A, g, e, lds);
+  __syncthreads();
+  double *red = lds.red;
+  put_partial(d.part, SL_RES0 + R_PRI_U, block_max(e.pu, red)); put_partial(d.part, SL_RES0 + R_AX_U, block_max(e.au, red));
+  put_partial(d.part, SL_RES0 + R_Z_U, block_max(e.zu, red)); put_partial(d.part, SL_RES0 + R_PRI_S, block_max(e.ps, red));
+  put_partial(d.part, SL_RES0 + R_AX_S, block_max(e.as, red)); put_partial(d.part, SL_RES0 + R_Z_S, block_max(e.zs, red));
+  put_partial(d.part, SL_RES0 + R_DY_U, block_max(e.du, red)); put_partial(d.part, SL_RES0 + R_DY_S, block_max(e.ds, red));
+  put_partial(d.part, SL_RES0 + R_PINF_LHS, block_sum(e.lhs, red)); put_partial(d.part, SL_RES0 + R_SUPP, block_sum(e.sup, red));
+}
+
+struct GTwo {        // P part -> sum 0 (with pn), A' part -> sum 1 (with pm)
+  const double *pn, *pm; int n;
+  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[2]) const {
+    if (c < n) { pr[0] = a * pn[c]; pr[1] = 0.0; } else { pr[0] = 0.0; pr[1] = a * pm[c - n]; }
+  }
+};
+struct EKr2 {
+  const double *x, *q, *dx, *D, *Dinv; double sigma;
+  double du = 0, pu = 0, au = 0, ds = 0, ps = 0, as = 0, xu = 0, xs = 0, xpx = 0, qx = 0, qdx = 0;
+  __device__ __forceinline__ void operator()(int j, const double (&s)[2]) {
+    const double xj = x[j], px = s[0] - sigma * xj, aty = s[1], qj = q[j], dr = px + qj + aty, di = Dinv[j], dxj = dx[j];
+    du = nanmax(du, fabs(di * dr)); pu = nanmax(pu, fabs(di * px)); au = nanmax(au, fabs(di * aty));
+    ds = nanmax(ds, fabs(dr)); ps = nanmax(ps, fabs(px)); as = nanmax(as, fabs(aty));
+    xu = nanmax(xu, fabs(D[j] * dxj)); xs = nanmax(xs, fabs(dxj));
+    xpx += xj * px; qx += qj * xj; qdx += qj * dxj;
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_res_n(Dev d) {
+  __shared__ StreamLds<2> lds;
+  GTwo g{d.x, d.y, d.n};
+  EKr2 e{d.x, d.q, d.dx, d.D, d.Dinv, d.sigma};
+  process_rows<2>(d.B, g, e, lds);
+  __syncthreads();
+  double *red = lds.red;
+  put_partial(d.part, SL_RES0 + R_DUA_U, block_max(e.du, red)); put_partial(d.part, SL_RES0 + R_PX_U, block_max(e.pu, red));
+  put_partial(d.part, SL_RES0 + R_ATY_U, block_max(e.au, red)); put_partial(d.part, SL_RES0 + R_DUA_S, block_max(e.ds, red));
+  put_partial(d.part, SL_RES0 + R_PX_S, block_max(e.ps, red)); put_partial(d.part, SL_RES0 + R_ATY_S, block_max(e.as, red));
+  put_partial(d.part, SL_RES0 + R_DX_U, block_max(e.xu, red)); put_partial(d.part, SL_RES0 + R_DX_S, block_max(e.xs, red));
+  put_partial(d.part, SL_RES0 + R_XPX, block_sum(e.xpx, red)); put_partial(d.part, SL_RES0 + R_QX, block_sum(e.qx, red));
+  put_partial(d.part, SL_RES0 + R_QDX, block_sum(e.qdx, red));
+}
+
+__device__ __forceinline__ bool res_is_sum(int q) {
+  return q == R_PINF_LHS || q == R_SUPP || q == R_XPX || q == R_QX || q == R_QDX || q == R_ADX_VIOL;
+}
+// final reduction of the per-workgroup partials: workgroup b handles quantity q0 + b
+__global__ __launch_bounds__(kBlock) void k_res_final(Dev d, int q0) {
+  __shared__ double sred[8];
+  const int q = q0 + blockIdx.x;
+  const double *slot = d.part + (SL_RES0 + q) * kGrid;
+  const double v = res_is_sum(q) ? partial_sum(slot, sred) : partial_max(slot, sred);
+  if (threadIdx.x == 0) d.res[q] = v;
+}
+
+// second-stage infeasibility tests (rare) -------------------------------------------------------
+struct GAtOnly { const double *pm; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = c >= n ? a * pm[c - n] : 0.0; } };
+struct GPOnly { const double *pn; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = c < n ? a * pn[c] : 0.0; } };
+struct EAbs2 {
+  const double *scale, *sub; double sigma; double mu = 0, ms = 0;
+  __device__ __forceinline__ void operator()(int j, const double (&s)[1]) {
+    const double v = s[0] - (sub ? sigma * sub[j] : 0.0);
+    mu = nanmax(mu, fabs(scale[j] * v)); ms = nanmax(ms, fabs(v));
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_inf_primal(Dev d) {            // || Dinv A' dy ||_inf  (_osqp.py:815-818)
+  __shared__ StreamLds<1> lds;
+  GAtOnly g{d.dy, d.n};
+  EAbs2 e{d.Dinv, nullptr, 0.0};
+  process_rows<1>(d.B, g, e, lds);
+  __syncthreads();
+  put_partial(d.part, SL_RES0 + R_ATDY_U, block_max(e.mu, lds.red)); put_partial(d.part, SL_RES0 + R_ATDY_S, block_max(e.ms, lds.red));
+}
+__global__ __launch_bounds__(kBlock) void k_inf_dual_p(Dev d) {            // || Dinv P dx ||_inf   (_osqp.py:846-853)
+  __shared__ StreamLds<1> lds;
+  GPOnly g{d.dx, d.n};
+  EAbs2 e{d.Dinv, d.dx, d.sigma};
+  process_rows<1>(d.B, g, e, lds);
+  __syncthreads();
+  put_partial(d.part, SL_RES0 + R_PDX_U, block_max(e.mu, lds.red)); put_partial(d.part, SL_RES0 + R_PDX_S, block_max(e.ms, lds.red));
+}
+struct EViol {
+  const double *l, *u, *Einv; double thr; int unscaled; double viol = 0;
+  __device__ __forceinline__ void operator()(int i, const double (&s)[1]) {    // _osqp.py:861-872
+    const double a = unscaled ? Einv[i] * s[0] : s[0];
+    if ((u[i] < OSQP_INFTY * 1e-4 && a > thr) || (l[i] > -OSQP_INFTY * 1e-4 && a < -thr)) viol += 1.0;
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_inf_dual_a(Dev d, double thr, int unscaled) {
+  __shared__ StreamLds<1> lds;
+  GVec g{d.dx};
+  EViol e{d.l, d.u, d.Einv, thr, unscaled};
+  process_rows<1>(d.A, g, e, lds);
+  __syncthreads();
+  put_partial(d.part, SL_RES0 + R_ADX_VIOL, block_sum(e.viol, lds.red));
+}
+
+// ---------------------------------------------------------------------------------------------- rho / preconditioner / init
+__global__ __launch_bounds__(kBlock) void k_set_rho(Dev d, double rho_bar) {
+  const int stride = gridDim.x * kBlock;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += stride) {
+    const int t = d.ctype[i];
+    const double r = t == -1 ? 1e-6 : (t == 1 ? 1e3 * rho_bar : rho_bar);     // _osqp.py:520-522, :1590-1594
+    d.rho[i] = r; d.rho_inv[i] = 1.0 / r;
+    d.v[i] = r * d.z[i] - d.y[i]; d.t0[i] = r * d.zt[i];
+  }
+}
+struct GPrec { const double *rho; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = c >= n ? rho[c - n] * a * a : 0.0; } };
+struct EPrec { const double *Bval; const int *Bdiag; double *Minv; __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { Minv[j] = 1.0 / (Bval[Bdiag[j]] + s[0]); } };
+__global__ __launch_bounds__(kBlock) void k_precond(Dev d) {
+  __shared__ StreamLds<1> lds;
+  GPrec g{d.rho, d.n};
+  EPrec e{d.B.val, d.Bdiag, d.Minv};
+  process_rows<1>(d.B, g, e, lds);
+}
+__global__ __launch_bounds__(kBlock) void k_fill(double *p, int n, double v) {
+  const int stride = gridDim.x * kBlock;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+__global__ __launch_bounds__(kBlock) void k_init_n(Dev d) {
+  const int stride = gridDim.x * kBlock;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) { d.xs[j] = d.x[j]; d.dx[j] = 0.0; }
+}
+struct EInit {
+  const double *rho, *y; double *z, *zt, *t0, *v, *dy; int full;
+  __device__ __forceinline__ void operator()(int i, const double (&s)[1]) {
+    const double a = s[0];
+    if (full) { z[i] = a; dy[i] = 0.0; }
+    zt[i] = a; t0[i] = rho[i] * a; v[i] = rho[i] * z[i] - y[i];
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_init_m(Dev d, int full) {
+  __shared__ StreamLds<1> lds;
+  GVec g{d.xs};
+  EInit e{d.rho, d.y, d.z, d.zt, d.t0, d.v, d.dy, full};
+  process_rows<1>(d.A, g, e, lds);
+}
+__global__ void k_set_scal(double *scal, double rel, double ab) { scal[S_TOL_REL] = rel; scal[S_TOL_ABS] = ab; }
+
+struct EStore { double *out; __device__ __forceinline__ void operator()(int r, const double (&s)[1]) { out[r] = s[0]; } };
+__global__ __launch_bounds__(kBlock) void k_test_spmv(DevCsr M, const double *in, double *out) {
+  __shared__ StreamLds<1> lds;
+  GVec g{in};
+  EStore e{out};
+  process_rows<1>(M, g, e, lds);
+}
+
+#define LAUNCH(kernel, d, ...) hipLaunchKernelGGL(kernel, dim3(kGrid), dim3(kBlock), 0, st(d), __VA_ARGS__)
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- interface
+const char *name() { return "hip-gfx950"; }
+
+int init(Dev &d, int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    std::fprintf(stderr, "osqp_hip: no HIP device available -- this engine has no CPU fallback\n");
+    return OSQP_ALGEBRA_LOAD_ERROR;
+  }
+  if (device >= count) return OSQP_SETTINGS_VALIDATION_ERROR;
+  d.device = device;
+  HIP_CHECK(hipSetDevice(device));
+  hipStream_t s;
+  HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  d.stream = s;
+  Impl *p = new Impl();
+  HIP_CHECK(hipEventCreate(&p->ev0)); HIP_CHECK(hipEventCreate(&p->ev1));
+  HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_res), sizeof(double) * R_COUNT, hipHostMallocDefault));
+  HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_flags), sizeof(int) * F_COUNT, hipHostMallocDefault));
+  d.impl = p;
+  return OSQP_NO_ERROR;
+}
+void destroy(Dev &d) {
+  if (!d.impl) return;
+  HIP_CHECK(hipSetDevice(d.device));
+  Impl &p = im(d);
+  (void)hipEventDestroy(p.ev0); (void)hipEventDestroy(p.ev1); (void)hipHostFree(p.pin_res); (void)hipHostFree(p.pin_flags);
+  delete &p; d.impl = nullptr;
+  if (d.stream) { (void)hipStreamDestroy(st(d)); d.stream = nullptr; }
+}
+void *alloc(Dev &d, size_t bytes) {
+  HIP_CHECK(hipSetDevice(d.device));
+  void *p = nullptr;
+  HIP_CHECK(hipMalloc(&p, bytes));
+  HIP_CHECK(hipMemsetAsync(p, 0, bytes, st(d)));
+  return p;
+}
+void dfree(Dev &d, void *p) { HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipFree(p)); }
+void h2d(Dev &d, void *dst, const void *src, size_t b) {
+  if (!b) return;
+  HIP_CHECK(hipSetDevice(d.device));
+  HIP_CHECK(hipMemcpyAsync(dst, src, b, hipMemcpyHostToDevice, st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));      // the host buffer may be a temporary
+}
+void d2h(Dev &d, void *dst, const void *src, size_t b) {
+  if (!b) return;
+  HIP_CHECK(hipSetDevice(d.device));
+  HIP_CHECK(hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToHost, st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+}
+void zero(Dev &d, void *dst, size_t b) { if (!b) return; HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipMemsetAsync(dst, 0, b, st(d))); }
+void sync(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipStreamSynchronize(st(d))); }
+void activate(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); }
+
+void kb_rhs(Dev &d) { LAUNCH(k_kb, d, d); }
+void k1(Dev &d, int i) { LAUNCH(k_k1, d, d, i, 0); }
+void k2(Dev &d, int) { LAUNCH(k_k2, d, d, 0); }
+void kv(Dev &d, int i) { LAUNCH(k_kv, d, d, i, 0); }
+void ka(Dev &d, int budget) { LAUNCH(k_ka, d, d, budget); }
+
+void residuals(Dev &d) {
+  HIP_CHECK(hipSetDevice(d.device));
+  LAUNCH(k_res_m, d, d);
+  LAUNCH(k_res_n, d, d);
+  hipLaunchKernelGGL(k_res_final, dim3(R_QDX + 1), dim3(kBlock), 0, st(d), d, 0);
+}
+void infeas_primal(Dev &d) {
+  HIP_CHECK(hipSetDevice(d.device));
+  LAUNCH(k_inf_primal, d, d);
+  hipLaunchKernelGGL(k_res_final, dim3(2), dim3(kBlock), 0, st(d), d, (int)R_ATDY_U);
+}
+void infeas_dual(Dev &d, double thr, int unscaled) {
+  HIP_CHECK(hipSetDevice(d.device));
+  LAUNCH(k_inf_dual_p, d, d);
+  LAUNCH(k_inf_dual_a, d, d, thr, unscaled);
+  hipLaunchKernelGGL(k_res_final, dim3(3), dim3(kBlock), 0, st(d), d, (int)R_PDX_U);
+}
+void fetch_res(Dev &d, double *h) {
+  HIP_CHECK(hipSetDevice(d.device));
+  HIP_CHECK(hipMemcpyAsync(im(d).pin_res, d.res, sizeof(double) * R_COUNT, hipMemcpyDeviceToHost, st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  std::memcpy(h, im(d).pin_res, sizeof(double) * R_COUNT);
+}
+void fetch_flags(Dev &d, int *h) {
+  HIP_CHECK(hipSetDevice(d.device));
+  HIP_CHECK(hipMemcpyAsync(im(d).pin_flags, d.flags, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, st(d)));
+  HIP_CHECK(hipMemsetAsync(d.flags + F_STAT_SUM, 0, sizeof(int) * (F_COUNT - F_STAT_SUM), st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  std::memcpy(h, im(d).pin_flags, sizeof(int) * F_COUNT);
+}
+
+void set_rho(Dev &d, double rho_bar) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_set_rho, d, d, rho_bar); }
+void precond(Dev &d, int diagonal) {
+  HIP_CHECK(hipSetDevice(d.device));
+  if (diagonal) LAUNCH(k_precond, d, d);
+  else LAUNCH(k_fill, d, d.Minv, d.n, 1.0);
+}
+void set_pcg_tol(Dev &d, double rel, double ab) {
+  HIP_CHECK(hipSetDevice(d.device));
+  hipLaunchKernelGGL(k_set_scal, dim3(1), dim3(1), 0, st(d), d.scal, rel, ab);
+}
+void init_iterates(Dev &d, int full) {
+  HIP_CHECK(hipSetDevice(d.device));
+  if (full) LAUNCH(k_init_n, d, d);
+  LAUNCH(k_init_m, d, d, full);
+}
+
+bool graphs_supported() { return true; }
+void graph_begin(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipStreamBeginCapture(st(d), hipStreamCaptureModeThreadLocal)); }
+void *graph_end(Dev &d) {
+  hipGraph_t g = nullptr; hipGraphExec_t ex = nullptr;
+  HIP_CHECK(hipStreamEndCapture(st(d), &g));
+  HIP_CHECK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+  HIP_CHECK(hipGraphDestroy(g));
+  return ex;
+}
+void graph_launch(Dev &d, void *g) { HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipGraphLaunch(static_cast<hipGraphExec_t>(g), st(d))); }
+void graph_free(Dev &d, void *g) { if (g) { HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipGraphExecDestroy(static_cast<hipGraphExec_t>(g))); } }
+
+void test_spmv(Dev &d, int which, const double *in, double *out) {
+  HIP_CHECK(hipSetDevice(d.device));
+  LAUNCH(k_test_spmv, d, which == 0 ? d.A : d.B, in, out);
+}
+
+// Mean duration of one launch of a hot-path kernel, measured with a hipEvent pair on the solver's stream.
+// Kernels run in probe mode (no convergence logic; Kv with alpha = beta = 0) on the solver's live buffers; the
+// iterate state that KB/KA/Kv overwrite is saved and restored around the measurement.
+float time_kernel(Dev &d, int which, int reps) {
+  HIP_CHECK(hipSetDevice(d.device));
+  Impl &p = im(d);
+  struct Save { double *ptr; size_t cnt; double *bak; };
+  const size_t n = d.n, m = d.m;
+  Save sv[] = {{d.x, n, nullptr}, {d.z, m, nullptr}, {d.y, m, nullptr}, {d.xs, n, nullptr}, {d.zt, m, nullptr}, {d.t0, m, nullptr},
+               {d.v, m, nullptr}, {d.dx, n, nullptr}, {d.dy, m, nullptr}, {d.r, n, nullptr}, {d.uu, n, nullptr}, {d.p, n, nullptr},
+               {d.s, n, nullptr}, {d.w, n, nullptr}, {d.t, m, nullptr}};
+  int flags_bak[F_COUNT];
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  HIP_CHECK(hipMemcpy(flags_bak, d.flags, sizeof(flags_bak), hipMemcpyDeviceToHost));
+  for (auto &s : sv) {
+    if (!s.cnt) continue;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s.bak), s.cnt * sizeof(double)));
+    HIP_CHECK(hipMemcpy(s.bak, s.ptr, s.cnt * sizeof(double), hipMemcpyDeviceToDevice));
+  }
+  auto launch = [&]() {
+    switch (which) {
+      case 0: LAUNCH(k_k1, d, d, 1, 1); break;
+      case 1: LAUNCH(k_k2, d, d, 1); break;
+      case 2: LAUNCH(k_kv, d, d, 1, 1); break;
+      case 3: LAUNCH(k_kb, d, d); break;
+      default: LAUNCH(k_ka, d, d, 0); break;
+    }
+  };
+  for (int w = 0; w < 5; w++) launch();
+  HIP_CHECK(hipEventRecord(p.ev0, st(d)));
+  for (int r = 0; r < reps; r++) launch();
+  HIP_CHECK(hipEventRecord(p.ev1, st(d)));
+  HIP_CHECK(hipEventSynchronize(p.ev1));
+  float ms = 0.f;
+  HIP_CHECK(hipEventElapsedTime(&ms, p.ev0, p.ev1));
+  for (auto &s : sv) {
+    if (!s.cnt) continue;
+    HIP_CHECK(hipMemcpy(s.ptr, s.bak, s.cnt * sizeof(double), hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipFree(s.bak));
+  }
+  HIP_CHECK(hipMemcpy(d.flags, flags_bak, sizeof(flags_bak), hipMemcpyHostToDevice));
+  return ms / reps;
+}
+
+}  // namespace be
+}  // namespace osqp_hip

@@ -1,0 +1,666 @@
+// engine.cpp -- see engine.hpp.  Formulas cite /root/reference/src/osqppurepy/_osqp.py ("_osqp.py:LINE"), the only
+// in-tree statement of the algorithm the reference's C core executes.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+namespace osqp_hip {
+
+namespace {
+constexpr double kRhoMin = 1e-6, kRhoMax = 1e6, kRhoTol = 1e-4;   // _osqp.py:25-28 (RHO_EQ_OVER_RHO_INEQ = 1e3 is applied in the set_rho kernel)
+constexpr double kMinScaling = 1e-4, kMaxScaling = 1e4;                                 // _osqp.py:44-45
+constexpr double kCgTolAbsMin = 1e-13;
+const double kNaN = std::numeric_limits<double>::quiet_NaN();
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+double limit_scaling(double v) { return v < kMinScaling ? 1.0 : (v > kMaxScaling ? kMaxScaling : v); }   // _osqp.py:363-387
+double clamp_rho(double r) { return std::min(std::max(r, kRhoMin), kRhoMax); }
+
+template <class T>
+T *dev_vec(Dev &d, size_t count) { return static_cast<T *>(be::alloc(d, std::max<size_t>(count, 1) * sizeof(T))); }
+
+// Row blocks for the CSR-stream kernels: consecutive rows whose nnz sum to <= kChunk (and <= kMaxRowsPerBlock rows);
+// a row with more than kLongRow entries is a block of its own (reduced by the whole workgroup).
+std::vector<int> build_row_blocks(const std::vector<int> &rowptr, int nrows) {
+  std::vector<int> rb; rb.push_back(0);
+  int r = 0;
+  while (r < nrows) {
+    int len = rowptr[r + 1] - rowptr[r];
+    if (len > kLongRow) { r++; rb.push_back(r); continue; }
+    int start = r, acc = 0;
+    while (r < nrows && r - start < kMaxRowsPerBlock) {
+      int l2 = rowptr[r + 1] - rowptr[r];
+      if (l2 > kLongRow || acc + l2 > kChunk) break;
+      acc += l2; r++;
+    }
+    rb.push_back(r);
+  }
+  return rb;
+}
+}  // namespace
+
+Engine::Engine() {
+  pub.settings = &settings; pub.solution = &solution; pub.info = &info; pub.work = reinterpret_cast<OSQPWorkspace *>(this);
+  const char *g = std::getenv("OSQP_HIP_GRAPH");
+  use_graph_ = !(g && g[0] == '0');
+}
+Engine::~Engine() { free_all(); }
+
+void Engine::drop_graphs() {
+  for (auto &kv : graphs_) be::graph_free(d_, kv.second);
+  graphs_.clear();
+}
+
+void Engine::free_all() {
+  if (!dev_ready_) return;
+  be::activate(d_);
+  be::sync(d_);
+  drop_graphs();
+  void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.rowblk, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.rowblk, d_.B.val, d_.Bdiag,
+                  d_.q, d_.l, d_.u, d_.D, d_.Dinv, d_.E, d_.Einv, d_.rho, d_.rho_inv, d_.ctype, d_.x, d_.z, d_.y, d_.dx,
+                  d_.dy, d_.xs, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.part, d_.res,
+                  d_.scal, d_.flags};
+  for (void *p : ptrs) if (p) be::dfree(d_, p);
+  be::destroy(d_);
+  d_ = Dev();
+  dev_ready_ = false;
+}
+
+// ------------------------------------------------------------------------------------------------ settings
+int Engine::validate_settings(const OSQPSettings *s, bool at_setup) {
+  if (!s) return OSQP_SETTINGS_VALIDATION_ERROR;
+  bool ok = s->device >= 0 && s->scaling >= 0 && s->rho > 0 && s->sigma > 0 && s->alpha > 0 && s->alpha < 2 &&
+            s->cg_max_iter > 0 && s->cg_tol_reduction > 0 && s->cg_tol_fraction > 0 && s->cg_tol_fraction < 1 &&
+            s->adaptive_rho_interval >= 0 && s->adaptive_rho_fraction > 0 && s->adaptive_rho_tolerance >= 1 &&
+            s->max_iter > 0 && s->eps_abs >= 0 && s->eps_rel >= 0 && (s->eps_abs > 0 || s->eps_rel > 0) &&
+            s->eps_prim_inf > 0 && s->eps_dual_inf > 0 && s->check_termination >= 0 && s->time_limit > 0 &&
+            s->delta > 0 && s->polish_refine_iter >= 0 &&
+            (s->cg_precond == OSQP_NO_PRECONDITIONER || s->cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  for (int flag : {s->verbose, s->warm_starting, s->polishing, s->rho_is_vec, s->adaptive_rho, s->scaled_termination, s->check_dualgap})
+    ok = ok && (flag == 0 || flag == 1);
+  if (!ok) return OSQP_SETTINGS_VALIDATION_ERROR;
+  if (at_setup && s->linsys_solver != OSQP_INDIRECT_SOLVER) return OSQP_LINSYS_SOLVER_INIT_ERROR;   // GPU engine is PCG only
+  return OSQP_NO_ERROR;
+}
+
+int Engine::auto_rho_interval() const {
+  if (settings.adaptive_rho_interval > 0) return settings.adaptive_rho_interval;
+  return settings.check_termination > 0 ? 2 * settings.check_termination : 50;
+}
+
+// ------------------------------------------------------------------------------------------------ scaling
+// Ruiz equilibration + cost normalisation, _osqp.py:389-497 (host, once per setup).
+void Engine::compute_scaling(std::vector<double> &Px, std::vector<double> &Ax, std::vector<double> &qs) {
+  D_.assign(n, 1.0); E_.assign(m, 1.0); c_ = 1.0;
+  std::vector<double> dt(n), et(m), nP(n);
+  auto p_col_norms = [&](std::vector<double> &out) {      // columns of the full symmetric P from its upper triangle
+    std::fill(out.begin(), out.end(), 0.0);
+    for (int j = 0; j < n; j++)
+      for (int k = P_.p[j]; k < P_.p[j + 1]; k++) {
+        double a = std::fabs(Px[k]); int i = P_.i[k];
+        out[j] = std::max(out[j], a); out[i] = std::max(out[i], a);
+      }
+  };
+  for (int it = 0; it < settings.scaling; it++) {
+    p_col_norms(dt);                                                    // _norm_KKT_cols :348-361
+    std::fill(et.begin(), et.end(), 0.0);
+    for (int j = 0; j < n; j++)
+      for (int k = A_.p[j]; k < A_.p[j + 1]; k++) {
+        double a = std::fabs(Ax[k]);
+        dt[j] = std::max(dt[j], a); et[A_.i[k]] = std::max(et[A_.i[k]], a);
+      }
+    for (int j = 0; j < n; j++) dt[j] = 1.0 / std::sqrt(limit_scaling(dt[j]));      // :419-421
+    for (int i = 0; i < m; i++) et[i] = 1.0 / std::sqrt(limit_scaling(et[i]));
+    for (int j = 0; j < n; j++) {                                                    // :432-439
+      for (int k = P_.p[j]; k < P_.p[j + 1]; k++) Px[k] *= dt[P_.i[k]] * dt[j];
+      for (int k = A_.p[j]; k < A_.p[j + 1]; k++) Ax[k] *= et[A_.i[k]] * dt[j];
+      qs[j] *= dt[j]; D_[j] *= dt[j];
+    }
+    for (int i = 0; i < m; i++) E_[i] *= et[i];
+    p_col_norms(nP);                                                                 // :443-468
+    double mean = 0; for (int j = 0; j < n; j++) mean += nP[j];
+    mean /= std::max(n, 1);
+    double nq = 0; for (int j = 0; j < n; j++) nq = std::max(nq, std::fabs(qs[j]));
+    double ct = 1.0 / limit_scaling(std::max(limit_scaling(nq), mean));
+    for (auto &v : Px) v *= ct;
+    for (auto &v : qs) v *= ct;
+    c_ *= ct;
+  }
+  Dinv_.resize(n); Einv_.resize(m);
+  for (int j = 0; j < n; j++) Dinv_[j] = 1.0 / D_[j];
+  for (int i = 0; i < m; i++) Einv_[i] = 1.0 / E_[i];
+  cinv_ = 1.0 / c_;
+}
+
+// P <- c D P D, A <- E A D with the stored scaling (_osqp.py:1443, :1463)
+void Engine::scale_matrix_values(std::vector<double> &Px, std::vector<double> &Ax) const {
+  Px.resize(P_.nnz()); Ax.resize(A_.nnz());
+  for (int j = 0; j < n; j++) {
+    for (int k = P_.p[j]; k < P_.p[j + 1]; k++) Px[k] = c_ * D_[P_.i[k]] * D_[j] * P_.x[k];
+    for (int k = A_.p[j]; k < A_.p[j + 1]; k++) Ax[k] = E_[A_.i[k]] * D_[j] * A_.x[k];
+  }
+}
+
+// constraint classes, _osqp.py:505-518 (on the SCALED bounds, as the reference does)
+void Engine::classify_constraints(const std::vector<double> &ls, const std::vector<double> &us) {
+  ctype_.resize(m);
+  for (int i = 0; i < m; i++) {
+    int t;
+    if (ls[i] < -OSQP_INFTY * kMinScaling && us[i] > OSQP_INFTY * kMinScaling) t = -1;
+    else if (us[i] - ls[i] < kRhoTol) t = 1;
+    else t = 0;
+    if (!settings.rho_is_vec) t = 0;
+    ctype_[i] = t;
+  }
+}
+
+void Engine::upload_bounds_and_types() {
+  std::vector<double> ls(m), us(m);
+  for (int i = 0; i < m; i++) { ls[i] = E_[i] * l0_[i]; us[i] = E_[i] * u0_[i]; }       // _osqp.py:435-436, :1357-1358
+  classify_constraints(ls, us);
+  be::h2d(d_, d_.l, ls.data(), sizeof(double) * m);
+  be::h2d(d_, d_.u, us.data(), sizeof(double) * m);
+  be::h2d(d_, d_.ctype, ctype_.data(), sizeof(int) * m);
+}
+
+void Engine::upload_q() {
+  std::vector<double> qs(n);
+  qnorm_s_ = 0; qnorm_u_ = 0;
+  for (int j = 0; j < n; j++) {
+    qs[j] = c_ * D_[j] * q0_[j];                                                         // _osqp.py:1328
+    qnorm_s_ = std::max(qnorm_s_, std::fabs(qs[j]));
+    qnorm_u_ = std::max(qnorm_u_, std::fabs(Dinv_[j] * qs[j]));
+  }
+  be::h2d(d_, d_.q, qs.data(), sizeof(double) * n);
+}
+
+void Engine::fill_matrix_values(const std::vector<double> &Px, const std::vector<double> &Ax) {
+  std::fill(Bval_.begin(), Bval_.end(), 0.0);
+  for (int j = 0; j < n; j++) Bval_[bdiag_[j]] = settings.sigma;
+  for (int k = 0; k < P_.nnz(); k++) {
+    Bval_[Pmap1_[k]] += Px[k];
+    if (Pmap2_[k] >= 0) Bval_[Pmap2_[k]] = Px[k];
+  }
+  for (int k = 0; k < A_.nnz(); k++) { Aval_[AmapA_[k]] = Ax[k]; Bval_[AmapB_[k]] = Ax[k]; }
+  be::h2d(d_, d_.A.val, Aval_.data(), sizeof(double) * Aval_.size());
+  be::h2d(d_, d_.B.val, Bval_.data(), sizeof(double) * Bval_.size());
+}
+
+// ------------------------------------------------------------------------------------------------ setup
+int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *A, const double *l, const double *u,
+                  int m_, int n_, const OSQPSettings *s) {
+  double t0 = now_s();
+  // ---- data validation (the C core's validate_data; error numbering bindings.cpp.in:364-375) ----
+  if (!P || !A || !q || n_ <= 0 || m_ < 0) return OSQP_DATA_VALIDATION_ERROR;
+  if (m_ > 0 && (!l || !u)) return OSQP_DATA_VALIDATION_ERROR;
+  if (P->m != n_ || P->n != n_ || A->m != m_ || A->n != n_) return OSQP_DATA_VALIDATION_ERROR;
+  auto csc_ok = [](const OSQPCscMatrix *M) {
+    if (!M->p) return false;
+    if (M->p[0] != 0) return false;
+    for (int j = 0; j < M->n; j++) if (M->p[j + 1] < M->p[j]) return false;
+    int nz = M->p[M->n];
+    if (nz > 0 && (!M->i || !M->x)) return false;
+    for (int k = 0; k < nz; k++) if (M->i[k] < 0 || M->i[k] >= M->m) return false;
+    return true;
+  };
+  if (!csc_ok(P) || !csc_ok(A)) return OSQP_DATA_VALIDATION_ERROR;
+  for (int j = 0; j < n_; j++)
+    for (int k = P->p[j]; k < P->p[j + 1]; k++) if (P->i[k] > j) return OSQP_DATA_VALIDATION_ERROR;   // upper triangular only
+  for (int i = 0; i < m_; i++) if (!(l[i] <= u[i])) return OSQP_DATA_VALIDATION_ERROR;
+  int err = validate_settings(s, true);
+  if (err) return err;
+
+  free_all();
+  n = n_; m = m_; settings = *s;
+  rho_bar_ = clamp_rho(settings.rho); settings.rho = rho_bar_;                            // _osqp.py:503
+  auto copy_csc = [](HostCsc &H, const OSQPCscMatrix *M) {
+    H.nr = M->m; H.nc = M->n; int nz = M->p[M->n];
+    H.p.assign(M->p, M->p + M->n + 1); H.i.assign(M->i, M->i + nz); H.x.assign(M->x, M->x + nz);
+  };
+  copy_csc(P_, P); copy_csc(A_, A);
+  q0_.assign(q, q + n); l0_.assign(l, l + m); u0_.assign(u, u + m);
+
+  // ---- scaling on the host (SURVEY §8f rank 1 moves it to the device later) ----
+  std::vector<double> Px = P_.x, Ax = A_.x, qs = q0_;
+  compute_scaling(Px, Ax, qs);
+
+  // ---- device ----
+  err = be::init(d_, settings.device);
+  if (err) return err;
+  dev_ready_ = true;
+  d_.n = n; d_.m = m; d_.sigma = settings.sigma; d_.alpha = settings.alpha;
+
+  // A as CSR (the incoming CSC is CSR(A')) + map CSC index -> CSR position
+  const int nzA = A_.nnz(), nzP = P_.nnz();
+  std::vector<int> Arp(m + 1, 0), Arj(nzA);
+  AmapA_.resize(nzA);
+  for (int k = 0; k < nzA; k++) Arp[A_.i[k] + 1]++;
+  for (int i = 0; i < m; i++) Arp[i + 1] += Arp[i];
+  {
+    std::vector<int> cur(Arp.begin(), Arp.end() - 1);
+    for (int j = 0; j < n; j++)
+      for (int k = A_.p[j]; k < A_.p[j + 1]; k++) { int pos = cur[A_.i[k]]++; Arj[pos] = j; AmapA_[k] = pos; }
+  }
+  // B = [P + sigma I | A'] as CSR with n rows; row j = (lower part of row j of P) (diag) (upper part) (column j of A)
+  std::vector<int> Brp(n + 1, 0);
+  std::vector<char> hasdiag(n, 0);
+  for (int j = 0; j < n; j++) {
+    Brp[j + 1] += 1 + (A_.p[j + 1] - A_.p[j]);
+    for (int k = P_.p[j]; k < P_.p[j + 1]; k++) {
+      int i = P_.i[k];
+      if (i == j) hasdiag[j] = 1; else { Brp[j + 1]++; Brp[i + 1]++; }
+    }
+  }
+  for (int j = 0; j < n; j++) Brp[j + 1] += Brp[j];
+  const int nzB = Brp[n];
+  std::vector<int> Bj(nzB); std::vector<int> &bdiag = bdiag_; bdiag.assign(n, 0);
+  Pmap1_.assign(nzP, -1); Pmap2_.assign(nzP, -1); AmapB_.resize(nzA);
+  {
+    std::vector<int> cur(Brp.begin(), Brp.end() - 1);
+    for (int j = 0; j < n; j++) {
+      int kd = -1;
+      for (int k = P_.p[j]; k < P_.p[j + 1]; k++) {
+        int i = P_.i[k];
+        if (i == j) { kd = k; continue; }
+        int p1 = cur[j]++; Bj[p1] = i; Pmap1_[k] = p1;      // (j, i): lower part of row j
+      }
+      bdiag[j] = cur[j]++; Bj[bdiag[j]] = j;
+      if (kd >= 0) Pmap1_[kd] = bdiag[j];
+      for (int k = P_.p[j]; k < P_.p[j + 1]; k++) {
+        int i = P_.i[k];
+        if (i == j) continue;
+        int p2 = cur[i]++; Bj[p2] = j; Pmap2_[k] = p2;      // (i, j): upper part of row i (its diagonal is already placed)
+      }
+    }
+    for (int j = 0; j < n; j++)
+      for (int k = A_.p[j]; k < A_.p[j + 1]; k++) { int pos = cur[j]++; Bj[pos] = n + A_.i[k]; AmapB_[k] = pos; }
+  }
+  std::vector<int> rbA = build_row_blocks(Arp, m), rbB = build_row_blocks(Brp, n);
+
+  auto up_i = [&](const std::vector<int> &h) { int *p = dev_vec<int>(d_, h.size()); be::h2d(d_, p, h.data(), sizeof(int) * h.size()); return p; };
+  d_.A.nrows = m; d_.A.ncols = n; d_.A.nnz = nzA; d_.A.nblk = (int)rbA.size() - 1;
+  d_.A.rowptr = up_i(Arp); d_.A.col = up_i(Arj); d_.A.rowblk = up_i(rbA); d_.A.val = dev_vec<double>(d_, nzA);
+  d_.B.nrows = n; d_.B.ncols = n + m; d_.B.nnz = nzB; d_.B.nblk = (int)rbB.size() - 1;
+  d_.B.rowptr = up_i(Brp); d_.B.col = up_i(Bj); d_.B.rowblk = up_i(rbB); d_.B.val = dev_vec<double>(d_, nzB);
+  d_.Bdiag = up_i(bdiag);
+  Aval_.assign(nzA, 0.0); Bval_.assign(nzB, 0.0);
+  fill_matrix_values(Px, Ax);
+
+  auto dv = [&](size_t cnt) { return dev_vec<double>(d_, cnt); };
+  d_.q = dv(n); d_.l = dv(m); d_.u = dv(m); d_.D = dv(n); d_.Dinv = dv(n); d_.E = dv(m); d_.Einv = dv(m);
+  d_.rho = dv(m); d_.rho_inv = dv(m); d_.ctype = dev_vec<int>(d_, m);
+  d_.x = dv(n); d_.z = dv(m); d_.y = dv(m); d_.dx = dv(n); d_.dy = dv(m); d_.xs = dv(n); d_.zt = dv(m); d_.t0 = dv(m); d_.v = dv(m);
+  d_.r = dv(n); d_.uu = dv(n); d_.p = dv(n); d_.s = dv(n); d_.w = dv(n); d_.t = dv(m); d_.Minv = dv(n);
+  d_.part = dv((size_t)32 * kGrid); d_.res = dv(R_COUNT); d_.scal = dv(S_HIST + 2 * (kMaxCg + 1)); d_.flags = dev_vec<int>(d_, F_COUNT);
+  be::h2d(d_, d_.D, D_.data(), sizeof(double) * n); be::h2d(d_, d_.Dinv, Dinv_.data(), sizeof(double) * n);
+  be::h2d(d_, d_.E, E_.data(), sizeof(double) * m); be::h2d(d_, d_.Einv, Einv_.data(), sizeof(double) * m);
+  upload_q();
+  upload_bounds_and_types();
+  be::set_rho(d_, rho_bar_);                                       // _osqp.py:499-524
+  be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  be::init_iterates(d_, 1);
+
+  sol_x_.assign(n, kNaN); sol_y_.assign(m, kNaN); sol_pc_.assign(m, kNaN); sol_dc_.assign(n, kNaN);
+  solution.x = sol_x_.data(); solution.y = sol_y_.data(); solution.prim_inf_cert = sol_pc_.data(); solution.dual_inf_cert = sol_dc_.data();
+  std::memset(&info, 0, sizeof(info));
+  set_status(OSQP_UNSOLVED);
+  cg_budget_ = 0; have_tol_ = false; first_run_ = true;
+  stats_ = OSQPHipStats(); stats_.nnzA = nzA; stats_.nnzB = nzB;
+  be::sync(d_);
+  info.setup_time = now_s() - t0;
+  if (settings.verbose) {
+    std::printf("-----------------------------------------------------------------\n");
+    std::printf("  OSQP ADMM engine for AMD MI355X (%s), indirect (PCG) solver\n", be::name());
+    std::printf("-----------------------------------------------------------------\n");
+    std::printf("problem:  variables n = %d, constraints m = %d\n          nnz(P) + nnz(A) = %d\n", n, m, nzP + nzA);
+    std::printf("settings: eps_abs = %.1e, eps_rel = %.1e, rho = %.2e%s, sigma = %.2e, alpha = %.2f,\n          max_iter = %d, scaling = %d, check_termination = %d, cg_max_iter = %d\n\n",
+                settings.eps_abs, settings.eps_rel, settings.rho, settings.adaptive_rho ? " (adaptive)" : "", settings.sigma,
+                settings.alpha, settings.max_iter, settings.scaling, settings.check_termination, settings.cg_max_iter);
+  }
+  return OSQP_NO_ERROR;
+}
+
+// ------------------------------------------------------------------------------------------------ driver
+void Engine::set_status(int st) {
+  info.status_val = st;
+  const char *s = "unsolved";
+  switch (st) {
+    case OSQP_SOLVED: s = "solved"; break;
+    case OSQP_SOLVED_INACCURATE: s = "solved inaccurate"; break;
+    case OSQP_PRIMAL_INFEASIBLE: s = "primal infeasible"; break;
+    case OSQP_PRIMAL_INFEASIBLE_INACCURATE: s = "primal infeasible inaccurate"; break;
+    case OSQP_DUAL_INFEASIBLE: s = "dual infeasible"; break;
+    case OSQP_DUAL_INFEASIBLE_INACCURATE: s = "dual infeasible inaccurate"; break;
+    case OSQP_MAX_ITER_REACHED: s = "maximum iterations reached"; break;
+    case OSQP_TIME_LIMIT_REACHED: s = "run time limit reached"; break;
+    case OSQP_NON_CVX: s = "problem non convex"; break;
+    case OSQP_SIGINT: s = "interrupted"; break;
+    default: break;
+  }
+  std::snprintf(info.status, sizeof(info.status), "%s", s);
+}
+
+// One chunk = `niter` ADMM iterations, each  KB, budget x (K1,K2,Kv), KA  -- enqueued eagerly or replayed from a
+// hipGraph captured once per (niter, budget).
+void Engine::run_chunk(int niter, int budget) {
+  auto enqueue = [&]() {
+    for (int it = 0; it < niter; it++) {
+      be::kb_rhs(d_);
+      for (int i = 0; i < budget; i++) { be::k1(d_, i); be::k2(d_, i); be::kv(d_, i); }
+      be::ka(d_, budget);
+    }
+  };
+  stats_.kernel_launches += (double)niter * (2 + 3 * budget);
+  if (use_graph_ && be::graphs_supported()) {
+    auto key = std::make_pair(niter, budget);
+    auto it = graphs_.find(key);
+    if (it == graphs_.end()) {
+      be::graph_begin(d_);
+      enqueue();
+      void *g = be::graph_end(d_);
+      it = graphs_.emplace(key, g).first;
+    }
+    be::graph_launch(d_, it->second);
+    stats_.graph_launches += 1;
+  } else {
+    enqueue();
+  }
+}
+
+double Engine::rho_estimate(const double *res) const {                                   // _osqp.py:880-908 (scaled quantities)
+  double pri = res[R_PRI_S] / (std::max(res[R_AX_S], res[R_Z_S]) + 1e-10);
+  double dua = res[R_DUA_S] / (std::max(std::max(res[R_ATY_S], res[R_PX_S]), qnorm_s_) + 1e-10);
+  return clamp_rho(rho_bar_ * std::sqrt(pri / (dua + 1e-10)));
+}
+
+// _osqp.py:998-1077.  Returns 1 when a terminal status was set.
+int Engine::check_termination(const double *res, bool approximate) {
+  double ea = settings.eps_abs, er = settings.eps_rel, epi = settings.eps_prim_inf, edi = settings.eps_dual_inf;
+  if (approximate) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
+  const bool unsc = settings.scaling && !settings.scaled_termination;
+  if (info.prim_res > OSQP_INFTY || info.dual_res > OSQP_INFTY || std::isnan(info.prim_res) || std::isnan(info.dual_res)) {
+    set_status(OSQP_NON_CVX); info.obj_val = kNaN; return 1;                            // :1025-1028
+  }
+  bool pri_ok = false, dua_ok = false, prim_inf = false, dual_inf = false;
+  if (m == 0) pri_ok = true;
+  else {
+    double eps_pri = ea + er * (unsc ? std::max(res[R_AX_U], res[R_Z_U]) : std::max(res[R_AX_S], res[R_Z_S]));   // :728-751
+    if (info.prim_res < eps_pri) pri_ok = true;
+    else {                                                                              // is_primal_infeasible :796-820
+      double nd = unsc ? res[R_DY_U] : res[R_DY_S];
+      if (nd > epi && res[R_PINF_LHS] < -epi * nd) {
+        be::infeas_primal(d_);
+        double r2[R_COUNT]; be::fetch_res(d_, r2);
+        prim_inf = (unsc ? r2[R_ATDY_U] : r2[R_ATDY_S]) < epi * nd;
+      }
+    }
+  }
+  double mx = unsc ? cinv_ * std::max(std::max(res[R_ATY_U], res[R_PX_U]), qnorm_u_)
+                   : std::max(std::max(res[R_ATY_S], res[R_PX_S]), qnorm_s_);             // :766-794
+  if (info.dual_res < ea + er * mx) dua_ok = true;
+  else {                                                                                // is_dual_infeasible :822-878
+    double nd = unsc ? res[R_DX_U] : res[R_DX_S], sc = unsc ? c_ : 1.0;
+    if (nd > edi && res[R_QDX] < -sc * edi * nd) {
+      be::infeas_dual(d_, edi * nd, unsc ? 1 : 0);
+      double r2[R_COUNT]; be::fetch_res(d_, r2);
+      if ((unsc ? r2[R_PDX_U] : r2[R_PDX_S]) < sc * edi * nd && r2[R_ADX_VIOL] == 0.0) dual_inf = true;
+    }
+  }
+  if (pri_ok && dua_ok) { set_status(approximate ? OSQP_SOLVED_INACCURATE : OSQP_SOLVED); return 1; }
+  if (prim_inf) { set_status(approximate ? OSQP_PRIMAL_INFEASIBLE_INACCURATE : OSQP_PRIMAL_INFEASIBLE); info.obj_val = OSQP_INFTY; return 1; }
+  if (dual_inf) { set_status(approximate ? OSQP_DUAL_INFEASIBLE_INACCURATE : OSQP_DUAL_INFEASIBLE); info.obj_val = -OSQP_INFTY; return 1; }
+  return 0;
+}
+
+int Engine::solve() {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  const double t0 = now_s();
+  if (clear_update_time_) { info.update_time = 0; }
+  info.update_time += update_time_acc_; update_time_acc_ = 0;
+  if (!settings.warm_starting) cold_start();                                            // _osqp.py:1204-1205
+  info.rho_updates = 0; info.status_polish = 0; info.polish_time = 0;
+  set_status(OSQP_UNSOLVED);
+  stats_.pcg_iters_total = stats_.pcg_iters_max = stats_.pcg_unconverged = 0;
+  stats_.kernel_launches = stats_.graph_launches = 0;
+  const int ct = settings.check_termination;
+  const int ari = settings.adaptive_rho ? auto_rho_interval() : 0;
+  // PCG tolerance for the first chunk: relative, ||rhs||/cg_tol_reduction (then tied to the ADMM residuals).
+  // Tolerance and budget restart with every solve so that a solve is a deterministic function of (data, iterates).
+  have_tol_ = false; cg_budget_ = 0;
+  if (!have_tol_) { be::set_pcg_tol(d_, 1.0 / settings.cg_tol_reduction, kCgTolAbsMin); eps_cg_prev_ = std::numeric_limits<double>::infinity(); }
+  if (cg_budget_ <= 0) cg_budget_ = std::min(settings.cg_max_iter, 5);
+  cg_budget_ = std::min(cg_budget_, std::min(settings.cg_max_iter, kMaxCg));
+  if (settings.verbose) std::printf("iter   objective    prim res   dual res   rho        cg   time\n");
+
+  int iter = 0;
+  double res[R_COUNT];
+  int flags[F_COUNT];
+  while (true) {
+    int next = settings.max_iter;
+    if (ct > 0) next = std::min(next, (iter / ct + 1) * ct);
+    if (ari > 0) next = std::min(next, (iter / ari + 1) * ari);
+    run_chunk(next - iter, cg_budget_);
+    iter = next;
+    be::residuals(d_);
+    be::fetch_res(d_, res);
+    be::fetch_flags(d_, flags);
+    stats_.pcg_iters_total += flags[F_STAT_SUM];
+    stats_.pcg_iters_max = std::max(stats_.pcg_iters_max, (double)flags[F_STAT_MAX]);
+    stats_.pcg_unconverged += flags[F_STAT_UNCONV];
+    const bool unsc = settings.scaling && !settings.scaled_termination;
+    info.iter = iter;
+    info.obj_val = (0.5 * res[R_XPX] + res[R_QX]) * (settings.scaling ? cinv_ : 1.0);      // _osqp.py:705-712
+    info.prim_res = (m == 0) ? 0.0 : (unsc ? res[R_PRI_U] : res[R_PRI_S]);                 // :714-726
+    info.dual_res = unsc ? cinv_ * res[R_DUA_U] : res[R_DUA_S];                            // :753-764
+    info.dual_obj_val = (-0.5 * res[R_XPX] - res[R_SUPP]) * (settings.scaling ? cinv_ : 1.0);
+    info.duality_gap = info.obj_val - info.dual_obj_val;
+    if (settings.verbose)
+      std::printf("%4d  %11.4e   %8.2e   %8.2e   %8.2e  %3d  %8.2es\n", iter, info.obj_val, info.prim_res, info.dual_res, rho_bar_,
+                  flags[F_STAT_MAX], now_s() - t0);
+    const bool do_check = (ct > 0 && iter % ct == 0) || iter == settings.max_iter;
+    if (do_check && check_termination(res, false)) break;
+    if (iter >= settings.max_iter) {                                                     // :1264-1266
+      if (!check_termination(res, true)) set_status(OSQP_MAX_ITER_REACHED);
+      break;
+    }
+    if (now_s() - t0 > settings.time_limit) { set_status(OSQP_TIME_LIMIT_REACHED); break; }
+    if (ari > 0 && iter % ari == 0) {                                                    // adapt_rho :910-930
+      double rn = rho_estimate(res);
+      info.rho_estimate = rn;
+      if (rn > settings.adaptive_rho_tolerance * rho_bar_ || rn < rho_bar_ / settings.adaptive_rho_tolerance) {
+        rho_bar_ = rn; settings.rho = rn;
+        be::set_rho(d_, rho_bar_);
+        be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+        info.rho_updates++;
+      }
+    }
+    // inner tolerance follows the (scaled) ADMM residuals and never loosens
+    double eps = settings.cg_tol_fraction * std::sqrt(res[R_PRI_S] * res[R_DUA_S]);
+    if (m == 0) eps = settings.cg_tol_fraction * res[R_DUA_S];
+    eps = std::max(std::min(eps, eps_cg_prev_), kCgTolAbsMin);
+    if (std::isfinite(eps)) { eps_cg_prev_ = eps; be::set_pcg_tol(d_, 1e-14, eps); have_tol_ = true; }
+    // PCG budget for the next chunk: track what the last chunk needed
+    const int cap = std::min(settings.cg_max_iter, kMaxCg);
+    if (flags[F_STAT_UNCONV] > 0) cg_budget_ = std::min(cap, std::max(cg_budget_ + 2, 2 * cg_budget_));
+    else cg_budget_ = std::min(cap, std::max(2, flags[F_STAT_MAX] + 2));
+  }
+  info.rho_estimate = rho_estimate(res);                                                 // :1275
+  store_solution();
+  be::sync(d_);
+  info.solve_time = now_s() - t0;
+  info.run_time = (first_run_ ? info.setup_time : info.update_time) + info.solve_time + info.polish_time;   // :1284-1289
+  first_run_ = false; clear_update_time_ = true;
+  if (settings.verbose)
+    std::printf("\nstatus:               %s\nnumber of iterations: %d\noptimal objective:    %.4f\nrun time:             %.2es\noptimal rho estimate: %.2e\n\n",
+                info.status, info.iter, info.obj_val, info.run_time, info.rho_estimate);
+  return OSQP_NO_ERROR;
+}
+
+void Engine::store_solution() {                                                          // _osqp.py:1098-1115
+  const int st = info.status_val;
+  const bool pinf = st == OSQP_PRIMAL_INFEASIBLE || st == OSQP_PRIMAL_INFEASIBLE_INACCURATE;
+  const bool dinf = st == OSQP_DUAL_INFEASIBLE || st == OSQP_DUAL_INFEASIBLE_INACCURATE;
+  const bool unsc = settings.scaling && !settings.scaled_termination;
+  std::fill(sol_pc_.begin(), sol_pc_.end(), kNaN); std::fill(sol_dc_.begin(), sol_dc_.end(), kNaN);
+  if (!pinf && !dinf) {
+    be::d2h(d_, sol_x_.data(), d_.x, sizeof(double) * n);
+    be::d2h(d_, sol_y_.data(), d_.y, sizeof(double) * m);
+    if (settings.scaling) {
+      for (int j = 0; j < n; j++) sol_x_[j] *= D_[j];
+      for (int i = 0; i < m; i++) sol_y_[i] *= cinv_ * E_[i];
+    }
+  } else {
+    std::fill(sol_x_.begin(), sol_x_.end(), kNaN); std::fill(sol_y_.begin(), sol_y_.end(), kNaN);
+    if (pinf) {
+      be::d2h(d_, sol_pc_.data(), d_.dy, sizeof(double) * m);
+      if (unsc) for (int i = 0; i < m; i++) sol_pc_[i] *= E_[i];                         // :1065-1066
+    } else {
+      be::d2h(d_, sol_dc_.data(), d_.dx, sizeof(double) * n);
+      if (unsc) for (int j = 0; j < n; j++) sol_dc_[j] *= D_[j];                         // :1074-1075
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ updates
+int Engine::cold_start() {                                                               // _osqp.py:636-642
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  be::zero(d_, d_.x, sizeof(double) * n); be::zero(d_, d_.z, sizeof(double) * m); be::zero(d_, d_.y, sizeof(double) * m);
+  be::init_iterates(d_, 1);
+  return OSQP_NO_ERROR;
+}
+
+int Engine::warm_start(const double *x, const double *y) {                               // _osqp.py:1493-1545
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  settings.warm_starting = 1;
+  if (x) {
+    std::vector<double> xs(n);
+    for (int j = 0; j < n; j++) xs[j] = x[j] * Dinv_[j];
+    be::h2d(d_, d_.x, xs.data(), sizeof(double) * n);
+  }
+  if (y) {
+    std::vector<double> ys(m);
+    for (int i = 0; i < m; i++) ys[i] = y[i] * Einv_[i] * c_;   // inverse of y = cinv E y_scaled (:1112); the C core includes c
+    be::h2d(d_, d_.y, ys.data(), sizeof(double) * m);
+  }
+  be::init_iterates(d_, 1);                                         // z = A x (:1509)
+  return OSQP_NO_ERROR;
+}
+
+int Engine::update_data_vec(const double *q, const double *l, const double *u) {          // _osqp.py:1312-1367
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  double t0 = now_s();
+  if (l || u) {
+    for (int i = 0; i < m; i++) {
+      double li = l ? l[i] : l0_[i], ui = u ? u[i] : u0_[i];
+      if (!(li <= ui)) return OSQP_DATA_VALIDATION_ERROR;                                // :1348-1349
+    }
+  }
+  if (q) { q0_.assign(q, q + n); upload_q(); }
+  if (l) l0_.assign(l, l + m);
+  if (u) u0_.assign(u, u + m);
+  if (l || u) {
+    upload_bounds_and_types();                                                          // update_rho_vec :526-562
+    be::set_rho(d_, rho_bar_);
+    be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  }
+  set_status(OSQP_UNSOLVED);                                                             // reset_info :932-941
+  be::sync(d_);
+  update_time_acc_ += now_s() - t0;
+  return OSQP_NO_ERROR;
+}
+
+int Engine::update_data_mat(const double *Px, const int *Px_idx, int P_n, const double *Ax, const int *Ax_idx, int A_n) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  double t0 = now_s();
+  const int nzP = P_.nnz(), nzA = A_.nnz();
+  if (Px) {                                                   // bindings.cpp.in:240-281: idx == NULL means all entries in order
+    if (Px_idx) { for (int k = 0; k < P_n; k++) if (Px_idx[k] < 0 || Px_idx[k] >= nzP) return OSQP_DATA_VALIDATION_ERROR; }
+    else if (P_n != nzP && P_n != 0) return OSQP_DATA_VALIDATION_ERROR;
+    for (int k = 0; k < (Px_idx ? P_n : nzP); k++) P_.x[Px_idx ? Px_idx[k] : k] = Px[k];
+  }
+  if (Ax) {
+    if (Ax_idx) { for (int k = 0; k < A_n; k++) if (Ax_idx[k] < 0 || Ax_idx[k] >= nzA) return OSQP_DATA_VALIDATION_ERROR; }
+    else if (A_n != nzA && A_n != 0) return OSQP_DATA_VALIDATION_ERROR;
+    for (int k = 0; k < (Ax_idx ? A_n : nzA); k++) A_.x[Ax_idx ? Ax_idx[k] : k] = Ax[k];
+  }
+  std::vector<double> Pxs, Axs;
+  scale_matrix_values(Pxs, Axs);                                                         // _osqp.py:1443,:1463
+  fill_matrix_values(Pxs, Axs);
+  be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);                   // the "refactor" of :1446,:1466,:1488
+  be::init_iterates(d_, 0);                                                              // z~, t0 depend on A; iterates untouched
+  set_status(OSQP_UNSOLVED);
+  be::sync(d_);
+  update_time_acc_ += now_s() - t0;
+  return OSQP_NO_ERROR;
+}
+
+int Engine::update_rho(double rho) {                                                     // _osqp.py:1579-1597
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  if (!(rho > 0)) return OSQP_SETTINGS_VALIDATION_ERROR;
+  rho_bar_ = clamp_rho(rho); settings.rho = rho_bar_;
+  be::set_rho(d_, rho_bar_);
+  be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  return OSQP_NO_ERROR;
+}
+
+int Engine::update_settings(const OSQPSettings *s) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  int err = validate_settings(s, false);
+  if (err) return err;
+  // settings that can change after setup (the reference: "These can be changed without running setup", _osqp.py:128-143)
+  settings.max_iter = s->max_iter; settings.eps_abs = s->eps_abs; settings.eps_rel = s->eps_rel;
+  settings.eps_prim_inf = s->eps_prim_inf; settings.eps_dual_inf = s->eps_dual_inf; settings.alpha = s->alpha;
+  settings.scaled_termination = s->scaled_termination; settings.check_termination = s->check_termination;
+  settings.check_dualgap = s->check_dualgap; settings.time_limit = s->time_limit; settings.warm_starting = s->warm_starting;
+  settings.verbose = s->verbose; settings.polishing = s->polishing; settings.delta = s->delta;
+  settings.polish_refine_iter = s->polish_refine_iter; settings.adaptive_rho = s->adaptive_rho;
+  settings.adaptive_rho_interval = s->adaptive_rho_interval; settings.adaptive_rho_fraction = s->adaptive_rho_fraction;
+  settings.adaptive_rho_tolerance = s->adaptive_rho_tolerance; settings.cg_max_iter = s->cg_max_iter;
+  settings.cg_tol_reduction = s->cg_tol_reduction; settings.cg_tol_fraction = s->cg_tol_fraction;
+  if (s->cg_precond != settings.cg_precond) { settings.cg_precond = s->cg_precond; be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER); }
+  if (d_.alpha != settings.alpha) { d_.alpha = settings.alpha; drop_graphs(); }     // alpha is baked into captured launches
+  have_tol_ = false; cg_budget_ = 0;
+  return OSQP_NO_ERROR;
+}
+
+int Engine::get_stats(OSQPHipStats *out) { if (!out) return OSQP_DATA_VALIDATION_ERROR; *out = stats_; return OSQP_NO_ERROR; }
+int Engine::time_kernel(int which, int reps, double *ms) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  if (which < 0 || which > 4 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
+  *ms = be::time_kernel(d_, which, reps);
+  return OSQP_NO_ERROR;
+}
+int Engine::test_spmv(int which, const double *in, double *out) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  const int nin = which == 0 ? n : n + m, nout = which == 0 ? m : n;
+  double *din = dev_vec<double>(d_, nin), *dout = dev_vec<double>(d_, nout);
+  be::h2d(d_, din, in, sizeof(double) * nin);
+  be::test_spmv(d_, which, din, dout);
+  be::d2h(d_, out, dout, sizeof(double) * nout);
+  be::dfree(d_, din); be::dfree(d_, dout);
+  return OSQP_NO_ERROR;
+}
+int Engine::get_scaling(double *D, double *E, double *c) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  std::copy(D_.begin(), D_.end(), D); std::copy(E_.begin(), E_.end(), E); *c = c_;
+  return OSQP_NO_ERROR;
+}
+
+}  // namespace osqp_hip

@@ -1,0 +1,91 @@
+// engine.hpp -- host side of the MI355X OSQP engine: problem setup (validation, Ruiz scaling, CSR/B assembly),
+// the ADMM driver loop, termination / infeasibility / adaptive-rho logic.  All per-iteration arithmetic runs in
+// the backend (backend.h); the host only sees R_COUNT doubles every check_termination iterations.
+#pragma once
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/osqp_hip.h"
+#include "backend.h"
+
+namespace osqp_hip {
+
+struct HostCsc {
+  int nr = 0, nc = 0;
+  std::vector<int> p, i;
+  std::vector<double> x;   // UNSCALED values as given by the caller
+  int nnz() const { return (int)i.size(); }
+};
+
+class Engine {
+ public:
+  Engine();
+  ~Engine();
+  // C-API entry points (names follow include/osqp_hip.h)
+  int setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *A, const double *l, const double *u, int m,
+            int n, const OSQPSettings *s);
+  int solve();
+  int warm_start(const double *x, const double *y);
+  int cold_start();
+  int update_data_vec(const double *q, const double *l, const double *u);
+  int update_data_mat(const double *Px, const int *Px_idx, int P_n, const double *Ax, const int *Ax_idx, int A_n);
+  int update_settings(const OSQPSettings *s);
+  int update_rho(double rho);
+  int get_stats(OSQPHipStats *out);
+  int time_kernel(int which, int reps, double *ms);
+  int test_spmv(int which, const double *in, double *out);
+  int get_scaling(double *D, double *E, double *c);
+
+  OSQPSolver pub{};          // what the caller holds
+  OSQPSettings settings{};
+  OSQPInfo info{};
+  OSQPSolution solution{};
+  int n = 0, m = 0;
+
+  static int validate_settings(const OSQPSettings *s, bool at_setup);
+
+ private:
+  // ---- host copies ----
+  HostCsc P_, A_;                       // P_: upper triangle
+  std::vector<double> q0_, l0_, u0_;    // unscaled
+  std::vector<double> D_, E_, Dinv_, Einv_; double c_ = 1.0, cinv_ = 1.0;
+  std::vector<int> ctype_;
+  std::vector<double> sol_x_, sol_y_, sol_pc_, sol_dc_;
+  double qnorm_s_ = 0, qnorm_u_ = 0;    // ||q_scaled||_inf, ||Dinv q_scaled||_inf
+  // maps for value updates
+  std::vector<int> Pmap1_, Pmap2_, AmapA_, AmapB_, bdiag_;
+  std::vector<double> Aval_, Bval_;     // host mirrors of the scaled device value arrays
+  // ---- device ----
+  Dev d_;
+  bool dev_ready_ = false;
+  // ---- driver state ----
+  double rho_bar_ = 0.1;
+  int cg_budget_ = 0;
+  double eps_cg_prev_ = 0;
+  bool first_run_ = true;
+  bool have_tol_ = false;
+  bool use_graph_ = true;
+  std::map<std::pair<int, int>, void *> graphs_;
+  OSQPHipStats stats_{};
+  double update_time_acc_ = 0;
+  bool clear_update_time_ = false;
+
+  void free_all();
+  void compute_scaling(std::vector<double> &Px_s, std::vector<double> &Ax_s, std::vector<double> &q_s);
+  void scale_matrix_values(std::vector<double> &Px_s, std::vector<double> &Ax_s) const;
+  void classify_constraints(const std::vector<double> &l_s, const std::vector<double> &u_s);
+  void upload_bounds_and_types();
+  void upload_q();
+  void fill_matrix_values(const std::vector<double> &Px_s, const std::vector<double> &Ax_s);
+  void run_chunk(int niter, int budget);
+  void drop_graphs();
+  int check_termination(const double *res, bool approximate);
+  double rho_estimate(const double *res) const;
+  void store_solution();
+  void set_status(int status);
+  int auto_rho_interval() const;
+};
+
+}  // namespace osqp_hip

@@ -1,0 +1,112 @@
+"""Loads libosqp_hip.so (the C-ABI engine built from ../csrc by ../Makefile) and declares its prototypes.
+
+There is deliberately NO fallback: if the HIP library is missing the import fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libosqp_hip.so')
+
+c_int_p = C.POINTER(C.c_int)
+c_double_p = C.POINTER(C.c_double)
+
+
+class CscStruct(C.Structure):          # OSQPCscMatrix, include/osqp_hip.h
+    _fields_ = [('m', C.c_int), ('n', C.c_int), ('p', c_int_p), ('i', c_int_p), ('x', c_double_p),
+                ('nzmax', C.c_int), ('nz', C.c_int)]
+
+
+SETTINGS_FIELDS = [            # OSQPSettings, same order as include/osqp_hip.h (= bindings.cpp.in:409-447)
+    ('device', C.c_int), ('linsys_solver', C.c_int), ('verbose', C.c_int), ('warm_starting', C.c_int),
+    ('scaling', C.c_int), ('polishing', C.c_int), ('rho', C.c_double), ('rho_is_vec', C.c_int),
+    ('sigma', C.c_double), ('alpha', C.c_double), ('cg_max_iter', C.c_int), ('cg_tol_reduction', C.c_int),
+    ('cg_tol_fraction', C.c_double), ('cg_precond', C.c_int), ('adaptive_rho', C.c_int),
+    ('adaptive_rho_interval', C.c_int), ('adaptive_rho_fraction', C.c_double), ('adaptive_rho_tolerance', C.c_double),
+    ('max_iter', C.c_int), ('eps_abs', C.c_double), ('eps_rel', C.c_double), ('eps_prim_inf', C.c_double),
+    ('eps_dual_inf', C.c_double), ('scaled_termination', C.c_int), ('check_termination', C.c_int),
+    ('check_dualgap', C.c_int), ('time_limit', C.c_double), ('delta', C.c_double), ('polish_refine_iter', C.c_int)]
+
+
+class SettingsStruct(C.Structure):
+    _fields_ = SETTINGS_FIELDS
+
+
+INFO_FIELDS = [               # OSQPInfo (bindings.cpp.in:473-492)
+    ('status', C.c_char * 32), ('status_val', C.c_int), ('status_polish', C.c_int), ('obj_val', C.c_double),
+    ('dual_obj_val', C.c_double), ('prim_res', C.c_double), ('dual_res', C.c_double), ('duality_gap', C.c_double),
+    ('iter', C.c_int), ('rho_updates', C.c_int), ('rho_estimate', C.c_double), ('setup_time', C.c_double),
+    ('solve_time', C.c_double), ('update_time', C.c_double), ('polish_time', C.c_double), ('run_time', C.c_double),
+    ('primdual_int', C.c_double), ('rel_kkt_error', C.c_double)]
+
+
+class InfoStruct(C.Structure):
+    _fields_ = INFO_FIELDS
+
+
+class SolutionStruct(C.Structure):
+    _fields_ = [('x', c_double_p), ('y', c_double_p), ('prim_inf_cert', c_double_p), ('dual_inf_cert', c_double_p)]
+
+
+class SolverStruct(C.Structure):
+    _fields_ = [('settings', C.POINTER(SettingsStruct)), ('solution', C.POINTER(SolutionStruct)),
+                ('info', C.POINTER(InfoStruct)), ('work', C.c_void_p)]
+
+
+class StatsStruct(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ('pcg_iters_total', 'pcg_iters_max', 'pcg_unconverged', 'kernel_launches',
+                                          'graph_launches', 'gpu_solve_ms', 'nnzA', 'nnzB')]
+
+
+SolverP = C.POINTER(SolverStruct)
+
+# every symbol include/osqp_hip.h declares: name -> (restype, argtypes)
+PROTOTYPES = {
+    'osqp_capabilities': (C.c_int, []),
+    'osqp_set_default_settings': (None, [C.POINTER(SettingsStruct)]),
+    'osqp_version': (C.c_char_p, []),
+    'osqp_setup': (C.c_int, [C.POINTER(SolverP), C.POINTER(CscStruct), c_double_p, C.POINTER(CscStruct), c_double_p,
+                             c_double_p, C.c_int, C.c_int, C.POINTER(SettingsStruct)]),
+    'osqp_solve': (C.c_int, [SolverP]),
+    'osqp_cleanup': (C.c_int, [SolverP]),
+    'osqp_warm_start': (C.c_int, [SolverP, c_double_p, c_double_p]),
+    'osqp_cold_start': (C.c_int, [SolverP]),
+    'osqp_update_data_vec': (C.c_int, [SolverP, c_double_p, c_double_p, c_double_p]),
+    'osqp_update_data_mat': (C.c_int, [SolverP, c_double_p, c_int_p, C.c_int, c_double_p, c_int_p, C.c_int]),
+    'osqp_update_settings': (C.c_int, [SolverP, C.POINTER(SettingsStruct)]),
+    'osqp_update_rho': (C.c_int, [SolverP, C.c_double]),
+    'osqp_get_dimensions': (None, [SolverP, c_int_p, c_int_p]),
+    'osqp_adjoint_derivative_compute': (C.c_int, [SolverP, c_double_p, c_double_p]),
+    'osqp_adjoint_derivative_get_mat': (C.c_int, [SolverP, C.POINTER(CscStruct), C.POINTER(CscStruct)]),
+    'osqp_adjoint_derivative_get_vec': (C.c_int, [SolverP, c_double_p, c_double_p, c_double_p]),
+    'osqp_codegen': (C.c_int, [SolverP, C.c_char_p, C.c_char_p, C.c_void_p]),
+    'osqp_set_default_codegen_defines': (None, [C.c_void_p]),
+    'osqp_hip_get_stats': (C.c_int, [SolverP, C.POINTER(StatsStruct)]),
+    'osqp_hip_time_kernel': (C.c_int, [SolverP, C.c_int, C.c_int, c_double_p]),
+    'osqp_hip_test_spmv': (C.c_int, [SolverP, C.c_int, c_double_p, c_double_p]),
+    'osqp_hip_get_scaling': (C.c_int, [SolverP, c_double_p, c_double_p, c_double_p]),
+    'osqp_hip_backend': (C.c_char_p, []),
+}
+
+
+def _bind(lib):
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_handle = None
+
+
+def handle():
+    """The loaded engine library.  Raises ImportError when it has not been built."""
+    global _handle
+    if _handle is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                'libosqp_hip.so not found at %s -- build the HIP engine first (python -c "import __graft_entry__ as g; '
+                'g.build()" or make -C osqp-python_amd).  There is no CPU fallback.' % LIB_PATH)
+        _handle = _bind(C.CDLL(LIB_PATH))
+    return _handle

@@ -1,0 +1,219 @@
+// tests/hostsim/backend_host.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Plain-loop implementation of the device-op interface (osqp-python_amd/csrc/backend.h).  Linked with the product's
+// host driver (engine.cpp, api.cpp) into tests/_build/libosqp_hostsim.so by tests/hostsim_build.py so the driver logic
+// can be exercised in CI containers that have no GPU.  The product library libosqp_hip.so links backend_hip.hip only,
+// has no CPU path, and never loads this file.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../osqp-python_amd/csrc/backend.h"
+#include "../../include/osqp_hip.h"
+
+namespace osqp_hip {
+namespace be {
+
+namespace {
+inline double nanmax(double r, double a) { return (a > r || a != a) ? a : r; }
+inline double *gam(Dev &d) { return d.scal + S_HIST; }
+inline double *alp(Dev &d) { return d.scal + S_HIST + kMaxCg + 1; }
+struct Impl { double gamma_next = 0, rnorm = 0, bnorm = 0, delta = 0; };
+inline Impl &im(Dev &d) { return *static_cast<Impl *>(d.impl); }
+}  // namespace
+
+const char *name() { return "hostsim"; }
+int init(Dev &d, int) { d.impl = new Impl(); return 0; }
+void destroy(Dev &d) { delete static_cast<Impl *>(d.impl); d.impl = nullptr; }
+void *alloc(Dev &, size_t bytes) { return std::calloc(1, bytes); }
+void dfree(Dev &, void *p) { std::free(p); }
+void h2d(Dev &, void *dst, const void *src, size_t b) { std::memcpy(dst, src, b); }
+void d2h(Dev &, void *dst, const void *src, size_t b) { std::memcpy(dst, src, b); }
+void zero(Dev &, void *dst, size_t b) { std::memset(dst, 0, b); }
+void sync(Dev &) {}
+void activate(Dev &) {}
+
+void kb_rhs(Dev &d) {
+  Impl &s = im(d);
+  double g = 0, rn = 0, bn = 0;
+  for (int j = 0; j < d.n; j++) {
+    double sA = 0, sK = 0;
+    for (int k = d.B.rowptr[j]; k < d.B.rowptr[j + 1]; k++) {
+      int c = d.B.col[k]; double v = d.B.val[k];
+      if (c < d.n) sK += v * d.xs[c];
+      else { sA += v * d.v[c - d.n]; sK += v * d.t0[c - d.n]; }
+    }
+    double rhs = d.sigma * d.x[j] - d.q[j] + sA;
+    double r = rhs - sK, u = d.Minv[j] * r;
+    d.r[j] = r; d.uu[j] = u;
+    g += r * u; rn = nanmax(rn, std::fabs(r)); bn = nanmax(bn, std::fabs(rhs));
+  }
+  s.gamma_next = g; s.rnorm = rn; s.bnorm = bn;
+  d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0;
+}
+
+void k1(Dev &d, int i) {
+  if (d.flags[F_DONE]) return;
+  Impl &s = im(d);
+  double tol = std::max(d.scal[S_TOL_REL] * s.bnorm, d.scal[S_TOL_ABS]);
+  if (!(s.rnorm > tol)) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = i; return; }
+  for (int r = 0; r < d.m; r++) {
+    double a = 0;
+    for (int k = d.A.rowptr[r]; k < d.A.rowptr[r + 1]; k++) a += d.A.val[k] * d.uu[d.A.col[k]];
+    d.t[r] = d.rho[r] * a;
+  }
+}
+
+void k2(Dev &d, int) {
+  if (d.flags[F_DONE]) return;
+  double dl = 0;
+  for (int j = 0; j < d.n; j++) {
+    double a = 0;
+    for (int k = d.B.rowptr[j]; k < d.B.rowptr[j + 1]; k++) { int c = d.B.col[k]; a += d.B.val[k] * (c < d.n ? d.uu[c] : d.t[c - d.n]); }
+    d.w[j] = a; dl += a * d.uu[j];
+  }
+  im(d).delta = dl;
+}
+
+void kv(Dev &d, int i) {
+  if (d.flags[F_DONE]) return;
+  Impl &s = im(d);
+  double gamma = s.gamma_next, delta = s.delta, alpha, beta;
+  if (i == 0) { beta = 0; alpha = gamma / delta; }
+  else { beta = gamma / gam(d)[i - 1]; alpha = gamma / (delta - beta * gamma / alp(d)[i - 1]); }
+  gam(d)[i] = gamma; alp(d)[i] = alpha;
+  double g = 0, rn = 0;
+  for (int j = 0; j < d.n; j++) {
+    double p = i == 0 ? d.uu[j] : d.uu[j] + beta * d.p[j];
+    double sv = i == 0 ? d.w[j] : d.w[j] + beta * d.s[j];
+    d.p[j] = p; d.s[j] = sv;
+    d.xs[j] += alpha * p;
+    double r = d.r[j] - alpha * sv, u = d.Minv[j] * r;
+    d.r[j] = r; d.uu[j] = u;
+    g += r * u; rn = nanmax(rn, std::fabs(r));
+  }
+  s.gamma_next = g; s.rnorm = rn;
+}
+
+void ka(Dev &d, int budget) {
+  for (int i = 0; i < d.m; i++) {
+    double zt = 0;
+    for (int k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; k++) zt += d.A.val[k] * d.xs[d.A.col[k]];
+    double zr = d.alpha * zt + (1.0 - d.alpha) * d.z[i];
+    double zn = std::fmin(std::fmax(zr + d.rho_inv[i] * d.y[i], d.l[i]), d.u[i]);
+    double dy = d.rho[i] * (zr - zn);
+    d.y[i] += dy; d.dy[i] = dy; d.z[i] = zn; d.zt[i] = zt;
+    d.v[i] = d.rho[i] * zn - d.y[i]; d.t0[i] = d.rho[i] * zt;
+  }
+  for (int j = 0; j < d.n; j++) {
+    double xn = d.alpha * d.xs[j] + (1.0 - d.alpha) * d.x[j];
+    d.dx[j] = xn - d.x[j]; d.x[j] = xn;
+  }
+  int used = d.flags[F_DONE] ? d.flags[F_ITERS] : budget;
+  d.flags[F_STAT_SUM] += used;
+  d.flags[F_STAT_MAX] = std::max(d.flags[F_STAT_MAX], used);
+  if (!d.flags[F_DONE]) d.flags[F_STAT_UNCONV] += 1;
+}
+
+void residuals(Dev &d) {
+  double *R = d.res;
+  for (int q = 0; q <= R_QDX; q++) R[q] = 0;
+  for (int i = 0; i < d.m; i++) {
+    double ax = 0;
+    for (int k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; k++) ax += d.A.val[k] * d.x[d.A.col[k]];
+    double pr = ax - d.z[i], ei = d.Einv[i];
+    R[R_PRI_U] = nanmax(R[R_PRI_U], std::fabs(ei * pr)); R[R_AX_U] = nanmax(R[R_AX_U], std::fabs(ei * ax)); R[R_Z_U] = nanmax(R[R_Z_U], std::fabs(ei * d.z[i]));
+    R[R_PRI_S] = nanmax(R[R_PRI_S], std::fabs(pr)); R[R_AX_S] = nanmax(R[R_AX_S], std::fabs(ax)); R[R_Z_S] = nanmax(R[R_Z_S], std::fabs(d.z[i]));
+    R[R_DY_U] = nanmax(R[R_DY_U], std::fabs(d.E[i] * d.dy[i])); R[R_DY_S] = nanmax(R[R_DY_S], std::fabs(d.dy[i]));
+    R[R_PINF_LHS] += d.u[i] * std::fmax(d.dy[i], 0.0) + d.l[i] * std::fmin(d.dy[i], 0.0);
+    double sup = 0;
+    if (d.y[i] > 0 && d.u[i] < OSQP_INFTY * 1e-4) sup = d.u[i] * d.y[i];
+    else if (d.y[i] < 0 && d.l[i] > -OSQP_INFTY * 1e-4) sup = d.l[i] * d.y[i];
+    R[R_SUPP] += sup;
+  }
+  for (int j = 0; j < d.n; j++) {
+    double sp = 0, sa = 0;
+    for (int k = d.B.rowptr[j]; k < d.B.rowptr[j + 1]; k++) { int c = d.B.col[k]; if (c < d.n) sp += d.B.val[k] * d.x[c]; else sa += d.B.val[k] * d.y[c - d.n]; }
+    double px = sp - d.sigma * d.x[j], dr = px + d.q[j] + sa, di = d.Dinv[j];
+    R[R_DUA_U] = nanmax(R[R_DUA_U], std::fabs(di * dr)); R[R_PX_U] = nanmax(R[R_PX_U], std::fabs(di * px)); R[R_ATY_U] = nanmax(R[R_ATY_U], std::fabs(di * sa));
+    R[R_DUA_S] = nanmax(R[R_DUA_S], std::fabs(dr)); R[R_PX_S] = nanmax(R[R_PX_S], std::fabs(px)); R[R_ATY_S] = nanmax(R[R_ATY_S], std::fabs(sa));
+    R[R_DX_U] = nanmax(R[R_DX_U], std::fabs(d.D[j] * d.dx[j])); R[R_DX_S] = nanmax(R[R_DX_S], std::fabs(d.dx[j]));
+    R[R_XPX] += d.x[j] * px; R[R_QX] += d.q[j] * d.x[j]; R[R_QDX] += d.q[j] * d.dx[j];
+  }
+}
+
+void infeas_primal(Dev &d) {
+  double u = 0, s = 0;
+  for (int j = 0; j < d.n; j++) {
+    double sa = 0;
+    for (int k = d.B.rowptr[j]; k < d.B.rowptr[j + 1]; k++) { int c = d.B.col[k]; if (c >= d.n) sa += d.B.val[k] * d.dy[c - d.n]; }
+    u = nanmax(u, std::fabs(d.Dinv[j] * sa)); s = nanmax(s, std::fabs(sa));
+  }
+  d.res[R_ATDY_U] = u; d.res[R_ATDY_S] = s;
+}
+
+void infeas_dual(Dev &d, double thr, int unscaled) {
+  double u = 0, s = 0, viol = 0;
+  for (int j = 0; j < d.n; j++) {
+    double sp = 0;
+    for (int k = d.B.rowptr[j]; k < d.B.rowptr[j + 1]; k++) { int c = d.B.col[k]; if (c < d.n) sp += d.B.val[k] * d.dx[c]; }
+    sp -= d.sigma * d.dx[j];
+    u = nanmax(u, std::fabs(d.Dinv[j] * sp)); s = nanmax(s, std::fabs(sp));
+  }
+  for (int i = 0; i < d.m; i++) {
+    double a = 0;
+    for (int k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; k++) a += d.A.val[k] * d.dx[d.A.col[k]];
+    if (unscaled) a *= d.Einv[i];
+    if ((d.u[i] < OSQP_INFTY * 1e-4 && a > thr) || (d.l[i] > -OSQP_INFTY * 1e-4 && a < -thr)) viol += 1;
+  }
+  d.res[R_PDX_U] = u; d.res[R_PDX_S] = s; d.res[R_ADX_VIOL] = viol;
+}
+
+void fetch_res(Dev &d, double *h) { std::memcpy(h, d.res, sizeof(double) * R_COUNT); }
+void fetch_flags(Dev &d, int *h) {
+  std::memcpy(h, d.flags, sizeof(int) * F_COUNT);
+  d.flags[F_STAT_SUM] = d.flags[F_STAT_MAX] = d.flags[F_STAT_UNCONV] = 0;
+}
+
+void set_rho(Dev &d, double rb) {
+  for (int i = 0; i < d.m; i++) {
+    double r = d.ctype[i] == -1 ? 1e-6 : (d.ctype[i] == 1 ? 1e3 * rb : rb);
+    d.rho[i] = r; d.rho_inv[i] = 1.0 / r;
+    d.v[i] = r * d.z[i] - d.y[i]; d.t0[i] = r * d.zt[i];
+  }
+}
+void precond(Dev &d, int diagonal) {
+  for (int j = 0; j < d.n; j++) {
+    if (!diagonal) { d.Minv[j] = 1.0; continue; }
+    double s = d.B.val[d.Bdiag[j]];
+    for (int k = d.B.rowptr[j]; k < d.B.rowptr[j + 1]; k++) { int c = d.B.col[k]; if (c >= d.n) s += d.rho[c - d.n] * d.B.val[k] * d.B.val[k]; }
+    d.Minv[j] = 1.0 / s;
+  }
+}
+void set_pcg_tol(Dev &d, double rel, double ab) { d.scal[S_TOL_REL] = rel; d.scal[S_TOL_ABS] = ab; }
+
+void init_iterates(Dev &d, int full) {
+  if (full) for (int j = 0; j < d.n; j++) { d.xs[j] = d.x[j]; d.dx[j] = 0; }
+  for (int i = 0; i < d.m; i++) {
+    double a = 0;
+    for (int k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; k++) a += d.A.val[k] * d.xs[d.A.col[k]];
+    if (full) { d.z[i] = a; d.dy[i] = 0; }
+    d.zt[i] = a; d.t0[i] = d.rho[i] * a; d.v[i] = d.rho[i] * d.z[i] - d.y[i];
+  }
+}
+
+bool graphs_supported() { return false; }
+void graph_begin(Dev &) {}
+void *graph_end(Dev &) { return nullptr; }
+void graph_launch(Dev &, void *) {}
+void graph_free(Dev &, void *) {}
+
+void test_spmv(Dev &d, int which, const double *in, double *out) {
+  const DevCsr &M = which == 0 ? d.A : d.B;
+  for (int r = 0; r < M.nrows; r++) { double a = 0; for (int k = M.rowptr[r]; k < M.rowptr[r + 1]; k++) a += M.val[k] * in[M.col[k]]; out[r] = a; }
+}
+float time_kernel(Dev &, int, int) { return 0.f; }
+
+}  // namespace be
+}  // namespace osqp_hip

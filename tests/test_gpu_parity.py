@@ -1,0 +1,158 @@
+"""GPU tier (-m gpu): the parity tests proper.  Every test calls the HIP engine through the C ABI (ctypes) and checks it
+against the oracle (oracle/osqp_oracle.c, the CPU restatement of the reference algorithm with a direct LDL' solve), the
+committed golden fixtures, and size-independent optimality properties (KKT certificate) at sizes the oracle cannot
+reach quickly.  Tolerance: north_star asks for agreement with the direct CPU path within eps_abs = eps_rel = 1e-6; both
+solvers stop at residuals <= eps, so solutions are compared at 1e-5 * (1 + ||.||_inf) unless stated otherwise."""
+import os
+import warnings
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+import scipy.sparse as sp
+
+import osqp_amd
+import problems
+from oracle import Oracle, SOLVED
+from util import Fixture
+
+pytestmark = pytest.mark.gpu
+warnings.simplefilter('ignore')
+EPS = 1e-6
+
+
+def hip_solve(P, q, A, l, u, **st):
+    kw = dict(eps_abs=EPS, eps_rel=EPS, verbose=False, max_iter=20000, cg_max_iter=100)
+    kw.update(st)
+    m = osqp_amd.OSQP(algebra='hip')
+    m.setup(P, q, A, l, u, **kw)
+    return m, m.solve()
+
+
+def oracle_solve(P, q, A, l, u, **st):
+    kw = dict(eps_abs=EPS / 10, eps_rel=EPS / 10, max_iter=50000, adaptive_rho_interval=50)
+    kw.update(st)
+    return Oracle().setup(P, q, A, l, u, **kw).solve()
+
+
+def test_backend_is_hip():
+    assert osqp_amd._lib.handle().osqp_hip_backend() == b'hip-gfx950'
+    import torch
+    assert torch.cuda.is_available()
+
+
+GENS = {
+    'random50': lambda: problems.random_qp(),
+    'banded2000': lambda: problems.banded_qp(2000, window=40),
+    'banded_unaligned': lambda: problems.banded_qp(1537, m=2999, nnz_per_row=7, window=61, seed=3),
+    'lasso': lambda: problems.lasso_qp(60, 300),                 # dense 300-entry rows -> long-row (workgroup) path
+    'portfolio': lambda: problems.portfolio_qp(400, 20),         # one 400-entry row + 200-entry rows
+}
+
+
+@pytest.mark.parametrize('name', list(GENS))
+def test_spmv_kernels_match_scipy(name):
+    """CSR-stream / long-row SpMV over A and B = [P + sigma I | A'] against SciPy on the engine's own scaled matrices."""
+    P, q, A, l, u = GENS[name]()
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, scaling=10)
+    s = m._solver
+    D, E, c = s.hip_scaling()
+    n, mm = len(q), len(l)
+    As = sp.diags(E) @ A @ sp.diags(D)
+    Ps = c * (sp.diags(D) @ P @ sp.diags(D))
+    rng = np.random.default_rng(7)
+    xin = rng.standard_normal(n); vin = rng.standard_normal(n + mm)
+    npt.assert_allclose(s.hip_test_spmv(0, xin), As @ xin, rtol=1e-12, atol=1e-12)
+    ref = Ps @ vin[:n] + m.settings.sigma * vin[:n] + As.T @ vin[n:]
+    npt.assert_allclose(s.hip_test_spmv(1, vin), ref, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', list(GENS))
+def test_solution_matches_oracle_direct(name):
+    P, q, A, l, u = GENS[name]()
+    m, r = hip_solve(P, q, A, l, u)
+    xo, yo, io = oracle_solve(P, q, A, l, u)
+    assert r.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED and io.status_val == SOLVED
+    npt.assert_allclose(r.x, xo, rtol=0, atol=2e-5 * (1 + np.abs(xo).max()))
+    npt.assert_allclose(r.y, yo, rtol=0, atol=2e-5 * (1 + np.abs(yo).max()))
+    assert abs(r.info.obj_val - io.obj_val) <= 1e-5 * (1 + abs(io.obj_val))
+    k = problems.kkt_certificate(P, q, A, l, u, r.x, r.y)
+    assert k['pri'] <= 10 * EPS * (1 + max(np.abs(A @ r.x).max(), 1)) and k['dua'] <= 10 * EPS * (1 + np.abs(q).max() + np.abs(P @ r.x).max())
+    # reported residuals are the true ones (recomputed on the host, unscaled)
+    z = np.clip(A @ r.x, l, u)
+    assert abs(np.abs(A @ r.x - z).max() - 0) <= r.info.prim_res * 1.5 + 1e-9
+    npt.assert_allclose(np.abs(P @ r.x + q + A.T @ r.y).max(), r.info.dual_res, rtol=1e-6, atol=1e-10)
+
+
+@pytest.mark.parametrize('case', ['basic_QP', 'matrices_solve', 'config1_random_qp', 'warm_start', 'polish_random_admm'])
+def test_fixture_matches_python_reference(case):
+    """x, y, obj of the importable pure-python reference (ref_* in the fixtures), tightened settings on both sides."""
+    f = Fixture(case)
+    m = osqp_amd.OSQP(); m.setup(f.P, f.q, f.A, f.l, f.u, **f.hip_settings(cg_max_iter=100))
+    r = m.solve()
+    assert r.info.status_val == int(f['ref_status']) == 1
+    tol = 50 * max(f.settings['eps_abs'], 1e-9)
+    npt.assert_allclose(r.x, f['ref_x'], rtol=0, atol=tol * (1 + np.abs(f['ref_x']).max()))
+    npt.assert_allclose(r.y, f['ref_y'], rtol=0, atol=tol * (1 + np.abs(f['ref_y']).max()))
+    assert abs(r.info.obj_val - float(f['ref_obj'])) <= tol * (1 + abs(float(f['ref_obj'])))
+    # same algorithm, inexact inner solves: the ADMM iteration count stays close to the reference's
+    assert abs(r.info.iter - int(f['ref_iter'])) <= max(25, 0.15 * int(f['ref_iter']))
+
+
+def test_graph_and_eager_launch_paths_agree_bitwise():
+    P, q, A, l, u = GENS['banded2000']()
+    out = []
+    for g in ('1', '0'):
+        os.environ['OSQP_HIP_GRAPH'] = g
+        m, r = hip_solve(P, q, A, l, u)
+        st = m._solver.hip_stats()
+        out.append((r.x.copy(), r.y.copy(), r.info.iter, st['graph_launches']))
+    os.environ.pop('OSQP_HIP_GRAPH')
+    assert out[0][3] > 0 and out[1][3] == 0
+    assert out[0][2] == out[1][2]
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_deterministic_repeat_and_resolve():
+    P, q, A, l, u = GENS['banded2000']()
+    m, r1 = hip_solve(P, q, A, l, u, warm_starting=False)
+    r2 = m.solve()
+    assert r1.info.iter == r2.info.iter and np.array_equal(r1.x, r2.x) and np.array_equal(r1.y, r2.y)
+
+
+def test_kernel_probe_leaves_state_untouched():
+    P, q, A, l, u = GENS['banded2000']()
+    m, r1 = hip_solve(P, q, A, l, u)
+    for which in range(5):
+        ms = m._solver.hip_time_kernel(which, 20)
+        assert 0 < ms < 50
+    m.warm_start(x=r1.x, y=r1.y)
+    r2 = m.solve()
+    assert r2.info.iter <= 50 and np.abs(r2.x - r1.x).max() < 1e-5
+
+
+def test_update_vectors_and_matrices_vs_oracle():
+    P, q, A, l, u = GENS['banded2000']()
+    rng = np.random.default_rng(5)
+    m, _ = hip_solve(P, q, A, l, u)
+    o = Oracle().setup(P, q, A, l, u, eps_abs=EPS / 10, eps_rel=EPS / 10, max_iter=50000, adaptive_rho_interval=50)
+    o.solve()
+    q2 = q + 0.3 * rng.standard_normal(len(q)); l2 = l - 0.1; u2 = u + 0.2
+    Pt = sp.triu(P, format='csc'); Px2 = Pt.data * (1 + 0.05 * rng.random(Pt.nnz)); Ax2 = A.data * (1 + 0.05 * rng.standard_normal(A.nnz))
+    m.update(q=q2, l=l2, u=u2); m.update(Px=Px2, Ax=Ax2)
+    o.update(q=q2, l=l2, u=u2); o.update(Px=Px2, Ax=Ax2)
+    r = m.solve(); xo, yo, io = o.solve()
+    assert r.info.status_val == 1 and io.status_val == SOLVED
+    npt.assert_allclose(r.x, xo, rtol=0, atol=2e-5 * (1 + np.abs(xo).max()))
+    npt.assert_allclose(r.y, yo, rtol=0, atol=2e-5 * (1 + np.abs(yo).max()))
+
+
+@pytest.mark.parametrize('n', [20000])
+def test_larger_banded_qp_kkt_certificate(n):
+    """Beyond quick-oracle size: size-independent optimality certificate of the returned (x, y)."""
+    P, q, A, l, u = problems.banded_qp(n)
+    m, r = hip_solve(P, q, A, l, u)
+    assert r.info.status_val == 1
+    k = problems.kkt_certificate(P, q, A, l, u, r.x, r.y)
+    scale_p = 1 + np.abs(A @ r.x).max(); scale_d = 1 + max(np.abs(P @ r.x).max(), np.abs(A.T @ r.y).max(), np.abs(q).max())
+    assert k['pri'] <= 2 * EPS * scale_p and k['dua'] <= 2 * EPS * scale_d and k['comp'] <= 1e-3
