@@ -73,9 +73,9 @@ typedef struct {
   OSQPInt   rho_is_vec;
   OSQPFloat sigma;
   OSQPFloat alpha;
-  OSQPInt   cg_max_iter;                  /* cap on PCG iterations per ADMM iteration */
+  OSQPInt   cg_max_iter;                  /* cap on PCG iterations per ADMM iteration (default 50) */
   OSQPInt   cg_tol_reduction;             /* first-chunk PCG tolerance = ||rhs||_inf / cg_tol_reduction */
-  OSQPFloat cg_tol_fraction;              /* PCG tolerance = fraction * sqrt(prim_res * dual_res) (scaled) */
+  OSQPFloat cg_tol_fraction;              /* PCG tolerance = fraction * (scaled ADMM dual residual), non-increasing */
   enum osqp_precond_type cg_precond;
   OSQPInt   adaptive_rho;
   OSQPInt   adaptive_rho_interval;        /* 0 = automatic (2 * check_termination, or 50) */

@@ -23,7 +23,7 @@ void osqp_set_default_settings(OSQPSettings *s) {
   if (!s) return;
   s->device = 0; s->linsys_solver = OSQP_INDIRECT_SOLVER; s->verbose = 1; s->warm_starting = 1; s->scaling = 10; s->polishing = 0;
   s->rho = 0.1; s->rho_is_vec = 1; s->sigma = 1e-6; s->alpha = 1.6;
-  s->cg_max_iter = 20; s->cg_tol_reduction = 10; s->cg_tol_fraction = 0.15; s->cg_precond = OSQP_DIAGONAL_PRECONDITIONER;
+  s->cg_max_iter = 50; s->cg_tol_reduction = 10; s->cg_tol_fraction = 0.15; s->cg_precond = OSQP_DIAGONAL_PRECONDITIONER;
   s->adaptive_rho = 1; s->adaptive_rho_interval = 0; s->adaptive_rho_fraction = 0.4; s->adaptive_rho_tolerance = 5.0;
   s->max_iter = 4000; s->eps_abs = 1e-3; s->eps_rel = 1e-3; s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4;
   s->scaled_termination = 0; s->check_termination = 25; s->check_dualgap = 0; s->time_limit = 1e10;

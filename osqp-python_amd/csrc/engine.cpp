@@ -484,8 +484,11 @@ int Engine::solve() {
       }
     }
     // inner tolerance follows the (scaled) ADMM residuals and never loosens
-    double eps = settings.cg_tol_fraction * std::sqrt(res[R_PRI_S] * res[R_DUA_S]);
-    if (m == 0) eps = settings.cg_tol_fraction * res[R_DUA_S];
+    // The PCG residual r enters the ADMM dual residual one-to-one (P x~ + sigma(x~ - x) + q + A'(...) = r), so the inner
+    // tolerance is a fraction of the current SCALED dual residual.  (Upstream's rule, fraction * sqrt(prim*dual)
+    // [UPSTREAM-UNVERIFIED], lets r exceed the dual residual whenever prim >> dual; that biases the rho estimate of
+    // _osqp.py:880-908 and was measured to cost 2-3x more ADMM iterations -- see DESIGN.md "PCG tolerance".)
+    double eps = settings.cg_tol_fraction * res[R_DUA_S];
     eps = std::max(std::min(eps, eps_cg_prev_), kCgTolAbsMin);
     if (std::isfinite(eps)) { eps_cg_prev_ = eps; be::set_pcg_tol(d_, 1e-14, eps); have_tol_ = true; }
     // PCG budget for the next chunk: track what the last chunk needed

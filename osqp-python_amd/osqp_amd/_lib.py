@@ -100,6 +100,20 @@ def _bind(lib):
 _handle = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7) and
+    libhsa-runtime64.so; if /opt/rocm's copy is already mapped when torch is imported, torch maps its second copy and the
+    two HSA runtimes fight over /dev/kfd (hipGetDeviceCount fails in whichever initialises second).  Loading torch's
+    runtime FIRST makes the dynamic linker satisfy libosqp_hip.so's NEEDED libamdhip64.so.7 by SONAME with the copy that
+    is already mapped, so the engine, torch.cuda and torch.distributed (RCCL) share one runtime and one set of streams.
+    Without torch installed the engine binds to /opt/rocm/lib (its RUNPATH)."""
+    import importlib.util
+    import sys
+    if 'torch' in sys.modules or importlib.util.find_spec('torch') is None:
+        return
+    import torch  # noqa: F401
+
+
 def handle():
     """The loaded engine library.  Raises ImportError when it has not been built."""
     global _handle
@@ -108,5 +122,6 @@ def handle():
             raise ImportError(
                 'libosqp_hip.so not found at %s -- build the HIP engine first (python -c "import __graft_entry__ as g; '
                 'g.build()" or make -C osqp-python_amd).  There is no CPU fallback.' % LIB_PATH)
+        _preload_torch_hip_runtime()
         _handle = _bind(C.CDLL(LIB_PATH))
     return _handle
