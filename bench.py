@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X OSQP engine (contract: see the task statement / DESIGN.md §Measurement).
+
+Metric (BASELINE.json): ADMM iterations/sec (+ achieved HBM GB/s of the PCG SpMV) on the n=100k, m=200k, nnz(A)=1M,
+nnz(P)=200k sparse QP (BASELINE configs[1], generator problems.banded_qp), indirect PCG.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N>1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one complete cold-started solve of the QP (setup -- scaling, CSR/B assembly, H2D -- is done once, outside the
+timed region: all inputs are resident in HBM when the clock starts).  value = ADMM iterations executed by all ranks in the
+K timed steps / wall time (max over ranks).  With N > 1 every rank owns one independent QP of the same shape (different
+seed): the path shards one-problem-per-GPU with no data-path collective; the only communication is the final all_gather of
+{status, iter, obj, prim_res, dual_res} over RCCL (scaling: weak).
+
+Rank 0 also reports
+  roofline      algorithmic bytes per launch / mean launch time (hipEvent pair on the solver's stream) of the dominant PCG
+                kernel (the SpMV over B = [P+sigma I | A']), against the 8 TB/s HBM peak;
+  cpu_baseline  the oracle (oracle/osqp_oracle.c: the CPU restatement of the reference algorithm with a direct LDL' KKT
+                solve -- the role QDLDL plays in the reference's builtin algebra), timed on this host's cores on a bounded
+                sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'osqp-python_amd'), os.path.join(ROOT, 'oracle')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def spmv_bytes(nnz, rows, cols):
+    """Algorithmic bytes of one CSR SpMV: fp64 values + int32 column indices, row pointers, the input
+    vector gathered once, the output written once."""
+    return 12 * nnz + 4 * (rows + 1) + 8 * cols + 8 * rows
+
+
+def cpu_baseline(P, q, A, l, u, settings, seconds_target=15.0):
+    """Oracle (direct LDL', AMD ordering, 1 thread) on the same QP; bounded number of ADMM iterations."""
+    from oracle import Oracle
+    t0 = time.time()
+    o = Oracle().setup(P, q, A, l, u, eps_abs=settings['eps_abs'], eps_rel=settings['eps_rel'], max_iter=20,
+                       adaptive_rho_interval=settings['adaptive_rho_interval'], check_termination=settings['check_termination'])
+    t_setup = time.time() - t0
+    _, _, info = o.solve()                       # 20 iterations: calibrates the per-iteration cost
+    per_it = info.solve_time / max(info.iter, 1)
+    k = int(max(20, min(2000, seconds_target / max(per_it, 1e-9))))
+    o.update_settings(max_iter=k, warm_start=0)
+    _, _, info = o.solve()
+    return {'value': info.iter / info.solve_time, 'unit': 'ADMM iter/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d cold-started ADMM iterations of the same QP in %.1f s; direct LDL\' KKT solve, own AMD ordering, '
+                      'nnz(L)=%.3g; setup (ordering+factorisation) %.1f s not included' % (info.iter, info.solve_time, info.lnz, t_setup),
+            'setup_s': t_setup}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--n', type=int, default=100000, help='variables (m = 2n, nnz(A) = 10n, nnz(P) = 2n)')
+    ap.add_argument('--eps', type=float, default=1e-6)
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='CPU-baseline budget (0 disables)')
+    ap.add_argument('--probe-reps', type=int, default=200)
+    args = ap.parse_args()
+    warnings.simplefilter('ignore')
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import osqp_amd
+    import problems
+
+    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))     # backend "nccl" is RCCL on ROCm
+
+    n = args.n
+    P, q, A, l, u = problems.banded_qp(n, seed=12345 + rank)
+    settings = dict(eps_abs=args.eps, eps_rel=args.eps, max_iter=20000, check_termination=25, adaptive_rho_interval=50,
+                    scaling=10, warm_starting=False, verbose=False, device=local)
+    m = osqp_amd.OSQP(algebra='hip')
+    t0 = time.time()
+    m.setup(P, q, A, l, u, **settings)
+    t_setup = time.time() - t0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        m.solve()
+    barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    res = None
+    for _ in range(args.steps):
+        res = m.solve()
+        iters += res.info.iter
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stats = m._solver.hip_stats()
+
+    # whole-job aggregate: total ADMM iterations / max-over-ranks time; final status/objective gather over RCCL
+    rec = torch.tensor([float(res.info.status_val), float(res.info.iter), res.info.obj_val, res.info.prim_res, res.info.dual_res,
+                        elapsed, float(iters)], dtype=torch.float64, device='cuda')
+    if world > 1:
+        allrec = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(allrec, rec)
+        allrec = torch.stack(allrec).cpu().numpy()
+    else:
+        allrec = rec.cpu().numpy()[None, :]
+    tmax = float(allrec[:, 5].max()); total_iters = float(allrec[:, 6].sum())
+
+    if rank == 0:
+        nnzA, nnzB, mm = int(stats['nnzA']), int(stats['nnzB']), len(l)
+        s = m._solver
+        kb = {   # algorithmic bytes per launch: SpMV formula + the fused epilogue/extra vectors
+            'K1 spmv A (t=rho.*(A u))': spmv_bytes(nnzA, mm, n) + 8 * mm,
+            'K2 spmv B (w=B[u;t], <w,u>)': spmv_bytes(nnzB, n, n + mm),
+            'Kv pcg vector update': 12 * 8 * n,
+            'KB rhs + pcg start': spmv_bytes(nnzB, n, n + mm) + 8 * mm + 8 * (4 * n),
+            'KA A x~ + z,y,x update': spmv_bytes(nnzA, mm, n) + 8 * (9 * mm) + 8 * (3 * n),
+        }
+        probes = {}
+        for which, name in enumerate(kb):
+            ms = s.hip_time_kernel(which, args.probe_reps)
+            probes[name] = {'ms': ms, 'bytes': kb[name], 'GBps': kb[name] / (ms * 1e-3) / 1e9}
+        dom = 'K2 spmv B (w=B[u;t], <w,u>)'
+        pcg_bytes = sum(kb[k] for k in list(kb)[:3]); pcg_ms = s.hip_time_kernel(5, args.probe_reps)   # K1,K2,Kv alternating
+        out = {
+            'metric': 'ADMM iterations/sec, n=%d m=%d nnz(A)=%d sparse QP (indirect PCG)' % (n, mm, A.nnz),
+            'value': total_iters / tmax, 'unit': 'ADMM iter/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * tmax / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: single QP n=%d m=%d nnz(A)=%d nnz(P)=%d (problems.banded_qp, seed 12345+rank), '
+                                   'eps_abs=eps_rel=%g, indirect PCG, one independent QP per GPU' % (n, mm, A.nnz, P.nnz, args.eps),
+                       'admm_iters_per_solve': int(res.info.iter), 'status': res.info.status, 'obj_val': res.info.obj_val,
+                       'prim_res': res.info.prim_res, 'dual_res': res.info.dual_res, 'rho_updates': int(res.info.rho_updates),
+                       'pcg_iters_per_admm_iter': stats['pcg_iters_total'] / max(res.info.iter, 1),
+                       'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
+                       'setup_s': t_setup, 'per_rank': [{'status': int(r[0]), 'iter': int(r[1]), 'obj': r[2]} for r in allrec]},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': probes[dom]['GBps'] / HBM_PEAK_GBS, 'traffic': None,
+                         'bytes_per_launch': kb[dom], 'ms_per_launch': probes[dom]['ms'],
+                         'pcg_iteration': {'bytes': pcg_bytes, 'ms': pcg_ms, 'GBps': pcg_bytes / (pcg_ms * 1e-3) / 1e9,
+                                           'frac': pcg_bytes / (pcg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         'kernels': probes},
+        }
+        if args.cpu_seconds > 0:
+            cb = cpu_baseline(P, q, A, l, u, settings, args.cpu_seconds)
+            out['cpu_baseline'] = cb
+            out['config']['gpu_over_cpu_iter_rate'] = (total_iters / tmax / world) / cb['value']
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -614,7 +614,8 @@ float time_kernel(Dev &d, int which, int reps) {
       case 1: LAUNCH(k_k2, d, d, 1); break;
       case 2: LAUNCH(k_kv, d, d, 1, 1); break;
       case 3: LAUNCH(k_kb, d, d); break;
-      default: LAUNCH(k_ka, d, d, 0); break;
+      case 4: LAUNCH(k_ka, d, d, 0); break;
+      default: LAUNCH(k_k1, d, d, 1, 1); LAUNCH(k_k2, d, d, 1); LAUNCH(k_kv, d, d, 1, 1); break;   // one PCG iteration
     }
   };
   for (int w = 0; w < 5; w++) launch();

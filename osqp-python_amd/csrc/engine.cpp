@@ -27,9 +27,9 @@ double clamp_rho(double r) { return std::min(std::max(r, kRhoMin), kRhoMax); }
 template <class T>
 T *dev_vec(Dev &d, size_t count) { return static_cast<T *>(be::alloc(d, std::max<size_t>(count, 1) * sizeof(T))); }
 
-// Row blocks for the CSR-stream kernels: consecutive rows whose nnz sum to <= kChunk (and <= kMaxRowsPerBlock rows);
+// Row blocks for the CSR-stream kernels: consecutive rows whose nnz sum to <= target (and <= kMaxRowsPerBlock rows);
 // a row with more than kLongRow entries is a block of its own (reduced by the whole workgroup).
-std::vector<int> build_row_blocks(const std::vector<int> &rowptr, int nrows) {
+std::vector<int> build_row_blocks_target(const std::vector<int> &rowptr, int nrows, int target) {
   std::vector<int> rb; rb.push_back(0);
   int r = 0;
   while (r < nrows) {
@@ -38,12 +38,27 @@ std::vector<int> build_row_blocks(const std::vector<int> &rowptr, int nrows) {
     int start = r, acc = 0;
     while (r < nrows && r - start < kMaxRowsPerBlock) {
       int l2 = rowptr[r + 1] - rowptr[r];
-      if (l2 > kLongRow || acc + l2 > kChunk) break;
+      if (l2 > kLongRow || (acc + l2 > target && r > start)) break;
       acc += l2; r++;
     }
     rb.push_back(r);
   }
   return rb;
+}
+// Every kernel runs kGrid workgroups, so the number of row blocks is made a whole multiple k of kGrid with equal
+// nnz per block (a 1172-block matrix on a 1024-workgroup grid would otherwise cost two full rounds).
+std::vector<int> build_row_blocks(const std::vector<int> &rowptr, int nrows) {
+  const long nnz = nrows > 0 ? rowptr[nrows] : 0;
+  long k = std::max<long>(1, (nnz + (long)kGrid * kChunk - 1) / ((long)kGrid * kChunk));
+  for (;; k++) {
+    int target = (int)std::max<long>(128, (nnz + kGrid * k - 1) / (kGrid * k));
+    for (int attempt = 0; attempt < 40 && target <= kChunk; attempt++) {
+      std::vector<int> rb = build_row_blocks_target(rowptr, nrows, target);
+      if ((long)rb.size() - 1 <= kGrid * k) return rb;
+      target = std::min<int>(kChunk + 1, target + std::max(1, target / 50));
+    }
+    if (k > 1024) return build_row_blocks_target(rowptr, nrows, kChunk);   // pathological (e.g. all rows long): accept
+  }
 }
 }  // namespace
 
@@ -436,7 +451,16 @@ int Engine::solve() {
   // PCG tolerance for the first chunk: relative, ||rhs||/cg_tol_reduction (then tied to the ADMM residuals).
   // Tolerance and budget restart with every solve so that a solve is a deterministic function of (data, iterates).
   have_tol_ = false; cg_budget_ = 0;
-  if (!have_tol_) { be::set_pcg_tol(d_, 1.0 / settings.cg_tol_reduction, kCgTolAbsMin); eps_cg_prev_ = std::numeric_limits<double>::infinity(); }
+  {
+    // residuals of the starting point (zeros on a cold start, the caller's iterate on a warm start): a warm start near
+    // the optimum must not be perturbed by a loose first-chunk solve (warm_start_test.py:52-57 expects < 10 iterations)
+    double r0[R_COUNT];
+    be::residuals(d_); be::fetch_res(d_, r0);
+    const double eps0 = settings.cg_tol_fraction * r0[R_DUA_S];
+    if (std::isfinite(eps0) && eps0 > kCgTolAbsMin) be::set_pcg_tol(d_, 1e-14, eps0);     // absolute, like every later chunk
+    else be::set_pcg_tol(d_, 1.0 / settings.cg_tol_reduction, kCgTolAbsMin);             // dual-feasible start (e.g. q = 0): relative
+    eps_cg_prev_ = std::numeric_limits<double>::infinity();
+  }
   if (cg_budget_ <= 0) cg_budget_ = std::min(settings.cg_max_iter, 5);
   cg_budget_ = std::min(cg_budget_, std::min(settings.cg_max_iter, kMaxCg));
   if (settings.verbose) std::printf("iter   objective    prim res   dual res   rho        cg   time\n");
@@ -645,7 +669,7 @@ int Engine::get_stats(OSQPHipStats *out) { if (!out) return OSQP_DATA_VALIDATION
 int Engine::time_kernel(int which, int reps, double *ms) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);
-  if (which < 0 || which > 4 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
+  if (which < 0 || which > 5 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
   *ms = be::time_kernel(d_, which, reps);
   return OSQP_NO_ERROR;
 }

@@ -67,15 +67,19 @@ def test_spmv_kernels_match_scipy(name):
     npt.assert_allclose(s.hip_test_spmv(1, vin), ref, rtol=1e-12, atol=1e-12)
 
 
+# measured on MI355X (round 1): at eps 1e-6 the worst case (portfolio) differs from the direct path by 4e-5 in x, 4e-4 in y
+# (both solvers only guarantee residuals <= eps); at eps 1e-8 by 3e-7 / 3e-6.  Tolerances = ~5x those.
+@pytest.mark.parametrize('eps,atol', [(1e-6, 2e-4), (1e-8, 2e-6)])
 @pytest.mark.parametrize('name', list(GENS))
-def test_solution_matches_oracle_direct(name):
+def test_solution_matches_oracle_direct(name, eps, atol):
     P, q, A, l, u = GENS[name]()
-    m, r = hip_solve(P, q, A, l, u)
-    xo, yo, io = oracle_solve(P, q, A, l, u)
+    m, r = hip_solve(P, q, A, l, u, eps_abs=eps, eps_rel=eps, max_iter=100000)
+    xo, yo, io = oracle_solve(P, q, A, l, u, eps_abs=1e-10, eps_rel=1e-10, max_iter=200000)
     assert r.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED and io.status_val == SOLVED
-    npt.assert_allclose(r.x, xo, rtol=0, atol=2e-5 * (1 + np.abs(xo).max()))
-    npt.assert_allclose(r.y, yo, rtol=0, atol=2e-5 * (1 + np.abs(yo).max()))
-    assert abs(r.info.obj_val - io.obj_val) <= 1e-5 * (1 + abs(io.obj_val))
+    npt.assert_allclose(r.x, xo, rtol=0, atol=atol * (1 + np.abs(xo).max()))
+    npt.assert_allclose(r.y, yo, rtol=0, atol=atol * (1 + np.abs(yo).max()))
+    assert abs(r.info.obj_val - io.obj_val) <= 10 * eps * (1 + abs(io.obj_val))
+    EPS = eps
     k = problems.kkt_certificate(P, q, A, l, u, r.x, r.y)
     assert k['pri'] <= 10 * EPS * (1 + max(np.abs(A @ r.x).max(), 1)) and k['dua'] <= 10 * EPS * (1 + np.abs(q).max() + np.abs(P @ r.x).max())
     # reported residuals are the true ones (recomputed on the host, unscaled)
@@ -115,7 +119,7 @@ def test_graph_and_eager_launch_paths_agree_bitwise():
 
 def test_deterministic_repeat_and_resolve():
     P, q, A, l, u = GENS['banded2000']()
-    m, r1 = hip_solve(P, q, A, l, u, warm_starting=False)
+    m, r1 = hip_solve(P, q, A, l, u, warm_starting=False, adaptive_rho=False)   # (an adapted rho persists across solves, as in the reference)
     r2 = m.solve()
     assert r1.info.iter == r2.info.iter and np.array_equal(r1.x, r2.x) and np.array_equal(r1.y, r2.y)
 
@@ -128,7 +132,7 @@ def test_kernel_probe_leaves_state_untouched():
         assert 0 < ms < 50
     m.warm_start(x=r1.x, y=r1.y)
     r2 = m.solve()
-    assert r2.info.iter <= 50 and np.abs(r2.x - r1.x).max() < 1e-5
+    assert r2.info.iter <= 25 and np.abs(r2.x - r1.x).max() < 1e-5
 
 
 def test_update_vectors_and_matrices_vs_oracle():
