@@ -185,7 +185,8 @@ OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
 /* Re-launch one hot-path kernel `reps` times on the solver's stream with the solver's current device state and
    return its mean duration in milliseconds (hipEvent pair on that stream).  which: 0 = SpMV A (K1),
    1 = SpMV B (K2), 2 = PCG vector update (Kv), 3 = rhs kernel (KB), 4 = A x~ + z,y,x update (KA),
-   5 = one whole PCG iteration (K1, K2, Kv in sequence; the time is per sequence).
+   5 = one whole PCG iteration (K1, K2, Kv in sequence; time per sequence) without the reductions of partials,
+   6 = the same with them (what a solve executes).
    The kernels run in a side-effect-free "probe" mode; solver state is unchanged. */
 OSQPInt osqp_hip_time_kernel(OSQPSolver *solver, OSQPInt which, OSQPInt reps, double *mean_ms);
 

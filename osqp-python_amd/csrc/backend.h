@@ -29,7 +29,8 @@ constexpr int kMaxCg = 1024;       // hard cap on the PCG budget (size of the al
 
 struct DevCsr {
   int nrows = 0, ncols = 0, nnz = 0, nblk = 0;
-  int *rowptr = nullptr, *col = nullptr, *rowblk = nullptr;
+  int *rowptr = nullptr, *col = nullptr;
+  int *blkdesc = nullptr;        // nblk x {first row, end row, first nnz, end nnz}: one 16-byte load per row block
   double *val = nullptr;
 };
 

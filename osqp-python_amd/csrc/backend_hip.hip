@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/osqp_hip.h"
 #include "backend.h"
@@ -63,7 +64,7 @@ __device__ __forceinline__ double wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = nanmax(v, __shfl_down(v, o, 64));
   return v;
 }
-// all threads receive the block total; sred needs >= 4 doubles
+// all threads receive the block total; sred needs >= 8 doubles
 __device__ __forceinline__ double block_sum(double v, double *sred) {
   v = wave_sum(v);
   if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
@@ -80,36 +81,67 @@ __device__ __forceinline__ double block_max(double v, double *sred) {
   __syncthreads();
   return t;
 }
-__device__ __forceinline__ double partial_sum(const double *slot, double *sred) {
-  double v = 0;
-#pragma unroll
-  for (int k = 0; k < kGrid / kBlock; k++) v += slot[threadIdx.x + k * kBlock];
-  return block_sum(v, sred);
+// two quantities behind ONE barrier pair
+__device__ __forceinline__ void block_sum2(double &a, double &b, double *sred) {
+  a = wave_sum(a); b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = a; sred[4 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  a = (sred[0] + sred[1]) + (sred[2] + sred[3]); b = (sred[4] + sred[5]) + (sred[6] + sred[7]);
+  __syncthreads();
 }
-__device__ __forceinline__ double partial_max(const double *slot, double *sred) {
-  double v = 0;
-#pragma unroll
-  for (int k = 0; k < kGrid / kBlock; k++) v = nanmax(v, slot[threadIdx.x + k * kBlock]);
-  return block_max(v, sred);
+__device__ __forceinline__ void block_max2(double &a, double &b, double *sred) {
+  a = wave_max(a); b = wave_max(b);
+  if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = a; sred[4 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  a = nanmax(nanmax(sred[0], sred[1]), nanmax(sred[2], sred[3])); b = nanmax(nanmax(sred[4], sred[5]), nanmax(sred[6], sred[7]));
+  __syncthreads();
 }
+// a = sum, b = max, ONE barrier pair
+__device__ __forceinline__ void block_sum_max(double &a, double &b, double *sred) {
+  a = wave_sum(a); b = wave_max(b);
+  if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = a; sred[4 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  a = (sred[0] + sred[1]) + (sred[2] + sred[3]); b = nanmax(nanmax(sred[4], sred[5]), nanmax(sred[6], sred[7]));
+  __syncthreads();
+}
+// per-thread slices of the kGrid partials of a slot: issue the loads early, reduce later
+struct PartRegs { double v[kGrid / kBlock]; };
+__device__ __forceinline__ PartRegs partial_load(const double *slot) {
+  PartRegs r;
+#pragma unroll
+  for (int k = 0; k < kGrid / kBlock; k++) r.v[k] = slot[threadIdx.x + k * kBlock];
+  return r;
+}
+__device__ __forceinline__ double partial_fold_sum(const PartRegs &r) { double v = 0; for (int k = 0; k < kGrid / kBlock; k++) v += r.v[k]; return v; }
+__device__ __forceinline__ double partial_fold_max(const PartRegs &r) { double v = 0; for (int k = 0; k < kGrid / kBlock; k++) v = nanmax(v, r.v[k]); return v; }
+__device__ __forceinline__ double partial_sum(const double *slot, double *sred) { return block_sum(partial_fold_sum(partial_load(slot)), sred); }
+__device__ __forceinline__ double partial_max(const double *slot, double *sred) { return block_max(partial_fold_max(partial_load(slot)), sred); }
 __device__ __forceinline__ void put_partial(double *part, int slot, double v) {
   if (threadIdx.x == 0) part[slot * kGrid + blockIdx.x] = v;
 }
 
 // CSR-stream / CSR-vector row processing shared by every sparse kernel.
 //   G: gather functor   void operator()(int col, double val, double (&prod)[NS])
-//   E: row epilogue     void operator()(int row, const double (&sum)[NS])   (called by exactly one lane per row)
+//   E: row epilogue     void prefetch(int row)                                (optional loads issued before the barrier)
+//                       void operator()(int row, const double (&sum)[NS])    (called by exactly one lane per row)
+//   Pre: bool pre()     block-uniform hook run ONCE, after the first row block's streaming loads have been issued (so
+//                       whatever it waits for -- a reduction of partials, a flag -- overlaps those loads); returning
+//                       false abandons the kernel for this workgroup.
 template <int NS>
 struct StreamLds { double prod[2][NS][kChunk]; double red[8]; };
+struct NoPre { __device__ __forceinline__ bool operator()() const { return true; } };
 
-template <int NS, class G, class E>
-__device__ __forceinline__ void process_rows(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds) {
+template <int NS, class G, class E, class Pre>
+__device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds, Pre pre) {
   int buf = 0;
+  bool first = true;
+  const int4 *desc = reinterpret_cast<const int4 *>(M.blkdesc);
   for (int b = blockIdx.x; b < M.nblk; b += gridDim.x) {
-    const int r0 = M.rowblk[b], r1 = M.rowblk[b + 1];
-    const int k0 = M.rowptr[r0], k1 = M.rowptr[r1];
+    const int4 ds = desc[b];
+    const int r0 = ds.x, r1 = ds.y, k0 = ds.z, k1 = ds.w;
     const int cnt = k1 - k0;
     if (r1 - r0 == 1 && cnt > kLongRow) {                       // one long row: whole workgroup reduces it
+      if (first) { first = false; if (!pre()) return false; }
       double acc[NS];
 #pragma unroll
       for (int s = 0; s < NS; s++) acc[s] = 0.0;
@@ -121,7 +153,7 @@ __device__ __forceinline__ void process_rows(const DevCsr &M, const G &g, E &e, 
       }
 #pragma unroll
       for (int s = 0; s < NS; s++) acc[s] = block_sum(acc[s], lds.red);
-      if (threadIdx.x == 0) e(r0, acc);
+      if (threadIdx.x == 0) { e.prefetch(r0); e(r0, acc); }
     } else {                                                    // many short rows: stage products in LDS
       int cc[kChunk / kBlock];
       double vv[kChunk / kBlock];
@@ -131,6 +163,10 @@ __device__ __forceinline__ void process_rows(const DevCsr &M, const G &g, E &e, 
         cc[u] = k < cnt ? M.col[k0 + k] : -1;
         vv[u] = k < cnt ? M.val[k0 + k] : 0.0;
       }
+      const int myr = r0 + threadIdx.x;                          // the row this lane reduces in the first pass
+      int ra = 0, rz = 0;
+      if (myr < r1) { ra = M.rowptr[myr] - k0; rz = M.rowptr[myr + 1] - k0; e.prefetch(myr); }
+      if (first) { first = false; if (!pre()) return false; }
 #pragma unroll
       for (int u = 0; u < kChunk / kBlock; u++) {                // then the gathers
         const int k = threadIdx.x + u * kBlock;
@@ -142,7 +178,17 @@ __device__ __forceinline__ void process_rows(const DevCsr &M, const G &g, E &e, 
         }
       }
       __syncthreads();
-      for (int r = r0 + threadIdx.x; r < r1; r += kBlock) {
+      if (myr < r1) {
+        double acc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) acc[s] = 0.0;
+        for (int k = ra; k < rz; k++) {
+#pragma unroll
+          for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
+        }
+        e(myr, acc);
+      }
+      for (int r = myr + kBlock; r < r1; r += kBlock) {          // blocks with more than kBlock (mostly empty) rows
         const int a = M.rowptr[r] - k0, z = M.rowptr[r + 1] - k0;
         double acc[NS];
 #pragma unroll
@@ -151,12 +197,17 @@ __device__ __forceinline__ void process_rows(const DevCsr &M, const G &g, E &e, 
 #pragma unroll
           for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
         }
-        e(r, acc);
+        e.prefetch(r); e(r, acc);
       }
       buf ^= 1;   // the next row block fills the other buffer, so one barrier per block suffices
     }
   }
+  if (first) return pre();   // a workgroup without rows still runs the hook (e.g. workgroup 0 owns the PCG flags)
+  return true;
 }
+template <int NS, class G, class E>
+__device__ __forceinline__ void process_rows(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds) { process_rows<NS>(M, g, e, lds, NoPre()); }
+struct NoPrefetch { __device__ __forceinline__ void prefetch(int) {} };
 
 // ---------------------------------------------------------------------------------------------- hot-path kernels
 // KB ------------------------------------------------------------------------------------------
@@ -168,10 +219,11 @@ struct GKb {
   }
 };
 struct EKb {
-  const double *x, *q, *Minv; double *r, *uu; double sigma; double g = 0, rn = 0, bn = 0;
+  const double *x, *q, *Minv; double *r, *uu; double sigma; double g = 0, rn = 0, bn = 0; double px = 0, pq = 0, pm = 0;
+  __device__ __forceinline__ void prefetch(int j) { px = x[j]; pq = q[j]; pm = Minv[j]; }
   __device__ __forceinline__ void operator()(int j, const double (&s)[2]) {
-    const double rhs = sigma * x[j] - q[j] + s[0];
-    const double rr = rhs - s[1], u = Minv[j] * rr;
+    const double rhs = sigma * px - pq + s[0];
+    const double rr = rhs - s[1], u = pm * rr;
     r[j] = rr; uu[j] = u;
     g += rr * u; rn = nanmax(rn, fabs(rr)); bn = nanmax(bn, fabs(rhs));
   }
@@ -182,29 +234,45 @@ __global__ __launch_bounds__(kBlock) void k_kb(Dev d) {
   EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma};
   process_rows<2>(d.B, g, e, lds);
   __syncthreads();
-  const double G = block_sum(e.g, lds.red), RN = block_max(e.rn, lds.red), BN = block_max(e.bn, lds.red);
+  const double G = block_sum(e.g, lds.red);
+  double RN = e.rn, BN = e.bn;
+  block_max2(RN, BN, lds.red);
   put_partial(d.part, SL_GAMMA0, G); put_partial(d.part, SL_RN0, RN); put_partial(d.part, SL_BN, BN);
   if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
 }
 
 // K1 ------------------------------------------------------------------------------------------
 struct GVec { const double *x; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * x[c]; } };
-struct EK1 { const double *rho; double *t; __device__ __forceinline__ void operator()(int i, const double (&s)[1]) { t[i] = rho[i] * s[0]; } };
-__global__ __launch_bounds__(kBlock) void k_k1(Dev d, int i, int probe) {
-  __shared__ StreamLds<1> lds;
-  if (!probe) {
-    if (d.flags[F_DONE]) return;
-    const double rn = partial_max(d.part + (SL_RN0 + (i & 1)) * kGrid, lds.red);
-    const double bn = partial_max(d.part + SL_BN * kGrid, lds.red);
+struct EK1 {
+  const double *rho; double *t; double pr = 0;
+  __device__ __forceinline__ void prefetch(int i) { pr = rho[i]; }
+  __device__ __forceinline__ void operator()(int i, const double (&s)[1]) { t[i] = pr * s[0]; }
+};
+// PCG stopping test, run by every working workgroup (and workgroup 0) while its first matrix loads are in flight
+struct PreK1 {
+  const Dev &d; int i, probe; double *red;
+  __device__ __forceinline__ bool operator()() const {
+    if (probe == 1) return true;
+    const int done = d.flags[F_DONE];
+    const PartRegs prn = partial_load(d.part + (SL_RN0 + (i & 1)) * kGrid), pbn = partial_load(d.part + SL_BN * kGrid);
+    double rn = partial_fold_max(prn), bn = partial_fold_max(pbn);
+    block_max2(rn, bn, red);
+    if (probe) { if (rn < -1.0) d.res[R_COUNT - 1] = bn; return true; }     // probe == 2: pay for the test, ignore it
+    if (done) return false;
     const double tol = fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS]);
     if (!(rn > tol)) {            // converged (a NaN residual also stops the inner loop; the ADMM residuals will flag it)
       if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = i; }
-      return;
+      return false;
     }
+    return true;
   }
+};
+__global__ __launch_bounds__(kBlock) void k_k1(Dev d, int i, int probe) {
+  __shared__ StreamLds<1> lds;
+  if (blockIdx.x >= d.A.nblk && blockIdx.x != 0) return;     // nothing to do and not the flag owner
   GVec g{d.uu};
   EK1 e{d.rho, d.t};
-  process_rows<1>(d.A, g, e, lds);
+  process_rows<1>(d.A, g, e, lds, PreK1{d, i, probe, lds.red});
 }
 
 // K2 ------------------------------------------------------------------------------------------
@@ -212,71 +280,88 @@ struct GSplit {      // [pn; pm] indexed by a B column
   const double *pn, *pm; int n;
   __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * (c < n ? pn[c] : pm[c - n]); }
 };
-struct EK2 { const double *uu; double *w; double dl = 0; __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { w[j] = s[0]; dl += s[0] * uu[j]; } };
+struct EK2 {
+  const double *uu; double *w; double dl = 0, pu = 0;
+  __device__ __forceinline__ void prefetch(int j) { pu = uu[j]; }
+  __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { w[j] = s[0]; dl += s[0] * pu; }
+};
+struct PreFlag { const int *flags; int probe; __device__ __forceinline__ bool operator()() const { return probe || !flags[F_DONE]; } };
 __global__ __launch_bounds__(kBlock) void k_k2(Dev d, int probe) {
   __shared__ StreamLds<1> lds;
-  if (!probe && d.flags[F_DONE]) return;
   GSplit g{d.uu, d.t, d.n};
   EK2 e{d.uu, d.w};
-  process_rows<1>(d.B, g, e, lds);
+  if (!process_rows<1>(d.B, g, e, lds, PreFlag{d.flags, probe})) return;
   __syncthreads();
   const double DL = block_sum(e.dl, lds.red);
   put_partial(d.part, SL_DELTA, DL);
 }
 
 // Kv ------------------------------------------------------------------------------------------
+// VEC = 2: one double2 per lane (large n); VEC = 1: one double per lane (keeps more workgroups busy at mid-size n)
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_kv(Dev d, int i, int probe) {
   __shared__ double sred[8];
-  if (!probe && d.flags[F_DONE]) return;
-  double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
-  double alpha, beta;
-  if (probe) { alpha = 0.0; beta = 0.0; }
-  else {
-    const double gamma = partial_sum(d.part + (SL_GAMMA0 + (i & 1)) * kGrid, sred);
-    const double delta = partial_sum(d.part + SL_DELTA * kGrid, sred);
-    if (i == 0) { beta = 0.0; alpha = gamma / delta; }
-    else { beta = gamma / gam[i - 1]; alpha = gamma / (delta - beta * gamma / alp[i - 1]); }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { gam[i] = gamma; alp[i] = alpha; }
-  }
-  const bool first = (i == 0) && !probe;
-  double g = 0, rn = 0;
-  const int n2 = d.n >> 1;
+  const int nv = d.n / VEC;                                       // vector elements (tail handled by workgroup 0)
   const int stride = gridDim.x * kBlock;
-  double2 *p2 = reinterpret_cast<double2 *>(d.p), *s2 = reinterpret_cast<double2 *>(d.s), *x2 = reinterpret_cast<double2 *>(d.xs),
-          *r2 = reinterpret_cast<double2 *>(d.r), *u2 = reinterpret_cast<double2 *>(d.uu);
-  const double2 *w2 = reinterpret_cast<const double2 *>(d.w), *m2 = reinterpret_cast<const double2 *>(d.Minv);
-  for (int j = blockIdx.x * kBlock + threadIdx.x; j < n2; j += stride) {
-    double2 u = u2[j], w = w2[j], x = x2[j], r = r2[j], mi = m2[j], p, s;
-    if (first) { p = u; s = w; }
-    else { p = p2[j]; s = s2[j]; p.x = u.x + beta * p.x; p.y = u.y + beta * p.y; s.x = w.x + beta * s.x; s.y = w.y + beta * s.y; }
-    x.x += alpha * p.x; x.y += alpha * p.y;
-    r.x -= alpha * s.x; r.y -= alpha * s.y;
-    u.x = mi.x * r.x; u.y = mi.y * r.y;
+  const int j0 = blockIdx.x * kBlock + threadIdx.x;
+  if (blockIdx.x * kBlock >= nv && blockIdx.x != 0) return;        // idle workgroup
+  const bool first = (i == 0) && !probe;
+  typedef typename std::conditional<VEC == 2, double2, double>::type V;
+  V *p2 = reinterpret_cast<V *>(d.p), *s2 = reinterpret_cast<V *>(d.s), *x2 = reinterpret_cast<V *>(d.xs), *r2 = reinterpret_cast<V *>(d.r),
+    *u2 = reinterpret_cast<V *>(d.uu);
+  const V *w2 = reinterpret_cast<const V *>(d.w), *m2 = reinterpret_cast<const V *>(d.Minv);
+  // issue this lane's first element loads, then fold the partials while they are in flight
+  const bool have = j0 < nv;
+  V u, w, x, r, mi, p, s;
+  if (have) { u = u2[j0]; w = w2[j0]; x = x2[j0]; r = r2[j0]; mi = m2[j0]; if (!first) { p = p2[j0]; s = s2[j0]; } }
+  double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
+  double alpha = 0.0, beta = 0.0;
+  if (probe != 1) {
+    const int done = d.flags[F_DONE];
+    const PartRegs pg = partial_load(d.part + (SL_GAMMA0 + (i & 1)) * kGrid), pd = partial_load(d.part + SL_DELTA * kGrid);
+    double gamma = partial_fold_sum(pg), delta = partial_fold_sum(pd);
+    block_sum2(gamma, delta, sred);
+    if (probe) { if (gamma == -1.2345e300) d.res[R_COUNT - 1] = delta; }   // probe == 2: pay for the reduction, ignore it
+    else {
+      if (done) return;
+      if (i == 0) { beta = 0.0; alpha = gamma / delta; }
+      else { beta = gamma / gam[i - 1]; alpha = gamma / (delta - beta * gamma / alp[i - 1]); }
+      if (blockIdx.x == 0 && threadIdx.x == 0) { gam[i] = gamma; alp[i] = alpha; }
+    }
+  }
+  double g = 0, rn = 0;
+  auto upd = [&](double &uu_, double ww_, double &xx_, double &rr_, double mm_, double &pp_, double &ss_) {
+    if (first) { pp_ = uu_; ss_ = ww_; } else { pp_ = uu_ + beta * pp_; ss_ = ww_ + beta * ss_; }
+    xx_ += alpha * pp_; rr_ -= alpha * ss_; uu_ = mm_ * rr_;
+    g += rr_ * uu_; rn = nanmax(rn, fabs(rr_));
+  };
+  for (int j = j0; j < nv; j += stride) {
+    if (j != j0) { u = u2[j]; w = w2[j]; x = x2[j]; r = r2[j]; mi = m2[j]; if (!first) { p = p2[j]; s = s2[j]; } }
+    if constexpr (VEC == 2) { upd(u.x, w.x, x.x, r.x, mi.x, p.x, s.x); upd(u.y, w.y, x.y, r.y, mi.y, p.y, s.y); }
+    else upd(u, w, x, r, mi, p, s);
     p2[j] = p; s2[j] = s; x2[j] = x; r2[j] = r; u2[j] = u;
-    g += r.x * u.x + r.y * u.y;
-    rn = nanmax(nanmax(rn, fabs(r.x)), fabs(r.y));
   }
-  if ((d.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {      // odd tail element
+  if (VEC == 2 && (d.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {      // odd tail element
     const int j = d.n - 1;
-    double p = first ? d.uu[j] : d.uu[j] + beta * d.p[j], s = first ? d.w[j] : d.w[j] + beta * d.s[j];
-    d.p[j] = p; d.s[j] = s; d.xs[j] += alpha * p;
-    const double r = d.r[j] - alpha * s, u = d.Minv[j] * r;
-    d.r[j] = r; d.uu[j] = u;
-    g += r * u; rn = nanmax(rn, fabs(r));
+    double uu_ = d.uu[j], xx_ = d.xs[j], rr_ = d.r[j], pp_ = first ? 0.0 : d.p[j], ss_ = first ? 0.0 : d.s[j];
+    upd(uu_, d.w[j], xx_, rr_, d.Minv[j], pp_, ss_);
+    d.uu[j] = uu_; d.xs[j] = xx_; d.r[j] = rr_; d.p[j] = pp_; d.s[j] = ss_;
   }
-  const double G = block_sum(g, sred), RN = block_max(rn, sred);
-  if (!probe) { put_partial(d.part, SL_GAMMA0 + ((i + 1) & 1), G); put_partial(d.part, SL_RN0 + ((i + 1) & 1), RN); }
+  block_sum_max(g, rn, sred);
+  if (!probe) { put_partial(d.part, SL_GAMMA0 + ((i + 1) & 1), g); put_partial(d.part, SL_RN0 + ((i + 1) & 1), rn); }
 }
 
 // KA ------------------------------------------------------------------------------------------
 struct EKa {
   const double *l, *u, *rho, *rho_inv; double *z, *y, *zt, *t0, *v, *dy; double alpha;
+  double pl = 0, pu = 0, prho = 0, prinv = 0, pz = 0, py = 0;
+  __device__ __forceinline__ void prefetch(int i) { pl = l[i]; pu = u[i]; prho = rho[i]; prinv = rho_inv[i]; pz = z[i]; py = y[i]; }
   __device__ __forceinline__ void operator()(int i, const double (&s)[1]) {
-    const double ztil = s[0], rh = rho[i], yi = y[i];
-    const double zr = alpha * ztil + (1.0 - alpha) * z[i];                 // _osqp.py:686-690
-    const double zn = fmin(fmax(zr + rho_inv[i] * yi, l[i]), u[i]);          // :674
-    const double dyi = rh * (zr - zn), yn = yi + dyi;                        // :698-703
-    y[i] = yn; dy[i] = dyi; z[i] = zn; zt[i] = ztil; v[i] = rh * zn - yn; t0[i] = rh * ztil;
+    const double ztil = s[0];
+    const double zr = alpha * ztil + (1.0 - alpha) * pz;                    // _osqp.py:686-690
+    const double zn = fmin(fmax(zr + prinv * py, pl), pu);                   // :674
+    const double dyi = prho * (zr - zn), yn = py + dyi;                      // :698-703
+    y[i] = yn; dy[i] = dyi; z[i] = zn; zt[i] = ztil; v[i] = prho * zn - yn; t0[i] = prho * ztil;
   }
 };
 __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
@@ -298,7 +383,7 @@ __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
 }
 
 // ---------------------------------------------------------------------------------------------- residual kernels
-struct EKr1 {
+struct EKr1 : NoPrefetch {
   const double *z, *y, *dy, *l, *u, *E, *Einv;
   double pu = 0, au = 0, zu = 0, ps = 0, as = 0, zs = 0, du = 0, ds = 0, lhs = 0, sup = 0;
   __device__ __forceinline__ void operator()(int i, const double (&s)[1]) {
@@ -314,7 +399,7 @@ struct EKr1 {
 __global__ __launch_bounds__(kBlock) void k_res_m(Dev d) {
   __shared__ StreamLds<1> lds;
   GVec g{d.x};
-  EKr1 e{d.z, d.y, d.dy, d.l, d.u, d.E, d.Einv};
+  EKr1 e{{}, d.z, d.y, d.dy, d.l, d.u, d.E, d.Einv};
   process_rows<1>(d.A, g, e, lds);
   __syncthreads();
   double *red = lds.red;
@@ -331,7 +416,7 @@ struct GTwo {        // P part -> sum 0 (with pn), A' part -> sum 1 (with pm)
     if (c < n) { pr[0] = a * pn[c]; pr[1] = 0.0; } else { pr[0] = 0.0; pr[1] = a * pm[c - n]; }
   }
 };
-struct EKr2 {
+struct EKr2 : NoPrefetch {
   const double *x, *q, *dx, *D, *Dinv; double sigma;
   double du = 0, pu = 0, au = 0, ds = 0, ps = 0, as = 0, xu = 0, xs = 0, xpx = 0, qx = 0, qdx = 0;
   __device__ __forceinline__ void operator()(int j, const double (&s)[2]) {
@@ -345,7 +430,7 @@ struct EKr2 {
 __global__ __launch_bounds__(kBlock) void k_res_n(Dev d) {
   __shared__ StreamLds<2> lds;
   GTwo g{d.x, d.y, d.n};
-  EKr2 e{d.x, d.q, d.dx, d.D, d.Dinv, d.sigma};
+  EKr2 e{{}, d.x, d.q, d.dx, d.D, d.Dinv, d.sigma};
   process_rows<2>(d.B, g, e, lds);
   __syncthreads();
   double *red = lds.red;
@@ -372,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void k_res_final(Dev d, int q0) {
 // second-stage infeasibility tests (rare) -------------------------------------------------------
 struct GAtOnly { const double *pm; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = c >= n ? a * pm[c - n] : 0.0; } };
 struct GPOnly { const double *pn; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = c < n ? a * pn[c] : 0.0; } };
-struct EAbs2 {
+struct EAbs2 : NoPrefetch {
   const double *scale, *sub; double sigma; double mu = 0, ms = 0;
   __device__ __forceinline__ void operator()(int j, const double (&s)[1]) {
     const double v = s[0] - (sub ? sigma * sub[j] : 0.0);
@@ -382,7 +467,7 @@ struct EAbs2 {
 __global__ __launch_bounds__(kBlock) void k_inf_primal(Dev d) {            // || Dinv A' dy ||_inf  (_osqp.py:815-818)
   __shared__ StreamLds<1> lds;
   GAtOnly g{d.dy, d.n};
-  EAbs2 e{d.Dinv, nullptr, 0.0};
+  EAbs2 e{{}, d.Dinv, nullptr, 0.0};
   process_rows<1>(d.B, g, e, lds);
   __syncthreads();
   put_partial(d.part, SL_RES0 + R_ATDY_U, block_max(e.mu, lds.red)); put_partial(d.part, SL_RES0 + R_ATDY_S, block_max(e.ms, lds.red));
@@ -390,12 +475,12 @@ __global__ __launch_bounds__(kBlock) void k_inf_primal(Dev d) {            // ||
 __global__ __launch_bounds__(kBlock) void k_inf_dual_p(Dev d) {            // || Dinv P dx ||_inf   (_osqp.py:846-853)
   __shared__ StreamLds<1> lds;
   GPOnly g{d.dx, d.n};
-  EAbs2 e{d.Dinv, d.dx, d.sigma};
+  EAbs2 e{{}, d.Dinv, d.dx, d.sigma};
   process_rows<1>(d.B, g, e, lds);
   __syncthreads();
   put_partial(d.part, SL_RES0 + R_PDX_U, block_max(e.mu, lds.red)); put_partial(d.part, SL_RES0 + R_PDX_S, block_max(e.ms, lds.red));
 }
-struct EViol {
+struct EViol : NoPrefetch {
   const double *l, *u, *Einv; double thr; int unscaled; double viol = 0;
   __device__ __forceinline__ void operator()(int i, const double (&s)[1]) {    // _osqp.py:861-872
     const double a = unscaled ? Einv[i] * s[0] : s[0];
@@ -405,7 +490,7 @@ struct EViol {
 __global__ __launch_bounds__(kBlock) void k_inf_dual_a(Dev d, double thr, int unscaled) {
   __shared__ StreamLds<1> lds;
   GVec g{d.dx};
-  EViol e{d.l, d.u, d.Einv, thr, unscaled};
+  EViol e{{}, d.l, d.u, d.Einv, thr, unscaled};
   process_rows<1>(d.A, g, e, lds);
   __syncthreads();
   put_partial(d.part, SL_RES0 + R_ADX_VIOL, block_sum(e.viol, lds.red));
@@ -422,11 +507,11 @@ __global__ __launch_bounds__(kBlock) void k_set_rho(Dev d, double rho_bar) {
   }
 }
 struct GPrec { const double *rho; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = c >= n ? rho[c - n] * a * a : 0.0; } };
-struct EPrec { const double *Bval; const int *Bdiag; double *Minv; __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { Minv[j] = 1.0 / (Bval[Bdiag[j]] + s[0]); } };
+struct EPrec : NoPrefetch { const double *Bval; const int *Bdiag; double *Minv; __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { Minv[j] = 1.0 / (Bval[Bdiag[j]] + s[0]); } };
 __global__ __launch_bounds__(kBlock) void k_precond(Dev d) {
   __shared__ StreamLds<1> lds;
   GPrec g{d.rho, d.n};
-  EPrec e{d.B.val, d.Bdiag, d.Minv};
+  EPrec e{{}, d.B.val, d.Bdiag, d.Minv};
   process_rows<1>(d.B, g, e, lds);
 }
 __global__ __launch_bounds__(kBlock) void k_fill(double *p, int n, double v) {
@@ -437,7 +522,7 @@ __global__ __launch_bounds__(kBlock) void k_init_n(Dev d) {
   const int stride = gridDim.x * kBlock;
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) { d.xs[j] = d.x[j]; d.dx[j] = 0.0; }
 }
-struct EInit {
+struct EInit : NoPrefetch {
   const double *rho, *y; double *z, *zt, *t0, *v, *dy; int full;
   __device__ __forceinline__ void operator()(int i, const double (&s)[1]) {
     const double a = s[0];
@@ -448,16 +533,16 @@ struct EInit {
 __global__ __launch_bounds__(kBlock) void k_init_m(Dev d, int full) {
   __shared__ StreamLds<1> lds;
   GVec g{d.xs};
-  EInit e{d.rho, d.y, d.z, d.zt, d.t0, d.v, d.dy, full};
+  EInit e{{}, d.rho, d.y, d.z, d.zt, d.t0, d.v, d.dy, full};
   process_rows<1>(d.A, g, e, lds);
 }
 __global__ void k_set_scal(double *scal, double rel, double ab) { scal[S_TOL_REL] = rel; scal[S_TOL_ABS] = ab; }
 
-struct EStore { double *out; __device__ __forceinline__ void operator()(int r, const double (&s)[1]) { out[r] = s[0]; } };
+struct EStore : NoPrefetch { double *out; __device__ __forceinline__ void operator()(int r, const double (&s)[1]) { out[r] = s[0]; } };
 __global__ __launch_bounds__(kBlock) void k_test_spmv(DevCsr M, const double *in, double *out) {
   __shared__ StreamLds<1> lds;
   GVec g{in};
-  EStore e{out};
+  EStore e{{}, out};
   process_rows<1>(M, g, e, lds);
 }
 
@@ -522,7 +607,7 @@ void activate(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); }
 void kb_rhs(Dev &d) { LAUNCH(k_kb, d, d); }
 void k1(Dev &d, int i) { LAUNCH(k_k1, d, d, i, 0); }
 void k2(Dev &d, int) { LAUNCH(k_k2, d, d, 0); }
-void kv(Dev &d, int i) { LAUNCH(k_kv, d, d, i, 0); }
+void kv(Dev &d, int i) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, i, 0); else LAUNCH(k_kv<1>, d, d, i, 0); }
 void ka(Dev &d, int budget) { LAUNCH(k_ka, d, d, budget); }
 
 void residuals(Dev &d) {
@@ -612,10 +697,11 @@ float time_kernel(Dev &d, int which, int reps) {
     switch (which) {
       case 0: LAUNCH(k_k1, d, d, 1, 1); break;
       case 1: LAUNCH(k_k2, d, d, 1); break;
-      case 2: LAUNCH(k_kv, d, d, 1, 1); break;
+      case 2: if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, 1, 1); else LAUNCH(k_kv<1>, d, d, 1, 1); break;
       case 3: LAUNCH(k_kb, d, d); break;
       case 4: LAUNCH(k_ka, d, d, 0); break;
-      default: LAUNCH(k_k1, d, d, 1, 1); LAUNCH(k_k2, d, d, 1); LAUNCH(k_kv, d, d, 1, 1); break;   // one PCG iteration
+      case 5: LAUNCH(k_k1, d, d, 1, 1); LAUNCH(k_k2, d, d, 1); if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, 1, 1); else LAUNCH(k_kv<1>, d, d, 1, 1); break;   // one PCG iteration, no reductions
+      default: LAUNCH(k_k1, d, d, 1, 2); LAUNCH(k_k2, d, d, 1); if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, 1, 2); else LAUNCH(k_kv<1>, d, d, 1, 2); break;   // ... with the reductions (as in a solve)
     }
   };
   for (int w = 0; w < 5; w++) launch();

@@ -79,7 +79,7 @@ void Engine::free_all() {
   be::activate(d_);
   be::sync(d_);
   drop_graphs();
-  void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.rowblk, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.rowblk, d_.B.val, d_.Bdiag,
+  void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag,
                   d_.q, d_.l, d_.u, d_.D, d_.Dinv, d_.E, d_.Einv, d_.rho, d_.rho_inv, d_.ctype, d_.x, d_.z, d_.y, d_.dx,
                   d_.dy, d_.xs, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.part, d_.res,
                   d_.scal, d_.flags};
@@ -299,12 +299,17 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
       for (int k = A_.p[j]; k < A_.p[j + 1]; k++) { int pos = cur[j]++; Bj[pos] = n + A_.i[k]; AmapB_[k] = pos; }
   }
   std::vector<int> rbA = build_row_blocks(Arp, m), rbB = build_row_blocks(Brp, n);
+  auto descs = [](const std::vector<int> &rb, const std::vector<int> &rp) {
+    std::vector<int> d; d.reserve(4 * rb.size());
+    for (size_t b = 0; b + 1 < rb.size(); b++) { d.push_back(rb[b]); d.push_back(rb[b + 1]); d.push_back(rp[rb[b]]); d.push_back(rp[rb[b + 1]]); }
+    return d;
+  };
 
   auto up_i = [&](const std::vector<int> &h) { int *p = dev_vec<int>(d_, h.size()); be::h2d(d_, p, h.data(), sizeof(int) * h.size()); return p; };
   d_.A.nrows = m; d_.A.ncols = n; d_.A.nnz = nzA; d_.A.nblk = (int)rbA.size() - 1;
-  d_.A.rowptr = up_i(Arp); d_.A.col = up_i(Arj); d_.A.rowblk = up_i(rbA); d_.A.val = dev_vec<double>(d_, nzA);
+  d_.A.rowptr = up_i(Arp); d_.A.col = up_i(Arj); d_.A.blkdesc = up_i(descs(rbA, Arp)); d_.A.val = dev_vec<double>(d_, nzA);
   d_.B.nrows = n; d_.B.ncols = n + m; d_.B.nnz = nzB; d_.B.nblk = (int)rbB.size() - 1;
-  d_.B.rowptr = up_i(Brp); d_.B.col = up_i(Bj); d_.B.rowblk = up_i(rbB); d_.B.val = dev_vec<double>(d_, nzB);
+  d_.B.rowptr = up_i(Brp); d_.B.col = up_i(Bj); d_.B.blkdesc = up_i(descs(rbB, Brp)); d_.B.val = dev_vec<double>(d_, nzB);
   d_.Bdiag = up_i(bdiag);
   Aval_.assign(nzA, 0.0); Bval_.assign(nzB, 0.0);
   fill_matrix_values(Px, Ax);
@@ -461,7 +466,9 @@ int Engine::solve() {
     else be::set_pcg_tol(d_, 1.0 / settings.cg_tol_reduction, kCgTolAbsMin);             // dual-feasible start (e.g. q = 0): relative
     eps_cg_prev_ = std::numeric_limits<double>::infinity();
   }
-  if (cg_budget_ <= 0) cg_budget_ = std::min(settings.cg_max_iter, 5);
+  // start with the full budget: a starved PCG in the first chunks costs far more ADMM iterations than the no-op
+  // launches it saves (measured: 1150 -> 825 ADMM iterations on the banded n=20000 QP); it shrinks after the first check
+  if (cg_budget_ <= 0) cg_budget_ = settings.cg_max_iter;
   cg_budget_ = std::min(cg_budget_, std::min(settings.cg_max_iter, kMaxCg));
   if (settings.verbose) std::printf("iter   objective    prim res   dual res   rho        cg   time\n");
 
@@ -669,7 +676,7 @@ int Engine::get_stats(OSQPHipStats *out) { if (!out) return OSQP_DATA_VALIDATION
 int Engine::time_kernel(int which, int reps, double *ms) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);
-  if (which < 0 || which > 5 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
+  if (which < 0 || which > 6 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
   *ms = be::time_kernel(d_, which, reps);
   return OSQP_NO_ERROR;
 }

@@ -1,0 +1,52 @@
+"""Multi-GPU execution of a batch of independent QPs (BASELINE north_star: "a batch of independent QPs shards
+one-problem-per-GPU ... with only a final RCCL status/objective gather over xGMI").
+
+There is no reference analogue with more than one process; the closest semantics are the reference's thread pools over
+independent solver objects (/root/reference/src/osqp/nn/torch.py:200-224, src/osqp/tests/multithread_test.py:44-53): every
+problem is solved on its own, results are collected per problem.  Here: problem i of B goes to rank  i*world // B
+(contiguous blocks), each rank drives its own GPU (OSQPSettings.device = LOCAL_RANK) with no data-path collective, and ONE
+all_gather of a packed record per problem ends the job (torch.distributed backend "nccl" = RCCL on ROCm, "gloo" on CPU).
+"""
+import numpy as np
+
+RECORD_FIELDS = ('index', 'status_val', 'iter', 'obj_val', 'prim_res', 'dual_res', 'solve_time')
+
+
+def shard_range(nproblems, rank, world):
+    """Contiguous block [lo, hi) of problem indices owned by `rank`."""
+    return (nproblems * rank) // world, (nproblems * (rank + 1)) // world
+
+
+def solve_local(problems_iter, make_solver, rank=0, world=1, nproblems=None):
+    """Solve this rank's share.  problems_iter(i) -> (P, q, A, l, u); make_solver() -> an un-setup osqp_amd.OSQP.
+    Same-structure consecutive problems re-use one solver through update(), like nn/torch.py:136-140."""
+    lo, hi = shard_range(nproblems, rank, world)
+    recs = np.zeros((hi - lo, len(RECORD_FIELDS)))
+    xs = []
+    for k, i in enumerate(range(lo, hi)):
+        P, q, A, l, u = problems_iter(i)
+        solver = make_solver()
+        solver.setup(P, q, A, l, u)
+        r = solver.solve()
+        recs[k] = (i, r.info.status_val, r.info.iter, r.info.obj_val, r.info.prim_res, r.info.dual_res, r.info.solve_time)
+        xs.append(r.x)
+    return recs, xs
+
+
+def gather_records(recs, nproblems, device=None):
+    """all_gather of the per-problem records; every rank returns the full (nproblems x fields) table ordered by index.
+    Ranks may own different counts (B not divisible by world): records are padded to the largest share."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return recs[np.argsort(recs[:, 0])]
+    world = dist.get_world_size()
+    share = max(shard_range(nproblems, r, world)[1] - shard_range(nproblems, r, world)[0] for r in range(world))
+    pad = np.full((share, recs.shape[1]), -1.0)
+    pad[:len(recs)] = recs
+    t = torch.as_tensor(pad, dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    table = torch.cat(out).cpu().numpy()
+    table = table[table[:, 0] >= 0]
+    return table[np.argsort(table[:, 0])]
