@@ -269,7 +269,7 @@ struct PreK1 {
 };
 __global__ __launch_bounds__(kBlock) void k_k1(Dev d, int i, int probe) {
   __shared__ StreamLds<1> lds;
-  if (blockIdx.x >= d.A.nblk && blockIdx.x != 0) return;     // nothing to do and not the flag owner
+  if ((int)blockIdx.x >= d.A.nblk && blockIdx.x != 0) return;     // nothing to do and not the flag owner
   GVec g{d.uu};
   EK1 e{d.rho, d.t};
   process_rows<1>(d.A, g, e, lds, PreK1{d, i, probe, lds.red});
@@ -304,7 +304,10 @@ __global__ __launch_bounds__(kBlock) void k_kv(Dev d, int i, int probe) {
   const int nv = d.n / VEC;                                       // vector elements (tail handled by workgroup 0)
   const int stride = gridDim.x * kBlock;
   const int j0 = blockIdx.x * kBlock + threadIdx.x;
-  if (blockIdx.x * kBlock >= nv && blockIdx.x != 0) return;        // idle workgroup
+  if ((int)(blockIdx.x * kBlock) >= nv && blockIdx.x != 0) {       // idle workgroup: its partial slots must still read 0
+    if (!probe) { put_partial(d.part, SL_GAMMA0 + ((i + 1) & 1), 0.0); put_partial(d.part, SL_RN0 + ((i + 1) & 1), 0.0); }
+    return;
+  }
   const bool first = (i == 0) && !probe;
   typedef typename std::conditional<VEC == 2, double2, double>::type V;
   V *p2 = reinterpret_cast<V *>(d.p), *s2 = reinterpret_cast<V *>(d.s), *x2 = reinterpret_cast<V *>(d.xs), *r2 = reinterpret_cast<V *>(d.r),
