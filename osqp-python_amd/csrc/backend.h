@@ -22,7 +22,7 @@ namespace osqp_hip {
 
 constexpr int kBlock = 256;        // threads per workgroup (4 wave64)
 constexpr int kGrid = 1024;        // workgroups per launch = number of partial-reduction slots
-constexpr int kChunk = 1024;       // nnz staged through LDS per row-block (4 per thread)
+constexpr int kChunk = 2048;       // nnz staged through LDS per row-block (8 per thread, all loads in flight at once)
 constexpr int kLongRow = 128;      // rows with more nnz get a workgroup of their own (block-wide reduction)
 constexpr int kMaxRowsPerBlock = 1024;
 constexpr int kMaxCg = 1024;       // hard cap on the PCG budget (size of the alpha/gamma history)

@@ -127,8 +127,8 @@ __device__ __forceinline__ void put_partial(double *part, int slot, double v) {
 //   Pre: bool pre()     block-uniform hook run ONCE, after the first row block's streaming loads have been issued (so
 //                       whatever it waits for -- a reduction of partials, a flag -- overlaps those loads); returning
 //                       false abandons the kernel for this workgroup.
-template <int NS>
-struct StreamLds { double prod[2][NS][kChunk]; double red[8]; };
+template <int NS, int NBUF = (NS == 1 ? 2 : 1)>
+struct StreamLds { static constexpr int kBuf = NBUF; double prod[NBUF][NS][kChunk]; double red[8]; };
 struct NoPre { __device__ __forceinline__ bool operator()() const { return true; } };
 
 template <int NS, class G, class E, class Pre>
@@ -199,7 +199,8 @@ __device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, 
         }
         e.prefetch(r); e(r, acc);
       }
-      buf ^= 1;   // the next row block fills the other buffer, so one barrier per block suffices
+      if (StreamLds<NS>::kBuf == 2) buf ^= 1;   // the next row block fills the other buffer: one barrier per block suffices
+      else __syncthreads();                      // single buffer (two-sum kernels): protect it before the next fill
     }
   }
   if (first) return pre();   // a workgroup without rows still runs the hook (e.g. workgroup 0 owns the PCG flags)

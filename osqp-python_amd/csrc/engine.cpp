@@ -371,27 +371,31 @@ void Engine::set_status(int st) {
 // One chunk = `niter` ADMM iterations, each  KB, budget x (K1,K2,Kv), KA  -- enqueued eagerly or replayed from a
 // hipGraph captured once per (niter, budget).
 void Engine::run_chunk(int niter, int budget) {
-  auto enqueue = [&]() {
-    for (int it = 0; it < niter; it++) {
+  auto enqueue = [&](int count) {
+    for (int it = 0; it < count; it++) {
       be::kb_rhs(d_);
       for (int i = 0; i < budget; i++) { be::k1(d_, i); be::k2(d_, i); be::kv(d_, i); }
       be::ka(d_, budget);
     }
   };
   stats_.kernel_launches += (double)niter * (2 + 3 * budget);
-  if (use_graph_ && be::graphs_supported()) {
-    auto key = std::make_pair(niter, budget);
+  if (!(use_graph_ && be::graphs_supported())) { enqueue(niter); return; }
+  // one executable graph per (ADMM iterations, PCG budget); graphs are kept below kMaxGraphNodes kernel nodes (a
+  // check_termination = 0 solve would otherwise capture max_iter * (2 + 3*budget) nodes in one graph)
+  constexpr int kMaxGraphNodes = 8192;
+  const int per = std::max(1, kMaxGraphNodes / (2 + 3 * budget));
+  for (int left = niter; left > 0;) {
+    const int cnt = std::min(left, per);
+    auto key = std::make_pair(cnt, budget);
     auto it = graphs_.find(key);
     if (it == graphs_.end()) {
       be::graph_begin(d_);
-      enqueue();
-      void *g = be::graph_end(d_);
-      it = graphs_.emplace(key, g).first;
+      enqueue(cnt);
+      it = graphs_.emplace(key, be::graph_end(d_)).first;
     }
     be::graph_launch(d_, it->second);
     stats_.graph_launches += 1;
-  } else {
-    enqueue();
+    left -= cnt;
   }
 }
 
@@ -495,8 +499,8 @@ int Engine::solve() {
     info.dual_obj_val = (-0.5 * res[R_XPX] - res[R_SUPP]) * (settings.scaling ? cinv_ : 1.0);
     info.duality_gap = info.obj_val - info.dual_obj_val;
     if (settings.verbose)
-      std::printf("%4d  %11.4e   %8.2e   %8.2e   %8.2e  %3d  %8.2es\n", iter, info.obj_val, info.prim_res, info.dual_res, rho_bar_,
-                  flags[F_STAT_MAX], now_s() - t0);
+      std::printf("%4d  %11.4e   %8.2e   %8.2e   %8.2e  %3d  %8.2es   (rho est %.2e, scaled res %.2e / %.2e)\n", iter, info.obj_val, info.prim_res,
+                  info.dual_res, rho_bar_, flags[F_STAT_MAX], now_s() - t0, rho_estimate(res), res[R_PRI_S], res[R_DUA_S]);
     const bool do_check = (ct > 0 && iter % ct == 0) || iter == settings.max_iter;
     if (do_check && check_termination(res, false)) break;
     if (iter >= settings.max_iter) {                                                     // :1264-1266
