@@ -192,6 +192,10 @@ OSQPInt osqp_hip_time_kernel(OSQPSolver *solver, OSQPInt which, OSQPInt reps, do
 
 /* Test hooks (used by tests/ only): y = A x, y = B [xn; xm] on the device with the scaled matrices. */
 OSQPInt osqp_hip_test_spmv(OSQPSolver *solver, OSQPInt which, const OSQPFloat *in, OSQPFloat *out);
+/* Weight of equality rows relative to inequality rows, rho_eq = factor * rho, used when equality and inequality rows are
+   mixed (default 10; the reference's 1e3 is kept when every active row is an equality).  See engine.cpp
+   classify_constraints() for the rationale.  Takes effect immediately (rho vector + preconditioner are rebuilt). */
+OSQPInt osqp_hip_set_rho_eq_factor(OSQPSolver *solver, OSQPFloat factor);
 /* copy out internal scaling D (n), E (m), c */
 OSQPInt osqp_hip_get_scaling(OSQPSolver *solver, OSQPFloat *D, OSQPFloat *E, OSQPFloat *c);
 /* name of the compute backend compiled into this library: "hip-gfx950" for the product */

@@ -49,6 +49,7 @@ enum ScalId { S_TOL_REL = 0, S_TOL_ABS, S_HIST = 8 /* gamma[kMaxCg+1], then alph
 struct Dev {
   int n = 0, m = 0, device = 0;
   double sigma = 0, alpha = 0;
+  double rho_eq_factor = 1e3;    // rho_i = rho_eq_factor * rho_bar on equality rows (_osqp.py:27 uses 1e3; see engine.cpp)
   DevCsr A, B;
   int *Bdiag = nullptr;          // position of the diagonal entry of row j inside B.val
   // problem data (scaled) and scaling

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(kBlock) void k_set_rho(Dev d, double rho_bar) {
   const int stride = gridDim.x * kBlock;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += stride) {
     const int t = d.ctype[i];
-    const double r = t == -1 ? 1e-6 : (t == 1 ? 1e3 * rho_bar : rho_bar);     // _osqp.py:520-522, :1590-1594
+    const double r = t == -1 ? 1e-6 : (t == 1 ? d.rho_eq_factor * rho_bar : rho_bar);     // _osqp.py:520-522, :1590-1594
     d.rho[i] = r; d.rho_inv[i] = 1.0 / r;
     d.v[i] = r * d.z[i] - d.y[i]; d.t0[i] = r * d.zt[i];
   }

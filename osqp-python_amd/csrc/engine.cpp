@@ -66,6 +66,7 @@ Engine::Engine() {
   pub.settings = &settings; pub.solution = &solution; pub.info = &info; pub.work = reinterpret_cast<OSQPWorkspace *>(this);
   const char *g = std::getenv("OSQP_HIP_GRAPH");
   use_graph_ = !(g && g[0] == '0');
+  if (const char *f = std::getenv("OSQP_HIP_RHO_EQ_FACTOR")) { double v = std::atof(f); if (v >= 1.0) eq_factor_mixed_ = v; }
 }
 Engine::~Engine() { free_all(); }
 
@@ -164,9 +165,21 @@ void Engine::scale_matrix_values(std::vector<double> &Px, std::vector<double> &A
   }
 }
 
-// constraint classes, _osqp.py:505-518 (on the SCALED bounds, as the reference does)
+// constraint classes, _osqp.py:505-518 (on the SCALED bounds, as the reference does).
+//
+// Weight of equality rows.  The reference sets rho_i = 1e3 * rho_bar on equality rows (RHO_EQ_OVER_RHO_INEQ,
+// _osqp.py:27,521) -- free for a direct KKT solve, but for the reduced-KKT PCG it puts weights 1 and 1000 side by side in
+// K = P + sigma I + A' diag(rho) A: the Jacobi-preconditioned condition number becomes ~1e3 (measured: 35 CG iterations
+// per decade on the banded QPs), the capped PCG stops converging and ADMM itself slows down (config 2: 1275 ADMM
+// iterations with the cap binding in every iteration vs 575 for the direct path).  Measured on the simulator with the
+// factor as the only change (DESIGN.md "Equality weight"): 10 instead of 1e3 gives the same ADMM iteration counts on
+// every MIXED problem tried and 2-11x fewer PCG iterations; when ALL active rows are equalities the ratio cannot
+// affect the conditioning, and the large value is what makes ADMM fast (feasibility_test.py: 475 vs 4250 iterations).
+// Hence: 1e3 (the reference's value) if no inequality row is active, eq_factor_mixed_ (10) otherwise.  The ADMM fixed
+// point, i.e. the solution, does not depend on it.  osqp_hip_set_rho_eq_factor() / OSQP_HIP_RHO_EQ_FACTOR override it.
 void Engine::classify_constraints(const std::vector<double> &ls, const std::vector<double> &us) {
   ctype_.resize(m);
+  int n_ineq = 0;
   for (int i = 0; i < m; i++) {
     int t;
     if (ls[i] < -OSQP_INFTY * kMinScaling && us[i] > OSQP_INFTY * kMinScaling) t = -1;
@@ -174,7 +187,20 @@ void Engine::classify_constraints(const std::vector<double> &ls, const std::vect
     else t = 0;
     if (!settings.rho_is_vec) t = 0;
     ctype_[i] = t;
+    n_ineq += (t == 0);
   }
+  d_.rho_eq_factor = (n_ineq == 0) ? 1e3 : eq_factor_mixed_;
+}
+
+int Engine::set_rho_eq_factor(double f) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (!(f >= 1.0)) return OSQP_SETTINGS_VALIDATION_ERROR;
+  be::activate(d_);
+  eq_factor_mixed_ = f;
+  upload_bounds_and_types();
+  be::set_rho(d_, rho_bar_);
+  be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  return OSQP_NO_ERROR;
 }
 
 void Engine::upload_bounds_and_types() {

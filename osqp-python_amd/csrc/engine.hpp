@@ -37,6 +37,7 @@ class Engine {
   int time_kernel(int which, int reps, double *ms);
   int test_spmv(int which, const double *in, double *out);
   int get_scaling(double *D, double *E, double *c);
+  int set_rho_eq_factor(double f);
 
   OSQPSolver pub{};          // what the caller holds
   OSQPSettings settings{};
@@ -62,6 +63,7 @@ class Engine {
   bool dev_ready_ = false;
   // ---- driver state ----
   double rho_bar_ = 0.1;
+  double eq_factor_mixed_ = 10.0;     // see classify_constraints()
   int cg_budget_ = 0;
   double eps_cg_prev_ = 0;
   bool first_run_ = true;

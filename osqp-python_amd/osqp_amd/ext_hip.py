@@ -230,6 +230,9 @@ class OSQPSolver:
         self._lib.osqp_hip_test_spmv(self._p, int(which), _ptr(vec, _lib.c_double_p), _ptr(out, _lib.c_double_p))
         return out
 
+    def hip_set_rho_eq_factor(self, factor):
+        return self._lib.osqp_hip_set_rho_eq_factor(self._p, float(factor))
+
     def hip_scaling(self):
         D, E, c = np.empty(self.n), np.empty(self.m), C.c_double()
         self._lib.osqp_hip_get_scaling(self._p, _ptr(D, _lib.c_double_p), _ptr(E, _lib.c_double_p), C.byref(c))

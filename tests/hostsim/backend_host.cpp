@@ -178,7 +178,7 @@ void fetch_flags(Dev &d, int *h) {
 
 void set_rho(Dev &d, double rb) {
   for (int i = 0; i < d.m; i++) {
-    double r = d.ctype[i] == -1 ? 1e-6 : (d.ctype[i] == 1 ? 1e3 * rb : rb);
+    double r = d.ctype[i] == -1 ? 1e-6 : (d.ctype[i] == 1 ? d.rho_eq_factor * rb : rb);
     d.rho[i] = r; d.rho_inv[i] = 1.0 / r;
     d.v[i] = r * d.z[i] - d.y[i]; d.t0[i] = r * d.zt[i];
   }
