@@ -136,7 +136,7 @@ def main():
             ms = s.hip_time_kernel(which, args.probe_reps)
             probes[name] = {'ms': ms, 'bytes': kb[name], 'GBps': kb[name] / (ms * 1e-3) / 1e9}
         dom = 'K2 spmv B (w=B[u;t], <w,u>)'
-        pcg_bytes = sum(kb[k] for k in list(kb)[:3]); pcg_ms = s.hip_time_kernel(5, args.probe_reps)   # K1,K2,Kv alternating
+        pcg_bytes = sum(kb[k] for k in list(kb)[:3]); pcg_ms = s.hip_time_kernel(6, args.probe_reps)   # K1,K2,Kv alternating, reductions included (as in a solve)
         out = {
             'metric': 'ADMM iterations/sec, n=%d m=%d nnz(A)=%d sparse QP (indirect PCG)' % (n, mm, A.nnz),
             'value': total_iters / tmax, 'unit': 'ADMM iter/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

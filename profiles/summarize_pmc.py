@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Aggregate a rocprofv3 --pmc counter_collection CSV per kernel: mean counter value per dispatch, split into 'active'
+dispatches and early-exit (no-op) ones by a duration-free criterion (counter value above 1% of the kernel's max)."""
+import csv
+import collections
+import sys
+
+path, out = sys.argv[1], sys.argv[2]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+with open(path) as f:
+    for row in csv.DictReader(f):
+        name = row.get('Kernel_Name') or row.get('Kernel Name') or ''
+        name = name.split('(')[0].split('::')[-1]
+        agg[name][row['Counter_Name']].append(float(row['Counter_Value']))
+with open(out, 'w') as g:
+    g.write('kernel,counter,dispatches,mean_all,active_dispatches,mean_active,max\n')
+    for k in sorted(agg):
+        for c, v in agg[k].items():
+            mx = max(v)
+            act = [x for x in v if x > 0.01 * mx] if mx > 0 else []
+            g.write('%s,%s,%d,%.6g,%d,%.6g,%.6g\n' % (k, c, len(v), sum(v) / len(v), len(act), (sum(act) / len(act)) if act else 0.0, mx))
+print(open(out).read())
