@@ -131,12 +131,25 @@ template <int NS, int NBUF = (NS == 1 ? 2 : 1)>
 struct StreamLds { static constexpr int kBuf = NBUF; double prod[NBUF][NS][kChunk]; double red[8]; };
 struct NoPre { __device__ __forceinline__ bool operator()() const { return true; } };
 
+__device__ __forceinline__ bool wg_has_rows(const DevCsr &M) {      // same mapping as process_rows
+  const int per = (M.nblk + 7) >> 3;
+  const int sl = blockIdx.x >> 3;
+  return sl < per && (int)(blockIdx.x & 7) * per + sl < M.nblk;
+}
 template <int NS, class G, class E, class Pre>
 __device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds, Pre pre) {
   int buf = 0;
   bool first = true;
   const int4 *desc = reinterpret_cast<const int4 *>(M.blkdesc);
-  for (int b = blockIdx.x; b < M.nblk; b += gridDim.x) {
+  // XCD-contiguous mapping (speed only; correctness never depends on placement): workgroup id b is observed to run on
+  // XCD b % 8, so XCD x is given the contiguous row-block range [x*per, (x+1)*per).  Neighbouring row blocks gather
+  // overlapping windows of the input vector; on one XCD they share those lines in one L2 instead of every XCD's L2
+  // fetching (nearly) the whole vector.
+  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int per = (M.nblk + 7) >> 3;
+  for (int sl = slot0; sl < per; sl += slots) {
+    const int b = xcd * per + sl;
+    if (b >= M.nblk) break;
     const int4 ds = desc[b];
     const int r0 = ds.x, r1 = ds.y, k0 = ds.z, k1 = ds.w;
     const int cnt = k1 - k0;
@@ -254,12 +267,11 @@ struct PreK1 {
   const Dev &d; int i, probe; double *red;
   __device__ __forceinline__ bool operator()() const {
     if (probe == 1) return true;
-    const int done = d.flags[F_DONE];
+    if (!probe && d.flags[F_DONE]) return false;          // already converged: leave before paying for the reduction
     const PartRegs prn = partial_load(d.part + (SL_RN0 + (i & 1)) * kGrid), pbn = partial_load(d.part + SL_BN * kGrid);
     double rn = partial_fold_max(prn), bn = partial_fold_max(pbn);
     block_max2(rn, bn, red);
     if (probe) { if (rn < -1.0) d.res[R_COUNT - 1] = bn; return true; }     // probe == 2: pay for the test, ignore it
-    if (done) return false;
     const double tol = fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS]);
     if (!(rn > tol)) {            // converged (a NaN residual also stops the inner loop; the ADMM residuals will flag it)
       if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = i; }
@@ -270,7 +282,8 @@ struct PreK1 {
 };
 __global__ __launch_bounds__(kBlock) void k_k1(Dev d, int i, int probe) {
   __shared__ StreamLds<1> lds;
-  if ((int)blockIdx.x >= d.A.nblk && blockIdx.x != 0) return;     // nothing to do and not the flag owner
+  if (!wg_has_rows(d.A) && blockIdx.x != 0) return;               // nothing to do and not the flag owner
+  if (!probe && d.flags[F_DONE]) return;                          // PCG already converged: cheapest possible exit
   GVec g{d.uu};
   EK1 e{d.rho, d.t};
   process_rows<1>(d.A, g, e, lds, PreK1{d, i, probe, lds.red});
@@ -289,9 +302,10 @@ struct EK2 {
 struct PreFlag { const int *flags; int probe; __device__ __forceinline__ bool operator()() const { return probe || !flags[F_DONE]; } };
 __global__ __launch_bounds__(kBlock) void k_k2(Dev d, int probe) {
   __shared__ StreamLds<1> lds;
+  if (!probe && d.flags[F_DONE]) return;
   GSplit g{d.uu, d.t, d.n};
   EK2 e{d.uu, d.w};
-  if (!process_rows<1>(d.B, g, e, lds, PreFlag{d.flags, probe})) return;
+  if (!process_rows<1>(d.B, g, e, lds, NoPre())) return;
   __syncthreads();
   const double DL = block_sum(e.dl, lds.red);
   put_partial(d.part, SL_DELTA, DL);
@@ -303,31 +317,34 @@ template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_kv(Dev d, int i, int probe) {
   __shared__ double sred[8];
   const int nv = d.n / VEC;                                       // vector elements (tail handled by workgroup 0)
-  const int stride = gridDim.x * kBlock;
-  const int j0 = blockIdx.x * kBlock + threadIdx.x;
-  if ((int)(blockIdx.x * kBlock) >= nv && blockIdx.x != 0) {       // idle workgroup: its partial slots must still read 0
+  // XCD-contiguous chunks of kBlock elements, as in process_rows (each XCD keeps 'its' eighth of the PCG vectors)
+  const int nchunk = (nv + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3, slots = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+  const int c0 = xcd * per + slot0;
+  const bool active = slot0 < per && c0 < nchunk;
+  const int j0 = c0 * kBlock + threadIdx.x;
+  if (!active && blockIdx.x != 0) {                                // idle workgroup: its partial slots must still read 0
     if (!probe) { put_partial(d.part, SL_GAMMA0 + ((i + 1) & 1), 0.0); put_partial(d.part, SL_RN0 + ((i + 1) & 1), 0.0); }
     return;
   }
+  if (!probe && d.flags[F_DONE]) return;                           // PCG already converged
   const bool first = (i == 0) && !probe;
   typedef typename std::conditional<VEC == 2, double2, double>::type V;
   V *p2 = reinterpret_cast<V *>(d.p), *s2 = reinterpret_cast<V *>(d.s), *x2 = reinterpret_cast<V *>(d.xs), *r2 = reinterpret_cast<V *>(d.r),
     *u2 = reinterpret_cast<V *>(d.uu);
   const V *w2 = reinterpret_cast<const V *>(d.w), *m2 = reinterpret_cast<const V *>(d.Minv);
   // issue this lane's first element loads, then fold the partials while they are in flight
-  const bool have = j0 < nv;
+  const bool have = active && j0 < nv;
   V u, w, x, r, mi, p, s;
   if (have) { u = u2[j0]; w = w2[j0]; x = x2[j0]; r = r2[j0]; mi = m2[j0]; if (!first) { p = p2[j0]; s = s2[j0]; } }
   double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
   double alpha = 0.0, beta = 0.0;
   if (probe != 1) {
-    const int done = d.flags[F_DONE];
     const PartRegs pg = partial_load(d.part + (SL_GAMMA0 + (i & 1)) * kGrid), pd = partial_load(d.part + SL_DELTA * kGrid);
     double gamma = partial_fold_sum(pg), delta = partial_fold_sum(pd);
     block_sum2(gamma, delta, sred);
     if (probe) { if (gamma == -1.2345e300) d.res[R_COUNT - 1] = delta; }   // probe == 2: pay for the reduction, ignore it
     else {
-      if (done) return;
       if (i == 0) { beta = 0.0; alpha = gamma / delta; }
       else { beta = gamma / gam[i - 1]; alpha = gamma / (delta - beta * gamma / alp[i - 1]); }
       if (blockIdx.x == 0 && threadIdx.x == 0) { gam[i] = gamma; alp[i] = alpha; }
@@ -339,8 +356,12 @@ __global__ __launch_bounds__(kBlock) void k_kv(Dev d, int i, int probe) {
     xx_ += alpha * pp_; rr_ -= alpha * ss_; uu_ = mm_ * rr_;
     g += rr_ * uu_; rn = nanmax(rn, fabs(rr_));
   };
-  for (int j = j0; j < nv; j += stride) {
-    if (j != j0) { u = u2[j]; w = w2[j]; x = x2[j]; r = r2[j]; mi = m2[j]; if (!first) { p = p2[j]; s = s2[j]; } }
+  for (int sl = slot0; active && sl < per; sl += slots) {
+    const int c = xcd * per + sl;
+    if (c >= nchunk) break;
+    const int j = c * kBlock + threadIdx.x;
+    if (j >= nv) break;
+    if (sl != slot0) { u = u2[j]; w = w2[j]; x = x2[j]; r = r2[j]; mi = m2[j]; if (!first) { p = p2[j]; s = s2[j]; } }
     if constexpr (VEC == 2) { upd(u.x, w.x, x.x, r.x, mi.x, p.x, s.x); upd(u.y, w.y, x.y, r.y, mi.y, p.y, s.y); }
     else upd(u, w, x, r, mi, p, s);
     p2[j] = p; s2[j] = s; x2[j] = x; r2[j] = r; u2[j] = u;

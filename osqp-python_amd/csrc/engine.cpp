@@ -555,7 +555,7 @@ int Engine::solve() {
     // PCG budget for the next chunk: track what the last chunk needed
     const int cap = std::min(settings.cg_max_iter, kMaxCg);
     if (flags[F_STAT_UNCONV] > 0) cg_budget_ = std::min(cap, std::max(cg_budget_ + 2, 2 * cg_budget_));
-    else cg_budget_ = std::min(cap, std::max(2, flags[F_STAT_MAX] + 2));
+    else cg_budget_ = std::min(cap, std::max(2, flags[F_STAT_MAX] + 1));
   }
   info.rho_estimate = rho_estimate(res);                                                 // :1275
   store_solution();

@@ -8,8 +8,11 @@ import sys
 path, out = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 with open(path) as f:
-    for row in csv.DictReader(f):
-        name = row.get('Kernel_Name') or row.get('Kernel Name') or ''
+    rd = csv.DictReader(f)
+    kcol = [c for c in rd.fieldnames if 'kernel' in c.lower() and 'name' in c.lower()]
+    print('columns:', rd.fieldnames, '-> kernel column', kcol)
+    for row in rd:
+        name = row[kcol[0]] if kcol else ''
         name = name.split('(')[0].split('::')[-1]
         agg[name][row['Counter_Name']].append(float(row['Counter_Value']))
 with open(out, 'w') as g:
