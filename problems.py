@@ -91,6 +91,51 @@ def portfolio_qp(na=200, k=10, seed=1, gamma=1.0):
     return P, q, A, l, u
 
 
+def mpc_batch(nbatch, nx=8, nu=4, N=10, seed=7):
+    """BASELINE configs[4]: `nbatch` MPC QPs sharing one sparsity pattern AND one (P, A): horizon N,
+    nx states, nu inputs => n = N(nx+nu) = 120 variables z = (x_1..x_N, u_0..u_{N-1});  rows: dynamics N*nx (equalities)
+    + variable box n + input-rate N*nu  => m = 240.  Only the bounds of the first nx dynamics rows (A_d x0) differ per problem
+    (mirrors the update-style batching of /root/reference/src/osqp/nn/torch.py:136-140).
+    Returns P, q, A and arrays L, U of shape (nbatch, m)."""
+    rng = np.random.default_rng(seed)
+    Ad = rng.standard_normal((nx, nx)); Ad *= 0.95 / np.abs(np.linalg.eigvals(Ad)).max()
+    Bd = rng.standard_normal((nx, nu)) / np.sqrt(nx)
+    n = N * (nx + nu); xo = lambda k: (k - 1) * nx; uo = lambda k: N * nx + k * nu      # offsets of x_k (k=1..N), u_k (k=0..N-1)
+    rows, cols, vals = [], [], []
+    def put(r, c, v):
+        rows.append(r); cols.append(c); vals.append(v)
+    r = 0
+    for k in range(N):                                     # x_{k+1} - Ad x_k - Bd u_k = (Ad x0 if k == 0 else 0)
+        for i in range(nx):
+            put(r + i, xo(k + 1) + i, 1.0)
+            for j in range(nu):
+                put(r + i, uo(k) + j, -Bd[i, j])
+            if k > 0:
+                for j in range(nx):
+                    put(r + i, xo(k) + j, -Ad[i, j])
+        r += nx
+    for j in range(n):                                     # box on every variable
+        put(r + j, j, 1.0)
+    r += n
+    for k in range(N):                                     # input rate u_k - u_{k-1}
+        for j in range(nu):
+            put(r + j, uo(k) + j, 1.0)
+            if k > 0:
+                put(r + j, uo(k - 1) + j, -1.0)
+        r += nu
+    m = r
+    A = sp.csc_matrix((vals, (rows, cols)), shape=(m, n)); A.sort_indices()
+    P = sp.diags(np.concatenate([np.ones(N * nx), 0.1 * np.ones(N * nu)]), format='csc')
+    q = np.zeros(n)
+    x0 = rng.standard_normal((nbatch, nx))
+    L = np.zeros((nbatch, m)); U = np.zeros((nbatch, m))
+    L[:, :nx] = U[:, :nx] = x0 @ Ad.T
+    L[:, N * nx:N * nx + N * nx] = -5.0; U[:, N * nx:N * nx + N * nx] = 5.0           # |x| <= 5
+    L[:, 2 * N * nx:N * nx + n] = -1.0; U[:, 2 * N * nx:N * nx + n] = 1.0              # |u| <= 1
+    L[:, N * nx + n:] = -0.5; U[:, N * nx + n:] = 0.5                                  # |du| <= 0.5
+    return P, q, A, L, U
+
+
 def kkt_certificate(P, q, A, l, u, x, y):
     """Independent optimality certificate (unscaled): primal residual, dual residual, complementarity, objective."""
     ax = A @ x

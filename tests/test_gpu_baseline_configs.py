@@ -1,0 +1,71 @@
+"""GPU tier: BASELINE.json's other configs as parity-test cases at their FULL sizes.  At these
+sizes the direct-LDL' oracle is not a quick check, so correctness is established by size-independent properties of the
+returned (x, y): the KKT optimality certificate (primal/dual residuals vs the termination tolerances, complementarity)
+recomputed on the host from the ORIGINAL unscaled data, plus agreement with the oracle on a down-scaled instance of the
+same generator (tests/test_gpu_parity.py) and, for the MPC batch, per-problem agreement with the oracle."""
+import warnings
+
+import numpy as np
+import pytest
+
+import osqp_amd
+import problems
+from oracle import Oracle, SOLVED
+
+pytestmark = pytest.mark.gpu
+warnings.simplefilter('ignore')
+EPS = 1e-6
+
+
+def certify(P, q, A, l, u, r, eps=EPS):
+    assert r.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED
+    k = problems.kkt_certificate(P, q, A, l, u, r.x, r.y)
+    ax = A @ r.x
+    scale_p = max(np.abs(ax).max(), np.abs(np.clip(ax, l, u)).max())
+    scale_d = max(np.abs(P @ r.x).max(), np.abs(A.T @ r.y).max(), np.abs(q).max())
+    assert k['pri'] <= 1.01 * (eps + eps * scale_p), k          # termination criterion, _osqp.py:728-751
+    assert k['dua'] <= 1.01 * (eps + eps * scale_d), k          # _osqp.py:766-794
+    assert abs(k['obj'] - r.info.obj_val) <= 1e-6 * (1 + abs(k['obj']))
+    return k
+
+
+def test_config3_lasso_full_size():
+    """Lasso-as-QP n=5k features, m=10k samples, fully dense data block (50M stored entries; long-row SpMV path)."""
+    P, q, A, l, u = problems.lasso_qp(5000, 10000)
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, eps_abs=EPS, eps_rel=EPS, verbose=False, max_iter=20000)
+    r = m.solve()
+    k = certify(P, q, A, l, u, r)
+    assert k['comp'] <= 1e-2 * (1 + np.abs(r.y).max())
+    print('lasso full: iter', r.info.iter, m._solver.hip_stats())
+
+
+def test_config4_portfolio_full_size():
+    """Portfolio factor model n=10k assets, k=100 factors (block-sparse P, rho heterogeneity, one 10k-entry row)."""
+    P, q, A, l, u = problems.portfolio_qp(10000, 100)
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, eps_abs=EPS, eps_rel=EPS, verbose=False, max_iter=50000)
+    r = m.solve()
+    certify(P, q, A, l, u, r)
+    assert abs(r.x[:10000].sum() - 1.0) < 1e-4 and r.x[:10000].min() > -1e-4
+    print('portfolio full: iter', r.info.iter, m._solver.hip_stats())
+
+
+def test_config5_mpc_batch_shard():
+    """Batch of MPC QPs (n=120, m=240) through the sharding layer (osqp_amd.sharded; world=1 here, the same code path the
+    multi-GPU job runs per rank) -- status/obj per problem against the oracle's direct solve."""
+    from osqp_amd import sharded
+    B = 32
+    P, q, A, L, U = problems.mpc_batch(B)
+
+    def make():
+        s = osqp_amd.OSQP()
+        orig = s.setup
+        s.setup = lambda P_, q_, A_, l_, u_: orig(P_, q_, A_, l_, u_, eps_abs=EPS, eps_rel=EPS, verbose=False)
+        return s
+    recs, xs = sharded.solve_local(lambda i: (P, q, A, L[i], U[i]), make, 0, 1, B)
+    table = sharded.gather_records(recs, B)
+    assert table.shape[0] == B and (table[:, 1] == 1).all()
+    for i in (0, 7, 31):
+        xo, yo, io = Oracle().setup(P, q, A, L[i], U[i], eps_abs=1e-9, eps_rel=1e-9, adaptive_rho_interval=50, max_iter=100000).solve()
+        assert io.status_val == SOLVED
+        assert abs(table[i, 3] - io.obj_val) <= 1e-5 * (1 + abs(io.obj_val))
+        assert np.abs(xs[i] - xo).max() <= 1e-4 * (1 + np.abs(xo).max())
