@@ -2,6 +2,7 @@
 """Aggregate a rocprofv3 --pmc counter_collection CSV per kernel: mean counter value per dispatch, split into 'active'
 dispatches and early-exit (no-op) ones by a duration-free criterion (counter value above 1% of the kernel's max)."""
 import csv
+import re
 import collections
 import sys
 
@@ -13,7 +14,8 @@ with open(path) as f:
     print('columns:', rd.fieldnames, '-> kernel column', kcol)
     for row in rd:
         name = row[kcol[0]] if kcol else ''
-        name = name.split('(')[0].split('::')[-1]
+        mm = re.search(r'(k_\w+(<\d+>)?)', name)
+        name = mm.group(1) if mm else name.split('(')[0]
         agg[name][row['Counter_Name']].append(float(row['Counter_Value']))
 with open(out, 'w') as g:
     g.write('kernel,counter,dispatches,mean_all,active_dispatches,mean_active,max\n')
