@@ -190,6 +190,16 @@ OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
    The kernels run in a side-effect-free "probe" mode; solver state is unchanged. */
 OSQPInt osqp_hip_time_kernel(OSQPSolver *solver, OSQPInt which, OSQPInt reps, double *mean_ms);
 
+/* Batched solve of `nbatch` QPs that share this solver's P, A, scaling and settings and differ in q / l / u (BASELINE
+   configs[4]; semantics of the reference's update-style batching, src/osqp/nn/torch.py:128-164, as ONE kernel launch:
+   one workgroup per problem, iterates in LDS).  q: nbatch x n, l/u: nbatch x m, row-major, NULL = the solver's current
+   vector for every problem.  x: nbatch x n, y: nbatch x m (in: warm start if warm != 0; out: solution, or the
+   infeasibility certificate).  rec: nbatch x 8 doubles {status_val, iter, obj_val, prim_res, dual_res, rho, rho_updates,
+   pcg_iters}.  Returns OSQP_FUNC_NOT_IMPLEMENTED when a problem does not fit one workgroup's LDS (10n + 8m doubles <= 64 KB):
+   callers then loop osqp_update_data_vec + osqp_solve. */
+OSQPInt osqp_hip_batch_solve(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u,
+                             OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm);
+
 /* Test hooks (used by tests/ only): y = A x, y = B [xn; xm] on the device with the scaled matrices. */
 OSQPInt osqp_hip_test_spmv(OSQPSolver *solver, OSQPInt which, const OSQPFloat *in, OSQPFloat *out);
 /* Weight of equality rows relative to inequality rows, rho_eq = factor * rho, used when equality and inequality rows are

@@ -72,6 +72,9 @@ OSQPInt osqp_hip_get_stats(OSQPSolver *s, OSQPHipStats *out) { Engine *e = eng(s
 OSQPInt osqp_hip_time_kernel(OSQPSolver *s, OSQPInt which, OSQPInt reps, double *ms) { Engine *e = eng(s); return e ? e->time_kernel(which, reps, ms) : OSQP_WORKSPACE_NOT_INIT_ERROR; }
 OSQPInt osqp_hip_test_spmv(OSQPSolver *s, OSQPInt which, const OSQPFloat *in, OSQPFloat *out) { Engine *e = eng(s); return e ? e->test_spmv(which, in, out) : OSQP_WORKSPACE_NOT_INIT_ERROR; }
 OSQPInt osqp_hip_set_rho_eq_factor(OSQPSolver *s, OSQPFloat f) { Engine *e = eng(s); return e ? e->set_rho_eq_factor(f) : OSQP_WORKSPACE_NOT_INIT_ERROR; }
+OSQPInt osqp_hip_batch_solve(OSQPSolver *s, OSQPInt nbatch, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u, OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm) {
+  Engine *e = eng(s); return e ? e->batch_solve(nbatch, q, l, u, x, y, rec, warm) : OSQP_WORKSPACE_NOT_INIT_ERROR;
+}
 OSQPInt osqp_hip_get_scaling(OSQPSolver *s, OSQPFloat *D, OSQPFloat *E, OSQPFloat *c) { Engine *e = eng(s); return e ? e->get_scaling(D, E, c) : OSQP_WORKSPACE_NOT_INIT_ERROR; }
 
 }  // extern "C"

@@ -73,7 +73,22 @@ struct Dev {
   void *impl = nullptr;          // backend private (events, graphs, pinned staging)
 };
 
+// Batched small-QP solve (batch_hip.hip): nbatch problems sharing the solver's scaled A / B, one workgroup each.
+struct BatchParams {
+  int n, m, nbatch;
+  DevCsr A, B;
+  const double *D, *Dinv, *E, *Einv;
+  double c, cinv, sigma, alpha, rho0, eq_factor, eps_abs, eps_rel, eps_pinf, eps_dinf, cg_frac, rho_tol;
+  int max_iter, check, rho_interval, cg_max, unscaled, scaling, precond, rho_is_vec, warm;
+  const double *q, *l, *u;      // scaled, [nbatch][n] / [nbatch][m]
+  double *x, *y;                // in: scaled warm start (if warm), out: UNSCALED solution  [nbatch][n] / [nbatch][m]
+  double *rec;                  // [nbatch][8]: status, iter, obj, prim_res, dual_res, rho, rho_updates, pcg_iters
+};
+
 namespace be {
+
+size_t batch_lds_bytes(int n, int m);                       // 0 if a problem does not fit one workgroup's LDS
+int batch_solve(Dev &d, const BatchParams &p);               // synchronous; OSQP_FUNC_NOT_IMPLEMENTED if it does not fit
 
 const char *name();
 int init(Dev &d, int device);            // select device, create stream; returns 0 or osqp_error_type

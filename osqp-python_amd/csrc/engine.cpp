@@ -702,6 +702,52 @@ int Engine::update_settings(const OSQPSettings *s) {
   return OSQP_NO_ERROR;
 }
 
+// Batch of nbatch QPs that share this solver's (P, A, scaling, settings) and differ in q / l / u -- the reference's
+// update-style batching (nn/torch.py:136-164: update(q,l,u) + solve() per element) as ONE kernel launch.
+// q: nbatch x n, l/u: nbatch x m (row-major; NULL = this solver's current vector for every problem);
+// x: nbatch x n, y: nbatch x m (in: unscaled warm start if warm != 0; out: solution, or certificate for infeasible ones);
+// rec: nbatch x 8 = {status_val, iter, obj_val, prim_res, dual_res, rho, rho_updates, pcg_iters}.
+int Engine::batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (nbatch <= 0 || !x || !y || !rec) return OSQP_DATA_VALIDATION_ERROR;
+  if (!be::batch_lds_bytes(n, m)) return OSQP_FUNC_NOT_IMPLEMENTED;
+  be::activate(d_);
+  const size_t N = (size_t)nbatch * n, M = (size_t)nbatch * m;
+  std::vector<double> qs(N), ls(M), us(M), xs(N, 0.0), ys(M, 0.0);
+  for (int b = 0; b < nbatch; b++) {
+    const double *qb = q ? q + (size_t)b * n : q0_.data(), *lb = l ? l + (size_t)b * m : l0_.data(), *ub = u ? u + (size_t)b * m : u0_.data();
+    for (int j = 0; j < n; j++) qs[(size_t)b * n + j] = c_ * D_[j] * qb[j];                          // _osqp.py:1328
+    for (int i = 0; i < m; i++) {
+      const double li = std::max(lb[i], -OSQP_INFTY), ui = std::min(ub[i], OSQP_INFTY);               // interface.py:334-337
+      if (!(li <= ui)) return OSQP_DATA_VALIDATION_ERROR;
+      ls[(size_t)b * m + i] = E_[i] * li; us[(size_t)b * m + i] = E_[i] * ui;                         // :1357-1358
+    }
+    if (warm) {
+      for (int j = 0; j < n; j++) xs[(size_t)b * n + j] = x[(size_t)b * n + j] * Dinv_[j];
+      for (int i = 0; i < m; i++) ys[(size_t)b * m + i] = y[(size_t)b * m + i] * Einv_[i] * c_;
+    }
+  }
+  auto dv = [&](size_t cnt) { return dev_vec<double>(d_, cnt); };
+  double *dq = dv(N), *dl = dv(M), *du = dv(M), *dx = dv(N), *dy = dv(M), *drec = dv((size_t)nbatch * 8);
+  be::h2d(d_, dq, qs.data(), sizeof(double) * N); be::h2d(d_, dl, ls.data(), sizeof(double) * M); be::h2d(d_, du, us.data(), sizeof(double) * M);
+  if (warm) { be::h2d(d_, dx, xs.data(), sizeof(double) * N); be::h2d(d_, dy, ys.data(), sizeof(double) * M); }
+  BatchParams p{};
+  p.n = n; p.m = m; p.nbatch = nbatch; p.A = d_.A; p.B = d_.B; p.D = d_.D; p.Dinv = d_.Dinv; p.E = d_.E; p.Einv = d_.Einv;
+  p.c = c_; p.cinv = cinv_; p.sigma = settings.sigma; p.alpha = settings.alpha; p.rho0 = clamp_rho(settings.rho); p.eq_factor = eq_factor_mixed_;
+  p.eps_abs = settings.eps_abs; p.eps_rel = settings.eps_rel; p.eps_pinf = settings.eps_prim_inf; p.eps_dinf = settings.eps_dual_inf;
+  p.cg_frac = settings.cg_tol_fraction; p.rho_tol = settings.adaptive_rho_tolerance;
+  p.max_iter = settings.max_iter; p.check = settings.check_termination; p.rho_interval = settings.adaptive_rho ? auto_rho_interval() : 0;
+  p.cg_max = settings.cg_max_iter; p.unscaled = settings.scaling && !settings.scaled_termination; p.scaling = settings.scaling;
+  p.precond = settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER; p.rho_is_vec = settings.rho_is_vec; p.warm = warm;
+  p.q = dq; p.l = dl; p.u = du; p.x = dx; p.y = dy; p.rec = drec;
+  int err = be::batch_solve(d_, p);
+  if (!err) {
+    be::d2h(d_, x, dx, sizeof(double) * N); be::d2h(d_, y, dy, sizeof(double) * M); be::d2h(d_, rec, drec, sizeof(double) * 8 * nbatch);
+  }
+  for (double *ptr : {dq, dl, du, dx, dy, drec}) be::dfree(d_, ptr);
+  return err;
+}
+
 int Engine::get_stats(OSQPHipStats *out) { if (!out) return OSQP_DATA_VALIDATION_ERROR; *out = stats_; return OSQP_NO_ERROR; }
 int Engine::time_kernel(int which, int reps, double *ms) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;

@@ -38,6 +38,7 @@ class Engine {
   int test_spmv(int which, const double *in, double *out);
   int get_scaling(double *D, double *E, double *c);
   int set_rho_eq_factor(double f);
+  int batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm);
 
   OSQPSolver pub{};          // what the caller holds
   OSQPSettings settings{};

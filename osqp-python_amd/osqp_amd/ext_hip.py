@@ -233,6 +233,28 @@ class OSQPSolver:
     def hip_set_rho_eq_factor(self, factor):
         return self._lib.osqp_hip_set_rho_eq_factor(self._p, float(factor))
 
+    BATCH_FIELDS = ('status_val', 'iter', 'obj_val', 'prim_res', 'dual_res', 'rho', 'rho_updates', 'pcg_iters')
+
+    def hip_batch_solve(self, q=None, l=None, u=None, x0=None, y0=None, nbatch=None):
+        """Solve a batch of QPs sharing this solver's P, A and settings (osqp_hip_batch_solve).  q: (B, n), l/u: (B, m).
+        Returns x (B, n), y (B, m), rec (B, 8) with columns BATCH_FIELDS."""
+        arrs = [a for a in (q, l, u, x0, y0) if a is not None]
+        B = int(nbatch) if nbatch is not None else int(np.asarray(arrs[0]).shape[0])
+        q, l, u = (None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(B, -1) for a in (q, l, u))
+        if l is not None:
+            l = np.maximum(l, -OSQP_INFTY)
+        if u is not None:
+            u = np.minimum(u, OSQP_INFTY)
+        warm = x0 is not None or y0 is not None
+        x = np.zeros((B, self.n)) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).reshape(B, self.n).copy()
+        y = np.zeros((B, self.m)) if y0 is None else np.ascontiguousarray(y0, dtype=np.float64).reshape(B, self.m).copy()
+        rec = np.zeros((B, 8))
+        st = self._lib.osqp_hip_batch_solve(self._p, B, _ptr(q, _lib.c_double_p), _ptr(l, _lib.c_double_p), _ptr(u, _lib.c_double_p),
+                                            _ptr(x, _lib.c_double_p), _ptr(y, _lib.c_double_p), _ptr(rec, _lib.c_double_p), int(warm))
+        if st:
+            raise ValueError(str(st))
+        return x, y, rec
+
     def hip_scaling(self):
         D, E, c = np.empty(self.n), np.empty(self.m), C.c_double()
         self._lib.osqp_hip_get_scaling(self._p, _ptr(D, _lib.c_double_p), _ptr(E, _lib.c_double_p), C.byref(c))

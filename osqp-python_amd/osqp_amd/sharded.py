@@ -50,3 +50,18 @@ def gather_records(recs, nproblems, device=None):
     table = torch.cat(out).cpu().numpy()
     table = table[table[:, 0] >= 0]
     return table[np.argsort(table[:, 0])]
+
+
+def solve_batch_sharded(solver, q=None, l=None, u=None, rank=0, world=1, device=None):
+    """BASELINE configs[4] path: a batch of B same-structure QPs (rows of q / l / u) is block-partitioned over the ranks
+    (SURVEY.md §8e), each rank solves its share with ONE batched kernel launch on its GPU (osqp_hip_batch_solve: one
+    workgroup per problem), then ONE all_gather of the packed per-problem records.  `solver` is a set-up osqp_amd.OSQP
+    holding the shared P, A and settings.  Returns (table[B, fields], x_local, y_local, (lo, hi))."""
+    B = next(np.asarray(a).shape[0] for a in (q, l, u) if a is not None)
+    lo, hi = shard_range(B, rank, world)
+    sl = lambda a: None if a is None else np.asarray(a)[lo:hi]
+    x, y, rec = solver._solver.hip_batch_solve(q=sl(q), l=sl(l), u=sl(u), nbatch=hi - lo)
+    recs = np.zeros((hi - lo, len(RECORD_FIELDS)))
+    recs[:, 0] = np.arange(lo, hi)
+    recs[:, 1:6] = rec[:, 0:5]                 # status_val, iter, obj_val, prim_res, dual_res
+    return gather_records(recs, B, device=device), x, y, (lo, hi)

@@ -203,6 +203,9 @@ void init_iterates(Dev &d, int full) {
   }
 }
 
+size_t batch_lds_bytes(int, int) { return 0; }
+int batch_solve(Dev &, const BatchParams &) { return OSQP_FUNC_NOT_IMPLEMENTED; }   // GPU-only feature
+
 bool graphs_supported() { return false; }
 void graph_begin(Dev &) {}
 void *graph_end(Dev &) { return nullptr; }

@@ -1,0 +1,84 @@
+"""GPU tier: the batched small-QP kernel (osqp_hip_batch_solve; BASELINE configs[4] = MPC QPs n=120, m=240) against the
+oracle and against the large-problem engine on the same problems."""
+import time
+import warnings
+
+import numpy as np
+import pytest
+
+import osqp_amd
+import problems
+from oracle import Oracle, SOLVED, PRIMAL_INFEASIBLE
+
+pytestmark = pytest.mark.gpu
+warnings.simplefilter('ignore')
+EPS = 1e-6
+ST = dict(eps_abs=EPS, eps_rel=EPS, verbose=False, max_iter=4000)
+
+
+def base_solver(P, q, A, l, u, **kw):
+    s = osqp_amd.OSQP()
+    st = dict(ST); st.update(kw)
+    s.setup(P, q, A, l, u, **st)
+    return s
+
+
+def test_batch_matches_oracle_and_single_engine():
+    B = 64
+    P, q, A, L, U = problems.mpc_batch(B)
+    s = base_solver(P, q, A, L[0], U[0])
+    x, y, rec = s._solver.hip_batch_solve(l=L, u=U)
+    assert (rec[:, 0] == 1).all(), rec[:, 0]
+    for i in (0, 5, 17, 63):
+        xo, yo, io = Oracle().setup(P, q, A, L[i], U[i], eps_abs=1e-9, eps_rel=1e-9, adaptive_rho_interval=50, max_iter=100000).solve()
+        assert io.status_val == SOLVED
+        assert abs(rec[i, 2] - io.obj_val) <= 1e-5 * (1 + abs(io.obj_val))
+        assert np.abs(x[i] - xo).max() <= 1e-4 * (1 + np.abs(xo).max())
+        assert np.abs(y[i] - yo).max() <= 1e-3 * (1 + np.abs(yo).max())
+        k = problems.kkt_certificate(P, q, A, L[i], U[i], x[i], y[i])
+        assert k['pri'] <= 2 * EPS * (1 + np.abs(A @ x[i]).max()) and k['dua'] <= 2 * EPS * (1 + np.abs(A.T @ y[i]).max() + np.abs(P @ x[i]).max())
+    # same problems through the single-QP engine (update + cold-started solve per problem: nn/torch.py:136-157)
+    s.update_settings(warm_starting=False)
+    for i in range(0, B, 9):
+        s.update(l=L[i], u=U[i])
+        r = s.solve()
+        assert r.info.status_val == 1
+        assert abs(r.info.obj_val - rec[i, 2]) <= 1e-5 * (1 + abs(rec[i, 2]))
+        assert np.abs(r.x - x[i]).max() <= 1e-4 * (1 + np.abs(x[i]).max())
+
+
+def test_batch_with_q_updates_infeasible_member_and_warm_start():
+    B = 16
+    P, q, A, L, U = problems.mpc_batch(B, seed=11)
+    rng = np.random.default_rng(3)
+    Q = 0.05 * rng.standard_normal((B, P.shape[0]))
+    L = L.copy(); U = U.copy()
+    L[3, :8] += 500.0; U[3, :8] += 500.0          # x_1 = Ad x0 + Bd u0 forced far outside |x| <= 5 : primal infeasible
+    s = base_solver(P, q, A, L[0], U[0])
+    x, y, rec = s._solver.hip_batch_solve(q=Q, l=L, u=U)
+    xo, yo, io = Oracle().setup(P, Q[3], A, L[3], U[3], eps_abs=EPS, eps_rel=EPS, adaptive_rho_interval=50, check_termination=25).solve()
+    assert io.status_val == PRIMAL_INFEASIBLE and rec[3, 0] == PRIMAL_INFEASIBLE
+    cert = y[3] / np.abs(y[3]).max()
+    assert np.abs(A.T @ cert).max() < 1e-3 and U[3] @ np.maximum(cert, 0) + L[3] @ np.minimum(cert, 0) < 0
+    ok = np.arange(B) != 3
+    assert (rec[ok, 0] == 1).all()
+    for i in (0, 8):
+        xo, yo, io = Oracle().setup(P, Q[i], A, L[i], U[i], eps_abs=1e-9, eps_rel=1e-9, adaptive_rho_interval=50, max_iter=100000).solve()
+        assert abs(rec[i, 2] - io.obj_val) <= 1e-5 * (1 + abs(io.obj_val))
+    # warm start at the solution: converged at the first check
+    x2, y2, rec2 = s._solver.hip_batch_solve(q=Q[ok], l=L[ok], u=U[ok], x0=x[ok], y0=y[ok])
+    assert (rec2[:, 0] == 1).all() and (rec2[:, 1] <= 25).all()
+    assert np.abs(x2 - x[ok]).max() < 1e-5
+
+
+def test_batch_sharded_table_and_throughput():
+    from osqp_amd import sharded
+    B = 4096
+    P, q, A, L, U = problems.mpc_batch(B)
+    s = base_solver(P, q, A, L[0], U[0])
+    s._solver.hip_batch_solve(l=L[:64], u=U[:64])          # warm-up
+    t0 = time.perf_counter()
+    table, x, y, (lo, hi) = sharded.solve_batch_sharded(s, l=L, u=U)
+    dt = time.perf_counter() - t0
+    assert table.shape == (B, len(sharded.RECORD_FIELDS)) and (table[:, 1] == 1).all() and (lo, hi) == (0, B)
+    print('batch of %d MPC QPs: %.1f ms (%.0f QPs/s, %.0f ADMM iter/s aggregate)' % (B, dt * 1e3, B / dt, table[:, 2].sum() / dt))
