@@ -41,6 +41,26 @@ def spmv_bytes(nnz, rows, cols):
     return 12 * nnz + 4 * (rows + 1) + 8 * cols + 8 * rows
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summaries (profiles/*_pmc_FETCH_SIZE.csv and
+    *_pmc_WRITE_SIZE.csv, produced by profiles/run_pmc.sh with one pass per counter): mean over the ACTIVE dispatches,
+    FETCH_SIZE / WRITE_SIZE are in KB, and on gfx950 FETCH_SIZE counts 64 B per 128-B request, i.e. half the bytes of a
+    coalesced stream (MI355X_MICROARCH.md, HBM section) -> doubled.  Returns None when no summary is present."""
+    import csv
+    import glob
+    vals = {}
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_%s.csv' % ctr)))
+        if not files:
+            return None
+        for row in csv.DictReader(open(files[-1])):
+            if row['kernel'] == kernel and row['counter'] == ctr:
+                vals[ctr] = float(row['mean_active'])
+    if len(vals) != 2:
+        return None
+    return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0
+
+
 def cpu_baseline(P, q, A, l, u, settings, seconds_target=15.0):
     """Oracle (direct LDL', AMD ordering, 1 thread) on the same QP; bounded number of ADMM iterations."""
     from oracle import Oracle
@@ -150,7 +170,7 @@ def main():
                        'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
                        'setup_s': t_setup, 'per_rank': [{'status': int(r[0]), 'iter': int(r[1]), 'obj': r[2]} for r in allrec]},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': probes[dom]['GBps'] / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': probes[dom]['GBps'] / HBM_PEAK_GBS, 'traffic': pmc_traffic('k_k2'),
                          'bytes_per_launch': kb[dom], 'ms_per_launch': probes[dom]['ms'],
                          'pcg_iteration': {'bytes': pcg_bytes, 'ms': pcg_ms, 'GBps': pcg_bytes / (pcg_ms * 1e-3) / 1e9,
                                            'frac': pcg_bytes / (pcg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
