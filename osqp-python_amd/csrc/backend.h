@@ -42,7 +42,7 @@ enum ResId {
   R_COUNT
 };
 // indices into the int32 status block
-enum FlagId { F_DONE = 0, F_ITERS, F_STAT_SUM, F_STAT_MAX, F_STAT_UNCONV, F_COUNT };
+enum FlagId { F_DONE = 0, F_ITERS, F_STAT_SUM, F_STAT_MAX, F_STAT_UNCONV, F_STAT_SUMSQ, F_STAT_N, F_COUNT };
 // indices into the fp64 scalar block
 enum ScalId { S_TOL_REL = 0, S_TOL_ABS, S_HIST = 8 /* gamma[kMaxCg+1], then alpha[kMaxCg+1] */ };
 

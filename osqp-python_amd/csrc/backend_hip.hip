@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {                                 // PCG statistics of this ADMM iteration
     const int done = d.flags[F_DONE], used = done ? d.flags[F_ITERS] : budget;
-    d.flags[F_STAT_SUM] += used;
+    d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;
     if (used > d.flags[F_STAT_MAX]) d.flags[F_STAT_MAX] = used;
     if (!done) d.flags[F_STAT_UNCONV] += 1;
   }

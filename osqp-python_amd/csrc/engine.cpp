@@ -554,8 +554,16 @@ int Engine::solve() {
     if (std::isfinite(eps)) { eps_cg_prev_ = eps; be::set_pcg_tol(d_, 1e-14, eps); have_tol_ = true; }
     // PCG budget for the next chunk: track what the last chunk needed
     const int cap = std::min(settings.cg_max_iter, kMaxCg);
-    if (flags[F_STAT_UNCONV] > 0) cg_budget_ = std::min(cap, std::max(cg_budget_ + 2, 2 * cg_budget_));
-    else cg_budget_ = std::min(cap, std::max(2, flags[F_STAT_MAX] + 1));
+    if (flags[F_STAT_UNCONV] * 4 > std::max(1, flags[F_STAT_N])) cg_budget_ = std::min(cap, std::max(cg_budget_ + 2, 2 * cg_budget_));
+    else if (flags[F_STAT_UNCONV] > 0) cg_budget_ = std::min(cap, cg_budget_ + 1);
+    else {
+      // mean + 3 sigma of the PCG counts of the last chunk (+1), never above its max + 1: rare spikes should not
+      // set the budget of the next 25 iterations (an occasional budget-limited solve is just a slightly less exact one)
+      const double cnt = std::max(1, flags[F_STAT_N]), mean = flags[F_STAT_SUM] / cnt;
+      const double var = std::max(0.0, flags[F_STAT_SUMSQ] / cnt - mean * mean);
+      const int q3 = (int)std::ceil(mean + 3.0 * std::sqrt(var)) + 1;
+      cg_budget_ = std::min(cap, std::max(2, std::min(flags[F_STAT_MAX] + 1, q3)));
+    }
   }
   info.rho_estimate = rho_estimate(res);                                                 // :1275
   store_solution();

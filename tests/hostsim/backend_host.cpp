@@ -111,7 +111,7 @@ void ka(Dev &d, int budget) {
     d.dx[j] = xn - d.x[j]; d.x[j] = xn;
   }
   int used = d.flags[F_DONE] ? d.flags[F_ITERS] : budget;
-  d.flags[F_STAT_SUM] += used;
+  d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;
   d.flags[F_STAT_MAX] = std::max(d.flags[F_STAT_MAX], used);
   if (!d.flags[F_DONE]) d.flags[F_STAT_UNCONV] += 1;
 }
@@ -173,7 +173,7 @@ void infeas_dual(Dev &d, double thr, int unscaled) {
 void fetch_res(Dev &d, double *h) { std::memcpy(h, d.res, sizeof(double) * R_COUNT); }
 void fetch_flags(Dev &d, int *h) {
   std::memcpy(h, d.flags, sizeof(int) * F_COUNT);
-  d.flags[F_STAT_SUM] = d.flags[F_STAT_MAX] = d.flags[F_STAT_UNCONV] = 0;
+  d.flags[F_STAT_SUM] = d.flags[F_STAT_MAX] = d.flags[F_STAT_UNCONV] = d.flags[F_STAT_SUMSQ] = d.flags[F_STAT_N] = 0;
 }
 
 void set_rho(Dev &d, double rb) {

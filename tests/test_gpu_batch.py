@@ -82,3 +82,23 @@ def test_batch_sharded_table_and_throughput():
     dt = time.perf_counter() - t0
     assert table.shape == (B, len(sharded.RECORD_FIELDS)) and (table[:, 1] == 1).all() and (lo, hi) == (0, B)
     print('batch of %d MPC QPs: %.1f ms (%.0f QPs/s, %.0f ADMM iter/s aggregate)' % (B, dt * 1e3, B / dt, table[:, 2].sum() / dt))
+
+
+def test_nn_module_forward_shared_and_per_element_matrices():
+    """osqp_amd.nn.torch.OSQP forward (reference: src/osqp/nn/torch.py:22-230; nn_test.py builds it the same way)."""
+    import torch
+    from osqp_amd.nn.torch import OSQP as OSQPLayer
+    B = 6
+    P, q, A, L, U = problems.mpc_batch(B, seed=21)
+    Pc, Ac = P.tocoo(), A.tocoo()
+    layer = OSQPLayer((Pc.row, Pc.col), P.shape, (Ac.row, Ac.col), A.shape, eps_abs=1e-6, eps_rel=1e-6)
+    Pv, Av = torch.tensor(Pc.data), torch.tensor(Ac.data)
+    qv = torch.zeros(B, P.shape[0], dtype=torch.float64)
+    x1 = layer(Pv, qv, Av, torch.tensor(L), torch.tensor(U))                       # shared matrices -> batched kernel
+    x2 = layer(Pv.repeat(B, 1) * 1.0, qv, Av.repeat(B, 1), torch.tensor(L), torch.tensor(U))   # per-element -> update() loop
+    assert x1.shape == (B, P.shape[0]) and torch.allclose(x1, x2, atol=2e-4)
+    xo, yo, io = Oracle().setup(P, q, A, L[2], U[2], eps_abs=1e-9, eps_rel=1e-9, adaptive_rho_interval=50, max_iter=100000).solve()
+    assert np.abs(x1[2].numpy() - xo).max() <= 1e-4 * (1 + np.abs(xo).max())
+    with pytest.raises(RuntimeError):                                              # unsolved element raises (nn/torch.py:158-162)
+        Lb, Ub = L.copy(), U.copy(); Lb[1, :8] += 500; Ub[1, :8] += 500
+        layer(Pv, qv, Av, torch.tensor(Lb), torch.tensor(Ub))
