@@ -399,11 +399,20 @@ __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
     const double xo = d.x[j], xn = d.alpha * d.xs[j] + (1.0 - d.alpha) * xo;
     d.dx[j] = xn - xo; d.x[j] = xn;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {                                 // PCG statistics of this ADMM iteration
-    const int done = d.flags[F_DONE], used = done ? d.flags[F_ITERS] : budget;
-    d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;
-    if (used > d.flags[F_STAT_MAX]) d.flags[F_STAT_MAX] = used;
-    if (!done) d.flags[F_STAT_UNCONV] += 1;
+  if (blockIdx.x == 0) {                                                     // PCG statistics of this ADMM iteration
+    int done = d.flags[F_DONE];
+    if (!done && budget > 0) {            // did the last budgeted iteration reach the tolerance? (no K1 ran after it)
+      __syncthreads();
+      double rn = partial_fold_max(partial_load(d.part + (SL_RN0 + (budget & 1)) * kGrid)), bn = partial_fold_max(partial_load(d.part + SL_BN * kGrid));
+      block_max2(rn, bn, lds.red);
+      done = !(rn > fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS])) ? 2 : 0;
+    }
+    if (threadIdx.x == 0) {
+      const int used = done == 1 ? d.flags[F_ITERS] : budget;
+      d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;
+      if (used > d.flags[F_STAT_MAX]) d.flags[F_STAT_MAX] = used;
+      if (!done) d.flags[F_STAT_UNCONV] += 1;
+    }
   }
 }
 

@@ -525,8 +525,9 @@ int Engine::solve() {
     info.dual_obj_val = (-0.5 * res[R_XPX] - res[R_SUPP]) * (settings.scaling ? cinv_ : 1.0);
     info.duality_gap = info.obj_val - info.dual_obj_val;
     if (settings.verbose)
-      std::printf("%4d  %11.4e   %8.2e   %8.2e   %8.2e  %3d  %8.2es   (rho est %.2e, scaled res %.2e / %.2e)\n", iter, info.obj_val, info.prim_res,
-                  info.dual_res, rho_bar_, flags[F_STAT_MAX], now_s() - t0, rho_estimate(res), res[R_PRI_S], res[R_DUA_S]);
+      std::printf("%4d  %11.4e   %8.2e   %8.2e   %8.2e  %3d  %8.2es   (cg mean %.1f budget %d unconv %d; rho est %.2e)\n", iter, info.obj_val, info.prim_res,
+                  info.dual_res, rho_bar_, flags[F_STAT_MAX], now_s() - t0, flags[F_STAT_SUM] / (double)std::max(1, flags[F_STAT_N]), cg_budget_,
+                  flags[F_STAT_UNCONV], rho_estimate(res));
     const bool do_check = (ct > 0 && iter % ct == 0) || iter == settings.max_iter;
     if (do_check && check_termination(res, false)) break;
     if (iter >= settings.max_iter) {                                                     // :1264-1266
