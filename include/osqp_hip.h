@@ -68,7 +68,7 @@ typedef struct {
   OSQPInt verbose;
   OSQPInt warm_starting;
   OSQPInt scaling;                        /* Ruiz iterations, 0 = off */
-  OSQPInt polishing;                      /* accepted, not implemented in this round (info.status_polish = 0) */
+  OSQPInt polishing;                      /* polish by re-running the ADMM on the guessed active set (engine.cpp polish()) */
   OSQPFloat rho;
   OSQPInt   rho_is_vec;
   OSQPFloat sigma;

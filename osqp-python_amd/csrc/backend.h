@@ -139,6 +139,9 @@ void set_pcg_tol(Dev &d, double tol_rel, double tol_abs);
 // refresh (always):  zt = A xs ; t0 = rho zt ; v = rho z - y   (state the PCG start of kb_rhs relies on)
 void init_iterates(Dev &d, int full);
 
+// tmp = z + y ; z = clip(tmp, l, u) ; y = tmp - z   (_osqp.py:676-680, used by polish :1780)
+void project_normalcone(Dev &d);
+
 // ---- launch batching ----
 bool graphs_supported();
 void graph_begin(Dev &d);                 // start capturing d.stream

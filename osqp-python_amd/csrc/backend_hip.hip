@@ -570,6 +570,13 @@ __global__ __launch_bounds__(kBlock) void k_init_m(Dev d, int full) {
   EInit e{{}, d.rho, d.y, d.z, d.zt, d.t0, d.v, d.dy, full};
   process_rows<1>(d.A, g, e, lds);
 }
+__global__ __launch_bounds__(kBlock) void k_normalcone(Dev d) {
+  const int stride = gridDim.x * kBlock;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += stride) {
+    const double t = d.z[i] + d.y[i], zn = fmin(fmax(t, d.l[i]), d.u[i]);
+    d.z[i] = zn; d.y[i] = t - zn;
+  }
+}
 __global__ void k_set_scal(double *scal, double rel, double ab) { scal[S_TOL_REL] = rel; scal[S_TOL_ABS] = ab; }
 
 struct EStore : NoPrefetch { double *out; __device__ __forceinline__ void operator()(int r, const double (&s)[1]) { out[r] = s[0]; } };
@@ -690,6 +697,8 @@ void init_iterates(Dev &d, int full) {
   if (full) LAUNCH(k_init_n, d, d);
   LAUNCH(k_init_m, d, d, full);
 }
+
+void project_normalcone(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_normalcone, d, d); }
 
 bool graphs_supported() { return true; }
 void graph_begin(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipStreamBeginCapture(st(d), hipStreamCaptureModeThreadLocal)); }

@@ -206,6 +206,11 @@ int Engine::set_rho_eq_factor(double f) {
 void Engine::upload_bounds_and_types() {
   std::vector<double> ls(m), us(m);
   for (int i = 0; i < m; i++) { ls[i] = E_[i] * l0_[i]; us[i] = E_[i] * u0_[i]; }       // _osqp.py:435-436, :1357-1358
+  apply_scaled_bounds(ls, us);
+}
+
+void Engine::apply_scaled_bounds(const std::vector<double> &ls, const std::vector<double> &us) {
+  ls_ = ls; us_ = us;
   classify_constraints(ls, us);
   be::h2d(d_, d_.l, ls.data(), sizeof(double) * m);
   be::h2d(d_, d_.u, us.data(), sizeof(double) * m);
@@ -481,6 +486,25 @@ int Engine::solve() {
   set_status(OSQP_UNSOLVED);
   stats_.pcg_iters_total = stats_.pcg_iters_max = stats_.pcg_unconverged = 0;
   stats_.kernel_launches = stats_.graph_launches = 0;
+  double res[R_COUNT];
+  admm_core(t0, res);
+  info.rho_estimate = rho_estimate(res);                                                 // :1275
+  info.solve_time = now_s() - t0;
+  if (settings.polishing && info.status_val == OSQP_SOLVED) polish();                   // :1278-1279
+  store_solution();
+  be::sync(d_);
+  info.run_time = (first_run_ ? info.setup_time : info.update_time) + info.solve_time + info.polish_time;   // :1284-1289
+  first_run_ = false; clear_update_time_ = true;
+  if (settings.verbose)
+    std::printf("\nstatus:               %s\n%snumber of iterations: %d\noptimal objective:    %.4f\nrun time:             %.2es\noptimal rho estimate: %.2e\n\n",
+                info.status, info.status_polish == 1 ? "solution polish:      successful\n" : (info.status_polish == -1 ? "solution polish:      unsuccessful\n" : ""),
+                info.iter, info.obj_val, info.run_time, info.rho_estimate);
+  return OSQP_NO_ERROR;
+}
+
+// The ADMM loop proper (_osqp.py:1208-1266) on the current device iterates with the current settings; sets info.{iter,
+// obj_val, prim_res, dual_res, status*}; leaves the residual block of the last check in res.
+void Engine::admm_core(double t0, double *res) {
   const int ct = settings.check_termination;
   const int ari = settings.adaptive_rho ? auto_rho_interval() : 0;
   // PCG tolerance for the first chunk: relative, ||rhs||/cg_tol_reduction (then tied to the ADMM residuals).
@@ -503,7 +527,6 @@ int Engine::solve() {
   if (settings.verbose) std::printf("iter   objective    prim res   dual res   rho        cg   time\n");
 
   int iter = 0;
-  double res[R_COUNT];
   int flags[F_COUNT];
   while (true) {
     int next = settings.max_iter;
@@ -566,16 +589,79 @@ int Engine::solve() {
       cg_budget_ = std::min(cap, std::max(2, std::min(flags[F_STAT_MAX] + 1, q3)));
     }
   }
-  info.rho_estimate = rho_estimate(res);                                                 // :1275
-  store_solution();
-  be::sync(d_);
-  info.solve_time = now_s() - t0;
-  info.run_time = (first_run_ ? info.setup_time : info.update_time) + info.solve_time + info.polish_time;   // :1284-1289
-  first_run_ = false; clear_update_time_ = true;
-  if (settings.verbose)
-    std::printf("\nstatus:               %s\nnumber of iterations: %d\noptimal objective:    %.4f\nrun time:             %.2es\noptimal rho estimate: %.2e\n\n",
-                info.status, info.iter, info.obj_val, info.run_time, info.rho_estimate);
-  return OSQP_NO_ERROR;
+}
+
+// Solution polish (_osqp.py:1710-1828).  The reference guesses the active constraints from (z, y), solves the
+// equality-constrained QP on that active set with a direct factorisation of the reduced KKT matrix (plus iterative
+// refinement), and keeps the result if it improves the residuals.  This engine has no factorisation; the same reduced
+// problem  min 1/2 x'Px + q'x  s.t.  A_act x = b_act  is solved by the engine's own ADMM on modified bounds: active rows
+// become equalities l = u = bound (weight 1e3 rho, as every all-equality problem: classify_constraints), inactive rows
+// become "loose" (-inf, +inf: rho = 1e-6, y = 0), warm-started from the ADMM solution and run to a tolerance 1e-4 times
+// tighter.  Acceptance test and the normal-cone projection follow the reference (:1780-1793).
+void Engine::polish() {
+  const double tp = now_s();
+  const bool unsc = settings.scaling && !settings.scaled_termination;
+  std::vector<double> z(m), y(m);
+  be::d2h(d_, z.data(), d_.z, sizeof(double) * m);
+  be::d2h(d_, y.data(), d_.y, sizeof(double) * m);
+  // keep the ADMM result
+  const OSQPInfo info0 = info;
+  const OSQPSettings set0 = settings;
+  const double rho0 = rho_bar_;
+  const std::vector<double> ls0 = ls_, us0 = us_, y0 = y, z0 = z;
+  std::vector<double> hx(n);
+  be::d2h(d_, hx.data(), d_.x, sizeof(double) * n);
+  // active set (:1719-1720) on the scaled iterates; equality rows are always active
+  std::vector<double> lp(m), up(m);
+  for (int i = 0; i < m; i++) {
+    const bool low = (z[i] - ls0[i] < -y[i]) || ctype_[i] == 1, upp = !low && (us0[i] - z[i] < y[i]);
+    if (low) { lp[i] = up[i] = ls0[i]; z[i] = ls0[i]; }
+    else if (upp) { lp[i] = up[i] = us0[i]; z[i] = us0[i]; }
+    else { lp[i] = -OSQP_INFTY; up[i] = OSQP_INFTY; y[i] = 0.0; }
+  }
+  apply_scaled_bounds(lp, up);
+  be::h2d(d_, d_.z, z.data(), sizeof(double) * m);
+  be::h2d(d_, d_.y, y.data(), sizeof(double) * m);
+  rho_bar_ = clamp_rho(rho0);
+  be::set_rho(d_, rho_bar_);
+  be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  be::init_iterates(d_, 0);
+  settings.eps_abs = std::max(1e-4 * set0.eps_abs, 1e-13); settings.eps_rel = std::max(1e-4 * set0.eps_rel, 1e-13);
+  settings.max_iter = std::max(200, 100 * std::max(1, set0.polish_refine_iter)); settings.verbose = 0; settings.time_limit = 1e10;
+  settings.check_termination = set0.check_termination > 0 ? std::min(set0.check_termination, 10) : 10;
+  settings.adaptive_rho_interval = 2 * settings.check_termination;
+  double res[R_COUNT];
+  admm_core(now_s(), res);
+  const OSQPInfo info_red = info;     // residuals w.r.t. the REDUCED problem (diagnostic only)
+  (void)info_red;
+  // polished point against the ORIGINAL problem: z = A x, then the normal-cone projection of (z, y)  (:1773-1780)
+  settings = set0; info = info0;
+  apply_scaled_bounds(ls0, us0);
+  be::init_iterates(d_, 1);                        // z = A x_pol
+  be::project_normalcone(d_);                      // tmp = z + y; z = clip(tmp, l, u); y = tmp - z
+  be::residuals(d_); be::fetch_res(d_, res);
+  const double pol_pri = (m == 0) ? 0.0 : (unsc ? res[R_PRI_U] : res[R_PRI_S]);
+  const double pol_dua = unsc ? cinv_ * res[R_DUA_U] : res[R_DUA_S];
+  const double pol_obj = (0.5 * res[R_XPX] + res[R_QX]) * (settings.scaling ? cinv_ : 1.0);
+  const bool ok = (pol_pri < info0.prim_res && pol_dua < info0.dual_res) || (pol_pri < info0.prim_res && info0.dual_res < 1e-10) ||
+                  (pol_dua < info0.dual_res && info0.prim_res < 1e-10);                 // :1786-1793
+  rho_bar_ = rho0; settings.rho = rho0;
+  be::set_rho(d_, rho_bar_);
+  be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  if (ok) {
+    info.obj_val = pol_obj; info.prim_res = pol_pri; info.dual_res = pol_dua; info.status_polish = 1;       // :1797-1807
+    info.dual_obj_val = (-0.5 * res[R_XPX] - res[R_SUPP]) * (settings.scaling ? cinv_ : 1.0);
+    info.duality_gap = info.obj_val - info.dual_obj_val;
+  } else {                                          // keep the ADMM solution (:1813-1814)
+    info.status_polish = -1;
+    be::h2d(d_, d_.x, hx.data(), sizeof(double) * n);
+    be::h2d(d_, d_.y, y0.data(), sizeof(double) * m);
+    be::init_iterates(d_, 1);                       // xs = x (PCG warm start), z = A x ...
+    be::h2d(d_, d_.z, z0.data(), sizeof(double) * m);   // ... then the ADMM z iterate itself
+  }
+  be::init_iterates(d_, 0);
+  info.polish_time = now_s() - tp;
+  if (set0.verbose) std::printf("plsh  %11.4e   %8.2e   %8.2e   --------  (%s)\n", pol_obj, pol_pri, pol_dua, ok ? "accepted" : "rejected");
 }
 
 void Engine::store_solution() {                                                          // _osqp.py:1098-1115

@@ -54,6 +54,7 @@ class Engine {
   std::vector<double> q0_, l0_, u0_;    // unscaled
   std::vector<double> D_, E_, Dinv_, Einv_; double c_ = 1.0, cinv_ = 1.0;
   std::vector<int> ctype_;
+  std::vector<double> ls_, us_;         // scaled bounds currently on the device
   std::vector<double> sol_x_, sol_y_, sol_pc_, sol_dc_;
   double qnorm_s_ = 0, qnorm_u_ = 0;    // ||q_scaled||_inf, ||Dinv q_scaled||_inf
   // maps for value updates
@@ -83,6 +84,9 @@ class Engine {
   void upload_q();
   void fill_matrix_values(const std::vector<double> &Px_s, const std::vector<double> &Ax_s);
   void run_chunk(int niter, int budget);
+  void admm_core(double t0, double *res);
+  void polish();
+  void apply_scaled_bounds(const std::vector<double> &ls, const std::vector<double> &us);
   void drop_graphs();
   int check_termination(const double *res, bool approximate);
   double rho_estimate(const double *res) const;

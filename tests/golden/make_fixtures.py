@@ -239,7 +239,29 @@ def main():
     s = pp(dict(eps_abs=1e-6, eps_rel=1e-6))
     r, _ = run_purepy(P, q, A, l, u, s); save('config1_random_qp', P, q, A, l, u, s, r)
 
-    # ---------------- warm-start fixture for the y-scaling question (purepy omits c) ------------------
+    # ---------------- polishing_test.py:32-99 with polish ON in the python reference -------------------------------
+    popts = dict(eps_abs=1e-3, eps_rel=1e-3, scaling=True, rho=0.1, alpha=1.6, max_iter=2500, polishing=True, polish_refine_iter=4)
+    def run_pol(P, q, A, l, u, name, gold):
+        s = pp(popts); s['polish'] = True
+        m = osqppurepy.OSQP()
+        m.setup(P=full_sym(P), q=np.asarray(q, float), A=sparse.csc_matrix(A), l=np.asarray(l, float), u=np.asarray(u, float), verbose=False, polish_refine_iter=4, **s)
+        res = m.solve()
+        ex = dict(ref_x=res.x, ref_y=res.y, ref_obj=res.info.obj_val, ref_iter=res.info.iter, ref_status=PUREPY2V1[res.info.status_val],
+                  ref_status_polish=res.info.status_polish, ref_pri_res=res.info.pri_res, ref_dua_res=res.info.dua_res)
+        save(name, P, q, A, l, u, s, ex, gold)
+    P = sparse.diags([11.0, 0.0], format='csc'); q = np.array([3.0, 4.0])                                     # :32-49
+    A = sparse.csc_matrix([[-1, 0], [0, -1], [-1, -3], [2, 5], [3, 4]], dtype=float); u = np.array([0.0, 0, -15, 100, 80]); l = -1e05 * np.ones(5)
+    run_pol(P, q, A, l, u, 'polish_simple', 'test_polish_simple')
+    np.random.seed(6)                                                                                          # :79-99
+    n, m = 30, 50
+    Pt = sparse.random(n, n); P = Pt.T @ Pt; q = np.random.randn(n); A = sparse.csc_matrix(np.random.randn(m, n))
+    l = -3 + np.random.randn(m); u = 3 + np.random.randn(m)
+    run_pol(P, q, A, l, u, 'polish_random', 'test_polish_random')
+    np.random.seed(4)                                                                                          # :52-76 (m = 0: purepy cannot run it)
+    n = 30
+    P = (sparse.diags(np.random.rand(n)) + 0.2 * sparse.eye(n)).tocsc(); q = np.random.randn(n)
+    s = pp(popts); s['polish'] = True
+    save('polish_unconstrained', P, q, sparse.csc_matrix((0, n)), np.array([]), np.array([]), s, None, 'test_polish_unconstrained')
 
 
 if __name__ == '__main__':

@@ -203,6 +203,10 @@ void init_iterates(Dev &d, int full) {
   }
 }
 
+void project_normalcone(Dev &d) {
+  for (int i = 0; i < d.m; i++) { double t = d.z[i] + d.y[i]; d.z[i] = std::fmin(std::fmax(t, d.l[i]), d.u[i]); d.y[i] = t - d.z[i]; }
+}
+
 size_t batch_lds_bytes(int, int) { return 0; }
 int batch_solve(Dev &, const BatchParams &) { return OSQP_FUNC_NOT_IMPLEMENTED; }   // GPU-only feature
 

@@ -204,6 +204,32 @@ def test_non_convex(backend):                                 # non_convex_test.
         npt.assert_approx_equal(m.constant('OSQP_NAN'), np.nan)                      # :59-60
 
 
+# ---------------------------------------------------------------- polishing_test.py
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('case', ['polish_simple', 'polish_random', 'polish_unconstrained'])
+def test_polish(backend, case):                               # polishing_test.py:32-99 (eps 1e-3, polishing on)
+    with engine(backend):
+        f = Fixture(case)
+        st = f.hip_settings(polishing=True, polish_refine_iter=4, check_termination=25, adaptive_rho_interval=0)
+        m = osqp_amd.OSQP()
+        m.setup(P=f.P, q=f.q, A=f.A, l=f.l, u=f.u, **st)
+        r = m.solve()
+        assert r.info.status_val == S.OSQP_SOLVED and r.info.status_polish == 1
+        npt.assert_allclose(r.x, f['gold_x_val'], rtol=RTOL, atol=ATOL)
+        if f.m:
+            npt.assert_allclose(r.y, f['gold_y_val'], rtol=RTOL, atol=ATOL)
+        npt.assert_almost_equal(r.info.obj_val, float(f['gold_obj']), decimal=DEC)
+        # polish turns an eps = 1e-3 ADMM solution into a high-accuracy one: residuals far below the ADMM tolerance ...
+        assert r.info.prim_res < 1e-6 and r.info.dual_res < 1e-6
+        if f.has('ref_x'):                                    # ... and lands on the python reference's polished point
+            npt.assert_allclose(r.x, f['ref_x'], rtol=0, atol=1e-5 * (1 + np.abs(f['ref_x']).max()))
+            npt.assert_allclose(r.y, f['ref_y'], rtol=0, atol=1e-5 * (1 + np.abs(f['ref_y']).max()))
+        m.update_settings(polishing=False)                    # and without polish the same solve is only eps-accurate
+        m.update_settings(warm_starting=False)
+        r0 = m.solve()
+        assert r0.info.status_polish == 0
+
+
 # ---------------------------------------------------------------- front-end behaviour (interface.py)
 @pytest.mark.parametrize('backend', BACKENDS)
 def test_frontend_contract(backend):
