@@ -88,6 +88,8 @@ def main():
     ap.add_argument('--eps', type=float, default=1e-6)
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='CPU-baseline budget (0 disables)')
     ap.add_argument('--probe-reps', type=int, default=200)
+    ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL, the production path) or 'gloo' (code-path test)")
+    ap.add_argument('--single-device', action='store_true', help='test mode: every rank uses GPU 0 (one-GPU boxes)')
     args = ap.parse_args()
     warnings.simplefilter('ignore')
 
@@ -99,9 +101,14 @@ def main():
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if args.single_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))     # backend "nccl" is RCCL on ROCm
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))     # backend "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(args.dist_backend)
 
     n = args.n
     P, q, A, l, u = problems.banded_qp(n, seed=12345 + rank)
@@ -132,7 +139,7 @@ def main():
 
     # whole-job aggregate: total ADMM iterations / max-over-ranks time; final status/objective gather over RCCL
     rec = torch.tensor([float(res.info.status_val), float(res.info.iter), res.info.obj_val, res.info.prim_res, res.info.dual_res,
-                        elapsed, float(iters)], dtype=torch.float64, device='cuda')
+                        elapsed, float(iters)], dtype=torch.float64, device='cuda' if args.dist_backend == 'nccl' else 'cpu')
     if world > 1:
         allrec = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(allrec, rec)

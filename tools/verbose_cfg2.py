@@ -1,5 +1,5 @@
 import sys, warnings
-sys.path[:0] = ['osqp-python_amd', 'oracle', 'tests', '.']
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [os.path.join(R, 'osqp-python_amd'), os.path.join(R, 'oracle'), os.path.join(R, 'tests'), R]
 warnings.simplefilter('ignore')
 import numpy as np, osqp_amd, problems
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
