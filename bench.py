@@ -9,9 +9,10 @@ nnz(P)=200k sparse QP (BASELINE configs[1], generator problems.banded_qp, SURVEY
 
 A "step" is one complete cold-started solve of the QP (setup -- scaling, CSR/B assembly, H2D -- is done once, outside the
 timed region: all inputs are resident in HBM when the clock starts).  value = ADMM iterations executed by all ranks in the
-K timed steps / wall time (max over ranks).  With N > 1 every rank owns one independent QP of the same shape (different
-seed): the path shards one-problem-per-GPU with no data-path collective; the only communication is the final all_gather of
-{status, iter, obj, prim_res, dual_res} over RCCL (scaling: weak).
+K timed steps / wall time (max over ranks).  A single QP does not shard (an n-vector all-reduce per PCG iteration would be
+latency-bound over xGMI: DESIGN.md §6), so with N > 1 every rank solves its own replica of the same QP on its own GPU -- one
+problem per GPU, no data-path collective; the only communication is the final all_gather of {status, iter, obj, prim_res,
+dual_res} over RCCL (scaling: weak).  The batched-QP path that really shards a workload is bench_batch.py.
 
 Rank 0 also reports
   roofline      algorithmic bytes per launch / mean launch time (hipEvent pair on the solver's stream) of the dominant PCG
@@ -111,7 +112,7 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     n = args.n
-    P, q, A, l, u = problems.banded_qp(n, seed=12345 + rank)
+    P, q, A, l, u = problems.banded_qp(n, seed=12345)      # replicas: every rank solves the same QP (identical work per GPU)
     settings = dict(eps_abs=args.eps, eps_rel=args.eps, max_iter=20000, check_termination=25, adaptive_rho_interval=50,
                     scaling=10, warm_starting=False, verbose=False, device=local)
     m = osqp_amd.OSQP(algebra='hip')
@@ -169,8 +170,8 @@ def main():
             'value': total_iters / tmax, 'unit': 'ADMM iter/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * tmax / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: single QP n=%d m=%d nnz(A)=%d nnz(P)=%d (problems.banded_qp, seed 12345+rank), '
-                                   'eps_abs=eps_rel=%g, indirect PCG, one independent QP per GPU' % (n, mm, A.nnz, P.nnz, args.eps),
+            'config': {'workload': 'BASELINE configs[1]: single QP n=%d m=%d nnz(A)=%d nnz(P)=%d (problems.banded_qp, seed 12345), '
+                                   'eps_abs=eps_rel=%g, indirect PCG, one replica per GPU' % (n, mm, A.nnz, P.nnz, args.eps),
                        'admm_iters_per_solve': int(res.info.iter), 'status': res.info.status, 'obj_val': res.info.obj_val,
                        'prim_res': res.info.prim_res, 'dual_res': res.info.dual_res, 'rho_updates': int(res.info.rho_updates),
                        'pcg_iters_per_admm_iter': stats['pcg_iters_total'] / max(res.info.iter, 1),
