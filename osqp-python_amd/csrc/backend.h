@@ -44,7 +44,7 @@ enum ResId {
 // indices into the int32 status block
 enum FlagId { F_DONE = 0, F_ITERS, F_STAT_SUM, F_STAT_MAX, F_STAT_UNCONV, F_STAT_SUMSQ, F_STAT_N, F_COUNT };
 // indices into the fp64 scalar block
-enum ScalId { S_TOL_REL = 0, S_TOL_ABS, S_THETA, S_HIST = 8 /* gamma[kMaxCg+1], then alpha[kMaxCg+1] */ };
+enum ScalId { S_TOL_REL = 0, S_TOL_ABS, S_HIST = 8 /* gamma[kMaxCg+1], then alpha[kMaxCg+1] */ };
 
 struct Dev {
   int n = 0, m = 0, device = 0;
@@ -59,10 +59,8 @@ struct Dev {
   // ADMM iterates
   double *x = nullptr, *z = nullptr, *y = nullptr, *dx = nullptr, *dy = nullptr;
   double *xs = nullptr;          // x~ : PCG solution, kept as warm start for the next ADMM iteration
-  double *zt = nullptr;          // A xe  (xe = the PCG start vector, see xe)
-  double *t0 = nullptr;          // rho .* zt  (so K xe = B [xe; t0] needs no extra SpMV)
-  double *xe = nullptr;          // PCG start: xs + theta (xs - xsp), the extrapolated warm start (theta = scal[S_THETA])
-  double *xsp = nullptr, *ztp = nullptr;   // x~ and A x~ of the previous ADMM iteration
+  double *zt = nullptr;          // z~ = A x~
+  double *t0 = nullptr;          // rho .* z~  (so K x~ = B [x~; t0] needs no extra SpMV)
   double *v = nullptr;           // rho .* z - y
   // PCG (Chronopoulos-Gear single-reduction form)
   double *r = nullptr, *uu = nullptr, *p = nullptr, *s = nullptr, *w = nullptr, *t = nullptr, *Minv = nullptr;
@@ -106,7 +104,7 @@ void activate(Dev &d);                  // make d.device current for the calling
 // ---- ADMM hot path (all asynchronous on d.stream) ----
 // KB: x-part of the rhs and the PCG start, one pass over B (two sums per row):
 //   rhs_j = sigma x_j - q_j + (A' v)_j                         (_osqp.py:649-650 folded into the reduced system)
-//   r_j   = rhs_j - (B [xe; t0])_j ;  u_j = Minv_j r_j ;  xs_j = xe_j   (PCG starts from the extrapolated x~)
+//   r_j   = rhs_j - (B [xs; t0])_j ;  u_j = Minv_j r_j
 //   partials: gamma0 = <r,u>, ||r||_inf, ||rhs||_inf ; resets F_DONE/F_ITERS
 void kb_rhs(Dev &d);
 // K1_i: if PCG already converged -> no-op.  Else test ||r_i||_inf <= max(tol_rel*||rhs||_inf, tol_abs); on success set
@@ -118,8 +116,8 @@ void k2(Dev &d, int i);
 //   p = u + beta p ; s = w + beta s ; xs += alpha p ; r -= alpha s ; u = Minv r ; partials gamma_{i+1}, ||r||_inf
 void kv(Dev &d, int i);
 // KA: after the PCG (budget = number of (K1,K2,Kv) triples that were enqueued):
-//   z~ = A xs ; z,y update (_osqp.py:682-703) ; v = rho z - y ; dy ; zt = z~ + theta (z~ - ztp) ; t0 = rho zt ; ztp = z~ ;
-//   and elementwise  x = alpha xs + (1-alpha) x ; dx (_osqp.py:660-668) ; xe = xs + theta (xs - xsp) ; xsp = xs.  Also folds the PCG statistics of this ADMM iteration.
+//   z~ = A xs ; z,y update (_osqp.py:682-703) ; v = rho z - y ; t0 = rho z~ ; dy ; and, on extra workgroups,
+//   x = alpha xs + (1-alpha) x ; dx (_osqp.py:660-668).  Also folds the PCG statistics of this ADMM iteration.
 void ka(Dev &d, int budget);
 
 // ---- every check_termination iterations ----
@@ -136,10 +134,9 @@ void set_rho(Dev &d, double rho_bar);
 // Minv_j = 1 / (B_jj + sum_i rho_i A_ij^2)   (diag of K; B_jj already contains sigma).  precond==0 -> Minv = 1
 void precond(Dev &d, int diagonal);
 void set_pcg_tol(Dev &d, double tol_rel, double tol_abs);
-void set_theta(Dev &d, double theta);     // warm-start extrapolation factor in [0, 1]
 
 // full != 0 (after warm_start / cold_start, _osqp.py:1493-1509):  z = A x ; xs = x ; dx = dy = 0, then the refresh;
-// refresh (always):  xe = xsp = xs ; zt = ztp = A xs ; t0 = rho zt ; v = rho z - y   (state kb_rhs relies on)
+// refresh (always):  zt = A xs ; t0 = rho zt ; v = rho z - y   (state the PCG start of kb_rhs relies on)
 void init_iterates(Dev &d, int full);
 
 // tmp = z + y ; z = clip(tmp, l, u) ; y = tmp - z   (_osqp.py:676-680, used by polish :1780)

@@ -226,26 +226,26 @@ struct NoPrefetch { __device__ __forceinline__ void prefetch(int) {} };
 // ---------------------------------------------------------------------------------------------- hot-path kernels
 // KB ------------------------------------------------------------------------------------------
 struct GKb {
-  const double *xe, *v, *t0; int n;
+  const double *xs, *v, *t0; int n;
   __device__ __forceinline__ void operator()(int c, double a, double (&pr)[2]) const {
-    if (c < n) { pr[0] = 0.0; pr[1] = a * xe[c]; }
+    if (c < n) { pr[0] = 0.0; pr[1] = a * xs[c]; }
     else { pr[0] = a * v[c - n]; pr[1] = a * t0[c - n]; }
   }
 };
 struct EKb {
-  const double *x, *q, *Minv, *xe; double *r, *uu, *xs; double sigma; double g = 0, rn = 0, bn = 0; double px = 0, pq = 0, pm = 0, pe = 0;
-  __device__ __forceinline__ void prefetch(int j) { px = x[j]; pq = q[j]; pm = Minv[j]; pe = xe[j]; }
+  const double *x, *q, *Minv; double *r, *uu; double sigma; double g = 0, rn = 0, bn = 0; double px = 0, pq = 0, pm = 0;
+  __device__ __forceinline__ void prefetch(int j) { px = x[j]; pq = q[j]; pm = Minv[j]; }
   __device__ __forceinline__ void operator()(int j, const double (&s)[2]) {
     const double rhs = sigma * px - pq + s[0];
     const double rr = rhs - s[1], u = pm * rr;
-    r[j] = rr; uu[j] = u; xs[j] = pe;                      // the PCG iterates on xs, starting from the extrapolated xe
+    r[j] = rr; uu[j] = u;
     g += rr * u; rn = nanmax(rn, fabs(rr)); bn = nanmax(bn, fabs(rhs));
   }
 };
 __global__ __launch_bounds__(kBlock) void k_kb(Dev d) {
   __shared__ StreamLds<2> lds;
-  GKb g{d.xe, d.v, d.t0, d.n};
-  EKb e{d.x, d.q, d.Minv, d.xe, d.r, d.uu, d.xs, d.sigma};
+  GKb g{d.xs, d.v, d.t0, d.n};
+  EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma};
   process_rows<2>(d.B, g, e, lds);
   __syncthreads();
   const double G = block_sum(e.g, lds.red);
@@ -378,29 +378,26 @@ __global__ __launch_bounds__(kBlock) void k_kv(Dev d, int i, int probe) {
 
 // KA ------------------------------------------------------------------------------------------
 struct EKa {
-  const double *l, *u, *rho, *rho_inv; double *z, *y, *zt, *t0, *v, *dy, *ztp; double alpha, theta;
-  double pl = 0, pu = 0, prho = 0, prinv = 0, pz = 0, py = 0, pzp = 0;
-  __device__ __forceinline__ void prefetch(int i) { pl = l[i]; pu = u[i]; prho = rho[i]; prinv = rho_inv[i]; pz = z[i]; py = y[i]; pzp = ztp[i]; }
+  const double *l, *u, *rho, *rho_inv; double *z, *y, *zt, *t0, *v, *dy; double alpha;
+  double pl = 0, pu = 0, prho = 0, prinv = 0, pz = 0, py = 0;
+  __device__ __forceinline__ void prefetch(int i) { pl = l[i]; pu = u[i]; prho = rho[i]; prinv = rho_inv[i]; pz = z[i]; py = y[i]; }
   __device__ __forceinline__ void operator()(int i, const double (&s)[1]) {
     const double ztil = s[0];
     const double zr = alpha * ztil + (1.0 - alpha) * pz;                    // _osqp.py:686-690
     const double zn = fmin(fmax(zr + prinv * py, pl), pu);                   // :674
     const double dyi = prho * (zr - zn), yn = py + dyi;                      // :698-703
-    const double ze = ztil + theta * (ztil - pzp);                           // A xe by linearity (extrapolated PCG start)
-    y[i] = yn; dy[i] = dyi; z[i] = zn; zt[i] = ze; ztp[i] = ztil; v[i] = prho * zn - yn; t0[i] = prho * ze;
+    y[i] = yn; dy[i] = dyi; z[i] = zn; zt[i] = ztil; v[i] = prho * zn - yn; t0[i] = prho * ztil;
   }
 };
 __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
   __shared__ StreamLds<1> lds;
   GVec g{d.xs};
-  const double theta = d.scal[S_THETA];
-  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.ztp, d.alpha, theta};
+  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha};
   process_rows<1>(d.A, g, e, lds);
   const int stride = gridDim.x * kBlock;
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) {    // _osqp.py:664-668
-    const double xo = d.x[j], xt = d.xs[j], xn = d.alpha * xt + (1.0 - d.alpha) * xo;
+    const double xo = d.x[j], xn = d.alpha * d.xs[j] + (1.0 - d.alpha) * xo;
     d.dx[j] = xn - xo; d.x[j] = xn;
-    d.xe[j] = xt + theta * (xt - d.xsp[j]); d.xsp[j] = xt;
   }
   if (blockIdx.x == 0) {                                                     // PCG statistics of this ADMM iteration
     int done = d.flags[F_DONE];
@@ -555,25 +552,22 @@ __global__ __launch_bounds__(kBlock) void k_fill(double *p, int n, double v) {
   const int stride = gridDim.x * kBlock;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) p[i] = v;
 }
-__global__ __launch_bounds__(kBlock) void k_init_n(Dev d, int full) {
+__global__ __launch_bounds__(kBlock) void k_init_n(Dev d) {
   const int stride = gridDim.x * kBlock;
-  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) {
-    if (full) { d.xs[j] = d.x[j]; d.dx[j] = 0.0; }
-    d.xe[j] = d.xs[j]; d.xsp[j] = d.xs[j];
-  }
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) { d.xs[j] = d.x[j]; d.dx[j] = 0.0; }
 }
 struct EInit : NoPrefetch {
-  const double *rho, *y; double *z, *zt, *t0, *v, *dy, *ztp; int full;
+  const double *rho, *y; double *z, *zt, *t0, *v, *dy; int full;
   __device__ __forceinline__ void operator()(int i, const double (&s)[1]) {
     const double a = s[0];
     if (full) { z[i] = a; dy[i] = 0.0; }
-    zt[i] = a; ztp[i] = a; t0[i] = rho[i] * a; v[i] = rho[i] * z[i] - y[i];
+    zt[i] = a; t0[i] = rho[i] * a; v[i] = rho[i] * z[i] - y[i];
   }
 };
 __global__ __launch_bounds__(kBlock) void k_init_m(Dev d, int full) {
   __shared__ StreamLds<1> lds;
   GVec g{d.xs};
-  EInit e{{}, d.rho, d.y, d.z, d.zt, d.t0, d.v, d.dy, d.ztp, full};
+  EInit e{{}, d.rho, d.y, d.z, d.zt, d.t0, d.v, d.dy, full};
   process_rows<1>(d.A, g, e, lds);
 }
 __global__ __launch_bounds__(kBlock) void k_normalcone(Dev d) {
@@ -584,7 +578,6 @@ __global__ __launch_bounds__(kBlock) void k_normalcone(Dev d) {
   }
 }
 __global__ void k_set_scal(double *scal, double rel, double ab) { scal[S_TOL_REL] = rel; scal[S_TOL_ABS] = ab; }
-__global__ void k_set_theta(double *scal, double th) { scal[S_THETA] = th; }
 
 struct EStore : NoPrefetch { double *out; __device__ __forceinline__ void operator()(int r, const double (&s)[1]) { out[r] = s[0]; } };
 __global__ __launch_bounds__(kBlock) void k_test_spmv(DevCsr M, const double *in, double *out) {
@@ -699,13 +692,9 @@ void set_pcg_tol(Dev &d, double rel, double ab) {
   HIP_CHECK(hipSetDevice(d.device));
   hipLaunchKernelGGL(k_set_scal, dim3(1), dim3(1), 0, st(d), d.scal, rel, ab);
 }
-void set_theta(Dev &d, double th) {
-  HIP_CHECK(hipSetDevice(d.device));
-  hipLaunchKernelGGL(k_set_theta, dim3(1), dim3(1), 0, st(d), d.scal, th);
-}
 void init_iterates(Dev &d, int full) {
   HIP_CHECK(hipSetDevice(d.device));
-  LAUNCH(k_init_n, d, d, full);
+  if (full) LAUNCH(k_init_n, d, d);
   LAUNCH(k_init_m, d, d, full);
 }
 
@@ -738,7 +727,7 @@ float time_kernel(Dev &d, int which, int reps) {
   const size_t n = d.n, m = d.m;
   Save sv[] = {{d.x, n, nullptr}, {d.z, m, nullptr}, {d.y, m, nullptr}, {d.xs, n, nullptr}, {d.zt, m, nullptr}, {d.t0, m, nullptr},
                {d.v, m, nullptr}, {d.dx, n, nullptr}, {d.dy, m, nullptr}, {d.r, n, nullptr}, {d.uu, n, nullptr}, {d.p, n, nullptr},
-               {d.s, n, nullptr}, {d.w, n, nullptr}, {d.t, m, nullptr}, {d.xe, n, nullptr}, {d.xsp, n, nullptr}, {d.ztp, m, nullptr}};
+               {d.s, n, nullptr}, {d.w, n, nullptr}, {d.t, m, nullptr}};
   int flags_bak[F_COUNT];
   HIP_CHECK(hipStreamSynchronize(st(d)));
   HIP_CHECK(hipMemcpy(flags_bak, d.flags, sizeof(flags_bak), hipMemcpyDeviceToHost));

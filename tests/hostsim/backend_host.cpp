@@ -41,7 +41,7 @@ void kb_rhs(Dev &d) {
     double sA = 0, sK = 0;
     for (int k = d.B.rowptr[j]; k < d.B.rowptr[j + 1]; k++) {
       int c = d.B.col[k]; double v = d.B.val[k];
-      if (c < d.n) sK += v * d.xe[c];
+      if (c < d.n) sK += v * d.xs[c];
       else { sA += v * d.v[c - d.n]; sK += v * d.t0[c - d.n]; }
     }
     double rhs = d.sigma * d.x[j] - d.q[j] + sA;
@@ -49,7 +49,6 @@ void kb_rhs(Dev &d) {
     d.r[j] = r; d.uu[j] = u;
     g += r * u; rn = nanmax(rn, std::fabs(r)); bn = nanmax(bn, std::fabs(rhs));
   }
-  for (int j = 0; j < d.n; j++) d.xs[j] = d.xe[j];
   s.gamma_next = g; s.rnorm = rn; s.bnorm = bn;
   d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0;
 }
@@ -104,14 +103,12 @@ void ka(Dev &d, int budget) {
     double zr = d.alpha * zt + (1.0 - d.alpha) * d.z[i];
     double zn = std::fmin(std::fmax(zr + d.rho_inv[i] * d.y[i], d.l[i]), d.u[i]);
     double dy = d.rho[i] * (zr - zn);
-    const double th = d.scal[S_THETA], ze = zt + th * (zt - d.ztp[i]);
-    d.y[i] += dy; d.dy[i] = dy; d.z[i] = zn; d.zt[i] = ze; d.ztp[i] = zt;
-    d.v[i] = d.rho[i] * zn - d.y[i]; d.t0[i] = d.rho[i] * ze;
+    d.y[i] += dy; d.dy[i] = dy; d.z[i] = zn; d.zt[i] = zt;
+    d.v[i] = d.rho[i] * zn - d.y[i]; d.t0[i] = d.rho[i] * zt;
   }
   for (int j = 0; j < d.n; j++) {
     double xn = d.alpha * d.xs[j] + (1.0 - d.alpha) * d.x[j];
     d.dx[j] = xn - d.x[j]; d.x[j] = xn;
-    d.xe[j] = d.xs[j] + d.scal[S_THETA] * (d.xs[j] - d.xsp[j]); d.xsp[j] = d.xs[j];
   }
   int used = d.flags[F_DONE] ? d.flags[F_ITERS] : budget;
   d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;
@@ -195,7 +192,6 @@ void precond(Dev &d, int diagonal) {
   }
 }
 void set_pcg_tol(Dev &d, double rel, double ab) { d.scal[S_TOL_REL] = rel; d.scal[S_TOL_ABS] = ab; }
-void set_theta(Dev &d, double th) { d.scal[S_THETA] = th; }
 
 void init_iterates(Dev &d, int full) {
   if (full) for (int j = 0; j < d.n; j++) { d.xs[j] = d.x[j]; d.dx[j] = 0; }
@@ -203,9 +199,8 @@ void init_iterates(Dev &d, int full) {
     double a = 0;
     for (int k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; k++) a += d.A.val[k] * d.xs[d.A.col[k]];
     if (full) { d.z[i] = a; d.dy[i] = 0; }
-    d.zt[i] = a; d.ztp[i] = a; d.t0[i] = d.rho[i] * a; d.v[i] = d.rho[i] * d.z[i] - d.y[i];
+    d.zt[i] = a; d.t0[i] = d.rho[i] * a; d.v[i] = d.rho[i] * d.z[i] - d.y[i];
   }
-  for (int j = 0; j < d.n; j++) { d.xe[j] = d.xs[j]; d.xsp[j] = d.xs[j]; }
 }
 
 void project_normalcone(Dev &d) {
