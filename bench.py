@@ -162,9 +162,17 @@ def main():
         probes = {}
         for which, name in enumerate(kb):
             ms = s.hip_time_kernel(which, args.probe_reps)
-            probes[name] = {'ms': ms, 'bytes': kb[name], 'GBps': kb[name] / (ms * 1e-3) / 1e9}
+            probes[name] = {'ms_same_kernel_repeat': ms, 'bytes': kb[name]}
+        # in-sequence times: T(K1,K2,Kv) minus T(sequence without the kernel); this is what a solve pays (L2-cold matrices)
+        pcg_ms = s.hip_time_kernel(6, args.probe_reps)
+        for name, which in zip(list(kb)[:3], (8, 7, 9)):
+            probes[name]['ms'] = max(pcg_ms - s.hip_time_kernel(which, args.probe_reps), 1e-6)
+        for name in list(kb)[3:]:
+            probes[name]['ms'] = probes[name]['ms_same_kernel_repeat']
+        for name in kb:
+            probes[name]['GBps'] = kb[name] / (probes[name]['ms'] * 1e-3) / 1e9
         dom = 'K2 spmv B (w=B[u;t], <w,u>)'
-        pcg_bytes = sum(kb[k] for k in list(kb)[:3]); pcg_ms = s.hip_time_kernel(6, args.probe_reps)   # K1,K2,Kv alternating, reductions included (as in a solve)
+        pcg_bytes = sum(kb[k] for k in list(kb)[:3])
         out = {
             'metric': 'ADMM iterations/sec, n=%d m=%d nnz(A)=%d sparse QP (indirect PCG)' % (n, mm, A.nnz),
             'value': total_iters / tmax, 'unit': 'ADMM iter/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

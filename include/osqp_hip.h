@@ -186,7 +186,9 @@ OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
    return its mean duration in milliseconds (hipEvent pair on that stream).  which: 0 = SpMV A (K1),
    1 = SpMV B (K2), 2 = PCG vector update (Kv), 3 = rhs kernel (KB), 4 = A x~ + z,y,x update (KA),
    5 = one whole PCG iteration (K1, K2, Kv in sequence; time per sequence) without the reductions of partials,
-   6 = the same with them (what a solve executes).
+   6 = the same with them (what a solve executes); 7 / 8 / 9 = sequence 6 without K2 / K1 / Kv, so that (6) - (7) is
+   K2's time INSIDE the sequence, i.e. with the caches in the state a solve leaves them (a same-kernel repeat keeps the
+   matrix L2-resident and flatters the kernel).
    The kernels run in a side-effect-free "probe" mode; solver state is unchanged. */
 OSQPInt osqp_hip_time_kernel(OSQPSolver *solver, OSQPInt which, OSQPInt reps, double *mean_ms);
 

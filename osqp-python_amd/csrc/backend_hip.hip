@@ -736,6 +736,9 @@ float time_kernel(Dev &d, int which, int reps) {
     HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s.bak), s.cnt * sizeof(double)));
     HIP_CHECK(hipMemcpy(s.bak, s.ptr, s.cnt * sizeof(double), hipMemcpyDeviceToDevice));
   }
+  auto K1 = [&](int pr) { LAUNCH(k_k1, d, d, 1, pr); };
+  auto K2 = [&]() { LAUNCH(k_k2, d, d, 1); };
+  auto KV = [&](int pr) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, 1, pr); else LAUNCH(k_kv<1>, d, d, 1, pr); };
   auto launch = [&]() {
     switch (which) {
       case 0: LAUNCH(k_k1, d, d, 1, 1); break;
@@ -743,8 +746,11 @@ float time_kernel(Dev &d, int which, int reps) {
       case 2: if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, 1, 1); else LAUNCH(k_kv<1>, d, d, 1, 1); break;
       case 3: LAUNCH(k_kb, d, d); break;
       case 4: LAUNCH(k_ka, d, d, 0); break;
-      case 5: LAUNCH(k_k1, d, d, 1, 1); LAUNCH(k_k2, d, d, 1); if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, 1, 1); else LAUNCH(k_kv<1>, d, d, 1, 1); break;   // one PCG iteration, no reductions
-      default: LAUNCH(k_k1, d, d, 1, 2); LAUNCH(k_k2, d, d, 1); if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, 1, 2); else LAUNCH(k_kv<1>, d, d, 1, 2); break;   // ... with the reductions (as in a solve)
+      case 5: K1(1); K2(); KV(1); break;      // one PCG iteration, reductions of partials skipped
+      case 6: K1(2); K2(); KV(2); break;      // one PCG iteration as a solve executes it
+      case 7: K1(2); KV(2); break;            // ... without K2   (6 minus 7 = K2's time inside the sequence, L2-cold like in a solve)
+      case 8: K2(); KV(2); break;             // ... without K1
+      default: K1(2); K2(); break;            // ... without Kv
     }
   };
   for (int w = 0; w < 5; w++) launch();

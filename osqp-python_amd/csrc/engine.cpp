@@ -847,7 +847,7 @@ int Engine::get_stats(OSQPHipStats *out) { if (!out) return OSQP_DATA_VALIDATION
 int Engine::time_kernel(int which, int reps, double *ms) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);
-  if (which < 0 || which > 6 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
+  if (which < 0 || which > 9 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
   *ms = be::time_kernel(d_, which, reps);
   return OSQP_NO_ERROR;
 }

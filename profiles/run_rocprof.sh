@@ -9,6 +9,8 @@ out=/tmp/prof_$tag; rm -rf $out; mkdir -p $out gpurun_out
 tail -2 $out/bench_stdout.log > gpurun_out/rocprof_${tag}_bench.json
 f=$(find $out -name '*kernel_stats.csv' | head -1)
 if [ -n "$f" ]; then cp "$f" gpurun_out/rocprof_${tag}_kernel_stats.csv; fi
+t=$(find $out -name '*kernel_trace.csv' | head -1)
+if [ -n "$t" ]; then python $repo/profiles/active_stats.py "$t" gpurun_out/rocprof_${tag}_active_stats.csv; fi
 find $out -name '*.csv' -size -2M -not -name '*kernel_trace*' -exec cp {} gpurun_out/ \; 2>/dev/null
 ls -la $out $(dirname "$f") 2>/dev/null | head -20
 cat gpurun_out/rocprof_${tag}_kernel_stats.csv 2>/dev/null | head -30
