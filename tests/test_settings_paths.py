@@ -1,0 +1,83 @@
+"""Less-travelled settings of the engine against the oracle (both tiers): scaling on/off, scaled termination, scalar rho,
+no preconditioner, alpha change after setup (captured graphs must be rebuilt), time limit, settings validation."""
+import warnings
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+import osqp_amd
+import problems
+from backend_param import BACKENDS, engine
+from oracle import Oracle, SOLVED
+
+warnings.simplefilter('ignore')
+S = osqp_amd.SolverStatus
+P, q, A, l, u = problems.banded_qp(600, window=30, seed=9)
+XO, YO, IO = Oracle().setup(P, q, A, l, u, eps_abs=1e-10, eps_rel=1e-10, max_iter=200000, adaptive_rho_interval=50).solve()
+assert IO.status_val == SOLVED
+
+
+def solve(**kw):
+    st = dict(eps_abs=1e-7, eps_rel=1e-7, verbose=False, max_iter=50000)
+    st.update(kw)
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, **st)
+    return m, m.solve()
+
+
+def close(r, tol=2e-5):
+    assert r.info.status_val == S.OSQP_SOLVED
+    npt.assert_allclose(r.x, XO, rtol=0, atol=tol * (1 + np.abs(XO).max()))
+    npt.assert_allclose(r.y, YO, rtol=0, atol=tol * (1 + np.abs(YO).max()))
+    assert abs(r.info.obj_val - IO.obj_val) <= 1e-6 * (1 + abs(IO.obj_val))
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('kw', [dict(scaling=0), dict(scaling=3), dict(scaled_termination=True), dict(rho_is_vec=False),
+                                dict(cg_preconditioner=None), dict(adaptive_rho=False, rho=0.3), dict(check_termination=7, adaptive_rho_interval=21),
+                                dict(alpha=1.0), dict(sigma=1e-4), dict(cg_max_iter=7), dict(cg_tol_fraction=0.5)],
+                         ids=lambda k: ','.join('%s=%s' % kv for kv in k.items()))
+def test_setting_variants_reach_the_same_solution(backend, kw):
+    with engine(backend):
+        m, r = solve(**kw)
+        close(r)
+        if 'scaled_termination' in kw or kw.get('scaling') == 0:       # residual definitions follow the oracle's for these modes
+            o = Oracle().setup(P, q, A, l, u, eps_abs=1e-7, eps_rel=1e-7, max_iter=50000, adaptive_rho_interval=50, check_termination=25,
+                               scaling=kw.get('scaling', 10), scaled_termination=int(kw.get('scaled_termination', False)))
+            xo, yo, io = o.solve()
+            assert io.status_val == SOLVED and abs(np.log10(r.info.prim_res + 1e-30) - np.log10(io.pri_res + 1e-30)) < 3
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_alpha_update_after_solve_rebuilds_launch_graphs(backend):
+    with engine(backend):
+        m, r1 = solve(alpha=1.6, warm_starting=False)
+        m.update_settings(alpha=1.0)
+        r2 = m.solve()
+        m2, r3 = solve(alpha=1.0, warm_starting=False, rho=m.settings.rho if False else 0.1)
+        close(r2)
+        if r1.info.rho_updates == 0:                                  # same state as a fresh alpha=1.0 solver
+            assert r2.info.iter == r3.info.iter and np.array_equal(r2.x, r3.x)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_time_limit_and_validation(backend):
+    with engine(backend):
+        m, r = solve(time_limit=1e-9, eps_abs=1e-12, eps_rel=1e-12)
+        assert r.info.status_val == S.OSQP_TIME_LIMIT_REACHED and r.info.iter > 0
+        for bad in (dict(rho=-1.0), dict(sigma=0.0), dict(alpha=2.5), dict(max_iter=0), dict(eps_abs=-1.0), dict(cg_max_iter=0),
+                    dict(adaptive_rho_tolerance=0.5), dict(check_termination=-1), dict(scaling=-2), dict(verbose=3)):
+            with pytest.raises(osqp_amd.OSQPException) as ei:
+                osqp_amd.OSQP().setup(P, q, A, l, u, **bad)
+            assert ei.value == osqp_amd.SolverError.OSQP_SETTINGS_VALIDATION_ERROR, bad
+        with pytest.raises(osqp_amd.OSQPException):                   # update_settings validates too (bindings.cpp.in:204-209)
+            m.update_settings(eps_rel=-1.0)
+        # malformed data: P with a lower-triangular entry straight through the ext layer, wrong dimensions
+        ext = m.ext
+        import scipy.sparse as sp
+        s = ext.OSQPSettings(); ext.osqp_set_default_settings(s)
+        bad_P = ext.CSC(sp.csc_matrix(np.array([[1.0, 0.0], [1.0, 1.0]])))
+        with pytest.raises(ValueError, match='1'):
+            ext.OSQPSolver(bad_P, np.zeros(2), ext.CSC(sp.eye(2, format='csc')), -np.ones(2), np.ones(2), 2, 2, s)
+        with pytest.raises(ValueError, match='1'):
+            ext.OSQPSolver(ext.CSC(sp.eye(3, format='csc')), np.zeros(2), ext.CSC(sp.eye(2, format='csc')), -np.ones(2), np.ones(2), 2, 2, s)
