@@ -61,6 +61,12 @@ struct Red {   // block reductions over kBB threads: all threads get the result
 
 namespace {
 
+// EA / EB > 0: every lane keeps EA entries of A and EB entries of B (value + column) in registers for the whole solve
+// (entry k belongs to lane k % kBB); an SpMV is then  prod[k] = val * v[col]  for the lane's own entries (LDS only),
+// a barrier, and one lane per row summing its segment of prod -- no matrix traffic inside the ADMM / PCG loops and a
+// balanced first phase (the MPC rows have 1..13 entries).  EA = EB = 0: generic row loops reading the matrices from
+// global memory (L1/L2), for patterns with more than 8 * kBB entries per matrix.
+template <int EA, int EB>
 __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = P.n, m = P.m, tid = threadIdx.x, b = blockIdx.x;
@@ -69,7 +75,50 @@ __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
   double *x = sm, *xs = x + n, *r = xs + n, *zv = r + n, *p = zv + n, *Kp = p + n, *q = Kp + n, *Minv = q + n, *dx = Minv + n, *tn = dx + n;
   double *z = tn + n, *y = z + m, *t = y + m, *l = t + m, *u = l + m, *rho = u + m, *zt = rho + m, *dy = zt + m;
   Red red{dy + m};
+  double *prod = dy + m + 16;                       // max(nnzA, nnzB) products (register path only)
   const DevCsr &A = P.A, &B = P.B;
+  constexpr bool kReg = EA > 0;
+  double aA[EA > 0 ? EA : 1], aB[EB > 0 ? EB : 1];
+  int cA[EA > 0 ? EA : 1], cB[EB > 0 ? EB : 1];
+  if constexpr (kReg) {
+#pragma unroll
+    for (int e = 0; e < EA; e++) { const int k = tid + e * kBB; const bool ok = k < A.nnz; aA[e] = ok ? A.val[k] : 0.0; cA[e] = ok ? A.col[k] : 0; }
+#pragma unroll
+    for (int e = 0; e < EB; e++) { const int k = tid + e * kBB; const bool ok = k < B.nnz; aB[e] = ok ? B.val[k] : 0.0; cB[e] = ok ? B.col[k] : 0; }
+  }
+  // out_i = f(i, (A v)_i)  for every row i of A
+  auto applyA = [&](const double *v, auto &&f) {
+    if constexpr (kReg) {
+#pragma unroll
+      for (int e = 0; e < EA; e++) { const int k = tid + e * kBB; if (k < A.nnz) prod[k] = aA[e] * v[cA[e]]; }
+      __syncthreads();
+      for (int i = tid; i < m; i += kBB) { double a = 0.0; for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) a += prod[k]; f(i, a); }
+      __syncthreads();
+    } else {
+      for (int i = tid; i < m; i += kBB) { double a = 0.0; for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) a += A.val[k] * v[A.col[k]]; f(i, a); }
+      __syncthreads();
+    }
+  };
+  // f(j, (B [pn; pm])_j) for every row j of B; pn == nullptr drops the P + sigma I part, pm == nullptr the A' part
+  auto applyB = [&](const double *pn, const double *pm, auto &&f) {
+    if constexpr (kReg) {
+#pragma unroll
+      for (int e = 0; e < EB; e++) {
+        const int k = tid + e * kBB;
+        if (k < B.nnz) { const int c = cB[e]; prod[k] = c < n ? (pn ? aB[e] * pn[c] : 0.0) : (pm ? aB[e] * pm[c - n] : 0.0); }
+      }
+      __syncthreads();
+      for (int j = tid; j < n; j += kBB) { double a = 0.0; for (int k = B.rowptr[j]; k < B.rowptr[j + 1]; k++) a += prod[k]; f(j, a); }
+      __syncthreads();
+    } else {
+      for (int j = tid; j < n; j += kBB) {
+        double a = 0.0;
+        for (int k = B.rowptr[j]; k < B.rowptr[j + 1]; k++) { const int c = B.col[k]; a += c < n ? (pn ? B.val[k] * pn[c] : 0.0) : (pm ? B.val[k] * pm[c - n] : 0.0); }
+        f(j, a);
+      }
+      __syncthreads();
+    }
+  };
   // ---- load the problem ----
   for (int j = tid; j < n; j += kBB) { q[j] = P.q[(size_t)b * n + j]; x[j] = P.warm ? P.x[(size_t)b * n + j] : 0.0; dx[j] = 0.0; }
   int n_ineq_local = 0;
@@ -158,30 +207,25 @@ __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
     iter++;
     // ---- rhs = sigma x - q + A'(rho z - y);  r = rhs - K xs with K xs = B[xs; rho zt]   (_osqp.py:649-650) ----
     double rz_l = 0, rn_l = 0, bn_l = 0;
-    for (int j = tid; j < n; j += kBB) {
-      double sA = 0.0, sK = 0.0;
-      for (int k = B.rowptr[j]; k < B.rowptr[j + 1]; k++) {
-        const int c = B.col[k]; const double a = B.val[k];
-        if (c < n) sK += a * xs[c];
-        else { const int i = c - n; sA += a * (rho[i] * z[i] - y[i]); sK += a * (rho[i] * zt[i]); }
-      }
-      const double rhs = P.sigma * x[j] - q[j] + sA, rr = rhs - sK, zz = Minv[j] * rr;
+    for (int i = tid; i < m; i += kBB) t[i] = rho[i] * z[i] - y[i];
+    __syncthreads();
+    applyB(nullptr, t, [&](int j, double sA) { Kp[j] = P.sigma * x[j] - q[j] + sA; });          // Kp holds rhs for a moment
+    for (int i = tid; i < m; i += kBB) t[i] = rho[i] * zt[i];
+    __syncthreads();
+    applyB(xs, t, [&](int j, double sK) {
+      const double rhs = Kp[j], rr = rhs - sK, zz = Minv[j] * rr;
       r[j] = rr; zv[j] = zz; p[j] = zz;
       rz_l += rr * zz; rn_l = nmax(rn_l, fabs(rr)); bn_l = nmax(bn_l, fabs(rhs));
-    }
+    });
     double rz = rz_l, rn = rn_l;
     red.sum_max(rz, rn);
     const double bn = red.max(bn_l);
     const double tol = rel_rule ? fmax(0.1 * bn, 1e-13) : fmax(1e-14 * bn, eps_cg);
     // ---- PCG on K = P + sigma I + A' diag(rho) A ----
     for (int it = 0; it < P.cg_max && rn > tol; it++) {
-      spmv_A(p, t, true);                                              // t = rho .* (A p)
+      applyA(p, [&](int i, double a) { t[i] = rho[i] * a; });              // t = rho .* (A p)
       double pkp_l = 0.0;
-      for (int j = tid; j < n; j += kBB) {
-        double a = 0.0;
-        for (int k = B.rowptr[j]; k < B.rowptr[j + 1]; k++) { const int c = B.col[k]; a += B.val[k] * (c < n ? p[c] : t[c - n]); }
-        Kp[j] = a; pkp_l += a * p[j];
-      }
+      applyB(p, t, [&](int j, double a) { Kp[j] = a; pkp_l += a * p[j]; });
       const double pkp = red.sum(pkp_l);
       const double al = rz / pkp;
       double rz2 = 0.0, rn2 = 0.0;
@@ -199,15 +243,13 @@ __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
       pcg_total++;
     }
     // ---- z~ = A xs; x, z, y update (_osqp.py:660-703) ----
-    for (int i = tid; i < m; i += kBB) {
-      double a = 0.0;
-      for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) a += A.val[k] * xs[A.col[k]];
+    applyA(xs, [&](int i, double a) {
       const double rh = rho[i], yi = y[i];
       const double zr = P.alpha * a + (1.0 - P.alpha) * z[i];
       const double zn = fmin(fmax(zr + yi / rh, l[i]), u[i]);
       const double dyi = rh * (zr - zn);
       y[i] = yi + dyi; dy[i] = dyi; z[i] = zn; zt[i] = a;
-    }
+    });
     for (int j = tid; j < n; j += kBB) { const double xo = x[j], xn = P.alpha * xs[j] + (1.0 - P.alpha) * xo; dx[j] = xn - xo; x[j] = xn; }
     __syncthreads();
 
@@ -295,18 +337,33 @@ __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
 
 }  // namespace
 
-// LDS needed per problem (bytes); 0 if the problem does not fit one workgroup's LDS
-size_t batch_lds_bytes(int n, int m) {
-  const size_t b = sizeof(double) * ((size_t)10 * n + (size_t)8 * m + 16);
+// LDS needed per problem (bytes); 0 if the problem does not fit one workgroup's LDS.  nnz > 0 adds the product buffer of
+// the register-resident path.
+size_t batch_lds_bytes_nnz(int n, int m, int nnz) {
+  const size_t b = sizeof(double) * ((size_t)10 * n + (size_t)8 * m + 16 + (size_t)nnz);
   return b <= 64 * 1024 ? b : 0;
 }
+size_t batch_lds_bytes(int n, int m) { return batch_lds_bytes_nnz(n, m, 0); }
 
 int batch_solve(Dev &d, const BatchParams &p) {
-  const size_t lds = batch_lds_bytes(p.n, p.m);
-  if (!lds) return OSQP_FUNC_NOT_IMPLEMENTED;
   if (hipSetDevice(d.device) != hipSuccess) return OSQP_ALGEBRA_LOAD_ERROR;
-  hipLaunchKernelGGL(k_batch_admm, dim3(p.nbatch), dim3(kBB), lds, static_cast<hipStream_t>(d.stream), p);
-  hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(d.stream));
+  hipStream_t st = static_cast<hipStream_t>(d.stream);
+  const int ea = (p.A.nnz + kBB - 1) / kBB, eb = (p.B.nnz + kBB - 1) / kBB, mx = p.A.nnz > p.B.nnz ? p.A.nnz : p.B.nnz;
+  const size_t lds_reg = batch_lds_bytes_nnz(p.n, p.m, mx), lds_gen = batch_lds_bytes(p.n, p.m);
+  if (lds_reg && ea <= 8 && eb <= 8 && !std::getenv("OSQP_HIP_BATCH_GENERIC")) {
+    const int e = (ea > eb ? ea : eb) <= 2 ? 2 : ((ea > eb ? ea : eb) <= 4 ? 4 : ((ea > eb ? ea : eb) <= 6 ? 6 : 8));
+    switch (e) {
+      case 2: hipLaunchKernelGGL((k_batch_admm<2, 2>), dim3(p.nbatch), dim3(kBB), lds_reg, st, p); break;
+      case 4: hipLaunchKernelGGL((k_batch_admm<4, 4>), dim3(p.nbatch), dim3(kBB), lds_reg, st, p); break;
+      case 6: hipLaunchKernelGGL((k_batch_admm<6, 6>), dim3(p.nbatch), dim3(kBB), lds_reg, st, p); break;
+      default: hipLaunchKernelGGL((k_batch_admm<8, 8>), dim3(p.nbatch), dim3(kBB), lds_reg, st, p); break;
+    }
+  } else if (lds_gen) {
+    hipLaunchKernelGGL((k_batch_admm<0, 0>), dim3(p.nbatch), dim3(kBB), lds_gen, st, p);
+  } else {
+    return OSQP_FUNC_NOT_IMPLEMENTED;
+  }
+  hipError_t e = hipStreamSynchronize(st);
   if (e != hipSuccess) { std::fprintf(stderr, "osqp_hip: batch kernel failed: %s\n", hipGetErrorString(e)); std::abort(); }
   return OSQP_NO_ERROR;
 }
