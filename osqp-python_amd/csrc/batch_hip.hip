@@ -14,6 +14,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "../../include/osqp_hip.h"
 #include "backend.h"
@@ -22,37 +23,60 @@ namespace osqp_hip {
 namespace be {
 
 namespace {
-constexpr int kBB = 256;   // threads per problem
 
 __device__ __forceinline__ double nmax(double r, double a) { return (a > r || a != a) ? a : r; }
 
-struct Red {   // block reductions over kBB threads: all threads get the result
-  double *s;   // >= 16 doubles of LDS
+// Block reductions; all threads get the result.  NW = waves per workgroup.  With ONE wave per problem (NW = 1) a
+// reduction is six __shfl_xor steps: no LDS, no barrier.
+template <int NW>
+struct Red {
+  double *s;   // >= 16 doubles of LDS (NW > 1 only)
   __device__ __forceinline__ double sum(double v) const {
+    if constexpr (NW == 1) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const double t = (s[0] + s[1]) + (s[2] + s[3]);
-    __syncthreads();
-    return t;
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      return v;
+    } else {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+      __syncthreads();
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) t += s[w];
+      __syncthreads();
+      return t;
+    }
   }
   __device__ __forceinline__ double max(double v) const {
+    if constexpr (NW == 1) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = nmax(v, __shfl_down(v, o, 64));
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const double t = nmax(nmax(s[0], s[1]), nmax(s[2], s[3]));
-    __syncthreads();
-    return t;
+      for (int o = 32; o > 0; o >>= 1) v = nmax(v, __shfl_xor(v, o, 64));
+      return v;
+    } else {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v = nmax(v, __shfl_down(v, o, 64));
+      if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+      __syncthreads();
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) t = nmax(t, s[w]);
+      __syncthreads();
+      return t;
+    }
   }
-  __device__ __forceinline__ void sum_max(double &a, double &b) const {   // a: sum, b: max, one barrier pair
+  __device__ __forceinline__ void sum_max(double &a, double &b) const {   // a: sum, b: max
+    if constexpr (NW == 1) { a = sum(a); b = max(b); }
+    else {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b = nmax(b, __shfl_down(b, o, 64)); }
-    if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = a; s[4 + (threadIdx.x >> 6)] = b; }
-    __syncthreads();
-    a = (s[0] + s[1]) + (s[2] + s[3]); b = nmax(nmax(s[4], s[5]), nmax(s[6], s[7]));
-    __syncthreads();
+      for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b = nmax(b, __shfl_down(b, o, 64)); }
+      if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = a; s[8 + (threadIdx.x >> 6)] = b; }
+      __syncthreads();
+      a = 0.0; b = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) { a += s[w]; b = nmax(b, s[8 + w]); }
+      __syncthreads();
+    }
   }
 };
 
@@ -61,12 +85,13 @@ struct Red {   // block reductions over kBB threads: all threads get the result
 
 namespace {
 
+// kBB = threads per problem: 64 (one wave: barriers are free, reductions are pure shuffles; small problems) or 256.
 // EA / EB > 0: every lane keeps EA entries of A and EB entries of B (value + column) in registers for the whole solve
 // (entry k belongs to lane k % kBB); an SpMV is then  prod[k] = val * v[col]  for the lane's own entries (LDS only),
 // a barrier, and one lane per row summing its segment of prod -- no matrix traffic inside the ADMM / PCG loops and a
 // balanced first phase (the MPC rows have 1..13 entries).  EA = EB = 0: generic row loops reading the matrices from
 // global memory (L1/L2), for patterns with more than 8 * kBB entries per matrix.
-template <int EA, int EB>
+template <int kBB, int EA, int EB>
 __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = P.n, m = P.m, tid = threadIdx.x, b = blockIdx.x;
@@ -74,7 +99,7 @@ __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
   // ---- LDS carve ----
   double *x = sm, *xs = x + n, *r = xs + n, *zv = r + n, *p = zv + n, *Kp = p + n, *q = Kp + n, *Minv = q + n, *dx = Minv + n, *tn = dx + n;
   double *z = tn + n, *y = z + m, *t = y + m, *l = t + m, *u = l + m, *rho = u + m, *zt = rho + m, *dy = zt + m;
-  Red red{dy + m};
+  Red<kBB / 64> red{dy + m};
   double *prod = dy + m + 16;                       // max(nnzA, nnzB) products (register path only)
   const DevCsr &A = P.A, &B = P.B;
   constexpr bool kReg = EA > 0;
@@ -348,21 +373,24 @@ size_t batch_lds_bytes(int n, int m) { return batch_lds_bytes_nnz(n, m, 0); }
 int batch_solve(Dev &d, const BatchParams &p) {
   if (hipSetDevice(d.device) != hipSuccess) return OSQP_ALGEBRA_LOAD_ERROR;
   hipStream_t st = static_cast<hipStream_t>(d.stream);
-  const int ea = (p.A.nnz + kBB - 1) / kBB, eb = (p.B.nnz + kBB - 1) / kBB, mx = p.A.nnz > p.B.nnz ? p.A.nnz : p.B.nnz;
+  const int mx = p.A.nnz > p.B.nnz ? p.A.nnz : p.B.nnz;
   const size_t lds_reg = batch_lds_bytes_nnz(p.n, p.m, mx), lds_gen = batch_lds_bytes(p.n, p.m);
-  if (lds_reg && ea <= 8 && eb <= 8 && !std::getenv("OSQP_HIP_BATCH_GENERIC")) {
-    const int e = (ea > eb ? ea : eb) <= 2 ? 2 : ((ea > eb ? ea : eb) <= 4 ? 4 : ((ea > eb ? ea : eb) <= 6 ? 6 : 8));
-    switch (e) {
-      case 2: hipLaunchKernelGGL((k_batch_admm<2, 2>), dim3(p.nbatch), dim3(kBB), lds_reg, st, p); break;
-      case 4: hipLaunchKernelGGL((k_batch_admm<4, 4>), dim3(p.nbatch), dim3(kBB), lds_reg, st, p); break;
-      case 6: hipLaunchKernelGGL((k_batch_admm<6, 6>), dim3(p.nbatch), dim3(kBB), lds_reg, st, p); break;
-      default: hipLaunchKernelGGL((k_batch_admm<8, 8>), dim3(p.nbatch), dim3(kBB), lds_reg, st, p); break;
-    }
+  const char *force = std::getenv("OSQP_HIP_BATCH_VARIANT");      // debugging: "w64", "w256", "generic"
+  const int e64 = (mx + 63) / 64, e256 = (mx + 255) / 256;
+  const bool can64 = lds_reg && e64 <= 24 && p.n <= 1024 && p.m <= 2048, can256 = lds_reg && e256 <= 8;
+  const bool use64 = force ? !std::strcmp(force, "w64") && can64 : can64;
+  const bool use256 = !use64 && (force ? !std::strcmp(force, "w256") && can256 : can256);
+#define BATCH_LAUNCH(TB, E, LDS) hipLaunchKernelGGL((k_batch_admm<TB, E, E>), dim3(p.nbatch), dim3(TB), LDS, st, p)
+  if (use64) {
+    if (e64 <= 8) BATCH_LAUNCH(64, 8, lds_reg); else if (e64 <= 16) BATCH_LAUNCH(64, 16, lds_reg); else BATCH_LAUNCH(64, 24, lds_reg);
+  } else if (use256) {
+    if (e256 <= 2) BATCH_LAUNCH(256, 2, lds_reg); else if (e256 <= 4) BATCH_LAUNCH(256, 4, lds_reg); else BATCH_LAUNCH(256, 8, lds_reg);
   } else if (lds_gen) {
-    hipLaunchKernelGGL((k_batch_admm<0, 0>), dim3(p.nbatch), dim3(kBB), lds_gen, st, p);
+    BATCH_LAUNCH(256, 0, lds_gen);
   } else {
     return OSQP_FUNC_NOT_IMPLEMENTED;
   }
+#undef BATCH_LAUNCH
   hipError_t e = hipStreamSynchronize(st);
   if (e != hipSuccess) { std::fprintf(stderr, "osqp_hip: batch kernel failed: %s\n", hipGetErrorString(e)); std::abort(); }
   return OSQP_NO_ERROR;
