@@ -80,8 +80,9 @@ struct BatchParams {
   const double *D, *Dinv, *E, *Einv;
   double c, cinv, sigma, alpha, rho0, eq_factor, eps_abs, eps_rel, eps_pinf, eps_dinf, cg_frac, rho_tol;
   int max_iter, check, rho_interval, cg_max, unscaled, scaling, precond, rho_is_vec, warm;
-  const double *q, *l, *u;      // scaled, [nbatch][n] / [nbatch][m]
-  double *x, *y;                // in: scaled warm start (if warm), out: UNSCALED solution  [nbatch][n] / [nbatch][m]
+  const double *q, *l, *u;      // UNSCALED, [nbatch][n] / [nbatch][m]; nullptr = the shared vector q0 / l0 / u0 for every problem
+  const double *q0, *l0, *u0;   // UNSCALED shared vectors [n] / [m]
+  double *x, *y;                // in: UNSCALED warm start (if warm), out: UNSCALED solution  [nbatch][n] / [nbatch][m]
   double *rec;                  // [nbatch][8]: status, iter, obj, prim_res, dual_res, rho, rho_updates, pcg_iters
 };
 

@@ -145,11 +145,16 @@ __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
     }
   };
   // ---- load the problem ----
-  for (int j = tid; j < n; j += kBB) { q[j] = P.q[(size_t)b * n + j]; x[j] = P.warm ? P.x[(size_t)b * n + j] : 0.0; dx[j] = 0.0; }
+  // inputs arrive UNSCALED; the scaling of update_lin_cost / update_bounds / warm_start (_osqp.py:1328, :1357-1358, :1505-1506)
+  // is applied here:  q <- c D q,  l,u <- E clamp(l,u),  x <- Dinv x,  y <- c Einv y
+  for (int j = tid; j < n; j += kBB) {
+    q[j] = P.c * P.D[j] * (P.q ? P.q[(size_t)b * n + j] : P.q0[j]);
+    x[j] = P.warm ? P.x[(size_t)b * n + j] * P.Dinv[j] : 0.0; dx[j] = 0.0;
+  }
   int n_ineq_local = 0;
   for (int i = tid; i < m; i += kBB) {
-    const double li = P.l[(size_t)b * m + i], ui = P.u[(size_t)b * m + i];
-    l[i] = li; u[i] = ui; y[i] = P.warm ? P.y[(size_t)b * m + i] : 0.0; dy[i] = 0.0;
+    const double li = P.E[i] * fmax(P.l ? P.l[(size_t)b * m + i] : P.l0[i], -OSQP_INFTY), ui = P.E[i] * fmin(P.u ? P.u[(size_t)b * m + i] : P.u0[i], OSQP_INFTY);
+    l[i] = li; u[i] = ui; y[i] = P.warm ? P.y[(size_t)b * m + i] * P.Einv[i] * P.c : 0.0; dy[i] = 0.0;
     int ty = (li < -OSQP_INFTY * 1e-4 && ui > OSQP_INFTY * 1e-4) ? -1 : ((ui - li < 1e-4) ? 1 : 0);   // _osqp.py:505-518
     if (!P.rho_is_vec) ty = 0;
     n_ineq_local += (ty == 0);

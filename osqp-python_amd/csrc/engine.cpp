@@ -80,6 +80,7 @@ void Engine::free_all() {
   be::activate(d_);
   be::sync(d_);
   drop_graphs();
+  if (bbuf_) { be::dfree(d_, bbuf_); bbuf_ = nullptr; bbuf_cap_ = 0; }
   void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag,
                   d_.q, d_.l, d_.u, d_.D, d_.Dinv, d_.E, d_.Einv, d_.rho, d_.rho_inv, d_.ctype, d_.x, d_.z, d_.y, d_.dx,
                   d_.dy, d_.xs, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.part, d_.res,
@@ -807,25 +808,24 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   if (nbatch <= 0 || !x || !y || !rec) return OSQP_DATA_VALIDATION_ERROR;
   if (!be::batch_lds_bytes(n, m)) return OSQP_FUNC_NOT_IMPLEMENTED;
   be::activate(d_);
+  const bool timing = std::getenv("OSQP_HIP_BATCH_TIMING") != nullptr;
+  double tph[5]; tph[0] = now_s();
   const size_t N = (size_t)nbatch * n, M = (size_t)nbatch * m;
-  std::vector<double> qs(N), ls(M), us(M), xs(N, 0.0), ys(M, 0.0);
-  for (int b = 0; b < nbatch; b++) {
-    const double *qb = q ? q + (size_t)b * n : q0_.data(), *lb = l ? l + (size_t)b * m : l0_.data(), *ub = u ? u + (size_t)b * m : u0_.data();
-    for (int j = 0; j < n; j++) qs[(size_t)b * n + j] = c_ * D_[j] * qb[j];                          // _osqp.py:1328
+  for (int b = 0; b < nbatch && (l || u); b++)                                                       // _osqp.py:1348-1349
     for (int i = 0; i < m; i++) {
-      const double li = std::max(lb[i], -OSQP_INFTY), ui = std::min(ub[i], OSQP_INFTY);               // interface.py:334-337
+      const double li = l ? l[(size_t)b * m + i] : l0_[i], ui = u ? u[(size_t)b * m + i] : u0_[i];
       if (!(li <= ui)) return OSQP_DATA_VALIDATION_ERROR;
-      ls[(size_t)b * m + i] = E_[i] * li; us[(size_t)b * m + i] = E_[i] * ui;                         // :1357-1358
     }
-    if (warm) {
-      for (int j = 0; j < n; j++) xs[(size_t)b * n + j] = x[(size_t)b * n + j] * Dinv_[j];
-      for (int i = 0; i < m; i++) ys[(size_t)b * m + i] = y[(size_t)b * m + i] * Einv_[i] * c_;
-    }
-  }
-  auto dv = [&](size_t cnt) { return dev_vec<double>(d_, cnt); };
-  double *dq = dv(N), *dl = dv(M), *du = dv(M), *dx = dv(N), *dy = dv(M), *drec = dv((size_t)nbatch * 8);
-  be::h2d(d_, dq, qs.data(), sizeof(double) * N); be::h2d(d_, dl, ls.data(), sizeof(double) * M); be::h2d(d_, du, us.data(), sizeof(double) * M);
-  if (warm) { be::h2d(d_, dx, xs.data(), sizeof(double) * N); be::h2d(d_, dy, ys.data(), sizeof(double) * M); }
+  tph[1] = now_s();
+  // one device scratch block, kept for the next call: [q | l | u | x | y | rec | q0 | l0 | u0]
+  const size_t need = 2 * N + 3 * M + (size_t)nbatch * 8 + n + 2 * (size_t)m;
+  if (need > bbuf_cap_) { if (bbuf_) be::dfree(d_, bbuf_); bbuf_ = dev_vec<double>(d_, need); bbuf_cap_ = need; }
+  double *dq = bbuf_, *dl = dq + N, *du = dl + M, *dx = du + M, *dy = dx + N, *drec = dy + M, *dq0 = drec + (size_t)nbatch * 8, *dl0 = dq0 + n, *du0 = dl0 + m;
+  if (q) be::h2d(d_, dq, q, sizeof(double) * N); else be::h2d(d_, dq0, q0_.data(), sizeof(double) * n);
+  if (l) be::h2d(d_, dl, l, sizeof(double) * M); else be::h2d(d_, dl0, l0_.data(), sizeof(double) * m);
+  if (u) be::h2d(d_, du, u, sizeof(double) * M); else be::h2d(d_, du0, u0_.data(), sizeof(double) * m);
+  if (warm) { be::h2d(d_, dx, x, sizeof(double) * N); be::h2d(d_, dy, y, sizeof(double) * M); }
+  be::sync(d_); tph[2] = now_s();
   BatchParams p{};
   p.n = n; p.m = m; p.nbatch = nbatch; p.A = d_.A; p.B = d_.B; p.D = d_.D; p.Dinv = d_.Dinv; p.E = d_.E; p.Einv = d_.Einv;
   p.c = c_; p.cinv = cinv_; p.sigma = settings.sigma; p.alpha = settings.alpha; p.rho0 = clamp_rho(settings.rho); p.eq_factor = eq_factor_mixed_;
@@ -834,12 +834,15 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   p.max_iter = settings.max_iter; p.check = settings.check_termination; p.rho_interval = settings.adaptive_rho ? auto_rho_interval() : 0;
   p.cg_max = settings.cg_max_iter; p.unscaled = settings.scaling && !settings.scaled_termination; p.scaling = settings.scaling;
   p.precond = settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER; p.rho_is_vec = settings.rho_is_vec; p.warm = warm;
-  p.q = dq; p.l = dl; p.u = du; p.x = dx; p.y = dy; p.rec = drec;
+  p.q = q ? dq : nullptr; p.l = l ? dl : nullptr; p.u = u ? du : nullptr; p.q0 = dq0; p.l0 = dl0; p.u0 = du0; p.x = dx; p.y = dy; p.rec = drec;
   int err = be::batch_solve(d_, p);
+  tph[3] = now_s();
   if (!err) {
     be::d2h(d_, x, dx, sizeof(double) * N); be::d2h(d_, y, dy, sizeof(double) * M); be::d2h(d_, rec, drec, sizeof(double) * 8 * nbatch);
   }
-  for (double *ptr : {dq, dl, du, dx, dy, drec}) be::dfree(d_, ptr);
+  tph[4] = now_s();
+  stats_.gpu_solve_ms = 1e3 * (tph[3] - tph[2]);
+  if (timing) std::fprintf(stderr, "osqp_hip batch: validate %.2f ms, H2D %.2f ms, kernel %.2f ms, D2H %.2f ms\n", 1e3 * (tph[1] - tph[0]), 1e3 * (tph[2] - tph[1]), 1e3 * (tph[3] - tph[2]), 1e3 * (tph[4] - tph[3]));
   return err;
 }
 

@@ -72,6 +72,7 @@ class Engine {
   bool have_tol_ = false;
   bool use_graph_ = true;
   std::map<std::pair<int, int>, void *> graphs_;
+  double *bbuf_ = nullptr; size_t bbuf_cap_ = 0;      // device scratch of batch_solve, kept across calls
   OSQPHipStats stats_{};
   double update_time_acc_ = 0;
   bool clear_update_time_ = false;

@@ -241,11 +241,7 @@ class OSQPSolver:
         arrs = [a for a in (q, l, u, x0, y0) if a is not None]
         B = int(nbatch) if nbatch is not None else int(np.asarray(arrs[0]).shape[0])
         q, l, u = (None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(B, -1) for a in (q, l, u))
-        if l is not None:
-            l = np.maximum(l, -OSQP_INFTY)
-        if u is not None:
-            u = np.minimum(u, OSQP_INFTY)
-        warm = x0 is not None or y0 is not None
+        warm = x0 is not None      # (l, u are clamped to +-OSQP_INFTY inside the kernel, like interface.py:334-337) or y0 is not None
         x = np.zeros((B, self.n)) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).reshape(B, self.n).copy()
         y = np.zeros((B, self.m)) if y0 is None else np.ascontiguousarray(y0, dtype=np.float64).reshape(B, self.m).copy()
         rec = np.zeros((B, 8))
