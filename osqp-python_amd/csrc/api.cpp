@@ -7,6 +7,18 @@ using osqp_hip::Engine;
 
 namespace {
 Engine *eng(OSQPSolver *s) { return s ? reinterpret_cast<Engine *>(s->work) : nullptr; }
+
+// Every entry point runs its body under this guard: a failed HIP call (osqp_hip::DeviceError) or an allocation failure
+// comes back to the caller as an osqp_error_type value, never as an exception across the C ABI and never as abort().
+template <class F>
+OSQPInt guarded(OSQPSolver *s, F &&f) {
+  Engine *e = eng(s);
+  if (!e) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  try { return f(*e); }
+  catch (const std::bad_alloc &) { return OSQP_MEM_ALLOC_ERROR; }
+  catch (const osqp_hip::DeviceError &) { return OSQP_ALGEBRA_LOAD_ERROR; }
+  catch (...) { return OSQP_LINSYS_SOLVER_INIT_ERROR; }
+}
 }
 
 extern "C" {
@@ -39,24 +51,25 @@ OSQPInt osqp_setup(OSQPSolver **solverp, const OSQPCscMatrix *P, const OSQPFloat
   int err;
   try { err = e->setup(P, q, A, l, u, m, n, settings); }
   catch (const std::bad_alloc &) { err = OSQP_MEM_ALLOC_ERROR; }
+  catch (const osqp_hip::DeviceError &) { err = OSQP_ALGEBRA_LOAD_ERROR; }
   catch (...) { err = OSQP_LINSYS_SOLVER_INIT_ERROR; }
   if (err) { delete e; return err; }
   *solverp = &e->pub;
   return OSQP_NO_ERROR;
 }
 
-OSQPInt osqp_solve(OSQPSolver *s) { Engine *e = eng(s); return e ? e->solve() : OSQP_WORKSPACE_NOT_INIT_ERROR; }
+OSQPInt osqp_solve(OSQPSolver *s) { return guarded(s, [&](Engine &e) { return e.solve(); }); }
 OSQPInt osqp_cleanup(OSQPSolver *s) { Engine *e = eng(s); if (e) delete e; return OSQP_NO_ERROR; }
-OSQPInt osqp_warm_start(OSQPSolver *s, const OSQPFloat *x, const OSQPFloat *y) { Engine *e = eng(s); return e ? e->warm_start(x, y) : OSQP_WORKSPACE_NOT_INIT_ERROR; }
-OSQPInt osqp_cold_start(OSQPSolver *s) { Engine *e = eng(s); return e ? e->cold_start() : OSQP_WORKSPACE_NOT_INIT_ERROR; }
+OSQPInt osqp_warm_start(OSQPSolver *s, const OSQPFloat *x, const OSQPFloat *y) { return guarded(s, [&](Engine &e) { return e.warm_start(x, y); }); }
+OSQPInt osqp_cold_start(OSQPSolver *s) { return guarded(s, [&](Engine &e) { return e.cold_start(); }); }
 OSQPInt osqp_update_data_vec(OSQPSolver *s, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u) {
-  Engine *e = eng(s); return e ? e->update_data_vec(q, l, u) : OSQP_WORKSPACE_NOT_INIT_ERROR;
+  return guarded(s, [&](Engine &e) { return e.update_data_vec(q, l, u); });
 }
 OSQPInt osqp_update_data_mat(OSQPSolver *s, const OSQPFloat *Px, const OSQPInt *Pi, OSQPInt Pn, const OSQPFloat *Ax, const OSQPInt *Ai, OSQPInt An) {
-  Engine *e = eng(s); return e ? e->update_data_mat(Px, Pi, Pn, Ax, Ai, An) : OSQP_WORKSPACE_NOT_INIT_ERROR;
+  return guarded(s, [&](Engine &e) { return e.update_data_mat(Px, Pi, Pn, Ax, Ai, An); });
 }
-OSQPInt osqp_update_settings(OSQPSolver *s, const OSQPSettings *ns) { Engine *e = eng(s); return e ? e->update_settings(ns) : OSQP_WORKSPACE_NOT_INIT_ERROR; }
-OSQPInt osqp_update_rho(OSQPSolver *s, OSQPFloat rho) { Engine *e = eng(s); return e ? e->update_rho(rho) : OSQP_WORKSPACE_NOT_INIT_ERROR; }
+OSQPInt osqp_update_settings(OSQPSolver *s, const OSQPSettings *ns) { return guarded(s, [&](Engine &e) { return e.update_settings(ns); }); }
+OSQPInt osqp_update_rho(OSQPSolver *s, OSQPFloat rho) { return guarded(s, [&](Engine &e) { return e.update_rho(rho); }); }
 void osqp_get_dimensions(OSQPSolver *s, OSQPInt *m, OSQPInt *n) { Engine *e = eng(s); if (e) { if (m) *m = e->m; if (n) *n = e->n; } }
 
 OSQPInt osqp_adjoint_derivative_compute(OSQPSolver *, OSQPFloat *, OSQPFloat *) { return OSQP_FUNC_NOT_IMPLEMENTED; }
@@ -68,13 +81,13 @@ void osqp_set_default_codegen_defines(OSQPCodegenDefines *d) {
   d->embedded_mode = 1; d->float_type = 0; d->printing_enable = 0; d->profiling_enable = 0; d->interrupt_enable = 0; d->derivatives_enable = 0;
 }
 
-OSQPInt osqp_hip_get_stats(OSQPSolver *s, OSQPHipStats *out) { Engine *e = eng(s); return e ? e->get_stats(out) : OSQP_WORKSPACE_NOT_INIT_ERROR; }
-OSQPInt osqp_hip_time_kernel(OSQPSolver *s, OSQPInt which, OSQPInt reps, double *ms) { Engine *e = eng(s); return e ? e->time_kernel(which, reps, ms) : OSQP_WORKSPACE_NOT_INIT_ERROR; }
-OSQPInt osqp_hip_test_spmv(OSQPSolver *s, OSQPInt which, const OSQPFloat *in, OSQPFloat *out) { Engine *e = eng(s); return e ? e->test_spmv(which, in, out) : OSQP_WORKSPACE_NOT_INIT_ERROR; }
-OSQPInt osqp_hip_set_rho_eq_factor(OSQPSolver *s, OSQPFloat f) { Engine *e = eng(s); return e ? e->set_rho_eq_factor(f) : OSQP_WORKSPACE_NOT_INIT_ERROR; }
+OSQPInt osqp_hip_get_stats(OSQPSolver *s, OSQPHipStats *out) { return guarded(s, [&](Engine &e) { return e.get_stats(out); }); }
+OSQPInt osqp_hip_time_kernel(OSQPSolver *s, OSQPInt which, OSQPInt reps, double *ms) { return guarded(s, [&](Engine &e) { return e.time_kernel(which, reps, ms); }); }
+OSQPInt osqp_hip_test_spmv(OSQPSolver *s, OSQPInt which, const OSQPFloat *in, OSQPFloat *out) { return guarded(s, [&](Engine &e) { return e.test_spmv(which, in, out); }); }
+OSQPInt osqp_hip_set_rho_eq_factor(OSQPSolver *s, OSQPFloat f) { return guarded(s, [&](Engine &e) { return e.set_rho_eq_factor(f); }); }
 OSQPInt osqp_hip_batch_solve(OSQPSolver *s, OSQPInt nbatch, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u, OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm) {
-  Engine *e = eng(s); return e ? e->batch_solve(nbatch, q, l, u, x, y, rec, warm) : OSQP_WORKSPACE_NOT_INIT_ERROR;
+  return guarded(s, [&](Engine &e) { return e.batch_solve(nbatch, q, l, u, x, y, rec, warm); });
 }
-OSQPInt osqp_hip_get_scaling(OSQPSolver *s, OSQPFloat *D, OSQPFloat *E, OSQPFloat *c) { Engine *e = eng(s); return e ? e->get_scaling(D, E, c) : OSQP_WORKSPACE_NOT_INIT_ERROR; }
+OSQPInt osqp_hip_get_scaling(OSQPSolver *s, OSQPFloat *D, OSQPFloat *E, OSQPFloat *c) { return guarded(s, [&](Engine &e) { return e.get_scaling(D, E, c); }); }
 
 }  // extern "C"

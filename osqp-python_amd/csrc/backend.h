@@ -17,8 +17,13 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <stdexcept>
 
 namespace osqp_hip {
+
+// A failed HIP runtime call.  Thrown by the backend, caught at the C-API boundary (api.cpp) and reported as an
+// osqp_error_type value -- the library never calls abort() and never falls back to a CPU path.
+struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
 
 constexpr int kBlock = 256;        // threads per workgroup (4 wave64)
 constexpr int kGrid = 1024;        // workgroups per launch = number of partial-reduction slots

@@ -33,8 +33,10 @@ namespace be {
   do {                                                                                                        \
     hipError_t e_ = (expr);                                                                                   \
     if (e_ != hipSuccess) {                                                                                   \
-      std::fprintf(stderr, "osqp_hip: HIP error %s at %s:%d (%s)\n", hipGetErrorString(e_), __FILE__, __LINE__, #expr); \
-      std::abort();                                                                                           \
+      char msg_[512];                                                                                         \
+      std::snprintf(msg_, sizeof(msg_), "osqp_hip: HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #expr); \
+      std::fprintf(stderr, "%s\n", msg_);                                                                     \
+      throw DeviceError(msg_);                                                                                \
     }                                                                                                         \
   } while (0)
 
@@ -299,7 +301,6 @@ struct EK2 {
   __device__ __forceinline__ void prefetch(int j) { pu = uu[j]; }
   __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { w[j] = s[0]; dl += s[0] * pu; }
 };
-struct PreFlag { const int *flags; int probe; __device__ __forceinline__ bool operator()() const { return probe || !flags[F_DONE]; } };
 __global__ __launch_bounds__(kBlock) void k_k2(Dev d, int probe) {
   __shared__ StreamLds<1> lds;
   if (!probe && d.flags[F_DONE]) return;
@@ -615,7 +616,7 @@ int init(Dev &d, int device) {
 }
 void destroy(Dev &d) {
   if (!d.impl) return;
-  HIP_CHECK(hipSetDevice(d.device));
+  (void)hipSetDevice(d.device);
   Impl &p = im(d);
   (void)hipEventDestroy(p.ev0); (void)hipEventDestroy(p.ev1); (void)hipHostFree(p.pin_res); (void)hipHostFree(p.pin_flags);
   delete &p; d.impl = nullptr;
@@ -628,7 +629,7 @@ void *alloc(Dev &d, size_t bytes) {
   HIP_CHECK(hipMemsetAsync(p, 0, bytes, st(d)));
   return p;
 }
-void dfree(Dev &d, void *p) { HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipFree(p)); }
+void dfree(Dev &d, void *p) { (void)hipSetDevice(d.device); (void)hipFree(p); }     // best effort: runs in destructors
 void h2d(Dev &d, void *dst, const void *src, size_t b) {
   if (!b) return;
   HIP_CHECK(hipSetDevice(d.device));
@@ -710,7 +711,7 @@ void *graph_end(Dev &d) {
   return ex;
 }
 void graph_launch(Dev &d, void *g) { HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipGraphLaunch(static_cast<hipGraphExec_t>(g), st(d))); }
-void graph_free(Dev &d, void *g) { if (g) { HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipGraphExecDestroy(static_cast<hipGraphExec_t>(g))); } }
+void graph_free(Dev &d, void *g) { if (g) { (void)hipSetDevice(d.device); (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(g)); } }
 
 void test_spmv(Dev &d, int which, const double *in, double *out) {
   HIP_CHECK(hipSetDevice(d.device));

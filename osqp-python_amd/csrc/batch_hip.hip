@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include "../../include/osqp_hip.h"
 #include "backend.h"
@@ -397,7 +398,7 @@ int batch_solve(Dev &d, const BatchParams &p) {
   }
 #undef BATCH_LAUNCH
   hipError_t e = hipStreamSynchronize(st);
-  if (e != hipSuccess) { std::fprintf(stderr, "osqp_hip: batch kernel failed: %s\n", hipGetErrorString(e)); std::abort(); }
+  if (e != hipSuccess) throw DeviceError(std::string("osqp_hip: batch kernel failed: ") + hipGetErrorString(e));
   return OSQP_NO_ERROR;
 }
 

@@ -77,8 +77,7 @@ void Engine::drop_graphs() {
 
 void Engine::free_all() {
   if (!dev_ready_) return;
-  be::activate(d_);
-  be::sync(d_);
+  try { be::activate(d_); be::sync(d_); } catch (const DeviceError &) {}       // runs in the destructor: release what we can
   drop_graphs();
   if (bbuf_) { be::dfree(d_, bbuf_); bbuf_ = nullptr; bbuf_cap_ = 0; }
   void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag,
@@ -586,8 +585,8 @@ void Engine::admm_core(double t0, double *res) {
       // set the budget of the next 25 iterations (an occasional budget-limited solve is just a slightly less exact one)
       const double cnt = std::max(1, flags[F_STAT_N]), mean = flags[F_STAT_SUM] / cnt;
       const double var = std::max(0.0, flags[F_STAT_SUMSQ] / cnt - mean * mean);
-      const int q3 = (int)std::ceil(mean + 3.0 * std::sqrt(var)) + 1;
-      cg_budget_ = std::min(cap, std::max(2, std::min(flags[F_STAT_MAX] + 1, q3)));
+      const int q3 = (int)std::ceil(mean + 3.0 * std::sqrt(var));     // (KA checks the residual after the last budgeted iteration)
+      cg_budget_ = std::min(cap, std::max(2, std::min(flags[F_STAT_MAX], q3)));
     }
   }
 }
