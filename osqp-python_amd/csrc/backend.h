@@ -69,6 +69,8 @@ struct Dev {
   double *v = nullptr;           // rho .* z - y
   // PCG (Chronopoulos-Gear single-reduction form)
   double *r = nullptr, *uu = nullptr, *p = nullptr, *s = nullptr, *w = nullptr, *t = nullptr, *Minv = nullptr;
+  double *r2 = nullptr, *s2 = nullptr;   // ping-pong partners of r / s for the fused PCG (r_k lives in (k&1 ? r2 : r), same for s)
+  int fused = 0;                 // 1: two kernels per PCG iteration (vector update k-1 fused into the SpMV-A kernel of iteration k)
   // reductions
   double *part = nullptr;        // [slot][kGrid] partial results, slots see backend implementation
   double *res = nullptr;         // [R_COUNT]
@@ -147,6 +149,10 @@ void init_iterates(Dev &d, int full);
 
 // tmp = z + y ; z = clip(tmp, l, u) ; y = tmp - z   (_osqp.py:676-680, used by polish :1780)
 void project_normalcone(Dev &d);
+
+// Two-kernel PCG iteration available?  When true the driver enqueues  k1(i); k2(i)  per iteration and kv(i) only after the
+// last budgeted one: k1(i), i >= 1, performs the vector update of iteration i-1 itself (backend_hip.hip k_k1f).
+bool pcg_fused(const Dev &d);
 
 // ---- launch batching ----
 bool graphs_supported();

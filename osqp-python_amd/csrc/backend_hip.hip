@@ -301,12 +301,13 @@ struct EK2 {
   __device__ __forceinline__ void prefetch(int j) { pu = uu[j]; }
   __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { w[j] = s[0]; dl += s[0] * pu; }
 };
-__global__ __launch_bounds__(kBlock) void k_k2(Dev d, int probe) {
+__global__ __launch_bounds__(kBlock) void k_k2(Dev d, int probe, int check_i) {
   __shared__ StreamLds<1> lds;
   if (!probe && d.flags[F_DONE]) return;
   GSplit g{d.uu, d.t, d.n};
   EK2 e{d.uu, d.w};
-  if (!process_rows<1>(d.B, g, e, lds, NoPre())) return;
+  // fused PCG: the stopping test of iteration check_i (> 0) runs here, on the ||r|| partials k_k1f has just produced
+  if (!(check_i > 0 ? process_rows<1>(d.B, g, e, lds, PreK1{d, check_i, probe ? 2 : 0, lds.red}) : process_rows<1>(d.B, g, e, lds, NoPre()))) return;
   __syncthreads();
   const double DL = block_sum(e.dl, lds.red);
   put_partial(d.part, SL_DELTA, DL);
@@ -331,13 +332,16 @@ __global__ __launch_bounds__(kBlock) void k_kv(Dev d, int i, int probe) {
   if (!probe && d.flags[F_DONE]) return;                           // PCG already converged
   const bool first = (i == 0) && !probe;
   typedef typename std::conditional<VEC == 2, double2, double>::type V;
-  V *p2 = reinterpret_cast<V *>(d.p), *s2 = reinterpret_cast<V *>(d.s), *x2 = reinterpret_cast<V *>(d.xs), *r2 = reinterpret_cast<V *>(d.r),
-    *u2 = reinterpret_cast<V *>(d.uu);
+  // fused PCG: update k = i reads s_{k-1}, r_k and writes s_k, r_{k+1} into the ping-pong partners (see k_k1f)
+  const bool pp = d.fused && !probe;
+  const V *rin = reinterpret_cast<const V *>(pp && (i & 1) ? d.r2 : d.r), *sin = reinterpret_cast<const V *>(pp && !(i & 1) ? d.s2 : d.s);
+  V *rout = reinterpret_cast<V *>(pp && !(i & 1) ? d.r2 : d.r), *sout = reinterpret_cast<V *>(pp && (i & 1) ? d.s2 : d.s);
+  V *p2 = reinterpret_cast<V *>(d.p), *x2 = reinterpret_cast<V *>(d.xs), *u2 = reinterpret_cast<V *>(d.uu);
   const V *w2 = reinterpret_cast<const V *>(d.w), *m2 = reinterpret_cast<const V *>(d.Minv);
   // issue this lane's first element loads, then fold the partials while they are in flight
   const bool have = active && j0 < nv;
   V u, w, x, r, mi, p, s;
-  if (have) { u = u2[j0]; w = w2[j0]; x = x2[j0]; r = r2[j0]; mi = m2[j0]; if (!first) { p = p2[j0]; s = s2[j0]; } }
+  if (have) { u = u2[j0]; w = w2[j0]; x = x2[j0]; r = rin[j0]; mi = m2[j0]; if (!first) { p = p2[j0]; s = sin[j0]; } }
   double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
   double alpha = 0.0, beta = 0.0;
   if (probe != 1) {
@@ -362,19 +366,85 @@ __global__ __launch_bounds__(kBlock) void k_kv(Dev d, int i, int probe) {
     if (c >= nchunk) break;
     const int j = c * kBlock + threadIdx.x;
     if (j >= nv) break;
-    if (sl != slot0) { u = u2[j]; w = w2[j]; x = x2[j]; r = r2[j]; mi = m2[j]; if (!first) { p = p2[j]; s = s2[j]; } }
+    if (sl != slot0) { u = u2[j]; w = w2[j]; x = x2[j]; r = rin[j]; mi = m2[j]; if (!first) { p = p2[j]; s = sin[j]; } }
     if constexpr (VEC == 2) { upd(u.x, w.x, x.x, r.x, mi.x, p.x, s.x); upd(u.y, w.y, x.y, r.y, mi.y, p.y, s.y); }
     else upd(u, w, x, r, mi, p, s);
-    p2[j] = p; s2[j] = s; x2[j] = x; r2[j] = r; u2[j] = u;
+    p2[j] = p; sout[j] = s; x2[j] = x; rout[j] = r; u2[j] = u;
   }
   if (VEC == 2 && (d.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {      // odd tail element
     const int j = d.n - 1;
-    double uu_ = d.uu[j], xx_ = d.xs[j], rr_ = d.r[j], pp_ = first ? 0.0 : d.p[j], ss_ = first ? 0.0 : d.s[j];
+    const double *rin1 = reinterpret_cast<const double *>(rin), *sin1 = reinterpret_cast<const double *>(sin);
+    double uu_ = d.uu[j], xx_ = d.xs[j], rr_ = rin1[j], pp_ = first ? 0.0 : d.p[j], ss_ = first ? 0.0 : sin1[j];
     upd(uu_, d.w[j], xx_, rr_, d.Minv[j], pp_, ss_);
-    d.uu[j] = uu_; d.xs[j] = xx_; d.r[j] = rr_; d.p[j] = pp_; d.s[j] = ss_;
+    d.uu[j] = uu_; d.xs[j] = xx_; reinterpret_cast<double *>(rout)[j] = rr_; d.p[j] = pp_; reinterpret_cast<double *>(sout)[j] = ss_;
   }
   block_sum_max(g, rn, sred);
   if (!probe) { put_partial(d.part, SL_GAMMA0 + ((i + 1) & 1), g); put_partial(d.part, SL_RN0 + ((i + 1) & 1), rn); }
+}
+
+
+// K1F (fused PCG, iteration i >= 1) -----------------------------------------------------------------------
+//   (a) the vector update of iteration k = i-1 (exactly k_kv<1>) on this workgroup's chunk of the n-vectors, and
+//   (b) t = rho .* (A u_{k+1}) where u_{k+1} is RECOMPUTED at every gathered column from the previous iteration's vectors
+//           u_{k+1}[c] = Minv[c] * ( r_k[c] - alpha * (w_k[c] + beta * s_{k-1}[c]) )
+//       (four gathers instead of one) so that (b) does not have to wait for (a) of other workgroups: (a) writes s_k and
+//       r_{k+1} into the ping-pong partners of the buffers (b) gathers from.  One launch and one dependent boundary less
+//       per PCG iteration; the stopping test moves to the start of k_k2.
+struct GRecomp {
+  const double *r, *s, *w, *Minv; double alpha, beta; int first;
+  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const {
+    const double sn = first ? w[c] : w[c] + beta * s[c];
+    pr[0] = a * (Minv[c] * (r[c] - alpha * sn));
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_k1f(Dev d, int i, int probe) {
+  __shared__ StreamLds<1> lds;
+  if (!probe && d.flags[F_DONE]) return;
+  const int k = i - 1;
+  const bool has_rows = wg_has_rows(d.A);
+  const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3, slots = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+  const bool has_vec = slot0 < per && xcd * per + slot0 < nchunk;
+  if (!has_rows && !has_vec && blockIdx.x != 0) {
+    if (!probe) { put_partial(d.part, SL_GAMMA0 + (i & 1), 0.0); put_partial(d.part, SL_RN0 + (i & 1), 0.0); }
+    return;
+  }
+  const double *rin = (k & 1) ? d.r2 : d.r, *sin = (k & 1) ? d.s : d.s2;
+  double *rout = (k & 1) ? d.r : d.r2, *sout = (k & 1) ? d.s2 : d.s;
+  double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
+  double alpha = 0.0, beta = 0.0;
+  {
+    const PartRegs pg = partial_load(d.part + (SL_GAMMA0 + (k & 1)) * kGrid), pd = partial_load(d.part + SL_DELTA * kGrid);
+    double gamma = partial_fold_sum(pg), delta = partial_fold_sum(pd);
+    block_sum2(gamma, delta, lds.red);
+    if (probe) { if (gamma == -1.2345e300) d.res[R_COUNT - 1] = delta; }
+    else {
+      if (k == 0) { beta = 0.0; alpha = gamma / delta; }
+      else { beta = gamma / gam[k - 1]; alpha = gamma / (delta - beta * gamma / alp[k - 1]); }
+      if (blockIdx.x == 0 && threadIdx.x == 0) { gam[k] = gamma; alp[k] = alpha; }
+    }
+  }
+  const int first = (k == 0) && !probe;
+  double g = 0, rn = 0;
+  if (has_vec) {
+    for (int sl = slot0; sl < per; sl += slots) {
+      const int c = xcd * per + sl;
+      if (c >= nchunk) break;
+      const int j = c * kBlock + threadIdx.x;
+      if (j >= d.n) break;
+      const double u = d.uu[j], w = d.w[j], mi = d.Minv[j];
+      double pp_ = first ? u : u + beta * d.p[j], ss_ = first ? w : w + beta * sin[j];
+      const double rr_ = rin[j] - alpha * ss_, un = mi * rr_;
+      if (!probe) { d.p[j] = pp_; sout[j] = ss_; d.xs[j] += alpha * pp_; rout[j] = rr_; d.uu[j] = un; }
+      g += rr_ * un; rn = nanmax(rn, fabs(rr_));
+    }
+  }
+  GRecomp gr{rin, sin, d.w, d.Minv, alpha, beta, first};
+  EK1 e{d.rho, d.t};
+  process_rows<1>(d.A, gr, e, lds);
+  __syncthreads();
+  block_sum_max(g, rn, lds.red);
+  if (!probe) { put_partial(d.part, SL_GAMMA0 + (i & 1), g); put_partial(d.part, SL_RN0 + (i & 1), rn); }
 }
 
 // KA ------------------------------------------------------------------------------------------
@@ -647,8 +717,9 @@ void sync(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipStreamSynchr
 void activate(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); }
 
 void kb_rhs(Dev &d) { LAUNCH(k_kb, d, d); }
-void k1(Dev &d, int i) { LAUNCH(k_k1, d, d, i, 0); }
-void k2(Dev &d, int) { LAUNCH(k_k2, d, d, 0); }
+bool pcg_fused(const Dev &d) { return d.fused != 0; }
+void k1(Dev &d, int i) { if (d.fused && i > 0) LAUNCH(k_k1f, d, d, i, 0); else LAUNCH(k_k1, d, d, i, 0); }
+void k2(Dev &d, int i) { LAUNCH(k_k2, d, d, 0, d.fused ? i : 0); }
 void kv(Dev &d, int i) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, i, 0); else LAUNCH(k_kv<1>, d, d, i, 0); }
 void ka(Dev &d, int budget) { LAUNCH(k_ka, d, d, budget); }
 
@@ -728,7 +799,7 @@ float time_kernel(Dev &d, int which, int reps) {
   const size_t n = d.n, m = d.m;
   Save sv[] = {{d.x, n, nullptr}, {d.z, m, nullptr}, {d.y, m, nullptr}, {d.xs, n, nullptr}, {d.zt, m, nullptr}, {d.t0, m, nullptr},
                {d.v, m, nullptr}, {d.dx, n, nullptr}, {d.dy, m, nullptr}, {d.r, n, nullptr}, {d.uu, n, nullptr}, {d.p, n, nullptr},
-               {d.s, n, nullptr}, {d.w, n, nullptr}, {d.t, m, nullptr}};
+               {d.s, n, nullptr}, {d.w, n, nullptr}, {d.t, m, nullptr}, {d.r2, n, nullptr}, {d.s2, n, nullptr}};
   int flags_bak[F_COUNT];
   HIP_CHECK(hipStreamSynchronize(st(d)));
   HIP_CHECK(hipMemcpy(flags_bak, d.flags, sizeof(flags_bak), hipMemcpyDeviceToHost));
@@ -738,12 +809,12 @@ float time_kernel(Dev &d, int which, int reps) {
     HIP_CHECK(hipMemcpy(s.bak, s.ptr, s.cnt * sizeof(double), hipMemcpyDeviceToDevice));
   }
   auto K1 = [&](int pr) { LAUNCH(k_k1, d, d, 1, pr); };
-  auto K2 = [&]() { LAUNCH(k_k2, d, d, 1); };
+  auto K2 = [&]() { LAUNCH(k_k2, d, d, 1, 0); };
   auto KV = [&](int pr) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, 1, pr); else LAUNCH(k_kv<1>, d, d, 1, pr); };
   auto launch = [&]() {
     switch (which) {
       case 0: LAUNCH(k_k1, d, d, 1, 1); break;
-      case 1: LAUNCH(k_k2, d, d, 1); break;
+      case 1: LAUNCH(k_k2, d, d, 1, 0); break;
       case 2: if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, 1, 1); else LAUNCH(k_kv<1>, d, d, 1, 1); break;
       case 3: LAUNCH(k_kb, d, d); break;
       case 4: LAUNCH(k_ka, d, d, 0); break;
@@ -751,7 +822,8 @@ float time_kernel(Dev &d, int which, int reps) {
       case 6: K1(2); K2(); KV(2); break;      // one PCG iteration as a solve executes it
       case 7: K1(2); KV(2); break;            // ... without K2   (6 minus 7 = K2's time inside the sequence, L2-cold like in a solve)
       case 8: K2(); KV(2); break;             // ... without K1
-      default: K1(2); K2(); break;            // ... without Kv
+      case 9: K1(2); K2(); break;             // ... without Kv
+      default: LAUNCH(k_k1f, d, d, 1, 2); LAUNCH(k_k2, d, d, 1, 1); break;   // one FUSED PCG iteration (two kernels)
     }
   };
   for (int w = 0; w < 5; w++) launch();

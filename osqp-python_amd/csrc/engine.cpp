@@ -82,7 +82,7 @@ void Engine::free_all() {
   if (bbuf_) { be::dfree(d_, bbuf_); bbuf_ = nullptr; bbuf_cap_ = 0; }
   void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag,
                   d_.q, d_.l, d_.u, d_.D, d_.Dinv, d_.E, d_.Einv, d_.rho, d_.rho_inv, d_.ctype, d_.x, d_.z, d_.y, d_.dx,
-                  d_.dy, d_.xs, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.part, d_.res,
+                  d_.dy, d_.xs, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.r2, d_.s2, d_.part, d_.res,
                   d_.scal, d_.flags};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   be::destroy(d_);
@@ -349,7 +349,8 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   d_.q = dv(n); d_.l = dv(m); d_.u = dv(m); d_.D = dv(n); d_.Dinv = dv(n); d_.E = dv(m); d_.Einv = dv(m);
   d_.rho = dv(m); d_.rho_inv = dv(m); d_.ctype = dev_vec<int>(d_, m);
   d_.x = dv(n); d_.z = dv(m); d_.y = dv(m); d_.dx = dv(n); d_.dy = dv(m); d_.xs = dv(n); d_.zt = dv(m); d_.t0 = dv(m); d_.v = dv(m);
-  d_.r = dv(n); d_.uu = dv(n); d_.p = dv(n); d_.s = dv(n); d_.w = dv(n); d_.t = dv(m); d_.Minv = dv(n);
+  d_.r = dv(n); d_.uu = dv(n); d_.p = dv(n); d_.s = dv(n); d_.w = dv(n); d_.t = dv(m); d_.Minv = dv(n); d_.r2 = dv(n); d_.s2 = dv(n);
+  { const char *f = std::getenv("OSQP_HIP_PCG_FUSED"); d_.fused = (f && f[0] == '1') ? 1 : 0; }
   d_.part = dv((size_t)32 * kGrid); d_.res = dv(R_COUNT); d_.scal = dv(S_HIST + 2 * (kMaxCg + 1)); d_.flags = dev_vec<int>(d_, F_COUNT);
   be::h2d(d_, d_.D, D_.data(), sizeof(double) * n); be::h2d(d_, d_.Dinv, Dinv_.data(), sizeof(double) * n);
   be::h2d(d_, d_.E, E_.data(), sizeof(double) * m); be::h2d(d_, d_.Einv, Einv_.data(), sizeof(double) * m);
@@ -402,14 +403,15 @@ void Engine::set_status(int st) {
 // One chunk = `niter` ADMM iterations, each  KB, budget x (K1,K2,Kv), KA  -- enqueued eagerly or replayed from a
 // hipGraph captured once per (niter, budget).
 void Engine::run_chunk(int niter, int budget) {
+  const bool fused = be::pcg_fused(d_);
   auto enqueue = [&](int count) {
     for (int it = 0; it < count; it++) {
       be::kb_rhs(d_);
-      for (int i = 0; i < budget; i++) { be::k1(d_, i); be::k2(d_, i); be::kv(d_, i); }
+      for (int i = 0; i < budget; i++) { be::k1(d_, i); be::k2(d_, i); if (!fused || i == budget - 1) be::kv(d_, i); }
       be::ka(d_, budget);
     }
   };
-  stats_.kernel_launches += (double)niter * (2 + 3 * budget);
+  stats_.kernel_launches += (double)niter * (fused ? 3 + 2 * budget : 2 + 3 * budget);
   if (!(use_graph_ && be::graphs_supported())) { enqueue(niter); return; }
   // one executable graph per (ADMM iterations, PCG budget); graphs are kept below kMaxGraphNodes kernel nodes (a
   // check_termination = 0 solve would otherwise capture max_iter * (2 + 3*budget) nodes in one graph)
@@ -849,7 +851,7 @@ int Engine::get_stats(OSQPHipStats *out) { if (!out) return OSQP_DATA_VALIDATION
 int Engine::time_kernel(int which, int reps, double *ms) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);
-  if (which < 0 || which > 9 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
+  if (which < 0 || which > 10 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
   *ms = be::time_kernel(d_, which, reps);
   return OSQP_NO_ERROR;
 }

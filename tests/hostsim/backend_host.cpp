@@ -210,6 +210,7 @@ void project_normalcone(Dev &d) {
 size_t batch_lds_bytes(int, int) { return 0; }
 int batch_solve(Dev &, const BatchParams &) { return OSQP_FUNC_NOT_IMPLEMENTED; }   // GPU-only feature
 
+bool pcg_fused(const Dev &) { return false; }
 bool graphs_supported() { return false; }
 void graph_begin(Dev &) {}
 void *graph_end(Dev &) { return nullptr; }
