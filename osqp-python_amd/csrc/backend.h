@@ -49,7 +49,7 @@ enum ResId {
 // indices into the int32 status block
 enum FlagId { F_DONE = 0, F_ITERS, F_STAT_SUM, F_STAT_MAX, F_STAT_UNCONV, F_STAT_SUMSQ, F_STAT_N, F_COUNT };
 // indices into the fp64 scalar block
-enum ScalId { S_TOL_REL = 0, S_TOL_ABS, S_HIST = 8 /* gamma[kMaxCg+1], then alpha[kMaxCg+1] */ };
+enum ScalId { S_TOL_REL = 0, S_TOL_ABS, S_TOL_NOW, S_HIST = 8 /* gamma[kMaxCg+1], alpha[kMaxCg+1], beta[kMaxCg+1] */ };
 
 struct Dev {
   int n = 0, m = 0, device = 0;
@@ -69,7 +69,7 @@ struct Dev {
   double *v = nullptr;           // rho .* z - y
   // PCG (Chronopoulos-Gear single-reduction form)
   double *r = nullptr, *uu = nullptr, *p = nullptr, *s = nullptr, *w = nullptr, *t = nullptr, *Minv = nullptr;
-  double *r2 = nullptr, *s2 = nullptr;   // ping-pong partners of r / s for the fused PCG (r_k lives in (k&1 ? r2 : r), same for s)
+  double *uu2 = nullptr, *ms = nullptr;  // fused PCG: u_k lives in (k&1 ? uu2 : uu); ms = Minv .* s
   int fused = 0;                 // 1: two kernels per PCG iteration (vector update k-1 fused into the SpMV-A kernel of iteration k)
   // reductions
   double *part = nullptr;        // [slot][kGrid] partial results, slots see backend implementation

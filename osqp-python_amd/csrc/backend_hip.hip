@@ -275,6 +275,7 @@ struct PreK1 {
     block_max2(rn, bn, red);
     if (probe) { if (rn < -1.0) d.res[R_COUNT - 1] = bn; return true; }     // probe == 2: pay for the test, ignore it
     const double tol = fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS]);
+    if (i == 0 && blockIdx.x == 0 && threadIdx.x == 0) d.scal[S_TOL_NOW] = tol;   // fused PCG: later tests read the scalar
     if (!(rn > tol)) {            // converged (a NaN residual also stops the inner loop; the ADMM residuals will flag it)
       if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = i; }
       return false;
@@ -301,13 +302,12 @@ struct EK2 {
   __device__ __forceinline__ void prefetch(int j) { pu = uu[j]; }
   __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { w[j] = s[0]; dl += s[0] * pu; }
 };
-__global__ __launch_bounds__(kBlock) void k_k2(Dev d, int probe, int check_i) {
+__global__ __launch_bounds__(kBlock) void k_k2(Dev d, int probe) {
   __shared__ StreamLds<1> lds;
   if (!probe && d.flags[F_DONE]) return;
   GSplit g{d.uu, d.t, d.n};
   EK2 e{d.uu, d.w};
-  // fused PCG: the stopping test of iteration check_i (> 0) runs here, on the ||r|| partials k_k1f has just produced
-  if (!(check_i > 0 ? process_rows<1>(d.B, g, e, lds, PreK1{d, check_i, probe ? 2 : 0, lds.red}) : process_rows<1>(d.B, g, e, lds, NoPre()))) return;
+  if (!process_rows<1>(d.B, g, e, lds, NoPre())) return;
   __syncthreads();
   const double DL = block_sum(e.dl, lds.red);
   put_partial(d.part, SL_DELTA, DL);
@@ -332,16 +332,17 @@ __global__ __launch_bounds__(kBlock) void k_kv(Dev d, int i, int probe) {
   if (!probe && d.flags[F_DONE]) return;                           // PCG already converged
   const bool first = (i == 0) && !probe;
   typedef typename std::conditional<VEC == 2, double2, double>::type V;
-  // fused PCG: update k = i reads s_{k-1}, r_k and writes s_k, r_{k+1} into the ping-pong partners (see k_k1f)
-  const bool pp = d.fused && !probe;
-  const V *rin = reinterpret_cast<const V *>(pp && (i & 1) ? d.r2 : d.r), *sin = reinterpret_cast<const V *>(pp && !(i & 1) ? d.s2 : d.s);
-  V *rout = reinterpret_cast<V *>(pp && !(i & 1) ? d.r2 : d.r), *sout = reinterpret_cast<V *>(pp && (i & 1) ? d.s2 : d.s);
-  V *p2 = reinterpret_cast<V *>(d.p), *x2 = reinterpret_cast<V *>(d.xs), *u2 = reinterpret_cast<V *>(d.uu);
+  // fused PCG (final update after the last budgeted iteration): s_i is already complete (k_k2 epilogue), w is not stored,
+  // u_i lives in the ping-pong buffer of parity i
+  const bool fz = d.fused && !probe;
+  const V *uin = reinterpret_cast<const V *>(fz && (i & 1) ? d.uu2 : d.uu);
+  V *uout = reinterpret_cast<V *>(fz && !(i & 1) ? d.uu2 : d.uu);
+  V *p2 = reinterpret_cast<V *>(d.p), *x2 = reinterpret_cast<V *>(d.xs), *r2 = reinterpret_cast<V *>(d.r), *s2 = reinterpret_cast<V *>(d.s);
   const V *w2 = reinterpret_cast<const V *>(d.w), *m2 = reinterpret_cast<const V *>(d.Minv);
   // issue this lane's first element loads, then fold the partials while they are in flight
   const bool have = active && j0 < nv;
   V u, w, x, r, mi, p, s;
-  if (have) { u = u2[j0]; w = w2[j0]; x = x2[j0]; r = rin[j0]; mi = m2[j0]; if (!first) { p = p2[j0]; s = sin[j0]; } }
+  if (have) { u = uin[j0]; x = x2[j0]; r = r2[j0]; mi = m2[j0]; if (fz) { s = s2[j0]; if (!first) p = p2[j0]; } else { w = w2[j0]; if (!first) { p = p2[j0]; s = s2[j0]; } } }
   double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
   double alpha = 0.0, beta = 0.0;
   if (probe != 1) {
@@ -357,7 +358,8 @@ __global__ __launch_bounds__(kBlock) void k_kv(Dev d, int i, int probe) {
   }
   double g = 0, rn = 0;
   auto upd = [&](double &uu_, double ww_, double &xx_, double &rr_, double mm_, double &pp_, double &ss_) {
-    if (first) { pp_ = uu_; ss_ = ww_; } else { pp_ = uu_ + beta * pp_; ss_ = ww_ + beta * ss_; }
+    if (fz) { pp_ = first ? uu_ : uu_ + beta * pp_; }                 // ss_ is s_i already
+    else if (first) { pp_ = uu_; ss_ = ww_; } else { pp_ = uu_ + beta * pp_; ss_ = ww_ + beta * ss_; }
     xx_ += alpha * pp_; rr_ -= alpha * ss_; uu_ = mm_ * rr_;
     g += rr_ * uu_; rn = nanmax(rn, fabs(rr_));
   };
@@ -366,65 +368,88 @@ __global__ __launch_bounds__(kBlock) void k_kv(Dev d, int i, int probe) {
     if (c >= nchunk) break;
     const int j = c * kBlock + threadIdx.x;
     if (j >= nv) break;
-    if (sl != slot0) { u = u2[j]; w = w2[j]; x = x2[j]; r = rin[j]; mi = m2[j]; if (!first) { p = p2[j]; s = sin[j]; } }
+    if (sl != slot0) { u = uin[j]; x = x2[j]; r = r2[j]; mi = m2[j]; if (fz) { s = s2[j]; if (!first) p = p2[j]; } else { w = w2[j]; if (!first) { p = p2[j]; s = s2[j]; } } }
     if constexpr (VEC == 2) { upd(u.x, w.x, x.x, r.x, mi.x, p.x, s.x); upd(u.y, w.y, x.y, r.y, mi.y, p.y, s.y); }
     else upd(u, w, x, r, mi, p, s);
-    p2[j] = p; sout[j] = s; x2[j] = x; rout[j] = r; u2[j] = u;
+    p2[j] = p; if (!fz) s2[j] = s; x2[j] = x; r2[j] = r; uout[j] = u;
   }
   if (VEC == 2 && (d.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {      // odd tail element
     const int j = d.n - 1;
-    const double *rin1 = reinterpret_cast<const double *>(rin), *sin1 = reinterpret_cast<const double *>(sin);
-    double uu_ = d.uu[j], xx_ = d.xs[j], rr_ = rin1[j], pp_ = first ? 0.0 : d.p[j], ss_ = first ? 0.0 : sin1[j];
-    upd(uu_, d.w[j], xx_, rr_, d.Minv[j], pp_, ss_);
-    d.uu[j] = uu_; d.xs[j] = xx_; reinterpret_cast<double *>(rout)[j] = rr_; d.p[j] = pp_; reinterpret_cast<double *>(sout)[j] = ss_;
+    const double *uin1 = reinterpret_cast<const double *>(uin); double *uout1 = reinterpret_cast<double *>(uout);
+    double uu_ = uin1[j], xx_ = d.xs[j], rr_ = d.r[j], pp_ = first ? 0.0 : d.p[j], ss_ = (first && !fz) ? 0.0 : d.s[j];
+    upd(uu_, fz ? 0.0 : d.w[j], xx_, rr_, d.Minv[j], pp_, ss_);
+    uout1[j] = uu_; d.xs[j] = xx_; d.r[j] = rr_; d.p[j] = pp_; if (!fz) d.s[j] = ss_;
   }
   block_sum_max(g, rn, sred);
   if (!probe) { put_partial(d.part, SL_GAMMA0 + ((i + 1) & 1), g); put_partial(d.part, SL_RN0 + ((i + 1) & 1), rn); }
 }
 
 
-// K1F (fused PCG, iteration i >= 1) -----------------------------------------------------------------------
-//   (a) the vector update of iteration k = i-1 (exactly k_kv<1>) on this workgroup's chunk of the n-vectors, and
-//   (b) t = rho .* (A u_{k+1}) where u_{k+1} is RECOMPUTED at every gathered column from the previous iteration's vectors
-//           u_{k+1}[c] = Minv[c] * ( r_k[c] - alpha * (w_k[c] + beta * s_{k-1}[c]) )
-//       (four gathers instead of one) so that (b) does not have to wait for (a) of other workgroups: (a) writes s_k and
-//       r_{k+1} into the ping-pong partners of the buffers (b) gathers from.  One launch and one dependent boundary less
-//       per PCG iteration; the stopping test moves to the start of k_k2.
-struct GRecomp {
-  const double *r, *s, *w, *Minv; double alpha, beta; int first;
-  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const {
-    const double sn = first ? w[c] : w[c] + beta * s[c];
-    pr[0] = a * (Minv[c] * (r[c] - alpha * sn));
+// Fused PCG (two kernels per iteration) --------------------------------------------------------------------------------
+// K2F_k :  stopping test on ||r_k||; beta_k = gamma_k / gamma_{k-1};  w = B [u_k; t_k];  delta_k = <w, u_k>;  and in the row
+//          epilogue  s_k = w + beta_k s_{k-1},  ms_k = Minv .* s_k   (w itself is never stored)
+// K1F_{k+1}: alpha_k = gamma_k / (delta_k - beta_k gamma_k / alpha_{k-1});
+//          (a) on this workgroup's chunk of the n-vectors:  p = u_k + beta_k p ; xs += alpha_k p ; r -= alpha_k s_k ;
+//              u_{k+1} = Minv r  (written to the OTHER u buffer) ; partials gamma_{k+1}, ||r_{k+1}||_inf
+//          (b) t_{k+1} = rho .* (A u_{k+1})  with u_{k+1}[c] = u_k[c] - alpha_k ms_k[c] recomputed at every gathered column
+//              (two gathers), so (b) never waits for (a) of another workgroup.
+struct GSplitU { const double *pn, *pm; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * (c < n ? pn[c] : pm[c - n]); } };
+struct EK2F {
+  const double *u, *Minv; double *s, *ms; double beta = 0; int first = 0; double dl = 0, pu = 0, pm = 0, ps = 0;
+  __device__ __forceinline__ void prefetch(int j) { pu = u[j]; pm = Minv[j]; ps = s[j]; }
+  __device__ __forceinline__ void operator()(int j, const double (&sm)[1]) {
+    const double w = sm[0], sn = first ? w : w + beta * ps;
+    dl += w * pu; s[j] = sn; ms[j] = pm * sn;
   }
 };
-__global__ __launch_bounds__(kBlock) void k_k1f(Dev d, int i, int probe) {
+struct PreK2F {
+  const Dev &d; int k; EK2F *e; double *red;
+  __device__ __forceinline__ bool operator()() const {
+    const PartRegs prn = partial_load(d.part + (SL_RN0 + (k & 1)) * kGrid), pg = partial_load(d.part + (SL_GAMMA0 + (k & 1)) * kGrid);
+    double gamma = partial_fold_sum(pg), rn = partial_fold_max(prn);
+    block_sum_max(gamma, rn, red);
+    double *gam = d.scal + S_HIST, *bet = d.scal + S_HIST + 2 * (kMaxCg + 1);
+    if (k > 0 && !(rn > d.scal[S_TOL_NOW])) {        // converged after k iterations (k == 0 was tested by k_k1)
+      if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = k; }
+      return false;
+    }
+    const double beta = k == 0 ? 0.0 : gamma / gam[k - 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { gam[k] = gamma; bet[k] = beta; }
+    e->beta = beta; e->first = (k == 0);
+    return true;
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_k2f(Dev d, int k) {
   __shared__ StreamLds<1> lds;
-  if (!probe && d.flags[F_DONE]) return;
+  if (d.flags[F_DONE]) return;
+  const double *u = (k & 1) ? d.uu2 : d.uu;
+  GSplitU g{u, d.t, d.n};
+  EK2F e{u, d.Minv, d.s, d.ms};
+  if (!process_rows<1>(d.B, g, e, lds, PreK2F{d, k, &e, lds.red})) return;
+  __syncthreads();
+  const double DL = block_sum(e.dl, lds.red);
+  put_partial(d.part, SL_DELTA, DL);
+}
+struct GTwoGather { const double *u, *ms; double alpha; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * (u[c] - alpha * ms[c]); } };
+__global__ __launch_bounds__(kBlock) void k_k1f(Dev d, int i) {          // i >= 1; performs the vector update of k = i - 1
+  __shared__ StreamLds<1> lds;
+  if (d.flags[F_DONE]) return;
   const int k = i - 1;
   const bool has_rows = wg_has_rows(d.A);
   const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3, slots = gridDim.x >> 3;
   const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
   const bool has_vec = slot0 < per && xcd * per + slot0 < nchunk;
   if (!has_rows && !has_vec && blockIdx.x != 0) {
-    if (!probe) { put_partial(d.part, SL_GAMMA0 + (i & 1), 0.0); put_partial(d.part, SL_RN0 + (i & 1), 0.0); }
+    put_partial(d.part, SL_GAMMA0 + (i & 1), 0.0); put_partial(d.part, SL_RN0 + (i & 1), 0.0);
     return;
   }
-  const double *rin = (k & 1) ? d.r2 : d.r, *sin = (k & 1) ? d.s : d.s2;
-  double *rout = (k & 1) ? d.r : d.r2, *sout = (k & 1) ? d.s2 : d.s;
-  double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
-  double alpha = 0.0, beta = 0.0;
-  {
-    const PartRegs pg = partial_load(d.part + (SL_GAMMA0 + (k & 1)) * kGrid), pd = partial_load(d.part + SL_DELTA * kGrid);
-    double gamma = partial_fold_sum(pg), delta = partial_fold_sum(pd);
-    block_sum2(gamma, delta, lds.red);
-    if (probe) { if (gamma == -1.2345e300) d.res[R_COUNT - 1] = delta; }
-    else {
-      if (k == 0) { beta = 0.0; alpha = gamma / delta; }
-      else { beta = gamma / gam[k - 1]; alpha = gamma / (delta - beta * gamma / alp[k - 1]); }
-      if (blockIdx.x == 0 && threadIdx.x == 0) { gam[k] = gamma; alp[k] = alpha; }
-    }
-  }
-  const int first = (k == 0) && !probe;
+  const double *uin = (k & 1) ? d.uu2 : d.uu;
+  double *uout = (k & 1) ? d.uu : d.uu2;
+  double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1, *bet = d.scal + S_HIST + 2 * (kMaxCg + 1);
+  const double delta = block_sum(partial_fold_sum(partial_load(d.part + SL_DELTA * kGrid)), lds.red);
+  const double gamma = gam[k], beta = bet[k];
+  const double alpha = k == 0 ? gamma / delta : gamma / (delta - beta * gamma / alp[k - 1]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) alp[k] = alpha;
   double g = 0, rn = 0;
   if (has_vec) {
     for (int sl = slot0; sl < per; sl += slots) {
@@ -432,19 +457,19 @@ __global__ __launch_bounds__(kBlock) void k_k1f(Dev d, int i, int probe) {
       if (c >= nchunk) break;
       const int j = c * kBlock + threadIdx.x;
       if (j >= d.n) break;
-      const double u = d.uu[j], w = d.w[j], mi = d.Minv[j];
-      double pp_ = first ? u : u + beta * d.p[j], ss_ = first ? w : w + beta * sin[j];
-      const double rr_ = rin[j] - alpha * ss_, un = mi * rr_;
-      if (!probe) { d.p[j] = pp_; sout[j] = ss_; d.xs[j] += alpha * pp_; rout[j] = rr_; d.uu[j] = un; }
+      const double u = uin[j];
+      const double pp_ = k == 0 ? u : u + beta * d.p[j];
+      const double rr_ = d.r[j] - alpha * d.s[j], un = d.Minv[j] * rr_;
+      d.p[j] = pp_; d.xs[j] += alpha * pp_; d.r[j] = rr_; uout[j] = un;
       g += rr_ * un; rn = nanmax(rn, fabs(rr_));
     }
   }
-  GRecomp gr{rin, sin, d.w, d.Minv, alpha, beta, first};
+  GTwoGather gr{uin, d.ms, alpha};
   EK1 e{d.rho, d.t};
   process_rows<1>(d.A, gr, e, lds);
   __syncthreads();
   block_sum_max(g, rn, lds.red);
-  if (!probe) { put_partial(d.part, SL_GAMMA0 + (i & 1), g); put_partial(d.part, SL_RN0 + (i & 1), rn); }
+  put_partial(d.part, SL_GAMMA0 + (i & 1), g); put_partial(d.part, SL_RN0 + (i & 1), rn);
 }
 
 // KA ------------------------------------------------------------------------------------------
@@ -718,8 +743,8 @@ void activate(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); }
 
 void kb_rhs(Dev &d) { LAUNCH(k_kb, d, d); }
 bool pcg_fused(const Dev &d) { return d.fused != 0; }
-void k1(Dev &d, int i) { if (d.fused && i > 0) LAUNCH(k_k1f, d, d, i, 0); else LAUNCH(k_k1, d, d, i, 0); }
-void k2(Dev &d, int i) { LAUNCH(k_k2, d, d, 0, d.fused ? i : 0); }
+void k1(Dev &d, int i) { if (d.fused && i > 0) LAUNCH(k_k1f, d, d, i); else LAUNCH(k_k1, d, d, i, 0); }
+void k2(Dev &d, int i) { if (d.fused) LAUNCH(k_k2f, d, d, i); else LAUNCH(k_k2, d, d, 0); }
 void kv(Dev &d, int i) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, i, 0); else LAUNCH(k_kv<1>, d, d, i, 0); }
 void ka(Dev &d, int budget) { LAUNCH(k_ka, d, d, budget); }
 
@@ -799,7 +824,7 @@ float time_kernel(Dev &d, int which, int reps) {
   const size_t n = d.n, m = d.m;
   Save sv[] = {{d.x, n, nullptr}, {d.z, m, nullptr}, {d.y, m, nullptr}, {d.xs, n, nullptr}, {d.zt, m, nullptr}, {d.t0, m, nullptr},
                {d.v, m, nullptr}, {d.dx, n, nullptr}, {d.dy, m, nullptr}, {d.r, n, nullptr}, {d.uu, n, nullptr}, {d.p, n, nullptr},
-               {d.s, n, nullptr}, {d.w, n, nullptr}, {d.t, m, nullptr}, {d.r2, n, nullptr}, {d.s2, n, nullptr}};
+               {d.s, n, nullptr}, {d.w, n, nullptr}, {d.t, m, nullptr}, {d.uu2, n, nullptr}, {d.ms, n, nullptr}};
   int flags_bak[F_COUNT];
   HIP_CHECK(hipStreamSynchronize(st(d)));
   HIP_CHECK(hipMemcpy(flags_bak, d.flags, sizeof(flags_bak), hipMemcpyDeviceToHost));
@@ -809,12 +834,12 @@ float time_kernel(Dev &d, int which, int reps) {
     HIP_CHECK(hipMemcpy(s.bak, s.ptr, s.cnt * sizeof(double), hipMemcpyDeviceToDevice));
   }
   auto K1 = [&](int pr) { LAUNCH(k_k1, d, d, 1, pr); };
-  auto K2 = [&]() { LAUNCH(k_k2, d, d, 1, 0); };
+  auto K2 = [&]() { LAUNCH(k_k2, d, d, 1); };
   auto KV = [&](int pr) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, 1, pr); else LAUNCH(k_kv<1>, d, d, 1, pr); };
   auto launch = [&]() {
     switch (which) {
       case 0: LAUNCH(k_k1, d, d, 1, 1); break;
-      case 1: LAUNCH(k_k2, d, d, 1, 0); break;
+      case 1: LAUNCH(k_k2, d, d, 1); break;
       case 2: if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, 1, 1); else LAUNCH(k_kv<1>, d, d, 1, 1); break;
       case 3: LAUNCH(k_kb, d, d); break;
       case 4: LAUNCH(k_ka, d, d, 0); break;
@@ -823,9 +848,10 @@ float time_kernel(Dev &d, int which, int reps) {
       case 7: K1(2); KV(2); break;            // ... without K2   (6 minus 7 = K2's time inside the sequence, L2-cold like in a solve)
       case 8: K2(); KV(2); break;             // ... without K1
       case 9: K1(2); K2(); break;             // ... without Kv
-      default: LAUNCH(k_k1f, d, d, 1, 2); LAUNCH(k_k2, d, d, 1, 1); break;   // one FUSED PCG iteration (two kernels)
+      default: LAUNCH(k_k2f, d, d, 0); LAUNCH(k_k1f, d, d, 1); break;   // one FUSED PCG iteration (two kernels): repeated exact line-search steps, bounded
     }
   };
+  if (which == 10) HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, 0, sizeof(int), st(d)));
   for (int w = 0; w < 5; w++) launch();
   HIP_CHECK(hipEventRecord(p.ev0, st(d)));
   for (int r = 0; r < reps; r++) launch();
