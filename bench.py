@@ -152,27 +152,45 @@ def main():
     if rank == 0:
         nnzA, nnzB, mm = int(stats['nnzA']), int(stats['nnzB']), len(l)
         s = m._solver
-        kb = {   # algorithmic bytes per launch: SpMV formula + the fused epilogue/extra vectors
-            'K1 spmv A (t=rho.*(A u))': spmv_bytes(nnzA, mm, n) + 8 * mm,
-            'K2 spmv B (w=B[u;t], <w,u>)': spmv_bytes(nnzB, n, n + mm),
-            'Kv pcg vector update': 12 * 8 * n,
-            'KB rhs + pcg start': spmv_bytes(nnzB, n, n + mm) + 8 * mm + 8 * (4 * n),
-            'KA A x~ + z,y,x update': spmv_bytes(nnzA, mm, n) + 8 * (9 * mm) + 8 * (3 * n),
+        fused = bool(stats.get('pcg_fused', 0))
+        sA, sB = spmv_bytes(nnzA, mm, n), spmv_bytes(nnzB, n, n + mm)
+        # algorithmic bytes per launch (DESIGN.md "Kernels"): SpMV formula + the fused epilogue / extra vectors
+        if fused:     # two kernels per PCG iteration
+            pcg_kernels = {
+                'K1F spmv A + pcg vector update (k_k1f)': (11, sA + 8 * mm + 8 * n + 9 * 8 * n),   # + rho, gathered Minv.*s; p r s Minv x~ read, p x~ r u written
+                'K2F spmv B + s, Minv.*s, <s,u> (k_k2f)': (12, sB + 3 * 8 * n),                      # + s read, Minv read, Minv.*s written (s replaces w)
+            }
+            seq_id, dom, dom_kernel = 10, 'K2F spmv B + s, Minv.*s, <s,u> (k_k2f)', 'k_k2f'
+        else:
+            pcg_kernels = {
+                'K1 spmv A (t=rho.*(A u))': (0, sA + 8 * mm),
+                'K2 spmv B (w=B[u;t], <w,u>)': (1, sB),
+                'Kv pcg vector update': (2, 12 * 8 * n),
+            }
+            seq_id, dom, dom_kernel = 6, 'K2 spmv B (w=B[u;t], <w,u>)', 'k_k2'
+        other = {
+            'KB rhs + pcg start': (3, sB + 8 * mm + 8 * (4 * n)),
+            'KA A x~ + z,y,x update': (4, sA + 8 * (9 * mm) + 8 * (3 * n)),
         }
         probes = {}
-        for which, name in enumerate(kb):
-            ms = s.hip_time_kernel(which, args.probe_reps)
-            probes[name] = {'ms_same_kernel_repeat': ms, 'bytes': kb[name]}
-        # in-sequence times: T(K1,K2,Kv) minus T(sequence without the kernel); this is what a solve pays (L2-cold matrices)
-        pcg_ms = s.hip_time_kernel(6, args.probe_reps)
-        for name, which in zip(list(kb)[:3], (8, 7, 9)):
-            probes[name]['ms'] = max(pcg_ms - s.hip_time_kernel(which, args.probe_reps), 1e-6)
-        for name in list(kb)[3:]:
+        for name, (which, nbytes) in {**pcg_kernels, **other}.items():
+            probes[name] = {'ms_same_kernel_repeat': s.hip_time_kernel(which, args.probe_reps), 'bytes': nbytes}
+        # in-sequence times: T(one PCG iteration as a solve runs it) minus T(the sequence without the kernel); this is what
+        # a solve pays (the kernels evict each other's matrix from L2)
+        pcg_ms = s.hip_time_kernel(seq_id, args.probe_reps)
+        if fused:     # the "sequence without the kernel" is the other kernel alone (L2-hot, so this is an upper bound)
+            names = list(pcg_kernels)
+            for name, other_name in zip(names, names[::-1]):
+                probes[name]['ms'] = max(pcg_ms - probes[other_name]['ms_same_kernel_repeat'], 1e-6)
+        else:
+            for name, which in zip(list(pcg_kernels), (8, 7, 9)):
+                probes[name]['ms'] = max(pcg_ms - s.hip_time_kernel(which, args.probe_reps), 1e-6)
+        for name in other:
             probes[name]['ms'] = probes[name]['ms_same_kernel_repeat']
-        for name in kb:
-            probes[name]['GBps'] = kb[name] / (probes[name]['ms'] * 1e-3) / 1e9
-        dom = 'K2 spmv B (w=B[u;t], <w,u>)'
-        pcg_bytes = sum(kb[k] for k in list(kb)[:3])
+        for name in probes:
+            probes[name]['GBps'] = probes[name]['bytes'] / (probes[name]['ms'] * 1e-3) / 1e9
+        kb = {name: probes[name]['bytes'] for name in probes}
+        pcg_bytes = sum(kb[k] for k in pcg_kernels)
         out = {
             'metric': 'ADMM iterations/sec, n=%d m=%d nnz(A)=%d sparse QP (indirect PCG)' % (n, mm, A.nnz),
             'value': total_iters / tmax, 'unit': 'ADMM iter/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -183,10 +201,10 @@ def main():
                        'admm_iters_per_solve': int(res.info.iter), 'status': res.info.status, 'obj_val': res.info.obj_val,
                        'prim_res': res.info.prim_res, 'dual_res': res.info.dual_res, 'rho_updates': int(res.info.rho_updates),
                        'pcg_iters_per_admm_iter': stats['pcg_iters_total'] / max(res.info.iter, 1),
-                       'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
+                       'pcg_kernels_per_iteration': 2 if fused else 3, 'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
                        'setup_s': t_setup, 'per_rank': [{'status': int(r[0]), 'iter': int(r[1]), 'obj': r[2]} for r in allrec]},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': probes[dom]['GBps'] / HBM_PEAK_GBS, 'traffic': pmc_traffic('k_k2'),
+                         'frac': probes[dom]['GBps'] / HBM_PEAK_GBS, 'traffic': pmc_traffic(dom_kernel),
                          'bytes_per_launch': kb[dom], 'ms_per_launch': probes[dom]['ms'],
                          'pcg_iteration': {'bytes': pcg_bytes, 'ms': pcg_ms, 'GBps': pcg_bytes / (pcg_ms * 1e-3) / 1e9,
                                            'frac': pcg_bytes / (pcg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},

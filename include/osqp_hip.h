@@ -179,6 +179,7 @@ typedef struct {
   double graph_launches;      /* hipGraphLaunch calls                                     */
   double gpu_solve_ms;        /* hipEvent time around the ADMM loop                       */
   double nnzA, nnzB;          /* stored entries of A (CSR) and B = [P+sigma I | A'] (CSR) */
+  double pcg_fused;           /* 1: two-kernel PCG iteration (k_k2f, k_k1f); 0: three (k_k1, k_k2, k_kv) */
 } OSQPHipStats;
 OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
 

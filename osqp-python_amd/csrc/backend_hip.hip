@@ -848,10 +848,12 @@ float time_kernel(Dev &d, int which, int reps) {
       case 7: K1(2); KV(2); break;            // ... without K2   (6 minus 7 = K2's time inside the sequence, L2-cold like in a solve)
       case 8: K2(); KV(2); break;             // ... without K1
       case 9: K1(2); K2(); break;             // ... without Kv
+      case 11: LAUNCH(k_k1f, d, d, 1); break;  // fused SpMV-A + vector update alone (alpha fixed by the stored history; drifts linearly, bounded)
+      case 12: LAUNCH(k_k2f, d, d, 0); break;  // fused SpMV-B alone
       default: LAUNCH(k_k2f, d, d, 0); LAUNCH(k_k1f, d, d, 1); break;   // one FUSED PCG iteration (two kernels): repeated exact line-search steps, bounded
     }
   };
-  if (which == 10) HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, 0, sizeof(int), st(d)));
+  if (which >= 10) HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, 0, sizeof(int), st(d)));
   for (int w = 0; w < 5; w++) launch();
   HIP_CHECK(hipEventRecord(p.ev0, st(d)));
   for (int r = 0; r < reps; r++) launch();

@@ -350,7 +350,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   d_.rho = dv(m); d_.rho_inv = dv(m); d_.ctype = dev_vec<int>(d_, m);
   d_.x = dv(n); d_.z = dv(m); d_.y = dv(m); d_.dx = dv(n); d_.dy = dv(m); d_.xs = dv(n); d_.zt = dv(m); d_.t0 = dv(m); d_.v = dv(m);
   d_.r = dv(n); d_.uu = dv(n); d_.p = dv(n); d_.s = dv(n); d_.w = dv(n); d_.t = dv(m); d_.Minv = dv(n); d_.uu2 = dv(n); d_.ms = dv(n);
-  { const char *f = std::getenv("OSQP_HIP_PCG_FUSED"); d_.fused = (f && f[0] == '1') ? 1 : 0; }
+  { const char *f = std::getenv("OSQP_HIP_PCG_FUSED"); d_.fused = (f && f[0] == '0') ? 0 : 1; }   // default on; =0 selects the 3-kernel sequence
   d_.part = dv((size_t)32 * kGrid); d_.res = dv(R_COUNT); d_.scal = dv(S_HIST + 3 * (kMaxCg + 1)); d_.flags = dev_vec<int>(d_, F_COUNT);
   be::h2d(d_, d_.D, D_.data(), sizeof(double) * n); be::h2d(d_, d_.Dinv, Dinv_.data(), sizeof(double) * n);
   be::h2d(d_, d_.E, E_.data(), sizeof(double) * m); be::h2d(d_, d_.Einv, Einv_.data(), sizeof(double) * m);
@@ -847,11 +847,11 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   return err;
 }
 
-int Engine::get_stats(OSQPHipStats *out) { if (!out) return OSQP_DATA_VALIDATION_ERROR; *out = stats_; return OSQP_NO_ERROR; }
+int Engine::get_stats(OSQPHipStats *out) { if (!out) return OSQP_DATA_VALIDATION_ERROR; *out = stats_; out->pcg_fused = be::pcg_fused(d_) ? 1.0 : 0.0; return OSQP_NO_ERROR; }
 int Engine::time_kernel(int which, int reps, double *ms) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);
-  if (which < 0 || which > 10 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
+  if (which < 0 || which > 12 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
   *ms = be::time_kernel(d_, which, reps);
   return OSQP_NO_ERROR;
 }
