@@ -204,6 +204,9 @@ OSQPInt osqp_hip_batch_solve(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat
                              OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm);
 
 /* Test hooks (used by tests/ only): y = A x, y = B [xn; xm] on the device with the scaled matrices. */
+/* Diagnostic builds only (make TRACE=1: kernels stamp the wall clock per workgroup and phase, 16 slots per workgroup):
+ * copies the stamps of the most recent launches.  The product library returns OSQP_FUNC_NOT_IMPLEMENTED. */
+OSQPInt osqp_hip_trace_read(OSQPSolver *solver, unsigned long long *out, OSQPInt count);
 OSQPInt osqp_hip_test_spmv(OSQPSolver *solver, OSQPInt which, const OSQPFloat *in, OSQPFloat *out);
 /* Weight of equality rows relative to inequality rows, rho_eq = factor * rho, used when equality and inequality rows are
    mixed (default 10; the reference's 1e3 is kept when every active row is an equality).  See engine.cpp

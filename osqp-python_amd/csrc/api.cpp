@@ -83,6 +83,7 @@ void osqp_set_default_codegen_defines(OSQPCodegenDefines *d) {
 
 OSQPInt osqp_hip_get_stats(OSQPSolver *s, OSQPHipStats *out) { return guarded(s, [&](Engine &e) { return e.get_stats(out); }); }
 OSQPInt osqp_hip_time_kernel(OSQPSolver *s, OSQPInt which, OSQPInt reps, double *ms) { return guarded(s, [&](Engine &e) { return e.time_kernel(which, reps, ms); }); }
+OSQPInt osqp_hip_trace_read(OSQPSolver *s, unsigned long long *out, OSQPInt count) { return guarded(s, [&](Engine &e) { return e.trace_read(out, count); }); }
 OSQPInt osqp_hip_test_spmv(OSQPSolver *s, OSQPInt which, const OSQPFloat *in, OSQPFloat *out) { return guarded(s, [&](Engine &e) { return e.test_spmv(which, in, out); }); }
 OSQPInt osqp_hip_set_rho_eq_factor(OSQPSolver *s, OSQPFloat f) { return guarded(s, [&](Engine &e) { return e.set_rho_eq_factor(f); }); }
 OSQPInt osqp_hip_batch_solve(OSQPSolver *s, OSQPInt nbatch, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u, OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm) {

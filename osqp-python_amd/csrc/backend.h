@@ -162,6 +162,7 @@ void graph_launch(Dev &d, void *g);
 void graph_free(Dev &d, void *g);
 
 // ---- probes / tests ----
+bool ktrace_read(Dev &d, unsigned long long *out, int count);   // diagnostic build only (OSQP_HIP_KTRACE); false otherwise
 void test_spmv(Dev &d, int which, const double *in_dev, double *out_dev);   // 0: out = A in ; 1: out = B in
 float time_kernel(Dev &d, int which, int reps);                             // mean ms per launch
 

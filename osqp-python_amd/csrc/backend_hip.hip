@@ -43,6 +43,15 @@ namespace be {
 namespace {
 
 // partial-reduction slots inside Dev::part (each kGrid doubles)
+// Diagnostic build (-DOSQP_HIP_KTRACE, tools/ktrace.py): lane 0 of every workgroup stamps the 100 MHz wall clock at a few
+// phase boundaries; read back with be::ktrace_read.  Compiles to nothing in the product library.
+#ifdef OSQP_HIP_KTRACE
+constexpr int kTraceSlots = 16;
+__device__ unsigned long long g_ktrace[kGrid * kTraceSlots];
+#define KT(p) do { if (threadIdx.x == 0) g_ktrace[blockIdx.x * kTraceSlots + (p)] = wall_clock64(); } while (0)
+#else
+#define KT(p) do { } while (0)
+#endif
 enum Slot { SL_GAMMA0 = 0, SL_GAMMA1, SL_RN0, SL_RN1, SL_BN, SL_DELTA, SL_RES0 /* .. SL_RES0 + R_COUNT - 1 */ };
 static_assert(SL_RES0 + R_COUNT <= 32, "Dev::part holds 32 slots");
 
@@ -131,15 +140,17 @@ __device__ __forceinline__ void put_partial(double *part, int slot, double v) {
 //                       false abandons the kernel for this workgroup.
 template <int NS, int NBUF = (NS == 1 ? 2 : 1)>
 struct StreamLds { static constexpr int kBuf = NBUF; double prod[NBUF][NS][kChunk]; double red[8]; };
-struct NoPre { __device__ __forceinline__ bool operator()() const { return true; } };
+struct NoPre { [[maybe_unused]] static constexpr int kTraceBase = 0; __device__ __forceinline__ bool operator()() const { return true; } };
 
 __device__ __forceinline__ bool wg_has_rows(const DevCsr &M) {      // same mapping as process_rows
   const int per = (M.nblk + 7) >> 3;
   const int sl = blockIdx.x >> 3;
   return sl < per && (int)(blockIdx.x & 7) * per + sl < M.nblk;
 }
-template <int NS, class G, class E, class Pre>
-__device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds, Pre pre) {
+//   done:           optional device flag; when set the workgroup abandons the kernel.  It is read TOGETHER with the first
+//                   block descriptor (one wait for both scalar loads) instead of ahead of it.
+template <int NS, bool HAS_DONE, class G, class E, class Pre>
+__device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds, Pre pre, const int *done) {
   int buf = 0;
   bool first = true;
   const int4 *desc = reinterpret_cast<const int4 *>(M.blkdesc);
@@ -149,10 +160,20 @@ __device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, 
   // fetching (nearly) the whole vector.
   const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, slots = gridDim.x >> 3;
   const int per = (M.nblk + 7) >> 3;
+  // The done flag and the first descriptor are requested back to back, ahead of any branch that depends on either, so
+  // the kernel's dependent-load chain is  {flag, descriptor} -> {col, val, rowptr} -> gather  (three levels, not five).
+  const int b0 = xcd * per + slot0;
+  const bool has0 = slot0 < per && b0 < M.nblk;
+  int dn = 0;
+  if (HAS_DONE) dn = *done;
+  int4 ds = make_int4(0, 0, 0, 0);
+  if (has0) ds = desc[b0];
+  KT(Pre::kTraceBase + 1);      // flag + first descriptor arrived
+  if (dn) return false;
   for (int sl = slot0; sl < per; sl += slots) {
     const int b = xcd * per + sl;
     if (b >= M.nblk) break;
-    const int4 ds = desc[b];
+    if (sl != slot0) ds = desc[b];
     const int r0 = ds.x, r1 = ds.y, k0 = ds.z, k1 = ds.w;
     const int cnt = k1 - k0;
     if (r1 - r0 == 1 && cnt > kLongRow) {                       // one long row: whole workgroup reduces it
@@ -181,7 +202,7 @@ __device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, 
       const int myr = r0 + threadIdx.x;                          // the row this lane reduces in the first pass
       int ra = 0, rz = 0;
       if (myr < r1) { ra = M.rowptr[myr] - k0; rz = M.rowptr[myr + 1] - k0; e.prefetch(myr); }
-      if (first) { first = false; if (!pre()) return false; }
+      if (first) { first = false; KT(Pre::kTraceBase + 2); if (!pre()) return false; KT(Pre::kTraceBase + 3); }
 #pragma unroll
       for (int u = 0; u < kChunk / kBlock; u++) {                // then the gathers
         const int k = threadIdx.x + u * kBlock;
@@ -193,6 +214,7 @@ __device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, 
         }
       }
       __syncthreads();
+      KT(Pre::kTraceBase + 4);    // products staged
       if (myr < r1) {
         double acc[NS];
 #pragma unroll
@@ -214,6 +236,7 @@ __device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, 
         }
         e.prefetch(r); e(r, acc);
       }
+      KT(Pre::kTraceBase + 5);    // row sums + epilogue done
       if (StreamLds<NS>::kBuf == 2) buf ^= 1;   // the next row block fills the other buffer: one barrier per block suffices
       else __syncthreads();                      // single buffer (two-sum kernels): protect it before the next fill
     }
@@ -221,8 +244,12 @@ __device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, 
   if (first) return pre();   // a workgroup without rows still runs the hook (e.g. workgroup 0 owns the PCG flags)
   return true;
 }
+template <int NS, class G, class E, class Pre>
+__device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds, Pre pre) { return process_rows_impl<NS, false>(M, g, e, lds, pre, nullptr); }
+template <int NS, class G, class E, class Pre>
+__device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds, Pre pre, const int *done) { return process_rows_impl<NS, true>(M, g, e, lds, pre, done); }
 template <int NS, class G, class E>
-__device__ __forceinline__ void process_rows(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds) { process_rows<NS>(M, g, e, lds, NoPre()); }
+__device__ __forceinline__ void process_rows(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds) { process_rows_impl<NS, false>(M, g, e, lds, NoPre(), nullptr); }
 struct NoPrefetch { __device__ __forceinline__ void prefetch(int) {} };
 
 // ---------------------------------------------------------------------------------------------- hot-path kernels
@@ -266,6 +293,7 @@ struct EK1 {
 };
 // PCG stopping test, run by every working workgroup (and workgroup 0) while its first matrix loads are in flight
 struct PreK1 {
+  [[maybe_unused]] static constexpr int kTraceBase = 0;
   const Dev &d; int i, probe; double *red;
   __device__ __forceinline__ bool operator()() const {
     if (probe == 1) return true;
@@ -311,6 +339,7 @@ __global__ __launch_bounds__(kBlock) void k_k2(Dev d, int probe) {
   __syncthreads();
   const double DL = block_sum(e.dl, lds.red);
   put_partial(d.part, SL_DELTA, DL);
+  KT(6);
 }
 
 // Kv ------------------------------------------------------------------------------------------
@@ -403,6 +432,7 @@ struct EK2F {
   }
 };
 struct PreK2F {
+  [[maybe_unused]] static constexpr int kTraceBase = 0;
   const Dev &d; int k; EK2F *e; double *red;
   __device__ __forceinline__ bool operator()() const {
     const PartRegs prn = partial_load(d.part + (SL_RN0 + (k & 1)) * kGrid), pg = partial_load(d.part + (SL_GAMMA0 + (k & 1)) * kGrid);
@@ -421,55 +451,84 @@ struct PreK2F {
 };
 __global__ __launch_bounds__(kBlock) void k_k2f(Dev d, int k) {
   __shared__ StreamLds<1> lds;
-  if (d.flags[F_DONE]) return;
+  KT(0);
   const double *u = (k & 1) ? d.uu2 : d.uu;
   GSplitU g{u, d.t, d.n};
   EK2F e{u, d.Minv, d.s, d.ms};
-  if (!process_rows<1>(d.B, g, e, lds, PreK2F{d, k, &e, lds.red})) return;
+  if (!process_rows<1>(d.B, g, e, lds, PreK2F{d, k, &e, lds.red}, d.flags + F_DONE)) return;
   __syncthreads();
   const double DL = block_sum(e.dl, lds.red);
   put_partial(d.part, SL_DELTA, DL);
+  KT(6);
 }
 struct GTwoGather { const double *u, *ms; double alpha; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * (u[c] - alpha * ms[c]); } };
+// Hook of k_k1f, run after the first row block's matrix loads are in flight: alpha from the delta partials, then this
+// workgroup's slice of the vector update of iteration k.
+struct PreK1F {
+  [[maybe_unused]] static constexpr int kTraceBase = 8;
+  const Dev &d; int k; bool has_vec; GTwoGather *gr; double *red; double *g, *rn;
+  __device__ __forceinline__ bool operator()() const {
+    const double *uin = (k & 1) ? d.uu2 : d.uu;
+    double *uout = (k & 1) ? d.uu : d.uu2;
+    double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1, *bet = d.scal + S_HIST + 2 * (kMaxCg + 1);
+    const PartRegs pd = partial_load(d.part + SL_DELTA * kGrid);
+    const double gamma = gam[k], beta = bet[k];
+    const double alast = k == 0 ? 1.0 : alp[k - 1];
+    const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3, slots = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+    // first slice's operands are requested before the reduction's barriers
+    const int j0 = (xcd * per + slot0) * kBlock + threadIdx.x;
+    const bool live0 = has_vec && j0 < d.n;
+    double u0 = 0, p0 = 0, r0 = 0, s0 = 0, m0 = 0, x0 = 0;
+    if (live0) { u0 = uin[j0]; p0 = k == 0 ? 0.0 : d.p[j0]; r0 = d.r[j0]; s0 = d.s[j0]; m0 = d.Minv[j0]; x0 = d.xs[j0]; }
+    const double delta = block_sum(partial_fold_sum(pd), red);
+    const double alpha = k == 0 ? gamma / delta : gamma / (delta - beta * gamma / alast);
+    if (blockIdx.x == 0 && threadIdx.x == 0) alp[k] = alpha;
+    gr->alpha = alpha;
+    double gg = 0, rr = 0;
+    if (live0) {
+      const double pp_ = k == 0 ? u0 : u0 + beta * p0;
+      const double rr_ = r0 - alpha * s0, un = m0 * rr_;
+      d.p[j0] = pp_; d.xs[j0] = x0 + alpha * pp_; d.r[j0] = rr_; uout[j0] = un;
+      gg += rr_ * un; rr = nanmax(rr, fabs(rr_));
+    }
+    if (has_vec) {
+      for (int sl = slot0 + slots; sl < per; sl += slots) {
+        const int c = xcd * per + sl;
+        if (c >= nchunk) break;
+        const int j = c * kBlock + threadIdx.x;
+        if (j >= d.n) break;
+        const double u = uin[j];
+        const double pp_ = k == 0 ? u : u + beta * d.p[j];
+        const double rr_ = d.r[j] - alpha * d.s[j], un = d.Minv[j] * rr_;
+        d.p[j] = pp_; d.xs[j] += alpha * pp_; d.r[j] = rr_; uout[j] = un;
+        gg += rr_ * un; rr = nanmax(rr, fabs(rr_));
+      }
+    }
+    *g = gg; *rn = rr;
+    return true;
+  }
+};
 __global__ __launch_bounds__(kBlock) void k_k1f(Dev d, int i) {          // i >= 1; performs the vector update of k = i - 1
   __shared__ StreamLds<1> lds;
-  if (d.flags[F_DONE]) return;
+  KT(8);
   const int k = i - 1;
   const bool has_rows = wg_has_rows(d.A);
-  const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3, slots = gridDim.x >> 3;
+  const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3;
   const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
   const bool has_vec = slot0 < per && xcd * per + slot0 < nchunk;
-  if (!has_rows && !has_vec && blockIdx.x != 0) {
+  if (!has_rows && !has_vec && blockIdx.x != 0) {     // (partials of a finished PCG are never read: no flag test needed)
     put_partial(d.part, SL_GAMMA0 + (i & 1), 0.0); put_partial(d.part, SL_RN0 + (i & 1), 0.0);
     return;
   }
-  const double *uin = (k & 1) ? d.uu2 : d.uu;
-  double *uout = (k & 1) ? d.uu : d.uu2;
-  double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1, *bet = d.scal + S_HIST + 2 * (kMaxCg + 1);
-  const double delta = block_sum(partial_fold_sum(partial_load(d.part + SL_DELTA * kGrid)), lds.red);
-  const double gamma = gam[k], beta = bet[k];
-  const double alpha = k == 0 ? gamma / delta : gamma / (delta - beta * gamma / alp[k - 1]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) alp[k] = alpha;
   double g = 0, rn = 0;
-  if (has_vec) {
-    for (int sl = slot0; sl < per; sl += slots) {
-      const int c = xcd * per + sl;
-      if (c >= nchunk) break;
-      const int j = c * kBlock + threadIdx.x;
-      if (j >= d.n) break;
-      const double u = uin[j];
-      const double pp_ = k == 0 ? u : u + beta * d.p[j];
-      const double rr_ = d.r[j] - alpha * d.s[j], un = d.Minv[j] * rr_;
-      d.p[j] = pp_; d.xs[j] += alpha * pp_; d.r[j] = rr_; uout[j] = un;
-      g += rr_ * un; rn = nanmax(rn, fabs(rr_));
-    }
-  }
-  GTwoGather gr{uin, d.ms, alpha};
+  GTwoGather gr{(k & 1) ? d.uu2 : d.uu, d.ms, 0.0};
   EK1 e{d.rho, d.t};
-  process_rows<1>(d.A, gr, e, lds);
+  if (!process_rows<1>(d.A, gr, e, lds, PreK1F{d, k, has_vec, &gr, lds.red, &g, &rn}, d.flags + F_DONE)) return;
   __syncthreads();
   block_sum_max(g, rn, lds.red);
   put_partial(d.part, SL_GAMMA0 + (i & 1), g); put_partial(d.part, SL_RN0 + (i & 1), rn);
+  KT(14);
 }
 
 // KA ------------------------------------------------------------------------------------------
@@ -868,6 +927,20 @@ float time_kernel(Dev &d, int which, int reps) {
   }
   HIP_CHECK(hipMemcpy(d.flags, flags_bak, sizeof(flags_bak), hipMemcpyHostToDevice));
   return ms / reps;
+}
+
+// Diagnostic: workgroup phase stamps of the last launches (count <= kGrid * 16); false when built without OSQP_HIP_KTRACE.
+bool ktrace_read(Dev &d, unsigned long long *out, int count) {
+#ifdef OSQP_HIP_KTRACE
+  HIP_CHECK(hipSetDevice(d.device));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  if (count > kGrid * kTraceSlots) count = kGrid * kTraceSlots;
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ktrace), sizeof(unsigned long long) * count));
+  return true;
+#else
+  (void)d; (void)out; (void)count;
+  return false;
+#endif
 }
 
 }  // namespace be

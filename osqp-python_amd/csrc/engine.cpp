@@ -855,6 +855,11 @@ int Engine::time_kernel(int which, int reps, double *ms) {
   *ms = be::time_kernel(d_, which, reps);
   return OSQP_NO_ERROR;
 }
+int Engine::trace_read(unsigned long long *out, int count) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (!out || count <= 0) return OSQP_DATA_VALIDATION_ERROR;
+  return be::ktrace_read(d_, out, count) ? OSQP_NO_ERROR : OSQP_FUNC_NOT_IMPLEMENTED;
+}
 int Engine::test_spmv(int which, const double *in, double *out) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);

@@ -36,6 +36,7 @@ class Engine {
   int get_stats(OSQPHipStats *out);
   int time_kernel(int which, int reps, double *ms);
   int test_spmv(int which, const double *in, double *out);
+  int trace_read(unsigned long long *out, int count);
   int get_scaling(double *D, double *E, double *c);
   int set_rho_eq_factor(double f);
   int batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm);

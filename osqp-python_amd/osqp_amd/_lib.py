@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libosqp_hip.so')
+# OSQP_HIP_LIBRARY selects another build of the same engine (e.g. the diagnostic libosqp_hip_trace.so of tools/ktrace.py)
+LIB_PATH = os.environ.get('OSQP_HIP_LIBRARY') or os.path.join(_HERE, 'libosqp_hip.so')
 
 c_int_p = C.POINTER(C.c_int)
 c_double_p = C.POINTER(C.c_double)
@@ -83,6 +84,7 @@ PROTOTYPES = {
     'osqp_set_default_codegen_defines': (None, [C.c_void_p]),
     'osqp_hip_get_stats': (C.c_int, [SolverP, C.POINTER(StatsStruct)]),
     'osqp_hip_time_kernel': (C.c_int, [SolverP, C.c_int, C.c_int, c_double_p]),
+    'osqp_hip_trace_read': (C.c_int, [SolverP, C.POINTER(C.c_ulonglong), C.c_int]),
     'osqp_hip_test_spmv': (C.c_int, [SolverP, C.c_int, c_double_p, c_double_p]),
     'osqp_hip_set_rho_eq_factor': (C.c_int, [SolverP, C.c_double]),
     'osqp_hip_batch_solve': (C.c_int, [SolverP, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),

@@ -224,6 +224,13 @@ class OSQPSolver:
             raise ValueError(str(st))
         return ms.value
 
+    def hip_trace_read(self, count=1024 * 16):
+        buf = (C.c_ulonglong * count)()
+        st = self._lib.osqp_hip_trace_read(self._p, buf, count)
+        if st:
+            raise ValueError(str(st))
+        return np.frombuffer(buf, dtype=np.uint64).copy()
+
     def hip_test_spmv(self, which, vec):
         vec = _vec(vec)
         out = np.empty(self.m if which == 0 else self.n)

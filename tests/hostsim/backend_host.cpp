@@ -217,6 +217,7 @@ void *graph_end(Dev &) { return nullptr; }
 void graph_launch(Dev &, void *) {}
 void graph_free(Dev &, void *) {}
 
+bool ktrace_read(Dev &, unsigned long long *, int) { return false; }
 void test_spmv(Dev &d, int which, const double *in, double *out) {
   const DevCsr &M = which == 0 ? d.A : d.B;
   for (int r = 0; r < M.nrows; r++) { double a = 0; for (int k = M.rowptr[r]; k < M.rowptr[r + 1]; k++) a += M.val[k] * in[M.col[k]]; out[r] = a; }
