@@ -69,7 +69,7 @@ struct Dev {
   double *v = nullptr;           // rho .* z - y
   // PCG (Chronopoulos-Gear single-reduction form)
   double *r = nullptr, *uu = nullptr, *p = nullptr, *s = nullptr, *w = nullptr, *t = nullptr, *Minv = nullptr;
-  double *uu2 = nullptr, *ms = nullptr;  // fused PCG: u_k lives in (k&1 ? uu2 : uu); ms = Minv .* s
+  double *uu2 = nullptr, *ms = nullptr;  // fused PCG: u_k lives in (k&1 ? uu2 : uu); ms (2n) = interleaved pairs {u_k[j], (Minv .* s_k)[j]}
   int fused = 0;                 // 1: two kernels per PCG iteration (vector update k-1 fused into the SpMV-A kernel of iteration k)
   // reductions
   double *part = nullptr;        // [slot][kGrid] partial results, slots see backend implementation

@@ -119,8 +119,10 @@ __device__ __forceinline__ void block_sum_max(double &a, double &b, double *sred
 struct PartRegs { double v[kGrid / kBlock]; };
 __device__ __forceinline__ PartRegs partial_load(const double *slot) {
   PartRegs r;
-#pragma unroll
-  for (int k = 0; k < kGrid / kBlock; k++) r.v[k] = slot[threadIdx.x + k * kBlock];
+  static_assert(kGrid / kBlock == 4, "partial_load reads four consecutive partials per lane");
+  const double2 *s2 = reinterpret_cast<const double2 *>(slot) + 2 * threadIdx.x;      // two 16-byte loads per lane (half the
+  const double2 a = s2[0], b = s2[1];                                                  // requests of four strided 8-byte ones: +3.5 %)
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
   return r;
 }
 __device__ __forceinline__ double partial_fold_sum(const PartRegs &r) { double v = 0; for (int k = 0; k < kGrid / kBlock; k++) v += r.v[k]; return v; }
@@ -147,12 +149,41 @@ __device__ __forceinline__ bool wg_has_rows(const DevCsr &M) {      // same mapp
   const int sl = blockIdx.x >> 3;
   return sl < per && (int)(blockIdx.x & 7) * per + sl < M.nblk;
 }
+// Optional two-phase forms (detected by a nested type), which let process_rows issue every load in the order it is needed
+// -- the memory counter retires loads in issue order, so a wait for a late-issued load drains everything before it:
+//   G:   using Ops;  Ops fetch(int col) const;                 the gathered operand(s), requested as soon as col arrives
+//                    void prod(const Ops &, double val, double (&prod)[NS]) const;   evaluated after the hook
+//   Pre: using Tok;  Tok begin() const;                        the hook's own loads, requested BEFORE the matrix loads
+//                    bool finish(const Tok &) const;           the rest of the hook (runs while the gathers are in flight)
+template <class T, class = void> struct has_ops : std::false_type {};
+template <class T> struct has_ops<T, std::void_t<typename T::Ops>> : std::true_type {};
+template <class T, class = void> struct has_tok : std::false_type {};
+template <class T> struct has_tok<T, std::void_t<typename T::Tok>> : std::true_type {};
+template <class G, bool = has_ops<G>::value> struct GatherOps {
+  struct Ops {};
+  static __device__ __forceinline__ Ops fetch(const G &, int) { return Ops(); }
+  template <int NS> static __device__ __forceinline__ void prod(const G &g, const Ops &, int c, double a, double (&pr)[NS]) { g(c, a, pr); }
+};
+template <class G> struct GatherOps<G, true> {
+  using Ops = typename G::Ops;
+  static __device__ __forceinline__ Ops fetch(const G &g, int c) { return g.fetch(c); }
+  template <int NS> static __device__ __forceinline__ void prod(const G &g, const Ops &o, int, double a, double (&pr)[NS]) { g.prod(o, a, pr); }
+};
+template <class P, bool = has_tok<P>::value> struct PreOps {
+  struct Tok {};
+  static __device__ __forceinline__ Tok begin(const P &) { return Tok(); }
+  static __device__ __forceinline__ bool finish(const P &p, const Tok &) { return p(); }
+};
+template <class P> struct PreOps<P, true> {
+  using Tok = typename P::Tok;
+  static __device__ __forceinline__ Tok begin(const P &p) { return p.begin(); }
+  static __device__ __forceinline__ bool finish(const P &p, const Tok &t) { return p.finish(t); }
+};
 //   done:           optional device flag; when set the workgroup abandons the kernel.  It is read TOGETHER with the first
 //                   block descriptor (one wait for both scalar loads) instead of ahead of it.
 template <int NS, bool HAS_DONE, class G, class E, class Pre>
 __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds, Pre pre, const int *done) {
   int buf = 0;
-  bool first = true;
   const int4 *desc = reinterpret_cast<const int4 *>(M.blkdesc);
   // XCD-contiguous mapping (speed only; correctness never depends on placement): workgroup id b is observed to run on
   // XCD b % 8, so XCD x is given the contiguous row-block range [x*per, (x+1)*per).  Neighbouring row blocks gather
@@ -170,14 +201,15 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
   if (has0) ds = desc[b0];
   KT(Pre::kTraceBase + 1);      // flag + first descriptor arrived
   if (dn) return false;
-  for (int sl = slot0; sl < per; sl += slots) {
-    const int b = xcd * per + sl;
-    if (b >= M.nblk) break;
-    if (sl != slot0) ds = desc[b];
+  if (!has0) return PreOps<Pre>::finish(pre, PreOps<Pre>::begin(pre));   // a workgroup without rows still runs the hook (e.g. workgroup 0 owns the PCG flags)
+  // One row block.  The first one (compile-time tag) also runs the hook; it is a separate instantiation so that no
+  // control-flow join sits between the hook's loads and the matrix loads (a join makes the compiler drain the counter).
+  auto block = [&](auto first_tag, const int4 ds) -> bool {
+    constexpr bool FIRST = decltype(first_tag)::value;
     const int r0 = ds.x, r1 = ds.y, k0 = ds.z, k1 = ds.w;
     const int cnt = k1 - k0;
     if (r1 - r0 == 1 && cnt > kLongRow) {                       // one long row: whole workgroup reduces it
-      if (first) { first = false; if (!pre()) return false; }
+      if constexpr (FIRST) { if (!PreOps<Pre>::finish(pre, PreOps<Pre>::begin(pre))) return false; }
       double acc[NS];
 #pragma unroll
       for (int s = 0; s < NS; s++) acc[s] = 0.0;
@@ -190,58 +222,70 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
 #pragma unroll
       for (int s = 0; s < NS; s++) acc[s] = block_sum(acc[s], lds.red);
       if (threadIdx.x == 0) { e.prefetch(r0); e(r0, acc); }
-    } else {                                                    // many short rows: stage products in LDS
-      int cc[kChunk / kBlock];
-      double vv[kChunk / kBlock];
-#pragma unroll
-      for (int u = 0; u < kChunk / kBlock; u++) {                // unit-stride loads first (all in flight together)
-        const int k = threadIdx.x + u * kBlock;
-        cc[u] = k < cnt ? M.col[k0 + k] : -1;
-        vv[u] = k < cnt ? M.val[k0 + k] : 0.0;
-      }
-      const int myr = r0 + threadIdx.x;                          // the row this lane reduces in the first pass
-      int ra = 0, rz = 0;
-      if (myr < r1) { ra = M.rowptr[myr] - k0; rz = M.rowptr[myr + 1] - k0; e.prefetch(myr); }
-      if (first) { first = false; KT(Pre::kTraceBase + 2); if (!pre()) return false; KT(Pre::kTraceBase + 3); }
-#pragma unroll
-      for (int u = 0; u < kChunk / kBlock; u++) {                // then the gathers
-        const int k = threadIdx.x + u * kBlock;
-        if (cc[u] >= 0) {
-          double pr[NS];
-          g(cc[u], vv[u], pr);
-#pragma unroll
-          for (int s = 0; s < NS; s++) lds.prod[buf][s][k] = pr[s];
-        }
-      }
-      __syncthreads();
-      KT(Pre::kTraceBase + 4);    // products staged
-      if (myr < r1) {
-        double acc[NS];
-#pragma unroll
-        for (int s = 0; s < NS; s++) acc[s] = 0.0;
-        for (int k = ra; k < rz; k++) {
-#pragma unroll
-          for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
-        }
-        e(myr, acc);
-      }
-      for (int r = myr + kBlock; r < r1; r += kBlock) {          // blocks with more than kBlock (mostly empty) rows
-        const int a = M.rowptr[r] - k0, z = M.rowptr[r + 1] - k0;
-        double acc[NS];
-#pragma unroll
-        for (int s = 0; s < NS; s++) acc[s] = 0.0;
-        for (int k = a; k < z; k++) {
-#pragma unroll
-          for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
-        }
-        e.prefetch(r); e(r, acc);
-      }
-      KT(Pre::kTraceBase + 5);    // row sums + epilogue done
-      if (StreamLds<NS>::kBuf == 2) buf ^= 1;   // the next row block fills the other buffer: one barrier per block suffices
-      else __syncthreads();                      // single buffer (two-sum kernels): protect it before the next fill
+      return true;
     }
+    // many short rows: stage products in LDS
+    typename PreOps<Pre>::Tok tok = typename PreOps<Pre>::Tok();
+    if constexpr (FIRST) tok = PreOps<Pre>::begin(pre);          // the hook's loads go out first: they are needed first
+    int cc[kChunk / kBlock];
+    double vv[kChunk / kBlock];
+    // (masked, not clamped: a lane past the block's last entry issues nothing.  Re-reading the last entry instead makes the
+    // code branch-free but was measured 6 % slower -- row blocks are ~2/3 full, and the extra requests cost more than the branches)
+#pragma unroll
+    for (int u = 0; u < kChunk / kBlock; u++) { const int k = threadIdx.x + u * kBlock; cc[u] = k < cnt ? M.col[k0 + k] : -1; }     // indices first:
+#pragma unroll
+    for (int u = 0; u < kChunk / kBlock; u++) { const int k = threadIdx.x + u * kBlock; vv[u] = k < cnt ? M.val[k0 + k] : 0.0; }    // the gathers wait only for them
+    const int myr = r0 + threadIdx.x;                            // the row this lane reduces in the first pass
+    int rp0 = 0, rp1 = 0;                                        // raw row pointers: not touched before the barrier
+    if (myr < r1) { rp0 = M.rowptr[myr]; rp1 = M.rowptr[myr + 1]; e.prefetch(myr); }
+    KT(Pre::kTraceBase + 2);
+    typename GatherOps<G>::Ops ops[kChunk / kBlock];
+#pragma unroll
+    for (int u = 0; u < kChunk / kBlock; u++) if (cc[u] >= 0) ops[u] = GatherOps<G>::fetch(g, cc[u]);   // gathers requested as the indices arrive
+    if constexpr (FIRST) { if (!PreOps<Pre>::finish(pre, tok)) return false; KT(Pre::kTraceBase + 3); }
+#pragma unroll
+    for (int u = 0; u < kChunk / kBlock; u++) {
+      if (cc[u] < 0) continue;
+      double pr[NS];
+      GatherOps<G>::template prod<NS>(g, ops[u], cc[u], vv[u], pr);
+#pragma unroll
+      for (int s = 0; s < NS; s++) lds.prod[buf][s][threadIdx.x + u * kBlock] = pr[s];
+    }
+    __syncthreads();
+    KT(Pre::kTraceBase + 4);    // products staged
+    if (myr < r1) {
+      const int ra = rp0 - k0, rz = rp1 - k0;
+      double acc[NS];
+#pragma unroll
+      for (int s = 0; s < NS; s++) acc[s] = 0.0;
+      for (int k = ra; k < rz; k++) {
+#pragma unroll
+        for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
+      }
+      e(myr, acc);
+    }
+    for (int r = myr + kBlock; r < r1; r += kBlock) {            // blocks with more than kBlock (mostly empty) rows
+      const int a = M.rowptr[r] - k0, z = M.rowptr[r + 1] - k0;
+      double acc[NS];
+#pragma unroll
+      for (int s = 0; s < NS; s++) acc[s] = 0.0;
+      for (int k = a; k < z; k++) {
+#pragma unroll
+        for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
+      }
+      e.prefetch(r); e(r, acc);
+    }
+    KT(Pre::kTraceBase + 5);    // row sums + epilogue done
+    if (StreamLds<NS>::kBuf == 2) buf ^= 1;   // the next row block fills the other buffer: one barrier per block suffices
+    else __syncthreads();                      // single buffer (two-sum kernels): protect it before the next fill
+    return true;
+  };
+  if (!block(std::true_type(), ds)) return false;
+  for (int sl = slot0 + slots; sl < per; sl += slots) {
+    const int b = xcd * per + sl;
+    if (b >= M.nblk) break;
+    block(std::false_type(), desc[b]);
   }
-  if (first) return pre();   // a workgroup without rows still runs the hook (e.g. workgroup 0 owns the PCG flags)
   return true;
 }
 template <int NS, class G, class E, class Pre>
@@ -422,28 +466,41 @@ __global__ __launch_bounds__(kBlock) void k_kv(Dev d, int i, int probe) {
 //              u_{k+1} = Minv r  (written to the OTHER u buffer) ; partials gamma_{k+1}, ||r_{k+1}||_inf
 //          (b) t_{k+1} = rho .* (A u_{k+1})  with u_{k+1}[c] = u_k[c] - alpha_k ms_k[c] recomputed at every gathered column
 //              (two gathers), so (b) never waits for (a) of another workgroup.
-struct GSplitU { const double *pn, *pm; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * (c < n ? pn[c] : pm[c - n]); } };
+struct GSplitU {
+  const double *pn, *pm; int n;
+  using Ops = double;
+  __device__ __forceinline__ Ops fetch(int c) const { return c < n ? pn[c] : pm[c - n]; }
+  __device__ __forceinline__ void prod(const Ops &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
+  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * fetch(c); }
+};
 struct EK2F {
   const double *u, *Minv; double *s, *ms; double beta = 0; int first = 0; double dl = 0, pu = 0, pm = 0, ps = 0;
   __device__ __forceinline__ void prefetch(int j) { pu = u[j]; pm = Minv[j]; ps = s[j]; }
   __device__ __forceinline__ void operator()(int j, const double (&sm)[1]) {
     const double w = sm[0], sn = first ? w : w + beta * ps;
-    dl += w * pu; s[j] = sn; ms[j] = pm * sn;
+    dl += w * pu; s[j] = sn;
+    reinterpret_cast<double2 *>(ms)[j] = make_double2(pu, pm * sn);      // the pair k_k1f gathers with one 16-byte load
   }
 };
 struct PreK2F {
   [[maybe_unused]] static constexpr int kTraceBase = 0;
   const Dev &d; int k; EK2F *e; double *red;
-  __device__ __forceinline__ bool operator()() const {
-    const PartRegs prn = partial_load(d.part + (SL_RN0 + (k & 1)) * kGrid), pg = partial_load(d.part + (SL_GAMMA0 + (k & 1)) * kGrid);
-    double gamma = partial_fold_sum(pg), rn = partial_fold_max(prn);
+  struct Tok { PartRegs prn, pg; double tol, glast; };
+  __device__ __forceinline__ Tok begin() const {
+    Tok t;
+    t.prn = partial_load(d.part + (SL_RN0 + (k & 1)) * kGrid); t.pg = partial_load(d.part + (SL_GAMMA0 + (k & 1)) * kGrid);
+    t.tol = d.scal[S_TOL_NOW]; t.glast = k == 0 ? 1.0 : d.scal[S_HIST + k - 1];
+    return t;
+  }
+  __device__ __forceinline__ bool finish(const Tok &t) const {
+    double gamma = partial_fold_sum(t.pg), rn = partial_fold_max(t.prn);
     block_sum_max(gamma, rn, red);
     double *gam = d.scal + S_HIST, *bet = d.scal + S_HIST + 2 * (kMaxCg + 1);
-    if (k > 0 && !(rn > d.scal[S_TOL_NOW])) {        // converged after k iterations (k == 0 was tested by k_k1)
+    if (k > 0 && !(rn > t.tol)) {        // converged after k iterations (k == 0 was tested by k_k1)
       if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = k; }
       return false;
     }
-    const double beta = k == 0 ? 0.0 : gamma / gam[k - 1];
+    const double beta = k == 0 ? 0.0 : gamma / t.glast;
     if (blockIdx.x == 0 && threadIdx.x == 0) { gam[k] = gamma; bet[k] = beta; }
     e->beta = beta; e->first = (k == 0);
     return true;
@@ -461,26 +518,45 @@ __global__ __launch_bounds__(kBlock) void k_k2f(Dev d, int k) {
   put_partial(d.part, SL_DELTA, DL);
   KT(6);
 }
-struct GTwoGather { const double *u, *ms; double alpha; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * (u[c] - alpha * ms[c]); } };
+struct GTwoGather {
+  const double *ms; double alpha;       // ms: interleaved pairs {u_k[j], (Minv .* s_k)[j]} written by k_k2f
+  struct Ops { double u, ms; };
+  __device__ __forceinline__ Ops fetch(int c) const { const double2 v = reinterpret_cast<const double2 *>(ms)[c]; return Ops{v.x, v.y}; }
+  __device__ __forceinline__ void prod(const Ops &o, double a, double (&pr)[1]) const { pr[0] = a * (o.u - alpha * o.ms); }   // alpha: set by the hook
+  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { prod(fetch(c), a, pr); }
+};
 // Hook of k_k1f, run after the first row block's matrix loads are in flight: alpha from the delta partials, then this
 // workgroup's slice of the vector update of iteration k.
 struct PreK1F {
   [[maybe_unused]] static constexpr int kTraceBase = 8;
   const Dev &d; int k; bool has_vec; GTwoGather *gr; double *red; double *g, *rn;
-  __device__ __forceinline__ bool operator()() const {
+  struct Tok { PartRegs pd; double gamma, beta, alast; double u0, p0, r0, s0, m0, x0; };
+  __device__ __forceinline__ int first_index() const {
+    const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3;
+    return (int)(((blockIdx.x & 7) * per + (blockIdx.x >> 3)) * kBlock + threadIdx.x);
+  }
+  __device__ __forceinline__ Tok begin() const {
+    const double *uin = (k & 1) ? d.uu2 : d.uu;
+    const double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1, *bet = d.scal + S_HIST + 2 * (kMaxCg + 1);
+    Tok t;
+    t.pd = partial_load(d.part + SL_DELTA * kGrid);
+    t.gamma = gam[k]; t.beta = bet[k]; t.alast = k == 0 ? 1.0 : alp[k - 1];
+    const int j0 = first_index();
+    t.u0 = t.p0 = t.r0 = t.s0 = t.m0 = t.x0 = 0.0;
+    if (has_vec && j0 < d.n) { t.u0 = uin[j0]; t.p0 = k == 0 ? 0.0 : d.p[j0]; t.r0 = d.r[j0]; t.s0 = d.s[j0]; t.m0 = d.Minv[j0]; t.x0 = d.xs[j0]; }
+    return t;
+  }
+  __device__ __forceinline__ bool finish(const Tok &t) const {
     const double *uin = (k & 1) ? d.uu2 : d.uu;
     double *uout = (k & 1) ? d.uu : d.uu2;
-    double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1, *bet = d.scal + S_HIST + 2 * (kMaxCg + 1);
-    const PartRegs pd = partial_load(d.part + SL_DELTA * kGrid);
-    const double gamma = gam[k], beta = bet[k];
-    const double alast = k == 0 ? 1.0 : alp[k - 1];
+    double *alp = d.scal + S_HIST + kMaxCg + 1;
+    const PartRegs &pd = t.pd;
+    const double gamma = t.gamma, beta = t.beta, alast = t.alast;
     const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3, slots = gridDim.x >> 3;
     const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
-    // first slice's operands are requested before the reduction's barriers
-    const int j0 = (xcd * per + slot0) * kBlock + threadIdx.x;
+    const int j0 = first_index();
     const bool live0 = has_vec && j0 < d.n;
-    double u0 = 0, p0 = 0, r0 = 0, s0 = 0, m0 = 0, x0 = 0;
-    if (live0) { u0 = uin[j0]; p0 = k == 0 ? 0.0 : d.p[j0]; r0 = d.r[j0]; s0 = d.s[j0]; m0 = d.Minv[j0]; x0 = d.xs[j0]; }
+    const double u0 = t.u0, p0 = t.p0, r0 = t.r0, s0 = t.s0, m0 = t.m0, x0 = t.x0;
     const double delta = block_sum(partial_fold_sum(pd), red);
     const double alpha = k == 0 ? gamma / delta : gamma / (delta - beta * gamma / alast);
     if (blockIdx.x == 0 && threadIdx.x == 0) alp[k] = alpha;
@@ -522,7 +598,7 @@ __global__ __launch_bounds__(kBlock) void k_k1f(Dev d, int i) {          // i >=
     return;
   }
   double g = 0, rn = 0;
-  GTwoGather gr{(k & 1) ? d.uu2 : d.uu, d.ms, 0.0};
+  GTwoGather gr{d.ms, 0.0};
   EK1 e{d.rho, d.t};
   if (!process_rows<1>(d.A, gr, e, lds, PreK1F{d, k, has_vec, &gr, lds.red, &g, &rn}, d.flags + F_DONE)) return;
   __syncthreads();
@@ -883,7 +959,7 @@ float time_kernel(Dev &d, int which, int reps) {
   const size_t n = d.n, m = d.m;
   Save sv[] = {{d.x, n, nullptr}, {d.z, m, nullptr}, {d.y, m, nullptr}, {d.xs, n, nullptr}, {d.zt, m, nullptr}, {d.t0, m, nullptr},
                {d.v, m, nullptr}, {d.dx, n, nullptr}, {d.dy, m, nullptr}, {d.r, n, nullptr}, {d.uu, n, nullptr}, {d.p, n, nullptr},
-               {d.s, n, nullptr}, {d.w, n, nullptr}, {d.t, m, nullptr}, {d.uu2, n, nullptr}, {d.ms, n, nullptr}};
+               {d.s, n, nullptr}, {d.w, n, nullptr}, {d.t, m, nullptr}, {d.uu2, n, nullptr}, {d.ms, 2 * n, nullptr}};
   int flags_bak[F_COUNT];
   HIP_CHECK(hipStreamSynchronize(st(d)));
   HIP_CHECK(hipMemcpy(flags_bak, d.flags, sizeof(flags_bak), hipMemcpyDeviceToHost));

@@ -349,7 +349,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   d_.q = dv(n); d_.l = dv(m); d_.u = dv(m); d_.D = dv(n); d_.Dinv = dv(n); d_.E = dv(m); d_.Einv = dv(m);
   d_.rho = dv(m); d_.rho_inv = dv(m); d_.ctype = dev_vec<int>(d_, m);
   d_.x = dv(n); d_.z = dv(m); d_.y = dv(m); d_.dx = dv(n); d_.dy = dv(m); d_.xs = dv(n); d_.zt = dv(m); d_.t0 = dv(m); d_.v = dv(m);
-  d_.r = dv(n); d_.uu = dv(n); d_.p = dv(n); d_.s = dv(n); d_.w = dv(n); d_.t = dv(m); d_.Minv = dv(n); d_.uu2 = dv(n); d_.ms = dv(n);
+  d_.r = dv(n); d_.uu = dv(n); d_.p = dv(n); d_.s = dv(n); d_.w = dv(n); d_.t = dv(m); d_.Minv = dv(n); d_.uu2 = dv(n); d_.ms = dv(2 * (size_t)n);
   { const char *f = std::getenv("OSQP_HIP_PCG_FUSED"); d_.fused = (f && f[0] == '0') ? 0 : 1; }   // default on; =0 selects the 3-kernel sequence
   d_.part = dv((size_t)32 * kGrid); d_.res = dv(R_COUNT); d_.scal = dv(S_HIST + 3 * (kMaxCg + 1)); d_.flags = dev_vec<int>(d_, F_COUNT);
   be::h2d(d_, d_.D, D_.data(), sizeof(double) * n); be::h2d(d_, d_.Dinv, Dinv_.data(), sizeof(double) * n);
