@@ -25,9 +25,13 @@ namespace osqp_hip {
 // osqp_error_type value -- the library never calls abort() and never falls back to a CPU path.
 struct DeviceError : std::runtime_error { using std::runtime_error::runtime_error; };
 
-constexpr int kBlock = 256;        // threads per workgroup (4 wave64)
-constexpr int kGrid = 1024;        // workgroups per launch = number of partial-reduction slots
-constexpr int kChunk = 2048;       // nnz staged through LDS per row-block (8 per thread, all loads in flight at once)
+#ifndef OSQP_HIP_KBLOCK
+#define OSQP_HIP_KBLOCK 256
+#define OSQP_HIP_KGRID 1024
+#endif
+constexpr int kBlock = OSQP_HIP_KBLOCK;   // threads per workgroup (wave64s)
+constexpr int kGrid = OSQP_HIP_KGRID;     // workgroups per launch = number of partial-reduction slots
+constexpr int kChunk = 8 * kBlock;        // nnz staged through LDS per row-block (8 per thread, all loads in flight at once)
 constexpr int kLongRow = 128;      // rows with more nnz get a workgroup of their own (block-wide reduction)
 constexpr int kMaxRowsPerBlock = 1024;
 constexpr int kMaxCg = 1024;       // hard cap on the PCG budget (size of the alpha/gamma history)

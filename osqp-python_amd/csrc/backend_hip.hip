@@ -75,12 +75,15 @@ __device__ __forceinline__ double wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = nanmax(v, __shfl_down(v, o, 64));
   return v;
 }
-// all threads receive the block total; sred needs >= 8 doubles
+constexpr int kWaves = kBlock / 64;      // block reductions: one value per wave through LDS; sred needs 2 * kWaves doubles
+__device__ __forceinline__ double sred_sum(const double *s) { double t = 0; for (int w = 0; w < kWaves; w += 2) t += s[w] + s[w + 1]; return t; }
+__device__ __forceinline__ double sred_max(const double *s) { double t = s[0]; for (int w = 1; w < kWaves; w++) t = nanmax(t, s[w]); return t; }
+// all threads receive the block total
 __device__ __forceinline__ double block_sum(double v, double *sred) {
   v = wave_sum(v);
   if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
   __syncthreads();
-  double t = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  double t = sred_sum(sred);
   __syncthreads();
   return t;
 }
@@ -88,45 +91,53 @@ __device__ __forceinline__ double block_max(double v, double *sred) {
   v = wave_max(v);
   if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
   __syncthreads();
-  double t = nanmax(nanmax(sred[0], sred[1]), nanmax(sred[2], sred[3]));
+  double t = sred_max(sred);
   __syncthreads();
   return t;
 }
 // two quantities behind ONE barrier pair
 __device__ __forceinline__ void block_sum2(double &a, double &b, double *sred) {
   a = wave_sum(a); b = wave_sum(b);
-  if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = a; sred[4 + (threadIdx.x >> 6)] = b; }
+  if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; }
   __syncthreads();
-  a = (sred[0] + sred[1]) + (sred[2] + sred[3]); b = (sred[4] + sred[5]) + (sred[6] + sred[7]);
+  a = sred_sum(sred); b = sred_sum(sred + kWaves);
   __syncthreads();
 }
 __device__ __forceinline__ void block_max2(double &a, double &b, double *sred) {
   a = wave_max(a); b = wave_max(b);
-  if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = a; sred[4 + (threadIdx.x >> 6)] = b; }
+  if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; }
   __syncthreads();
-  a = nanmax(nanmax(sred[0], sred[1]), nanmax(sred[2], sred[3])); b = nanmax(nanmax(sred[4], sred[5]), nanmax(sred[6], sred[7]));
+  a = sred_max(sred); b = sred_max(sred + kWaves);
   __syncthreads();
 }
 // a = sum, b = max, ONE barrier pair
 __device__ __forceinline__ void block_sum_max(double &a, double &b, double *sred) {
   a = wave_sum(a); b = wave_max(b);
-  if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = a; sred[4 + (threadIdx.x >> 6)] = b; }
+  if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; }
   __syncthreads();
-  a = (sred[0] + sred[1]) + (sred[2] + sred[3]); b = nanmax(nanmax(sred[4], sred[5]), nanmax(sred[6], sred[7]));
+  a = sred_sum(sred); b = sred_max(sred + kWaves);
   __syncthreads();
 }
-// per-thread slices of the kGrid partials of a slot: issue the loads early, reduce later
-struct PartRegs { double v[kGrid / kBlock]; };
+// per-thread slices of the kGrid partials of a slot: issue the loads early, reduce later.  Every lane reads kPart
+// CONSECUTIVE partials with 16-byte loads where it can (half the requests of strided 8-byte ones: +3.5 %); with fewer
+// partials than threads the first kGrid lanes read one each.
+constexpr int kPart = kGrid >= kBlock ? kGrid / kBlock : 1;
+static_assert(kGrid >= kBlock ? kGrid % kBlock == 0 : kBlock % kGrid == 0, "kGrid and kBlock must divide one another");
+static_assert(kWaves % 2 == 0, "block reductions pair the waves");
+struct PartRegs { double v[kPart]; };
 __device__ __forceinline__ PartRegs partial_load(const double *slot) {
   PartRegs r;
-  static_assert(kGrid / kBlock == 4, "partial_load reads four consecutive partials per lane");
-  const double2 *s2 = reinterpret_cast<const double2 *>(slot) + 2 * threadIdx.x;      // two 16-byte loads per lane (half the
-  const double2 a = s2[0], b = s2[1];                                                  // requests of four strided 8-byte ones: +3.5 %)
-  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
+  if (kPart % 2 == 0) {
+    const double2 *s2 = reinterpret_cast<const double2 *>(slot) + (kPart / 2) * threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kPart / 2; k++) { const double2 a = s2[k]; r.v[2 * k] = a.x; r.v[2 * k + 1] = a.y; }
+  } else {
+    r.v[0] = (kGrid >= kBlock || (int)threadIdx.x < kGrid) ? slot[threadIdx.x] : 0.0;     // 0: identity of both folds (maxima are of magnitudes)
+  }
   return r;
 }
-__device__ __forceinline__ double partial_fold_sum(const PartRegs &r) { double v = 0; for (int k = 0; k < kGrid / kBlock; k++) v += r.v[k]; return v; }
-__device__ __forceinline__ double partial_fold_max(const PartRegs &r) { double v = 0; for (int k = 0; k < kGrid / kBlock; k++) v = nanmax(v, r.v[k]); return v; }
+__device__ __forceinline__ double partial_fold_sum(const PartRegs &r) { double v = 0; for (int k = 0; k < kPart; k++) v += r.v[k]; return v; }
+__device__ __forceinline__ double partial_fold_max(const PartRegs &r) { double v = 0; for (int k = 0; k < kPart; k++) v = nanmax(v, r.v[k]); return v; }
 __device__ __forceinline__ double partial_sum(const double *slot, double *sred) { return block_sum(partial_fold_sum(partial_load(slot)), sred); }
 __device__ __forceinline__ double partial_max(const double *slot, double *sred) { return block_max(partial_fold_max(partial_load(slot)), sred); }
 __device__ __forceinline__ void put_partial(double *part, int slot, double v) {
@@ -141,7 +152,7 @@ __device__ __forceinline__ void put_partial(double *part, int slot, double v) {
 //                       whatever it waits for -- a reduction of partials, a flag -- overlaps those loads); returning
 //                       false abandons the kernel for this workgroup.
 template <int NS, int NBUF = (NS == 1 ? 2 : 1)>
-struct StreamLds { static constexpr int kBuf = NBUF; double prod[NBUF][NS][kChunk]; double red[8]; };
+struct StreamLds { static constexpr int kBuf = NBUF; double prod[NBUF][NS][kChunk]; double red[2 * kWaves]; };
 struct NoPre { [[maybe_unused]] static constexpr int kTraceBase = 0; __device__ __forceinline__ bool operator()() const { return true; } };
 
 __device__ __forceinline__ bool wg_has_rows(const DevCsr &M) {      // same mapping as process_rows
@@ -390,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void k_k2(Dev d, int probe) {
 // VEC = 2: one double2 per lane (large n); VEC = 1: one double per lane (keeps more workgroups busy at mid-size n)
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_kv(Dev d, int i, int probe) {
-  __shared__ double sred[8];
+  __shared__ double sred[2 * kWaves];
   const int nv = d.n / VEC;                                       // vector elements (tail handled by workgroup 0)
   // XCD-contiguous chunks of kBlock elements, as in process_rows (each XCD keeps 'its' eighth of the PCG vectors)
   const int nchunk = (nv + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3, slots = gridDim.x >> 3;
@@ -712,7 +723,7 @@ __device__ __forceinline__ bool res_is_sum(int q) {
 }
 // final reduction of the per-workgroup partials: workgroup b handles quantity q0 + b
 __global__ __launch_bounds__(kBlock) void k_res_final(Dev d, int q0) {
-  __shared__ double sred[8];
+  __shared__ double sred[2 * kWaves];
   const int q = q0 + blockIdx.x;
   const double *slot = d.part + (SL_RES0 + q) * kGrid;
   const double v = res_is_sum(q) ? partial_sum(slot, sred) : partial_max(slot, sred);
@@ -985,10 +996,11 @@ float time_kernel(Dev &d, int which, int reps) {
       case 9: K1(2); K2(); break;             // ... without Kv
       case 11: LAUNCH(k_k1f, d, d, 1); break;  // fused SpMV-A + vector update alone (alpha fixed by the stored history; drifts linearly, bounded)
       case 12: LAUNCH(k_k2f, d, d, 0); break;  // fused SpMV-B alone
+      case 13: LAUNCH(k_k2f, d, d, 2); LAUNCH(k_k1f, d, d, 3); break;   // the same pair with the done flag set: what an early-exit pair costs
       default: LAUNCH(k_k2f, d, d, 0); LAUNCH(k_k1f, d, d, 1); break;   // one FUSED PCG iteration (two kernels): repeated exact line-search steps, bounded
     }
   };
-  if (which >= 10) HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, 0, sizeof(int), st(d)));
+  if (which >= 10) HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, which == 13 ? 1 : 0, sizeof(int), st(d)));   // (byte pattern 1 -> nonzero flag)
   for (int w = 0; w < 5; w++) launch();
   HIP_CHECK(hipEventRecord(p.ev0, st(d)));
   for (int r = 0; r < reps; r++) launch();

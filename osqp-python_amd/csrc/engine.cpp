@@ -587,7 +587,8 @@ void Engine::admm_core(double t0, double *res) {
       // set the budget of the next 25 iterations (an occasional budget-limited solve is just a slightly less exact one)
       const double cnt = std::max(1, flags[F_STAT_N]), mean = flags[F_STAT_SUM] / cnt;
       const double var = std::max(0.0, flags[F_STAT_SUMSQ] / cnt - mean * mean);
-      const int q3 = (int)std::ceil(mean + 3.0 * std::sqrt(var));     // (KA checks the residual after the last budgeted iteration)
+      static const double nsig = [] { const char *e = std::getenv("OSQP_HIP_BUDGET_SIGMA"); return e ? std::atof(e) : 3.0; }();
+      const int q3 = (int)std::ceil(mean + nsig * std::sqrt(var));     // (KA checks the residual after the last budgeted iteration)
       cg_budget_ = std::min(cap, std::max(2, std::min(flags[F_STAT_MAX], q3)));
     }
   }
@@ -851,7 +852,7 @@ int Engine::get_stats(OSQPHipStats *out) { if (!out) return OSQP_DATA_VALIDATION
 int Engine::time_kernel(int which, int reps, double *ms) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);
-  if (which < 0 || which > 12 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
+  if (which < 0 || which > 13 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
   *ms = be::time_kernel(d_, which, reps);
   return OSQP_NO_ERROR;
 }
