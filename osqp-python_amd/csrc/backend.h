@@ -61,6 +61,12 @@ struct Dev {
   double rho_eq_factor = 1e3;    // rho_i = rho_eq_factor * rho_bar on equality rows (_osqp.py:27 uses 1e3; see engine.cpp)
   DevCsr A, B;
   int *Bdiag = nullptr;          // position of the diagonal entry of row j inside B.val
+  // device-side assembly (setup, update_data_mat): the caller's UNSCALED values in their CSC order and where each goes
+  double *Praw = nullptr, *Araw = nullptr;
+  int nzP = 0, nzA = 0;
+  int *Pi = nullptr, *Pj = nullptr, *Pm1 = nullptr, *Pm2 = nullptr;   // row, column, position in B.val, position of the mirrored entry (-1: diagonal)
+  int *Ai = nullptr, *Aj = nullptr, *AmA = nullptr, *AmB = nullptr;   // row, column, position in A.val, position in B.val
+  double *cs = nullptr;          // [2] device scalars of the equilibration: cost scale c, this pass's factor
   // problem data (scaled) and scaling
   double *q = nullptr, *l = nullptr, *u = nullptr, *D = nullptr, *Dinv = nullptr, *E = nullptr, *Einv = nullptr;
   double *rho = nullptr, *rho_inv = nullptr;
@@ -164,6 +170,16 @@ void graph_begin(Dev &d);                 // start capturing d.stream
 void *graph_end(Dev &d);                  // stop capturing, instantiate; returns executable-graph handle
 void graph_launch(Dev &d, void *g);
 void graph_free(Dev &d, void *g);
+
+// ---- assembly / scaling on the device ----
+// false: the driver scales on the host and uploads finished value arrays (the test-only host simulator).
+bool device_assembly();
+// A.val, B.val <- scatter of Araw / Praw through the maps, scaled as  E A D  and  c D P D  when scaled != 0, with sigma on B's
+// diagonal when with_sigma != 0   (_osqp.py:432-436, 464, 1443, 1463)
+void assemble(Dev &d, int scaled, double c, int with_sigma);
+// Ruiz equilibration + cost normalisation (_osqp.py:389-497) of A.val, B.val (assembled unscaled, no sigma) and d.q IN PLACE:
+// fills d.D, d.E, d.Dinv, d.Einv, adds sigma to B's diagonal, returns the cost scale c.  iters == 0: D = E = 1, c = 1.
+double ruiz(Dev &d, int iters);
 
 // ---- probes / tests ----
 bool ktrace_read(Dev &d, unsigned long long *out, int count);   // diagnostic build only (OSQP_HIP_KTRACE); false otherwise

@@ -829,6 +829,83 @@ __global__ __launch_bounds__(kBlock) void k_test_spmv(DevCsr M, const double *in
   process_rows<1>(M, g, e, lds);
 }
 
+
+// ---------------------------------------------------------------------------------------------- assembly and scaling
+// (setup / update_data_mat only: plain grid-stride kernels, one thread per entry or per row)
+__device__ __forceinline__ double limit_scaling_dev(double v) { return v < 1e-4 ? 1.0 : (v > 1e4 ? 1e4 : v); }     // _osqp.py:363-387
+__global__ __launch_bounds__(kBlock) void k_asm_diag(Dev d, double sigma) {
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += gridDim.x * kBlock) d.B.val[d.Bdiag[j]] = sigma;
+}
+__global__ __launch_bounds__(kBlock) void k_asm_scatter(Dev d, int scaled, double c, double sigma) {
+  const int stride = gridDim.x * kBlock;
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < d.nzA; k += stride) {
+    double v = d.Araw[k];
+    if (scaled) v *= d.E[d.Ai[k]] * d.D[d.Aj[k]];
+    d.A.val[d.AmA[k]] = v; d.B.val[d.AmB[k]] = v;
+  }
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < d.nzP; k += stride) {
+    const int i = d.Pi[k], j = d.Pj[k];
+    double v = d.Praw[k];
+    if (scaled) v *= c * d.D[i] * d.D[j];
+    if (i == j) d.B.val[d.Pm1[k]] = sigma + v;          // k_asm_diag has run: an absent diagonal keeps sigma alone
+    else { d.B.val[d.Pm1[k]] = v; d.B.val[d.Pm2[k]] = v; }
+  }
+}
+// out[r] = max |val| over the entries of row r with column < climit
+__global__ __launch_bounds__(kBlock) void k_rowmax(DevCsr M, int climit, double *out) {
+  for (int r = blockIdx.x * kBlock + threadIdx.x; r < M.nrows; r += gridDim.x * kBlock) {
+    double mx = 0.0;
+    for (int k = M.rowptr[r]; k < M.rowptr[r + 1]; k++) if (M.col[k] < climit) mx = fmax(mx, fabs(M.val[k]));
+    out[r] = mx;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_ruiz_delta(double *v, int cnt) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < cnt; i += gridDim.x * kBlock) v[i] = 1.0 / sqrt(limit_scaling_dev(v[i]));
+}
+// A <- diag(et) A diag(dt) ; E *= et
+__global__ __launch_bounds__(kBlock) void k_ruiz_scale_A(Dev d, const double *dt, const double *et) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += gridDim.x * kBlock) {
+    const double ei = et[i];
+    for (int k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; k++) d.A.val[k] *= ei * dt[d.A.col[k]];
+    d.E[i] *= ei;
+  }
+}
+// B = [P | A'] <- [diag(dt) P diag(dt) | diag(dt) A' diag(et)] ; q *= dt ; D *= dt
+__global__ __launch_bounds__(kBlock) void k_ruiz_scale_B(Dev d, const double *dt, const double *et) {
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += gridDim.x * kBlock) {
+    const double dj = dt[j];
+    for (int k = d.B.rowptr[j]; k < d.B.rowptr[j + 1]; k++) {
+      const int c = d.B.col[k];
+      d.B.val[k] *= c < d.n ? dt[c] * dj : et[c - d.n] * dj;     // (same factor, same order of operands, as the entry's copy in A)
+    }
+    d.q[j] *= dj; d.D[j] *= dj;
+  }
+}
+// cost normalisation, one workgroup: ct = 1 / limit(max(limit(||q||_inf), mean_j ||P_:j||_inf)) ; c *= ct     (_osqp.py:443-448)
+__global__ __launch_bounds__(kBlock) void k_ruiz_cost(Dev d, const double *np) {
+  __shared__ double sred[2 * kWaves];
+  double sum = 0.0, nq = 0.0;
+  for (int j = threadIdx.x; j < d.n; j += kBlock) { sum += np[j]; nq = fmax(nq, fabs(d.q[j])); }
+  block_sum_max(sum, nq, sred);
+  if (threadIdx.x == 0) {
+    const double mean = sum / (double)(d.n > 0 ? d.n : 1);
+    const double ct = 1.0 / limit_scaling_dev(fmax(limit_scaling_dev(nq), mean));
+    d.cs[1] = ct; d.cs[0] *= ct;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_ruiz_cost_apply(Dev d) {
+  const double ct = d.cs[1];
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += gridDim.x * kBlock) {
+    for (int k = d.B.rowptr[j]; k < d.B.rowptr[j + 1]; k++) if (d.B.col[k] < d.n) d.B.val[k] *= ct;
+    d.q[j] *= ct;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_ruiz_finish(Dev d, double sigma) {
+  const int stride = gridDim.x * kBlock;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) { d.Dinv[j] = 1.0 / d.D[j]; d.B.val[d.Bdiag[j]] += sigma; }
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += stride) d.Einv[i] = 1.0 / d.E[i];
+}
+
 #define LAUNCH(kernel, d, ...) hipLaunchKernelGGL(kernel, dim3(kGrid), dim3(kBlock), 0, st(d), __VA_ARGS__)
 
 }  // namespace
@@ -942,6 +1019,37 @@ void init_iterates(Dev &d, int full) {
 }
 
 void project_normalcone(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_normalcone, d, d); }
+
+
+bool device_assembly() { return true; }
+void assemble(Dev &d, int scaled, double c, int with_sigma) {
+  HIP_CHECK(hipSetDevice(d.device));
+  const double sg = with_sigma ? d.sigma : 0.0;
+  LAUNCH(k_asm_diag, d, d, sg);
+  LAUNCH(k_asm_scatter, d, d, scaled, c, sg);
+}
+double ruiz(Dev &d, int iters) {
+  HIP_CHECK(hipSetDevice(d.device));
+  const double one[2] = {1.0, 1.0};
+  HIP_CHECK(hipMemcpyAsync(d.cs, one, sizeof(one), hipMemcpyHostToDevice, st(d)));
+  LAUNCH(k_fill, d, d.D, d.n, 1.0);
+  if (d.m > 0) LAUNCH(k_fill, d, d.E, d.m, 1.0);
+  double *dt = d.w, *np = d.p, *et = d.t;            // PCG work vectors are free during setup
+  for (int it = 0; it < iters; it++) {
+    LAUNCH(k_rowmax, d, d.B, d.n + d.m, dt);          // KKT column j = row j of [P | A']      (_norm_KKT_cols :348-361)
+    LAUNCH(k_ruiz_delta, d, dt, d.n);
+    if (d.m > 0) { LAUNCH(k_rowmax, d, d.A, d.n, et); LAUNCH(k_ruiz_delta, d, et, d.m); LAUNCH(k_ruiz_scale_A, d, d, dt, et); }
+    LAUNCH(k_ruiz_scale_B, d, d, dt, et);
+    LAUNCH(k_rowmax, d, d.B, d.n, np);                // column norms of the scaled P
+    hipLaunchKernelGGL(k_ruiz_cost, dim3(1), dim3(kBlock), 0, st(d), d, np);
+    LAUNCH(k_ruiz_cost_apply, d, d);
+  }
+  LAUNCH(k_ruiz_finish, d, d, d.sigma);
+  double cs[2];
+  HIP_CHECK(hipMemcpyAsync(cs, d.cs, sizeof(cs), hipMemcpyDeviceToHost, st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  return cs[0];
+}
 
 bool graphs_supported() { return true; }
 void graph_begin(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipStreamBeginCapture(st(d), hipStreamCaptureModeThreadLocal)); }

@@ -83,7 +83,7 @@ void Engine::free_all() {
   void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag,
                   d_.q, d_.l, d_.u, d_.D, d_.Dinv, d_.E, d_.Einv, d_.rho, d_.rho_inv, d_.ctype, d_.x, d_.z, d_.y, d_.dx,
                   d_.dy, d_.xs, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.uu2, d_.ms, d_.part, d_.res,
-                  d_.scal, d_.flags};
+                  d_.scal, d_.flags, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   be::destroy(d_);
   d_ = Dev();
@@ -244,6 +244,9 @@ void Engine::fill_matrix_values(const std::vector<double> &Px, const std::vector
 int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *A, const double *l, const double *u,
                   int m_, int n_, const OSQPSettings *s) {
   double t0 = now_s();
+  static const bool ptime = std::getenv("OSQP_HIP_SETUP_TIMING") != nullptr;
+  double tl = t0;
+  auto lap = [&](const char *what) { if (ptime) { double t = now_s(); std::fprintf(stderr, "[osqp_hip setup] %-28s %8.2f ms\n", what, 1e3 * (t - tl)); tl = t; } };
   // ---- data validation (the C core's validate_data; error numbering bindings.cpp.in:364-375) ----
   if (!P || !A || !q || n_ <= 0 || m_ < 0) return OSQP_DATA_VALIDATION_ERROR;
   if (m_ > 0 && (!l || !u)) return OSQP_DATA_VALIDATION_ERROR;
@@ -273,15 +276,18 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   };
   copy_csc(P_, P); copy_csc(A_, A);
   q0_.assign(q, q + n); l0_.assign(l, l + m); u0_.assign(u, u + m);
-
-  // ---- scaling on the host (SURVEY §8f rank 1 moves it to the device later) ----
-  std::vector<double> Px = P_.x, Ax = A_.x, qs = q0_;
-  compute_scaling(Px, Ax, qs);
+  lap("validate + copy");
 
   // ---- device ----
   err = be::init(d_, settings.device);
   if (err) return err;
+  lap("device init");
   dev_ready_ = true;
+  // ---- scaling: on the device once the matrices are assembled there; the test-only host simulator
+  //      keeps the driver's host restatement of _osqp.py:389-497 ----
+  const bool dev_asm = be::device_assembly();
+  std::vector<double> Px, Ax, qs;
+  if (!dev_asm) { Px = P_.x; Ax = A_.x; qs = q0_; compute_scaling(Px, Ax, qs); lap("Ruiz scaling (host)"); }
   d_.n = n; d_.m = m; d_.sigma = settings.sigma; d_.alpha = settings.alpha;
 
   // A as CSR (the incoming CSC is CSR(A')) + map CSC index -> CSR position
@@ -329,7 +335,9 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
     for (int j = 0; j < n; j++)
       for (int k = A_.p[j]; k < A_.p[j + 1]; k++) { int pos = cur[j]++; Bj[pos] = n + A_.i[k]; AmapB_[k] = pos; }
   }
+  lap("CSR(A), B structure, maps");
   std::vector<int> rbA = build_row_blocks(Arp, m), rbB = build_row_blocks(Brp, n);
+  lap("row blocks");
   auto descs = [](const std::vector<int> &rb, const std::vector<int> &rp) {
     std::vector<int> d; d.reserve(4 * rb.size());
     for (size_t b = 0; b + 1 < rb.size(); b++) { d.push_back(rb[b]); d.push_back(rb[b + 1]); d.push_back(rp[rb[b]]); d.push_back(rp[rb[b + 1]]); }
@@ -342,9 +350,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   d_.B.nrows = n; d_.B.ncols = n + m; d_.B.nnz = nzB; d_.B.nblk = (int)rbB.size() - 1;
   d_.B.rowptr = up_i(Brp); d_.B.col = up_i(Bj); d_.B.blkdesc = up_i(descs(rbB, Brp)); d_.B.val = dev_vec<double>(d_, nzB);
   d_.Bdiag = up_i(bdiag);
-  Aval_.assign(nzA, 0.0); Bval_.assign(nzB, 0.0);
-  fill_matrix_values(Px, Ax);
-
+  lap("upload structure");
   auto dv = [&](size_t cnt) { return dev_vec<double>(d_, cnt); };
   d_.q = dv(n); d_.l = dv(m); d_.u = dv(m); d_.D = dv(n); d_.Dinv = dv(n); d_.E = dv(m); d_.Einv = dv(m);
   d_.rho = dv(m); d_.rho_inv = dv(m); d_.ctype = dev_vec<int>(d_, m);
@@ -352,8 +358,30 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   d_.r = dv(n); d_.uu = dv(n); d_.p = dv(n); d_.s = dv(n); d_.w = dv(n); d_.t = dv(m); d_.Minv = dv(n); d_.uu2 = dv(n); d_.ms = dv(2 * (size_t)n);
   { const char *f = std::getenv("OSQP_HIP_PCG_FUSED"); d_.fused = (f && f[0] == '0') ? 0 : 1; }   // default on; =0 selects the 3-kernel sequence
   d_.part = dv((size_t)32 * kGrid); d_.res = dv(R_COUNT); d_.scal = dv(S_HIST + 3 * (kMaxCg + 1)); d_.flags = dev_vec<int>(d_, F_COUNT);
-  be::h2d(d_, d_.D, D_.data(), sizeof(double) * n); be::h2d(d_, d_.Dinv, Dinv_.data(), sizeof(double) * n);
-  be::h2d(d_, d_.E, E_.data(), sizeof(double) * m); be::h2d(d_, d_.Einv, Einv_.data(), sizeof(double) * m);
+  if (dev_asm) {
+    // the caller's values go up once, in their own (CSC) order; every later (re)assembly and the equilibration run on the device
+    std::vector<int> Pj(nzP), Aj(nzA);
+    for (int j = 0; j < n; j++) { for (int k = P_.p[j]; k < P_.p[j + 1]; k++) Pj[k] = j; for (int k = A_.p[j]; k < A_.p[j + 1]; k++) Aj[k] = j; }
+    d_.nzP = nzP; d_.nzA = nzA;
+    d_.Praw = dv(nzP); d_.Araw = dv(nzA); d_.cs = dv(2);
+    d_.Pi = up_i(P_.i); d_.Pj = up_i(Pj); d_.Pm1 = up_i(Pmap1_); d_.Pm2 = up_i(Pmap2_);
+    d_.Ai = up_i(A_.i); d_.Aj = up_i(Aj); d_.AmA = up_i(AmapA_); d_.AmB = up_i(AmapB_);
+    be::h2d(d_, d_.Praw, P_.x.data(), sizeof(double) * nzP); be::h2d(d_, d_.Araw, A_.x.data(), sizeof(double) * nzA);
+    be::h2d(d_, d_.q, q0_.data(), sizeof(double) * n);
+    be::assemble(d_, 0, 1.0, 0);                                     // unscaled, sigma added after the equilibration
+    c_ = be::ruiz(d_, settings.scaling);                             // _osqp.py:389-497
+    cinv_ = 1.0 / c_;
+    D_.resize(n); E_.resize(m); Dinv_.resize(n); Einv_.resize(m);
+    be::d2h(d_, D_.data(), d_.D, sizeof(double) * n); be::d2h(d_, Dinv_.data(), d_.Dinv, sizeof(double) * n);
+    if (m > 0) { be::d2h(d_, E_.data(), d_.E, sizeof(double) * m); be::d2h(d_, Einv_.data(), d_.Einv, sizeof(double) * m); }
+    lap("assembly + Ruiz scaling (device)");
+  } else {
+    Aval_.assign(nzA, 0.0); Bval_.assign(nzB, 0.0);
+    fill_matrix_values(Px, Ax);
+    be::h2d(d_, d_.D, D_.data(), sizeof(double) * n); be::h2d(d_, d_.Dinv, Dinv_.data(), sizeof(double) * n);
+    be::h2d(d_, d_.E, E_.data(), sizeof(double) * m); be::h2d(d_, d_.Einv, Einv_.data(), sizeof(double) * m);
+    lap("matrix values (host-scaled)");
+  }
   upload_q();
   upload_bounds_and_types();
   be::set_rho(d_, rho_bar_);                                       // _osqp.py:499-524
@@ -367,6 +395,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   cg_budget_ = 0; have_tol_ = false; first_run_ = true;
   stats_ = OSQPHipStats(); stats_.nnzA = nzA; stats_.nnzB = nzB;
   be::sync(d_);
+  lap("vectors, rho, preconditioner");
   info.setup_time = now_s() - t0;
   if (settings.verbose) {
     std::printf("-----------------------------------------------------------------\n");
@@ -758,9 +787,15 @@ int Engine::update_data_mat(const double *Px, const int *Px_idx, int P_n, const 
     else if (A_n != nzA && A_n != 0) return OSQP_DATA_VALIDATION_ERROR;
     for (int k = 0; k < (Ax_idx ? A_n : nzA); k++) A_.x[Ax_idx ? Ax_idx[k] : k] = Ax[k];
   }
-  std::vector<double> Pxs, Axs;
-  scale_matrix_values(Pxs, Axs);                                                         // _osqp.py:1443,:1463
-  fill_matrix_values(Pxs, Axs);
+  if (be::device_assembly()) {                                                           // _osqp.py:1443,:1463 on the device
+    if (Px) be::h2d(d_, d_.Praw, P_.x.data(), sizeof(double) * nzP);
+    if (Ax) be::h2d(d_, d_.Araw, A_.x.data(), sizeof(double) * nzA);
+    be::assemble(d_, 1, c_, 1);
+  } else {
+    std::vector<double> Pxs, Axs;
+    scale_matrix_values(Pxs, Axs);
+    fill_matrix_values(Pxs, Axs);
+  }
   be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);                   // the "refactor" of :1446,:1466,:1488
   be::init_iterates(d_, 0);                                                              // z~, t0 depend on A; iterates untouched
   set_status(OSQP_UNSOLVED);

@@ -218,6 +218,9 @@ void graph_launch(Dev &, void *) {}
 void graph_free(Dev &, void *) {}
 
 bool ktrace_read(Dev &, unsigned long long *, int) { return false; }
+bool device_assembly() { return false; }        // the simulator exercises the driver's host scaling path
+void assemble(Dev &, int, double, int) {}
+double ruiz(Dev &, int) { return 1.0; }
 void test_spmv(Dev &d, int which, const double *in, double *out) {
   const DevCsr &M = which == 0 ? d.A : d.B;
   for (int r = 0; r < M.nrows; r++) { double a = 0; for (int k = M.rowptr[r]; k < M.rowptr[r + 1]; k++) a += M.val[k] * in[M.col[k]]; out[r] = a; }

@@ -151,6 +151,55 @@ def test_update_vectors_and_matrices_vs_oracle():
     npt.assert_allclose(r.y, yo, rtol=0, atol=2e-5 * (1 + np.abs(yo).max()))
 
 
+@pytest.mark.parametrize('scaling', [0, 3, 10])
+@pytest.mark.parametrize('name', list(GENS))
+def test_device_ruiz_scaling_matches_oracle(name, scaling):
+    """The equilibration runs on the device (k_rowmax / k_ruiz_*): D, E, c against the oracle's restatement of
+    _osqp.py:389-497 (max-norms, sqrt and products are exact IEEE operations on both sides; only the mean in the cost
+    normalisation is summed in a different order -> agreement to a few ulps), and the scaled matrices the kernels then
+    stream (through the SpMV probes) against  c D P D + sigma I  and  E A D  built from those factors."""
+    P, q, A, l, u = GENS[name]()
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, scaling=scaling)
+    D, E, c = m._solver.hip_scaling()
+    o = Oracle().setup(P, q, A, l, u, scaling=scaling)
+    Do, Eo, co = o.scaling()
+    npt.assert_allclose(D, Do, rtol=1e-12); npt.assert_allclose(E, Eo, rtol=1e-12); npt.assert_allclose(c, co, rtol=1e-12)
+    if scaling == 0:
+        assert np.all(D == 1) and np.all(E == 1) and c == 1
+    n, mm = len(q), len(l)
+    rng = np.random.default_rng(11)
+    xin = rng.standard_normal(n)
+    As = sp.diags(E) @ sp.csr_matrix(A) @ sp.diags(D)
+    npt.assert_allclose(m._solver.hip_test_spmv(0, xin), As @ xin, rtol=1e-12, atol=1e-12)
+    Pf = sp.csc_matrix(P); Pf = sp.triu(Pf) + sp.triu(Pf, 1).T
+    Ps = c * (sp.diags(D) @ Pf @ sp.diags(D)) + m.settings.sigma * sp.eye(n)
+    vin = rng.standard_normal(n + mm)
+    npt.assert_allclose(m._solver.hip_test_spmv(1, vin), Ps @ vin[:n] + As.T @ vin[n:], rtol=1e-12, atol=1e-11)
+
+
+def test_update_matrices_by_index_reassembles_on_device():
+    """update_data_mat with index lists (bindings.cpp.in:240-281): the raw values go up, the device re-scatters and
+    re-scales them with the stored D, E, c; the streamed matrices must equal the host-side expectation."""
+    P, q, A, l, u = GENS['banded_unaligned']()
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False)
+    D, E, c = m._solver.hip_scaling()
+    rng = np.random.default_rng(3)
+    Pt = sp.triu(P, format='csc'); A = sp.csc_matrix(A)
+    pi = np.sort(rng.choice(Pt.nnz, size=Pt.nnz // 3, replace=False)).astype(np.int32)
+    ai = np.sort(rng.choice(A.nnz, size=A.nnz // 2, replace=False)).astype(np.int32)
+    Px = Pt.data.copy(); Ax = A.data.copy()
+    Px[pi] *= 1.5; Ax[ai] = rng.standard_normal(ai.size)
+    m.update(Px=Px[pi], Px_idx=pi, Ax=Ax[ai], Ax_idx=ai)
+    n, mm = len(q), len(l)
+    P2 = sp.csc_matrix((Px, Pt.indices, Pt.indptr), shape=Pt.shape); P2 = P2 + sp.triu(P2, 1).T
+    A2 = sp.csc_matrix((Ax, A.indices, A.indptr), shape=A.shape)
+    As = sp.diags(E) @ A2 @ sp.diags(D)
+    Ps = c * (sp.diags(D) @ P2 @ sp.diags(D)) + m.settings.sigma * sp.eye(n)
+    xin = rng.standard_normal(n); vin = rng.standard_normal(n + mm)
+    npt.assert_allclose(m._solver.hip_test_spmv(0, xin), As @ xin, rtol=1e-12, atol=1e-12)
+    npt.assert_allclose(m._solver.hip_test_spmv(1, vin), Ps @ vin[:n] + As.T @ vin[n:], rtol=1e-12, atol=1e-11)
+
+
 @pytest.mark.parametrize('n', [20000])
 def test_larger_banded_qp_kkt_certificate(n):
     """Beyond quick-oracle size: size-independent optimality certificate of the returned (x, y)."""
