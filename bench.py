@@ -157,8 +157,11 @@ def main():
         # algorithmic bytes per launch (DESIGN.md "Kernels"): SpMV formula + the fused epilogue / extra vectors
         if fused:     # two kernels per PCG iteration
             pcg_kernels = {
-                'K1F spmv A + pcg vector update (k_k1f)': (11, sA + 8 * mm + 8 * n + 9 * 8 * n),   # + rho, gathered Minv.*s; p r s Minv x~ read, p x~ r u written
-                'K2F spmv B + s, Minv.*s, <s,u> (k_k2f)': (12, sB + 3 * 8 * n),                      # + s read, Minv read, Minv.*s written (s replaces w)
+                # SpMV(A) with the gathered vector being the 16-byte pairs {u, Minv.*s} (+8n), + rho (8m), + the vector update:
+                # u p r s Minv x~ read, p x~ r u' written (10 x 8n)
+                'K1F spmv A + pcg vector update (k_k1f)': (11, sA + 8 * n + 8 * mm + 10 * 8 * n),
+                # SpMV(B) whose output is s (w is never stored), + s and Minv read (16n), + the pair {u, Minv.*s} written (16n)
+                'K2F spmv B + s, Minv.*s, <s,u> (k_k2f)': (12, sB + 4 * 8 * n),
             }
             seq_id, dom, dom_kernel = 10, 'K2F spmv B + s, Minv.*s, <s,u> (k_k2f)', 'k_k2f'
         else:
