@@ -91,6 +91,9 @@ struct Dev {
 };
 
 // Batched small-QP solve (batch_hip.hip): nbatch problems sharing the solver's scaled A / B, one workgroup each.
+constexpr int kBatchNB = 8;             // pivots per block of the batch kernel's substitutions; the band is stored with kBatchNB zeros of padding per column
+constexpr int kBatchDirectMaxBw = 64 - kBatchNB;   // band limit of the batch kernel's direct solve: one wave holds the live window of a block
+
 struct BatchParams {
   int n, m, nbatch;
   DevCsr A, B;
@@ -101,12 +104,26 @@ struct BatchParams {
   const double *q0, *l0, *u0;   // UNSCALED shared vectors [n] / [m]
   double *x, *y;                // in: UNSCALED warm start (if warm), out: UNSCALED solution  [nbatch][n] / [nbatch][m]
   double *rec;                  // [nbatch][8]: status, iter, obj, prim_res, dual_res, rho, rho_updates, pcg_iters
+  // Direct linear solve (banded Cholesky of K = P + sigma I + A' diag(rho) A under a bandwidth-reducing symmetric
+  // permutation, factor held in LDS): bw < 0 selects the PCG path.  Built by Engine::prepare_batch_direct().
+  int bw = -1;                  // half bandwidth of the permuted K (<= kBatchDirectMaxBw)
+  double eq_factor_direct = 1e3; // equality-row weight of the direct variant: the reference's 1e3 (_osqp.py:27) -- the value 10 of
+                                 // the PCG variants exists only to keep K well conditioned for CG (engine.cpp classify_constraints)
+  int nents = 0, ntri = 0;
+  const int *perm = nullptr;    // [n] position in the permuted order -> variable
+  const int *bp_slot = nullptr; // [nnz(B)] band slot (column * (bw + kBatchNB) + row - column) of each (P + sigma I) entry of B in the permuted lower triangle, else -1
+  const int *ke_slot = nullptr, *ke_ptr = nullptr;   // band slots that receive A' rho A terms, and their product ranges
+  const int *kp_row = nullptr;  // per product: constraint row i (-> rho_i)
+  const double *kp_val = nullptr;                    // per product: A_ia * A_ib (scaled values; refreshed before every batch call)
+  const int *tri = nullptr;     // [ntri] (a | b << 8), 1 <= a <= b <= bw: the trailing-update pairs of one elimination step
 };
 
 namespace be {
 
 size_t batch_lds_bytes(int n, int m);                       // 0 if a problem does not fit one workgroup's LDS
 int batch_solve(Dev &d, const BatchParams &p);               // synchronous; OSQP_FUNC_NOT_IMPLEMENTED if it does not fit
+size_t batch_direct_lds_bytes(int n, int m, int nnz, int bw); // 0 if the banded factor does not fit next to the iterates
+void batch_products(Dev &d, int nprod, const int *a, const int *b, double *out);   // out[p] = A.val[a[p]] * A.val[b[p]]
 
 const char *name();
 int init(Dev &d, int device);            // select device, create stream; returns 0 or osqp_error_type

@@ -26,6 +26,11 @@ namespace be {
 namespace {
 
 __device__ __forceinline__ double nmax(double r, double a) { return (a > r || a != a) ? a : r; }
+// value of v in lane `lane` (wave-uniform index) broadcast to the whole wave: two v_readlane_b32
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
 
 // Block reductions; all threads get the result.  NW = waves per workgroup.  With ONE wave per problem (NW = 1) a
 // reduction is six __shfl_xor steps: no LDS, no barrier.
@@ -92,8 +97,26 @@ namespace {
 // a barrier, and one lane per row summing its segment of prod -- no matrix traffic inside the ADMM / PCG loops and a
 // balanced first phase (the MPC rows have 1..13 entries).  EA = EB = 0: generic row loops reading the matrices from
 // global memory (L1/L2), for patterns with more than 8 * kBB entries per matrix.
-template <int kBB, int EA, int EB>
+//
+// DIRECT (kBB == 64 only): the linear system of every ADMM iteration is solved exactly, as the reference's direct path does
+// (_osqp.py:286-311), instead of by PCG.  K = P + sigma I + A' diag(rho) A is assembled in LDS under the bandwidth-reducing
+// permutation prepared by the engine (column-major lower band, W = bw + 1 doubles per column), Cholesky-factorised in
+// place at every rho change, and each solve is two substitutions that keep the live window of the right-hand side in
+// REGISTERS: element e of the vector lives in lane e % 64 from the step that loads it until its own pivot step (bw < 64),
+// a pivot is broadcast with v_readlane, every other lane applies its one update -- no LDS traffic on the dependency chain
+// except the (prefetchable) column of L.
+template <int kBB, int EA, int EB, bool DIRECT>
 __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
+  static_assert(!DIRECT || kBB == 64, "the direct solve is written for one wave per problem");
+#ifdef OSQP_HIP_KTRACE
+  // diagnostic build: 100 MHz clock ticks spent in the phases; reported in rec[5..7] INSTEAD of rho / rho_updates / pcg_iters
+  unsigned long long tk_all = wall_clock64(), tk_fact = 0, tk_solve = 0, tk0 = 0;
+#define BT_BEGIN() (tk0 = wall_clock64())
+#define BT_END(acc) (acc += wall_clock64() - tk0)
+#else
+#define BT_BEGIN() ((void)0)
+#define BT_END(acc) ((void)0)
+#endif
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = P.n, m = P.m, tid = threadIdx.x, b = blockIdx.x;
   if (b >= P.nbatch) return;
@@ -103,6 +126,11 @@ __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
   Red<kBB / 64> red{dy + m};
   double *prod = dy + m + 16;                       // max(nnzA, nnzB) products (register path only)
   const DevCsr &A = P.A, &B = P.B;
+  // DIRECT: band factor.  Column c occupies Lb[c W .. c W + bw] (W = bw + kBatchNB: kBatchNB zeros of padding per column, and
+  // kBatchNB zeros in front of column 0), for n rounded up to a multiple of kBatchNB columns, + 64 doubles of read slack.
+  const int bw = P.bw, W = P.bw + kBatchNB, n8 = (n + kBatchNB - 1) / kBatchNB * kBatchNB;
+  double *Lb = prod + (((A.nnz > B.nnz ? A.nnz : B.nnz) + 1) & ~1) + kBatchNB;
+  double *dinv = zv, *wbuf = r;                     // DIRECT: 1/D and the permuted right-hand side / solution reuse PCG vectors
   constexpr bool kReg = EA > 0;
   double aA[EA > 0 ? EA : 1], aB[EB > 0 ? EB : 1];
   int cA[EA > 0 ? EA : 1], cB[EB > 0 ? EB : 1];
@@ -162,7 +190,7 @@ __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
   }
   __syncthreads();
   const double n_ineq = red.sum((double)n_ineq_local);
-  const double eqf = (n_ineq == 0.0) ? 1e3 : P.eq_factor;  // engine.cpp classify_constraints()
+  const double eqf = (n_ineq == 0.0) ? 1e3 : (DIRECT ? P.eq_factor_direct : P.eq_factor);  // engine.cpp classify_constraints()
   double rho_bar = P.rho0;
   auto set_rho = [&](double rb) {
     for (int i = tid; i < m; i += kBB) {
@@ -172,11 +200,132 @@ __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
       rho[i] = ty == -1 ? 1e-6 : (ty == 1 ? eqf * rb : rb);                                       // _osqp.py:520-522
     }
     __syncthreads();
-    for (int j = tid; j < n; j += kBB) {                   // Jacobi preconditioner = 1/diag(K)
-      double sacc = 0.0, dg = 0.0;
-      for (int k = B.rowptr[j]; k < B.rowptr[j + 1]; k++) { const int c = B.col[k]; const double a = B.val[k]; if (c == j) dg = a; if (c >= n) sacc += rho[c - n] * a * a; }
-      Minv[j] = P.precond ? 1.0 / (dg + sacc) : 1.0;
+    if constexpr (DIRECT) {
+      BT_BEGIN();
+      // ---- assemble K (lower band, permuted) ----
+      for (int s_ = tid - kBatchNB; s_ < n8 * W + 64; s_ += kBB) Lb[s_] = 0.0;
+      __syncthreads();
+      for (int k = tid; k < B.nnz; k += kBB) { const int s_ = P.bp_slot[k]; if (s_ >= 0) Lb[s_] = B.val[k]; }      // P + sigma I
+      __syncthreads();
+      for (int e = tid; e < P.nents; e += kBB) {                                                              // + A' rho A
+        double acc = 0.0;
+        for (int q_ = P.ke_ptr[e]; q_ < P.ke_ptr[e + 1]; q_++) acc += rho[P.kp_row[q_]] * P.kp_val[q_];
+        Lb[P.ke_slot[e]] += acc;
+      }
+      __syncthreads();
+      // ---- banded Cholesky, right-looking: column c, then the (bw x bw)/2 trailing update spread over the wave ----
+      for (int c = 0; c < n; c++) {
+        const double di = 1.0 / sqrt(Lb[c * W]);
+        const int kmax = min(bw, n - 1 - c);
+        const bool mine = tid >= 1 && tid <= kmax;
+        double v = 0.0;
+        if (mine) v = Lb[c * W + tid] * di;
+        __syncthreads();
+        if (mine) Lb[c * W + tid] = v;
+        if (tid == 0) dinv[c] = di;
+        __syncthreads();
+        for (int t_ = tid; t_ < P.ntri; t_ += kBB) {
+          const int ab = P.tri[t_], a = ab & 255, b_ = ab >> 8;
+          if (b_ <= kmax) Lb[(c + a) * W + (b_ - a)] -= Lb[c * W + b_] * Lb[c * W + a];
+        }
+        __syncthreads();
+      }
+      // K = L L' = L^ D L^' with unit-lower L^ = L diag(1/L_jj), D = diag(L_jj^2): the substitutions then carry no
+      // division or pivot scaling on their dependency chain.  Lb <- L^ (strictly lower part), dinv <- 1/D.
+      for (int s_ = tid; s_ < n * W; s_ += kBB) { const int c = s_ / W, k = s_ - c * W; if (k >= 1 && k <= bw) Lb[s_] *= dinv[c]; }
+      __syncthreads();
+      for (int c = tid; c < n; c += kBB) { const double di = dinv[c]; dinv[c] = di * di; Lb[c * W] = 0.0; }   // (diagonal slots read as L^ = 0)
+      __syncthreads();
+      BT_END(tk_fact);
+    } else {
+      for (int j = tid; j < n; j += kBB) {                   // Jacobi preconditioner = 1/diag(K)
+        double sacc = 0.0, dg = 0.0;
+        for (int k = B.rowptr[j]; k < B.rowptr[j + 1]; k++) { const int c = B.col[k]; const double a = B.val[k]; if (c == j) dg = a; if (c >= n) sacc += rho[c - n] * a * a; }
+        Minv[j] = P.precond ? 1.0 / (dg + sacc) : 1.0;
+      }
+      __syncthreads();
     }
+  };
+  // DIRECT: out = K^-1 rhs  (both in the caller's variable order):  L^ v = P rhs ;  g = D^-1 v ;  L^' x = g ;  out = P' x.
+  // Substitutions on ONE wave, kBatchNB pivots per block.  Element e lives in lane e % 64 while it is within 64 of the
+  // pivots.  Per block a lane fetches its kBatchNB entries of L^ with plain strided LDS reads one block AHEAD (the padded
+  // band makes every out-of-band read a zero, lanes beyond the block's reach are masked once), then for each pivot:
+  // v_readlane broadcast + one FMA.  Lanes whose element has pivoted store it and continue with the element 64 further on,
+  // already waiting in a register.  ~8 instructions per pivot, no LDS access, branch or division on the dependency chain.
+  auto ksolve = [&](const double *rhs, double *out) {
+    const double *__restrict__ Lr = Lb;
+    double *__restrict__ buf = wbuf;
+    constexpr int NB = kBatchNB;
+    for (int k = tid; k < n; k += kBB) buf[k] = rhs[P.perm[k]];
+    __syncthreads();
+    const int nblk = n8 / NB;
+    // ---- forward, unit lower:  v_e = w_e - sum_{j in [e-bw, e)} L^[e][j] v_j ;  L^[p0 + dl][p0 + q] = Lr[(p0 + q) W + dl - q] ----
+    {
+      double cur = tid < n ? buf[tid] : 0.0, nxt = 64 + tid < n ? buf[64 + tid] : 0.0;
+      // lanes beyond the block's reach read the zero in front of column 0 eight times (stride 0): no masking after the load
+      auto fetch = [&](int p0, double (&l)[NB]) {
+        const int dl = (tid - p0) & 63;
+        const bool act = dl < bw + NB && p0 < n8;
+        const double *col = act ? Lr + p0 * W + dl : Lr - 1;
+        const int stride = act ? W - 1 : 0;
+#pragma unroll
+        for (int q = 0; q < NB; q++) l[q] = col[q * stride];
+      };
+      auto block = [&](int p0, const double (&l)[NB]) {
+#pragma unroll
+        for (int q = 0; q < NB; q++) { const double vq = readlane_f64(cur, (p0 + q) & 63); cur -= l[q] * vq; }
+        const int dl = (tid - p0) & 63;
+        if (dl < NB) {                                          // pivoted in this block: final
+          const int e = p0 + dl;
+          if (e < n) buf[e] = cur;
+          cur = nxt; nxt = e + 128 < n ? buf[e + 128] : 0.0;
+        }
+      };
+      double la[NB], lb[NB];                                    // two blocks in flight, roles alternate (no register rotation)
+      fetch(0, la);
+      for (int b = 0; b < nblk; b += 2) {
+        fetch((b + 1) * NB, lb);
+        block(b * NB, la);
+        if (b + 1 < nblk) { fetch((b + 2) * NB, la); block((b + 1) * NB, lb); }
+      }
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += kBB) buf[k] *= dinv[k];                          // g = D^-1 v
+    __syncthreads();
+    // ---- backward, unit upper (L^'):  x_i = g_i - sum_{j in (i, i+bw]} L^[j][i] x_j ; blocks from the top, pivots top - q ;
+    //      lane's element i = top - dl ;  L^[top - q][i] = Lr[i W + dl - q] ----
+    {
+      auto elem = [&](int top) { return top - ((top - tid) & 63); };
+      const int i0 = elem(n8 - 1);
+      double cur = (i0 >= 0 && i0 < n) ? buf[i0] : 0.0, nxt = i0 - 64 >= 0 ? buf[i0 - 64] : 0.0;
+      auto fetch = [&](int top, double (&l)[NB]) {
+        const int dl = (top - tid) & 63, i = top - dl;
+        const bool act = dl < bw + NB && i >= 0 && top >= 0;
+        const double *row = act ? Lr + i * W + dl : Lr - 1;
+        const int stride = act ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < NB; q++) l[q] = row[-q * stride];
+      };
+      auto block = [&](int top, const double (&l)[NB]) {
+#pragma unroll
+        for (int q = 0; q < NB; q++) { const double xq = readlane_f64(cur, (top - q) & 63); cur -= l[q] * xq; }
+        const int dl = (top - tid) & 63;
+        if (dl < NB) {
+          const int i = top - dl;
+          if (i < n) buf[i] = cur;
+          cur = nxt; nxt = i - 128 >= 0 ? buf[i - 128] : 0.0;
+        }
+      };
+      double la[NB], lb[NB];
+      fetch(n8 - 1, la);
+      for (int b = nblk - 1; b >= 0; b -= 2) {
+        fetch(b * NB - 1, lb);
+        block(b * NB + NB - 1, la);
+        if (b >= 1) { fetch(b * NB - NB - 1, la); block(b * NB - 1, lb); }
+      }
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += kBB) out[P.perm[k]] = buf[k];
     __syncthreads();
   };
   set_rho(rho_bar);
@@ -237,41 +386,47 @@ __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
   while (true) {
     iter++;
     // ---- rhs = sigma x - q + A'(rho z - y);  r = rhs - K xs with K xs = B[xs; rho zt]   (_osqp.py:649-650) ----
-    double rz_l = 0, rn_l = 0, bn_l = 0;
+    [[maybe_unused]] double rz_l = 0, rn_l = 0, bn_l = 0;
     for (int i = tid; i < m; i += kBB) t[i] = rho[i] * z[i] - y[i];
     __syncthreads();
     applyB(nullptr, t, [&](int j, double sA) { Kp[j] = P.sigma * x[j] - q[j] + sA; });          // Kp holds rhs for a moment
-    for (int i = tid; i < m; i += kBB) t[i] = rho[i] * zt[i];
-    __syncthreads();
-    applyB(xs, t, [&](int j, double sK) {
-      const double rhs = Kp[j], rr = rhs - sK, zz = Minv[j] * rr;
-      r[j] = rr; zv[j] = zz; p[j] = zz;
-      rz_l += rr * zz; rn_l = nmax(rn_l, fabs(rr)); bn_l = nmax(bn_l, fabs(rhs));
-    });
-    double rz = rz_l, rn = rn_l;
-    red.sum_max(rz, rn);
-    const double bn = red.max(bn_l);
-    const double tol = rel_rule ? fmax(0.1 * bn, 1e-13) : fmax(1e-14 * bn, eps_cg);
-    // ---- PCG on K = P + sigma I + A' diag(rho) A ----
-    for (int it = 0; it < P.cg_max && rn > tol; it++) {
-      applyA(p, [&](int i, double a) { t[i] = rho[i] * a; });              // t = rho .* (A p)
-      double pkp_l = 0.0;
-      applyB(p, t, [&](int j, double a) { Kp[j] = a; pkp_l += a * p[j]; });
-      const double pkp = red.sum(pkp_l);
-      const double al = rz / pkp;
-      double rz2 = 0.0, rn2 = 0.0;
-      for (int j = tid; j < n; j += kBB) {
-        xs[j] += al * p[j];
-        const double rr = r[j] - al * Kp[j], zz = Minv[j] * rr;
-        r[j] = rr; zv[j] = zz;
-        rz2 += rr * zz; rn2 = nmax(rn2, fabs(rr));
-      }
-      red.sum_max(rz2, rn2);
-      const double be = rz2 / rz;
-      rz = rz2; rn = rn2;
-      for (int j = tid; j < n; j += kBB) p[j] = zv[j] + be * p[j];
+    if constexpr (DIRECT) {
+      BT_BEGIN();
+      ksolve(Kp, xs);                                                                    // x~ = K^-1 rhs   (_osqp.py:307-311, reduced form)
+      BT_END(tk_solve);
+    } else {
+      for (int i = tid; i < m; i += kBB) t[i] = rho[i] * zt[i];
       __syncthreads();
-      pcg_total++;
+      applyB(xs, t, [&](int j, double sK) {
+        const double rhs = Kp[j], rr = rhs - sK, zz = Minv[j] * rr;
+        r[j] = rr; zv[j] = zz; p[j] = zz;
+        rz_l += rr * zz; rn_l = nmax(rn_l, fabs(rr)); bn_l = nmax(bn_l, fabs(rhs));
+      });
+      double rz = rz_l, rn = rn_l;
+      red.sum_max(rz, rn);
+      const double bn = red.max(bn_l);
+      const double tol = rel_rule ? fmax(0.1 * bn, 1e-13) : fmax(1e-14 * bn, eps_cg);
+      // ---- PCG on K = P + sigma I + A' diag(rho) A ----
+      for (int it = 0; it < P.cg_max && rn > tol; it++) {
+        applyA(p, [&](int i, double a) { t[i] = rho[i] * a; });              // t = rho .* (A p)
+        double pkp_l = 0.0;
+        applyB(p, t, [&](int j, double a) { Kp[j] = a; pkp_l += a * p[j]; });
+        const double pkp = red.sum(pkp_l);
+        const double al = rz / pkp;
+        double rz2 = 0.0, rn2 = 0.0;
+        for (int j = tid; j < n; j += kBB) {
+          xs[j] += al * p[j];
+          const double rr = r[j] - al * Kp[j], zz = Minv[j] * rr;
+          r[j] = rr; zv[j] = zz;
+          rz2 += rr * zz; rn2 = nmax(rn2, fabs(rr));
+        }
+        red.sum_max(rz2, rn2);
+        const double be = rz2 / rz;
+        rz = rz2; rn = rn2;
+        for (int j = tid; j < n; j += kBB) p[j] = zv[j] + be * p[j];
+        __syncthreads();
+        pcg_total++;
+      }
     }
     // ---- z~ = A xs; x, z, y update (_osqp.py:660-703) ----
     applyA(xs, [&](int i, double a) {
@@ -363,6 +518,9 @@ __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
   if (tid == 0) {
     double *rc = P.rec + (size_t)b * 8;
     rc[0] = status; rc[1] = iter; rc[2] = obj; rc[3] = prim_res; rc[4] = dual_res; rc[5] = rho_bar; rc[6] = rho_updates; rc[7] = (double)pcg_total;
+#ifdef OSQP_HIP_KTRACE
+    rc[5] = (double)tk_fact; rc[6] = (double)tk_solve; rc[7] = (double)(wall_clock64() - tk_all);
+#endif
   }
 }
 
@@ -375,19 +533,41 @@ size_t batch_lds_bytes_nnz(int n, int m, int nnz) {
   return b <= 64 * 1024 ? b : 0;
 }
 size_t batch_lds_bytes(int n, int m) { return batch_lds_bytes_nnz(n, m, 0); }
+size_t batch_direct_lds_bytes(int n, int m, int nnz, int bw) {
+  if (bw < 0 || bw > kBatchDirectMaxBw) return 0;
+  const size_t n8 = (size_t)(n + kBatchNB - 1) / kBatchNB * kBatchNB;
+  const size_t b = sizeof(double) * ((size_t)10 * n + (size_t)8 * m + 16 + (size_t)((nnz + 1) & ~1) + kBatchNB + n8 * (bw + kBatchNB) + 64);
+  return b <= 96 * 1024 ? b : 0;          // (above the default 64 KB dynamic-LDS limit: batch_solve raises it; gfx950 has 160 KB per CU)
+}
+__global__ void k_batch_products(DevCsr A, int nprod, const int *a, const int *b, double *out) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < nprod; p += gridDim.x * blockDim.x) out[p] = A.val[a[p]] * A.val[b[p]];
+}
+void batch_products(Dev &d, int nprod, const int *a, const int *b, double *out) {
+  if (hipSetDevice(d.device) != hipSuccess) throw DeviceError("osqp_hip: hipSetDevice failed");
+  if (nprod > 0) hipLaunchKernelGGL(k_batch_products, dim3((nprod + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(d.stream), d.A, nprod, a, b, out);
+}
 
 int batch_solve(Dev &d, const BatchParams &p) {
   if (hipSetDevice(d.device) != hipSuccess) return OSQP_ALGEBRA_LOAD_ERROR;
   hipStream_t st = static_cast<hipStream_t>(d.stream);
   const int mx = p.A.nnz > p.B.nnz ? p.A.nnz : p.B.nnz;
   const size_t lds_reg = batch_lds_bytes_nnz(p.n, p.m, mx), lds_gen = batch_lds_bytes(p.n, p.m);
-  const char *force = std::getenv("OSQP_HIP_BATCH_VARIANT");      // debugging: "w64", "w256", "generic"
+  const char *force = std::getenv("OSQP_HIP_BATCH_VARIANT");      // debugging: "direct", "w64", "w256", "generic"
   const int e64 = (mx + 63) / 64, e256 = (mx + 255) / 256;
   const bool can64 = lds_reg && e64 <= 24 && p.n <= 1024 && p.m <= 2048, can256 = lds_reg && e256 <= 8;
-  const bool use64 = force ? !std::strcmp(force, "w64") && can64 : can64;
+  const size_t lds_dir = batch_direct_lds_bytes(p.n, p.m, mx, p.bw);
+  const bool can_dir = can64 && lds_dir && p.perm;
+  const bool use_dir = force ? !std::strcmp(force, "direct") && can_dir : can_dir;
+  const bool use64 = !use_dir && (force ? !std::strcmp(force, "w64") && can64 : can64);
   const bool use256 = !use64 && (force ? !std::strcmp(force, "w256") && can256 : can256);
-#define BATCH_LAUNCH(TB, E, LDS) hipLaunchKernelGGL((k_batch_admm<TB, E, E>), dim3(p.nbatch), dim3(TB), LDS, st, p)
-  if (use64) {
+#define BATCH_LAUNCH(TB, E, LDS) hipLaunchKernelGGL((k_batch_admm<TB, E, E, false>), dim3(p.nbatch), dim3(TB), LDS, st, p)
+#define BATCH_LAUNCH_DIRECT(E) do { \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<64, E, E, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dir) != hipSuccess) \
+      throw DeviceError("osqp_hip: cannot reserve LDS for the direct batch kernel"); \
+    hipLaunchKernelGGL((k_batch_admm<64, E, E, true>), dim3(p.nbatch), dim3(64), lds_dir, st, p); } while (0)
+  if (use_dir) {
+    if (e64 <= 8) BATCH_LAUNCH_DIRECT(8); else if (e64 <= 16) BATCH_LAUNCH_DIRECT(16); else BATCH_LAUNCH_DIRECT(24);
+  } else if (use64) {
     if (e64 <= 8) BATCH_LAUNCH(64, 8, lds_reg); else if (e64 <= 16) BATCH_LAUNCH(64, 16, lds_reg); else BATCH_LAUNCH(64, 24, lds_reg);
   } else if (use256) {
     if (e256 <= 2) BATCH_LAUNCH(256, 2, lds_reg); else if (e256 <= 4) BATCH_LAUNCH(256, 4, lds_reg); else BATCH_LAUNCH(256, 8, lds_reg);
@@ -397,6 +577,7 @@ int batch_solve(Dev &d, const BatchParams &p) {
     return OSQP_FUNC_NOT_IMPLEMENTED;
   }
 #undef BATCH_LAUNCH
+#undef BATCH_LAUNCH_DIRECT
   hipError_t e = hipStreamSynchronize(st);
   if (e != hipSuccess) throw DeviceError(std::string("osqp_hip: batch kernel failed: ") + hipGetErrorString(e));
   return OSQP_NO_ERROR;

@@ -80,6 +80,7 @@ void Engine::free_all() {
   try { be::activate(d_); be::sync(d_); } catch (const DeviceError &) {}       // runs in the destructor: release what we can
   drop_graphs();
   if (bbuf_) { be::dfree(d_, bbuf_); bbuf_ = nullptr; bbuf_cap_ = 0; }
+  free_batch_direct();
   void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag,
                   d_.q, d_.l, d_.u, d_.D, d_.Dinv, d_.E, d_.Einv, d_.rho, d_.rho_inv, d_.ctype, d_.x, d_.z, d_.y, d_.dx,
                   d_.dy, d_.xs, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.uu2, d_.ms, d_.part, d_.res,
@@ -196,7 +197,7 @@ int Engine::set_rho_eq_factor(double f) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   if (!(f >= 1.0)) return OSQP_SETTINGS_VALIDATION_ERROR;
   be::activate(d_);
-  eq_factor_mixed_ = f;
+  eq_factor_mixed_ = f; eq_factor_set_ = true;
   upload_bounds_and_types();
   be::set_rho(d_, rho_bar_);
   be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
@@ -335,6 +336,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
     for (int j = 0; j < n; j++)
       for (int k = A_.p[j]; k < A_.p[j + 1]; k++) { int pos = cur[j]++; Bj[pos] = n + A_.i[k]; AmapB_[k] = pos; }
   }
+  Arp_ = Arp; Arj_ = Arj; Brp_ = Brp; Bj_ = Bj;
   lap("CSR(A), B structure, maps");
   std::vector<int> rbA = build_row_blocks(Arp, m), rbB = build_row_blocks(Brp, n);
   lap("row blocks");
@@ -840,6 +842,115 @@ int Engine::update_settings(const OSQPSettings *s) {
 // q: nbatch x n, l/u: nbatch x m (row-major; NULL = this solver's current vector for every problem);
 // x: nbatch x n, y: nbatch x m (in: unscaled warm start if warm != 0; out: solution, or certificate for infeasible ones);
 // rec: nbatch x 8 = {status_val, iter, obj_val, prim_res, dual_res, rho, rho_updates, pcg_iters}.
+
+// ------------------------------------------------------------------------------------------------ batch path, direct solve
+// Symbolic preparation of the banded-Cholesky linear solve of the batch kernel (batch_hip.hip): the pattern of
+// K = P + sigma I + A' diag(rho) A, a reverse Cuthill-McKee ordering of it, the band slot of every P entry, and for
+// every band slot the list of products A_ia A_ib that rho_i multiplies.  The reference's builtin algebra factorises the
+// KKT matrix with QDLDL after an AMD ordering; for QPs small enough to live in one workgroup's LDS the
+// reduced matrix K (n x n, SPD) under a BANDWIDTH-reducing ordering is the better fit: no indirect addressing in the
+// factor, fixed trip counts.
+void Engine::free_batch_direct() {
+  void *ptrs[] = {bd_.perm, bd_.bp_slot, bd_.ke_slot, bd_.ke_ptr, bd_.kp_row, bd_.kp_a, bd_.kp_b, bd_.tri, bd_.kp_val};
+  for (void *p : ptrs) if (p) be::dfree(d_, p);
+  bd_ = BatchDirect();
+}
+
+void Engine::prepare_batch_direct() {
+  if (bd_.tried) return;
+  bd_.tried = true;
+  const int nzA = (int)Arj_.size(), nzB = (int)Bj_.size();
+  // adjacency of K (excluding the diagonal)
+  double pairs = 0;
+  for (int i = 0; i < m; i++) { const double len = Arp_[i + 1] - Arp_[i]; pairs += len * (len + 1) / 2; }
+  if (pairs > 4e6 || n > 4096) return;                       // dense rows: K would be (nearly) dense -- PCG path
+  std::vector<std::vector<int>> adj(n);
+  for (int j = 0; j < n; j++)
+    for (int k = Brp_[j]; k < Brp_[j + 1]; k++) { const int c = Bj_[k]; if (c < n && c != j) adj[j].push_back(c); }
+  for (int i = 0; i < m; i++)
+    for (int a = Arp_[i]; a < Arp_[i + 1]; a++)
+      for (int b = Arp_[i]; b < Arp_[i + 1]; b++) if (a != b) adj[Arj_[a]].push_back(Arj_[b]);
+  for (auto &v : adj) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+  // reverse Cuthill-McKee, component by component, each started from a pseudo-peripheral node
+  std::vector<int> order; order.reserve(n);
+  std::vector<char> seen(n, 0);
+  std::vector<int> level(n, -1), frontier, next;
+  auto bfs_far = [&](int start, int &ecc) {                  // farthest node of minimum degree from start (within its component)
+    std::vector<int> touched;
+    frontier.assign(1, start); level[start] = 0; touched.push_back(start);
+    int last = start; ecc = 0;
+    while (!frontier.empty()) {
+      next.clear();
+      int best = frontier[0];
+      for (int v : frontier) if (adj[v].size() < adj[best].size()) best = v;
+      last = best; ecc = level[best];
+      for (int v : frontier) for (int w : adj[v]) if (level[w] < 0) { level[w] = level[v] + 1; next.push_back(w); touched.push_back(w); }
+      frontier.swap(next);
+    }
+    for (int v : touched) level[v] = -1;
+    return last;
+  };
+  for (int s0 = 0; s0 < n; s0++) {
+    if (seen[s0]) continue;
+    int start = s0, ecc = -1;
+    for (int rounds = 0; rounds < 8; rounds++) {            // pseudo-peripheral node (George-Liu)
+      int e2; const int far = bfs_far(start, e2);
+      if (e2 <= ecc) break;
+      ecc = e2; start = far;
+    }
+    size_t head = order.size();
+    order.push_back(start); seen[start] = 1;
+    while (head < order.size()) {
+      const int v = order[head++];
+      std::vector<int> nb;
+      for (int w : adj[v]) if (!seen[w]) { seen[w] = 1; nb.push_back(w); }
+      std::sort(nb.begin(), nb.end(), [&](int a, int b) { return adj[a].size() != adj[b].size() ? adj[a].size() < adj[b].size() : a < b; });
+      order.insert(order.end(), nb.begin(), nb.end());
+    }
+  }
+  std::reverse(order.begin(), order.end());
+  std::vector<int> iperm(n);
+  for (int k = 0; k < n; k++) iperm[order[k]] = k;
+  int bw = 0;
+  for (int j = 0; j < n; j++) for (int c : adj[j]) bw = std::max(bw, std::abs(iperm[j] - iperm[c]));
+  const int W = bw + kBatchNB;                              // column stride of the padded band (batch_hip.hip)
+  if (bw > kBatchDirectMaxBw || !be::batch_direct_lds_bytes(n, m, std::max(nzA, nzB), bw)) return;
+  // band slot (column-major band: slot = col * W + (row - col), row >= col, permuted indices) of the P + sigma I entries of B
+  std::vector<int> bp_slot(nzB, -1);
+  for (int j = 0; j < n; j++)
+    for (int k = Brp_[j]; k < Brp_[j + 1]; k++) {
+      const int c = Bj_[k];
+      if (c >= n) continue;
+      const int pr = iperm[j], pc = iperm[c];
+      if (pr >= pc) bp_slot[k] = pc * W + (pr - pc);
+    }
+  // products of A' rho A, grouped by slot
+  struct Prod { int slot, row, a, b; };
+  std::vector<Prod> prods; prods.reserve((size_t)pairs);
+  for (int i = 0; i < m; i++)
+    for (int a = Arp_[i]; a < Arp_[i + 1]; a++)
+      for (int b = a; b < Arp_[i + 1]; b++) {
+        const int pa = iperm[Arj_[a]], pb = iperm[Arj_[b]];
+        const int r = std::max(pa, pb), c = std::min(pa, pb);
+        prods.push_back({c * W + (r - c), i, a, b});
+      }
+  std::stable_sort(prods.begin(), prods.end(), [](const Prod &x, const Prod &y) { return x.slot < y.slot; });
+  std::vector<int> ke_slot, ke_ptr, kp_row(prods.size()), kp_a(prods.size()), kp_b(prods.size());
+  for (size_t p = 0; p < prods.size(); p++) {
+    if (p == 0 || prods[p].slot != prods[p - 1].slot) { ke_slot.push_back(prods[p].slot); ke_ptr.push_back((int)p); }
+    kp_row[p] = prods[p].row; kp_a[p] = prods[p].a; kp_b[p] = prods[p].b;
+  }
+  ke_ptr.push_back((int)prods.size());
+  std::vector<int> tri;
+  for (int a = 1; a <= bw; a++) for (int b = a; b <= bw; b++) tri.push_back(a | (b << 8));
+  auto up = [&](const std::vector<int> &h) { int *p = dev_vec<int>(d_, h.size()); if (!h.empty()) be::h2d(d_, p, h.data(), sizeof(int) * h.size()); return p; };
+  bd_.perm = up(order); bd_.bp_slot = up(bp_slot); bd_.ke_slot = up(ke_slot); bd_.ke_ptr = up(ke_ptr);
+  bd_.kp_row = up(kp_row); bd_.kp_a = up(kp_a); bd_.kp_b = up(kp_b); bd_.tri = up(tri);
+  bd_.kp_val = dev_vec<double>(d_, prods.size());
+  bd_.bw = bw; bd_.nents = (int)ke_slot.size(); bd_.nprod = (int)prods.size(); bd_.ntri = (int)tri.size();
+  bd_.ok = true;
+}
+
 int Engine::batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   if (nbatch <= 0 || !x || !y || !rec) return OSQP_DATA_VALIDATION_ERROR;
@@ -872,6 +983,13 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   p.cg_max = settings.cg_max_iter; p.unscaled = settings.scaling && !settings.scaled_termination; p.scaling = settings.scaling;
   p.precond = settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER; p.rho_is_vec = settings.rho_is_vec; p.warm = warm;
   p.q = q ? dq : nullptr; p.l = l ? dl : nullptr; p.u = u ? du : nullptr; p.q0 = dq0; p.l0 = dl0; p.u0 = du0; p.x = dx; p.y = dy; p.rec = drec;
+  prepare_batch_direct();
+  if (bd_.ok) {
+    be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);             // A's values may have changed since the last call
+    p.eq_factor_direct = eq_factor_set_ ? eq_factor_mixed_ : 1e3;
+    p.bw = bd_.bw; p.nents = bd_.nents; p.ntri = bd_.ntri; p.perm = bd_.perm; p.bp_slot = bd_.bp_slot; p.ke_slot = bd_.ke_slot;
+    p.ke_ptr = bd_.ke_ptr; p.kp_row = bd_.kp_row; p.kp_val = bd_.kp_val; p.tri = bd_.tri;
+  }
   int err = be::batch_solve(d_, p);
   tph[3] = now_s();
   if (!err) {

@@ -67,6 +67,7 @@ class Engine {
   // ---- driver state ----
   double rho_bar_ = 0.1;
   double eq_factor_mixed_ = 10.0;     // see classify_constraints()
+  bool eq_factor_set_ = false;        // osqp_hip_set_rho_eq_factor was called: the batch path's direct variant honours it too
   int cg_budget_ = 0;
   double eps_cg_prev_ = 0;
   bool first_run_ = true;
@@ -74,6 +75,16 @@ class Engine {
   bool use_graph_ = true;
   std::map<std::pair<int, int>, void *> graphs_;
   double *bbuf_ = nullptr; size_t bbuf_cap_ = 0;      // device scratch of batch_solve, kept across calls
+  std::vector<int> Arp_, Arj_, Brp_, Bj_;             // host copies of the CSR structure of A and B (symbolic work of the batch path)
+  // direct (banded Cholesky) linear solve of the batch path: symbolic data, built on first use
+  struct BatchDirect {
+    bool tried = false, ok = false;
+    int bw = -1, nents = 0, nprod = 0, ntri = 0;
+    int *perm = nullptr, *bp_slot = nullptr, *ke_slot = nullptr, *ke_ptr = nullptr, *kp_row = nullptr, *kp_a = nullptr, *kp_b = nullptr, *tri = nullptr;
+    double *kp_val = nullptr;
+  } bd_;
+  void prepare_batch_direct();
+  void free_batch_direct();
   OSQPHipStats stats_{};
   double update_time_acc_ = 0;
   bool clear_update_time_ = false;

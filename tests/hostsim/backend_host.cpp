@@ -208,6 +208,8 @@ void project_normalcone(Dev &d) {
 }
 
 size_t batch_lds_bytes(int, int) { return 0; }
+size_t batch_direct_lds_bytes(int, int, int, int) { return 0; }
+void batch_products(Dev &, int, const int *, const int *, double *) {}
 int batch_solve(Dev &, const BatchParams &) { return OSQP_FUNC_NOT_IMPLEMENTED; }   // GPU-only feature
 
 bool pcg_fused(const Dev &) { return false; }
