@@ -98,7 +98,7 @@ namespace {
 // balanced first phase (the MPC rows have 1..13 entries).  EA = EB = 0: generic row loops reading the matrices from
 // global memory (L1/L2), for patterns with more than 8 * kBB entries per matrix.
 //
-// DIRECT (kBB == 64 only): the linear system of every ADMM iteration is solved exactly, as the reference's direct path does
+// DIRECT: the linear system of every ADMM iteration is solved exactly, as the reference's direct path does
 // (_osqp.py:286-311), instead of by PCG.  K = P + sigma I + A' diag(rho) A is assembled in LDS under the bandwidth-reducing
 // permutation prepared by the engine (column-major lower band, W = bw + 1 doubles per column), Cholesky-factorised in
 // place at every rho change, and each solve is two substitutions that keep the live window of the right-hand side in
@@ -106,8 +106,7 @@ namespace {
 // a pivot is broadcast with v_readlane, every other lane applies its one update -- no LDS traffic on the dependency chain
 // except the (prefetchable) column of L.
 template <int kBB, int EA, int EB, bool DIRECT>
-__global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
-  static_assert(!DIRECT || kBB == 64, "the direct solve is written for one wave per problem");
+__global__ __launch_bounds__(kBB, (DIRECT && kBB == 256) ? 2 : 1) void k_batch_admm(BatchParams P) {
 #ifdef OSQP_HIP_KTRACE
   // diagnostic build: 100 MHz clock ticks spent in the phases; reported in rec[5..7] INSTEAD of rho / rho_updates / pcg_iters
   unsigned long long tk_all = wall_clock64(), tk_fact = 0, tk_solve = 0, tk0 = 0;
@@ -259,8 +258,9 @@ __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
     for (int k = tid; k < n; k += kBB) buf[k] = rhs[P.perm[k]];
     __syncthreads();
     const int nblk = n8 / NB;
+    const bool w0 = tid < 64;                                   // the substitutions run on wave 0; other waves wait at the barriers
     // ---- forward, unit lower:  v_e = w_e - sum_{j in [e-bw, e)} L^[e][j] v_j ;  L^[p0 + dl][p0 + q] = Lr[(p0 + q) W + dl - q] ----
-    {
+    if (w0) {
       double cur = tid < n ? buf[tid] : 0.0, nxt = 64 + tid < n ? buf[64 + tid] : 0.0;
       // lanes beyond the block's reach read the zero in front of column 0 eight times (stride 0): no masking after the load
       auto fetch = [&](int p0, double (&l)[NB]) {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kBB) void k_batch_admm(BatchParams P) {
     __syncthreads();
     // ---- backward, unit upper (L^'):  x_i = g_i - sum_{j in (i, i+bw]} L^[j][i] x_j ; blocks from the top, pivots top - q ;
     //      lane's element i = top - dl ;  L^[top - q][i] = Lr[i W + dl - q] ----
-    {
+    if (w0) {
       auto elem = [&](int top) { return top - ((top - tid) & 63); };
       const int i0 = elem(n8 - 1);
       double cur = (i0 >= 0 && i0 < n) ? buf[i0] : 0.0, nxt = i0 - 64 >= 0 ? buf[i0 - 64] : 0.0;
@@ -552,21 +552,25 @@ int batch_solve(Dev &d, const BatchParams &p) {
   hipStream_t st = static_cast<hipStream_t>(d.stream);
   const int mx = p.A.nnz > p.B.nnz ? p.A.nnz : p.B.nnz;
   const size_t lds_reg = batch_lds_bytes_nnz(p.n, p.m, mx), lds_gen = batch_lds_bytes(p.n, p.m);
-  const char *force = std::getenv("OSQP_HIP_BATCH_VARIANT");      // debugging: "direct", "w64", "w256", "generic"
+  const char *force = std::getenv("OSQP_HIP_BATCH_VARIANT");      // debugging: "direct", "direct256", "w64", "w256", "generic"
   const int e64 = (mx + 63) / 64, e256 = (mx + 255) / 256;
   const bool can64 = lds_reg && e64 <= 24 && p.n <= 1024 && p.m <= 2048, can256 = lds_reg && e256 <= 8;
   const size_t lds_dir = batch_direct_lds_bytes(p.n, p.m, mx, p.bw);
-  const bool can_dir = can64 && lds_dir && p.perm;
-  const bool use_dir = force ? !std::strcmp(force, "direct") && can_dir : can_dir;
-  const bool use64 = !use_dir && (force ? !std::strcmp(force, "w64") && can64 : can64);
+  const bool can_dir = can64 && lds_dir && p.perm, can_dir256 = can256 && lds_dir && p.perm;
+  // default: the direct solve with four waves per problem (MPC batch: 14.2 ms; one wave 18.6 ms; PCG, one wave: 37 ms)
+  const bool use_dir256 = force ? !std::strcmp(force, "direct256") && can_dir256 : can_dir256;
+  const bool use_dir = !use_dir256 && (force ? !std::strcmp(force, "direct") && can_dir : can_dir);
+  const bool use64 = !use_dir && !use_dir256 && (force ? !std::strcmp(force, "w64") && can64 : can64);
   const bool use256 = !use64 && (force ? !std::strcmp(force, "w256") && can256 : can256);
 #define BATCH_LAUNCH(TB, E, LDS) hipLaunchKernelGGL((k_batch_admm<TB, E, E, false>), dim3(p.nbatch), dim3(TB), LDS, st, p)
-#define BATCH_LAUNCH_DIRECT(E) do { \
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<64, E, E, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dir) != hipSuccess) \
+#define BATCH_LAUNCH_DIRECT(TB, E) do { \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<TB, E, E, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dir) != hipSuccess) \
       throw DeviceError("osqp_hip: cannot reserve LDS for the direct batch kernel"); \
-    hipLaunchKernelGGL((k_batch_admm<64, E, E, true>), dim3(p.nbatch), dim3(64), lds_dir, st, p); } while (0)
-  if (use_dir) {
-    if (e64 <= 8) BATCH_LAUNCH_DIRECT(8); else if (e64 <= 16) BATCH_LAUNCH_DIRECT(16); else BATCH_LAUNCH_DIRECT(24);
+    hipLaunchKernelGGL((k_batch_admm<TB, E, E, true>), dim3(p.nbatch), dim3(TB), lds_dir, st, p); } while (0)
+  if (use_dir256) {
+    if (e256 <= 2) BATCH_LAUNCH_DIRECT(256, 2); else if (e256 <= 4) BATCH_LAUNCH_DIRECT(256, 4); else BATCH_LAUNCH_DIRECT(256, 8);
+  } else if (use_dir) {
+    if (e64 <= 8) BATCH_LAUNCH_DIRECT(64, 8); else if (e64 <= 16) BATCH_LAUNCH_DIRECT(64, 16); else BATCH_LAUNCH_DIRECT(64, 24);
   } else if (use64) {
     if (e64 <= 8) BATCH_LAUNCH(64, 8, lds_reg); else if (e64 <= 16) BATCH_LAUNCH(64, 16, lds_reg); else BATCH_LAUNCH(64, 24, lds_reg);
   } else if (use256) {
