@@ -537,7 +537,7 @@ size_t batch_direct_lds_bytes(int n, int m, int nnz, int bw) {
   if (bw < 0 || bw > kBatchDirectMaxBw) return 0;
   const size_t n8 = (size_t)(n + kBatchNB - 1) / kBatchNB * kBatchNB;
   const size_t b = sizeof(double) * ((size_t)10 * n + (size_t)8 * m + 16 + (size_t)((nnz + 1) & ~1) + kBatchNB + n8 * (bw + kBatchNB) + 64);
-  return b <= 96 * 1024 ? b : 0;          // (above the default 64 KB dynamic-LDS limit: batch_solve raises it; gfx950 has 160 KB per CU)
+  return b <= 144 * 1024 ? b : 0;         // (above the default 64 KB dynamic-LDS limit: batch_solve raises it; gfx950 has 160 KB per CU)
 }
 __global__ void k_batch_products(DevCsr A, int nprod, const int *a, const int *b, double *out) {
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < nprod; p += gridDim.x * blockDim.x) out[p] = A.val[a[p]] * A.val[b[p]];

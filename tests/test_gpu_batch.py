@@ -125,3 +125,19 @@ def test_batch_variants_agree_with_oracle(variant, monkeypatch):
         assert np.abs(x[i] - xo).max() <= 2e-4 * (1 + np.abs(xo).max())
         if variant == 'direct':
             print('direct iterations', rec[i, 1], 'oracle', io.iter)
+
+
+def test_batch_direct_longer_horizon_three_epochs(monkeypatch, variant='direct256'):
+    """n = 180 (horizon 15): the substitutions run over three 64-pivot epochs and the factor needs 100 KB of LDS (the
+    one-wave variant does not apply: more than 24 matrix entries per lane)."""
+    monkeypatch.setenv('OSQP_HIP_BATCH_VARIANT', variant)
+    B = 12
+    P, q, A, L, U = problems.mpc_batch(B, N=15, seed=2)
+    s = base_solver(P, q, A, L[0], U[0])
+    x, y, rec = s._solver.hip_batch_solve(l=L, u=U)
+    assert (rec[:, 0] == 1).all() and (rec[:, 7] == 0).all(), rec[:, [0, 7]]
+    for i in (0, 6, 11):
+        xo, yo, io = Oracle().setup(P, q, A, L[i], U[i], eps_abs=1e-9, eps_rel=1e-9, adaptive_rho_interval=50, max_iter=100000).solve()
+        assert io.status_val == SOLVED
+        assert abs(rec[i, 2] - io.obj_val) <= 1e-5 * (1 + abs(io.obj_val))
+        assert np.abs(x[i] - xo).max() <= 1e-4 * (1 + np.abs(xo).max())
