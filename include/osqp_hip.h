@@ -204,6 +204,40 @@ OSQPInt osqp_hip_batch_solve(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat
                              OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm);
 
 /* Test hooks (used by tests/ only): y = A x, y = B [xn; xm] on the device with the scaled matrices. */
+
+/* ---- LinSysSolver slot (north_star's second boundary) -------------------------------------------------------
+ * The reference's C core reaches its KKT solver through a table of function pointers created by an init_linsys_solver_*()
+ * call; that header is not in the reference tree (the core is fetched at configure time, CMakeLists.txt:31-37), so the
+ * member list below follows SURVEY 8b's reconstruction [UPSTREAM-UNVERIFIED]: type, name, solve, update_settings,
+ * warm_start, adjoint_derivative, free, update_matrices, update_rho_vec, nthreads.  What is pinned by the reference is the
+ * MEANING of solve (purepy's linsys_solver.solve, _osqp.py:307-311, and update_xz_tilde, :644-658):
+ *     b = [rhs_x (n); rhs_z (m)]   ->   b = [x~ ; z~],   [[P + sigma I, A'], [A, -diag(1/rho)]] [x~; nu] = b,  z~ = rhs_z + nu / rho
+ * which this (indirect) solver computes on the device as  (P + sigma I + A' diag(rho) A) x~ = rhs_x + A'(rho .* rhs_z)  by PCG
+ * (warm-started from the previous x~) and  z~ = A x~.  P (upper triangle) and A arrive ALREADY SCALED, rho_vec is given per
+ * constraint; the object owns device copies.  b is a host buffer of n + m doubles. */
+typedef struct OSQPHipLinSysSolver_ OSQPHipLinSysSolver;
+struct OSQPHipLinSysSolver_ {
+  enum osqp_linsys_solver_type type;                                              /* OSQP_INDIRECT_SOLVER */
+  const char *(*name)(OSQPHipLinSysSolver *self);
+  OSQPInt (*solve)(OSQPHipLinSysSolver *self, OSQPFloat *b, OSQPInt admm_iter);    /* 0, or an osqp_error_type */
+  void (*update_settings)(OSQPHipLinSysSolver *self, const OSQPSettings *settings);/* cg_max_iter, cg_tol_*, cg_precond */
+  void (*warm_start)(OSQPHipLinSysSolver *self, const OSQPFloat *x);               /* start vector of the next PCG (n) */
+  OSQPInt (*adjoint_derivative)(OSQPHipLinSysSolver *self);                        /* OSQP_FUNC_NOT_IMPLEMENTED */
+  void (*free)(OSQPHipLinSysSolver *self);
+  OSQPInt (*update_matrices)(OSQPHipLinSysSolver *self, const OSQPCscMatrix *P, const OSQPInt *Px_new_idx, OSQPInt P_new_n,
+                             const OSQPCscMatrix *A, const OSQPInt *Ax_new_idx, OSQPInt A_new_n);   /* same pattern, new values */
+  OSQPInt (*update_rho_vec)(OSQPHipLinSysSolver *self, const OSQPFloat *rho_vec, OSQPFloat rho_sc);
+  OSQPInt nthreads;                                                                /* 1 host thread drives the device */
+  OSQPInt pcg_iters;                                                               /* PCG iterations of the last solve */
+  void *impl;
+};
+/* scaled_prim_res / scaled_dual_res: optional pointers to the caller's CURRENT scaled ADMM residuals; when given, a solve stops
+ * at ||r||_inf <= cg_tol_fraction * (*scaled_dual_res) (this engine's rule, DESIGN.md "PCG tolerance"), otherwise (and while
+ * that value is not positive) at a relative reduction of 1e-7.  polishing != 0: always the tight relative rule. */
+OSQPInt osqp_hip_linsys_init(OSQPHipLinSysSolver **self, const OSQPCscMatrix *P, const OSQPCscMatrix *A, const OSQPFloat *rho_vec,
+                             const OSQPSettings *settings, const OSQPFloat *scaled_prim_res, const OSQPFloat *scaled_dual_res,
+                             OSQPInt polishing);
+
 /* Diagnostic builds only (make TRACE=1: kernels stamp the wall clock per workgroup and phase, 16 slots per workgroup):
  * copies the stamps of the most recent launches.  The product library returns OSQP_FUNC_NOT_IMPLEMENTED. */
 OSQPInt osqp_hip_trace_read(OSQPSolver *solver, unsigned long long *out, OSQPInt count);

@@ -1,4 +1,5 @@
 // api.cpp -- extern "C" surface of libosqp_hip.so (include/osqp_hip.h).  Thin: every call forwards to Engine.
+#include <memory>
 #include <new>
 
 #include "engine.hpp"
@@ -92,3 +93,76 @@ OSQPInt osqp_hip_batch_solve(OSQPSolver *s, OSQPInt nbatch, const OSQPFloat *q, 
 OSQPInt osqp_hip_get_scaling(OSQPSolver *s, OSQPFloat *D, OSQPFloat *E, OSQPFloat *c) { return guarded(s, [&](Engine &e) { return e.get_scaling(D, E, c); }); }
 
 }  // extern "C"
+
+// ---- LinSysSolver slot ----
+namespace {
+struct LinSysImpl {
+  Engine eng;
+  const OSQPFloat *prim = nullptr, *dual = nullptr;
+  OSQPInt polishing = 0;
+};
+LinSysImpl *ls(OSQPHipLinSysSolver *s) { return s ? static_cast<LinSysImpl *>(s->impl) : nullptr; }
+template <class F>
+OSQPInt ls_guarded(OSQPHipLinSysSolver *s, F &&f) {
+  LinSysImpl *im = ls(s);
+  if (!im) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  try { return f(*im); }
+  catch (const std::bad_alloc &) { return OSQP_MEM_ALLOC_ERROR; }
+  catch (const osqp_hip::DeviceError &) { return OSQP_ALGEBRA_LOAD_ERROR; }
+  catch (...) { return OSQP_LINSYS_SOLVER_INIT_ERROR; }
+}
+const char *ls_name(OSQPHipLinSysSolver *) { return "HIP reduced-KKT PCG (gfx950)"; }
+OSQPInt ls_solve(OSQPHipLinSysSolver *s, OSQPFloat *b, OSQPInt) {
+  return ls_guarded(s, [&](LinSysImpl &im) {
+    double tol_rel = 1e-7, tol_abs = 0.0;                                  // no residual information: relative reduction
+    if (im.polishing) tol_rel = 1e-12;
+    else if (im.dual && *im.dual > 0) { tol_rel = 1e-14; tol_abs = im.eng.settings.cg_tol_fraction * *im.dual; }
+    int it = 0;
+    const int err = im.eng.ls_solve(b, tol_rel, tol_abs, &it);
+    s->pcg_iters = it;
+    return err;
+  });
+}
+void ls_update_settings(OSQPHipLinSysSolver *s, const OSQPSettings *st) {
+  LinSysImpl *im = ls(s);
+  if (!im || !st) return;
+  if (st->cg_max_iter > 0) im->eng.settings.cg_max_iter = st->cg_max_iter;
+  if (st->cg_tol_fraction > 0 && st->cg_tol_fraction < 1) im->eng.settings.cg_tol_fraction = st->cg_tol_fraction;
+  if (st->cg_tol_reduction > 0) im->eng.settings.cg_tol_reduction = st->cg_tol_reduction;
+}
+void ls_warm_start(OSQPHipLinSysSolver *s, const OSQPFloat *x) { (void)ls_guarded(s, [&](LinSysImpl &im) { return im.eng.ls_warm_start(x); }); }
+OSQPInt ls_adjoint(OSQPHipLinSysSolver *) { return OSQP_FUNC_NOT_IMPLEMENTED; }
+void ls_free(OSQPHipLinSysSolver *s) { if (!s) return; delete ls(s); delete s; }
+OSQPInt ls_update_matrices(OSQPHipLinSysSolver *s, const OSQPCscMatrix *P, const OSQPInt *Pidx, OSQPInt Pn, const OSQPCscMatrix *A, const OSQPInt *Aidx, OSQPInt An) {
+  // the slot hands over the FULL updated matrices (plus the changed positions, which a value-only refresh does not need)
+  (void)Pidx; (void)Pn; (void)Aidx; (void)An;
+  return ls_guarded(s, [&](LinSysImpl &im) {
+    return im.eng.update_data_mat(P ? P->x : nullptr, nullptr, P ? P->p[P->n] : 0, A ? A->x : nullptr, nullptr, A ? A->p[A->n] : 0);
+  });
+}
+OSQPInt ls_update_rho_vec(OSQPHipLinSysSolver *s, const OSQPFloat *rho_vec, OSQPFloat) {
+  return ls_guarded(s, [&](LinSysImpl &im) { return im.eng.ls_set_rho_vec(rho_vec); });
+}
+}  // namespace
+
+extern "C" OSQPInt osqp_hip_linsys_init(OSQPHipLinSysSolver **out, const OSQPCscMatrix *P, const OSQPCscMatrix *A, const OSQPFloat *rho_vec,
+                                        const OSQPSettings *settings, const OSQPFloat *scaled_prim_res, const OSQPFloat *scaled_dual_res,
+                                        OSQPInt polishing) {
+  if (!out) return OSQP_DATA_VALIDATION_ERROR;
+  *out = nullptr;
+  try {
+    std::unique_ptr<LinSysImpl> im(new LinSysImpl());
+    im->prim = scaled_prim_res; im->dual = scaled_dual_res; im->polishing = polishing;
+    const OSQPInt err = im->eng.ls_setup(P, A, rho_vec, settings);
+    if (err) return err;
+    OSQPHipLinSysSolver *s = new OSQPHipLinSysSolver();
+    s->type = OSQP_INDIRECT_SOLVER; s->name = ls_name; s->solve = ls_solve; s->update_settings = ls_update_settings;
+    s->warm_start = ls_warm_start; s->adjoint_derivative = ls_adjoint; s->free = ls_free; s->update_matrices = ls_update_matrices;
+    s->update_rho_vec = ls_update_rho_vec; s->nthreads = 1; s->pcg_iters = 0; s->impl = im.release();
+    *out = s;
+    return OSQP_NO_ERROR;
+  }
+  catch (const std::bad_alloc &) { return OSQP_MEM_ALLOC_ERROR; }
+  catch (const osqp_hip::DeviceError &) { return OSQP_ALGEBRA_LOAD_ERROR; }
+  catch (...) { return OSQP_LINSYS_SOLVER_INIT_ERROR; }
+}

@@ -843,6 +843,82 @@ int Engine::update_settings(const OSQPSettings *s) {
 // x: nbatch x n, y: nbatch x m (in: unscaled warm start if warm != 0; out: solution, or certificate for infeasible ones);
 // rec: nbatch x 8 = {status_val, iter, obj_val, prim_res, dual_res, rho, rho_updates, pcg_iters}.
 
+
+// ------------------------------------------------------------------------------------------------ LinSysSolver slot
+// The reduced-KKT PCG as a stand-alone linear solver (include/osqp_hip.h), built from the same backend
+// operations as the ADMM loop:  kb_rhs  forms  rhs = sigma x - q + A' v  and the PCG start residual, so with  x = 0,
+// q = -rhs_x,  v = rho .* rhs_z  it forms exactly the right-hand side of the reduced system;  k1/k2/kv  are the PCG
+// iterations (three-kernel form: a solve may be continued past its first budget);  init_iterates(0)  leaves  z~ = A x~.
+int Engine::ls_setup(const OSQPCscMatrix *P, const OSQPCscMatrix *A, const double *rho_vec, const OSQPSettings *s) {
+  if (!P || !A || !rho_vec || !s) return OSQP_DATA_VALIDATION_ERROR;
+  OSQPSettings st = *s;
+  st.scaling = 0; st.linsys_solver = OSQP_INDIRECT_SOLVER; st.verbose = 0; st.polishing = 0;   // the matrices arrive scaled
+  const int nn = P->n, mm = A->m;
+  std::vector<double> q(nn, 0.0), l(mm, -OSQP_INFTY), u(mm, OSQP_INFTY);
+  int err = setup(P, q.data(), A, l.data(), u.data(), mm, nn, &st);
+  if (err) return err;
+  d_.fused = 0;
+  return ls_set_rho_vec(rho_vec);
+}
+
+int Engine::ls_set_rho_vec(const double *rho_vec) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (!rho_vec) return OSQP_DATA_VALIDATION_ERROR;
+  be::activate(d_);
+  ls_rho_.assign(rho_vec, rho_vec + m);
+  std::vector<double> rinv(m);
+  for (int i = 0; i < m; i++) { if (!(ls_rho_[i] > 0)) return OSQP_DATA_VALIDATION_ERROR; rinv[i] = 1.0 / ls_rho_[i]; }
+  be::h2d(d_, d_.rho, ls_rho_.data(), sizeof(double) * m);
+  be::h2d(d_, d_.rho_inv, rinv.data(), sizeof(double) * m);
+  be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  be::init_iterates(d_, 0);                        // t0 = rho .* (A x~) must match the new rho
+  be::sync(d_);
+  return OSQP_NO_ERROR;
+}
+
+int Engine::ls_warm_start(const double *x) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (!x) return OSQP_DATA_VALIDATION_ERROR;
+  be::activate(d_);
+  be::h2d(d_, d_.xs, x, sizeof(double) * n);
+  be::init_iterates(d_, 0);
+  be::sync(d_);
+  return OSQP_NO_ERROR;
+}
+
+int Engine::ls_solve(double *b, double tol_rel, double tol_abs, int *iters) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (!b) return OSQP_DATA_VALIDATION_ERROR;
+  be::activate(d_);
+  std::vector<double> nq(n), v(m);
+  for (int j = 0; j < n; j++) nq[j] = -b[j];
+  for (int i = 0; i < m; i++) v[i] = ls_rho_[i] * b[n + i];
+  be::h2d(d_, d_.q, nq.data(), sizeof(double) * n);
+  be::h2d(d_, d_.v, v.data(), sizeof(double) * m);
+  be::zero(d_, d_.x, sizeof(double) * n);
+  be::set_pcg_tol(d_, tol_rel, tol_abs);
+  be::kb_rhs(d_);
+  const int cap = std::min(settings.cg_max_iter, kMaxCg);
+  int flags[F_COUNT] = {0};
+  int done = 0;
+  for (int i0 = 0; i0 < cap && !done;) {           // budget: what the previous solve needed + 2, then doubling
+    const int bud = std::min(cap - i0, std::max(4, i0 == 0 ? cg_budget_ + 2 : i0));
+    for (int i = i0; i < i0 + bud; i++) { be::k1(d_, i); be::k2(d_, i); be::kv(d_, i); }
+    i0 += bud;
+    be::k1(d_, i0 < cap ? i0 : cap);               // the stopping test of the last update (its SpMV is wasted only if the cap was hit)
+    be::fetch_flags(d_, flags);
+    done = flags[F_DONE];
+    if (!done && i0 >= cap) break;
+    if (!done) { be::k2(d_, i0); be::kv(d_, i0); i0++; }
+  }
+  cg_budget_ = done ? flags[F_ITERS] : cap;
+  if (iters) *iters = cg_budget_;
+  be::init_iterates(d_, 0);                        // z~ = A x~ ; t0 for the next solve's start residual
+  be::d2h(d_, b, d_.xs, sizeof(double) * n);
+  if (m > 0) be::d2h(d_, b + n, d_.zt, sizeof(double) * m);
+  return OSQP_NO_ERROR;
+}
+
 // ------------------------------------------------------------------------------------------------ batch path, direct solve
 // Symbolic preparation of the banded-Cholesky linear solve of the batch kernel (batch_hip.hip): the pattern of
 // K = P + sigma I + A' diag(rho) A, a reverse Cuthill-McKee ordering of it, the band slot of every P entry, and for

@@ -40,6 +40,11 @@ class Engine {
   int get_scaling(double *D, double *E, double *c);
   int set_rho_eq_factor(double f);
   int batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm);
+  // LinSysSolver slot (include/osqp_hip.h): this Engine instance is then used ONLY as the reduced-KKT solver
+  int ls_setup(const OSQPCscMatrix *P, const OSQPCscMatrix *A, const double *rho_vec, const OSQPSettings *s);
+  int ls_set_rho_vec(const double *rho_vec);
+  int ls_warm_start(const double *x);
+  int ls_solve(double *b, double tol_rel, double tol_abs, int *iters);
 
   OSQPSolver pub{};          // what the caller holds
   OSQPSettings settings{};
@@ -75,6 +80,7 @@ class Engine {
   bool use_graph_ = true;
   std::map<std::pair<int, int>, void *> graphs_;
   double *bbuf_ = nullptr; size_t bbuf_cap_ = 0;      // device scratch of batch_solve, kept across calls
+  std::vector<double> ls_rho_;                        // LinSysSolver slot: host copy of rho_vec
   std::vector<int> Arp_, Arj_, Brp_, Bj_;             // host copies of the CSR structure of A and B (symbolic work of the batch path)
   // direct (banded Cholesky) linear solve of the batch path: symbolic data, built on first use
   struct BatchDirect {

@@ -61,6 +61,24 @@ class StatsStruct(C.Structure):
 
 SolverP = C.POINTER(SolverStruct)
 
+
+class LinSysStruct(C.Structure):      # OSQPHipLinSysSolver, include/osqp_hip.h (the LinSysSolver slot)
+    pass
+
+
+LinSysP = C.POINTER(LinSysStruct)
+LinSysStruct._fields_ = [
+    ('type', C.c_int),
+    ('name', C.CFUNCTYPE(C.c_char_p, LinSysP)),
+    ('solve', C.CFUNCTYPE(C.c_int, LinSysP, c_double_p, C.c_int)),
+    ('update_settings', C.CFUNCTYPE(None, LinSysP, C.POINTER(SettingsStruct))),
+    ('warm_start', C.CFUNCTYPE(None, LinSysP, c_double_p)),
+    ('adjoint_derivative', C.CFUNCTYPE(C.c_int, LinSysP)),
+    ('free', C.CFUNCTYPE(None, LinSysP)),
+    ('update_matrices', C.CFUNCTYPE(C.c_int, LinSysP, C.POINTER(CscStruct), c_int_p, C.c_int, C.POINTER(CscStruct), c_int_p, C.c_int)),
+    ('update_rho_vec', C.CFUNCTYPE(C.c_int, LinSysP, c_double_p, C.c_double)),
+    ('nthreads', C.c_int), ('pcg_iters', C.c_int), ('impl', C.c_void_p)]
+
 # every symbol include/osqp_hip.h declares: name -> (restype, argtypes)
 PROTOTYPES = {
     'osqp_capabilities': (C.c_int, []),
@@ -90,6 +108,8 @@ PROTOTYPES = {
     'osqp_hip_batch_solve': (C.c_int, [SolverP, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),
     'osqp_hip_get_scaling': (C.c_int, [SolverP, c_double_p, c_double_p, c_double_p]),
     'osqp_hip_backend': (C.c_char_p, []),
+    'osqp_hip_linsys_init': (C.c_int, [C.POINTER(LinSysP), C.POINTER(CscStruct), C.POINTER(CscStruct), c_double_p,
+                                       C.POINTER(SettingsStruct), c_double_p, c_double_p, C.c_int]),
 }
 
 
