@@ -202,6 +202,12 @@ OSQPInt osqp_hip_time_kernel(OSQPSolver *solver, OSQPInt which, OSQPInt reps, do
    callers then loop osqp_update_data_vec + osqp_solve. */
 OSQPInt osqp_hip_batch_solve(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u,
                              OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm);
+/* The same solve with EVERY array in device memory of this solver's device (e.g. torch ROCm tensors through data_ptr(); SURVEY 8f
+ * rank 2: no PCIe round trip).  Asynchronous: the kernel is enqueued on `stream` (a hipStream_t; inputs must be ready on it and
+ * the outputs are valid once it has drained -- the solver handle must not be used again before that); stream == NULL uses the
+ * solver's own stream and waits for it.  l <= u is NOT validated on this path. */
+OSQPInt osqp_hip_batch_solve_device(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat *q_dev, const OSQPFloat *l_dev, const OSQPFloat *u_dev,
+                                    OSQPFloat *x_dev, OSQPFloat *y_dev, OSQPFloat *rec_dev, OSQPInt warm_start, void *stream);
 
 /* Test hooks (used by tests/ only): y = A x, y = B [xn; xm] on the device with the scaled matrices. */
 

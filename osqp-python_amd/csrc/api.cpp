@@ -90,6 +90,9 @@ OSQPInt osqp_hip_set_rho_eq_factor(OSQPSolver *s, OSQPFloat f) { return guarded(
 OSQPInt osqp_hip_batch_solve(OSQPSolver *s, OSQPInt nbatch, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u, OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm) {
   return guarded(s, [&](Engine &e) { return e.batch_solve(nbatch, q, l, u, x, y, rec, warm); });
 }
+OSQPInt osqp_hip_batch_solve_device(OSQPSolver *s, OSQPInt nbatch, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u, OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm, void *stream) {
+  return guarded(s, [&](Engine &e) { return e.batch_solve_device(nbatch, q, l, u, x, y, rec, warm, stream); });
+}
 OSQPInt osqp_hip_get_scaling(OSQPSolver *s, OSQPFloat *D, OSQPFloat *E, OSQPFloat *c) { return guarded(s, [&](Engine &e) { return e.get_scaling(D, E, c); }); }
 
 }  // extern "C"

@@ -547,9 +547,9 @@ void batch_products(Dev &d, int nprod, const int *a, const int *b, double *out) 
   if (nprod > 0) hipLaunchKernelGGL(k_batch_products, dim3((nprod + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(d.stream), d.A, nprod, a, b, out);
 }
 
-int batch_solve(Dev &d, const BatchParams &p) {
+int batch_solve(Dev &d, const BatchParams &p, void *stream) {
   if (hipSetDevice(d.device) != hipSuccess) return OSQP_ALGEBRA_LOAD_ERROR;
-  hipStream_t st = static_cast<hipStream_t>(d.stream);
+  hipStream_t st = static_cast<hipStream_t>(stream ? stream : d.stream);
   const int mx = p.A.nnz > p.B.nnz ? p.A.nnz : p.B.nnz;
   const size_t lds_reg = batch_lds_bytes_nnz(p.n, p.m, mx), lds_gen = batch_lds_bytes(p.n, p.m);
   const char *force = std::getenv("OSQP_HIP_BATCH_VARIANT");      // debugging: "direct", "direct256", "w64", "w256", "generic"
@@ -582,7 +582,7 @@ int batch_solve(Dev &d, const BatchParams &p) {
   }
 #undef BATCH_LAUNCH
 #undef BATCH_LAUNCH_DIRECT
-  hipError_t e = hipStreamSynchronize(st);
+  hipError_t e = stream ? hipGetLastError() : hipStreamSynchronize(st);
   if (e != hipSuccess) throw DeviceError(std::string("osqp_hip: batch kernel failed: ") + hipGetErrorString(e));
   return OSQP_NO_ERROR;
 }

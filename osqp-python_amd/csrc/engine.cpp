@@ -1027,6 +1027,16 @@ void Engine::prepare_batch_direct() {
   bd_.ok = true;
 }
 
+void Engine::fill_batch_params(BatchParams &p, int nbatch, int warm) {
+  p.n = n; p.m = m; p.nbatch = nbatch; p.A = d_.A; p.B = d_.B; p.D = d_.D; p.Dinv = d_.Dinv; p.E = d_.E; p.Einv = d_.Einv;
+  p.c = c_; p.cinv = cinv_; p.sigma = settings.sigma; p.alpha = settings.alpha; p.rho0 = clamp_rho(settings.rho); p.eq_factor = eq_factor_mixed_;
+  p.eps_abs = settings.eps_abs; p.eps_rel = settings.eps_rel; p.eps_pinf = settings.eps_prim_inf; p.eps_dinf = settings.eps_dual_inf;
+  p.cg_frac = settings.cg_tol_fraction; p.rho_tol = settings.adaptive_rho_tolerance;
+  p.max_iter = settings.max_iter; p.check = settings.check_termination; p.rho_interval = settings.adaptive_rho ? auto_rho_interval() : 0;
+  p.cg_max = settings.cg_max_iter; p.unscaled = settings.scaling && !settings.scaled_termination; p.scaling = settings.scaling;
+  p.precond = settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER; p.rho_is_vec = settings.rho_is_vec; p.warm = warm;
+}
+
 int Engine::batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   if (nbatch <= 0 || !x || !y || !rec) return OSQP_DATA_VALIDATION_ERROR;
@@ -1051,13 +1061,7 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   if (warm) { be::h2d(d_, dx, x, sizeof(double) * N); be::h2d(d_, dy, y, sizeof(double) * M); }
   be::sync(d_); tph[2] = now_s();
   BatchParams p{};
-  p.n = n; p.m = m; p.nbatch = nbatch; p.A = d_.A; p.B = d_.B; p.D = d_.D; p.Dinv = d_.Dinv; p.E = d_.E; p.Einv = d_.Einv;
-  p.c = c_; p.cinv = cinv_; p.sigma = settings.sigma; p.alpha = settings.alpha; p.rho0 = clamp_rho(settings.rho); p.eq_factor = eq_factor_mixed_;
-  p.eps_abs = settings.eps_abs; p.eps_rel = settings.eps_rel; p.eps_pinf = settings.eps_prim_inf; p.eps_dinf = settings.eps_dual_inf;
-  p.cg_frac = settings.cg_tol_fraction; p.rho_tol = settings.adaptive_rho_tolerance;
-  p.max_iter = settings.max_iter; p.check = settings.check_termination; p.rho_interval = settings.adaptive_rho ? auto_rho_interval() : 0;
-  p.cg_max = settings.cg_max_iter; p.unscaled = settings.scaling && !settings.scaled_termination; p.scaling = settings.scaling;
-  p.precond = settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER; p.rho_is_vec = settings.rho_is_vec; p.warm = warm;
+  fill_batch_params(p, nbatch, warm);
   p.q = q ? dq : nullptr; p.l = l ? dl : nullptr; p.u = u ? du : nullptr; p.q0 = dq0; p.l0 = dl0; p.u0 = du0; p.x = dx; p.y = dy; p.rec = drec;
   prepare_batch_direct();
   if (bd_.ok) {
@@ -1075,6 +1079,35 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   stats_.gpu_solve_ms = 1e3 * (tph[3] - tph[2]);
   if (timing) std::fprintf(stderr, "osqp_hip batch: validate %.2f ms, H2D %.2f ms, kernel %.2f ms, D2H %.2f ms\n", 1e3 * (tph[1] - tph[0]), 1e3 * (tph[2] - tph[1]), 1e3 * (tph[3] - tph[2]), 1e3 * (tph[4] - tph[3]));
   return err;
+}
+
+
+// Device-resident variant: q, l, u, x, y, rec are device pointers on this solver's device; the kernel is
+// enqueued on the caller's stream and not waited for (stream == nullptr: the solver's stream, synchronous).
+int Engine::batch_solve_device(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, void *stream) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (nbatch <= 0 || !x || !y || !rec) return OSQP_DATA_VALIDATION_ERROR;
+  if (!be::batch_lds_bytes(n, m)) return OSQP_FUNC_NOT_IMPLEMENTED;
+  be::activate(d_);
+  // shared vectors (for the arguments given as NULL) live in the solver's scratch block
+  const size_t need = n + 2 * (size_t)m;
+  if (need > bbuf_cap_) { if (bbuf_) be::dfree(d_, bbuf_); bbuf_ = dev_vec<double>(d_, need); bbuf_cap_ = need; }
+  double *dq0 = bbuf_ + bbuf_cap_ - need, *dl0 = dq0 + n, *du0 = dl0 + m;
+  if (!q) be::h2d(d_, dq0, q0_.data(), sizeof(double) * n);
+  if (!l) be::h2d(d_, dl0, l0_.data(), sizeof(double) * m);
+  if (!u) be::h2d(d_, du0, u0_.data(), sizeof(double) * m);
+  BatchParams p{};
+  fill_batch_params(p, nbatch, warm);
+  p.q = q; p.l = l; p.u = u; p.q0 = dq0; p.l0 = dl0; p.u0 = du0; p.x = x; p.y = y; p.rec = rec;
+  prepare_batch_direct();
+  if (bd_.ok) {
+    be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);
+    p.eq_factor_direct = eq_factor_set_ ? eq_factor_mixed_ : 1e3;
+    p.bw = bd_.bw; p.nents = bd_.nents; p.ntri = bd_.ntri; p.perm = bd_.perm; p.bp_slot = bd_.bp_slot; p.ke_slot = bd_.ke_slot;
+    p.ke_ptr = bd_.ke_ptr; p.kp_row = bd_.kp_row; p.kp_val = bd_.kp_val; p.tri = bd_.tri;
+  }
+  be::sync(d_);                                   // the uploads and the product refresh ran on the solver's stream
+  return be::batch_solve(d_, p, stream);
 }
 
 int Engine::get_stats(OSQPHipStats *out) { if (!out) return OSQP_DATA_VALIDATION_ERROR; *out = stats_; out->pcg_fused = be::pcg_fused(d_) ? 1.0 : 0.0; return OSQP_NO_ERROR; }

@@ -40,6 +40,8 @@ class Engine {
   int get_scaling(double *D, double *E, double *c);
   int set_rho_eq_factor(double f);
   int batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm);
+  int batch_solve_device(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, void *stream);
+  void fill_batch_params(BatchParams &p, int nbatch, int warm);
   // LinSysSolver slot (include/osqp_hip.h): this Engine instance is then used ONLY as the reduced-KKT solver
   int ls_setup(const OSQPCscMatrix *P, const OSQPCscMatrix *A, const double *rho_vec, const OSQPSettings *s);
   int ls_set_rho_vec(const double *rho_vec);

@@ -106,6 +106,7 @@ PROTOTYPES = {
     'osqp_hip_test_spmv': (C.c_int, [SolverP, C.c_int, c_double_p, c_double_p]),
     'osqp_hip_set_rho_eq_factor': (C.c_int, [SolverP, C.c_double]),
     'osqp_hip_batch_solve': (C.c_int, [SolverP, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),
+    'osqp_hip_batch_solve_device': (C.c_int, [SolverP, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'osqp_hip_get_scaling': (C.c_int, [SolverP, c_double_p, c_double_p, c_double_p]),
     'osqp_hip_backend': (C.c_char_p, []),
     'osqp_hip_linsys_init': (C.c_int, [C.POINTER(LinSysP), C.POINTER(CscStruct), C.POINTER(CscStruct), c_double_p,

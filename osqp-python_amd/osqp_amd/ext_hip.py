@@ -258,6 +258,13 @@ class OSQPSolver:
             raise ValueError(str(st))
         return x, y, rec
 
+    def hip_batch_solve_device(self, nbatch, q_ptr, l_ptr, u_ptr, x_ptr, y_ptr, rec_ptr, warm=False, stream=None):
+        """osqp_hip_batch_solve_device: raw device addresses (int or None) of float64 arrays laid out as in hip_batch_solve;
+        rec: (B, 8).  Enqueued on `stream` (hipStream_t handle as int; None: the solver's stream, synchronous)."""
+        st = self._lib.osqp_hip_batch_solve_device(self._p, int(nbatch), q_ptr, l_ptr, u_ptr, x_ptr, y_ptr, rec_ptr, int(bool(warm)), stream)
+        if st:
+            raise ValueError(str(st))
+
     def hip_scaling(self):
         D, E, c = np.empty(self.n), np.empty(self.m), C.c_double()
         self._lib.osqp_hip_get_scaling(self._p, _ptr(D, _lib.c_double_p), _ptr(E, _lib.c_double_p), C.byref(c))

@@ -210,7 +210,7 @@ void project_normalcone(Dev &d) {
 size_t batch_lds_bytes(int, int) { return 0; }
 size_t batch_direct_lds_bytes(int, int, int, int) { return 0; }
 void batch_products(Dev &, int, const int *, const int *, double *) {}
-int batch_solve(Dev &, const BatchParams &) { return OSQP_FUNC_NOT_IMPLEMENTED; }   // GPU-only feature
+int batch_solve(Dev &, const BatchParams &, void *) { return OSQP_FUNC_NOT_IMPLEMENTED; }   // GPU-only feature
 
 bool pcg_fused(const Dev &) { return false; }
 bool graphs_supported() { return false; }

@@ -104,6 +104,32 @@ def test_nn_module_forward_shared_and_per_element_matrices():
         layer(Pv, qv, Av, torch.tensor(Lb), torch.tensor(Ub))
 
 
+def test_nn_module_forward_zero_copy_device_tensors():
+    """q, l, u as torch ROCm tensors: handed to the batch kernel by device pointer on torch's current stream
+    (osqp_hip_batch_solve_device), result produced on the device; must equal the host-array path bit for bit (same kernel,
+    same inputs), also when the inputs are produced by torch kernels queued just before on the same stream."""
+    import torch
+    from osqp_amd.nn.torch import OSQP as OSQPLayer
+    B = 40
+    P, q, A, L, U = problems.mpc_batch(B, seed=8)
+    Pc, Ac = P.tocoo(), A.tocoo()
+    layer = OSQPLayer((Pc.row, Pc.col), P.shape, (Ac.row, Ac.col), A.shape, eps_abs=1e-6, eps_rel=1e-6)
+    Pv, Av = torch.tensor(Pc.data), torch.tensor(Ac.data)
+    qh = 0.02 * torch.randn(B, P.shape[0], dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    xh = layer(Pv, qh, Av, torch.tensor(L), torch.tensor(U))
+    dev = torch.device('cuda:0')
+    # inputs computed ON the device right before the call (ordering on the stream matters)
+    qd = (qh.to(dev) * 2.0) / 2.0
+    Ld, Ud = torch.tensor(L, device=dev) + 0.0, torch.tensor(U, device=dev) + 0.0
+    xd = layer(Pv, qd, Av, Ld, Ud)
+    assert xd.is_cuda and xd.shape == xh.shape and xd.dtype == xh.dtype
+    assert torch.equal(xd.cpu(), xh)
+    assert layer.last_dual.is_cuda and layer.last_dual.shape == (B, A.shape[0])
+    with pytest.raises(RuntimeError):
+        Lb, Ub = Ld.clone(), Ud.clone(); Lb[1, :8] += 500; Ub[1, :8] += 500
+        layer(Pv, qd, Av, Lb, Ub)
+
+
 @pytest.mark.parametrize('variant', ['direct', 'direct256', 'w64'])
 def test_batch_variants_agree_with_oracle(variant, monkeypatch):
     """Both linear-solve variants of the batch kernel (banded Cholesky in LDS / PCG) on the same MPC batch; the direct one

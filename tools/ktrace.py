@@ -53,5 +53,11 @@ for rep in range(3):
     print('--- repetition %d: pair time by hipEvent %.2f us' % (rep, ms * 1e3))
     a = report(tr, 0, 'k_k2f', '')
     b = report(tr, 8, 'k_k1f', ', alpha, vector update')
+    for base, nm in ((0, 'k_k2f'), (8, 'k_k1f')):
+        t0 = int(tr[:, base].min()); ex = (tr[:, base + 6].astype(np.int64) - t0) * 0.01; en = (tr[:, base].astype(np.int64) - t0) * 0.01
+        wg = np.arange(1024)
+        print('  %s exit by XCD (wg %% 8): ' % nm + ' '.join('%d:%.2f/%.2f' % (x, np.median(ex[wg % 8 == x]), ex[wg % 8 == x].max()) for x in range(8)) + '   (median/max us)')
+        print('  %s exit by slot quarter (wg // 8 in 0-31, 32-63, 64-95, 96-127): ' % nm + ' '.join('%.2f/%.2f' % (np.median(ex[(wg // 8) // 32 == k]), ex[(wg // 8) // 32 == k].max()) for k in range(4)))
+        print('  %s entry by slot quarter: ' % nm + ' '.join('%.2f' % np.median(en[(wg // 8) // 32 == k]) for k in range(4)) + '; slowest 20 wgs: ' + ' '.join(str(i) for i in np.argsort(-ex)[:20]))
     print('  k_k1f first entry - k_k2f last exit: %.2f us;  k_k2f entry -> k_k1f last exit: %.2f us'
           % ((int(b) - int(tr[:, 6].max())) * 0.01, (int(tr[:, 14].max()) - int(a)) * 0.01))
