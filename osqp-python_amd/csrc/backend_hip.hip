@@ -262,9 +262,14 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
     for (int u = 0; u < kChunk / kBlock; u++) { const int k = threadIdx.x + u * kBlock; cc[u] = k < cnt ? M.col[k0 + k] : -1; }     // indices first:
 #pragma unroll
     for (int u = 0; u < kChunk / kBlock; u++) { const int k = threadIdx.x + u * kBlock; vv[u] = k < cnt ? M.val[k0 + k] : 0.0; }    // the gathers wait only for them
-    const int myr = r0 + threadIdx.x;                            // the row this lane reduces in the first pass
+    // Row sums: one lane per row, or -- when the block has at most kBlock/2 rows -- TWO lanes per row (even/odd entries,
+    // combined with one shuffle): halves the serial chain of LDS reads of the row-sum phase for matrices with ~100 rows of
+    // ~14 entries per block (B at config 2: k_k2f 7.9 -> 7.5 us back to back).
+    const int lpr = 2 * (r1 - r0) <= kBlock ? 2 : 1;
+    const int sub = lpr == 2 ? (int)(threadIdx.x & 1) : 0;
+    const int myr = r0 + (lpr == 2 ? (int)(threadIdx.x >> 1) : (int)threadIdx.x);   // the row this lane reduces in the first pass
     int rp0 = 0, rp1 = 0;                                        // raw row pointers: not touched before the barrier
-    if (myr < r1) { rp0 = M.rowptr[myr]; rp1 = M.rowptr[myr + 1]; e.prefetch(myr); }
+    if (myr < r1) { rp0 = M.rowptr[myr]; rp1 = M.rowptr[myr + 1]; if (sub == 0) e.prefetch(myr); }
     KT(Pre::kTraceBase + 2);
     typename GatherOps<G>::Ops ops[kChunk / kBlock];
 #pragma unroll
@@ -280,7 +285,21 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
     }
     __syncthreads();
     KT(Pre::kTraceBase + 4);    // products staged
-    if (myr < r1) {
+    if (lpr == 2) {
+      double acc[NS];
+#pragma unroll
+      for (int s = 0; s < NS; s++) acc[s] = 0.0;
+      if (myr < r1) {
+        const int ra = rp0 - k0, rz = rp1 - k0;
+        for (int k = ra + sub; k < rz; k += 2) {
+#pragma unroll
+          for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < NS; s++) acc[s] += __shfl_xor(acc[s], 1, 64);      // (whole waves take this path: lpr is block-uniform)
+      if (myr < r1 && sub == 0) e(myr, acc);
+    } else if (myr < r1) {
       const int ra = rp0 - k0, rz = rp1 - k0;
       double acc[NS];
 #pragma unroll
@@ -291,7 +310,7 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
       }
       e(myr, acc);
     }
-    for (int r = myr + kBlock; r < r1; r += kBlock) {            // blocks with more than kBlock (mostly empty) rows
+    for (int r = myr + kBlock; lpr == 1 && r < r1; r += kBlock) {   // blocks with more than kBlock (mostly empty) rows
       const int a = M.rowptr[r] - k0, z = M.rowptr[r + 1] - k0;
       double acc[NS];
 #pragma unroll
