@@ -46,8 +46,11 @@ def main():
     for _ in range(args.warmup):
         table, x, y, rng = sharded.solve_batch_sharded(s, l=L, u=U, rank=rank, world=world, device=dev if world > 1 else None)
     barrier(); t0 = time.perf_counter()
+    step_ms = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         table, x, y, rng = sharded.solve_batch_sharded(s, l=L, u=U, rank=rank, world=world, device=dev if world > 1 else None)
+        step_ms.append(1e3 * (time.perf_counter() - ts))
     barrier(); el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device='cuda')
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -57,6 +60,7 @@ def main():
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * el / args.steps, 'higher_is_better': True, 'scaling': 'strong',
                'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                'config': {'workload': 'BASELINE configs[4]: %d MPC QPs, horizon 10, nx=8, nu=4 (problems.mpc_batch); host scaling + H2D/D2H included' % B,
+                          'ms_per_step_median': float(sorted(step_ms)[len(step_ms) // 2]), 'kernel_ms_last_step': s._solver.hip_stats()['gpu_solve_ms'],
                           'solved': int((table[:, 1] == 1).sum()), 'admm_iters_total': float(table[:, 2].sum()),
                           'admm_iters_per_s': float(table[:, 2].sum()) * args.steps / el}}
         if args.cpu_sample > 0:
