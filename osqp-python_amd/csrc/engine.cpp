@@ -565,6 +565,8 @@ void Engine::admm_core(double t0, double *res) {
     int next = settings.max_iter;
     if (ct > 0) next = std::min(next, (iter / ct + 1) * ct);
     if (ari > 0) next = std::min(next, (iter / ari + 1) * ari);
+    static const bool full_budget = std::getenv("OSQP_HIP_BUDGET_FULL") != nullptr;      // debugging: never starve the PCG
+    if (full_budget) cg_budget_ = std::min(settings.cg_max_iter, kMaxCg);
     run_chunk(next - iter, cg_budget_);
     iter = next;
     be::residuals(d_);
