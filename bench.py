@@ -203,7 +203,7 @@ def main():
                                    'eps_abs=eps_rel=%g, indirect PCG, one replica per GPU' % (n, mm, A.nnz, P.nnz, args.eps),
                        'admm_iters_per_solve': int(res.info.iter), 'status': res.info.status, 'obj_val': res.info.obj_val,
                        'prim_res': res.info.prim_res, 'dual_res': res.info.dual_res, 'rho_updates': int(res.info.rho_updates),
-                       'pcg_iters_per_admm_iter': stats['pcg_iters_total'] / max(res.info.iter, 1),
+                       'pcg_iters_per_admm_iter': stats['pcg_iters_total'] / max(res.info.iter, 1), 'pcg_budget_limited_iters': int(stats['pcg_unconverged']),
                        'pcg_kernels_per_iteration': 2 if fused else 3, 'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
                        'setup_s': t_setup, 'per_rank': [{'status': int(r[0]), 'iter': int(r[1]), 'obj': r[2]} for r in allrec]},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

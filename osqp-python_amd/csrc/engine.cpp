@@ -622,7 +622,8 @@ void Engine::admm_core(double t0, double *res) {
       const double var = std::max(0.0, flags[F_STAT_SUMSQ] / cnt - mean * mean);
       static const double nsig = [] { const char *e = std::getenv("OSQP_HIP_BUDGET_SIGMA"); return e ? std::atof(e) : 3.0; }();
       const int q3 = (int)std::ceil(mean + nsig * std::sqrt(var));     // (KA checks the residual after the last budgeted iteration)
-      cg_budget_ = std::min(cap, std::max(2, std::min(flags[F_STAT_MAX], q3)));
+      static const int slack = [] { const char *e = std::getenv("OSQP_HIP_BUDGET_SLACK"); return e ? std::atoi(e) : 0; }();
+      cg_budget_ = std::min(cap, std::max(2, std::min(flags[F_STAT_MAX], q3)) + slack);
     }
   }
 }

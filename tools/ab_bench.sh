@@ -9,7 +9,7 @@ for rep in 1 2; do
     env ${!envvar} OSQP_HIP_LIBRARY=$lib python bench.py --steps 3 --warmup 1 --cpu-seconds 0 2>&1 | tail -1 > gpurun_out/ab_$v.json
     python - <<PY
 import json; d=json.load(open("gpurun_out/ab_$v.json")); r=d["roofline"]
-print("$v", round(d["value"],1), round(d["ms_per_step"],2), d["config"]["admm_iters_per_solve"], round(d["config"]["pcg_iters_per_admm_iter"],2), int(d["config"]["kernel_launches_per_solve"]), "pcg_pair_us", round(r["pcg_iteration"]["ms"]*1e3,2), {k.split()[0]: round(v["ms_same_kernel_repeat"]*1e3,2) for k,v in r["kernels"].items()})
+print("$v", round(d["value"],1), round(d["ms_per_step"],2), d["config"]["admm_iters_per_solve"], round(d["config"]["pcg_iters_per_admm_iter"],2), int(d["config"]["kernel_launches_per_solve"]), "unconv", d["config"].get("pcg_budget_limited_iters"), "pcg_pair_us", round(r["pcg_iteration"]["ms"]*1e3,2), {k.split()[0]: round(v["ms_same_kernel_repeat"]*1e3,2) for k,v in r["kernels"].items()})
 PY
   done
 done
