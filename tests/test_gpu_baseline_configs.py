@@ -29,6 +29,26 @@ def certify(P, q, A, l, u, r, eps=EPS):
     return k
 
 
+def test_config2_full_size_matches_oracle_direct_solution():
+    """BASELINE configs[1] at FULL size (n = 100k, m = 200k, nnz(A) = 1M): the HIP engine's solution against the oracle's
+    direct-LDL' ADMM run to the same tolerance on the host (about a minute of CPU: 2 s ordering + factorisation, ~1300
+    iterations of two triangular solves over nnz(L) = 2.7e7).  north_star's bar: agreement with the qdldl-direct CPU path
+    within eps_abs = eps_rel = 1e-6; both iterates stop at residuals <= eps, so x, y are compared at 2e-4 relative to the
+    solution's scale and the objectives at 1e-6."""
+    P, q, A, l, u = problems.banded_qp(100000)
+    st = dict(eps_abs=EPS, eps_rel=EPS, max_iter=20000, adaptive_rho_interval=50, check_termination=25)
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, **st)
+    r = m.solve()
+    certify(P, q, A, l, u, r)
+    xo, yo, io = Oracle().setup(P, q, A, l, u, **st).solve()
+    assert io.status_val == SOLVED
+    print('config 2 full size: engine %d iterations, oracle %d; |dx| %.2e |dy| %.2e |dobj| %.2e'
+          % (r.info.iter, io.iter, np.abs(r.x - xo).max(), np.abs(r.y - yo).max(), abs(r.info.obj_val - io.obj_val)))
+    assert np.abs(r.x - xo).max() <= 2e-4 * (1 + np.abs(xo).max())
+    assert np.abs(r.y - yo).max() <= 2e-4 * (1 + np.abs(yo).max())
+    assert abs(r.info.obj_val - io.obj_val) <= 1e-6 * (1 + abs(io.obj_val))
+
+
 def test_config3_lasso_full_size():
     """Lasso-as-QP n=5k features, m=10k samples, fully dense data block (50M stored entries; long-row SpMV path)."""
     P, q, A, l, u = problems.lasso_qp(5000, 10000)
