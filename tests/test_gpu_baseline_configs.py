@@ -49,6 +49,16 @@ def test_config2_full_size_matches_oracle_direct_solution():
     assert abs(r.info.obj_val - io.obj_val) <= 1e-6 * (1 + abs(io.obj_val))
 
 
+def test_ten_times_config2_kkt_certificate():
+    """n = 1M, m = 2M, nnz(A) = 10M (each workgroup streams ~10 row blocks per kernel: the multi-block path of every sparse
+    kernel, 0.5 GB of matrices): optimality certificate of the returned (x, y) recomputed on the host."""
+    P, q, A, l, u = problems.banded_qp(1000000)
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, eps_abs=EPS, eps_rel=EPS, verbose=False, max_iter=20000)
+    r = m.solve()
+    k = certify(P, q, A, l, u, r)
+    print('n=1M: iter', r.info.iter, 'certificate', k)
+
+
 def test_config3_lasso_full_size():
     """Lasso-as-QP n=5k features, m=10k samples, fully dense data block (50M stored entries; long-row SpMV path)."""
     P, q, A, l, u = problems.lasso_qp(5000, 10000)
