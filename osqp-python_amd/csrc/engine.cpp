@@ -613,8 +613,9 @@ void Engine::admm_core(double t0, double *res) {
     if (std::isfinite(eps)) { eps_cg_prev_ = eps; be::set_pcg_tol(d_, 1e-14, eps); have_tol_ = true; }
     // PCG budget for the next chunk: track what the last chunk needed
     const int cap = std::min(settings.cg_max_iter, kMaxCg);
-    if (flags[F_STAT_UNCONV] * 4 > std::max(1, flags[F_STAT_N])) cg_budget_ = std::min(cap, std::max(cg_budget_ + 2, 2 * cg_budget_));
-    else if (flags[F_STAT_UNCONV] > 0) cg_budget_ = std::min(cap, cg_budget_ + 1);
+    static const double tolerate = [] { const char *e = std::getenv("OSQP_HIP_BUDGET_TOLERATE"); return e ? std::atof(e) : 0.0; }();
+    if (flags[F_STAT_UNCONV] * 4 > std::max(1, flags[F_STAT_N]) && flags[F_STAT_UNCONV] > tolerate * flags[F_STAT_N]) cg_budget_ = std::min(cap, std::max(cg_budget_ + 2, 2 * cg_budget_));
+    else if (flags[F_STAT_UNCONV] > tolerate * flags[F_STAT_N]) cg_budget_ = std::min(cap, cg_budget_ + 1);
     else {
       // mean + 3 sigma of the PCG counts of the last chunk (+1), never above its max + 1: rare spikes should not
       // set the budget of the next 25 iterations (an occasional budget-limited solve is just a slightly less exact one)
