@@ -189,8 +189,9 @@ OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
    5 = one whole PCG iteration (K1, K2, Kv in sequence; time per sequence) without the reductions of partials,
    6 = the same with them (what a solve executes); 7 / 8 / 9 = sequence 6 without K2 / K1 / Kv, so that (6) - (7) is
    K2's time INSIDE the sequence, i.e. with the caches in the state a solve leaves them (a same-kernel repeat keeps the
-   matrix L2-resident and flatters the kernel).
-   The kernels run in a side-effect-free "probe" mode; solver state is unchanged. */
+   matrix L2-resident and flatters the kernel).  10 = one FUSED PCG iteration (k_k2f, k_k1f: the default form), 11 / 12 = each
+   of the two alone, 13 = the pair with the converged flag set (eager-launch cost of an early-exit pair).
+   The kernels run in a side-effect-free "probe" mode or on saved-and-restored state; solver state is unchanged. */
 OSQPInt osqp_hip_time_kernel(OSQPSolver *solver, OSQPInt which, OSQPInt reps, double *mean_ms);
 
 /* Batched solve of `nbatch` QPs that share this solver's P, A, scaling and settings and differ in q / l / u (BASELINE
@@ -198,8 +199,10 @@ OSQPInt osqp_hip_time_kernel(OSQPSolver *solver, OSQPInt which, OSQPInt reps, do
    one workgroup per problem, iterates in LDS).  q: nbatch x n, l/u: nbatch x m, row-major, NULL = the solver's current
    vector for every problem.  x: nbatch x n, y: nbatch x m (in: warm start if warm != 0; out: solution, or the
    infeasibility certificate).  rec: nbatch x 8 doubles {status_val, iter, obj_val, prim_res, dual_res, rho, rho_updates,
-   pcg_iters}.  Returns OSQP_FUNC_NOT_IMPLEMENTED when a problem does not fit one workgroup's LDS (10n + 8m doubles <= 64 KB):
-   callers then loop osqp_update_data_vec + osqp_solve. */
+   pcg_iters}.  The linear system of each ADMM iteration is solved DIRECTLY (banded LDL' of the reduced KKT matrix in LDS under a
+   bandwidth-reducing ordering; pcg_iters = 0, equality weight 1e3 as in the reference) when that band fits next to the iterates
+   (<= 144 KB, permuted half bandwidth <= 56), by PCG otherwise.  Returns OSQP_FUNC_NOT_IMPLEMENTED when a problem does not fit
+   one workgroup's LDS at all (10n + 8m doubles > 64 KB): callers then loop osqp_update_data_vec + osqp_solve. */
 OSQPInt osqp_hip_batch_solve(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u,
                              OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm);
 /* The same solve with EVERY array in device memory of this solver's device (e.g. torch ROCm tensors through data_ptr(); SURVEY 8f
@@ -209,7 +212,6 @@ OSQPInt osqp_hip_batch_solve(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat
 OSQPInt osqp_hip_batch_solve_device(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat *q_dev, const OSQPFloat *l_dev, const OSQPFloat *u_dev,
                                     OSQPFloat *x_dev, OSQPFloat *y_dev, OSQPFloat *rec_dev, OSQPInt warm_start, void *stream);
 
-/* Test hooks (used by tests/ only): y = A x, y = B [xn; xm] on the device with the scaled matrices. */
 
 /* ---- LinSysSolver slot (north_star's second boundary) -------------------------------------------------------
  * The reference's C core reaches its KKT solver through a table of function pointers created by an init_linsys_solver_*()
@@ -247,6 +249,7 @@ OSQPInt osqp_hip_linsys_init(OSQPHipLinSysSolver **self, const OSQPCscMatrix *P,
 /* Diagnostic builds only (make TRACE=1: kernels stamp the wall clock per workgroup and phase, 16 slots per workgroup):
  * copies the stamps of the most recent launches.  The product library returns OSQP_FUNC_NOT_IMPLEMENTED. */
 OSQPInt osqp_hip_trace_read(OSQPSolver *solver, unsigned long long *out, OSQPInt count);
+/* Test hook (used by tests/ only): which = 0: out = A in (n -> m); 1: out = B [in_n; in_m] (n + m -> n), with the scaled device matrices. */
 OSQPInt osqp_hip_test_spmv(OSQPSolver *solver, OSQPInt which, const OSQPFloat *in, OSQPFloat *out);
 /* Weight of equality rows relative to inequality rows, rho_eq = factor * rho, used when equality and inequality rows are
    mixed (default 10; the reference's 1e3 is kept when every active row is an equality).  See engine.cpp
