@@ -124,6 +124,7 @@ size_t batch_lds_bytes(int n, int m);                       // 0 if a problem do
 // stream == nullptr: on d.stream, synchronous.  Otherwise enqueued on that hipStream_t and NOT waited for.  OSQP_FUNC_NOT_IMPLEMENTED if it does not fit
 int batch_solve(Dev &d, const BatchParams &p, void *stream = nullptr);
 size_t batch_direct_lds_bytes(int n, int m, int nnz, int bw); // 0 if the banded factor does not fit next to the iterates
+bool batch_direct_selected(const BatchParams &p);              // would batch_solve run a direct (banded LDL') variant for p?
 void batch_products(Dev &d, int nprod, const int *a, const int *b, double *out);   // out[p] = A.val[a[p]] * A.val[b[p]]
 
 const char *name();

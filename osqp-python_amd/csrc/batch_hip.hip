@@ -547,21 +547,35 @@ void batch_products(Dev &d, int nprod, const int *a, const int *b, double *out) 
   if (nprod > 0) hipLaunchKernelGGL(k_batch_products, dim3((nprod + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(d.stream), d.A, nprod, a, b, out);
 }
 
+namespace {
+struct BatchChoice { bool dir256, dir64, w64, w256, generic; int e64, e256; size_t lds_reg, lds_gen, lds_dir; };
+BatchChoice choose_batch_variant(const BatchParams &p) {
+  BatchChoice c{};
+  const int mx = p.A.nnz > p.B.nnz ? p.A.nnz : p.B.nnz;
+  c.lds_reg = batch_lds_bytes_nnz(p.n, p.m, mx); c.lds_gen = batch_lds_bytes(p.n, p.m);
+  const char *force = std::getenv("OSQP_HIP_BATCH_VARIANT");      // debugging: "direct", "direct256", "w64", "w256", "generic"
+  c.e64 = (mx + 63) / 64; c.e256 = (mx + 255) / 256;
+  const bool can64 = c.lds_reg && c.e64 <= 24 && p.n <= 1024 && p.m <= 2048, can256 = c.lds_reg && c.e256 <= 8;
+  c.lds_dir = batch_direct_lds_bytes(p.n, p.m, mx, p.bw);
+  const bool can_dir = can64 && c.lds_dir && p.perm, can_dir256 = can256 && c.lds_dir && p.perm;
+  // default: the direct solve with four waves per problem (MPC batch: 14.2 ms; one wave 18.6 ms; PCG, one wave: 37 ms)
+  c.dir256 = force ? !std::strcmp(force, "direct256") && can_dir256 : can_dir256;
+  c.dir64 = !c.dir256 && (force ? !std::strcmp(force, "direct") && can_dir : can_dir);
+  c.w64 = !c.dir64 && !c.dir256 && (force ? !std::strcmp(force, "w64") && can64 : can64);
+  c.w256 = !c.dir64 && !c.dir256 && !c.w64 && (force ? !std::strcmp(force, "w256") && can256 : can256);
+  c.generic = !c.dir64 && !c.dir256 && !c.w64 && !c.w256 && c.lds_gen;
+  return c;
+}
+}  // namespace
+bool batch_direct_selected(const BatchParams &p) { const BatchChoice c = choose_batch_variant(p); return c.dir256 || c.dir64; }
+
 int batch_solve(Dev &d, const BatchParams &p, void *stream) {
   if (hipSetDevice(d.device) != hipSuccess) return OSQP_ALGEBRA_LOAD_ERROR;
   hipStream_t st = static_cast<hipStream_t>(stream ? stream : d.stream);
-  const int mx = p.A.nnz > p.B.nnz ? p.A.nnz : p.B.nnz;
-  const size_t lds_reg = batch_lds_bytes_nnz(p.n, p.m, mx), lds_gen = batch_lds_bytes(p.n, p.m);
-  const char *force = std::getenv("OSQP_HIP_BATCH_VARIANT");      // debugging: "direct", "direct256", "w64", "w256", "generic"
-  const int e64 = (mx + 63) / 64, e256 = (mx + 255) / 256;
-  const bool can64 = lds_reg && e64 <= 24 && p.n <= 1024 && p.m <= 2048, can256 = lds_reg && e256 <= 8;
-  const size_t lds_dir = batch_direct_lds_bytes(p.n, p.m, mx, p.bw);
-  const bool can_dir = can64 && lds_dir && p.perm, can_dir256 = can256 && lds_dir && p.perm;
-  // default: the direct solve with four waves per problem (MPC batch: 14.2 ms; one wave 18.6 ms; PCG, one wave: 37 ms)
-  const bool use_dir256 = force ? !std::strcmp(force, "direct256") && can_dir256 : can_dir256;
-  const bool use_dir = !use_dir256 && (force ? !std::strcmp(force, "direct") && can_dir : can_dir);
-  const bool use64 = !use_dir && !use_dir256 && (force ? !std::strcmp(force, "w64") && can64 : can64);
-  const bool use256 = !use64 && (force ? !std::strcmp(force, "w256") && can256 : can256);
+  const BatchChoice ch = choose_batch_variant(p);
+  const int e64 = ch.e64, e256 = ch.e256;
+  const size_t lds_reg = ch.lds_reg, lds_gen = ch.lds_gen, lds_dir = ch.lds_dir;
+  const bool use_dir256 = ch.dir256, use_dir = ch.dir64, use64 = ch.w64, use256 = ch.w256;
 #define BATCH_LAUNCH(TB, E, LDS) hipLaunchKernelGGL((k_batch_admm<TB, E, E, false>), dim3(p.nbatch), dim3(TB), LDS, st, p)
 #define BATCH_LAUNCH_DIRECT(TB, E) do { \
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<TB, E, E, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dir) != hipSuccess) \

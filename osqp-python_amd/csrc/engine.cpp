@@ -517,6 +517,10 @@ int Engine::solve() {
   if (!settings.warm_starting) cold_start();                                            // _osqp.py:1204-1205
   info.rho_updates = 0; info.status_polish = 0; info.polish_time = 0;
   set_status(OSQP_UNSOLVED);
+  if (small_direct_applicable()) {
+    const int err = solve_small_direct(t0);
+    if (err != OSQP_FUNC_NOT_IMPLEMENTED) return err;
+  }
   stats_.pcg_iters_total = stats_.pcg_iters_max = stats_.pcg_unconverged = 0;
   stats_.kernel_launches = stats_.graph_launches = 0;
   double res[R_COUNT];
@@ -1041,6 +1045,77 @@ void Engine::fill_batch_params(BatchParams &p, int nbatch, int warm) {
   p.precond = settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER; p.rho_is_vec = settings.rho_is_vec; p.warm = warm;
 }
 
+void Engine::attach_batch_direct(BatchParams &p) {
+  if (!bd_.ok) return;
+  p.eq_factor_direct = eq_factor_set_ ? eq_factor_mixed_ : 1e3;
+  p.bw = bd_.bw; p.nents = bd_.nents; p.ntri = bd_.ntri; p.perm = bd_.perm; p.bp_slot = bd_.bp_slot; p.ke_slot = bd_.ke_slot;
+  p.ke_ptr = bd_.ke_ptr; p.kp_row = bd_.kp_row; p.kp_val = bd_.kp_val; p.tri = bd_.tri;
+}
+
+// ------------------------------------------------------------------------------------------------ small problems
+// A QP small enough for the batch kernel's DIRECT variant (iterates, matrices and the banded LDL' factor of the reduced
+// KKT matrix in one workgroup's LDS) is solved by ONE launch of that kernel with a batch of one: the whole ADMM loop runs
+// on the device with exact linear solves and the reference's rho rule, i.e. the algorithm of the reference's direct path
+// (same iteration counts as the oracle), instead of thousands of graph-replayed multi-kernel iterations with inexact
+// inner solves -- on small LPs / rank-deficient QPs the latter can need 10x more ADMM iterations (fuzz).
+// Not taken with polishing or verbose output (per-iteration printing and polish live in the host-driven loop), with a
+// time limit, or when OSQP_HIP_SMALL_DIRECT=0.
+bool Engine::small_direct_applicable() {
+  const char *env = std::getenv("OSQP_HIP_SMALL_DIRECT");       // read per solve: tests and tools switch it at run time
+  const bool off = env && env[0] == '0';
+  if (off || !be::device_assembly() || settings.polishing || settings.verbose || settings.time_limit < 1e9) return false;
+  if (!be::batch_lds_bytes(n, m)) return false;
+  prepare_batch_direct();
+  if (!bd_.ok) return false;
+  BatchParams p{};
+  fill_batch_params(p, 1, 0);
+  attach_batch_direct(p);
+  return be::batch_direct_selected(p);
+}
+
+int Engine::solve_small_direct(double t0) {
+  const int warm = settings.warm_starting ? 1 : 0;
+  std::vector<double> x(n, 0.0), y(std::max(m, 1), 0.0);       // (m = 0: batch_solve still wants a non-null y)
+  if (warm) {                                                   // continue from the device iterates (x, y; z = A x as in warm_start)
+    be::d2h(d_, x.data(), d_.x, sizeof(double) * n);
+    if (m > 0) be::d2h(d_, y.data(), d_.y, sizeof(double) * m);
+    for (int j = 0; j < n; j++) x[j] *= D_[j];
+    for (int i = 0; i < m; i++) y[i] *= cinv_ * E_[i];
+  }
+  double rec[8] = {0};
+  const int err = batch_solve(1, nullptr, nullptr, nullptr, x.data(), y.data(), rec, warm);
+  if (err) return err;
+  const int st = (int)rec[0];
+  set_status(st);
+  info.iter = (int)rec[1]; info.obj_val = rec[2]; info.prim_res = rec[3]; info.dual_res = rec[4];
+  info.rho_updates = (int)rec[6]; info.rho_estimate = rec[5];
+  if (rec[5] != rho_bar_) {                                     // adaptive rho moved: keep the handle's state in step (_osqp.py:923-930)
+    rho_bar_ = clamp_rho(rec[5]); settings.rho = rho_bar_;
+    be::set_rho(d_, rho_bar_);
+    be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  }
+  const bool pinf = st == OSQP_PRIMAL_INFEASIBLE || st == OSQP_PRIMAL_INFEASIBLE_INACCURATE;
+  const bool dinf = st == OSQP_DUAL_INFEASIBLE || st == OSQP_DUAL_INFEASIBLE_INACCURATE;
+  std::fill(sol_pc_.begin(), sol_pc_.end(), kNaN); std::fill(sol_dc_.begin(), sol_dc_.end(), kNaN);
+  if (!pinf && !dinf) {
+    std::copy(x.begin(), x.end(), sol_x_.begin()); std::copy(y.begin(), y.begin() + m, sol_y_.begin());   // (solution.x/y point into these)
+    const int keep = settings.warm_starting;
+    warm_start(x.data(), m > 0 ? y.data() : nullptr);           // device iterates follow (a later solve continues from them)
+    settings.warm_starting = keep;
+  } else {
+    std::fill(sol_x_.begin(), sol_x_.end(), kNaN); std::fill(sol_y_.begin(), sol_y_.end(), kNaN);
+    if (pinf) std::copy(y.begin(), y.begin() + m, sol_pc_.begin()); else std::copy(x.begin(), x.end(), sol_dc_.begin());                    // the kernel returns the certificate in place of y / x
+    cold_start();
+  }
+  stats_.pcg_iters_total = stats_.pcg_iters_max = stats_.pcg_unconverged = 0;
+  stats_.kernel_launches = 1; stats_.graph_launches = 0;
+  be::sync(d_);
+  info.solve_time = now_s() - t0;
+  info.run_time = (first_run_ ? info.setup_time : info.update_time) + info.solve_time;
+  first_run_ = false; clear_update_time_ = true;
+  return OSQP_NO_ERROR;
+}
+
 int Engine::batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   if (nbatch <= 0 || !x || !y || !rec) return OSQP_DATA_VALIDATION_ERROR;
@@ -1070,9 +1145,7 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   prepare_batch_direct();
   if (bd_.ok) {
     be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);             // A's values may have changed since the last call
-    p.eq_factor_direct = eq_factor_set_ ? eq_factor_mixed_ : 1e3;
-    p.bw = bd_.bw; p.nents = bd_.nents; p.ntri = bd_.ntri; p.perm = bd_.perm; p.bp_slot = bd_.bp_slot; p.ke_slot = bd_.ke_slot;
-    p.ke_ptr = bd_.ke_ptr; p.kp_row = bd_.kp_row; p.kp_val = bd_.kp_val; p.tri = bd_.tri;
+    attach_batch_direct(p);
   }
   int err = be::batch_solve(d_, p);
   tph[3] = now_s();
@@ -1106,9 +1179,7 @@ int Engine::batch_solve_device(int nbatch, const double *q, const double *l, con
   prepare_batch_direct();
   if (bd_.ok) {
     be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);
-    p.eq_factor_direct = eq_factor_set_ ? eq_factor_mixed_ : 1e3;
-    p.bw = bd_.bw; p.nents = bd_.nents; p.ntri = bd_.ntri; p.perm = bd_.perm; p.bp_slot = bd_.bp_slot; p.ke_slot = bd_.ke_slot;
-    p.ke_ptr = bd_.ke_ptr; p.kp_row = bd_.kp_row; p.kp_val = bd_.kp_val; p.tri = bd_.tri;
+    attach_batch_direct(p);
   }
   be::sync(d_);                                   // the uploads and the product refresh ran on the solver's stream
   return be::batch_solve(d_, p, stream);

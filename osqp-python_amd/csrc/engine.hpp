@@ -92,6 +92,9 @@ class Engine {
     double *kp_val = nullptr;
   } bd_;
   void prepare_batch_direct();
+  bool small_direct_applicable();
+  int solve_small_direct(double t0);
+  void attach_batch_direct(BatchParams &p);
   void free_batch_direct();
   OSQPHipStats stats_{};
   double update_time_acc_ = 0;

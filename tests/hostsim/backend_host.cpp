@@ -113,7 +113,10 @@ void ka(Dev &d, int budget) {
   int used = d.flags[F_DONE] ? d.flags[F_ITERS] : budget;
   d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;
   d.flags[F_STAT_MAX] = std::max(d.flags[F_STAT_MAX], used);
-  if (!d.flags[F_DONE]) d.flags[F_STAT_UNCONV] += 1;
+  // like k_ka of the HIP backend: a PCG whose LAST budgeted update reached the tolerance is converged, not budget-limited
+  bool done = d.flags[F_DONE] != 0;
+  if (!done) { Impl &s = im(d); const double tol = std::max(d.scal[S_TOL_REL] * s.bnorm, d.scal[S_TOL_ABS]); done = !(s.rnorm > tol); }
+  if (!done) d.flags[F_STAT_UNCONV] += 1;
 }
 
 void residuals(Dev &d) {
@@ -209,6 +212,7 @@ void project_normalcone(Dev &d) {
 
 size_t batch_lds_bytes(int, int) { return 0; }
 size_t batch_direct_lds_bytes(int, int, int, int) { return 0; }
+bool batch_direct_selected(const BatchParams &) { return false; }
 void batch_products(Dev &, int, const int *, const int *, double *) {}
 int batch_solve(Dev &, const BatchParams &, void *) { return OSQP_FUNC_NOT_IMPLEMENTED; }   // GPU-only feature
 

@@ -38,8 +38,14 @@ for t in range(count):
         A = sp.vstack([A, sp.eye(n)]).tocsc(); l = np.concatenate([l, x0 - 2]); u = np.concatenate([u, x0 + 2]); m += n
     st = dict(eps_abs=EPS, eps_rel=EPS, max_iter=20000, verbose=False)
     xo, yo, io = Oracle().setup(P, q, A, l, u, eps_abs=EPS, eps_rel=EPS, max_iter=20000, adaptive_rho_interval=50, check_termination=25).solve()
+    os.environ.pop('OSQP_HIP_BATCH_VARIANT', None)
+    os.environ['OSQP_HIP_SMALL_DIRECT'] = '1'
     s = osqp_amd.OSQP(); s.setup(P, q, A, l, u, **st)
-    res = s.solve()
+    res = s.solve()                                                       # default: one launch of the direct batch kernel when it applies
+    fast = s._solver.hip_stats()['kernel_launches'] == 1
+    os.environ['OSQP_HIP_SMALL_DIRECT'] = '0'
+    s2 = osqp_amd.OSQP(); s2.setup(P, q, A, l, u, **st)
+    res2 = s2.solve()                                                     # the multi-kernel PCG engine on the same problem
     tag = '%s n=%d m=%d' % (kind, n, m)
     def agree(name, status, x, obj, iters):
         global bad, soft
@@ -57,7 +63,9 @@ for t in range(count):
             print('%s %s [%s]: status %d (%d it) vs oracle %d (%d it), obj %.6g vs %.6g' % ('iteration-limit' if limit else 'MISMATCH', name, tag, status, iters,
                                                                                             io.status_val, io.iter, obj, io.obj_val), flush=True)
         stats[name] = stats.get(name, 0) + 1
-    agree('engine', res.info.status_val, res.x, res.info.obj_val, res.info.iter)
+    agree('engine:direct' if fast else 'engine:pcg(default)', res.info.status_val, res.x, res.info.obj_val, res.info.iter)
+    if fast:
+        agree('engine:pcg(forced)', res2.info.status_val, res2.x, res2.info.obj_val, res2.info.iter)
     for variant in ('direct256', 'direct', 'w64'):
         os.environ['OSQP_HIP_BATCH_VARIANT'] = variant
         try:
