@@ -1,0 +1,105 @@
+"""GPU tier: osqp_solve on small QPs = one launch of the batch kernel's direct variant (Engine::solve_small_direct).
+Checks that the path is taken, that it reproduces the oracle's direct-LDL' ADMM iteration for iteration (same algorithm,
+same rho rule), and the handle semantics around it: warm continuation, updates, rho persistence, certificates, opt-out."""
+import warnings
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+import scipy.sparse as sp
+
+import osqp_amd
+import problems
+from oracle import Oracle, SOLVED, PRIMAL_INFEASIBLE
+
+pytestmark = pytest.mark.gpu
+warnings.simplefilter('ignore')
+EPS = 1e-6
+ST = dict(eps_abs=EPS, eps_rel=EPS, max_iter=20000, adaptive_rho_interval=50, check_termination=25)
+
+
+def mpc1(seed=3):
+    P, q, A, L, U = problems.mpc_batch(1, seed=seed)
+    return P, q, A, L[0], U[0]
+
+
+def launches(m):
+    return int(m._solver.hip_stats()['kernel_launches'])
+
+
+@pytest.mark.parametrize('gen', [mpc1, lambda: problems.banded_qp(150, window=20), lambda: problems.banded_qp(60, m=90, window=12, seed=5)])
+def test_one_launch_and_same_iterations_as_oracle(gen):
+    P, q, A, l, u = gen()
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, **ST)
+    r = m.solve()
+    assert launches(m) == 1 and r.info.status_val == 1
+    xo, yo, io = Oracle().setup(P, q, A, l, u, **ST).solve()
+    assert io.status_val == SOLVED and r.info.iter == io.iter and r.info.rho_updates == io.rho_updates
+    npt.assert_allclose(r.x, xo, rtol=0, atol=1e-7 * (1 + np.abs(xo).max()))
+    npt.assert_allclose(r.y, yo, rtol=0, atol=1e-7 * (1 + np.abs(yo).max()))
+    assert abs(r.info.obj_val - io.obj_val) <= 1e-9 * (1 + abs(io.obj_val))
+
+
+def test_opt_out_and_excluded_settings(monkeypatch):
+    P, q, A, l, u = mpc1()
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, polishing=True, **ST)
+    r = m.solve()
+    assert launches(m) > 1 and r.info.status_val == 1                 # polish lives in the host-driven loop
+    monkeypatch.setenv('OSQP_HIP_SMALL_DIRECT', '0')
+    m2 = osqp_amd.OSQP(); m2.setup(P, q, A, l, u, verbose=False, **ST)
+    r2 = m2.solve()
+    assert launches(m2) > 1 and r2.info.status_val == 1
+    monkeypatch.delenv('OSQP_HIP_SMALL_DIRECT')
+    m3 = osqp_amd.OSQP(); m3.setup(P, q, A, l, u, verbose=False, **ST)
+    r3 = m3.solve()
+    assert launches(m3) == 1
+    npt.assert_allclose(r3.x, r2.x, rtol=0, atol=2e-5 * (1 + np.abs(r2.x).max()))
+
+
+def test_handle_state_follows_warm_continuation_updates_rho():
+    P, q, A, l, u = mpc1(seed=9)
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, **ST)
+    r1 = m.solve()
+    assert launches(m) == 1 and r1.info.rho_updates >= 0
+    rho_after = m._solver.get_settings().rho                            # the C-side settings (bindings.cpp.in:163)
+    r2 = m.solve()                                                       # continues from the solution: done at the first check
+    assert r2.info.iter <= 25 and r2.info.status_val == 1
+    npt.assert_allclose(r2.x, r1.x, rtol=0, atol=1e-5 * (1 + np.abs(r1.x).max()))
+    # update the linear cost, re-solve warm, compare with a fresh cold solve of the new problem
+    q2 = q + 0.05 * np.random.default_rng(1).standard_normal(len(q))
+    m.update(q=q2)
+    r3 = m.solve()
+    f = osqp_amd.OSQP(); f.setup(P, q2, A, l, u, verbose=False, **ST)
+    r4 = f.solve()
+    assert r3.info.status_val == 1 and r3.info.iter <= r4.info.iter
+    npt.assert_allclose(r3.x, r4.x, rtol=0, atol=2e-5 * (1 + np.abs(r4.x).max()))
+    # explicit warm start with the optimum of the new problem
+    m.warm_start(x=r4.x, y=r4.y)
+    r5 = m.solve()
+    assert r5.info.iter <= 25
+    # the adapted rho stays with the handle, as the reference's work.settings.rho does (_osqp.py:923-930)
+    assert (rho_after != 0.1) == (r1.info.rho_updates > 0)
+
+
+def test_infeasible_problem_certificate_through_the_direct_path():
+    P, q, A, l, u = mpc1(seed=4)
+    l = l.copy(); u = u.copy(); l[:8] += 500.0; u[:8] += 500.0
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, **ST)
+    r = m.solve()
+    xo, yo, io = Oracle().setup(P, q, A, l, u, **ST).solve()
+    assert launches(m) == 1 and io.status_val == PRIMAL_INFEASIBLE and r.info.status_val == PRIMAL_INFEASIBLE
+    cert = r.prim_inf_cert / np.abs(r.prim_inf_cert).max()
+    assert np.all(np.isnan(r.x)) and np.abs(A.T @ cert).max() < 1e-3 and u @ np.maximum(cert, 0) + l @ np.minimum(cert, 0) < 0
+
+
+def test_unconstrained_and_tiny_problems():
+    n = 5
+    P = sp.diags([1.0, 2.0, 0.5, 3.0, 1.5]).tocsc(); q = np.array([1.0, -2.0, 0.3, 0.0, 4.0])
+    m = osqp_amd.OSQP(); m.setup(P, q, sp.csc_matrix((0, n)), np.zeros(0), np.zeros(0), verbose=False, eps_abs=1e-9, eps_rel=1e-9)
+    r = m.solve()
+    assert launches(m) == 1 and r.info.status_val == 1
+    npt.assert_allclose(r.x, -q / P.diagonal(), rtol=0, atol=1e-8)
+    # n = 1, one constraint
+    m = osqp_amd.OSQP(); m.setup(sp.csc_matrix([[2.0]]), np.array([-1.0]), sp.csc_matrix([[1.0]]), np.array([1.0]), np.array([3.0]), verbose=False, eps_abs=1e-9, eps_rel=1e-9)
+    r = m.solve()
+    assert launches(m) == 1 and r.info.status_val == 1 and abs(r.x[0] - 1.0) < 1e-7 and abs(r.y[0] + 1.0) < 1e-6
