@@ -1058,12 +1058,12 @@ void Engine::attach_batch_direct(BatchParams &p) {
 // on the device with exact linear solves and the reference's rho rule, i.e. the algorithm of the reference's direct path
 // (same iteration counts as the oracle), instead of thousands of graph-replayed multi-kernel iterations with inexact
 // inner solves -- on small LPs / rank-deficient QPs the latter can need 10x more ADMM iterations (fuzz).
-// Not taken with polishing or verbose output (per-iteration printing and polish live in the host-driven loop), with a
-// time limit, or when OSQP_HIP_SMALL_DIRECT=0.
+// Polish (host-driven, Engine::polish) then runs on the device iterates this path leaves behind.  Not taken with verbose
+// output (per-iteration printing lives in the host-driven loop), with a time limit, or when OSQP_HIP_SMALL_DIRECT=0.
 bool Engine::small_direct_applicable() {
   const char *env = std::getenv("OSQP_HIP_SMALL_DIRECT");       // read per solve: tests and tools switch it at run time
   const bool off = env && env[0] == '0';
-  if (off || !be::device_assembly() || settings.polishing || settings.verbose || settings.time_limit < 1e9) return false;
+  if (off || !be::device_assembly() || settings.verbose || settings.time_limit < 1e9) return false;
   if (!be::batch_lds_bytes(n, m)) return false;
   prepare_batch_direct();
   if (!bd_.ok) return false;
@@ -1111,7 +1111,8 @@ int Engine::solve_small_direct(double t0) {
   stats_.kernel_launches = 1; stats_.graph_launches = 0;
   be::sync(d_);
   info.solve_time = now_s() - t0;
-  info.run_time = (first_run_ ? info.setup_time : info.update_time) + info.solve_time;
+  if (settings.polishing && st == OSQP_SOLVED) { polish(); store_solution(); be::sync(d_); }   // _osqp.py:1278-1279
+  info.run_time = (first_run_ ? info.setup_time : info.update_time) + info.solve_time + info.polish_time;
   first_run_ = false; clear_update_time_ = true;
   return OSQP_NO_ERROR;
 }
