@@ -10,13 +10,14 @@ import osqp_amd
 from oracle import Oracle
 
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+NMIN = int(os.environ.get('FUZZ_NMIN', 1)); NMAX = int(os.environ.get('FUZZ_NMAX', 40))        # variable-count range
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 EPS = 1e-6
 bad = 0
 soft = 0
 stats = {}
 for t in range(count):
-    n = int(rng.integers(1, 41)); m = int(rng.integers(0, 61))
+    n = int(rng.integers(NMIN, NMAX + 1)); m = int(rng.integers(0, int(1.5 * NMAX) + 1))
     dens = rng.choice([0.1, 0.3, 0.8])
     kind = rng.choice(['spd', 'psd_lowrank', 'zero', 'diag'])
     if kind == 'spd':
