@@ -39,7 +39,11 @@ constexpr int kMaxCg = 1024;       // hard cap on the PCG budget (size of the al
 struct DevCsr {
   int nrows = 0, ncols = 0, nnz = 0, nblk = 0;
   int *rowptr = nullptr, *col = nullptr;
-  int *blkdesc = nullptr;        // nblk x {first row, end row, first nnz, end nnz}: one 16-byte load per row block
+  int *blkdesc = nullptr;        // nblk x {first row, end row, first nnz, end nnz}: one 16-byte load per row block.  A LONG row
+                                 // (one row, more than kLongRow entries: reduced by the whole workgroup) carries -(1 + base) as its
+                                 // end row: base = its first entry in runinfo
+  int *runinfo = nullptr;        // per kChunk-entry slice of a long row: first column if the slice's columns are consecutive
+                                 // (dense data blocks: the kernels then skip the index loads, 4 of 12 bytes per entry), else -1
   double *val = nullptr;
 };
 

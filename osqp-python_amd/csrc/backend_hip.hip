@@ -217,9 +217,11 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
   // control-flow join sits between the hook's loads and the matrix loads (a join makes the compiler drain the counter).
   auto block = [&](auto first_tag, const int4 ds) -> bool {
     constexpr bool FIRST = decltype(first_tag)::value;
-    const int r0 = ds.x, r1 = ds.y, k0 = ds.z, k1 = ds.w;
+    const int r0 = ds.x, k0 = ds.z, k1 = ds.w;
+    const int r1 = ds.y < 0 ? r0 + 1 : ds.y;                    // (ds.y < 0: a long row, -(1 + index of its run table))
     const int cnt = k1 - k0;
-    if (r1 - r0 == 1 && cnt > kLongRow) {                       // one long row: whole workgroup reduces it
+    if (ds.y < 0) {                                             // one long row: whole workgroup reduces it
+      const int *runs = M.runinfo - (1 + ds.y);
       if constexpr (FIRST) { if (!PreOps<Pre>::finish(pre, PreOps<Pre>::begin(pre))) return false; }
       if (threadIdx.x == 0) e.prefetch(r0);                     // epilogue operands requested before the stream, not after it
       double acc[NS];
@@ -227,11 +229,19 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
       for (int s = 0; s < NS; s++) acc[s] = 0.0;
       // kChunk entries per step, as in the short-row path: 8 index loads, 8 value loads, 8 gathers per lane in flight
       // together (one load batch per lane and step reached 2.9 TB/s on dense 5000-entry rows; this form is the fix)
-      for (int base = k0; base < k1; base += kChunk) {
+      int c0 = runs[0];                                         // (requested one slice ahead: it gates the slice's first loads)
+      for (int base = k0, j = 0; base < k1; base += kChunk, j++) {
         int cc[kChunk / kBlock];
         double vv[kChunk / kBlock];
+        const int crun = c0;
+        if (base + kChunk < k1) c0 = runs[j + 1];
+        if (crun >= 0) {                                        // consecutive columns (dense block): no index loads for this slice
 #pragma unroll
-        for (int u = 0; u < kChunk / kBlock; u++) { const int k = base + (int)threadIdx.x + u * kBlock; cc[u] = k < k1 ? M.col[k] : -1; }
+          for (int u = 0; u < kChunk / kBlock; u++) { const int k = base + (int)threadIdx.x + u * kBlock; cc[u] = k < k1 ? crun + (k - base) : -1; }
+        } else {
+#pragma unroll
+          for (int u = 0; u < kChunk / kBlock; u++) { const int k = base + (int)threadIdx.x + u * kBlock; cc[u] = k < k1 ? M.col[k] : -1; }
+        }
 #pragma unroll
         for (int u = 0; u < kChunk / kBlock; u++) { const int k = base + (int)threadIdx.x + u * kBlock; vv[u] = k < k1 ? M.val[k] : 0.0; }
         typename GatherOps<G>::Ops ops[kChunk / kBlock];
