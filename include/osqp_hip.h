@@ -201,7 +201,7 @@ OSQPInt osqp_hip_time_kernel(OSQPSolver *solver, OSQPInt which, OSQPInt reps, do
    infeasibility certificate).  rec: nbatch x 8 doubles {status_val, iter, obj_val, prim_res, dual_res, rho, rho_updates,
    pcg_iters}.  The linear system of each ADMM iteration is solved DIRECTLY (banded LDL' of the reduced KKT matrix in LDS under a
    bandwidth-reducing ordering; pcg_iters = 0, equality weight 1e3 as in the reference) when that band fits next to the iterates
-   (<= 144 KB, permuted half bandwidth <= 56), by PCG otherwise.  Returns OSQP_FUNC_NOT_IMPLEMENTED when a problem does not fit
+   (<= 144 KB, permuted half bandwidth <= 56, <= 4096 stored entries per matrix), by PCG otherwise.  Returns OSQP_FUNC_NOT_IMPLEMENTED when a problem does not fit
    one workgroup's LDS at all (10n + 8m doubles > 64 KB): callers then loop osqp_update_data_vec + osqp_solve. */
 OSQPInt osqp_hip_batch_solve(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u,
                              OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm);

@@ -106,7 +106,7 @@ namespace {
 // a pivot is broadcast with v_readlane, every other lane applies its one update -- no LDS traffic on the dependency chain
 // except the (prefetchable) column of L.
 template <int kBB, int EA, int EB, bool DIRECT>
-__global__ __launch_bounds__(kBB, (DIRECT && kBB == 256) ? 2 : 1) void k_batch_admm(BatchParams P) {
+__global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) void k_batch_admm(BatchParams P) {
 #ifdef OSQP_HIP_KTRACE
   // diagnostic build: 100 MHz clock ticks spent in the phases; reported in rec[5..7] INSTEAD of rho / rho_updates / pcg_iters
   unsigned long long tk_all = wall_clock64(), tk_fact = 0, tk_solve = 0, tk0 = 0;
@@ -557,7 +557,8 @@ BatchChoice choose_batch_variant(const BatchParams &p) {
   c.e64 = (mx + 63) / 64; c.e256 = (mx + 255) / 256;
   const bool can64 = c.lds_reg && c.e64 <= 24 && p.n <= 1024 && p.m <= 2048, can256 = c.lds_reg && c.e256 <= 8;
   c.lds_dir = batch_direct_lds_bytes(p.n, p.m, mx, p.bw);
-  const bool can_dir = can64 && c.lds_dir && p.perm, can_dir256 = can256 && c.lds_dir && p.perm;
+  // (the direct variant with four waves also comes with 16 entries per lane: up to 4096 stored entries per matrix, one problem per CU)
+  const bool can_dir = can64 && c.lds_dir && p.perm, can_dir256 = c.lds_reg && c.e256 <= 16 && c.lds_dir && p.perm;
   // default: the direct solve with four waves per problem (MPC batch: 14.2 ms; one wave 18.6 ms; PCG, one wave: 37 ms)
   c.dir256 = force ? !std::strcmp(force, "direct256") && can_dir256 : can_dir256;
   c.dir64 = !c.dir256 && (force ? !std::strcmp(force, "direct") && can_dir : can_dir);
@@ -582,7 +583,7 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
       throw DeviceError("osqp_hip: cannot reserve LDS for the direct batch kernel"); \
     hipLaunchKernelGGL((k_batch_admm<TB, E, E, true>), dim3(p.nbatch), dim3(TB), lds_dir, st, p); } while (0)
   if (use_dir256) {
-    if (e256 <= 2) BATCH_LAUNCH_DIRECT(256, 2); else if (e256 <= 4) BATCH_LAUNCH_DIRECT(256, 4); else BATCH_LAUNCH_DIRECT(256, 8);
+    if (e256 <= 2) BATCH_LAUNCH_DIRECT(256, 2); else if (e256 <= 4) BATCH_LAUNCH_DIRECT(256, 4); else if (e256 <= 8) BATCH_LAUNCH_DIRECT(256, 8); else BATCH_LAUNCH_DIRECT(256, 16);
   } else if (use_dir) {
     if (e64 <= 8) BATCH_LAUNCH_DIRECT(64, 8); else if (e64 <= 16) BATCH_LAUNCH_DIRECT(64, 16); else BATCH_LAUNCH_DIRECT(64, 24);
   } else if (use64) {

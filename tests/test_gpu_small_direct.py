@@ -105,3 +105,15 @@ def test_unconstrained_and_tiny_problems():
     m = osqp_amd.OSQP(); m.setup(sp.csc_matrix([[2.0]]), np.array([-1.0]), sp.csc_matrix([[1.0]]), np.array([1.0]), np.array([3.0]), verbose=False, eps_abs=1e-9, eps_rel=1e-9)
     r = m.solve()
     assert launches(m) == 1 and r.info.status_val == 1 and abs(r.x[0] - 1.0) < 1e-7 and abs(r.y[0] + 1.0) < 1e-6
+
+
+def test_baseline_config1_takes_the_direct_path_and_matches_the_python_reference_fixture():
+    """BASELINE configs[0] (n = 50, m = 100, dense P = M M' + 0.01 I: 3300 stored entries in B -> the 16-entries-per-lane variant):
+    one launch, same iterations as the oracle, solution within the fixture's tolerance."""
+    P, q, A, l, u = problems.random_qp()
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, **ST)
+    r = m.solve()
+    xo, yo, io = Oracle().setup(P, q, A, l, u, **ST).solve()
+    assert launches(m) == 1 and r.info.status_val == 1 and io.status_val == SOLVED and r.info.iter == io.iter
+    npt.assert_allclose(r.x, xo, rtol=0, atol=1e-7 * (1 + np.abs(xo).max()))
+    npt.assert_allclose(r.y, yo, rtol=0, atol=1e-7 * (1 + np.abs(yo).max()))
