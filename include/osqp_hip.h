@@ -180,6 +180,8 @@ typedef struct {
   double gpu_solve_ms;        /* hipEvent time around the ADMM loop                       */
   double nnzA, nnzB;          /* stored entries of A (CSR) and B = [P+sigma I | A'] (CSR) */
   double pcg_fused;           /* 1: two-kernel PCG iteration (k_k2f, k_k1f); 0: three (k_k1, k_k2, k_kv) */
+  double batch_direct_bw;     /* half bandwidth of the reduced KKT matrix under the engine's RCM ordering (batch / small-QP direct
+                                 solve); -1 before the first batch or small solve, -2 if the pattern is too dense to analyse */
 } OSQPHipStats;
 OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
 

@@ -964,7 +964,7 @@ void Engine::prepare_batch_direct() {
   // adjacency of K (excluding the diagonal)
   double pairs = 0;
   for (int i = 0; i < m; i++) { const double len = Arp_[i + 1] - Arp_[i]; pairs += len * (len + 1) / 2; }
-  if (pairs > 4e6 || n > 4096) return;                       // dense rows: K would be (nearly) dense -- PCG path
+  if (pairs > 4e6 || n > 4096) { bd_.bw_symbolic = -2; return; }   // dense rows: K would be (nearly) dense -- PCG path
   std::vector<std::vector<int>> adj(n);
   for (int j = 0; j < n; j++)
     for (int k = Brp_[j]; k < Brp_[j + 1]; k++) { const int c = Bj_[k]; if (c < n && c != j) adj[j].push_back(c); }
@@ -1014,6 +1014,7 @@ void Engine::prepare_batch_direct() {
   for (int k = 0; k < n; k++) iperm[order[k]] = k;
   int bw = 0;
   for (int j = 0; j < n; j++) for (int c : adj[j]) bw = std::max(bw, std::abs(iperm[j] - iperm[c]));
+  bd_.bw_symbolic = bw;
   const int W = bw + kBatchNB;                              // column stride of the padded band (batch_hip.hip)
   if (bw > kBatchDirectMaxBw || !be::batch_direct_lds_bytes(n, m, std::max(nzA, nzB), bw)) return;
   // band slot (column-major band: slot = col * W + (row - col), row >= col, permuted indices) of the P + sigma I entries of B
@@ -1137,6 +1138,7 @@ int Engine::solve_small_direct(double t0) {
 int Engine::batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   if (nbatch <= 0 || !x || !y || !rec) return OSQP_DATA_VALIDATION_ERROR;
+  prepare_batch_direct();                                     // (symbolic part runs on every backend: tests read the bandwidth)
   if (!be::batch_lds_bytes(n, m)) return OSQP_FUNC_NOT_IMPLEMENTED;
   be::activate(d_);
   const bool timing = std::getenv("OSQP_HIP_BATCH_TIMING") != nullptr;
@@ -1203,7 +1205,7 @@ int Engine::batch_solve_device(int nbatch, const double *q, const double *l, con
   return be::batch_solve(d_, p, stream);
 }
 
-int Engine::get_stats(OSQPHipStats *out) { if (!out) return OSQP_DATA_VALIDATION_ERROR; *out = stats_; out->pcg_fused = be::pcg_fused(d_) ? 1.0 : 0.0; return OSQP_NO_ERROR; }
+int Engine::get_stats(OSQPHipStats *out) { if (!out) return OSQP_DATA_VALIDATION_ERROR; *out = stats_; out->pcg_fused = be::pcg_fused(d_) ? 1.0 : 0.0; out->batch_direct_bw = bd_.bw_symbolic; return OSQP_NO_ERROR; }
 int Engine::time_kernel(int which, int reps, double *ms) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);

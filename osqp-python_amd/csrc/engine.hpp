@@ -88,6 +88,7 @@ class Engine {
   struct BatchDirect {
     bool tried = false, ok = false;
     int bw = -1, nents = 0, nprod = 0, ntri = 0;
+    int bw_symbolic = -1;          // bandwidth found by the ordering, also when the device path does not apply (-2: not analysed)
     int *perm = nullptr, *bp_slot = nullptr, *ke_slot = nullptr, *ke_ptr = nullptr, *kp_row = nullptr, *kp_a = nullptr, *kp_b = nullptr, *tri = nullptr;
     double *kp_val = nullptr;
   } bd_;

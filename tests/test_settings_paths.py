@@ -4,6 +4,7 @@ import warnings
 
 import numpy as np
 import numpy.testing as npt
+import scipy.sparse as sp
 import pytest
 
 import osqp_amd
@@ -81,3 +82,31 @@ def test_time_limit_and_validation(backend):
             ext.OSQPSolver(bad_P, np.zeros(2), ext.CSC(sp.eye(2, format='csc')), -np.ones(2), np.ones(2), 2, 2, s)
         with pytest.raises(ValueError, match='1'):
             ext.OSQPSolver(ext.CSC(sp.eye(3, format='csc')), np.zeros(2), ext.CSC(sp.eye(2, format='csc')), -np.ones(2), np.ones(2), 2, 2, s)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_batch_direct_symbolic_ordering(backend):
+    """Host-side symbolic work of the direct batch / small-QP solve (Engine::prepare_batch_direct): reverse Cuthill-McKee on the
+    pattern of P + sigma I + A' A.  MPC (horizon 10, nx 8, nu 4): natural bandwidth 87, ordered <= 30; a tridiagonal chain stays 1-2;
+    disconnected components are handled; the analysis runs on every backend (the device solve itself only on the GPU)."""
+    import problems
+    with engine(backend):
+        P, q, A, L, U = problems.mpc_batch(2)
+        s = osqp_amd.OSQP(); s.setup(P, q, A, L[0], U[0], verbose=False)
+        try:
+            s._solver.hip_batch_solve(l=L, u=U)
+        except ValueError:
+            assert backend == 'hostsim'                                     # no batch kernel in the simulator
+        bw = s._solver.hip_stats()['batch_direct_bw']
+        assert 12 <= bw <= 30, bw
+        n = 40                                                             # two disconnected tridiagonal chains
+        T = sp.diags([np.ones(n - 1), 2 * np.ones(n), np.ones(n - 1)], [-1, 0, 1]).tolil()
+        T[n // 2 - 1, n // 2] = 0; T[n // 2, n // 2 - 1] = 0
+        perm = np.random.default_rng(0).permutation(n)
+        Pm = sp.csc_matrix(T.tocsr()[perm][:, perm])
+        s = osqp_amd.OSQP(); s.setup(Pm, np.ones(n), sp.eye(n, format='csc'), -np.ones(n), np.ones(n), verbose=False)
+        try:
+            s._solver.hip_batch_solve(q=np.ones((2, n)))
+        except ValueError:
+            assert backend == 'hostsim'
+        assert 1 <= s._solver.hip_stats()['batch_direct_bw'] <= 2
