@@ -168,6 +168,7 @@ void infeas_primal(Dev &d);                         // d.res[R_ATDY_*] = || (Din
 void infeas_dual(Dev &d, double thr, int unscaled);               // d.res[R_PDX_*], d.res[R_ADX_VIOL]              (_osqp.py:846-872)
 void fetch_res(Dev &d, double *host_res);           // D2H of d.res + stream sync
 void fetch_flags(Dev &d, int *host_flags);          // D2H of d.flags (+ reset of the F_STAT_* counters)
+void fetch_res_flags(Dev &d, double *host_res, int *host_flags);   // both behind ONE stream synchronisation (per termination check)
 
 // ---- rho / preconditioner ----
 // rho_i by constraint type (_osqp.py:1590-1594), rho_inv, v = rho z - y, t0 = rho z~

@@ -1046,6 +1046,15 @@ void fetch_flags(Dev &d, int *h) {
   HIP_CHECK(hipStreamSynchronize(st(d)));
   std::memcpy(h, im(d).pin_flags, sizeof(int) * F_COUNT);
 }
+void fetch_res_flags(Dev &d, double *hr, int *hf) {
+  HIP_CHECK(hipSetDevice(d.device));
+  HIP_CHECK(hipMemcpyAsync(im(d).pin_res, d.res, sizeof(double) * R_COUNT, hipMemcpyDeviceToHost, st(d)));
+  HIP_CHECK(hipMemcpyAsync(im(d).pin_flags, d.flags, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, st(d)));
+  HIP_CHECK(hipMemsetAsync(d.flags + F_STAT_SUM, 0, sizeof(int) * (F_COUNT - F_STAT_SUM), st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  std::memcpy(hr, im(d).pin_res, sizeof(double) * R_COUNT);
+  std::memcpy(hf, im(d).pin_flags, sizeof(int) * F_COUNT);
+}
 
 void set_rho(Dev &d, double rho_bar) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_set_rho, d, d, rho_bar); }
 void precond(Dev &d, int diagonal) {

@@ -591,8 +591,7 @@ void Engine::admm_core(double t0, double *res) {
     run_chunk(next - iter, cg_budget_);
     iter = next;
     be::residuals(d_);
-    be::fetch_res(d_, res);
-    be::fetch_flags(d_, flags);
+    be::fetch_res_flags(d_, res, flags);
     stats_.pcg_iters_total += flags[F_STAT_SUM];
     stats_.pcg_iters_max = std::max(stats_.pcg_iters_max, (double)flags[F_STAT_MAX]);
     stats_.pcg_unconverged += flags[F_STAT_UNCONV];

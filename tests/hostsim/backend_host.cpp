@@ -178,6 +178,7 @@ void fetch_flags(Dev &d, int *h) {
   std::memcpy(h, d.flags, sizeof(int) * F_COUNT);
   d.flags[F_STAT_SUM] = d.flags[F_STAT_MAX] = d.flags[F_STAT_UNCONV] = d.flags[F_STAT_SUMSQ] = d.flags[F_STAT_N] = 0;
 }
+void fetch_res_flags(Dev &d, double *hr, int *hf) { fetch_res(d, hr); fetch_flags(d, hf); }
 
 void set_rho(Dev &d, double rb) {
   for (int i = 0; i < d.m; i++) {
