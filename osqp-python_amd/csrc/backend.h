@@ -35,6 +35,7 @@ constexpr int kChunk = 8 * kBlock;        // nnz staged through LDS per row-bloc
 constexpr int kLongRow = 128;      // rows with more nnz get a workgroup of their own (block-wide reduction)
 constexpr int kMaxRowsPerBlock = 1024;
 constexpr int kMaxCg = 1024;       // hard cap on the PCG budget (size of the alpha/gamma history)
+constexpr int kWinCap = 1472;      // input-vector window of a row block staged in LDS (elements; 23 KB as 16-byte pairs: 4 workgroups per CU)
 
 struct DevCsr {
   int nrows = 0, ncols = 0, nnz = 0, nblk = 0;
@@ -45,6 +46,15 @@ struct DevCsr {
   int *runinfo = nullptr;        // per kChunk-entry slice of a long row: first column if the slice's columns are consecutive
                                  // (dense data blocks: the kernels then skip the index loads, 4 of 12 bytes per entry), else -1
   double *val = nullptr;
+  // Windowed row blocks (banded matrices): the columns a block touches lie in at most two short ranges -- [w.x, w.x + w.y) of the
+  // columns below `split` and [split + w.z, split + w.z + w.w) of those from `split` on (B = [P | A']: split = n; A: split = ncols) --
+  // with w.y + w.w <= kWinCap.  The kernels then stage that window of the input vector(s) in LDS with coalesced loads and gather
+  // from LDS through 16-bit LOCAL indices (10 instead of 12 bytes per entry, and no dependent global gather).
+  int *blkwin = nullptr;         // nblk x {w.x, w.y, w.z, w.w}; w.y < 0: not windowed (global gather through col)
+  unsigned short *lcol = nullptr;// [nnz] position inside the block's window (first range, then second); unused for other blocks
+  int split = 0;
+  int nwin = 0;                  // number of windowed blocks (statistics)
+  int single = 0;                // 1: at most kGrid row blocks, each with at most kBlock rows (a workgroup's first pass covers all its rows)
 };
 
 // indices into Dev::res (results of the residual kernels, reduced on the device)

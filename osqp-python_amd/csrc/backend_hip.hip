@@ -52,6 +52,11 @@ __device__ unsigned long long g_ktrace[kGrid * kTraceSlots];
 #else
 #define KT(p) do { } while (0)
 #endif
+// Ablation builds (-DOSQP_HIP_KNOCK=mask, timing experiments only -- results are WRONG): which phases of the windowed k_k2f cost what
+#ifndef OSQP_HIP_KNOCK
+#define OSQP_HIP_KNOCK 0
+#endif
+#define KNOCKED(bit) ((OSQP_HIP_KNOCK & (bit)) != 0)
 enum Slot { SL_GAMMA0 = 0, SL_GAMMA1, SL_RN0, SL_RN1, SL_BN, SL_DELTA, SL_RES0 /* .. SL_RES0 + R_COUNT - 1 */ };
 static_assert(SL_RES0 + R_COUNT <= 32, "Dev::part holds 32 slots");
 
@@ -152,7 +157,11 @@ __device__ __forceinline__ void put_partial(double *part, int slot, double v) {
 //                       whatever it waits for -- a reduction of partials, a flag -- overlaps those loads); returning
 //                       false abandons the kernel for this workgroup.
 template <int NS, int NBUF = (NS == 1 ? 2 : 1)>
-struct StreamLds { static constexpr int kBuf = NBUF; double prod[NBUF][NS][kChunk]; double red[2 * kWaves]; };
+struct StreamLds { static constexpr int kBuf = NBUF; static constexpr bool kWin = false; double prod[NBUF][NS][kChunk]; double red[3 * kWaves]; };
+// Variant for kernels whose gather functor can stage a block's input-vector window in LDS (DevCsr::blkwin): single product
+// buffer + the window (T = what one column contributes: a double, or a 16-byte pair).  <= 40 KB: four workgroups per CU.
+template <int NS, class T>
+struct StreamLdsW { static constexpr int kBuf = 1; static constexpr bool kWin = true; double prod[1][NS][kChunk]; T win[kWinCap]; double red[3 * kWaves]; };
 struct NoPre { [[maybe_unused]] static constexpr int kTraceBase = 0; __device__ __forceinline__ bool operator()() const { return true; } };
 
 __device__ __forceinline__ bool wg_has_rows(const DevCsr &M) {      // same mapping as process_rows
@@ -190,12 +199,30 @@ template <class P> struct PreOps<P, true> {
   static __device__ __forceinline__ Tok begin(const P &p) { return p.begin(); }
   static __device__ __forceinline__ bool finish(const P &p, const Tok &t) { return p.finish(t); }
 };
+// LATE hooks (static constexpr bool kLate = true): nothing the hook computes is needed before the row EPILOGUE, so its loads are
+// requested after the matrix stream and   bool finish(const Tok &, const double (&acc)[NS], bool owner)   runs once, between the
+// first block's row sums and its epilogue calls (acc: this lane's row sum, owner: this lane runs the epilogue of a row).  The
+// reductions of partials then cost no time at the front of the kernel (k_k2f: 1.8 of 7.6 us, tools/ablate.py).
+template <class T, class = void> struct is_late : std::false_type {};
+template <class T> struct is_late<T, std::void_t<decltype(T::kLate)>> : std::bool_constant<T::kLate> {};
+template <class P, bool = is_late<P>::value> struct LateOps {
+  static __device__ __forceinline__ typename PreOps<P>::Tok begin(const P &) { return typename PreOps<P>::Tok(); }
+  template <int NS> static __device__ __forceinline__ bool finish(const P &, const typename PreOps<P>::Tok &, const double (&)[NS], bool) { return true; }
+};
+template <class P> struct LateOps<P, true> {
+  static __device__ __forceinline__ typename P::Tok begin(const P &p) { return p.begin(); }
+  template <int NS> static __device__ __forceinline__ bool finish(const P &p, const typename P::Tok &t, const double (&acc)[NS], bool owner) { return p.finish(t, acc, owner); }
+};
 //   done:           optional device flag; when set the workgroup abandons the kernel.  It is read TOGETHER with the first
 //                   block descriptor (one wait for both scalar loads) instead of ahead of it.
-template <int NS, bool HAS_DONE, class G, class E, class Pre>
-__device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds, Pre pre, const int *done) {
+//   Windowed blocks (L::kWin, DevCsr::blkwin):  G additionally provides
+//                    using Win;  Win stage(int seg, int c) const;      element c of the input vector(s) of column segment seg
+//                    void wprod(const Win &, double val, double (&prod)[NS]) const;
+template <int NS, bool HAS_DONE, class G, class E, class Pre, class L>
+__device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E &e, L &lds, Pre pre, const int *done) {
   int buf = 0;
   const int4 *desc = reinterpret_cast<const int4 *>(M.blkdesc);
+  [[maybe_unused]] const int4 *wdesc = reinterpret_cast<const int4 *>(M.blkwin);
   // XCD-contiguous mapping (speed only; correctness never depends on placement): workgroup id b is observed to run on
   // XCD b % 8, so XCD x is given the contiguous row-block range [x*per, (x+1)*per).  Neighbouring row blocks gather
   // overlapping windows of the input vector; on one XCD they share those lines in one L2 instead of every XCD's L2
@@ -208,22 +235,28 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
   const bool has0 = slot0 < per && b0 < M.nblk;
   int dn = 0;
   if (HAS_DONE) dn = *done;
-  int4 ds = make_int4(0, 0, 0, 0);
-  if (has0) ds = desc[b0];
+  int4 ds = make_int4(0, 0, 0, 0), ws = make_int4(0, -1, 0, 0);
+  if (has0) { ds = desc[b0]; if constexpr (L::kWin) ws = wdesc[b0]; }
   KT(Pre::kTraceBase + 1);      // flag + first descriptor arrived
   if (dn) return false;
-  if (!has0) return PreOps<Pre>::finish(pre, PreOps<Pre>::begin(pre));   // a workgroup without rows still runs the hook (e.g. workgroup 0 owns the PCG flags)
+  constexpr bool LATE = is_late<Pre>::value;
+  if (!has0) {      // a workgroup without rows still runs the hook (e.g. workgroup 0 owns the PCG flags)
+    if constexpr (LATE) { const double zero[NS] = {}; return LateOps<Pre>::template finish<NS>(pre, LateOps<Pre>::begin(pre), zero, false); }
+    else return PreOps<Pre>::finish(pre, PreOps<Pre>::begin(pre));
+  }
   // One row block.  The first one (compile-time tag) also runs the hook; it is a separate instantiation so that no
   // control-flow join sits between the hook's loads and the matrix loads (a join makes the compiler drain the counter).
-  auto block = [&](auto first_tag, const int4 ds) -> bool {
+  auto block = [&](auto first_tag, const int4 ds, [[maybe_unused]] const int4 ws) -> bool {
     constexpr bool FIRST = decltype(first_tag)::value;
     const int r0 = ds.x, k0 = ds.z, k1 = ds.w;
     const int r1 = ds.y < 0 ? r0 + 1 : ds.y;                    // (ds.y < 0: a long row, -(1 + index of its run table))
     const int cnt = k1 - k0;
     if (ds.y < 0) {                                             // one long row: whole workgroup reduces it
       const int *runs = M.runinfo - (1 + ds.y);
-      if constexpr (FIRST) { if (!PreOps<Pre>::finish(pre, PreOps<Pre>::begin(pre))) return false; }
+      typename PreOps<Pre>::Tok ltok = typename PreOps<Pre>::Tok();
+      if constexpr (FIRST && !LATE) { if (!PreOps<Pre>::finish(pre, PreOps<Pre>::begin(pre))) return false; }
       if (threadIdx.x == 0) e.prefetch(r0);                     // epilogue operands requested before the stream, not after it
+      if constexpr (FIRST && LATE) ltok = LateOps<Pre>::begin(pre);
       double acc[NS];
 #pragma unroll
       for (int s = 0; s < NS; s++) acc[s] = 0.0;
@@ -258,12 +291,56 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
       }
 #pragma unroll
       for (int s = 0; s < NS; s++) acc[s] = block_sum(acc[s], lds.red);
+      if constexpr (FIRST && LATE) { if (!LateOps<Pre>::template finish<NS>(pre, ltok, acc, threadIdx.x == 0)) return false; }
       if (threadIdx.x == 0) e(r0, acc);
       return true;
     }
     // many short rows: stage products in LDS
     typename PreOps<Pre>::Tok tok = typename PreOps<Pre>::Tok();
-    if constexpr (FIRST) tok = PreOps<Pre>::begin(pre);          // the hook's loads go out first: they are needed first
+    if constexpr (FIRST && !LATE) tok = PreOps<Pre>::begin(pre);   // the hook's loads go out first: they are needed first
+    const int lpr = 2 * (r1 - r0) <= kBlock ? 2 : 1;
+    const int sub = lpr == 2 ? (int)(threadIdx.x & 1) : 0;
+    const int myr = r0 + (lpr == 2 ? (int)(threadIdx.x >> 1) : (int)threadIdx.x);   // the row this lane reduces in the first pass
+    int rp0 = 0, rp1 = 0;                                        // raw row pointers: not touched before the barrier
+    bool staged = false;
+    if constexpr (L::kWin) {
+      if (ws.y >= 0) {
+        // Windowed block: the window of the input vector(s) is fetched with coalesced loads (requested FIRST: it is needed
+        // first), written to LDS, and the per-entry gathers are LDS reads through 16-bit local indices.
+        using T = typename G::Win;
+        constexpr int CW = (kWinCap + kBlock - 1) / kBlock;
+        const int wl = ws.y + ws.w;
+        T we[CW];
+#pragma unroll
+        for (int u = 0; u < CW; u++) {
+          const int p = threadIdx.x + u * kBlock;
+          if (p < wl && !KNOCKED(2)) we[u] = p < ws.y ? g.stage(0, ws.x + p) : g.stage(1, ws.z + (p - ws.y));
+        }
+        int lc[kChunk / kBlock];
+        double vw[kChunk / kBlock];
+#pragma unroll
+        for (int u = 0; u < kChunk / kBlock; u++) { const int k = threadIdx.x + u * kBlock; lc[u] = k < cnt ? (KNOCKED(8) ? (k & 511) : (int)M.lcol[k0 + k]) : -1; }
+#pragma unroll
+        for (int u = 0; u < kChunk / kBlock; u++) { const int k = threadIdx.x + u * kBlock; vw[u] = (k < cnt && !KNOCKED(4)) ? M.val[k0 + k] : 1.0; }
+        if (myr < r1) { if (KNOCKED(128)) { rp0 = k0 + 12 * (myr - r0); rp1 = rp0 + 12; } else { rp0 = M.rowptr[myr]; rp1 = M.rowptr[myr + 1]; if (sub == 0) e.prefetch(myr); } }
+        if constexpr (FIRST && LATE) tok = LateOps<Pre>::begin(pre);            // a late hook's loads go out last
+        KT(Pre::kTraceBase + 2);
+#pragma unroll
+        for (int u = 0; u < CW; u++) { const int p = threadIdx.x + u * kBlock; if (p < wl && !KNOCKED(2)) lds.win[p] = we[u]; }
+        if constexpr (FIRST && !LATE) { if (!PreOps<Pre>::finish(pre, tok)) return false; KT(Pre::kTraceBase + 3); }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kChunk / kBlock; u++) {
+          if (lc[u] < 0) continue;
+          double pr[NS];
+          if (KNOCKED(2)) pr[0] = vw[u]; else g.wprod(lds.win[lc[u]], vw[u], pr);
+#pragma unroll
+          for (int s = 0; s < NS; s++) lds.prod[buf][s][threadIdx.x + u * kBlock] = pr[s];
+        }
+        staged = true;
+      }
+    }
+    if (!staged) {
     int cc[kChunk / kBlock];
     double vv[kChunk / kBlock];
     // (masked, not clamped: a lane past the block's last entry issues nothing.  Re-reading the last entry instead makes the
@@ -275,16 +352,13 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
     // Row sums: one lane per row, or -- when the block has at most kBlock/2 rows -- TWO lanes per row (even/odd entries,
     // combined with one shuffle): halves the serial chain of LDS reads of the row-sum phase for matrices with ~100 rows of
     // ~14 entries per block (B at config 2: k_k2f 7.9 -> 7.5 us back to back).
-    const int lpr = 2 * (r1 - r0) <= kBlock ? 2 : 1;
-    const int sub = lpr == 2 ? (int)(threadIdx.x & 1) : 0;
-    const int myr = r0 + (lpr == 2 ? (int)(threadIdx.x >> 1) : (int)threadIdx.x);   // the row this lane reduces in the first pass
-    int rp0 = 0, rp1 = 0;                                        // raw row pointers: not touched before the barrier
     if (myr < r1) { rp0 = M.rowptr[myr]; rp1 = M.rowptr[myr + 1]; if (sub == 0) e.prefetch(myr); }
     KT(Pre::kTraceBase + 2);
     typename GatherOps<G>::Ops ops[kChunk / kBlock];
 #pragma unroll
     for (int u = 0; u < kChunk / kBlock; u++) if (cc[u] >= 0) ops[u] = GatherOps<G>::fetch(g, cc[u]);   // gathers requested as the indices arrive
-    if constexpr (FIRST) { if (!PreOps<Pre>::finish(pre, tok)) return false; KT(Pre::kTraceBase + 3); }
+    if constexpr (FIRST && LATE) tok = LateOps<Pre>::begin(pre);
+    if constexpr (FIRST && !LATE) { if (!PreOps<Pre>::finish(pre, tok)) return false; KT(Pre::kTraceBase + 3); }
 #pragma unroll
     for (int u = 0; u < kChunk / kBlock; u++) {
       if (cc[u] < 0) continue;
@@ -293,32 +367,34 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
 #pragma unroll
       for (int s = 0; s < NS; s++) lds.prod[buf][s][threadIdx.x + u * kBlock] = pr[s];
     }
+    }  // !staged
     __syncthreads();
     KT(Pre::kTraceBase + 4);    // products staged
-    if (lpr == 2) {
+    {
       double acc[NS];
 #pragma unroll
       for (int s = 0; s < NS; s++) acc[s] = 0.0;
-      if (myr < r1) {
+      const bool owner = myr < r1 && sub == 0;
+      if (KNOCKED(16)) { if (owner) for (int s = 0; s < NS; s++) acc[s] = lds.prod[buf][s][threadIdx.x]; }
+      else if (lpr == 2) {
+        if (myr < r1) {
+          const int ra = rp0 - k0, rz = rp1 - k0;
+          for (int k = ra + sub; k < rz; k += 2) {
+#pragma unroll
+            for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; s++) acc[s] += __shfl_xor(acc[s], 1, 64);      // (whole waves take this path: lpr is block-uniform)
+      } else if (myr < r1) {
         const int ra = rp0 - k0, rz = rp1 - k0;
-        for (int k = ra + sub; k < rz; k += 2) {
+        for (int k = ra; k < rz; k++) {
 #pragma unroll
           for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
         }
       }
-#pragma unroll
-      for (int s = 0; s < NS; s++) acc[s] += __shfl_xor(acc[s], 1, 64);      // (whole waves take this path: lpr is block-uniform)
-      if (myr < r1 && sub == 0) e(myr, acc);
-    } else if (myr < r1) {
-      const int ra = rp0 - k0, rz = rp1 - k0;
-      double acc[NS];
-#pragma unroll
-      for (int s = 0; s < NS; s++) acc[s] = 0.0;
-      for (int k = ra; k < rz; k++) {
-#pragma unroll
-        for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
-      }
-      e(myr, acc);
+      if constexpr (FIRST && LATE) { if (!LateOps<Pre>::template finish<NS>(pre, tok, acc, owner)) return false; KT(Pre::kTraceBase + 3); }
+      if (owner) e(myr, acc);
     }
     for (int r = myr + kBlock; lpr == 1 && r < r1; r += kBlock) {   // blocks with more than kBlock (mostly empty) rows
       const int a = M.rowptr[r] - k0, z = M.rowptr[r + 1] - k0;
@@ -332,24 +408,26 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
       e.prefetch(r); e(r, acc);
     }
     KT(Pre::kTraceBase + 5);    // row sums + epilogue done
-    if (StreamLds<NS>::kBuf == 2) buf ^= 1;   // the next row block fills the other buffer: one barrier per block suffices
-    else __syncthreads();                      // single buffer (two-sum kernels): protect it before the next fill
+    if (L::kBuf == 2) buf ^= 1;               // the next row block fills the other buffer: one barrier per block suffices
+    else __syncthreads();                      // single buffer (two-sum and windowed kernels): protect it before the next fill
     return true;
   };
-  if (!block(std::true_type(), ds)) return false;
+  if (!block(std::true_type(), ds, ws)) return false;
   for (int sl = slot0 + slots; sl < per; sl += slots) {
     const int b = xcd * per + sl;
     if (b >= M.nblk) break;
-    block(std::false_type(), desc[b]);
+    int4 wn = make_int4(0, -1, 0, 0);
+    if constexpr (L::kWin) wn = wdesc[b];
+    block(std::false_type(), desc[b], wn);
   }
   return true;
 }
-template <int NS, class G, class E, class Pre>
-__device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds, Pre pre) { return process_rows_impl<NS, false>(M, g, e, lds, pre, nullptr); }
-template <int NS, class G, class E, class Pre>
-__device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds, Pre pre, const int *done) { return process_rows_impl<NS, true>(M, g, e, lds, pre, done); }
-template <int NS, class G, class E>
-__device__ __forceinline__ void process_rows(const DevCsr &M, const G &g, E &e, StreamLds<NS> &lds) { process_rows_impl<NS, false>(M, g, e, lds, NoPre(), nullptr); }
+template <int NS, class G, class E, class Pre, class L>
+__device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, L &lds, Pre pre) { return process_rows_impl<NS, false>(M, g, e, lds, pre, nullptr); }
+template <int NS, class G, class E, class Pre, class L>
+__device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, L &lds, Pre pre, const int *done) { return process_rows_impl<NS, true>(M, g, e, lds, pre, done); }
+template <int NS, class G, class E, class L>
+__device__ __forceinline__ void process_rows(const DevCsr &M, const G &g, E &e, L &lds) { process_rows_impl<NS, false>(M, g, e, lds, NoPre(), nullptr); }
 struct NoPrefetch { __device__ __forceinline__ void prefetch(int) {} };
 
 // ---------------------------------------------------------------------------------------------- hot-path kernels
@@ -528,29 +606,49 @@ struct GSplitU {
   __device__ __forceinline__ Ops fetch(int c) const { return c < n ? pn[c] : pm[c - n]; }
   __device__ __forceinline__ void prod(const Ops &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
   __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * fetch(c); }
+  using Win = double;
+  __device__ __forceinline__ Win stage(int seg, int c) const { return seg ? pm[c] : pn[c]; }
+  __device__ __forceinline__ void wprod(const Win &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
 };
 struct EK2F {
   const double *u, *Minv; double *s, *ms; double beta = 0; int first = 0; double dl = 0, pu = 0, pm = 0, ps = 0;
   __device__ __forceinline__ void prefetch(int j) { pu = u[j]; pm = Minv[j]; ps = s[j]; }
   __device__ __forceinline__ void operator()(int j, const double (&sm)[1]) {
     const double w = sm[0], sn = first ? w : w + beta * ps;
-    dl += w * pu; s[j] = sn;
-    reinterpret_cast<double2 *>(ms)[j] = make_double2(pu, pm * sn);      // the pair k_k1f gathers with one 16-byte load
+    dl += w * pu;
+    if (KNOCKED(32)) { if (sn == -1.2345e300) s[j] = sn; return; }
+    s[j] = sn;
+    ms[j] = pm * sn;                                                       // Minv .* s_k: the vector k_k1f applies A to
   }
 };
+// block reduction of three quantities (sum, max, sum) behind ONE barrier pair; sred needs 3 * kWaves doubles
+__device__ __forceinline__ void block_sum_max_sum(double &a, double &b, double &c, double *sred) {
+  a = wave_sum(a); b = wave_max(b); c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; sred[2 * kWaves + (threadIdx.x >> 6)] = c; }
+  __syncthreads();
+  a = sred_sum(sred); b = sred_max(sred + kWaves); c = sred_sum(sred + 2 * kWaves);
+  __syncthreads();
+}
+// LATE hook of k_k2f (runs between the row sums and the epilogue): folds gamma_k and ||r_k||_inf together with this
+// workgroup's share of delta_k = <w, u_k> (one barrier pair for all three), stopping test, beta_k.
 struct PreK2F {
   [[maybe_unused]] static constexpr int kTraceBase = 0;
-  const Dev &d; int k; EK2F *e; double *red;
+  static constexpr bool kLate = true;
+  const Dev &d; int k; EK2F *e; double *red; double *dl_first;
   struct Tok { PartRegs prn, pg; double tol, glast; };
   __device__ __forceinline__ Tok begin() const {
     Tok t;
+    if (KNOCKED(1)) { t.tol = 0; t.glast = 1; return t; }
     t.prn = partial_load(d.part + (SL_RN0 + (k & 1)) * kGrid); t.pg = partial_load(d.part + (SL_GAMMA0 + (k & 1)) * kGrid);
     t.tol = d.scal[S_TOL_NOW]; t.glast = k == 0 ? 1.0 : d.scal[S_HIST + k - 1];
     return t;
   }
-  __device__ __forceinline__ bool finish(const Tok &t) const {
+  __device__ __forceinline__ bool finish(const Tok &t, const double (&acc)[1], bool owner) const {
+    if (KNOCKED(1)) { e->beta = 0.5; e->first = 0; *dl_first = 0; return true; }
     double gamma = partial_fold_sum(t.pg), rn = partial_fold_max(t.prn);
-    block_sum_max(gamma, rn, red);
+    const double dl0 = owner ? acc[0] * e->pu : 0.0;
+    double dls = dl0;
+    block_sum_max_sum(gamma, rn, dls, red);
     double *gam = d.scal + S_HIST, *bet = d.scal + S_HIST + 2 * (kMaxCg + 1);
     if (k > 0 && !(rn > t.tol)) {        // converged after k iterations (k == 0 was tested by k_k1)
       if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = k; }
@@ -559,33 +657,47 @@ struct PreK2F {
     const double beta = k == 0 ? 0.0 : gamma / t.glast;
     if (blockIdx.x == 0 && threadIdx.x == 0) { gam[k] = gamma; bet[k] = beta; }
     e->beta = beta; e->first = (k == 0);
+    e->dl = -dl0;                        // the epilogue adds this row's term again: e->dl then holds only LATER rows' terms
+    *dl_first = dls;
     return true;
   }
 };
 __global__ __launch_bounds__(kBlock) void k_k2f(Dev d, int k) {
-  __shared__ StreamLds<1> lds;
+  __shared__ StreamLdsW<1, double> lds;
   KT(0);
   const double *u = (k & 1) ? d.uu2 : d.uu;
   GSplitU g{u, d.t, d.n};
   EK2F e{u, d.Minv, d.s, d.ms};
-  if (!process_rows<1>(d.B, g, e, lds, PreK2F{d, k, &e, lds.red}, d.flags + F_DONE)) return;
-  __syncthreads();
-  const double DL = block_sum(e.dl, lds.red);
+  double dl_first = 0.0;
+  if (!process_rows<1>(d.B, g, e, lds, PreK2F{d, k, &e, lds.red, &dl_first}, d.flags + F_DONE)) return;
+  if (KNOCKED(64)) { if (e.dl == -1.2345e300) put_partial(d.part, SL_DELTA, e.dl); return; }
+  double DL = dl_first;
+  if (!d.B.single) { __syncthreads(); DL += block_sum(e.dl, lds.red); }    // rows beyond the first pass of the first block
   put_partial(d.part, SL_DELTA, DL);
   KT(6);
 }
-struct GTwoGather {
-  const double *ms; double alpha;       // ms: interleaved pairs {u_k[j], (Minv .* s_k)[j]} written by k_k2f
-  struct Ops { double u, ms; };
-  __device__ __forceinline__ Ops fetch(int c) const { const double2 v = reinterpret_cast<const double2 *>(ms)[c]; return Ops{v.x, v.y}; }
-  __device__ __forceinline__ void prod(const Ops &o, double a, double (&pr)[1]) const { pr[0] = a * (o.u - alpha * o.ms); }   // alpha: set by the hook
-  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { prod(fetch(c), a, pr); }
+// K1F_{k+1}: S = A (Minv .* s_k) needs no scalar; alpha_k (from the delta partials) enters only the row epilogue
+//   t_{k+1} = t_k - alpha_k rho .* S      ( = rho .* A u_{k+1},  u_{k+1} = u_k - alpha_k Minv .* s_k )
+// and this workgroup's slice of the vector update, so the reduction of partials runs LATE, behind the matrix stream.
+struct GMs {
+  const double *ms;
+  using Ops = double;
+  __device__ __forceinline__ Ops fetch(int c) const { return ms[c]; }
+  __device__ __forceinline__ void prod(const Ops &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
+  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * ms[c]; }
+  using Win = double;
+  __device__ __forceinline__ Win stage(int, int c) const { return ms[c]; }
+  __device__ __forceinline__ void wprod(const Win &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
 };
-// Hook of k_k1f, run after the first row block's matrix loads are in flight: alpha from the delta partials, then this
-// workgroup's slice of the vector update of iteration k.
+struct EK1F {
+  const double *rho; double *t; double alpha = 0, pr = 0, pt = 0;
+  __device__ __forceinline__ void prefetch(int i) { pr = rho[i]; pt = t[i]; }
+  __device__ __forceinline__ void operator()(int i, const double (&s)[1]) { t[i] = pt - alpha * pr * s[0]; }
+};
 struct PreK1F {
   [[maybe_unused]] static constexpr int kTraceBase = 8;
-  const Dev &d; int k; bool has_vec; GTwoGather *gr; double *red; double *g, *rn;
+  static constexpr bool kLate = true;
+  const Dev &d; int k; bool has_vec; EK1F *e; double *red; double *g, *rn;
   struct Tok { PartRegs pd; double gamma, beta, alast; double u0, p0, r0, s0, m0, x0; };
   __device__ __forceinline__ int first_index() const {
     const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3;
@@ -602,7 +714,7 @@ struct PreK1F {
     if (has_vec && j0 < d.n) { t.u0 = uin[j0]; t.p0 = k == 0 ? 0.0 : d.p[j0]; t.r0 = d.r[j0]; t.s0 = d.s[j0]; t.m0 = d.Minv[j0]; t.x0 = d.xs[j0]; }
     return t;
   }
-  __device__ __forceinline__ bool finish(const Tok &t) const {
+  __device__ __forceinline__ bool finish(const Tok &t, const double (&)[1], bool) const {
     const double *uin = (k & 1) ? d.uu2 : d.uu;
     double *uout = (k & 1) ? d.uu : d.uu2;
     double *alp = d.scal + S_HIST + kMaxCg + 1;
@@ -616,7 +728,7 @@ struct PreK1F {
     const double delta = block_sum(partial_fold_sum(pd), red);
     const double alpha = k == 0 ? gamma / delta : gamma / (delta - beta * gamma / alast);
     if (blockIdx.x == 0 && threadIdx.x == 0) alp[k] = alpha;
-    gr->alpha = alpha;
+    e->alpha = alpha;
     double gg = 0, rr = 0;
     if (live0) {
       const double pp_ = k == 0 ? u0 : u0 + beta * p0;
@@ -642,7 +754,7 @@ struct PreK1F {
   }
 };
 __global__ __launch_bounds__(kBlock) void k_k1f(Dev d, int i) {          // i >= 1; performs the vector update of k = i - 1
-  __shared__ StreamLds<1> lds;
+  __shared__ StreamLdsW<1, double> lds;
   KT(8);
   const int k = i - 1;
   const bool has_rows = wg_has_rows(d.A);
@@ -654,9 +766,9 @@ __global__ __launch_bounds__(kBlock) void k_k1f(Dev d, int i) {          // i >=
     return;
   }
   double g = 0, rn = 0;
-  GTwoGather gr{d.ms, 0.0};
-  EK1 e{d.rho, d.t};
-  if (!process_rows<1>(d.A, gr, e, lds, PreK1F{d, k, has_vec, &gr, lds.red, &g, &rn}, d.flags + F_DONE)) return;
+  GMs gr{d.ms};
+  EK1F e{d.rho, d.t};
+  if (!process_rows<1>(d.A, gr, e, lds, PreK1F{d, k, has_vec, &e, lds.red, &g, &rn}, d.flags + F_DONE)) return;
   __syncthreads();
   block_sum_max(g, rn, lds.red);
   put_partial(d.part, SL_GAMMA0 + (i & 1), g); put_partial(d.part, SL_RN0 + (i & 1), rn);

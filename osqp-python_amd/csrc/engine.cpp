@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -81,7 +82,7 @@ void Engine::free_all() {
   drop_graphs();
   if (bbuf_) { be::dfree(d_, bbuf_); bbuf_ = nullptr; bbuf_cap_ = 0; }
   free_batch_direct();
-  void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag, d_.A.runinfo, d_.B.runinfo,
+  void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag, d_.A.runinfo, d_.B.runinfo, d_.A.blkwin, d_.B.blkwin, d_.A.lcol, d_.B.lcol,
                   d_.q, d_.l, d_.u, d_.D, d_.Dinv, d_.E, d_.Einv, d_.rho, d_.rho_inv, d_.ctype, d_.x, d_.z, d_.y, d_.dx,
                   d_.dy, d_.xs, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.uu2, d_.ms, d_.part, d_.res,
                   d_.scal, d_.flags, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB};
@@ -363,12 +364,52 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
     return d;
   };
 
+  // column windows of the (short-row) blocks, see DevCsr::blkwin.  OSQP_HIP_WINDOW=0 turns the windowed path off (A/B runs).
+  static const bool win_on = [] { const char *e = std::getenv("OSQP_HIP_WINDOW"); return !(e && e[0] == '0'); }();
+  auto windows = [](const std::vector<int> &rb, const std::vector<int> &rp, const std::vector<int> &cj, int split,
+                    std::vector<int> &win, std::vector<unsigned short> &lcol) {
+    const size_t nb = rb.size() - 1;
+    win.assign(4 * nb, 0); lcol.assign(std::max<size_t>(cj.size(), 1), 0);
+    int nwin = 0;
+    for (size_t b = 0; b < nb; b++) {
+      const int r0 = rb[b], r1 = rb[b + 1], k0 = rp[r0], k1 = rp[r1];
+      win[4 * b + 1] = -1;
+      if (!win_on || (r1 - r0 == 1 && k1 - k0 > kLongRow) || k1 == k0) continue;
+      int lo0 = INT32_MAX, hi0 = -1, lo1 = INT32_MAX, hi1 = -1;
+      for (int k = k0; k < k1; k++) {
+        const int c = cj[k];
+        if (c < split) { lo0 = std::min(lo0, c); hi0 = std::max(hi0, c); } else { lo1 = std::min(lo1, c - split); hi1 = std::max(hi1, c - split); }
+      }
+      const long len0 = hi0 >= 0 ? (long)hi0 - lo0 + 1 : 0, len1 = hi1 >= 0 ? (long)hi1 - lo1 + 1 : 0;
+      if (len0 + len1 > kWinCap) continue;
+      if (len0 == 0) lo0 = 0;
+      if (len1 == 0) lo1 = 0;
+      win[4 * b] = lo0; win[4 * b + 1] = (int)len0; win[4 * b + 2] = lo1; win[4 * b + 3] = (int)len1;
+      for (int k = k0; k < k1; k++) {
+        const int c = cj[k];
+        lcol[k] = (unsigned short)(c < split ? c - lo0 : len0 + (c - split - lo1));
+      }
+      nwin++;
+    }
+    return nwin;
+  };
   auto up_i = [&](const std::vector<int> &h) { int *p = dev_vec<int>(d_, h.size()); be::h2d(d_, p, h.data(), sizeof(int) * h.size()); return p; };
+  auto up_win = [&](DevCsr &M, const std::vector<int> &rb, const std::vector<int> &rp, const std::vector<int> &cj, int split) {
+    std::vector<int> win; std::vector<unsigned short> lcol;
+    M.split = split;
+    M.single = (int)rb.size() - 1 <= kGrid;
+    for (size_t b = 0; b + 1 < rb.size(); b++) if (rb[b + 1] - rb[b] > kBlock) M.single = 0;
+    M.nwin = windows(rb, rp, cj, split, win, lcol);
+    M.blkwin = up_i(win);
+    M.lcol = dev_vec<unsigned short>(d_, lcol.size());
+    be::h2d(d_, M.lcol, lcol.data(), sizeof(unsigned short) * lcol.size());
+  };
   d_.A.nrows = m; d_.A.ncols = n; d_.A.nnz = nzA; d_.A.nblk = (int)rbA.size() - 1;
   d_.A.rowptr = up_i(Arp); d_.A.col = up_i(Arj); { std::vector<int> runs; d_.A.blkdesc = up_i(descs(rbA, Arp, Arj, runs)); d_.A.runinfo = up_i(runs); } d_.A.val = dev_vec<double>(d_, nzA);
   d_.B.nrows = n; d_.B.ncols = n + m; d_.B.nnz = nzB; d_.B.nblk = (int)rbB.size() - 1;
   d_.B.rowptr = up_i(Brp); d_.B.col = up_i(Bj); { std::vector<int> runs; d_.B.blkdesc = up_i(descs(rbB, Brp, Bj, runs)); d_.B.runinfo = up_i(runs); } d_.B.val = dev_vec<double>(d_, nzB);
   d_.Bdiag = up_i(bdiag);
+  up_win(d_.A, rbA, Arp, Arj, n); up_win(d_.B, rbB, Brp, Bj, n);
   lap("upload structure");
   auto dv = [&](size_t cnt) { return dev_vec<double>(d_, cnt); };
   d_.q = dv(n); d_.l = dv(m); d_.u = dv(m); d_.D = dv(n); d_.Dinv = dv(n); d_.E = dv(m); d_.Einv = dv(m);
@@ -561,24 +602,49 @@ int Engine::solve() {
 void Engine::admm_core(double t0, double *res) {
   const int ct = settings.check_termination;
   const int ari = settings.adaptive_rho ? auto_rho_interval() : 0;
+  const int cap = std::min(settings.cg_max_iter, kMaxCg);
+  // Inexact inner solves bias the rho estimate (_osqp.py:880-908): their error shows up in the PRIMAL residual (measured at
+  // config 2: 7.5x the primal residual of exact solves at an unchanged dual residual, estimate 0.6 rho instead of 0.2 rho), so
+  // the last `tightW` iterations before every adaptation point run with a `tightF` times smaller PCG tolerance -- the bias
+  // flushes within ~10 iterations (DESIGN.md "Adaptive rho on the indirect path").
+  static const int tightW_env = [] { const char *e = std::getenv("OSQP_HIP_RHO_WINDOW"); return e ? std::atoi(e) : 10; }();
+  static const double tightF = [] { const char *e = std::getenv("OSQP_HIP_RHO_WINDOW_TOL"); return e ? std::atof(e) : 0.1; }();
+  static const bool persist = [] { const char *e = std::getenv("OSQP_HIP_RHO_PERSIST"); return !(e && e[0] == '0'); }();
+  const int tightW = (ari > 1 && tightW_env > 0) ? std::min(tightW_env, ari - 1) : 0;
   // PCG tolerance for the first chunk: relative, ||rhs||/cg_tol_reduction (then tied to the ADMM residuals).
   // Tolerance and budget restart with every solve so that a solve is a deterministic function of (data, iterates).
-  have_tol_ = false; cg_budget_ = 0;
+  have_tol_ = false;
+  double tol_rel = 1e-14, tol_abs = kCgTolAbsMin;
   {
     // residuals of the starting point (zeros on a cold start, the caller's iterate on a warm start): a warm start near
     // the optimum must not be perturbed by a loose first-chunk solve (warm_start_test.py:52-57 expects < 10 iterations)
     double r0[R_COUNT];
     be::residuals(d_); be::fetch_res(d_, r0);
     const double eps0 = settings.cg_tol_fraction * r0[R_DUA_S];
-    if (std::isfinite(eps0) && eps0 > kCgTolAbsMin) be::set_pcg_tol(d_, 1e-14, eps0);     // absolute, like every later chunk
-    else be::set_pcg_tol(d_, 1.0 / settings.cg_tol_reduction, kCgTolAbsMin);             // dual-feasible start (e.g. q = 0): relative
+    if (std::isfinite(eps0) && eps0 > kCgTolAbsMin) tol_abs = eps0;                        // absolute, like every later chunk
+    else { tol_rel = 1.0 / settings.cg_tol_reduction; tol_abs = kCgTolAbsMin; }           // dual-feasible start (e.g. q = 0): relative
     eps_cg_prev_ = std::numeric_limits<double>::infinity();
   }
   // start with the full budget: a starved PCG in the first chunks costs far more ADMM iterations than the no-op
   // launches it saves (measured: 1150 -> 825 ADMM iterations on the banded n=20000 QP); it shrinks after the first check
-  if (cg_budget_ <= 0) cg_budget_ = settings.cg_max_iter;
-  cg_budget_ = std::min(cg_budget_, std::min(settings.cg_max_iter, kMaxCg));
+  int budget[2] = {cap, cap};                       // [0] ordinary iterations, [1] the tight window before an adaptation point
+  bool tight_seen = false;
+  int last_side = 0;                                // side of rho the estimate fell on at the previous adaptation point
   if (settings.verbose) std::printf("iter   objective    prim res   dual res   rho        cg   time\n");
+
+  auto next_budget = [&](int cur, const int *flags) {
+    static const double tolerate = [] { const char *e = std::getenv("OSQP_HIP_BUDGET_TOLERATE"); return e ? std::atof(e) : 0.0; }();
+    if (flags[F_STAT_UNCONV] * 4 > std::max(1, flags[F_STAT_N]) && flags[F_STAT_UNCONV] > tolerate * flags[F_STAT_N]) return std::min(cap, std::max(cur + 2, 2 * cur));
+    if (flags[F_STAT_UNCONV] > tolerate * flags[F_STAT_N]) return std::min(cap, cur + 1);
+    // mean + 3 sigma of the PCG counts of the last chunk (+1), never above its max + 1: rare spikes should not
+    // set the budget of the next 25 iterations (an occasional budget-limited solve is just a slightly less exact one)
+    const double cnt = std::max(1, flags[F_STAT_N]), mean = flags[F_STAT_SUM] / cnt;
+    const double var = std::max(0.0, flags[F_STAT_SUMSQ] / cnt - mean * mean);
+    static const double nsig = [] { const char *e = std::getenv("OSQP_HIP_BUDGET_SIGMA"); return e ? std::atof(e) : 3.0; }();
+    const int q3 = (int)std::ceil(mean + nsig * std::sqrt(var));     // (KA checks the residual after the last budgeted iteration)
+    static const int slack = [] { const char *e = std::getenv("OSQP_HIP_BUDGET_SLACK"); return e ? std::atoi(e) : 0; }();
+    return std::min(cap, std::max(2, std::min(flags[F_STAT_MAX], q3)) + slack);
+  };
 
   int iter = 0;
   int flags[F_COUNT];
@@ -586,10 +652,28 @@ void Engine::admm_core(double t0, double *res) {
     int next = settings.max_iter;
     if (ct > 0) next = std::min(next, (iter / ct + 1) * ct);
     if (ari > 0) next = std::min(next, (iter / ari + 1) * ari);
+    bool tight = false;
+    if (tightW > 0) {
+      const int ts = (iter / ari + 1) * ari - tightW;       // start of the tight window before the next adaptation point
+      if (iter >= ts) tight = true;
+      else if (ts < next) next = ts;
+    }
     static const bool full_budget = std::getenv("OSQP_HIP_BUDGET_FULL") != nullptr;      // debugging: never starve the PCG
-    if (full_budget) cg_budget_ = std::min(settings.cg_max_iter, kMaxCg);
-    run_chunk(next - iter, cg_budget_);
+    if (full_budget) budget[0] = budget[1] = cap;
+    if (tight && !tight_seen) { budget[1] = std::min(cap, 3 * budget[0] + 2); tight_seen = true; }
+    be::set_pcg_tol(d_, tol_rel, tight ? std::max(tightF * tol_abs, kCgTolAbsMin) : tol_abs);
+    run_chunk(next - iter, budget[tight]);
+    cg_budget_ = budget[tight];
     iter = next;
+    const bool at_check = (ct > 0 && iter % ct == 0) || iter >= settings.max_iter || (ari > 0 && iter % ari == 0);
+    if (!at_check) {                                  // boundary of a tight window only: PCG statistics, no residuals
+      be::fetch_flags(d_, flags);
+      stats_.pcg_iters_total += flags[F_STAT_SUM];
+      stats_.pcg_iters_max = std::max(stats_.pcg_iters_max, (double)flags[F_STAT_MAX]);
+      stats_.pcg_unconverged += flags[F_STAT_UNCONV];
+      budget[tight] = next_budget(budget[tight], flags);
+      continue;
+    }
     be::residuals(d_);
     be::fetch_res_flags(d_, res, flags);
     stats_.pcg_iters_total += flags[F_STAT_SUM];
@@ -604,7 +688,7 @@ void Engine::admm_core(double t0, double *res) {
     info.duality_gap = info.obj_val - info.dual_obj_val;
     if (settings.verbose)
       std::printf("%4d  %11.4e   %8.2e   %8.2e   %8.2e  %3d  %8.2es   (cg mean %.1f budget %d unconv %d; rho est %.2e)\n", iter, info.obj_val, info.prim_res,
-                  info.dual_res, rho_bar_, flags[F_STAT_MAX], now_s() - t0, flags[F_STAT_SUM] / (double)std::max(1, flags[F_STAT_N]), cg_budget_,
+                  info.dual_res, rho_bar_, flags[F_STAT_MAX], now_s() - t0, flags[F_STAT_SUM] / (double)std::max(1, flags[F_STAT_N]), budget[tight],
                   flags[F_STAT_UNCONV], rho_estimate(res));
     const bool do_check = (ct > 0 && iter % ct == 0) || iter == settings.max_iter;
     if (do_check && check_termination(res, false)) break;
@@ -614,13 +698,24 @@ void Engine::admm_core(double t0, double *res) {
     }
     if (now_s() - t0 > settings.time_limit) { set_status(OSQP_TIME_LIMIT_REACHED); break; }
     if (ari > 0 && iter % ari == 0) {                                                    // adapt_rho :910-930
-      double rn = rho_estimate(res);
+      const double rn = rho_estimate(res), tol = settings.adaptive_rho_tolerance;
       info.rho_estimate = rn;
-      if (rn > settings.adaptive_rho_tolerance * rho_bar_ || rn < rho_bar_ / settings.adaptive_rho_tolerance) {
+      // The reference applies the estimate when it differs from rho by more than the tolerance (5): a guard against
+      // refactorisations, which cost the indirect path nothing.  Here an estimate that falls on the same side of rho by
+      // more than sqrt(tolerance) at two CONSECUTIVE adaptation points is applied as well: the reference rule alone sits on a
+      // knife edge at config 2 (the estimate settles at 0.2 rho: the oracle fires at iteration 350 with the 1e3 equality
+      // weight and never with weight 10 -- 575 vs 1250 iterations).
+      const double st = std::sqrt(tol);
+      const int side = rn > st * rho_bar_ ? 1 : (rn < rho_bar_ / st ? -1 : 0);
+      const bool big = rn > tol * rho_bar_ || rn < rho_bar_ / tol;
+      const bool persistent = persist && side != 0 && side == last_side;
+      last_side = side;
+      if (big || persistent) {
         rho_bar_ = rn; settings.rho = rn;
         be::set_rho(d_, rho_bar_);
         be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
         info.rho_updates++;
+        last_side = 0;
       }
     }
     // inner tolerance follows the (scaled) ADMM residuals and never loosens
@@ -630,22 +725,9 @@ void Engine::admm_core(double t0, double *res) {
     // _osqp.py:880-908 and was measured to cost 2-3x more ADMM iterations -- see DESIGN.md "PCG tolerance".)
     double eps = settings.cg_tol_fraction * res[R_DUA_S];
     eps = std::max(std::min(eps, eps_cg_prev_), kCgTolAbsMin);
-    if (std::isfinite(eps)) { eps_cg_prev_ = eps; be::set_pcg_tol(d_, 1e-14, eps); have_tol_ = true; }
-    // PCG budget for the next chunk: track what the last chunk needed
-    const int cap = std::min(settings.cg_max_iter, kMaxCg);
-    static const double tolerate = [] { const char *e = std::getenv("OSQP_HIP_BUDGET_TOLERATE"); return e ? std::atof(e) : 0.0; }();
-    if (flags[F_STAT_UNCONV] * 4 > std::max(1, flags[F_STAT_N]) && flags[F_STAT_UNCONV] > tolerate * flags[F_STAT_N]) cg_budget_ = std::min(cap, std::max(cg_budget_ + 2, 2 * cg_budget_));
-    else if (flags[F_STAT_UNCONV] > tolerate * flags[F_STAT_N]) cg_budget_ = std::min(cap, cg_budget_ + 1);
-    else {
-      // mean + 3 sigma of the PCG counts of the last chunk (+1), never above its max + 1: rare spikes should not
-      // set the budget of the next 25 iterations (an occasional budget-limited solve is just a slightly less exact one)
-      const double cnt = std::max(1, flags[F_STAT_N]), mean = flags[F_STAT_SUM] / cnt;
-      const double var = std::max(0.0, flags[F_STAT_SUMSQ] / cnt - mean * mean);
-      static const double nsig = [] { const char *e = std::getenv("OSQP_HIP_BUDGET_SIGMA"); return e ? std::atof(e) : 3.0; }();
-      const int q3 = (int)std::ceil(mean + nsig * std::sqrt(var));     // (KA checks the residual after the last budgeted iteration)
-      static const int slack = [] { const char *e = std::getenv("OSQP_HIP_BUDGET_SLACK"); return e ? std::atoi(e) : 0; }();
-      cg_budget_ = std::min(cap, std::max(2, std::min(flags[F_STAT_MAX], q3)) + slack);
-    }
+    if (std::isfinite(eps)) { eps_cg_prev_ = eps; tol_rel = 1e-14; tol_abs = eps; have_tol_ = true; }
+    // PCG budget for the next chunk of this kind: track what the last chunk needed
+    budget[tight] = next_budget(budget[tight], flags);
   }
 }
 
