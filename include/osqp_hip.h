@@ -182,6 +182,9 @@ typedef struct {
   double pcg_fused;           /* 1: two-kernel PCG iteration (k_k2f, k_k1f); 0: three (k_k1, k_k2, k_kv) */
   double batch_direct_bw;     /* half bandwidth of the reduced KKT matrix under the engine's RCM ordering (batch / small-QP direct
                                  solve); -1 before the first batch or small solve, -2 if the pattern is too dense to analyse */
+  double cg_cap_escalations;  /* times the last solve doubled its PCG iteration cap because most solves of a chunk stagnated at it */
+  double windowed_blocks;     /* row blocks of A and B whose input-vector window is staged in LDS (16-bit local column indices) */
+  double row_blocks;          /* row blocks of A and B in total */
 } OSQPHipStats;
 OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
 
@@ -213,6 +216,16 @@ OSQPInt osqp_hip_batch_solve(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat
  * solver's own stream and waits for it.  l <= u is NOT validated on this path. */
 OSQPInt osqp_hip_batch_solve_device(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat *q_dev, const OSQPFloat *l_dev, const OSQPFloat *u_dev,
                                     OSQPFloat *x_dev, OSQPFloat *y_dev, OSQPFloat *rec_dev, OSQPInt warm_start, void *stream);
+
+/* Parametric re-solve with the new data ALREADY ON THE GPU (the reference's update(q, l, u) + solve() loop,
+ * src/osqp/nn/torch.py:136-140, /root/reference/src/osqppurepy/_osqp.py:1312-1367 and :1493-1545 restated as kernels):
+ * q_dev / l_dev / u_dev / x_dev / y_dev are UNSCALED float64 arrays in device memory of this solver's device, NULL = unchanged.
+ * The solver's stream first waits for everything queued on `stream` so far (NULL: the arrays are ready), copies the vectors
+ * device-to-device and rescales / re-classifies them with kernels -- no host round trip except the 4-byte l <= u verdict of
+ * osqp_hip_update_data_vec_device (OSQP_DATA_VALIDATION_ERROR, nothing changed).  The host-pointer entry points
+ * osqp_update_data_vec / osqp_warm_start run the same kernels behind one H2D copy per vector. */
+OSQPInt osqp_hip_update_data_vec_device(OSQPSolver *solver, const OSQPFloat *q_dev, const OSQPFloat *l_dev, const OSQPFloat *u_dev, void *stream);
+OSQPInt osqp_hip_warm_start_device(OSQPSolver *solver, const OSQPFloat *x_dev, const OSQPFloat *y_dev, void *stream);
 
 
 /* ---- LinSysSolver slot (north_star's second boundary) -------------------------------------------------------

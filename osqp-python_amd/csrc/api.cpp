@@ -93,6 +93,12 @@ OSQPInt osqp_hip_batch_solve(OSQPSolver *s, OSQPInt nbatch, const OSQPFloat *q, 
 OSQPInt osqp_hip_batch_solve_device(OSQPSolver *s, OSQPInt nbatch, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u, OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm, void *stream) {
   return guarded(s, [&](Engine &e) { return e.batch_solve_device(nbatch, q, l, u, x, y, rec, warm, stream); });
 }
+OSQPInt osqp_hip_update_data_vec_device(OSQPSolver *s, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u, void *stream) {
+  return guarded(s, [&](Engine &e) { return e.update_data_vec_device(q, l, u, stream); });
+}
+OSQPInt osqp_hip_warm_start_device(OSQPSolver *s, const OSQPFloat *x, const OSQPFloat *y, void *stream) {
+  return guarded(s, [&](Engine &e) { return e.warm_start_device(x, y, stream); });
+}
 OSQPInt osqp_hip_get_scaling(OSQPSolver *s, OSQPFloat *D, OSQPFloat *E, OSQPFloat *c) { return guarded(s, [&](Engine &e) { return e.get_scaling(D, E, c); }); }
 
 }  // extern "C"

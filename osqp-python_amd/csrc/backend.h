@@ -34,6 +34,7 @@ constexpr int kGrid = OSQP_HIP_KGRID;     // workgroups per launch = number of p
 constexpr int kChunk = 8 * kBlock;        // nnz staged through LDS per row-block (8 per thread, all loads in flight at once)
 constexpr int kLongRow = 128;      // rows with more nnz get a workgroup of their own (block-wide reduction)
 constexpr int kMaxRowsPerBlock = 1024;
+constexpr int kPartSlots = 40;     // rows of Dev::part (each kGrid doubles)
 constexpr int kMaxCg = 1024;       // hard cap on the PCG budget (size of the alpha/gamma history)
 constexpr int kWinCap = 1472;      // input-vector window of a row block staged in LDS (elements; 23 KB as 16-byte pairs: 4 workgroups per CU)
 
@@ -61,6 +62,7 @@ struct DevCsr {
 enum ResId {
   R_PRI_U = 0, R_AX_U, R_Z_U, R_PRI_S, R_AX_S, R_Z_S, R_DY_U, R_DY_S, R_PINF_LHS, R_SUPP,   // m-side
   R_DUA_U, R_PX_U, R_ATY_U, R_DUA_S, R_PX_S, R_ATY_S, R_DX_U, R_DX_S, R_XPX, R_QX, R_QDX,    // n-side
+  R_QN_S, R_QN_U,                                                                            // ||q||_inf, ||Dinv q||_inf (scaled q)
   R_ATDY_U, R_ATDY_S, R_PDX_U, R_PDX_S, R_ADX_VIOL,                                          // infeasibility 2nd stage
   R_COUNT
 };
@@ -85,6 +87,12 @@ struct Dev {
   double *q = nullptr, *l = nullptr, *u = nullptr, *D = nullptr, *Dinv = nullptr, *E = nullptr, *Einv = nullptr;
   double *rho = nullptr, *rho_inv = nullptr;
   int *ctype = nullptr;          // -1 loose, 0 inequality, 1 equality (_osqp.py:516-518)
+  // vector updates on the device: the caller's UNSCALED q, l, u stay resident; scaling (_osqp.py:1328, :1357-1358)
+  // and the constraint classification (:505-518) are kernels
+  double *qraw = nullptr, *lraw = nullptr, *uraw = nullptr;
+  int *cnt = nullptr;            // [2] device counters: {inequality rows found by the classification, rows with l > u}
+  int eq_from_cnt = 0;           // 1: k_set_rho derives the equality weight from cnt[0] (device classification), 0: rho_eq_factor
+  double rho_eq_mixed = 10.0;    // equality weight when inequality rows exist (engine.cpp classify_constraints)
   // ADMM iterates
   double *x = nullptr, *z = nullptr, *y = nullptr, *dx = nullptr, *dy = nullptr;
   double *xs = nullptr;          // x~ : PCG solution, kept as warm start for the next ADMM iteration
@@ -96,7 +104,7 @@ struct Dev {
   double *uu2 = nullptr, *ms = nullptr;  // fused PCG: u_k lives in (k&1 ? uu2 : uu); ms (2n) = interleaved pairs {u_k[j], (Minv .* s_k)[j]}
   int fused = 0;                 // 1: two kernels per PCG iteration (vector update k-1 fused into the SpMV-A kernel of iteration k)
   // reductions
-  double *part = nullptr;        // [slot][kGrid] partial results, slots see backend implementation
+  double *part = nullptr;        // [kPartSlots][kGrid] partial results, slots see backend implementation
   double *res = nullptr;         // [R_COUNT]
   double *scal = nullptr;        // [S_HIST + 2*(kMaxCg+1)]
   int *flags = nullptr;          // [F_COUNT]
@@ -151,6 +159,10 @@ void d2h(Dev &d, void *dst, const void *src, size_t bytes);   // synchronous w.r
 void zero(Dev &d, void *dst, size_t bytes);
 void sync(Dev &d);
 void activate(Dev &d);                  // make d.device current for the calling thread (HIP's current device is thread-local)
+// Work enqueued on a CALLER's stream that reads solver-owned memory (batch_solve with a stream): ext_record marks its end on that
+// stream, ext_wait makes the host wait for it before the solver overwrites or frees that memory (no-op when nothing is pending).
+void ext_record(Dev &d, void *stream);
+void ext_wait(Dev &d);
 
 // ---- ADMM hot path (all asynchronous on d.stream) ----
 // KB: x-part of the rhs and the PCG start, one pass over B (two sums per row):
@@ -214,6 +226,16 @@ void assemble(Dev &d, int scaled, double c, int with_sigma);
 // Ruiz equilibration + cost normalisation (_osqp.py:389-497) of A.val, B.val (assembled unscaled, no sigma) and d.q IN PLACE:
 // fills d.D, d.E, d.Dinv, d.Einv, adds sigma to B's diagonal, returns the cost scale c.  iters == 0: D = E = 1, c = 1.
 double ruiz(Dev &d, int iters);
+
+// ---- vector updates / warm start on the device ----
+bool device_vec_updates();               // false: the host simulator (the driver scales on the host and uploads finished vectors)
+// dst (device) <- src, asynchronous on the solver's stream; src_on_device = 0: host memory (reusable when the call returns)
+void copy_in(Dev &d, void *dst, const void *src, size_t bytes, int src_on_device);
+void stream_wait(Dev &d, void *caller_stream);       // the solver's stream waits for everything queued on caller_stream so far
+void scale_q(Dev &d, double c);                       // q = c D qraw                                  (_osqp.py:1328)
+void scale_bounds(Dev &d, int rho_is_vec);            // l = E lraw, u = E uraw; ctype; cnt[0]       (:1357-1358, :505-518)
+int count_bad_bounds(Dev &d, const double *l_dev, const double *u_dev);   // rows with !(l <= u) (:1348-1349); synchronises
+void scale_warm(Dev &d, const double *x_dev, const double *y_dev, double c);   // x = Dinv x_in ; y = c Einv y_in  (:1493-1545); NULL: keep
 
 // ---- probes / tests ----
 bool ktrace_read(Dev &d, unsigned long long *out, int count);   // diagnostic build only (OSQP_HIP_KTRACE); false otherwise

@@ -58,10 +58,11 @@ __device__ unsigned long long g_ktrace[kGrid * kTraceSlots];
 #endif
 #define KNOCKED(bit) ((OSQP_HIP_KNOCK & (bit)) != 0)
 enum Slot { SL_GAMMA0 = 0, SL_GAMMA1, SL_RN0, SL_RN1, SL_BN, SL_DELTA, SL_RES0 /* .. SL_RES0 + R_COUNT - 1 */ };
-static_assert(SL_RES0 + R_COUNT <= 32, "Dev::part holds 32 slots");
+static_assert(SL_RES0 + R_COUNT <= kPartSlots, "Dev::part is too small");
 
 struct Impl {
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_ext = nullptr;
+  bool ext_pending = false;
   double *pin_res = nullptr;
   int *pin_flags = nullptr;
 };
@@ -639,7 +640,8 @@ struct PreK2F {
   __device__ __forceinline__ Tok begin() const {
     Tok t;
     if (KNOCKED(1)) { t.tol = 0; t.glast = 1; return t; }
-    t.prn = partial_load(d.part + (SL_RN0 + (k & 1)) * kGrid); t.pg = partial_load(d.part + (SL_GAMMA0 + (k & 1)) * kGrid);
+    if (KNOCKED(256)) { for (int q = 0; q < kPart; q++) { t.prn.v[q] = 1.0; t.pg.v[q] = 1.0; } }
+    else { t.prn = partial_load(d.part + (SL_RN0 + (k & 1)) * kGrid); t.pg = partial_load(d.part + (SL_GAMMA0 + (k & 1)) * kGrid); }
     t.tol = d.scal[S_TOL_NOW]; t.glast = k == 0 ? 1.0 : d.scal[S_HIST + k - 1];
     return t;
   }
@@ -707,7 +709,7 @@ struct PreK1F {
     const double *uin = (k & 1) ? d.uu2 : d.uu;
     const double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1, *bet = d.scal + S_HIST + 2 * (kMaxCg + 1);
     Tok t;
-    t.pd = partial_load(d.part + SL_DELTA * kGrid);
+    if (KNOCKED(512)) { for (int q = 0; q < kPart; q++) t.pd.v[q] = 1.0; } else t.pd = partial_load(d.part + SL_DELTA * kGrid);
     t.gamma = gam[k]; t.beta = bet[k]; t.alast = k == 0 ? 1.0 : alp[k - 1];
     const int j0 = first_index();
     t.u0 = t.p0 = t.r0 = t.s0 = t.m0 = t.x0 = 0.0;
@@ -851,9 +853,10 @@ struct GTwo {        // P part -> sum 0 (with pn), A' part -> sum 1 (with pm)
 };
 struct EKr2 : NoPrefetch {
   const double *x, *q, *dx, *D, *Dinv; double sigma;
-  double du = 0, pu = 0, au = 0, ds = 0, ps = 0, as = 0, xu = 0, xs = 0, xpx = 0, qx = 0, qdx = 0;
+  double du = 0, pu = 0, au = 0, ds = 0, ps = 0, as = 0, xu = 0, xs = 0, xpx = 0, qx = 0, qdx = 0, qns = 0, qnu = 0;
   __device__ __forceinline__ void operator()(int j, const double (&s)[2]) {
     const double xj = x[j], px = s[0] - sigma * xj, aty = s[1], qj = q[j], dr = px + qj + aty, di = Dinv[j], dxj = dx[j];
+    qns = nanmax(qns, fabs(qj)); qnu = nanmax(qnu, fabs(di * qj));                          // _osqp.py:766-794 (the q terms)
     du = nanmax(du, fabs(di * dr)); pu = nanmax(pu, fabs(di * px)); au = nanmax(au, fabs(di * aty));
     ds = nanmax(ds, fabs(dr)); ps = nanmax(ps, fabs(px)); as = nanmax(as, fabs(aty));
     xu = nanmax(xu, fabs(D[j] * dxj)); xs = nanmax(xs, fabs(dxj));
@@ -873,6 +876,7 @@ __global__ __launch_bounds__(kBlock) void k_res_n(Dev d) {
   put_partial(d.part, SL_RES0 + R_DX_U, block_max(e.xu, red)); put_partial(d.part, SL_RES0 + R_DX_S, block_max(e.xs, red));
   put_partial(d.part, SL_RES0 + R_XPX, block_sum(e.xpx, red)); put_partial(d.part, SL_RES0 + R_QX, block_sum(e.qx, red));
   put_partial(d.part, SL_RES0 + R_QDX, block_sum(e.qdx, red));
+  put_partial(d.part, SL_RES0 + R_QN_S, block_max(e.qns, red)); put_partial(d.part, SL_RES0 + R_QN_U, block_max(e.qnu, red));
 }
 
 __device__ __forceinline__ bool res_is_sum(int q) {
@@ -934,7 +938,8 @@ __global__ __launch_bounds__(kBlock) void k_set_rho(Dev d, double rho_bar) {
   const int stride = gridDim.x * kBlock;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += stride) {
     const int t = d.ctype[i];
-    const double r = t == -1 ? 1e-6 : (t == 1 ? d.rho_eq_factor * rho_bar : rho_bar);     // _osqp.py:520-522, :1590-1594
+    const double eqf = d.eq_from_cnt ? (d.cnt[0] == 0 ? 1e3 : d.rho_eq_mixed) : d.rho_eq_factor;   // engine.cpp classify_constraints
+    const double r = t == -1 ? 1e-6 : (t == 1 ? eqf * rho_bar : rho_bar);                 // _osqp.py:520-522, :1590-1594
     d.rho[i] = r; d.rho_inv[i] = 1.0 / r;
     d.v[i] = r * d.z[i] - d.y[i]; d.t0[i] = r * d.zt[i];
   }
@@ -977,6 +982,37 @@ __global__ __launch_bounds__(kBlock) void k_normalcone(Dev d) {
   }
 }
 __global__ void k_set_scal(double *scal, double rel, double ab) { scal[S_TOL_REL] = rel; scal[S_TOL_ABS] = ab; }
+// vector updates on the device ----------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_scale_q(Dev d, double c) {                     // _osqp.py:1328
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += gridDim.x * kBlock) d.q[j] = c * d.D[j] * d.qraw[j];
+}
+__global__ __launch_bounds__(kBlock) void k_scale_bounds(Dev d, int rho_is_vec) {          // :1357-1358, :505-518 (on the scaled bounds)
+  int ineq = 0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += gridDim.x * kBlock) {
+    const double ls = d.E[i] * d.lraw[i], us = d.E[i] * d.uraw[i];
+    d.l[i] = ls; d.u[i] = us;
+    int t;
+    if (ls < -OSQP_INFTY * 1e-4 && us > OSQP_INFTY * 1e-4) t = -1;
+    else if (us - ls < 1e-4) t = 1;
+    else t = 0;
+    if (!rho_is_vec) t = 0;
+    d.ctype[i] = t;
+    ineq += (t == 0);
+  }
+  for (int o = 32; o > 0; o >>= 1) ineq += __shfl_down(ineq, o, 64);
+  if ((threadIdx.x & 63) == 0 && ineq) atomicAdd(&d.cnt[0], ineq);                         // (integer: order-independent)
+}
+__global__ __launch_bounds__(kBlock) void k_count_bad(int m, const double *l, const double *u, int *cnt) {   // :1348-1349
+  int bad = 0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock) bad += !(l[i] <= u[i]);
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_down(bad, o, 64);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(&cnt[1], bad);
+}
+__global__ __launch_bounds__(kBlock) void k_scale_warm(Dev d, const double *xin, const double *yin, double c) {   // :1493-1545
+  const int stride = gridDim.x * kBlock;
+  if (xin) for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) d.x[j] = d.Dinv[j] * xin[j];
+  if (yin) for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += stride) d.y[i] = c * d.Einv[i] * yin[i];
+}
 
 struct EStore : NoPrefetch { double *out; __device__ __forceinline__ void operator()(int r, const double (&s)[1]) { out[r] = s[0]; } };
 __global__ __launch_bounds__(kBlock) void k_test_spmv(DevCsr M, const double *in, double *out) {
@@ -1004,7 +1040,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_scatter(Dev d, int scaled, doubl
     const int i = d.Pi[k], j = d.Pj[k];
     double v = d.Praw[k];
     if (scaled) v *= c * d.D[i] * d.D[j];
-    if (i == j) d.B.val[d.Pm1[k]] = sigma + v;          // k_asm_diag has run: an absent diagonal keeps sigma alone
+    if (i == j) atomicAdd(&d.B.val[d.Pm1[k]], v);      // onto the sigma k_asm_diag stored (repeated (j, j) entries of a valid CSC sum up)
     else { d.B.val[d.Pm1[k]] = v; d.B.val[d.Pm2[k]] = v; }
   }
 }
@@ -1083,7 +1119,7 @@ int init(Dev &d, int device) {
   HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   d.stream = s;
   Impl *p = new Impl();
-  HIP_CHECK(hipEventCreate(&p->ev0)); HIP_CHECK(hipEventCreate(&p->ev1));
+  HIP_CHECK(hipEventCreate(&p->ev0)); HIP_CHECK(hipEventCreate(&p->ev1)); HIP_CHECK(hipEventCreateWithFlags(&p->ev_ext, hipEventDisableTiming));
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_res), sizeof(double) * R_COUNT, hipHostMallocDefault));
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_flags), sizeof(int) * F_COUNT, hipHostMallocDefault));
   d.impl = p;
@@ -1093,7 +1129,7 @@ void destroy(Dev &d) {
   if (!d.impl) return;
   (void)hipSetDevice(d.device);
   Impl &p = im(d);
-  (void)hipEventDestroy(p.ev0); (void)hipEventDestroy(p.ev1); (void)hipHostFree(p.pin_res); (void)hipHostFree(p.pin_flags);
+  (void)hipEventDestroy(p.ev0); (void)hipEventDestroy(p.ev1); (void)hipEventDestroy(p.ev_ext); (void)hipHostFree(p.pin_res); (void)hipHostFree(p.pin_flags);
   delete &p; d.impl = nullptr;
   if (d.stream) { (void)hipStreamDestroy(st(d)); d.stream = nullptr; }
 }
@@ -1120,6 +1156,18 @@ void d2h(Dev &d, void *dst, const void *src, size_t b) {
 void zero(Dev &d, void *dst, size_t b) { if (!b) return; HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipMemsetAsync(dst, 0, b, st(d))); }
 void sync(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipStreamSynchronize(st(d))); }
 void activate(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); }
+void ext_record(Dev &d, void *stream) {
+  if (!stream || !d.impl) return;
+  HIP_CHECK(hipSetDevice(d.device));
+  HIP_CHECK(hipEventRecord(im(d).ev_ext, static_cast<hipStream_t>(stream)));
+  im(d).ext_pending = true;
+}
+void ext_wait(Dev &d) {
+  if (!d.impl || !im(d).ext_pending) return;
+  HIP_CHECK(hipSetDevice(d.device));
+  HIP_CHECK(hipEventSynchronize(im(d).ev_ext));
+  im(d).ext_pending = false;
+}
 
 void kb_rhs(Dev &d) { LAUNCH(k_kb, d, d); }
 bool pcg_fused(const Dev &d) { return d.fused != 0; }
@@ -1132,7 +1180,7 @@ void residuals(Dev &d) {
   HIP_CHECK(hipSetDevice(d.device));
   LAUNCH(k_res_m, d, d);
   LAUNCH(k_res_n, d, d);
-  hipLaunchKernelGGL(k_res_final, dim3(R_QDX + 1), dim3(kBlock), 0, st(d), d, 0);
+  hipLaunchKernelGGL(k_res_final, dim3(R_QN_U + 1), dim3(kBlock), 0, st(d), d, 0);
 }
 void infeas_primal(Dev &d) {
   HIP_CHECK(hipSetDevice(d.device));
@@ -1183,6 +1231,36 @@ void init_iterates(Dev &d, int full) {
   if (full) LAUNCH(k_init_n, d, d);
   LAUNCH(k_init_m, d, d, full);
 }
+
+bool device_vec_updates() { return true; }
+void copy_in(Dev &d, void *dst, const void *src, size_t bytes, int src_on_device) {
+  if (!bytes) return;
+  HIP_CHECK(hipSetDevice(d.device));
+  HIP_CHECK(hipMemcpyAsync(dst, src, bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st(d)));
+}
+void stream_wait(Dev &d, void *caller_stream) {
+  if (!caller_stream || caller_stream == d.stream) return;
+  HIP_CHECK(hipSetDevice(d.device));
+  HIP_CHECK(hipEventRecord(im(d).ev_ext, static_cast<hipStream_t>(caller_stream)));
+  HIP_CHECK(hipStreamWaitEvent(st(d), im(d).ev_ext, 0));
+}
+void scale_q(Dev &d, double c) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_scale_q, d, d, c); }
+void scale_bounds(Dev &d, int rho_is_vec) {
+  HIP_CHECK(hipSetDevice(d.device));
+  HIP_CHECK(hipMemsetAsync(d.cnt, 0, sizeof(int), st(d)));
+  if (d.m > 0) LAUNCH(k_scale_bounds, d, d, rho_is_vec);
+}
+int count_bad_bounds(Dev &d, const double *l, const double *u) {
+  if (d.m == 0) return 0;
+  HIP_CHECK(hipSetDevice(d.device));
+  HIP_CHECK(hipMemsetAsync(d.cnt + 1, 0, sizeof(int), st(d)));
+  LAUNCH(k_count_bad, d, d.m, l, u, d.cnt);
+  int bad = 0;
+  HIP_CHECK(hipMemcpyAsync(&bad, d.cnt + 1, sizeof(int), hipMemcpyDeviceToHost, st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  return bad;
+}
+void scale_warm(Dev &d, const double *x, const double *y, double c) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_scale_warm, d, d, x, y, c); }
 
 void project_normalcone(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_normalcone, d, d); }
 

@@ -67,7 +67,7 @@ Engine::Engine() {
   pub.settings = &settings; pub.solution = &solution; pub.info = &info; pub.work = reinterpret_cast<OSQPWorkspace *>(this);
   const char *g = std::getenv("OSQP_HIP_GRAPH");
   use_graph_ = !(g && g[0] == '0');
-  if (const char *f = std::getenv("OSQP_HIP_RHO_EQ_FACTOR")) { double v = std::atof(f); if (v >= 1.0) eq_factor_mixed_ = v; }
+  if (const char *f = std::getenv("OSQP_HIP_RHO_EQ_FACTOR")) { double v = std::atof(f); if (v >= 1.0) { eq_factor_mixed_ = v; eq_factor_env_ = true; } }
 }
 Engine::~Engine() { free_all(); }
 
@@ -78,11 +78,12 @@ void Engine::drop_graphs() {
 
 void Engine::free_all() {
   if (!dev_ready_) return;
-  try { be::activate(d_); be::sync(d_); } catch (const DeviceError &) {}       // runs in the destructor: release what we can
+  try { be::activate(d_); be::ext_wait(d_); be::sync(d_); } catch (const DeviceError &) {}       // runs in the destructor: release what we can
   drop_graphs();
   if (bbuf_) { be::dfree(d_, bbuf_); bbuf_ = nullptr; bbuf_cap_ = 0; }
+  if (ckpt_) { be::dfree(d_, ckpt_); ckpt_ = nullptr; }
   free_batch_direct();
-  void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag, d_.A.runinfo, d_.B.runinfo, d_.A.blkwin, d_.B.blkwin, d_.A.lcol, d_.B.lcol,
+  void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag, d_.A.runinfo, d_.B.runinfo, d_.A.blkwin, d_.B.blkwin, d_.A.lcol, d_.B.lcol, d_.qraw, d_.lraw, d_.uraw, d_.cnt,
                   d_.q, d_.l, d_.u, d_.D, d_.Dinv, d_.E, d_.Einv, d_.rho, d_.rho_inv, d_.ctype, d_.x, d_.z, d_.y, d_.dx,
                   d_.dy, d_.xs, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.uu2, d_.ms, d_.part, d_.res,
                   d_.scal, d_.flags, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB};
@@ -191,7 +192,43 @@ void Engine::classify_constraints(const std::vector<double> &ls, const std::vect
     ctype_[i] = t;
     n_ineq += (t == 0);
   }
-  d_.rho_eq_factor = (n_ineq == 0) ? 1e3 : eq_factor_mixed_;
+  d_.rho_eq_factor = (n_ineq == 0) ? 1e3 : mixed_eq_factor();
+  d_.eq_from_cnt = 0;                                   // host classification: k_set_rho takes the factor from rho_eq_factor
+}
+
+// Device-side counterpart of upload_q / upload_bounds_and_types: scaling and classification kernels over the resident raw vectors
+void Engine::device_scale_vectors(bool q, bool bounds) {
+  if (q) be::scale_q(d_, c_);
+  if (bounds) {
+    d_.rho_eq_mixed = mixed_eq_factor(); d_.eq_from_cnt = 1;
+    be::scale_bounds(d_, settings.rho_is_vec);
+    scaled_stale_ = true;
+  }
+}
+
+void Engine::ensure_host_vectors() {
+  if (raw_stale_) {                                     // the last update came through device pointers
+    be::d2h(d_, q0_.data(), d_.qraw, sizeof(double) * n);
+    if (m > 0) { be::d2h(d_, l0_.data(), d_.lraw, sizeof(double) * m); be::d2h(d_, u0_.data(), d_.uraw, sizeof(double) * m); }
+    raw_stale_ = false;
+  }
+  if (scaled_stale_) {
+    ls_.resize(m); us_.resize(m);
+    for (int i = 0; i < m; i++) { ls_[i] = E_[i] * l0_[i]; us_[i] = E_[i] * u0_[i]; }
+    const int keep = d_.eq_from_cnt; const double keepf = d_.rho_eq_factor;
+    classify_constraints(ls_, us_);                     // (host copy of ctype only: the device already holds its own)
+    d_.eq_from_cnt = keep; if (keep) d_.rho_eq_factor = keepf;
+    scaled_stale_ = false;
+  }
+}
+
+// Equality weight on problems with inequality rows.  The value 10 (see above) is what the PCG needs at scale; a problem with at
+// most kSmallEqN variables is solved by CG in at most n steps whatever the conditioning, and on small LPs / rank-deficient QPs the
+// reference's 1e3 is what ADMM itself needs (fuzz: 3 of 150 random small problems reach max_iter with 10 and solve in 500-5000
+// iterations, like the oracle, with 1e3).  osqp_hip_set_rho_eq_factor() overrides both.
+double Engine::mixed_eq_factor() const {
+  constexpr int kSmallEqN = 256;
+  return (!eq_factor_set_ && !eq_factor_env_ && n <= kSmallEqN) ? 1e3 : eq_factor_mixed_;
 }
 
 int Engine::set_rho_eq_factor(double f) {
@@ -199,6 +236,7 @@ int Engine::set_rho_eq_factor(double f) {
   if (!(f >= 1.0)) return OSQP_SETTINGS_VALIDATION_ERROR;
   be::activate(d_);
   eq_factor_mixed_ = f; eq_factor_set_ = true;
+  ensure_host_vectors();
   upload_bounds_and_types();
   be::set_rho(d_, rho_bar_);
   be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
@@ -221,12 +259,7 @@ void Engine::apply_scaled_bounds(const std::vector<double> &ls, const std::vecto
 
 void Engine::upload_q() {
   std::vector<double> qs(n);
-  qnorm_s_ = 0; qnorm_u_ = 0;
-  for (int j = 0; j < n; j++) {
-    qs[j] = c_ * D_[j] * q0_[j];                                                         // _osqp.py:1328
-    qnorm_s_ = std::max(qnorm_s_, std::fabs(qs[j]));
-    qnorm_u_ = std::max(qnorm_u_, std::fabs(Dinv_[j] * qs[j]));
-  }
+  for (int j = 0; j < n; j++) qs[j] = c_ * D_[j] * q0_[j];                              // _osqp.py:1328
   be::h2d(d_, d_.q, qs.data(), sizeof(double) * n);
 }
 
@@ -320,14 +353,14 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   {
     std::vector<int> cur(Brp.begin(), Brp.end() - 1);
     for (int j = 0; j < n; j++) {
-      int kd = -1;
       for (int k = P_.p[j]; k < P_.p[j + 1]; k++) {
         int i = P_.i[k];
-        if (i == j) { kd = k; continue; }
+        if (i == j) continue;
         int p1 = cur[j]++; Bj[p1] = i; Pmap1_[k] = p1;      // (j, i): lower part of row j
       }
       bdiag[j] = cur[j]++; Bj[bdiag[j]] = j;
-      if (kd >= 0) Pmap1_[kd] = bdiag[j];
+      for (int k = P_.p[j]; k < P_.p[j + 1]; k++)           // every stored (j, j) entry -- valid CSC may repeat it -- adds into the one slot
+        if (P_.i[k] == j) Pmap1_[k] = bdiag[j];
       for (int k = P_.p[j]; k < P_.p[j + 1]; k++) {
         int i = P_.i[k];
         if (i == j) continue;
@@ -417,7 +450,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   d_.x = dv(n); d_.z = dv(m); d_.y = dv(m); d_.dx = dv(n); d_.dy = dv(m); d_.xs = dv(n); d_.zt = dv(m); d_.t0 = dv(m); d_.v = dv(m);
   d_.r = dv(n); d_.uu = dv(n); d_.p = dv(n); d_.s = dv(n); d_.w = dv(n); d_.t = dv(m); d_.Minv = dv(n); d_.uu2 = dv(n); d_.ms = dv(2 * (size_t)n);
   { const char *f = std::getenv("OSQP_HIP_PCG_FUSED"); d_.fused = (f && f[0] == '0') ? 0 : 1; }   // default on; =0 selects the 3-kernel sequence
-  d_.part = dv((size_t)32 * kGrid); d_.res = dv(R_COUNT); d_.scal = dv(S_HIST + 3 * (kMaxCg + 1)); d_.flags = dev_vec<int>(d_, F_COUNT);
+  d_.part = dv((size_t)kPartSlots * kGrid); d_.res = dv(R_COUNT); d_.scal = dv(S_HIST + 3 * (kMaxCg + 1)); d_.flags = dev_vec<int>(d_, F_COUNT);
   if (dev_asm) {
     // the caller's values go up once, in their own (CSC) order; every later (re)assembly and the equilibration run on the device
     std::vector<int> Pj(nzP), Aj(nzA);
@@ -442,8 +475,16 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
     be::h2d(d_, d_.E, E_.data(), sizeof(double) * m); be::h2d(d_, d_.Einv, Einv_.data(), sizeof(double) * m);
     lap("matrix values (host-scaled)");
   }
-  upload_q();
-  upload_bounds_and_types();
+  d_.qraw = dv(n); d_.lraw = dv(m); d_.uraw = dv(m); d_.cnt = dev_vec<int>(d_, 2);
+  raw_stale_ = scaled_stale_ = false;
+  if (be::device_vec_updates()) {
+    be::copy_in(d_, d_.qraw, q0_.data(), sizeof(double) * n, 0);
+    be::copy_in(d_, d_.lraw, l0_.data(), sizeof(double) * m, 0); be::copy_in(d_, d_.uraw, u0_.data(), sizeof(double) * m, 0);
+    device_scale_vectors(true, true);
+  } else {
+    upload_q();
+    upload_bounds_and_types();
+  }
   be::set_rho(d_, rho_bar_);                                       // _osqp.py:499-524
   be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
   be::init_iterates(d_, 1);
@@ -523,7 +564,7 @@ void Engine::run_chunk(int niter, int budget) {
 
 double Engine::rho_estimate(const double *res) const {                                   // _osqp.py:880-908 (scaled quantities)
   double pri = res[R_PRI_S] / (std::max(res[R_AX_S], res[R_Z_S]) + 1e-10);
-  double dua = res[R_DUA_S] / (std::max(std::max(res[R_ATY_S], res[R_PX_S]), qnorm_s_) + 1e-10);
+  double dua = res[R_DUA_S] / (std::max(std::max(res[R_ATY_S], res[R_PX_S]), res[R_QN_S]) + 1e-10);
   return clamp_rho(rho_bar_ * std::sqrt(pri / (dua + 1e-10)));
 }
 
@@ -549,8 +590,8 @@ int Engine::check_termination(const double *res, bool approximate) {
       }
     }
   }
-  double mx = unsc ? cinv_ * std::max(std::max(res[R_ATY_U], res[R_PX_U]), qnorm_u_)
-                   : std::max(std::max(res[R_ATY_S], res[R_PX_S]), qnorm_s_);             // :766-794
+  double mx = unsc ? cinv_ * std::max(std::max(res[R_ATY_U], res[R_PX_U]), res[R_QN_U])
+                   : std::max(std::max(res[R_ATY_S], res[R_PX_S]), res[R_QN_S]);             // :766-794
   if (info.dual_res < ea + er * mx) dua_ok = true;
   else {                                                                                // is_dual_infeasible :822-878
     double nd = unsc ? res[R_DX_U] : res[R_DX_S], sc = unsc ? c_ : 1.0;
@@ -580,7 +621,7 @@ int Engine::solve() {
     if (err != OSQP_FUNC_NOT_IMPLEMENTED) return err;
   }
   stats_.pcg_iters_total = stats_.pcg_iters_max = stats_.pcg_unconverged = 0;
-  stats_.kernel_launches = stats_.graph_launches = 0;
+  stats_.kernel_launches = stats_.graph_launches = 0; stats_.cg_cap_escalations = 0;
   double res[R_COUNT];
   admm_core(t0, res);
   info.rho_estimate = rho_estimate(res);                                                 // :1275
@@ -602,7 +643,7 @@ int Engine::solve() {
 void Engine::admm_core(double t0, double *res) {
   const int ct = settings.check_termination;
   const int ari = settings.adaptive_rho ? auto_rho_interval() : 0;
-  const int cap = std::min(settings.cg_max_iter, kMaxCg);
+  int cap = std::min(settings.cg_max_iter, kMaxCg);    // PCG iterations per solve; escalated below when the PCG stagnates at it
   // Inexact inner solves bias the rho estimate (_osqp.py:880-908): their error shows up in the PRIMAL residual (measured at
   // config 2: 7.5x the primal residual of exact solves at an unchanged dual residual, estimate 0.6 rho instead of 0.2 rho), so
   // the last `tightW` iterations before every adaptation point run with a `tightF` times smaller PCG tolerance -- the bias
@@ -646,8 +687,20 @@ void Engine::admm_core(double t0, double *res) {
     return std::min(cap, std::max(2, std::min(flags[F_STAT_MAX], q3)) + slack);
   };
 
+  // cg_max_iter escalation: when most solves of a chunk ran into the cap itself the inner solver is stagnating (typically an
+  // unbounded LP / rank-deficient QP with n > m, whose reduced matrix has eigenvalues sigma = 1e-6: DESIGN.md section 5) and ADMM
+  // would crawl to max_iter on inexact steps where the direct path finishes in 25 iterations.  The cap then doubles (up to kMaxCg).
+  auto escalate = [&](bool tight, const int *flags) {
+    if (budget[tight] >= cap && cap < kMaxCg && flags[F_STAT_UNCONV] * 2 > std::max(1, flags[F_STAT_N])) {
+      cap = std::min(kMaxCg, 2 * cap);
+      stats_.cg_cap_escalations += 1;
+    }
+  };
+
+  double stall = 1.0, prev_dua = std::numeric_limits<double>::infinity(), prev_pri = std::numeric_limits<double>::infinity();
   int iter = 0;
-  int flags[F_COUNT];
+  int flags[F_COUNT], first_flags[F_COUNT];
+  bool first_flags_valid = false;
   while (true) {
     int next = settings.max_iter;
     if (ct > 0) next = std::min(next, (iter / ct + 1) * ct);
@@ -662,23 +715,62 @@ void Engine::admm_core(double t0, double *res) {
     if (full_budget) budget[0] = budget[1] = cap;
     if (tight && !tight_seen) { budget[1] = std::min(cap, 3 * budget[0] + 2); tight_seen = true; }
     be::set_pcg_tol(d_, tol_rel, tight ? std::max(tightF * tol_abs, kCgTolAbsMin) : tol_abs);
+    // The FIRST chunk is checkpointed: if the PCG starves at the cap in most of its solves, the chunk is repeated from the
+    // same iterates with a four times larger cap (ADMM steps taken with stagnating inner solves derail exactly the problems --
+    // unbounded / rank-deficient ones -- whose status the first checks decide; with the larger cap from the start the engine
+    // follows the direct path: DUAL_INFEASIBLE at iteration 25 instead of max_iter, tools/fuzz_gpu.py, tests/test_gpu_fuzz.py).
+    const bool first_chunk = iter == 0;
+    if (first_chunk && cap < kMaxCg) {
+      if (!ckpt_) ckpt_ = dev_vec<double>(d_, 2 * (size_t)n + 2 * (size_t)m);
+      be::copy_in(d_, ckpt_, d_.x, sizeof(double) * n, 1); be::copy_in(d_, ckpt_ + n, d_.xs, sizeof(double) * n, 1);
+      be::copy_in(d_, ckpt_ + 2 * (size_t)n, d_.z, sizeof(double) * m, 1); be::copy_in(d_, ckpt_ + 2 * (size_t)n + m, d_.y, sizeof(double) * m, 1);
+    }
     run_chunk(next - iter, budget[tight]);
     cg_budget_ = budget[tight];
-    iter = next;
-    const bool at_check = (ct > 0 && iter % ct == 0) || iter >= settings.max_iter || (ari > 0 && iter % ari == 0);
-    if (!at_check) {                                  // boundary of a tight window only: PCG statistics, no residuals
+    if (first_chunk && cap < kMaxCg) {
       be::fetch_flags(d_, flags);
+      if (budget[tight] >= cap && flags[F_STAT_UNCONV] * 2 > std::max(1, flags[F_STAT_N])) {
+        be::copy_in(d_, d_.x, ckpt_, sizeof(double) * n, 1); be::copy_in(d_, d_.xs, ckpt_ + n, sizeof(double) * n, 1);
+        be::copy_in(d_, d_.z, ckpt_ + 2 * (size_t)n, sizeof(double) * m, 1); be::copy_in(d_, d_.y, ckpt_ + 2 * (size_t)n + m, sizeof(double) * m, 1);
+        be::zero(d_, d_.dx, sizeof(double) * n); be::zero(d_, d_.dy, sizeof(double) * m);
+        be::init_iterates(d_, 0);
+        cap = std::min(kMaxCg, 4 * cap); budget[0] = budget[1] = cap;
+        stats_.cg_cap_escalations += 1;
+        stats_.kernel_launches = 0; stats_.graph_launches = 0;
+        continue;                                       // same chunk again (iter is still 0)
+      }
+      // keep the statistics of this chunk for the bookkeeping below (fetch_flags reset the device counters)
       stats_.pcg_iters_total += flags[F_STAT_SUM];
       stats_.pcg_iters_max = std::max(stats_.pcg_iters_max, (double)flags[F_STAT_MAX]);
       stats_.pcg_unconverged += flags[F_STAT_UNCONV];
+      first_flags_valid = true;
+      for (int k = 0; k < F_COUNT; k++) first_flags[k] = flags[k];
+    }
+    iter = next;
+    const bool at_check = (ct > 0 && iter % ct == 0) || iter >= settings.max_iter || (ari > 0 && iter % ari == 0);
+    if (!at_check) {                                  // boundary of a tight window only: PCG statistics, no residuals
+      if (first_flags_valid) { for (int k = 0; k < F_COUNT; k++) flags[k] = first_flags[k]; first_flags_valid = false; }
+      else {
+        be::fetch_flags(d_, flags);
+        stats_.pcg_iters_total += flags[F_STAT_SUM];
+        stats_.pcg_iters_max = std::max(stats_.pcg_iters_max, (double)flags[F_STAT_MAX]);
+        stats_.pcg_unconverged += flags[F_STAT_UNCONV];
+      }
+      escalate(tight, flags);
       budget[tight] = next_budget(budget[tight], flags);
       continue;
     }
     be::residuals(d_);
-    be::fetch_res_flags(d_, res, flags);
-    stats_.pcg_iters_total += flags[F_STAT_SUM];
-    stats_.pcg_iters_max = std::max(stats_.pcg_iters_max, (double)flags[F_STAT_MAX]);
-    stats_.pcg_unconverged += flags[F_STAT_UNCONV];
+    if (first_flags_valid) {                          // the first chunk's PCG statistics were read (and counted) above
+      be::fetch_res(d_, res);
+      for (int k = 0; k < F_COUNT; k++) flags[k] = first_flags[k];
+      first_flags_valid = false;
+    } else {
+      be::fetch_res_flags(d_, res, flags);
+      stats_.pcg_iters_total += flags[F_STAT_SUM];
+      stats_.pcg_iters_max = std::max(stats_.pcg_iters_max, (double)flags[F_STAT_MAX]);
+      stats_.pcg_unconverged += flags[F_STAT_UNCONV];
+    }
     const bool unsc = settings.scaling && !settings.scaled_termination;
     info.iter = iter;
     info.obj_val = (0.5 * res[R_XPX] + res[R_QX]) * (settings.scaling ? cinv_ : 1.0);      // _osqp.py:705-712
@@ -723,10 +815,18 @@ void Engine::admm_core(double t0, double *res) {
     // tolerance is a fraction of the current SCALED dual residual.  (Upstream's rule, fraction * sqrt(prim*dual)
     // [UPSTREAM-UNVERIFIED], lets r exceed the dual residual whenever prim >> dual; that biases the rho estimate of
     // _osqp.py:880-908 and was measured to cost 2-3x more ADMM iterations -- see DESIGN.md "PCG tolerance".)
+    // When NEITHER residual makes progress between two checks (an infeasible / unbounded problem: the dual residual of an
+    // unbounded LP stays O(1) for ever), a tolerance tied to the residual never tightens and the certificates of
+    // _osqp.py:796-878 -- conditions on dx, dy relative to 1e-4 ||dx|| -- are never met by the inexact steps: the tolerance
+    // then drops by 10x per stalled check (and recovers when progress resumes).
+    if (res[R_DUA_S] > 0.9 * prev_dua && res[R_PRI_S] > 0.9 * prev_pri) stall = std::max(1e-8, 0.1 * stall);
+    else stall = std::min(1.0, 10.0 * stall);
+    prev_dua = res[R_DUA_S]; prev_pri = res[R_PRI_S];
     double eps = settings.cg_tol_fraction * res[R_DUA_S];
     eps = std::max(std::min(eps, eps_cg_prev_), kCgTolAbsMin);
-    if (std::isfinite(eps)) { eps_cg_prev_ = eps; tol_rel = 1e-14; tol_abs = eps; have_tol_ = true; }
+    if (std::isfinite(eps)) { eps_cg_prev_ = eps; tol_rel = 1e-14; tol_abs = std::max(eps * stall, kCgTolAbsMin); have_tol_ = true; }
     // PCG budget for the next chunk of this kind: track what the last chunk needed
+    escalate(tight, flags);
     budget[tight] = next_budget(budget[tight], flags);
   }
 }
@@ -740,6 +840,7 @@ void Engine::admm_core(double t0, double *res) {
 // tighter.  Acceptance test and the normal-cone projection follow the reference (:1780-1793).
 void Engine::polish() {
   const double tp = now_s();
+  ensure_host_vectors();
   const bool unsc = settings.scaling && !settings.scaled_termination;
   std::vector<double> z(m), y(m);
   be::d2h(d_, z.data(), d_.z, sizeof(double) * m);
@@ -771,9 +872,12 @@ void Engine::polish() {
   settings.check_termination = set0.check_termination > 0 ? std::min(set0.check_termination, 10) : 10;
   settings.adaptive_rho_interval = 2 * settings.check_termination;
   double res[R_COUNT];
-  admm_core(now_s(), res);
-  const OSQPInfo info_red = info;     // residuals w.r.t. the REDUCED problem (diagnostic only)
-  (void)info_red;
+  try { admm_core(now_s(), res); }
+  catch (...) {                       // a device failure mid-polish must not leave the polish's settings / bounds on the handle
+    settings = set0; info = info0; rho_bar_ = rho0; settings.rho = rho0; ls_ = ls0; us_ = us0;
+    classify_constraints(ls_, us_);
+    throw;
+  }
   // polished point against the ORIGINAL problem: z = A x, then the normal-cone projection of (z, y)  (:1773-1780)
   settings = set0; info = info0;
   apply_scaled_bounds(ls0, us0);
@@ -842,40 +946,86 @@ int Engine::warm_start(const double *x, const double *y) {                      
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);
   settings.warm_starting = 1;
-  if (x) {
-    std::vector<double> xs(n);
-    for (int j = 0; j < n; j++) xs[j] = x[j] * Dinv_[j];
-    be::h2d(d_, d_.x, xs.data(), sizeof(double) * n);
-  }
-  if (y) {
-    std::vector<double> ys(m);
-    for (int i = 0; i < m; i++) ys[i] = y[i] * Einv_[i] * c_;   // inverse of y = cinv E y_scaled (:1112); the C core includes c
-    be::h2d(d_, d_.y, ys.data(), sizeof(double) * m);
+  if (be::device_vec_updates()) {                      // raw vectors go up as they are; x = Dinv x, y = c Einv y on the device
+    double *sx = d_.w, *sy = d_.t;                     // PCG work vectors are free between solves
+    if (x) be::copy_in(d_, sx, x, sizeof(double) * n, 0);
+    if (y) be::copy_in(d_, sy, y, sizeof(double) * m, 0);
+    be::scale_warm(d_, x ? sx : nullptr, y ? sy : nullptr, c_);
+  } else {
+    if (x) {
+      std::vector<double> xs(n);
+      for (int j = 0; j < n; j++) xs[j] = x[j] * Dinv_[j];
+      be::h2d(d_, d_.x, xs.data(), sizeof(double) * n);
+    }
+    if (y) {
+      std::vector<double> ys(m);
+      for (int i = 0; i < m; i++) ys[i] = y[i] * Einv_[i] * c_;   // inverse of y = cinv E y_scaled (:1112); the C core includes c
+      be::h2d(d_, d_.y, ys.data(), sizeof(double) * m);
+    }
   }
   be::init_iterates(d_, 1);                                         // z = A x (:1509)
+  return OSQP_NO_ERROR;
+}
+
+int Engine::warm_start_device(const double *x, const double *y, void *stream) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (!be::device_vec_updates()) return OSQP_FUNC_NOT_IMPLEMENTED;
+  be::activate(d_);
+  settings.warm_starting = 1;
+  be::stream_wait(d_, stream);
+  be::scale_warm(d_, x, y, c_);
+  be::init_iterates(d_, 1);
   return OSQP_NO_ERROR;
 }
 
 int Engine::update_data_vec(const double *q, const double *l, const double *u) {          // _osqp.py:1312-1367
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);
+  be::ext_wait(d_);                                 // a batch kernel on a caller's stream may still read the bounds / q
   double t0 = now_s();
   if (l || u) {
+    if (raw_stale_) ensure_host_vectors();
     for (int i = 0; i < m; i++) {
       double li = l ? l[i] : l0_[i], ui = u ? u[i] : u0_[i];
       if (!(li <= ui)) return OSQP_DATA_VALIDATION_ERROR;                                // :1348-1349
     }
   }
-  if (q) { q0_.assign(q, q + n); upload_q(); }
-  if (l) l0_.assign(l, l + m);
-  if (u) u0_.assign(u, u + m);
+  const bool dev = be::device_vec_updates();
+  if (q) { q0_.assign(q, q + n); if (dev) be::copy_in(d_, d_.qraw, q, sizeof(double) * n, 0); else upload_q(); }
+  if (l) { l0_.assign(l, l + m); if (dev) be::copy_in(d_, d_.lraw, l, sizeof(double) * m, 0); }
+  if (u) { u0_.assign(u, u + m); if (dev) be::copy_in(d_, d_.uraw, u, sizeof(double) * m, 0); }
+  if (dev) device_scale_vectors(q != nullptr, l || u);
+  else if (l || u) upload_bounds_and_types();                                           // update_rho_vec :526-562
   if (l || u) {
-    upload_bounds_and_types();                                                          // update_rho_vec :526-562
     be::set_rho(d_, rho_bar_);
     be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
   }
   set_status(OSQP_UNSOLVED);                                                             // reset_info :932-941
-  be::sync(d_);
+  if (!dev) be::sync(d_);                           // (device path: everything is stream-ordered; the next solve waits for it)
+  update_time_acc_ += now_s() - t0;
+  return OSQP_NO_ERROR;
+}
+
+// q / l / u given by DEVICE pointer (parametric re-solve with the data produced on the GPU, nn/torch.py:136-140): one device-to-device
+// copy per vector, then the same kernels.  The bounds are validated on the device BEFORE anything changes (one 4-byte read-back).
+int Engine::update_data_vec_device(const double *q, const double *l, const double *u, void *stream) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (!be::device_vec_updates()) return OSQP_FUNC_NOT_IMPLEMENTED;
+  be::activate(d_);
+  be::ext_wait(d_);
+  double t0 = now_s();
+  be::stream_wait(d_, stream);
+  if ((l || u) && be::count_bad_bounds(d_, l ? l : d_.lraw, u ? u : d_.uraw) > 0) return OSQP_DATA_VALIDATION_ERROR;
+  if (q) be::copy_in(d_, d_.qraw, q, sizeof(double) * n, 1);
+  if (l) be::copy_in(d_, d_.lraw, l, sizeof(double) * m, 1);
+  if (u) be::copy_in(d_, d_.uraw, u, sizeof(double) * m, 1);
+  if (q || l || u) raw_stale_ = true;
+  device_scale_vectors(q != nullptr, l || u);
+  if (l || u) {
+    be::set_rho(d_, rho_bar_);
+    be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  }
+  set_status(OSQP_UNSOLVED);
   update_time_acc_ += now_s() - t0;
   return OSQP_NO_ERROR;
 }
@@ -883,18 +1033,21 @@ int Engine::update_data_vec(const double *q, const double *l, const double *u) {
 int Engine::update_data_mat(const double *Px, const int *Px_idx, int P_n, const double *Ax, const int *Ax_idx, int A_n) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);
+  be::ext_wait(d_);
   double t0 = now_s();
   const int nzP = P_.nnz(), nzA = A_.nnz();
-  if (Px) {                                                   // bindings.cpp.in:240-281: idx == NULL means all entries in order
+  // bindings.cpp.in:240-281: idx == NULL means all entries in order.  Both arguments are validated BEFORE anything is changed:
+  // a rejected call leaves the host copies (and therefore the next upload) untouched.
+  if (Px) {
     if (Px_idx) { for (int k = 0; k < P_n; k++) if (Px_idx[k] < 0 || Px_idx[k] >= nzP) return OSQP_DATA_VALIDATION_ERROR; }
     else if (P_n != nzP && P_n != 0) return OSQP_DATA_VALIDATION_ERROR;
-    for (int k = 0; k < (Px_idx ? P_n : nzP); k++) P_.x[Px_idx ? Px_idx[k] : k] = Px[k];
   }
   if (Ax) {
     if (Ax_idx) { for (int k = 0; k < A_n; k++) if (Ax_idx[k] < 0 || Ax_idx[k] >= nzA) return OSQP_DATA_VALIDATION_ERROR; }
     else if (A_n != nzA && A_n != 0) return OSQP_DATA_VALIDATION_ERROR;
-    for (int k = 0; k < (Ax_idx ? A_n : nzA); k++) A_.x[Ax_idx ? Ax_idx[k] : k] = Ax[k];
   }
+  if (Px) for (int k = 0; k < (Px_idx ? P_n : nzP); k++) P_.x[Px_idx ? Px_idx[k] : k] = Px[k];
+  if (Ax) for (int k = 0; k < (Ax_idx ? A_n : nzA); k++) A_.x[Ax_idx ? Ax_idx[k] : k] = Ax[k];
   if (be::device_assembly()) {                                                           // _osqp.py:1443,:1463 on the device
     if (Px) be::h2d(d_, d_.Praw, P_.x.data(), sizeof(double) * nzP);
     if (Ax) be::h2d(d_, d_.Araw, A_.x.data(), sizeof(double) * nzA);
@@ -1222,9 +1375,11 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   prepare_batch_direct();                                     // (symbolic part runs on every backend: tests read the bandwidth)
   if (!be::batch_lds_bytes(n, m)) return OSQP_FUNC_NOT_IMPLEMENTED;
   be::activate(d_);
+  be::ext_wait(d_);                                 // the scratch block may still be read by a kernel on a caller's stream
   const bool timing = std::getenv("OSQP_HIP_BATCH_TIMING") != nullptr;
   double tph[5]; tph[0] = now_s();
   const size_t N = (size_t)nbatch * n, M = (size_t)nbatch * m;
+  if ((l || u) && !(l && u)) ensure_host_vectors();
   for (int b = 0; b < nbatch && (l || u); b++)                                                       // _osqp.py:1348-1349
     for (int i = 0; i < m; i++) {
       const double li = l ? l[(size_t)b * m + i] : l0_[i], ui = u ? u[(size_t)b * m + i] : u0_[i];
@@ -1235,9 +1390,10 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   const size_t need = 2 * N + 3 * M + (size_t)nbatch * 8 + n + 2 * (size_t)m;
   if (need > bbuf_cap_) { if (bbuf_) be::dfree(d_, bbuf_); bbuf_ = dev_vec<double>(d_, need); bbuf_cap_ = need; }
   double *dq = bbuf_, *dl = dq + N, *du = dl + M, *dx = du + M, *dy = dx + N, *drec = dy + M, *dq0 = drec + (size_t)nbatch * 8, *dl0 = dq0 + n, *du0 = dl0 + m;
-  if (q) be::h2d(d_, dq, q, sizeof(double) * N); else be::h2d(d_, dq0, q0_.data(), sizeof(double) * n);
-  if (l) be::h2d(d_, dl, l, sizeof(double) * M); else be::h2d(d_, dl0, l0_.data(), sizeof(double) * m);
-  if (u) be::h2d(d_, du, u, sizeof(double) * M); else be::h2d(d_, du0, u0_.data(), sizeof(double) * m);
+  const bool devv = be::device_vec_updates();         // then the solver's own q, l, u are resident (unscaled): no upload for NULL arguments
+  if (q) be::h2d(d_, dq, q, sizeof(double) * N); else if (devv) dq0 = d_.qraw; else be::h2d(d_, dq0, q0_.data(), sizeof(double) * n);
+  if (l) be::h2d(d_, dl, l, sizeof(double) * M); else if (devv) dl0 = d_.lraw; else be::h2d(d_, dl0, l0_.data(), sizeof(double) * m);
+  if (u) be::h2d(d_, du, u, sizeof(double) * M); else if (devv) du0 = d_.uraw; else be::h2d(d_, du0, u0_.data(), sizeof(double) * m);
   if (warm) { be::h2d(d_, dx, x, sizeof(double) * N); be::h2d(d_, dy, y, sizeof(double) * M); }
   be::sync(d_); tph[2] = now_s();
   BatchParams p{};
@@ -1267,13 +1423,9 @@ int Engine::batch_solve_device(int nbatch, const double *q, const double *l, con
   if (nbatch <= 0 || !x || !y || !rec) return OSQP_DATA_VALIDATION_ERROR;
   if (!be::batch_lds_bytes(n, m)) return OSQP_FUNC_NOT_IMPLEMENTED;
   be::activate(d_);
-  // shared vectors (for the arguments given as NULL) live in the solver's scratch block
-  const size_t need = n + 2 * (size_t)m;
-  if (need > bbuf_cap_) { if (bbuf_) be::dfree(d_, bbuf_); bbuf_ = dev_vec<double>(d_, need); bbuf_cap_ = need; }
-  double *dq0 = bbuf_ + bbuf_cap_ - need, *dl0 = dq0 + n, *du0 = dl0 + m;
-  if (!q) be::h2d(d_, dq0, q0_.data(), sizeof(double) * n);
-  if (!l) be::h2d(d_, dl0, l0_.data(), sizeof(double) * m);
-  if (!u) be::h2d(d_, du0, u0_.data(), sizeof(double) * m);
+  be::ext_wait(d_);                                 // the previous device-pointer call: its kernel reads the shared vectors and kp_val
+  // shared vectors (for the arguments given as NULL): the solver's own resident unscaled q, l, u
+  double *dq0 = d_.qraw, *dl0 = d_.lraw, *du0 = d_.uraw;
   BatchParams p{};
   fill_batch_params(p, nbatch, warm);
   p.q = q; p.l = l; p.u = u; p.q0 = dq0; p.l0 = dl0; p.u0 = du0; p.x = x; p.y = y; p.rec = rec;
@@ -1283,10 +1435,17 @@ int Engine::batch_solve_device(int nbatch, const double *q, const double *l, con
     attach_batch_direct(p);
   }
   be::sync(d_);                                   // the uploads and the product refresh ran on the solver's stream
-  return be::batch_solve(d_, p, stream);
+  const int err = be::batch_solve(d_, p, stream);
+  if (!err) be::ext_record(d_, stream);           // later calls that overwrite or free what this kernel reads wait for it (ext_wait)
+  return err;
 }
 
-int Engine::get_stats(OSQPHipStats *out) { if (!out) return OSQP_DATA_VALIDATION_ERROR; *out = stats_; out->pcg_fused = be::pcg_fused(d_) ? 1.0 : 0.0; out->batch_direct_bw = bd_.bw_symbolic; return OSQP_NO_ERROR; }
+int Engine::get_stats(OSQPHipStats *out) {
+  if (!out) return OSQP_DATA_VALIDATION_ERROR;
+  *out = stats_; out->pcg_fused = be::pcg_fused(d_) ? 1.0 : 0.0; out->batch_direct_bw = bd_.bw_symbolic;
+  out->windowed_blocks = d_.A.nwin + d_.B.nwin; out->row_blocks = d_.A.nblk + d_.B.nblk;
+  return OSQP_NO_ERROR;
+}
 int Engine::time_kernel(int which, int reps, double *ms) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);

@@ -30,6 +30,9 @@ class Engine {
   int warm_start(const double *x, const double *y);
   int cold_start();
   int update_data_vec(const double *q, const double *l, const double *u);
+  // the same with DEVICE pointers (this solver's GPU), ordered after the work queued on `stream` so far (NULL: nothing to wait for)
+  int update_data_vec_device(const double *q, const double *l, const double *u, void *stream);
+  int warm_start_device(const double *x, const double *y, void *stream);
   int update_data_mat(const double *Px, const int *Px_idx, int P_n, const double *Ax, const int *Ax_idx, int A_n);
   int update_settings(const OSQPSettings *s);
   int update_rho(double rho);
@@ -64,7 +67,6 @@ class Engine {
   std::vector<int> ctype_;
   std::vector<double> ls_, us_;         // scaled bounds currently on the device
   std::vector<double> sol_x_, sol_y_, sol_pc_, sol_dc_;
-  double qnorm_s_ = 0, qnorm_u_ = 0;    // ||q_scaled||_inf, ||Dinv q_scaled||_inf
   // maps for value updates
   std::vector<int> Pmap1_, Pmap2_, AmapA_, AmapB_, bdiag_;
   std::vector<double> Aval_, Bval_;     // host mirrors of the scaled device value arrays
@@ -74,6 +76,8 @@ class Engine {
   // ---- driver state ----
   double rho_bar_ = 0.1;
   double eq_factor_mixed_ = 10.0;     // see classify_constraints()
+  bool eq_factor_env_ = false;        // OSQP_HIP_RHO_EQ_FACTOR given
+  double mixed_eq_factor() const;
   bool eq_factor_set_ = false;        // osqp_hip_set_rho_eq_factor was called: the batch path's direct variant honours it too
   int cg_budget_ = 0;
   double eps_cg_prev_ = 0;
@@ -82,6 +86,7 @@ class Engine {
   bool use_graph_ = true;
   std::map<std::pair<int, int>, void *> graphs_;
   double *bbuf_ = nullptr; size_t bbuf_cap_ = 0;      // device scratch of batch_solve, kept across calls
+  double *ckpt_ = nullptr;                            // device copy of (x, x~, z, y) taken before a solve's first chunk (cg cap escalation)
   std::vector<double> ls_rho_;                        // LinSysSolver slot: host copy of rho_vec
   std::vector<int> Arp_, Arj_, Brp_, Bj_;             // host copies of the CSR structure of A and B (symbolic work of the batch path)
   // direct (banded Cholesky) linear solve of the batch path: symbolic data, built on first use
@@ -106,6 +111,9 @@ class Engine {
   void scale_matrix_values(std::vector<double> &Px_s, std::vector<double> &Ax_s) const;
   void classify_constraints(const std::vector<double> &l_s, const std::vector<double> &u_s);
   void upload_bounds_and_types();
+  void device_scale_vectors(bool q, bool bounds);
+  void ensure_host_vectors();           // host mirrors of q, l, u (unscaled), the scaled bounds and the constraint types, refreshed on demand
+  bool raw_stale_ = false, scaled_stale_ = false;
   void upload_q();
   void fill_matrix_values(const std::vector<double> &Px_s, const std::vector<double> &Ax_s);
   void run_chunk(int niter, int budget);

@@ -56,7 +56,8 @@ class SolverStruct(C.Structure):
 
 class StatsStruct(C.Structure):
     _fields_ = [(k, C.c_double) for k in ('pcg_iters_total', 'pcg_iters_max', 'pcg_unconverged', 'kernel_launches',
-                                          'graph_launches', 'gpu_solve_ms', 'nnzA', 'nnzB', 'pcg_fused', 'batch_direct_bw')]
+                                          'graph_launches', 'gpu_solve_ms', 'nnzA', 'nnzB', 'pcg_fused', 'batch_direct_bw',
+                                          'cg_cap_escalations', 'windowed_blocks', 'row_blocks')]
 
 
 SolverP = C.POINTER(SolverStruct)
@@ -107,6 +108,8 @@ PROTOTYPES = {
     'osqp_hip_set_rho_eq_factor': (C.c_int, [SolverP, C.c_double]),
     'osqp_hip_batch_solve': (C.c_int, [SolverP, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),
     'osqp_hip_batch_solve_device': (C.c_int, [SolverP, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'osqp_hip_update_data_vec_device': (C.c_int, [SolverP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'osqp_hip_warm_start_device': (C.c_int, [SolverP, C.c_void_p, C.c_void_p, C.c_void_p]),
     'osqp_hip_get_scaling': (C.c_int, [SolverP, c_double_p, c_double_p, c_double_p]),
     'osqp_hip_backend': (C.c_char_p, []),
     'osqp_hip_linsys_init': (C.c_int, [C.POINTER(LinSysP), C.POINTER(CscStruct), C.POINTER(CscStruct), c_double_p,

@@ -187,6 +187,14 @@ class OSQPSolver:
         q, l, u = _vec(q), _vec(l), _vec(u)
         return self._lib.osqp_update_data_vec(self._p, _ptr(q, _lib.c_double_p), _ptr(l, _lib.c_double_p), _ptr(u, _lib.c_double_p))
 
+    def hip_update_data_vec_device(self, q_ptr=None, l_ptr=None, u_ptr=None, stream=None):
+        """osqp_hip_update_data_vec_device: raw device addresses (int or None = unchanged) of UNSCALED float64 vectors on this
+        solver's GPU, e.g. torch_tensor.data_ptr(); ordered after the work queued on `stream` (hipStream_t handle as int)."""
+        return self._lib.osqp_hip_update_data_vec_device(self._p, q_ptr, l_ptr, u_ptr, stream)
+
+    def hip_warm_start_device(self, x_ptr=None, y_ptr=None, stream=None):
+        return self._lib.osqp_hip_warm_start_device(self._p, x_ptr, y_ptr, stream)
+
     def update_data_mat(self, P_x=None, P_i=None, A_x=None, A_i=None):        # bindings.cpp.in:240-281
         P_x, A_x = _vec(P_x), _vec(A_x)
         P_i, A_i = _vec(P_i, np.int32), _vec(A_i, np.int32)
@@ -248,7 +256,8 @@ class OSQPSolver:
         arrs = [a for a in (q, l, u, x0, y0) if a is not None]
         B = int(nbatch) if nbatch is not None else int(np.asarray(arrs[0]).shape[0])
         q, l, u = (None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(B, -1) for a in (q, l, u))
-        warm = x0 is not None      # (l, u are clamped to +-OSQP_INFTY inside the kernel, like interface.py:334-337) or y0 is not None
+        warm = x0 is not None or y0 is not None      # a missing one starts from zero, like warm_start(x=None) / (y=None) of a single solver
+        # (l, u are clamped to +-OSQP_INFTY inside the kernel, like interface.py:334-337)
         x = np.zeros((B, self.n)) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).reshape(B, self.n).copy()
         y = np.zeros((B, self.m)) if y0 is None else np.ascontiguousarray(y0, dtype=np.float64).reshape(B, self.m).copy()
         rec = np.zeros((B, 8))

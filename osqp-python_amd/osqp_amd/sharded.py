@@ -60,8 +60,35 @@ def solve_batch_sharded(solver, q=None, l=None, u=None, rank=0, world=1, device=
     B = next(np.asarray(a).shape[0] for a in (q, l, u) if a is not None)
     lo, hi = shard_range(B, rank, world)
     sl = lambda a: None if a is None else np.asarray(a)[lo:hi]
-    x, y, rec = solver._solver.hip_batch_solve(q=sl(q), l=sl(l), u=sl(u), nbatch=hi - lo)
+    try:
+        x, y, rec = solver._solver.hip_batch_solve(q=sl(q), l=sl(l), u=sl(u), nbatch=hi - lo)
+    except ValueError:                         # the problem does not fit the one-workgroup batch kernel: this rank's share, one
+        x = np.zeros((hi - lo, solver.n)); y = np.zeros((hi - lo, solver.m)); rec = np.zeros((hi - lo, 8))   # update()+solve() at a time
+        for k in range(hi - lo):
+            solver.update(**{name: a[k] for name, a in (('q', sl(q)), ('l', sl(l)), ('u', sl(u))) if a is not None})
+            r = solver.solve()
+            x[k], y[k] = r.x, r.y
+            rec[k, 0:5] = (r.info.status_val, r.info.iter, r.info.obj_val, r.info.prim_res, r.info.dual_res)
     recs = np.zeros((hi - lo, len(RECORD_FIELDS)))
     recs[:, 0] = np.arange(lo, hi)
     recs[:, 1:6] = rec[:, 0:5]                 # status_val, iter, obj_val, prim_res, dual_res
     return gather_records(recs, B, device=device), x, y, (lo, hi)
+
+
+def gather_rows(rows_local, nproblems, device=None):
+    """all_gather of per-problem rows (e.g. the solutions x of every rank's share, block-partitioned like shard_range):
+    every rank returns the full (nproblems x k) array in problem order.  One collective; shares may differ by one row."""
+    import torch
+    import torch.distributed as dist
+    rows_local = np.asarray(rows_local, dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rows_local
+    world = dist.get_world_size()
+    spans = [shard_range(nproblems, r, world) for r in range(world)]
+    share = max(hi - lo for lo, hi in spans)
+    pad = np.zeros((share, rows_local.shape[1]))
+    pad[:len(rows_local)] = rows_local
+    t = torch.as_tensor(pad, dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return np.concatenate([o.cpu().numpy()[:hi - lo] for o, (lo, hi) in zip(out, spans)])

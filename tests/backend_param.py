@@ -6,7 +6,12 @@ import contextlib
 
 import pytest
 
-BACKENDS = [pytest.param('hostsim'), pytest.param('hip', marks=pytest.mark.gpu)]
+import os
+
+# 'hip'      small problems take the one-launch direct path (banded LDL' in LDS, batch_hip.hip) -- the default
+# 'hip-pcg'  OSQP_HIP_SMALL_DIRECT=0: the same problems through the multi-kernel PCG engine (backend_hip.hip), so that the
+#            reference's goldens pin BOTH kernels
+BACKENDS = [pytest.param('hostsim'), pytest.param('hip', marks=pytest.mark.gpu), pytest.param('hip-pcg', marks=pytest.mark.gpu)]
 
 
 @contextlib.contextmanager
@@ -20,4 +25,12 @@ def engine(backend):
         from osqp_amd import _lib
         h = _lib.handle()
         assert h.osqp_hip_backend() == b'hip-gfx950', 'GPU tier must run the HIP library'
-        yield h
+        old = os.environ.get('OSQP_HIP_SMALL_DIRECT')
+        os.environ['OSQP_HIP_SMALL_DIRECT'] = '0' if backend == 'hip-pcg' else '1'
+        try:
+            yield h
+        finally:
+            if old is None:
+                os.environ.pop('OSQP_HIP_SMALL_DIRECT', None)
+            else:
+                os.environ['OSQP_HIP_SMALL_DIRECT'] = old

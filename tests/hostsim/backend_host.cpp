@@ -33,6 +33,15 @@ void d2h(Dev &, void *dst, const void *src, size_t b) { std::memcpy(dst, src, b)
 void zero(Dev &, void *dst, size_t b) { std::memset(dst, 0, b); }
 void sync(Dev &) {}
 void activate(Dev &) {}
+bool device_vec_updates() { return false; }
+void copy_in(Dev &, void *dst, const void *src, size_t bytes, int) { std::memcpy(dst, src, bytes); }
+void stream_wait(Dev &, void *) {}
+void scale_q(Dev &, double) {}
+void scale_bounds(Dev &, int) {}
+int count_bad_bounds(Dev &, const double *, const double *) { return 0; }
+void scale_warm(Dev &, const double *, const double *, double) {}
+void ext_record(Dev &, void *) {}
+void ext_wait(Dev &) {}
 
 void kb_rhs(Dev &d) {
   Impl &s = im(d);
@@ -121,7 +130,7 @@ void ka(Dev &d, int budget) {
 
 void residuals(Dev &d) {
   double *R = d.res;
-  for (int q = 0; q <= R_QDX; q++) R[q] = 0;
+  for (int q = 0; q <= R_QN_U; q++) R[q] = 0;
   for (int i = 0; i < d.m; i++) {
     double ax = 0;
     for (int k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; k++) ax += d.A.val[k] * d.x[d.A.col[k]];
@@ -143,6 +152,7 @@ void residuals(Dev &d) {
     R[R_DUA_S] = nanmax(R[R_DUA_S], std::fabs(dr)); R[R_PX_S] = nanmax(R[R_PX_S], std::fabs(px)); R[R_ATY_S] = nanmax(R[R_ATY_S], std::fabs(sa));
     R[R_DX_U] = nanmax(R[R_DX_U], std::fabs(d.D[j] * d.dx[j])); R[R_DX_S] = nanmax(R[R_DX_S], std::fabs(d.dx[j]));
     R[R_XPX] += d.x[j] * px; R[R_QX] += d.q[j] * d.x[j]; R[R_QDX] += d.q[j] * d.dx[j];
+    R[R_QN_S] = nanmax(R[R_QN_S], std::fabs(d.q[j])); R[R_QN_U] = nanmax(R[R_QN_U], std::fabs(di * d.q[j]));
   }
 }
 

@@ -49,6 +49,39 @@ def test_config2_full_size_matches_oracle_direct_solution():
     assert abs(r.info.obj_val - io.obj_val) <= 1e-6 * (1 + abs(io.obj_val))
 
 
+def _tight(P, q, A, l, u, atol=2e-6, **st):
+    """eps = 1e-8 on both sides: the two iterates are then within ~1e-8-accurate KKT points of the same QP, so they are compared at
+    north_star's bar itself (atol 2e-6 relative to the solution's scale) -- the leg where a wrong answer would bite."""
+    kw = dict(eps_abs=1e-8, eps_rel=1e-8, max_iter=50000, adaptive_rho_interval=50, check_termination=25)
+    kw.update(st)
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, **kw)
+    r = m.solve()
+    certify(P, q, A, l, u, r, eps=1e-8)
+    xo, yo, io = Oracle().setup(P, q, A, l, u, **kw).solve()
+    assert io.status_val == SOLVED
+    ex = np.abs(r.x - xo).max() / (1 + np.abs(xo).max()); ey = np.abs(r.y - yo).max() / (1 + np.abs(yo).max())
+    print('eps 1e-8: engine %d iterations, oracle %d; |dx| %.2e |dy| %.2e (relative) |dobj| %.2e' % (r.info.iter, io.iter, ex, ey, abs(r.info.obj_val - io.obj_val)))
+    assert ex <= atol and ey <= atol
+    assert abs(r.info.obj_val - io.obj_val) <= 1e-8 * (1 + abs(io.obj_val))
+    return r, io
+
+
+def test_config2_full_size_tight_tolerance():
+    """BASELINE configs[1] at full size, eps_abs = eps_rel = 1e-8, x and y within 2e-6 of the oracle's direct-LDL' solution."""
+    _tight(*problems.banded_qp(100000))
+
+
+def test_config4_portfolio_full_size_tight_tolerance():
+    """BASELINE configs[3] at full size (n = 10k assets, k = 100 factors), eps 1e-8 against the oracle's direct solve."""
+    _tight(*problems.portfolio_qp(10000, 100))
+
+
+def test_config3_lasso_tight_tolerance():
+    """BASELINE configs[2] (lasso, dense data block) at a size the oracle factorises in seconds (500 features x 1000 samples: 0.5M
+    stored entries, long-row SpMV path), eps 1e-8."""
+    _tight(*problems.lasso_qp(500, 1000))
+
+
 def test_ten_times_config2_kkt_certificate():
     """n = 1M, m = 2M, nnz(A) = 10M (each workgroup streams ~10 row blocks per kernel: the multi-block path of every sparse
     kernel, 0.5 GB of matrices): optimality certificate of the returned (x, y) recomputed on the host."""

@@ -130,6 +130,35 @@ def test_nn_module_forward_zero_copy_device_tensors():
         layer(Pv, qd, Av, Lb, Ub)
 
 
+def test_nn_module_keeps_one_solver_across_forwards():
+    """The reference keeps its solver objects across forward calls and only update()s them (nn/torch.py:113-140).  Here: one
+    osqp_setup for any number of same-structure forwards (host and device tensors), a changed P_val / A_val goes through
+    update_data_mat (device re-assembly), and every later forward equals a freshly set-up layer's result bit for bit."""
+    import torch
+    from osqp_amd.nn.torch import OSQP as OSQPLayer
+    B = 16
+    P, q, A, L, U = problems.mpc_batch(B, seed=5)
+    Pc, Ac = P.tocoo(), A.tocoo()
+    mk = lambda: OSQPLayer((Pc.row, Pc.col), P.shape, (Ac.row, Ac.col), A.shape, eps_abs=1e-6, eps_rel=1e-6)
+    layer = mk()
+    Pv, Av = torch.tensor(Pc.data), torch.tensor(Ac.data)
+    qv = torch.zeros(B, P.shape[0], dtype=torch.float64)
+    t = lambda a: torch.tensor(a)
+    layer(Pv, qv, Av, t(L), t(U))
+    x2 = layer(Pv, qv, Av, t(L + 0.05), t(U + 0.05))                              # new bounds only
+    assert layer.setup_count == 1
+    assert torch.equal(x2, mk()(Pv, qv, Av, t(L + 0.05), t(U + 0.05)))
+    dev = torch.device('cuda:0')
+    x3 = layer(Pv, qv.to(dev), Av, t(L + 0.05).to(dev), t(U + 0.05).to(dev))      # device tensors: same handle (device 0)
+    assert layer.setup_count == 1 and torch.equal(x3.cpu(), x2)
+    x4 = layer(Pv * 1.5, qv, Av * 0.9, t(L), t(U))                                # new matrix VALUES: update_data_mat, no setup
+    assert layer.setup_count == 1
+    x4f = mk()(Pv * 1.5, qv, Av * 0.9, t(L), t(U))
+    assert torch.allclose(x4, x4f, atol=5e-5)                                     # (scaling D, E, c stays that of the first setup: _osqp.py:1443)
+    x5 = layer(Pv, qv, Av, t(L), t(U))                                            # and back
+    assert layer.setup_count == 1 and torch.allclose(x5, mk()(Pv, qv, Av, t(L), t(U)), atol=5e-5)
+
+
 @pytest.mark.parametrize('variant', ['direct', 'direct256', 'w64'])
 def test_batch_variants_agree_with_oracle(variant, monkeypatch):
     """Both linear-solve variants of the batch kernel (banded Cholesky in LDS / PCG) on the same MPC batch; the direct one

@@ -61,3 +61,49 @@ def test_shard_range_partition():
         for w in (1, 2, 3, 8):
             r = [shard_range(B, k, w) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == B and all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+
+
+LAYER_WORKER = r'''
+import os, sys, warnings
+warnings.simplefilter('ignore')
+root = sys.argv[1]
+for p in (root, os.path.join(root, 'osqp-python_amd'), os.path.join(root, 'tests'), os.path.join(root, 'oracle')):
+    sys.path.insert(0, p)
+import numpy as np, torch, torch.distributed as dist
+import problems
+from hostsim_util import hostsim
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%s' % os.environ['MASTER_PORT'], rank=rank, world_size=world)
+P, q, A, L, U = problems.mpc_batch(5, nx=3, nu=2, N=4)          # 5 problems: ragged shares over 2 ranks
+P = P.tocoo(); A = A.tocoo()
+with hostsim():
+    from osqp_amd.nn.torch import OSQP as Layer
+    layer = Layer((P.row, P.col), P.shape, (A.row, A.col), A.shape, eps_abs=1e-7, eps_rel=1e-7)
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    x1 = layer(t(P.data), t(q), t(A.data), t(L), t(U))
+    x2 = layer(t(P.data), t(q), t(A.data), t(L + 0.01), t(U + 0.01))       # second forward: no new setup
+    np.save(os.path.join(sys.argv[2], 'layer_%d.npy' % rank), np.stack([x1.numpy(), x2.numpy()]))
+    assert layer.setup_count == 1, layer.setup_count
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_torch_layer_two_rank_gloo(tmp_path):
+    """The torch layer under torch.distributed: the batch is block-partitioned over the ranks, rows are all-gathered, every rank
+    returns the full solution; the handle is set up once for both forwards (reference: nn/torch.py:136-140)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'layer_worker.py'
+    script.write_text(LAYER_WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29519', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script), root, str(tmp_path)], env=dict(env, RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    a, b = np.load(tmp_path / 'layer_0.npy'), np.load(tmp_path / 'layer_1.npy')
+    assert np.array_equal(a, b) and a.shape[:2] == (2, 5)
+    sys.path.insert(0, os.path.join(root, 'oracle')); sys.path.insert(0, root)
+    import problems
+    from oracle import Oracle
+    P, q, A, L, U = problems.mpc_batch(5, nx=3, nu=2, N=4)
+    for i in (0, 4):
+        xo, yo, io = Oracle().setup(P, q, A, L[i], U[i], eps_abs=1e-9, eps_rel=1e-9, adaptive_rho_interval=50).solve()
+        assert np.abs(a[0, i] - xo).max() < 1e-5 * (1 + np.abs(xo).max())
