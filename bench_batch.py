@@ -16,6 +16,19 @@ for _p in (ROOT, os.path.join(ROOT, 'osqp-python_amd'), os.path.join(ROOT, 'orac
         sys.path.insert(0, _p)
 
 
+_CPU = {}
+
+
+def _cpu_init(P, q, A):
+    _CPU['pqa'] = (P, q, A)
+
+
+def _cpu_solve(lu):
+    from oracle import Oracle
+    P, q, A = _CPU['pqa']
+    return Oracle().setup(P, q, A, lu[0], lu[1], eps_abs=1e-6, eps_rel=1e-6, adaptive_rho_interval=50, check_termination=25).solve()[2].iter
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1); ap.add_argument('--steps', type=int, default=5); ap.add_argument('--warmup', type=int, default=1)
@@ -63,15 +76,37 @@ def main():
                           'ms_per_step_median': float(sorted(step_ms)[len(step_ms) // 2]), 'kernel_ms_last_step': s._solver.hip_stats()['gpu_solve_ms'],
                           'solved': int((table[:, 1] == 1).sum()), 'admm_iters_total': float(table[:, 2].sum()),
                           'admm_iters_per_s': float(table[:, 2].sum()) * args.steps / el}}
+        # Roofline of the batch kernel (k_batch_admm<256, 8, 8, true>, one workgroup per QP, everything in LDS / registers): neither HBM
+        # (7.7 KB of vectors per QP in and out) nor MFMA applies.  What bounds it is the DEPENDENT chain of the two banded
+        # triangular substitutions of every ADMM iteration, which run on one wave: 2n pivots, each one broadcast (v_readlane pair)
+        # + one fp64 FMA that the next pivot depends on.  Floor = 2n pivots x kChainCycles at the 2.4 GHz peak clock with the CU's
+        # problems perfectly overlapped; achieved = ADMM iterations per second per resident problem.  
+        n_var = P.shape[0]
+        kChainCycles = 16.0           # dependent readlane + v_fma_f64 per pivot (MI355X_MICROARCH.md: ~4-cycle issue slots, 64-bit FMA on a SIMD-32)
+        kernel_s = 1e-3 * s._solver.hip_stats()['gpu_solve_ms']
+        iters_per_qp = float(table[:, 2].sum()) / B
+        resident = 2 * 256            # two problems per CU (69 KB of LDS each), 256 CUs
+        waves_of_qps = -(-int(B // world) // resident)
+        t_iter = kernel_s / (waves_of_qps * iters_per_qp)              # wall time of one ADMM iteration of a resident QP
+        floor_iter = 2 * n_var * kChainCycles / 2.4e9
+        out['roofline'] = {'bound': 'latency', 'kernel': 'k_batch_admm<256,8,8,true>', 'unit': 'ADMM iter/s per resident QP',
+                           'achieved': 1.0 / t_iter, 'peak': 1.0 / floor_iter, 'frac': floor_iter / t_iter, 'traffic': None,
+                           'model': 'dependent chain of the banded substitutions: 2n = %d pivots x %.0f cycles at 2.4 GHz = %.2f us per ADMM iteration; '
+                                    'measured %.2f us (%.1f ADMM iterations per QP, %d QPs resident at a time, kernel %.2f ms)'
+                                    % (2 * n_var, kChainCycles, 1e6 * floor_iter, 1e6 * t_iter, iters_per_qp, resident, 1e3 * kernel_s)}
         if args.cpu_sample > 0:
-            from oracle import Oracle
-            t0 = time.perf_counter(); its = 0
-            for i in range(args.cpu_sample):
-                xo, yo, io = Oracle().setup(P, q, A, L[i], U[i], eps_abs=1e-6, eps_rel=1e-6, adaptive_rho_interval=50, check_termination=25).solve()
-                its += io.iter
-            dt = time.perf_counter() - t0
-            out['cpu_baseline'] = {'value': args.cpu_sample / dt, 'unit': 'QP/s', 'cores': 1, 'kind': 'port',
-                                   'sample': '%d of the %d QPs, oracle direct LDL\' (setup+solve per problem), %d ADMM iterations in %.2f s' % (args.cpu_sample, B, its, dt)}
+            import multiprocessing as mp
+            cores = os.cpu_count() or 1
+            sample = max(args.cpu_sample, 4 * cores)
+            sample = min(sample, B)
+            with mp.get_context('spawn').Pool(cores, initializer=_cpu_init, initargs=(P, q, A)) as pool:      # (spawn: the parent holds a HIP context)
+                pool.map(_cpu_solve, [(L[i], U[i]) for i in range(min(cores, sample))])          # warm the workers (library load)
+                t0 = time.perf_counter()
+                its = sum(pool.map(_cpu_solve, [(L[i], U[i]) for i in range(sample)], chunksize=max(1, sample // (4 * cores))))
+                dt = time.perf_counter() - t0
+            out['cpu_baseline'] = {'value': sample / dt, 'unit': 'QP/s', 'cores': cores, 'kind': 'port',
+                                   'sample': '%d of the %d QPs over %d worker processes (one per host core), oracle direct LDL\' (setup+solve per '
+                                             'problem), %d ADMM iterations in %.2f s' % (sample, B, cores, its, dt)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()

@@ -601,10 +601,37 @@ int Engine::check_termination(const double *res, bool approximate) {
       if ((unsc ? r2[R_PDX_U] : r2[R_PDX_S]) < sc * edi * nd && r2[R_ADX_VIOL] == 0.0) dual_inf = true;
     }
   }
-  if (pri_ok && dua_ok) { set_status(approximate ? OSQP_SOLVED_INACCURATE : OSQP_SOLVED); return 1; }
+  // check_dualgap (bindings.cpp.in:442): additionally |duality gap| < eps_abs + eps_rel max(|obj|, |dual obj|)   [UPSTREAM-UNVERIFIED form]
+  const bool gap_ok = !settings.check_dualgap ||
+                      std::fabs(info.duality_gap) < ea + er * std::max(std::fabs(info.obj_val), std::fabs(info.dual_obj_val));
+  if (pri_ok && dua_ok && gap_ok) { set_status(approximate ? OSQP_SOLVED_INACCURATE : OSQP_SOLVED); return 1; }
   if (prim_inf) { set_status(approximate ? OSQP_PRIMAL_INFEASIBLE_INACCURATE : OSQP_PRIMAL_INFEASIBLE); info.obj_val = OSQP_INFTY; return 1; }
   if (dual_inf) { set_status(approximate ? OSQP_DUAL_INFEASIBLE_INACCURATE : OSQP_DUAL_INFEASIBLE); info.obj_val = -OSQP_INFTY; return 1; }
   return 0;
+}
+
+// The v1 info fields beyond purepy's (bindings.cpp.in:475, 478, 491-492; defined by the un-vendored C core, so the formulas
+// are this engine's reading of their names [UPSTREAM-UNVERIFIED]):
+//   dual_obj_val   -1/2 x'Px - sup_{l <= z <= u} y'z   (the support function of the box at y; finite where y respects infinite bounds)
+//   duality_gap    obj_val - dual_obj_val
+//   rel_kkt_error  max( prim_res / max(||Ax||, ||z||),  dual_res / max(||Px||, ||A'y||, ||q||),  |gap| / max(|obj|, |dual obj|) )
+//   primdual_int   integral over the solve time of |duality_gap| (accumulated at the termination checks)
+// t0 < 0: no time integration (polish).
+void Engine::update_gap_info(const double *res, double t0) {
+  const bool unsc = settings.scaling && !settings.scaled_termination;
+  const double ci = settings.scaling ? cinv_ : 1.0;
+  info.dual_obj_val = (-0.5 * res[R_XPX] - res[R_SUPP]) * ci;
+  info.duality_gap = info.obj_val - info.dual_obj_val;
+  const double pn = unsc ? std::max(res[R_AX_U], res[R_Z_U]) : std::max(res[R_AX_S], res[R_Z_S]);
+  const double dn = unsc ? cinv_ * std::max(std::max(res[R_ATY_U], res[R_PX_U]), res[R_QN_U]) : std::max(std::max(res[R_ATY_S], res[R_PX_S]), res[R_QN_S]);
+  const double gn = std::max(std::fabs(info.obj_val), std::fabs(info.dual_obj_val));
+  const double tiny = 1e-10;
+  info.rel_kkt_error = std::max(std::max(m == 0 ? 0.0 : info.prim_res / (pn + tiny), info.dual_res / (dn + tiny)), std::fabs(info.duality_gap) / (gn + tiny));
+  if (t0 >= 0) {
+    const double t = now_s() - t0;
+    info.primdual_int += std::fabs(info.duality_gap) * std::max(0.0, t - gap_time_);
+    gap_time_ = t;
+  }
 }
 
 int Engine::solve() {
@@ -614,7 +641,7 @@ int Engine::solve() {
   if (clear_update_time_) { info.update_time = 0; }
   info.update_time += update_time_acc_; update_time_acc_ = 0;
   if (!settings.warm_starting) cold_start();                                            // _osqp.py:1204-1205
-  info.rho_updates = 0; info.status_polish = 0; info.polish_time = 0;
+  info.rho_updates = 0; info.status_polish = 0; info.polish_time = 0; info.primdual_int = 0; gap_time_ = 0;
   set_status(OSQP_UNSOLVED);
   if (small_direct_applicable()) {
     const int err = solve_small_direct(t0);
@@ -697,7 +724,8 @@ void Engine::admm_core(double t0, double *res) {
     }
   };
 
-  double stall = 1.0, prev_dua = std::numeric_limits<double>::infinity(), prev_pri = std::numeric_limits<double>::infinity();
+  double stall = 1.0, best_dua = std::numeric_limits<double>::infinity();
+  int stalled_checks = 0;
   int iter = 0;
   int flags[F_COUNT], first_flags[F_COUNT];
   bool first_flags_valid = false;
@@ -776,8 +804,7 @@ void Engine::admm_core(double t0, double *res) {
     info.obj_val = (0.5 * res[R_XPX] + res[R_QX]) * (settings.scaling ? cinv_ : 1.0);      // _osqp.py:705-712
     info.prim_res = (m == 0) ? 0.0 : (unsc ? res[R_PRI_U] : res[R_PRI_S]);                 // :714-726
     info.dual_res = unsc ? cinv_ * res[R_DUA_U] : res[R_DUA_S];                            // :753-764
-    info.dual_obj_val = (-0.5 * res[R_XPX] - res[R_SUPP]) * (settings.scaling ? cinv_ : 1.0);
-    info.duality_gap = info.obj_val - info.dual_obj_val;
+    update_gap_info(res, t0);
     if (settings.verbose)
       std::printf("%4d  %11.4e   %8.2e   %8.2e   %8.2e  %3d  %8.2es   (cg mean %.1f budget %d unconv %d; rho est %.2e)\n", iter, info.obj_val, info.prim_res,
                   info.dual_res, rho_bar_, flags[F_STAT_MAX], now_s() - t0, flags[F_STAT_SUM] / (double)std::max(1, flags[F_STAT_N]), budget[tight],
@@ -815,13 +842,13 @@ void Engine::admm_core(double t0, double *res) {
     // tolerance is a fraction of the current SCALED dual residual.  (Upstream's rule, fraction * sqrt(prim*dual)
     // [UPSTREAM-UNVERIFIED], lets r exceed the dual residual whenever prim >> dual; that biases the rho estimate of
     // _osqp.py:880-908 and was measured to cost 2-3x more ADMM iterations -- see DESIGN.md "PCG tolerance".)
-    // When NEITHER residual makes progress between two checks (an infeasible / unbounded problem: the dual residual of an
-    // unbounded LP stays O(1) for ever), a tolerance tied to the residual never tightens and the certificates of
-    // _osqp.py:796-878 -- conditions on dx, dy relative to 1e-4 ||dx|| -- are never met by the inexact steps: the tolerance
-    // then drops by 10x per stalled check (and recovers when progress resumes).
-    if (res[R_DUA_S] > 0.9 * prev_dua && res[R_PRI_S] > 0.9 * prev_pri) stall = std::max(1e-8, 0.1 * stall);
-    else stall = std::min(1.0, 10.0 * stall);
-    prev_dua = res[R_DUA_S]; prev_pri = res[R_PRI_S];
+    // When the dual residual stops improving on its best value for two checks in a row (typically an unbounded problem: the dual
+    // residual of an unbounded LP stays O(1) for ever while the primal one jumps around), a tolerance tied to it never tightens
+    // and the certificates of _osqp.py:796-878 -- conditions on dx, dy relative to 1e-4 ||dx|| -- are never met by the inexact
+    // steps: the tolerance then drops by 10x per further stalled check (and recovers when progress resumes).
+    if (res[R_DUA_S] > 0.9 * best_dua) { if (++stalled_checks >= 2) stall = std::max(1e-8, 0.1 * stall); }
+    else { stalled_checks = 0; stall = std::min(1.0, 10.0 * stall); }
+    best_dua = std::min(best_dua, res[R_DUA_S]);
     double eps = settings.cg_tol_fraction * res[R_DUA_S];
     eps = std::max(std::min(eps, eps_cg_prev_), kCgTolAbsMin);
     if (std::isfinite(eps)) { eps_cg_prev_ = eps; tol_rel = 1e-14; tol_abs = std::max(eps * stall, kCgTolAbsMin); have_tol_ = true; }
@@ -894,8 +921,7 @@ void Engine::polish() {
   be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
   if (ok) {
     info.obj_val = pol_obj; info.prim_res = pol_pri; info.dual_res = pol_dua; info.status_polish = 1;       // :1797-1807
-    info.dual_obj_val = (-0.5 * res[R_XPX] - res[R_SUPP]) * (settings.scaling ? cinv_ : 1.0);
-    info.duality_gap = info.obj_val - info.dual_obj_val;
+    update_gap_info(res, -1.0);
   } else {                                          // keep the ADMM solution (:1813-1814)
     info.status_polish = -1;
     be::h2d(d_, d_.x, hx.data(), sizeof(double) * n);
@@ -1349,11 +1375,36 @@ int Engine::solve_small_direct(double t0) {
   const bool pinf = st == OSQP_PRIMAL_INFEASIBLE || st == OSQP_PRIMAL_INFEASIBLE_INACCURATE;
   const bool dinf = st == OSQP_DUAL_INFEASIBLE || st == OSQP_DUAL_INFEASIBLE_INACCURATE;
   std::fill(sol_pc_.begin(), sol_pc_.end(), kNaN); std::fill(sol_dc_.begin(), sol_dc_.end(), kNaN);
+  const bool finite_xy = std::isfinite(rec[2]) && st != OSQP_NON_CVX;
   if (!pinf && !dinf) {
     std::copy(x.begin(), x.end(), sol_x_.begin()); std::copy(y.begin(), y.begin() + m, sol_y_.begin());   // (solution.x/y point into these)
-    const int keep = settings.warm_starting;
-    warm_start(x.data(), m > 0 ? y.data() : nullptr);           // device iterates follow (a later solve continues from them)
-    settings.warm_starting = keep;
+    if (finite_xy) {
+      const int keep = settings.warm_starting;
+      warm_start(x.data(), m > 0 ? y.data() : nullptr);         // device iterates follow (a later solve continues from them)
+      settings.warm_starting = keep;
+      // the v1 gap fields (update_gap_info) from the unscaled data on the host: a few hundred entries
+      ensure_host_vectors();
+      std::vector<double> px(n, 0.0), ax(m, 0.0), aty(n, 0.0);
+      for (int j = 0; j < n; j++)
+        for (int k = P_.p[j]; k < P_.p[j + 1]; k++) { const int i = P_.i[k]; px[i] += P_.x[k] * x[j]; if (i != j) px[j] += P_.x[k] * x[i]; }
+      for (int j = 0; j < n; j++)
+        for (int k = A_.p[j]; k < A_.p[j + 1]; k++) { ax[A_.i[k]] += A_.x[k] * x[j]; aty[j] += A_.x[k] * y[A_.i[k]]; }
+      double xpx = 0, sup = 0, nax = 0, nz = 0, npx = 0, naty = 0, nq = 0;
+      for (int j = 0; j < n; j++) { xpx += x[j] * px[j]; npx = std::max(npx, std::fabs(px[j])); naty = std::max(naty, std::fabs(aty[j])); nq = std::max(nq, std::fabs(q0_[j])); }
+      for (int i = 0; i < m; i++) {
+        if (y[i] > 0 && u0_[i] < OSQP_INFTY * kMinScaling) sup += u0_[i] * y[i];
+        else if (y[i] < 0 && l0_[i] > -OSQP_INFTY * kMinScaling) sup += l0_[i] * y[i];
+        nax = std::max(nax, std::fabs(ax[i])); nz = std::max(nz, std::fabs(std::min(std::max(ax[i], l0_[i]), u0_[i])));
+      }
+      info.dual_obj_val = -0.5 * xpx - sup;
+      info.duality_gap = info.obj_val - info.dual_obj_val;
+      const double tiny = 1e-10, gn = std::max(std::fabs(info.obj_val), std::fabs(info.dual_obj_val));
+      info.rel_kkt_error = std::max(std::max(m == 0 ? 0.0 : info.prim_res / (std::max(nax, nz) + tiny), info.dual_res / (std::max(std::max(npx, naty), nq) + tiny)),
+                                    std::fabs(info.duality_gap) / (gn + tiny));
+    } else {
+      cold_start();                                             // NaN iterates (non-convex problem) are no warm start
+      info.dual_obj_val = info.duality_gap = info.rel_kkt_error = kNaN;
+    }
   } else {
     std::fill(sol_x_.begin(), sol_x_.end(), kNaN); std::fill(sol_y_.begin(), sol_y_.end(), kNaN);
     if (pinf) std::copy(y.begin(), y.begin() + m, sol_pc_.begin()); else std::copy(x.begin(), x.end(), sol_dc_.begin());                    // the kernel returns the certificate in place of y / x

@@ -122,6 +122,8 @@ class Engine {
   void apply_scaled_bounds(const std::vector<double> &ls, const std::vector<double> &us);
   void drop_graphs();
   int check_termination(const double *res, bool approximate);
+  void update_gap_info(const double *res, double t0);
+  double gap_time_ = 0;
   double rho_estimate(const double *res) const;
   void store_solution();
   void set_status(int status);

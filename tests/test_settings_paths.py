@@ -110,3 +110,27 @@ def test_batch_direct_symbolic_ordering(backend):
         except ValueError:
             assert backend == 'hostsim'
         assert 1 <= s._solver.hip_stats()['batch_direct_bw'] <= 2
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_duality_gap_fields_and_check_dualgap(backend):
+    """The v1 info fields purepy does not have (bindings.cpp.in:475, 478, 491-492) and the check_dualgap termination test (:442):
+    at a solved point the dual objective closes on the primal one, rel_kkt_error is at the tolerance level, the primal-dual
+    integral is positive; with check_dualgap the returned gap satisfies eps_abs + eps_rel max(|obj|, |dual obj|)."""
+    with engine(backend):
+        m, r = solve()
+        i = r.info
+        assert i.status_val == S.OSQP_SOLVED
+        assert abs(i.dual_obj_val - IO.obj_val) <= 1e-4 * (1 + abs(IO.obj_val))
+        assert abs(i.duality_gap - (i.obj_val - i.dual_obj_val)) <= 1e-12 * (1 + abs(i.obj_val))
+        assert 0 <= i.rel_kkt_error <= 1e-4 and i.primdual_int > 0
+        m2, r2 = solve(check_dualgap=True)
+        j = r2.info
+        assert j.status_val == S.OSQP_SOLVED and j.iter >= i.iter
+        assert abs(j.duality_gap) < 1e-7 + 1e-7 * max(abs(j.obj_val), abs(j.dual_obj_val))
+        close(r2)
+    Ps, qs, As, ls, us = problems.random_qp()                 # a problem of the one-launch direct path (GPU): same fields, computed on the host
+    with engine(backend):
+        s = osqp_amd.OSQP(); s.setup(Ps, qs, As, ls, us, eps_abs=1e-7, eps_rel=1e-7, verbose=False)
+        k = s.solve().info
+        assert k.status_val == S.OSQP_SOLVED and abs(k.duality_gap) <= 1e-4 * (1 + abs(k.obj_val)) and 0 <= k.rel_kkt_error <= 1e-3
