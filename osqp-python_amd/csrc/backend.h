@@ -108,6 +108,7 @@ struct Dev {
   double *res = nullptr;         // [R_COUNT]
   double *scal = nullptr;        // [S_HIST + 2*(kMaxCg+1)]
   int *flags = nullptr;          // [F_COUNT]
+  int *slot = nullptr;           // [16] the two phase records of the slot kernels (backend_hip.hip "slot kernels"); nullptr: not used
   void *stream = nullptr;        // hipStream_t (product) / unused (host simulator)
   void *impl = nullptr;          // backend private (events, graphs, pinned staging)
 };
@@ -182,6 +183,12 @@ void kv(Dev &d, int i);
 //   z~ = A xs ; z,y update (_osqp.py:682-703) ; v = rho z - y ; t0 = rho z~ ; dy ; and, on extra workgroups,
 //   x = alpha xs + (1-alpha) x ; dx (_osqp.py:660-668).  Also folds the PCG statistics of this ADMM iteration.
 void ka(Dev &d, int budget);
+// Slot form of a chunk (device-side scheduling of KB / K1 / K2F / K1F / KA; see backend_hip.hip): slot_begin(target) once, then any
+// number of slot_pair(cap) launches; slot_done() = ADMM iterations completed so far (== target when the chunk is finished).
+bool slots_supported(const Dev &d);
+void slot_begin(Dev &d, int target);
+void slot_pair(Dev &d, int cap);
+int slot_done(Dev &d);
 
 // ---- every check_termination iterations ----
 // residual norms / objective pieces of (x,z,y) -> d.res[0 .. R_QDX]   (_osqp.py:705-794, 880-908)

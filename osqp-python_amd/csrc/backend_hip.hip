@@ -817,6 +817,126 @@ __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- slot kernels
+// Device-side scheduling of the ADMM / PCG phases (no launch is wasted on a converged PCG).  A chunk of ADMM iterations is a fixed
+// string of launches  B A B A ...  ("slots"): a B slot streams B = [P + sigma I | A'] and runs whichever B-phase is due (KB, or
+// the K2F of the current PCG iteration), an A slot streams A and runs the A-phase that is due (the first K1, a K1F, or KA).  Which
+// phase is due is a small record in device memory: every slot reads the record its predecessor wrote (kernel boundary = ordering),
+// its workgroup 0 writes the successor's -- two records, so that no workgroup of a launch can observe its own launch's update.
+// The PCG of ADMM iteration j therefore takes exactly as many slot pairs as it has iterations (plus the pair that detects
+// convergence and runs KA), whatever the neighbouring iterations needed; only the few slots left over at the END of a chunk idle.
+enum SlotPhase { P_KB = 0, P_K1, P_K2F, P_K1F, P_KA, P_IDLE };
+enum SlotRec { SR_PHASE = 0, SR_K, SR_ADMM, SR_TARGET, SR_USED, SR_CONV, SR_WORDS = 8 };
+
+struct SlotState { int ph, k, admm, target, used, conv; };
+__device__ __forceinline__ SlotState slot_read(const int *r) { return SlotState{r[SR_PHASE], r[SR_K], r[SR_ADMM], r[SR_TARGET], r[SR_USED], r[SR_CONV]}; }
+__device__ __forceinline__ void slot_write(int *w, const SlotState &s) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { w[SR_PHASE] = s.ph; w[SR_K] = s.k; w[SR_ADMM] = s.admm; w[SR_TARGET] = s.target; w[SR_USED] = s.used; w[SR_CONV] = s.conv; }
+}
+__global__ void k_slot_init(int *slot, int target) {
+  slot[SR_PHASE] = P_KB; slot[SR_K] = 0; slot[SR_ADMM] = 0; slot[SR_TARGET] = target; slot[SR_USED] = 0; slot[SR_CONV] = 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
+  __shared__ union { StreamLds<2> kb; StreamLdsW<1, double> k2f; } lds;
+  SlotState st = slot_read(d.slot);                    // written by the previous A slot (or k_slot_init)
+  int *W = d.slot + SR_WORDS;
+  if (st.ph == P_KB) {
+    if (st.admm >= st.target) { st.ph = P_IDLE; slot_write(W, st); return; }
+    GKb g{d.xs, d.v, d.t0, d.n};
+    EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma};
+    process_rows<2>(d.B, g, e, lds.kb);
+    __syncthreads();
+    const double G = block_sum(e.g, lds.kb.red);
+    double RN = e.rn, BN = e.bn;
+    block_max2(RN, BN, lds.kb.red);
+    put_partial(d.part, SL_GAMMA0, G); put_partial(d.part, SL_RN0, RN); put_partial(d.part, SL_BN, BN);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
+    st.ph = P_K1; st.k = 0;
+  } else if (st.ph == P_K2F) {
+    const int k = st.k;
+    const double *u = (k & 1) ? d.uu2 : d.uu;
+    GSplitU g{u, d.t, d.n};
+    EK2F e{u, d.Minv, d.s, d.ms};
+    double dl_first = 0.0;
+    if (!process_rows<1>(d.B, g, e, lds.k2f, PreK2F{d, k, &e, lds.k2f.red, &dl_first})) {   // converged after k iterations
+      st.ph = P_KA; st.used = k; st.conv = 1;
+      slot_write(W, st);
+      return;
+    }
+    double DL = dl_first;
+    if (!d.B.single) { __syncthreads(); DL += block_sum(e.dl, lds.k2f.red); }
+    put_partial(d.part, SL_DELTA, DL);
+    st.ph = P_K1F;
+  }
+  slot_write(W, st);                                   // (P_KA pending after a PCG that hit the cap, P_IDLE: passed through)
+}
+
+// KA with the PCG statistics taken from the slot record (used iterations; conv = 0: the PCG stopped at the cap -- did its last
+// iterate reach the tolerance anyway?)
+template <class L>
+__device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv) {
+  GVec g{d.xs};
+  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha};
+  process_rows<1>(d.A, g, e, lds);
+  const int stride = gridDim.x * kBlock;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) {    // _osqp.py:664-668
+    const double xo = d.x[j], xn = d.alpha * d.xs[j] + (1.0 - d.alpha) * xo;
+    d.dx[j] = xn - xo; d.x[j] = xn;
+  }
+  if (blockIdx.x == 0) {
+    if (!conv) {
+      __syncthreads();
+      double rn = partial_fold_max(partial_load(d.part + (SL_RN0 + (used & 1)) * kGrid)), bn = partial_fold_max(partial_load(d.part + SL_BN * kGrid));
+      block_max2(rn, bn, lds.red);
+      conv = !(rn > fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS])) ? 2 : 0;
+    }
+    if (threadIdx.x == 0) {
+      d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;
+      if (used > d.flags[F_STAT_MAX]) d.flags[F_STAT_MAX] = used;
+      if (!conv) d.flags[F_STAT_UNCONV] += 1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_slot_a(Dev d, int cap) {
+  __shared__ union { StreamLds<1> k1; StreamLdsW<1, double> k1f; } lds;
+  SlotState st = slot_read(d.slot + SR_WORDS);         // written by the previous B slot
+  int *W = d.slot;
+  if (st.ph == P_K1) {                                 // first A-apply of this ADMM iteration's PCG: stopping test on r_0, t_0 = rho .* (A u_0)
+    GVec g{d.uu};
+    EK1 e{d.rho, d.t};
+    if (process_rows<1>(d.A, g, e, lds.k1, PreK1{d, 0, 0, lds.k1.red})) { st.ph = P_K2F; st.k = 0; }
+    else {                                             // the warm start already meets the tolerance: no PCG iteration, KA right here
+      __syncthreads();
+      slot_ka(d, lds.k1, 0, 1);
+      st.ph = P_KB; st.admm += 1;
+    }
+  } else if (st.ph == P_K1F) {
+    const int k = st.k, i = k + 1;
+    const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3;
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+    const bool has_vec = slot0 < per && xcd * per + slot0 < nchunk;
+    if (!wg_has_rows(d.A) && !has_vec && blockIdx.x != 0) {
+      put_partial(d.part, SL_GAMMA0 + (i & 1), 0.0); put_partial(d.part, SL_RN0 + (i & 1), 0.0);
+    } else {
+      double g = 0, rn = 0;
+      GMs gr{d.ms};
+      EK1F e{d.rho, d.t};
+      process_rows<1>(d.A, gr, e, lds.k1f, PreK1F{d, k, has_vec, &e, lds.k1f.red, &g, &rn});
+      __syncthreads();
+      block_sum_max(g, rn, lds.k1f.red);
+      put_partial(d.part, SL_GAMMA0 + (i & 1), g); put_partial(d.part, SL_RN0 + (i & 1), rn);
+    }
+    if (i >= cap) { st.ph = P_KA; st.used = i; st.conv = 0; }      // the PCG stops at the cap; the next A slot runs KA
+    else { st.ph = P_K2F; st.k = i; }
+  } else if (st.ph == P_KA) {
+    slot_ka(d, lds.k1, st.used, st.conv);
+    st.ph = P_KB; st.admm += 1;
+  }
+  slot_write(W, st);
+}
+
 // ---------------------------------------------------------------------------------------------- residual kernels
 struct EKr1 : NoPrefetch {
   const double *z, *y, *dy, *l, *u, *E, *Einv;
@@ -1175,6 +1295,16 @@ void k1(Dev &d, int i) { if (d.fused && i > 0) LAUNCH(k_k1f, d, d, i); else LAUN
 void k2(Dev &d, int i) { if (d.fused) LAUNCH(k_k2f, d, d, i); else LAUNCH(k_k2, d, d, 0); }
 void kv(Dev &d, int i) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, i, 0); else LAUNCH(k_kv<1>, d, d, i, 0); }
 void ka(Dev &d, int budget) { LAUNCH(k_ka, d, d, budget); }
+bool slots_supported(const Dev &d) { return d.fused != 0 && d.slot != nullptr; }
+void slot_begin(Dev &d, int target) { hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(1), 0, st(d), d.slot, target); }
+void slot_pair(Dev &d, int cap) { LAUNCH(k_slot_b, d, d); LAUNCH(k_slot_a, d, d, cap); }
+int slot_done(Dev &d) {                                  // ADMM iterations completed by the chunk so far (synchronises)
+  HIP_CHECK(hipSetDevice(d.device));
+  int rec[2 * SR_WORDS];
+  HIP_CHECK(hipMemcpyAsync(rec, d.slot, sizeof(rec), hipMemcpyDeviceToHost, st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  return rec[SR_ADMM] >= rec[SR_TARGET] ? rec[SR_TARGET] : rec[SR_ADMM];     // (record A: written by the last A slot)
+}
 
 void residuals(Dev &d) {
   HIP_CHECK(hipSetDevice(d.device));

@@ -40,6 +40,10 @@ void scale_q(Dev &, double) {}
 void scale_bounds(Dev &, int) {}
 int count_bad_bounds(Dev &, const double *, const double *) { return 0; }
 void scale_warm(Dev &, const double *, const double *, double) {}
+bool slots_supported(const Dev &) { return false; }
+void slot_begin(Dev &, int) {}
+void slot_pair(Dev &, int) {}
+int slot_done(Dev &) { return 0; }
 void ext_record(Dev &, void *) {}
 void ext_wait(Dev &) {}
 
