@@ -185,6 +185,7 @@ typedef struct {
   double cg_cap_escalations;  /* times the last solve doubled its PCG iteration cap because most solves of a chunk stagnated at it */
   double windowed_blocks;     /* row blocks of A and B whose input-vector window is staged in LDS (16-bit local column indices) */
   double row_blocks;          /* row blocks of A and B in total */
+  double slot_topups;         /* last solve: chunks whose string of slot launches ended before the chunk did (more launches followed) */
 } OSQPHipStats;
 OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
 

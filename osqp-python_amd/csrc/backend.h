@@ -183,11 +183,11 @@ void kv(Dev &d, int i);
 //   z~ = A xs ; z,y update (_osqp.py:682-703) ; v = rho z - y ; t0 = rho z~ ; dy ; and, on extra workgroups,
 //   x = alpha xs + (1-alpha) x ; dx (_osqp.py:660-668).  Also folds the PCG statistics of this ADMM iteration.
 void ka(Dev &d, int budget);
-// Slot form of a chunk (device-side scheduling of KB / K1 / K2F / K1F / KA; see backend_hip.hip): slot_begin(target) once, then any
-// number of slot_pair(cap) launches; slot_done() = ADMM iterations completed so far (== target when the chunk is finished).
+// Slot form of a chunk (device-side scheduling of KB / K1 / K2F / K1F / KA; see backend_hip.hip): slot_begin(target, cap) once, then any
+// number of slot_pair() launches; slot_done() = ADMM iterations the chunk had completed at the last fetch_flags / fetch_res_flags.
 bool slots_supported(const Dev &d);
-void slot_begin(Dev &d, int target);
-void slot_pair(Dev &d, int cap);
+void slot_begin(Dev &d, int target, int cap);
+void slot_pair(Dev &d);
 int slot_done(Dev &d);
 
 // ---- every check_termination iterations ----

@@ -64,7 +64,7 @@ struct Impl {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_ext = nullptr;
   bool ext_pending = false;
   double *pin_res = nullptr;
-  int *pin_flags = nullptr;
+  int *pin_flags = nullptr;      // [F_COUNT + 16]: the flags block followed by the two slot records
 };
 inline Impl &im(Dev &d) { return *static_cast<Impl *>(d.impl); }
 inline hipStream_t st(Dev &d) { return static_cast<hipStream_t>(d.stream); }
@@ -219,8 +219,22 @@ template <class P> struct LateOps<P, true> {
 //   Windowed blocks (L::kWin, DevCsr::blkwin):  G additionally provides
 //                    using Win;  Win stage(int seg, int c) const;      element c of the input vector(s) of column segment seg
 //                    void wprod(const Win &, double val, double (&prod)[NS]) const;
+// The first row block's descriptors, loadable AHEAD of process_rows (the slot kernels request them together with the phase record
+// they branch on, so that the record's latency is not added to the kernel's dependent-load chain).
+struct FirstDesc { int4 ds, ws; };
+template <bool WIN>
+__device__ __forceinline__ FirstDesc first_desc(const DevCsr &M) {
+  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, per = (M.nblk + 7) >> 3;
+  const int b0 = xcd * per + slot0;
+  FirstDesc f{make_int4(0, 0, 0, 0), make_int4(0, -1, 0, 0)};
+  if (slot0 < per && b0 < M.nblk) {
+    f.ds = reinterpret_cast<const int4 *>(M.blkdesc)[b0];
+    if (WIN) f.ws = reinterpret_cast<const int4 *>(M.blkwin)[b0];
+  }
+  return f;
+}
 template <int NS, bool HAS_DONE, class G, class E, class Pre, class L>
-__device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E &e, L &lds, Pre pre, const int *done) {
+__device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E &e, L &lds, Pre pre, const int *done, const FirstDesc *fd = nullptr) {
   int buf = 0;
   const int4 *desc = reinterpret_cast<const int4 *>(M.blkdesc);
   [[maybe_unused]] const int4 *wdesc = reinterpret_cast<const int4 *>(M.blkwin);
@@ -237,7 +251,8 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
   int dn = 0;
   if (HAS_DONE) dn = *done;
   int4 ds = make_int4(0, 0, 0, 0), ws = make_int4(0, -1, 0, 0);
-  if (has0) { ds = desc[b0]; if constexpr (L::kWin) ws = wdesc[b0]; }
+  if (fd) { ds = fd->ds; if constexpr (L::kWin) ws = fd->ws; }
+  else if (has0) { ds = desc[b0]; if constexpr (L::kWin) ws = wdesc[b0]; }
   KT(Pre::kTraceBase + 1);      // flag + first descriptor arrived
   if (dn) return false;
   constexpr bool LATE = is_late<Pre>::value;
@@ -394,7 +409,7 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
           for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
         }
       }
-      if constexpr (FIRST && LATE) { if (!LateOps<Pre>::template finish<NS>(pre, tok, acc, owner)) return false; KT(Pre::kTraceBase + 3); }
+      if constexpr (FIRST && LATE) { KT(Pre::kTraceBase + 7); if (!LateOps<Pre>::template finish<NS>(pre, tok, acc, owner)) return false; KT(Pre::kTraceBase + 3); }
       if (owner) e(myr, acc);
     }
     for (int r = myr + kBlock; lpr == 1 && r < r1; r += kBlock) {   // blocks with more than kBlock (mostly empty) rows
@@ -429,6 +444,8 @@ template <int NS, class G, class E, class Pre, class L>
 __device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, L &lds, Pre pre, const int *done) { return process_rows_impl<NS, true>(M, g, e, lds, pre, done); }
 template <int NS, class G, class E, class L>
 __device__ __forceinline__ void process_rows(const DevCsr &M, const G &g, E &e, L &lds) { process_rows_impl<NS, false>(M, g, e, lds, NoPre(), nullptr); }
+template <int NS, class G, class E, class Pre, class L>
+__device__ __forceinline__ bool process_rows_fd(const DevCsr &M, const G &g, E &e, L &lds, Pre pre, const FirstDesc &fd) { return process_rows_impl<NS, false>(M, g, e, lds, pre, nullptr, &fd); }
 struct NoPrefetch { __device__ __forceinline__ void prefetch(int) {} };
 
 // ---------------------------------------------------------------------------------------------- hot-path kernels
@@ -826,26 +843,27 @@ __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
 // The PCG of ADMM iteration j therefore takes exactly as many slot pairs as it has iterations (plus the pair that detects
 // convergence and runs KA), whatever the neighbouring iterations needed; only the few slots left over at the END of a chunk idle.
 enum SlotPhase { P_KB = 0, P_K1, P_K2F, P_K1F, P_KA, P_IDLE };
-enum SlotRec { SR_PHASE = 0, SR_K, SR_ADMM, SR_TARGET, SR_USED, SR_CONV, SR_WORDS = 8 };
+enum SlotRec { SR_PHASE = 0, SR_K, SR_ADMM, SR_TARGET, SR_USED, SR_CONV, SR_CAP, SR_WORDS = 8 };
 
-struct SlotState { int ph, k, admm, target, used, conv; };
-__device__ __forceinline__ SlotState slot_read(const int *r) { return SlotState{r[SR_PHASE], r[SR_K], r[SR_ADMM], r[SR_TARGET], r[SR_USED], r[SR_CONV]}; }
+struct SlotState { int ph, k, admm, target, used, conv, cap; };
+__device__ __forceinline__ SlotState slot_read(const int *r) { return SlotState{r[SR_PHASE], r[SR_K], r[SR_ADMM], r[SR_TARGET], r[SR_USED], r[SR_CONV], r[SR_CAP]}; }
 __device__ __forceinline__ void slot_write(int *w, const SlotState &s) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) { w[SR_PHASE] = s.ph; w[SR_K] = s.k; w[SR_ADMM] = s.admm; w[SR_TARGET] = s.target; w[SR_USED] = s.used; w[SR_CONV] = s.conv; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { w[SR_PHASE] = s.ph; w[SR_K] = s.k; w[SR_ADMM] = s.admm; w[SR_TARGET] = s.target; w[SR_USED] = s.used; w[SR_CONV] = s.conv; w[SR_CAP] = s.cap; }
 }
-__global__ void k_slot_init(int *slot, int target) {
-  slot[SR_PHASE] = P_KB; slot[SR_K] = 0; slot[SR_ADMM] = 0; slot[SR_TARGET] = target; slot[SR_USED] = 0; slot[SR_CONV] = 0;
+__global__ void k_slot_init(int *slot, int target, int cap) {      // (cap: PCG iterations per solve; in the record, not a kernel argument, so that captured strings of slots serve every chunk)
+  slot[SR_PHASE] = P_KB; slot[SR_K] = 0; slot[SR_ADMM] = 0; slot[SR_TARGET] = target; slot[SR_USED] = 0; slot[SR_CONV] = 0; slot[SR_CAP] = cap;
 }
 
 __global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
   __shared__ union { StreamLds<2> kb; StreamLdsW<1, double> k2f; } lds;
+  const FirstDesc fd = first_desc<true>(d.B);          // (both B phases start from the same descriptors: requested before the branch)
   SlotState st = slot_read(d.slot);                    // written by the previous A slot (or k_slot_init)
   int *W = d.slot + SR_WORDS;
   if (st.ph == P_KB) {
     if (st.admm >= st.target) { st.ph = P_IDLE; slot_write(W, st); return; }
     GKb g{d.xs, d.v, d.t0, d.n};
     EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma};
-    process_rows<2>(d.B, g, e, lds.kb);
+    process_rows_fd<2>(d.B, g, e, lds.kb, NoPre(), fd);
     __syncthreads();
     const double G = block_sum(e.g, lds.kb.red);
     double RN = e.rn, BN = e.bn;
@@ -859,7 +877,7 @@ __global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
     GSplitU g{u, d.t, d.n};
     EK2F e{u, d.Minv, d.s, d.ms};
     double dl_first = 0.0;
-    if (!process_rows<1>(d.B, g, e, lds.k2f, PreK2F{d, k, &e, lds.k2f.red, &dl_first})) {   // converged after k iterations
+    if (!process_rows_fd<1>(d.B, g, e, lds.k2f, PreK2F{d, k, &e, lds.k2f.red, &dl_first}, fd)) {   // converged after k iterations
       st.ph = P_KA; st.used = k; st.conv = 1;
       slot_write(W, st);
       return;
@@ -875,10 +893,10 @@ __global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
 // KA with the PCG statistics taken from the slot record (used iterations; conv = 0: the PCG stopped at the cap -- did its last
 // iterate reach the tolerance anyway?)
 template <class L>
-__device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv) {
+__device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv, const FirstDesc &fd) {
   GVec g{d.xs};
   EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha};
-  process_rows<1>(d.A, g, e, lds);
+  process_rows_fd<1>(d.A, g, e, lds, NoPre(), fd);
   const int stride = gridDim.x * kBlock;
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) {    // _osqp.py:664-668
     const double xo = d.x[j], xn = d.alpha * d.xs[j] + (1.0 - d.alpha) * xo;
@@ -899,17 +917,18 @@ __device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_slot_a(Dev d, int cap) {
+__global__ __launch_bounds__(kBlock) void k_slot_a(Dev d) {
   __shared__ union { StreamLds<1> k1; StreamLdsW<1, double> k1f; } lds;
+  const FirstDesc fd = first_desc<true>(d.A);
   SlotState st = slot_read(d.slot + SR_WORDS);         // written by the previous B slot
   int *W = d.slot;
   if (st.ph == P_K1) {                                 // first A-apply of this ADMM iteration's PCG: stopping test on r_0, t_0 = rho .* (A u_0)
     GVec g{d.uu};
     EK1 e{d.rho, d.t};
-    if (process_rows<1>(d.A, g, e, lds.k1, PreK1{d, 0, 0, lds.k1.red})) { st.ph = P_K2F; st.k = 0; }
+    if (process_rows_fd<1>(d.A, g, e, lds.k1, PreK1{d, 0, 0, lds.k1.red}, fd)) { st.ph = P_K2F; st.k = 0; }
     else {                                             // the warm start already meets the tolerance: no PCG iteration, KA right here
       __syncthreads();
-      slot_ka(d, lds.k1, 0, 1);
+      slot_ka(d, lds.k1, 0, 1, fd);
       st.ph = P_KB; st.admm += 1;
     }
   } else if (st.ph == P_K1F) {
@@ -923,15 +942,15 @@ __global__ __launch_bounds__(kBlock) void k_slot_a(Dev d, int cap) {
       double g = 0, rn = 0;
       GMs gr{d.ms};
       EK1F e{d.rho, d.t};
-      process_rows<1>(d.A, gr, e, lds.k1f, PreK1F{d, k, has_vec, &e, lds.k1f.red, &g, &rn});
+      process_rows_fd<1>(d.A, gr, e, lds.k1f, PreK1F{d, k, has_vec, &e, lds.k1f.red, &g, &rn}, fd);
       __syncthreads();
       block_sum_max(g, rn, lds.k1f.red);
       put_partial(d.part, SL_GAMMA0 + (i & 1), g); put_partial(d.part, SL_RN0 + (i & 1), rn);
     }
-    if (i >= cap) { st.ph = P_KA; st.used = i; st.conv = 0; }      // the PCG stops at the cap; the next A slot runs KA
+    if (i >= st.cap) { st.ph = P_KA; st.used = i; st.conv = 0; }      // the PCG stops at the cap; the next A slot runs KA
     else { st.ph = P_K2F; st.k = i; }
   } else if (st.ph == P_KA) {
-    slot_ka(d, lds.k1, st.used, st.conv);
+    slot_ka(d, lds.k1, st.used, st.conv, fd);
     st.ph = P_KB; st.admm += 1;
   }
   slot_write(W, st);
@@ -1241,7 +1260,7 @@ int init(Dev &d, int device) {
   Impl *p = new Impl();
   HIP_CHECK(hipEventCreate(&p->ev0)); HIP_CHECK(hipEventCreate(&p->ev1)); HIP_CHECK(hipEventCreateWithFlags(&p->ev_ext, hipEventDisableTiming));
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_res), sizeof(double) * R_COUNT, hipHostMallocDefault));
-  HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_flags), sizeof(int) * F_COUNT, hipHostMallocDefault));
+  HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_flags), sizeof(int) * (F_COUNT + 16), hipHostMallocDefault));
   d.impl = p;
   return OSQP_NO_ERROR;
 }
@@ -1296,14 +1315,11 @@ void k2(Dev &d, int i) { if (d.fused) LAUNCH(k_k2f, d, d, i); else LAUNCH(k_k2, 
 void kv(Dev &d, int i) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, i, 0); else LAUNCH(k_kv<1>, d, d, i, 0); }
 void ka(Dev &d, int budget) { LAUNCH(k_ka, d, d, budget); }
 bool slots_supported(const Dev &d) { return d.fused != 0 && d.slot != nullptr; }
-void slot_begin(Dev &d, int target) { hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(1), 0, st(d), d.slot, target); }
-void slot_pair(Dev &d, int cap) { LAUNCH(k_slot_b, d, d); LAUNCH(k_slot_a, d, d, cap); }
-int slot_done(Dev &d) {                                  // ADMM iterations completed by the chunk so far (synchronises)
-  HIP_CHECK(hipSetDevice(d.device));
-  int rec[2 * SR_WORDS];
-  HIP_CHECK(hipMemcpyAsync(rec, d.slot, sizeof(rec), hipMemcpyDeviceToHost, st(d)));
-  HIP_CHECK(hipStreamSynchronize(st(d)));
-  return rec[SR_ADMM] >= rec[SR_TARGET] ? rec[SR_TARGET] : rec[SR_ADMM];     // (record A: written by the last A slot)
+void slot_begin(Dev &d, int target, int cap) { HIP_CHECK(hipSetDevice(d.device)); hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(1), 0, st(d), d.slot, target, cap); }
+void slot_pair(Dev &d) { LAUNCH(k_slot_b, d, d); LAUNCH(k_slot_a, d, d); }
+int slot_done(Dev &d) {        // ADMM iterations completed by the chunk, as of the last fetch_flags / fetch_res_flags (record A: written by the last A slot)
+  const int *rec = im(d).pin_flags + F_COUNT;
+  return rec[SR_ADMM];
 }
 
 void residuals(Dev &d) {
@@ -1332,6 +1348,7 @@ void fetch_res(Dev &d, double *h) {
 void fetch_flags(Dev &d, int *h) {
   HIP_CHECK(hipSetDevice(d.device));
   HIP_CHECK(hipMemcpyAsync(im(d).pin_flags, d.flags, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, st(d)));
+  if (d.slot) HIP_CHECK(hipMemcpyAsync(im(d).pin_flags + F_COUNT, d.slot, sizeof(int) * 16, hipMemcpyDeviceToHost, st(d)));
   HIP_CHECK(hipMemsetAsync(d.flags + F_STAT_SUM, 0, sizeof(int) * (F_COUNT - F_STAT_SUM), st(d)));
   HIP_CHECK(hipStreamSynchronize(st(d)));
   std::memcpy(h, im(d).pin_flags, sizeof(int) * F_COUNT);
@@ -1340,6 +1357,7 @@ void fetch_res_flags(Dev &d, double *hr, int *hf) {
   HIP_CHECK(hipSetDevice(d.device));
   HIP_CHECK(hipMemcpyAsync(im(d).pin_res, d.res, sizeof(double) * R_COUNT, hipMemcpyDeviceToHost, st(d)));
   HIP_CHECK(hipMemcpyAsync(im(d).pin_flags, d.flags, sizeof(int) * F_COUNT, hipMemcpyDeviceToHost, st(d)));
+  if (d.slot) HIP_CHECK(hipMemcpyAsync(im(d).pin_flags + F_COUNT, d.slot, sizeof(int) * 16, hipMemcpyDeviceToHost, st(d)));
   HIP_CHECK(hipMemsetAsync(d.flags + F_STAT_SUM, 0, sizeof(int) * (F_COUNT - F_STAT_SUM), st(d)));
   HIP_CHECK(hipStreamSynchronize(st(d)));
   std::memcpy(hr, im(d).pin_res, sizeof(double) * R_COUNT);

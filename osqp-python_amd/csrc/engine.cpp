@@ -67,6 +67,8 @@ Engine::Engine() {
   pub.settings = &settings; pub.solution = &solution; pub.info = &info; pub.work = reinterpret_cast<OSQPWorkspace *>(this);
   const char *g = std::getenv("OSQP_HIP_GRAPH");
   use_graph_ = !(g && g[0] == '0');
+  const char *sl = std::getenv("OSQP_HIP_SLOTS");
+  use_slots_ = !(sl && sl[0] == '0');
   if (const char *f = std::getenv("OSQP_HIP_RHO_EQ_FACTOR")) { double v = std::atof(f); if (v >= 1.0) { eq_factor_mixed_ = v; eq_factor_env_ = true; } }
 }
 Engine::~Engine() { free_all(); }
@@ -74,6 +76,8 @@ Engine::~Engine() { free_all(); }
 void Engine::drop_graphs() {
   for (auto &kv : graphs_) be::graph_free(d_, kv.second);
   graphs_.clear();
+  for (auto &kv : sgraphs_) be::graph_free(d_, kv.second);
+  sgraphs_.clear();
 }
 
 void Engine::free_all() {
@@ -86,7 +90,7 @@ void Engine::free_all() {
   void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag, d_.A.runinfo, d_.B.runinfo, d_.A.blkwin, d_.B.blkwin, d_.A.lcol, d_.B.lcol, d_.qraw, d_.lraw, d_.uraw, d_.cnt,
                   d_.q, d_.l, d_.u, d_.D, d_.Dinv, d_.E, d_.Einv, d_.rho, d_.rho_inv, d_.ctype, d_.x, d_.z, d_.y, d_.dx,
                   d_.dy, d_.xs, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.uu2, d_.ms, d_.part, d_.res,
-                  d_.scal, d_.flags, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB};
+                  d_.scal, d_.flags, d_.slot, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   be::destroy(d_);
   d_ = Dev();
@@ -450,7 +454,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   d_.x = dv(n); d_.z = dv(m); d_.y = dv(m); d_.dx = dv(n); d_.dy = dv(m); d_.xs = dv(n); d_.zt = dv(m); d_.t0 = dv(m); d_.v = dv(m);
   d_.r = dv(n); d_.uu = dv(n); d_.p = dv(n); d_.s = dv(n); d_.w = dv(n); d_.t = dv(m); d_.Minv = dv(n); d_.uu2 = dv(n); d_.ms = dv(2 * (size_t)n);
   { const char *f = std::getenv("OSQP_HIP_PCG_FUSED"); d_.fused = (f && f[0] == '0') ? 0 : 1; }   // default on; =0 selects the 3-kernel sequence
-  d_.part = dv((size_t)kPartSlots * kGrid); d_.res = dv(R_COUNT); d_.scal = dv(S_HIST + 3 * (kMaxCg + 1)); d_.flags = dev_vec<int>(d_, F_COUNT);
+  d_.part = dv((size_t)kPartSlots * kGrid); d_.res = dv(R_COUNT); d_.scal = dv(S_HIST + 3 * (kMaxCg + 1)); d_.flags = dev_vec<int>(d_, F_COUNT); d_.slot = dev_vec<int>(d_, 16);
   if (dev_asm) {
     // the caller's values go up once, in their own (CSC) order; every later (re)assembly and the equilibration run on the device
     std::vector<int> Pj(nzP), Aj(nzA);
@@ -562,6 +566,30 @@ void Engine::run_chunk(int niter, int budget) {
   }
 }
 
+// Slot form of a chunk (backend_hip.hip "slot kernels"): begin_target > 0 starts a chunk of that many ADMM iterations (eager one-thread
+// launch: target and PCG cap travel in the phase record), then `pairs` (B slot, A slot) launches follow as replays of captured
+// strings of 256 / 64 / 16 / 4 / 1 pairs -- the same five graphs serve every chunk, whatever its length; begin_target == 0 tops up
+// a chunk that has not finished.
+void Engine::run_slots(int begin_target, int pairs, int cap) {
+  stats_.kernel_launches += 2.0 * pairs + (begin_target > 0 ? 1 : 0);
+  if (begin_target > 0) be::slot_begin(d_, begin_target, cap);
+  if (!(use_graph_ && be::graphs_supported())) { for (int k = 0; k < pairs; k++) be::slot_pair(d_); return; }
+  for (int left = pairs; left > 0;) {
+    int unit = 1;
+    for (int u : {256, 64, 16, 4}) if (left >= u) { unit = u; break; }
+    const std::array<int, 3> key = {unit, 0, 0};
+    auto it = sgraphs_.find(key);
+    if (it == sgraphs_.end()) {
+      be::graph_begin(d_);
+      for (int k = 0; k < unit; k++) be::slot_pair(d_);
+      it = sgraphs_.emplace(key, be::graph_end(d_)).first;
+    }
+    be::graph_launch(d_, it->second);
+    stats_.graph_launches += 1;
+    left -= unit;
+  }
+}
+
 double Engine::rho_estimate(const double *res) const {                                   // _osqp.py:880-908 (scaled quantities)
   double pri = res[R_PRI_S] / (std::max(res[R_AX_S], res[R_Z_S]) + 1e-10);
   double dua = res[R_DUA_S] / (std::max(std::max(res[R_ATY_S], res[R_PX_S]), res[R_QN_S]) + 1e-10);
@@ -648,7 +676,7 @@ int Engine::solve() {
     if (err != OSQP_FUNC_NOT_IMPLEMENTED) return err;
   }
   stats_.pcg_iters_total = stats_.pcg_iters_max = stats_.pcg_unconverged = 0;
-  stats_.kernel_launches = stats_.graph_launches = 0; stats_.cg_cap_escalations = 0;
+  stats_.kernel_launches = stats_.graph_launches = 0; stats_.cg_cap_escalations = 0; stats_.slot_topups = 0;
   double res[R_COUNT];
   admm_core(t0, res);
   info.rho_estimate = rho_estimate(res);                                                 // :1275
@@ -727,8 +755,38 @@ void Engine::admm_core(double t0, double *res) {
   double stall = 1.0, best_dua = std::numeric_limits<double>::infinity();
   int stalled_checks = 0;
   int iter = 0;
-  int flags[F_COUNT], first_flags[F_COUNT];
-  bool first_flags_valid = false;
+  int flags[F_COUNT];
+  // One chunk of `cnt` ADMM iterations; afterwards `flags` holds the chunk's PCG statistics and, if with_res, `res` the residual
+  // block of its last iterate.  Slot form (default, backend_hip.hip "slot kernels"): the chunk is a string of (B slot, A slot) launches
+  // sized from the PCG iterations the previous chunk of this kind needed (+10 %); if the string ends before the chunk does, more
+  // pairs follow (the residual kernels that ran on the unfinished iterates are simply repeated).
+  const bool slots = use_slots_ && be::slots_supported(d_);
+  double pred[2] = {std::min<double>(cap, 12.0), std::min<double>(cap, 24.0)};     // mean PCG iterations per ADMM iteration, per chunk kind
+  auto exec_chunk = [&](int cnt, bool tight, bool with_res) {
+    if (!slots) {
+      run_chunk(cnt, budget[tight]);
+      if (with_res) { be::residuals(d_); be::fetch_res_flags(d_, res, flags); } else be::fetch_flags(d_, flags);
+      return;
+    }
+    int tot[F_COUNT] = {0}, f[F_COUNT];
+    // (per-solve iteration limit = the budget rule of the launch-per-iteration form: the two forms then execute the SAME arithmetic
+    // -- truncating the rare long solve at mean + 3 sigma of the previous chunk costs no ADMM iterations and a third of the PCG work)
+    const int lim = budget[tight];
+    run_slots(cnt, 2 * cnt + (int)std::ceil(1.1 * std::min<double>(pred[tight], lim) * cnt) + 4, lim);
+    for (;;) {
+      if (with_res) { be::residuals(d_); be::fetch_res_flags(d_, res, f); } else be::fetch_flags(d_, f);
+      tot[F_STAT_SUM] += f[F_STAT_SUM]; tot[F_STAT_SUMSQ] += f[F_STAT_SUMSQ]; tot[F_STAT_N] += f[F_STAT_N]; tot[F_STAT_UNCONV] += f[F_STAT_UNCONV];
+      tot[F_STAT_MAX] = std::max(tot[F_STAT_MAX], f[F_STAT_MAX]);
+      const int done = be::slot_done(d_);
+      if (done >= cnt) break;
+      const int rem = cnt - done;
+      const double seen = tot[F_STAT_N] > 0 ? (double)tot[F_STAT_SUM] / tot[F_STAT_N] : pred[tight];
+      run_slots(0, 2 * rem + (int)std::ceil(1.25 * std::min<double>(std::max(seen, pred[tight]), lim) * rem) + 8, lim);
+      stats_.slot_topups += 1;
+    }
+    for (int k = 0; k < F_COUNT; k++) flags[k] = tot[k];
+    if (tot[F_STAT_N] > 0) pred[tight] = (double)tot[F_STAT_SUM] / tot[F_STAT_N];
+  };
   while (true) {
     int next = settings.max_iter;
     if (ct > 0) next = std::min(next, (iter / ct + 1) * ct);
@@ -753,10 +811,11 @@ void Engine::admm_core(double t0, double *res) {
       be::copy_in(d_, ckpt_, d_.x, sizeof(double) * n, 1); be::copy_in(d_, ckpt_ + n, d_.xs, sizeof(double) * n, 1);
       be::copy_in(d_, ckpt_ + 2 * (size_t)n, d_.z, sizeof(double) * m, 1); be::copy_in(d_, ckpt_ + 2 * (size_t)n + m, d_.y, sizeof(double) * m, 1);
     }
-    run_chunk(next - iter, budget[tight]);
+    const bool at_check = (ct > 0 && next % ct == 0) || next >= settings.max_iter || (ari > 0 && next % ari == 0);
+    const bool ckpt_chunk = first_chunk && cap < kMaxCg;
+    exec_chunk(next - iter, tight, at_check && !ckpt_chunk);
     cg_budget_ = budget[tight];
-    if (first_chunk && cap < kMaxCg) {
-      be::fetch_flags(d_, flags);
+    if (ckpt_chunk) {
       if (budget[tight] >= cap && flags[F_STAT_UNCONV] * 2 > std::max(1, flags[F_STAT_N])) {
         be::copy_in(d_, d_.x, ckpt_, sizeof(double) * n, 1); be::copy_in(d_, d_.xs, ckpt_ + n, sizeof(double) * n, 1);
         be::copy_in(d_, d_.z, ckpt_ + 2 * (size_t)n, sizeof(double) * m, 1); be::copy_in(d_, d_.y, ckpt_ + 2 * (size_t)n + m, sizeof(double) * m, 1);
@@ -767,37 +826,16 @@ void Engine::admm_core(double t0, double *res) {
         stats_.kernel_launches = 0; stats_.graph_launches = 0;
         continue;                                       // same chunk again (iter is still 0)
       }
-      // keep the statistics of this chunk for the bookkeeping below (fetch_flags reset the device counters)
-      stats_.pcg_iters_total += flags[F_STAT_SUM];
-      stats_.pcg_iters_max = std::max(stats_.pcg_iters_max, (double)flags[F_STAT_MAX]);
-      stats_.pcg_unconverged += flags[F_STAT_UNCONV];
-      first_flags_valid = true;
-      for (int k = 0; k < F_COUNT; k++) first_flags[k] = flags[k];
+      if (at_check) { be::residuals(d_); be::fetch_res(d_, res); }      // (the chunk's PCG statistics are already in flags)
     }
+    stats_.pcg_iters_total += flags[F_STAT_SUM];
+    stats_.pcg_iters_max = std::max(stats_.pcg_iters_max, (double)flags[F_STAT_MAX]);
+    stats_.pcg_unconverged += flags[F_STAT_UNCONV];
     iter = next;
-    const bool at_check = (ct > 0 && iter % ct == 0) || iter >= settings.max_iter || (ari > 0 && iter % ari == 0);
     if (!at_check) {                                  // boundary of a tight window only: PCG statistics, no residuals
-      if (first_flags_valid) { for (int k = 0; k < F_COUNT; k++) flags[k] = first_flags[k]; first_flags_valid = false; }
-      else {
-        be::fetch_flags(d_, flags);
-        stats_.pcg_iters_total += flags[F_STAT_SUM];
-        stats_.pcg_iters_max = std::max(stats_.pcg_iters_max, (double)flags[F_STAT_MAX]);
-        stats_.pcg_unconverged += flags[F_STAT_UNCONV];
-      }
       escalate(tight, flags);
       budget[tight] = next_budget(budget[tight], flags);
       continue;
-    }
-    be::residuals(d_);
-    if (first_flags_valid) {                          // the first chunk's PCG statistics were read (and counted) above
-      be::fetch_res(d_, res);
-      for (int k = 0; k < F_COUNT; k++) flags[k] = first_flags[k];
-      first_flags_valid = false;
-    } else {
-      be::fetch_res_flags(d_, res, flags);
-      stats_.pcg_iters_total += flags[F_STAT_SUM];
-      stats_.pcg_iters_max = std::max(stats_.pcg_iters_max, (double)flags[F_STAT_MAX]);
-      stats_.pcg_unconverged += flags[F_STAT_UNCONV];
     }
     const bool unsc = settings.scaling && !settings.scaled_termination;
     info.iter = iter;

@@ -2,6 +2,7 @@
 // the ADMM driver loop, termination / infeasibility / adaptive-rho logic.  All per-iteration arithmetic runs in
 // the backend (backend.h); the host only sees R_COUNT doubles every check_termination iterations.
 #pragma once
+#include <array>
 #include <map>
 #include <string>
 #include <utility>
@@ -117,6 +118,9 @@ class Engine {
   void upload_q();
   void fill_matrix_values(const std::vector<double> &Px_s, const std::vector<double> &Ax_s);
   void run_chunk(int niter, int budget);
+  void run_slots(int begin_target, int pairs, int cap);     // slot form: [slot_begin(begin_target)] + pairs x (B slot, A slot)
+  bool use_slots_ = true;
+  std::map<std::array<int, 3>, void *> sgraphs_;
   void admm_core(double t0, double *res);
   void polish();
   void apply_scaled_bounds(const std::vector<double> &ls, const std::vector<double> &us);

@@ -41,8 +41,8 @@ void scale_bounds(Dev &, int) {}
 int count_bad_bounds(Dev &, const double *, const double *) { return 0; }
 void scale_warm(Dev &, const double *, const double *, double) {}
 bool slots_supported(const Dev &) { return false; }
-void slot_begin(Dev &, int) {}
-void slot_pair(Dev &, int) {}
+void slot_begin(Dev &, int, int) {}
+void slot_pair(Dev &) {}
 int slot_done(Dev &) { return 0; }
 void ext_record(Dev &, void *) {}
 void ext_wait(Dev &) {}

@@ -31,13 +31,14 @@ m.update_settings(max_iter=60)
 m.solve()
 s = m._solver
 NAMES = {0: 'entry', 1: 'flag+descriptor arrived', 2: 'matrix loads issued', 3: 'hook done (partials folded%s)',
-         4: 'gathers done, products staged', 5: 'row sums + epilogue done', 6: 'exit (block reduce + partial store)'}
+         4: 'gathers done, products staged', 5: 'row sums + epilogue done', 6: 'exit (block reduce + partial store)',
+         7: 'row sums done (late hook starts)'}
 
 
 def report(tr, base, label, extra):
     t0 = tr[:, base].min()
     print('%s   (first workgroup entry = 0)' % label)
-    for p in range(7):
+    for p in (0, 1, 2, 4, 7, 3, 5, 6):
         v = (tr[:, base + p].astype(np.int64) - int(t0)) * 0.01        # 100 MHz -> us
         v = v[tr[:, base + p] > 0]
         if len(v) == 0:
