@@ -71,14 +71,29 @@ inline hipStream_t st(Dev &d) { return static_cast<hipStream_t>(d.stream); }
 
 // ---------------------------------------------------------------------------------------------- device helpers
 __device__ __forceinline__ double nanmax(double r, double a) { return (a > r || a != a) ? a : r; }
+// Wave64 reductions with DPP moves (VALU rate).  HIP's __shfl_* compile to ds_bpermute_b32 -- an LDS round trip of ~100+ cycles
+// per 32-bit half and step: the three block reductions of a PCG kernel cost ~1 us each that way (tools/ktrace.py: 1.07 us in the
+// late hook of k_k2f, 0.9 us in k_k1f's exit).  dpp<CTRL, ROWS>(v): v of the DPP source lane, 0.0 where there is none / the row is
+// masked (0 = identity of the sums and of the maxima of magnitudes taken here).  The wave's result ends up in LANE 63.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+constexpr int kReduceLane = 63;          // the lane that holds a wave_sum / wave_max result
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  v += dpp<0xb1>(v);            // quad_perm [1,0,3,2]
+  v += dpp<0x4e>(v);            // quad_perm [2,3,0,1]: every lane holds its quad's total
+  v += dpp<0x114>(v);           // row_shr:4
+  v += dpp<0x118>(v);           // row_shr:8: lane 15 of every row of 16 holds the row's total
+  v += dpp<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+  v += dpp<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's total
   return v;
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = nanmax(v, __shfl_down(v, o, 64));
+__device__ __forceinline__ double wave_max(double v) {                 // of non-negative values (or NaN)
+  v = nanmax(v, dpp<0xb1>(v)); v = nanmax(v, dpp<0x4e>(v)); v = nanmax(v, dpp<0x114>(v)); v = nanmax(v, dpp<0x118>(v));
+  v = nanmax(v, dpp<0x142, 0xa>(v)); v = nanmax(v, dpp<0x143, 0xc>(v));
   return v;
 }
 constexpr int kWaves = kBlock / 64;      // block reductions: one value per wave through LDS; sred needs 2 * kWaves doubles
@@ -87,7 +102,7 @@ __device__ __forceinline__ double sred_max(const double *s) { double t = s[0]; f
 // all threads receive the block total
 __device__ __forceinline__ double block_sum(double v, double *sred) {
   v = wave_sum(v);
-  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == kReduceLane) sred[threadIdx.x >> 6] = v;
   __syncthreads();
   double t = sred_sum(sred);
   __syncthreads();
@@ -95,7 +110,7 @@ __device__ __forceinline__ double block_sum(double v, double *sred) {
 }
 __device__ __forceinline__ double block_max(double v, double *sred) {
   v = wave_max(v);
-  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == kReduceLane) sred[threadIdx.x >> 6] = v;
   __syncthreads();
   double t = sred_max(sred);
   __syncthreads();
@@ -104,14 +119,14 @@ __device__ __forceinline__ double block_max(double v, double *sred) {
 // two quantities behind ONE barrier pair
 __device__ __forceinline__ void block_sum2(double &a, double &b, double *sred) {
   a = wave_sum(a); b = wave_sum(b);
-  if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; }
+  if ((threadIdx.x & 63) == kReduceLane) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; }
   __syncthreads();
   a = sred_sum(sred); b = sred_sum(sred + kWaves);
   __syncthreads();
 }
 __device__ __forceinline__ void block_max2(double &a, double &b, double *sred) {
   a = wave_max(a); b = wave_max(b);
-  if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; }
+  if ((threadIdx.x & 63) == kReduceLane) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; }
   __syncthreads();
   a = sred_max(sred); b = sred_max(sred + kWaves);
   __syncthreads();
@@ -119,7 +134,7 @@ __device__ __forceinline__ void block_max2(double &a, double &b, double *sred) {
 // a = sum, b = max, ONE barrier pair
 __device__ __forceinline__ void block_sum_max(double &a, double &b, double *sred) {
   a = wave_sum(a); b = wave_max(b);
-  if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; }
+  if ((threadIdx.x & 63) == kReduceLane) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; }
   __syncthreads();
   a = sred_sum(sred); b = sred_max(sred + kWaves);
   __syncthreads();
@@ -323,35 +338,48 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
       if (ws.y >= 0) {
         // Windowed block: the window of the input vector(s) is fetched with coalesced loads (requested FIRST: it is needed
         // first), written to LDS, and the per-entry gathers are LDS reads through 16-bit local indices.
+        // Instruction count matters as much as bytes here (the load-issue phase was ~700 instructions per wave with one exec-mask
+        // branch per load: 1.7 us of the kernel's 6.7): trip counts are BLOCK-UNIFORM (scalar branches), lanes past the end of the
+        // last partial batch re-read the last element (same cache line as their neighbours) instead of branching around the load.
         using T = typename G::Win;
         constexpr int CW = (kWinCap + kBlock - 1) / kBlock;
+        constexpr int CE = kChunk / kBlock;
         const int wl = ws.y + ws.w;
+        const int nw = (wl + kBlock - 1) / kBlock, nu = (cnt + kBlock - 1) / kBlock;      // (cnt >= 1, wl >= 1 for a windowed block)
         T we[CW];
 #pragma unroll
         for (int u = 0; u < CW; u++) {
-          const int p = threadIdx.x + u * kBlock;
-          if (p < wl && !KNOCKED(2)) we[u] = p < ws.y ? g.stage(0, ws.x + p) : g.stage(1, ws.z + (p - ws.y));
+          if (u < nw) {
+            const int p = min((int)threadIdx.x + u * kBlock, wl - 1);
+            we[u] = p < ws.y ? g.stage(0, ws.x + p) : g.stage(1, ws.z + (p - ws.y));
+          }
         }
-        int lc[kChunk / kBlock];
-        double vw[kChunk / kBlock];
+        int lc[CE];
+        double vw[CE];
+        const unsigned short *lcp = M.lcol + k0;
+        const double *vp = M.val + k0;
 #pragma unroll
-        for (int u = 0; u < kChunk / kBlock; u++) { const int k = threadIdx.x + u * kBlock; lc[u] = k < cnt ? (KNOCKED(8) ? (k & 511) : (int)M.lcol[k0 + k]) : -1; }
+        for (int u = 0; u < CE; u++) { if (u < nu) lc[u] = (int)lcp[min((int)threadIdx.x + u * kBlock, cnt - 1)]; }
 #pragma unroll
-        for (int u = 0; u < kChunk / kBlock; u++) { const int k = threadIdx.x + u * kBlock; vw[u] = (k < cnt && !KNOCKED(4)) ? M.val[k0 + k] : 1.0; }
-        if (myr < r1) { if (KNOCKED(128)) { rp0 = k0 + 12 * (myr - r0); rp1 = rp0 + 12; } else { rp0 = M.rowptr[myr]; rp1 = M.rowptr[myr + 1]; if (sub == 0) e.prefetch(myr); } }
+        for (int u = 0; u < CE; u++) { if (u < nu) vw[u] = vp[min((int)threadIdx.x + u * kBlock, cnt - 1)]; }
+        if (myr < r1) { rp0 = M.rowptr[myr]; rp1 = M.rowptr[myr + 1]; if (sub == 0) e.prefetch(myr); }
         if constexpr (FIRST && LATE) tok = LateOps<Pre>::begin(pre);            // a late hook's loads go out last
         KT(Pre::kTraceBase + 2);
 #pragma unroll
-        for (int u = 0; u < CW; u++) { const int p = threadIdx.x + u * kBlock; if (p < wl && !KNOCKED(2)) lds.win[p] = we[u]; }
+        for (int u = 0; u < CW; u++) { if (u < nw) lds.win[min((int)threadIdx.x + u * kBlock, wl - 1)] = we[u]; }     // (clamped lanes store the same value)
         if constexpr (FIRST && !LATE) { if (!PreOps<Pre>::finish(pre, tok)) return false; KT(Pre::kTraceBase + 3); }
         __syncthreads();
+        T gv[CE];
 #pragma unroll
-        for (int u = 0; u < kChunk / kBlock; u++) {
-          if (lc[u] < 0) continue;
-          double pr[NS];
-          if (KNOCKED(2)) pr[0] = vw[u]; else g.wprod(lds.win[lc[u]], vw[u], pr);
+        for (int u = 0; u < CE; u++) { if (u < nu) gv[u] = lds.win[lc[u]]; }            // all LDS gathers in flight together
 #pragma unroll
-          for (int s = 0; s < NS; s++) lds.prod[buf][s][threadIdx.x + u * kBlock] = pr[s];
+        for (int u = 0; u < CE; u++) {
+          if (u < nu) {
+            double pr[NS];
+            g.wprod(gv[u], vw[u], pr);         // (slots past cnt hold a copy of the last product: never read by the row sums)
+#pragma unroll
+            for (int s = 0; s < NS; s++) lds.prod[buf][s][threadIdx.x + u * kBlock] = pr[s];
+          }
         }
         staged = true;
       }
@@ -392,21 +420,33 @@ __device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E
       for (int s = 0; s < NS; s++) acc[s] = 0.0;
       const bool owner = myr < r1 && sub == 0;
       if (KNOCKED(16)) { if (owner) for (int s = 0; s < NS; s++) acc[s] = lds.prod[buf][s][threadIdx.x]; }
-      else if (lpr == 2) {
+      else {
+        // The first kRowBatch entries of the lane's share are read with INDEPENDENT LDS loads (one latency, not one per entry:
+        // the variable-trip-count loop below serialised a ds_read + wait per entry, 0.75 us for the 12-entry rows of B at config
+        // 2) and added in entry order -- the same sum as the plain loop, since the masked slots add 0.0.
+        constexpr int kRowBatch = 8;
         if (myr < r1) {
           const int ra = rp0 - k0, rz = rp1 - k0;
-          for (int k = ra + sub; k < rz; k += 2) {
+          double v[NS][kRowBatch];
+#pragma unroll
+          for (int b = 0; b < kRowBatch; b++) {
+            const int k = ra + sub + lpr * b;
+#pragma unroll
+            for (int s = 0; s < NS; s++) v[s][b] = k < rz ? lds.prod[buf][s][k] : 0.0;
+          }
+#pragma unroll
+          for (int b = 0; b < kRowBatch; b++) {
+#pragma unroll
+            for (int s = 0; s < NS; s++) acc[s] += v[s][b];
+          }
+          for (int k = ra + sub + lpr * kRowBatch; k < rz; k += lpr) {
 #pragma unroll
             for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
           }
         }
+        if (lpr == 2) {
 #pragma unroll
-        for (int s = 0; s < NS; s++) acc[s] += __shfl_xor(acc[s], 1, 64);      // (whole waves take this path: lpr is block-uniform)
-      } else if (myr < r1) {
-        const int ra = rp0 - k0, rz = rp1 - k0;
-        for (int k = ra; k < rz; k++) {
-#pragma unroll
-          for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
+          for (int s = 0; s < NS; s++) acc[s] += dpp<0xb1>(acc[s]);            // lane ^ 1 (whole waves take this path: lpr is block-uniform)
         }
       }
       if constexpr (FIRST && LATE) { KT(Pre::kTraceBase + 7); if (!LateOps<Pre>::template finish<NS>(pre, tok, acc, owner)) return false; KT(Pre::kTraceBase + 3); }
@@ -642,7 +682,7 @@ struct EK2F {
 // block reduction of three quantities (sum, max, sum) behind ONE barrier pair; sred needs 3 * kWaves doubles
 __device__ __forceinline__ void block_sum_max_sum(double &a, double &b, double &c, double *sred) {
   a = wave_sum(a); b = wave_max(b); c = wave_sum(c);
-  if ((threadIdx.x & 63) == 0) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; sred[2 * kWaves + (threadIdx.x >> 6)] = c; }
+  if ((threadIdx.x & 63) == kReduceLane) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; sred[2 * kWaves + (threadIdx.x >> 6)] = c; }
   __syncthreads();
   a = sred_sum(sred); b = sred_max(sred + kWaves); c = sred_sum(sred + 2 * kWaves);
   __syncthreads();
