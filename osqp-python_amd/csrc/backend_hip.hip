@@ -521,7 +521,13 @@ __global__ __launch_bounds__(kBlock) void k_kb(Dev d) {
 }
 
 // K1 ------------------------------------------------------------------------------------------
-struct GVec { const double *x; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * x[c]; } };
+struct GVec {
+  const double *x;
+  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * x[c]; }
+  using Win = double;                                     // windowed row blocks: x's window staged in LDS
+  __device__ __forceinline__ Win stage(int, int c) const { return x[c]; }
+  __device__ __forceinline__ void wprod(const Win &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
+};
 struct EK1 {
   const double *rho; double *t; double pr = 0;
   __device__ __forceinline__ void prefetch(int i) { pr = rho[i]; }
@@ -548,7 +554,7 @@ struct PreK1 {
   }
 };
 __global__ __launch_bounds__(kBlock) void k_k1(Dev d, int i, int probe) {
-  __shared__ StreamLds<1> lds;
+  __shared__ StreamLdsW<1, double> lds;
   if (!wg_has_rows(d.A) && blockIdx.x != 0) return;               // nothing to do and not the flag owner
   if (!probe && d.flags[F_DONE]) return;                          // PCG already converged: cheapest possible exit
   GVec g{d.uu};
@@ -848,7 +854,7 @@ struct EKa {
   }
 };
 __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
-  __shared__ StreamLds<1> lds;
+  __shared__ StreamLdsW<1, double> lds;
   GVec g{d.xs};
   EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha};
   process_rows<1>(d.A, g, e, lds);
@@ -958,7 +964,7 @@ __device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv
 }
 
 __global__ __launch_bounds__(kBlock) void k_slot_a(Dev d) {
-  __shared__ union { StreamLds<1> k1; StreamLdsW<1, double> k1f; } lds;
+  __shared__ union { StreamLdsW<1, double> k1; StreamLdsW<1, double> k1f; } lds;
   const FirstDesc fd = first_desc<true>(d.A);
   SlotState st = slot_read(d.slot + SR_WORDS);         // written by the previous B slot
   int *W = d.slot;
@@ -1011,7 +1017,7 @@ struct EKr1 : NoPrefetch {
   }
 };
 __global__ __launch_bounds__(kBlock) void k_res_m(Dev d) {
-  __shared__ StreamLds<1> lds;
+  __shared__ StreamLdsW<1, double> lds;
   GVec g{d.x};
   EKr1 e{{}, d.z, d.y, d.dy, d.l, d.u, d.E, d.Einv};
   process_rows<1>(d.A, g, e, lds);
@@ -1104,7 +1110,7 @@ struct EViol : NoPrefetch {
   }
 };
 __global__ __launch_bounds__(kBlock) void k_inf_dual_a(Dev d, double thr, int unscaled) {
-  __shared__ StreamLds<1> lds;
+  __shared__ StreamLdsW<1, double> lds;
   GVec g{d.dx};
   EViol e{{}, d.l, d.u, d.Einv, thr, unscaled};
   process_rows<1>(d.A, g, e, lds);
@@ -1148,7 +1154,7 @@ struct EInit : NoPrefetch {
   }
 };
 __global__ __launch_bounds__(kBlock) void k_init_m(Dev d, int full) {
-  __shared__ StreamLds<1> lds;
+  __shared__ StreamLdsW<1, double> lds;
   GVec g{d.xs};
   EInit e{{}, d.rho, d.y, d.z, d.zt, d.t0, d.v, d.dy, full};
   process_rows<1>(d.A, g, e, lds);
@@ -1194,9 +1200,16 @@ __global__ __launch_bounds__(kBlock) void k_scale_warm(Dev d, const double *xin,
 }
 
 struct EStore : NoPrefetch { double *out; __device__ __forceinline__ void operator()(int r, const double (&s)[1]) { out[r] = s[0]; } };
-__global__ __launch_bounds__(kBlock) void k_test_spmv(DevCsr M, const double *in, double *out) {
-  __shared__ StreamLds<1> lds;
-  GVec g{in};
+struct GVecSplit {           // one concatenated input vector; windowed blocks address its two column segments separately
+  const double *x; int split;
+  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * x[c]; }
+  using Win = double;
+  __device__ __forceinline__ Win stage(int seg, int c) const { return x[seg ? split + c : c]; }
+  __device__ __forceinline__ void wprod(const Win &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
+};
+__global__ __launch_bounds__(kBlock) void k_test_spmv(DevCsr M, const double *in, double *out) {     // the path the hot kernels take (windowed where the block is)
+  __shared__ StreamLdsW<1, double> lds;
+  GVecSplit g{in, M.split};
   EStore e{{}, out};
   process_rows<1>(M, g, e, lds);
 }

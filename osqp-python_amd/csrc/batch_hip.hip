@@ -32,20 +32,34 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// Wave64 reductions with DPP moves (VALU rate; HIP's __shfl_* compile to ds_bpermute_b32 -- an LDS round trip per 32-bit half
+// and step; see backend_hip.hip wave_sum).  Zero fill = identity of the sums and of the maxima of magnitudes.  Result in LANE 63.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double bdpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wsum63(double v) {
+  v += bdpp<0xb1>(v); v += bdpp<0x4e>(v); v += bdpp<0x114>(v); v += bdpp<0x118>(v); v += bdpp<0x142, 0xa>(v); v += bdpp<0x143, 0xc>(v);
+  return v;
+}
+__device__ __forceinline__ double wmax63(double v) {
+  v = nmax(v, bdpp<0xb1>(v)); v = nmax(v, bdpp<0x4e>(v)); v = nmax(v, bdpp<0x114>(v)); v = nmax(v, bdpp<0x118>(v));
+  v = nmax(v, bdpp<0x142, 0xa>(v)); v = nmax(v, bdpp<0x143, 0xc>(v));
+  return v;
+}
+
 // Block reductions; all threads get the result.  NW = waves per workgroup.  With ONE wave per problem (NW = 1) a
-// reduction is six __shfl_xor steps: no LDS, no barrier.
+// reduction is six DPP steps and a v_readlane broadcast: no LDS, no barrier.
 template <int NW>
 struct Red {
   double *s;   // >= 16 doubles of LDS (NW > 1 only)
   __device__ __forceinline__ double sum(double v) const {
-    if constexpr (NW == 1) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      return v;
-    } else {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-      if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    v = wsum63(v);
+    if constexpr (NW == 1) return readlane_f64(v, 63);
+    else {
+      if ((threadIdx.x & 63) == 63) s[threadIdx.x >> 6] = v;
       __syncthreads();
       double t = 0.0;
 #pragma unroll
@@ -55,14 +69,10 @@ struct Red {
     }
   }
   __device__ __forceinline__ double max(double v) const {
-    if constexpr (NW == 1) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v = nmax(v, __shfl_xor(v, o, 64));
-      return v;
-    } else {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v = nmax(v, __shfl_down(v, o, 64));
-      if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    v = wmax63(v);
+    if constexpr (NW == 1) return readlane_f64(v, 63);
+    else {
+      if ((threadIdx.x & 63) == 63) s[threadIdx.x >> 6] = v;
       __syncthreads();
       double t = 0.0;
 #pragma unroll
@@ -74,9 +84,8 @@ struct Red {
   __device__ __forceinline__ void sum_max(double &a, double &b) const {   // a: sum, b: max
     if constexpr (NW == 1) { a = sum(a); b = max(b); }
     else {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b = nmax(b, __shfl_down(b, o, 64)); }
-      if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = a; s[8 + (threadIdx.x >> 6)] = b; }
+      a = wsum63(a); b = wmax63(b);
+      if ((threadIdx.x & 63) == 63) { s[threadIdx.x >> 6] = a; s[8 + (threadIdx.x >> 6)] = b; }
       __syncthreads();
       a = 0.0; b = 0.0;
 #pragma unroll
