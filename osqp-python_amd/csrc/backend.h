@@ -67,9 +67,11 @@ enum ResId {
   R_COUNT
 };
 // indices into the int32 status block
-enum FlagId { F_DONE = 0, F_ITERS, F_STAT_SUM, F_STAT_MAX, F_STAT_UNCONV, F_STAT_SUMSQ, F_STAT_N, F_COUNT };
+// F_STAT_STAG: solves that ran into the iteration limit having reduced the residual by less than 10x (a STAGNATING inner solver, as
+// opposed to one that converges steadily but needs more iterations than it was given)
+enum FlagId { F_DONE = 0, F_ITERS, F_STAT_SUM, F_STAT_MAX, F_STAT_UNCONV, F_STAT_SUMSQ, F_STAT_N, F_STAT_STAG, F_COUNT };
 // indices into the fp64 scalar block
-enum ScalId { S_TOL_REL = 0, S_TOL_ABS, S_TOL_NOW, S_HIST = 8 /* gamma[kMaxCg+1], alpha[kMaxCg+1], beta[kMaxCg+1] */ };
+enum ScalId { S_TOL_REL = 0, S_TOL_ABS, S_TOL_NOW, S_RN0 /* ||r_0||_inf of the current PCG */, S_HIST = 8 /* gamma[kMaxCg+1], alpha[kMaxCg+1], beta[kMaxCg+1] */ };
 
 struct Dev {
   int n = 0, m = 0, device = 0;

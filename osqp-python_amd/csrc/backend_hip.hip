@@ -545,7 +545,7 @@ struct PreK1 {
     block_max2(rn, bn, red);
     if (probe) { if (rn < -1.0) d.res[R_COUNT - 1] = bn; return true; }     // probe == 2: pay for the test, ignore it
     const double tol = fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS]);
-    if (i == 0 && blockIdx.x == 0 && threadIdx.x == 0) d.scal[S_TOL_NOW] = tol;   // fused PCG: later tests read the scalar
+    if (i == 0 && blockIdx.x == 0 && threadIdx.x == 0) { d.scal[S_TOL_NOW] = tol; d.scal[S_RN0] = rn; }   // fused PCG: later tests read the scalar
     if (!(rn > tol)) {            // converged (a NaN residual also stops the inner loop; the ADMM residuals will flag it)
       if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = i; }
       return false;
@@ -870,6 +870,7 @@ __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
       double rn = partial_fold_max(partial_load(d.part + (SL_RN0 + (budget & 1)) * kGrid)), bn = partial_fold_max(partial_load(d.part + SL_BN * kGrid));
       block_max2(rn, bn, lds.red);
       done = !(rn > fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS])) ? 2 : 0;
+      if (!done && threadIdx.x == 0 && rn > 0.1 * d.scal[S_RN0]) d.flags[F_STAT_STAG] += 1;
     }
     if (threadIdx.x == 0) {
       const int used = done == 1 ? d.flags[F_ITERS] : budget;
@@ -954,6 +955,7 @@ __device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv
       double rn = partial_fold_max(partial_load(d.part + (SL_RN0 + (used & 1)) * kGrid)), bn = partial_fold_max(partial_load(d.part + SL_BN * kGrid));
       block_max2(rn, bn, lds.red);
       conv = !(rn > fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS])) ? 2 : 0;
+      if (!conv && threadIdx.x == 0 && rn > 0.1 * d.scal[S_RN0]) d.flags[F_STAT_STAG] += 1;
     }
     if (threadIdx.x == 0) {
       d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;

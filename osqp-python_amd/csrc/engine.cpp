@@ -742,17 +742,21 @@ void Engine::admm_core(double t0, double *res) {
     return std::min(cap, std::max(2, std::min(flags[F_STAT_MAX], q3)) + slack);
   };
 
-  // cg_max_iter escalation: when most solves of a chunk ran into the cap itself the inner solver is stagnating (typically an
-  // unbounded LP / rank-deficient QP with n > m, whose reduced matrix has eigenvalues sigma = 1e-6: DESIGN.md section 5) and ADMM
-  // would crawl to max_iter on inexact steps where the direct path finishes in 25 iterations.  The cap then doubles (up to kMaxCg).
+  // cg_max_iter escalation: when most solves of a chunk ran into the cap having reduced their residual by less than 10x the inner
+  // solver is STAGNATING (typically an unbounded LP / rank-deficient QP with n > m, whose reduced matrix has eigenvalues sigma =
+  // 1e-6: DESIGN.md section 5) and ADMM would crawl to max_iter on inexact steps where the direct path finishes in 25 iterations:
+  // the cap then doubles (up to kMaxCg).  Solves that merely need more iterations than the cap allows but converge steadily
+  // (portfolio, lasso: 2-3 decades within 50 iterations) do not count: for them a larger cap buys no ADMM iterations back.
+  static const bool esc_on = [] { const char *e = std::getenv("OSQP_HIP_CG_ESCALATE"); return !(e && e[0] == '0'); }();
+  static const bool stall_on = [] { const char *e = std::getenv("OSQP_HIP_STALL"); return !(e && e[0] == '0'); }();
   auto escalate = [&](bool tight, const int *flags) {
-    if (budget[tight] >= cap && cap < kMaxCg && flags[F_STAT_UNCONV] * 2 > std::max(1, flags[F_STAT_N])) {
+    if (esc_on && budget[tight] >= cap && cap < kMaxCg && flags[F_STAT_STAG] * 2 > std::max(1, flags[F_STAT_N])) {
       cap = std::min(kMaxCg, 2 * cap);
       stats_.cg_cap_escalations += 1;
     }
   };
 
-  double stall = 1.0, best_dua = std::numeric_limits<double>::infinity();
+  double stall = 1.0, best_dua = std::numeric_limits<double>::infinity(), prev_aobj = std::numeric_limits<double>::infinity();
   int stalled_checks = 0;
   int iter = 0;
   int flags[F_COUNT];
@@ -775,7 +779,7 @@ void Engine::admm_core(double t0, double *res) {
     run_slots(cnt, 2 * cnt + (int)std::ceil(1.1 * std::min<double>(pred[tight], lim) * cnt) + 4, lim);
     for (;;) {
       if (with_res) { be::residuals(d_); be::fetch_res_flags(d_, res, f); } else be::fetch_flags(d_, f);
-      tot[F_STAT_SUM] += f[F_STAT_SUM]; tot[F_STAT_SUMSQ] += f[F_STAT_SUMSQ]; tot[F_STAT_N] += f[F_STAT_N]; tot[F_STAT_UNCONV] += f[F_STAT_UNCONV];
+      tot[F_STAT_SUM] += f[F_STAT_SUM]; tot[F_STAT_SUMSQ] += f[F_STAT_SUMSQ]; tot[F_STAT_N] += f[F_STAT_N]; tot[F_STAT_UNCONV] += f[F_STAT_UNCONV]; tot[F_STAT_STAG] += f[F_STAT_STAG];
       tot[F_STAT_MAX] = std::max(tot[F_STAT_MAX], f[F_STAT_MAX]);
       const int done = be::slot_done(d_);
       if (done >= cnt) break;
@@ -806,17 +810,17 @@ void Engine::admm_core(double t0, double *res) {
     // unbounded / rank-deficient ones -- whose status the first checks decide; with the larger cap from the start the engine
     // follows the direct path: DUAL_INFEASIBLE at iteration 25 instead of max_iter, tools/fuzz_gpu.py, tests/test_gpu_fuzz.py).
     const bool first_chunk = iter == 0;
-    if (first_chunk && cap < kMaxCg) {
+    if (first_chunk && cap < kMaxCg && esc_on) {
       if (!ckpt_) ckpt_ = dev_vec<double>(d_, 2 * (size_t)n + 2 * (size_t)m);
       be::copy_in(d_, ckpt_, d_.x, sizeof(double) * n, 1); be::copy_in(d_, ckpt_ + n, d_.xs, sizeof(double) * n, 1);
       be::copy_in(d_, ckpt_ + 2 * (size_t)n, d_.z, sizeof(double) * m, 1); be::copy_in(d_, ckpt_ + 2 * (size_t)n + m, d_.y, sizeof(double) * m, 1);
     }
     const bool at_check = (ct > 0 && next % ct == 0) || next >= settings.max_iter || (ari > 0 && next % ari == 0);
-    const bool ckpt_chunk = first_chunk && cap < kMaxCg;
+    const bool ckpt_chunk = first_chunk && cap < kMaxCg && esc_on;
     exec_chunk(next - iter, tight, at_check && !ckpt_chunk);
     cg_budget_ = budget[tight];
     if (ckpt_chunk) {
-      if (budget[tight] >= cap && flags[F_STAT_UNCONV] * 2 > std::max(1, flags[F_STAT_N])) {
+      if (budget[tight] >= cap && flags[F_STAT_STAG] * 2 > std::max(1, flags[F_STAT_N])) {
         be::copy_in(d_, d_.x, ckpt_, sizeof(double) * n, 1); be::copy_in(d_, d_.xs, ckpt_ + n, sizeof(double) * n, 1);
         be::copy_in(d_, d_.z, ckpt_ + 2 * (size_t)n, sizeof(double) * m, 1); be::copy_in(d_, d_.y, ckpt_ + 2 * (size_t)n + m, sizeof(double) * m, 1);
         be::zero(d_, d_.dx, sizeof(double) * n); be::zero(d_, d_.dy, sizeof(double) * m);
@@ -880,12 +884,17 @@ void Engine::admm_core(double t0, double *res) {
     // tolerance is a fraction of the current SCALED dual residual.  (Upstream's rule, fraction * sqrt(prim*dual)
     // [UPSTREAM-UNVERIFIED], lets r exceed the dual residual whenever prim >> dual; that biases the rho estimate of
     // _osqp.py:880-908 and was measured to cost 2-3x more ADMM iterations -- see DESIGN.md "PCG tolerance".)
-    // When the dual residual stops improving on its best value for two checks in a row (typically an unbounded problem: the dual
-    // residual of an unbounded LP stays O(1) for ever while the primal one jumps around), a tolerance tied to it never tightens
-    // and the certificates of _osqp.py:796-878 -- conditions on dx, dy relative to 1e-4 ||dx|| -- are never met by the inexact
-    // steps: the tolerance then drops by 10x per further stalled check (and recovers when progress resumes).
-    if (res[R_DUA_S] > 0.9 * best_dua) { if (++stalled_checks >= 2) stall = std::max(1e-8, 0.1 * stall); }
-    else { stalled_checks = 0; stall = std::min(1.0, 10.0 * stall); }
+    // Unbounded problems: the dual residual stays O(1) for ever while |objective| keeps growing from check to check.  A tolerance
+    // tied to the dual residual then never tightens and the certificates of _osqp.py:796-878 -- conditions on dx relative to
+    // 1e-4 ||dx|| -- are never met by the inexact steps: from the second such check on the tolerance drops by 10x per check
+    // (and recovers once the dual residual improves on its best value again).  Plateaus of the dual residual on BOUNDED problems (slow ADMM phases of the
+    // lasso / portfolio configs) do not trigger it: tightening there costs 2x the PCG work and buys nothing.
+    const double aobj = std::fabs(info.obj_val);
+    const bool growing = aobj > 1.0 && aobj > 1.02 * prev_aobj;             // |objective| still growing from check to check: the iterates run away
+    prev_aobj = aobj;
+    if (!stall_on) stall = 1.0;
+    else if (res[R_DUA_S] > 0.9 * best_dua) { if (growing && ++stalled_checks >= 2) stall = std::max(1e-8, 0.1 * stall); }
+    else { stalled_checks = 0; stall = std::min(1.0, 10.0 * stall); }        // the dual residual improves again
     best_dua = std::min(best_dua, res[R_DUA_S]);
     double eps = settings.cg_tol_fraction * res[R_DUA_S];
     eps = std::max(std::min(eps, eps_cg_prev_), kCgTolAbsMin);

@@ -63,6 +63,7 @@ void kb_rhs(Dev &d) {
     g += r * u; rn = nanmax(rn, std::fabs(r)); bn = nanmax(bn, std::fabs(rhs));
   }
   s.gamma_next = g; s.rnorm = rn; s.bnorm = bn;
+  d.scal[S_RN0] = rn;
   d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0;
 }
 
@@ -129,7 +130,7 @@ void ka(Dev &d, int budget) {
   // like k_ka of the HIP backend: a PCG whose LAST budgeted update reached the tolerance is converged, not budget-limited
   bool done = d.flags[F_DONE] != 0;
   if (!done) { Impl &s = im(d); const double tol = std::max(d.scal[S_TOL_REL] * s.bnorm, d.scal[S_TOL_ABS]); done = !(s.rnorm > tol); }
-  if (!done) d.flags[F_STAT_UNCONV] += 1;
+  if (!done) { d.flags[F_STAT_UNCONV] += 1; if (im(d).rnorm > 0.1 * d.scal[S_RN0]) d.flags[F_STAT_STAG] += 1; }
 }
 
 void residuals(Dev &d) {
@@ -190,7 +191,7 @@ void infeas_dual(Dev &d, double thr, int unscaled) {
 void fetch_res(Dev &d, double *h) { std::memcpy(h, d.res, sizeof(double) * R_COUNT); }
 void fetch_flags(Dev &d, int *h) {
   std::memcpy(h, d.flags, sizeof(int) * F_COUNT);
-  d.flags[F_STAT_SUM] = d.flags[F_STAT_MAX] = d.flags[F_STAT_UNCONV] = d.flags[F_STAT_SUMSQ] = d.flags[F_STAT_N] = 0;
+  d.flags[F_STAT_SUM] = d.flags[F_STAT_MAX] = d.flags[F_STAT_UNCONV] = d.flags[F_STAT_SUMSQ] = d.flags[F_STAT_N] = d.flags[F_STAT_STAG] = 0;
 }
 void fetch_res_flags(Dev &d, double *hr, int *hf) { fetch_res(d, hr); fetch_flags(d, hf); }
 
