@@ -2,20 +2,21 @@
 //
 // Everything on the ADMM / PCG hot path is a hand-written HIP kernel; there is no rocSPARSE / hipBLAS call and no
 // CPU path.  The path is sparse and bandwidth-bound (~0.17 flop/byte), so no MFMA: the design goals are
-//   * coalesced streaming of the CSR value/index arrays (12 B per stored entry) -- "CSR-stream": a workgroup stages
-//     a contiguous chunk of <= kChunk products val*x[col] in LDS with unit-stride global loads (4 independent
-//     loads + 4 independent gathers in flight per lane), then one lane per row sums its LDS segment.  Rows longer
-//     than kLongRow get a workgroup of their own and are reduced with wave64 __shfl_down + an LDS cross-wave step;
-//   * as few launches as possible per PCG iteration: the Chronopoulos-Gear single-reduction form of PCG needs only
-//     three kernels per iteration (K1: t = rho.*(A u), K2: w = B[u;t] + <w,u>, Kv: fused 5-vector update + <r,u> +
-//     ||r||_inf), every dot product / norm is fused into the kernel that produces its operands;
-//   * no host round trip inside a chunk of ADMM iterations: alpha/beta, the PCG stopping test and the PCG statistics
-//     live in device memory; a converged PCG turns the remaining (K1,K2,Kv) launches of that ADMM iteration into
-//     immediate returns;
+//   * coalesced streaming of the CSR arrays -- "CSR-stream": a workgroup stages a contiguous chunk of <= kChunk products
+//     val * x[col] in LDS with unit-stride global loads, then one (or two) lanes per row sum their LDS segment.  Banded
+//     ("windowed") row blocks fetch the window of the input vector they touch with coalesced loads, keep it in LDS and gather
+//     from LDS through 16-bit local indices (10 bytes per entry, no dependent global gather); rows longer than kLongRow get a
+//     workgroup of their own;
+//   * two kernels per PCG iteration (Chronopoulos-Gear single-reduction PCG with the vector update fused into the SpMV-A
+//     kernel and  t = rho .* (A u)  kept by a recurrence), every dot product / norm fused into the kernel that produces its
+//     operands, and no reduction result needed before a kernel's row EPILOGUE (late hooks);
+//   * wave reductions with DPP moves, never __shfl (which compiles to an LDS round trip per 32-bit half and step);
+//   * no host round trip inside a chunk of ADMM iterations, and no launch wasted on a converged PCG: which phase a launch runs
+//     (KB / K2F on a B slot; K1 / K1F / KA on an A slot) is decided on the device from a phase record ("slot kernels");
 //   * deterministic reductions: every kernel runs with exactly kGrid workgroups; a workgroup writes ONE partial per
 //     reduced quantity (slot[blockIdx.x]) and the consumer kernel sums the kGrid partials in a fixed order
 //     (no atomics), so iteration counts are reproducible run to run;
-//   * launch batching with hipGraph (one graph per (ADMM iterations, PCG budget) pair, see engine.cpp).
+//   * launch batching with hipGraph (five captured strings of slot launches serve every chunk, see engine.cpp).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

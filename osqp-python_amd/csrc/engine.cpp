@@ -497,7 +497,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   solution.x = sol_x_.data(); solution.y = sol_y_.data(); solution.prim_inf_cert = sol_pc_.data(); solution.dual_inf_cert = sol_dc_.data();
   std::memset(&info, 0, sizeof(info));
   set_status(OSQP_UNSOLVED);
-  cg_budget_ = 0; have_tol_ = false; first_run_ = true;
+  cg_budget_ = 0; have_tol_ = false; first_run_ = true; slot_pred_[0] = 6.0; slot_pred_[1] = 14.0;
   stats_ = OSQPHipStats(); stats_.nnzA = nzA; stats_.nnzB = nzB;
   be::sync(d_);
   lap("vectors, rho, preconditioner");
@@ -765,7 +765,7 @@ void Engine::admm_core(double t0, double *res) {
   // sized from the PCG iterations the previous chunk of this kind needed (+10 %); if the string ends before the chunk does, more
   // pairs follow (the residual kernels that ran on the unfinished iterates are simply repeated).
   const bool slots = use_slots_ && be::slots_supported(d_);
-  double pred[2] = {std::min<double>(cap, 12.0), std::min<double>(cap, 24.0)};     // mean PCG iterations per ADMM iteration, per chunk kind
+  double *pred = slot_pred_;                         // mean PCG iterations per ADMM iteration, per chunk kind; kept across solves of the handle
   auto exec_chunk = [&](int cnt, bool tight, bool with_res) {
     if (!slots) {
       run_chunk(cnt, budget[tight]);
@@ -776,7 +776,7 @@ void Engine::admm_core(double t0, double *res) {
     // (per-solve iteration limit = the budget rule of the launch-per-iteration form: the two forms then execute the SAME arithmetic
     // -- truncating the rare long solve at mean + 3 sigma of the previous chunk costs no ADMM iterations and a third of the PCG work)
     const int lim = budget[tight];
-    run_slots(cnt, 2 * cnt + (int)std::ceil(1.1 * std::min<double>(pred[tight], lim) * cnt) + 4, lim);
+    run_slots(cnt, 2 * cnt + (int)std::ceil(1.05 * std::min<double>(pred[tight], lim) * cnt) + 2, lim);
     for (;;) {
       if (with_res) { be::residuals(d_); be::fetch_res_flags(d_, res, f); } else be::fetch_flags(d_, f);
       tot[F_STAT_SUM] += f[F_STAT_SUM]; tot[F_STAT_SUMSQ] += f[F_STAT_SUMSQ]; tot[F_STAT_N] += f[F_STAT_N]; tot[F_STAT_UNCONV] += f[F_STAT_UNCONV]; tot[F_STAT_STAG] += f[F_STAT_STAG];

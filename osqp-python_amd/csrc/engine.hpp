@@ -120,6 +120,7 @@ class Engine {
   void run_chunk(int niter, int budget);
   void run_slots(int begin_target, int pairs, int cap);     // slot form: [slot_begin(begin_target)] + pairs x (B slot, A slot)
   bool use_slots_ = true;
+  double slot_pred_[2] = {6.0, 14.0};   // PCG iterations per ADMM iteration the slot strings are sized for (ordinary / tight chunks)
   std::map<std::array<int, 3>, void *> sgraphs_;
   void admm_core(double t0, double *res);
   void polish();
