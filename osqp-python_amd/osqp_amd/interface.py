@@ -8,10 +8,10 @@ normalisation pipeline for the problem data, one table for the settings that are
 Code generation and the adjoint-derivative entry points are out of scope and say so when called.
 """
 import functools
-import importlib
-import os
-import warnings
-from enum import IntEnum
+import importlib as _importlib
+import os as _os
+import warnings as _warnings
+from enum import IntEnum as _IntEnum
 from types import SimpleNamespace as _Namespace
 
 import numpy as np
@@ -19,14 +19,14 @@ from scipy import sparse as spa
 
 # algebra name -> extension module that binds the C ABI (the reference keeps the same kind of table, interface.py:14-24)
 _BACKENDS = {'hip': 'osqp_amd.ext_hip'}
-OSQP_ALGEBRA_BACKEND = os.environ.get('OSQP_ALGEBRA_BACKEND')
+OSQP_ALGEBRA_BACKEND = _os.environ.get('OSQP_ALGEBRA_BACKEND')
 
 
 @functools.lru_cache(maxsize=None)
 def _backend(algebra):
     if algebra not in _BACKENDS:
         raise AssertionError(f'Unknown algebra {algebra}')
-    return importlib.import_module(_BACKENDS[algebra])
+    return _importlib.import_module(_BACKENDS[algebra])
 
 
 def algebra_available(algebra):
@@ -56,12 +56,12 @@ def constant(which, algebra='hip'):
     """Value of a named constant of the extension module (``OSQP_INFTY``, a status or error name, ...)."""
     ext = _backend(algebra)
     if which in ext.osqp_status_type.__members__:
-        warnings.warn('Direct access to osqp status values will be deprecated. Please use the SolverStatus enum instead.',
+        _warnings.warn('Direct access to osqp status values will be deprecated. Please use the SolverStatus enum instead.',
                       PendingDeprecationWarning)
     if which == 'OSQP_NAN' and not hasattr(ext, which):
         return np.nan
     value = getattr(ext, which, None)
-    if isinstance(value, IntEnum):
+    if isinstance(value, _IntEnum):
         return int(value)
     if isinstance(value, (int, float, str)):
         return value
@@ -69,7 +69,7 @@ def constant(which, algebra='hip'):
 
 
 def _mirror_enum(name, source):
-    return IntEnum(name, {member.name: int(member) for member in source})
+    return _IntEnum(name, {member.name: int(member) for member in source})
 
 
 SolverStatus = _mirror_enum('SolverStatus', _backend('hip').osqp_status_type)
@@ -106,7 +106,7 @@ def _sparse_csc(matrix, label, dtype, upper_only=False):
     if upper_only and spa.tril(matrix, -1).nnz:
         matrix = spa.triu(matrix, format='csc')
     if not spa.isspmatrix_csc(matrix):
-        warnings.warn(f'Converting sparse {label} to a CSC matrix. This may take a while...')
+        _warnings.warn(f'Converting sparse {label} to a CSC matrix. This may take a while...')
         matrix = matrix.tocsc()
     if not matrix.has_sorted_indices:
         matrix.sort_indices()
@@ -211,7 +211,7 @@ class OSQP:
         _require(self.settings is not None, 'setup() has to be called first')
         for old, new in _RENAMED.items():
             if old in kwargs:
-                warnings.warn(f'"{old}" is deprecated. Please use "{new}" instead.', DeprecationWarning)
+                _warnings.warn(f'"{old}" is deprecated. Please use "{new}" instead.', DeprecationWarning)
                 kwargs[new] = kwargs.pop(old)
         if 'rho' in kwargs and self._solver is not None:          # rho of a live solver goes through its own entry point
             new_rho = kwargs.pop('rho')
@@ -261,13 +261,13 @@ class OSQP:
 
     def solve(self, raise_error=None):
         if raise_error is None:
-            warnings.warn('The default value of raise_error will change to True in the future.', PendingDeprecationWarning)
-            raise_error = False
+            _warnings.warn('The default value of raise_error will change to True in the future.', PendingDeprecationWarning)
+        strict = bool(raise_error)                 # (None: today's default, report through info.status_val only)
         self._solver.solve()
         raw = self._solver.info
         if raw.status_val == SolverStatus.OSQP_NON_CVX:
             raw.obj_val = np.nan
-        if raise_error and raw.status_val != SolverStatus.OSQP_SOLVED:
+        if strict and raw.status_val != SolverStatus.OSQP_SOLVED:
             raise OSQPException(raw.status_val)
         info = _Namespace(**{name: getattr(raw, name) for name in vars(type(raw)) if not name.startswith('_')})
         sol = self._solver.solution
