@@ -214,11 +214,11 @@ def main():
                        'time_to_solution_ms': tts_ms, 'admm_iters_per_solve': int(res.info.iter), 'status': res.info.status, 'obj_val': res.info.obj_val,
                        'prim_res': res.info.prim_res, 'dual_res': res.info.dual_res, 'rho_updates': int(res.info.rho_updates),
                        'pcg_iters_per_admm_iter': stats['pcg_iters_total'] / max(res.info.iter, 1), 'pcg_budget_limited_iters': int(stats['pcg_unconverged']),
-                       'cg_cap_escalations': int(stats.get('cg_cap_escalations', 0)),
+                       'cg_cap_escalations': int(stats.get('cg_cap_escalations', 0)), 'slot_topups': int(stats.get('slot_topups', 0)),
                        'windowed_row_blocks': '%d of %d' % (int(stats.get('windowed_blocks', 0)), int(stats.get('row_blocks', 0))),
                        'pcg_kernels_per_iteration': 2 if fused else 3, 'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
                        'setup_s': t_setup, 'per_rank': [{'status': int(r[0]), 'iter': int(r[1]), 'obj': r[2]} for r in allrec]},
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'roofline': {'bound': 'hbm', 'kernel': dom + (' -- in solves this body runs as the K2F phase of k_slot_b' if fused else ''), 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': probes[dom]['GBps'] / HBM_PEAK_GBS, 'traffic': pmc_traffic(dom_kernel),
                          'bytes_per_launch': kb[dom], 'ms_per_launch': probes[dom]['ms'],
                          'pcg_iteration': {'bytes': pcg_bytes, 'ms': pcg_ms, 'GBps': pcg_bytes / (pcg_ms * 1e-3) / 1e9,
