@@ -108,6 +108,14 @@ class Oracle:
         self.cert = cert
         return x, y, info
 
+    def polish(self, delta=1e-6, polish_refine_iter=3):
+        """The reference's polish step on the iterates the last solve() left (status must be SOLVED): returns x, y, info, status_polish."""
+        x = np.empty(self.n); y = np.empty(self.m); info = Info()
+        L = lib()
+        L.oracle_polish.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Info)]
+        st = L.oracle_polish(C.c_void_p(self._h), float(delta), int(polish_refine_iter), _dp(x), _dp(y), C.byref(info))
+        return x, y, info, st
+
     def update(self, q=None, l=None, u=None, Px=None, Ax=None):
         L = lib(); h = C.c_void_p(self._h)
         if q is not None:

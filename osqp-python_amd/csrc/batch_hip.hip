@@ -100,6 +100,17 @@ struct Red {
 
 namespace {
 
+// hi + lo += a * v in double-double: the product exactly (FMA), the sum by TwoSum.  Contraction is switched off for this body:
+// a fused a * v + hi would break the error terms.
+__device__ __forceinline__ void dd_acc(double a, double v, double &hi, double &lo) {
+#pragma clang fp contract(off)
+  const double pr = a * v;
+  const double pe = __builtin_fma(a, v, -pr);
+  const double sm_ = hi + pr, bv = sm_ - hi;
+  lo += ((hi - (sm_ - bv)) + (pr - bv)) + pe;
+  hi = sm_;
+}
+
 // kBB = threads per problem: 64 (one wave: barriers are free, reductions are pure shuffles; small problems) or 256.
 // EA / EB > 0: every lane keeps EA entries of A and EB entries of B (value + column) in registers for the whole solve
 // (entry k belongs to lane k % kBB); an SpMV is then  prod[k] = val * v[col]  for the lane's own entries (LDS only),
@@ -114,7 +125,9 @@ namespace {
 // REGISTERS: element e of the vector lives in lane e % 64 from the step that loads it until its own pivot step (bw < 64),
 // a pivot is broadcast with v_readlane, every other lane applies its one update -- no LDS traffic on the dependency chain
 // except the (prefetchable) column of L.
-template <int kBB, int EA, int EB, bool DIRECT>
+// POLISH (direct variants): a separate instantiation that ends with the polish step, so that the plain kernel's register allocation
+// is not touched by code most launches never run.
+template <int kBB, int EA, int EB, bool DIRECT, bool POLISH = false>
 __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) void k_batch_admm(BatchParams P) {
 #ifdef OSQP_HIP_KTRACE
   // diagnostic build: 100 MHz clock ticks spent in the phases; reported in rec[5..7] INSTEAD of rho / rho_updates / pcg_iters
@@ -200,6 +213,47 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
   const double n_ineq = red.sum((double)n_ineq_local);
   const double eqf = (n_ineq == 0.0) ? 1e3 : (DIRECT ? P.eq_factor_direct : P.eq_factor);  // engine.cpp classify_constraints()
   double rho_bar = P.rho0;
+  // DIRECT: assemble  K = (P + sigma I) + shift I + A' diag(rho) A  in the band and factorise it (shift = 0 for the ADMM system;
+  // the polish step factorises P + delta I + A_act' (1/delta) A_act with shift = delta - sigma and rho = the active-row weights)
+  [[maybe_unused]] auto factorize = [&](double shift) {
+    BT_BEGIN();
+    // ---- assemble K (lower band, permuted) ----
+    for (int s_ = tid - kBatchNB; s_ < n8 * W + 64; s_ += kBB) Lb[s_] = 0.0;
+    __syncthreads();
+    for (int k = tid; k < B.nnz; k += kBB) { const int s_ = P.bp_slot[k]; if (s_ >= 0) Lb[s_] = B.val[k]; }      // P + sigma I
+    __syncthreads();
+    if (shift != 0.0) { for (int c = tid; c < n; c += kBB) Lb[c * W] += shift; __syncthreads(); }
+    for (int e = tid; e < P.nents; e += kBB) {                                                              // + A' rho A
+      double acc = 0.0;
+      for (int q_ = P.ke_ptr[e]; q_ < P.ke_ptr[e + 1]; q_++) acc += rho[P.kp_row[q_]] * P.kp_val[q_];
+      Lb[P.ke_slot[e]] += acc;
+    }
+    __syncthreads();
+    // ---- banded Cholesky, right-looking: column c, then the (bw x bw)/2 trailing update spread over the wave ----
+    for (int c = 0; c < n; c++) {
+      const double di = 1.0 / sqrt(Lb[c * W]);
+      const int kmax = min(bw, n - 1 - c);
+      const bool mine = tid >= 1 && tid <= kmax;
+      double v = 0.0;
+      if (mine) v = Lb[c * W + tid] * di;
+      __syncthreads();
+      if (mine) Lb[c * W + tid] = v;
+      if (tid == 0) dinv[c] = di;
+      __syncthreads();
+      for (int t_ = tid; t_ < P.ntri; t_ += kBB) {
+        const int ab = P.tri[t_], a = ab & 255, b_ = ab >> 8;
+        if (b_ <= kmax) Lb[(c + a) * W + (b_ - a)] -= Lb[c * W + b_] * Lb[c * W + a];
+      }
+      __syncthreads();
+    }
+    // K = L L' = L^ D L^' with unit-lower L^ = L diag(1/L_jj), D = diag(L_jj^2): the substitutions then carry no
+    // division or pivot scaling on their dependency chain.  Lb <- L^ (strictly lower part), dinv <- 1/D.
+    for (int s_ = tid; s_ < n * W; s_ += kBB) { const int c = s_ / W, k = s_ - c * W; if (k >= 1 && k <= bw) Lb[s_] *= dinv[c]; }
+    __syncthreads();
+    for (int c = tid; c < n; c += kBB) { const double di = dinv[c]; dinv[c] = di * di; Lb[c * W] = 0.0; }   // (diagonal slots read as L^ = 0)
+    __syncthreads();
+    BT_END(tk_fact);
+  };
   auto set_rho = [&](double rb) {
     for (int i = tid; i < m; i += kBB) {
       const double li = l[i], ui = u[i];
@@ -208,44 +262,8 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
       rho[i] = ty == -1 ? 1e-6 : (ty == 1 ? eqf * rb : rb);                                       // _osqp.py:520-522
     }
     __syncthreads();
-    if constexpr (DIRECT) {
-      BT_BEGIN();
-      // ---- assemble K (lower band, permuted) ----
-      for (int s_ = tid - kBatchNB; s_ < n8 * W + 64; s_ += kBB) Lb[s_] = 0.0;
-      __syncthreads();
-      for (int k = tid; k < B.nnz; k += kBB) { const int s_ = P.bp_slot[k]; if (s_ >= 0) Lb[s_] = B.val[k]; }      // P + sigma I
-      __syncthreads();
-      for (int e = tid; e < P.nents; e += kBB) {                                                              // + A' rho A
-        double acc = 0.0;
-        for (int q_ = P.ke_ptr[e]; q_ < P.ke_ptr[e + 1]; q_++) acc += rho[P.kp_row[q_]] * P.kp_val[q_];
-        Lb[P.ke_slot[e]] += acc;
-      }
-      __syncthreads();
-      // ---- banded Cholesky, right-looking: column c, then the (bw x bw)/2 trailing update spread over the wave ----
-      for (int c = 0; c < n; c++) {
-        const double di = 1.0 / sqrt(Lb[c * W]);
-        const int kmax = min(bw, n - 1 - c);
-        const bool mine = tid >= 1 && tid <= kmax;
-        double v = 0.0;
-        if (mine) v = Lb[c * W + tid] * di;
-        __syncthreads();
-        if (mine) Lb[c * W + tid] = v;
-        if (tid == 0) dinv[c] = di;
-        __syncthreads();
-        for (int t_ = tid; t_ < P.ntri; t_ += kBB) {
-          const int ab = P.tri[t_], a = ab & 255, b_ = ab >> 8;
-          if (b_ <= kmax) Lb[(c + a) * W + (b_ - a)] -= Lb[c * W + b_] * Lb[c * W + a];
-        }
-        __syncthreads();
-      }
-      // K = L L' = L^ D L^' with unit-lower L^ = L diag(1/L_jj), D = diag(L_jj^2): the substitutions then carry no
-      // division or pivot scaling on their dependency chain.  Lb <- L^ (strictly lower part), dinv <- 1/D.
-      for (int s_ = tid; s_ < n * W; s_ += kBB) { const int c = s_ / W, k = s_ - c * W; if (k >= 1 && k <= bw) Lb[s_] *= dinv[c]; }
-      __syncthreads();
-      for (int c = tid; c < n; c += kBB) { const double di = dinv[c]; dinv[c] = di * di; Lb[c * W] = 0.0; }   // (diagonal slots read as L^ = 0)
-      __syncthreads();
-      BT_END(tk_fact);
-    } else {
+    if constexpr (DIRECT) factorize(0.0);
+    else {
       for (int j = tid; j < n; j += kBB) {                   // Jacobi preconditioner = 1/diag(K)
         double sacc = 0.0, dg = 0.0;
         for (int k = B.rowptr[j]; k < B.rowptr[j + 1]; k++) { const int c = B.col[k]; const double a = B.val[k]; if (c == j) dg = a; if (c >= n) sacc += rho[c - n] * a * a; }
@@ -519,14 +537,79 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
     e2 = fmax(fmin(e2, eps_prev), 1e-13);
     if (isfinite(e2)) { eps_prev = e2; eps_cg = e2; rel_rule = false; }
   }
+  // ---- polish (_osqp.py:1710-1828), direct variants only: the reference's algorithm on the factor already in LDS ----
+  // Active rows guessed from the scaled (z, y) (:1719-1720); the regularised reduced KKT system
+  //     [P + delta I, A_act'; A_act, -delta I] [dx; dy] = [r1; r2]
+  // is solved through its Schur complement  (P + delta I + A_act' A_act / delta) dx = r1 + A_act' r2 / delta,  dy = (A_act dx - r2) / delta,
+  // ONE banded factorisation (factorize: weights 1/delta on active rows, 0 elsewhere, diagonal shift delta - sigma), and the
+  // first solve plus polish_refine_iter refinement steps (:1692-1708) all have the same form: with (x, y) = 0 at the start,
+  //     t = y - (b - A_act x) / delta,   rhs = -q - P x - A_act' t,   dx = K^-1 rhs,   x += dx,   y = t + A_act dx / delta.
+  // Then z = A x, the normal-cone projection (:1773-1780) and the accept test on the residuals (:1786-1793).
+  int status_polish = 0;
+  [[maybe_unused]] unsigned long long pol_ticks = 0;
+  if constexpr (DIRECT && POLISH) {
+    if (status == OSQP_SOLVED) {
+      const unsigned long long tp0 = wall_clock64();
+      const double idel = 1.0 / P.delta;
+      // ADMM point kept in p (x), zt (z), dy (y): none of them is live in the direct variant after the loop
+      for (int j = tid; j < n; j += kBB) { p[j] = x[j]; x[j] = 0.0; }
+      for (int i = tid; i < m; i += kBB) {
+        const double zi = z[i], yi = y[i];
+        zt[i] = zi; dy[i] = yi;
+        const bool low = zi - l[i] < -yi, upp = !low && (u[i] - zi < yi);      // (a row active on both sides enters once, at its lower bound)
+        rho[i] = (low || upp) ? idel : 0.0;
+        z[i] = low ? l[i] : u[i];                                              // b_i of an active row (unused otherwise)
+        y[i] = 0.0;
+      }
+      __syncthreads();
+      factorize(P.delta - P.sigma);
+      // The Schur complement amplifies an error of A x - b by 1/delta: the constraint residual of the current x is accumulated in
+      // double-double (exact products by FMA, compensated sums), the classic higher-precision residual of iterative refinement,
+      // and y advances by the correction of the step (t + A dx / delta) -- its noise floor is eps |y|, not eps |A||x| / delta.
+      for (int k = 0; k <= P.refine; k++) {
+        for (int i = tid; i < m; i += kBB) {
+          double tv = 0.0;
+          if (rho[i] != 0.0) {
+            double hi = -z[i], lo = 0.0;                                        // (A x)_i - b_i
+            for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; e++) {
+              const double a = A.val[e], v = x[A.col[e]];
+              dd_acc(a, v, hi, lo);
+            }
+            tv = y[i] + (hi + lo) * idel;                                       // y - r2 / delta,  r2 = b - A x
+          }
+          t[i] = tv;
+        }
+        __syncthreads();
+        applyB(x, t, [&](int j, double s_) { Kp[j] = -q[j] + P.sigma * x[j] - s_; });       // (B carries P + sigma I)
+        ksolve(Kp, Minv);
+        for (int j = tid; j < n; j += kBB) x[j] += Minv[j];
+        __syncthreads();
+        applyA(Minv, [&](int i, double adx) { if (rho[i] != 0.0) y[i] = t[i] + adx * idel; });
+      }
+      applyA(x, [&](int i, double ax) { const double tmp = ax + y[i], zc = fmin(fmax(tmp, l[i]), u[i]); z[i] = zc; y[i] = tmp - zc; });
+      const double pri0 = prim_res, dua0 = dual_res;
+      residuals();
+      const double ppri = m == 0 ? 0.0 : (unsc ? pri_u : pri_s), pdua = unsc ? P.cinv * dua_u : dua_s;
+      const bool ok = (ppri < pri0 && pdua < dua0) || (ppri < pri0 && dua0 < 1e-10) || (pdua < dua0 && pri0 < 1e-10);
+      if (ok) { obj = (0.5 * xpx + qx) * (P.scaling ? P.cinv : 1.0); prim_res = ppri; dual_res = pdua; status_polish = 1; }
+      else {
+        status_polish = -1;
+        for (int j = tid; j < n; j += kBB) x[j] = p[j];
+        for (int i = tid; i < m; i += kBB) { z[i] = zt[i]; y[i] = dy[i]; }
+      }
+      __syncthreads();
+      pol_ticks = wall_clock64() - tp0;
+    }
+  }
   // ---- store: x = D x, y = cinv E y (_osqp.py:1110-1112); certificates in place of x / y for infeasible problems ----
   const bool pinf = status == OSQP_PRIMAL_INFEASIBLE || status == OSQP_PRIMAL_INFEASIBLE_INACCURATE;
   const bool dinf = status == OSQP_DUAL_INFEASIBLE || status == OSQP_DUAL_INFEASIBLE_INACCURATE;
   for (int j = tid; j < n; j += kBB) P.x[(size_t)b * n + j] = dinf ? (unsc ? P.D[j] * dx[j] : dx[j]) : (pinf ? NAN : (P.scaling ? P.D[j] * x[j] : x[j]));
   for (int i = tid; i < m; i += kBB) P.y[(size_t)b * m + i] = pinf ? (unsc ? P.E[i] * dy[i] : dy[i]) : (dinf ? NAN : (P.scaling ? P.cinv * P.E[i] * y[i] : y[i]));
   if (tid == 0) {
-    double *rc = P.rec + (size_t)b * 8;
+    double *rc = P.rec + (size_t)b * kBatchRec;
     rc[0] = status; rc[1] = iter; rc[2] = obj; rc[3] = prim_res; rc[4] = dual_res; rc[5] = rho_bar; rc[6] = rho_updates; rc[7] = (double)pcg_total;
+    rc[8] = status_polish; rc[9] = 1e-8 * (double)pol_ticks;      // (100 MHz wall clock -> seconds)
 #ifdef OSQP_HIP_KTRACE
     rc[5] = (double)tk_fact; rc[6] = (double)tk_solve; rc[7] = (double)(wall_clock64() - tk_all);
 #endif
@@ -587,10 +670,11 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
   const size_t lds_reg = ch.lds_reg, lds_gen = ch.lds_gen, lds_dir = ch.lds_dir;
   const bool use_dir256 = ch.dir256, use_dir = ch.dir64, use64 = ch.w64, use256 = ch.w256;
 #define BATCH_LAUNCH(TB, E, LDS) hipLaunchKernelGGL((k_batch_admm<TB, E, E, false>), dim3(p.nbatch), dim3(TB), LDS, st, p)
-#define BATCH_LAUNCH_DIRECT(TB, E) do { \
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<TB, E, E, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dir) != hipSuccess) \
+#define BATCH_LAUNCH_DIRECT_P(TB, E, POL) do { \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<TB, E, E, true, POL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dir) != hipSuccess) \
       throw DeviceError("osqp_hip: cannot reserve LDS for the direct batch kernel"); \
-    hipLaunchKernelGGL((k_batch_admm<TB, E, E, true>), dim3(p.nbatch), dim3(TB), lds_dir, st, p); } while (0)
+    hipLaunchKernelGGL((k_batch_admm<TB, E, E, true, POL>), dim3(p.nbatch), dim3(TB), lds_dir, st, p); } while (0)
+#define BATCH_LAUNCH_DIRECT(TB, E) do { if (p.polish) BATCH_LAUNCH_DIRECT_P(TB, E, true); else BATCH_LAUNCH_DIRECT_P(TB, E, false); } while (0)
   if (use_dir256) {
     if (e256 <= 2) BATCH_LAUNCH_DIRECT(256, 2); else if (e256 <= 4) BATCH_LAUNCH_DIRECT(256, 4); else if (e256 <= 8) BATCH_LAUNCH_DIRECT(256, 8); else BATCH_LAUNCH_DIRECT(256, 16);
   } else if (use_dir) {
@@ -606,6 +690,7 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
   }
 #undef BATCH_LAUNCH
 #undef BATCH_LAUNCH_DIRECT
+#undef BATCH_LAUNCH_DIRECT_P
   hipError_t e = stream ? hipGetLastError() : hipStreamSynchronize(st);
   if (e != hipSuccess) throw DeviceError(std::string("osqp_hip: batch kernel failed: ") + hipGetErrorString(e));
   return OSQP_NO_ERROR;

@@ -1173,7 +1173,7 @@ int Engine::update_settings(const OSQPSettings *s) {
 // update-style batching (nn/torch.py:136-164: update(q,l,u) + solve() per element) as ONE kernel launch.
 // q: nbatch x n, l/u: nbatch x m (row-major; NULL = this solver's current vector for every problem);
 // x: nbatch x n, y: nbatch x m (in: unscaled warm start if warm != 0; out: solution, or certificate for infeasible ones);
-// rec: nbatch x 8 = {status_val, iter, obj_val, prim_res, dual_res, rho, rho_updates, pcg_iters}.
+// rec: nbatch x kBatchRec = {status_val, iter, obj_val, prim_res, dual_res, rho, rho_updates, pcg_iters, status_polish, polish_time}.
 
 
 // ------------------------------------------------------------------------------------------------ LinSysSolver slot
@@ -1368,6 +1368,7 @@ void Engine::fill_batch_params(BatchParams &p, int nbatch, int warm) {
   p.max_iter = settings.max_iter; p.check = settings.check_termination; p.rho_interval = settings.adaptive_rho ? auto_rho_interval() : 0;
   p.cg_max = settings.cg_max_iter; p.unscaled = settings.scaling && !settings.scaled_termination; p.scaling = settings.scaling;
   p.precond = settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER; p.rho_is_vec = settings.rho_is_vec; p.warm = warm;
+  p.polish = settings.polishing; p.refine = settings.polish_refine_iter; p.delta = settings.delta;      // (honoured by the direct variants)
 }
 
 void Engine::attach_batch_direct(BatchParams &p) {
@@ -1383,7 +1384,8 @@ void Engine::attach_batch_direct(BatchParams &p) {
 // on the device with exact linear solves and the reference's rho rule, i.e. the algorithm of the reference's direct path
 // (same iteration counts as the oracle), instead of thousands of graph-replayed multi-kernel iterations with inexact
 // inner solves -- on small LPs / rank-deficient QPs the latter can need 10x more ADMM iterations (fuzz).
-// Polish (host-driven, Engine::polish) then runs on the device iterates this path leaves behind.  Not taken with verbose
+// With `polishing`, a SOLVED problem is polished in the same launch (reduced KKT system on the active set, factorised in LDS,
+// polish_refine_iter refinement steps: the reference's algorithm, _osqp.py:1710-1828).  Not taken with verbose
 // output (per-iteration printing lives in the host-driven loop), with a time limit, or when OSQP_HIP_SMALL_DIRECT=0.
 bool Engine::small_direct_applicable() {
   const char *env = std::getenv("OSQP_HIP_SMALL_DIRECT");       // read per solve: tests and tools switch it at run time
@@ -1407,13 +1409,14 @@ int Engine::solve_small_direct(double t0) {
     for (int j = 0; j < n; j++) x[j] *= D_[j];
     for (int i = 0; i < m; i++) y[i] *= cinv_ * E_[i];
   }
-  double rec[8] = {0};
+  double rec[kBatchRec] = {0};
   const int err = batch_solve(1, nullptr, nullptr, nullptr, x.data(), y.data(), rec, warm);
   if (err) return err;
   const int st = (int)rec[0];
   set_status(st);
   info.iter = (int)rec[1]; info.obj_val = rec[2]; info.prim_res = rec[3]; info.dual_res = rec[4];
   info.rho_updates = (int)rec[6]; info.rho_estimate = rec[5];
+  info.status_polish = (int)rec[8]; info.polish_time = rec[9];      // polished inside the kernel (reduced KKT on the factor in LDS)
   if (rec[5] != rho_bar_) {                                     // adaptive rho moved: keep the handle's state in step (_osqp.py:923-930)
     rho_bar_ = clamp_rho(rec[5]); settings.rho = rho_bar_;
     be::set_rho(d_, rho_bar_);
@@ -1460,8 +1463,7 @@ int Engine::solve_small_direct(double t0) {
   stats_.pcg_iters_total = stats_.pcg_iters_max = stats_.pcg_unconverged = 0;
   stats_.kernel_launches = 1; stats_.graph_launches = 0;
   be::sync(d_);
-  info.solve_time = now_s() - t0;
-  if (settings.polishing && st == OSQP_SOLVED) { polish(); store_solution(); be::sync(d_); }   // _osqp.py:1278-1279
+  info.solve_time = std::max(now_s() - t0 - info.polish_time, 0.0);
   info.run_time = (first_run_ ? info.setup_time : info.update_time) + info.solve_time + info.polish_time;
   first_run_ = false; clear_update_time_ = true;
   return OSQP_NO_ERROR;
@@ -1485,9 +1487,9 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
     }
   tph[1] = now_s();
   // one device scratch block, kept for the next call: [q | l | u | x | y | rec | q0 | l0 | u0]
-  const size_t need = 2 * N + 3 * M + (size_t)nbatch * 8 + n + 2 * (size_t)m;
+  const size_t need = 2 * N + 3 * M + (size_t)nbatch * kBatchRec + n + 2 * (size_t)m;
   if (need > bbuf_cap_) { if (bbuf_) be::dfree(d_, bbuf_); bbuf_ = dev_vec<double>(d_, need); bbuf_cap_ = need; }
-  double *dq = bbuf_, *dl = dq + N, *du = dl + M, *dx = du + M, *dy = dx + N, *drec = dy + M, *dq0 = drec + (size_t)nbatch * 8, *dl0 = dq0 + n, *du0 = dl0 + m;
+  double *dq = bbuf_, *dl = dq + N, *du = dl + M, *dx = du + M, *dy = dx + N, *drec = dy + M, *dq0 = drec + (size_t)nbatch * kBatchRec, *dl0 = dq0 + n, *du0 = dl0 + m;
   const bool devv = be::device_vec_updates();         // then the solver's own q, l, u are resident (unscaled): no upload for NULL arguments
   if (q) be::h2d(d_, dq, q, sizeof(double) * N); else if (devv) dq0 = d_.qraw; else be::h2d(d_, dq0, q0_.data(), sizeof(double) * n);
   if (l) be::h2d(d_, dl, l, sizeof(double) * M); else if (devv) dl0 = d_.lraw; else be::h2d(d_, dl0, l0_.data(), sizeof(double) * m);
@@ -1505,7 +1507,7 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   int err = be::batch_solve(d_, p);
   tph[3] = now_s();
   if (!err) {
-    be::d2h(d_, x, dx, sizeof(double) * N); be::d2h(d_, y, dy, sizeof(double) * M); be::d2h(d_, rec, drec, sizeof(double) * 8 * nbatch);
+    be::d2h(d_, x, dx, sizeof(double) * N); be::d2h(d_, y, dy, sizeof(double) * M); be::d2h(d_, rec, drec, sizeof(double) * kBatchRec * nbatch);
   }
   tph[4] = now_s();
   stats_.gpu_solve_ms = 1e3 * (tph[3] - tph[2]);

@@ -248,11 +248,12 @@ class OSQPSolver:
     def hip_set_rho_eq_factor(self, factor):
         return self._lib.osqp_hip_set_rho_eq_factor(self._p, float(factor))
 
-    BATCH_FIELDS = ('status_val', 'iter', 'obj_val', 'prim_res', 'dual_res', 'rho', 'rho_updates', 'pcg_iters')
+    BATCH_FIELDS = ('status_val', 'iter', 'obj_val', 'prim_res', 'dual_res', 'rho', 'rho_updates', 'pcg_iters', 'status_polish', 'polish_time')
+    BATCH_REC = len(BATCH_FIELDS)        # OSQP_HIP_BATCH_REC
 
     def hip_batch_solve(self, q=None, l=None, u=None, x0=None, y0=None, nbatch=None):
         """Solve a batch of QPs sharing this solver's P, A and settings (osqp_hip_batch_solve).  q: (B, n), l/u: (B, m).
-        Returns x (B, n), y (B, m), rec (B, 8) with columns BATCH_FIELDS."""
+        Returns x (B, n), y (B, m), rec (B, BATCH_REC) with columns BATCH_FIELDS."""
         arrs = [a for a in (q, l, u, x0, y0) if a is not None]
         B = int(nbatch) if nbatch is not None else int(np.asarray(arrs[0]).shape[0])
         q, l, u = (None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(B, -1) for a in (q, l, u))
@@ -260,7 +261,7 @@ class OSQPSolver:
         # (l, u are clamped to +-OSQP_INFTY inside the kernel, like interface.py:334-337)
         x = np.zeros((B, self.n)) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).reshape(B, self.n).copy()
         y = np.zeros((B, self.m)) if y0 is None else np.ascontiguousarray(y0, dtype=np.float64).reshape(B, self.m).copy()
-        rec = np.zeros((B, 8))
+        rec = np.zeros((B, self.BATCH_REC))
         st = self._lib.osqp_hip_batch_solve(self._p, B, _ptr(q, _lib.c_double_p), _ptr(l, _lib.c_double_p), _ptr(u, _lib.c_double_p),
                                             _ptr(x, _lib.c_double_p), _ptr(y, _lib.c_double_p), _ptr(rec, _lib.c_double_p), int(warm))
         if st:
@@ -269,7 +270,7 @@ class OSQPSolver:
 
     def hip_batch_solve_device(self, nbatch, q_ptr, l_ptr, u_ptr, x_ptr, y_ptr, rec_ptr, warm=False, stream=None):
         """osqp_hip_batch_solve_device: raw device addresses (int or None) of float64 arrays laid out as in hip_batch_solve;
-        rec: (B, 8).  Enqueued on `stream` (hipStream_t handle as int; None: the solver's stream, synchronous)."""
+        rec: (B, BATCH_REC).  Enqueued on `stream` (hipStream_t handle as int; None: the solver's stream, synchronous)."""
         st = self._lib.osqp_hip_batch_solve_device(self._p, int(nbatch), q_ptr, l_ptr, u_ptr, x_ptr, y_ptr, rec_ptr, int(bool(warm)), stream)
         if st:
             raise ValueError(str(st))

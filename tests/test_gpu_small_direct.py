@@ -44,7 +44,7 @@ def test_opt_out_and_excluded_settings(monkeypatch):
     P, q, A, l, u = mpc1()
     m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, polishing=True, **ST)
     r = m.solve()
-    assert r.info.status_val == 1 and r.info.status_polish == 1       # direct solve, then the host-driven polish on its iterates
+    assert r.info.status_val == 1 and r.info.status_polish == 1       # direct solve and polish in the same launch
     k = problems.kkt_certificate(P, q, A, l, u, r.x, r.y)
     assert k['pri'] <= 1e-7 and k['dua'] <= 1e-7                       # polished: far below eps = 1e-6
     monkeypatch.setenv('OSQP_HIP_SMALL_DIRECT', '0')

@@ -121,3 +121,26 @@ def test_oracle_warm_start():                # warm_start_test.py:25-57
     assert o.solve()[2].iter == info.iter
     o.warm_start(x=x, y=y)
     assert o.solve()[2].iter < 10
+
+
+@pytest.mark.parametrize('name', ['polish_simple', 'polish_random', 'polish_unconstrained'])
+def test_oracle_polish_matches_purepy_and_c_core(name):      # polishing_test.py:32-99; _osqp.py:1710-1828
+    """The oracle's polish step (dense LU in place of the reference's sparse LU) lands on the pure-python reference's polished
+    point to rounding, and on the C core's golden solution within the reference's own tolerances."""
+    f = Fixture(name)
+    o = Oracle().setup(f.P, f.q, f.A, f.l, f.u, **f.oracle_settings())
+    x0, y0, i0 = o.solve()
+    assert i0.status_val == SOLVED
+    pri0, dua0 = i0.pri_res, i0.dua_res
+    x, y, info, status_polish = o.polish(delta=1e-6, polish_refine_iter=3)
+    assert status_polish == 1
+    assert info.pri_res <= pri0 and info.dua_res < dua0 and info.dua_res < 1e-9
+    npt.assert_allclose(x, f['gold_x_val'], rtol=RTOL, atol=ATOL)
+    if f.m:
+        npt.assert_allclose(y, f['gold_y_val'], rtol=RTOL, atol=ATOL)
+    npt.assert_almost_equal(info.obj_val, float(f['gold_obj']), decimal=DEC)
+    if f.has('ref_x'):
+        assert int(f['ref_status_polish']) == 1
+        npt.assert_allclose(x, f['ref_x'], rtol=0, atol=1e-12 * (1 + np.abs(f['ref_x']).max()))
+        npt.assert_allclose(y, f['ref_y'], rtol=0, atol=1e-12 * (1 + np.abs(f['ref_y']).max()))
+        npt.assert_allclose(info.obj_val, float(f['ref_obj']), rtol=1e-12)
