@@ -87,9 +87,12 @@ def main():
         # (7.7 KB of vectors per QP in and out) nor MFMA applies.  What bounds it is the DEPENDENT chain of the two banded
         # triangular substitutions of every ADMM iteration, which run on one wave: 2n pivots, each one broadcast (v_readlane pair)
         # + one fp64 FMA that the next pivot depends on.  Floor = 2n pivots x kChainCycles at the 2.4 GHz peak clock with the CU's
-        # problems perfectly overlapped; achieved = ADMM iterations per second per resident problem.  
+        # problems perfectly overlapped and nothing else in the iteration; achieved = ADMM iterations per second per resident
+        # problem.  Where the rest goes (tools/batch_trace.py, profiles/r02e_batch_trace.txt): per-block overhead of the substitutions
+        # (fetch of the next block of L, store / refill of finished elements), the two products, residual checks.  
         n_var = P.shape[0]
-        kChainCycles = 16.0           # dependent readlane + v_fma_f64 per pivot (MI355X_MICROARCH.md: ~4-cycle issue slots, 64-bit FMA on a SIMD-32)
+        kChainCycles = 43.5           # MEASURED cost of one pivot: two v_readlane_b32 (~14 cycles each, on or off a chain) + the dependent v_fma_f64
+                                      # (tools/lane_bcast_bench.hip, profiles/r02e_lane_bcast.txt)
         kernel_s = 1e-3 * s._solver.hip_stats()['gpu_solve_ms']
         iters_per_qp = float(table[:, 2].sum()) / B
         resident = 2 * 256            # two problems per CU (69 KB of LDS each), 256 CUs
@@ -98,7 +101,7 @@ def main():
         floor_iter = 2 * n_var * kChainCycles / 2.4e9
         out['roofline'] = {'bound': 'latency', 'kernel': 'k_batch_admm<256,8,8,true>', 'unit': 'ADMM iter/s per resident QP',
                            'achieved': 1.0 / t_iter, 'peak': 1.0 / floor_iter, 'frac': floor_iter / t_iter, 'traffic': None,
-                           'model': 'dependent chain of the banded substitutions: 2n = %d pivots x %.0f cycles at 2.4 GHz = %.2f us per ADMM iteration; '
+                           'model': 'dependent chain of the banded substitutions: 2n = %d pivots x %.1f cycles (broadcast + FMA, measured) at 2.4 GHz = %.2f us per ADMM iteration; '
                                     'measured %.2f us (%.1f ADMM iterations per QP, %d QPs resident at a time, kernel %.2f ms)'
                                     % (2 * n_var, kChainCycles, 1e6 * floor_iter, 1e6 * t_iter, iters_per_qp, resident, 1e3 * kernel_s)}
         if args.cpu_sample > 0:

@@ -100,6 +100,29 @@ struct Red {
 
 namespace {
 
+// Doubles of LDS taken by the index arrays of the register path: row pointers of A (m + 1) and B (n + 1), permutation (n).
+__host__ __device__ inline int batch_index_doubles(int n, int m) { return (m + 2 * n + 2 + 1) / 2; }
+// sum of prod[a .. z) in entry order; the loads of a batch of eight are independent (one LDS latency per batch, not per entry)
+__device__ __forceinline__ double row_sum(const double *prod, int a, int z) {
+  double acc = 0.0;
+  int k = a;
+  for (; k + 8 <= z; k += 8) {
+    double v[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) v[b] = prod[k + b];
+#pragma unroll
+    for (int b = 0; b < 8; b++) acc += v[b];
+  }
+  if (k < z) {
+    double v[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) v[b] = k + b < z ? prod[k + b] : 0.0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) acc += v[b];
+  }
+  return acc;
+}
+
 // hi + lo += a * v in double-double: the product exactly (FMA), the sum by TwoSum.  Contraction is switched off for this body:
 // a fused a * v + hi would break the error terms.
 __device__ __forceinline__ void dd_acc(double a, double v, double &hi, double &lo) {
@@ -131,12 +154,16 @@ template <int kBB, int EA, int EB, bool DIRECT, bool POLISH = false>
 __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) void k_batch_admm(BatchParams P) {
 #ifdef OSQP_HIP_KTRACE
   // diagnostic build: 100 MHz clock ticks spent in the phases; reported in rec[5..7] INSTEAD of rho / rho_updates / pcg_iters
-  unsigned long long tk_all = wall_clock64(), tk_fact = 0, tk_solve = 0, tk0 = 0;
+  unsigned long long tk_all = wall_clock64(), tk_fact = 0, tk_solve = 0, tk0 = 0, tk1 = 0, tk_rhs = 0, tk_upd = 0, tk_fwd = 0, tk_res = 0;
 #define BT_BEGIN() (tk0 = wall_clock64())
 #define BT_END(acc) (acc += wall_clock64() - tk0)
+#define BT2_BEGIN() (tk1 = wall_clock64())
+#define BT2_END(acc) (acc += wall_clock64() - tk1)
 #else
 #define BT_BEGIN() ((void)0)
 #define BT_END(acc) ((void)0)
+#define BT2_BEGIN() ((void)0)
+#define BT2_END(acc) ((void)0)
 #endif
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = P.n, m = P.m, tid = threadIdx.x, b = blockIdx.x;
@@ -150,7 +177,11 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
   // DIRECT: band factor.  Column c occupies Lb[c W .. c W + bw] (W = bw + kBatchNB: kBatchNB zeros of padding per column, and
   // kBatchNB zeros in front of column 0), for n rounded up to a multiple of kBatchNB columns, + 64 doubles of read slack.
   const int bw = P.bw, W = P.bw + kBatchNB, n8 = (n + kBatchNB - 1) / kBatchNB * kBatchNB;
-  double *Lb = prod + (((A.nnz > B.nnz ? A.nnz : B.nnz) + 1) & ~1) + kBatchNB;
+  // register path: the row pointers of A and B and the direct variant's permutation live in LDS too (they are read in every
+  // SpMV / solve of every iteration: an L2 round trip each time otherwise)
+  const int prod_len = ((A.nnz > B.nnz ? A.nnz : B.nnz) + 1) & ~1;
+  int *rpA = reinterpret_cast<int *>(prod + prod_len), *rpB = rpA + (m + 1), *perm_l = rpB + (n + 1);
+  double *Lb = prod + prod_len + batch_index_doubles(n, m) + kBatchNB;
   double *dinv = zv, *wbuf = r;                     // DIRECT: 1/D and the permuted right-hand side / solution reuse PCG vectors
   constexpr bool kReg = EA > 0;
   double aA[EA > 0 ? EA : 1], aB[EB > 0 ? EB : 1];
@@ -167,7 +198,7 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
 #pragma unroll
       for (int e = 0; e < EA; e++) { const int k = tid + e * kBB; if (k < A.nnz) prod[k] = aA[e] * v[cA[e]]; }
       __syncthreads();
-      for (int i = tid; i < m; i += kBB) { double a = 0.0; for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) a += prod[k]; f(i, a); }
+      for (int i = tid; i < m; i += kBB) f(i, row_sum(prod, rpA[i], rpA[i + 1]));
       __syncthreads();
     } else {
       for (int i = tid; i < m; i += kBB) { double a = 0.0; for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; k++) a += A.val[k] * v[A.col[k]]; f(i, a); }
@@ -183,7 +214,7 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
         if (k < B.nnz) { const int c = cB[e]; prod[k] = c < n ? (pn ? aB[e] * pn[c] : 0.0) : (pm ? aB[e] * pm[c - n] : 0.0); }
       }
       __syncthreads();
-      for (int j = tid; j < n; j += kBB) { double a = 0.0; for (int k = B.rowptr[j]; k < B.rowptr[j + 1]; k++) a += prod[k]; f(j, a); }
+      for (int j = tid; j < n; j += kBB) f(j, row_sum(prod, rpB[j], rpB[j + 1]));
       __syncthreads();
     } else {
       for (int j = tid; j < n; j += kBB) {
@@ -194,6 +225,11 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
       __syncthreads();
     }
   };
+  if constexpr (kReg) {
+    for (int i = tid; i <= m; i += kBB) rpA[i] = A.rowptr[i];
+    for (int j = tid; j <= n; j += kBB) rpB[j] = B.rowptr[j];
+    if constexpr (DIRECT) { for (int j = tid; j < n; j += kBB) perm_l[j] = P.perm[j]; }
+  }
   // ---- load the problem ----
   // inputs arrive UNSCALED; the scaling of update_lin_cost / update_bounds / warm_start (_osqp.py:1328, :1357-1358, :1505-1506)
   // is applied here:  q <- c D q,  l,u <- E clamp(l,u),  x <- Dinv x,  y <- c Einv y
@@ -278,14 +314,20 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
   // band makes every out-of-band read a zero, lanes beyond the block's reach are masked once), then for each pivot:
   // v_readlane broadcast + one FMA.  Lanes whose element has pivoted store it and continue with the element 64 further on,
   // already waiting in a register.  ~8 instructions per pivot, no LDS access, branch or division on the dependency chain.
+  // What a pivot costs is the broadcast itself (tools/lane_bcast_bench.hip, one wave: v_readlane_b32 ~14 cycles whether or not it
+  // is on a dependency chain -> 43.5 cycles per pivot for the two halves + FMA; DPP row_newbcast 30.6 but only inside a row of 16;
+  // an LDS round trip 178 per 8 values): resolving a block of 8 through its inverted diagonal block (two rounds of 8 INDEPENDENT
+  // broadcasts instead of a chain of 8) was tried and is slower, 12.6 vs 9.0 us per solve -- twice the broadcasts, and they do
+  // not pipeline.
   auto ksolve = [&](const double *rhs, double *out) {
     const double *__restrict__ Lr = Lb;
     double *__restrict__ buf = wbuf;
     constexpr int NB = kBatchNB;
-    for (int k = tid; k < n; k += kBB) buf[k] = rhs[P.perm[k]];
+    for (int k = tid; k < n; k += kBB) buf[k] = rhs[perm_l[k]];
     __syncthreads();
     const int nblk = n8 / NB;
     const bool w0 = tid < 64;                                   // the substitutions run on wave 0; other waves wait at the barriers
+    BT2_BEGIN();
     // ---- forward, unit lower:  v_e = w_e - sum_{j in [e-bw, e)} L^[e][j] v_j ;  L^[p0 + dl][p0 + q] = Lr[(p0 + q) W + dl - q] ----
     if (w0) {
       double cur = tid < n ? buf[tid] : 0.0, nxt = 64 + tid < n ? buf[64 + tid] : 0.0;
@@ -305,7 +347,7 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
         if (dl < NB) {                                          // pivoted in this block: final
           const int e = p0 + dl;
           if (e < n) buf[e] = cur;
-          cur = nxt; nxt = e + 128 < n ? buf[e + 128] : 0.0;
+          cur = nxt; nxt = e + 128 < n ? buf[e + 128] : 0.0;   // (requesting this before the chain was tried: the compiler then drains the LDS counter in front of the chain, +17 %)
         }
       };
       double la[NB], lb[NB];                                    // two blocks in flight, roles alternate (no register rotation)
@@ -317,6 +359,7 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
       }
     }
     __syncthreads();
+    BT2_END(tk_fwd);
     for (int k = tid; k < n; k += kBB) buf[k] *= dinv[k];                          // g = D^-1 v
     __syncthreads();
     // ---- backward, unit upper (L^'):  x_i = g_i - sum_{j in (i, i+bw]} L^[j][i] x_j ; blocks from the top, pivots top - q ;
@@ -352,7 +395,7 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
       }
     }
     __syncthreads();
-    for (int k = tid; k < n; k += kBB) out[P.perm[k]] = buf[k];
+    for (int k = tid; k < n; k += kBB) out[perm_l[k]] = buf[k];
     __syncthreads();
   };
   set_rho(rho_bar);
@@ -414,9 +457,11 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
     iter++;
     // ---- rhs = sigma x - q + A'(rho z - y);  r = rhs - K xs with K xs = B[xs; rho zt]   (_osqp.py:649-650) ----
     [[maybe_unused]] double rz_l = 0, rn_l = 0, bn_l = 0;
+    BT2_BEGIN();
     for (int i = tid; i < m; i += kBB) t[i] = rho[i] * z[i] - y[i];
     __syncthreads();
     applyB(nullptr, t, [&](int j, double sA) { Kp[j] = P.sigma * x[j] - q[j] + sA; });          // Kp holds rhs for a moment
+    BT2_END(tk_rhs);
     if constexpr (DIRECT) {
       BT_BEGIN();
       ksolve(Kp, xs);                                                                    // x~ = K^-1 rhs   (_osqp.py:307-311, reduced form)
@@ -456,6 +501,7 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
       }
     }
     // ---- z~ = A xs; x, z, y update (_osqp.py:660-703) ----
+    BT2_BEGIN();
     applyA(xs, [&](int i, double a) {
       const double rh = rho[i], yi = y[i];
       const double zr = P.alpha * a + (1.0 - P.alpha) * z[i];
@@ -465,11 +511,14 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
     });
     for (int j = tid; j < n; j += kBB) { const double xo = x[j], xn = P.alpha * xs[j] + (1.0 - P.alpha) * xo; dx[j] = xn - xo; x[j] = xn; }
     __syncthreads();
+    BT2_END(tk_upd);
 
     const bool at_check = (P.check > 0 && iter % P.check == 0) || iter >= P.max_iter;
     const bool at_rho = P.rho_interval > 0 && iter % P.rho_interval == 0;
     if (!at_check && !at_rho) continue;
+    BT2_BEGIN();
     residuals();
+    BT2_END(tk_res);
     obj = (0.5 * xpx + qx) * (P.scaling ? P.cinv : 1.0);                               // _osqp.py:705-712
     prim_res = m == 0 ? 0.0 : (unsc ? pri_u : pri_s);
     dual_res = unsc ? P.cinv * dua_u : dua_s;
@@ -612,6 +661,7 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
     rc[8] = status_polish; rc[9] = 1e-8 * (double)pol_ticks;      // (100 MHz wall clock -> seconds)
 #ifdef OSQP_HIP_KTRACE
     rc[5] = (double)tk_fact; rc[6] = (double)tk_solve; rc[7] = (double)(wall_clock64() - tk_all);
+    rc[3] = (double)tk_rhs; rc[4] = (double)tk_upd; rc[8] = (double)tk_fwd; rc[9] = (double)tk_res;
 #endif
   }
 }
@@ -621,14 +671,14 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
 // LDS needed per problem (bytes); 0 if the problem does not fit one workgroup's LDS.  nnz > 0 adds the product buffer of
 // the register-resident path.
 size_t batch_lds_bytes_nnz(int n, int m, int nnz) {
-  const size_t b = sizeof(double) * ((size_t)10 * n + (size_t)8 * m + 16 + (size_t)nnz);
+  const size_t b = sizeof(double) * ((size_t)10 * n + (size_t)8 * m + 16 + (nnz > 0 ? (size_t)((nnz + 1) & ~1) + batch_index_doubles(n, m) : 0));
   return b <= 64 * 1024 ? b : 0;
 }
 size_t batch_lds_bytes(int n, int m) { return batch_lds_bytes_nnz(n, m, 0); }
 size_t batch_direct_lds_bytes(int n, int m, int nnz, int bw) {
   if (bw < 0 || bw > kBatchDirectMaxBw) return 0;
   const size_t n8 = (size_t)(n + kBatchNB - 1) / kBatchNB * kBatchNB;
-  const size_t b = sizeof(double) * ((size_t)10 * n + (size_t)8 * m + 16 + (size_t)((nnz + 1) & ~1) + kBatchNB + n8 * (bw + kBatchNB) + 64);
+  const size_t b = sizeof(double) * ((size_t)10 * n + (size_t)8 * m + 16 + (size_t)((nnz + 1) & ~1) + batch_index_doubles(n, m) + kBatchNB + n8 * (bw + kBatchNB) + 64);
   return b <= 144 * 1024 ? b : 0;         // (above the default 64 KB dynamic-LDS limit: batch_solve raises it; gfx950 has 160 KB per CU)
 }
 __global__ void k_batch_products(DevCsr A, int nprod, const int *a, const int *b, double *out) {

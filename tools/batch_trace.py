@@ -26,4 +26,7 @@ it = rec[:, 1]; tf, ts, ta = rec[:, 5] * 0.01, rec[:, 6] * 0.01, rec[:, 7] * 0.0
 print('problems %d, solved %d; iterations mean %.1f max %d' % (B, (rec[:, 0] == 1).sum(), it.mean(), it.max()))
 print('per problem (us): total mean %.0f max %.0f | factorisations mean %.0f | substitutions mean %.0f = %.2f per iteration | rest %.2f per iteration'
       % (ta.mean(), ta.max(), tf.mean(), ts.mean(), (ts / it).mean(), ((ta - tf - ts) / it).mean()))
+trhs, tupd, tfwd, tres = rec[:, 3] * 0.01, rec[:, 4] * 0.01, rec[:, 8] * 0.01, rec[:, 9] * 0.01
+print('per iteration (us): rhs (t, B product) %.2f | solve %.2f (forward substitution %.2f) | A product + z, y, x update %.2f | residuals %.2f | unaccounted %.2f'
+      % ((trhs / it).mean(), (ts / it).mean(), (tfwd / it).mean(), (tupd / it).mean(), (tres / it).mean(), ((ta - tf - ts - trhs - tupd - tres) / it).mean()))
 print('sum of per-problem totals / (256 CUs x 2 resident) = %.1f ms' % (ta.sum() / 512 / 1e3))
