@@ -94,7 +94,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--n', type=int, default=100000, help='variables (m = 2n, nnz(A) = 10n, nnz(P) = 2n)')
+    ap.add_argument('--n', '--vars', dest='n', type=int, default=100000, help='variables (m = 2n, nnz(A) = 10n, nnz(P) = 2n); --vars: the spelling torch.distributed.run passes through')
     ap.add_argument('--eps', type=float, default=1e-6)
     ap.add_argument('--cpu-seconds', type=float, default=40.0, help='CPU-baseline budget (0 disables)')
     ap.add_argument('--probe-reps', type=int, default=200)
@@ -113,8 +113,10 @@ def main():
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     if args.single_device:
         local = 0
+    # OSQP_BENCH_FORCE_DIST=1: initialise the process group (RCCL) also for one rank -- exercises init / barrier / all_gather on a 1-GPU box
+    use_dist = world > 1 or bool(os.environ.get('OSQP_BENCH_FORCE_DIST'))
     torch.cuda.set_device(local)
-    if world > 1:
+    if use_dist:
         if args.dist_backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))     # backend "nccl" is RCCL on ROCm
         else:
@@ -130,7 +132,7 @@ def main():
     t_setup = time.time() - t0
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -150,7 +152,7 @@ def main():
     # whole-job aggregate: total ADMM iterations / max-over-ranks time; final status/objective gather over RCCL
     rec = torch.tensor([float(res.info.status_val), float(res.info.iter), res.info.obj_val, res.info.prim_res, res.info.dual_res,
                         elapsed, float(iters)], dtype=torch.float64, device='cuda' if args.dist_backend == 'nccl' else 'cpu')
-    if world > 1:
+    if use_dist:
         allrec = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(allrec, rec)
         allrec = torch.stack(allrec).cpu().numpy()
@@ -236,7 +238,7 @@ def main():
                 out['config']['reference_equivalent_iters_per_s'] = cb['iters_to_converge'] / (tts_ms * 1e-3)
                 out['config']['gpu_over_cpu_time_to_solution'] = cb['time_to_solution_ms'] / tts_ms
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -50,9 +50,10 @@ def main():
     from osqp_amd import sharded
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
     assert world == args.gpus
+    use_dist = world > 1 or bool(os.environ.get('OSQP_BENCH_FORCE_DIST'))     # (one-rank RCCL run: exercises init / barrier / all_reduce on a 1-GPU box)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    if use_dist:
         dist.init_process_group('nccl', device_id=dev)
     B = args.batch
     P, q, A, L, U = problems.mpc_batch(B)
@@ -60,19 +61,19 @@ def main():
     s.setup(P, q, A, L[0], U[0], eps_abs=1e-6, eps_rel=1e-6, verbose=False, max_iter=4000, device=local)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
-        table, x, y, rng = sharded.solve_batch_sharded(s, l=L, u=U, rank=rank, world=world, device=dev if world > 1 else None)
+        table, x, y, rng = sharded.solve_batch_sharded(s, l=L, u=U, rank=rank, world=world, device=dev if use_dist else None)
     barrier(); t0 = time.perf_counter()
     step_ms = []
     for _ in range(args.steps):
         ts = time.perf_counter()
-        table, x, y, rng = sharded.solve_batch_sharded(s, l=L, u=U, rank=rank, world=world, device=dev if world > 1 else None)
+        table, x, y, rng = sharded.solve_batch_sharded(s, l=L, u=U, rank=rank, world=world, device=dev if use_dist else None)
         step_ms.append(1e3 * (time.perf_counter() - ts))
     barrier(); el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device='cuda')
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     el = float(el.item())
     if rank == 0:
@@ -119,7 +120,7 @@ def main():
                                    'sample': 'all %d QPs split over %d worker processes (host has %d cores), oracle direct LDL\' (setup+solve per problem), '
                                              '%d ADMM iterations in %.2f s wall (slowest worker busy %.2f s)' % (sample, cores, os.cpu_count() or 1, its, dt, busy)}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier(); dist.destroy_process_group()
 
 

@@ -38,7 +38,7 @@ def gather_records(recs, nproblems, device=None):
     Ranks may own different counts (B not divisible by world): records are padded to the largest share."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):        # (a one-rank group still goes through the collective: smoke-tests RCCL)
         return recs[np.argsort(recs[:, 0])]
     world = dist.get_world_size()
     share = max(shard_range(nproblems, r, world)[1] - shard_range(nproblems, r, world)[0] for r in range(world))
@@ -81,7 +81,7 @@ def gather_rows(rows_local, nproblems, device=None):
     import torch
     import torch.distributed as dist
     rows_local = np.asarray(rows_local, dtype=np.float64)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return rows_local
     world = dist.get_world_size()
     spans = [shard_range(nproblems, r, world) for r in range(world)]
