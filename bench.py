@@ -183,8 +183,10 @@ def main():
             }
             seq_id, dom, dom_kernel = 6, 'K2 spmv B (w=B[u;t], <w,u>)', 'k_k2'
         other = {
-            'KB rhs + pcg start': (3, sB + 8 * mm + 8 * (4 * n)),
-            'KA A x~ + z,y,x update': (4, sA + 8 * (9 * mm) + 8 * (3 * n)),
+            # (+ the extrapolated PCG start: KB resets x~ to it (8n written); KA reads the previous z~ and x~_prev and writes
+            #  A xg, xg, x~_prev: 8m + 8n read, 8m + 16n written)
+            'KB rhs + pcg start': (3, sB + 8 * mm + 8 * (5 * n)),
+            'KA A x~ + z,y,x update + next PCG start': (4, sA + 8 * (11 * mm) + 8 * (6 * n)),
         }
         probes = {}
         for name, (which, nbytes) in {**pcg_kernels, **other}.items():

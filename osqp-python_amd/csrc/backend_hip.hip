@@ -492,26 +492,26 @@ struct NoPrefetch { __device__ __forceinline__ void prefetch(int) {} };
 // ---------------------------------------------------------------------------------------------- hot-path kernels
 // KB ------------------------------------------------------------------------------------------
 struct GKb {
-  const double *xs, *v, *t0; int n;
+  const double *xg, *v, *t0; int n;      // (xg: the PCG start, Dev::xg; t0 = rho .* (A xg))
   __device__ __forceinline__ void operator()(int c, double a, double (&pr)[2]) const {
-    if (c < n) { pr[0] = 0.0; pr[1] = a * xs[c]; }
+    if (c < n) { pr[0] = 0.0; pr[1] = a * xg[c]; }
     else { pr[0] = a * v[c - n]; pr[1] = a * t0[c - n]; }
   }
 };
 struct EKb {
-  const double *x, *q, *Minv; double *r, *uu; double sigma; double g = 0, rn = 0, bn = 0; double px = 0, pq = 0, pm = 0;
-  __device__ __forceinline__ void prefetch(int j) { px = x[j]; pq = q[j]; pm = Minv[j]; }
+  const double *x, *q, *Minv; double *r, *uu; double sigma; const double *xg; double *xs; double g = 0, rn = 0, bn = 0; double px = 0, pq = 0, pm = 0, pg = 0;
+  __device__ __forceinline__ void prefetch(int j) { px = x[j]; pq = q[j]; pm = Minv[j]; pg = xg[j]; }
   __device__ __forceinline__ void operator()(int j, const double (&s)[2]) {
     const double rhs = sigma * px - pq + s[0];
     const double rr = rhs - s[1], u = pm * rr;
-    r[j] = rr; uu[j] = u;
+    r[j] = rr; uu[j] = u; xs[j] = pg;           // x~ restarts from the extrapolated point (nobody gathers xs in this kernel)
     g += rr * u; rn = nanmax(rn, fabs(rr)); bn = nanmax(bn, fabs(rhs));
   }
 };
 __global__ __launch_bounds__(kBlock) void k_kb(Dev d) {
   __shared__ StreamLds<2> lds;
-  GKb g{d.xs, d.v, d.t0, d.n};
-  EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma};
+  GKb g{d.xg, d.v, d.t0, d.n};
+  EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma, d.xg, d.xs};
   process_rows<2>(d.B, g, e, lds);
   __syncthreads();
   const double G = block_sum(e.g, lds.red);
@@ -843,26 +843,28 @@ __global__ __launch_bounds__(kBlock) void k_k1f(Dev d, int i) {          // i >=
 
 // KA ------------------------------------------------------------------------------------------
 struct EKa {
-  const double *l, *u, *rho, *rho_inv; double *z, *y, *zt, *t0, *v, *dy; double alpha;
-  double pl = 0, pu = 0, prho = 0, prinv = 0, pz = 0, py = 0;
-  __device__ __forceinline__ void prefetch(int i) { pl = l[i]; pu = u[i]; prho = rho[i]; prinv = rho_inv[i]; pz = z[i]; py = y[i]; }
+  const double *l, *u, *rho, *rho_inv; double *z, *y, *zt, *t0, *v, *dy; double alpha; double *ztg; double theta;
+  double pl = 0, pu = 0, prho = 0, prinv = 0, pz = 0, py = 0, pzt = 0;
+  __device__ __forceinline__ void prefetch(int i) { pl = l[i]; pu = u[i]; prho = rho[i]; prinv = rho_inv[i]; pz = z[i]; py = y[i]; pzt = zt[i]; }
   __device__ __forceinline__ void operator()(int i, const double (&s)[1]) {
     const double ztil = s[0];
     const double zr = alpha * ztil + (1.0 - alpha) * pz;                    // _osqp.py:686-690
     const double zn = fmin(fmax(zr + prinv * py, pl), pu);                   // :674
     const double dyi = prho * (zr - zn), yn = py + dyi;                      // :698-703
-    y[i] = yn; dy[i] = dyi; z[i] = zn; zt[i] = ztil; v[i] = prho * zn - yn; t0[i] = prho * ztil;
+    const double zg = ztil + theta * (ztil - pzt);                           // A xg (Dev::ztg)
+    y[i] = yn; dy[i] = dyi; z[i] = zn; zt[i] = ztil; v[i] = prho * zn - yn; ztg[i] = zg; t0[i] = prho * zg;
   }
 };
 __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
   __shared__ StreamLdsW<1, double> lds;
   GVec g{d.xs};
-  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha};
+  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, d.theta};
   process_rows<1>(d.A, g, e, lds);
   const int stride = gridDim.x * kBlock;
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) {    // _osqp.py:664-668
-    const double xo = d.x[j], xn = d.alpha * d.xs[j] + (1.0 - d.alpha) * xo;
+    const double xt = d.xs[j], xo = d.x[j], xn = d.alpha * xt + (1.0 - d.alpha) * xo;
     d.dx[j] = xn - xo; d.x[j] = xn;
+    d.xg[j] = xt + d.theta * (xt - d.xsp[j]); d.xsp[j] = xt;                 // next PCG start (Dev::xg)
   }
   if (blockIdx.x == 0) {                                                     // PCG statistics of this ADMM iteration
     int done = d.flags[F_DONE];
@@ -909,8 +911,8 @@ __global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
   int *W = d.slot + SR_WORDS;
   if (st.ph == P_KB) {
     if (st.admm >= st.target) { st.ph = P_IDLE; slot_write(W, st); return; }
-    GKb g{d.xs, d.v, d.t0, d.n};
-    EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma};
+    GKb g{d.xg, d.v, d.t0, d.n};
+    EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma, d.xg, d.xs};
     process_rows_fd<2>(d.B, g, e, lds.kb, NoPre(), fd);
     __syncthreads();
     const double G = block_sum(e.g, lds.kb.red);
@@ -943,12 +945,13 @@ __global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
 template <class L>
 __device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv, const FirstDesc &fd) {
   GVec g{d.xs};
-  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha};
+  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, d.theta};
   process_rows_fd<1>(d.A, g, e, lds, NoPre(), fd);
   const int stride = gridDim.x * kBlock;
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) {    // _osqp.py:664-668
-    const double xo = d.x[j], xn = d.alpha * d.xs[j] + (1.0 - d.alpha) * xo;
+    const double xt = d.xs[j], xo = d.x[j], xn = d.alpha * xt + (1.0 - d.alpha) * xo;
     d.dx[j] = xn - xo; d.x[j] = xn;
+    d.xg[j] = xt + d.theta * (xt - d.xsp[j]); d.xsp[j] = xt;                 // next PCG start (Dev::xg)
   }
   if (blockIdx.x == 0) {
     if (!conv) {
@@ -1129,7 +1132,7 @@ __global__ __launch_bounds__(kBlock) void k_set_rho(Dev d, double rho_bar) {
     const double eqf = d.eq_from_cnt ? (d.cnt[0] == 0 ? 1e3 : d.rho_eq_mixed) : d.rho_eq_factor;   // engine.cpp classify_constraints
     const double r = t == -1 ? 1e-6 : (t == 1 ? eqf * rho_bar : rho_bar);                 // _osqp.py:520-522, :1590-1594
     d.rho[i] = r; d.rho_inv[i] = 1.0 / r;
-    d.v[i] = r * d.z[i] - d.y[i]; d.t0[i] = r * d.zt[i];
+    d.v[i] = r * d.z[i] - d.y[i]; d.t0[i] = r * d.ztg[i];
   }
 }
 struct GPrec { const double *rho; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = c >= n ? rho[c - n] * a * a : 0.0; } };
@@ -1148,18 +1151,22 @@ __global__ __launch_bounds__(kBlock) void k_init_n(Dev d) {
   const int stride = gridDim.x * kBlock;
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) { d.xs[j] = d.x[j]; d.dx[j] = 0.0; }
 }
+__global__ __launch_bounds__(kBlock) void k_init_guess(Dev d) {      // no history: the next PCG starts from x~ itself
+  const int stride = gridDim.x * kBlock;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) { const double v = d.xs[j]; d.xg[j] = v; d.xsp[j] = v; }
+}
 struct EInit : NoPrefetch {
-  const double *rho, *y; double *z, *zt, *t0, *v, *dy; int full;
+  const double *rho, *y; double *z, *zt, *t0, *v, *dy; int full; double *ztg;
   __device__ __forceinline__ void operator()(int i, const double (&s)[1]) {
     const double a = s[0];
     if (full) { z[i] = a; dy[i] = 0.0; }
-    zt[i] = a; t0[i] = rho[i] * a; v[i] = rho[i] * z[i] - y[i];
+    zt[i] = a; ztg[i] = a; t0[i] = rho[i] * a; v[i] = rho[i] * z[i] - y[i];
   }
 };
 __global__ __launch_bounds__(kBlock) void k_init_m(Dev d, int full) {
   __shared__ StreamLdsW<1, double> lds;
   GVec g{d.xs};
-  EInit e{{}, d.rho, d.y, d.z, d.zt, d.t0, d.v, d.dy, full};
+  EInit e{{}, d.rho, d.y, d.z, d.zt, d.t0, d.v, d.dy, full, d.ztg};
   process_rows<1>(d.A, g, e, lds);
 }
 __global__ __launch_bounds__(kBlock) void k_normalcone(Dev d) {
@@ -1433,6 +1440,7 @@ void set_pcg_tol(Dev &d, double rel, double ab) {
 void init_iterates(Dev &d, int full) {
   HIP_CHECK(hipSetDevice(d.device));
   if (full) LAUNCH(k_init_n, d, d);
+  LAUNCH(k_init_guess, d, d);
   LAUNCH(k_init_m, d, d, full);
 }
 
@@ -1526,7 +1534,8 @@ float time_kernel(Dev &d, int which, int reps) {
   const size_t n = d.n, m = d.m;
   Save sv[] = {{d.x, n, nullptr}, {d.z, m, nullptr}, {d.y, m, nullptr}, {d.xs, n, nullptr}, {d.zt, m, nullptr}, {d.t0, m, nullptr},
                {d.v, m, nullptr}, {d.dx, n, nullptr}, {d.dy, m, nullptr}, {d.r, n, nullptr}, {d.uu, n, nullptr}, {d.p, n, nullptr},
-               {d.s, n, nullptr}, {d.w, n, nullptr}, {d.t, m, nullptr}, {d.uu2, n, nullptr}, {d.ms, 2 * n, nullptr}};
+               {d.s, n, nullptr}, {d.w, n, nullptr}, {d.t, m, nullptr}, {d.uu2, n, nullptr}, {d.ms, 2 * n, nullptr},
+               {d.xg, n, nullptr}, {d.xsp, n, nullptr}, {d.ztg, m, nullptr}};
   int flags_bak[F_COUNT];
   HIP_CHECK(hipStreamSynchronize(st(d)));
   HIP_CHECK(hipMemcpy(flags_bak, d.flags, sizeof(flags_bak), hipMemcpyDeviceToHost));

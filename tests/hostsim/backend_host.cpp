@@ -54,7 +54,7 @@ void kb_rhs(Dev &d) {
     double sA = 0, sK = 0;
     for (int k = d.B.rowptr[j]; k < d.B.rowptr[j + 1]; k++) {
       int c = d.B.col[k]; double v = d.B.val[k];
-      if (c < d.n) sK += v * d.xs[c];
+      if (c < d.n) sK += v * d.xg[c];                       // the PCG starts from the extrapolated point (backend.h Dev::xg)
       else { sA += v * d.v[c - d.n]; sK += v * d.t0[c - d.n]; }
     }
     double rhs = d.sigma * d.x[j] - d.q[j] + sA;
@@ -62,6 +62,7 @@ void kb_rhs(Dev &d) {
     d.r[j] = r; d.uu[j] = u;
     g += r * u; rn = nanmax(rn, std::fabs(r)); bn = nanmax(bn, std::fabs(rhs));
   }
+  for (int j = 0; j < d.n; j++) d.xs[j] = d.xg[j];
   s.gamma_next = g; s.rnorm = rn; s.bnorm = bn;
   d.scal[S_RN0] = rn;
   d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0;
@@ -117,12 +118,15 @@ void ka(Dev &d, int budget) {
     double zr = d.alpha * zt + (1.0 - d.alpha) * d.z[i];
     double zn = std::fmin(std::fmax(zr + d.rho_inv[i] * d.y[i], d.l[i]), d.u[i]);
     double dy = d.rho[i] * (zr - zn);
-    d.y[i] += dy; d.dy[i] = dy; d.z[i] = zn; d.zt[i] = zt;
-    d.v[i] = d.rho[i] * zn - d.y[i]; d.t0[i] = d.rho[i] * zt;
+    const double zg = zt + d.theta * (zt - d.zt[i]);
+    d.y[i] += dy; d.dy[i] = dy; d.z[i] = zn; d.zt[i] = zt; d.ztg[i] = zg;
+    d.v[i] = d.rho[i] * zn - d.y[i]; d.t0[i] = d.rho[i] * zg;
   }
   for (int j = 0; j < d.n; j++) {
-    double xn = d.alpha * d.xs[j] + (1.0 - d.alpha) * d.x[j];
+    const double xt = d.xs[j];
+    double xn = d.alpha * xt + (1.0 - d.alpha) * d.x[j];
     d.dx[j] = xn - d.x[j]; d.x[j] = xn;
+    d.xg[j] = xt + d.theta * (xt - d.xsp[j]); d.xsp[j] = xt;
   }
   int used = d.flags[F_DONE] ? d.flags[F_ITERS] : budget;
   d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;
@@ -199,7 +203,7 @@ void set_rho(Dev &d, double rb) {
   for (int i = 0; i < d.m; i++) {
     double r = d.ctype[i] == -1 ? 1e-6 : (d.ctype[i] == 1 ? d.rho_eq_factor * rb : rb);
     d.rho[i] = r; d.rho_inv[i] = 1.0 / r;
-    d.v[i] = r * d.z[i] - d.y[i]; d.t0[i] = r * d.zt[i];
+    d.v[i] = r * d.z[i] - d.y[i]; d.t0[i] = r * d.ztg[i];
   }
 }
 void precond(Dev &d, int diagonal) {
@@ -214,11 +218,12 @@ void set_pcg_tol(Dev &d, double rel, double ab) { d.scal[S_TOL_REL] = rel; d.sca
 
 void init_iterates(Dev &d, int full) {
   if (full) for (int j = 0; j < d.n; j++) { d.xs[j] = d.x[j]; d.dx[j] = 0; }
+  for (int j = 0; j < d.n; j++) { d.xg[j] = d.xs[j]; d.xsp[j] = d.xs[j]; }
   for (int i = 0; i < d.m; i++) {
     double a = 0;
     for (int k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; k++) a += d.A.val[k] * d.xs[d.A.col[k]];
     if (full) { d.z[i] = a; d.dy[i] = 0; }
-    d.zt[i] = a; d.t0[i] = d.rho[i] * a; d.v[i] = d.rho[i] * d.z[i] - d.y[i];
+    d.zt[i] = a; d.ztg[i] = a; d.t0[i] = d.rho[i] * a; d.v[i] = d.rho[i] * d.z[i] - d.y[i];
   }
 }
 

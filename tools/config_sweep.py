@@ -16,6 +16,8 @@ import problems  # noqa: E402
 
 CASES = {
     'config2_banded_100k': lambda: problems.banded_qp(100000),
+    'config2_banded_100k_seed1': lambda: problems.banded_qp(100000, seed=1),
+    'config2_banded_100k_seed2': lambda: problems.banded_qp(100000, seed=2),
     'config2_unstructured_100k': lambda: problems.banded_qp(100000, window=100000),
     'banded_200k': lambda: problems.banded_qp(200000),
     'banded_300k': lambda: problems.banded_qp(300000),
@@ -24,7 +26,7 @@ CASES = {
     'config3_lasso_5k_10k': lambda: problems.lasso_qp(5000, 10000),
     'config4_portfolio_10k_100': lambda: problems.portfolio_qp(10000, 100),
 }
-names = sys.argv[1:] or [k for k in CASES if k not in ('banded_200k', 'banded_300k', 'banded_500k')]
+names = sys.argv[1:] or [k for k in CASES if k not in ('banded_200k', 'banded_300k', 'banded_500k', 'config2_banded_100k_seed1', 'config2_banded_100k_seed2')]
 for name in names:
     P, q, A, l, u = CASES[name]()
     n, mm = len(q), len(l)
