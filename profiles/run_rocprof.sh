@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.." && repo=$(pwd)
 export TMPDIR=/tmp
 out=/tmp/prof_$tag; rm -rf $out; mkdir -p $out gpurun_out
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out -o bench -- python $repo/bench.py --cpu-seconds 0 "$@" > $out/bench_stdout.log 2>&1)
-tail -2 $out/bench_stdout.log > gpurun_out/rocprof_${tag}_bench.json
+grep '^{' $out/bench_stdout.log | tail -1 > gpurun_out/rocprof_${tag}_bench.json
 f=$(find $out -name '*kernel_stats.csv' | head -1)
 if [ -n "$f" ]; then cp "$f" gpurun_out/rocprof_${tag}_kernel_stats.csv; fi
 t=$(find $out -name '*kernel_trace.csv' | head -1)
