@@ -499,7 +499,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   solution.x = sol_x_.data(); solution.y = sol_y_.data(); solution.prim_inf_cert = sol_pc_.data(); solution.dual_inf_cert = sol_dc_.data();
   std::memset(&info, 0, sizeof(info));
   set_status(OSQP_UNSOLVED);
-  cg_budget_ = 0; have_tol_ = false; first_run_ = true; slot_pred_[0] = 6.0; slot_pred_[1] = 14.0;
+  cg_budget_ = 0; have_tol_ = false; first_run_ = true; slot_pred_[0] = slot_pred_[1] = 6.0; slot_pred_[2] = 14.0;
   stats_ = OSQPHipStats(); stats_.nnzA = nzA; stats_.nnzB = nzB;
   be::sync(d_);
   lap("vectors, rho, preconditioner");
@@ -768,7 +768,7 @@ void Engine::admm_core(double t0, double *res) {
   // pairs follow (the residual kernels that ran on the unfinished iterates are simply repeated).
   const bool slots = use_slots_ && be::slots_supported(d_);
   double *pred = slot_pred_;                         // mean PCG iterations per ADMM iteration, per chunk kind; kept across solves of the handle
-  auto exec_chunk = [&](int cnt, bool tight, bool with_res) {
+  auto exec_chunk = [&](int cnt, bool tight, bool with_res, int kind) {
     if (!slots) {
       run_chunk(cnt, budget[tight]);
       if (with_res) { be::residuals(d_); be::fetch_res_flags(d_, res, flags); } else be::fetch_flags(d_, flags);
@@ -778,7 +778,7 @@ void Engine::admm_core(double t0, double *res) {
     // (per-solve iteration limit = the budget rule of the launch-per-iteration form: the two forms then execute the SAME arithmetic
     // -- truncating the rare long solve at mean + 3 sigma of the previous chunk costs no ADMM iterations and a third of the PCG work)
     const int lim = budget[tight];
-    run_slots(cnt, 2 * cnt + (int)std::ceil(1.05 * std::min<double>(pred[tight], lim) * cnt) + 2, lim);
+    run_slots(cnt, 2 * cnt + (int)std::ceil(1.05 * std::min<double>(pred[kind], lim) * cnt) + 2, lim);
     for (;;) {
       if (with_res) { be::residuals(d_); be::fetch_res_flags(d_, res, f); } else be::fetch_flags(d_, f);
       tot[F_STAT_SUM] += f[F_STAT_SUM]; tot[F_STAT_SUMSQ] += f[F_STAT_SUMSQ]; tot[F_STAT_N] += f[F_STAT_N]; tot[F_STAT_UNCONV] += f[F_STAT_UNCONV]; tot[F_STAT_STAG] += f[F_STAT_STAG];
@@ -786,12 +786,14 @@ void Engine::admm_core(double t0, double *res) {
       const int done = be::slot_done(d_);
       if (done >= cnt) break;
       const int rem = cnt - done;
-      const double seen = tot[F_STAT_N] > 0 ? (double)tot[F_STAT_SUM] / tot[F_STAT_N] : pred[tight];
-      run_slots(0, 2 * rem + (int)std::ceil(1.25 * std::min<double>(std::max(seen, pred[tight]), lim) * rem) + 8, lim);
+      const double seen = tot[F_STAT_N] > 0 ? (double)tot[F_STAT_SUM] / tot[F_STAT_N] : pred[kind];
+      run_slots(0, 2 * rem + (int)std::ceil(1.25 * std::min<double>(std::max(seen, pred[kind]), lim) * rem) + 8, lim);
       stats_.slot_topups += 1;
     }
     for (int k = 0; k < F_COUNT; k++) flags[k] = tot[k];
-    if (tot[F_STAT_N] > 0) pred[tight] = (double)tot[F_STAT_SUM] / tot[F_STAT_N];
+    { static const bool slog = std::getenv("OSQP_HIP_SLOT_LOG") != nullptr;
+      if (slog) std::fprintf(stderr, "chunk cnt %d kind %d lim %d pred %.2f used-mean %.2f needed-pairs %d\n", cnt, kind, lim, pred[kind], tot[F_STAT_N] > 0 ? (double)tot[F_STAT_SUM] / tot[F_STAT_N] : 0.0, 2 * cnt + tot[F_STAT_SUM]); }
+    if (tot[F_STAT_N] > 0) pred[kind] = (double)tot[F_STAT_SUM] / tot[F_STAT_N];
   };
   while (true) {
     int next = settings.max_iter;
@@ -819,7 +821,8 @@ void Engine::admm_core(double t0, double *res) {
     }
     const bool at_check = (ct > 0 && next % ct == 0) || next >= settings.max_iter || (ari > 0 && next % ari == 0);
     const bool ckpt_chunk = first_chunk && cap < kMaxCg && esc_on;
-    exec_chunk(next - iter, tight, at_check && !ckpt_chunk);
+    const int kind = tight ? 2 : ((ari > 0 && tightW > 0 && iter % ari == 0) ? 0 : 1);
+    exec_chunk(next - iter, tight, at_check && !ckpt_chunk, kind);
     cg_budget_ = budget[tight];
     if (ckpt_chunk) {
       if (budget[tight] >= cap && flags[F_STAT_STAG] * 2 > std::max(1, flags[F_STAT_N])) {

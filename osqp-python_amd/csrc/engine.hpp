@@ -120,7 +120,8 @@ class Engine {
   void run_chunk(int niter, int budget);
   void run_slots(int begin_target, int pairs, int cap);     // slot form: [slot_begin(begin_target)] + pairs x (B slot, A slot)
   bool use_slots_ = true;
-  double slot_pred_[2] = {6.0, 14.0};   // PCG iterations per ADMM iteration the slot strings are sized for (ordinary / tight chunks)
+  double slot_pred_[3] = {6.0, 6.0, 14.0};   // PCG iterations per ADMM iteration the slot strings are sized for, per chunk kind: first after an
+                                             // adaptation point (its PCGs start from an accurately solved iterate: fewer iterations), ordinary, tight
   std::map<std::array<int, 3>, void *> sgraphs_;
   void admm_core(double t0, double *res);
   void polish();
