@@ -134,3 +134,30 @@ def test_duality_gap_fields_and_check_dualgap(backend):
         s = osqp_amd.OSQP(); s.setup(Ps, qs, As, ls, us, eps_abs=1e-7, eps_rel=1e-7, verbose=False)
         k = s.solve().info
         assert k.status_val == S.OSQP_SOLVED and abs(k.duality_gap) <= 1e-4 * (1 + abs(k.obj_val)) and 0 <= k.rel_kkt_error <= 1e-3
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_extrapolated_pcg_start(backend, monkeypatch):
+    """the PCG of an ADMM iteration starts from x~ extrapolated along the last step (weight OSQP_HIP_EXTRAP, default 0.9).
+    Same fixed point whatever the weight (it only changes where the inner solver starts); fewer inner iterations than the plain
+    warm start (weight 0) on a problem whose PCG takes several iterations; the history is cleared by warm_start / updates."""
+    if backend == 'hip-pcg':
+        pytest.skip('same kernels as hip at this size')
+    with engine(backend):
+        Pb, qb, Ab, lb, ub = problems.banded_qp(3000, window=60, seed=4)
+        out = {}
+        for theta in ('0', '0.9'):
+            monkeypatch.setenv('OSQP_HIP_EXTRAP', theta)
+            monkeypatch.setenv('OSQP_HIP_SMALL_DIRECT', '0')
+            m = osqp_amd.OSQP(); m.setup(Pb, qb, Ab, lb, ub, eps_abs=1e-7, eps_rel=1e-7, verbose=False, max_iter=50000)
+            r = m.solve()
+            assert r.info.status_val == S.OSQP_SOLVED
+            out[theta] = (r, m._solver.hip_stats()['pcg_iters_total'])
+            # a re-solve from the solution (history cleared by warm_start) stops at the first check
+            m.warm_start(x=r.x, y=r.y)
+            r2 = m.solve()
+            assert r2.info.status_val == S.OSQP_SOLVED and r2.info.iter <= 50
+        (r0, pcg0), (r9, pcg9) = out['0'], out['0.9']
+        npt.assert_allclose(r9.x, r0.x, rtol=0, atol=2e-5 * (1 + np.abs(r0.x).max()))
+        npt.assert_allclose(r9.y, r0.y, rtol=0, atol=2e-5 * (1 + np.abs(r0.y).max()))
+        assert pcg9 < 0.95 * pcg0, (pcg0, pcg9)
