@@ -205,13 +205,13 @@ OSQPInt osqp_hip_time_kernel(OSQPSolver *solver, OSQPInt which, OSQPInt reps, do
    one workgroup per problem, iterates in LDS).  q: nbatch x n, l/u: nbatch x m, row-major, NULL = the solver's current
    vector for every problem.  x: nbatch x n, y: nbatch x m (in: warm start if warm != 0; out: solution, or the
    infeasibility certificate).  rec: nbatch x OSQP_HIP_BATCH_REC doubles {status_val, iter, obj_val, prim_res, dual_res, rho, rho_updates,
-   pcg_iters, status_polish, polish_time}.  With the `polishing` setting, every SOLVED problem of a directly-solved batch is polished inside
+   pcg_iters, status_polish, polish_time, rho_estimate, reserved}.  With the `polishing` setting, every SOLVED problem of a directly-solved batch is polished inside
    the kernel (reduced KKT system of the guessed active set, regularised by `delta`, factorised in LDS, `polish_refine_iter` refinement
    steps: /root/reference/src/osqppurepy/_osqp.py:1710-1828); the PCG variants do not polish (status_polish = 0).  The linear system of each ADMM iteration is solved DIRECTLY (banded LDL' of the reduced KKT matrix in LDS under a
    bandwidth-reducing ordering; pcg_iters = 0, equality weight 1e3 as in the reference) when that band fits next to the iterates
    (<= 144 KB, permuted half bandwidth <= 56, <= 4096 stored entries per matrix), by PCG otherwise.  Returns OSQP_FUNC_NOT_IMPLEMENTED when a problem does not fit
    one workgroup's LDS at all (10n + 8m doubles > 64 KB): callers then loop osqp_update_data_vec + osqp_solve. */
-#define OSQP_HIP_BATCH_REC 10
+#define OSQP_HIP_BATCH_REC 12
 OSQPInt osqp_hip_batch_solve(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u,
                              OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm);
 /* The same solve with EVERY array in device memory of this solver's device (e.g. torch ROCm tensors through data_ptr(); SURVEY 8f

@@ -123,7 +123,7 @@ struct Dev {
 constexpr int kBatchNB = 8;             // pivots per block of the batch kernel's substitutions; the band is stored with kBatchNB zeros of padding per column
 constexpr int kBatchDirectMaxBw = 64 - kBatchNB;   // band limit of the batch kernel's direct solve: one wave holds the live window of a block
 
-constexpr int kBatchRec = 10;     // doubles per problem in the result record of the batch kernels (OSQP_HIP_BATCH_REC in include/osqp_hip.h)
+constexpr int kBatchRec = 12;     // doubles per problem in the result record of the batch kernels (OSQP_HIP_BATCH_REC in include/osqp_hip.h)
 struct BatchParams {
   int n, m, nbatch;
   DevCsr A, B;
@@ -133,7 +133,10 @@ struct BatchParams {
   const double *q, *l, *u;      // UNSCALED, [nbatch][n] / [nbatch][m]; nullptr = the shared vector q0 / l0 / u0 for every problem
   const double *q0, *l0, *u0;   // UNSCALED shared vectors [n] / [m]
   double *x, *y;                // in: UNSCALED warm start (if warm), out: UNSCALED solution  [nbatch][n] / [nbatch][m]
-  double *rec;                  // [nbatch][kBatchRec]: status, iter, obj, prim_res, dual_res, rho, rho_updates, pcg_iters, status_polish, polish seconds
+  double *rec;                  // [nbatch][kBatchRec]: status, iter, obj, prim_res, dual_res, rho, rho_updates, pcg_iters, status_polish, polish seconds,
+                                // rho_estimate (_osqp.py:1275, at the ADMM point), reserved
+  double *zs = nullptr;         // optional, SCALED z iterates [nbatch][m]: read as the start when warm (a continued solve keeps its z, _osqp.py:1197-1204),
+                                // written at the end (single-QP path: the handle's own d.z)
   int polish = 0, refine = 0;   // direct variants: polish a SOLVED problem in the kernel (reduced KKT on the active set + refine refinement steps)
   double delta = 1e-6;          // polish regularisation (_osqp.py:1740-1754)
   // Direct linear solve (banded Cholesky of K = P + sigma I + A' diag(rho) A under a bandwidth-reducing symmetric

@@ -1439,9 +1439,9 @@ void set_pcg_tol(Dev &d, double rel, double ab) {
 }
 void init_iterates(Dev &d, int full) {
   HIP_CHECK(hipSetDevice(d.device));
-  if (full) LAUNCH(k_init_n, d, d);
+  if (full) LAUNCH(k_init_n, d, d);                 // full = 2: x~ = x like 1, but the z iterate in place is kept (as full = 0 does)
   LAUNCH(k_init_guess, d, d);
-  LAUNCH(k_init_m, d, d, full);
+  LAUNCH(k_init_m, d, d, full == 1 ? 1 : 0);
 }
 
 bool device_vec_updates() { return true; }

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
   for (int j = tid; j < n; j += kBB) xs[j] = x[j];
   __syncthreads();
   spmv_A(x, z, false);
-  for (int i = tid; i < m; i += kBB) zt[i] = z[i];
+  for (int i = tid; i < m; i += kBB) { zt[i] = z[i]; if (P.zs && P.warm) z[i] = P.zs[(size_t)b * m + i]; }      // (a continued solve keeps its z iterate)
   __syncthreads();
 
   // residuals of the current (x, z, y): returns through references; all threads hold identical values
@@ -594,6 +594,8 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
   // first solve plus polish_refine_iter refinement steps (:1692-1708) all have the same form: with (x, y) = 0 at the start,
   //     t = y - (b - A_act x) / delta,   rhs = -q - P x - A_act' t,   dx = K^-1 rhs,   x += dx,   y = t + A_act dx / delta.
   // Then z = A x, the normal-cone projection (:1773-1780) and the accept test on the residuals (:1786-1793).
+  // rho estimate of the ADMM point (_osqp.py:1275, :880-908), before any polish
+  const double rho_est = fmin(fmax(rho_bar * sqrt((pri_s / (fmax(ax_s, z_s) + 1e-10)) / (dua_s / (fmax(fmax(aty_s, px_s), qn_s) + 1e-10) + 1e-10)), 1e-6), 1e6);
   int status_polish = 0;
   [[maybe_unused]] unsigned long long pol_ticks = 0;
   if constexpr (DIRECT && POLISH) {
@@ -654,11 +656,13 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
   const bool pinf = status == OSQP_PRIMAL_INFEASIBLE || status == OSQP_PRIMAL_INFEASIBLE_INACCURATE;
   const bool dinf = status == OSQP_DUAL_INFEASIBLE || status == OSQP_DUAL_INFEASIBLE_INACCURATE;
   for (int j = tid; j < n; j += kBB) P.x[(size_t)b * n + j] = dinf ? (unsc ? P.D[j] * dx[j] : dx[j]) : (pinf ? NAN : (P.scaling ? P.D[j] * x[j] : x[j]));
+  if (P.zs) for (int i = tid; i < m; i += kBB) P.zs[(size_t)b * m + i] = z[i];
   for (int i = tid; i < m; i += kBB) P.y[(size_t)b * m + i] = pinf ? (unsc ? P.E[i] * dy[i] : dy[i]) : (dinf ? NAN : (P.scaling ? P.cinv * P.E[i] * y[i] : y[i]));
   if (tid == 0) {
     double *rc = P.rec + (size_t)b * kBatchRec;
     rc[0] = status; rc[1] = iter; rc[2] = obj; rc[3] = prim_res; rc[4] = dual_res; rc[5] = rho_bar; rc[6] = rho_updates; rc[7] = (double)pcg_total;
     rc[8] = status_polish; rc[9] = 1e-8 * (double)pol_ticks;      // (100 MHz wall clock -> seconds)
+    rc[10] = rho_est; rc[11] = 0.0;
 #ifdef OSQP_HIP_KTRACE
     rc[5] = (double)tk_fact; rc[6] = (double)tk_solve; rc[7] = (double)(wall_clock64() - tk_all);
     rc[3] = (double)tk_rhs; rc[4] = (double)tk_upd; rc[8] = (double)tk_fwd; rc[9] = (double)tk_res;

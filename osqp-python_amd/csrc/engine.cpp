@@ -1020,7 +1020,7 @@ int Engine::cold_start() {                                                      
   return OSQP_NO_ERROR;
 }
 
-int Engine::warm_start(const double *x, const double *y) {                               // _osqp.py:1493-1545
+int Engine::warm_start(const double *x, const double *y, bool keep_z) {                  // _osqp.py:1493-1545
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);
   settings.warm_starting = 1;
@@ -1041,7 +1041,7 @@ int Engine::warm_start(const double *x, const double *y) {                      
       be::h2d(d_, d_.y, ys.data(), sizeof(double) * m);
     }
   }
-  be::init_iterates(d_, 1);                                         // z = A x (:1509)
+  be::init_iterates(d_, keep_z ? 2 : 1);                            // z = A x (:1509); keep_z: the caller has put the z iterate in place
   return OSQP_NO_ERROR;
 }
 
@@ -1178,7 +1178,7 @@ int Engine::update_settings(const OSQPSettings *s) {
 // update-style batching (nn/torch.py:136-164: update(q,l,u) + solve() per element) as ONE kernel launch.
 // q: nbatch x n, l/u: nbatch x m (row-major; NULL = this solver's current vector for every problem);
 // x: nbatch x n, y: nbatch x m (in: unscaled warm start if warm != 0; out: solution, or certificate for infeasible ones);
-// rec: nbatch x kBatchRec = {status_val, iter, obj_val, prim_res, dual_res, rho, rho_updates, pcg_iters, status_polish, polish_time}.
+// rec: nbatch x kBatchRec = {status_val, iter, obj_val, prim_res, dual_res, rho, rho_updates, pcg_iters, status_polish, polish_time, rho_estimate, reserved}.
 
 
 // ------------------------------------------------------------------------------------------------ LinSysSolver slot
@@ -1415,12 +1415,13 @@ int Engine::solve_small_direct(double t0) {
     for (int i = 0; i < m; i++) y[i] *= cinv_ * E_[i];
   }
   double rec[kBatchRec] = {0};
-  const int err = batch_solve(1, nullptr, nullptr, nullptr, x.data(), y.data(), rec, warm);
+  // (the handle's own scaled z goes in and out by device pointer: a continued solve keeps its z iterate, _osqp.py:1197-1204)
+  const int err = batch_solve(1, nullptr, nullptr, nullptr, x.data(), y.data(), rec, warm, m > 0 ? d_.z : nullptr);
   if (err) return err;
   const int st = (int)rec[0];
   set_status(st);
   info.iter = (int)rec[1]; info.obj_val = rec[2]; info.prim_res = rec[3]; info.dual_res = rec[4];
-  info.rho_updates = (int)rec[6]; info.rho_estimate = rec[5];
+  info.rho_updates = (int)rec[6]; info.rho_estimate = rec[10];                 // (_osqp.py:1275)
   info.status_polish = (int)rec[8]; info.polish_time = rec[9];      // polished inside the kernel (reduced KKT on the factor in LDS)
   if (rec[5] != rho_bar_) {                                     // adaptive rho moved: keep the handle's state in step (_osqp.py:923-930)
     rho_bar_ = clamp_rho(rec[5]); settings.rho = rho_bar_;
@@ -1435,7 +1436,7 @@ int Engine::solve_small_direct(double t0) {
     std::copy(x.begin(), x.end(), sol_x_.begin()); std::copy(y.begin(), y.begin() + m, sol_y_.begin());   // (solution.x/y point into these)
     if (finite_xy) {
       const int keep = settings.warm_starting;
-      warm_start(x.data(), m > 0 ? y.data() : nullptr);         // device iterates follow (a later solve continues from them)
+      warm_start(x.data(), m > 0 ? y.data() : nullptr, /*keep_z=*/true);   // device x, y follow; z is the kernel's own (a later solve continues from them)
       settings.warm_starting = keep;
       // the v1 gap fields (update_gap_info) from the unscaled data on the host: a few hundred entries
       ensure_host_vectors();
@@ -1474,7 +1475,7 @@ int Engine::solve_small_direct(double t0) {
   return OSQP_NO_ERROR;
 }
 
-int Engine::batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm) {
+int Engine::batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, double *zs_dev) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   if (nbatch <= 0 || !x || !y || !rec) return OSQP_DATA_VALIDATION_ERROR;
   prepare_batch_direct();                                     // (symbolic part runs on every backend: tests read the bandwidth)
@@ -1504,6 +1505,7 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   BatchParams p{};
   fill_batch_params(p, nbatch, warm);
   p.q = q ? dq : nullptr; p.l = l ? dl : nullptr; p.u = u ? du : nullptr; p.q0 = dq0; p.l0 = dl0; p.u0 = du0; p.x = dx; p.y = dy; p.rec = drec;
+  p.zs = zs_dev;
   prepare_batch_direct();
   if (bd_.ok) {
     be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);             // A's values may have changed since the last call

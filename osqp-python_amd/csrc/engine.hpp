@@ -28,7 +28,7 @@ class Engine {
   int setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *A, const double *l, const double *u, int m,
             int n, const OSQPSettings *s);
   int solve();
-  int warm_start(const double *x, const double *y);
+  int warm_start(const double *x, const double *y, bool keep_z = false);
   int cold_start();
   int update_data_vec(const double *q, const double *l, const double *u);
   // the same with DEVICE pointers (this solver's GPU), ordered after the work queued on `stream` so far (NULL: nothing to wait for)
@@ -43,7 +43,7 @@ class Engine {
   int trace_read(unsigned long long *out, int count);
   int get_scaling(double *D, double *E, double *c);
   int set_rho_eq_factor(double f);
-  int batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm);
+  int batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, double *zs_dev = nullptr);
   int batch_solve_device(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, void *stream);
   void fill_batch_params(BatchParams &p, int nbatch, int warm);
   // LinSysSolver slot (include/osqp_hip.h): this Engine instance is then used ONLY as the reduced-KKT solver

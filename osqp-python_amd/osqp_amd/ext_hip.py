@@ -248,7 +248,7 @@ class OSQPSolver:
     def hip_set_rho_eq_factor(self, factor):
         return self._lib.osqp_hip_set_rho_eq_factor(self._p, float(factor))
 
-    BATCH_FIELDS = ('status_val', 'iter', 'obj_val', 'prim_res', 'dual_res', 'rho', 'rho_updates', 'pcg_iters', 'status_polish', 'polish_time')
+    BATCH_FIELDS = ('status_val', 'iter', 'obj_val', 'prim_res', 'dual_res', 'rho', 'rho_updates', 'pcg_iters', 'status_polish', 'polish_time', 'rho_estimate', 'reserved')
     BATCH_REC = len(BATCH_FIELDS)        # OSQP_HIP_BATCH_REC
 
     def hip_batch_solve(self, q=None, l=None, u=None, x0=None, y0=None, nbatch=None):

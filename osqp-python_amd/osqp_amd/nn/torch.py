@@ -124,7 +124,7 @@ class OSQP(Module):
             s = self._handle(Pn, An, None, None, None, device=dev.index or 0)
         x = torch.empty((nb, self.n), dtype=torch.float64, device=dev)
         y = torch.empty((nb, self.m), dtype=torch.float64, device=dev)
-        rec = torch.empty((nb, 10), dtype=torch.float64, device=dev)    # OSQP_HIP_BATCH_REC
+        rec = torch.empty((nb, 12), dtype=torch.float64, device=dev)    # OSQP_HIP_BATCH_REC
         stream = torch.cuda.current_stream(dev).cuda_stream
         try:
             s._solver.hip_batch_solve_device(nb, qd.data_ptr(), ld.data_ptr(), ud.data_ptr(), x.data_ptr(), y.data_ptr(), rec.data_ptr(),

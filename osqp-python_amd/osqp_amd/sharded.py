@@ -63,7 +63,7 @@ def solve_batch_sharded(solver, q=None, l=None, u=None, rank=0, world=1, device=
     try:
         x, y, rec = solver._solver.hip_batch_solve(q=sl(q), l=sl(l), u=sl(u), nbatch=hi - lo)
     except ValueError:                         # the problem does not fit the one-workgroup batch kernel: this rank's share, one
-        x = np.zeros((hi - lo, solver.n)); y = np.zeros((hi - lo, solver.m)); rec = np.zeros((hi - lo, 10))   # update()+solve() at a time
+        x = np.zeros((hi - lo, solver.n)); y = np.zeros((hi - lo, solver.m)); rec = np.zeros((hi - lo, 12))   # update()+solve() at a time
         for k in range(hi - lo):
             solver.update(**{name: a[k] for name, a in (('q', sl(q)), ('l', sl(l)), ('u', sl(u))) if a is not None})
             r = solver.solve()

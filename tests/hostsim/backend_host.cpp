@@ -222,7 +222,7 @@ void init_iterates(Dev &d, int full) {
   for (int i = 0; i < d.m; i++) {
     double a = 0;
     for (int k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; k++) a += d.A.val[k] * d.xs[d.A.col[k]];
-    if (full) { d.z[i] = a; d.dy[i] = 0; }
+    if (full == 1) { d.z[i] = a; d.dy[i] = 0; }                      // (full = 2: x~ = x, z kept)
     d.zt[i] = a; d.ztg[i] = a; d.t0[i] = d.rho[i] * a; d.v[i] = d.rho[i] * d.z[i] - d.y[i];
   }
 }

@@ -117,3 +117,24 @@ def test_baseline_config1_takes_the_direct_path_and_matches_the_python_reference
     assert launches(m) == 1 and r.info.status_val == 1 and io.status_val == SOLVED and r.info.iter == io.iter
     npt.assert_allclose(r.x, xo, rtol=0, atol=1e-7 * (1 + np.abs(xo).max()))
     npt.assert_allclose(r.y, yo, rtol=0, atol=1e-7 * (1 + np.abs(yo).max()))
+
+
+def test_interrupted_solve_continues_like_the_oracle_and_reports_the_rho_estimate():
+    """A solve stopped by max_iter and continued by a second solve() keeps ALL its iterates -- x, y and the z iterate itself, not
+    z = A x (_osqp.py:1197-1204) -- so the continuation takes exactly the oracle's iterations; info.rho_estimate is the reference's
+    estimate at the final ADMM point (:1275), not the rho in use."""
+    P, q, A, l, u = mpc1(seed=6)
+    st = dict(ST, max_iter=60)
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, **st)
+    o = Oracle().setup(P, q, A, l, u, **st)
+    r1 = m.solve(); x1, y1, i1 = o.solve()
+    assert launches(m) == 1 and r1.info.status_val == i1.status_val == 7 and r1.info.iter == i1.iter == 60      # MAX_ITER_REACHED
+    npt.assert_allclose(r1.info.rho_estimate, i1.rho_estimate, rtol=1e-6)
+    m.update_settings(max_iter=20000); o.update_settings(max_iter=20000)
+    r2 = m.solve(); x2, y2, i2 = o.solve()
+    assert launches(m) == 1 and r2.info.status_val == 1 and i2.status_val == SOLVED
+    assert r2.info.iter == i2.iter and r2.info.rho_updates == i2.rho_updates
+    npt.assert_allclose(r2.x, x2, rtol=0, atol=1e-8 * (1 + np.abs(x2).max()))
+    npt.assert_allclose(r2.y, y2, rtol=0, atol=1e-8 * (1 + np.abs(y2).max()))
+    npt.assert_allclose(r2.info.rho_estimate, i2.rho_estimate, rtol=1e-5)
+    assert r2.info.rho_estimate != m._solver.get_settings().rho or r2.info.rho_updates == 0
