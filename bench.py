@@ -229,7 +229,7 @@ def main():
                                            'frac': pcg_bytes / (pcg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          'kernels': probes},
         }
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:          # (the CPU baseline is timed at N = 1 only: the other ranks would wait 40 s at the barrier)
             cb = cpu_baseline(P, q, A, l, u, settings, args.cpu_seconds)
             out['cpu_baseline'] = cb
             out['config']['gpu_over_cpu_iter_rate'] = (total_iters / tmax / world) / cb['value']

@@ -105,7 +105,7 @@ def main():
                            'model': 'dependent chain of the banded substitutions: 2n = %d pivots x %.1f cycles (broadcast + FMA, measured) at 2.4 GHz = %.2f us per ADMM iteration; '
                                     'measured %.2f us (%.1f ADMM iterations per QP, %d QPs resident at a time, kernel %.2f ms)'
                                     % (2 * n_var, kChainCycles, 1e6 * floor_iter, 1e6 * t_iter, iters_per_qp, resident, 1e3 * kernel_s)}
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:
             import multiprocessing as mp
             cores = min(os.cpu_count() or 1, 64)       # worker processes (one contiguous share of the batch each)
             sample = B
