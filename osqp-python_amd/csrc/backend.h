@@ -201,6 +201,7 @@ bool slots_supported(const Dev &d);
 void slot_begin(Dev &d, int target, int cap);
 void slot_pair(Dev &d);
 int slot_done(Dev &d);
+int slot_seq(Dev &d);                      // slots executed since slot_begin (consistency check of the record hand-over)
 
 // ---- every check_termination iterations ----
 // residual norms / objective pieces of (x,z,y) -> d.res[0 .. R_QDX]   (_osqp.py:705-794, 880-908)

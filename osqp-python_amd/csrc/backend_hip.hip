@@ -540,7 +540,10 @@ struct PreK1 {
   const Dev &d; int i, probe; double *red;
   __device__ __forceinline__ bool operator()() const {
     if (probe == 1) return true;
-    if (!probe && d.flags[F_DONE]) return false;          // already converged: leave before paying for the reduction
+    // (No early exit on d.flags[F_DONE] here: in the slot form workgroup 0 of THIS launch may set the flag while other workgroups are
+    // still arriving, the waves of one workgroup then read different values, one skips the barriers of the reduction below and
+    // meets its siblings at the next __syncthreads() instead -- they fold its stale LDS slot.  Seen as run-to-run differences of
+    // solves running concurrently on several streams, 1-4 % of them (tools/thread_stress.py); every wave takes the reduction now.)
     const PartRegs prn = partial_load(d.part + (SL_RN0 + (i & 1)) * kGrid), pbn = partial_load(d.part + SL_BN * kGrid);
     double rn = partial_fold_max(prn), bn = partial_fold_max(pbn);
     block_max2(rn, bn, red);
@@ -857,14 +860,15 @@ struct EKa {
 };
 __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
   __shared__ StreamLdsW<1, double> lds;
+  const double theta = d.theta;
   GVec g{d.xs};
-  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, d.theta};
+  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, theta};
   process_rows<1>(d.A, g, e, lds);
   const int stride = gridDim.x * kBlock;
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) {    // _osqp.py:664-668
     const double xt = d.xs[j], xo = d.x[j], xn = d.alpha * xt + (1.0 - d.alpha) * xo;
     d.dx[j] = xn - xo; d.x[j] = xn;
-    d.xg[j] = xt + d.theta * (xt - d.xsp[j]); d.xsp[j] = xt;                 // next PCG start (Dev::xg)
+    d.xg[j] = xt + theta * (xt - d.xsp[j]); d.xsp[j] = xt;                   // next PCG start (Dev::xg)
   }
   if (blockIdx.x == 0) {                                                     // PCG statistics of this ADMM iteration
     int done = d.flags[F_DONE];
@@ -893,15 +897,15 @@ __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
 // The PCG of ADMM iteration j therefore takes exactly as many slot pairs as it has iterations (plus the pair that detects
 // convergence and runs KA), whatever the neighbouring iterations needed; only the few slots left over at the END of a chunk idle.
 enum SlotPhase { P_KB = 0, P_K1, P_K2F, P_K1F, P_KA, P_IDLE };
-enum SlotRec { SR_PHASE = 0, SR_K, SR_ADMM, SR_TARGET, SR_USED, SR_CONV, SR_CAP, SR_WORDS = 8 };
+enum SlotRec { SR_PHASE = 0, SR_K, SR_ADMM, SR_TARGET, SR_USED, SR_CONV, SR_CAP, SR_SEQ /* slots executed since k_slot_init: every slot adds one */, SR_WORDS = 8 };
 
-struct SlotState { int ph, k, admm, target, used, conv, cap; };
-__device__ __forceinline__ SlotState slot_read(const int *r) { return SlotState{r[SR_PHASE], r[SR_K], r[SR_ADMM], r[SR_TARGET], r[SR_USED], r[SR_CONV], r[SR_CAP]}; }
+struct SlotState { int ph, k, admm, target, used, conv, cap, seq; };
+__device__ __forceinline__ SlotState slot_read(const int *r) { return SlotState{r[SR_PHASE], r[SR_K], r[SR_ADMM], r[SR_TARGET], r[SR_USED], r[SR_CONV], r[SR_CAP], r[SR_SEQ]}; }
 __device__ __forceinline__ void slot_write(int *w, const SlotState &s) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) { w[SR_PHASE] = s.ph; w[SR_K] = s.k; w[SR_ADMM] = s.admm; w[SR_TARGET] = s.target; w[SR_USED] = s.used; w[SR_CONV] = s.conv; w[SR_CAP] = s.cap; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { w[SR_PHASE] = s.ph; w[SR_K] = s.k; w[SR_ADMM] = s.admm; w[SR_TARGET] = s.target; w[SR_USED] = s.used; w[SR_CONV] = s.conv; w[SR_CAP] = s.cap; w[SR_SEQ] = s.seq + 1; }
 }
 __global__ void k_slot_init(int *slot, int target, int cap) {      // (cap: PCG iterations per solve; in the record, not a kernel argument, so that captured strings of slots serve every chunk)
-  slot[SR_PHASE] = P_KB; slot[SR_K] = 0; slot[SR_ADMM] = 0; slot[SR_TARGET] = target; slot[SR_USED] = 0; slot[SR_CONV] = 0; slot[SR_CAP] = cap;
+  slot[SR_PHASE] = P_KB; slot[SR_K] = 0; slot[SR_ADMM] = 0; slot[SR_TARGET] = target; slot[SR_USED] = 0; slot[SR_CONV] = 0; slot[SR_CAP] = cap; slot[SR_SEQ] = 0;
 }
 
 __global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
@@ -944,14 +948,15 @@ __global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
 // iterate reach the tolerance anyway?)
 template <class L>
 __device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv, const FirstDesc &fd) {
+  const double theta = d.theta;
   GVec g{d.xs};
-  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, d.theta};
+  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, theta};
   process_rows_fd<1>(d.A, g, e, lds, NoPre(), fd);
   const int stride = gridDim.x * kBlock;
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) {    // _osqp.py:664-668
     const double xt = d.xs[j], xo = d.x[j], xn = d.alpha * xt + (1.0 - d.alpha) * xo;
     d.dx[j] = xn - xo; d.x[j] = xn;
-    d.xg[j] = xt + d.theta * (xt - d.xsp[j]); d.xsp[j] = xt;                 // next PCG start (Dev::xg)
+    d.xg[j] = xt + theta * (xt - d.xsp[j]); d.xsp[j] = xt;                   // next PCG start (Dev::xg)
   }
   if (blockIdx.x == 0) {
     if (!conv) {
@@ -1380,6 +1385,7 @@ void ka(Dev &d, int budget) { LAUNCH(k_ka, d, d, budget); }
 bool slots_supported(const Dev &d) { return d.fused != 0 && d.slot != nullptr; }
 void slot_begin(Dev &d, int target, int cap) { HIP_CHECK(hipSetDevice(d.device)); hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(1), 0, st(d), d.slot, target, cap); }
 void slot_pair(Dev &d) { LAUNCH(k_slot_b, d, d); LAUNCH(k_slot_a, d, d); }
+int slot_seq(Dev &d) { return (im(d).pin_flags + F_COUNT)[SR_SEQ]; }      // slots executed since slot_begin, as of the last fetch (record A)
 int slot_done(Dev &d) {        // ADMM iterations completed by the chunk, as of the last fetch_flags / fetch_res_flags (record A: written by the last A slot)
   const int *rec = im(d).pin_flags + F_COUNT;
   return rec[SR_ADMM];
@@ -1449,6 +1455,7 @@ void copy_in(Dev &d, void *dst, const void *src, size_t bytes, int src_on_device
   if (!bytes) return;
   HIP_CHECK(hipSetDevice(d.device));
   HIP_CHECK(hipMemcpyAsync(dst, src, bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st(d)));
+  if (!src_on_device) HIP_CHECK(hipStreamSynchronize(st(d)));      // the caller may reuse its (pageable) buffer as soon as the call returns
 }
 void stream_wait(Dev &d, void *caller_stream) {
   if (!caller_stream || caller_stream == d.stream) return;

@@ -44,6 +44,7 @@ bool slots_supported(const Dev &) { return false; }
 void slot_begin(Dev &, int, int) {}
 void slot_pair(Dev &) {}
 int slot_done(Dev &) { return 0; }
+int slot_seq(Dev &) { return 0; }
 void ext_record(Dev &, void *) {}
 void ext_wait(Dev &) {}
 
@@ -112,13 +113,14 @@ void kv(Dev &d, int i) {
 }
 
 void ka(Dev &d, int budget) {
+  const double theta = d.theta;
   for (int i = 0; i < d.m; i++) {
     double zt = 0;
     for (int k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; k++) zt += d.A.val[k] * d.xs[d.A.col[k]];
     double zr = d.alpha * zt + (1.0 - d.alpha) * d.z[i];
     double zn = std::fmin(std::fmax(zr + d.rho_inv[i] * d.y[i], d.l[i]), d.u[i]);
     double dy = d.rho[i] * (zr - zn);
-    const double zg = zt + d.theta * (zt - d.zt[i]);
+    const double zg = zt + theta * (zt - d.zt[i]);
     d.y[i] += dy; d.dy[i] = dy; d.z[i] = zn; d.zt[i] = zt; d.ztg[i] = zg;
     d.v[i] = d.rho[i] * zn - d.y[i]; d.t0[i] = d.rho[i] * zg;
   }
@@ -126,7 +128,7 @@ void ka(Dev &d, int budget) {
     const double xt = d.xs[j];
     double xn = d.alpha * xt + (1.0 - d.alpha) * d.x[j];
     d.dx[j] = xn - d.x[j]; d.x[j] = xn;
-    d.xg[j] = xt + d.theta * (xt - d.xsp[j]); d.xsp[j] = xt;
+    d.xg[j] = xt + theta * (xt - d.xsp[j]); d.xsp[j] = xt;
   }
   int used = d.flags[F_DONE] ? d.flags[F_ITERS] : budget;
   d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;

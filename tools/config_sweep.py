@@ -31,7 +31,8 @@ for name in names:
     P, q, A, l, u = CASES[name]()
     n, mm = len(q), len(l)
     m = osqp_amd.OSQP()
-    t = time.perf_counter(); m.setup(P, q, A, l, u, verbose=False, eps_abs=1e-6, eps_rel=1e-6, max_iter=50000); ts = time.perf_counter() - t
+    kw = dict(verbose=False, eps_abs=1e-6, eps_rel=1e-6, max_iter=50000); kw.update(eval(os.environ.get('SWEEP_KW', '{}')))     # e.g. SWEEP_KW="dict(adaptive_rho_tolerance=2)"
+    t = time.perf_counter(); m.setup(P, q, A, l, u, **kw); ts = time.perf_counter() - t
     t = time.perf_counter(); r = m.solve(); t1 = time.perf_counter() - t
     st = m._solver.hip_stats()
     nnzA, nnzB = int(st['nnzA']), int(st['nnzB'])
