@@ -135,6 +135,8 @@ struct BatchParams {
   double *x, *y;                // in: UNSCALED warm start (if warm), out: UNSCALED solution  [nbatch][n] / [nbatch][m]
   double *rec;                  // [nbatch][kBatchRec]: status, iter, obj, prim_res, dual_res, rho, rho_updates, pcg_iters, status_polish, polish seconds,
                                 // rho_estimate (_osqp.py:1275, at the ADMM point), reserved
+  const int *order = nullptr;   // optional [nbatch]: workgroup w solves problem order[w] (longest-expected first: the batch ends with its slowest
+                                // problems otherwise; Engine::batch_solve keeps the order of the previous call's iteration counts)
   double *zs = nullptr;         // optional, SCALED z iterates [nbatch][m]: read as the start when warm (a continued solve keeps its z, _osqp.py:1197-1204),
                                 // written at the end (single-QP path: the handle's own d.z)
   int polish = 0, refine = 0;   // direct variants: polish a SOLVED problem in the kernel (reduced KKT on the active set + refine refinement steps)

@@ -166,8 +166,9 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
 #define BT2_END(acc) ((void)0)
 #endif
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int n = P.n, m = P.m, tid = threadIdx.x, b = blockIdx.x;
-  if (b >= P.nbatch) return;
+  const int n = P.n, m = P.m, tid = threadIdx.x;
+  if ((int)blockIdx.x >= P.nbatch) return;
+  const int b = P.order ? P.order[blockIdx.x] : (int)blockIdx.x;      // (workgroups are dispatched in index order: expected-longest problems first)
   // ---- LDS carve ----
   double *x = sm, *xs = x + n, *r = xs + n, *zv = r + n, *p = zv + n, *Kp = p + n, *q = Kp + n, *Minv = q + n, *dx = Minv + n, *tn = dx + n;
   double *z = tn + n, *y = z + m, *t = y + m, *l = t + m, *u = l + m, *rho = u + m, *zt = rho + m, *dy = zt + m;
