@@ -196,3 +196,16 @@ def test_batch_direct_longer_horizon_three_epochs(monkeypatch, variant='direct25
         assert io.status_val == SOLVED
         assert abs(rec[i, 2] - io.obj_val) <= 1e-5 * (1 + abs(io.obj_val))
         assert np.abs(x[i] - xo).max() <= 1e-4 * (1 + np.abs(xo).max())
+
+
+def test_launch_order_of_a_repeated_batch_does_not_change_results(monkeypatch):
+    """The second call of a batch launches its problems longest-last-time first (Engine::batch_solve): scheduling only -- every
+    record and solution is bitwise what index order gives."""
+    B = 96
+    P, q, A, L, U = problems.mpc_batch(B, seed=21)
+    s = osqp_amd.OSQP(); s.setup(P, q, A, L[0], U[0], eps_abs=1e-6, eps_rel=1e-6, verbose=False)
+    x1, y1, r1 = s._solver.hip_batch_solve(l=L, u=U)            # index order (no history yet)
+    x2, y2, r2 = s._solver.hip_batch_solve(l=L, u=U)            # reordered by r1's iteration counts
+    assert len(set(r1[:, 1])) > 3                                 # the iteration counts do differ between problems
+    assert np.array_equal(x1, x2) and np.array_equal(y1, y2) and np.array_equal(r1[:, :9], r2[:, :9])
+    monkeypatch.setenv('OSQP_HIP_BATCH_REORDER', '0')
