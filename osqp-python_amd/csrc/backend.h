@@ -71,7 +71,7 @@ enum ResId {
 // opposed to one that converges steadily but needs more iterations than it was given)
 enum FlagId { F_DONE = 0, F_ITERS, F_STAT_SUM, F_STAT_MAX, F_STAT_UNCONV, F_STAT_SUMSQ, F_STAT_N, F_STAT_STAG, F_COUNT };
 // indices into the fp64 scalar block
-enum ScalId { S_TOL_REL = 0, S_TOL_ABS, S_TOL_NOW, S_RN0 /* ||r_0||_inf of the current PCG */, S_HIST = 8 /* gamma[kMaxCg+1], alpha[kMaxCg+1], beta[kMaxCg+1] */ };
+enum ScalId { S_TOL_REL = 0, S_TOL_ABS, S_TOL_NOW, S_RN0 /* ||r_0||_inf of the current PCG */, S_RN0H /* the same by parity of the ADMM iteration (slot form): [2] */, S_HIST = 8 /* gamma[kMaxCg+1], alpha[kMaxCg+1], beta[kMaxCg+1] */ };
 
 struct Dev {
   int n = 0, m = 0, device = 0;

@@ -537,7 +537,7 @@ struct EK1 {
 // PCG stopping test, run by every working workgroup (and workgroup 0) while its first matrix loads are in flight
 struct PreK1 {
   [[maybe_unused]] static constexpr int kTraceBase = 0;
-  const Dev &d; int i, probe; double *red;
+  const Dev &d; int i, probe; double *red; int par = -1;      // par: parity of the ADMM iteration (slot form), -1: not recorded
   __device__ __forceinline__ bool operator()() const {
     if (probe == 1) return true;
     // (No early exit on d.flags[F_DONE] here: in the slot form workgroup 0 of THIS launch may set the flag while other workgroups are
@@ -549,7 +549,7 @@ struct PreK1 {
     block_max2(rn, bn, red);
     if (probe) { if (rn < -1.0) d.res[R_COUNT - 1] = bn; return true; }     // probe == 2: pay for the test, ignore it
     const double tol = fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS]);
-    if (i == 0 && blockIdx.x == 0 && threadIdx.x == 0) { d.scal[S_TOL_NOW] = tol; d.scal[S_RN0] = rn; }   // fused PCG: later tests read the scalar
+    if (i == 0 && blockIdx.x == 0 && threadIdx.x == 0) { d.scal[S_TOL_NOW] = tol; d.scal[S_RN0] = rn; if (par >= 0) d.scal[S_RN0H + par] = rn; }   // fused PCG: later tests read the scalar
     if (!(rn > tol)) {            // converged (a NaN residual also stops the inner loop; the ADMM residuals will flag it)
       if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = i; }
       return false;
@@ -858,9 +858,30 @@ struct EKa {
     y[i] = yn; dy[i] = dyi; z[i] = zn; zt[i] = ztil; v[i] = prho * zn - yn; ztg[i] = zg; t0[i] = prho * zg;
   }
 };
+// The extrapolated PCG start is used after a solve that REACHED its tolerance -- and after a cut-off one only while the start
+// residuals keep falling (slot form, below).  A cut-off solve leaves an error that the few
+// iterations it was given barely touched in the slow modes of K; extrapolating along a step that contains it feeds that error, times
+// (1 + theta), to the next cut-off solve, and through z and y back into the next right-hand side: observed as iterates growing to
+// 1e12 within 25 ADMM iterations after a rho update had left five-iteration budgets on an ill-conditioned system (then 500
+// iterations of recovery; unstructured config 2 with cg_tol_fraction 0.1).  Limiting theta by the measured residual reduction of
+// the cut-off solve did not prevent it (the residual norm says little about the slow modes); starting from x~ itself does.
+// Every workgroup takes the same branch (conv / done come from an earlier launch); rn, bn of the last iterate are folded for
+// workgroup 0's statistics.
+__device__ __forceinline__ double cutoff_theta(const Dev &d, int slot, double *red, double &rn, double &bn, int admm = -1) {
+  rn = partial_fold_max(partial_load(d.part + (SL_RN0 + slot) * kGrid)); bn = partial_fold_max(partial_load(d.part + SL_BN * kGrid));
+  block_max2(rn, bn, red);
+  if (admm < 1) return 0.0;
+  // slot form: the start residuals of this and of the previous ADMM iteration are on record (written by earlier launches).  While they
+  // FALL the cut-off solves are keeping up and the extrapolation stays (config 2: budget-limited chunks are part of normal operation,
+  // 53 vs 65 ms); once the start residual grows, the next solve starts from x~ itself.
+  const double now = d.scal[S_RN0H + (admm & 1)], prev = d.scal[S_RN0H + ((admm + 1) & 1)];
+  return (now < prev) ? d.theta : 0.0;
+}
 __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
   __shared__ StreamLdsW<1, double> lds;
-  const double theta = d.theta;
+  int done = d.flags[F_DONE];                       // (set by an earlier launch: the same value in every wave)
+  double theta = d.theta, rn_last = 0.0, bn_last = 0.0;
+  if (!done && budget > 0) { theta = cutoff_theta(d, budget & 1, lds.red, rn_last, bn_last); __syncthreads(); }
   GVec g{d.xs};
   EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, theta};
   process_rows<1>(d.A, g, e, lds);
@@ -871,11 +892,8 @@ __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
     d.xg[j] = xt + theta * (xt - d.xsp[j]); d.xsp[j] = xt;                   // next PCG start (Dev::xg)
   }
   if (blockIdx.x == 0) {                                                     // PCG statistics of this ADMM iteration
-    int done = d.flags[F_DONE];
     if (!done && budget > 0) {            // did the last budgeted iteration reach the tolerance? (no K1 ran after it)
-      __syncthreads();
-      double rn = partial_fold_max(partial_load(d.part + (SL_RN0 + (budget & 1)) * kGrid)), bn = partial_fold_max(partial_load(d.part + SL_BN * kGrid));
-      block_max2(rn, bn, lds.red);
+      const double rn = rn_last, bn = bn_last;
       done = !(rn > fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS])) ? 2 : 0;
       if (!done && threadIdx.x == 0 && rn > 0.1 * d.scal[S_RN0]) d.flags[F_STAT_STAG] += 1;
     }
@@ -947,8 +965,9 @@ __global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
 // KA with the PCG statistics taken from the slot record (used iterations; conv = 0: the PCG stopped at the cap -- did its last
 // iterate reach the tolerance anyway?)
 template <class L>
-__device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv, const FirstDesc &fd) {
-  const double theta = d.theta;
+__device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv, const FirstDesc &fd, int admm) {
+  double theta = d.theta, rn_last = 0.0, bn_last = 0.0;
+  if (!conv) { theta = cutoff_theta(d, used & 1, lds.red, rn_last, bn_last, admm); __syncthreads(); }      // (conv comes from the slot record: uniform)
   GVec g{d.xs};
   EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, theta};
   process_rows_fd<1>(d.A, g, e, lds, NoPre(), fd);
@@ -960,9 +979,7 @@ __device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv
   }
   if (blockIdx.x == 0) {
     if (!conv) {
-      __syncthreads();
-      double rn = partial_fold_max(partial_load(d.part + (SL_RN0 + (used & 1)) * kGrid)), bn = partial_fold_max(partial_load(d.part + SL_BN * kGrid));
-      block_max2(rn, bn, lds.red);
+      const double rn = rn_last, bn = bn_last;
       conv = !(rn > fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS])) ? 2 : 0;
       if (!conv && threadIdx.x == 0 && rn > 0.1 * d.scal[S_RN0]) d.flags[F_STAT_STAG] += 1;
     }
@@ -982,10 +999,10 @@ __global__ __launch_bounds__(kBlock) void k_slot_a(Dev d) {
   if (st.ph == P_K1) {                                 // first A-apply of this ADMM iteration's PCG: stopping test on r_0, t_0 = rho .* (A u_0)
     GVec g{d.uu};
     EK1 e{d.rho, d.t};
-    if (process_rows_fd<1>(d.A, g, e, lds.k1, PreK1{d, 0, 0, lds.k1.red}, fd)) { st.ph = P_K2F; st.k = 0; }
+    if (process_rows_fd<1>(d.A, g, e, lds.k1, PreK1{d, 0, 0, lds.k1.red, st.admm & 1}, fd)) { st.ph = P_K2F; st.k = 0; }
     else {                                             // the warm start already meets the tolerance: no PCG iteration, KA right here
       __syncthreads();
-      slot_ka(d, lds.k1, 0, 1, fd);
+      slot_ka(d, lds.k1, 0, 1, fd, st.admm);
       st.ph = P_KB; st.admm += 1;
     }
   } else if (st.ph == P_K1F) {
@@ -1007,7 +1024,7 @@ __global__ __launch_bounds__(kBlock) void k_slot_a(Dev d) {
     if (i >= st.cap) { st.ph = P_KA; st.used = i; st.conv = 0; }      // the PCG stops at the cap; the next A slot runs KA
     else { st.ph = P_K2F; st.k = i; }
   } else if (st.ph == P_KA) {
-    slot_ka(d, lds.k1, st.used, st.conv, fd);
+    slot_ka(d, lds.k1, st.used, st.conv, fd, st.admm);
     st.ph = P_KB; st.admm += 1;
   }
   slot_write(W, st);
@@ -1137,7 +1154,7 @@ __global__ __launch_bounds__(kBlock) void k_set_rho(Dev d, double rho_bar) {
     const double eqf = d.eq_from_cnt ? (d.cnt[0] == 0 ? 1e3 : d.rho_eq_mixed) : d.rho_eq_factor;   // engine.cpp classify_constraints
     const double r = t == -1 ? 1e-6 : (t == 1 ? eqf * rho_bar : rho_bar);                 // _osqp.py:520-522, :1590-1594
     d.rho[i] = r; d.rho_inv[i] = 1.0 / r;
-    d.v[i] = r * d.z[i] - d.y[i]; d.t0[i] = r * d.ztg[i];
+    d.v[i] = r * d.z[i] - d.y[i]; d.ztg[i] = d.zt[i]; d.t0[i] = r * d.zt[i];      // (the x~ sequence has a kink at a rho change: the next PCG starts from x~ itself)
   }
 }
 struct GPrec { const double *rho; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = c >= n ? rho[c - n] * a * a : 0.0; } };
@@ -1433,7 +1450,7 @@ void fetch_res_flags(Dev &d, double *hr, int *hf) {
   std::memcpy(hf, im(d).pin_flags, sizeof(int) * F_COUNT);
 }
 
-void set_rho(Dev &d, double rho_bar) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_set_rho, d, d, rho_bar); }
+void set_rho(Dev &d, double rho_bar) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_set_rho, d, d, rho_bar); LAUNCH(k_init_guess, d, d); }
 void precond(Dev &d, int diagonal) {
   HIP_CHECK(hipSetDevice(d.device));
   if (diagonal) LAUNCH(k_precond, d, d);

@@ -113,7 +113,8 @@ void kv(Dev &d, int i) {
 }
 
 void ka(Dev &d, int budget) {
-  const double theta = d.theta;
+  double theta = d.theta;
+  if (!d.flags[F_DONE] && budget > 0) theta = 0.0;     // after a cut-off solve the next one starts from x~ itself (backend_hip.hip cutoff_theta)
   for (int i = 0; i < d.m; i++) {
     double zt = 0;
     for (int k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; k++) zt += d.A.val[k] * d.xs[d.A.col[k]];
@@ -202,10 +203,11 @@ void fetch_flags(Dev &d, int *h) {
 void fetch_res_flags(Dev &d, double *hr, int *hf) { fetch_res(d, hr); fetch_flags(d, hf); }
 
 void set_rho(Dev &d, double rb) {
+  for (int j = 0; j < d.n; j++) { d.xg[j] = d.xs[j]; d.xsp[j] = d.xs[j]; }      // history cleared (backend_hip.hip set_rho)
   for (int i = 0; i < d.m; i++) {
     double r = d.ctype[i] == -1 ? 1e-6 : (d.ctype[i] == 1 ? d.rho_eq_factor * rb : rb);
     d.rho[i] = r; d.rho_inv[i] = 1.0 / r;
-    d.v[i] = r * d.z[i] - d.y[i]; d.t0[i] = r * d.ztg[i];
+    d.v[i] = r * d.z[i] - d.y[i]; d.ztg[i] = d.zt[i]; d.t0[i] = r * d.zt[i];
   }
 }
 void precond(Dev &d, int diagonal) {
