@@ -17,7 +17,7 @@ def banded_qp(n, m=None, nnz_per_row=5, window=200, eq_frac=0.1, seed=12345):
     """BASELINE configs[1] ("Single QP n=100k m=200k nnz(A)=1M nnz(P)=200k"), SURVEY §8d config 2:
     A has exactly `nnz_per_row` N(0,1) entries per row in a random-within-a-band pattern (columns drawn from a window
     of `window` columns around i*n/m), P = diag(U(0.1,1.1)) + one symmetric off-diagonal pair per two rows inside the
-    band (diagonally dominant => PSD, stored full nnz(P) = 2n), 10 % equality rows; feasible by construction."""
+    band, the diagonal raised by the row's off-diagonal mass (strictly diagonally dominant: eigenvalues >= 0.1; stored full nnz(P) = 2n), 10 % equality rows; feasible by construction."""
     rng = np.random.default_rng(seed)
     m = 2 * n if m is None else m
     k = min(nnz_per_row, n)
@@ -30,10 +30,13 @@ def banded_qp(n, m=None, nnz_per_row=5, window=200, eq_frac=0.1, seed=12345):
     A.sort_indices()
     d = rng.uniform(0.1, 1.1, n)
     i = np.arange(0, n - 1, 2)
-    j = np.minimum(i + 1 + rng.integers(0, max(w - 1, 1), size=i.size), n - 1)
+    # (partner column inside the band; near the last column the offset wraps inside what is left of the row -- clamping to n - 1 piled
+    #  every late pair onto the last column: an arrow that made P indefinite for wide windows, found with tools/robustness_grid.py)
+    j = i + 1 + rng.integers(0, max(w - 1, 1), size=i.size) % np.maximum(n - 1 - i, 1)
     keep = j > i
     i, j = i[keep], j[keep]
     off = rng.uniform(-0.04, 0.04, size=i.size)
+    d = d + np.bincount(i, np.abs(off), n) + np.bincount(j, np.abs(off), n)      # strictly diagonally dominant: eigenvalues >= 0.1
     P = sp.coo_matrix((np.concatenate([d, off, off]), (np.concatenate([np.arange(n), i, j]), np.concatenate([np.arange(n), j, i]))), shape=(n, n)).tocsc()
     P.sort_indices()
     q = rng.standard_normal(n)
