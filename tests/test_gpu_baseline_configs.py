@@ -137,9 +137,10 @@ def test_config5_mpc_batch_shard():
 
 
 def test_cut_off_inner_solves_after_a_rho_update_do_not_run_away():
-    """Regression (r02f): config 2 with unstructured columns and a tight inner tolerance (cg_tol_fraction = 0.1).  A rho update near
-    iteration 400 leaves five-iteration PCG budgets on a much worse conditioned system; with the extrapolated PCG start applied after
-    cut-off solves the iterates grew to 1e12 and the solve took 1000-1100 iterations (425-675 without).  DESIGN.md section 2.2."""
+    """Regression (r02f): config 2 with unstructured columns and a tight inner tolerance (cg_tol_fraction = 0.1).  With the first
+    generator of this problem (P indefinite for wide windows) a rho update near iteration 400 sent the iterates to 1e12 and the solve
+    took 1000-1100 iterations; with the corrected one it is a plain 400-500 iteration solve.  Kept as a guard on the combination
+    wide matrix + tight inner tolerance + adaptive rho + extrapolated PCG start.  DESIGN.md section 2.2."""
     P, q, A, l, u = problems.banded_qp(100000, window=100000)
     m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, eps_abs=EPS, eps_rel=EPS, max_iter=50000, cg_tol_fraction=0.1)
     r = m.solve()
