@@ -210,7 +210,8 @@ OSQPInt osqp_hip_time_kernel(OSQPSolver *solver, OSQPInt which, OSQPInt reps, do
    steps: /root/reference/src/osqppurepy/_osqp.py:1710-1828); the PCG variants do not polish (status_polish = 0).  The linear system of each ADMM iteration is solved DIRECTLY (banded LDL' of the reduced KKT matrix in LDS under a
    bandwidth-reducing ordering; pcg_iters = 0, equality weight 1e3 as in the reference) when that band fits next to the iterates
    (<= 144 KB, permuted half bandwidth <= 56, <= 4096 stored entries per matrix), by PCG otherwise.  Returns OSQP_FUNC_NOT_IMPLEMENTED when a problem does not fit
-   one workgroup's LDS at all (10n + 8m doubles > 64 KB): callers then loop osqp_update_data_vec + osqp_solve. */
+   one workgroup's LDS at all (10n + 8m doubles > 64 KB): callers then loop osqp_update_data_vec + osqp_solve.  A repeated batch of the
+   same size is launched in the order of the previous call's iteration counts, longest first (scheduling only; results do not depend on it). */
 #define OSQP_HIP_BATCH_REC 12
 OSQPInt osqp_hip_batch_solve(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u,
                              OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm);
