@@ -84,7 +84,7 @@ def main():
                           'ms_per_step_median': float(sorted(step_ms)[len(step_ms) // 2]), 'kernel_ms_last_step': s._solver.hip_stats()['gpu_solve_ms'],
                           'solved': int((table[:, 1] == 1).sum()), 'admm_iters_total': float(table[:, 2].sum()),
                           'admm_iters_per_s': float(table[:, 2].sum()) * args.steps / el}}
-        # Roofline of the batch kernel (k_batch_admm<256, 8, 8, true>, one workgroup per QP, everything in LDS / registers): neither HBM
+        # Roofline of the batch kernel (k_batch_admm<256, 6, 6, true>: six stored entries of A and of B per lane, one workgroup per QP, everything in LDS / registers): neither HBM
         # (7.7 KB of vectors per QP in and out) nor MFMA applies.  What bounds it is the DEPENDENT chain of the two banded
         # triangular substitutions of every ADMM iteration, which run on one wave: 2n pivots, each one broadcast (v_readlane pair)
         # + one fp64 FMA that the next pivot depends on.  Floor = 2n pivots x kChainCycles at the 2.4 GHz peak clock with the CU's
@@ -100,7 +100,7 @@ def main():
         waves_of_qps = -(-int(B // world) // resident)
         t_iter = kernel_s / (waves_of_qps * iters_per_qp)              # wall time of one ADMM iteration of a resident QP
         floor_iter = 2 * n_var * kChainCycles / 2.4e9
-        out['roofline'] = {'bound': 'latency', 'kernel': 'k_batch_admm<256,8,8,true>', 'unit': 'ADMM iter/s per resident QP',
+        out['roofline'] = {'bound': 'latency', 'kernel': 'k_batch_admm<256,6,6,true>', 'unit': 'ADMM iter/s per resident QP',
                            'achieved': 1.0 / t_iter, 'peak': 1.0 / floor_iter, 'frac': floor_iter / t_iter, 'traffic': None,
                            'model': 'dependent chain of the banded substitutions: 2n = %d pivots x %.1f cycles (broadcast + FMA, measured) at 2.4 GHz = %.2f us per ADMM iteration; '
                                     'measured %.2f us (%.1f ADMM iterations per QP, %d QPs resident at a time, kernel %.2f ms)'

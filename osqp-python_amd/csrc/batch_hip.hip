@@ -731,7 +731,7 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
     hipLaunchKernelGGL((k_batch_admm<TB, E, E, true, POL>), dim3(p.nbatch), dim3(TB), lds_dir, st, p); } while (0)
 #define BATCH_LAUNCH_DIRECT(TB, E) do { if (p.polish) BATCH_LAUNCH_DIRECT_P(TB, E, true); else BATCH_LAUNCH_DIRECT_P(TB, E, false); } while (0)
   if (use_dir256) {
-    if (e256 <= 2) BATCH_LAUNCH_DIRECT(256, 2); else if (e256 <= 4) BATCH_LAUNCH_DIRECT(256, 4); else if (e256 <= 8) BATCH_LAUNCH_DIRECT(256, 8); else BATCH_LAUNCH_DIRECT(256, 16);
+    if (e256 <= 2) BATCH_LAUNCH_DIRECT(256, 2); else if (e256 <= 4) BATCH_LAUNCH_DIRECT(256, 4); else if (e256 <= 6) BATCH_LAUNCH_DIRECT(256, 6); else if (e256 <= 8) BATCH_LAUNCH_DIRECT(256, 8); else BATCH_LAUNCH_DIRECT(256, 16);
   } else if (use_dir) {
     if (e64 <= 8) BATCH_LAUNCH_DIRECT(64, 8); else if (e64 <= 16) BATCH_LAUNCH_DIRECT(64, 16); else BATCH_LAUNCH_DIRECT(64, 24);
   } else if (use64) {
