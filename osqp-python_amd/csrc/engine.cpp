@@ -572,7 +572,7 @@ void Engine::run_chunk(int niter, int budget) {
 
 // Slot form of a chunk (backend_hip.hip "slot kernels"): begin_target > 0 starts a chunk of that many ADMM iterations (eager one-thread
 // launch: target and PCG cap travel in the phase record), then `pairs` (B slot, A slot) launches follow as replays of captured
-// strings of 256 / 64 / 16 / 4 / 1 pairs -- the same five graphs serve every chunk, whatever its length; begin_target == 0 tops up
+// strings of 256 / 128 / ... / 2 / 1 pairs -- the same nine graphs serve every chunk, whatever its length; begin_target == 0 tops up
 // a chunk that has not finished.
 void Engine::run_slots(int begin_target, int pairs, int cap) {
   stats_.kernel_launches += 2.0 * pairs + (begin_target > 0 ? 1 : 0);
@@ -580,7 +580,7 @@ void Engine::run_slots(int begin_target, int pairs, int cap) {
   if (!(use_graph_ && be::graphs_supported())) { for (int k = 0; k < pairs; k++) be::slot_pair(d_); return; }
   for (int left = pairs; left > 0;) {
     int unit = 1;
-    for (int u : {256, 64, 16, 4}) if (left >= u) { unit = u; break; }
+    for (int u : {256, 128, 64, 32, 16, 8, 4, 2}) if (left >= u) { unit = u; break; }
     const std::array<int, 3> key = {unit, 0, 0};
     auto it = sgraphs_.find(key);
     if (it == sgraphs_.end()) {
