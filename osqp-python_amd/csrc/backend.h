@@ -135,6 +135,7 @@ struct BatchParams {
   double *x, *y;                // in: UNSCALED warm start (if warm), out: UNSCALED solution  [nbatch][n] / [nbatch][m]
   double *rec;                  // [nbatch][kBatchRec]: status, iter, obj, prim_res, dual_res, rho, rho_updates, pcg_iters, status_polish, polish seconds,
                                 // rho_estimate (_osqp.py:1275, at the ADMM point), reserved
+  int *iters_out = nullptr;     // optional [nbatch]: ADMM iterations of every problem (device; feeds the next call's launch order)
   const int *order = nullptr;   // optional [nbatch]: workgroup w solves problem order[w] (longest-expected first: the batch ends with its slowest
                                 // problems otherwise; Engine::batch_solve keeps the order of the previous call's iteration counts)
   double *zs = nullptr;         // optional, SCALED z iterates [nbatch][m]: read as the start when warm (a continued solve keeps its z, _osqp.py:1197-1204),
@@ -163,6 +164,7 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream = nullptr);
 size_t batch_direct_lds_bytes(int n, int m, int nnz, int bw); // 0 if the banded factor does not fit next to the iterates
 bool batch_direct_selected(const BatchParams &p);              // would batch_solve run a direct (banded LDL') variant for p?
 void batch_products(Dev &d, int nprod, const int *a, const int *b, double *out);   // out[p] = A.val[a[p]] * A.val[b[p]]
+void batch_order(Dev &d, int nbatch, const int *iters, int *order, void *stream);  // order = problems by descending iters (ties by index), on `stream`
 
 const char *name();
 int init(Dev &d, int device);            // select device, create stream; returns 0 or osqp_error_type

@@ -664,6 +664,7 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
     rc[0] = status; rc[1] = iter; rc[2] = obj; rc[3] = prim_res; rc[4] = dual_res; rc[5] = rho_bar; rc[6] = rho_updates; rc[7] = (double)pcg_total;
     rc[8] = status_polish; rc[9] = 1e-8 * (double)pol_ticks;      // (100 MHz wall clock -> seconds)
     rc[10] = rho_est; rc[11] = 0.0;
+    if (P.iters_out) P.iters_out[b] = iter;
 #ifdef OSQP_HIP_KTRACE
     rc[5] = (double)tk_fact; rc[6] = (double)tk_solve; rc[7] = (double)(wall_clock64() - tk_all);
     rc[3] = (double)tk_rhs; rc[4] = (double)tk_upd; rc[8] = (double)tk_fwd; rc[9] = (double)tk_res;
@@ -688,6 +689,19 @@ size_t batch_direct_lds_bytes(int n, int m, int nnz, int bw) {
 }
 __global__ void k_batch_products(DevCsr A, int nprod, const int *a, const int *b, double *out) {
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < nprod; p += gridDim.x * blockDim.x) out[p] = A.val[a[p]] * A.val[b[p]];
+}
+// rank of problem b among all by descending iteration count (ties by index) = its place in the launch order
+__global__ void k_batch_order(int nbatch, const int *iters, int *order) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbatch) return;
+  const int mine = iters[b];
+  int rank = 0;
+  for (int j = 0; j < nbatch; j++) { const int v = iters[j]; rank += (v > mine) || (v == mine && j < b); }
+  order[rank] = b;
+}
+void batch_order(Dev &d, int nbatch, const int *iters, int *order, void *stream) {
+  if (hipSetDevice(d.device) != hipSuccess) throw DeviceError("osqp_hip: hipSetDevice failed");
+  if (nbatch > 0) hipLaunchKernelGGL(k_batch_order, dim3((nbatch + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream ? stream : d.stream), nbatch, iters, order);
 }
 void batch_products(Dev &d, int nprod, const int *a, const int *b, double *out) {
   if (hipSetDevice(d.device) != hipSuccess) throw DeviceError("osqp_hip: hipSetDevice failed");

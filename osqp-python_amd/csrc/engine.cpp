@@ -86,6 +86,7 @@ void Engine::free_all() {
   drop_graphs();
   if (bbuf_) { be::dfree(d_, bbuf_); bbuf_ = nullptr; bbuf_cap_ = 0; }
   if (d_batch_order_) { be::dfree(d_, d_batch_order_); d_batch_order_ = nullptr; batch_order_cap_ = 0; }
+  if (d_batch_iters_) { be::dfree(d_, d_batch_iters_); d_batch_iters_ = nullptr; d_batch_iters_n_ = 0; }
   batch_order_.clear();
   if (ckpt_) { be::dfree(d_, ckpt_); ckpt_ = nullptr; }
   free_batch_direct();
@@ -1524,10 +1525,15 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   // 4096 MPC QPs 13.3 -> 11 ms).  Scheduling only: every problem is solved by its own workgroup exactly as before.
   static const bool reorder = [] { const char *e = std::getenv("OSQP_HIP_BATCH_REORDER"); return !(e && e[0] == '0'); }();
   if (reorder && nbatch > 1 && (int)batch_order_.size() == nbatch) {
-    if ((size_t)nbatch > batch_order_cap_) { if (d_batch_order_) be::dfree(d_, d_batch_order_); d_batch_order_ = dev_vec<int>(d_, nbatch); batch_order_cap_ = nbatch; }
+    if ((size_t)nbatch > batch_order_cap_) {
+      if (d_batch_order_) be::dfree(d_, d_batch_order_);
+      if (d_batch_iters_) { be::dfree(d_, d_batch_iters_); d_batch_iters_ = nullptr; d_batch_iters_n_ = 0; }
+      d_batch_order_ = dev_vec<int>(d_, nbatch); batch_order_cap_ = nbatch;
+    }
     be::h2d(d_, d_batch_order_, batch_order_.data(), sizeof(int) * nbatch);
     p.order = d_batch_order_;
   }
+  d_batch_iters_n_ = 0;                            // (the device-pointer path's history does not describe this call)
   prepare_batch_direct();
   if (bd_.ok) {
     be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);             // A's values may have changed since the last call
@@ -1563,6 +1569,22 @@ int Engine::batch_solve_device(int nbatch, const double *q, const double *l, con
   BatchParams p{};
   fill_batch_params(p, nbatch, warm);
   p.q = q; p.l = l; p.u = u; p.q0 = dq0; p.l0 = dl0; p.u0 = du0; p.x = x; p.y = y; p.rec = rec;
+  // launch order as in batch_solve, entirely on the device: the kernel leaves every problem's iteration count, a rank kernel turns
+  // the previous call's counts into this call's order (both on the caller's stream: ordered with the batch kernels themselves)
+  static const bool reorder = [] { const char *e = std::getenv("OSQP_HIP_BATCH_REORDER"); return !(e && e[0] == '0'); }();
+  if (reorder && nbatch > 1) {
+    if ((size_t)nbatch > batch_order_cap_) {           // (both buffers have the same capacity)
+      if (d_batch_order_) be::dfree(d_, d_batch_order_);
+      if (d_batch_iters_) be::dfree(d_, d_batch_iters_);
+      d_batch_order_ = dev_vec<int>(d_, nbatch); d_batch_iters_ = nullptr; batch_order_cap_ = nbatch; d_batch_iters_n_ = 0;
+    }
+    if (!d_batch_iters_) { d_batch_iters_ = dev_vec<int>(d_, batch_order_cap_); d_batch_iters_n_ = 0; }
+    be::sync(d_);                                    // (allocations / zero fills ran on the solver's stream)
+    if (d_batch_iters_n_ == nbatch) { be::batch_order(d_, nbatch, d_batch_iters_, d_batch_order_, stream); p.order = d_batch_order_; }
+    p.iters_out = d_batch_iters_;
+    d_batch_iters_n_ = nbatch;
+    batch_order_.clear();                            // (the host path's order does not describe this call)
+  }
   prepare_batch_direct();
   if (bd_.ok) {
     be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);

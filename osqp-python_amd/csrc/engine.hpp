@@ -87,6 +87,7 @@ class Engine {
   bool use_graph_ = true;
   std::map<std::pair<int, int>, void *> graphs_;
   double *bbuf_ = nullptr; size_t bbuf_cap_ = 0;      // device scratch of batch_solve, kept across calls
+  int *d_batch_iters_ = nullptr; int d_batch_iters_n_ = 0;      // device-pointer path: iteration counts of the previous call (its records never reach the host)
   std::vector<int> batch_order_; int *d_batch_order_ = nullptr; size_t batch_order_cap_ = 0;   // problems by descending iteration count of the previous batch call
   double *ckpt_ = nullptr;                            // device copy of (x, x~, z, y) taken before a solve's first chunk (cg cap escalation)
   std::vector<double> ls_rho_;                        // LinSysSolver slot: host copy of rho_vec

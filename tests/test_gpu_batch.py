@@ -209,3 +209,27 @@ def test_launch_order_of_a_repeated_batch_does_not_change_results(monkeypatch):
     assert len(set(r1[:, 1])) > 3                                 # the iteration counts do differ between problems
     assert np.array_equal(x1, x2) and np.array_equal(y1, y2) and np.array_equal(r1[:, :9], r2[:, :9])
     monkeypatch.setenv('OSQP_HIP_BATCH_REORDER', '0')
+
+
+def test_device_pointer_batches_reorder_on_the_device_and_keep_their_results():
+    """osqp_hip_batch_solve_device: the launch order of a repeated batch comes from a rank kernel over the previous call's iteration
+    counts (nothing of it reaches the host); results are bitwise those of the first (index-order) call."""
+    import torch
+    B = 64
+    P, q, A, L, U = problems.mpc_batch(B, seed=31)
+    s = osqp_amd.OSQP(); s.setup(P, q, A, L[0], U[0], eps_abs=1e-6, eps_rel=1e-6, verbose=False)
+    dev = torch.device('cuda:0')
+    Ld, Ud = torch.tensor(L, device=dev), torch.tensor(U, device=dev)
+    outs = []
+    for _ in range(3):
+        x = torch.empty((B, P.shape[0]), dtype=torch.float64, device=dev); y = torch.empty((B, A.shape[0]), dtype=torch.float64, device=dev)
+        rec = torch.empty((B, s._solver.BATCH_REC), dtype=torch.float64, device=dev)
+        s._solver.hip_batch_solve_device(B, None, Ld.data_ptr(), Ud.data_ptr(), x.data_ptr(), y.data_ptr(), rec.data_ptr(), warm=False,
+                                         stream=torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize()
+        outs.append((x.cpu().numpy(), y.cpu().numpy(), rec.cpu().numpy()))
+    assert (outs[0][2][:, 0] == 1).all()
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2][:, :9], outs[0][2][:, :9])
+    xh, yh, rh = s._solver.hip_batch_solve(l=L, u=U)                 # host path afterwards: same results again
+    assert np.array_equal(xh, outs[0][0]) and np.array_equal(rh[:, :9], outs[0][2][:, :9])
