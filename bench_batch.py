@@ -100,7 +100,7 @@ def main():
         waves_of_qps = -(-int(B // world) // resident)
         t_iter = kernel_s / (waves_of_qps * iters_per_qp)              # wall time of one ADMM iteration of a resident QP
         floor_iter = 2 * n_var * kChainCycles / 2.4e9
-        out['roofline'] = {'bound': 'latency', 'kernel': 'k_batch_admm<256,6,6,true>', 'unit': 'ADMM iter/s per resident QP',
+        out['roofline'] = {'bound': 'latency', 'kernel': 'k_batch_admm<256,6,6,true,false,true>', 'unit': 'ADMM iter/s per resident QP',
                            'achieved': 1.0 / t_iter, 'peak': 1.0 / floor_iter, 'frac': floor_iter / t_iter, 'traffic': None,
                            'model': 'dependent chain of the banded substitutions: 2n = %d pivots x %.1f cycles (broadcast + FMA, measured) at 2.4 GHz = %.2f us per ADMM iteration; '
                                     'measured %.2f us (%.1f ADMM iterations per QP, %d QPs resident at a time, kernel %.2f ms)'

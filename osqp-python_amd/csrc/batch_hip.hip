@@ -150,7 +150,7 @@ __device__ __forceinline__ void dd_acc(double a, double v, double &hi, double &l
 // except the (prefetchable) column of L.
 // POLISH (direct variants): a separate instantiation that ends with the polish step, so that the plain kernel's register allocation
 // is not touched by code most launches never run.
-template <int kBB, int EA, int EB, bool DIRECT, bool POLISH = false>
+template <int kBB, int EA, int EB, bool DIRECT, bool POLISH = false, bool N128 = false>
 __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) void k_batch_admm(BatchParams P) {
 #ifdef OSQP_HIP_KTRACE
   // diagnostic build: 100 MHz clock ticks spent in the phases; reported in rec[5..7] INSTEAD of rho / rho_updates / pcg_iters
@@ -324,6 +324,84 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
     const double *__restrict__ Lr = Lb;
     double *__restrict__ buf = wbuf;
     constexpr int NB = kBatchNB;
+    // N128 (n <= 128, chosen by the host for the 256-thread kernels): a lane's (at most) two elements e = tid, tid + 64 stay in
+    // registers from the right-hand side to the solution -- no store / refill of finished elements (an LDS round trip behind the
+    // block's eight factor reads on the in-order LDS counter), no barrier between the passes, the D^-1 scaling in registers.
+    // Same operations in the same order as the general form below: bit-identical results.  Two things the compiler has to be
+    // told: not to unroll the block loop (it then keeps every block's LDS addresses and masks live: 80 spilled VGPRs), and not to
+    // sink the next block's factor reads below the chain they are meant to overlap (without an LDS write in the loop nothing
+    // stops it): 286 k QP/s without the pin, 327 k with it, 310 k for the general form.
+    if constexpr (N128) {
+#define KSOLVE_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+      BT2_BEGIN();
+      if (tid < 64) {
+        const int e0 = tid, e1 = tid + 64;
+        double cur = e0 < n ? rhs[perm_l[e0]] : 0.0, nxt = e1 < n ? rhs[perm_l[e1]] : 0.0;
+        const double di0 = e0 < n ? dinv[e0] : 0.0, di1 = e1 < n ? dinv[e1] : 0.0;
+        double v0 = 0.0, v1 = 0.0;
+        const int nblk = n8 / NB;
+        {
+          auto fetch = [&](int p0, double (&l)[NB]) {
+            const int dl = (tid - p0) & 63;
+            const bool act = dl < bw + NB && p0 < n8;
+            const double *col = act ? Lr + p0 * W + dl : Lr - 1;
+            const int stride = act ? W - 1 : 0;
+#pragma unroll
+            for (int q = 0; q < NB; q++) l[q] = col[q * stride];
+          };
+          auto block = [&](int p0, const double (&l)[NB]) {
+#pragma unroll
+            for (int q = 0; q < NB; q++) { const double vq = readlane_f64(cur, (p0 + q) & 63); cur -= l[q] * vq; }
+            const bool piv = ((tid - p0) & 63) < NB, lo = p0 < 64;   // pivoted in this block: final (blocks never straddle element 64)
+            v0 = (piv && lo) ? cur : v0; v1 = (piv && !lo) ? cur : v1;
+            cur = piv ? nxt : cur;
+          };
+          double la[NB], lb[NB];
+          fetch(0, la);
+#pragma clang loop unroll(disable)
+          for (int b = 0; b < nblk; b += 2) {
+            fetch((b + 1) * NB, lb); KSOLVE_PIN();
+            block(b * NB, la);
+            if (b + 1 < nblk) { fetch((b + 2) * NB, la); KSOLVE_PIN(); block((b + 1) * NB, lb); }
+          }
+        }
+        BT2_END(tk_fwd);
+        v0 *= di0; v1 *= di1;                                     // g = D^-1 v
+        {
+          const bool two = e1 <= n8 - 1;                          // this lane holds an element of the upper half
+          cur = two ? v1 : v0; nxt = two ? v0 : 0.0;
+          double x0 = 0.0, x1 = 0.0;
+          auto fetch = [&](int top, double (&l)[NB]) {
+            const int dl = (top - tid) & 63, i = top - dl;
+            const bool act = dl < bw + NB && i >= 0 && top >= 0;
+            const double *row = act ? Lr + i * W + dl : Lr - 1;
+            const int stride = act ? 1 : 0;
+#pragma unroll
+            for (int q = 0; q < NB; q++) l[q] = row[-q * stride];
+          };
+          auto block = [&](int top, const double (&l)[NB]) {
+#pragma unroll
+            for (int q = 0; q < NB; q++) { const double xq = readlane_f64(cur, (top - q) & 63); cur -= l[q] * xq; }
+            const bool piv = ((top - tid) & 63) < NB, hi = top >= 64;
+            x1 = (piv && hi) ? cur : x1; x0 = (piv && !hi) ? cur : x0;
+            cur = piv ? nxt : cur;
+          };
+          double la[NB], lb[NB];
+          fetch(n8 - 1, la);
+#pragma clang loop unroll(disable)
+          for (int b = nblk - 1; b >= 0; b -= 2) {
+            fetch(b * NB - 1, lb); KSOLVE_PIN();
+            block(b * NB + NB - 1, la);
+            if (b >= 1) { fetch(b * NB - NB - 1, la); KSOLVE_PIN(); block(b * NB - 1, lb); }
+          }
+          if (e0 < n) out[perm_l[e0]] = x0;
+          if (e1 < n) out[perm_l[e1]] = x1;
+        }
+      }
+      __syncthreads();
+      return;
+#undef KSOLVE_PIN
+    }
     for (int k = tid; k < n; k += kBB) buf[k] = rhs[perm_l[k]];
     __syncthreads();
     const int nblk = n8 / NB;
@@ -739,11 +817,13 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
   const size_t lds_reg = ch.lds_reg, lds_gen = ch.lds_gen, lds_dir = ch.lds_dir;
   const bool use_dir256 = ch.dir256, use_dir = ch.dir64, use64 = ch.w64, use256 = ch.w256;
 #define BATCH_LAUNCH(TB, E, LDS) hipLaunchKernelGGL((k_batch_admm<TB, E, E, false>), dim3(p.nbatch), dim3(TB), LDS, st, p)
-#define BATCH_LAUNCH_DIRECT_P(TB, E, POL) do { \
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<TB, E, E, true, POL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dir) != hipSuccess) \
+#define BATCH_LAUNCH_DIRECT_P(TB, E, POL, SMALL) do { \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<TB, E, E, true, POL, SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dir) != hipSuccess) \
       throw DeviceError("osqp_hip: cannot reserve LDS for the direct batch kernel"); \
-    hipLaunchKernelGGL((k_batch_admm<TB, E, E, true, POL>), dim3(p.nbatch), dim3(TB), lds_dir, st, p); } while (0)
-#define BATCH_LAUNCH_DIRECT(TB, E) do { if (p.polish) BATCH_LAUNCH_DIRECT_P(TB, E, true); else BATCH_LAUNCH_DIRECT_P(TB, E, false); } while (0)
+    hipLaunchKernelGGL((k_batch_admm<TB, E, E, true, POL, SMALL>), dim3(p.nbatch), dim3(TB), lds_dir, st, p); } while (0)
+#define BATCH_LAUNCH_DIRECT_N(TB, E, SMALL) do { if (p.polish) BATCH_LAUNCH_DIRECT_P(TB, E, true, SMALL); else BATCH_LAUNCH_DIRECT_P(TB, E, false, SMALL); } while (0)
+  // (256-thread kernels: n <= 128 takes the instantiation whose substitutions keep every element in registers, ksolve)
+#define BATCH_LAUNCH_DIRECT(TB, E) do { if (TB == 256 && p.n <= 128) BATCH_LAUNCH_DIRECT_N(TB, E, (TB == 256)); else BATCH_LAUNCH_DIRECT_N(TB, E, false); } while (0)
   if (use_dir256) {
     if (e256 <= 2) BATCH_LAUNCH_DIRECT(256, 2); else if (e256 <= 4) BATCH_LAUNCH_DIRECT(256, 4); else if (e256 <= 6) BATCH_LAUNCH_DIRECT(256, 6); else if (e256 <= 8) BATCH_LAUNCH_DIRECT(256, 8); else BATCH_LAUNCH_DIRECT(256, 16);
   } else if (use_dir) {
@@ -760,6 +840,7 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
 #undef BATCH_LAUNCH
 #undef BATCH_LAUNCH_DIRECT
 #undef BATCH_LAUNCH_DIRECT_P
+#undef BATCH_LAUNCH_DIRECT_N
   hipError_t e = stream ? hipGetLastError() : hipStreamSynchronize(st);
   if (e != hipSuccess) throw DeviceError(std::string("osqp_hip: batch kernel failed: ") + hipGetErrorString(e));
   return OSQP_NO_ERROR;
