@@ -206,6 +206,8 @@ void slot_begin(Dev &d, int target, int cap);
 void slot_pair(Dev &d);
 int slot_done(Dev &d);
 int slot_seq(Dev &d);                      // slots executed since slot_begin (consistency check of the record hand-over)
+constexpr int kSlotInts = 24;  // Dev::slot: two phase records of 8 words + the chunk epoch
+void slot_poll(Dev &d, int *seq, int *done); // the same two numbers of the RUNNING chunk, read on a side stream without waiting for the launches
 
 // ---- every check_termination iterations ----
 // residual norms / objective pieces of (x,z,y) -> d.res[0 .. R_QDX]   (_osqp.py:705-794, 880-908)

@@ -66,6 +66,9 @@ struct Impl {
   bool ext_pending = false;
   double *pin_res = nullptr;
   int *pin_flags = nullptr;      // [F_COUNT + 16]: the flags block followed by the two slot records
+  hipStream_t side = nullptr;    // slot_poll(): reads the slot records while the chunk's launches are still running on d.stream
+  int *pin_poll = nullptr;       // [kSlotInts]
+  int epoch = 0;                 // chunks begun (slot_begin); the device copy sits behind the two records
 };
 inline Impl &im(Dev &d) { return *static_cast<Impl *>(d.impl); }
 inline hipStream_t st(Dev &d) { return static_cast<hipStream_t>(d.stream); }
@@ -922,8 +925,10 @@ __device__ __forceinline__ SlotState slot_read(const int *r) { return SlotState{
 __device__ __forceinline__ void slot_write(int *w, const SlotState &s) {
   if (blockIdx.x == 0 && threadIdx.x == 0) { w[SR_PHASE] = s.ph; w[SR_K] = s.k; w[SR_ADMM] = s.admm; w[SR_TARGET] = s.target; w[SR_USED] = s.used; w[SR_CONV] = s.conv; w[SR_CAP] = s.cap; w[SR_SEQ] = s.seq + 1; }
 }
-__global__ void k_slot_init(int *slot, int target, int cap) {      // (cap: PCG iterations per solve; in the record, not a kernel argument, so that captured strings of slots serve every chunk)
+__global__ void k_slot_init(int *slot, int target, int cap, int epoch) {      // (cap: PCG iterations per solve; in the record, not a kernel argument, so that captured strings of slots serve every chunk)
   slot[SR_PHASE] = P_KB; slot[SR_K] = 0; slot[SR_ADMM] = 0; slot[SR_TARGET] = target; slot[SR_USED] = 0; slot[SR_CONV] = 0; slot[SR_CAP] = cap; slot[SR_SEQ] = 0;
+  slot[SR_WORDS + SR_SEQ] = 0; slot[SR_WORDS + SR_ADMM] = 0;        // (record B still holds the previous chunk's last state: slot_poll takes the newer record)
+  slot[2 * SR_WORDS] = epoch;                                        // which chunk the records belong to (slot_poll)
 }
 
 __global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
@@ -1346,6 +1351,8 @@ int init(Dev &d, int device) {
   HIP_CHECK(hipEventCreate(&p->ev0)); HIP_CHECK(hipEventCreate(&p->ev1)); HIP_CHECK(hipEventCreateWithFlags(&p->ev_ext, hipEventDisableTiming));
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_res), sizeof(double) * R_COUNT, hipHostMallocDefault));
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_flags), sizeof(int) * (F_COUNT + 16), hipHostMallocDefault));
+  HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_poll), sizeof(int) * kSlotInts, hipHostMallocDefault));
+  HIP_CHECK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
   d.impl = p;
   return OSQP_NO_ERROR;
 }
@@ -1354,6 +1361,7 @@ void destroy(Dev &d) {
   (void)hipSetDevice(d.device);
   Impl &p = im(d);
   (void)hipEventDestroy(p.ev0); (void)hipEventDestroy(p.ev1); (void)hipEventDestroy(p.ev_ext); (void)hipHostFree(p.pin_res); (void)hipHostFree(p.pin_flags);
+  (void)hipHostFree(p.pin_poll); if (p.side) (void)hipStreamDestroy(p.side);
   delete &p; d.impl = nullptr;
   if (d.stream) { (void)hipStreamDestroy(st(d)); d.stream = nullptr; }
 }
@@ -1400,12 +1408,27 @@ void k2(Dev &d, int i) { if (d.fused) LAUNCH(k_k2f, d, d, i); else LAUNCH(k_k2, 
 void kv(Dev &d, int i) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, i, 0); else LAUNCH(k_kv<1>, d, d, i, 0); }
 void ka(Dev &d, int budget) { LAUNCH(k_ka, d, d, budget); }
 bool slots_supported(const Dev &d) { return d.fused != 0 && d.slot != nullptr; }
-void slot_begin(Dev &d, int target, int cap) { HIP_CHECK(hipSetDevice(d.device)); hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(1), 0, st(d), d.slot, target, cap); }
+void slot_begin(Dev &d, int target, int cap) { HIP_CHECK(hipSetDevice(d.device)); hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(1), 0, st(d), d.slot, target, cap, ++im(d).epoch); }
 void slot_pair(Dev &d) { LAUNCH(k_slot_b, d, d); LAUNCH(k_slot_a, d, d); }
 int slot_seq(Dev &d) { return (im(d).pin_flags + F_COUNT)[SR_SEQ]; }      // slots executed since slot_begin, as of the last fetch (record A)
 int slot_done(Dev &d) {        // ADMM iterations completed by the chunk, as of the last fetch_flags / fetch_res_flags (record A: written by the last A slot)
   const int *rec = im(d).pin_flags + F_COUNT;
   return rec[SR_ADMM];
+}
+
+// Progress of the running chunk, read on a side stream WITHOUT waiting for d.stream: slots executed and ADMM iterations completed
+// according to the newer of the two records (a record is eight words written by one thread -- a read may mix two states of it, but
+// both counters only grow, so neither is ever ahead of the truth).  Scheduling information only: Engine::exec_chunk tops the chunk's
+// string of slot launches up before it runs dry; what the slots compute does not depend on how many of them are enqueued.
+void slot_poll(Dev &d, int *seq, int *done) {
+  HIP_CHECK(hipSetDevice(d.device));
+  Impl &p = im(d);
+  HIP_CHECK(hipMemcpyAsync(p.pin_poll, d.slot, sizeof(int) * kSlotInts, hipMemcpyDeviceToHost, p.side));
+  HIP_CHECK(hipStreamSynchronize(p.side));
+  if (p.pin_poll[2 * SR_WORDS] != p.epoch) { *seq = 0; *done = 0; return; }      // the chunk's first launch (k_slot_init) has not run yet
+  const int *ra = p.pin_poll, *rb = p.pin_poll + SR_WORDS;
+  const int *nw = ra[SR_SEQ] >= rb[SR_SEQ] ? ra : rb;
+  *seq = nw[SR_SEQ]; *done = nw[SR_ADMM];
 }
 
 void residuals(Dev &d) {

@@ -459,7 +459,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   { const char *f = std::getenv("OSQP_HIP_EXTRAP"); d_.theta = f ? std::atof(f) : 0.9; }     // PCG start extrapolation (backend.h Dev::xg)
   d_.r = dv(n); d_.uu = dv(n); d_.p = dv(n); d_.s = dv(n); d_.w = dv(n); d_.t = dv(m); d_.Minv = dv(n); d_.uu2 = dv(n); d_.ms = dv(2 * (size_t)n);
   { const char *f = std::getenv("OSQP_HIP_PCG_FUSED"); d_.fused = (f && f[0] == '0') ? 0 : 1; }   // default on; =0 selects the 3-kernel sequence
-  d_.part = dv((size_t)kPartSlots * kGrid); d_.res = dv(R_COUNT); d_.scal = dv(S_HIST + 3 * (kMaxCg + 1)); d_.flags = dev_vec<int>(d_, F_COUNT); d_.slot = dev_vec<int>(d_, 16);
+  d_.part = dv((size_t)kPartSlots * kGrid); d_.res = dv(R_COUNT); d_.scal = dv(S_HIST + 3 * (kMaxCg + 1)); d_.flags = dev_vec<int>(d_, F_COUNT); d_.slot = dev_vec<int>(d_, be::kSlotInts);
   if (dev_asm) {
     // the caller's values go up once, in their own (CSC) order; every later (re)assembly and the equilibration run on the device
     std::vector<int> Pj(nzP), Aj(nzA);
@@ -784,6 +784,43 @@ void Engine::admm_core(double t0, double *res) {
     // (per-solve iteration limit = the budget rule of the launch-per-iteration form: the two forms then execute the SAME arithmetic
     // -- truncating the rare long solve at mean + 3 sigma of the previous chunk costs no ADMM iterations and a third of the PCG work)
     const int lim = budget[tight];
+    // The string of slot launches is cut SHORT of the prediction and topped up while it runs: the host watches the chunk's progress on a
+    // side stream (be::slot_poll: slots executed, ADMM iterations completed) and, whenever fewer than kLow pairs are left in the queue,
+    // enqueues what the iterations still to come need at the rate observed so far.  A chunk then ends with a handful of idle slots
+    // instead of the prediction's error (r02g: 9 % of all launches idle, one costs 4.5 us inside a graph; and an under-predicted chunk
+    // no longer costs a residual evaluation on unfinished iterates + a synchronisation).  What the slots compute does not depend on
+    // how many are enqueued or when: iterates and iteration counts are those of the budgeted form.  OSQP_HIP_SLOT_POLL=0: the r02g rule.
+    static const bool poll_on = [] { const char *e = std::getenv("OSQP_HIP_SLOT_POLL"); return !(e && e[0] == '0'); }();
+    if (poll_on) {
+      static const int kLow = [] { const char *e = std::getenv("OSQP_HIP_POLL_LOW"); return e ? std::atoi(e) : 6; }();
+      static const double kFirst = [] { const char *e = std::getenv("OSQP_HIP_POLL_FIRST"); return e ? std::atof(e) : 0.8; }();
+      static const double kFrac = [] { const char *e = std::getenv("OSQP_HIP_POLL_FRAC"); return e ? std::atof(e) : 0.75; }();
+      static const double kWait = [] { const char *e = std::getenv("OSQP_HIP_POLL_WAIT"); return e ? std::atof(e) : 0.7; }();
+      const double p0 = std::min<double>(pred[kind], lim);
+      { const int np = 2 * cnt + std::max(2, (int)std::floor(kFirst * p0 * cnt)); run_slots(cnt, np, lim); launched_pairs += np; }
+      double pair_s = 9e-6, t_prev = now_s();                        // duration of a slot pair, re-estimated from the progress between two polls
+      int seq_prev = 0;
+      for (int seq = 0, done = 0;;) {
+        be::slot_poll(d_, &seq, &done);
+        if (done >= cnt) break;
+        { const double t_now = now_s();
+          if (seq - seq_prev >= 8) { pair_s = std::max(5e-6, 2.0 * (t_now - t_prev) / (seq - seq_prev)); t_prev = t_now; seq_prev = seq; } }
+        const int ahead = launched_pairs - seq / 2;                  // pairs enqueued and not yet executed
+        if (ahead > kLow) {
+          // (every poll is a small copy that has to squeeze in between the chunk's kernels: poll when the queue can have run
+          // low at the earliest, not continuously)
+          const double until = now_s() + kWait * (ahead - kLow) * pair_s;
+          while (now_s() < until) {}
+          continue;
+        }
+        const int rem = cnt - done;
+        const double rate = done > 0 ? std::min<double>(2.0 + lim, (0.5 * seq) / done) : 2.0 + p0;      // pairs per ADMM iteration so far
+        const int need = (int)std::ceil(rem * rate) + 1 - ahead;
+        const int np = std::max(2, need > 12 ? (int)std::ceil(kFrac * need) : need);
+        run_slots(0, np, lim); launched_pairs += np;
+        stats_.slot_topups += 1;
+      }
+    } else
     { const int np = 2 * cnt + (int)std::ceil(1.05 * std::min<double>(pred[kind], lim) * cnt) + 2; run_slots(cnt, np, lim); launched_pairs += np; }
     for (;;) {
       if (with_res) { be::residuals(d_); be::fetch_res_flags(d_, res, f); } else be::fetch_flags(d_, f);

@@ -45,6 +45,7 @@ void slot_begin(Dev &, int, int) {}
 void slot_pair(Dev &) {}
 int slot_done(Dev &) { return 0; }
 int slot_seq(Dev &) { return 0; }
+void slot_poll(Dev &, int *seq, int *done) { *seq = 0; *done = 0; }
 void ext_record(Dev &, void *) {}
 void ext_wait(Dev &) {}
 
