@@ -3,7 +3,10 @@ against the oracle (oracle/osqp_oracle.c, the CPU restatement of the reference a
 committed golden fixtures, and size-independent optimality properties (KKT certificate) at sizes the oracle cannot
 reach quickly.  Tolerance: north_star asks for agreement with the direct CPU path within eps_abs = eps_rel = 1e-6; both
 solvers stop at residuals <= eps, so solutions are compared at 1e-5 * (1 + ||.||_inf) unless stated otherwise."""
+import json
 import os
+import subprocess
+import sys
 import warnings
 
 import numpy as np
@@ -15,6 +18,8 @@ import osqp_amd
 import problems
 from oracle import Oracle, SOLVED
 from util import Fixture
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 warnings.simplefilter('ignore')
@@ -122,6 +127,32 @@ def test_graph_and_eager_launch_paths_agree_bitwise():
     assert out[0][3] > 0 and out[1][3] == 0
     assert out[0][2] == out[1][2]
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_polled_top_ups_do_not_change_the_iterates():
+    """The string of slot launches of a chunk is topped up from polled progress (Engine::exec_chunk, be::slot_poll) -- scheduling
+    only: iterates and iteration count are bitwise those of the one-shot rule (OSQP_HIP_SLOT_POLL=0), with fewer launches."""
+    src = """
+import os, sys, json, warnings
+sys.path[:0] = [%r, %r]
+warnings.simplefilter('ignore')
+import numpy as np, osqp_amd, problems
+P, q, A, l, u = problems.banded_qp(20000)
+m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, eps_abs=1e-6, eps_rel=1e-6)
+r = m.solve(); st = m._solver.hip_stats()
+print(json.dumps(dict(it=int(r.info.iter), status=int(r.info.status_val), x=r.x.tobytes().hex()[:4096], y=r.y.tobytes().hex()[:4096],
+                      sx=float(np.abs(r.x).sum()), sy=float(np.abs(r.y).sum()), launches=float(st['kernel_launches']))))
+""" % (os.path.join(ROOT, 'osqp-python_amd'), ROOT)
+    out = []
+    for v in ('1', '0'):                                   # (the knob is read once per process)
+        env = dict(os.environ, OSQP_HIP_SLOT_POLL=v)
+        o = subprocess.run([sys.executable, '-c', src], env=env, capture_output=True, text=True, timeout=600)
+        assert o.returncode == 0, o.stderr[-2000:]
+        out.append(json.loads(o.stdout.strip().splitlines()[-1]))
+    a, b = out
+    assert a['status'] == b['status'] == 1 and a['it'] == b['it']
+    assert a['x'] == b['x'] and a['y'] == b['y'] and a['sx'] == b['sx'] and a['sy'] == b['sy']
+    assert a['launches'] < b['launches']
 
 
 def test_deterministic_repeat_and_resolve():
