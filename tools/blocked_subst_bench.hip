@@ -63,8 +63,13 @@ __device__ void solve_chain(const Prob P, const double *Lr, const double *dinv, 
       const bool act = dl < bw + NB && p0 < n8;
       const double *col = act ? Lr + p0 * W + dl : Lr - 1;
       const int stride = act ? W - 1 : 0;
+#ifdef CHAIN_INCR
+#pragma unroll
+      for (int q = 0; q < NB; q++) { l[q] = *col; col += stride; }
+#else
 #pragma unroll
       for (int q = 0; q < NB; q++) l[q] = col[q * stride];
+#endif
     };
     auto block = [&](int p0, const double (&l)[NB]) {
 #pragma unroll
