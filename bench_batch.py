@@ -75,13 +75,42 @@ def main():
     barrier(); el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device='cuda')
     if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el_host = float(el.item())
+    kernel_ms = s._solver.hip_stats()['gpu_solve_ms']               # the batch kernel's launch, HIP events on its stream (last host-array step)
+    # ---- the same batch with every array RESIDENT in HBM (osqp_hip_batch_solve_device: bounds in, x / y / records out by device
+    #      pointer, the zero-copy path of osqp_amd.nn.torch): this is `value`.  A step = this rank's share in one launch, the
+    #      records (12 doubles per QP) to the host, one all_gather of the packed status table; x and y stay on the device. ----
+    lo, hi = sharded.shard_range(B, rank, world)
+    nb = hi - lo
+    Ld, Ud = torch.tensor(L[lo:hi], device=dev), torch.tensor(U[lo:hi], device=dev)
+    xd = torch.empty((nb, P.shape[0]), dtype=torch.float64, device=dev); yd = torch.empty((nb, A.shape[0]), dtype=torch.float64, device=dev)
+    recd = torch.empty((nb, s._solver.BATCH_REC), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def device_step():
+        s._solver.hip_batch_solve_device(nb, None, Ld.data_ptr(), Ud.data_ptr(), xd.data_ptr(), yd.data_ptr(), recd.data_ptr(), warm=False, stream=stream)
+        rec = recd.cpu().numpy()                                     # (synchronises with the solve)
+        recs = np.zeros((nb, len(sharded.RECORD_FIELDS))); recs[:, 0] = np.arange(lo, hi); recs[:, 1:6] = rec[:, 0:5]
+        return sharded.gather_records(recs, B, device=dev if use_dist else None)
+    for _ in range(max(args.warmup, 1)):
+        table_d = device_step()
+    barrier(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        table_d = device_step()
+    barrier(); el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device='cuda')
+    if use_dist:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
     el = float(el.item())
+    assert np.array_equal(table_d[:, 1:3], table[:, 1:3]), 'device-pointer and host-array paths disagree on status / iterations'
+    assert np.array_equal(xd.cpu().numpy(), x) and np.array_equal(yd.cpu().numpy(), y), 'device-pointer and host-array paths disagree on x / y'
     if rank == 0:
         out = {'metric': 'QPs/sec, batch of %d MPC QPs (n=120, m=240), eps 1e-6' % B, 'value': B * args.steps / el, 'unit': 'QP/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * el / args.steps, 'higher_is_better': True, 'scaling': 'strong',
                'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-               'config': {'workload': 'BASELINE configs[4]: %d MPC QPs, horizon 10, nx=8, nu=4 (problems.mpc_batch); host scaling + H2D/D2H included' % B,
-                          'ms_per_step_median': float(sorted(step_ms)[len(step_ms) // 2]), 'kernel_ms_last_step': s._solver.hip_stats()['gpu_solve_ms'],
+               'config': {'workload': 'BASELINE configs[4]: %d MPC QPs, horizon 10, nx=8, nu=4 (problems.mpc_batch); bounds resident in HBM, x / y left in HBM, status table gathered to the host' % B,
+                          'host_array_path': {'QP_per_s': B * args.steps / el_host, 'ms_per_step': 1e3 * el_host / args.steps,
+                                              'note': 'osqp_hip_batch_solve with numpy arrays: H2D of the bounds and D2H of x, y, records (28 MB over PCIe per step) included'},
+                          'ms_per_step_median': float(sorted(step_ms)[len(step_ms) // 2]), 'kernel_ms_last_step': kernel_ms,
                           'solved': int((table[:, 1] == 1).sum()), 'admm_iters_total': float(table[:, 2].sum()),
                           'admm_iters_per_s': float(table[:, 2].sum()) * args.steps / el}}
         # Roofline of the batch kernel (k_batch_admm<256, 6, 6, true>: six stored entries of A and of B per lane, one workgroup per QP, everything in LDS / registers): neither HBM
@@ -94,7 +123,7 @@ def main():
         n_var = P.shape[0]
         kChainCycles = 43.5           # MEASURED cost of one pivot: two v_readlane_b32 (~14 cycles each, on or off a chain) + the dependent v_fma_f64
                                       # (tools/lane_bcast_bench.hip, profiles/r02e_lane_bcast.txt)
-        kernel_s = 1e-3 * s._solver.hip_stats()['gpu_solve_ms']
+        kernel_s = 1e-3 * kernel_ms
         iters_per_qp = float(table[:, 2].sum()) / B
         resident = 2 * 256            # two problems per CU (69 KB of LDS each), 256 CUs
         waves_of_qps = -(-int(B // world) // resident)
