@@ -40,6 +40,26 @@ def test_one_launch_and_same_iterations_as_oracle(gen):
     assert abs(r.info.obj_val - io.obj_val) <= 1e-9 * (1 + abs(io.obj_val))
 
 
+@pytest.mark.parametrize('n', [57, 64, 65, 72, 100, 117, 128, 129, 136])
+def test_sizes_around_the_register_resident_substitutions(n):
+    """n <= 128 takes the kernel instantiation whose substitutions keep a lane's two elements (lane, lane + 64) in registers
+    (batch_hip.hip ksolve, N128), larger n the windowed general form: sizes on both sides of 64 and of 128, multiples of 8 and
+    not -- iteration for iteration against the oracle, and the polish on the same factorisation code."""
+    P, q, A, l, u = problems.banded_qp(n, window=14, seed=n)
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, polishing=True, **ST)
+    r = m.solve()
+    assert launches(m) == 1 and r.info.status_val == 1
+    o = Oracle().setup(P, q, A, l, u, **ST)
+    xo, yo, io = o.solve()
+    assert io.status_val == SOLVED and r.info.iter == io.iter and r.info.rho_updates == io.rho_updates
+    xp, yp, ip, sp_ = o.polish()
+    assert r.info.status_polish == sp_
+    xr, yr = (xp, yp) if sp_ == 1 else (xo, yo)
+    tol = 1e-9 if sp_ == 1 else 1e-7
+    npt.assert_allclose(r.x, xr, rtol=0, atol=tol * (1 + np.abs(xr).max()))
+    npt.assert_allclose(r.y, yr, rtol=0, atol=tol * (1 + np.abs(yr).max()))
+
+
 def test_opt_out_and_excluded_settings(monkeypatch):
     P, q, A, l, u = mpc1()
     m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, polishing=True, **ST)
