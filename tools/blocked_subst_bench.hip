@@ -10,6 +10,7 @@
 #include <cmath>
 #include <vector>
 #include <random>
+#include <type_traits>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
@@ -114,6 +115,81 @@ __device__ void solve_chain(const Prob P, const double *Lr, const double *dinv, 
       fetch(b * NB - 1, lb); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
       block(b * NB + NB - 1, la);
       if (b >= 1) { fetch(b * NB - NB - 1, la); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); block(b * NB - 1, lb); }
+    }
+    if (e0 < n) out[e0] = x0;
+    if (e1 < n) out[e1] = x1;
+  }
+}
+
+// ---- (a') the same chain with COMPILE-TIME lane indices: the block loop unrolled over one rotation of the 64 lanes (8 blocks), so that
+//      v_readlane takes an immediate lane (no s_add / s_nop per pivot) ----
+__device__ void solve_chain_imm(const Prob P, const double *Lr, const double *dinv, const double *rhs, double *out) {
+  const int tid = threadIdx.x, n = P.n, bw = P.bw, W = P.W, n8 = P.n8;
+  const int e0 = tid, e1 = tid + 64;
+  double cur = e0 < n ? rhs[e0] : 0.0, nxt = e1 < n ? rhs[e1] : 0.0;
+  const double di0 = e0 < n ? dinv[e0] : 0.0, di1 = e1 < n ? dinv[e1] : 0.0;
+  double v0 = 0.0, v1 = 0.0;
+  const int nblk = n8 / NB;
+  {
+    auto fetch = [&](int p0, double (&l)[NB]) {
+      const int dl = (tid - p0) & 63;
+      const bool act = dl < bw + NB && p0 < n8;
+      const double *col = act ? Lr + p0 * W + dl : Lr - 1;
+      const int stride = act ? W - 1 : 0;
+#pragma unroll
+      for (int q = 0; q < NB; q++) l[q] = col[q * stride];
+    };
+    auto block = [&](auto BB, int p0, const double (&l)[NB]) {
+      constexpr int L0 = decltype(BB)::value * NB;
+#pragma unroll
+      for (int q = 0; q < NB; q++) { const double vq = readlane_f64(cur, L0 + q); cur -= l[q] * vq; }
+      const bool piv = ((tid - p0) & 63) < NB, lo = p0 < 64;
+      v0 = (piv && lo) ? cur : v0; v1 = (piv && !lo) ? cur : v1;
+      cur = piv ? nxt : cur;
+    };
+    double la[NB], lb[NB];
+    fetch(0, la);
+#pragma clang loop unroll(disable)
+    for (int g = 0; g < nblk; g += 8) {
+#define STEP(BBV, A, B) if (g + BBV < nblk) { fetch((g + BBV + 1) * NB, B); PIN(); block(std::integral_constant<int, BBV>{}, (g + BBV) * NB, A); }
+      STEP(0, la, lb) STEP(1, lb, la) STEP(2, la, lb) STEP(3, lb, la) STEP(4, la, lb) STEP(5, lb, la) STEP(6, la, lb) STEP(7, lb, la)
+#undef STEP
+    }
+  }
+  v0 *= di0; v1 *= di1;
+  {
+    const bool two = e1 <= n8 - 1;
+    cur = two ? v1 : v0; nxt = two ? v0 : 0.0;
+    double x0 = 0.0, x1 = 0.0;
+    auto fetch = [&](int top, double (&l)[NB]) {
+      const int dl = (top - tid) & 63, i = top - dl;
+      const bool act = dl < bw + NB && i >= 0 && top >= 0;
+      const double *row = act ? Lr + i * W + dl : Lr - 1;
+      const int stride = act ? 1 : 0;
+#pragma unroll
+      for (int q = 0; q < NB; q++) l[q] = row[-q * stride];
+    };
+    // blocks from the top: block index b (elements 8b .. 8b+7), lane of pivot (top - q) & 63 with top = 8b + 7: compile-time for b mod 8
+    auto block = [&](auto BB, int top, const double (&l)[NB]) {
+      constexpr int T0 = decltype(BB)::value * NB + NB - 1;
+#pragma unroll
+      for (int q = 0; q < NB; q++) { const double xq = readlane_f64(cur, T0 - q); cur -= l[q] * xq; }
+      const bool piv = ((top - tid) & 63) < NB, hi = top >= 64;
+      x1 = (piv && hi) ? cur : x1; x0 = (piv && !hi) ? cur : x0;
+      cur = piv ? nxt : cur;
+    };
+    double la[NB], lb[NB];
+    // walk b = nblk-1 .. 0; within a group of 8 (b & 7 = 7 .. 0) the lanes are compile-time; the first group may be partial
+    int b = nblk - 1;
+    fetch(b * NB + NB - 1, la);
+    bool useA = true;
+#pragma clang loop unroll(disable)
+    for (int gtop = (b | 7); gtop >= 7; gtop -= 8) {
+#define STEP(BBV) if (gtop - (7 - BBV) <= b && gtop - (7 - BBV) >= 0) { const int bb_ = gtop - (7 - BBV); \
+        if (useA) { fetch(bb_ * NB - 1, lb); PIN(); block(std::integral_constant<int, BBV>{}, bb_ * NB + NB - 1, la); } \
+        else { fetch(bb_ * NB - 1, la); PIN(); block(std::integral_constant<int, BBV>{}, bb_ * NB + NB - 1, lb); } useA = !useA; }
+      STEP(7) STEP(6) STEP(5) STEP(4) STEP(3) STEP(2) STEP(1) STEP(0)
+#undef STEP
     }
     if (e0 < n) out[e0] = x0;
     if (e1 < n) out[e1] = x1;
@@ -269,7 +345,7 @@ __global__ void k_solve(int mode, Prob P, const double *Lg, const double *Lqg, c
   }
   const long long t0 = __builtin_readcyclecounter();
   for (int rep = 0; rep < kReps; rep++) {
-    if (mode == 0) solve_chain(P, La, dinv, rhs, out); else if (mode == 1 || mode == 6) solve_blocked<0>(P, Lqa, dinv, rhs, out, vbuf); else if (mode == 2) solve_blocked<1>(P, Lqa, dinv, rhs, out, vbuf);
+    if (mode == 0) solve_chain(P, La, dinv, rhs, out); else if (mode == 7) solve_chain_imm(P, La, dinv, rhs, out); else if (mode == 1 || mode == 6) solve_blocked<0>(P, Lqa, dinv, rhs, out, vbuf); else if (mode == 2) solve_blocked<1>(P, Lqa, dinv, rhs, out, vbuf);
     else if (mode == 3) solve_blocked<2>(P, Lqa, dinv, rhs, out, vbuf); else if (mode == 4) solve_blocked<4>(P, Lqa, dinv, rhs, out, vbuf); else solve_blocked<7>(P, Lqa, dinv, rhs, out, vbuf);
     __syncthreads();
   }
@@ -320,8 +396,8 @@ int main() {
   for (int t = 0; t < 5; t++) { std::printf("%-34s", nm[t]); for (int l = 0; l < 64; l += (t < 3 ? 1 : 1)) if (l < 36 || t >= 3) std::printf(" %d", chk[t * 64 + l]); std::printf("\n"); }
   const size_t lds = (size_t)(2 * tot + 4 * n16) * 8;
   CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const char *mn[7] = {"readlane chain", "blocked by 16, DPP", "  - without the row sums (wrong)", "  - without stage 2 (wrong)", "  - without the coefficient loads (wrong)", "  - without all three (wrong)", "blocked, inverse blocks computed on the device"};
-  for (int mode = 0; mode < 7; mode++) {
+  const char *mn[8] = {"readlane chain", "blocked by 16, DPP", "  - without the row sums (wrong)", "  - without stage 2 (wrong)", "  - without the coefficient loads (wrong)", "  - without all three (wrong)", "blocked, inverse blocks computed on the device", "readlane chain, immediate lane indices"};
+  for (int mode = 0; mode < 8; mode++) {
     for (int rep = 0; rep < 2; rep++) { hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), lds, 0, mode, P, dL, dLq, dd, dr, dout, dc, 0); CK(hipDeviceSynchronize()); }
     std::vector<double> x(n); long long c[2];
     CK(hipMemcpy(x.data(), dout, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(c, dc, 16, hipMemcpyDeviceToHost));
