@@ -164,9 +164,21 @@ def main():
         nnzA, nnzB, mm = int(stats['nnzA']), int(stats['nnzB']), len(l)
         s = m._solver
         fused = bool(stats.get('pcg_fused', 0))
+        f1 = int(stats.get('pcg_fused', 0)) == 2          # one launch per PCG iteration
+        f1_D = int(stats.get('f1_replicas', 0))
         sA, sB = spmv_bytes(nnzA, mm, n), spmv_bytes(nnzB, n, n + mm)
+        # B_pcg = B_P + B_A + B_At + 104 n  (the reference algorithm's PCG iteration: three SpMVs + 13 n-vector passes)
+        nnzP_full = nnzB - nnzA
+        survey_pcg_bytes = spmv_bytes(nnzP_full, n, n) + spmv_bytes(nnzA, mm, n) + spmv_bytes(nnzA, n, mm) + 104 * n
         # algorithmic bytes per launch (DESIGN.md "Kernels"): SpMV formula + the fused epilogue / extra vectors
-        if fused:     # two kernels per PCG iteration
+        if f1:
+            # what the F1 kernel itself has to move: A once (8-byte values + one packed 32-bit index word per entry, row pointers, rho,
+            # 16-bit column pointers of the windows ~ 2 bytes per column and replica), P + sigma I once (CSR), and per column: Minv, r, pu,
+            # s, D replicas read; p, x~ read; s, r, p, x~, pu and D replicas written
+            f1_bytes = 12 * nnzA + 4 * (mm + 1) + 8 * mm + 2 * f1_D * n + 12 * nnzP_full + 4 * (n + 1) + 8 * n * (4 + f1_D + 2 + 5 + f1_D)
+            pcg_kernels = {'F1 one PCG iteration per launch (k_slot1 phase F)': (14, f1_bytes)}
+            seq_id, dom, dom_kernel = 15, 'F1 one PCG iteration per launch (k_slot1 phase F)', 'k_slot1'
+        elif fused:     # two kernels per PCG iteration
             pcg_kernels = {
                 # SpMV(A) applied to Minv.*s (the gathered vector, counted in sA) with the epilogue t = t - alpha rho S (+ rho, t read:
                 # 16m; t written = sA's output), + the vector update: u p r s Minv x~ read, p x~ r u' written (10 x 8n)
@@ -194,7 +206,10 @@ def main():
         # in-sequence times: T(one PCG iteration as a solve runs it) minus T(the sequence without the kernel); this is what
         # a solve pays (the kernels evict each other's matrix from L2)
         pcg_ms = s.hip_time_kernel(seq_id, args.probe_reps)
-        if fused:     # the "sequence without the kernel" is the other kernel alone (L2-hot, so this is an upper bound)
+        if f1:        # probe 15 = two consecutive iterations (the double-buffered vectors alternate as in a solve)
+            pcg_ms *= 0.5
+            probes[dom]['ms'] = pcg_ms
+        elif fused:   # the "sequence without the kernel" is the other kernel alone (L2-hot, so this is an upper bound)
             names = list(pcg_kernels)
             for name, other_name in zip(names, names[::-1]):
                 probes[name]['ms'] = max(pcg_ms - probes[other_name]['ms_same_kernel_repeat'], 1e-6)
@@ -207,6 +222,13 @@ def main():
             probes[name]['GBps'] = probes[name]['bytes'] / (probes[name]['ms'] * 1e-3) / 1e9
         kb = {name: probes[name]['bytes'] for name in probes}
         pcg_bytes = sum(kb[k] for k in pcg_kernels)
+        if f1:
+            # one launch = one PCG iteration of the reference algorithm: the contract's algorithmic bytes per launch are SURVEY §8(d)'s
+            # B_pcg; the kernel's own (smaller) traffic model is reported next to it as streamed_bytes / frac_streamed
+            probes[dom]['streamed_bytes'] = kb[dom]; probes[dom]['GBps_streamed'] = probes[dom]['GBps']
+            kb[dom] = survey_pcg_bytes; probes[dom]['bytes'] = survey_pcg_bytes
+            probes[dom]['GBps'] = survey_pcg_bytes / (probes[dom]['ms'] * 1e-3) / 1e9
+            streamed = pcg_bytes; pcg_bytes = survey_pcg_bytes
         tts_ms = 1e3 * tmax / args.steps
         out = {
             'metric': 'ADMM iterations/sec, n=%d m=%d nnz(A)=%d sparse QP (indirect PCG)' % (n, mm, A.nnz),
@@ -220,15 +242,21 @@ def main():
                        'pcg_iters_per_admm_iter': stats['pcg_iters_total'] / max(res.info.iter, 1), 'pcg_budget_limited_iters': int(stats['pcg_unconverged']),
                        'cg_cap_escalations': int(stats.get('cg_cap_escalations', 0)), 'slot_topups': int(stats.get('slot_topups', 0)),
                        'windowed_row_blocks': '%d of %d' % (int(stats.get('windowed_blocks', 0)), int(stats.get('row_blocks', 0))),
-                       'pcg_kernels_per_iteration': 2 if fused else 3, 'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
+                       'pcg_kernels_per_iteration': 1 if f1 else (2 if fused else 3), 'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
                        'setup_s': t_setup, 'per_rank': [{'status': int(r[0]), 'iter': int(r[1]), 'obj': r[2]} for r in allrec]},
-            'roofline': {'bound': 'hbm', 'kernel': dom + (' -- in solves this body runs as the K2F phase of k_slot_b' if fused else ''), 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'roofline': {'bound': 'hbm', 'kernel': dom + (' -- in solves this body runs as the K2F phase of k_slot_b' if (fused and not f1) else ''), 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': probes[dom]['GBps'] / HBM_PEAK_GBS, 'traffic': pmc_traffic(dom_kernel),
                          'bytes_per_launch': kb[dom], 'ms_per_launch': probes[dom]['ms'],
                          'pcg_iteration': {'bytes': pcg_bytes, 'ms': pcg_ms, 'GBps': pcg_bytes / (pcg_ms * 1e-3) / 1e9,
-                                           'frac': pcg_bytes / (pcg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                           'frac': pcg_bytes / (pcg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           'bytes_survey_8d': survey_pcg_bytes,
+                                           'frac_survey_8d': survey_pcg_bytes / (pcg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          'kernels': probes},
         }
+        if f1:
+            out['roofline']['streamed_bytes'] = streamed
+            out['roofline']['frac_streamed'] = streamed / (pcg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out['roofline']['replicas'] = f1_D
         if args.cpu_seconds > 0 and world == 1:          # (the CPU baseline is timed at N = 1 only: the other ranks would wait 40 s at the barrier)
             cb = cpu_baseline(P, q, A, l, u, settings, args.cpu_seconds)
             out['cpu_baseline'] = cb

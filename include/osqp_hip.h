@@ -179,13 +179,14 @@ typedef struct {
   double graph_launches;      /* hipGraphLaunch calls                                     */
   double gpu_solve_ms;        /* hipEvent time around the ADMM loop                       */
   double nnzA, nnzB;          /* stored entries of A (CSR) and B = [P+sigma I | A'] (CSR) */
-  double pcg_fused;           /* 1: two-kernel PCG iteration (k_k2f, k_k1f); 0: three (k_k1, k_k2, k_kv) */
+  double pcg_fused;           /* 2: ONE launch per PCG iteration (k_slot1, the F1 form); 1: two kernels (k_k2f, k_k1f); 0: three (k_k1, k_k2, k_kv) */
   double batch_direct_bw;     /* half bandwidth of the reduced KKT matrix under the engine's RCM ordering (batch / small-QP direct
                                  solve); -1 before the first batch or small solve, -2 if the pattern is too dense to analyse */
   double cg_cap_escalations;  /* times the last solve doubled its PCG iteration cap because most solves of a chunk stagnated at it */
   double windowed_blocks;     /* row blocks of A and B whose input-vector window is staged in LDS (16-bit local column indices) */
   double row_blocks;          /* row blocks of A and B in total */
   double slot_topups;         /* last solve: chunks whose string of slot launches ended before the chunk did (more launches followed) */
+  double f1_replicas;         /* F1 form: replica vectors of the partial A' t (0: the form does not apply to this problem) */
 } OSQPHipStats;
 OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
 

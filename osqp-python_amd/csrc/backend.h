@@ -37,6 +37,12 @@ constexpr int kMaxRowsPerBlock = 1024;
 constexpr int kPartSlots = 40;     // rows of Dev::part (each kGrid doubles)
 constexpr int kMaxCg = 1024;       // hard cap on the PCG budget (size of the alpha/gamma history)
 constexpr int kWinCap = 1472;      // input-vector window of a row block staged in LDS (elements; 23 KB as 16-byte pairs: 4 workgroups per CU)
+// One-launch PCG iteration ("F1" form, DevF1 below)
+constexpr int kF1Win = 512;        // widest window of a row block of A the F1 form takes (two elements per lane)
+constexpr int kF1MaxD = 4;         // most replicas of the partial A' t vector
+constexpr int kF1PChunk = 512;     // most (P + sigma I) entries of a block's own rows
+constexpr int kF1MaxOwn = 512;     // most own columns of a block
+constexpr int kF1MaxRows = 512;    // most rows of a block
 
 struct DevCsr {
   int nrows = 0, ncols = 0, nnz = 0, nblk = 0;
@@ -56,6 +62,31 @@ struct DevCsr {
   int split = 0;
   int nwin = 0;                  // number of windowed blocks (statistics)
   int single = 0;                // 1: at most kGrid row blocks, each with at most kBlock rows (a workgroup's first pass covers all its rows)
+};
+
+// One launch per PCG iteration ("F1" form).  K = P + sigma I + A' diag(rho) A is applied from A ALONE: the
+// workgroup that owns row block g of A forms  t = rho .* (A u)  for its rows and, in the same launch, the products  A_g' t_g  of those
+// rows summed per column of the block's window (a second, column-ordered pass over the block's entries held in registers: the
+// entries' 16-bit local row and their position in column order are stored next to the local column).  That partial slice goes to
+// one of D "replica" n-vectors (block g -> replica g mod D; the windows of blocks g and g + D never overlap, and a block also zero-
+// fills the gap up to the next window of its replica, so every replica is rewritten completely by every launch); whoever needs
+// (A' t)_j next -- every workgroup whose window holds column j -- sums the D replicas in index order (deterministic, no atomics).
+// The (P + sigma I) part is applied by the block to its OWN columns [cs0, cs1) from a compact CSR of P + sigma I.  One launch then
+// performs a whole Chronopoulos-Gear iteration: scalars from the previous launch's partials, vector update on the window (each
+// workgroup recomputes u_{k+1} on the columns it gathers -- nothing is exchanged inside a launch), SpMV, partials for the next.
+struct DevF1 {
+  int on = 0;                    // plan valid (Engine::prepare_f1); 0: the two-kernel form
+  int D = 0;                     // replicas
+  int *desc = nullptr;           // nblk(A) x {cov0, cov1, cs0, cs1}: replica coverage [cov0, cov1) (zero outside the window), own columns [cs0, cs1)
+  int *desc2 = nullptr;          // nblk(A) x {offset of the block's column pointers in cptr, first and end entry of its own rows in the P arrays, 0}
+  unsigned int *ent = nullptr;   // nnz(A): local column (9 bits) | local row << 9 (9 bits) | position of the entry in the block's column-major order << 18 (11 bits)
+  unsigned short *cptr = nullptr;// per block: window length + 1 column pointers (block-local, column-major entry positions)
+  int *prp = nullptr, *pcol = nullptr, *psrc = nullptr;   // compact CSR of P + sigma I (n rows): row pointers, columns, position of each entry in B.val
+  double *pval = nullptr;        // values, refreshed from B.val by be::f1_refresh (after assembly / equilibration / matrix updates)
+  int pnnz = 0;
+  double *rep = nullptr;         // [2][D][n] partial A' t, by parity of the PCG iteration
+  double *pu = nullptr;          // [2][n]  (P + sigma I) u_k on the own columns
+  double *r2 = nullptr, *s2 = nullptr;   // second buffers of r and s (r_k lives in k & 1 ? r2 : Dev::r, s_k likewise)
 };
 
 // indices into Dev::res (results of the residual kernels, reduced on the device)
@@ -109,6 +140,7 @@ struct Dev {
   double *r = nullptr, *uu = nullptr, *p = nullptr, *s = nullptr, *w = nullptr, *t = nullptr, *Minv = nullptr;
   double *uu2 = nullptr, *ms = nullptr;  // fused PCG: u_k lives in (k&1 ? uu2 : uu); ms (2n) = interleaved pairs {u_k[j], (Minv .* s_k)[j]}
   int fused = 0;                 // 1: two kernels per PCG iteration (vector update k-1 fused into the SpMV-A kernel of iteration k)
+  DevF1 f1;                      // one launch per PCG iteration (slot form only; f1.on)
   // reductions
   double *part = nullptr;        // [kPartSlots][kGrid] partial results, slots see backend implementation
   double *res = nullptr;         // [R_COUNT]
@@ -206,6 +238,11 @@ void slot_begin(Dev &d, int target, int cap);
 void slot_pair(Dev &d);
 int slot_done(Dev &d);
 int slot_seq(Dev &d);                      // slots executed since slot_begin (consistency check of the record hand-over)
+// launches one ADMM iteration with `pcg` PCG iterations needs in the slot form (a slot_pair() is two of them):
+//   two-kernel form  2 (pcg + 2)   KB, K1, pcg x (K2F, K1F), the K2F that detects convergence, KA
+//   F1 form          pcg + 3       KB, F_0, F_1 .. F_pcg, KA (run by the launch whose scalar fold detects convergence)
+inline double slot_launches(const Dev &d, double pcg) { return d.f1.on ? pcg + 3.0 : 2.0 * (pcg + 2.0); }
+void f1_refresh(Dev &d);                   // f1.pval <- B.val (no-op without a plan)
 constexpr int kSlotInts = 24;  // Dev::slot: two phase records of 8 words + the chunk epoch
 void slot_poll(Dev &d, int *seq, int *done); // the same two numbers of the RUNNING chunk, read on a side stream without waiting for the launches
 

@@ -58,7 +58,7 @@ __device__ unsigned long long g_ktrace[kGrid * kTraceSlots];
 #define OSQP_HIP_KNOCK 0
 #endif
 #define KNOCKED(bit) ((OSQP_HIP_KNOCK & (bit)) != 0)
-enum Slot { SL_GAMMA0 = 0, SL_GAMMA1, SL_RN0, SL_RN1, SL_BN, SL_DELTA, SL_RES0 /* .. SL_RES0 + R_COUNT - 1 */ };
+enum Slot { SL_GAMMA0 = 0, SL_GAMMA1, SL_RN0, SL_RN1, SL_BN, SL_DELTA, SL_DELTA1 /* F1 form: delta by parity (SL_DELTA + (k & 1)) */, SL_RES0 /* .. SL_RES0 + R_COUNT - 1 */ };
 static_assert(SL_RES0 + R_COUNT <= kPartSlots, "Dev::part is too small");
 
 struct Impl {
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
 // its workgroup 0 writes the successor's -- two records, so that no workgroup of a launch can observe its own launch's update.
 // The PCG of ADMM iteration j therefore takes exactly as many slot pairs as it has iterations (plus the pair that detects
 // convergence and runs KA), whatever the neighbouring iterations needed; only the few slots left over at the END of a chunk idle.
-enum SlotPhase { P_KB = 0, P_K1, P_K2F, P_K1F, P_KA, P_IDLE };
+enum SlotPhase { P_KB = 0, P_K1, P_K2F, P_K1F, P_KA, P_IDLE, P_F /* a PCG iteration of the F1 form (k_slot1) */ };
 enum SlotRec { SR_PHASE = 0, SR_K, SR_ADMM, SR_TARGET, SR_USED, SR_CONV, SR_CAP, SR_SEQ /* slots executed since k_slot_init: every slot adds one */, SR_WORDS = 8 };
 
 struct SlotState { int ph, k, admm, target, used, conv, cap, seq; };
@@ -1030,6 +1030,278 @@ __global__ __launch_bounds__(kBlock) void k_slot_a(Dev d) {
     else { st.ph = P_K2F; st.k = i; }
   } else if (st.ph == P_KA) {
     slot_ka(d, lds.k1, st.used, st.conv, fd, st.admm);
+    st.ph = P_KB; st.admm += 1;
+  }
+  slot_write(W, st);
+}
+
+
+// ---------------------------------------------------------------------------------------------- one launch per PCG iteration (F1)
+// backend.h DevF1.  Launch F_k of the PCG of one ADMM iteration (k = 0 .. iterations):
+//   scalars   k = 0:  ||r_0||, ||rhs|| (KB's partials) -> tolerance, stopping test
+//             k >= 1: gamma_{k-1}, delta_{k-1}, ||r_{k-1}|| (partials of F_{k-1}) -> stopping test (k >= 2), beta_{k-1}, alpha_{k-1}
+//   window    u_k[c] = Minv (r_{k-1} - alpha (w_{k-1} + beta s_{k-2}))[c],  w_{k-1} = pu_{k-1} + sum_d rep_d   (k = 0: Minv r_0)
+//             for every column c of the block's window -- recomputed by every workgroup that gathers c, with the same instruction
+//             sequence as the owner's update below (f1_upd), so all copies are bit-identical
+//   own cols  s_{k-1}, r_k, p_{k-1}, x~ += alpha p_{k-1}  stored;  partials gamma_k = <r_k, Minv r_k>, ||r_k||_inf
+//   SpMV      t = rho .* (A_g u_k)  (rows of the block, products staged in LDS, one lane per row),
+//             pu_k = (P + sigma I) u_k  on the own columns,  rep_{g mod D} = A_g' t  per window column (second, column-ordered pass
+//             over the entries still held in registers),  partial delta_k = <t, A u_k> + <u_k, pu_k>_own = <u_k, K u_k>
+// r, s, pu, rep are double-buffered by the parity of k: a workgroup reads what the PREVIOUS launch wrote while its neighbours
+// write this launch's values.  Five workgroup barriers per block, no global synchronisation inside the launch.
+struct F1Lds {
+  double win[kF1Win];            // u_k on the block's window
+  double prod[kChunk];           // A products in row-major entry order, then val * t[row] in column-major order
+  double tvec[kF1MaxRows];       // t of the block's rows
+  double uown[kF1MaxOwn];        // u_k on the own columns
+  double pprod[kF1PChunk];       // (P + sigma I) products of the own rows
+  double red[3 * kWaves];
+};
+static_assert(sizeof(F1Lds) <= 40 * 1024, "four workgroups per CU");
+struct F1Scal { double alpha, beta; int mode; };       // mode 0: F_0 (u = Minv r_0); 1: first update (s_0 = w_0, p_0 = u_0); 2: general
+__device__ __forceinline__ double f1_w(double pu, const double (&rp)[kF1MaxD], int D) {     // fixed order: deterministic
+  double w = pu;
+#pragma unroll
+  for (int q = 0; q < kF1MaxD; q++) if (q < D) w += rp[q];
+  return w;
+}
+__device__ __forceinline__ void f1_upd(const F1Scal &sc, double minv, double r, double w, double sp, double &sn, double &rn, double &un) {
+  sn = sc.mode == 2 ? fma(sc.beta, sp, w) : w;
+  rn = fma(-sc.alpha, sn, r);
+  un = minv * rn;
+}
+// sum of seg[a .. z): the first eight entries with independent LDS reads (as process_rows)
+__device__ __forceinline__ double f1_segsum(const double *seg, int a, int z) {
+  constexpr int kB = 8;
+  double v[kB];
+#pragma unroll
+  for (int q = 0; q < kB; q++) v[q] = a + q < z ? seg[a + q] : 0.0;
+  double acc = 0.0;
+#pragma unroll
+  for (int q = 0; q < kB; q++) acc += v[q];
+  for (int k = a + kB; k < z; k++) acc += seg[k];
+  return acc;
+}
+// returns false when the PCG had already converged (nothing done: the caller runs KA in this launch)
+__device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const int cap, const int admm_par, const int probe, F1Lds &L) {
+  const DevF1 &f = d.f1;
+  const int n = d.n, D = f.D, tid = threadIdx.x;
+  double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
+  const int cur = (k + 1) & 1, nxt = k & 1;               // parity of k - 1 / of k
+  F1Scal sc{0.0, 0.0, 0};
+  if (probe) { sc.alpha = 1e-3; sc.beta = 0.5; sc.mode = k == 0 ? 0 : (k == 1 ? 1 : 2); }
+  else if (k == 0) {
+    const PartRegs prn = partial_load(d.part + SL_RN0 * kGrid), pbn = partial_load(d.part + SL_BN * kGrid);
+    double rn = partial_fold_max(prn), bn = partial_fold_max(pbn);
+    block_max2(rn, bn, L.red);
+    const double tol = fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS]);
+    if (blockIdx.x == 0 && tid == 0) { d.scal[S_TOL_NOW] = tol; d.scal[S_RN0] = rn; d.scal[S_RN0H + admm_par] = rn; }
+    if (!(rn > tol)) return false;                          // the start already meets the tolerance (a NaN also ends the inner loop)
+  } else {
+    const PartRegs pg = partial_load(d.part + (SL_GAMMA0 + cur) * kGrid), pd = partial_load(d.part + (SL_DELTA + cur) * kGrid),
+                   prn = partial_load(d.part + (SL_RN0 + cur) * kGrid);
+    const double tol = d.scal[S_TOL_NOW], glast = k >= 2 ? gam[k - 2] : 1.0, alast = k >= 2 ? alp[k - 2] : 1.0;
+    double gamma = partial_fold_sum(pg), rn = partial_fold_max(prn), delta = partial_fold_sum(pd);
+    block_sum_max_sum(gamma, rn, delta, L.red);
+    if (k >= 2 && !(rn > tol)) return false;                // converged after k - 1 iterations (r_0 was tested by F_0)
+    sc.beta = k >= 2 ? gamma / glast : 0.0;
+    sc.alpha = k >= 2 ? gamma / (delta - sc.beta * gamma / alast) : gamma / delta;
+    sc.mode = k >= 2 ? 2 : 1;
+    if (blockIdx.x == 0 && tid == 0) { gam[k - 1] = gamma; alp[k - 1] = sc.alpha; }
+  }
+  const int mode = sc.mode;
+  const bool vec_only = !probe && k >= cap;                 // the last budgeted update: no operator apply follows
+  const double *rread = (k == 0 || cur == 0) ? d.r : f.r2;  // r_{k-1} (k = 0: r_0)
+  double *rnxt = nxt ? f.r2 : d.r;                          // r_k
+  const double *sprev = nxt ? f.s2 : d.s;                   // s_{k-2}: parity of k
+  double *snew = cur ? f.s2 : d.s;                          // s_{k-1}
+  const double *pucur = f.pu + (size_t)cur * n, *repcur = f.rep + (size_t)cur * D * n;
+  double *punxt = f.pu + (size_t)nxt * n, *repnxt = f.rep + (size_t)nxt * D * n;
+  const int4 *desc = reinterpret_cast<const int4 *>(d.A.blkdesc), *wdesc = reinterpret_cast<const int4 *>(d.A.blkwin);
+  const int4 *fdesc = reinterpret_cast<const int4 *>(f.desc), *fdesc2 = reinterpret_cast<const int4 *>(f.desc2);
+  // u_k at column c from global memory (P entries whose column lies outside the block's window)
+  auto u_global = [&](int c) -> double {
+    const double mi = d.Minv[c], r = rread[c];
+    if (mode == 0) return mi * r;
+    double rp[kF1MaxD];
+#pragma unroll
+    for (int q = 0; q < kF1MaxD; q++) if (q < D) rp[q] = repcur[(size_t)q * n + c];
+    const double w = f1_w(pucur[c], rp, D), sp = mode == 2 ? sprev[c] : 0.0;
+    double sn, rn, un;
+    f1_upd(sc, mi, r, w, sp, sn, rn, un);
+    return un;
+  };
+  double g_acc = 0.0, rn_acc = 0.0, dl_acc = 0.0;
+  // the vector update of one own column (everything in registers already): stores s_{k-1}, r_k, p_{k-1}, x~; returns u_k
+  auto own_update = [&](int j, double mi, double r, double w, double sp, double pp, double x) -> double {
+    if (mode == 0) return mi * r;
+    double sn, rn, un;
+    f1_upd(sc, mi, r, w, sp, sn, rn, un);
+    const double uold = mi * r, pn = mode == 2 ? fma(sc.beta, pp, uold) : uold;
+    d.xs[j] = fma(sc.alpha, pn, x); d.p[j] = pn; snew[j] = sn; rnxt[j] = rn;
+    g_acc += rn * un; rn_acc = nanmax(rn_acc, fabs(rn));
+    return un;
+  };
+  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int per = (d.A.nblk + 7) >> 3;
+  constexpr int CW = kF1Win / kBlock, CE = kChunk / kBlock, CP = kF1PChunk / kBlock;
+  for (int sl = slot0; sl < per; sl += slots) {
+    const int b = xcd * per + sl;
+    if (b >= d.A.nblk) break;
+    const int4 ds = desc[b], ws = wdesc[b], fa = fdesc[b], fb = fdesc2[b];
+    const int r0 = ds.x, nrows = ds.y - ds.x, k0 = ds.z, cnt = ds.w - ds.z;
+    const int a0 = ws.x, wl = vec_only ? 0 : ws.y;          // (the last budgeted update applies no operator: no window)
+    const int cov0 = fa.x, cov1 = fa.y, cs0 = fa.z, nown = fa.w - fa.z;
+    const int cpo = fb.x, pk0 = fb.y, pcnt = fb.z - fb.y;
+    const int nw = (wl + kBlock - 1) / kBlock, nu = (cnt + kBlock - 1) / kBlock, np = (pcnt + kBlock - 1) / kBlock;
+    // ---- loads, in the order they are needed: window parts (+ p, x~ where the window column is one of the block's own), matrix
+    //      entries, row / column pointers
+    double wm[CW], wr[CW], wp[CW], wsv[CW], wq[CW][kF1MaxD], wpp[CW], wx[CW];
+    bool wown[CW];
+#pragma unroll
+    for (int u = 0; u < CW; u++) {
+      wown[u] = false;
+      if (u < nw) {
+        const int e = tid + u * kBlock, c = a0 + min(e, wl - 1);
+        wown[u] = e < wl && c >= cs0 && c - cs0 < nown;
+        wm[u] = d.Minv[c]; wr[u] = rread[c];
+        if (mode >= 1) {
+          wp[u] = pucur[c];
+#pragma unroll
+          for (int q = 0; q < kF1MaxD; q++) if (q < D) wq[u][q] = repcur[(size_t)q * n + c];
+          if (mode == 2) wsv[u] = sprev[c];
+          if (wown[u]) { wx[u] = d.xs[c]; if (mode == 2) wpp[u] = d.p[c]; }
+        }
+      }
+    }
+    double vw[CE]; unsigned int en[CE];
+    double pv[CP]; int pc[CP];
+    int rp0 = 0, rp1 = 0; double rrho = 0.0;
+    int cp0[CW], cp1[CW];
+    int pp0 = 0, pp1 = 0;
+    if (!vec_only) {
+#pragma unroll
+      for (int u = 0; u < CE; u++) { if (u < nu) { const int e = k0 + min(tid + u * kBlock, cnt - 1); vw[u] = d.A.val[e]; en[u] = f.ent[e]; } }
+#pragma unroll
+      for (int u = 0; u < CP; u++) { if (u < np) { const int e = pk0 + min(tid + u * kBlock, pcnt - 1); pv[u] = f.pval[e]; pc[u] = f.pcol[e]; } }
+      if (tid < nrows) { rp0 = d.A.rowptr[r0 + tid]; rp1 = d.A.rowptr[r0 + tid + 1]; rrho = d.rho[r0 + tid]; }
+#pragma unroll
+      for (int u = 0; u < CW; u++) { if (u < nw) { const int c = min(tid + u * kBlock, wl - 1); cp0[u] = f.cptr[cpo + c]; cp1[u] = f.cptr[cpo + c + 1]; } }
+      if (tid < nown) { pp0 = f.prp[cs0 + tid]; pp1 = f.prp[cs0 + tid + 1]; }
+    }
+    // ---- u_k on the window -> LDS; the lane of an own column also performs that column's vector update
+#pragma unroll
+    for (int u = 0; u < CW; u++) {
+      if (u < nw) {
+        const int e = min(tid + u * kBlock, wl - 1);
+        const double w = mode >= 1 ? f1_w(wp[u], wq[u], D) : 0.0;
+        double un;
+        if (wown[u]) { un = own_update(a0 + e, wm[u], wr[u], w, wsv[u], wpp[u], wx[u]); L.uown[a0 + e - cs0] = un; }
+        else if (mode == 0) un = wm[u] * wr[u];
+        else { double sn, rn; f1_upd(sc, wm[u], wr[u], w, wsv[u], sn, rn, un); }
+        L.win[e] = un;                                      // (clamped lanes store the same value)
+      }
+    }
+    // ---- own columns outside the window (none on banded problems; all of them in the last budgeted update)
+    for (int jj = tid; jj < nown; jj += kBlock) {
+      const int j = cs0 + jj;
+      if (j >= a0 && j - a0 < wl) continue;
+      const double mi = d.Minv[j], r = rread[j];
+      double w = 0.0, sp = 0.0, pp = 0.0, x = 0.0;
+      if (mode >= 1) {
+        double rp[kF1MaxD];
+#pragma unroll
+        for (int q = 0; q < kF1MaxD; q++) if (q < D) rp[q] = repcur[(size_t)q * n + j];
+        w = f1_w(pucur[j], rp, D); x = d.xs[j];
+        if (mode == 2) { sp = sprev[j]; pp = d.p[j]; }
+      }
+      const double un = own_update(j, mi, r, w, sp, pp, x);
+      if (!vec_only) L.uown[jj] = un;
+    }
+    if (vec_only) continue;
+    __syncthreads();
+    // ---- products: A entries against the window; (P + sigma I) entries against the window or, outside it, recomputed operands
+#pragma unroll
+    for (int u = 0; u < CE; u++) { if (u < nu) L.prod[tid + u * kBlock] = vw[u] * L.win[en[u] & 0x1ffu]; }
+#pragma unroll
+    for (int u = 0; u < CP; u++) {
+      if (u < np) {
+        const int c = pc[u] - a0;
+        const double uv = (c >= 0 && c < wl) ? L.win[c] : u_global(pc[u]);
+        L.pprod[tid + u * kBlock] = pv[u] * uv;
+      }
+    }
+    __syncthreads();
+    // ---- row sums: t = rho .* (A u) -> LDS;  pu = (P + sigma I) u on the own columns -> global
+    for (int row = tid; row < nrows; row += kBlock) {
+      if (row != tid) { rp0 = d.A.rowptr[r0 + row]; rp1 = d.A.rowptr[r0 + row + 1]; rrho = d.rho[r0 + row]; }
+      const double au = f1_segsum(L.prod, rp0 - k0, rp1 - k0), t = rrho * au;
+      L.tvec[row] = t; dl_acc += t * au;
+    }
+    for (int jj = tid; jj < nown; jj += kBlock) {
+      if (jj != tid) { pp0 = f.prp[cs0 + jj]; pp1 = f.prp[cs0 + jj + 1]; }
+      const double pu = f1_segsum(L.pprod, pp0 - pk0, pp1 - pk0);
+      punxt[cs0 + jj] = pu; dl_acc += L.uown[jj] * pu;
+    }
+    __syncthreads();
+    // ---- A_g' t: val * t[row] scattered to column-major order, then one lane per window column
+#pragma unroll
+    for (int u = 0; u < CE; u++) { if (u < nu) L.prod[en[u] >> 18] = vw[u] * L.tvec[(en[u] >> 9) & 0x1ffu]; }     // (clamped lanes repeat the last entry's store)
+    __syncthreads();
+    double *rout = repnxt + (size_t)(b % D) * n;
+#pragma unroll
+    for (int u = 0; u < CW; u++) {
+      if (u < nw) { const int c = tid + u * kBlock; if (c < wl) rout[a0 + c] = f1_segsum(L.prod, cp0[u], cp1[u]); }
+    }
+    for (int j = cov0 + tid; j < a0; j += kBlock) rout[j] = 0.0;             // the replica's gap up to the next window of this replica
+    for (int j = a0 + wl + tid; j < cov1; j += kBlock) rout[j] = 0.0;
+    __syncthreads();
+  }
+  __syncthreads();
+  block_sum_max_sum(g_acc, rn_acc, dl_acc, L.red);
+  if (mode >= 1) { put_partial(d.part, SL_GAMMA0 + nxt, g_acc); put_partial(d.part, SL_RN0 + nxt, rn_acc); }   // (F_0 leaves KB's gamma_0, ||r_0||)
+  if (!vec_only) put_partial(d.part, SL_DELTA + nxt, dl_acc);
+  return true;
+}
+__global__ __launch_bounds__(kBlock) void k_f1_refresh(Dev d) {
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < d.f1.pnnz; k += gridDim.x * kBlock) d.f1.pval[k] = d.B.val[d.f1.psrc[k]];
+}
+// timing probe: one F launch with fixed scalars (no stopping test)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_f1_probe(Dev d, int k) {
+  __shared__ F1Lds lds;
+  f1_iteration(d, k, 1 << 30, 0, 1, lds);
+}
+
+// The slot kernel of the F1 form: every launch of a chunk's string is this kernel (par: which of the two phase records it reads);
+// the phase that is due -- KB (streams B), a PCG iteration F_k (streams A and P), KA (streams A) -- comes from the record.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_slot1(Dev d, int par) {
+  __shared__ union { StreamLds<2> kb; StreamLdsW<1, double> ka; F1Lds f; } lds;
+  const int *R = d.slot + (par ? SR_WORDS : 0);
+  int *W = d.slot + (par ? 0 : SR_WORDS);
+  SlotState st = slot_read(R);
+  if (st.ph == P_KB) {
+    if (st.admm >= st.target) { st.ph = P_IDLE; slot_write(W, st); return; }
+    GKb g{d.xg, d.v, d.t0, d.n};
+    EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma, d.xg, d.xs};
+    process_rows<2>(d.B, g, e, lds.kb);
+    __syncthreads();
+    const double G = block_sum(e.g, lds.kb.red);
+    double RN = e.rn, BN = e.bn;
+    block_max2(RN, BN, lds.kb.red);
+    put_partial(d.part, SL_GAMMA0, G); put_partial(d.part, SL_RN0, RN); put_partial(d.part, SL_BN, BN);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
+    st.ph = P_F; st.k = 0;
+  } else if (st.ph == P_F) {
+    if (f1_iteration(d, st.k, st.cap, st.admm & 1, 0, lds.f)) {
+      if (st.k >= st.cap) { st.ph = P_KA; st.used = st.k; st.conv = 0; }      // stopped at the cap: the next launch runs KA
+      else st.k += 1;
+    } else {                                             // converged: KA right here
+      __syncthreads();
+      slot_ka(d, lds.ka, st.k == 0 ? 0 : st.k - 1, 1, first_desc<true>(d.A), st.admm);
+      st.ph = P_KB; st.admm += 1;
+    }
+  } else if (st.ph == P_KA) {
+    slot_ka(d, lds.ka, st.used, st.conv, first_desc<true>(d.A), st.admm);
     st.ph = P_KB; st.admm += 1;
   }
   slot_write(W, st);
@@ -1409,7 +1681,11 @@ void kv(Dev &d, int i) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, i,
 void ka(Dev &d, int budget) { LAUNCH(k_ka, d, d, budget); }
 bool slots_supported(const Dev &d) { return d.fused != 0 && d.slot != nullptr; }
 void slot_begin(Dev &d, int target, int cap) { HIP_CHECK(hipSetDevice(d.device)); hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(1), 0, st(d), d.slot, target, cap, ++im(d).epoch); }
-void slot_pair(Dev &d) { LAUNCH(k_slot_b, d, d); LAUNCH(k_slot_a, d, d); }
+void slot_pair(Dev &d) {
+  if (d.f1.on) { LAUNCH(k_slot1, d, d, 0); LAUNCH(k_slot1, d, d, 1); }
+  else { LAUNCH(k_slot_b, d, d); LAUNCH(k_slot_a, d, d); }
+}
+void f1_refresh(Dev &d) { if (d.f1.on) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_f1_refresh, d, d); } }
 int slot_seq(Dev &d) { return (im(d).pin_flags + F_COUNT)[SR_SEQ]; }      // slots executed since slot_begin, as of the last fetch (record A)
 int slot_done(Dev &d) {        // ADMM iterations completed by the chunk, as of the last fetch_flags / fetch_res_flags (record A: written by the last A slot)
   const int *rec = im(d).pin_flags + F_COUNT;
@@ -1609,9 +1885,12 @@ float time_kernel(Dev &d, int which, int reps) {
       case 11: LAUNCH(k_k1f, d, d, 1); break;  // fused SpMV-A + vector update alone (alpha fixed by the stored history; drifts linearly, bounded)
       case 12: LAUNCH(k_k2f, d, d, 0); break;  // fused SpMV-B alone
       case 13: LAUNCH(k_k2f, d, d, 2); LAUNCH(k_k1f, d, d, 3); break;   // the same pair with the done flag set: what an early-exit pair costs
+      case 14: LAUNCH(k_f1_probe, d, d, 2); break;                       // F1 form: one PCG iteration = one launch, repeated on the same buffers
+      case 15: LAUNCH(k_f1_probe, d, d, 2); LAUNCH(k_f1_probe, d, d, 3); break;   // ... two consecutive iterations as a solve runs them (buffers alternate)
       default: LAUNCH(k_k2f, d, d, 0); LAUNCH(k_k1f, d, d, 1); break;   // one FUSED PCG iteration (two kernels): repeated exact line-search steps, bounded
     }
   };
+  if (which >= 14 && !d.f1.on) return 0.f;
   if (which >= 10) HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, which == 13 ? 1 : 0, sizeof(int), st(d)));   // (byte pattern 1 -> nonzero flag)
   for (int w = 0; w < 5; w++) launch();
   HIP_CHECK(hipEventRecord(p.ev0, st(d)));

@@ -93,7 +93,8 @@ void Engine::free_all() {
   void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag, d_.A.runinfo, d_.B.runinfo, d_.A.blkwin, d_.B.blkwin, d_.A.lcol, d_.B.lcol, d_.qraw, d_.lraw, d_.uraw, d_.cnt,
                   d_.q, d_.l, d_.u, d_.D, d_.Dinv, d_.E, d_.Einv, d_.rho, d_.rho_inv, d_.ctype, d_.x, d_.z, d_.y, d_.dx,
                   d_.dy, d_.xs, d_.xg, d_.xsp, d_.ztg, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.uu2, d_.ms, d_.part, d_.res,
-                  d_.scal, d_.flags, d_.slot, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB};
+                  d_.scal, d_.flags, d_.slot, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB,
+                  d_.f1.desc, d_.f1.desc2, d_.f1.ent, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.rep, d_.f1.pu, d_.f1.r2, d_.f1.s2};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   be::destroy(d_);
   d_ = Dev();
@@ -282,6 +283,79 @@ void Engine::fill_matrix_values(const std::vector<double> &Px, const std::vector
   be::h2d(d_, d_.B.val, Bval_.data(), sizeof(double) * Bval_.size());
 }
 
+
+// ------------------------------------------------------------------------------------------------ F1 plan
+// One launch per PCG iteration (backend.h DevF1): symbolic data, built once at setup from the row blocks of A.  The form applies when
+// every row block of A is windowed with a window of at most kF1Win columns and at most kF1MaxRows rows, the windows of blocks g and
+// g + D never overlap for some D <= kF1MaxD (banded / block-banded A), and each block's own columns -- [rb[g] n / m, rb[g+1] n / m):
+// for a banded A these lie inside the block's window -- number at most kF1MaxOwn with at most kF1PChunk entries of P + sigma I.
+// Anything else keeps the two-kernel form.  OSQP_HIP_F1=0 switches the plan off.
+void Engine::prepare_f1(const std::vector<int> &rb, const std::vector<int> &Arp, const std::vector<int> &Arj,
+                        const std::vector<int> &Brp, const std::vector<int> &Bj) {
+  d_.f1 = DevF1();
+  if (const char *e = std::getenv("OSQP_HIP_F1")) if (e[0] == '0') return;
+  const int nb = (int)rb.size() - 1;
+  if (!be::device_assembly() || m == 0 || nb < kGrid / 4) return;      // (few blocks: most workgroups would idle in the vector update)
+  std::vector<int> a0(nb), wl(nb);
+  for (int b = 0; b < nb; b++) {
+    const int r0 = rb[b], r1 = rb[b + 1], k0 = Arp[r0], k1 = Arp[r1];
+    if (k1 == k0 || r1 - r0 > kF1MaxRows || k1 - k0 > kChunk || (r1 - r0 == 1 && k1 - k0 > kLongRow)) return;
+    int lo = INT32_MAX, hi = -1;
+    for (int k = k0; k < k1; k++) { lo = std::min(lo, Arj[k]); hi = std::max(hi, Arj[k]); }
+    if (hi - lo + 1 > kF1Win) return;
+    a0[b] = lo; wl[b] = hi - lo + 1;
+  }
+  int D = 0;
+  for (int t = 1; t <= kF1MaxD && !D; t++) {
+    bool ok = true;
+    for (int g = 0; g + t < nb && ok; g++) ok = a0[g] + wl[g] <= a0[g + t];
+    if (ok) D = t;
+  }
+  if (!D) return;
+  // own columns and the compact CSR of P + sigma I (row j of B up to its first A' entry)
+  std::vector<int> cs(nb + 1);
+  for (int g = 0; g <= nb; g++) cs[g] = (int)((long)rb[g] * n / m);
+  cs[nb] = n;
+  std::vector<int> prp(n + 1, 0);
+  for (int j = 0; j < n; j++) { int c = 0; for (int k = Brp[j]; k < Brp[j + 1] && Bj[k] < n; k++) c++; prp[j + 1] = prp[j] + c; }
+  const int pnnz = prp[n];
+  std::vector<int> pcol(std::max(pnnz, 1)), psrc(std::max(pnnz, 1));
+  for (int j = 0; j < n; j++) for (int k = Brp[j], o = prp[j]; k < Brp[j + 1] && Bj[k] < n; k++, o++) { pcol[o] = Bj[k]; psrc[o] = k; }
+  std::vector<int> desc(4 * (size_t)nb), desc2(4 * (size_t)nb);
+  std::vector<unsigned int> ent(Arj.size());
+  std::vector<unsigned short> cptr;
+  std::vector<int> order;
+  for (int b = 0; b < nb; b++) {
+    if (cs[b + 1] - cs[b] > kF1MaxOwn || prp[cs[b + 1]] - prp[cs[b]] > kF1PChunk) return;
+    const int r0 = rb[b], r1 = rb[b + 1], k0 = Arp[r0], k1 = Arp[r1], cnt = k1 - k0;
+    desc[4 * b] = b < D ? 0 : a0[b]; desc[4 * b + 1] = b + D < nb ? a0[b + D] : n; desc[4 * b + 2] = cs[b]; desc[4 * b + 3] = cs[b + 1];
+    desc2[4 * b] = (int)cptr.size(); desc2[4 * b + 1] = prp[cs[b]]; desc2[4 * b + 2] = prp[cs[b + 1]]; desc2[4 * b + 3] = 0;
+    // column-major order of the block's entries: stable by local column (rows ascending within a column)
+    order.resize(cnt);
+    for (int e = 0; e < cnt; e++) order[e] = e;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Arj[k0 + x] < Arj[k0 + y]; });
+    std::vector<int> tpos(cnt);
+    for (int t = 0; t < cnt; t++) tpos[order[t]] = t;
+    for (int r = r0; r < r1; r++)
+      for (int k = Arp[r]; k < Arp[r + 1]; k++)
+        ent[k] = (unsigned)(Arj[k] - a0[b]) | ((unsigned)(r - r0) << 9) | ((unsigned)tpos[k - k0] << 18);
+    const size_t base = cptr.size();
+    cptr.resize(base + wl[b] + 1, 0);
+    for (int e = 0; e < cnt; e++) cptr[base + (Arj[k0 + e] - a0[b]) + 1]++;
+    for (int c = 0; c < wl[b]; c++) cptr[base + c + 1] = (unsigned short)(cptr[base + c + 1] + cptr[base + c]);
+  }
+  auto up_i = [&](const std::vector<int> &h) { int *p = dev_vec<int>(d_, h.size()); if (!h.empty()) be::h2d(d_, p, h.data(), sizeof(int) * h.size()); return p; };
+  DevF1 &f = d_.f1;
+  f.D = D; f.pnnz = pnnz;
+  f.desc = up_i(desc); f.desc2 = up_i(desc2); f.prp = up_i(prp); f.pcol = up_i(pcol); f.psrc = up_i(psrc);
+  f.ent = dev_vec<unsigned int>(d_, ent.size()); be::h2d(d_, f.ent, ent.data(), sizeof(unsigned int) * ent.size());
+  f.cptr = dev_vec<unsigned short>(d_, cptr.size()); be::h2d(d_, f.cptr, cptr.data(), sizeof(unsigned short) * cptr.size());
+  f.pval = dev_vec<double>(d_, pnnz);
+  f.rep = dev_vec<double>(d_, 2 * (size_t)D * n); f.pu = dev_vec<double>(d_, 2 * (size_t)n);
+  f.r2 = dev_vec<double>(d_, n); f.s2 = dev_vec<double>(d_, n);
+  f.on = 1;
+}
+
 // ------------------------------------------------------------------------------------------------ setup
 int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *A, const double *l, const double *u,
                   int m_, int n_, const OSQPSettings *s) {
@@ -451,6 +525,9 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   d_.Bdiag = up_i(bdiag);
   up_win(d_.A, rbA, Arp, Arj, n); up_win(d_.B, rbB, Brp, Bj, n);
   lap("upload structure");
+  { const char *f = std::getenv("OSQP_HIP_PCG_FUSED"); d_.fused = (f && f[0] == '0') ? 0 : 1; }   // default on; =0 selects the 3-kernel sequence
+  if (d_.fused && use_slots_ && d_.A.nwin == d_.A.nblk) prepare_f1(rbA, Arp, Arj, Brp, Bj);
+  lap("F1 plan");
   auto dv = [&](size_t cnt) { return dev_vec<double>(d_, cnt); };
   d_.q = dv(n); d_.l = dv(m); d_.u = dv(m); d_.D = dv(n); d_.Dinv = dv(n); d_.E = dv(m); d_.Einv = dv(m);
   d_.rho = dv(m); d_.rho_inv = dv(m); d_.ctype = dev_vec<int>(d_, m);
@@ -458,7 +535,6 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   d_.xg = dv(n); d_.xsp = dv(n); d_.ztg = dv(m);
   { const char *f = std::getenv("OSQP_HIP_EXTRAP"); d_.theta = f ? std::atof(f) : 0.9; }     // PCG start extrapolation (backend.h Dev::xg)
   d_.r = dv(n); d_.uu = dv(n); d_.p = dv(n); d_.s = dv(n); d_.w = dv(n); d_.t = dv(m); d_.Minv = dv(n); d_.uu2 = dv(n); d_.ms = dv(2 * (size_t)n);
-  { const char *f = std::getenv("OSQP_HIP_PCG_FUSED"); d_.fused = (f && f[0] == '0') ? 0 : 1; }   // default on; =0 selects the 3-kernel sequence
   d_.part = dv((size_t)kPartSlots * kGrid); d_.res = dv(R_COUNT); d_.scal = dv(S_HIST + 3 * (kMaxCg + 1)); d_.flags = dev_vec<int>(d_, F_COUNT); d_.slot = dev_vec<int>(d_, be::kSlotInts);
   if (dev_asm) {
     // the caller's values go up once, in their own (CSC) order; every later (re)assembly and the equilibration run on the device
@@ -473,6 +549,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
     be::assemble(d_, 0, 1.0, 0);                                     // unscaled, sigma added after the equilibration
     c_ = be::ruiz(d_, settings.scaling);                             // _osqp.py:389-497
     cinv_ = 1.0 / c_;
+    be::f1_refresh(d_);
     D_.resize(n); E_.resize(m); Dinv_.resize(n); Einv_.resize(m);
     be::d2h(d_, D_.data(), d_.D, sizeof(double) * n); be::d2h(d_, Dinv_.data(), d_.Dinv, sizeof(double) * n);
     if (m > 0) { be::d2h(d_, E_.data(), d_.E, sizeof(double) * m); be::d2h(d_, Einv_.data(), d_.Einv, sizeof(double) * m); }
@@ -781,6 +858,8 @@ void Engine::admm_core(double t0, double *res) {
     }
     int tot[F_COUNT] = {0}, f[F_COUNT];
     int launched_pairs = 0;
+    // slot pairs (two launches each) that `its` ADMM iterations with `pcg` PCG iterations each need (backend.h slot_launches)
+    auto pairs_for = [&](double its, double pcg) { return 0.5 * its * be::slot_launches(d_, pcg); };
     // (per-solve iteration limit = the budget rule of the launch-per-iteration form: the two forms then execute the SAME arithmetic
     // -- truncating the rare long solve at mean + 3 sigma of the previous chunk costs no ADMM iterations and a third of the PCG work)
     const int lim = budget[tight];
@@ -797,7 +876,7 @@ void Engine::admm_core(double t0, double *res) {
       static const double kFrac = [] { const char *e = std::getenv("OSQP_HIP_POLL_FRAC"); return e ? std::atof(e) : 0.75; }();
       static const double kWait = [] { const char *e = std::getenv("OSQP_HIP_POLL_WAIT"); return e ? std::atof(e) : 0.7; }();
       const double p0 = std::min<double>(pred[kind], lim);
-      { const int np = 2 * cnt + std::max(2, (int)std::floor(kFirst * p0 * cnt)); run_slots(cnt, np, lim); launched_pairs += np; }
+      { const int np = (int)std::ceil(pairs_for(cnt, 0)) + std::max(2, (int)std::floor(kFirst * (pairs_for(cnt, p0) - pairs_for(cnt, 0)))); run_slots(cnt, np, lim); launched_pairs += np; }
       double pair_s = 9e-6, t_prev = now_s();                        // duration of a slot pair, re-estimated from the progress between two polls
       int seq_prev = 0;
       for (int seq = 0, done = 0;;) {
@@ -814,14 +893,15 @@ void Engine::admm_core(double t0, double *res) {
           continue;
         }
         const int rem = cnt - done;
-        const double rate = done > 0 ? std::min<double>(2.0 + lim, (0.5 * seq) / done) : 2.0 + p0;      // pairs per ADMM iteration so far
+        const double rate = done > 0 ? std::min<double>(pairs_for(1, lim), (0.5 * seq) / done) : pairs_for(1, p0);      // pairs per ADMM iteration so far
         const int need = (int)std::ceil(rem * rate) + 1 - ahead;
         const int np = std::max(2, need > 12 ? (int)std::ceil(kFrac * need) : need);
         run_slots(0, np, lim); launched_pairs += np;
         stats_.slot_topups += 1;
       }
     } else
-    { const int np = 2 * cnt + (int)std::ceil(1.05 * std::min<double>(pred[kind], lim) * cnt) + 2; run_slots(cnt, np, lim); launched_pairs += np; }
+    { const double pm = std::min<double>(pred[kind], lim);
+      const int np = (int)std::ceil(pairs_for(cnt, 0) + 1.05 * (pairs_for(cnt, pm) - pairs_for(cnt, 0))) + 2; run_slots(cnt, np, lim); launched_pairs += np; }
     for (;;) {
       if (with_res) { be::residuals(d_); be::fetch_res_flags(d_, res, f); } else be::fetch_flags(d_, f);
       tot[F_STAT_SUM] += f[F_STAT_SUM]; tot[F_STAT_SUMSQ] += f[F_STAT_SUMSQ]; tot[F_STAT_N] += f[F_STAT_N]; tot[F_STAT_UNCONV] += f[F_STAT_UNCONV]; tot[F_STAT_STAG] += f[F_STAT_STAG];
@@ -831,7 +911,8 @@ void Engine::admm_core(double t0, double *res) {
       if (done >= cnt) break;
       const int rem = cnt - done;
       const double seen = tot[F_STAT_N] > 0 ? (double)tot[F_STAT_SUM] / tot[F_STAT_N] : pred[kind];
-      { const int np = 2 * rem + (int)std::ceil(1.25 * std::min<double>(std::max(seen, pred[kind]), lim) * rem) + 8; run_slots(0, np, lim); launched_pairs += np; }
+      { const double pm = std::min<double>(std::max(seen, pred[kind]), lim);
+        const int np = (int)std::ceil(pairs_for(rem, 0) + 1.25 * (pairs_for(rem, pm) - pairs_for(rem, 0))) + 8; run_slots(0, np, lim); launched_pairs += np; }
       stats_.slot_topups += 1;
     }
     for (int k = 0; k < F_COUNT; k++) flags[k] = tot[k];
@@ -1181,6 +1262,7 @@ int Engine::update_data_mat(const double *Px, const int *Px_idx, int P_n, const 
     if (Px) be::h2d(d_, d_.Praw, P_.x.data(), sizeof(double) * nzP);
     if (Ax) be::h2d(d_, d_.Araw, A_.x.data(), sizeof(double) * nzA);
     be::assemble(d_, 1, c_, 1);
+    be::f1_refresh(d_);
   } else {
     std::vector<double> Pxs, Axs;
     scale_matrix_values(Pxs, Axs);
@@ -1245,7 +1327,7 @@ int Engine::ls_setup(const OSQPCscMatrix *P, const OSQPCscMatrix *A, const doubl
   std::vector<double> q(nn, 0.0), l(mm, -OSQP_INFTY), u(mm, OSQP_INFTY);
   int err = setup(P, q.data(), A, l.data(), u.data(), mm, nn, &st);
   if (err) return err;
-  d_.fused = 0;
+  d_.fused = 0; d_.f1.on = 0;
   return ls_set_rho_vec(rho_vec);
 }
 
@@ -1635,14 +1717,15 @@ int Engine::batch_solve_device(int nbatch, const double *q, const double *l, con
 
 int Engine::get_stats(OSQPHipStats *out) {
   if (!out) return OSQP_DATA_VALIDATION_ERROR;
-  *out = stats_; out->pcg_fused = be::pcg_fused(d_) ? 1.0 : 0.0; out->batch_direct_bw = bd_.bw_symbolic;
+  *out = stats_; out->pcg_fused = (d_.f1.on && use_slots_) ? 2.0 : (be::pcg_fused(d_) ? 1.0 : 0.0); out->batch_direct_bw = bd_.bw_symbolic;
+  out->f1_replicas = d_.f1.on ? d_.f1.D : 0;
   out->windowed_blocks = d_.A.nwin + d_.B.nwin; out->row_blocks = d_.A.nblk + d_.B.nblk;
   return OSQP_NO_ERROR;
 }
 int Engine::time_kernel(int which, int reps, double *ms) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);
-  if (which < 0 || which > 13 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
+  if (which < 0 || which > 15 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
   *ms = be::time_kernel(d_, which, reps);
   return OSQP_NO_ERROR;
 }

@@ -46,6 +46,7 @@ void slot_pair(Dev &) {}
 int slot_done(Dev &) { return 0; }
 int slot_seq(Dev &) { return 0; }
 void slot_poll(Dev &, int *seq, int *done) { *seq = 0; *done = 0; }
+void f1_refresh(Dev &) {}
 void ext_record(Dev &, void *) {}
 void ext_wait(Dev &) {}
 

@@ -1,0 +1,110 @@
+"""GPU tier: the one-launch-per-PCG-iteration form (k_slot1, DESIGN.md §4.5: A-only operator apply with replica vectors for
+A't, double-buffered r / s, device-scheduled KB / F_k / KA phases) against the two-kernel form of the same engine and against the
+oracle's direct solve.  Both forms execute the same Chronopoulos-Gear recurrences; they differ in summation order only, so their
+solutions agree far inside the termination tolerance and their iteration counts to within a termination check."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+import osqp_amd
+import problems
+from oracle import Oracle, SOLVED
+
+pytestmark = pytest.mark.gpu
+warnings.simplefilter('ignore')
+
+
+def _solve(P, q, A, l, u, f1, graph=True, **kw):
+    old = {k: os.environ.get(k) for k in ('OSQP_HIP_F1', 'OSQP_HIP_GRAPH')}
+    os.environ['OSQP_HIP_F1'] = '1' if f1 else '0'
+    os.environ['OSQP_HIP_GRAPH'] = '1' if graph else '0'
+    try:
+        st = dict(eps_abs=1e-6, eps_rel=1e-6, max_iter=20000, adaptive_rho_interval=50, check_termination=25, verbose=False)
+        st.update(kw)
+        m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, **st)
+        r = m.solve()
+        return m, r, m._solver.hip_stats()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / (1 + np.abs(b).max())
+
+
+@pytest.mark.parametrize('n,window', [(20000, 40), (100000, 200)])
+def test_f1_form_matches_two_kernel_form_and_oracle(n, window):
+    P, q, A, l, u = problems.banded_qp(n, window=window)
+    m1, r1, s1 = _solve(P, q, A, l, u, True)
+    m0, r0, s0 = _solve(P, q, A, l, u, False)
+    assert int(s1['pcg_fused']) == 2 and 1 <= int(s1['f1_replicas']) <= 4, s1
+    assert int(s0['pcg_fused']) == 1 and int(s0['f1_replicas']) == 0
+    assert r1.info.status_val == r0.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED
+    print('n=%d F1: %d iterations, %.1f PCG each, %d launches; two-kernel: %d iterations, %.1f PCG each, %d launches; |dx| %.2e |dy| %.2e'
+          % (n, r1.info.iter, s1['pcg_iters_total'] / r1.info.iter, s1['kernel_launches'], r0.info.iter, s0['pcg_iters_total'] / r0.info.iter,
+             s0['kernel_launches'], _rel(r1.x, r0.x), _rel(r1.y, r0.y)))
+    assert _rel(r1.x, r0.x) < 2e-5 and _rel(r1.y, r0.y) < 2e-5
+    assert abs(r1.info.obj_val - r0.info.obj_val) <= 1e-6 * (1 + abs(r0.info.obj_val))
+    assert abs(r1.info.iter - r0.info.iter) <= 50
+    assert s1['kernel_launches'] < 0.75 * s0['kernel_launches']
+    if n <= 20000:                                     # the oracle's direct solve takes seconds at this size
+        xo, yo, io = Oracle().setup(P, q, A, l, u, eps_abs=1e-8, eps_rel=1e-8, max_iter=50000, adaptive_rho_interval=50).solve()
+        assert io.status_val == SOLVED
+        assert _rel(r1.x, xo) < 2e-5 and _rel(r1.y, yo) < 2e-5
+
+
+def test_f1_form_tight_tolerance_against_oracle():
+    P, q, A, l, u = problems.banded_qp(20000, window=40)
+    kw = dict(eps_abs=1e-8, eps_rel=1e-8, max_iter=50000)
+    _, r1, s1 = _solve(P, q, A, l, u, True, **kw)
+    assert int(s1['pcg_fused']) == 2
+    xo, yo, io = Oracle().setup(P, q, A, l, u, adaptive_rho_interval=50, check_termination=25, **kw).solve()
+    assert io.status_val == SOLVED and r1.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED
+    print('tight: engine %d iterations, oracle %d; |dx| %.2e |dy| %.2e' % (r1.info.iter, io.iter, _rel(r1.x, xo), _rel(r1.y, yo)))
+    assert _rel(r1.x, xo) < 2e-6 and _rel(r1.y, yo) < 2e-6
+
+
+def test_f1_form_is_deterministic_and_graph_replay_equals_eager_launches():
+    P, q, A, l, u = problems.banded_qp(20000, window=40)
+    m, ra, _ = _solve(P, q, A, l, u, True)
+    rb = m.solve()                                      # cold start again (warm_starting defaults to True in the front-end: force it)
+    m2, rc, _ = _solve(P, q, A, l, u, True, graph=False)
+    m3, rd, _ = _solve(P, q, A, l, u, True)
+    assert ra.info.iter == rc.info.iter == rd.info.iter
+    assert np.array_equal(ra.x, rc.x) and np.array_equal(ra.y, rc.y)          # graph replay vs eager launches: bit-identical
+    assert np.array_equal(ra.x, rd.x) and np.array_equal(ra.y, rd.y)          # a second handle: bit-identical
+    assert rb.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED
+
+
+def test_f1_form_warm_start_update_and_cap():
+    """Vector updates, warm starts and a binding PCG cap (cg_max_iter = 3: every solve stops at the cap, the last budgeted update
+    applies no operator) through the F1 phases."""
+    P, q, A, l, u = problems.banded_qp(20000, window=40)
+    m, r, s = _solve(P, q, A, l, u, True, warm_starting=True)
+    assert int(s['pcg_fused']) == 2
+    rng = np.random.default_rng(3)
+    q2 = q + 0.01 * rng.standard_normal(q.size)
+    m.update(q=q2)
+    r2 = m.solve()
+    m0, _, _ = _solve(P, q2, A, l, u, False)
+    r0 = m0.solve()
+    assert r2.info.status_val == r0.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED
+    assert _rel(r2.x, r0.x) < 2e-5 and _rel(r2.y, r0.y) < 2e-5
+    mc, rc, sc = _solve(P, q, A, l, u, True, cg_max_iter=3)
+    assert rc.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED
+    assert sc['pcg_iters_max'] <= 3
+    assert _rel(rc.x, r.x) < 5e-5 and _rel(rc.y, r.y) < 5e-5
+
+
+def test_f1_form_is_not_taken_where_it_does_not_apply():
+    rng = np.random.default_rng(0)
+    P, q, A, l, u = problems.banded_qp(30000, window=30000)        # unstructured columns: no windows
+    _, r, s = _solve(P, q, A, l, u, True)
+    assert int(s['pcg_fused']) == 1 and int(s['f1_replicas']) == 0
+    assert r.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED
