@@ -40,9 +40,10 @@ constexpr int kWinCap = 1472;      // input-vector window of a row block staged 
 // One-launch PCG iteration ("F1" form, DevF1 below)
 constexpr int kF1Win = 512;        // widest window of a row block of A the F1 form takes (two elements per lane)
 constexpr int kF1MaxD = 4;         // most replicas of the partial A' t vector
-constexpr int kF1PChunk = 512;     // most (P + sigma I) entries of a block's own rows
+constexpr int kF1PChunk = 256;     // most (P + sigma I) entries of a block's own rows (one per lane)
 constexpr int kF1MaxOwn = 512;     // most own columns of a block
 constexpr int kF1MaxRows = 512;    // most rows of a block
+constexpr int kF1Chunk = 1024;     // most entries of a row block of A
 
 struct DevCsr {
   int nrows = 0, ncols = 0, nnz = 0, nblk = 0;
@@ -77,16 +78,21 @@ struct DevCsr {
 struct DevF1 {
   int on = 0;                    // plan valid (Engine::prepare_f1); 0: the two-kernel form
   int D = 0;                     // replicas
-  int *desc = nullptr;           // nblk(A) x {cov0, cov1, cs0, cs1}: replica coverage [cov0, cov1) (zero outside the window), own columns [cs0, cs1)
-  int *desc2 = nullptr;          // nblk(A) x {offset of the block's column pointers in cptr, first and end entry of its own rows in the P arrays, 0}
-  unsigned int *ent = nullptr;   // nnz(A): local column (9 bits) | local row << 9 (9 bits) | position of the entry in the block's column-major order << 18 (11 bits)
+  int *blk = nullptr;            // nblk(A) x 16 words, one scalar load per block:
+                                 //   {first row, end row, first entry, end entry}  (the block's descriptor in A)
+                                 //   {cov0, cov1, cs0, cs1}: replica coverage [cov0, cov1) (zero outside the window), own columns [cs0, cs1)
+                                 //   {offset of the block's column pointers in cptr, first and end entry of its own rows in the P arrays, 0}
+                                 //   {g0, gl, a0, wl}: gather window [g0, g0 + gl) (columns of the block's rows of A -- plus those of its own
+                                 //   rows of P if that widens it by at most a quarter), scatter window [a0, a0 + wl) (columns of its rows of A)
+  unsigned int *ent = nullptr;   // nnz(A): column relative to g0 (9 bits) | local row << 9 (9 bits) | position of the entry in the block's column-major order << 18 (11 bits)
   unsigned short *cptr = nullptr;// per block: window length + 1 column pointers (block-local, column-major entry positions)
   int *prp = nullptr, *pcol = nullptr, *psrc = nullptr;   // compact CSR of P + sigma I (n rows): row pointers, columns, position of each entry in B.val
   double *pval = nullptr;        // values, refreshed from B.val by be::f1_refresh (after assembly / equilibration / matrix updates)
   int pnnz = 0;
-  double *rep = nullptr;         // [2][D][n] partial A' t, by parity of the PCG iteration
-  double *pu = nullptr;          // [2][n]  (P + sigma I) u_k on the own columns
-  double *r2 = nullptr, *s2 = nullptr;   // second buffers of r and s (r_k lives in k & 1 ? r2 : Dev::r, s_k likewise)
+  // the n-vectors of the iteration in ONE arena, stride ns doubles: Minv, x~, p, r (parity 0 = Dev::r, 1), s (0 = Dev::s, 1), pu (0, 1),
+  // rep (parity 0: D vectors, parity 1: D vectors).  Dev::Minv / xs / p / r / s point into it.  r_k, s_{k-1}, pu_k and rep_k (what launch
+  // F_k writes) live in parity k & 1.
+  double *va = nullptr; size_t ns = 0;
 };
 
 // indices into Dev::res (results of the residual kernels, reduced on the device)

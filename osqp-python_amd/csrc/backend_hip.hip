@@ -1041,38 +1041,41 @@ __global__ __launch_bounds__(kBlock) void k_slot_a(Dev d) {
 //   scalars   k = 0:  ||r_0||, ||rhs|| (KB's partials) -> tolerance, stopping test
 //             k >= 1: gamma_{k-1}, delta_{k-1}, ||r_{k-1}|| (partials of F_{k-1}) -> stopping test (k >= 2), beta_{k-1}, alpha_{k-1}
 //   window    u_k[c] = Minv (r_{k-1} - alpha (w_{k-1} + beta s_{k-2}))[c],  w_{k-1} = pu_{k-1} + sum_d rep_d   (k = 0: Minv r_0)
-//             for every column c of the block's window -- recomputed by every workgroup that gathers c, with the same instruction
-//             sequence as the owner's update below (f1_upd), so all copies are bit-identical
-//   own cols  s_{k-1}, r_k, p_{k-1}, x~ += alpha p_{k-1}  stored;  partials gamma_k = <r_k, Minv r_k>, ||r_k||_inf
+//             for every column c of the block's GATHER window (the columns its rows of A and its own rows of P touch) -- recomputed
+//             by every workgroup that gathers c, with the same instruction sequence as the owner's update (f1_upd): all copies
+//             are bit-identical.  The lane whose window column is one of the block's OWN columns also performs that column's
+//             vector update:  s_{k-1}, r_k, p_{k-1}, x~ += alpha p_{k-1}  stored;  partials gamma_k = <r_k, Minv r_k>, ||r_k||_inf
 //   SpMV      t = rho .* (A_g u_k)  (rows of the block, products staged in LDS, one lane per row),
-//             pu_k = (P + sigma I) u_k  on the own columns,  rep_{g mod D} = A_g' t  per window column (second, column-ordered pass
-//             over the entries still held in registers),  partial delta_k = <t, A u_k> + <u_k, pu_k>_own = <u_k, K u_k>
+//             pu_k = (P + sigma I) u_k  on the own columns,  rep_{g mod D} = A_g' t  per column of the block's SCATTER window (the
+//             columns of its rows of A; second, column-ordered pass over the entries still held in registers),
+//             partial delta_k = <t, A u_k> + <u_k, pu_k>_own = <u_k, K u_k>
 // r, s, pu, rep are double-buffered by the parity of k: a workgroup reads what the PREVIOUS launch wrote while its neighbours
-// write this launch's values.  Five workgroup barriers per block, no global synchronisation inside the launch.
+// write this launch's values.  Four workgroup barriers per block, no global synchronisation inside the launch.
+// Template: D = replicas, FIRST = the launch F_0 (straight-line code: no run-time branch on either).
 struct F1Lds {
-  double win[kF1Win];            // u_k on the block's window
-  double prod[kChunk];           // A products in row-major entry order, then val * t[row] in column-major order
+  double win[kF1Win];            // u_k on the block's gather window
+  double prod[kF1Chunk];         // A products in row-major entry order, then val * t[row] in column-major order
   double tvec[kF1MaxRows];       // t of the block's rows
   double uown[kF1MaxOwn];        // u_k on the own columns
   double pprod[kF1PChunk];       // (P + sigma I) products of the own rows
   double red[3 * kWaves];
 };
-static_assert(sizeof(F1Lds) <= 40 * 1024, "four workgroups per CU");
-struct F1Scal { double alpha, beta; int mode; };       // mode 0: F_0 (u = Minv r_0); 1: first update (s_0 = w_0, p_0 = u_0); 2: general
-__device__ __forceinline__ double f1_w(double pu, const double (&rp)[kF1MaxD], int D) {     // fixed order: deterministic
+struct F1Scal { double alpha, beta; int general; };       // general = 0: the first update (s_0 = w_0, p_0 = u_0: s_{-1}, p_{-1} are not used)
+template <int D>
+__device__ __forceinline__ double f1_w(double pu, const double (&rp)[D]) {     // fixed order: deterministic
   double w = pu;
 #pragma unroll
-  for (int q = 0; q < kF1MaxD; q++) if (q < D) w += rp[q];
+  for (int q = 0; q < D; q++) w += rp[q];
   return w;
 }
 __device__ __forceinline__ void f1_upd(const F1Scal &sc, double minv, double r, double w, double sp, double &sn, double &rn, double &un) {
-  sn = sc.mode == 2 ? fma(sc.beta, sp, w) : w;
+  sn = fma(sc.beta, sc.general ? sp : 0.0, w);           // (first update: beta = 0 and the stale s is masked, so s_0 = w_0 exactly)
   rn = fma(-sc.alpha, sn, r);
   un = minv * rn;
 }
-// sum of seg[a .. z): the first eight entries with independent LDS reads (as process_rows)
+// sum of seg[a .. z): the first kB entries with independent LDS reads (as process_rows)
+template <int kB>
 __device__ __forceinline__ double f1_segsum(const double *seg, int a, int z) {
-  constexpr int kB = 8;
   double v[kB];
 #pragma unroll
   for (int q = 0; q < kB; q++) v[q] = a + q < z ? seg[a + q] : 0.0;
@@ -1082,185 +1085,241 @@ __device__ __forceinline__ double f1_segsum(const double *seg, int a, int z) {
   for (int k = a + kB; k < z; k++) acc += seg[k];
   return acc;
 }
-// returns false when the PCG had already converged (nothing done: the caller runs KA in this launch)
-__device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const int cap, const int admm_par, const int probe, F1Lds &L) {
-  const DevF1 &f = d.f1;
-  const int n = d.n, D = f.D, tid = threadIdx.x;
+// The scalar part of launch F_k.  Returns false when the PCG had already converged (the caller runs KA in this launch).
+__device__ __forceinline__ bool f1_scalars(const Dev &d, const int k, const int admm_par, const int probe, double *red, F1Scal &sc) {
   double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
-  const int cur = (k + 1) & 1, nxt = k & 1;               // parity of k - 1 / of k
-  F1Scal sc{0.0, 0.0, 0};
-  if (probe) { sc.alpha = 1e-3; sc.beta = 0.5; sc.mode = k == 0 ? 0 : (k == 1 ? 1 : 2); }
-  else if (k == 0) {
+  const int cur = (k + 1) & 1, tid = threadIdx.x;
+  sc = F1Scal{0.0, 0.0, k >= 2};
+  if (probe) { sc.alpha = 1e-3; sc.beta = k >= 2 ? 0.5 : 0.0; return true; }
+  if (k == 0) {
     const PartRegs prn = partial_load(d.part + SL_RN0 * kGrid), pbn = partial_load(d.part + SL_BN * kGrid);
     double rn = partial_fold_max(prn), bn = partial_fold_max(pbn);
-    block_max2(rn, bn, L.red);
+    block_max2(rn, bn, red);
     const double tol = fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS]);
     if (blockIdx.x == 0 && tid == 0) { d.scal[S_TOL_NOW] = tol; d.scal[S_RN0] = rn; d.scal[S_RN0H + admm_par] = rn; }
-    if (!(rn > tol)) return false;                          // the start already meets the tolerance (a NaN also ends the inner loop)
-  } else {
-    const PartRegs pg = partial_load(d.part + (SL_GAMMA0 + cur) * kGrid), pd = partial_load(d.part + (SL_DELTA + cur) * kGrid),
-                   prn = partial_load(d.part + (SL_RN0 + cur) * kGrid);
-    const double tol = d.scal[S_TOL_NOW], glast = k >= 2 ? gam[k - 2] : 1.0, alast = k >= 2 ? alp[k - 2] : 1.0;
-    double gamma = partial_fold_sum(pg), rn = partial_fold_max(prn), delta = partial_fold_sum(pd);
-    block_sum_max_sum(gamma, rn, delta, L.red);
-    if (k >= 2 && !(rn > tol)) return false;                // converged after k - 1 iterations (r_0 was tested by F_0)
-    sc.beta = k >= 2 ? gamma / glast : 0.0;
-    sc.alpha = k >= 2 ? gamma / (delta - sc.beta * gamma / alast) : gamma / delta;
-    sc.mode = k >= 2 ? 2 : 1;
-    if (blockIdx.x == 0 && tid == 0) { gam[k - 1] = gamma; alp[k - 1] = sc.alpha; }
+    return rn > tol;                                        // false: the start already meets the tolerance (a NaN also ends the inner loop)
   }
-  const int mode = sc.mode;
-  const bool vec_only = !probe && k >= cap;                 // the last budgeted update: no operator apply follows
-  const double *rread = (k == 0 || cur == 0) ? d.r : f.r2;  // r_{k-1} (k = 0: r_0)
-  double *rnxt = nxt ? f.r2 : d.r;                          // r_k
-  const double *sprev = nxt ? f.s2 : d.s;                   // s_{k-2}: parity of k
-  double *snew = cur ? f.s2 : d.s;                          // s_{k-1}
-  const double *pucur = f.pu + (size_t)cur * n, *repcur = f.rep + (size_t)cur * D * n;
-  double *punxt = f.pu + (size_t)nxt * n, *repnxt = f.rep + (size_t)nxt * D * n;
-  const int4 *desc = reinterpret_cast<const int4 *>(d.A.blkdesc), *wdesc = reinterpret_cast<const int4 *>(d.A.blkwin);
-  const int4 *fdesc = reinterpret_cast<const int4 *>(f.desc), *fdesc2 = reinterpret_cast<const int4 *>(f.desc2);
-  // u_k at column c from global memory (P entries whose column lies outside the block's window)
-  auto u_global = [&](int c) -> double {
-    const double mi = d.Minv[c], r = rread[c];
-    if (mode == 0) return mi * r;
-    double rp[kF1MaxD];
-#pragma unroll
-    for (int q = 0; q < kF1MaxD; q++) if (q < D) rp[q] = repcur[(size_t)q * n + c];
-    const double w = f1_w(pucur[c], rp, D), sp = mode == 2 ? sprev[c] : 0.0;
-    double sn, rn, un;
-    f1_upd(sc, mi, r, w, sp, sn, rn, un);
-    return un;
-  };
+  const PartRegs pg = partial_load(d.part + (SL_GAMMA0 + cur) * kGrid), pd = partial_load(d.part + (SL_DELTA + cur) * kGrid),
+                 prn = partial_load(d.part + (SL_RN0 + cur) * kGrid);
+  const double tol = d.scal[S_TOL_NOW], glast = k >= 2 ? gam[k - 2] : 1.0, alast = k >= 2 ? alp[k - 2] : 1.0;
+  double gamma = partial_fold_sum(pg), rn = partial_fold_max(prn), delta = partial_fold_sum(pd);
+  block_sum_max_sum(gamma, rn, delta, red);
+  if (k >= 2 && !(rn > tol)) return false;                  // converged after k - 1 iterations (r_0 was tested by F_0)
+  sc.beta = k >= 2 ? gamma / glast : 0.0;
+  sc.alpha = k >= 2 ? gamma / (delta - sc.beta * gamma / alast) : gamma / delta;
+  if (blockIdx.x == 0 && tid == 0) { gam[k - 1] = gamma; alp[k - 1] = sc.alpha; }
+  return true;
+}
+// base[idx] as int4 through the CONSTANT address space: with a wave-uniform index the compiler emits scalar loads
+__device__ __forceinline__ int4 sload_int4(const int *base, size_t idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef int __attribute__((ext_vector_type(4))) v4i;
+  typedef const v4i __attribute__((address_space(4))) *cptr;
+  const v4i v = ((cptr)(unsigned long long)base)[idx];
+  return make_int4(v.x, v.y, v.z, v.w);
+#else
+  return reinterpret_cast<const int4 *>(base)[idx];
+#endif
+}
+template <int D, bool FIRST>
+__device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool vec_only, const F1Scal sc, F1Lds &L) {
+  const DevF1 &f = d.f1;
+  const int n = d.n, tid = threadIdx.x;
+  const int cur = (k + 1) & 1, nxt = k & 1;               // parity of k - 1 / of k
+  KT(1);
+  // every n-vector of the iteration lives in ONE arena (DevF1::va, stride ns): the addresses derive from one base pointer by scalar
+  // adds instead of a kernel-argument load per vector
+  const double *va = f.va; const size_t ns = f.ns;
+  const double *Minv = va, *xs_r = va + ns, *p_r = va + 2 * ns;
+  double *xs_w = f.va + ns, *p_w = f.va + 2 * ns;
+  const double *rread = va + (3 + ((FIRST || cur == 0) ? 0 : 1)) * ns;      // r_{k-1} (F_0: r_0)
+  double *rnxt = f.va + (3 + nxt) * ns;                     // r_k
+  const double *sprev = va + (5 + cur) * ns;                // s_{k-2}: stored next to r_{k-1}
+  double *snew = f.va + (5 + nxt) * ns;                     // s_{k-1}: stored next to r_k
+  const double *pucur = va + (7 + cur) * ns, *repcur = va + (9 + (size_t)cur * D) * ns;
+  double *punxt = f.va + (7 + nxt) * ns, *repnxt = f.va + (9 + (size_t)nxt * D) * ns;
   double g_acc = 0.0, rn_acc = 0.0, dl_acc = 0.0;
-  // the vector update of one own column (everything in registers already): stores s_{k-1}, r_k, p_{k-1}, x~; returns u_k
+  // the vector update of one own column (operands in registers): stores s_{k-1}, r_k, p_{k-1}, x~; returns u_k
   auto own_update = [&](int j, double mi, double r, double w, double sp, double pp, double x) -> double {
-    if (mode == 0) return mi * r;
     double sn, rn, un;
     f1_upd(sc, mi, r, w, sp, sn, rn, un);
-    const double uold = mi * r, pn = mode == 2 ? fma(sc.beta, pp, uold) : uold;
-    d.xs[j] = fma(sc.alpha, pn, x); d.p[j] = pn; snew[j] = sn; rnxt[j] = rn;
+    const double pn = fma(sc.beta, sc.general ? pp : 0.0, mi * r);
+    xs_w[j] = fma(sc.alpha, pn, x); p_w[j] = pn; snew[j] = sn; rnxt[j] = rn;
     g_acc += rn * un; rn_acc = nanmax(rn_acc, fabs(rn));
     return un;
   };
   const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, slots = gridDim.x >> 3;
   const int per = (d.A.nblk + 7) >> 3;
-  constexpr int CW = kF1Win / kBlock, CE = kChunk / kBlock, CP = kF1PChunk / kBlock;
+  constexpr int CW = kF1Win / kBlock, CE = kF1Chunk / kBlock;
+  static_assert(kF1PChunk == kBlock, "one (P + sigma I) entry per lane");
   for (int sl = slot0; sl < per; sl += slots) {
-    const int b = xcd * per + sl;
+    const int b = __builtin_amdgcn_readfirstlane(xcd * per + sl);
     if (b >= d.A.nblk) break;
-    const int4 ds = desc[b], ws = wdesc[b], fa = fdesc[b], fb = fdesc2[b];
+    // the block's record: 16 words, one scalar load
+    // (read through the constant address space: the index is wave-uniform, so the four int4 become scalar loads behind ONE wait --
+    //  as generic-pointer loads inside this loop they were four vector loads, each waited for before the next was issued)
+    const int4 ds = sload_int4(f.blk, 4 * (size_t)b), fa = sload_int4(f.blk, 4 * (size_t)b + 1), fb = sload_int4(f.blk, 4 * (size_t)b + 2),
+               fc = sload_int4(f.blk, 4 * (size_t)b + 3);
     const int r0 = ds.x, nrows = ds.y - ds.x, k0 = ds.z, cnt = ds.w - ds.z;
-    const int a0 = ws.x, wl = vec_only ? 0 : ws.y;          // (the last budgeted update applies no operator: no window)
     const int cov0 = fa.x, cov1 = fa.y, cs0 = fa.z, nown = fa.w - fa.z;
     const int cpo = fb.x, pk0 = fb.y, pcnt = fb.z - fb.y;
-    const int nw = (wl + kBlock - 1) / kBlock, nu = (cnt + kBlock - 1) / kBlock, np = (pcnt + kBlock - 1) / kBlock;
-    // ---- loads, in the order they are needed: window parts (+ p, x~ where the window column is one of the block's own), matrix
-    //      entries, row / column pointers
-    double wm[CW], wr[CW], wp[CW], wsv[CW], wq[CW][kF1MaxD], wpp[CW], wx[CW];
+    const int g0 = fc.x, gl = vec_only ? 0 : fc.y, a0 = fc.z, wl = fc.w;      // gather window [g0, g0 + gl), scatter window [a0, a0 + wl)
+    const int nw = (gl + kBlock - 1) / kBlock, nu = (cnt + kBlock - 1) / kBlock, ns2 = (wl + kBlock - 1) / kBlock;
+    KT(2);
+    // ---- loads.  First the (P + sigma I) entry of this lane: its column decides whether the operand comes from the window or has
+    //      to be recomputed from its parts (columns outside the window), and those loads should leave with the window's, not after it
+    double pv = 0.0; int pc = g0;
+    const bool hasp = !vec_only && tid < pcnt;
+    if (!vec_only) { const int e = pk0 + max(0, min(tid, pcnt - 1)); pv = f.pval[e]; pc = f.pcol[e]; }
+    // ---- window parts (+ p, x~ where the window column is one of the block's own)
+    double wm[CW], wr[CW], wp[CW], wsv[CW], wq[CW][D], wpp[CW], wx[CW];
     bool wown[CW];
 #pragma unroll
     for (int u = 0; u < CW; u++) {
       wown[u] = false;
       if (u < nw) {
-        const int e = tid + u * kBlock, c = a0 + min(e, wl - 1);
-        wown[u] = e < wl && c >= cs0 && c - cs0 < nown;
-        wm[u] = d.Minv[c]; wr[u] = rread[c];
-        if (mode >= 1) {
+        const int e = tid + u * kBlock, c = g0 + min(e, gl - 1);
+        wown[u] = e < gl && c >= cs0 && c - cs0 < nown;
+        wm[u] = Minv[c]; wr[u] = rread[c];
+        if (!FIRST) {
           wp[u] = pucur[c];
 #pragma unroll
-          for (int q = 0; q < kF1MaxD; q++) if (q < D) wq[u][q] = repcur[(size_t)q * n + c];
-          if (mode == 2) wsv[u] = sprev[c];
-          if (wown[u]) { wx[u] = d.xs[c]; if (mode == 2) wpp[u] = d.p[c]; }
+          for (int q = 0; q < D; q++) wq[u][q] = repcur[q * ns + c];
+          wsv[u] = sprev[c];
+          const int co = wown[u] ? c : g0;                  // (other lanes re-read one valid element: no branch around the loads)
+          wx[u] = xs_r[co]; wpp[u] = p_r[co];
         }
       }
     }
+    // ---- matrix entries, row / column pointers
     double vw[CE]; unsigned int en[CE];
-    double pv[CP]; int pc[CP];
     int rp0 = 0, rp1 = 0; double rrho = 0.0;
     int cp0[CW], cp1[CW];
     int pp0 = 0, pp1 = 0;
     if (!vec_only) {
 #pragma unroll
       for (int u = 0; u < CE; u++) { if (u < nu) { const int e = k0 + min(tid + u * kBlock, cnt - 1); vw[u] = d.A.val[e]; en[u] = f.ent[e]; } }
+      { const int row = r0 + min(tid, nrows - 1); rp0 = d.A.rowptr[row]; rp1 = d.A.rowptr[row + 1]; rrho = d.rho[row]; }
 #pragma unroll
-      for (int u = 0; u < CP; u++) { if (u < np) { const int e = pk0 + min(tid + u * kBlock, pcnt - 1); pv[u] = f.pval[e]; pc[u] = f.pcol[e]; } }
-      if (tid < nrows) { rp0 = d.A.rowptr[r0 + tid]; rp1 = d.A.rowptr[r0 + tid + 1]; rrho = d.rho[r0 + tid]; }
-#pragma unroll
-      for (int u = 0; u < CW; u++) { if (u < nw) { const int c = min(tid + u * kBlock, wl - 1); cp0[u] = f.cptr[cpo + c]; cp1[u] = f.cptr[cpo + c + 1]; } }
-      if (tid < nown) { pp0 = f.prp[cs0 + tid]; pp1 = f.prp[cs0 + tid + 1]; }
+      for (int u = 0; u < CW; u++) { if (u < ns2) { const int c = cpo + min(tid + u * kBlock, wl - 1); cp0[u] = f.cptr[c]; cp1[u] = f.cptr[c + 1]; } }
+      { const int j = min(cs0 + max(0, min(tid, nown - 1)), n - 1); pp0 = f.prp[j]; pp1 = f.prp[j + 1]; }
     }
+    // ---- operand of a (P + sigma I) entry whose column lies outside the window: its parts, requested now
+    const int pcl = pc - g0;
+    const bool esc = hasp && !(pcl >= 0 && pcl < gl);
+    double em = 0, er = 0, ep = 0, es = 0, eq[D];
+#pragma unroll
+    for (int q = 0; q < D; q++) eq[q] = 0.0;
+    if (esc) {
+      em = Minv[pc]; er = rread[pc];
+      if (!FIRST) {
+        ep = pucur[pc]; es = sprev[pc];
+#pragma unroll
+        for (int q = 0; q < D; q++) eq[q] = repcur[q * ns + pc];
+      }
+    }
+    KT(3);
     // ---- u_k on the window -> LDS; the lane of an own column also performs that column's vector update
 #pragma unroll
     for (int u = 0; u < CW; u++) {
       if (u < nw) {
-        const int e = min(tid + u * kBlock, wl - 1);
-        const double w = mode >= 1 ? f1_w(wp[u], wq[u], D) : 0.0;
+        const int e = min(tid + u * kBlock, gl - 1);
         double un;
-        if (wown[u]) { un = own_update(a0 + e, wm[u], wr[u], w, wsv[u], wpp[u], wx[u]); L.uown[a0 + e - cs0] = un; }
-        else if (mode == 0) un = wm[u] * wr[u];
-        else { double sn, rn; f1_upd(sc, wm[u], wr[u], w, wsv[u], sn, rn, un); }
+        if (FIRST) un = wm[u] * wr[u];
+        else {
+          const double w = f1_w<D>(wp[u], wq[u]);
+          if (wown[u]) un = own_update(g0 + e, wm[u], wr[u], w, wsv[u], wpp[u], wx[u]);
+          else { double sn, rn; f1_upd(sc, wm[u], wr[u], w, wsv[u], sn, rn, un); }
+        }
+        if (wown[u]) L.uown[g0 + e - cs0] = un;
         L.win[e] = un;                                      // (clamped lanes store the same value)
       }
     }
-    // ---- own columns outside the window (none on banded problems; all of them in the last budgeted update)
+    // ---- own columns outside the gather window (none on banded problems; all of them in the last budgeted update)
     for (int jj = tid; jj < nown; jj += kBlock) {
       const int j = cs0 + jj;
-      if (j >= a0 && j - a0 < wl) continue;
-      const double mi = d.Minv[j], r = rread[j];
-      double w = 0.0, sp = 0.0, pp = 0.0, x = 0.0;
-      if (mode >= 1) {
-        double rp[kF1MaxD];
+      if (j >= g0 && j - g0 < gl) continue;
+      const double mi = Minv[j], r = rread[j];
+      double un = mi * r;
+      if (!FIRST) {
+        double rp[D];
 #pragma unroll
-        for (int q = 0; q < kF1MaxD; q++) if (q < D) rp[q] = repcur[(size_t)q * n + j];
-        w = f1_w(pucur[j], rp, D); x = d.xs[j];
-        if (mode == 2) { sp = sprev[j]; pp = d.p[j]; }
+        for (int q = 0; q < D; q++) rp[q] = repcur[q * ns + j];
+        un = own_update(j, mi, r, f1_w<D>(pucur[j], rp), sprev[j], p_r[j], xs_r[j]);
       }
-      const double un = own_update(j, mi, r, w, sp, pp, x);
       if (!vec_only) L.uown[jj] = un;
     }
     if (vec_only) continue;
+    KT(4);
     __syncthreads();
-    // ---- products: A entries against the window; (P + sigma I) entries against the window or, outside it, recomputed operands
+    // ---- products: A entries against the window; the (P + sigma I) entry against the window or its recomputed operand
 #pragma unroll
     for (int u = 0; u < CE; u++) { if (u < nu) L.prod[tid + u * kBlock] = vw[u] * L.win[en[u] & 0x1ffu]; }
-#pragma unroll
-    for (int u = 0; u < CP; u++) {
-      if (u < np) {
-        const int c = pc[u] - a0;
-        const double uv = (c >= 0 && c < wl) ? L.win[c] : u_global(pc[u]);
-        L.pprod[tid + u * kBlock] = pv[u] * uv;
-      }
+    if (hasp) {
+      double uv;
+      if (!esc) uv = L.win[pcl];
+      else if (FIRST) uv = em * er;
+      else { double sn, rn; f1_upd(sc, em, er, f1_w<D>(ep, eq), es, sn, rn, uv); }
+      L.pprod[tid] = pv * uv;
     }
+    KT(5);
     __syncthreads();
-    // ---- row sums: t = rho .* (A u) -> LDS;  pu = (P + sigma I) u on the own columns -> global
+    // ---- row sums: t = rho .* (A u) -> LDS
     for (int row = tid; row < nrows; row += kBlock) {
       if (row != tid) { rp0 = d.A.rowptr[r0 + row]; rp1 = d.A.rowptr[r0 + row + 1]; rrho = d.rho[r0 + row]; }
-      const double au = f1_segsum(L.prod, rp0 - k0, rp1 - k0), t = rrho * au;
+      const double au = f1_segsum<6>(L.prod, rp0 - k0, rp1 - k0), t = rrho * au;
       L.tvec[row] = t; dl_acc += t * au;
     }
-    for (int jj = tid; jj < nown; jj += kBlock) {
-      if (jj != tid) { pp0 = f.prp[cs0 + jj]; pp1 = f.prp[cs0 + jj + 1]; }
-      const double pu = f1_segsum(L.pprod, pp0 - pk0, pp1 - pk0);
-      punxt[cs0 + jj] = pu; dl_acc += L.uown[jj] * pu;
-    }
+    KT(6);
     __syncthreads();
-    // ---- A_g' t: val * t[row] scattered to column-major order, then one lane per window column
+    // ---- A_g' t: val * t[row] scattered to column-major order;  pu = (P + sigma I) u on the own columns -> global
 #pragma unroll
     for (int u = 0; u < CE; u++) { if (u < nu) L.prod[en[u] >> 18] = vw[u] * L.tvec[(en[u] >> 9) & 0x1ffu]; }     // (clamped lanes repeat the last entry's store)
+    for (int jj = tid; jj < nown; jj += kBlock) {
+      if (jj != tid) { pp0 = f.prp[cs0 + jj]; pp1 = f.prp[cs0 + jj + 1]; }
+      const double pu = f1_segsum<4>(L.pprod, pp0 - pk0, pp1 - pk0);
+      punxt[cs0 + jj] = pu; dl_acc += L.uown[jj] * pu;
+    }
+    KT(7);
     __syncthreads();
-    double *rout = repnxt + (size_t)(b % D) * n;
+    // ---- one lane per column of the scatter window
+    double *rout = repnxt + (size_t)(b % D) * ns;
 #pragma unroll
     for (int u = 0; u < CW; u++) {
-      if (u < nw) { const int c = tid + u * kBlock; if (c < wl) rout[a0 + c] = f1_segsum(L.prod, cp0[u], cp1[u]); }
+      if (u < ns2) { const int c = tid + u * kBlock; if (c < wl) rout[a0 + c] = f1_segsum<8>(L.prod, cp0[u], cp1[u]); }
     }
     for (int j = cov0 + tid; j < a0; j += kBlock) rout[j] = 0.0;             // the replica's gap up to the next window of this replica
     for (int j = a0 + wl + tid; j < cov1; j += kBlock) rout[j] = 0.0;
-    __syncthreads();
+    KT(8);
+    if (sl + slots < per) __syncthreads();                  // (another block follows: the LDS arrays are reused)
   }
   __syncthreads();
   block_sum_max_sum(g_acc, rn_acc, dl_acc, L.red);
-  if (mode >= 1) { put_partial(d.part, SL_GAMMA0 + nxt, g_acc); put_partial(d.part, SL_RN0 + nxt, rn_acc); }   // (F_0 leaves KB's gamma_0, ||r_0||)
+  if (!FIRST) { put_partial(d.part, SL_GAMMA0 + nxt, g_acc); put_partial(d.part, SL_RN0 + nxt, rn_acc); }   // (F_0 leaves KB's gamma_0, ||r_0||)
   if (!vec_only) put_partial(d.part, SL_DELTA + nxt, dl_acc);
+  KT(9);
+}
+// returns false when the PCG had already converged (nothing done: the caller runs KA in this launch)
+__device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const int cap, const int admm_par, const int probe, F1Lds &L) {
+  KT(0);
+  F1Scal sc;
+  if (!f1_scalars(d, k, admm_par, probe, L.red, sc)) return false;
+  const bool vec_only = !probe && k >= cap;                 // the last budgeted update: no operator apply follows
+  if (k == 0) {
+    switch (d.f1.D) {
+      case 1: f1_body<1, true>(d, k, vec_only, sc, L); break;
+      case 2: f1_body<2, true>(d, k, vec_only, sc, L); break;
+      case 3: f1_body<3, true>(d, k, vec_only, sc, L); break;
+      default: f1_body<4, true>(d, k, vec_only, sc, L); break;
+    }
+  } else {
+    switch (d.f1.D) {
+      case 1: f1_body<1, false>(d, k, vec_only, sc, L); break;
+      case 2: f1_body<2, false>(d, k, vec_only, sc, L); break;
+      case 3: f1_body<3, false>(d, k, vec_only, sc, L); break;
+      default: f1_body<4, false>(d, k, vec_only, sc, L); break;
+    }
+  }
   return true;
 }
 __global__ __launch_bounds__(kBlock) void k_f1_refresh(Dev d) {

@@ -90,11 +90,12 @@ void Engine::free_all() {
   batch_order_.clear();
   if (ckpt_) { be::dfree(d_, ckpt_); ckpt_ = nullptr; }
   free_batch_direct();
+  if (d_.f1.va) d_.Minv = d_.xs = d_.p = d_.r = d_.s = nullptr;      // (these point into the F1 arena, freed as one block below)
   void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag, d_.A.runinfo, d_.B.runinfo, d_.A.blkwin, d_.B.blkwin, d_.A.lcol, d_.B.lcol, d_.qraw, d_.lraw, d_.uraw, d_.cnt,
                   d_.q, d_.l, d_.u, d_.D, d_.Dinv, d_.E, d_.Einv, d_.rho, d_.rho_inv, d_.ctype, d_.x, d_.z, d_.y, d_.dx,
                   d_.dy, d_.xs, d_.xg, d_.xsp, d_.ztg, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.uu2, d_.ms, d_.part, d_.res,
                   d_.scal, d_.flags, d_.slot, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB,
-                  d_.f1.desc, d_.f1.desc2, d_.f1.ent, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.rep, d_.f1.pu, d_.f1.r2, d_.f1.s2};
+                  d_.f1.blk, d_.f1.ent, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.va};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   be::destroy(d_);
   d_ = Dev();
@@ -299,7 +300,7 @@ void Engine::prepare_f1(const std::vector<int> &rb, const std::vector<int> &Arp,
   std::vector<int> a0(nb), wl(nb);
   for (int b = 0; b < nb; b++) {
     const int r0 = rb[b], r1 = rb[b + 1], k0 = Arp[r0], k1 = Arp[r1];
-    if (k1 == k0 || r1 - r0 > kF1MaxRows || k1 - k0 > kChunk || (r1 - r0 == 1 && k1 - k0 > kLongRow)) return;
+    if (k1 == k0 || r1 - r0 > kF1MaxRows || k1 - k0 > kF1Chunk || (r1 - r0 == 1 && k1 - k0 > kLongRow)) return;
     int lo = INT32_MAX, hi = -1;
     for (int k = k0; k < k1; k++) { lo = std::min(lo, Arj[k]); hi = std::max(hi, Arj[k]); }
     if (hi - lo + 1 > kF1Win) return;
@@ -321,15 +322,23 @@ void Engine::prepare_f1(const std::vector<int> &rb, const std::vector<int> &Arp,
   const int pnnz = prp[n];
   std::vector<int> pcol(std::max(pnnz, 1)), psrc(std::max(pnnz, 1));
   for (int j = 0; j < n; j++) for (int k = Brp[j], o = prp[j]; k < Brp[j + 1] && Bj[k] < n; k++, o++) { pcol[o] = Bj[k]; psrc[o] = k; }
-  std::vector<int> desc(4 * (size_t)nb), desc2(4 * (size_t)nb);
+  std::vector<int> blk(16 * (size_t)nb);
   std::vector<unsigned int> ent(Arj.size());
   std::vector<unsigned short> cptr;
   std::vector<int> order;
   for (int b = 0; b < nb; b++) {
     if (cs[b + 1] - cs[b] > kF1MaxOwn || prp[cs[b + 1]] - prp[cs[b]] > kF1PChunk) return;
     const int r0 = rb[b], r1 = rb[b + 1], k0 = Arp[r0], k1 = Arp[r1], cnt = k1 - k0;
-    desc[4 * b] = b < D ? 0 : a0[b]; desc[4 * b + 1] = b + D < nb ? a0[b + D] : n; desc[4 * b + 2] = cs[b]; desc[4 * b + 3] = cs[b + 1];
-    desc2[4 * b] = (int)cptr.size(); desc2[4 * b + 1] = prp[cs[b]]; desc2[4 * b + 2] = prp[cs[b + 1]]; desc2[4 * b + 3] = 0;
+    int *w = &blk[16 * (size_t)b];
+    w[0] = r0; w[1] = r1; w[2] = k0; w[3] = k1;
+    w[4] = b < D ? 0 : a0[b]; w[5] = b + D < nb ? a0[b + D] : n; w[6] = cs[b]; w[7] = cs[b + 1];
+    w[8] = (int)cptr.size(); w[9] = prp[cs[b]]; w[10] = prp[cs[b + 1]]; w[11] = 0;
+    // gather window: the columns of the block's rows of A, together with those of its own rows of P + sigma I when that widens the
+    // window by at most a quarter (every window column costs 4 + D vector loads; a P entry outside the window costs as many, once)
+    int g0 = a0[b], g1 = a0[b] + wl[b];
+    for (int k = prp[cs[b]]; k < prp[cs[b + 1]]; k++) { g0 = std::min(g0, pcol[k]); g1 = std::max(g1, pcol[k] + 1); }
+    if (g1 - g0 > kF1Win || 4 * (g1 - g0) > 5 * wl[b]) { g0 = a0[b]; g1 = a0[b] + wl[b]; }
+    w[12] = g0; w[13] = g1 - g0; w[14] = a0[b]; w[15] = wl[b];
     // column-major order of the block's entries: stable by local column (rows ascending within a column)
     order.resize(cnt);
     for (int e = 0; e < cnt; e++) order[e] = e;
@@ -338,7 +347,7 @@ void Engine::prepare_f1(const std::vector<int> &rb, const std::vector<int> &Arp,
     for (int t = 0; t < cnt; t++) tpos[order[t]] = t;
     for (int r = r0; r < r1; r++)
       for (int k = Arp[r]; k < Arp[r + 1]; k++)
-        ent[k] = (unsigned)(Arj[k] - a0[b]) | ((unsigned)(r - r0) << 9) | ((unsigned)tpos[k - k0] << 18);
+        ent[k] = (unsigned)(Arj[k] - g0) | ((unsigned)(r - r0) << 9) | ((unsigned)tpos[k - k0] << 18);
     const size_t base = cptr.size();
     cptr.resize(base + wl[b] + 1, 0);
     for (int e = 0; e < cnt; e++) cptr[base + (Arj[k0 + e] - a0[b]) + 1]++;
@@ -347,12 +356,12 @@ void Engine::prepare_f1(const std::vector<int> &rb, const std::vector<int> &Arp,
   auto up_i = [&](const std::vector<int> &h) { int *p = dev_vec<int>(d_, h.size()); if (!h.empty()) be::h2d(d_, p, h.data(), sizeof(int) * h.size()); return p; };
   DevF1 &f = d_.f1;
   f.D = D; f.pnnz = pnnz;
-  f.desc = up_i(desc); f.desc2 = up_i(desc2); f.prp = up_i(prp); f.pcol = up_i(pcol); f.psrc = up_i(psrc);
+  f.blk = up_i(blk); f.prp = up_i(prp); f.pcol = up_i(pcol); f.psrc = up_i(psrc);
   f.ent = dev_vec<unsigned int>(d_, ent.size()); be::h2d(d_, f.ent, ent.data(), sizeof(unsigned int) * ent.size());
   f.cptr = dev_vec<unsigned short>(d_, cptr.size()); be::h2d(d_, f.cptr, cptr.data(), sizeof(unsigned short) * cptr.size());
   f.pval = dev_vec<double>(d_, pnnz);
-  f.rep = dev_vec<double>(d_, 2 * (size_t)D * n); f.pu = dev_vec<double>(d_, 2 * (size_t)n);
-  f.r2 = dev_vec<double>(d_, n); f.s2 = dev_vec<double>(d_, n);
+  f.ns = ((size_t)n + 31) / 32 * 32;                       // 256-byte aligned vectors
+  f.va = dev_vec<double>(d_, (9 + 2 * (size_t)D) * f.ns);
   f.on = 1;
 }
 
@@ -531,10 +540,12 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   auto dv = [&](size_t cnt) { return dev_vec<double>(d_, cnt); };
   d_.q = dv(n); d_.l = dv(m); d_.u = dv(m); d_.D = dv(n); d_.Dinv = dv(n); d_.E = dv(m); d_.Einv = dv(m);
   d_.rho = dv(m); d_.rho_inv = dv(m); d_.ctype = dev_vec<int>(d_, m);
-  d_.x = dv(n); d_.z = dv(m); d_.y = dv(m); d_.dx = dv(n); d_.dy = dv(m); d_.xs = dv(n); d_.zt = dv(m); d_.t0 = dv(m); d_.v = dv(m);
+  d_.x = dv(n); d_.z = dv(m); d_.y = dv(m); d_.dx = dv(n); d_.dy = dv(m); d_.zt = dv(m); d_.t0 = dv(m); d_.v = dv(m);
   d_.xg = dv(n); d_.xsp = dv(n); d_.ztg = dv(m);
   { const char *f = std::getenv("OSQP_HIP_EXTRAP"); d_.theta = f ? std::atof(f) : 0.9; }     // PCG start extrapolation (backend.h Dev::xg)
-  d_.r = dv(n); d_.uu = dv(n); d_.p = dv(n); d_.s = dv(n); d_.w = dv(n); d_.t = dv(m); d_.Minv = dv(n); d_.uu2 = dv(n); d_.ms = dv(2 * (size_t)n);
+  d_.uu = dv(n); d_.w = dv(n); d_.t = dv(m); d_.uu2 = dv(n); d_.ms = dv(2 * (size_t)n);
+  if (d_.f1.on) { const size_t ns = d_.f1.ns; double *va = d_.f1.va; d_.Minv = va; d_.xs = va + ns; d_.p = va + 2 * ns; d_.r = va + 3 * ns; d_.s = va + 5 * ns; }   // backend.h DevF1::va
+  else { d_.r = dv(n); d_.p = dv(n); d_.s = dv(n); d_.Minv = dv(n); d_.xs = dv(n); }
   d_.part = dv((size_t)kPartSlots * kGrid); d_.res = dv(R_COUNT); d_.scal = dv(S_HIST + 3 * (kMaxCg + 1)); d_.flags = dev_vec<int>(d_, F_COUNT); d_.slot = dev_vec<int>(d_, be::kSlotInts);
   if (dev_asm) {
     // the caller's values go up once, in their own (CSC) order; every later (re)assembly and the equilibration run on the device

@@ -14,7 +14,7 @@ rows.sort()
 st = np.array([r[0] for r in rows], dtype=np.int64); en = np.array([r[1] for r in rows], dtype=np.int64)
 names = [r[2] for r in rows]
 # analyse the span from the first to the last slot kernel (the solves), skipping setup
-idx = [i for i, nm in enumerate(names) if 'k_slot_' in nm]
+idx = [i for i, nm in enumerate(names) if 'k_slot' in nm]
 lo, hi = idx[0], idx[-1]
 st, en, names = st[lo:hi + 1], en[lo:hi + 1], names[lo:hi + 1]
 busy = (en - st).sum(); span = en[-1] - st[0]
@@ -25,8 +25,10 @@ for lo_us, hi_us in ((0, 2), (2, 5), (5, 20), (20, 100), (100, 1000), (1000, 1e9
     sel = (gaps >= lo_us * 1e3) & (gaps < hi_us * 1e3)
     print('  gaps %6g - %6g us: %6d, total %.2f ms' % (lo_us, hi_us, sel.sum(), gaps[sel].sum() / 1e6))
 dur = en - st
-for key in ('k_slot_a', 'k_slot_b'):
+for key in ('k_slot_a', 'k_slot_b', 'k_slot1'):
     d = np.array([dur[i] for i, nm in enumerate(names) if key in nm])
+    if len(d) == 0:
+        continue
     print('  %s: %d launches, total %.2f ms, median %.2f us; under 3 us (nothing to do): %d launches, %.2f ms' % (key, len(d), d.sum() / 1e6, np.median(d) / 1e3, (d < 3000).sum(), d[d < 3000].sum() / 1e6))
     print('    duration histogram (us):', ' '.join('%g-%g:%d' % (a, b, ((d >= a * 1e3) & (d < b * 1e3)).sum()) for a, b in ((0, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10), (10, 12), (12, 1e6))))
 big = np.argsort(-gaps)[:12]
