@@ -267,6 +267,46 @@ OSQPInt osqp_hip_linsys_init(OSQPHipLinSysSolver **self, const OSQPCscMatrix *P,
                              const OSQPSettings *settings, const OSQPFloat *scaled_prim_res, const OSQPFloat *scaled_dual_res,
                              OSQPInt polishing);
 
+/* ---- engine policy (no reference analogue) ----------------------------------------------------------------------------------
+ * Everything this engine decides beyond OSQPSettings, PER SOLVER HANDLE: which kernel forms it may use, the rules it adds to the
+ * reference's ADMM loop on the indirect path (DESIGN.md sections 2, 2.1, 2.2) and how it schedules its launches.  Defaults =
+ * osqp_hip_default_policy(); a new handle starts from the defaults overridden by OSQP_HIP_* environment variables (experiments and
+ * A/B runs; read in ONE place, Engine's policy_from_env(), when the handle is created and -- the run-time fields -- at every solve
+ * until osqp_hip_set_policy() has been called on it).  osqp_hip_set_policy() changes a handle's policy; fields marked [setup] only
+ * matter to handles created afterwards through osqp_hip_set_default_policy() (process-wide default for the NEXT osqp_setup calls of
+ * the calling thread), because they choose data structures built at setup. */
+typedef struct {
+  /* kernel forms */
+  OSQPInt graph;              /* replay captured launch strings (hipGraph) instead of enqueuing them one by one                 [setup] */
+  OSQPInt slots;              /* device-side scheduling of the ADMM / PCG phases ("slot" kernels)                               [setup] */
+  OSQPInt pcg_fused;          /* 1: vector update fused into the SpMV kernels; 0: the three-kernel PCG iteration                [setup] */
+  OSQPInt f1;                 /* one launch per PCG iteration where the matrices allow it (banded A)                            [setup] */
+  OSQPInt window;             /* windowed row blocks (16-bit local column indices, input window in LDS)                         [setup] */
+  OSQPInt device_driven;      /* chunk boundaries (termination test, adaptive rho, PCG tolerance / budget) decided on the device */
+  OSQPInt small_direct;       /* small QPs: the whole solve as ONE launch of the batch kernel's direct (banded LDL') variant */
+  OSQPInt batch_reorder;      /* batch solves: launch the problems in the order of the previous call's iteration counts */
+  OSQPInt batch_variant;      /* 0 automatic; 1 direct (one wave), 2 direct256, 3 w64 (PCG), 4 w256 (PCG), 5 generic -- if applicable */
+  /* rules on top of the reference's loop */
+  OSQPFloat extrap;           /* PCG start = x~ + extrap * (x~ - x~_prev)  (0: the previous x~)                                  [setup] */
+  OSQPFloat rho_eq_factor;    /* equality-row weight on problems with inequality rows; 0 = automatic (10, or 1e3 for n <= 256)   [setup] */
+  OSQPInt rho_window;         /* ADMM iterations before an adaptation point that run with a tighter PCG tolerance (0: none) */
+  OSQPFloat rho_window_tol;   /* ... tolerance factor of that window */
+  OSQPInt rho_persist;        /* apply a rho estimate that stays on one side of rho at two consecutive adaptation points */
+  OSQPFloat rho_tol_exp;      /* adaptive_rho_tolerance is spent as tolerance^rho_tol_exp on QPs (1 = the setting's literal value) */
+  OSQPFloat budget_tolerate, budget_sigma; OSQPInt budget_slack, budget_full;   /* PCG limit per solve: mean + sigma * std of the last chunk (+ slack); full: never below cg_max_iter */
+  OSQPInt cg_escalate;        /* double cg_max_iter while the inner solver stagnates; checkpointed first chunk */
+  OSQPInt stall;              /* drop the PCG tolerance while the iterates run away (unbounded problems) */
+  /* scheduling of the launch strings (results never depend on these) */
+  OSQPInt slot_poll; OSQPInt poll_low; OSQPFloat poll_first, poll_frac, poll_wait;      /* host-synchronous chunks: top-ups from polled progress */
+  OSQPInt units_ahead; OSQPInt poll_sleep_us; OSQPFloat unit_margin;                    /* device-driven chunks: strings kept in the queue, poll pause, over-provisioning */
+  /* diagnostics */
+  OSQPInt slot_log, setup_timing, batch_timing;
+} OSQPHipPolicy;
+void    osqp_hip_default_policy(OSQPHipPolicy *policy);
+OSQPInt osqp_hip_set_policy(OSQPSolver *solver, const OSQPHipPolicy *policy);
+OSQPInt osqp_hip_get_policy(OSQPSolver *solver, OSQPHipPolicy *policy);
+void    osqp_hip_set_default_policy(const OSQPHipPolicy *policy);      /* NULL: back to osqp_hip_default_policy() + environment */
+
 /* Diagnostic builds only (make TRACE=1: kernels stamp the wall clock per workgroup and phase, 16 slots per workgroup):
  * copies the stamps of the most recent launches.  The product library returns OSQP_FUNC_NOT_IMPLEMENTED. */
 OSQPInt osqp_hip_trace_read(OSQPSolver *solver, unsigned long long *out, OSQPInt count);

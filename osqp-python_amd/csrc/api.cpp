@@ -87,6 +87,10 @@ OSQPInt osqp_hip_time_kernel(OSQPSolver *s, OSQPInt which, OSQPInt reps, double 
 OSQPInt osqp_hip_trace_read(OSQPSolver *s, unsigned long long *out, OSQPInt count) { return guarded(s, [&](Engine &e) { return e.trace_read(out, count); }); }
 OSQPInt osqp_hip_test_spmv(OSQPSolver *s, OSQPInt which, const OSQPFloat *in, OSQPFloat *out) { return guarded(s, [&](Engine &e) { return e.test_spmv(which, in, out); }); }
 OSQPInt osqp_hip_set_rho_eq_factor(OSQPSolver *s, OSQPFloat f) { return guarded(s, [&](Engine &e) { return e.set_rho_eq_factor(f); }); }
+void osqp_hip_default_policy(OSQPHipPolicy *p) { Engine::default_policy(p); }
+void osqp_hip_set_default_policy(const OSQPHipPolicy *p) { Engine::set_default_policy(p); }
+OSQPInt osqp_hip_set_policy(OSQPSolver *s, const OSQPHipPolicy *p) { return guarded(s, [&](Engine &e) { return e.set_policy(p); }); }
+OSQPInt osqp_hip_get_policy(OSQPSolver *s, OSQPHipPolicy *p) { return guarded(s, [&](Engine &e) { return e.get_policy(p); }); }
 OSQPInt osqp_hip_batch_solve(OSQPSolver *s, OSQPInt nbatch, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u, OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm) {
   return guarded(s, [&](Engine &e) { return e.batch_solve(nbatch, q, l, u, x, y, rec, warm); });
 }

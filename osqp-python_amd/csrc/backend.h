@@ -110,8 +110,10 @@ enum FlagId { F_DONE = 0, F_ITERS, F_STAT_SUM, F_STAT_MAX, F_STAT_UNCONV, F_STAT
 // indices into the fp64 scalar block
 enum ScalId { S_TOL_REL = 0, S_TOL_ABS, S_TOL_NOW, S_RN0 /* ||r_0||_inf of the current PCG */, S_RN0H /* the same by parity of the ADMM iteration (slot form): [2] */, S_HIST = 8 /* gamma[kMaxCg+1], alpha[kMaxCg+1], beta[kMaxCg+1] */ };
 
+struct Ctl;       // policy.h: the state block of the chunk-boundary rules (device-driven solves keep one in device memory)
 struct Dev {
   int n = 0, m = 0, device = 0;
+  Ctl *ctl = nullptr;            // device copy of the driver's state block (nullptr: boundaries are processed by the host)
   double sigma = 0, alpha = 0;
   double rho_eq_factor = 1e3;    // rho_i = rho_eq_factor * rho_bar on equality rows (_osqp.py:27 uses 1e3; see engine.cpp)
   DevCsr A, B;
@@ -178,6 +180,7 @@ struct BatchParams {
                                 // problems otherwise; Engine::batch_solve keeps the order of the previous call's iteration counts)
   double *zs = nullptr;         // optional, SCALED z iterates [nbatch][m]: read as the start when warm (a continued solve keeps its z, _osqp.py:1197-1204),
                                 // written at the end (single-QP path: the handle's own d.z)
+  int variant = 0;              // 0: automatic choice of the kernel variant; 1-5 force one (OSQPHipPolicy::batch_variant)
   int polish = 0, refine = 0;   // direct variants: polish a SOLVED problem in the kernel (reduced KKT on the active set + refine refinement steps)
   double delta = 1e-6;          // polish regularisation (_osqp.py:1740-1754)
   // Direct linear solve (banded Cholesky of K = P + sigma I + A' diag(rho) A under a bandwidth-reducing symmetric
@@ -249,6 +252,15 @@ int slot_seq(Dev &d);                      // slots executed since slot_begin (c
 //   F1 form          pcg + 3       KB, F_0, F_1 .. F_pcg, KA (run by the launch whose scalar fold detects convergence)
 inline double slot_launches(const Dev &d, double pcg) { return d.f1.on ? pcg + 3.0 : 2.0 * (pcg + 2.0); }
 void f1_refresh(Dev &d);                   // f1.pval <- B.val (no-op without a plan)
+// ---- device-driven chunk boundaries (policy.h; backend_hip.hip "boundary kernels").  The host uploads the state block once per solve,
+// then only feeds launches: strings of slot launches and, after each chunk's worth, one boundary group -- conditional residual
+// kernels, k_decide (the rules of policy.h on the device: termination, rho, tolerance, budget, next chunk), conditional rho update.
+bool ctl_supported(const Dev &d);
+void ctl_upload(Dev &d, const Ctl &c);     // host -> device copy of the state block (stream-ordered)
+void ctl_begin(Dev &d);                    // start the chunk the state block describes (slot record, PCG tolerance, statistics reset)
+void ctl_group(Dev &d, int diagonal);      // enqueue one boundary group (diagonal: the Jacobi preconditioner follows rho)
+void ctl_poll(Dev &d, Ctl *out, int *seq); // snapshot of the state block + slots executed, read on the side stream WITHOUT waiting for d.stream
+void ctl_download(Dev &d, Ctl *out);       // after a stream synchronisation
 constexpr int kSlotInts = 24;  // Dev::slot: two phase records of 8 words + the chunk epoch
 void slot_poll(Dev &d, int *seq, int *done); // the same two numbers of the RUNNING chunk, read on a side stream without waiting for the launches
 

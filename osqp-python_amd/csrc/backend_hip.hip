@@ -26,6 +26,7 @@
 
 #include "../../include/osqp_hip.h"
 #include "backend.h"
+#include "policy.h"
 
 namespace osqp_hip {
 namespace be {
@@ -68,6 +69,7 @@ struct Impl {
   int *pin_flags = nullptr;      // [F_COUNT + 16]: the flags block followed by the two slot records
   hipStream_t side = nullptr;    // slot_poll(): reads the slot records while the chunk's launches are still running on d.stream
   int *pin_poll = nullptr;       // [kSlotInts]
+  Ctl *pin_ctl = nullptr, *pin_ctl2 = nullptr;   // staging of the state block (upload / poll + download)
   int epoch = 0;                 // chunks begun (slot_begin); the device copy sits behind the two records
 };
 inline Impl &im(Dev &d) { return *static_cast<Impl *>(d.impl); }
@@ -970,7 +972,7 @@ __global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
 // KA with the PCG statistics taken from the slot record (used iterations; conv = 0: the PCG stopped at the cap -- did its last
 // iterate reach the tolerance anyway?)
 template <class L>
-__device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv, const FirstDesc &fd, int admm) {
+__device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv, const FirstDesc &fd, int admm, int target) {
   double theta = d.theta, rn_last = 0.0, bn_last = 0.0;
   if (!conv) { theta = cutoff_theta(d, used & 1, lds.red, rn_last, bn_last, admm); __syncthreads(); }      // (conv comes from the slot record: uniform)
   GVec g{d.xs};
@@ -992,6 +994,7 @@ __device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv
       d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;
       if (used > d.flags[F_STAT_MAX]) d.flags[F_STAT_MAX] = used;
       if (!conv) d.flags[F_STAT_UNCONV] += 1;
+      if (d.ctl && admm + 1 >= target) d.ctl->chunk_done = 1;      // device-driven boundaries: the chunk's last ADMM iteration (read by LATER launches)
     }
   }
 }
@@ -1007,7 +1010,7 @@ __global__ __launch_bounds__(kBlock) void k_slot_a(Dev d) {
     if (process_rows_fd<1>(d.A, g, e, lds.k1, PreK1{d, 0, 0, lds.k1.red, st.admm & 1}, fd)) { st.ph = P_K2F; st.k = 0; }
     else {                                             // the warm start already meets the tolerance: no PCG iteration, KA right here
       __syncthreads();
-      slot_ka(d, lds.k1, 0, 1, fd, st.admm);
+      slot_ka(d, lds.k1, 0, 1, fd, st.admm, st.target);
       st.ph = P_KB; st.admm += 1;
     }
   } else if (st.ph == P_K1F) {
@@ -1029,7 +1032,7 @@ __global__ __launch_bounds__(kBlock) void k_slot_a(Dev d) {
     if (i >= st.cap) { st.ph = P_KA; st.used = i; st.conv = 0; }      // the PCG stops at the cap; the next A slot runs KA
     else { st.ph = P_K2F; st.k = i; }
   } else if (st.ph == P_KA) {
-    slot_ka(d, lds.k1, st.used, st.conv, fd, st.admm);
+    slot_ka(d, lds.k1, st.used, st.conv, fd, st.admm, st.target);
     st.ph = P_KB; st.admm += 1;
   }
   slot_write(W, st);
@@ -1356,11 +1359,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
       else st.k += 1;
     } else {                                             // converged: KA right here
       __syncthreads();
-      slot_ka(d, lds.ka, st.k == 0 ? 0 : st.k - 1, 1, first_desc<true>(d.A), st.admm);
+      slot_ka(d, lds.ka, st.k == 0 ? 0 : st.k - 1, 1, first_desc<true>(d.A), st.admm, st.target);
       st.ph = P_KB; st.admm += 1;
     }
   } else if (st.ph == P_KA) {
-    slot_ka(d, lds.ka, st.used, st.conv, first_desc<true>(d.A), st.admm);
+    slot_ka(d, lds.ka, st.used, st.conv, first_desc<true>(d.A), st.admm, st.target);
     st.ph = P_KB; st.admm += 1;
   }
   slot_write(W, st);
@@ -1380,8 +1383,11 @@ struct EKr1 : NoPrefetch {
     else if (yi < 0.0 && li > -OSQP_INFTY * 1e-4) sup += li * yi;
   }
 };
-__global__ __launch_bounds__(kBlock) void k_res_m(Dev d) {
+// cond != 0 (boundary group of a device-driven solve): run only when the chunk has finished at a termination check / adaptation point
+__device__ __forceinline__ bool ctl_res_due(const Dev &d) { return d.ctl->chunk_done && d.ctl->ch_at_check && d.ctl->status == CTL_RUNNING; }
+__global__ __launch_bounds__(kBlock) void k_res_m(Dev d, int cond) {
   __shared__ StreamLdsW<1, double> lds;
+  if (cond && !ctl_res_due(d)) return;
   GVec g{d.x};
   EKr1 e{{}, d.z, d.y, d.dy, d.l, d.u, d.E, d.Einv};
   process_rows<1>(d.A, g, e, lds);
@@ -1412,8 +1418,9 @@ struct EKr2 : NoPrefetch {
     xpx += xj * px; qx += qj * xj; qdx += qj * dxj;
   }
 };
-__global__ __launch_bounds__(kBlock) void k_res_n(Dev d) {
+__global__ __launch_bounds__(kBlock) void k_res_n(Dev d, int cond) {
   __shared__ StreamLds<2> lds;
+  if (cond && !ctl_res_due(d)) return;
   GTwo g{d.x, d.y, d.n};
   EKr2 e{{}, d.x, d.q, d.dx, d.D, d.Dinv, d.sigma};
   process_rows<2>(d.B, g, e, lds);
@@ -1432,8 +1439,9 @@ __device__ __forceinline__ bool res_is_sum(int q) {
   return q == R_PINF_LHS || q == R_SUPP || q == R_XPX || q == R_QX || q == R_QDX || q == R_ADX_VIOL;
 }
 // final reduction of the per-workgroup partials: workgroup b handles quantity q0 + b
-__global__ __launch_bounds__(kBlock) void k_res_final(Dev d, int q0) {
+__global__ __launch_bounds__(kBlock) void k_res_final(Dev d, int q0, int cond) {
   __shared__ double sred[2 * kWaves];
+  if (cond && !ctl_res_due(d)) return;
   const int q = q0 + blockIdx.x;
   const double *slot = d.part + (SL_RES0 + q) * kGrid;
   const double v = res_is_sum(q) ? partial_sum(slot, sred) : partial_max(slot, sred);
@@ -1483,7 +1491,8 @@ __global__ __launch_bounds__(kBlock) void k_inf_dual_a(Dev d, double thr, int un
 }
 
 // ---------------------------------------------------------------------------------------------- rho / preconditioner / init
-__global__ __launch_bounds__(kBlock) void k_set_rho(Dev d, double rho_bar) {
+__global__ __launch_bounds__(kBlock) void k_set_rho(Dev d, double rho_bar, int cond) {
+  if (cond) { if (!d.ctl->rho_flag) return; rho_bar = d.ctl->rho_bar; }        // boundary group: rho_bar as k_decide left it
   const int stride = gridDim.x * kBlock;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += stride) {
     const int t = d.ctype[i];
@@ -1495,8 +1504,9 @@ __global__ __launch_bounds__(kBlock) void k_set_rho(Dev d, double rho_bar) {
 }
 struct GPrec { const double *rho; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = c >= n ? rho[c - n] * a * a : 0.0; } };
 struct EPrec : NoPrefetch { const double *Bval; const int *Bdiag; double *Minv; __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { Minv[j] = 1.0 / (Bval[Bdiag[j]] + s[0]); } };
-__global__ __launch_bounds__(kBlock) void k_precond(Dev d) {
+__global__ __launch_bounds__(kBlock) void k_precond(Dev d, int cond) {
   __shared__ StreamLds<1> lds;
+  if (cond && !d.ctl->rho_flag) return;
   GPrec g{d.rho, d.n};
   EPrec e{{}, d.B.val, d.Bdiag, d.Minv};
   process_rows<1>(d.B, g, e, lds);
@@ -1509,7 +1519,8 @@ __global__ __launch_bounds__(kBlock) void k_init_n(Dev d) {
   const int stride = gridDim.x * kBlock;
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) { d.xs[j] = d.x[j]; d.dx[j] = 0.0; }
 }
-__global__ __launch_bounds__(kBlock) void k_init_guess(Dev d) {      // no history: the next PCG starts from x~ itself
+__global__ __launch_bounds__(kBlock) void k_init_guess(Dev d, int cond) {      // no history: the next PCG starts from x~ itself
+  if (cond && !d.ctl->rho_flag) return;
   const int stride = gridDim.x * kBlock;
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) { const double v = d.xs[j]; d.xg[j] = v; d.xsp[j] = v; }
 }
@@ -1659,6 +1670,51 @@ __global__ __launch_bounds__(kBlock) void k_ruiz_finish(Dev d, double sigma) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += stride) d.Einv[i] = 1.0 / d.E[i];
 }
 
+// ---------------------------------------------------------------------------------------------- boundary kernels (device-driven solves)
+// The chunk described by the state block starts: phase record A (read by the next slot launch: strings are enqueued in pairs, so
+// the launch after a boundary group has parity 0), PCG tolerance, statistics.  seq carries on across the chunks of a solve.
+__device__ __forceinline__ void ctl_begin_chunk(const Dev &d, const Ctl &c, int seq) {
+  int *r = d.slot;
+  r[SR_PHASE] = P_KB; r[SR_K] = 0; r[SR_ADMM] = 0; r[SR_TARGET] = c.ch_next - c.iter; r[SR_USED] = 0; r[SR_CONV] = 0;
+  r[SR_CAP] = c.budget[c.ch_tight]; r[SR_SEQ] = seq;
+  r[SR_WORDS + SR_SEQ] = seq - 1; r[SR_WORDS + SR_ADMM] = 0;      // (record A is the newer one)
+  d.scal[S_TOL_REL] = c.tol_rel; d.scal[S_TOL_ABS] = ctl_chunk_tol_abs(c);
+  for (int q = F_STAT_SUM; q < F_COUNT; q++) d.flags[q] = 0;
+}
+__global__ void k_ctl_begin(Dev d, int epoch) {
+  Ctl &c = *d.ctl;
+  c.chunk_done = 0; c.rho_flag = 0; c.status = CTL_RUNNING;
+  ctl_begin_chunk(d, c, 0);
+  d.slot[2 * SR_WORDS] = epoch;
+}
+// The rules of policy.h at a finished chunk.  One wave: the state block, the residual block and the statistics are staged in LDS
+// (coalesced), lane 0 runs the rules on the LDS copy, the block goes back coalesced.
+__global__ __launch_bounds__(64) void k_decide(Dev d) {
+  __shared__ Ctl c;
+  __shared__ double res[R_COUNT];
+  __shared__ int fl[F_COUNT];
+  Ctl *g = d.ctl;
+  if (!(g->chunk_done && g->status == CTL_RUNNING)) return;            // the chunk has not finished (short string), or the solve has
+  static_assert(sizeof(Ctl) % sizeof(int) == 0, "Ctl is copied word by word");
+  constexpr int W = sizeof(Ctl) / sizeof(int);
+  const int *gi = reinterpret_cast<const int *>(g);
+  int *ci = reinterpret_cast<int *>(&c);
+  for (int i = threadIdx.x; i < W; i += 64) ci[i] = gi[i];
+  for (int i = threadIdx.x; i < R_COUNT; i += 64) res[i] = d.res[i];
+  for (int i = threadIdx.x; i < F_COUNT; i += 64) fl[i] = d.flags[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    c.chunk_done = 0;
+    for (int q = 0; q < F_COUNT; q++) c.last_flags[q] = fl[q];
+    const int st = ctl_boundary(c, res, fl);
+    c.status = st;
+    if (st == CTL_RUNNING) ctl_begin_chunk(d, c, d.slot[SR_SEQ]);       // (record A: written by the last slot launch of the string)
+  }
+  __syncthreads();
+  int *go = reinterpret_cast<int *>(g);
+  for (int i = threadIdx.x; i < W; i += 64) go[i] = ci[i];
+}
+
 #define LAUNCH(kernel, d, ...) hipLaunchKernelGGL(kernel, dim3(kGrid), dim3(kBlock), 0, st(d), __VA_ARGS__)
 
 }  // namespace
@@ -1684,6 +1740,8 @@ int init(Dev &d, int device) {
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_flags), sizeof(int) * (F_COUNT + 16), hipHostMallocDefault));
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_poll), sizeof(int) * kSlotInts, hipHostMallocDefault));
   HIP_CHECK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+  HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_ctl), sizeof(Ctl), hipHostMallocDefault));
+  HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_ctl2), sizeof(Ctl), hipHostMallocDefault));
   d.impl = p;
   return OSQP_NO_ERROR;
 }
@@ -1693,6 +1751,7 @@ void destroy(Dev &d) {
   Impl &p = im(d);
   (void)hipEventDestroy(p.ev0); (void)hipEventDestroy(p.ev1); (void)hipEventDestroy(p.ev_ext); (void)hipHostFree(p.pin_res); (void)hipHostFree(p.pin_flags);
   (void)hipHostFree(p.pin_poll); if (p.side) (void)hipStreamDestroy(p.side);
+  (void)hipHostFree(p.pin_ctl); (void)hipHostFree(p.pin_ctl2);
   delete &p; d.impl = nullptr;
   if (d.stream) { (void)hipStreamDestroy(st(d)); d.stream = nullptr; }
 }
@@ -1766,22 +1825,59 @@ void slot_poll(Dev &d, int *seq, int *done) {
   *seq = nw[SR_SEQ]; *done = nw[SR_ADMM];
 }
 
+bool ctl_supported(const Dev &d) { return d.ctl != nullptr && d.slot != nullptr; }
+void ctl_upload(Dev &d, const Ctl &c) {
+  HIP_CHECK(hipSetDevice(d.device));
+  Impl &p = im(d);
+  std::memcpy(p.pin_ctl, &c, sizeof(Ctl));
+  HIP_CHECK(hipMemcpyAsync(d.ctl, p.pin_ctl, sizeof(Ctl), hipMemcpyHostToDevice, st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));          // (the staging buffer is reused)
+}
+void ctl_begin(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); hipLaunchKernelGGL(k_ctl_begin, dim3(1), dim3(1), 0, st(d), d, ++im(d).epoch); }
+void ctl_group(Dev &d, int diagonal) {
+  LAUNCH(k_res_m, d, d, 1);
+  LAUNCH(k_res_n, d, d, 1);
+  hipLaunchKernelGGL(k_res_final, dim3(R_QN_U + 1), dim3(kBlock), 0, st(d), d, 0, 1);
+  hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, st(d), d);
+  LAUNCH(k_set_rho, d, d, 0.0, 1);
+  LAUNCH(k_init_guess, d, d, 1);
+  if (diagonal) LAUNCH(k_precond, d, d, 1);
+}
+void ctl_poll(Dev &d, Ctl *out, int *seq) {
+  HIP_CHECK(hipSetDevice(d.device));
+  Impl &p = im(d);
+  HIP_CHECK(hipMemcpyAsync(p.pin_ctl2, d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, p.side));
+  HIP_CHECK(hipMemcpyAsync(p.pin_poll, d.slot, sizeof(int) * kSlotInts, hipMemcpyDeviceToHost, p.side));
+  HIP_CHECK(hipStreamSynchronize(p.side));
+  std::memcpy(out, p.pin_ctl2, sizeof(Ctl));
+  if (p.pin_poll[2 * SR_WORDS] != p.epoch) { *seq = 0; out->status = CTL_RUNNING; return; }      // k_ctl_begin has not run yet
+  const int *ra = p.pin_poll, *rb = p.pin_poll + SR_WORDS;
+  *seq = ra[SR_SEQ] >= rb[SR_SEQ] ? ra[SR_SEQ] : rb[SR_SEQ];
+}
+void ctl_download(Dev &d, Ctl *out) {
+  HIP_CHECK(hipSetDevice(d.device));
+  Impl &p = im(d);
+  HIP_CHECK(hipMemcpyAsync(p.pin_ctl2, d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  std::memcpy(out, p.pin_ctl2, sizeof(Ctl));
+}
+
 void residuals(Dev &d) {
   HIP_CHECK(hipSetDevice(d.device));
-  LAUNCH(k_res_m, d, d);
-  LAUNCH(k_res_n, d, d);
-  hipLaunchKernelGGL(k_res_final, dim3(R_QN_U + 1), dim3(kBlock), 0, st(d), d, 0);
+  LAUNCH(k_res_m, d, d, 0);
+  LAUNCH(k_res_n, d, d, 0);
+  hipLaunchKernelGGL(k_res_final, dim3(R_QN_U + 1), dim3(kBlock), 0, st(d), d, 0, 0);
 }
 void infeas_primal(Dev &d) {
   HIP_CHECK(hipSetDevice(d.device));
   LAUNCH(k_inf_primal, d, d);
-  hipLaunchKernelGGL(k_res_final, dim3(2), dim3(kBlock), 0, st(d), d, (int)R_ATDY_U);
+  hipLaunchKernelGGL(k_res_final, dim3(2), dim3(kBlock), 0, st(d), d, (int)R_ATDY_U, 0);
 }
 void infeas_dual(Dev &d, double thr, int unscaled) {
   HIP_CHECK(hipSetDevice(d.device));
   LAUNCH(k_inf_dual_p, d, d);
   LAUNCH(k_inf_dual_a, d, d, thr, unscaled);
-  hipLaunchKernelGGL(k_res_final, dim3(3), dim3(kBlock), 0, st(d), d, (int)R_PDX_U);
+  hipLaunchKernelGGL(k_res_final, dim3(3), dim3(kBlock), 0, st(d), d, (int)R_PDX_U, 0);
 }
 void fetch_res(Dev &d, double *h) {
   HIP_CHECK(hipSetDevice(d.device));
@@ -1808,10 +1904,10 @@ void fetch_res_flags(Dev &d, double *hr, int *hf) {
   std::memcpy(hf, im(d).pin_flags, sizeof(int) * F_COUNT);
 }
 
-void set_rho(Dev &d, double rho_bar) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_set_rho, d, d, rho_bar); LAUNCH(k_init_guess, d, d); }
+void set_rho(Dev &d, double rho_bar) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_set_rho, d, d, rho_bar, 0); LAUNCH(k_init_guess, d, d, 0); }
 void precond(Dev &d, int diagonal) {
   HIP_CHECK(hipSetDevice(d.device));
-  if (diagonal) LAUNCH(k_precond, d, d);
+  if (diagonal) LAUNCH(k_precond, d, d, 0);
   else LAUNCH(k_fill, d, d.Minv, d.n, 1.0);
 }
 void set_pcg_tol(Dev &d, double rel, double ab) {
@@ -1821,7 +1917,7 @@ void set_pcg_tol(Dev &d, double rel, double ab) {
 void init_iterates(Dev &d, int full) {
   HIP_CHECK(hipSetDevice(d.device));
   if (full) LAUNCH(k_init_n, d, d);                 // full = 2: x~ = x like 1, but the z iterate in place is kept (as full = 0 does)
-  LAUNCH(k_init_guess, d, d);
+  LAUNCH(k_init_guess, d, d, 0);
   LAUNCH(k_init_m, d, d, full == 1 ? 1 : 0);
 }
 

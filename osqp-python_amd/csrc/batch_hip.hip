@@ -792,7 +792,8 @@ BatchChoice choose_batch_variant(const BatchParams &p) {
   BatchChoice c{};
   const int mx = p.A.nnz > p.B.nnz ? p.A.nnz : p.B.nnz;
   c.lds_reg = batch_lds_bytes_nnz(p.n, p.m, mx); c.lds_gen = batch_lds_bytes(p.n, p.m);
-  const char *force = std::getenv("OSQP_HIP_BATCH_VARIANT");      // debugging: "direct", "direct256", "w64", "w256", "generic"
+  static const char *const names[] = {nullptr, "direct", "direct256", "w64", "w256", "generic"};      // OSQPHipPolicy::batch_variant (debugging / A-B runs)
+  const char *force = (p.variant >= 1 && p.variant <= 5) ? names[p.variant] : nullptr;
   c.e64 = (mx + 63) / 64; c.e256 = (mx + 255) / 256;
   const bool can64 = c.lds_reg && c.e64 <= 24 && p.n <= 1024 && p.m <= 2048, can256 = c.lds_reg && c.e256 <= 8;
   c.lds_dir = batch_direct_lds_bytes(p.n, p.m, mx, p.bw);

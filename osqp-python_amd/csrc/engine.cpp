@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <thread>
 #include <limits>
 
 namespace osqp_hip {
@@ -16,7 +18,6 @@ namespace osqp_hip {
 namespace {
 constexpr double kRhoMin = 1e-6, kRhoMax = 1e6, kRhoTol = 1e-4;   // _osqp.py:25-28 (RHO_EQ_OVER_RHO_INEQ = 1e3 is applied in the set_rho kernel)
 constexpr double kMinScaling = 1e-4, kMaxScaling = 1e4;                                 // _osqp.py:44-45
-constexpr double kCgTolAbsMin = 1e-13;
 const double kNaN = std::numeric_limits<double>::quiet_NaN();
 
 double now_s() {
@@ -63,13 +64,78 @@ std::vector<int> build_row_blocks(const std::vector<int> &rowptr, int nrows) {
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ policy
+// include/osqp_hip.h OSQPHipPolicy.  The ONLY place of the library that reads the environment is policy_from_env().
+namespace {
+thread_local OSQPHipPolicy g_default_policy;
+thread_local bool g_default_policy_set = false;
+
+// runtime_only: refresh the fields that may change between two solves of a handle (experiments switch OSQP_HIP_SMALL_DIRECT etc. at run time)
+void policy_from_env(OSQPHipPolicy &p, bool runtime_only) {
+  if (!runtime_only) { if (g_default_policy_set) p = g_default_policy; else Engine::default_policy(&p); }
+  auto on = [](const char *name, OSQPInt &v) { if (const char *e = std::getenv(name)) v = e[0] != '0'; };      // "0" switches off, anything else on
+  auto num = [](const char *name, OSQPInt &v) { if (const char *e = std::getenv(name)) v = std::atoi(e); };
+  auto real = [](const char *name, OSQPFloat &v) { if (const char *e = std::getenv(name)) v = std::atof(e); };
+  on("OSQP_HIP_SMALL_DIRECT", p.small_direct); on("OSQP_HIP_DEVICE_DRIVEN", p.device_driven); on("OSQP_HIP_BATCH_REORDER", p.batch_reorder);
+  num("OSQP_HIP_RHO_WINDOW", p.rho_window); real("OSQP_HIP_RHO_WINDOW_TOL", p.rho_window_tol); on("OSQP_HIP_RHO_PERSIST", p.rho_persist);
+  if (const char *e = std::getenv("OSQP_HIP_RHO_TOL_EXP")) { const double v = std::atof(e); p.rho_tol_exp = v > 0 && v <= 1 ? v : 0.5; }
+  real("OSQP_HIP_BUDGET_TOLERATE", p.budget_tolerate); real("OSQP_HIP_BUDGET_SIGMA", p.budget_sigma); num("OSQP_HIP_BUDGET_SLACK", p.budget_slack);
+  if (std::getenv("OSQP_HIP_BUDGET_FULL")) p.budget_full = 1;
+  on("OSQP_HIP_CG_ESCALATE", p.cg_escalate); on("OSQP_HIP_STALL", p.stall);
+  on("OSQP_HIP_SLOT_POLL", p.slot_poll); num("OSQP_HIP_POLL_LOW", p.poll_low); real("OSQP_HIP_POLL_FIRST", p.poll_first);
+  real("OSQP_HIP_POLL_FRAC", p.poll_frac); real("OSQP_HIP_POLL_WAIT", p.poll_wait);
+  num("OSQP_HIP_UNITS_AHEAD", p.units_ahead); num("OSQP_HIP_POLL_SLEEP_US", p.poll_sleep_us); real("OSQP_HIP_UNIT_MARGIN", p.unit_margin);
+  if (std::getenv("OSQP_HIP_SLOT_LOG")) p.slot_log = 1;
+  if (std::getenv("OSQP_HIP_BATCH_TIMING")) p.batch_timing = 1;
+  if (const char *e = std::getenv("OSQP_HIP_BATCH_VARIANT")) {
+    static const char *names[] = {"", "direct", "direct256", "w64", "w256", "generic"};
+    p.batch_variant = 0;
+    for (int k = 1; k <= 5; k++) if (!std::strcmp(e, names[k])) p.batch_variant = k;
+  }
+  if (runtime_only) return;
+  on("OSQP_HIP_GRAPH", p.graph); on("OSQP_HIP_SLOTS", p.slots); on("OSQP_HIP_PCG_FUSED", p.pcg_fused); on("OSQP_HIP_F1", p.f1); on("OSQP_HIP_WINDOW", p.window);
+  real("OSQP_HIP_EXTRAP", p.extrap);
+  if (const char *e = std::getenv("OSQP_HIP_RHO_EQ_FACTOR")) { const double v = std::atof(e); if (v >= 1.0) p.rho_eq_factor = v; }
+  if (std::getenv("OSQP_HIP_SETUP_TIMING")) p.setup_timing = 1;
+}
+}  // namespace
+
+void Engine::default_policy(OSQPHipPolicy *p) {
+  if (!p) return;
+  *p = OSQPHipPolicy();
+  p->graph = p->slots = p->pcg_fused = p->f1 = p->window = p->device_driven = p->small_direct = p->batch_reorder = 1; p->batch_variant = 0;
+  p->extrap = 0.9; p->rho_eq_factor = 0.0;
+  p->rho_window = 10; p->rho_window_tol = 0.1; p->rho_persist = 1; p->rho_tol_exp = 0.5;
+  p->budget_tolerate = 0.0; p->budget_sigma = 3.0; p->budget_slack = 0; p->budget_full = 0; p->cg_escalate = 1; p->stall = 1;
+  p->slot_poll = 1; p->poll_low = 6; p->poll_first = 0.8; p->poll_frac = 0.75; p->poll_wait = 0.7;
+  p->units_ahead = 2; p->poll_sleep_us = 30; p->unit_margin = 1.08;
+}
+void Engine::set_default_policy(const OSQPHipPolicy *p) {
+  g_default_policy_set = p != nullptr;
+  if (p) g_default_policy = *p;
+}
+int Engine::get_policy(OSQPHipPolicy *p) const { if (!p) return OSQP_DATA_VALIDATION_ERROR; *p = pol_; return OSQP_NO_ERROR; }
+int Engine::set_policy(const OSQPHipPolicy *p) {
+  if (!p) return OSQP_DATA_VALIDATION_ERROR;
+  if (!(p->extrap >= 0 && p->extrap <= 2) || p->rho_window < 0 || !(p->rho_window_tol > 0) || !(p->rho_tol_exp > 0 && p->rho_tol_exp <= 1) ||
+      !(p->budget_sigma >= 0) || p->units_ahead < 1 || !(p->unit_margin >= 1) || p->batch_variant < 0 || p->batch_variant > 5 ||
+      !(p->rho_eq_factor == 0 || p->rho_eq_factor >= 1))
+    return OSQP_SETTINGS_VALIDATION_ERROR;
+  const OSQPHipPolicy old = pol_;
+  pol_ = *p; pol_explicit_ = true;
+  // [setup] fields keep the value the handle was built with
+  pol_.slots = old.slots; pol_.pcg_fused = old.pcg_fused; pol_.f1 = old.f1; pol_.window = old.window;
+  if (pol_.graph != old.graph) { use_graph_ = pol_.graph != 0; if (dev_ready_) { be::activate(d_); be::sync(d_); drop_graphs(); } }
+  if (dev_ready_) d_.theta = pol_.extrap;
+  if (dev_ready_ && pol_.rho_eq_factor >= 1.0 && pol_.rho_eq_factor != old.rho_eq_factor) return set_rho_eq_factor(pol_.rho_eq_factor);
+  return OSQP_NO_ERROR;
+}
+
 Engine::Engine() {
   pub.settings = &settings; pub.solution = &solution; pub.info = &info; pub.work = reinterpret_cast<OSQPWorkspace *>(this);
-  const char *g = std::getenv("OSQP_HIP_GRAPH");
-  use_graph_ = !(g && g[0] == '0');
-  const char *sl = std::getenv("OSQP_HIP_SLOTS");
-  use_slots_ = !(sl && sl[0] == '0');
-  if (const char *f = std::getenv("OSQP_HIP_RHO_EQ_FACTOR")) { double v = std::atof(f); if (v >= 1.0) { eq_factor_mixed_ = v; eq_factor_env_ = true; } }
+  policy_from_env(pol_, false);
+  use_graph_ = pol_.graph != 0; use_slots_ = pol_.slots != 0;
+  if (pol_.rho_eq_factor >= 1.0) { eq_factor_mixed_ = pol_.rho_eq_factor; eq_factor_env_ = true; }
 }
 Engine::~Engine() { free_all(); }
 
@@ -95,7 +161,7 @@ void Engine::free_all() {
                   d_.q, d_.l, d_.u, d_.D, d_.Dinv, d_.E, d_.Einv, d_.rho, d_.rho_inv, d_.ctype, d_.x, d_.z, d_.y, d_.dx,
                   d_.dy, d_.xs, d_.xg, d_.xsp, d_.ztg, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.uu2, d_.ms, d_.part, d_.res,
                   d_.scal, d_.flags, d_.slot, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB,
-                  d_.f1.blk, d_.f1.ent, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.va};
+                  d_.ctl, d_.f1.blk, d_.f1.ent, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.va};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   be::destroy(d_);
   d_ = Dev();
@@ -290,11 +356,11 @@ void Engine::fill_matrix_values(const std::vector<double> &Px, const std::vector
 // every row block of A is windowed with a window of at most kF1Win columns and at most kF1MaxRows rows, the windows of blocks g and
 // g + D never overlap for some D <= kF1MaxD (banded / block-banded A), and each block's own columns -- [rb[g] n / m, rb[g+1] n / m):
 // for a banded A these lie inside the block's window -- number at most kF1MaxOwn with at most kF1PChunk entries of P + sigma I.
-// Anything else keeps the two-kernel form.  OSQP_HIP_F1=0 switches the plan off.
+// Anything else keeps the two-kernel form.  OSQPHipPolicy::f1 = 0 switches the plan off.
 void Engine::prepare_f1(const std::vector<int> &rb, const std::vector<int> &Arp, const std::vector<int> &Arj,
                         const std::vector<int> &Brp, const std::vector<int> &Bj) {
   d_.f1 = DevF1();
-  if (const char *e = std::getenv("OSQP_HIP_F1")) if (e[0] == '0') return;
+  if (!pol_.f1) return;
   const int nb = (int)rb.size() - 1;
   if (!be::device_assembly() || m == 0 || nb < kGrid / 4) return;      // (few blocks: most workgroups would idle in the vector update)
   std::vector<int> a0(nb), wl(nb);
@@ -369,7 +435,7 @@ void Engine::prepare_f1(const std::vector<int> &rb, const std::vector<int> &Arp,
 int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *A, const double *l, const double *u,
                   int m_, int n_, const OSQPSettings *s) {
   double t0 = now_s();
-  static const bool ptime = std::getenv("OSQP_HIP_SETUP_TIMING") != nullptr;
+  const bool ptime = pol_.setup_timing != 0;
   double tl = t0;
   auto lap = [&](const char *what) { if (ptime) { double t = now_s(); std::fprintf(stderr, "[osqp_hip setup] %-28s %8.2f ms\n", what, 1e3 * (t - tl)); tl = t; } };
   // ---- data validation (the C core's validate_data; error numbering bindings.cpp.in:364-375) ----
@@ -487,9 +553,9 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
     return d;
   };
 
-  // column windows of the (short-row) blocks, see DevCsr::blkwin.  OSQP_HIP_WINDOW=0 turns the windowed path off (A/B runs).
-  static const bool win_on = [] { const char *e = std::getenv("OSQP_HIP_WINDOW"); return !(e && e[0] == '0'); }();
-  auto windows = [](const std::vector<int> &rb, const std::vector<int> &rp, const std::vector<int> &cj, int split,
+  // column windows of the (short-row) blocks, see DevCsr::blkwin.  OSQPHipPolicy::window = 0 turns the windowed path off (A/B runs).
+  const bool win_on = pol_.window != 0;
+  auto windows = [win_on](const std::vector<int> &rb, const std::vector<int> &rp, const std::vector<int> &cj, int split,
                     std::vector<int> &win, std::vector<unsigned short> &lcol) {
     const size_t nb = rb.size() - 1;
     win.assign(4 * nb, 0); lcol.assign(std::max<size_t>(cj.size(), 1), 0);
@@ -534,7 +600,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   d_.Bdiag = up_i(bdiag);
   up_win(d_.A, rbA, Arp, Arj, n); up_win(d_.B, rbB, Brp, Bj, n);
   lap("upload structure");
-  { const char *f = std::getenv("OSQP_HIP_PCG_FUSED"); d_.fused = (f && f[0] == '0') ? 0 : 1; }   // default on; =0 selects the 3-kernel sequence
+  d_.fused = pol_.pcg_fused ? 1 : 0;                 // 0 selects the 3-kernel sequence
   if (d_.fused && use_slots_ && d_.A.nwin == d_.A.nblk) prepare_f1(rbA, Arp, Arj, Brp, Bj);
   lap("F1 plan");
   auto dv = [&](size_t cnt) { return dev_vec<double>(d_, cnt); };
@@ -542,11 +608,12 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   d_.rho = dv(m); d_.rho_inv = dv(m); d_.ctype = dev_vec<int>(d_, m);
   d_.x = dv(n); d_.z = dv(m); d_.y = dv(m); d_.dx = dv(n); d_.dy = dv(m); d_.zt = dv(m); d_.t0 = dv(m); d_.v = dv(m);
   d_.xg = dv(n); d_.xsp = dv(n); d_.ztg = dv(m);
-  { const char *f = std::getenv("OSQP_HIP_EXTRAP"); d_.theta = f ? std::atof(f) : 0.9; }     // PCG start extrapolation (backend.h Dev::xg)
+  d_.theta = pol_.extrap;                            // PCG start extrapolation (backend.h Dev::xg)
   d_.uu = dv(n); d_.w = dv(n); d_.t = dv(m); d_.uu2 = dv(n); d_.ms = dv(2 * (size_t)n);
   if (d_.f1.on) { const size_t ns = d_.f1.ns; double *va = d_.f1.va; d_.Minv = va; d_.xs = va + ns; d_.p = va + 2 * ns; d_.r = va + 3 * ns; d_.s = va + 5 * ns; }   // backend.h DevF1::va
   else { d_.r = dv(n); d_.p = dv(n); d_.s = dv(n); d_.Minv = dv(n); d_.xs = dv(n); }
   d_.part = dv((size_t)kPartSlots * kGrid); d_.res = dv(R_COUNT); d_.scal = dv(S_HIST + 3 * (kMaxCg + 1)); d_.flags = dev_vec<int>(d_, F_COUNT); d_.slot = dev_vec<int>(d_, be::kSlotInts);
+  d_.ctl = be::device_assembly() ? static_cast<Ctl *>(be::alloc(d_, sizeof(Ctl))) : nullptr;      // (the host simulator processes every boundary on the host)
   if (dev_asm) {
     // the caller's values go up once, in their own (CSC) order; every later (re)assembly and the equilibration run on the device
     std::vector<int> Pj(nzP), Aj(nzA);
@@ -759,6 +826,7 @@ int Engine::solve() {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);
   const double t0 = now_s();
+  if (!pol_explicit_) policy_from_env(pol_, true);
   if (clear_update_time_) { info.update_time = 0; }
   info.update_time += update_time_acc_; update_time_acc_ = 0;
   if (!settings.warm_starting) cold_start();                                            // _osqp.py:1204-1205
@@ -788,269 +856,274 @@ int Engine::solve() {
 
 // The ADMM loop proper (_osqp.py:1208-1266) on the current device iterates with the current settings; sets info.{iter,
 // obj_val, prim_res, dual_res, status*}; leaves the residual block of the last check in res.
-void Engine::admm_core(double t0, double *res) {
-  const int ct = settings.check_termination;
+//
+// The loop is a sequence of CHUNKS of ADMM iterations (up to the next termination check / rho adaptation point / start of the tight
+// PCG window in front of one); what happens at a chunk boundary -- termination test, adaptive rho, PCG tolerance and budget -- is
+// policy.h, one text for host and device.  Two ways of running it:
+//   host-synchronous  (exec_chunk_sync + ctl_boundary on the host): the launch-per-iteration form, the host simulator, verbose
+//                     solves, and the FIRST chunk of every solve (it is checkpointed and may be repeated with a larger PCG cap);
+//   device-driven     (run_device_driven): the host only feeds strings of slot launches and boundary groups; the device applies
+//                     policy.h itself (k_decide) and the host reads the state block when it says "done" or "need host" (second
+//                     stage of an infeasibility test, approximate tolerances at max_iter).
+void Engine::ctl_setup() {
+  Ctl &c = ctl_;
+  c = Ctl();
   const int ari = settings.adaptive_rho ? auto_rho_interval() : 0;
-  int cap = std::min(settings.cg_max_iter, kMaxCg);    // PCG iterations per solve; escalated below when the PCG stagnates at it
-  // Inexact inner solves bias the rho estimate (_osqp.py:880-908): their error shows up in the PRIMAL residual (measured at
-  // config 2: 7.5x the primal residual of exact solves at an unchanged dual residual, estimate 0.6 rho instead of 0.2 rho), so
-  // the last `tightW` iterations before every adaptation point run with a `tightF` times smaller PCG tolerance -- the bias
-  // flushes within ~10 iterations (DESIGN.md "Adaptive rho on the indirect path").
-  static const int tightW_env = [] { const char *e = std::getenv("OSQP_HIP_RHO_WINDOW"); return e ? std::atoi(e) : 10; }();
-  static const double tightF = [] { const char *e = std::getenv("OSQP_HIP_RHO_WINDOW_TOL"); return e ? std::atof(e) : 0.1; }();
-  static const bool persist = [] { const char *e = std::getenv("OSQP_HIP_RHO_PERSIST"); return !(e && e[0] == '0'); }();
-  const int tightW = (ari > 1 && tightW_env > 0) ? std::min(tightW_env, ari - 1) : 0;
-  // PCG tolerance for the first chunk: relative, ||rhs||/cg_tol_reduction (then tied to the ADMM residuals).
-  // Tolerance and budget restart with every solve so that a solve is a deterministic function of (data, iterates).
-  have_tol_ = false;
-  double tol_rel = 1e-14, tol_abs = kCgTolAbsMin;
+  c.ct = settings.check_termination; c.ari = ari; c.max_iter = settings.max_iter;
+  c.tightW = (ari > 1 && pol_.rho_window > 0) ? std::min(pol_.rho_window, ari - 1) : 0;
+  c.tightF = pol_.rho_window_tol; c.persist = pol_.rho_persist; c.tol_exp = pol_.rho_tol_exp;
+  c.m = m; c.scaling = settings.scaling; c.scaled_termination = settings.scaled_termination; c.check_dualgap = settings.check_dualgap;
+  c.has_quad = 0;
+  for (double v : P_.x) if (v != 0.0) { c.has_quad = 1; break; }      // LPs adapt rho by the setting's literal tolerance (policy.h ctl_rho_rule)
+  c.esc_on = pol_.cg_escalate; c.stall_on = pol_.stall; c.full_budget = pol_.budget_full; c.cap_max = kMaxCg;
+  c.cg_tol_fraction = settings.cg_tol_fraction; c.cg_tol_reduction = settings.cg_tol_reduction; c.rho_tolerance = settings.adaptive_rho_tolerance;
+  c.eps_abs = settings.eps_abs; c.eps_rel = settings.eps_rel; c.eps_pinf = settings.eps_prim_inf; c.eps_dinf = settings.eps_dual_inf;
+  c.c = c_; c.cinv = cinv_;
+  c.budget_tolerate = pol_.budget_tolerate; c.budget_sigma = pol_.budget_sigma; c.budget_slack = pol_.budget_slack;
+  c.iter = 0; c.cap = std::min(settings.cg_max_iter, kMaxCg);
+  // start with the full budget: a starved PCG in the first chunks costs far more ADMM iterations than the launches it saves
+  c.budget[0] = c.budget[1] = c.cap;
+  c.stall = 1.0; c.best_dua = INFINITY; c.prev_aobj = INFINITY; c.rho_bar = rho_bar_;
+  c.status = CTL_RUNNING;
+}
+
+void Engine::apply_rho(double rho) {
+  rho_bar_ = rho; settings.rho = rho;
+  be::set_rho(d_, rho_bar_);
+  be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+}
+
+// info fields of the last check from the state block (+ the time integral of |gap|, accumulated where the host sees a check)
+void Engine::info_from_ctl(double t0) {
+  const Ctl &c = ctl_;
+  info.iter = c.iter; info.obj_val = c.obj_val; info.prim_res = c.prim_res; info.dual_res = c.dual_res;
+  info.dual_obj_val = c.dual_obj_val; info.duality_gap = c.duality_gap; info.rel_kkt_error = c.rel_kkt_error;
+  info.rho_updates = c.rho_updates;
+  if (c.rho_estimate > 0) info.rho_estimate = c.rho_estimate;
+  if (t0 >= 0) {
+    const double t = now_s() - t0;
+    info.primdual_int += std::fabs(info.duality_gap) * std::max(0.0, t - gap_time_);
+    gap_time_ = t;
+  }
+}
+
+// One chunk of `cnt` ADMM iterations with at most `lim` PCG iterations per solve, host-synchronous; afterwards `flags` holds the chunk's
+// PCG statistics and, if with_res, `res` the residual block of its last iterate.  Slot form (backend_hip.hip "slot kernels"): the
+// chunk is a string of slot launches sized from the PCG iterations the previous chunk of this kind needed; the host watches the
+// chunk's progress on a side stream and tops the string up before it runs dry.
+void Engine::exec_chunk_sync(int cnt, int lim, bool with_res, int kind, double *res, int *flags) {
+  const bool slots = use_slots_ && be::slots_supported(d_);
+  if (!slots) {
+    run_chunk(cnt, lim);
+    if (with_res) { be::residuals(d_); be::fetch_res_flags(d_, res, flags); } else be::fetch_flags(d_, flags);
+    return;
+  }
+  double *pred = slot_pred_;
+  int tot[F_COUNT] = {0}, f[F_COUNT];
+  int launched_pairs = 0;
+  // slot pairs (two launches each) that `its` ADMM iterations with `pcg` PCG iterations each need (backend.h slot_launches)
+  auto pairs_for = [&](double its, double pcg) { return 0.5 * its * be::slot_launches(d_, pcg); };
+  const double t_chunk = now_s();
+  if (pol_.slot_poll) {
+    const int kLow = pol_.poll_low; const double kFirst = pol_.poll_first, kFrac = pol_.poll_frac, kWait = pol_.poll_wait;
+    const double p0 = std::min<double>(pred[kind], lim);
+    { const int np = (int)std::ceil(pairs_for(cnt, 0)) + std::max(2, (int)std::floor(kFirst * (pairs_for(cnt, p0) - pairs_for(cnt, 0)))); run_slots(cnt, np, lim); launched_pairs += np; }
+    double pair_s = 9e-6, t_prev = now_s();                        // duration of a slot pair, re-estimated from the progress between two polls
+    int seq_prev = 0, topups = 0;
+    for (int seq = 0, done = 0;;) {
+      be::slot_poll(d_, &seq, &done);
+      if (done >= cnt) break;
+      const double t_now = now_s();
+      // (bounded: a record that stops advancing must not make the host enqueue launches for ever -- the synchronising fetch below
+      //  then reports what the device did)
+      if (t_now - t_chunk > settings.time_limit || topups > 64 + 4 * cnt) break;
+      if (seq - seq_prev >= 8) { pair_s = std::max(5e-6, 2.0 * (t_now - t_prev) / (seq - seq_prev)); t_prev = t_now; seq_prev = seq; }
+      const int ahead = launched_pairs - seq / 2;                  // pairs enqueued and not yet executed
+      if (ahead > kLow) {
+        // (every poll is a small copy that has to squeeze in between the chunk's kernels: poll when the queue can have run low at the
+        // earliest, not continuously -- and sleep, not spin: a solving handle must not pin a host core)
+        std::this_thread::sleep_for(std::chrono::duration<double>(std::min(2e-3, kWait * (ahead - kLow) * pair_s)));
+        continue;
+      }
+      const int rem = cnt - done;
+      const double rate = done > 0 ? std::min<double>(pairs_for(1, lim), (0.5 * seq) / done) : pairs_for(1, p0);      // pairs per ADMM iteration so far
+      const int need = (int)std::ceil(rem * rate) + 1 - ahead;
+      const int np = std::max(2, need > 12 ? (int)std::ceil(kFrac * need) : need);
+      run_slots(0, np, lim); launched_pairs += np;
+      stats_.slot_topups += 1; topups++;
+    }
+  } else {
+    const double pm = std::min<double>(pred[kind], lim);
+    const int np = (int)std::ceil(pairs_for(cnt, 0) + 1.05 * (pairs_for(cnt, pm) - pairs_for(cnt, 0))) + 2; run_slots(cnt, np, lim); launched_pairs += np;
+  }
+  for (int round = 0;; round++) {
+    if (with_res) { be::residuals(d_); be::fetch_res_flags(d_, res, f); } else be::fetch_flags(d_, f);
+    tot[F_STAT_SUM] += f[F_STAT_SUM]; tot[F_STAT_SUMSQ] += f[F_STAT_SUMSQ]; tot[F_STAT_N] += f[F_STAT_N]; tot[F_STAT_UNCONV] += f[F_STAT_UNCONV]; tot[F_STAT_STAG] += f[F_STAT_STAG];
+    tot[F_STAT_MAX] = std::max(tot[F_STAT_MAX], f[F_STAT_MAX]);
+    const int done = be::slot_done(d_);
+    if (be::slot_seq(d_) != 2 * launched_pairs) {        // the record hand-over between the slot launches is broken: nothing computed since is trustworthy
+      char msg[160];
+      std::snprintf(msg, sizeof(msg), "osqp_hip: slot record hand-over broken: %d slots launched, record counts %d", 2 * launched_pairs, be::slot_seq(d_));
+      throw DeviceError(msg);
+    }
+    if (done >= cnt) break;
+    if (round > 64 + cnt) throw DeviceError("osqp_hip: a chunk of ADMM iterations does not finish");
+    const int rem = cnt - done;
+    const double seen = tot[F_STAT_N] > 0 ? (double)tot[F_STAT_SUM] / tot[F_STAT_N] : pred[kind];
+    const double pm = std::min<double>(std::max(seen, pred[kind]), lim);
+    const int np = (int)std::ceil(pairs_for(rem, 0) + 1.25 * (pairs_for(rem, pm) - pairs_for(rem, 0))) + 8; run_slots(0, np, lim); launched_pairs += np;
+    stats_.slot_topups += 1;
+  }
+  for (int k = 0; k < F_COUNT; k++) flags[k] = tot[k];
+  if (pol_.slot_log)
+    std::fprintf(stderr, "chunk %p it %d cnt %d kind %d lim %d pred %.2f used-mean %.2f topups %d unconv %d rho %.4e\n", (void *)this, ctl_.iter, cnt, kind, lim, pred[kind],
+                 tot[F_STAT_N] > 0 ? (double)tot[F_STAT_SUM] / tot[F_STAT_N] : 0.0, (int)stats_.slot_topups, tot[F_STAT_UNCONV], rho_bar_);
+  if (tot[F_STAT_N] > 0) pred[kind] = (double)tot[F_STAT_SUM] / tot[F_STAT_N];
+}
+
+// Device-driven chunks from the state block's current chunk on: returns CTL_DONE, CTL_NEED_HOST, or -2 when the time limit passed.
+// The stream carries   [slots for a chunk] [boundary group] [slots] [group] ...   -- a group acts only when the chunk in flight has
+// finished, the slots after a finished chunk idle until the group has set the next one up, and everything idles once the state
+// block says the solve is over: what is computed never depends on how the host sizes or times the strings.
+int Engine::run_device_driven(double t0, double *res, int *flags) {
+  Ctl &c = ctl_;
+  c.status = CTL_RUNNING; c.chunk_done = 0; c.rho_flag = 0;
+  be::ctl_upload(d_, c);
+  be::ctl_begin(d_);
+  stats_.kernel_launches += 1;
+  const int diagonal = settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER;
+  auto pairs_for = [&](double its, double pcg) { return 0.5 * its * be::slot_launches(d_, pcg); };
+  Ctl mir = c;                                       // chunk geometry ahead of the device (a function of the iteration count only)
+  Ctl snap = c;
+  long launched = 0;                                 // slot launches enqueued
+  std::deque<long> unit_end;                         // cumulative slot launches at the end of each unit in the queue
+  auto enqueue_unit = [&]() {
+    int cnt = mir.ch_next - mir.iter, kind = mir.ch_kind, tight = mir.ch_tight;
+    if (cnt <= 0) { cnt = c.ct > 0 ? c.ct : 25; kind = 1; tight = 0; }        // (the mirror ran past max_iter: the device lags behind it)
+    const double lim = snap.budget[tight];
+    double pm = snap.kind_n[kind] > 0 ? snap.kind_sum[kind] / snap.kind_n[kind] : slot_pred_[kind];
+    pm = std::min(pm, lim);
+    const int np = (int)std::ceil(pairs_for(cnt, 0) + pol_.unit_margin * (pairs_for(cnt, pm) - pairs_for(cnt, 0))) + 2;
+    run_slots(0, np, 0);
+    run_group(diagonal);
+    launched += 2L * np; unit_end.push_back(launched);
+    if (mir.ch_next > mir.iter) { mir.iter = mir.ch_next; ctl_next_chunk(mir); }
+  };
+  enqueue_unit();
+  bool timed_out = false;
+  int seq = 0;
+  for (;;) {
+    be::ctl_poll(d_, &snap, &seq);
+    if (snap.status != CTL_RUNNING) break;
+    if (now_s() - t0 > settings.time_limit) { timed_out = true; break; }
+    while (!unit_end.empty() && unit_end.front() <= seq) unit_end.pop_front();      // units the device is through with
+    if ((int)unit_end.size() < pol_.units_ahead) enqueue_unit();
+    else std::this_thread::sleep_for(std::chrono::microseconds(pol_.poll_sleep_us));
+  }
+  be::sync(d_);                                      // (what is still queued idles: the state block says the solve is over -- or, after
+  be::ctl_download(d_, &c);                          //  a time-out, runs to the end of the strings)
+  for (int q = 0; q < R_COUNT; q++) res[q] = c.res[q];
+  for (int q = 0; q < F_COUNT; q++) flags[q] = c.last_flags[q];
+  for (int k = 0; k < 3; k++) if (c.kind_n[k] > 0) slot_pred_[k] = c.kind_sum[k] / c.kind_n[k];
+  if (c.rho_bar != rho_bar_) { rho_bar_ = c.rho_bar; settings.rho = rho_bar_; }      // (applied on the device)
+  if (timed_out && c.status == CTL_RUNNING) return -2;
+  return c.status;
+}
+
+void Engine::run_group(int diagonal) {
+  stats_.kernel_launches += 6 + (diagonal ? 1 : 0);
+  if (!(use_graph_ && be::graphs_supported())) { be::ctl_group(d_, diagonal); return; }
+  const std::array<int, 3> key = {0, 1, diagonal};
+  auto it = sgraphs_.find(key);
+  if (it == sgraphs_.end()) {
+    be::graph_begin(d_);
+    be::ctl_group(d_, diagonal);
+    it = sgraphs_.emplace(key, be::graph_end(d_)).first;
+  }
+  be::graph_launch(d_, it->second);
+  stats_.graph_launches += 1;
+}
+
+void Engine::admm_core(double t0, double *res) {
+  Ctl &c = ctl_;
+  ctl_setup();
   {
-    // residuals of the starting point (zeros on a cold start, the caller's iterate on a warm start): a warm start near
-    // the optimum must not be perturbed by a loose first-chunk solve (warm_start_test.py:52-57 expects < 10 iterations)
     double r0[R_COUNT];
     be::residuals(d_); be::fetch_res(d_, r0);
-    const double eps0 = settings.cg_tol_fraction * r0[R_DUA_S];
-    if (std::isfinite(eps0) && eps0 > kCgTolAbsMin) tol_abs = eps0;                        // absolute, like every later chunk
-    else { tol_rel = 1.0 / settings.cg_tol_reduction; tol_abs = kCgTolAbsMin; }           // dual-feasible start (e.g. q = 0): relative
-    eps_cg_prev_ = std::numeric_limits<double>::infinity();
+    ctl_init_tol(c, r0);                               // tolerance and budget restart with every solve: a solve is a deterministic function of (data, iterates)
   }
-  // start with the full budget: a starved PCG in the first chunks costs far more ADMM iterations than the no-op
-  // launches it saves (measured: 1150 -> 825 ADMM iterations on the banded n=20000 QP); it shrinks after the first check
-  int budget[2] = {cap, cap};                       // [0] ordinary iterations, [1] the tight window before an adaptation point
-  bool tight_seen = false;
-  int last_side = 0;                                // side of rho the estimate fell on at the previous adaptation point
+  have_tol_ = false;
+  ctl_next_chunk(c);
   if (settings.verbose) std::printf("iter   objective    prim res   dual res   rho        cg   time\n");
-
-  auto next_budget = [&](int cur, const int *flags) {
-    static const double tolerate = [] { const char *e = std::getenv("OSQP_HIP_BUDGET_TOLERATE"); return e ? std::atof(e) : 0.0; }();
-    if (flags[F_STAT_UNCONV] * 4 > std::max(1, flags[F_STAT_N]) && flags[F_STAT_UNCONV] > tolerate * flags[F_STAT_N]) return std::min(cap, std::max(cur + 2, 2 * cur));
-    if (flags[F_STAT_UNCONV] > tolerate * flags[F_STAT_N]) return std::min(cap, cur + 1);
-    // mean + 3 sigma of the PCG counts of the last chunk (+1), never above its max + 1: rare spikes should not
-    // set the budget of the next 25 iterations (an occasional budget-limited solve is just a slightly less exact one)
-    const double cnt = std::max(1, flags[F_STAT_N]), mean = flags[F_STAT_SUM] / cnt;
-    const double var = std::max(0.0, flags[F_STAT_SUMSQ] / cnt - mean * mean);
-    static const double nsig = [] { const char *e = std::getenv("OSQP_HIP_BUDGET_SIGMA"); return e ? std::atof(e) : 3.0; }();
-    const int q3 = (int)std::ceil(mean + nsig * std::sqrt(var));     // (KA checks the residual after the last budgeted iteration)
-    static const int slack = [] { const char *e = std::getenv("OSQP_HIP_BUDGET_SLACK"); return e ? std::atoi(e) : 0; }();
-    return std::min(cap, std::max(2, std::min(flags[F_STAT_MAX], q3)) + slack);
-  };
-
-  // cg_max_iter escalation: when most solves of a chunk ran into the cap having reduced their residual by less than 10x the inner
-  // solver is STAGNATING (typically an unbounded LP / rank-deficient QP with n > m, whose reduced matrix has eigenvalues sigma =
-  // 1e-6: DESIGN.md section 5) and ADMM would crawl to max_iter on inexact steps where the direct path finishes in 25 iterations:
-  // the cap then doubles (up to kMaxCg).  Solves that merely need more iterations than the cap allows but converge steadily
-  // (portfolio, lasso: 2-3 decades within 50 iterations) do not count: for them a larger cap buys no ADMM iterations back.
-  static const bool esc_on = [] { const char *e = std::getenv("OSQP_HIP_CG_ESCALATE"); return !(e && e[0] == '0'); }();
-  static const bool stall_on = [] { const char *e = std::getenv("OSQP_HIP_STALL"); return !(e && e[0] == '0'); }();
-  auto escalate = [&](bool tight, const int *flags) {
-    if (esc_on && budget[tight] >= cap && cap < kMaxCg && flags[F_STAT_STAG] * 2 > std::max(1, flags[F_STAT_N])) {
-      cap = std::min(kMaxCg, 2 * cap);
-      stats_.cg_cap_escalations += 1;
-    }
-  };
-
-  double stall = 1.0, best_dua = std::numeric_limits<double>::infinity(), prev_aobj = std::numeric_limits<double>::infinity();
-  int stalled_checks = 0;
-  int iter = 0;
-  int flags[F_COUNT];
-  // One chunk of `cnt` ADMM iterations; afterwards `flags` holds the chunk's PCG statistics and, if with_res, `res` the residual
-  // block of its last iterate.  Slot form (default, backend_hip.hip "slot kernels"): the chunk is a string of (B slot, A slot) launches
-  // sized from the PCG iterations the previous chunk of this kind needed (+10 %); if the string ends before the chunk does, more
-  // pairs follow (the residual kernels that ran on the unfinished iterates are simply repeated).
   const bool slots = use_slots_ && be::slots_supported(d_);
-  bool has_quad = false;                              // any nonzero in P? (LPs adapt rho by the setting's literal tolerance, below)
-  for (double v : P_.x) if (v != 0.0) { has_quad = true; break; }
-  double *pred = slot_pred_;                         // mean PCG iterations per ADMM iteration, per chunk kind; kept across solves of the handle
-  auto exec_chunk = [&](int cnt, bool tight, bool with_res, int kind) {
-    if (!slots) {
-      run_chunk(cnt, budget[tight]);
-      if (with_res) { be::residuals(d_); be::fetch_res_flags(d_, res, flags); } else be::fetch_flags(d_, flags);
-      return;
-    }
-    int tot[F_COUNT] = {0}, f[F_COUNT];
-    int launched_pairs = 0;
-    // slot pairs (two launches each) that `its` ADMM iterations with `pcg` PCG iterations each need (backend.h slot_launches)
-    auto pairs_for = [&](double its, double pcg) { return 0.5 * its * be::slot_launches(d_, pcg); };
-    // (per-solve iteration limit = the budget rule of the launch-per-iteration form: the two forms then execute the SAME arithmetic
-    // -- truncating the rare long solve at mean + 3 sigma of the previous chunk costs no ADMM iterations and a third of the PCG work)
-    const int lim = budget[tight];
-    // The string of slot launches is cut SHORT of the prediction and topped up while it runs: the host watches the chunk's progress on a
-    // side stream (be::slot_poll: slots executed, ADMM iterations completed) and, whenever fewer than kLow pairs are left in the queue,
-    // enqueues what the iterations still to come need at the rate observed so far.  A chunk then ends with a handful of idle slots
-    // instead of the prediction's error (r02g: 9 % of all launches idle, one costs 4.5 us inside a graph; and an under-predicted chunk
-    // no longer costs a residual evaluation on unfinished iterates + a synchronisation).  What the slots compute does not depend on
-    // how many are enqueued or when: iterates and iteration counts are those of the budgeted form.  OSQP_HIP_SLOT_POLL=0: the r02g rule.
-    static const bool poll_on = [] { const char *e = std::getenv("OSQP_HIP_SLOT_POLL"); return !(e && e[0] == '0'); }();
-    if (poll_on) {
-      static const int kLow = [] { const char *e = std::getenv("OSQP_HIP_POLL_LOW"); return e ? std::atoi(e) : 6; }();
-      static const double kFirst = [] { const char *e = std::getenv("OSQP_HIP_POLL_FIRST"); return e ? std::atof(e) : 0.8; }();
-      static const double kFrac = [] { const char *e = std::getenv("OSQP_HIP_POLL_FRAC"); return e ? std::atof(e) : 0.75; }();
-      static const double kWait = [] { const char *e = std::getenv("OSQP_HIP_POLL_WAIT"); return e ? std::atof(e) : 0.7; }();
-      const double p0 = std::min<double>(pred[kind], lim);
-      { const int np = (int)std::ceil(pairs_for(cnt, 0)) + std::max(2, (int)std::floor(kFirst * (pairs_for(cnt, p0) - pairs_for(cnt, 0)))); run_slots(cnt, np, lim); launched_pairs += np; }
-      double pair_s = 9e-6, t_prev = now_s();                        // duration of a slot pair, re-estimated from the progress between two polls
-      int seq_prev = 0;
-      for (int seq = 0, done = 0;;) {
-        be::slot_poll(d_, &seq, &done);
-        if (done >= cnt) break;
-        { const double t_now = now_s();
-          if (seq - seq_prev >= 8) { pair_s = std::max(5e-6, 2.0 * (t_now - t_prev) / (seq - seq_prev)); t_prev = t_now; seq_prev = seq; } }
-        const int ahead = launched_pairs - seq / 2;                  // pairs enqueued and not yet executed
-        if (ahead > kLow) {
-          // (every poll is a small copy that has to squeeze in between the chunk's kernels: poll when the queue can have run
-          // low at the earliest, not continuously)
-          const double until = now_s() + kWait * (ahead - kLow) * pair_s;
-          while (now_s() < until) {}
-          continue;
+  const bool device_driven = slots && pol_.device_driven && !settings.verbose && be::ctl_supported(d_);
+  int flags[F_COUNT] = {0};
+  for (;;) {
+    int st;
+    const bool first_chunk = c.iter == 0;
+    if (first_chunk || !device_driven) {
+      be::set_pcg_tol(d_, c.tol_rel, ctl_chunk_tol_abs(c));
+      // The FIRST chunk is checkpointed: if the PCG starves at the cap in most of its solves, the chunk is repeated from the same
+      // iterates with a four times larger cap (ADMM steps taken with stagnating inner solves derail exactly the problems --
+      // unbounded / rank-deficient ones -- whose status the first checks decide: tools/fuzz_gpu.py, tests/test_gpu_fuzz.py).
+      const bool ckpt_chunk = first_chunk && c.cap < kMaxCg && c.esc_on;
+      if (ckpt_chunk) {
+        if (!ckpt_) ckpt_ = dev_vec<double>(d_, 2 * (size_t)n + 2 * (size_t)m);
+        be::copy_in(d_, ckpt_, d_.x, sizeof(double) * n, 1); be::copy_in(d_, ckpt_ + n, d_.xs, sizeof(double) * n, 1);
+        be::copy_in(d_, ckpt_ + 2 * (size_t)n, d_.z, sizeof(double) * m, 1); be::copy_in(d_, ckpt_ + 2 * (size_t)n + m, d_.y, sizeof(double) * m, 1);
+      }
+      const int lim = c.budget[c.ch_tight], tight = c.ch_tight;
+      const double rho_was = rho_bar_;
+      exec_chunk_sync(c.ch_next - c.iter, lim, c.ch_at_check && !ckpt_chunk, c.ch_kind, res, flags);
+      cg_budget_ = lim;
+      if (ckpt_chunk) {
+        if (lim >= c.cap && flags[F_STAT_STAG] * 2 > std::max(1, flags[F_STAT_N])) {
+          be::copy_in(d_, d_.x, ckpt_, sizeof(double) * n, 1); be::copy_in(d_, d_.xs, ckpt_ + n, sizeof(double) * n, 1);
+          be::copy_in(d_, d_.z, ckpt_ + 2 * (size_t)n, sizeof(double) * m, 1); be::copy_in(d_, d_.y, ckpt_ + 2 * (size_t)n + m, sizeof(double) * m, 1);
+          be::zero(d_, d_.dx, sizeof(double) * n); be::zero(d_, d_.dy, sizeof(double) * m);
+          be::init_iterates(d_, 0);
+          c.cap = std::min(kMaxCg, 4 * c.cap); c.budget[0] = c.budget[1] = c.cap;
+          c.escalations += 1;
+          stats_.kernel_launches = 0; stats_.graph_launches = 0;
+          continue;                                       // same chunk again (iter is still 0)
         }
-        const int rem = cnt - done;
-        const double rate = done > 0 ? std::min<double>(pairs_for(1, lim), (0.5 * seq) / done) : pairs_for(1, p0);      // pairs per ADMM iteration so far
-        const int need = (int)std::ceil(rem * rate) + 1 - ahead;
-        const int np = std::max(2, need > 12 ? (int)std::ceil(kFrac * need) : need);
-        run_slots(0, np, lim); launched_pairs += np;
-        stats_.slot_topups += 1;
+        if (c.ch_at_check) { be::residuals(d_); be::fetch_res(d_, res); }      // (the chunk's PCG statistics are already in flags)
       }
-    } else
-    { const double pm = std::min<double>(pred[kind], lim);
-      const int np = (int)std::ceil(pairs_for(cnt, 0) + 1.05 * (pairs_for(cnt, pm) - pairs_for(cnt, 0))) + 2; run_slots(cnt, np, lim); launched_pairs += np; }
-    for (;;) {
-      if (with_res) { be::residuals(d_); be::fetch_res_flags(d_, res, f); } else be::fetch_flags(d_, f);
-      tot[F_STAT_SUM] += f[F_STAT_SUM]; tot[F_STAT_SUMSQ] += f[F_STAT_SUMSQ]; tot[F_STAT_N] += f[F_STAT_N]; tot[F_STAT_UNCONV] += f[F_STAT_UNCONV]; tot[F_STAT_STAG] += f[F_STAT_STAG];
-      tot[F_STAT_MAX] = std::max(tot[F_STAT_MAX], f[F_STAT_MAX]);
-      const int done = be::slot_done(d_);
-      if (be::slot_seq(d_) != 2 * launched_pairs) { std::fprintf(stderr, "osqp_hip: SLOT RECORD HAND-OVER BROKEN: %d slots launched, record counts %d\n", 2 * launched_pairs, be::slot_seq(d_)); }
-      if (done >= cnt) break;
-      const int rem = cnt - done;
-      const double seen = tot[F_STAT_N] > 0 ? (double)tot[F_STAT_SUM] / tot[F_STAT_N] : pred[kind];
-      { const double pm = std::min<double>(std::max(seen, pred[kind]), lim);
-        const int np = (int)std::ceil(pairs_for(rem, 0) + 1.25 * (pairs_for(rem, pm) - pairs_for(rem, 0))) + 8; run_slots(0, np, lim); launched_pairs += np; }
-      stats_.slot_topups += 1;
-    }
-    for (int k = 0; k < F_COUNT; k++) flags[k] = tot[k];
-    { static const bool slog = std::getenv("OSQP_HIP_SLOT_LOG") != nullptr;
-      double sc4[4] = {0, 0, 0, 0}; if (slog) be::d2h(d_, sc4, d_.scal, sizeof(sc4));
-      if (slog) std::fprintf(stderr, "chunk %p it %d cnt %d kind %d lim %d pred %.2f used-mean %.2f needed-pairs %d topups %d unconv %d tol %.3e rho %.4e dev-tol-abs %.3e dev-tol-now %.3e rn0 %.3e\n", (void *)this, iter, cnt, kind, lim, pred[kind], tot[F_STAT_N] > 0 ? (double)tot[F_STAT_SUM] / tot[F_STAT_N] : 0.0, 2 * cnt + tot[F_STAT_SUM], (int)stats_.slot_topups, tot[F_STAT_UNCONV], tol_abs, rho_bar_, sc4[1], sc4[2], sc4[3]); }
-    if (tot[F_STAT_N] > 0) pred[kind] = (double)tot[F_STAT_SUM] / tot[F_STAT_N];
-  };
-  while (true) {
-    int next = settings.max_iter;
-    if (ct > 0) next = std::min(next, (iter / ct + 1) * ct);
-    if (ari > 0) next = std::min(next, (iter / ari + 1) * ari);
-    bool tight = false;
-    if (tightW > 0) {
-      const int ts = (iter / ari + 1) * ari - tightW;       // start of the tight window before the next adaptation point
-      if (iter >= ts) tight = true;
-      else if (ts < next) next = ts;
-    }
-    static const bool full_budget = std::getenv("OSQP_HIP_BUDGET_FULL") != nullptr;      // debugging: never starve the PCG
-    if (full_budget) budget[0] = budget[1] = cap;
-    if (tight && !tight_seen) { budget[1] = std::min(cap, 3 * budget[0] + 2); tight_seen = true; }
-    be::set_pcg_tol(d_, tol_rel, tight ? std::max(tightF * tol_abs, kCgTolAbsMin) : tol_abs);
-    // The FIRST chunk is checkpointed: if the PCG starves at the cap in most of its solves, the chunk is repeated from the
-    // same iterates with a four times larger cap (ADMM steps taken with stagnating inner solves derail exactly the problems --
-    // unbounded / rank-deficient ones -- whose status the first checks decide; with the larger cap from the start the engine
-    // follows the direct path: DUAL_INFEASIBLE at iteration 25 instead of max_iter, tools/fuzz_gpu.py, tests/test_gpu_fuzz.py).
-    const bool first_chunk = iter == 0;
-    if (first_chunk && cap < kMaxCg && esc_on) {
-      if (!ckpt_) ckpt_ = dev_vec<double>(d_, 2 * (size_t)n + 2 * (size_t)m);
-      be::copy_in(d_, ckpt_, d_.x, sizeof(double) * n, 1); be::copy_in(d_, ckpt_ + n, d_.xs, sizeof(double) * n, 1);
-      be::copy_in(d_, ckpt_ + 2 * (size_t)n, d_.z, sizeof(double) * m, 1); be::copy_in(d_, ckpt_ + 2 * (size_t)n + m, d_.y, sizeof(double) * m, 1);
-    }
-    const bool at_check = (ct > 0 && next % ct == 0) || next >= settings.max_iter || (ari > 0 && next % ari == 0);
-    const bool ckpt_chunk = first_chunk && cap < kMaxCg && esc_on;
-    const int kind = tight ? 2 : ((ari > 0 && tightW > 0 && iter % ari == 0) ? 0 : 1);
-    exec_chunk(next - iter, tight, at_check && !ckpt_chunk, kind);
-    cg_budget_ = budget[tight];
-    if (ckpt_chunk) {
-      if (budget[tight] >= cap && flags[F_STAT_STAG] * 2 > std::max(1, flags[F_STAT_N])) {
-        be::copy_in(d_, d_.x, ckpt_, sizeof(double) * n, 1); be::copy_in(d_, d_.xs, ckpt_ + n, sizeof(double) * n, 1);
-        be::copy_in(d_, d_.z, ckpt_ + 2 * (size_t)n, sizeof(double) * m, 1); be::copy_in(d_, d_.y, ckpt_ + 2 * (size_t)n + m, sizeof(double) * m, 1);
-        be::zero(d_, d_.dx, sizeof(double) * n); be::zero(d_, d_.dy, sizeof(double) * m);
-        be::init_iterates(d_, 0);
-        cap = std::min(kMaxCg, 4 * cap); budget[0] = budget[1] = cap;
-        stats_.cg_cap_escalations += 1;
-        stats_.kernel_launches = 0; stats_.graph_launches = 0;
-        continue;                                       // same chunk again (iter is still 0)
+      const bool was_check = c.ch_at_check;
+      st = ctl_boundary(c, res, flags);
+      if (was_check) {
+        info_from_ctl(t0);
+        if (settings.verbose)
+          std::printf("%4d  %11.4e   %8.2e   %8.2e   %8.2e  %3d  %8.2es   (cg mean %.1f budget %d unconv %d; rho est %.2e)\n", c.iter, info.obj_val, info.prim_res,
+                      info.dual_res, rho_was, flags[F_STAT_MAX], now_s() - t0, flags[F_STAT_SUM] / (double)std::max(1, flags[F_STAT_N]), lim,
+                      flags[F_STAT_UNCONV], pol_rho_estimate(rho_was, res));
       }
-      if (at_check) { be::residuals(d_); be::fetch_res(d_, res); }      // (the chunk's PCG statistics are already in flags)
+      (void)tight;
+      if (st == CTL_RUNNING && c.rho_flag) apply_rho(c.rho_bar);
+    } else {
+      st = run_device_driven(t0, res, flags);
+      info_from_ctl(t0);
+      if (st == -2) { set_status(OSQP_TIME_LIMIT_REACHED); break; }
     }
-    stats_.pcg_iters_total += flags[F_STAT_SUM];
-    stats_.pcg_iters_max = std::max(stats_.pcg_iters_max, (double)flags[F_STAT_MAX]);
-    stats_.pcg_unconverged += flags[F_STAT_UNCONV];
-    iter = next;
-    if (!at_check) {                                  // boundary of a tight window only: PCG statistics, no residuals
-      escalate(tight, flags);
-      budget[tight] = next_budget(budget[tight], flags);
-      continue;
-    }
-    const bool unsc = settings.scaling && !settings.scaled_termination;
-    info.iter = iter;
-    info.obj_val = (0.5 * res[R_XPX] + res[R_QX]) * (settings.scaling ? cinv_ : 1.0);      // _osqp.py:705-712
-    info.prim_res = (m == 0) ? 0.0 : (unsc ? res[R_PRI_U] : res[R_PRI_S]);                 // :714-726
-    info.dual_res = unsc ? cinv_ * res[R_DUA_U] : res[R_DUA_S];                            // :753-764
-    update_gap_info(res, t0);
-    if (settings.verbose)
-      std::printf("%4d  %11.4e   %8.2e   %8.2e   %8.2e  %3d  %8.2es   (cg mean %.1f budget %d unconv %d; rho est %.2e)\n", iter, info.obj_val, info.prim_res,
-                  info.dual_res, rho_bar_, flags[F_STAT_MAX], now_s() - t0, flags[F_STAT_SUM] / (double)std::max(1, flags[F_STAT_N]), budget[tight],
-                  flags[F_STAT_UNCONV], rho_estimate(res));
-    const bool do_check = (ct > 0 && iter % ct == 0) || iter == settings.max_iter;
-    if (do_check && check_termination(res, false)) break;
-    if (iter >= settings.max_iter) {                                                     // :1264-1266
-      if (!check_termination(res, true)) set_status(OSQP_MAX_ITER_REACHED);
+    if (st == CTL_DONE) {
+      set_status(c.osqp_status);
+      if (c.osqp_status == OSQP_NON_CVX) info.obj_val = kNaN;
       break;
     }
-    if (now_s() - t0 > settings.time_limit) { set_status(OSQP_TIME_LIMIT_REACHED); break; }
-    if (ari > 0 && iter % ari == 0) {                                                    // adapt_rho :910-930
-      // (An update costs this path two small kernels, not a refactorisation -- the reason for the reference's factor-5 guard --
-      // so the tolerance is spent on a square-root scale: the setting's default 5 fires at a ratio of 2.24.  Measured over seven
-      // problems, tolerance 5 / 3 / 2.24 / 2 / 1.5: mean time to solution 1 / 0.92 / 0.88 / 0.85 / 0.84, lasso 5.1 -> 3.2 s;
-      // profiles/r02e_rho_tolerance_sweep.txt.  OSQP_HIP_RHO_TOL_EXP=1 restores the setting's literal value.)
-      static const double tol_exp = [] { const char *e = std::getenv("OSQP_HIP_RHO_TOL_EXP"); const double v = e ? std::atof(e) : 0.5; return v > 0 && v <= 1 ? v : 0.5; }();
-      // (LPs keep the literal tolerance: with P = 0 the small corrections made 3 more of the fuzz set's 40 LPs run into max_iter)
-      const double rn = rho_estimate(res), tol = std::pow(settings.adaptive_rho_tolerance, has_quad ? tol_exp : 1.0);
-      info.rho_estimate = rn;
-      // The reference applies the estimate when it differs from rho by more than the tolerance (5): a guard against
-      // refactorisations, which cost the indirect path nothing.  Here an estimate that falls on the same side of rho by
-      // more than sqrt(tolerance) at two CONSECUTIVE adaptation points is applied as well: the reference rule alone sits on a
-      // knife edge at config 2 (the estimate settles at 0.2 rho: the oracle fires at iteration 350 with the 1e3 equality
-      // weight and never with weight 10 -- 575 vs 1250 iterations).
-      const double st = std::sqrt(tol);
-      const int side = rn > st * rho_bar_ ? 1 : (rn < rho_bar_ / st ? -1 : 0);
-      const bool big = rn > tol * rho_bar_ || rn < rho_bar_ / tol;
-      const bool persistent = persist && side != 0 && side == last_side;
-      last_side = side;
-      if (big || persistent) {
-        rho_bar_ = rn; settings.rho = rn;
-        be::set_rho(d_, rho_bar_);
-        be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
-        info.rho_updates++;
-        last_side = 0;
+    if (st == CTL_NEED_HOST) {
+      // second stage of the infeasibility tests (two more SpMVs) / approximate tolerances at max_iter: Engine::check_termination
+      if ((c.need & (NEED_PINF | NEED_DINF)) && check_termination(res, false)) break;
+      if (c.iter >= settings.max_iter) {                                                   // :1264-1266
+        if (!check_termination(res, true)) set_status(OSQP_MAX_ITER_REACHED);
+        break;
       }
+      if (ctl_boundary_continue(c, res, flags)) apply_rho(c.rho_bar);
     }
-    // inner tolerance follows the (scaled) ADMM residuals and never loosens
-    // The PCG residual r enters the ADMM dual residual one-to-one (P x~ + sigma(x~ - x) + q + A'(...) = r), so the inner
-    // tolerance is a fraction of the current SCALED dual residual.  (Upstream's rule, fraction * sqrt(prim*dual)
-    // [UPSTREAM-UNVERIFIED], lets r exceed the dual residual whenever prim >> dual; that biases the rho estimate of
-    // _osqp.py:880-908 and was measured to cost 2-3x more ADMM iterations -- see DESIGN.md "PCG tolerance".)
-    // Unbounded problems: the dual residual stays O(1) for ever while |objective| keeps growing from check to check.  A tolerance
-    // tied to the dual residual then never tightens and the certificates of _osqp.py:796-878 -- conditions on dx relative to
-    // 1e-4 ||dx|| -- are never met by the inexact steps: from the second such check on the tolerance drops by 10x per check
-    // (and recovers once the dual residual improves on its best value again).  Plateaus of the dual residual on BOUNDED problems (slow ADMM phases of the
-    // lasso / portfolio configs) do not trigger it: tightening there costs 2x the PCG work and buys nothing.
-    const double aobj = std::fabs(info.obj_val);
-    const bool growing = aobj > 1.0 && aobj > 1.02 * prev_aobj;             // |objective| still growing from check to check: the iterates run away
-    prev_aobj = aobj;
-    if (!stall_on) stall = 1.0;
-    else if (res[R_DUA_S] > 0.9 * best_dua) { if (growing && ++stalled_checks >= 2) stall = std::max(1e-8, 0.1 * stall); }
-    else { stalled_checks = 0; stall = std::min(1.0, 10.0 * stall); }        // the dual residual improves again
-    best_dua = std::min(best_dua, res[R_DUA_S]);
-    double eps = settings.cg_tol_fraction * res[R_DUA_S];
-    eps = std::max(std::min(eps, eps_cg_prev_), kCgTolAbsMin);
-    if (std::isfinite(eps)) { eps_cg_prev_ = eps; tol_rel = 1e-14; tol_abs = std::max(eps * stall, kCgTolAbsMin); have_tol_ = true; }
-    // PCG budget for the next chunk of this kind: track what the last chunk needed
-    escalate(tight, flags);
-    budget[tight] = next_budget(budget[tight], flags);
+    if (now_s() - t0 > settings.time_limit) { set_status(OSQP_TIME_LIMIT_REACHED); break; }
   }
+  info.rho_updates = c.rho_updates;
+  stats_.pcg_iters_total = c.pcg_total; stats_.pcg_iters_max = c.pcg_max; stats_.pcg_unconverged = c.pcg_unconv;
+  stats_.cg_cap_escalations = c.escalations;
 }
 
 // Solution polish (_osqp.py:1710-1828).  The reference guesses the active constraints from (z, y), solves the
@@ -1518,6 +1591,7 @@ void Engine::fill_batch_params(BatchParams &p, int nbatch, int warm) {
   p.cg_max = settings.cg_max_iter; p.unscaled = settings.scaling && !settings.scaled_termination; p.scaling = settings.scaling;
   p.precond = settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER; p.rho_is_vec = settings.rho_is_vec; p.warm = warm;
   p.polish = settings.polishing; p.refine = settings.polish_refine_iter; p.delta = settings.delta;      // (honoured by the direct variants)
+  p.variant = pol_.batch_variant;
 }
 
 void Engine::attach_batch_direct(BatchParams &p) {
@@ -1537,9 +1611,7 @@ void Engine::attach_batch_direct(BatchParams &p) {
 // polish_refine_iter refinement steps: the reference's algorithm, _osqp.py:1710-1828).  Not taken with verbose
 // output (per-iteration printing lives in the host-driven loop), with a time limit, or when OSQP_HIP_SMALL_DIRECT=0.
 bool Engine::small_direct_applicable() {
-  const char *env = std::getenv("OSQP_HIP_SMALL_DIRECT");       // read per solve: tests and tools switch it at run time
-  const bool off = env && env[0] == '0';
-  if (off || !be::device_assembly() || settings.verbose || settings.time_limit < 1e9) return false;
+  if (!pol_.small_direct || !be::device_assembly() || settings.verbose || settings.time_limit < 1e9) return false;
   if (!be::batch_lds_bytes(n, m)) return false;
   prepare_batch_direct();
   if (!bd_.ok) return false;
@@ -1626,7 +1698,7 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   if (!be::batch_lds_bytes(n, m)) return OSQP_FUNC_NOT_IMPLEMENTED;
   be::activate(d_);
   be::ext_wait(d_);                                 // the scratch block may still be read by a kernel on a caller's stream
-  const bool timing = std::getenv("OSQP_HIP_BATCH_TIMING") != nullptr;
+  const bool timing = pol_.batch_timing != 0;
   double tph[5]; tph[0] = now_s();
   const size_t N = (size_t)nbatch * n, M = (size_t)nbatch * m;
   if ((l || u) && !(l && u)) ensure_host_vectors();
@@ -1653,7 +1725,7 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   // Launch order: the problems that took most iterations in the PREVIOUS call of the same size go first (parametric batches -- MPC
   // steps, training epochs -- repeat their hard problems; with index order the last round of workgroups waits for stragglers:
   // 4096 MPC QPs 13.3 -> 11 ms).  Scheduling only: every problem is solved by its own workgroup exactly as before.
-  static const bool reorder = [] { const char *e = std::getenv("OSQP_HIP_BATCH_REORDER"); return !(e && e[0] == '0'); }();
+  const bool reorder = pol_.batch_reorder != 0;
   if (reorder && nbatch > 1 && (int)batch_order_.size() == nbatch) {
     if ((size_t)nbatch > batch_order_cap_) {
       if (d_batch_order_) be::dfree(d_, d_batch_order_);
@@ -1701,7 +1773,7 @@ int Engine::batch_solve_device(int nbatch, const double *q, const double *l, con
   p.q = q; p.l = l; p.u = u; p.q0 = dq0; p.l0 = dl0; p.u0 = du0; p.x = x; p.y = y; p.rec = rec;
   // launch order as in batch_solve, entirely on the device: the kernel leaves every problem's iteration count, a rank kernel turns
   // the previous call's counts into this call's order (both on the caller's stream: ordered with the batch kernels themselves)
-  static const bool reorder = [] { const char *e = std::getenv("OSQP_HIP_BATCH_REORDER"); return !(e && e[0] == '0'); }();
+  const bool reorder = pol_.batch_reorder != 0;
   if (reorder && nbatch > 1) {
     if ((size_t)nbatch > batch_order_cap_) {           // (both buffers have the same capacity)
       if (d_batch_order_) be::dfree(d_, d_batch_order_);

@@ -10,6 +10,7 @@
 
 #include "../../include/osqp_hip.h"
 #include "backend.h"
+#include "policy.h"
 
 namespace osqp_hip {
 
@@ -38,6 +39,10 @@ class Engine {
   int update_settings(const OSQPSettings *s);
   int update_rho(double rho);
   int get_stats(OSQPHipStats *out);
+  int set_policy(const OSQPHipPolicy *p);
+  int get_policy(OSQPHipPolicy *p) const;
+  static void default_policy(OSQPHipPolicy *p);
+  static void set_default_policy(const OSQPHipPolicy *p);
   int time_kernel(int which, int reps, double *ms);
   int test_spmv(int which, const double *in, double *out);
   int trace_read(unsigned long long *out, int count);
@@ -77,11 +82,10 @@ class Engine {
   // ---- driver state ----
   double rho_bar_ = 0.1;
   double eq_factor_mixed_ = 10.0;     // see classify_constraints()
-  bool eq_factor_env_ = false;        // OSQP_HIP_RHO_EQ_FACTOR given
+  bool eq_factor_env_ = false;        // policy rho_eq_factor given
   double mixed_eq_factor() const;
   bool eq_factor_set_ = false;        // osqp_hip_set_rho_eq_factor was called: the batch path's direct variant honours it too
   int cg_budget_ = 0;
-  double eps_cg_prev_ = 0;
   bool first_run_ = true;
   bool have_tol_ = false;
   bool use_graph_ = true;
@@ -127,6 +131,15 @@ class Engine {
                                              // adaptation point (its PCGs start from an accurately solved iterate: fewer iterations), ordinary, tight
   std::map<std::array<int, 3>, void *> sgraphs_;
   void admm_core(double t0, double *res);
+  OSQPHipPolicy pol_{};                 // this handle's policy (include/osqp_hip.h)
+  bool pol_explicit_ = false;           // osqp_hip_set_policy was called: the environment no longer overrides the run-time fields
+  Ctl ctl_{};                           // state block of the chunk-boundary rules (policy.h)
+  void ctl_setup();
+  void apply_rho(double rho);
+  void info_from_ctl(double t0);
+  void exec_chunk_sync(int cnt, int lim, bool with_res, int kind, double *res, int *flags);
+  int run_device_driven(double t0, double *res, int *flags);
+  void run_group(int diagonal);
   void polish();
   void apply_scaled_bounds(const std::vector<double> &ls, const std::vector<double> &us);
   void drop_graphs();

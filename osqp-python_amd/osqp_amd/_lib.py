@@ -60,6 +60,15 @@ class StatsStruct(C.Structure):
                                           'cg_cap_escalations', 'windowed_blocks', 'row_blocks', 'slot_topups', 'f1_replicas')]
 
 
+class PolicyStruct(C.Structure):       # OSQPHipPolicy, include/osqp_hip.h (same order)
+    _fields_ = ([(k, C.c_int) for k in ('graph', 'slots', 'pcg_fused', 'f1', 'window', 'device_driven', 'small_direct', 'batch_reorder', 'batch_variant')] +
+                [('extrap', C.c_double), ('rho_eq_factor', C.c_double), ('rho_window', C.c_int), ('rho_window_tol', C.c_double), ('rho_persist', C.c_int),
+                 ('rho_tol_exp', C.c_double), ('budget_tolerate', C.c_double), ('budget_sigma', C.c_double), ('budget_slack', C.c_int), ('budget_full', C.c_int),
+                 ('cg_escalate', C.c_int), ('stall', C.c_int), ('slot_poll', C.c_int), ('poll_low', C.c_int), ('poll_first', C.c_double),
+                 ('poll_frac', C.c_double), ('poll_wait', C.c_double), ('units_ahead', C.c_int), ('poll_sleep_us', C.c_int), ('unit_margin', C.c_double),
+                 ('slot_log', C.c_int), ('setup_timing', C.c_int), ('batch_timing', C.c_int)])
+
+
 SolverP = C.POINTER(SolverStruct)
 
 
@@ -106,6 +115,10 @@ PROTOTYPES = {
     'osqp_hip_trace_read': (C.c_int, [SolverP, C.POINTER(C.c_ulonglong), C.c_int]),
     'osqp_hip_test_spmv': (C.c_int, [SolverP, C.c_int, c_double_p, c_double_p]),
     'osqp_hip_set_rho_eq_factor': (C.c_int, [SolverP, C.c_double]),
+    'osqp_hip_default_policy': (None, [C.POINTER(PolicyStruct)]),
+    'osqp_hip_set_default_policy': (None, [C.POINTER(PolicyStruct)]),
+    'osqp_hip_set_policy': (C.c_int, [SolverP, C.POINTER(PolicyStruct)]),
+    'osqp_hip_get_policy': (C.c_int, [SolverP, C.POINTER(PolicyStruct)]),
     'osqp_hip_batch_solve': (C.c_int, [SolverP, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),
     'osqp_hip_batch_solve_device': (C.c_int, [SolverP, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'osqp_hip_update_data_vec_device': (C.c_int, [SolverP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -225,6 +225,24 @@ class OSQPSolver:
         self._lib.osqp_hip_get_stats(self._p, C.byref(s))
         return {k: getattr(s, k) for k, _ in s._fields_}
 
+    def get_policy(self):
+        """This handle's engine policy (include/osqp_hip.h OSQPHipPolicy) as a dict."""
+        p = _lib.PolicyStruct()
+        self._lib.osqp_hip_get_policy(self._p, C.byref(p))
+        return {k: getattr(p, k) for k, _ in p._fields_}
+
+    def set_policy(self, **fields):
+        """Change fields of this handle's policy, e.g. set_policy(small_direct=0, rho_window=0).  [setup] fields keep their value."""
+        p = _lib.PolicyStruct()
+        self._lib.osqp_hip_get_policy(self._p, C.byref(p))
+        for k, v in fields.items():
+            if k not in dict(p._fields_):
+                raise ValueError('unknown policy field %r' % k)
+            setattr(p, k, v)
+        st = self._lib.osqp_hip_set_policy(self._p, C.byref(p))
+        if st:
+            raise ValueError(str(st))
+
     def hip_time_kernel(self, which, reps=50):
         ms = C.c_double()
         st = self._lib.osqp_hip_time_kernel(self._p, int(which), int(reps), C.byref(ms))
