@@ -298,7 +298,7 @@ typedef struct {
   OSQPInt stall;              /* drop the PCG tolerance while the iterates run away (unbounded problems) */
   /* scheduling of the launch strings (results never depend on these) */
   OSQPInt slot_poll; OSQPInt poll_low; OSQPFloat poll_first, poll_frac, poll_wait;      /* host-synchronous chunks: top-ups from polled progress */
-  OSQPInt units_ahead; OSQPInt poll_sleep_us; OSQPFloat unit_margin;                    /* device-driven chunks: strings kept in the queue, poll pause, over-provisioning */
+  OSQPInt finish_pairs; OSQPInt poll_sleep_us;      /* device-driven chunks: a boundary group goes out when at most finish_pairs slot pairs are missing; pause between polls */
   /* diagnostics */
   OSQPInt slot_log, setup_timing, batch_timing;
 } OSQPHipPolicy;

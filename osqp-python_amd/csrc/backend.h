@@ -259,7 +259,7 @@ bool ctl_supported(const Dev &d);
 void ctl_upload(Dev &d, const Ctl &c);     // host -> device copy of the state block (stream-ordered)
 void ctl_begin(Dev &d);                    // start the chunk the state block describes (slot record, PCG tolerance, statistics reset)
 void ctl_group(Dev &d, int diagonal);      // enqueue one boundary group (diagonal: the Jacobi preconditioner follows rho)
-void ctl_poll(Dev &d, Ctl *out, int *seq); // snapshot of the state block + slots executed, read on the side stream WITHOUT waiting for d.stream
+void ctl_poll(Dev &d, Ctl *out, int *seq, int *done);   // snapshot of the state block + slots executed + ADMM iterations of the chunk in flight, read on the side stream WITHOUT waiting for d.stream
 void ctl_download(Dev &d, Ctl *out);       // after a stream synchronisation
 constexpr int kSlotInts = 24;  // Dev::slot: two phase records of 8 words + the chunk epoch
 void slot_poll(Dev &d, int *seq, int *done); // the same two numbers of the RUNNING chunk, read on a side stream without waiting for the launches

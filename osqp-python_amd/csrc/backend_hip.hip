@@ -1439,9 +1439,11 @@ __device__ __forceinline__ bool res_is_sum(int q) {
   return q == R_PINF_LHS || q == R_SUPP || q == R_XPX || q == R_QX || q == R_QDX || q == R_ADX_VIOL;
 }
 // final reduction of the per-workgroup partials: workgroup b handles quantity q0 + b
-__global__ __launch_bounds__(kBlock) void k_res_final(Dev d, int q0, int cond) {
+__device__ __forceinline__ bool ctl_stage2_due(const Dev &d, int bits) { return d.ctl->status == CTL_RUNNING && (d.ctl->stage2 & bits) != 0; }
+__global__ __launch_bounds__(kBlock) void k_res_final(Dev d, int q0, int cond) {        // cond 1: first stage of a boundary group, 2: its second stage
   __shared__ double sred[2 * kWaves];
-  if (cond && !ctl_res_due(d)) return;
+  if (cond == 1 && !ctl_res_due(d)) return;
+  if (cond == 2 && !ctl_stage2_due(d, NEED_PINF | NEED_DINF)) return;
   const int q = q0 + blockIdx.x;
   const double *slot = d.part + (SL_RES0 + q) * kGrid;
   const double v = res_is_sum(q) ? partial_sum(slot, sred) : partial_max(slot, sred);
@@ -1458,16 +1460,18 @@ struct EAbs2 : NoPrefetch {
     mu = nanmax(mu, fabs(scale[j] * v)); ms = nanmax(ms, fabs(v));
   }
 };
-__global__ __launch_bounds__(kBlock) void k_inf_primal(Dev d) {            // || Dinv A' dy ||_inf  (_osqp.py:815-818)
+__global__ __launch_bounds__(kBlock) void k_inf_primal(Dev d, int cond) {            // || Dinv A' dy ||_inf  (_osqp.py:815-818)
   __shared__ StreamLds<1> lds;
+  if (cond && !ctl_stage2_due(d, NEED_PINF)) return;
   GAtOnly g{d.dy, d.n};
   EAbs2 e{{}, d.Dinv, nullptr, 0.0};
   process_rows<1>(d.B, g, e, lds);
   __syncthreads();
   put_partial(d.part, SL_RES0 + R_ATDY_U, block_max(e.mu, lds.red)); put_partial(d.part, SL_RES0 + R_ATDY_S, block_max(e.ms, lds.red));
 }
-__global__ __launch_bounds__(kBlock) void k_inf_dual_p(Dev d) {            // || Dinv P dx ||_inf   (_osqp.py:846-853)
+__global__ __launch_bounds__(kBlock) void k_inf_dual_p(Dev d, int cond) {            // || Dinv P dx ||_inf   (_osqp.py:846-853)
   __shared__ StreamLds<1> lds;
+  if (cond && !ctl_stage2_due(d, NEED_DINF)) return;
   GPOnly g{d.dx, d.n};
   EAbs2 e{{}, d.Dinv, d.dx, d.sigma};
   process_rows<1>(d.B, g, e, lds);
@@ -1481,8 +1485,9 @@ struct EViol : NoPrefetch {
     if ((u[i] < OSQP_INFTY * 1e-4 && a > thr) || (l[i] > -OSQP_INFTY * 1e-4 && a < -thr)) viol += 1.0;
   }
 };
-__global__ __launch_bounds__(kBlock) void k_inf_dual_a(Dev d, double thr, int unscaled) {
+__global__ __launch_bounds__(kBlock) void k_inf_dual_a(Dev d, double thr, int unscaled, int cond) {
   __shared__ StreamLdsW<1, double> lds;
+  if (cond) { if (!ctl_stage2_due(d, NEED_DINF)) return; thr = d.ctl->inf_thr_d; unscaled = d.ctl->inf_unscaled; }
   GVec g{d.dx};
   EViol e{{}, d.l, d.u, d.Einv, thr, unscaled};
   process_rows<1>(d.A, g, e, lds);
@@ -1683,18 +1688,24 @@ __device__ __forceinline__ void ctl_begin_chunk(const Dev &d, const Ctl &c, int 
 }
 __global__ void k_ctl_begin(Dev d, int epoch) {
   Ctl &c = *d.ctl;
-  c.chunk_done = 0; c.rho_flag = 0; c.status = CTL_RUNNING;
+  c.chunk_done = 0; c.rho_flag = 0; c.stage2 = 0; c.status = CTL_RUNNING;
   ctl_begin_chunk(d, c, 0);
   d.slot[2 * SR_WORDS] = epoch;
 }
 // The rules of policy.h at a finished chunk.  One wave: the state block, the residual block and the statistics are staged in LDS
 // (coalesced), lane 0 runs the rules on the LDS copy, the block goes back coalesced.
-__global__ __launch_bounds__(64) void k_decide(Dev d) {
+__global__ __launch_bounds__(64) void k_decide(Dev d, int stage) {
   __shared__ Ctl c;
   __shared__ double res[R_COUNT];
   __shared__ int fl[F_COUNT];
   Ctl *g = d.ctl;
-  if (!(g->chunk_done && g->status == CTL_RUNNING)) return;            // the chunk has not finished (short string), or the solve has
+  if (g->status != CTL_RUNNING) return;                                // the solve is over (or handed to the host)
+  if (stage == 1 ? !g->chunk_done : !g->stage2) {                      // the chunk has not finished (short string) / no second stage pending
+    // (a group that finds its chunk unfinished must not repeat the rho update the PREVIOUS boundary asked for: k_set_rho / k_init_guess
+    //  in the middle of a chunk would reset the PCG start history -- results would depend on how the host timed its strings)
+    if (stage == 1 && threadIdx.x == 0) g->rho_flag = 0;
+    return;
+  }
   static_assert(sizeof(Ctl) % sizeof(int) == 0, "Ctl is copied word by word");
   constexpr int W = sizeof(Ctl) / sizeof(int);
   const int *gi = reinterpret_cast<const int *>(g);
@@ -1704,11 +1715,14 @@ __global__ __launch_bounds__(64) void k_decide(Dev d) {
   for (int i = threadIdx.x; i < F_COUNT; i += 64) fl[i] = d.flags[i];
   __syncthreads();
   if (threadIdx.x == 0) {
-    c.chunk_done = 0;
-    for (int q = 0; q < F_COUNT; q++) c.last_flags[q] = fl[q];
-    const int st = ctl_boundary(c, res, fl);
+    int st;
+    if (stage == 1) {
+      c.chunk_done = 0;
+      for (int q = 0; q < F_COUNT; q++) c.last_flags[q] = fl[q];
+      st = ctl_boundary(c, res, fl);
+    } else st = ctl_boundary_stage2(c, res, c.last_flags);
     c.status = st;
-    if (st == CTL_RUNNING) ctl_begin_chunk(d, c, d.slot[SR_SEQ]);       // (record A: written by the last slot launch of the string)
+    if (st == CTL_RUNNING && !c.stage2) ctl_begin_chunk(d, c, d.slot[SR_SEQ]);       // (record A: written by the last slot launch of the string)
   }
   __syncthreads();
   int *go = reinterpret_cast<int *>(g);
@@ -1838,21 +1852,28 @@ void ctl_group(Dev &d, int diagonal) {
   LAUNCH(k_res_m, d, d, 1);
   LAUNCH(k_res_n, d, d, 1);
   hipLaunchKernelGGL(k_res_final, dim3(R_QN_U + 1), dim3(kBlock), 0, st(d), d, 0, 1);
-  hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, st(d), d);
+  hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, st(d), d, 1);
+  // second stage of the infeasibility tests, when the first asked for it (_osqp.py:815-818, :846-872)
+  LAUNCH(k_inf_primal, d, d, 1);
+  LAUNCH(k_inf_dual_p, d, d, 1);
+  LAUNCH(k_inf_dual_a, d, d, 0.0, 0, 1);
+  hipLaunchKernelGGL(k_res_final, dim3(5), dim3(kBlock), 0, st(d), d, (int)R_ATDY_U, 2);
+  hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, st(d), d, 2);
   LAUNCH(k_set_rho, d, d, 0.0, 1);
   LAUNCH(k_init_guess, d, d, 1);
   if (diagonal) LAUNCH(k_precond, d, d, 1);
 }
-void ctl_poll(Dev &d, Ctl *out, int *seq) {
+void ctl_poll(Dev &d, Ctl *out, int *seq, int *done) {
   HIP_CHECK(hipSetDevice(d.device));
   Impl &p = im(d);
   HIP_CHECK(hipMemcpyAsync(p.pin_ctl2, d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, p.side));
   HIP_CHECK(hipMemcpyAsync(p.pin_poll, d.slot, sizeof(int) * kSlotInts, hipMemcpyDeviceToHost, p.side));
   HIP_CHECK(hipStreamSynchronize(p.side));
   std::memcpy(out, p.pin_ctl2, sizeof(Ctl));
-  if (p.pin_poll[2 * SR_WORDS] != p.epoch) { *seq = 0; out->status = CTL_RUNNING; return; }      // k_ctl_begin has not run yet
+  if (p.pin_poll[2 * SR_WORDS] != p.epoch) { *seq = 0; *done = 0; out->status = CTL_RUNNING; return; }      // k_ctl_begin has not run yet
   const int *ra = p.pin_poll, *rb = p.pin_poll + SR_WORDS;
-  *seq = ra[SR_SEQ] >= rb[SR_SEQ] ? ra[SR_SEQ] : rb[SR_SEQ];
+  const int *nw = ra[SR_SEQ] >= rb[SR_SEQ] ? ra : rb;
+  *seq = nw[SR_SEQ]; *done = nw[SR_ADMM];
 }
 void ctl_download(Dev &d, Ctl *out) {
   HIP_CHECK(hipSetDevice(d.device));
@@ -1870,13 +1891,13 @@ void residuals(Dev &d) {
 }
 void infeas_primal(Dev &d) {
   HIP_CHECK(hipSetDevice(d.device));
-  LAUNCH(k_inf_primal, d, d);
+  LAUNCH(k_inf_primal, d, d, 0);
   hipLaunchKernelGGL(k_res_final, dim3(2), dim3(kBlock), 0, st(d), d, (int)R_ATDY_U, 0);
 }
 void infeas_dual(Dev &d, double thr, int unscaled) {
   HIP_CHECK(hipSetDevice(d.device));
-  LAUNCH(k_inf_dual_p, d, d);
-  LAUNCH(k_inf_dual_a, d, d, thr, unscaled);
+  LAUNCH(k_inf_dual_p, d, d, 0);
+  LAUNCH(k_inf_dual_a, d, d, thr, unscaled, 0);
   hipLaunchKernelGGL(k_res_final, dim3(3), dim3(kBlock), 0, st(d), d, (int)R_PDX_U, 0);
 }
 void fetch_res(Dev &d, double *h) {

@@ -84,7 +84,7 @@ void policy_from_env(OSQPHipPolicy &p, bool runtime_only) {
   on("OSQP_HIP_CG_ESCALATE", p.cg_escalate); on("OSQP_HIP_STALL", p.stall);
   on("OSQP_HIP_SLOT_POLL", p.slot_poll); num("OSQP_HIP_POLL_LOW", p.poll_low); real("OSQP_HIP_POLL_FIRST", p.poll_first);
   real("OSQP_HIP_POLL_FRAC", p.poll_frac); real("OSQP_HIP_POLL_WAIT", p.poll_wait);
-  num("OSQP_HIP_UNITS_AHEAD", p.units_ahead); num("OSQP_HIP_POLL_SLEEP_US", p.poll_sleep_us); real("OSQP_HIP_UNIT_MARGIN", p.unit_margin);
+  num("OSQP_HIP_FINISH_PAIRS", p.finish_pairs); num("OSQP_HIP_POLL_SLEEP_US", p.poll_sleep_us);
   if (std::getenv("OSQP_HIP_SLOT_LOG")) p.slot_log = 1;
   if (std::getenv("OSQP_HIP_BATCH_TIMING")) p.batch_timing = 1;
   if (const char *e = std::getenv("OSQP_HIP_BATCH_VARIANT")) {
@@ -108,7 +108,7 @@ void Engine::default_policy(OSQPHipPolicy *p) {
   p->rho_window = 10; p->rho_window_tol = 0.1; p->rho_persist = 1; p->rho_tol_exp = 0.5;
   p->budget_tolerate = 0.0; p->budget_sigma = 3.0; p->budget_slack = 0; p->budget_full = 0; p->cg_escalate = 1; p->stall = 1;
   p->slot_poll = 1; p->poll_low = 6; p->poll_first = 0.8; p->poll_frac = 0.75; p->poll_wait = 0.7;
-  p->units_ahead = 2; p->poll_sleep_us = 30; p->unit_margin = 1.08;
+  p->finish_pairs = 12; p->poll_sleep_us = 30;
 }
 void Engine::set_default_policy(const OSQPHipPolicy *p) {
   g_default_policy_set = p != nullptr;
@@ -118,7 +118,7 @@ int Engine::get_policy(OSQPHipPolicy *p) const { if (!p) return OSQP_DATA_VALIDA
 int Engine::set_policy(const OSQPHipPolicy *p) {
   if (!p) return OSQP_DATA_VALIDATION_ERROR;
   if (!(p->extrap >= 0 && p->extrap <= 2) || p->rho_window < 0 || !(p->rho_window_tol > 0) || !(p->rho_tol_exp > 0 && p->rho_tol_exp <= 1) ||
-      !(p->budget_sigma >= 0) || p->units_ahead < 1 || !(p->unit_margin >= 1) || p->batch_variant < 0 || p->batch_variant > 5 ||
+      !(p->budget_sigma >= 0) || p->finish_pairs < 1 || p->batch_variant < 0 || p->batch_variant > 5 ||
       !(p->rho_eq_factor == 0 || p->rho_eq_factor >= 1))
     return OSQP_SETTINGS_VALIDATION_ERROR;
   const OSQPHipPolicy old = pol_;
@@ -982,43 +982,65 @@ void Engine::exec_chunk_sync(int cnt, int lim, bool with_res, int kind, double *
 }
 
 // Device-driven chunks from the state block's current chunk on: returns CTL_DONE, CTL_NEED_HOST, or -2 when the time limit passed.
-// The stream carries   [slots for a chunk] [boundary group] [slots] [group] ...   -- a group acts only when the chunk in flight has
-// finished, the slots after a finished chunk idle until the group has set the next one up, and everything idles once the state
-// block says the solve is over: what is computed never depends on how the host sizes or times the strings.
+// The stream carries   [slots] [slots] .. [boundary group] [slots] ..   -- a group acts only when the chunk in flight has finished, the
+// slots after a finished chunk idle until a group has set the next one up, and everything idles once the state block says the solve
+// is over: what is computed never depends on how the host sizes or times the strings.  The host watches the progress on a side
+// stream (be::ctl_poll: no wait on the solve's stream) and keeps the queue a few slot pairs deep: most of what the chunk in flight
+// still needs at the rate observed so far; when little is left, the rest plus a boundary group plus the first part of the NEXT
+// chunk (by then the device has set it up itself).  Between polls the host sleeps.
 int Engine::run_device_driven(double t0, double *res, int *flags) {
   Ctl &c = ctl_;
-  c.status = CTL_RUNNING; c.chunk_done = 0; c.rho_flag = 0;
+  c.status = CTL_RUNNING; c.chunk_done = 0; c.rho_flag = 0; c.stage2 = 0;
   be::ctl_upload(d_, c);
   be::ctl_begin(d_);
   stats_.kernel_launches += 1;
   const int diagonal = settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER;
   auto pairs_for = [&](double its, double pcg) { return 0.5 * its * be::slot_launches(d_, pcg); };
-  Ctl mir = c;                                       // chunk geometry ahead of the device (a function of the iteration count only)
-  Ctl snap = c;
-  long launched = 0;                                 // slot launches enqueued
-  std::deque<long> unit_end;                         // cumulative slot launches at the end of each unit in the queue
-  auto enqueue_unit = [&]() {
-    int cnt = mir.ch_next - mir.iter, kind = mir.ch_kind, tight = mir.ch_tight;
-    if (cnt <= 0) { cnt = c.ct > 0 ? c.ct : 25; kind = 1; tight = 0; }        // (the mirror ran past max_iter: the device lags behind it)
-    const double lim = snap.budget[tight];
-    double pm = snap.kind_n[kind] > 0 ? snap.kind_sum[kind] / snap.kind_n[kind] : slot_pred_[kind];
-    pm = std::min(pm, lim);
-    const int np = (int)std::ceil(pairs_for(cnt, 0) + pol_.unit_margin * (pairs_for(cnt, pm) - pairs_for(cnt, 0))) + 2;
-    run_slots(0, np, 0);
-    run_group(diagonal);
-    launched += 2L * np; unit_end.push_back(launched);
-    if (mir.ch_next > mir.iter) { mir.iter = mir.ch_next; ctl_next_chunk(mir); }
+  auto pred_for = [&](const Ctl &s, int kind, int tight) {
+    const double pm = s.kind_n[kind] > 0 ? s.kind_sum[kind] / s.kind_n[kind] : slot_pred_[kind];
+    return std::min<double>(pm, s.budget[tight]);
   };
-  enqueue_unit();
+  Ctl snap = c;
+  long launched = 0;                                 // slot PAIRS enqueued
+  int seq = 0, done = 0;                             // slot launches executed / ADMM iterations completed in the chunk in flight (polled)
+  const int kLow = pol_.poll_low;
   bool timed_out = false;
-  int seq = 0;
+  // chunk in flight as of the last poll, and the progress counters at the first poll that saw it (rate estimate)
+  int cur_boundaries = snap.boundaries; long seq0 = 0;
+  { const int cnt = snap.ch_next - snap.iter;
+    const int np = std::max(2, (int)std::floor(pol_.poll_first * pairs_for(cnt, pred_for(snap, snap.ch_kind, snap.ch_tight))));
+    run_slots(0, np, 0); launched += np; }
   for (;;) {
-    be::ctl_poll(d_, &snap, &seq);
+    be::ctl_poll(d_, &snap, &seq, &done);
     if (snap.status != CTL_RUNNING) break;
     if (now_s() - t0 > settings.time_limit) { timed_out = true; break; }
-    while (!unit_end.empty() && unit_end.front() <= seq) unit_end.pop_front();      // units the device is through with
-    if ((int)unit_end.size() < pol_.units_ahead) enqueue_unit();
-    else std::this_thread::sleep_for(std::chrono::microseconds(pol_.poll_sleep_us));
+    if (snap.boundaries != cur_boundaries) { cur_boundaries = snap.boundaries; seq0 = seq; }
+    const long ahead = launched - seq / 2;           // pairs enqueued and not yet executed
+    if (ahead > kLow) { std::this_thread::sleep_for(std::chrono::microseconds(pol_.poll_sleep_us)); continue; }
+    const int cnt = snap.ch_next - snap.iter, rem = std::max(0, cnt - done);
+    const double pm = pred_for(snap, snap.ch_kind, snap.ch_tight);
+    const double rate = done >= 2 ? std::min<double>(pairs_for(1, snap.budget[snap.ch_tight]), 0.5 * (double)(seq - seq0) / done) : pairs_for(1, pm);   // pairs per ADMM iteration
+    const int need = (int)std::ceil(rem * rate) + 1 - (int)ahead;
+    if (need > pol_.finish_pairs) {                  // far from the chunk's end: most of what is missing
+      const int np = std::max(2, (int)std::ceil(pol_.poll_frac * need));
+      run_slots(0, np, 0); launched += np;
+      stats_.slot_topups += 1;
+      continue;
+    }
+    // the chunk's end is within reach: the rest, the boundary group, and the first part of the next chunk
+    const int np = std::max(1, need);
+    run_slots(0, np, 0); launched += np;
+    run_group(diagonal);
+    {
+      Ctl nx = snap; nx.iter = snap.ch_next; ctl_next_chunk(nx);
+      const int ncnt = nx.ch_next - nx.iter;
+      if (ncnt > 0) {
+        const int nq = std::max(2, (int)std::floor(pol_.poll_first * pairs_for(ncnt, pred_for(snap, nx.ch_kind, nx.ch_tight))));
+        run_slots(0, nq, 0); launched += nq;
+      }
+    }
+    if (pol_.slot_log) std::fprintf(stderr, "group: device iter %d chunk %d..%d kind %d done %d rem %d rate %.2f ahead %ld pairs %d (launched %ld, seq %d) budget %d/%d tol %.3e rho %.4e\n",
+                                    snap.iter, snap.iter, snap.ch_next, snap.ch_kind, done, rem, rate, ahead, np, launched, seq, snap.budget[0], snap.budget[1], snap.tol_abs, snap.rho_bar);
   }
   be::sync(d_);                                      // (what is still queued idles: the state block says the solve is over -- or, after
   be::ctl_download(d_, &c);                          //  a time-out, runs to the end of the strings)
@@ -1031,7 +1053,7 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
 }
 
 void Engine::run_group(int diagonal) {
-  stats_.kernel_launches += 6 + (diagonal ? 1 : 0);
+  stats_.kernel_launches += 11 + (diagonal ? 1 : 0);
   if (!(use_graph_ && be::graphs_supported())) { be::ctl_group(d_, diagonal); return; }
   const std::array<int, 3> key = {0, 1, diagonal};
   auto it = sgraphs_.find(key);
@@ -1047,6 +1069,7 @@ void Engine::run_group(int diagonal) {
 void Engine::admm_core(double t0, double *res) {
   Ctl &c = ctl_;
   ctl_setup();
+  be::zero(d_, d_.flags + F_STAT_SUM, sizeof(int) * (F_COUNT - F_STAT_SUM));      // (a device-driven solve leaves its last chunk's statistics behind)
   {
     double r0[R_COUNT];
     be::residuals(d_); be::fetch_res(d_, r0);
@@ -1091,6 +1114,13 @@ void Engine::admm_core(double t0, double *res) {
       }
       const bool was_check = c.ch_at_check;
       st = ctl_boundary(c, res, flags);
+      if (st == CTL_RUNNING && c.stage2) {               // second stage of the infeasibility tests (two more SpMVs), then the rest of the boundary
+        if (c.stage2 & NEED_PINF) be::infeas_primal(d_);
+        if (c.stage2 & NEED_DINF) be::infeas_dual(d_, c.inf_thr_d, c.inf_unscaled);
+        double r2[R_COUNT]; be::fetch_res(d_, r2);
+        for (int q = R_ATDY_U; q <= R_ADX_VIOL; q++) res[q] = r2[q];
+        st = ctl_boundary_stage2(c, res, flags);
+      }
       if (was_check) {
         info_from_ctl(t0);
         if (settings.verbose)
@@ -1106,18 +1136,16 @@ void Engine::admm_core(double t0, double *res) {
       if (st == -2) { set_status(OSQP_TIME_LIMIT_REACHED); break; }
     }
     if (st == CTL_DONE) {
-      set_status(c.osqp_status);
-      if (c.osqp_status == OSQP_NON_CVX) info.obj_val = kNaN;
+      const int os = c.osqp_status;
+      set_status(os);
+      if (os == OSQP_NON_CVX) info.obj_val = kNaN;
+      else if (os == OSQP_PRIMAL_INFEASIBLE || os == OSQP_PRIMAL_INFEASIBLE_INACCURATE) info.obj_val = OSQP_INFTY;
+      else if (os == OSQP_DUAL_INFEASIBLE || os == OSQP_DUAL_INFEASIBLE_INACCURATE) info.obj_val = -OSQP_INFTY;
       break;
     }
-    if (st == CTL_NEED_HOST) {
-      // second stage of the infeasibility tests (two more SpMVs) / approximate tolerances at max_iter: Engine::check_termination
-      if ((c.need & (NEED_PINF | NEED_DINF)) && check_termination(res, false)) break;
-      if (c.iter >= settings.max_iter) {                                                   // :1264-1266
-        if (!check_termination(res, true)) set_status(OSQP_MAX_ITER_REACHED);
-        break;
-      }
-      if (ctl_boundary_continue(c, res, flags)) apply_rho(c.rho_bar);
+    if (st == CTL_NEED_HOST) {                            // max_iter without convergence: the approximate-tolerance pass (:1264-1266)
+      if (!check_termination(res, true)) set_status(OSQP_MAX_ITER_REACHED);
+      break;
     }
     if (now_s() - t0 > settings.time_limit) { set_status(OSQP_TIME_LIMIT_REACHED); break; }
   }

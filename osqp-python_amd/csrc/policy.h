@@ -46,6 +46,9 @@ struct Ctl {
   int ch_next, ch_tight, ch_kind, ch_at_check;
   int chunk_done;                 // device: set by the slot kernel that completes the chunk's last ADMM iteration
   int rho_flag;                   // device: rho_bar changed at this boundary -- the conditional set_rho / precond kernels act
+  int stage2;                     // CtlNeed bits: second stage of the infeasibility tests pending (its kernels run, then ctl_boundary_stage2)
+  double inf_nd_p, inf_nd_d;      // ||dy||, ||dx|| of the pending tests (_osqp.py:806, :836); inf_thr_d = eps_dual_inf ||dx|| (threshold of the A dx test)
+  double inf_thr_d; int inf_unscaled;
   int boundaries;                 // boundaries processed (progress, polled by the host)
   int last_flags[F_COUNT];        // PCG statistics of the chunk the last boundary closed (the host needs them when it finishes a boundary)
   // ---- statistics of the solve
@@ -156,26 +159,41 @@ OSQP_HD inline int ctl_stage1(Ctl &c, const double *res, bool approximate, bool 
   if (c.prim_res > OSQP_INFTY || c.dual_res > OSQP_INFTY || c.prim_res != c.prim_res || c.dual_res != c.dual_res) return OSQP_NON_CVX;   // :1025-1028
   bool pri_ok = false, dua_ok = false;
   c.need = NEED_NONE;
+  c.inf_unscaled = unsc ? 1 : 0;
   if (c.m == 0) pri_ok = true;
   else {
     const double eps_pri = ea + er * (unsc ? fmax(res[R_AX_U], res[R_Z_U]) : fmax(res[R_AX_S], res[R_Z_S]));   // :728-751
     if (c.prim_res < eps_pri) pri_ok = true;
     else {
       const double nd = unsc ? res[R_DY_U] : res[R_DY_S];
-      if (nd > epi && res[R_PINF_LHS] < -epi * nd) c.need |= NEED_PINF;
+      if (nd > epi && res[R_PINF_LHS] < -epi * nd) { c.need |= NEED_PINF; c.inf_nd_p = nd; }
     }
   }
   const double mx = unsc ? c.cinv * fmax(fmax(res[R_ATY_U], res[R_PX_U]), res[R_QN_U]) : fmax(fmax(res[R_ATY_S], res[R_PX_S]), res[R_QN_S]);   // :766-794
   if (c.dual_res < ea + er * mx) dua_ok = true;
   else {
     const double nd = unsc ? res[R_DX_U] : res[R_DX_S], sc = unsc ? c.c : 1.0;
-    if (nd > edi && res[R_QDX] < -sc * edi * nd) c.need |= NEED_DINF;
+    if (nd > edi && res[R_QDX] < -sc * edi * nd) { c.need |= NEED_DINF; c.inf_nd_d = nd; c.inf_thr_d = edi * nd; }
   }
   const bool gap_ok = !c.check_dualgap || fabs(c.duality_gap) < ea + er * fmax(fabs(c.obj_val), fabs(c.dual_obj_val));
   if (pri_ok_out) *pri_ok_out = pri_ok;
   if (dua_ok_out) *dua_ok_out = dua_ok;
   if (pri_ok && dua_ok && gap_ok) return approximate ? OSQP_SOLVED_INACCURATE : OSQP_SOLVED;
   return c.need ? -1 : 0;
+}
+
+// Second stage (r2: the block with R_ATDY_*, R_PDX_*, R_ADX_VIOL filled by the second-stage kernels for the tests in c.need):
+// an osqp_status_type value when an infeasibility certificate holds (:815-818, :846-872), else 0.
+OSQP_HD inline int ctl_stage2(const Ctl &c, const double *r2, bool approximate) {
+  double epi = c.eps_pinf, edi = c.eps_dinf;
+  if (approximate) { epi *= 10; edi *= 10; }
+  const bool unsc = c.inf_unscaled != 0;
+  if ((c.need & NEED_PINF) && (unsc ? r2[R_ATDY_U] : r2[R_ATDY_S]) < epi * c.inf_nd_p)
+    return approximate ? OSQP_PRIMAL_INFEASIBLE_INACCURATE : OSQP_PRIMAL_INFEASIBLE;
+  const double sc = unsc ? c.c : 1.0;
+  if ((c.need & NEED_DINF) && (unsc ? r2[R_PDX_U] : r2[R_PDX_S]) < sc * edi * c.inf_nd_d && r2[R_ADX_VIOL] == 0.0)
+    return approximate ? OSQP_DUAL_INFEASIBLE_INACCURATE : OSQP_DUAL_INFEASIBLE;
+  return 0;
 }
 
 // adapt_rho (_osqp.py:910-930) on the indirect path.  Returns true when rho_bar changed.
@@ -219,13 +237,14 @@ OSQP_HD inline bool ctl_boundary_continue(Ctl &c, const double *res, const int *
   ctl_next_chunk(c);
   return rho_changed;
 }
-// A finished chunk, everything that can be decided without the second stage of the infeasibility tests.  Returns CTL_RUNNING (the
-// next chunk is set up in ch_*; rho_flag says whether rho_bar changed), CTL_DONE (osqp_status set) or CTL_NEED_HOST (c.need says why;
-// beyond the accounting and the info fields nothing has been changed: the host finishes the boundary -- second-stage kernels,
-// approximate tolerances at max_iter -- and, if the solve goes on, calls ctl_boundary_continue itself).
+// A finished chunk, first part.  Returns
+//   CTL_RUNNING    the next chunk is set up in ch_* (rho_flag: rho_bar changed) -- or, with c.stage2 != 0, the second stage of the
+//                  infeasibility tests is pending: its kernels have to run, then ctl_boundary_stage2 finishes the boundary;
+//   CTL_DONE       osqp_status set;
+//   CTL_NEED_HOST  max_iter reached without convergence: the approximate-tolerance pass (:1264-1266) is the host's.
 OSQP_HD inline int ctl_boundary(Ctl &c, const double *res, const int *flags) {
   ctl_account(c, flags);
-  c.rho_flag = 0; c.need = NEED_NONE;
+  c.rho_flag = 0; c.need = NEED_NONE; c.stage2 = 0;
   c.boundaries++;
   if (!c.ch_at_check) { ctl_budget_rule(c, flags); ctl_next_chunk(c); return CTL_RUNNING; }
   ctl_info(c, res);
@@ -233,10 +252,19 @@ OSQP_HD inline int ctl_boundary(Ctl &c, const double *res, const int *flags) {
   if (do_check) {
     const int st = ctl_stage1(c, res, false, nullptr, nullptr);
     if (st > 0) { c.osqp_status = st; return CTL_DONE; }
-    if (st < 0) return CTL_NEED_HOST;
+    if (st < 0) { c.stage2 = c.need; return CTL_RUNNING; }
   }
-  if (c.iter >= c.max_iter) { c.need = NEED_MAXITER; return CTL_NEED_HOST; }        // approximate tolerances (:1264-1266): host
+  if (c.iter >= c.max_iter) { c.need = NEED_MAXITER; return CTL_NEED_HOST; }
   ctl_boundary_continue(c, res, flags);
+  return CTL_RUNNING;
+}
+// ... second part, after the second-stage kernels (res: the residual block with their results)
+OSQP_HD inline int ctl_boundary_stage2(Ctl &c, const double *res, const int *flags) {
+  const int st = ctl_stage2(c, res, false);
+  c.stage2 = 0;
+  if (st > 0) { c.osqp_status = st; return CTL_DONE; }
+  if (c.iter >= c.max_iter) { c.need = NEED_MAXITER; return CTL_NEED_HOST; }
+  ctl_boundary_continue(c, c.res, flags);
   return CTL_RUNNING;
 }
 

@@ -51,7 +51,7 @@ bool ctl_supported(const Dev &) { return false; }
 void ctl_upload(Dev &, const Ctl &) {}
 void ctl_begin(Dev &) {}
 void ctl_group(Dev &, int) {}
-void ctl_poll(Dev &, Ctl *, int *seq) { *seq = 0; }
+void ctl_poll(Dev &, Ctl *, int *seq, int *done) { *seq = 0; *done = 0; }
 void ctl_download(Dev &, Ctl *) {}
 void ext_record(Dev &, void *) {}
 void ext_wait(Dev &) {}
