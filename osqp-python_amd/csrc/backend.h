@@ -89,9 +89,9 @@ struct DevF1 {
   int *prp = nullptr, *pcol = nullptr, *psrc = nullptr;   // compact CSR of P + sigma I (n rows): row pointers, columns, position of each entry in B.val
   double *pval = nullptr;        // values, refreshed from B.val by be::f1_refresh (after assembly / equilibration / matrix updates)
   int pnnz = 0;
-  // the n-vectors of the iteration in ONE arena, stride ns doubles: Minv, x~, p, r (parity 0 = Dev::r, 1), s (0 = Dev::s, 1), pu (0, 1),
-  // rep (parity 0: D vectors, parity 1: D vectors).  Dev::Minv / xs / p / r / s point into it.  r_k, s_{k-1}, pu_k and rep_k (what launch
-  // F_k writes) live in parity k & 1.
+  // the n-vectors of the iteration in ONE arena, stride ns doubles: Minv, x~, p, r (parity 0 = Dev::r, 1), s (0 = Dev::s, 1),
+  // rep (parity 0: D vectors, parity 1: D vectors; their sum is K u_k: a block adds (P + sigma I) u_k of its own columns to its slice).
+  // Dev::Minv / xs / p / r / s point into it.  r_k, s_{k-1} and rep_k (what launch F_k writes) live in parity k & 1.
   double *va = nullptr; size_t ns = 0;
 };
 

@@ -1043,16 +1043,16 @@ __global__ __launch_bounds__(kBlock) void k_slot_a(Dev d) {
 // backend.h DevF1.  Launch F_k of the PCG of one ADMM iteration (k = 0 .. iterations):
 //   scalars   k = 0:  ||r_0||, ||rhs|| (KB's partials) -> tolerance, stopping test
 //             k >= 1: gamma_{k-1}, delta_{k-1}, ||r_{k-1}|| (partials of F_{k-1}) -> stopping test (k >= 2), beta_{k-1}, alpha_{k-1}
-//   window    u_k[c] = Minv (r_{k-1} - alpha (w_{k-1} + beta s_{k-2}))[c],  w_{k-1} = pu_{k-1} + sum_d rep_d   (k = 0: Minv r_0)
+//   window    u_k[c] = Minv (r_{k-1} - alpha (w_{k-1} + beta s_{k-2}))[c],  w_{k-1} = sum_d rep_d = K u_{k-1}   (k = 0: Minv r_0)
 //             for every column c of the block's GATHER window (the columns its rows of A and its own rows of P touch) -- recomputed
 //             by every workgroup that gathers c, with the same instruction sequence as the owner's update (f1_upd): all copies
 //             are bit-identical.  The lane whose window column is one of the block's OWN columns also performs that column's
 //             vector update:  s_{k-1}, r_k, p_{k-1}, x~ += alpha p_{k-1}  stored;  partials gamma_k = <r_k, Minv r_k>, ||r_k||_inf
 //   SpMV      t = rho .* (A_g u_k)  (rows of the block, products staged in LDS, one lane per row),
-//             pu_k = (P + sigma I) u_k  on the own columns,  rep_{g mod D} = A_g' t  per column of the block's SCATTER window (the
-//             columns of its rows of A; second, column-ordered pass over the entries still held in registers),
-//             partial delta_k = <t, A u_k> + <u_k, pu_k>_own = <u_k, K u_k>
-// r, s, pu, rep are double-buffered by the parity of k: a workgroup reads what the PREVIOUS launch wrote while its neighbours
+//             pu_k = (P + sigma I) u_k  on the own columns,  rep_{g mod D} = A_g' t (+ pu_k on the own columns)  per column of the block's
+//             SCATTER window (the columns of its rows of A, which include its own columns; second, column-ordered pass over the
+//             entries still held in registers),  partial delta_k = <t, A u_k> + <u_k, pu_k>_own = <u_k, K u_k>
+// r, s, rep are double-buffered by the parity of k: a workgroup reads what the PREVIOUS launch wrote while its neighbours
 // write this launch's values.  Four workgroup barriers per block, no global synchronisation inside the launch.
 // Template: D = replicas, FIRST = the launch F_0 (straight-line code: no run-time branch on either).
 struct F1Lds {
@@ -1060,15 +1060,16 @@ struct F1Lds {
   double prod[kF1Chunk];         // A products in row-major entry order, then val * t[row] in column-major order
   double tvec[kF1MaxRows];       // t of the block's rows
   double uown[kF1MaxOwn];        // u_k on the own columns
+  double puown[kF1MaxOwn];       // (P + sigma I) u_k on the own columns: added to the block's own slice of A' t (the own columns lie inside its scatter window)
   double pprod[kF1PChunk];       // (P + sigma I) products of the own rows
   double red[3 * kWaves];
 };
 struct F1Scal { double alpha, beta; int general; };       // general = 0: the first update (s_0 = w_0, p_0 = u_0: s_{-1}, p_{-1} are not used)
 template <int D>
-__device__ __forceinline__ double f1_w(double pu, const double (&rp)[D]) {     // fixed order: deterministic
-  double w = pu;
+__device__ __forceinline__ double f1_w(const double (&rp)[D]) {     // w_{k-1} = K u_{k-1}: the replicas in index order (deterministic)
+  double w = rp[0];
 #pragma unroll
-  for (int q = 0; q < D; q++) w += rp[q];
+  for (int q = 1; q < D; q++) w += rp[q];
   return w;
 }
 __device__ __forceinline__ void f1_upd(const F1Scal &sc, double minv, double r, double w, double sp, double &sn, double &rn, double &un) {
@@ -1124,8 +1125,12 @@ __device__ __forceinline__ int4 sload_int4(const int *base, size_t idx) {
   return reinterpret_cast<const int4 *>(base)[idx];
 #endif
 }
+struct F1Rec { int4 ds, fa, fb, fc; };      // a block's record (DevF1::blk)
+__device__ __forceinline__ F1Rec f1_record(const DevF1 &f, int b) {
+  return F1Rec{sload_int4(f.blk, 4 * (size_t)b), sload_int4(f.blk, 4 * (size_t)b + 1), sload_int4(f.blk, 4 * (size_t)b + 2), sload_int4(f.blk, 4 * (size_t)b + 3)};
+}
 template <int D, bool FIRST>
-__device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool vec_only, const F1Scal sc, F1Lds &L) {
+__device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool vec_only, const F1Scal sc, F1Lds &L, const F1Rec &rec0) {
   const DevF1 &f = d.f1;
   const int n = d.n, tid = threadIdx.x;
   const int cur = (k + 1) & 1, nxt = k & 1;               // parity of k - 1 / of k
@@ -1139,8 +1144,8 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
   double *rnxt = f.va + (3 + nxt) * ns;                     // r_k
   const double *sprev = va + (5 + cur) * ns;                // s_{k-2}: stored next to r_{k-1}
   double *snew = f.va + (5 + nxt) * ns;                     // s_{k-1}: stored next to r_k
-  const double *pucur = va + (7 + cur) * ns, *repcur = va + (9 + (size_t)cur * D) * ns;
-  double *punxt = f.va + (7 + nxt) * ns, *repnxt = f.va + (9 + (size_t)nxt * D) * ns;
+  const double *repcur = va + (7 + (size_t)cur * D) * ns;   // K u_{k-1} in D partial vectors
+  double *repnxt = f.va + (7 + (size_t)nxt * D) * ns;
   double g_acc = 0.0, rn_acc = 0.0, dl_acc = 0.0;
   // the vector update of one own column (operands in registers): stores s_{k-1}, r_k, p_{k-1}, x~; returns u_k
   auto own_update = [&](int j, double mi, double r, double w, double sp, double pp, double x) -> double {
@@ -1161,8 +1166,8 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     // the block's record: 16 words, one scalar load
     // (read through the constant address space: the index is wave-uniform, so the four int4 become scalar loads behind ONE wait --
     //  as generic-pointer loads inside this loop they were four vector loads, each waited for before the next was issued)
-    const int4 ds = sload_int4(f.blk, 4 * (size_t)b), fa = sload_int4(f.blk, 4 * (size_t)b + 1), fb = sload_int4(f.blk, 4 * (size_t)b + 2),
-               fc = sload_int4(f.blk, 4 * (size_t)b + 3);
+    const F1Rec rec = sl == slot0 ? rec0 : f1_record(f, b);      // (the first block's record was requested before the scalar fold)
+    const int4 ds = rec.ds, fa = rec.fa, fb = rec.fb, fc = rec.fc;
     const int r0 = ds.x, nrows = ds.y - ds.x, k0 = ds.z, cnt = ds.w - ds.z;
     const int cov0 = fa.x, cov1 = fa.y, cs0 = fa.z, nown = fa.w - fa.z;
     const int cpo = fb.x, pk0 = fb.y, pcnt = fb.z - fb.y;
@@ -1175,7 +1180,7 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     const bool hasp = !vec_only && tid < pcnt;
     if (!vec_only) { const int e = pk0 + max(0, min(tid, pcnt - 1)); pv = f.pval[e]; pc = f.pcol[e]; }
     // ---- window parts (+ p, x~ where the window column is one of the block's own)
-    double wm[CW], wr[CW], wp[CW], wsv[CW], wq[CW][D], wpp[CW], wx[CW];
+    double wm[CW], wr[CW], wsv[CW], wq[CW][D], wpp[CW], wx[CW];
     bool wown[CW];
 #pragma unroll
     for (int u = 0; u < CW; u++) {
@@ -1185,7 +1190,6 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
         wown[u] = e < gl && c >= cs0 && c - cs0 < nown;
         wm[u] = Minv[c]; wr[u] = rread[c];
         if (!FIRST) {
-          wp[u] = pucur[c];
 #pragma unroll
           for (int q = 0; q < D; q++) wq[u][q] = repcur[q * ns + c];
           wsv[u] = sprev[c];
@@ -1210,13 +1214,13 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     // ---- operand of a (P + sigma I) entry whose column lies outside the window: its parts, requested now
     const int pcl = pc - g0;
     const bool esc = hasp && !(pcl >= 0 && pcl < gl);
-    double em = 0, er = 0, ep = 0, es = 0, eq[D];
+    double em = 0, er = 0, es = 0, eq[D];
 #pragma unroll
     for (int q = 0; q < D; q++) eq[q] = 0.0;
     if (esc) {
       em = Minv[pc]; er = rread[pc];
       if (!FIRST) {
-        ep = pucur[pc]; es = sprev[pc];
+        es = sprev[pc];
 #pragma unroll
         for (int q = 0; q < D; q++) eq[q] = repcur[q * ns + pc];
       }
@@ -1230,7 +1234,7 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
         double un;
         if (FIRST) un = wm[u] * wr[u];
         else {
-          const double w = f1_w<D>(wp[u], wq[u]);
+          const double w = f1_w<D>(wq[u]);
           if (wown[u]) un = own_update(g0 + e, wm[u], wr[u], w, wsv[u], wpp[u], wx[u]);
           else { double sn, rn; f1_upd(sc, wm[u], wr[u], w, wsv[u], sn, rn, un); }
         }
@@ -1248,7 +1252,7 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
         double rp[D];
 #pragma unroll
         for (int q = 0; q < D; q++) rp[q] = repcur[q * ns + j];
-        un = own_update(j, mi, r, f1_w<D>(pucur[j], rp), sprev[j], p_r[j], xs_r[j]);
+        un = own_update(j, mi, r, f1_w<D>(rp), sprev[j], p_r[j], xs_r[j]);
       }
       if (!vec_only) L.uown[jj] = un;
     }
@@ -1262,7 +1266,7 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
       double uv;
       if (!esc) uv = L.win[pcl];
       else if (FIRST) uv = em * er;
-      else { double sn, rn; f1_upd(sc, em, er, f1_w<D>(ep, eq), es, sn, rn, uv); }
+      else { double sn, rn; f1_upd(sc, em, er, f1_w<D>(eq), es, sn, rn, uv); }
       L.pprod[tid] = pv * uv;
     }
     KT(5);
@@ -1281,7 +1285,7 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     for (int jj = tid; jj < nown; jj += kBlock) {
       if (jj != tid) { pp0 = f.prp[cs0 + jj]; pp1 = f.prp[cs0 + jj + 1]; }
       const double pu = f1_segsum<4>(L.pprod, pp0 - pk0, pp1 - pk0);
-      punxt[cs0 + jj] = pu; dl_acc += L.uown[jj] * pu;
+      L.puown[jj] = pu; dl_acc += L.uown[jj] * pu;
     }
     KT(7);
     __syncthreads();
@@ -1289,7 +1293,15 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     double *rout = repnxt + (size_t)(b % D) * ns;
 #pragma unroll
     for (int u = 0; u < CW; u++) {
-      if (u < ns2) { const int c = tid + u * kBlock; if (c < wl) rout[a0 + c] = f1_segsum<8>(L.prod, cp0[u], cp1[u]); }
+      if (u < ns2) {
+        const int c = tid + u * kBlock;
+        if (c < wl) {
+          double v = f1_segsum<8>(L.prod, cp0[u], cp1[u]);
+          const int jo = a0 + c - cs0;
+          if (jo >= 0 && jo < nown) v += L.puown[jo];         // this block owns the column: + (P + sigma I) u
+          rout[a0 + c] = v;
+        }
+      }
     }
     for (int j = cov0 + tid; j < a0; j += kBlock) rout[j] = 0.0;             // the replica's gap up to the next window of this replica
     for (int j = a0 + wl + tid; j < cov1; j += kBlock) rout[j] = 0.0;
@@ -1305,22 +1317,25 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
 // returns false when the PCG had already converged (nothing done: the caller runs KA in this launch)
 __device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const int cap, const int admm_par, const int probe, F1Lds &L) {
   KT(0);
+  // the first block's record goes out ahead of the partials of the scalar fold: both latencies overlap
+  const int b0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * ((d.A.nblk + 7) >> 3) + (int)(blockIdx.x >> 3));
+  const F1Rec rec0 = f1_record(d.f1, min(b0, d.A.nblk - 1));
   F1Scal sc;
   if (!f1_scalars(d, k, admm_par, probe, L.red, sc)) return false;
   const bool vec_only = !probe && k >= cap;                 // the last budgeted update: no operator apply follows
   if (k == 0) {
     switch (d.f1.D) {
-      case 1: f1_body<1, true>(d, k, vec_only, sc, L); break;
-      case 2: f1_body<2, true>(d, k, vec_only, sc, L); break;
-      case 3: f1_body<3, true>(d, k, vec_only, sc, L); break;
-      default: f1_body<4, true>(d, k, vec_only, sc, L); break;
+      case 1: f1_body<1, true>(d, k, vec_only, sc, L, rec0); break;
+      case 2: f1_body<2, true>(d, k, vec_only, sc, L, rec0); break;
+      case 3: f1_body<3, true>(d, k, vec_only, sc, L, rec0); break;
+      default: f1_body<4, true>(d, k, vec_only, sc, L, rec0); break;
     }
   } else {
     switch (d.f1.D) {
-      case 1: f1_body<1, false>(d, k, vec_only, sc, L); break;
-      case 2: f1_body<2, false>(d, k, vec_only, sc, L); break;
-      case 3: f1_body<3, false>(d, k, vec_only, sc, L); break;
-      default: f1_body<4, false>(d, k, vec_only, sc, L); break;
+      case 1: f1_body<1, false>(d, k, vec_only, sc, L, rec0); break;
+      case 2: f1_body<2, false>(d, k, vec_only, sc, L, rec0); break;
+      case 3: f1_body<3, false>(d, k, vec_only, sc, L, rec0); break;
+      default: f1_body<4, false>(d, k, vec_only, sc, L, rec0); break;
     }
   }
   return true;

@@ -369,6 +369,10 @@ void Engine::prepare_f1(const std::vector<int> &rb, const std::vector<int> &Arp,
     if (k1 == k0 || r1 - r0 > kF1MaxRows || k1 - k0 > kF1Chunk || (r1 - r0 == 1 && k1 - k0 > kLongRow)) return;
     int lo = INT32_MAX, hi = -1;
     for (int k = k0; k < k1; k++) { lo = std::min(lo, Arj[k]); hi = std::max(hi, Arj[k]); }
+    // (the scatter window also covers the block's own columns [rb[b] n / m, rb[b+1] n / m): (P + sigma I) u of those joins the block's
+    //  slice of A' t; a column without entries of the block's rows simply has an empty segment)
+    const int c0 = (int)((long)r0 * n / m), c1 = b + 1 == nb ? n : (int)((long)r1 * n / m);
+    if (c1 > c0) { lo = std::min(lo, c0); hi = std::max(hi, c1 - 1); }
     if (hi - lo + 1 > kF1Win) return;
     a0[b] = lo; wl[b] = hi - lo + 1;
   }
@@ -394,6 +398,7 @@ void Engine::prepare_f1(const std::vector<int> &rb, const std::vector<int> &Arp,
   std::vector<int> order;
   for (int b = 0; b < nb; b++) {
     if (cs[b + 1] - cs[b] > kF1MaxOwn || prp[cs[b + 1]] - prp[cs[b]] > kF1PChunk) return;
+    if (cs[b + 1] > cs[b] && (cs[b] < a0[b] || cs[b + 1] > a0[b] + wl[b])) return;      // the own columns must lie inside the scatter window ((P + sigma I) u joins the block's slice of A' t)
     const int r0 = rb[b], r1 = rb[b + 1], k0 = Arp[r0], k1 = Arp[r1], cnt = k1 - k0;
     int *w = &blk[16 * (size_t)b];
     w[0] = r0; w[1] = r1; w[2] = k0; w[3] = k1;
@@ -427,7 +432,7 @@ void Engine::prepare_f1(const std::vector<int> &rb, const std::vector<int> &Arp,
   f.cptr = dev_vec<unsigned short>(d_, cptr.size()); be::h2d(d_, f.cptr, cptr.data(), sizeof(unsigned short) * cptr.size());
   f.pval = dev_vec<double>(d_, pnnz);
   f.ns = ((size_t)n + 31) / 32 * 32;                       // 256-byte aligned vectors
-  f.va = dev_vec<double>(d_, (9 + 2 * (size_t)D) * f.ns);
+  f.va = dev_vec<double>(d_, (7 + 2 * (size_t)D) * f.ns);
   f.on = 1;
 }
 
