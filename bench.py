@@ -42,16 +42,17 @@ def spmv_bytes(nnz, rows, cols):
     return 12 * nnz + 4 * (rows + 1) + 8 * cols + 8 * rows
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summaries (profiles/*_pmc_FETCH_SIZE.csv and
-    *_pmc_WRITE_SIZE.csv, produced by profiles/run_pmc.sh with one pass per counter): mean over the ACTIVE dispatches,
-    FETCH_SIZE / WRITE_SIZE are in KB, and on gfx950 FETCH_SIZE counts 64 B per 128-B request, i.e. half the bytes of a
-    coalesced stream (MI355X_MICROARCH.md, HBM section) -> doubled.  Returns None when no summary is present."""
+def pmc_traffic(kernel, workload):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summaries of THIS workload (profiles/*_pmc_<workload>_
+    FETCH_SIZE.csv and ..._WRITE_SIZE.csv, produced by profiles/run_pmc.sh with one pass per counter -- PMC passes cannot run inside
+    the timed bench): mean over the ACTIVE dispatches; FETCH_SIZE / WRITE_SIZE are in KB, and on gfx950 FETCH_SIZE counts 64 B per
+    128-B request, i.e. half the bytes of a coalesced stream (MI355X_MICROARCH.md, HBM section) -> doubled.  None when no summary of
+    this workload (same generator, same size) is present -- a figure measured on another problem size is not reported."""
     import csv
     import glob
     vals = {}
     for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
-        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_%s.csv' % ctr)))
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_%s_%s.csv' % (workload, ctr))))
         if not files:
             return None
         for row in csv.DictReader(open(files[-1])):
@@ -62,14 +63,41 @@ def pmc_traffic(kernel):
     return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0
 
 
+def _cpu_child(conn, P, q, A, l, u, settings, seconds_target, linsys):
+    try:
+        conn.send(_cpu_baseline(P, q, A, l, u, settings, seconds_target, linsys))
+    except Exception as e:          # noqa: BLE001 -- reported to the parent, which falls back
+        conn.send({'error': repr(e)})
+
+
 def cpu_baseline(P, q, A, l, u, settings, seconds_target=40.0):
+    """The oracle in a child process with a hard time limit (3x the budget): the direct LDL' path first; when its ordering +
+    factorisation does not fit (dense data blocks: lasso), the oracle's reduced-KKT PCG path on a bounded sample instead -- said
+    so in `sample`."""
+    import multiprocessing as mp
+    ctx = mp.get_context('fork')
+    for linsys in (0, 1):
+        parent, child = ctx.Pipe(duplex=False)
+        pr = ctx.Process(target=_cpu_child, args=(child, P, q, A, l, u, settings, seconds_target, linsys))
+        pr.start()
+        out = parent.recv() if parent.poll(3.0 * seconds_target + 20.0) else None
+        if out is None:
+            pr.terminate()
+        pr.join(5.0)
+        if out is not None and 'error' not in out:
+            return out
+    return {'value': None, 'unit': 'ADMM iter/s', 'cores': 1, 'kind': 'port', 'sample': 'the oracle did not finish a sample within %.0f s' % (3 * seconds_target)}
+
+
+def _cpu_baseline(P, q, A, l, u, settings, seconds_target, linsys):
     """Oracle (direct LDL', AMD ordering, 1 thread) on the same QP, cold-started, for at most ~seconds_target of ADMM
     iterations: run to convergence when that fits (then its iteration count and time-to-solution are reported), else a bounded
     sample of iterations."""
     from oracle import Oracle, SOLVED
     t0 = time.time()
     o = Oracle().setup(P, q, A, l, u, eps_abs=settings['eps_abs'], eps_rel=settings['eps_rel'], max_iter=20,
-                       adaptive_rho_interval=settings['adaptive_rho_interval'], check_termination=settings['check_termination'])
+                       adaptive_rho_interval=settings['adaptive_rho_interval'], check_termination=settings['check_termination'],
+                       linsys=linsys, **({'pcg_max_iter': 200, 'pcg_tol': 1e-7} if linsys else {}))
     t_setup = time.time() - t0
     _, _, info = o.solve()                       # 20 iterations: calibrates the per-iteration cost
     per_it = info.solve_time / max(info.iter, 1)
@@ -78,9 +106,10 @@ def cpu_baseline(P, q, A, l, u, settings, seconds_target=40.0):
     _, _, info = o.solve()
     done = info.status_val == SOLVED
     out = {'value': info.iter / info.solve_time, 'unit': 'ADMM iter/s', 'cores': 1, 'kind': 'port',
-           'sample': '%d cold-started ADMM iterations of the same QP in %.1f s (%s); direct LDL\' KKT solve, own AMD ordering, '
-                     'nnz(L)=%.3g; setup (ordering+factorisation) %.1f s not included'
-                     % (info.iter, info.solve_time, 'run to convergence' if done else 'bounded sample, not converged', info.lnz, t_setup),
+           'sample': '%d cold-started ADMM iterations of the same QP in %.1f s (%s); %s; setup %.1f s not included'
+                     % (info.iter, info.solve_time, 'run to convergence' if done else 'bounded sample, not converged',
+                        ('direct LDL\' KKT solve, own AMD ordering, nnz(L)=%.3g' % info.lnz) if linsys == 0 else
+                        'reduced-KKT Jacobi-PCG (the direct factorisation did not fit the time limit), %.1f PCG iterations per ADMM iteration' % (info.pcg_iters / max(info.iter, 1)), t_setup),
            'setup_s': t_setup}
     if done:
         out['iters_to_converge'] = int(info.iter)
@@ -95,6 +124,9 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--n', '--vars', dest='n', type=int, default=100000, help='variables (m = 2n, nnz(A) = 10n, nnz(P) = 2n); --vars: the spelling torch.distributed.run passes through')
+    ap.add_argument('--config', default='banded', choices=['banded', 'unstructured', 'lasso', 'portfolio'],
+                    help="banded = BASELINE configs[1] (the headline); unstructured = the same sizes with columns drawn from the whole row (GB/s only, "
+                         "SURVEY 8d); lasso = configs[2] (5k features x 10k samples, dense data block); portfolio = configs[3] (10k assets, 100 factors)")
     ap.add_argument('--eps', type=float, default=1e-6)
     ap.add_argument('--cpu-seconds', type=float, default=40.0, help='CPU-baseline budget (0 disables)')
     ap.add_argument('--probe-reps', type=int, default=200)
@@ -123,9 +155,22 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     n = args.n
-    P, q, A, l, u = problems.banded_qp(n, seed=12345)      # replicas: every rank solves the same QP (identical work per GPU)
-    settings = dict(eps_abs=args.eps, eps_rel=args.eps, max_iter=20000, check_termination=25, adaptive_rho_interval=50,
-                    scaling=10, warm_starting=False, verbose=False, device=local)
+    # replicas: every rank solves the same QP (identical work per GPU)
+    if args.config == 'banded':
+        P, q, A, l, u = problems.banded_qp(n, seed=12345); wl_tag = 'banded_n%d' % n
+        wl_name = 'BASELINE configs[1]: single QP n=%d m=%d nnz(A)=%d nnz(P)=%d (problems.banded_qp, seed 12345)'
+    elif args.config == 'unstructured':
+        P, q, A, l, u = problems.banded_qp(n, window=n, seed=12345); wl_tag = 'unstructured_n%d' % n
+        wl_name = 'configs[1] sizes with UNSTRUCTURED columns (SURVEY 8d: GB/s only): single QP n=%d m=%d nnz(A)=%d nnz(P)=%d (problems.banded_qp, window = n)'
+    elif args.config == 'lasso':
+        P, q, A, l, u = problems.lasso_qp(5000, 10000); wl_tag = 'lasso_5k_10k'
+        wl_name = 'BASELINE configs[2]: lasso-as-QP, 5k features x 10k samples, dense data block: n=%d m=%d nnz(A)=%d nnz(P)=%d (problems.lasso_qp, seed 1)'
+    else:
+        P, q, A, l, u = problems.portfolio_qp(10000, 100); wl_tag = 'portfolio_10k_100'
+        wl_name = 'BASELINE configs[3]: portfolio factor model, 10k assets, 100 factors: n=%d m=%d nnz(A)=%d nnz(P)=%d (problems.portfolio_qp, seed 1)'
+    n = len(q)
+    settings = dict(eps_abs=args.eps, eps_rel=args.eps, max_iter=50000 if args.config in ('lasso', 'portfolio') else 20000, check_termination=25,
+                    adaptive_rho_interval=50, scaling=10, warm_starting=False, verbose=False, device=local)
     m = osqp_amd.OSQP(algebra='hip')
     t0 = time.time()
     m.setup(P, q, A, l, u, **settings)
@@ -136,15 +181,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        m.solve()
+    # the FIRST solve of the handle is the true cold solve (rho = the setting); it is timed on its own (it also pays the one-time
+    # capture of the launch graphs).  Every later solve restarts x, z, y from zero but -- like the reference's solver object, whose
+    # adapt_rho writes settings.rho (_osqp.py:923-930) -- keeps the rho the previous solve ended with.
+    first_ms, first_iters = None, None
+    step_iters, step_ms = [], []
+    for w in range(args.warmup):
+        tw = time.perf_counter(); rw = m.solve(); torch.cuda.synchronize()
+        if w == 0:
+            first_ms, first_iters = 1e3 * (time.perf_counter() - tw), int(rw.info.iter)
     barrier()
     t0 = time.perf_counter()
     iters = 0
     res = None
     for _ in range(args.steps):
+        ts = time.perf_counter()
         res = m.solve()
         iters += res.info.iter
+        step_iters.append(int(res.info.iter)); step_ms.append(1e3 * (time.perf_counter() - ts))
     barrier()
     elapsed = time.perf_counter() - t0
     stats = m._solver.hip_stats()
@@ -177,7 +231,7 @@ def main():
             # s, D replicas read; p, x~ read; s, r, p, x~, pu and D replicas written
             f1_bytes = 12 * nnzA + 4 * (mm + 1) + 8 * mm + 2 * f1_D * n + 12 * nnzP_full + 4 * (n + 1) + 8 * n * (4 + f1_D + 2 + 5 + f1_D)
             pcg_kernels = {'F1 one PCG iteration per launch (k_slot1 phase F)': (14, f1_bytes)}
-            seq_id, dom, dom_kernel = 15, 'F1 one PCG iteration per launch (k_slot1 phase F)', 'k_slot1'
+            seq_id, dom, dom_kernel = 15, 'F1 one PCG iteration per launch (k_slot1 phase F)', 'k_f1_probe'
         elif fused:     # two kernels per PCG iteration
             pcg_kernels = {
                 # SpMV(A) applied to Minv.*s (the gathered vector, counted in sA) with the epilogue t = t - alpha rho S (+ rho, t read:
@@ -231,13 +285,17 @@ def main():
             streamed = pcg_bytes; pcg_bytes = survey_pcg_bytes
         tts_ms = 1e3 * tmax / args.steps
         out = {
-            'metric': 'ADMM iterations/sec, n=%d m=%d nnz(A)=%d sparse QP (indirect PCG)' % (n, mm, A.nnz),
+            'metric': 'ADMM iterations/sec, n=%d m=%d nnz(A)=%d %s (indirect PCG)' % (n, mm, A.nnz, 'sparse QP' if args.config in ('banded', 'unstructured') else args.config + ' QP'),
             'value': total_iters / tmax, 'unit': 'ADMM iter/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * tmax / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: single QP n=%d m=%d nnz(A)=%d nnz(P)=%d (problems.banded_qp, seed 12345), '
-                                   'eps_abs=eps_rel=%g, indirect PCG, one replica per GPU' % (n, mm, A.nnz, P.nnz, args.eps),
+            'config': {'workload': (wl_name % (n, mm, A.nnz, P.nnz)) + ', eps_abs=eps_rel=%g, indirect PCG, one replica per GPU' % args.eps,
                        'time_to_solution_ms': tts_ms, 'admm_iters_per_solve': int(res.info.iter), 'status': res.info.status, 'obj_val': res.info.obj_val,
+                       # what a step is, exactly: x, z, y restart from zero; rho is the one the previous solve ended with (the reference's
+                       # solver object behaves the same); the handle's first solve (rho = setting) is reported separately
+                       'rho_carried_between_steps': True, 'first_cold_solve_ms': first_ms, 'first_cold_solve_admm_iters': first_iters,
+                       'mean_admm_iters_per_step': sum(step_iters) / max(len(step_iters), 1), 'admm_iters_per_step': step_iters,
+                       'ms_per_step_each': [round(v, 3) for v in step_ms],
                        'prim_res': res.info.prim_res, 'dual_res': res.info.dual_res, 'rho_updates': int(res.info.rho_updates),
                        'pcg_iters_per_admm_iter': stats['pcg_iters_total'] / max(res.info.iter, 1), 'pcg_budget_limited_iters': int(stats['pcg_unconverged']),
                        'cg_cap_escalations': int(stats.get('cg_cap_escalations', 0)), 'slot_topups': int(stats.get('slot_topups', 0)),
@@ -245,7 +303,7 @@ def main():
                        'pcg_kernels_per_iteration': 1 if f1 else (2 if fused else 3), 'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
                        'setup_s': t_setup, 'per_rank': [{'status': int(r[0]), 'iter': int(r[1]), 'obj': r[2]} for r in allrec]},
             'roofline': {'bound': 'hbm', 'kernel': dom + (' -- in solves this body runs as the K2F phase of k_slot_b' if (fused and not f1) else ''), 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': probes[dom]['GBps'] / HBM_PEAK_GBS, 'traffic': pmc_traffic(dom_kernel),
+                         'frac': probes[dom]['GBps'] / HBM_PEAK_GBS, 'traffic': pmc_traffic(dom_kernel, wl_tag),
                          'bytes_per_launch': kb[dom], 'ms_per_launch': probes[dom]['ms'],
                          'pcg_iteration': {'bytes': pcg_bytes, 'ms': pcg_ms, 'GBps': pcg_bytes / (pcg_ms * 1e-3) / 1e9,
                                            'frac': pcg_bytes / (pcg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

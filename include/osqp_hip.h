@@ -79,7 +79,7 @@ typedef struct {
   enum osqp_precond_type cg_precond;
   OSQPInt   adaptive_rho;
   OSQPInt   adaptive_rho_interval;        /* 0 = automatic (2 * check_termination, or 50) */
-  OSQPFloat adaptive_rho_fraction;        /* accepted for API parity; the automatic interval is not time-based */
+  OSQPFloat adaptive_rho_fraction;        /* IGNORED (validated > 0 for API parity): the automatic interval (adaptive_rho_interval = 0) is 2 * check_termination, not a fraction of the setup time */
   OSQPFloat adaptive_rho_tolerance;
   OSQPInt   max_iter;
   OSQPFloat eps_abs;
@@ -88,7 +88,8 @@ typedef struct {
   OSQPFloat eps_dual_inf;
   OSQPInt   scaled_termination;
   OSQPInt   check_termination;            /* interval; 0 = only at max_iter */
-  OSQPInt   check_dualgap;
+  OSQPInt   check_dualgap;                /* termination additionally requires |duality gap| < eps_abs + eps_rel max(|obj|, |dual obj|); honoured by osqp_solve (small QPs
+                                             then take the host-driven loop, not the one-launch kernel); the batch entry points have no gap test and IGNORE it */
   OSQPFloat time_limit;
   OSQPFloat delta;
   OSQPInt   polish_refine_iter;

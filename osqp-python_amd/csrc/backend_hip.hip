@@ -63,7 +63,7 @@ enum Slot { SL_GAMMA0 = 0, SL_GAMMA1, SL_RN0, SL_RN1, SL_BN, SL_DELTA, SL_DELTA1
 static_assert(SL_RES0 + R_COUNT <= kPartSlots, "Dev::part is too small");
 
 struct Impl {
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_ext = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_ext = nullptr, ev_wait = nullptr;      // ev_ext: end of a batch kernel on a caller's stream (ext_record / ext_wait); ev_wait: stream_wait
   bool ext_pending = false;
   double *pin_res = nullptr;
   int *pin_flags = nullptr;      // [F_COUNT + 16]: the flags block followed by the two slot records
@@ -1764,7 +1764,7 @@ int init(Dev &d, int device) {
   HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   d.stream = s;
   Impl *p = new Impl();
-  HIP_CHECK(hipEventCreate(&p->ev0)); HIP_CHECK(hipEventCreate(&p->ev1)); HIP_CHECK(hipEventCreateWithFlags(&p->ev_ext, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreate(&p->ev0)); HIP_CHECK(hipEventCreate(&p->ev1)); HIP_CHECK(hipEventCreateWithFlags(&p->ev_ext, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&p->ev_wait, hipEventDisableTiming));
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_res), sizeof(double) * R_COUNT, hipHostMallocDefault));
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_flags), sizeof(int) * (F_COUNT + 16), hipHostMallocDefault));
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_poll), sizeof(int) * kSlotInts, hipHostMallocDefault));
@@ -1778,7 +1778,7 @@ void destroy(Dev &d) {
   if (!d.impl) return;
   (void)hipSetDevice(d.device);
   Impl &p = im(d);
-  (void)hipEventDestroy(p.ev0); (void)hipEventDestroy(p.ev1); (void)hipEventDestroy(p.ev_ext); (void)hipHostFree(p.pin_res); (void)hipHostFree(p.pin_flags);
+  (void)hipEventDestroy(p.ev0); (void)hipEventDestroy(p.ev1); (void)hipEventDestroy(p.ev_ext); (void)hipEventDestroy(p.ev_wait); (void)hipHostFree(p.pin_res); (void)hipHostFree(p.pin_flags);
   (void)hipHostFree(p.pin_poll); if (p.side) (void)hipStreamDestroy(p.side);
   (void)hipHostFree(p.pin_ctl); (void)hipHostFree(p.pin_ctl2);
   delete &p; d.impl = nullptr;
@@ -1967,8 +1967,8 @@ void copy_in(Dev &d, void *dst, const void *src, size_t bytes, int src_on_device
 void stream_wait(Dev &d, void *caller_stream) {
   if (!caller_stream || caller_stream == d.stream) return;
   HIP_CHECK(hipSetDevice(d.device));
-  HIP_CHECK(hipEventRecord(im(d).ev_ext, static_cast<hipStream_t>(caller_stream)));
-  HIP_CHECK(hipStreamWaitEvent(st(d), im(d).ev_ext, 0));
+  HIP_CHECK(hipEventRecord(im(d).ev_wait, static_cast<hipStream_t>(caller_stream)));      // (its own event: ev_ext may still mark a pending batch kernel)
+  HIP_CHECK(hipStreamWaitEvent(st(d), im(d).ev_wait, 0));
 }
 void scale_q(Dev &d, double c) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_scale_q, d, d, c); }
 void scale_bounds(Dev &d, int rho_is_vec) {

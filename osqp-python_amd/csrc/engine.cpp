@@ -1298,6 +1298,7 @@ int Engine::warm_start_device(const double *x, const double *y, void *stream) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   if (!be::device_vec_updates()) return OSQP_FUNC_NOT_IMPLEMENTED;
   be::activate(d_);
+  be::ext_wait(d_);                                 // a batch kernel on a caller's stream may still read this solver's vectors
   settings.warm_starting = 1;
   be::stream_wait(d_, stream);
   be::scale_warm(d_, x, y, c_);
@@ -1645,6 +1646,7 @@ void Engine::attach_batch_direct(BatchParams &p) {
 // output (per-iteration printing lives in the host-driven loop), with a time limit, or when OSQP_HIP_SMALL_DIRECT=0.
 bool Engine::small_direct_applicable() {
   if (!pol_.small_direct || !be::device_assembly() || settings.verbose || settings.time_limit < 1e9) return false;
+  if (settings.check_dualgap) return false;            // the one-launch kernel has no duality-gap test: the host-driven loop honours the setting
   if (!be::batch_lds_bytes(n, m)) return false;
   prepare_batch_direct();
   if (!bd_.ok) return false;

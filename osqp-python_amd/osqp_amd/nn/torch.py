@@ -103,10 +103,13 @@ class OSQP(Module):
                 else:
                     x, y, rec = s._solver.hip_batch_solve(q=qn, l=ln, u=un)
                     self.last_dual = y
-            except ValueError:                                                         # does not fit one workgroup's LDS
-                x, rec = self._loop(Pn, qn, An, ln, un, nb, batched)
+            except ValueError as e:                                                    # only "does not fit one workgroup's LDS" falls back
+                if str(e) != str(int(osqp_amd.SolverError.OSQP_FUNC_NOT_IMPLEMENTED)):
+                    raise
+                x, rec = self._loop(Pn, qn, An, ln, un, nb, batched, dev_index)
         else:
-            x, rec = self._loop(Pn, qn, An, ln, un, nb, batched)
+            dev_index = (device.index or 0) if q_val.is_cuda else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+            x, rec = self._loop(Pn, qn, An, ln, un, nb, batched, dev_index)
         bad = np.nonzero(rec[:, 0] != int(osqp_amd.SolverStatus.OSQP_SOLVED))[0]
         if bad.size:
             raise RuntimeError('Unable to solve QP, status: %d (batch element %d)' % (int(rec[bad[0], 0]), int(bad[0])))
@@ -129,7 +132,9 @@ class OSQP(Module):
         try:
             s._solver.hip_batch_solve_device(nb, qd.data_ptr(), ld.data_ptr(), ud.data_ptr(), x.data_ptr(), y.data_ptr(), rec.data_ptr(),
                                              warm=False, stream=stream)
-        except ValueError:
+        except ValueError as e:
+            if str(e) != str(int(osqp_amd.SolverError.OSQP_FUNC_NOT_IMPLEMENTED)):
+                raise
             return None                                                                # does not fit one workgroup's LDS
         st = rec[:, 0].to('cpu')                                                        # (waits for the stream)
         bad = torch.nonzero(st != int(osqp_amd.SolverStatus.OSQP_SOLVED)).flatten()
@@ -138,14 +143,14 @@ class OSQP(Module):
         self.last_dual = y
         return x.to(q_val.dtype)
 
-    def _loop(self, Pn, qn, An, ln, un, nb, batched):
+    def _loop(self, Pn, qn, An, ln, un, nb, batched, dev_index=0):
         """Per-element matrices (or a problem too large for the batch kernel): the single-QP engine, one element after the
         other on the persistent handle -- update(Px, Ax, q, l, u) + solve(), as nn/torch.py:136-157."""
         x = np.zeros((nb, self.n)); rec = np.zeros((nb, 8))
         for i in range(nb):
             Pv = Pn[i] if batched[0] else Pn
             Av = An[i] if batched[2] else An
-            s = self._handle(Pv, Av, qn[i], ln[i], un[i], device=self._device or 0)
+            s = self._handle(Pv, Av, qn[i], ln[i], un[i], device=dev_index)
             s.update(q=qn[i], l=ln[i], u=un[i])
             r = s.solve()
             x[i] = r.x
