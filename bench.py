@@ -124,6 +124,7 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--n', '--vars', dest='n', type=int, default=100000, help='variables (m = 2n, nnz(A) = 10n, nnz(P) = 2n); --vars: the spelling torch.distributed.run passes through')
+    ap.add_argument('--carry-rho', action='store_true', help='keep the rho a solve ended with for the next step (the solver object\'s natural behaviour) instead of restarting every step from the setting')
     ap.add_argument('--config', default='banded', choices=['banded', 'unstructured', 'lasso', 'portfolio'],
                     help="banded = BASELINE configs[1] (the headline); unstructured = the same sizes with columns drawn from the whole row (GB/s only, "
                          "SURVEY 8d); lasso = configs[2] (5k features x 10k samples, dense data block); portfolio = configs[3] (10k assets, 100 factors)")
@@ -181,13 +182,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the FIRST solve of the handle is the true cold solve (rho = the setting); it is timed on its own (it also pays the one-time
-    # capture of the launch graphs).  Every later solve restarts x, z, y from zero but -- like the reference's solver object, whose
-    # adapt_rho writes settings.rho (_osqp.py:923-930) -- keeps the rho the previous solve ended with.
+    # Every step is a TRUE cold solve: x, z, y restart from zero (warm_starting = False) and rho is put back to the setting's value
+    # (the solver object, like the reference's -- adapt_rho writes settings.rho, _osqp.py:923-930 -- would otherwise carry the rho a
+    # solve ended with into the next, and the iteration count of a step would depend on how many steps came before it; --carry-rho
+    # restores that behaviour).  The handle's first solve also pays the one-time capture of the launch graphs: timed on its own.
+    rho0 = 0.1
+    def cold_solve():
+        if not args.carry_rho:
+            m.update_settings(rho=rho0)
+        return m.solve()
     first_ms, first_iters = None, None
     step_iters, step_ms = [], []
     for w in range(args.warmup):
-        tw = time.perf_counter(); rw = m.solve(); torch.cuda.synchronize()
+        tw = time.perf_counter(); rw = cold_solve(); torch.cuda.synchronize()
         if w == 0:
             first_ms, first_iters = 1e3 * (time.perf_counter() - tw), int(rw.info.iter)
     barrier()
@@ -196,7 +203,7 @@ def main():
     res = None
     for _ in range(args.steps):
         ts = time.perf_counter()
-        res = m.solve()
+        res = cold_solve()
         iters += res.info.iter
         step_iters.append(int(res.info.iter)); step_ms.append(1e3 * (time.perf_counter() - ts))
     barrier()
@@ -291,9 +298,9 @@ def main():
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': (wl_name % (n, mm, A.nnz, P.nnz)) + ', eps_abs=eps_rel=%g, indirect PCG, one replica per GPU' % args.eps,
                        'time_to_solution_ms': tts_ms, 'admm_iters_per_solve': int(res.info.iter), 'status': res.info.status, 'obj_val': res.info.obj_val,
-                       # what a step is, exactly: x, z, y restart from zero; rho is the one the previous solve ended with (the reference's
-                       # solver object behaves the same); the handle's first solve (rho = setting) is reported separately
-                       'rho_carried_between_steps': True, 'first_cold_solve_ms': first_ms, 'first_cold_solve_admm_iters': first_iters,
+                       # what a step is, exactly: x, z, y restart from zero and rho restarts from the setting (see cold_solve above); the
+                       # handle's first solve, which also captures the launch graphs, is reported separately
+                       'rho_carried_between_steps': bool(args.carry_rho), 'first_cold_solve_ms': first_ms, 'first_cold_solve_admm_iters': first_iters,
                        'mean_admm_iters_per_step': sum(step_iters) / max(len(step_iters), 1), 'admm_iters_per_step': step_iters,
                        'ms_per_step_each': [round(v, 3) for v in step_ms],
                        'prim_res': res.info.prim_res, 'dual_res': res.info.dual_res, 'rho_updates': int(res.info.rho_updates),
@@ -318,7 +325,8 @@ def main():
         if args.cpu_seconds > 0 and world == 1:          # (the CPU baseline is timed at N = 1 only: the other ranks would wait 40 s at the barrier)
             cb = cpu_baseline(P, q, A, l, u, settings, args.cpu_seconds)
             out['cpu_baseline'] = cb
-            out['config']['gpu_over_cpu_iter_rate'] = (total_iters / tmax / world) / cb['value']
+            if cb.get('value'):
+                out['config']['gpu_over_cpu_iter_rate'] = (total_iters / tmax / world) / cb['value']
             if 'iters_to_converge' in cb:
                 # the iteration-rate ratio overstates the end-to-end ratio when the two sides need different iteration counts:
                 # report time-to-solution on both sides and the engine's rate in units of the reference path's iterations

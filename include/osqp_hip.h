@@ -297,6 +297,8 @@ typedef struct {
   OSQPFloat budget_tolerate, budget_sigma; OSQPInt budget_slack, budget_full;   /* PCG limit per solve: mean + sigma * std of the last chunk (+ slack); full: never below cg_max_iter */
   OSQPInt cg_escalate;        /* double cg_max_iter while the inner solver stagnates; checkpointed first chunk */
   OSQPInt stall;              /* drop the PCG tolerance while the iterates run away (unbounded problems) */
+  OSQPFloat polish_delta_floor; /* polish on the PCG path: the refinement recurrence runs with delta_eff = max(settings.delta, this) (Engine::polish) */
+  OSQPFloat polish_pcg_tol;   /* ... relative residual its inner systems are solved to */
   /* scheduling of the launch strings (results never depend on these) */
   OSQPInt slot_poll; OSQPInt poll_low; OSQPFloat poll_first, poll_frac, poll_wait;      /* host-synchronous chunks: top-ups from polled progress */
   OSQPInt finish_pairs; OSQPInt poll_sleep_us;      /* device-driven chunks: a boundary group goes out when at most finish_pairs slot pairs are missing; pause between polls */

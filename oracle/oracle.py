@@ -108,12 +108,18 @@ class Oracle:
         self.cert = cert
         return x, y, info
 
-    def polish(self, delta=1e-6, polish_refine_iter=3):
-        """The reference's polish step on the iterates the last solve() left (status must be SOLVED): returns x, y, info, status_polish."""
+    def polish(self, delta=1e-6, polish_refine_iter=3, sparse=None):
+        """The reference's polish step on the iterates the last solve() left (status must be SOLVED): returns x, y, info, status_polish.
+        sparse: factorise the reduced KKT matrix with the sparse LDL' of the direct path (oracle_polish_sparse) instead of the dense LU
+        (default: from n + m > 4000 on -- the dense LU is O(N^3)); both restate the same algorithm, tests/test_oracle_golden.py checks
+        one against the other."""
         x = np.empty(self.n); y = np.empty(self.m); info = Info()
         L = lib()
-        L.oracle_polish.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Info)]
-        st = L.oracle_polish(C.c_void_p(self._h), float(delta), int(polish_refine_iter), _dp(x), _dp(y), C.byref(info))
+        if sparse is None:
+            sparse = self.n + self.m > 4000 and self.settings.linsys == 0
+        fn = L.oracle_polish_sparse if sparse else L.oracle_polish
+        fn.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Info)]
+        st = fn(C.c_void_p(self._h), float(delta), int(polish_refine_iter), _dp(x), _dp(y), C.byref(info))
         return x, y, info, st
 
     def update(self, q=None, l=None, u=None, Px=None, Ax=None):

@@ -82,6 +82,7 @@ void policy_from_env(OSQPHipPolicy &p, bool runtime_only) {
   real("OSQP_HIP_BUDGET_TOLERATE", p.budget_tolerate); real("OSQP_HIP_BUDGET_SIGMA", p.budget_sigma); num("OSQP_HIP_BUDGET_SLACK", p.budget_slack);
   if (std::getenv("OSQP_HIP_BUDGET_FULL")) p.budget_full = 1;
   on("OSQP_HIP_CG_ESCALATE", p.cg_escalate); on("OSQP_HIP_STALL", p.stall);
+  real("OSQP_HIP_POLISH_DELTA_FLOOR", p.polish_delta_floor); real("OSQP_HIP_POLISH_PCG_TOL", p.polish_pcg_tol);
   on("OSQP_HIP_SLOT_POLL", p.slot_poll); num("OSQP_HIP_POLL_LOW", p.poll_low); real("OSQP_HIP_POLL_FIRST", p.poll_first);
   real("OSQP_HIP_POLL_FRAC", p.poll_frac); real("OSQP_HIP_POLL_WAIT", p.poll_wait);
   num("OSQP_HIP_FINISH_PAIRS", p.finish_pairs); num("OSQP_HIP_POLL_SLEEP_US", p.poll_sleep_us);
@@ -107,6 +108,7 @@ void Engine::default_policy(OSQPHipPolicy *p) {
   p->extrap = 0.9; p->rho_eq_factor = 0.0;
   p->rho_window = 10; p->rho_window_tol = 0.1; p->rho_persist = 1; p->rho_tol_exp = 0.5;
   p->budget_tolerate = 0.0; p->budget_sigma = 3.0; p->budget_slack = 0; p->budget_full = 0; p->cg_escalate = 1; p->stall = 1;
+  p->polish_delta_floor = 1e-3; p->polish_pcg_tol = 1e-15;
   p->slot_poll = 1; p->poll_low = 6; p->poll_first = 0.8; p->poll_frac = 0.75; p->poll_wait = 0.7;
   p->finish_pairs = 12; p->poll_sleep_us = 30;
 }
@@ -119,7 +121,7 @@ int Engine::set_policy(const OSQPHipPolicy *p) {
   if (!p) return OSQP_DATA_VALIDATION_ERROR;
   if (!(p->extrap >= 0 && p->extrap <= 2) || p->rho_window < 0 || !(p->rho_window_tol > 0) || !(p->rho_tol_exp > 0 && p->rho_tol_exp <= 1) ||
       !(p->budget_sigma >= 0) || p->finish_pairs < 1 || p->batch_variant < 0 || p->batch_variant > 5 ||
-      !(p->rho_eq_factor == 0 || p->rho_eq_factor >= 1))
+      !(p->rho_eq_factor == 0 || p->rho_eq_factor >= 1) || !(p->polish_delta_floor > 0) || !(p->polish_pcg_tol > 0 && p->polish_pcg_tol < 1))
     return OSQP_SETTINGS_VALIDATION_ERROR;
   const OSQPHipPolicy old = pol_;
   pol_ = *p; pol_explicit_ = true;
@@ -1159,14 +1161,28 @@ void Engine::admm_core(double t0, double *res) {
   stats_.cg_cap_escalations = c.escalations;
 }
 
-// Solution polish (_osqp.py:1710-1828).  The reference guesses the active constraints from (z, y), solves the
-// equality-constrained QP on that active set with a direct factorisation of the reduced KKT matrix (plus iterative
-// refinement), and keeps the result if it improves the residuals.  This engine has no factorisation; the same reduced
-// problem  min 1/2 x'Px + q'x  s.t.  A_act x = b_act  is solved by the engine's own ADMM on modified bounds: active rows
-// become equalities l = u = bound (weight 1e3 rho, as every all-equality problem: classify_constraints), inactive rows
-// become "loose" (-inf, +inf: rho = 1e-6, y = 0), warm-started from the ADMM solution and run to a tolerance 1e-4 times
-// tighter.  Acceptance test and the normal-cone projection follow the reference (:1780-1793).
+// Solution polish (_osqp.py:1710-1828) on the multi-kernel (PCG) path.  The reference guesses the active constraints from (z, y)
+// (:1719-1720), solves the reduced KKT system of the equality-constrained QP on that active set
+//     [ P   Aa' ] [x ]   [ -q ]
+//     [ Aa  0   ] [ya] = [ ba ]            regularised by  diag(+delta I, -delta I)   (:1740-1754)
+// with a direct factorisation, repairs the regularisation's error by `polish_refine_iter` steps of iterative refinement
+//     s <- s + (K + dK)^-1 (rhs - K s)                                                   (:1692-1708)
+// and keeps the result if it improves the residuals (:1786-1793).  Eliminating ya from one refinement step gives
+//     (P + delta I + Aa' Aa / delta) x+ = -q + delta x - Aa' ya + Aa' ba / delta ,    ya+ = ya + (Aa x+ - ba) / delta
+// -- the proximal method of multipliers with parameter delta, and at the same time ONE ADMM iteration of this engine (alpha = 1) on
+// the problem whose active rows are equalities at their bound with weight rho_i = 1 / delta and whose other rows are free: KB forms
+// exactly that right-hand side from (x, z = ba, y = ya), the PCG solves the system, KA's y-update is the multiplier step.  So the
+// polish IS the reference's recurrence, run by the engine's own kernels with the inner systems solved to a relative residual of 1e-15
+// (the right-hand side carries the 1 / delta_eff weights: 1e-12 there leaves 1e-8 in the dual residual).  What differs:
+//   * 1 / delta = 1e6 (the default) is out of reach of a Jacobi-preconditioned PCG (condition number ~ ||Aa||^2 / (delta lambda_min)):
+//     the recurrence runs with delta_eff = max(delta, 1e-3).  The fixed point -- the solution of the unregularised reduced KKT system
+//     -- does not depend on delta; only the contraction per step does (~ delta / mu instead of 1e-6 / mu), so
+//   * `polish_refine_iter` is the MINIMUM number of refinement steps: the recurrence continues (at most kPolishMaxSteps) until the
+//     reduced system's residuals stop improving, which is where the reference's few steps at delta = 1e-6 end up as well
+//     (tests/test_gpu_polish.py compares with the oracle's polish, pinned to the reference, to 1e-8);
+//   * the proximal term uses sigma (already on B's diagonal) in place of delta: any positive weight has the same fixed point.
 void Engine::polish() {
+  constexpr int kPolishMaxSteps = 30;
   const double tp = now_s();
   ensure_host_vectors();
   const bool unsc = settings.scaling && !settings.scaled_termination;
@@ -1175,8 +1191,10 @@ void Engine::polish() {
   be::d2h(d_, y.data(), d_.y, sizeof(double) * m);
   // keep the ADMM result
   const OSQPInfo info0 = info;
-  const OSQPSettings set0 = settings;
-  const double rho0 = rho_bar_;
+  const OSQPHipStats stats0 = stats_;
+  const double rho0 = rho_bar_, alpha0 = d_.alpha;
+  const int eq_from_cnt0 = d_.eq_from_cnt; const double eq_factor0 = d_.rho_eq_factor;
+  const double pred0[3] = {slot_pred_[0], slot_pred_[1], slot_pred_[2]};
   const std::vector<double> ls0 = ls_, us0 = us_, y0 = y, z0 = z;
   std::vector<double> hx(n);
   be::d2h(d_, hx.data(), d_.x, sizeof(double) * n);
@@ -1188,26 +1206,46 @@ void Engine::polish() {
     else if (upp) { lp[i] = up[i] = us0[i]; z[i] = us0[i]; }
     else { lp[i] = -OSQP_INFTY; up[i] = OSQP_INFTY; y[i] = 0.0; }
   }
-  apply_scaled_bounds(lp, up);
-  be::h2d(d_, d_.z, z.data(), sizeof(double) * m);
-  be::h2d(d_, d_.y, y.data(), sizeof(double) * m);
-  rho_bar_ = clamp_rho(rho0);
-  be::set_rho(d_, rho_bar_);
-  be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
-  be::init_iterates(d_, 0);
-  settings.eps_abs = std::max(1e-4 * set0.eps_abs, 1e-13); settings.eps_rel = std::max(1e-4 * set0.eps_rel, 1e-13);
-  settings.max_iter = std::max(200, 100 * std::max(1, set0.polish_refine_iter)); settings.verbose = 0; settings.time_limit = 1e10;
-  settings.check_termination = set0.check_termination > 0 ? std::min(set0.check_termination, 10) : 10;
-  settings.adaptive_rho_interval = 2 * settings.check_termination;
+  auto restore = [&]() {
+    d_.alpha = alpha0; drop_graphs();
+    for (int k = 0; k < 3; k++) slot_pred_[k] = pred0[k];
+    stats_ = stats0;
+  };
   double res[R_COUNT];
-  try { admm_core(now_s(), res); }
-  catch (...) {                       // a device failure mid-polish must not leave the polish's settings / bounds on the handle
-    settings = set0; info = info0; rho_bar_ = rho0; settings.rho = rho0; ls_ = ls0; us_ = us0;
+  try {
+    apply_scaled_bounds(lp, up);                      // active rows: equalities at their bound; the others: loose (rho = 1e-6, y = 0)
+    be::h2d(d_, d_.z, z.data(), sizeof(double) * m);
+    be::h2d(d_, d_.y, y.data(), sizeof(double) * m);
+    const double de = std::max(settings.delta, pol_.polish_delta_floor);
+    d_.rho_eq_factor = 1.0; d_.eq_from_cnt = 0;       // rho_i = rho_bar = 1 / delta_eff on the active rows
+    rho_bar_ = clamp_rho(1.0 / de);
+    be::set_rho(d_, rho_bar_);
+    be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+    be::init_iterates(d_, 0);
+    d_.alpha = 1.0; drop_graphs();                    // (no relaxation: the refinement recurrence; alpha is baked into captured launches)
+    int flags[F_COUNT];
+    double best = std::numeric_limits<double>::infinity();
+    int worse = 0;
+    const int min_steps = 1 + std::max(0, settings.polish_refine_iter);
+    for (int s = 0; s < kPolishMaxSteps; s++) {
+      be::set_pcg_tol(d_, pol_.polish_pcg_tol, 1e-15);  // ||r|| <= polish_pcg_tol ||rhs||
+      exec_chunk_sync(1, kMaxCg, true, 1, res, flags);
+      // residuals of the reduced KKT system: Aa x - ba (active rows) and P x + q + Aa' ya, in the scaled space
+      const double err = std::max(res[R_PRI_S] / (std::max(res[R_AX_S], res[R_Z_S]) + 1e-30),
+                                  res[R_DUA_S] / (std::max(std::max(res[R_ATY_S], res[R_PX_S]), res[R_QN_S]) + 1e-30));
+      if (!(err < 0.5 * best)) worse++; else worse = 0;
+      best = std::min(best, err);
+      if (s + 1 >= min_steps && (err < 1e-13 || worse >= 2)) break;
+    }
+  } catch (...) {                       // a device failure mid-polish must not leave the polish's weights / bounds on the handle
+    restore();
+    info = info0; rho_bar_ = rho0; settings.rho = rho0; ls_ = ls0; us_ = us0;
     classify_constraints(ls_, us_);
     throw;
   }
+  restore();
   // polished point against the ORIGINAL problem: z = A x, then the normal-cone projection of (z, y)  (:1773-1780)
-  settings = set0; info = info0;
+  info = info0;
   apply_scaled_bounds(ls0, us0);
   be::init_iterates(d_, 1);                        // z = A x_pol
   be::project_normalcone(d_);                      // tmp = z + y; z = clip(tmp, l, u); y = tmp - z
@@ -1218,6 +1256,7 @@ void Engine::polish() {
   const bool ok = (pol_pri < info0.prim_res && pol_dua < info0.dual_res) || (pol_pri < info0.prim_res && info0.dual_res < 1e-10) ||
                   (pol_dua < info0.dual_res && info0.prim_res < 1e-10);                 // :1786-1793
   rho_bar_ = rho0; settings.rho = rho0;
+  d_.eq_from_cnt = eq_from_cnt0; if (eq_from_cnt0) d_.rho_eq_factor = eq_factor0;
   be::set_rho(d_, rho_bar_);
   be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
   if (ok) {
@@ -1232,7 +1271,7 @@ void Engine::polish() {
   }
   be::init_iterates(d_, 0);
   info.polish_time = now_s() - tp;
-  if (set0.verbose) std::printf("plsh  %11.4e   %8.2e   %8.2e   --------  (%s)\n", pol_obj, pol_pri, pol_dua, ok ? "accepted" : "rejected");
+  if (settings.verbose) std::printf("plsh  %11.4e   %8.2e   %8.2e   --------  (%s)\n", pol_obj, pol_pri, pol_dua, ok ? "accepted" : "rejected");
 }
 
 void Engine::store_solution() {                                                          // _osqp.py:1098-1115

@@ -64,7 +64,7 @@ class PolicyStruct(C.Structure):       # OSQPHipPolicy, include/osqp_hip.h (same
     _fields_ = ([(k, C.c_int) for k in ('graph', 'slots', 'pcg_fused', 'f1', 'window', 'device_driven', 'small_direct', 'batch_reorder', 'batch_variant')] +
                 [('extrap', C.c_double), ('rho_eq_factor', C.c_double), ('rho_window', C.c_int), ('rho_window_tol', C.c_double), ('rho_persist', C.c_int),
                  ('rho_tol_exp', C.c_double), ('budget_tolerate', C.c_double), ('budget_sigma', C.c_double), ('budget_slack', C.c_int), ('budget_full', C.c_int),
-                 ('cg_escalate', C.c_int), ('stall', C.c_int), ('slot_poll', C.c_int), ('poll_low', C.c_int), ('poll_first', C.c_double),
+                 ('cg_escalate', C.c_int), ('stall', C.c_int), ('polish_delta_floor', C.c_double), ('polish_pcg_tol', C.c_double), ('slot_poll', C.c_int), ('poll_low', C.c_int), ('poll_first', C.c_double),
                  ('poll_frac', C.c_double), ('poll_wait', C.c_double), ('finish_pairs', C.c_int), ('poll_sleep_us', C.c_int),
                  ('slot_log', C.c_int), ('setup_timing', C.c_int), ('batch_timing', C.c_int)])
 

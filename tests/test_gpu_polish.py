@@ -125,3 +125,48 @@ def test_batch_polish():
     assert (rec0[:, F.index('status_polish')] == 0).all()
     k = problems.kkt_certificate(P, q, A, L[0], U[0], x0[0], y0[0])
     assert max(k['pri'], k['dua']) > 1e-6                                     # (the unpolished eps = 1e-3 point, for contrast)
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / (1 + np.abs(b).max())
+
+
+@pytest.mark.parametrize('n,window,eps', [(2000, 40, 1e-4), (20000, 40, 1e-4), (100000, 200, 1e-4)])
+def test_polish_on_the_pcg_path_matches_the_oracle(n, window, eps):
+    """The multi-kernel (PCG) path -- the one BASELINE configs 2-4 take: the reference's refinement recurrence run by the engine's own
+    kernels (Engine::polish: proximal method of multipliers = one ADMM iteration with alpha = 1, weight 1 / delta_eff on the active rows
+    and the inner system solved to 1e-15) against the oracle's polish (reduced KKT system factorised directly, delta = 1e-6, three
+    refinement steps; pinned to the pure-python reference, the sparse variant to the dense one in tests/test_oracle_golden.py).
+    Whenever the active-set guess is the optimal one both land on the solution of the same reduced KKT system: 1e-8 in x and y.
+    The two sides guess from DIFFERENT ADMM iterates (direct vs inexact inner solves stop at different points); where the oracle's
+    guess is off -- its polished residuals then stay at 1e-5, the reference algorithm accepts that as an improvement -- the engine's
+    result is certified on its own: KKT residuals of the ORIGINAL problem recomputed on the host at 1e-9.  (At eps = 1e-3 the oracle's
+    polish rejects its own result on these problems while the engine's succeeds: tools/polish_pcg_probe.py.)"""
+    P, q, A, l, u = problems.banded_qp(n, window=window)
+    st = dict(eps_abs=eps, eps_rel=eps, max_iter=20000, adaptive_rho_interval=50, check_termination=25)
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, polishing=True, **st)
+    r = m.solve()
+    assert int(m._solver.hip_stats()['kernel_launches']) > 1                 # the multi-kernel path
+    assert r.info.status_val == 1 and r.info.status_polish == 1
+    k = problems.kkt_certificate(P, q, A, l, u, r.x, r.y)
+    ax = A @ r.x
+    scale_p = 1 + max(np.abs(ax).max(), np.abs(np.clip(ax, l, u)).max())
+    scale_d = 1 + max(np.abs(P @ r.x).max(), np.abs(A.T @ r.y).max(), np.abs(q).max())
+    assert k['pri'] <= 1e-9 * scale_p and k['dua'] <= 1e-9 * scale_d, k          # (relative to the terms the residuals are differences of)
+    assert r.info.prim_res <= 1e-9 * scale_p and r.info.dual_res <= 1e-9 * scale_d
+    o = Oracle().setup(P, q, A, l, u, **st)
+    xo, yo, io = o.solve()
+    assert io.status_val == SOLVED
+    xp, yp, ip, sp_ = o.polish(delta=1e-6, polish_refine_iter=3)
+    print('n=%d eps=%g: ADMM %d iterations (oracle %d); polish %s in %.1f ms; |dx| %.2e |dy| %.2e; residuals %.1e / %.1e (oracle polish %d: %.1e / %.1e)'
+          % (n, eps, r.info.iter, io.iter, r.info.status_polish, 1e3 * r.info.polish_time, _rel(r.x, xp), _rel(r.y, yp), r.info.prim_res, r.info.dual_res, sp_, ip.pri_res, ip.dua_res))
+    if sp_ == 1 and ip.pri_res <= 1e-12 and ip.dua_res <= 1e-12:             # the oracle's guess was the optimal active set too
+        assert _rel(r.x, xp) < 1e-8 and _rel(r.y, yp) < 1e-8
+        assert abs(r.info.obj_val - ip.obj_val) <= 1e-9 * (1 + abs(ip.obj_val))
+    else:
+        assert n > 2000                                                      # (the small case must be a real comparison)
+    if n <= 20000:
+        # delta and polish_refine_iter are honoured: a larger delta_eff contracts less per step, more steps repair it -- same fixed point
+        m2 = osqp_amd.OSQP(); m2.setup(P, q, A, l, u, verbose=False, polishing=True, delta=1e-2, polish_refine_iter=8, **st)
+        r2 = m2.solve()
+        assert r2.info.status_polish == 1 and _rel(r2.x, r.x) < 1e-7 and _rel(r2.y, r.y) < 1e-7

@@ -144,3 +144,25 @@ def test_oracle_polish_matches_purepy_and_c_core(name):      # polishing_test.py
         npt.assert_allclose(x, f['ref_x'], rtol=0, atol=1e-12 * (1 + np.abs(f['ref_x']).max()))
         npt.assert_allclose(y, f['ref_y'], rtol=0, atol=1e-12 * (1 + np.abs(f['ref_y']).max()))
         npt.assert_allclose(info.obj_val, float(f['ref_obj']), rtol=1e-12)
+
+
+def test_oracle_sparse_polish_equals_the_dense_restatement():
+    """oracle_polish_sparse (the reduced KKT matrix assembled into the direct path's LDL' structure: what makes the oracle's polish usable
+    at BASELINE sizes) against oracle_polish (dense LU, pinned to the pure-python reference above): same algorithm, 1e-12."""
+    import problems
+    for gen in (lambda: problems.banded_qp(1200, window=40), lambda: problems.random_qp(), lambda: problems.portfolio_qp(150, 8),
+                lambda: problems.banded_qp(60, m=90, window=12, seed=5)):
+        P, q, A, l, u = gen()
+        out = []
+        for sparse in (False, True):
+            o = Oracle().setup(P, q, A, l, u, eps_abs=1e-4, eps_rel=1e-4, max_iter=20000, adaptive_rho_interval=50, check_termination=25)
+            _, _, io = o.solve()
+            assert io.status_val == SOLVED
+            xp, yp, ip, st = o.polish(delta=1e-6, polish_refine_iter=3, sparse=sparse)
+            _, _, again = o.solve()                        # the ADMM factorisation is intact afterwards
+            assert again.status_val == SOLVED
+            out.append((xp, yp, st, ip.obj_val))
+        (xa, ya, sa, oa), (xb, yb, sb, ob) = out
+        assert sa == sb == 1
+        assert np.abs(xa - xb).max() <= 1e-12 * (1 + np.abs(xa).max()) and np.abs(ya - yb).max() <= 1e-12 * (1 + np.abs(ya).max())
+        assert abs(oa - ob) <= 1e-12 * (1 + abs(oa))
