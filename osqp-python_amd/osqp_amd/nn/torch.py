@@ -85,8 +85,8 @@ class OSQP(Module):
         shared = not batched[0] and not batched[2]
         Pn, An = _np(P_val), _np(A_val)                                                # (small: the matrix VALUES, once per forward)
         rank, world = _distributed()
-        if shared and q_val.is_cuda and world == 1:                                    # data on the GPU: zero-copy
-            out = self._forward_device(Pn, An, q_val, l_val, u_val, nb)
+        if shared and q_val.is_cuda:                                                   # data on the GPU: zero-copy (one rank, or this rank's share)
+            out = self._forward_device(Pn, An, q_val, l_val, u_val, nb, rank, world)
             if out is not None:
                 return out if any(batched) else out.squeeze(0)
         bc = lambda a, k: a if a.ndim == 2 else np.broadcast_to(a, (nb, k))          # nn/torch.py:184-188
@@ -116,8 +116,10 @@ class OSQP(Module):
         out = torch.as_tensor(x, dtype=dtype, device=device)
         return out if any(batched) else out.squeeze(0)
 
-    def _forward_device(self, Pn, An, q_val, l_val, u_val, nb):
-        """q, l, u stay where they are (float64, contiguous, (nb, .) on q_val's device); x comes back as a device tensor."""
+    def _forward_device(self, Pn, An, q_val, l_val, u_val, nb, rank=0, world=1):
+        """q, l, u stay where they are (float64, contiguous, (nb, .) on q_val's device); x comes back as a device tensor.  In a
+        distributed job (world > 1) this rank solves its contiguous share by device pointer and the shares meet in two all_gathers of
+        device tensors (records, solutions) -- no host copy of q, l, u or x (sharded.solve_batch_sharded_device)."""
         dev = q_val.device
         exp = lambda t, k: t.detach().to(device=dev, dtype=torch.float64).expand(nb, k).contiguous()
         qd, ld, ud = exp(q_val, self.n), exp(l_val, self.m), exp(u_val, self.m)
@@ -125,6 +127,19 @@ class OSQP(Module):
             s = self._handle(Pn, An, qd[0].cpu().numpy(), ld[0].cpu().numpy(), ud[0].cpu().numpy(), device=dev.index or 0)
         else:
             s = self._handle(Pn, An, None, None, None, device=dev.index or 0)
+        if world > 1:
+            try:
+                table, xl, yl, (lo, hi) = sharded.solve_batch_sharded_device(s, q=qd, l=ld, u=ud, rank=rank, world=world)
+            except ValueError as e:
+                if str(e) != str(int(osqp_amd.SolverError.OSQP_FUNC_NOT_IMPLEMENTED)):
+                    raise
+                return None
+            st = table[:, 1].to('cpu')                                                  # 8 bytes per problem: the statuses
+            bad = torch.nonzero(st != int(osqp_amd.SolverStatus.OSQP_SOLVED)).flatten()
+            if bad.numel():
+                raise RuntimeError('Unable to solve QP, status: %d (batch element %d)' % (int(st[bad[0]]), int(bad[0])))
+            self.last_dual = sharded.gather_rows_device(yl, nb)
+            return sharded.gather_rows_device(xl, nb).to(q_val.dtype)
         x = torch.empty((nb, self.n), dtype=torch.float64, device=dev)
         y = torch.empty((nb, self.m), dtype=torch.float64, device=dev)
         rec = torch.empty((nb, 12), dtype=torch.float64, device=dev)    # OSQP_HIP_BATCH_REC

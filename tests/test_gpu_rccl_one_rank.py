@@ -31,3 +31,19 @@ def test_batch_bench_through_rccl_with_one_rank():
 def test_headline_bench_through_rccl_with_one_rank():
     d = _run('bench.py', ['--steps', '1', '--warmup', '0', '--vars', '4000', '--cpu-seconds', '0', '--probe-reps', '5'], 29532)
     assert d['n_gpus'] == 1 and d['config']['status'] == 'solved' and d['value'] > 0
+
+
+def test_device_resident_sharded_batch_through_rccl_with_one_rank():
+    """sharded.solve_batch_sharded_device: this rank's share by device pointer, records assembled on the device, both all_gathers on
+    device tensors over RCCL -- and no host copy of q / l / u / x (torch.Tensor.cpu is instrumented in the script); the two shares of a
+    2-rank split reproduce the full batch bit for bit."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'tests', 'scripts', 'sharded_device_rccl.py')]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['solved'] == d['B'] and d['table_is_cuda'] and d['x_is_cuda']
+    assert d['max_dx_vs_host_path'] == 0.0 and d['max_dx_two_shares'] == 0.0
+    assert d['shares'] == [[0, 18], [18, 37]] and d['indices_ok']
+    assert d['big_host_copies'] == []
