@@ -95,6 +95,26 @@ struct DevF1 {
   double *va = nullptr; size_t ns = 0;
 };
 
+// Woodbury correction of the Jacobi preconditioner for a FEW dense rows of A (portfolio: k + 1 rows with thousands of entries next to
+// n one-entry rows).  With L = the long rows (more than kLongRow entries; at most kWbMaxRows of them),
+//     K = K0 + A_L' diag(rho_L) A_L ,   M = D0 + A_L' diag(rho_L) A_L ,   D0 = diag(K0) = diag(P) + sigma + sum_{i not in L} rho_i A_ij^2
+//     M^-1 r = y - D0^-1 A_L' S^-1 A_L y ,   y = D0^-1 r ,   S = diag(1 / rho_L) + A_L D0^-1 A_L'          (r_L x r_L, dense, SPD)
+// Jacobi alone sees nothing of the rank-r_L block, which carries the large eigenvalues (portfolio: 18.6 PCG iterations per ADMM
+// iteration); M is exact whenever K0 is diagonal.  Per application: one pass over the long rows (g = A_L y), an r_L x r_L product
+// (h = S^-1 g, S^-1 formed on the host at every rho update: r_L^3 / 3 flops), one pass over their transpose.  Three-kernel PCG form.
+constexpr int kWbMaxRows = 128;
+struct DevWb {
+  int on = 0, r = 0;
+  DevCsr AL, ALT;                // the long rows (r x n) and their transpose (n x r); values gathered from A.val through al_src / alt_src
+  int *al_src = nullptr, *alt_src = nullptr;
+  unsigned char *islong = nullptr;   // [m]
+  int *rows = nullptr;           // [r] row indices in A
+  double *WT = nullptr;          // [n][r] dense transpose of the long rows (column j of A_L contiguous): S is formed from it
+  double *S = nullptr, *Sinv = nullptr;   // [r][r]
+  double *g = nullptr, *h = nullptr;      // [r]
+  double *Dinv0 = nullptr;       // [n]  1 / D0
+};
+
 // indices into Dev::res (results of the residual kernels, reduced on the device)
 enum ResId {
   R_PRI_U = 0, R_AX_U, R_Z_U, R_PRI_S, R_AX_S, R_Z_S, R_DY_U, R_DY_S, R_PINF_LHS, R_SUPP,   // m-side
@@ -149,6 +169,7 @@ struct Dev {
   double *uu2 = nullptr, *ms = nullptr;  // fused PCG: u_k lives in (k&1 ? uu2 : uu); ms (2n) = interleaved pairs {u_k[j], (Minv .* s_k)[j]}
   int fused = 0;                 // 1: two kernels per PCG iteration (vector update k-1 fused into the SpMV-A kernel of iteration k)
   DevF1 f1;                      // one launch per PCG iteration (slot form only; f1.on)
+  DevWb wb;                      // Woodbury-corrected preconditioner for a few dense rows (three-kernel PCG form; wb.on)
   // reductions
   double *part = nullptr;        // [kPartSlots][kGrid] partial results, slots see backend implementation
   double *res = nullptr;         // [R_COUNT]
@@ -252,6 +273,9 @@ int slot_seq(Dev &d);                      // slots executed since slot_begin (c
 //   F1 form          pcg + 3       KB, F_0, F_1 .. F_pcg, KA (run by the launch whose scalar fold detects convergence)
 inline double slot_launches(const Dev &d, double pcg) { return d.f1.on ? pcg + 3.0 : 2.0 * (pcg + 2.0); }
 void f1_refresh(Dev &d);                   // f1.pval <- B.val (no-op without a plan)
+bool wb_supported();                       // Woodbury preconditioner available (false: the host simulator)
+void wb_refresh(Dev &d);                   // wb.AL / ALT / WT values <- A.val (after assembly / equilibration / matrix updates)
+void wb_apply(Dev &d, int parity);         // u = M^-1 r with the partials gamma = <r, u>, ||r||_inf in the slots of `parity` (after kb_rhs: 0, after kv(i): (i + 1) & 1)
 // ---- device-driven chunk boundaries (policy.h; backend_hip.hip "boundary kernels").  The host uploads the state block once per solve,
 // then only feeds launches: strings of slot launches and, after each chunk's worth, one boundary group -- conditional residual
 // kernels, k_decide (the rules of policy.h on the device: termination, rho, tolerance, budget, next chunk), conditional rho update.

@@ -23,6 +23,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <vector>
+#include <cmath>
 
 #include "../../include/osqp_hip.h"
 #include "backend.h"
@@ -1744,6 +1746,76 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, int stage) {
   for (int i = threadIdx.x; i < W; i += 64) go[i] = ci[i];
 }
 
+// ---------------------------------------------------------------------------------------------- Woodbury preconditioner (backend.h DevWb)
+__global__ __launch_bounds__(kBlock) void k_wb_gather(Dev d) {
+  const DevWb &w = d.wb;
+  const int stride = gridDim.x * kBlock;
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < w.AL.nnz; k += stride) w.AL.val[k] = d.A.val[w.al_src[k]];
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < w.ALT.nnz; k += stride) w.ALT.val[k] = d.A.val[w.alt_src[k]];
+  for (int a = 0; a < w.r; a++)                                            // dense transpose (pattern fixed: the other entries stay zero)
+    for (int k = w.AL.rowptr[a] + blockIdx.x * kBlock + threadIdx.x; k < w.AL.rowptr[a + 1]; k += stride) w.WT[(size_t)w.AL.col[k] * w.r + a] = d.A.val[w.al_src[k]];
+}
+// D0 = B_jj + sum over the SHORT rows of rho_i A_ij^2
+struct GPrecShort { const double *rho; const unsigned char *islong; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = (c >= n && !islong[c - n]) ? rho[c - n] * a * a : 0.0; } };
+__global__ __launch_bounds__(kBlock) void k_wb_diag(Dev d) {
+  __shared__ StreamLds<1> lds;
+  GPrecShort g{d.rho, d.wb.islong, d.n};
+  EPrec e{{}, d.B.val, d.Bdiag, d.wb.Dinv0};
+  process_rows<1>(d.B, g, e, lds);
+}
+// S_ab = sum_j A_L[a,j] A_L[b,j] / D0_j + (a == b) / rho_a : workgroup a, thread b; column j of A_L is contiguous in WT
+__global__ __launch_bounds__(kWbMaxRows) void k_wb_S(Dev d) {
+  const DevWb &w = d.wb;
+  const int a = blockIdx.x, b = threadIdx.x, r = w.r;
+  if (b >= r) return;
+  double acc = 0.0;
+  for (int j = 0; j < d.n; j++) {
+    const double wa = w.WT[(size_t)j * r + a];
+    if (wa != 0.0) acc += wa * w.Dinv0[j] * w.WT[(size_t)j * r + b];        // (wa is workgroup-uniform: no divergence)
+  }
+  if (a == b) acc += d.rho_inv[w.rows[a]];
+  w.S[(size_t)a * r + b] = acc;
+}
+struct GDr { const double *Dinv0, *r; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * Dinv0[c] * r[c]; } };
+__global__ __launch_bounds__(kBlock) void k_wb_p1(Dev d) {                 // g = A_L (D0^-1 r)
+  __shared__ StreamLds<1> lds;
+  if (d.flags[F_DONE]) return;
+  GDr g{d.wb.Dinv0, d.r};
+  EStore e{{}, d.wb.g};
+  process_rows<1>(d.wb.AL, g, e, lds);
+}
+__global__ __launch_bounds__(kWbMaxRows) void k_wb_p2(Dev d) {             // h = S^-1 g
+  const DevWb &w = d.wb;
+  if (d.flags[F_DONE]) return;
+  __shared__ double sg[kWbMaxRows];
+  const int a = threadIdx.x, r = w.r;
+  if (a < r) sg[a] = w.g[a];
+  __syncthreads();
+  if (a >= r) return;
+  double acc = 0.0;
+  for (int b = 0; b < r; b++) acc += w.Sinv[(size_t)a * r + b] * sg[b];
+  w.h[a] = acc;
+}
+struct EWb3 {
+  const double *Dinv0, *r; double *uu; double g = 0, rn = 0, pr = 0, pd = 0;
+  __device__ __forceinline__ void prefetch(int j) { pr = r[j]; pd = Dinv0[j]; }
+  __device__ __forceinline__ void operator()(int j, const double (&s)[1]) {
+    const double u = pd * (pr - s[0]);
+    uu[j] = u; g += pr * u; rn = nanmax(rn, fabs(pr));
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_wb_p3(Dev d, int parity) {     // u = D0^-1 (r - A_L' h); partials gamma = <r, u>, ||r||_inf
+  __shared__ StreamLds<1> lds;
+  if (d.flags[F_DONE]) return;
+  GVec g{d.wb.h};
+  EWb3 e{d.wb.Dinv0, d.r, d.uu};
+  process_rows<1>(d.wb.ALT, g, e, lds);
+  __syncthreads();
+  double G = e.g, RN = e.rn;
+  block_sum_max(G, RN, lds.red);
+  put_partial(d.part, SL_GAMMA0 + parity, G); put_partial(d.part, SL_RN0 + parity, RN);
+}
+
 #define LAUNCH(kernel, d, ...) hipLaunchKernelGGL(kernel, dim3(kGrid), dim3(kBlock), 0, st(d), __VA_ARGS__)
 
 }  // namespace
@@ -1941,10 +2013,56 @@ void fetch_res_flags(Dev &d, double *hr, int *hf) {
 }
 
 void set_rho(Dev &d, double rho_bar) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_set_rho, d, d, rho_bar, 0); LAUNCH(k_init_guess, d, d, 0); }
+bool wb_supported() { return true; }
+void wb_refresh(Dev &d) { if (d.wb.on) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_wb_gather, d, d); } }
+void wb_apply(Dev &d, int parity) {
+  LAUNCH(k_wb_p1, d, d);
+  hipLaunchKernelGGL(k_wb_p2, dim3(1), dim3(kWbMaxRows), 0, st(d), d);
+  LAUNCH(k_wb_p3, d, d, parity);
+}
+// D0, S on the device; S^-1 on the host (r <= kWbMaxRows: a Cholesky factorisation of a few thousand entries, once per rho update)
+static void wb_factor(Dev &d) {
+  DevWb &w = d.wb;
+  const int r = w.r;
+  LAUNCH(k_wb_diag, d, d);
+  hipLaunchKernelGGL(k_wb_S, dim3(r), dim3(kWbMaxRows), 0, st(d), d);
+  std::vector<double> S((size_t)r * r), L((size_t)r * r, 0.0), Li((size_t)r * r, 0.0), Si((size_t)r * r, 0.0);
+  HIP_CHECK(hipMemcpyAsync(S.data(), w.S, sizeof(double) * S.size(), hipMemcpyDeviceToHost, st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  for (int j = 0; j < r; j++) {                               // S = L L'
+    double dj = S[(size_t)j * r + j];
+    for (int k = 0; k < j; k++) dj -= L[(size_t)j * r + k] * L[(size_t)j * r + k];
+    if (!(dj > 0.0)) throw DeviceError("osqp_hip: the Woodbury system of the preconditioner is not positive definite");
+    const double ljj = std::sqrt(dj);
+    L[(size_t)j * r + j] = ljj;
+    for (int i = j + 1; i < r; i++) {
+      double v = S[(size_t)i * r + j];
+      for (int k = 0; k < j; k++) v -= L[(size_t)i * r + k] * L[(size_t)j * r + k];
+      L[(size_t)i * r + j] = v / ljj;
+    }
+  }
+  for (int c = 0; c < r; c++) {                               // Li = L^-1 (lower triangular), column by column
+    Li[(size_t)c * r + c] = 1.0 / L[(size_t)c * r + c];
+    for (int i = c + 1; i < r; i++) {
+      double v = 0.0;
+      for (int k = c; k < i; k++) v -= L[(size_t)i * r + k] * Li[(size_t)k * r + c];
+      Li[(size_t)i * r + c] = v / L[(size_t)i * r + i];
+    }
+  }
+  for (int a = 0; a < r; a++)                                 // S^-1 = Li' Li
+    for (int b = 0; b <= a; b++) {
+      double v = 0.0;
+      for (int k = a; k < r; k++) v += Li[(size_t)k * r + a] * Li[(size_t)k * r + b];
+      Si[(size_t)a * r + b] = Si[(size_t)b * r + a] = v;
+    }
+  HIP_CHECK(hipMemcpyAsync(w.Sinv, Si.data(), sizeof(double) * Si.size(), hipMemcpyHostToDevice, st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+}
 void precond(Dev &d, int diagonal) {
   HIP_CHECK(hipSetDevice(d.device));
   if (diagonal) LAUNCH(k_precond, d, d, 0);
   else LAUNCH(k_fill, d, d.Minv, d.n, 1.0);
+  if (d.wb.on) wb_factor(d);
 }
 void set_pcg_tol(Dev &d, double rel, double ab) {
   HIP_CHECK(hipSetDevice(d.device));

@@ -62,6 +62,27 @@ std::vector<int> build_row_blocks(const std::vector<int> &rowptr, int nrows) {
     if (k > 1024) return build_row_blocks_target(rowptr, nrows, kChunk);   // pathological (e.g. all rows long): accept
   }
 }
+// block descriptors {first row, end row, first nnz, end nnz}; long rows also get their run table (see DevCsr::runinfo).  Slices are the
+// fixed kChunk steps the kernels take from the row's first entry
+std::vector<int> block_descs(const std::vector<int> &rb, const std::vector<int> &rp, const std::vector<int> &cj, std::vector<int> &runs) {
+  std::vector<int> d; d.reserve(4 * rb.size());
+  runs.clear();
+  for (size_t b = 0; b + 1 < rb.size(); b++) {
+    const int r0 = rb[b], r1 = rb[b + 1], k0 = rp[r0], k1 = rp[r1];
+    int end_row = r1;
+    if (r1 - r0 == 1 && k1 - k0 > kLongRow) {
+      end_row = -(1 + (int)runs.size());
+      for (int base = k0; base < k1; base += kChunk) {
+        const int end = std::min(k1, base + kChunk);
+        bool run = true;
+        for (int k = base + 1; k < end && run; k++) run = cj[k] == cj[k - 1] + 1;
+        runs.push_back(run ? cj[base] : -1);
+      }
+    }
+    d.push_back(r0); d.push_back(end_row); d.push_back(k0); d.push_back(k1);
+  }
+  return d;
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ policy
@@ -94,6 +115,7 @@ void policy_from_env(OSQPHipPolicy &p, bool runtime_only) {
     for (int k = 1; k <= 5; k++) if (!std::strcmp(e, names[k])) p.batch_variant = k;
   }
   if (runtime_only) return;
+  on("OSQP_HIP_WOODBURY", p.woodbury);
   on("OSQP_HIP_GRAPH", p.graph); on("OSQP_HIP_SLOTS", p.slots); on("OSQP_HIP_PCG_FUSED", p.pcg_fused); on("OSQP_HIP_F1", p.f1); on("OSQP_HIP_WINDOW", p.window);
   real("OSQP_HIP_EXTRAP", p.extrap);
   if (const char *e = std::getenv("OSQP_HIP_RHO_EQ_FACTOR")) { const double v = std::atof(e); if (v >= 1.0) p.rho_eq_factor = v; }
@@ -108,7 +130,7 @@ void Engine::default_policy(OSQPHipPolicy *p) {
   p->extrap = 0.9; p->rho_eq_factor = 0.0;
   p->rho_window = 10; p->rho_window_tol = 0.1; p->rho_persist = 1; p->rho_tol_exp = 0.5;
   p->budget_tolerate = 0.0; p->budget_sigma = 3.0; p->budget_slack = 0; p->budget_full = 0; p->cg_escalate = 1; p->stall = 1;
-  p->polish_delta_floor = 1e-3; p->polish_pcg_tol = 1e-15;
+  p->polish_delta_floor = 1e-3; p->polish_pcg_tol = 1e-15; p->woodbury = 1;
   p->slot_poll = 1; p->poll_low = 6; p->poll_first = 0.8; p->poll_frac = 0.75; p->poll_wait = 0.7;
   p->finish_pairs = 12; p->poll_sleep_us = 30;
 }
@@ -126,7 +148,7 @@ int Engine::set_policy(const OSQPHipPolicy *p) {
   const OSQPHipPolicy old = pol_;
   pol_ = *p; pol_explicit_ = true;
   // [setup] fields keep the value the handle was built with
-  pol_.slots = old.slots; pol_.pcg_fused = old.pcg_fused; pol_.f1 = old.f1; pol_.window = old.window;
+  pol_.slots = old.slots; pol_.pcg_fused = old.pcg_fused; pol_.f1 = old.f1; pol_.window = old.window; pol_.woodbury = old.woodbury;
   if (pol_.graph != old.graph) { use_graph_ = pol_.graph != 0; if (dev_ready_) { be::activate(d_); be::sync(d_); drop_graphs(); } }
   if (dev_ready_) d_.theta = pol_.extrap;
   if (dev_ready_ && pol_.rho_eq_factor >= 1.0 && pol_.rho_eq_factor != old.rho_eq_factor) return set_rho_eq_factor(pol_.rho_eq_factor);
@@ -163,6 +185,8 @@ void Engine::free_all() {
                   d_.q, d_.l, d_.u, d_.D, d_.Dinv, d_.E, d_.Einv, d_.rho, d_.rho_inv, d_.ctype, d_.x, d_.z, d_.y, d_.dx,
                   d_.dy, d_.xs, d_.xg, d_.xsp, d_.ztg, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.uu2, d_.ms, d_.part, d_.res,
                   d_.scal, d_.flags, d_.slot, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB,
+                  d_.wb.AL.rowptr, d_.wb.AL.col, d_.wb.AL.blkdesc, d_.wb.AL.runinfo, d_.wb.AL.val, d_.wb.ALT.rowptr, d_.wb.ALT.col, d_.wb.ALT.blkdesc, d_.wb.ALT.runinfo, d_.wb.ALT.val,
+                  d_.wb.al_src, d_.wb.alt_src, d_.wb.islong, d_.wb.rows, d_.wb.WT, d_.wb.S, d_.wb.Sinv, d_.wb.g, d_.wb.h, d_.wb.Dinv0,
                   d_.ctl, d_.f1.blk, d_.f1.ent, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.va};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   be::destroy(d_);
@@ -438,6 +462,48 @@ void Engine::prepare_f1(const std::vector<int> &rb, const std::vector<int> &Arp,
   f.on = 1;
 }
 
+// ------------------------------------------------------------------------------------------------ Woodbury plan
+// backend.h DevWb: the rows of A with more than kLongRow entries, when there are between 1 and kWbMaxRows of them, are treated exactly
+// in the preconditioner.  Symbolic data: the long rows as their own CSR (r x n), its transpose (n x r), where each entry sits in A.val.
+void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj) {
+  d_.wb = DevWb();
+  if (!pol_.woodbury || !be::wb_supported() || settings.cg_precond != OSQP_DIAGONAL_PRECONDITIONER || m == 0) return;
+  std::vector<int> rows;
+  for (int i = 0; i < m; i++) if (Arp[i + 1] - Arp[i] > kLongRow) rows.push_back(i);
+  const int r = (int)rows.size();
+  if (r < 1 || r > kWbMaxRows) return;
+  std::vector<unsigned char> islong(m, 0);
+  std::vector<int> lrp(r + 1, 0), lcol, lsrc;
+  for (int a = 0; a < r; a++) {
+    const int i = rows[a]; islong[i] = 1;
+    for (int k = Arp[i]; k < Arp[i + 1]; k++) { lcol.push_back(Arj[k]); lsrc.push_back(k); }
+    lrp[a + 1] = (int)lcol.size();
+  }
+  std::vector<int> trp(n + 1, 0), tcol(lcol.size()), tsrc(lcol.size());
+  for (int c : lcol) trp[c + 1]++;
+  for (int j = 0; j < n; j++) trp[j + 1] += trp[j];
+  { std::vector<int> cur(trp.begin(), trp.end() - 1);
+    for (int a = 0; a < r; a++) for (int k = lrp[a]; k < lrp[a + 1]; k++) { const int pos = cur[lcol[k]]++; tcol[pos] = a; tsrc[pos] = lsrc[k]; } }
+  auto up_i = [&](const std::vector<int> &h) { int *p = dev_vec<int>(d_, h.size()); if (!h.empty()) be::h2d(d_, p, h.data(), sizeof(int) * h.size()); return p; };
+  auto up_csr = [&](DevCsr &M, int nr, int nc, const std::vector<int> &rp, const std::vector<int> &cj) {
+    std::vector<int> rb;
+    if (&M == &d_.wb.AL) { for (int a = 0; a <= nr; a++) rb.push_back(a); }      // every long row is a block of its own
+    else rb = build_row_blocks(rp, nr);
+    std::vector<int> runs;
+    M.nrows = nr; M.ncols = nc; M.nnz = (int)cj.size(); M.nblk = (int)rb.size() - 1; M.split = nc; M.single = 0; M.nwin = 0;
+    M.rowptr = up_i(rp); M.col = up_i(cj); M.blkdesc = up_i(block_descs(rb, rp, cj, runs)); M.runinfo = up_i(runs);
+    M.val = dev_vec<double>(d_, cj.size());
+  };
+  DevWb &w = d_.wb;
+  w.r = r;
+  up_csr(w.AL, r, n, lrp, lcol); up_csr(w.ALT, n, r, trp, tcol);
+  w.al_src = up_i(lsrc); w.alt_src = up_i(tsrc); w.rows = up_i(rows);
+  w.islong = dev_vec<unsigned char>(d_, m); be::h2d(d_, w.islong, islong.data(), m);
+  w.WT = dev_vec<double>(d_, (size_t)n * r); w.S = dev_vec<double>(d_, (size_t)r * r); w.Sinv = dev_vec<double>(d_, (size_t)r * r);
+  w.g = dev_vec<double>(d_, r); w.h = dev_vec<double>(d_, r); w.Dinv0 = dev_vec<double>(d_, n);
+  w.on = 1;
+}
+
 // ------------------------------------------------------------------------------------------------ setup
 int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *A, const double *l, const double *u,
                   int m_, int n_, const OSQPSettings *s) {
@@ -608,8 +674,10 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   up_win(d_.A, rbA, Arp, Arj, n); up_win(d_.B, rbB, Brp, Bj, n);
   lap("upload structure");
   d_.fused = pol_.pcg_fused ? 1 : 0;                 // 0 selects the 3-kernel sequence
+  prepare_wb(Arp, Arj);
+  if (d_.wb.on) d_.fused = 0;                        // (the Woodbury-corrected preconditioner lives in the three-kernel PCG form)
   if (d_.fused && use_slots_ && d_.A.nwin == d_.A.nblk) prepare_f1(rbA, Arp, Arj, Brp, Bj);
-  lap("F1 plan");
+  lap("F1 / Woodbury plans");
   auto dv = [&](size_t cnt) { return dev_vec<double>(d_, cnt); };
   d_.q = dv(n); d_.l = dv(m); d_.u = dv(m); d_.D = dv(n); d_.Dinv = dv(n); d_.E = dv(m); d_.Einv = dv(m);
   d_.rho = dv(m); d_.rho_inv = dv(m); d_.ctype = dev_vec<int>(d_, m);
@@ -634,7 +702,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
     be::assemble(d_, 0, 1.0, 0);                                     // unscaled, sigma added after the equilibration
     c_ = be::ruiz(d_, settings.scaling);                             // _osqp.py:389-497
     cinv_ = 1.0 / c_;
-    be::f1_refresh(d_);
+    be::f1_refresh(d_); be::wb_refresh(d_);
     D_.resize(n); E_.resize(m); Dinv_.resize(n); Einv_.resize(m);
     be::d2h(d_, D_.data(), d_.D, sizeof(double) * n); be::d2h(d_, Dinv_.data(), d_.Dinv, sizeof(double) * n);
     if (m > 0) { be::d2h(d_, E_.data(), d_.E, sizeof(double) * m); be::d2h(d_, Einv_.data(), d_.Einv, sizeof(double) * m); }
@@ -704,20 +772,21 @@ void Engine::set_status(int st) {
 // One chunk = `niter` ADMM iterations, each  KB, budget x (K1,K2,Kv), KA  -- enqueued eagerly or replayed from a
 // hipGraph captured once per (niter, budget).
 void Engine::run_chunk(int niter, int budget) {
-  const bool fused = be::pcg_fused(d_);
+  const bool fused = be::pcg_fused(d_), wb = d_.wb.on != 0;
   auto enqueue = [&](int count) {
     for (int it = 0; it < count; it++) {
       be::kb_rhs(d_);
-      for (int i = 0; i < budget; i++) { be::k1(d_, i); be::k2(d_, i); if (!fused || i == budget - 1) be::kv(d_, i); }
+      if (wb) be::wb_apply(d_, 0);
+      for (int i = 0; i < budget; i++) { be::k1(d_, i); be::k2(d_, i); if (!fused || i == budget - 1) { be::kv(d_, i); if (wb) be::wb_apply(d_, (i + 1) & 1); } }
       be::ka(d_, budget);
     }
   };
-  stats_.kernel_launches += (double)niter * (fused ? 3 + 2 * budget : 2 + 3 * budget);
+  stats_.kernel_launches += (double)niter * (fused ? 3 + 2 * budget : 2 + 3 * budget + (wb ? 3 * (budget + 1) : 0));
   if (!(use_graph_ && be::graphs_supported())) { enqueue(niter); return; }
   // one executable graph per (ADMM iterations, PCG budget); graphs are kept below kMaxGraphNodes kernel nodes (a
   // check_termination = 0 solve would otherwise capture max_iter * (2 + 3*budget) nodes in one graph)
   constexpr int kMaxGraphNodes = 8192;
-  const int per = std::max(1, kMaxGraphNodes / (2 + 3 * budget));
+  const int per = std::max(1, kMaxGraphNodes / (2 + 3 * budget + (wb ? 3 * (budget + 1) : 0)));
   for (int left = niter; left > 0;) {
     const int cnt = std::min(left, per);
     auto key = std::make_pair(cnt, budget);
@@ -1419,7 +1488,7 @@ int Engine::update_data_mat(const double *Px, const int *Px_idx, int P_n, const 
     if (Px) be::h2d(d_, d_.Praw, P_.x.data(), sizeof(double) * nzP);
     if (Ax) be::h2d(d_, d_.Araw, A_.x.data(), sizeof(double) * nzA);
     be::assemble(d_, 1, c_, 1);
-    be::f1_refresh(d_);
+    be::f1_refresh(d_); be::wb_refresh(d_);
   } else {
     std::vector<double> Pxs, Axs;
     scale_matrix_values(Pxs, Axs);
@@ -1484,7 +1553,7 @@ int Engine::ls_setup(const OSQPCscMatrix *P, const OSQPCscMatrix *A, const doubl
   std::vector<double> q(nn, 0.0), l(mm, -OSQP_INFTY), u(mm, OSQP_INFTY);
   int err = setup(P, q.data(), A, l.data(), u.data(), mm, nn, &st);
   if (err) return err;
-  d_.fused = 0; d_.f1.on = 0;
+  d_.fused = 0; d_.f1.on = 0; d_.wb.on = 0;
   return ls_set_rho_vec(rho_vec);
 }
 

@@ -105,6 +105,7 @@ class Engine {
     double *kp_val = nullptr;
   } bd_;
   void prepare_batch_direct();
+  void prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj);
   void prepare_f1(const std::vector<int> &rb, const std::vector<int> &Arp, const std::vector<int> &Arj, const std::vector<int> &Brp, const std::vector<int> &Bj);
   bool small_direct_applicable();
   int solve_small_direct(double t0);

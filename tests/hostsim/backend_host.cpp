@@ -47,6 +47,9 @@ int slot_done(Dev &) { return 0; }
 int slot_seq(Dev &) { return 0; }
 void slot_poll(Dev &, int *seq, int *done) { *seq = 0; *done = 0; }
 void f1_refresh(Dev &) {}
+bool wb_supported() { return false; }
+void wb_refresh(Dev &) {}
+void wb_apply(Dev &, int) {}
 bool ctl_supported(const Dev &) { return false; }
 void ctl_upload(Dev &, const Ctl &) {}
 void ctl_begin(Dev &) {}
