@@ -955,7 +955,7 @@ void Engine::ctl_setup() {
   c.cg_tol_fraction = settings.cg_tol_fraction; c.cg_tol_reduction = settings.cg_tol_reduction; c.rho_tolerance = settings.adaptive_rho_tolerance;
   c.eps_abs = settings.eps_abs; c.eps_rel = settings.eps_rel; c.eps_pinf = settings.eps_prim_inf; c.eps_dinf = settings.eps_dual_inf;
   c.c = c_; c.cinv = cinv_;
-  c.budget_tolerate = pol_.budget_tolerate; c.budget_sigma = pol_.budget_sigma; c.budget_slack = pol_.budget_slack;
+  c.budget_tolerate = pol_.budget_tolerate; c.budget_sigma = pol_.budget_sigma; c.budget_slack = pol_.budget_slack; c.budget_min = d_.wb.on ? 1 : 2;
   c.iter = 0; c.cap = std::min(settings.cg_max_iter, kMaxCg);
   // start with the full budget: a starved PCG in the first chunks costs far more ADMM iterations than the launches it saves
   c.budget[0] = c.budget[1] = c.cap;

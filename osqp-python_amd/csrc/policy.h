@@ -38,7 +38,7 @@ struct Ctl {
   // ---- settings snapshot (constant during a solve)
   int ct, ari, max_iter, tightW, m, scaling, scaled_termination, check_dualgap, has_quad, persist, esc_on, stall_on, full_budget, cap_max;
   double tightF, tol_exp, cg_tol_fraction, cg_tol_reduction, rho_tolerance, eps_abs, eps_rel, eps_pinf, eps_dinf, c, cinv;
-  double budget_tolerate, budget_sigma; int budget_slack;
+  double budget_tolerate, budget_sigma; int budget_slack, budget_min;      // budget_min: smallest PCG limit per solve (2; 1 with the Woodbury preconditioner, whose solves take one iteration)
   // ---- state
   int iter, cap, budget[2], tight_seen, last_side, stalled_checks, rho_updates, status, need, osqp_status;
   double tol_rel, tol_abs, eps_cg_prev, stall, best_dua, prev_aobj, rho_bar;
@@ -117,7 +117,7 @@ OSQP_HD inline int ctl_next_budget(const Ctl &c, int cur, const int *flags) {
   const double cnt = pol_imax(1, flags[F_STAT_N]), mean = flags[F_STAT_SUM] / cnt;
   const double var = fmax(0.0, flags[F_STAT_SUMSQ] / cnt - mean * mean);
   const int q3 = (int)ceil(mean + c.budget_sigma * sqrt(var));
-  return pol_imin(c.cap, pol_imax(2, pol_imin(flags[F_STAT_MAX], q3)) + c.budget_slack);
+  return pol_imin(c.cap, pol_imax(c.budget_min, pol_imin(flags[F_STAT_MAX], q3)) + c.budget_slack);
 }
 OSQP_HD inline void ctl_budget_rule(Ctl &c, const int *flags) {
   ctl_escalate(c, flags);
