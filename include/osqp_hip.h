@@ -284,6 +284,7 @@ typedef struct {
   OSQPInt f1;                 /* one launch per PCG iteration where the matrices allow it (banded A)                            [setup] */
   OSQPInt window;             /* windowed row blocks (16-bit local column indices, input window in LDS)                         [setup] */
   OSQPInt woodbury;           /* a few dense rows of A (1..128 rows with > 128 entries) are treated exactly in the preconditioner   [setup] */
+  OSQPInt woodbury_direct;    /* ... and when the rest of K is diagonal, that preconditioner IS K^-1: the linear solve without PCG iterations [setup] */
   OSQPInt device_driven;      /* chunk boundaries (termination test, adaptive rho, PCG tolerance / budget) decided on the device */
   OSQPInt small_direct;       /* small QPs: the whole solve as ONE launch of the batch kernel's direct (banded LDL') variant */
   OSQPInt batch_reorder;      /* batch solves: launch the problems in the order of the previous call's iteration counts */

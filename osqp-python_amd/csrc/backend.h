@@ -105,6 +105,8 @@ struct DevF1 {
 constexpr int kWbMaxRows = 128;
 struct DevWb {
   int on = 0, r = 0;
+  int exact = 0;                 // K0 is diagonal (P diagonal, every short row of A has one entry): M = K, and M^-1 r_0 IS the solve -- no PCG iteration
+                                 // (Engine::run_chunk: KB, the three kernels of M^-1, k_wb_direct, KA); cleared when S^-1 fails its accuracy check
   DevCsr AL, ALT;                // the long rows (r x n) and their transpose (n x r); values gathered from A.val through al_src / alt_src
   int *al_src = nullptr, *alt_src = nullptr;
   unsigned char *islong = nullptr;   // [m]
@@ -275,6 +277,7 @@ inline double slot_launches(const Dev &d, double pcg) { return d.f1.on ? pcg + 3
 void f1_refresh(Dev &d);                   // f1.pval <- B.val (no-op without a plan)
 bool wb_supported();                       // Woodbury preconditioner available (false: the host simulator)
 void wb_refresh(Dev &d);                   // wb.AL / ALT / WT values <- A.val (after assembly / equilibration / matrix updates)
+void wb_direct(Dev &d);                    // exact mode: x~ = x_g + M^-1 r_0 (after kb_rhs + wb_apply(0)); marks the solve as converged after one step
 void wb_apply(Dev &d, int parity);         // u = M^-1 r with the partials gamma = <r, u>, ||r||_inf in the slots of `parity` (after kb_rhs: 0, after kv(i): (i + 1) & 1)
 // ---- device-driven chunk boundaries (policy.h; backend_hip.hip "boundary kernels").  The host uploads the state block once per solve,
 // then only feeds launches: strings of slot launches and, after each chunk's worth, one boundary group -- conditional residual

@@ -115,7 +115,7 @@ void policy_from_env(OSQPHipPolicy &p, bool runtime_only) {
     for (int k = 1; k <= 5; k++) if (!std::strcmp(e, names[k])) p.batch_variant = k;
   }
   if (runtime_only) return;
-  on("OSQP_HIP_WOODBURY", p.woodbury);
+  on("OSQP_HIP_WOODBURY", p.woodbury); on("OSQP_HIP_WOODBURY_DIRECT", p.woodbury_direct);
   on("OSQP_HIP_GRAPH", p.graph); on("OSQP_HIP_SLOTS", p.slots); on("OSQP_HIP_PCG_FUSED", p.pcg_fused); on("OSQP_HIP_F1", p.f1); on("OSQP_HIP_WINDOW", p.window);
   real("OSQP_HIP_EXTRAP", p.extrap);
   if (const char *e = std::getenv("OSQP_HIP_RHO_EQ_FACTOR")) { const double v = std::atof(e); if (v >= 1.0) p.rho_eq_factor = v; }
@@ -130,7 +130,7 @@ void Engine::default_policy(OSQPHipPolicy *p) {
   p->extrap = 0.9; p->rho_eq_factor = 0.0;
   p->rho_window = 10; p->rho_window_tol = 0.1; p->rho_persist = 1; p->rho_tol_exp = 0.5;
   p->budget_tolerate = 0.0; p->budget_sigma = 3.0; p->budget_slack = 0; p->budget_full = 0; p->cg_escalate = 1; p->stall = 1;
-  p->polish_delta_floor = 1e-3; p->polish_pcg_tol = 1e-15; p->woodbury = 1;
+  p->polish_delta_floor = 1e-3; p->polish_pcg_tol = 1e-15; p->woodbury = 1; p->woodbury_direct = 1;
   p->slot_poll = 1; p->poll_low = 6; p->poll_first = 0.8; p->poll_frac = 0.75; p->poll_wait = 0.7;
   p->finish_pairs = 12; p->poll_sleep_us = 30;
 }
@@ -148,7 +148,7 @@ int Engine::set_policy(const OSQPHipPolicy *p) {
   const OSQPHipPolicy old = pol_;
   pol_ = *p; pol_explicit_ = true;
   // [setup] fields keep the value the handle was built with
-  pol_.slots = old.slots; pol_.pcg_fused = old.pcg_fused; pol_.f1 = old.f1; pol_.window = old.window; pol_.woodbury = old.woodbury;
+  pol_.slots = old.slots; pol_.pcg_fused = old.pcg_fused; pol_.f1 = old.f1; pol_.window = old.window; pol_.woodbury = old.woodbury; pol_.woodbury_direct = old.woodbury_direct;
   if (pol_.graph != old.graph) { use_graph_ = pol_.graph != 0; if (dev_ready_) { be::activate(d_); be::sync(d_); drop_graphs(); } }
   if (dev_ready_) d_.theta = pol_.extrap;
   if (dev_ready_ && pol_.rho_eq_factor >= 1.0 && pol_.rho_eq_factor != old.rho_eq_factor) return set_rho_eq_factor(pol_.rho_eq_factor);
@@ -502,6 +502,11 @@ void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj
   w.WT = dev_vec<double>(d_, (size_t)n * r); w.S = dev_vec<double>(d_, (size_t)r * r); w.Sinv = dev_vec<double>(d_, (size_t)r * r);
   w.g = dev_vec<double>(d_, r); w.h = dev_vec<double>(d_, r); w.Dinv0 = dev_vec<double>(d_, n);
   w.on = 1;
+  // K0 diagonal <=> P has diagonal entries only and every short row of A has exactly one entry: then M = K (backend.h DevWb::exact)
+  bool diag = pol_.woodbury_direct != 0;
+  for (int j = 0; j < n && diag; j++) for (int k = P_.p[j]; k < P_.p[j + 1]; k++) if (P_.i[k] != j) { diag = false; break; }
+  for (int i = 0; i < m && diag; i++) if (!islong[i] && Arp[i + 1] - Arp[i] > 1) diag = false;
+  w.exact = diag ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ setup
@@ -777,11 +782,12 @@ void Engine::run_chunk(int niter, int budget) {
     for (int it = 0; it < count; it++) {
       be::kb_rhs(d_);
       if (wb) be::wb_apply(d_, 0);
+      if (wb && d_.wb.exact) { be::wb_direct(d_); be::ka(d_, budget); continue; }      // M^-1 r_0 is the solve
       for (int i = 0; i < budget; i++) { be::k1(d_, i); be::k2(d_, i); if (!fused || i == budget - 1) { be::kv(d_, i); if (wb) be::wb_apply(d_, (i + 1) & 1); } }
       be::ka(d_, budget);
     }
   };
-  stats_.kernel_launches += (double)niter * (fused ? 3 + 2 * budget : 2 + 3 * budget + (wb ? 3 * (budget + 1) : 0));
+  stats_.kernel_launches += (double)niter * ((wb && d_.wb.exact) ? 6 : (fused ? 3 + 2 * budget : 2 + 3 * budget + (wb ? 3 * (budget + 1) : 0)));
   if (!(use_graph_ && be::graphs_supported())) { enqueue(niter); return; }
   // one executable graph per (ADMM iterations, PCG budget); graphs are kept below kMaxGraphNodes kernel nodes (a
   // check_termination = 0 solve would otherwise capture max_iter * (2 + 3*budget) nodes in one graph)
@@ -804,7 +810,7 @@ void Engine::run_chunk(int niter, int budget) {
 
 // Slot form of a chunk (backend_hip.hip "slot kernels"): begin_target > 0 starts a chunk of that many ADMM iterations (eager one-thread
 // launch: target and PCG cap travel in the phase record), then `pairs` (B slot, A slot) launches follow as replays of captured
-// strings of 256 / 128 / ... / 2 / 1 pairs -- the same nine graphs serve every chunk, whatever its length; begin_target == 0 tops up
+// strings of 256 / 192 / 128 / 96 / ... / 3 / 2 / 1 pairs -- the same sixteen graphs serve every chunk, whatever its length; begin_target == 0 tops up
 // a chunk that has not finished.
 void Engine::run_slots(int begin_target, int pairs, int cap) {
   stats_.kernel_launches += 2.0 * pairs + (begin_target > 0 ? 1 : 0);
@@ -812,7 +818,9 @@ void Engine::run_slots(int begin_target, int pairs, int cap) {
   if (!(use_graph_ && be::graphs_supported())) { for (int k = 0; k < pairs; k++) be::slot_pair(d_); return; }
   for (int left = pairs; left > 0;) {
     int unit = 1;
-    for (int u : {256, 128, 64, 32, 16, 8, 4, 2}) if (left >= u) { unit = u; break; }
+    // (captured string lengths: a denser set than powers of two -- every replay boundary is a bubble of a few microseconds, 63 pairs are
+    //  48 + 12 + 3, not 32 + 16 + 8 + 4 + 2 + 1)
+    for (int u : {256, 192, 128, 96, 64, 48, 32, 24, 16, 12, 8, 6, 4, 3, 2}) if (left >= u) { unit = u; break; }
     const std::array<int, 3> key = {unit, 0, 0};
     auto it = sgraphs_.find(key);
     if (it == sgraphs_.end()) {
@@ -1079,8 +1087,18 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
   Ctl snap = c;
   long launched = 0;                                 // slot PAIRS enqueued
   int seq = 0, done = 0;                             // slot launches executed / ADMM iterations completed in the chunk in flight (polled)
-  const int kLow = pol_.poll_low;
+  // The queue is kept deep enough for a SLOW host as well: the low-water mark follows the measured duration of a poll + top-up cycle
+  // (three cycles' worth of slot pairs, never below poll_low) -- under a profiler, or on a loaded host, every runtime call costs a multiple
+  // of its usual time, and a 6-pair queue would run dry between two top-ups.
+  int kLow = pol_.poll_low, kFinish = pol_.finish_pairs;
+  double cycle_s = 0.0, pair_s = 22e-6, t_cycle = now_s(), t_rate = t_cycle; long seq_rate = 0;
   bool timed_out = false;
+  auto cycle_done = [&]() {                          // one poll + top-up cycle of the host has ended
+    const double t_now = now_s(), c = t_now - t_cycle;
+    cycle_s = cycle_s > 0 ? 0.7 * cycle_s + 0.3 * c : c; t_cycle = t_now;
+    kLow = std::min(96, std::max<int>(pol_.poll_low, (int)std::ceil(3.0 * cycle_s / pair_s)));
+    kFinish = std::max<int>(pol_.finish_pairs, 2 * kLow);
+  };
   // chunk in flight as of the last poll, and the progress counters at the first poll that saw it (rate estimate)
   int cur_boundaries = snap.boundaries; long seq0 = 0;
   { const int cnt = snap.ch_next - snap.iter;
@@ -1092,15 +1110,18 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
     if (now_s() - t0 > settings.time_limit) { timed_out = true; break; }
     if (snap.boundaries != cur_boundaries) { cur_boundaries = snap.boundaries; seq0 = seq; }
     const long ahead = launched - seq / 2;           // pairs enqueued and not yet executed
-    if (ahead > kLow) { std::this_thread::sleep_for(std::chrono::microseconds(pol_.poll_sleep_us)); continue; }
+    { const double t_now = now_s();
+      if (seq - seq_rate >= 16) { pair_s = std::max(5e-6, 2.0 * (t_now - t_rate) / (double)(seq - seq_rate)); t_rate = t_now; seq_rate = seq; } }
+    if (ahead > kLow) { std::this_thread::sleep_for(std::chrono::microseconds(pol_.poll_sleep_us)); t_cycle = now_s(); continue; }
     const int cnt = snap.ch_next - snap.iter, rem = std::max(0, cnt - done);
     const double pm = pred_for(snap, snap.ch_kind, snap.ch_tight);
     const double rate = done >= 2 ? std::min<double>(pairs_for(1, snap.budget[snap.ch_tight]), 0.5 * (double)(seq - seq0) / done) : pairs_for(1, pm);   // pairs per ADMM iteration
     const int need = (int)std::ceil(rem * rate) + 1 - (int)ahead;
-    if (need > pol_.finish_pairs) {                  // far from the chunk's end: most of what is missing
+    if (need > kFinish) {                            // far from the chunk's end: most of what is missing
       const int np = std::max(2, (int)std::ceil(pol_.poll_frac * need));
       run_slots(0, np, 0); launched += np;
       stats_.slot_topups += 1;
+      cycle_done();
       continue;
     }
     // the chunk's end is within reach: the rest, the boundary group, and the first part of the next chunk
@@ -1115,6 +1136,7 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
         run_slots(0, nq, 0); launched += nq;
       }
     }
+    cycle_done();
     if (pol_.slot_log) std::fprintf(stderr, "group: device iter %d chunk %d..%d kind %d done %d rem %d rate %.2f ahead %ld pairs %d (launched %ld, seq %d) budget %d/%d tol %.3e rho %.4e\n",
                                     snap.iter, snap.iter, snap.ch_next, snap.ch_kind, done, rem, rate, ahead, np, launched, seq, snap.budget[0], snap.budget[1], snap.tol_abs, snap.rho_bar);
   }
