@@ -1,4 +1,5 @@
 // api.cpp -- extern "C" surface of libosqp_hip.so (include/osqp_hip.h).  Thin: every call forwards to Engine.
+#include <cstdio>
 #include <memory>
 #include <new>
 
@@ -17,7 +18,7 @@ OSQPInt guarded(OSQPSolver *s, F &&f) {
   if (!e) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   try { return f(*e); }
   catch (const std::bad_alloc &) { return OSQP_MEM_ALLOC_ERROR; }
-  catch (const osqp_hip::DeviceError &) { return OSQP_ALGEBRA_LOAD_ERROR; }
+  catch (const osqp_hip::DeviceError &err) { std::fprintf(stderr, "osqp_hip: device error: %s\n", err.what()); return OSQP_ALGEBRA_LOAD_ERROR; }
   catch (...) { return OSQP_LINSYS_SOLVER_INIT_ERROR; }
 }
 }

@@ -1008,19 +1008,23 @@ void Engine::exec_chunk_sync(int cnt, int lim, bool with_res, int kind, double *
   // slot pairs (two launches each) that `its` ADMM iterations with `pcg` PCG iterations each need (backend.h slot_launches)
   auto pairs_for = [&](double its, double pcg) { return 0.5 * its * be::slot_launches(d_, pcg); };
   const double t_chunk = now_s();
+  // every launch of an unfinished chunk advances it, so `cnt` iterations under the cap `lim` never need more than this many pairs:
+  // the bound on what the host enqueues (a record that stops advancing must not make it enqueue for ever), not a count of top-ups
+  // -- one long PCG (the polish: up to kMaxCg iterations at a relative tolerance of 1e-15) legitimately takes many of them
+  const int max_pairs = (int)std::ceil(pairs_for(cnt, lim)) + 8;
   if (pol_.slot_poll) {
     const int kLow = pol_.poll_low; const double kFirst = pol_.poll_first, kFrac = pol_.poll_frac, kWait = pol_.poll_wait;
     const double p0 = std::min<double>(pred[kind], lim);
     { const int np = (int)std::ceil(pairs_for(cnt, 0)) + std::max(2, (int)std::floor(kFirst * (pairs_for(cnt, p0) - pairs_for(cnt, 0)))); run_slots(cnt, np, lim); launched_pairs += np; }
     double pair_s = 9e-6, t_prev = now_s();                        // duration of a slot pair, re-estimated from the progress between two polls
-    int seq_prev = 0, topups = 0;
+    int seq_prev = 0;
     for (int seq = 0, done = 0;;) {
       be::slot_poll(d_, &seq, &done);
       if (done >= cnt) break;
       const double t_now = now_s();
       // (bounded: a record that stops advancing must not make the host enqueue launches for ever -- the synchronising fetch below
       //  then reports what the device did)
-      if (t_now - t_chunk > settings.time_limit || topups > 64 + 4 * cnt) break;
+      if (t_now - t_chunk > settings.time_limit || launched_pairs > max_pairs) break;
       if (seq - seq_prev >= 8) { pair_s = std::max(5e-6, 2.0 * (t_now - t_prev) / (seq - seq_prev)); t_prev = t_now; seq_prev = seq; }
       const int ahead = launched_pairs - seq / 2;                  // pairs enqueued and not yet executed
       if (ahead > kLow) {
@@ -1032,15 +1036,16 @@ void Engine::exec_chunk_sync(int cnt, int lim, bool with_res, int kind, double *
       const int rem = cnt - done;
       const double rate = done > 0 ? std::min<double>(pairs_for(1, lim), (0.5 * seq) / done) : pairs_for(1, p0);      // pairs per ADMM iteration so far
       const int need = (int)std::ceil(rem * rate) + 1 - ahead;
-      const int np = std::max(2, need > 12 ? (int)std::ceil(kFrac * need) : need);
+      // (an iteration that has outrun the prediction by far -- no iteration finished yet, many pairs consumed: grow geometrically)
+      const int np = std::max(std::max(2, need > 12 ? (int)std::ceil(kFrac * need) : need), done == 0 ? launched_pairs / 4 : 0);
       run_slots(0, np, lim); launched_pairs += np;
-      stats_.slot_topups += 1; topups++;
+      stats_.slot_topups += 1;
     }
   } else {
     const double pm = std::min<double>(pred[kind], lim);
     const int np = (int)std::ceil(pairs_for(cnt, 0) + 1.05 * (pairs_for(cnt, pm) - pairs_for(cnt, 0))) + 2; run_slots(cnt, np, lim); launched_pairs += np;
   }
-  for (int round = 0;; round++) {
+  for (;;) {
     if (with_res) { be::residuals(d_); be::fetch_res_flags(d_, res, f); } else be::fetch_flags(d_, f);
     tot[F_STAT_SUM] += f[F_STAT_SUM]; tot[F_STAT_SUMSQ] += f[F_STAT_SUMSQ]; tot[F_STAT_N] += f[F_STAT_N]; tot[F_STAT_UNCONV] += f[F_STAT_UNCONV]; tot[F_STAT_STAG] += f[F_STAT_STAG];
     tot[F_STAT_MAX] = std::max(tot[F_STAT_MAX], f[F_STAT_MAX]);
@@ -1051,11 +1056,12 @@ void Engine::exec_chunk_sync(int cnt, int lim, bool with_res, int kind, double *
       throw DeviceError(msg);
     }
     if (done >= cnt) break;
-    if (round > 64 + cnt) throw DeviceError("osqp_hip: a chunk of ADMM iterations does not finish");
+    if (launched_pairs > max_pairs) throw DeviceError("osqp_hip: a chunk of ADMM iterations does not finish");
     const int rem = cnt - done;
     const double seen = tot[F_STAT_N] > 0 ? (double)tot[F_STAT_SUM] / tot[F_STAT_N] : pred[kind];
     const double pm = std::min<double>(std::max(seen, pred[kind]), lim);
-    const int np = (int)std::ceil(pairs_for(rem, 0) + 1.25 * (pairs_for(rem, pm) - pairs_for(rem, 0))) + 8; run_slots(0, np, lim); launched_pairs += np;
+    const int np = std::max((int)std::ceil(pairs_for(rem, 0) + 1.25 * (pairs_for(rem, pm) - pairs_for(rem, 0))) + 8, launched_pairs / 2);
+    run_slots(0, np, lim); launched_pairs += np;
     stats_.slot_topups += 1;
   }
   for (int k = 0; k < F_COUNT; k++) flags[k] = tot[k];

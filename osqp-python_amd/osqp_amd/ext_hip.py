@@ -177,7 +177,10 @@ class OSQPSolver:
         return s
 
     def solve(self):                                     # ctypes drops the GIL for the call (cf. bindings.cpp.in:196-201)
-        return self._lib.osqp_solve(self._p)
+        status = self._lib.osqp_solve(self._p)
+        if status:                                       # a device / allocation failure inside the solve: never a silent stale result
+            raise RuntimeError('osqp_solve failed with osqp_error_type %d' % status)
+        return status
 
     def warm_start(self, x=None, y=None):
         x, y = _vec(x), _vec(y)

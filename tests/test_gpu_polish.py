@@ -170,3 +170,26 @@ def test_polish_on_the_pcg_path_matches_the_oracle(n, window, eps):
         m2 = osqp_amd.OSQP(); m2.setup(P, q, A, l, u, verbose=False, polishing=True, delta=1e-2, polish_refine_iter=8, **st)
         r2 = m2.solve()
         assert r2.info.status_polish == 1 and _rel(r2.x, r.x) < 1e-7 and _rel(r2.y, r.y) < 1e-7
+
+
+def test_polish_after_short_pcg_history_runs_to_the_end():
+    """The polish's inner systems (relative tolerance 1e-15) take hundreds of PCG iterations where the ADMM chunks before them took two
+    or three: the host must keep feeding the one long iteration (it used to give up after a number of top-ups sized by the prediction,
+    the solve came back with a device error and the handle kept the PREVIOUS solve's solution; tools/mt_debug3.py)."""
+    seed = 72
+    rng = np.random.default_rng(seed)
+    P, q, A, l, u = problems.banded_qp(3000, window=60, seed=seed)
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, eps_abs=1e-6, eps_rel=1e-6, verbose=False, max_iter=20000)
+    r = m.solve()
+    m.update(q=q * (1 + 0.01 * rng.standard_normal(len(q)))); r = m.solve()
+    m.update(l=l - 0.05, u=u + 0.05); r = m.solve()
+    m.warm_start(x=r.x * 0.9, y=r.y * 0.9); r = m.solve()
+    Pt = sp.triu(P, format='csc')
+    Px, Ax = Pt.data * (1 + 0.02 * rng.random(Pt.nnz)), A.data * (1 + 0.02 * rng.standard_normal(A.nnz))
+    m.update(Px=Px, Ax=Ax)
+    m.update_settings(polishing=True)
+    r = m.solve(raise_error=True)
+    assert r.info.status_polish == 1
+    A2 = sp.csc_matrix((Ax, A.indices, A.indptr), shape=A.shape)
+    z = A2 @ r.x
+    assert max(np.maximum(z - (u + 0.05), 0).max(), np.maximum((l - 0.05) - z, 0).max()) < 1e-9
