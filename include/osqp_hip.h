@@ -188,6 +188,8 @@ typedef struct {
   double row_blocks;          /* row blocks of A and B in total */
   double slot_topups;         /* last solve: chunks whose string of slot launches ended before the chunk did (more launches followed) */
   double f1_replicas;         /* F1 form: replica vectors of the partial A' t (0: the form does not apply to this problem) */
+  double woodbury_rows;       /* dense rows of A treated exactly in the preconditioner (0: plain Jacobi) */
+  double woodbury_direct;     /* 1: that preconditioner is K^-1 for the current rho (the linear solves run without PCG iterations) */
 } OSQPHipStats;
 OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
 
@@ -285,6 +287,8 @@ typedef struct {
   OSQPInt window;             /* windowed row blocks (16-bit local column indices, input window in LDS)                         [setup] */
   OSQPInt woodbury;           /* a few dense rows of A (1..128 rows with > 128 entries) are treated exactly in the preconditioner   [setup] */
   OSQPInt woodbury_direct;    /* ... and when the rest of K is diagonal, that preconditioner IS K^-1: the linear solve without PCG iterations [setup] */
+  OSQPInt woodbury_large;     /* up to 16384 dense rows carrying most of A: the same correction with the r x r system formed, factorised and inverted on
+                                 the device (rocBLAS / rocSOLVER, loaded on demand; off where they are missing)                    [setup] */
   OSQPInt device_driven;      /* chunk boundaries (termination test, adaptive rho, PCG tolerance / budget) decided on the device */
   OSQPInt small_direct;       /* small QPs: the whole solve as ONE launch of the batch kernel's direct (banded LDL') variant */
   OSQPInt batch_reorder;      /* batch solves: launch the problems in the order of the previous call's iteration counts */

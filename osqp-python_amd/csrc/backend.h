@@ -103,8 +103,21 @@ struct DevF1 {
 // iteration); M is exact whenever K0 is diagonal.  Per application: one pass over the long rows (g = A_L y), an r_L x r_L product
 // (h = S^-1 g, S^-1 formed on the host at every rho update: r_L^3 / 3 flops), one pass over their transpose.  Three-kernel PCG form.
 constexpr int kWbMaxRows = 128;
+// MANY dense rows (lasso: 10 000 sample rows of 5 000 entries next to two-entry rows): the same correction with S formed, factorised
+// and inverted on the device -- W = A_L D0^-1/2 as a dense r x ct block (ct = columns the long rows touch), S = W W' + diag(1 / rho_L)
+// by one fp64 GEMM, Cholesky + inverse by the ROCm dense solver library (rocBLAS / rocSOLVER, loaded on demand: without them this
+// mode is simply off), h = S^-1 g by a dense matrix-vector kernel (r^2 x 8 bytes per application).  Whether M = K (the direct mode) is
+// decided NUMERICALLY after every factorisation: M^-1 (K v) must reproduce a probe vector v to 1e-9.
+constexpr int kWbLargeMax = 16384;
 struct DevWb {
   int on = 0, r = 0;
+  int large = 0;                 // r > kWbMaxRows: device-side dense factorisation; WT unused, W / colmap / ct in use
+  int ct = 0;                    // columns with an entry in a long row
+  int probe = 0;                 // decide `exact` by the probe after every factorisation (large mode)
+  int *colmap = nullptr;         // [n] column -> position among the ct touched ones (-1: untouched)
+  double *W = nullptr;           // [r][ct] rows of A_L scaled by D0^-1/2 (zero where A_L has no entry)
+  double *pv = nullptr;          // [n + m + n] probe vector v, rho .* (A v), v again (the reference M^-1 K v is compared with)
+  int *info = nullptr;           // [2] status words of the factorisation / inversion
   int exact = 0;                 // K0 is diagonal (P diagonal, every short row of A has one entry): M = K, and M^-1 r_0 IS the solve -- no PCG iteration
                                  // (Engine::run_chunk: KB, the three kernels of M^-1, k_wb_direct, KA); cleared when S^-1 fails its accuracy check
   DevCsr AL, ALT;                // the long rows (r x n) and their transpose (n x r); values gathered from A.val through al_src / alt_src
@@ -275,7 +288,8 @@ int slot_seq(Dev &d);                      // slots executed since slot_begin (c
 //   F1 form          pcg + 3       KB, F_0, F_1 .. F_pcg, KA (run by the launch whose scalar fold detects convergence)
 inline double slot_launches(const Dev &d, double pcg) { return d.f1.on ? pcg + 3.0 : 2.0 * (pcg + 2.0); }
 void f1_refresh(Dev &d);                   // f1.pval <- B.val (no-op without a plan)
-bool wb_supported();                       // Woodbury preconditioner available (false: the host simulator)
+bool wb_supported();
+bool wb_large_supported();                 // the dense solver libraries could be loaded                       // Woodbury preconditioner available (false: the host simulator)
 void wb_refresh(Dev &d);                   // wb.AL / ALT / WT values <- A.val (after assembly / equilibration / matrix updates)
 void wb_direct(Dev &d);                    // exact mode: x~ = x_g + M^-1 r_0 (after kb_rhs + wb_apply(0)); marks the solve as converged after one step
 void wb_apply(Dev &d, int parity);         // u = M^-1 r with the partials gamma = <r, u>, ||r||_inf in the slots of `parity` (after kb_rhs: 0, after kv(i): (i + 1) & 1)

@@ -18,10 +18,17 @@
 //     (no atomics), so iteration counts are reproducible run to run;
 //   * launch batching with hipGraph (five captured strings of slot launches serve every chunk, see engine.cpp).
 #include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>          // types and prototypes only: the libraries are dlopen()ed (dense_libs)
+#include <rocsolver/rocsolver.h>
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <chrono>
+#include <initializer_list>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 #include <cmath>
@@ -73,6 +80,7 @@ struct Impl {
   int *pin_poll = nullptr;       // [kSlotInts]
   Ctl *pin_ctl = nullptr, *pin_ctl2 = nullptr;   // staging of the state block (upload / poll + download)
   int epoch = 0;                 // chunks begun (slot_begin); the device copy sits behind the two records
+  void *blas = nullptr;          // rocblas_handle of the large-rank Woodbury factorisation (created on first use)
 };
 inline Impl &im(Dev &d) { return *static_cast<Impl *>(d.impl); }
 inline hipStream_t st(Dev &d) { return static_cast<hipStream_t>(d.stream); }
@@ -1821,8 +1829,106 @@ __global__ __launch_bounds__(kBlock) void k_wb_p3(Dev d, int parity) {     // u 
   put_partial(d.part, SL_GAMMA0 + parity, G); put_partial(d.part, SL_RN0 + parity, RN);
 }
 
+// ---- many long rows (DevWb::large): dense S on the device
+// W[a][colmap[j]] = A_L[a, j] / sqrt(D0_j): workgroups stride over the long rows (the pattern is fixed, the other entries stay zero)
+__global__ __launch_bounds__(kBlock) void k_wb_fillW(Dev d) {
+  const DevWb &w = d.wb;
+  for (int a = blockIdx.x; a < w.r; a += gridDim.x)
+    for (int k = w.AL.rowptr[a] + threadIdx.x; k < w.AL.rowptr[a + 1]; k += kBlock) {
+      const int j = w.AL.col[k];
+      w.W[(size_t)a * w.ct + w.colmap[j]] = w.AL.val[k] * sqrt(w.Dinv0[j]);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_wb_gather_large(Dev d) {
+  const DevWb &w = d.wb;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < (size_t)w.AL.nnz; k += stride) w.AL.val[k] = d.A.val[w.al_src[k]];
+  for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < (size_t)w.ALT.nnz; k += stride) w.ALT.val[k] = d.A.val[w.alt_src[k]];
+}
+__global__ __launch_bounds__(kBlock) void k_wb_adddiag(Dev d) {
+  const DevWb &w = d.wb;
+  for (int a = blockIdx.x * kBlock + threadIdx.x; a < w.r; a += gridDim.x * kBlock) w.S[(size_t)a * w.r + a] += d.rho_inv[w.rows[a]];
+}
+// the factorisation works on one triangle (entries M[c * r + q], q >= c): mirror it
+__global__ __launch_bounds__(kBlock) void k_wb_symm(double *M, int r) {
+  for (int c = blockIdx.x; c < r; c += gridDim.x)
+    for (int q = c + 1 + threadIdx.x; q < r; q += kBlock) M[(size_t)q * r + c] = M[(size_t)c * r + q];
+}
+// out = M in  (M: r x r, symmetric, full storage): one workgroup per row, 8 r^2 bytes per launch -- HBM-bound
+__global__ __launch_bounds__(kBlock) void k_wb_gemv(const double *M, const double *in, double *out, int r, const int *done) {
+  __shared__ double red[2 * kWaves];
+  if (done && *done) return;
+  for (int a = blockIdx.x; a < r; a += gridDim.x) {
+    const double *row = M + (size_t)a * r;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int k = threadIdx.x;
+    for (; k + 3 * kBlock < r; k += 4 * kBlock) {
+      const double m0 = row[k], m1 = row[k + kBlock], m2 = row[k + 2 * kBlock], m3 = row[k + 3 * kBlock];
+      acc0 += m0 * in[k]; acc1 += m1 * in[k + kBlock]; acc2 += m2 * in[k + 2 * kBlock]; acc3 += m3 * in[k + 3 * kBlock];
+    }
+    for (; k < r; k += kBlock) acc0 += row[k] * in[k];
+    const double tot = block_sum((acc0 + acc1) + (acc2 + acc3), red);
+    if (threadIdx.x == 0) out[a] = tot;
+  }
+}
+// probe of the direct mode: v, rho .* (A v), comparison of M^-1 K v with v
+__global__ __launch_bounds__(kBlock) void k_wb_probe_init(Dev d) {
+  const DevWb &w = d.wb;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += gridDim.x * kBlock) {
+    const double v = 0.5 + (double)((((unsigned)j * 2654435761u) >> 8) & 0xffffu) / 65536.0;
+    w.pv[j] = v; w.pv[(size_t)d.n + d.m + j] = v;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_wb_probe_rho(Dev d) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += gridDim.x * kBlock) d.wb.pv[(size_t)d.n + i] *= d.rho[i];
+}
+__global__ __launch_bounds__(kBlock) void k_wb_maxdiff(const double *a, const double *b, int cnt, double *out) {      // one workgroup: out[0] = max |a - b|, out[1] = max |b|
+  __shared__ double red[2 * kWaves];
+  double e = 0.0, s = 0.0;
+  for (int j = threadIdx.x; j < cnt; j += kBlock) { e = nanmax(e, fabs(a[j] - b[j])); s = nanmax(s, fabs(b[j])); }
+  block_max2(e, s, red);
+  if (threadIdx.x == 0) { out[0] = e; out[1] = s; }
+}
+__global__ void k_wb_seq(double *g, int r) { for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < r; a += gridDim.x * blockDim.x) g[a] = 1.0 + 0.25 * (a % 7); }
+
 #define LAUNCH(kernel, d, ...) hipLaunchKernelGGL(kernel, dim3(kGrid), dim3(kBlock), 0, st(d), __VA_ARGS__)
 
+}  // namespace
+
+// ---- dense solver libraries, loaded on first use (rocBLAS: fp64 GEMM; rocSOLVER: Cholesky factorisation and inverse).  Nothing of the
+// engine links against them: where they are missing the large-rank mode is off and such problems keep the Jacobi preconditioner.
+namespace {
+struct DenseLibs {
+  bool tried = false, ok = false;
+  void *hblas = nullptr, *hsolver = nullptr;
+  rocblas_status (*create)(rocblas_handle *) = nullptr;
+  rocblas_status (*destroy)(rocblas_handle) = nullptr;
+  rocblas_status (*set_stream)(rocblas_handle, hipStream_t) = nullptr;
+  rocblas_status (*dgemm)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const double *, const double *, rocblas_int,
+                          const double *, rocblas_int, const double *, double *, rocblas_int) = nullptr;
+  rocblas_status (*dpotrf)(rocblas_handle, const rocblas_fill, const rocblas_int, double *, const rocblas_int, rocblas_int *) = nullptr;
+  rocblas_status (*dpotri)(rocblas_handle, const rocblas_fill, const rocblas_int, double *, const rocblas_int, rocblas_int *) = nullptr;
+};
+DenseLibs &dense_libs() {
+  static DenseLibs L;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (L.tried) return L;
+  L.tried = true;
+  auto open_any = [](std::initializer_list<const char *> names) -> void * { for (const char *nm : names) if (void *h = dlopen(nm, RTLD_NOW | RTLD_LOCAL)) return h; return nullptr; };
+  L.hblas = open_any({"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so"});
+  L.hsolver = open_any({"librocsolver.so.0", "librocsolver.so", "/opt/rocm/lib/librocsolver.so"});
+  if (!L.hblas || !L.hsolver) return L;
+  auto sym = [](void *h, const char *nm) { return dlsym(h, nm); };
+  L.create = reinterpret_cast<decltype(L.create)>(sym(L.hblas, "rocblas_create_handle"));
+  L.destroy = reinterpret_cast<decltype(L.destroy)>(sym(L.hblas, "rocblas_destroy_handle"));
+  L.set_stream = reinterpret_cast<decltype(L.set_stream)>(sym(L.hblas, "rocblas_set_stream"));
+  L.dgemm = reinterpret_cast<decltype(L.dgemm)>(sym(L.hblas, "rocblas_dgemm"));
+  L.dpotrf = reinterpret_cast<decltype(L.dpotrf)>(sym(L.hsolver, "rocsolver_dpotrf"));
+  L.dpotri = reinterpret_cast<decltype(L.dpotri)>(sym(L.hsolver, "rocsolver_dpotri"));
+  L.ok = L.create && L.destroy && L.set_stream && L.dgemm && L.dpotrf && L.dpotri;
+  return L;
+}
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- interface
@@ -1858,6 +1964,7 @@ void destroy(Dev &d) {
   (void)hipEventDestroy(p.ev0); (void)hipEventDestroy(p.ev1); (void)hipEventDestroy(p.ev_ext); (void)hipEventDestroy(p.ev_wait); (void)hipHostFree(p.pin_res); (void)hipHostFree(p.pin_flags);
   (void)hipHostFree(p.pin_poll); if (p.side) (void)hipStreamDestroy(p.side);
   (void)hipHostFree(p.pin_ctl); (void)hipHostFree(p.pin_ctl2);
+  if (p.blas && dense_libs().ok) (void)dense_libs().destroy(static_cast<rocblas_handle>(p.blas));
   delete &p; d.impl = nullptr;
   if (d.stream) { (void)hipStreamDestroy(st(d)); d.stream = nullptr; }
 }
@@ -2019,16 +2126,88 @@ void fetch_res_flags(Dev &d, double *hr, int *hf) {
 
 void set_rho(Dev &d, double rho_bar) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_set_rho, d, d, rho_bar, 0); LAUNCH(k_init_guess, d, d, 0); }
 bool wb_supported() { return true; }
-void wb_refresh(Dev &d) { if (d.wb.on) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_wb_gather, d, d); } }
+void wb_refresh(Dev &d) {
+  if (!d.wb.on) return;
+  HIP_CHECK(hipSetDevice(d.device));
+  if (d.wb.large) LAUNCH(k_wb_gather_large, d, d); else LAUNCH(k_wb_gather, d, d);
+}
 void wb_direct(Dev &d) { LAUNCH(k_wb_direct, d, d); }
 void wb_apply(Dev &d, int parity) {
   LAUNCH(k_wb_p1, d, d);
-  hipLaunchKernelGGL(k_wb_p2, dim3(1), dim3(kWbMaxRows), 0, st(d), d);
+  if (d.wb.large) hipLaunchKernelGGL(k_wb_gemv, dim3(std::min(d.wb.r, 8 * kGrid)), dim3(kBlock), 0, st(d), d.wb.Sinv, d.wb.g, d.wb.h, d.wb.r, d.flags + F_DONE);
+  else hipLaunchKernelGGL(k_wb_p2, dim3(1), dim3(kWbMaxRows), 0, st(d), d);
   LAUNCH(k_wb_p3, d, d, parity);
+}
+
+bool wb_large_supported() { return dense_libs().ok; }
+
+// D0, W, S = W W' + 1 / rho_L, S^-1 -- all on the device (r up to kWbLargeMax); then the two numerical checks
+static void wb_factor_large(Dev &d) {
+  DevWb &w = d.wb;
+  DenseLibs &L = dense_libs();
+  Impl &p = im(d);
+  if (!L.ok) throw DeviceError("osqp_hip: the dense solver libraries are not available");
+  if (!p.blas) {
+    rocblas_handle h = nullptr;
+    if (L.create(&h) != rocblas_status_success) throw DeviceError("osqp_hip: rocblas_create_handle failed");
+    p.blas = h;
+  }
+  rocblas_handle h = static_cast<rocblas_handle>(p.blas);
+  if (L.set_stream(h, st(d)) != rocblas_status_success) throw DeviceError("osqp_hip: rocblas_set_stream failed");
+  const int r = w.r, ct = w.ct;
+  const bool log = std::getenv("OSQP_HIP_WB_LOG") != nullptr;
+  double tlap[6] = {0, 0, 0, 0, 0, 0};
+  auto lap = [&](int k) { if (log) { HIP_CHECK(hipStreamSynchronize(st(d))); tlap[k] = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); } };
+  lap(0);
+  LAUNCH(k_wb_diag, d, d);
+  LAUNCH(k_wb_fillW, d, d);
+  lap(1);
+  const double one = 1.0, zero = 0.0;
+  // W is r x ct row-major = ct x r column-major (ld ct): S = W' W in the library's convention
+  if (L.dgemm(h, rocblas_operation_transpose, rocblas_operation_none, r, r, ct, &one, w.W, ct, w.W, ct, &zero, w.S, r) != rocblas_status_success)
+    throw DeviceError("osqp_hip: rocblas_dgemm failed");
+  LAUNCH(k_wb_adddiag, d, d);
+  lap(2);
+  HIP_CHECK(hipMemcpyAsync(w.Sinv, w.S, sizeof(double) * (size_t)r * r, hipMemcpyDeviceToDevice, st(d)));
+  if (L.dpotrf(h, rocblas_fill_lower, r, w.Sinv, r, w.info) != rocblas_status_success) throw DeviceError("osqp_hip: rocsolver_dpotrf failed");
+  lap(3);
+  if (L.dpotri(h, rocblas_fill_lower, r, w.Sinv, r, w.info + 1) != rocblas_status_success) throw DeviceError("osqp_hip: rocsolver_dpotri failed");
+  lap(4);
+  hipLaunchKernelGGL(k_wb_symm, dim3(std::min(r, 8 * kGrid)), dim3(kBlock), 0, st(d), w.Sinv, r);
+  // S^-1 against S on a fixed vector:  S (S^-1 g) = g
+  double *out = w.pv + (size_t)d.n + d.m + d.n;                 // [4 + r] scratch behind the probe vectors
+  hipLaunchKernelGGL(k_wb_seq, dim3(64), dim3(256), 0, st(d), w.g, r);
+  hipLaunchKernelGGL(k_wb_gemv, dim3(std::min(r, 8 * kGrid)), dim3(kBlock), 0, st(d), w.Sinv, w.g, w.h, r, nullptr);
+  hipLaunchKernelGGL(k_wb_gemv, dim3(std::min(r, 8 * kGrid)), dim3(kBlock), 0, st(d), w.S, w.h, out + 4, r, nullptr);
+  hipLaunchKernelGGL(k_wb_maxdiff, dim3(1), dim3(kBlock), 0, st(d), out + 4, w.g, r, out);
+  // M^-1 (K v) = v ?   K v = B [v; rho .* (A v)]
+  if (w.probe) {
+    LAUNCH(k_wb_probe_init, d, d);
+    LAUNCH(k_test_spmv, d, d.A, w.pv, w.pv + d.n);
+    LAUNCH(k_wb_probe_rho, d, d);
+    LAUNCH(k_test_spmv, d, d.B, w.pv, d.r);
+    HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, 0, sizeof(int), st(d)));
+    wb_apply(d, 0);
+    hipLaunchKernelGGL(k_wb_maxdiff, dim3(1), dim3(kBlock), 0, st(d), d.uu, w.pv + (size_t)d.n + d.m, d.n, out + 2);
+  }
+  int info[2] = {0, 0};
+  double chk[4] = {0, 1, 0, 1};
+  HIP_CHECK(hipMemcpyAsync(info, w.info, sizeof(info), hipMemcpyDeviceToHost, st(d)));
+  HIP_CHECK(hipMemcpyAsync(chk, out, sizeof(double) * (w.probe ? 4 : 2), hipMemcpyDeviceToHost, st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  if (info[0] != 0 || info[1] != 0) throw DeviceError("osqp_hip: the Woodbury system of the preconditioner is not positive definite");
+  const bool inv_ok = chk[0] <= 1e-8 * chk[1];
+  w.exact = (w.probe && inv_ok && chk[2] <= 1e-9 * chk[3]) ? 1 : 0;
+  if (log) {
+    lap(5);
+    std::fprintf(stderr, "osqp_hip woodbury: r %d ct %d  |S S^-1 g - g| %.2e / %.2e   |M^-1 K v - v| %.2e / %.2e   direct %d;  D0 + W %.1f ms, GEMM %.1f ms, Cholesky %.1f ms, inverse %.1f ms, mirror + checks %.1f ms\n",
+                 r, ct, chk[0], chk[1], chk[2], chk[3], w.exact, 1e3 * (tlap[1] - tlap[0]), 1e3 * (tlap[2] - tlap[1]), 1e3 * (tlap[3] - tlap[2]), 1e3 * (tlap[4] - tlap[3]), 1e3 * (tlap[5] - tlap[4]));
+  }
 }
 // D0, S on the device; S^-1 on the host (r <= kWbMaxRows: a Cholesky factorisation of a few thousand entries, once per rho update)
 static void wb_factor(Dev &d) {
   DevWb &w = d.wb;
+  if (w.large) { wb_factor_large(d); return; }
   const int r = w.r;
   LAUNCH(k_wb_diag, d, d);
   hipLaunchKernelGGL(k_wb_S, dim3(r), dim3(kWbMaxRows), 0, st(d), d);

@@ -115,7 +115,7 @@ void policy_from_env(OSQPHipPolicy &p, bool runtime_only) {
     for (int k = 1; k <= 5; k++) if (!std::strcmp(e, names[k])) p.batch_variant = k;
   }
   if (runtime_only) return;
-  on("OSQP_HIP_WOODBURY", p.woodbury); on("OSQP_HIP_WOODBURY_DIRECT", p.woodbury_direct);
+  on("OSQP_HIP_WOODBURY", p.woodbury); on("OSQP_HIP_WOODBURY_DIRECT", p.woodbury_direct); on("OSQP_HIP_WOODBURY_LARGE", p.woodbury_large);
   on("OSQP_HIP_GRAPH", p.graph); on("OSQP_HIP_SLOTS", p.slots); on("OSQP_HIP_PCG_FUSED", p.pcg_fused); on("OSQP_HIP_F1", p.f1); on("OSQP_HIP_WINDOW", p.window);
   real("OSQP_HIP_EXTRAP", p.extrap);
   if (const char *e = std::getenv("OSQP_HIP_RHO_EQ_FACTOR")) { const double v = std::atof(e); if (v >= 1.0) p.rho_eq_factor = v; }
@@ -130,7 +130,7 @@ void Engine::default_policy(OSQPHipPolicy *p) {
   p->extrap = 0.9; p->rho_eq_factor = 0.0;
   p->rho_window = 10; p->rho_window_tol = 0.1; p->rho_persist = 1; p->rho_tol_exp = 0.5;
   p->budget_tolerate = 0.0; p->budget_sigma = 3.0; p->budget_slack = 0; p->budget_full = 0; p->cg_escalate = 1; p->stall = 1;
-  p->polish_delta_floor = 1e-3; p->polish_pcg_tol = 1e-15; p->woodbury = 1; p->woodbury_direct = 1;
+  p->polish_delta_floor = 1e-3; p->polish_pcg_tol = 1e-15; p->woodbury = 1; p->woodbury_direct = 1; p->woodbury_large = 1;
   p->slot_poll = 1; p->poll_low = 6; p->poll_first = 0.8; p->poll_frac = 0.75; p->poll_wait = 0.7;
   p->finish_pairs = 12; p->poll_sleep_us = 30;
 }
@@ -148,7 +148,7 @@ int Engine::set_policy(const OSQPHipPolicy *p) {
   const OSQPHipPolicy old = pol_;
   pol_ = *p; pol_explicit_ = true;
   // [setup] fields keep the value the handle was built with
-  pol_.slots = old.slots; pol_.pcg_fused = old.pcg_fused; pol_.f1 = old.f1; pol_.window = old.window; pol_.woodbury = old.woodbury; pol_.woodbury_direct = old.woodbury_direct;
+  pol_.slots = old.slots; pol_.pcg_fused = old.pcg_fused; pol_.f1 = old.f1; pol_.window = old.window; pol_.woodbury = old.woodbury; pol_.woodbury_direct = old.woodbury_direct; pol_.woodbury_large = old.woodbury_large;
   if (pol_.graph != old.graph) { use_graph_ = pol_.graph != 0; if (dev_ready_) { be::activate(d_); be::sync(d_); drop_graphs(); } }
   if (dev_ready_) d_.theta = pol_.extrap;
   if (dev_ready_ && pol_.rho_eq_factor >= 1.0 && pol_.rho_eq_factor != old.rho_eq_factor) return set_rho_eq_factor(pol_.rho_eq_factor);
@@ -186,7 +186,7 @@ void Engine::free_all() {
                   d_.dy, d_.xs, d_.xg, d_.xsp, d_.ztg, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.uu2, d_.ms, d_.part, d_.res,
                   d_.scal, d_.flags, d_.slot, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB,
                   d_.wb.AL.rowptr, d_.wb.AL.col, d_.wb.AL.blkdesc, d_.wb.AL.runinfo, d_.wb.AL.val, d_.wb.ALT.rowptr, d_.wb.ALT.col, d_.wb.ALT.blkdesc, d_.wb.ALT.runinfo, d_.wb.ALT.val,
-                  d_.wb.al_src, d_.wb.alt_src, d_.wb.islong, d_.wb.rows, d_.wb.WT, d_.wb.S, d_.wb.Sinv, d_.wb.g, d_.wb.h, d_.wb.Dinv0,
+                  d_.wb.al_src, d_.wb.alt_src, d_.wb.islong, d_.wb.rows, d_.wb.WT, d_.wb.S, d_.wb.Sinv, d_.wb.g, d_.wb.h, d_.wb.Dinv0, d_.wb.colmap, d_.wb.W, d_.wb.pv, d_.wb.info,
                   d_.ctl, d_.f1.blk, d_.f1.ent, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.va};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   be::destroy(d_);
@@ -471,7 +471,23 @@ void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj
   std::vector<int> rows;
   for (int i = 0; i < m; i++) if (Arp[i + 1] - Arp[i] > kLongRow) rows.push_back(i);
   const int r = (int)rows.size();
-  if (r < 1 || r > kWbMaxRows) return;
+  if (r < 1) return;
+  // many long rows: dense S on the device (backend.h kWbLargeMax) -- when the libraries load, the dense blocks fit comfortably (W, S, S^-1:
+  // 8 (r ct + 2 r^2) bytes against a budget of 24 GiB of the 288) and the long rows carry most of A (else Jacobi is not the problem)
+  bool large = false;
+  std::vector<int> colmap;
+  int ct = 0;
+  if (r > kWbMaxRows) {
+    if (r > kWbLargeMax || !pol_.woodbury_large || !be::wb_large_supported()) return;
+    size_t nz_long = 0;
+    for (int i : rows) nz_long += (size_t)(Arp[i + 1] - Arp[i]);
+    if (2 * nz_long < (size_t)Arp[m]) return;
+    colmap.assign(n, -1);
+    for (int i : rows) for (int k = Arp[i]; k < Arp[i + 1]; k++) colmap[Arj[k]] = 0;
+    for (int j = 0; j < n; j++) if (colmap[j] == 0) colmap[j] = ct++;
+    if (8.0 * ((double)r * ct + 2.0 * (double)r * r) > 24.0 * 1024 * 1024 * 1024) return;
+    large = true;
+  }
   std::vector<unsigned char> islong(m, 0);
   std::vector<int> lrp(r + 1, 0), lcol, lsrc;
   for (int a = 0; a < r; a++) {
@@ -499,14 +515,22 @@ void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj
   up_csr(w.AL, r, n, lrp, lcol); up_csr(w.ALT, n, r, trp, tcol);
   w.al_src = up_i(lsrc); w.alt_src = up_i(tsrc); w.rows = up_i(rows);
   w.islong = dev_vec<unsigned char>(d_, m); be::h2d(d_, w.islong, islong.data(), m);
-  w.WT = dev_vec<double>(d_, (size_t)n * r); w.S = dev_vec<double>(d_, (size_t)r * r); w.Sinv = dev_vec<double>(d_, (size_t)r * r);
+  w.S = dev_vec<double>(d_, (size_t)r * r); w.Sinv = dev_vec<double>(d_, (size_t)r * r);
   w.g = dev_vec<double>(d_, r); w.h = dev_vec<double>(d_, r); w.Dinv0 = dev_vec<double>(d_, n);
+  if (large) {
+    w.large = 1; w.ct = ct; w.colmap = up_i(colmap);
+    w.W = dev_vec<double>(d_, (size_t)r * ct);                  // (zero-filled by the allocator: only the pattern's positions are ever written)
+    w.pv = dev_vec<double>(d_, (size_t)n + m + n + 4 + r); w.info = dev_vec<int>(d_, 2);
+  } else w.WT = dev_vec<double>(d_, (size_t)n * r);
   w.on = 1;
   // K0 diagonal <=> P has diagonal entries only and every short row of A has exactly one entry: then M = K (backend.h DevWb::exact)
   bool diag = pol_.woodbury_direct != 0;
   for (int j = 0; j < n && diag; j++) for (int k = P_.p[j]; k < P_.p[j + 1]; k++) if (P_.i[k] != j) { diag = false; break; }
   for (int i = 0; i < m && diag; i++) if (!islong[i] && Arp[i + 1] - Arp[i] > 1) diag = false;
   w.exact = diag ? 1 : 0;
+  // (large mode: decided numerically after every factorisation -- two-entry rows whose contributions to K0's off-diagonal cancel, as in
+  //  the lasso's  -t <= x <= t , are as good as one-entry rows)
+  if (large) { w.probe = pol_.woodbury_direct != 0; w.exact = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------ setup
@@ -1973,6 +1997,7 @@ int Engine::get_stats(OSQPHipStats *out) {
   if (!out) return OSQP_DATA_VALIDATION_ERROR;
   *out = stats_; out->pcg_fused = (d_.f1.on && use_slots_) ? 2.0 : (be::pcg_fused(d_) ? 1.0 : 0.0); out->batch_direct_bw = bd_.bw_symbolic;
   out->f1_replicas = d_.f1.on ? d_.f1.D : 0;
+  out->woodbury_rows = d_.wb.on ? d_.wb.r : 0; out->woodbury_direct = (d_.wb.on && d_.wb.exact) ? 1 : 0;
   out->windowed_blocks = d_.A.nwin + d_.B.nwin; out->row_blocks = d_.A.nblk + d_.B.nblk;
   return OSQP_NO_ERROR;
 }

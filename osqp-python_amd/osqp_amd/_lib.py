@@ -57,11 +57,11 @@ class SolverStruct(C.Structure):
 class StatsStruct(C.Structure):
     _fields_ = [(k, C.c_double) for k in ('pcg_iters_total', 'pcg_iters_max', 'pcg_unconverged', 'kernel_launches',
                                           'graph_launches', 'gpu_solve_ms', 'nnzA', 'nnzB', 'pcg_fused', 'batch_direct_bw',
-                                          'cg_cap_escalations', 'windowed_blocks', 'row_blocks', 'slot_topups', 'f1_replicas')]
+                                          'cg_cap_escalations', 'windowed_blocks', 'row_blocks', 'slot_topups', 'f1_replicas', 'woodbury_rows', 'woodbury_direct')]
 
 
 class PolicyStruct(C.Structure):       # OSQPHipPolicy, include/osqp_hip.h (same order)
-    _fields_ = ([(k, C.c_int) for k in ('graph', 'slots', 'pcg_fused', 'f1', 'window', 'woodbury', 'woodbury_direct', 'device_driven', 'small_direct', 'batch_reorder', 'batch_variant')] +
+    _fields_ = ([(k, C.c_int) for k in ('graph', 'slots', 'pcg_fused', 'f1', 'window', 'woodbury', 'woodbury_direct', 'woodbury_large', 'device_driven', 'small_direct', 'batch_reorder', 'batch_variant')] +
                 [('extrap', C.c_double), ('rho_eq_factor', C.c_double), ('rho_window', C.c_int), ('rho_window_tol', C.c_double), ('rho_persist', C.c_int),
                  ('rho_tol_exp', C.c_double), ('budget_tolerate', C.c_double), ('budget_sigma', C.c_double), ('budget_slack', C.c_int), ('budget_full', C.c_int),
                  ('cg_escalate', C.c_int), ('stall', C.c_int), ('polish_delta_floor', C.c_double), ('polish_pcg_tol', C.c_double), ('slot_poll', C.c_int), ('poll_low', C.c_int), ('poll_first', C.c_double),

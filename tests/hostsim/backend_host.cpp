@@ -48,6 +48,7 @@ int slot_seq(Dev &) { return 0; }
 void slot_poll(Dev &, int *seq, int *done) { *seq = 0; *done = 0; }
 void f1_refresh(Dev &) {}
 bool wb_supported() { return false; }
+bool wb_large_supported() { return false; }
 void wb_refresh(Dev &) {}
 void wb_apply(Dev &, int) {}
 void wb_direct(Dev &) {}

@@ -1,6 +1,7 @@
 """GPU tier: the Woodbury-corrected preconditioner for a few dense rows (portfolio-like QPs) -- plain Jacobi, the
 corrected preconditioner inside the PCG, and the direct mode (the rest of K diagonal: M^-1 is K^-1) reach the same solution as the
 oracle's direct solve; the corrected forms need ~1 PCG iteration per ADMM iteration where Jacobi needs many."""
+import contextlib
 import os
 import warnings
 
@@ -24,6 +25,20 @@ def _solve(P, q, A, l, u, woodbury, direct, **kw):
         m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, **st)
         r = m.solve()
         return m, r, m._solver.hip_stats()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@contextlib.contextmanager
+def _env(**kv):
+    old = {k: os.environ.get(k) for k in kv}
+    os.environ.update(kv)
+    try:
+        yield
     finally:
         for k, v in old.items():
             if v is None:
@@ -73,3 +88,48 @@ def test_dense_rows_next_to_a_banded_block_use_the_corrected_preconditioner_insi
     for r in (rj, rw):
         assert r.info.status_val == 1 and _rel(r.x, xo) < 5e-5 and _rel(r.y, yo) < 2e-4
     assert sw['pcg_iters_total'] / rw.info.iter < sj['pcg_iters_total'] / rj.info.iter
+
+
+def test_lasso_many_dense_rows_large_rank_correction():
+    """600 sample rows of 301 entries next to the two-entry rows  -t <= x <= t : more long rows than the host-factorised form takes, so the
+    r x r system is formed, factorised and inverted on the device (backend.h kWbLargeMax).  The correction is exact here (the two-entry
+    rows' contributions to the off-diagonal of K0 cancel) and the probe after each factorisation finds that out: direct mode."""
+    P, q, A, l, u = problems.lasso_qp(300, 600)
+    xo, yo, io = Oracle().setup(P, q, A, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000).solve()
+    assert io.status_val == SOLVED
+    res = {}
+    for name, env in (('jacobi', {'OSQP_HIP_WOODBURY_LARGE': '0'}), ('large-pcg', {'OSQP_HIP_WOODBURY_DIRECT': '0'}), ('large-direct', {})):
+        with _env(**env):
+            m = osqp_amd.OSQP()
+            m.setup(P, q, A, l, u, eps_abs=1e-7, eps_rel=1e-7, verbose=False, max_iter=50000)
+            r = m.solve(raise_error=True)
+            s = m._solver.hip_stats()
+        res[name] = (r, s)
+        print('%-14s %d iterations, %.2f PCG iterations each, %d launches, rows %d direct %d; |dx| %.2e |dy| %.2e' %
+              (name, r.info.iter, s['pcg_iters_total'] / r.info.iter, s['kernel_launches'], s['woodbury_rows'], s['woodbury_direct'], _rel(r.x, xo), _rel(r.y, yo)))
+        assert _rel(r.x, xo) < 5e-5 and _rel(r.y, yo) < 2e-4
+        assert abs(r.info.obj_val - io.obj_val) <= 2e-5 * (1 + abs(io.obj_val))
+    assert res['jacobi'][1]['woodbury_rows'] == 0 and res['large-pcg'][1]['woodbury_rows'] == 600
+    assert res['large-pcg'][1]['woodbury_direct'] == 0 and res['large-direct'][1]['woodbury_direct'] == 1
+    pj = res['jacobi'][1]['pcg_iters_total'] / res['jacobi'][0].info.iter
+    pw = res['large-pcg'][1]['pcg_iters_total'] / res['large-pcg'][0].info.iter
+    assert pw <= 1.5 and pj >= 3 * pw
+    assert res['large-direct'][1]['kernel_launches'] < 0.7 * res['large-pcg'][1]['kernel_launches']
+
+
+def test_large_rank_correction_follows_matrix_updates_and_polish():
+    import scipy.sparse as sp
+    P, q, A, l, u = problems.lasso_qp(200, 400, seed=3)
+    m = osqp_amd.OSQP()
+    m.setup(P, q, A, l, u, eps_abs=1e-6, eps_rel=1e-6, verbose=False, max_iter=50000, polishing=True)
+    assert m._solver.hip_stats()['woodbury_rows'] == 400
+    r0 = m.solve(raise_error=True)
+    rng = np.random.default_rng(0)
+    Ax = A.data * (1 + 0.05 * rng.standard_normal(A.nnz))
+    m.update(Ax=Ax)
+    r1 = m.solve(raise_error=True)
+    A2 = sp.csc_matrix((Ax, A.indices, A.indptr), shape=A.shape)
+    xo, yo, io = Oracle().setup(P, q, A2, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000).solve()
+    assert io.status_val == SOLVED
+    assert abs(r1.info.obj_val - io.obj_val) <= 2e-5 * (1 + abs(io.obj_val)) and _rel(r1.x, xo) < 1e-4
+    assert abs(r0.info.obj_val - r1.info.obj_val) > 1e-6 * (1 + abs(io.obj_val))          # (the update did change the problem)

@@ -21,7 +21,7 @@ def test_policy_defaults_roundtrip_and_validation(backend):
         from osqp_amd import _lib
         p = _lib.PolicyStruct()
         h.osqp_hip_default_policy(ctypes.byref(p))
-        assert (p.graph, p.slots, p.pcg_fused, p.f1, p.window, p.woodbury, p.woodbury_direct, p.device_driven, p.small_direct, p.batch_reorder, p.batch_variant) == (1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0)
+        assert (p.graph, p.slots, p.pcg_fused, p.f1, p.window, p.woodbury, p.woodbury_direct, p.woodbury_large, p.device_driven, p.small_direct, p.batch_reorder, p.batch_variant) == (1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0)
         assert (p.extrap, p.rho_eq_factor, p.rho_window, p.rho_window_tol, p.rho_persist, p.rho_tol_exp) == (0.9, 0.0, 10, 0.1, 1, 0.5)
         assert (p.budget_sigma, p.cg_escalate, p.stall, p.finish_pairs) == (3.0, 1, 1, 12)
         P, q, A, l, u = problems.banded_qp(400, window=30, seed=4)
