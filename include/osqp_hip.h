@@ -309,7 +309,7 @@ typedef struct {
   OSQPInt slot_poll; OSQPInt poll_low; OSQPFloat poll_first, poll_frac, poll_wait;      /* host-synchronous chunks: top-ups from polled progress */
   OSQPInt finish_pairs; OSQPInt poll_sleep_us;      /* device-driven chunks: a boundary group goes out when at most finish_pairs slot pairs are missing; pause between polls */
   /* diagnostics */
-  OSQPInt slot_log, setup_timing, batch_timing;
+  OSQPInt slot_log, setup_timing, batch_timing, woodbury_log;
 } OSQPHipPolicy;
 void    osqp_hip_default_policy(OSQPHipPolicy *policy);
 OSQPInt osqp_hip_set_policy(OSQPSolver *solver, const OSQPHipPolicy *policy);

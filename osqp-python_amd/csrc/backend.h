@@ -114,6 +114,7 @@ struct DevWb {
   int large = 0;                 // r > kWbMaxRows: device-side dense factorisation; WT unused, W / colmap / ct in use
   int ct = 0;                    // columns with an entry in a long row
   int probe = 0;                 // decide `exact` by the probe after every factorisation (large mode)
+  int log = 0;                   // print the checks and the timing of every factorisation (OSQPHipPolicy::woodbury_log)
   int *colmap = nullptr;         // [n] column -> position among the ct touched ones (-1: untouched)
   double *W = nullptr;           // [r][ct] rows of A_L scaled by D0^-1/2 (zero where A_L has no entry)
   double *pv = nullptr;          // [n + m + n] probe vector v, rho .* (A v), v again (the reference M^-1 K v is compared with)

@@ -2155,7 +2155,7 @@ static void wb_factor_large(Dev &d) {
   rocblas_handle h = static_cast<rocblas_handle>(p.blas);
   if (L.set_stream(h, st(d)) != rocblas_status_success) throw DeviceError("osqp_hip: rocblas_set_stream failed");
   const int r = w.r, ct = w.ct;
-  const bool log = std::getenv("OSQP_HIP_WB_LOG") != nullptr;
+  const bool log = w.log != 0;
   double tlap[6] = {0, 0, 0, 0, 0, 0};
   auto lap = [&](int k) { if (log) { HIP_CHECK(hipStreamSynchronize(st(d))); tlap[k] = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); } };
   lap(0);

@@ -109,6 +109,7 @@ void policy_from_env(OSQPHipPolicy &p, bool runtime_only) {
   num("OSQP_HIP_FINISH_PAIRS", p.finish_pairs); num("OSQP_HIP_POLL_SLEEP_US", p.poll_sleep_us);
   if (std::getenv("OSQP_HIP_SLOT_LOG")) p.slot_log = 1;
   if (std::getenv("OSQP_HIP_BATCH_TIMING")) p.batch_timing = 1;
+  if (std::getenv("OSQP_HIP_WB_LOG")) p.woodbury_log = 1;
   if (const char *e = std::getenv("OSQP_HIP_BATCH_VARIANT")) {
     static const char *names[] = {"", "direct", "direct256", "w64", "w256", "generic"};
     p.batch_variant = 0;
@@ -530,7 +531,7 @@ void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj
   w.exact = diag ? 1 : 0;
   // (large mode: decided numerically after every factorisation -- two-entry rows whose contributions to K0's off-diagonal cancel, as in
   //  the lasso's  -t <= x <= t , are as good as one-entry rows)
-  if (large) { w.probe = pol_.woodbury_direct != 0; w.exact = 0; }
+  if (large) { w.probe = pol_.woodbury_direct != 0; w.exact = 0; w.log = pol_.woodbury_log; }
 }
 
 // ------------------------------------------------------------------------------------------------ setup
@@ -1060,8 +1061,10 @@ void Engine::exec_chunk_sync(int cnt, int lim, bool with_res, int kind, double *
       const int rem = cnt - done;
       const double rate = done > 0 ? std::min<double>(pairs_for(1, lim), (0.5 * seq) / done) : pairs_for(1, p0);      // pairs per ADMM iteration so far
       const int need = (int)std::ceil(rem * rate) + 1 - ahead;
-      // (an iteration that has outrun the prediction by far -- no iteration finished yet, many pairs consumed: grow geometrically)
-      const int np = std::max(std::max(2, need > 12 ? (int)std::ceil(kFrac * need) : need), done == 0 ? launched_pairs / 4 : 0);
+      // (an iteration that has outrun the prediction by far -- none finished yet, more than twice the chunk's predicted need consumed:
+      //  grow geometrically)
+      const bool outrun = done == 0 && launched_pairs > 2 * (int)std::ceil(pairs_for(cnt, p0)) + 8;
+      const int np = std::max(std::max(2, need > 12 ? (int)std::ceil(kFrac * need) : need), outrun ? launched_pairs / 4 : 0);
       run_slots(0, np, lim); launched_pairs += np;
       stats_.slot_topups += 1;
     }

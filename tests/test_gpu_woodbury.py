@@ -133,3 +133,24 @@ def test_large_rank_correction_follows_matrix_updates_and_polish():
     assert io.status_val == SOLVED
     assert abs(r1.info.obj_val - io.obj_val) <= 2e-5 * (1 + abs(io.obj_val)) and _rel(r1.x, xo) < 1e-4
     assert abs(r0.info.obj_val - r1.info.obj_val) > 1e-6 * (1 + abs(io.obj_val))          # (the update did change the problem)
+
+
+def test_large_rank_correction_with_dense_P_is_only_a_preconditioner():
+    """All 300 rows of A dense (200 entries) and P dense: K0 = P + sigma I is far from diagonal, the probe must refuse the direct mode and the
+    PCG must still reach the oracle's solution with the corrected preconditioner."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    n, m = 200, 300
+    M = rng.standard_normal((n, n)); P = sp.csc_matrix(M @ M.T / n + 0.1 * np.eye(n))
+    A = sp.csc_matrix(rng.standard_normal((m, n)))
+    q = rng.standard_normal(n); l = -rng.random(m) - 0.1; u = rng.random(m) + 0.1
+    l[:20] = u[:20] = 0.05 * rng.standard_normal(20)
+    xo, yo, io = Oracle().setup(P, q, A, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000).solve()
+    assert io.status_val == SOLVED
+    mdl = osqp_amd.OSQP()
+    mdl.setup(P, q, A, l, u, eps_abs=1e-7, eps_rel=1e-7, verbose=False, max_iter=50000)
+    r = mdl.solve(raise_error=True)
+    s = mdl._solver.hip_stats()
+    print('dense P: %d iterations, %.2f PCG each, rows %d direct %d, |dx| %.2e |dy| %.2e' % (r.info.iter, s['pcg_iters_total'] / r.info.iter, s['woodbury_rows'], s['woodbury_direct'], _rel(r.x, xo), _rel(r.y, yo)))
+    assert s['woodbury_rows'] == 300 and s['woodbury_direct'] == 0
+    assert _rel(r.x, xo) < 5e-5 and _rel(r.y, yo) < 2e-4
