@@ -267,9 +267,10 @@ def main():
         # in-sequence times: T(one PCG iteration as a solve runs it) minus T(the sequence without the kernel); this is what
         # a solve pays (the kernels evict each other's matrix from L2)
         pcg_ms = s.hip_time_kernel(seq_id, args.probe_reps)
-        if f1:        # probe 15 = two consecutive iterations (the double-buffered vectors alternate as in a solve)
-            pcg_ms *= 0.5
+        if f1:        # probes 14 / 15 = two consecutive iterations (the double-buffered vectors alternate as in a solve); 15 pays for the scalar
+            pcg_ms *= 0.5                         # fold of the previous launch's partials at the head of the launch like every launch of a solve, 14 skips it
             probes[dom]['ms'] = pcg_ms
+            probes[dom]['ms_without_scalar_fold'] = 0.5 * probes[dom].pop('ms_same_kernel_repeat')
         elif fused:   # the "sequence without the kernel" is the other kernel alone (L2-hot, so this is an upper bound)
             names = list(pcg_kernels)
             for name, other_name in zip(names, names[::-1]):

@@ -1104,7 +1104,7 @@ __device__ __forceinline__ bool f1_scalars(const Dev &d, const int k, const int 
   double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
   const int cur = (k + 1) & 1, tid = threadIdx.x;
   sc = F1Scal{0.0, 0.0, k >= 2};
-  if (probe) { sc.alpha = 1e-3; sc.beta = k >= 2 ? 0.5 : 0.0; return true; }
+  if (probe == 1) { sc.alpha = 1e-3; sc.beta = k >= 2 ? 0.5 : 0.0; return true; }      // (probe == 2 pays for the fold like a solve's launch, then uses the fixed scalars)
   if (k == 0) {
     const PartRegs prn = partial_load(d.part + SL_RN0 * kGrid), pbn = partial_load(d.part + SL_BN * kGrid);
     double rn = partial_fold_max(prn), bn = partial_fold_max(pbn);
@@ -1118,6 +1118,11 @@ __device__ __forceinline__ bool f1_scalars(const Dev &d, const int k, const int 
   const double tol = d.scal[S_TOL_NOW], glast = k >= 2 ? gam[k - 2] : 1.0, alast = k >= 2 ? alp[k - 2] : 1.0;
   double gamma = partial_fold_sum(pg), rn = partial_fold_max(prn), delta = partial_fold_sum(pd);
   block_sum_max_sum(gamma, rn, delta, red);
+  if (probe) {                                              // timing probe: the fold above was paid for; bounded, repeatable scalars instead of its result
+    if (rn < -1.0) d.res[R_COUNT - 1] = gamma + delta + tol + glast + alast;      // (never true: keeps the fold alive)
+    sc.alpha = 1e-3; sc.beta = k >= 2 ? 0.5 : 0.0;
+    return true;
+  }
   if (k >= 2 && !(rn > tol)) return false;                  // converged after k - 1 iterations (r_0 was tested by F_0)
   sc.beta = k >= 2 ? gamma / glast : 0.0;
   sc.alpha = k >= 2 ? gamma / (delta - sc.beta * gamma / alast) : gamma / delta;
@@ -1353,10 +1358,11 @@ __device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const in
 __global__ __launch_bounds__(kBlock) void k_f1_refresh(Dev d) {
   for (int k = blockIdx.x * kBlock + threadIdx.x; k < d.f1.pnnz; k += gridDim.x * kBlock) d.f1.pval[k] = d.B.val[d.f1.psrc[k]];
 }
-// timing probe: one F launch with fixed scalars (no stopping test)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_f1_probe(Dev d, int k) {
+// timing probe: one F launch as a solve runs it -- the scalar fold of the previous launch's partials included -- with fixed alpha, beta
+// and no stopping test (mode 2; mode 1 skips the fold: what the launch costs without it)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_f1_probe(Dev d, int k, int mode) {
   __shared__ F1Lds lds;
-  f1_iteration(d, k, 1 << 30, 0, 1, lds);
+  f1_iteration(d, k, 1 << 30, 0, mode, lds);
 }
 
 // The slot kernel of the F1 form: every launch of a chunk's string is this kernel (par: which of the two phase records it reads);
@@ -1713,7 +1719,7 @@ __device__ __forceinline__ void ctl_begin_chunk(const Dev &d, const Ctl &c, int 
 }
 __global__ void k_ctl_begin(Dev d, int epoch) {
   Ctl &c = *d.ctl;
-  c.chunk_done = 0; c.rho_flag = 0; c.stage2 = 0; c.status = CTL_RUNNING;
+  c.chunk_done = 0; c.rho_flag = 0; c.stage2 = 0; c.status = CTL_RUNNING; c.seq_begin = 0;
   ctl_begin_chunk(d, c, 0);
   d.slot[2 * SR_WORDS] = epoch;
 }
@@ -1747,7 +1753,7 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, int stage) {
       st = ctl_boundary(c, res, fl);
     } else st = ctl_boundary_stage2(c, res, c.last_flags);
     c.status = st;
-    if (st == CTL_RUNNING && !c.stage2) ctl_begin_chunk(d, c, d.slot[SR_SEQ]);       // (record A: written by the last slot launch of the string)
+    if (st == CTL_RUNNING && !c.stage2) { c.seq_begin = d.slot[SR_SEQ]; ctl_begin_chunk(d, c, d.slot[SR_SEQ]); }       // (record A: written by the last slot launch of the string)
   }
   __syncthreads();
   int *go = reinterpret_cast<int *>(g);
@@ -2389,8 +2395,8 @@ float time_kernel(Dev &d, int which, int reps) {
       case 11: LAUNCH(k_k1f, d, d, 1); break;  // fused SpMV-A + vector update alone (alpha fixed by the stored history; drifts linearly, bounded)
       case 12: LAUNCH(k_k2f, d, d, 0); break;  // fused SpMV-B alone
       case 13: LAUNCH(k_k2f, d, d, 2); LAUNCH(k_k1f, d, d, 3); break;   // the same pair with the done flag set: what an early-exit pair costs
-      case 14: LAUNCH(k_f1_probe, d, d, 2); break;                       // F1 form: one PCG iteration = one launch, repeated on the same buffers
-      case 15: LAUNCH(k_f1_probe, d, d, 2); LAUNCH(k_f1_probe, d, d, 3); break;   // ... two consecutive iterations as a solve runs them (buffers alternate)
+      case 14: LAUNCH(k_f1_probe, d, d, 2, 1); LAUNCH(k_f1_probe, d, d, 3, 1); break;   // F1 form without the scalar fold at the head of the launch (two consecutive iterations)
+      case 15: LAUNCH(k_f1_probe, d, d, 2, 2); LAUNCH(k_f1_probe, d, d, 3, 2); break;   // F1 form: one PCG iteration = one launch; two consecutive iterations as a solve runs them (buffers alternate, fold included)
       default: LAUNCH(k_k2f, d, d, 0); LAUNCH(k_k1f, d, d, 1); break;   // one FUSED PCG iteration (two kernels): repeated exact line-search steps, bounded
     }
   };

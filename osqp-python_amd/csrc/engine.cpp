@@ -1133,7 +1133,6 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
     kFinish = std::max<int>(pol_.finish_pairs, 2 * kLow);
   };
   // chunk in flight as of the last poll, and the progress counters at the first poll that saw it (rate estimate)
-  int cur_boundaries = snap.boundaries; long seq0 = 0;
   { const int cnt = snap.ch_next - snap.iter;
     const int np = std::max(2, (int)std::floor(pol_.poll_first * pairs_for(cnt, pred_for(snap, snap.ch_kind, snap.ch_tight))));
     run_slots(0, np, 0); launched += np; }
@@ -1141,15 +1140,16 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
     be::ctl_poll(d_, &snap, &seq, &done);
     if (snap.status != CTL_RUNNING) break;
     if (now_s() - t0 > settings.time_limit) { timed_out = true; break; }
-    if (snap.boundaries != cur_boundaries) { cur_boundaries = snap.boundaries; seq0 = seq; }
     const long ahead = launched - seq / 2;           // pairs enqueued and not yet executed
     { const double t_now = now_s();
       if (seq - seq_rate >= 16) { pair_s = std::max(5e-6, 2.0 * (t_now - t_rate) / (double)(seq - seq_rate)); t_rate = t_now; seq_rate = seq; } }
     if (ahead > kLow) { std::this_thread::sleep_for(std::chrono::microseconds(pol_.poll_sleep_us)); t_cycle = now_s(); continue; }
     const int cnt = snap.ch_next - snap.iter, rem = std::max(0, cnt - done);
     const double pm = pred_for(snap, snap.ch_kind, snap.ch_tight);
-    const double rate = done >= 2 ? std::min<double>(pairs_for(1, snap.budget[snap.ch_tight]), 0.5 * (double)(seq - seq0) / done) : pairs_for(1, pm);   // pairs per ADMM iteration
-    const int need = (int)std::ceil(rem * rate) + 1 - (int)ahead;
+    // pairs per ADMM iteration: what THIS chunk has consumed so far per finished iteration (a premature boundary group costs two orders of
+    // magnitude more than a late one -- everything queued behind it idles until the next group -- hence the two pairs of slack)
+    const double rate = done >= 2 ? std::min<double>(pairs_for(1, snap.budget[snap.ch_tight]), 0.5 * (double)std::max(0, seq - snap.seq_begin) / done) : 1.1 * pairs_for(1, pm);
+    const int need = (int)std::ceil(rem * rate) + 2 - (int)ahead;
     if (need > kFinish) {                            // far from the chunk's end: most of what is missing
       const int np = std::max(2, (int)std::ceil(pol_.poll_frac * need));
       run_slots(0, np, 0); launched += np;
@@ -1170,8 +1170,8 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
       }
     }
     cycle_done();
-    if (pol_.slot_log) std::fprintf(stderr, "group: device iter %d chunk %d..%d kind %d done %d rem %d rate %.2f ahead %ld pairs %d (launched %ld, seq %d) budget %d/%d tol %.3e rho %.4e\n",
-                                    snap.iter, snap.iter, snap.ch_next, snap.ch_kind, done, rem, rate, ahead, np, launched, seq, snap.budget[0], snap.budget[1], snap.tol_abs, snap.rho_bar);
+    if (pol_.slot_log) std::fprintf(stderr, "group: device iter %d chunk %d..%d kind %d done %d rem %d rate %.2f ahead %ld pairs %d (launched %ld, seq %d) budget %d/%d tol %.3e rho %.4e; host cycle %.0f us, pair %.1f us, low-water %d\n",
+                                    snap.iter, snap.iter, snap.ch_next, snap.ch_kind, done, rem, rate, ahead, np, launched, seq, snap.budget[0], snap.budget[1], snap.tol_abs, snap.rho_bar, 1e6 * cycle_s, 1e6 * pair_s, kLow);
   }
   be::sync(d_);                                      // (what is still queued idles: the state block says the solve is over -- or, after
   be::ctl_download(d_, &c);                          //  a time-out, runs to the end of the strings)

@@ -50,6 +50,7 @@ struct Ctl {
   double inf_nd_p, inf_nd_d;      // ||dy||, ||dx|| of the pending tests (_osqp.py:806, :836); inf_thr_d = eps_dual_inf ||dx|| (threshold of the A dx test)
   double inf_thr_d; int inf_unscaled;
   int boundaries;                 // boundaries processed (progress, polled by the host)
+  int seq_begin;                  // slot launches executed when the chunk in flight began (the host's rate estimate: launches of THIS chunk per finished iteration)
   int last_flags[F_COUNT];        // PCG statistics of the chunk the last boundary closed (the host needs them when it finishes a boundary)
   // ---- statistics of the solve
   double pcg_total, pcg_max, pcg_unconv; int escalations;

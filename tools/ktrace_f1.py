@@ -30,7 +30,7 @@ s = m._solver
 NAMES = ['entry', 'scalars ready', 'descriptors arrived', 'loads issued', 'window staged (+ own update)', 'products staged', 'row sums done',
          'transposed products staged', 'column sums + stores done', 'exit']
 for rep in range(3):
-    ms = s.hip_time_kernel(14, 20)
+    ms = 0.5 * s.hip_time_kernel(15, 20)         # (the probe is two consecutive launches; the stamps are those of the last one)
     tr = s.hip_trace_read().reshape(1024, 16).astype(np.int64)
     t0 = tr[:, 0].min()
     print('--- repetition %d: launch time by hipEvent %.2f us' % (rep, ms * 1e3))
