@@ -755,7 +755,15 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
     upload_bounds_and_types();
   }
   be::set_rho(d_, rho_bar_);                                       // _osqp.py:499-524
-  be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  try { be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER); }
+  catch (const DeviceError &err) {
+    // the first device-side factorisation of the large-rank correction failed (a dense-library call, not this engine's kernels): the
+    // handle falls back to plain Jacobi -- said loudly, and visible in OSQPHipStats::woodbury_rows = 0
+    if (!(d_.wb.on && d_.wb.large)) throw;
+    std::fprintf(stderr, "osqp_hip: large-rank Woodbury correction switched off for this handle (%s)\n", err.what());
+    d_.wb.on = 0;
+    be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  }
   be::init_iterates(d_, 1);
 
   sol_x_.assign(n, kNaN); sol_y_.assign(m, kNaN); sol_pc_.assign(m, kNaN); sol_dc_.assign(n, kNaN);
