@@ -1330,11 +1330,13 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
   KT(9);
 }
 // returns false when the PCG had already converged (nothing done: the caller runs KA in this launch)
-__device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const int cap, const int admm_par, const int probe, F1Lds &L) {
-  KT(0);
-  // the first block's record goes out ahead of the partials of the scalar fold: both latencies overlap
+// the record of the workgroup's first row block
+__device__ __forceinline__ F1Rec f1_first_record(const Dev &d) {
   const int b0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * ((d.A.nblk + 7) >> 3) + (int)(blockIdx.x >> 3));
-  const F1Rec rec0 = f1_record(d.f1, min(b0, d.A.nblk - 1));
+  return f1_record(d.f1, min(b0, d.A.nblk - 1));
+}
+__device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const int cap, const int admm_par, const int probe, F1Lds &L, const F1Rec &rec0) {
+  KT(0);
   F1Scal sc;
   if (!f1_scalars(d, k, admm_par, probe, L.red, sc)) return false;
   const bool vec_only = !probe && k >= cap;                 // the last budgeted update: no operator apply follows
@@ -1362,7 +1364,7 @@ __global__ __launch_bounds__(kBlock) void k_f1_refresh(Dev d) {
 // and no stopping test (mode 2; mode 1 skips the fold: what the launch costs without it)
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_f1_probe(Dev d, int k, int mode) {
   __shared__ F1Lds lds;
-  f1_iteration(d, k, 1 << 30, 0, mode, lds);
+  f1_iteration(d, k, 1 << 30, 0, mode, lds, f1_first_record(d));      // (the first block's record goes out ahead of the partials of the scalar fold: both latencies overlap)
 }
 
 // The slot kernel of the F1 form: every launch of a chunk's string is this kernel (par: which of the two phase records it reads);
@@ -1371,7 +1373,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   __shared__ union { StreamLds<2> kb; StreamLdsW<1, double> ka; F1Lds f; } lds;
   const int *R = d.slot + (par ? SR_WORDS : 0);
   int *W = d.slot + (par ? 0 : SR_WORDS);
+  // The head of every launch is a chain of dependent scalar loads (kernel arguments -> phase record -> block record -> first vector loads):
+  // the arguments the F phase needs are pinned into registers HERE, behind one wait, and the block record is requested together with the
+  // phase record (most launches are F launches; KB / KA request their own descriptors after the branch)
+  const F1Rec rec0 = f1_first_record(d);
   SlotState st = slot_read(R);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // both records and the phases' base pointers are in registers HERE: requested together, one wait
+  asm volatile("" :: "s"(st.ph), "s"(rec0.ds.x), "s"(rec0.fc.w), "s"(d.part), "s"(d.scal), "s"(d.f1.va), "s"(d.x), "s"(d.ztg), "s"(d.v), "s"(d.uu), "s"(d.n));
+#endif
   if (st.ph == P_KB) {
     if (st.admm >= st.target) { st.ph = P_IDLE; slot_write(W, st); return; }
     GKb g{d.xg, d.v, d.t0, d.n};
@@ -1385,7 +1395,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
     st.ph = P_F; st.k = 0;
   } else if (st.ph == P_F) {
-    if (f1_iteration(d, st.k, st.cap, st.admm & 1, 0, lds.f)) {
+    if (f1_iteration(d, st.k, st.cap, st.admm & 1, 0, lds.f, rec0)) {
       if (st.k >= st.cap) { st.ph = P_KA; st.used = st.k; st.conv = 0; }      // stopped at the cap: the next launch runs KA
       else st.k += 1;
     } else {                                             // converged: KA right here
