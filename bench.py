@@ -238,7 +238,7 @@ def main():
             # s, D replicas read; p, x~ read; s, r, p, x~, pu and D replicas written
             f1_bytes = 12 * nnzA + 4 * (mm + 1) + 8 * mm + 2 * f1_D * n + 12 * nnzP_full + 4 * (n + 1) + 8 * n * (4 + f1_D + 2 + 5 + f1_D)
             pcg_kernels = {'F1 one PCG iteration per launch (k_slot1 phase F)': (14, f1_bytes)}
-            seq_id, dom, dom_kernel = 15, 'F1 one PCG iteration per launch (k_slot1 phase F)', 'k_f1_probe'
+            seq_id, dom, dom_kernel = 16, 'F1 one PCG iteration per launch (k_slot1 phase F)', 'k_f1_probe'
         elif fused:     # two kernels per PCG iteration
             pcg_kernels = {
                 # SpMV(A) applied to Minv.*s (the gathered vector, counted in sA) with the epilogue t = t - alpha rho S (+ rho, t read:
@@ -267,10 +267,15 @@ def main():
         # in-sequence times: T(one PCG iteration as a solve runs it) minus T(the sequence without the kernel); this is what
         # a solve pays (the kernels evict each other's matrix from L2)
         pcg_ms = s.hip_time_kernel(seq_id, args.probe_reps)
-        if f1:        # probes 14 / 15 = two consecutive iterations (the double-buffered vectors alternate as in a solve); 15 pays for the scalar
-            pcg_ms *= 0.5                         # fold of the previous launch's partials at the head of the launch like every launch of a solve, 14 skips it
+        if f1:
+            # every probe = two consecutive iterations (the double-buffered vectors alternate as in a solve).  16: F launches of the SLOT KERNEL
+            # ITSELF (phase record, scalars from the fold of the previous launch's partials, stopping test that never fires): what a launch costs
+            # inside a solve -- the figure the roofline uses.  15: the same iteration in a kernel that holds nothing but the F phase, fixed
+            # scalars; 14: that kernel without the fold.
+            pcg_ms *= 0.5
             probes[dom]['ms'] = pcg_ms
-            probes[dom]['ms_without_scalar_fold'] = 0.5 * probes[dom].pop('ms_same_kernel_repeat')
+            probes[dom]['ms_f_only_kernel'] = 0.5 * s.hip_time_kernel(15, args.probe_reps)
+            probes[dom]['ms_f_only_kernel_without_scalar_fold'] = 0.5 * probes[dom].pop('ms_same_kernel_repeat')
         elif fused:   # the "sequence without the kernel" is the other kernel alone (L2-hot, so this is an upper bound)
             names = list(pcg_kernels)
             for name, other_name in zip(names, names[::-1]):

@@ -982,9 +982,10 @@ __global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
 // KA with the PCG statistics taken from the slot record (used iterations; conv = 0: the PCG stopped at the cap -- did its last
 // iterate reach the tolerance anyway?)
 template <class L>
-__device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv, const FirstDesc &fd, int admm, int target) {
+__device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv, const FirstDesc &fd, int admm, int target, int rn_slot = -1) {
   double theta = d.theta, rn_last = 0.0, bn_last = 0.0;
-  if (!conv) { theta = cutoff_theta(d, used & 1, lds.red, rn_last, bn_last, admm); __syncthreads(); }      // (conv comes from the slot record: uniform)
+  // (rn_slot: which of the two ||r|| partial buffers the last PCG launch wrote -- the parity of `used` in the two-kernel form, of the LAUNCH in the F1 form)
+  if (!conv) { theta = cutoff_theta(d, rn_slot >= 0 ? rn_slot : (used & 1), lds.red, rn_last, bn_last, admm); __syncthreads(); }      // (conv comes from the slot record: uniform)
   GVec g{d.xs};
   EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, theta};
   process_rows_fd<1>(d.A, g, e, lds, NoPre(), fd);
@@ -1099,24 +1100,35 @@ __device__ __forceinline__ double f1_segsum(const double *seg, int a, int z) {
   for (int k = a + kB; k < z; k++) acc += seg[k];
   return acc;
 }
-// The scalar part of launch F_k.  Returns false when the PCG had already converged (the caller runs KA in this launch).
-__device__ __forceinline__ bool f1_scalars(const Dev &d, const int k, const int admm_par, const int probe, double *red, F1Scal &sc) {
+// The scalar part of launch F_k.  The per-workgroup partials (gamma, delta, ||r||) are double-buffered by the parity of the LAUNCH, not of k:
+// a launch reads what the previous launch of the string wrote -- KB: gamma_0, ||r_0||, ||rhs|| (in delta's slot); F_k: gamma_k, delta_k, ||r_k|| --
+// so the three loads depend on nothing but the kernel's `par` argument and leave at the very head of the launch (f1_fold_issue), next to
+// the phase record instead of behind it.  f1_fold_finish returns false when the PCG had already converged (the caller runs KA in this launch).
+struct F1Fold { PartRegs a, b, c; };
+__device__ __forceinline__ F1Fold f1_fold_issue(const Dev &d, const int par, const int probe) {
+  F1Fold f;
+#pragma unroll
+  for (int q = 0; q < kPart; q++) { f.a.v[q] = 0.0; f.b.v[q] = 0.0; f.c.v[q] = 0.0; }
+  if (probe == 1) return f;                                 // (probe == 2 pays for the fold like a solve's launch, then uses the fixed scalars)
+  const int prev = par ^ 1;
+  f.a = partial_load(d.part + (SL_GAMMA0 + prev) * kGrid); f.b = partial_load(d.part + (SL_DELTA + prev) * kGrid); f.c = partial_load(d.part + (SL_RN0 + prev) * kGrid);
+  return f;
+}
+__device__ __forceinline__ bool f1_fold_finish(const Dev &d, const int k, const int admm_par, const int probe, const F1Fold &f, double *red, F1Scal &sc) {
   double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
-  const int cur = (k + 1) & 1, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   sc = F1Scal{0.0, 0.0, k >= 2};
-  if (probe == 1) { sc.alpha = 1e-3; sc.beta = k >= 2 ? 0.5 : 0.0; return true; }      // (probe == 2 pays for the fold like a solve's launch, then uses the fixed scalars)
+  if (probe == 1) { sc.alpha = 1e-3; sc.beta = k >= 2 ? 0.5 : 0.0; return true; }
   if (k == 0) {
-    const PartRegs prn = partial_load(d.part + SL_RN0 * kGrid), pbn = partial_load(d.part + SL_BN * kGrid);
-    double rn = partial_fold_max(prn), bn = partial_fold_max(pbn);
+    double rn = partial_fold_max(f.c), bn = partial_fold_max(f.b);
     block_max2(rn, bn, red);
     const double tol = fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS]);
+    if (probe) { if (rn < -1.0) d.res[R_COUNT - 1] = bn + tol; return true; }
     if (blockIdx.x == 0 && tid == 0) { d.scal[S_TOL_NOW] = tol; d.scal[S_RN0] = rn; d.scal[S_RN0H + admm_par] = rn; }
     return rn > tol;                                        // false: the start already meets the tolerance (a NaN also ends the inner loop)
   }
-  const PartRegs pg = partial_load(d.part + (SL_GAMMA0 + cur) * kGrid), pd = partial_load(d.part + (SL_DELTA + cur) * kGrid),
-                 prn = partial_load(d.part + (SL_RN0 + cur) * kGrid);
   const double tol = d.scal[S_TOL_NOW], glast = k >= 2 ? gam[k - 2] : 1.0, alast = k >= 2 ? alp[k - 2] : 1.0;
-  double gamma = partial_fold_sum(pg), rn = partial_fold_max(prn), delta = partial_fold_sum(pd);
+  double gamma = partial_fold_sum(f.a), rn = partial_fold_max(f.c), delta = partial_fold_sum(f.b);
   block_sum_max_sum(gamma, rn, delta, red);
   if (probe) {                                              // timing probe: the fold above was paid for; bounded, repeatable scalars instead of its result
     if (rn < -1.0) d.res[R_COUNT - 1] = gamma + delta + tol + glast + alast;      // (never true: keeps the fold alive)
@@ -1145,7 +1157,7 @@ __device__ __forceinline__ F1Rec f1_record(const DevF1 &f, int b) {
   return F1Rec{sload_int4(f.blk, 4 * (size_t)b), sload_int4(f.blk, 4 * (size_t)b + 1), sload_int4(f.blk, 4 * (size_t)b + 2), sload_int4(f.blk, 4 * (size_t)b + 3)};
 }
 template <int D, bool FIRST>
-__device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool vec_only, const F1Scal sc, F1Lds &L, const F1Rec &rec0) {
+__device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool vec_only, const F1Scal sc, F1Lds &L, const F1Rec &rec0, const int par) {
   const DevF1 &f = d.f1;
   const int n = d.n, tid = threadIdx.x;
   const int cur = (k + 1) & 1, nxt = k & 1;               // parity of k - 1 / of k
@@ -1325,8 +1337,12 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
   }
   __syncthreads();
   block_sum_max_sum(g_acc, rn_acc, dl_acc, L.red);
-  if (!FIRST) { put_partial(d.part, SL_GAMMA0 + nxt, g_acc); put_partial(d.part, SL_RN0 + nxt, rn_acc); }   // (F_0 leaves KB's gamma_0, ||r_0||)
-  if (!vec_only) put_partial(d.part, SL_DELTA + nxt, dl_acc);
+  if (!FIRST) { put_partial(d.part, SL_GAMMA0 + par, g_acc); put_partial(d.part, SL_RN0 + par, rn_acc); }
+  else if (tid == 0) {                                      // F_0 hands KB's gamma_0, ||r_0|| on: this workgroup's entries move to this launch's buffers
+    d.part[(SL_GAMMA0 + par) * kGrid + blockIdx.x] = d.part[(SL_GAMMA0 + (par ^ 1)) * kGrid + blockIdx.x];
+    d.part[(SL_RN0 + par) * kGrid + blockIdx.x] = d.part[(SL_RN0 + (par ^ 1)) * kGrid + blockIdx.x];
+  }
+  if (!vec_only) put_partial(d.part, SL_DELTA + par, dl_acc);
   KT(9);
 }
 // returns false when the PCG had already converged (nothing done: the caller runs KA in this launch)
@@ -1335,26 +1351,17 @@ __device__ __forceinline__ F1Rec f1_first_record(const Dev &d) {
   const int b0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * ((d.A.nblk + 7) >> 3) + (int)(blockIdx.x >> 3));
   return f1_record(d.f1, min(b0, d.A.nblk - 1));
 }
-__device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const int cap, const int admm_par, const int probe, F1Lds &L, const F1Rec &rec0) {
+// D (the number of replica vectors, DevF1::D) is a TEMPLATE parameter of the kernels: a slot kernel that carries the bodies of all four
+// values pays for the three it never runs in every launch (the head of a launch is as long as the kernel's register / code footprint
+// makes it)
+template <int D>
+__device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const int cap, const int admm_par, const int probe, F1Lds &L, const F1Rec &rec0, const F1Fold &fold, const int par) {
   KT(0);
   F1Scal sc;
-  if (!f1_scalars(d, k, admm_par, probe, L.red, sc)) return false;
+  if (!f1_fold_finish(d, k, admm_par, probe, fold, L.red, sc)) return false;
   const bool vec_only = !probe && k >= cap;                 // the last budgeted update: no operator apply follows
-  if (k == 0) {
-    switch (d.f1.D) {
-      case 1: f1_body<1, true>(d, k, vec_only, sc, L, rec0); break;
-      case 2: f1_body<2, true>(d, k, vec_only, sc, L, rec0); break;
-      case 3: f1_body<3, true>(d, k, vec_only, sc, L, rec0); break;
-      default: f1_body<4, true>(d, k, vec_only, sc, L, rec0); break;
-    }
-  } else {
-    switch (d.f1.D) {
-      case 1: f1_body<1, false>(d, k, vec_only, sc, L, rec0); break;
-      case 2: f1_body<2, false>(d, k, vec_only, sc, L, rec0); break;
-      case 3: f1_body<3, false>(d, k, vec_only, sc, L, rec0); break;
-      default: f1_body<4, false>(d, k, vec_only, sc, L, rec0); break;
-    }
-  }
+  if (k == 0) f1_body<D, true>(d, k, vec_only, sc, L, rec0, par);
+  else f1_body<D, false>(d, k, vec_only, sc, L, rec0, par);
   return true;
 }
 __global__ __launch_bounds__(kBlock) void k_f1_refresh(Dev d) {
@@ -1362,13 +1369,17 @@ __global__ __launch_bounds__(kBlock) void k_f1_refresh(Dev d) {
 }
 // timing probe: one F launch as a solve runs it -- the scalar fold of the previous launch's partials included -- with fixed alpha, beta
 // and no stopping test (mode 2; mode 1 skips the fold: what the launch costs without it)
+template <int D>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_f1_probe(Dev d, int k, int mode) {
   __shared__ F1Lds lds;
-  f1_iteration(d, k, 1 << 30, 0, mode, lds, f1_first_record(d));      // (the first block's record goes out ahead of the partials of the scalar fold: both latencies overlap)
+  const int par = k & 1;
+  const F1Fold fold = f1_fold_issue(d, par, mode);
+  f1_iteration<D>(d, k, 1 << 30, 0, mode, lds, f1_first_record(d), fold, par);      // (the first block's record goes out ahead of the partials of the scalar fold: both latencies overlap)
 }
 
 // The slot kernel of the F1 form: every launch of a chunk's string is this kernel (par: which of the two phase records it reads);
 // the phase that is due -- KB (streams B), a PCG iteration F_k (streams A and P), KA (streams A) -- comes from the record.
+template <int D>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_slot1(Dev d, int par) {
   __shared__ union { StreamLds<2> kb; StreamLdsW<1, double> ka; F1Lds f; } lds;
   const int *R = d.slot + (par ? SR_WORDS : 0);
@@ -1376,11 +1387,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   // The head of every launch is a chain of dependent scalar loads (kernel arguments -> phase record -> block record -> first vector loads):
   // the arguments the F phase needs are pinned into registers HERE, behind one wait, and the block record is requested together with the
   // phase record (most launches are F launches; KB / KA request their own descriptors after the branch)
+  const F1Fold fold = f1_fold_issue(d, par, 0);         // the previous launch's partials: their address depends on `par` alone
   const F1Rec rec0 = f1_first_record(d);
   SlotState st = slot_read(R);
 #if defined(__HIP_DEVICE_COMPILE__)
-  // both records and the phases' base pointers are in registers HERE: requested together, one wait
-  asm volatile("" :: "s"(st.ph), "s"(rec0.ds.x), "s"(rec0.fc.w), "s"(d.part), "s"(d.scal), "s"(d.f1.va), "s"(d.x), "s"(d.ztg), "s"(d.v), "s"(d.uu), "s"(d.n));
+  // both records, the partials and the phases' base pointers are in registers HERE: requested together, one wait
+  asm volatile("" :: "s"(st.ph), "s"(rec0.ds.x), "s"(rec0.fc.w), "s"(d.part), "s"(d.scal), "s"(d.f1.va), "s"(d.x), "s"(d.ztg), "s"(d.v), "s"(d.uu), "s"(d.n),
+               "v"(fold.a.v[0]), "v"(fold.a.v[kPart - 1]), "v"(fold.b.v[0]), "v"(fold.b.v[kPart - 1]), "v"(fold.c.v[0]), "v"(fold.c.v[kPart - 1]));
 #endif
   if (st.ph == P_KB) {
     if (st.admm >= st.target) { st.ph = P_IDLE; slot_write(W, st); return; }
@@ -1391,11 +1404,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     const double G = block_sum(e.g, lds.kb.red);
     double RN = e.rn, BN = e.bn;
     block_max2(RN, BN, lds.kb.red);
-    put_partial(d.part, SL_GAMMA0, G); put_partial(d.part, SL_RN0, RN); put_partial(d.part, SL_BN, BN);
+    put_partial(d.part, SL_GAMMA0 + par, G); put_partial(d.part, SL_RN0 + par, RN); put_partial(d.part, SL_DELTA + par, BN);      // (||rhs|| travels in delta's slot: f1_fold_finish, k = 0)
+    put_partial(d.part, SL_BN, BN);                        // (... and stays on record for the KA of a PCG that ran into its cap)
     if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
     st.ph = P_F; st.k = 0;
   } else if (st.ph == P_F) {
-    if (f1_iteration(d, st.k, st.cap, st.admm & 1, 0, lds.f, rec0)) {
+    if (f1_iteration<D>(d, st.k, st.cap, st.admm & 1, 0, lds.f, rec0, fold, par)) {
       if (st.k >= st.cap) { st.ph = P_KA; st.used = st.k; st.conv = 0; }      // stopped at the cap: the next launch runs KA
       else st.k += 1;
     } else {                                             // converged: KA right here
@@ -1404,7 +1418,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
       st.ph = P_KB; st.admm += 1;
     }
   } else if (st.ph == P_KA) {
-    slot_ka(d, lds.ka, st.used, st.conv, first_desc<true>(d.A), st.admm, st.target);
+    slot_ka(d, lds.ka, st.used, st.conv, first_desc<true>(d.A), st.admm, st.target, par ^ 1);
     st.ph = P_KB; st.admm += 1;
   }
   slot_write(W, st);
@@ -2029,7 +2043,14 @@ void ka(Dev &d, int budget) { LAUNCH(k_ka, d, d, budget); }
 bool slots_supported(const Dev &d) { return d.fused != 0 && d.slot != nullptr; }
 void slot_begin(Dev &d, int target, int cap) { HIP_CHECK(hipSetDevice(d.device)); hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(1), 0, st(d), d.slot, target, cap, ++im(d).epoch); }
 void slot_pair(Dev &d) {
-  if (d.f1.on) { LAUNCH(k_slot1, d, d, 0); LAUNCH(k_slot1, d, d, 1); }
+  if (d.f1.on) {
+    switch (d.f1.D) {
+      case 1: LAUNCH(k_slot1<1>, d, d, 0); LAUNCH(k_slot1<1>, d, d, 1); break;
+      case 2: LAUNCH(k_slot1<2>, d, d, 0); LAUNCH(k_slot1<2>, d, d, 1); break;
+      case 3: LAUNCH(k_slot1<3>, d, d, 0); LAUNCH(k_slot1<3>, d, d, 1); break;
+      default: LAUNCH(k_slot1<4>, d, d, 0); LAUNCH(k_slot1<4>, d, d, 1); break;
+    }
+  }
   else { LAUNCH(k_slot_b, d, d); LAUNCH(k_slot_a, d, d); }
 }
 void f1_refresh(Dev &d) { if (d.f1.on) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_f1_refresh, d, d); } }
@@ -2370,6 +2391,23 @@ void test_spmv(Dev &d, int which, const double *in, double *out) {
 // Mean duration of one launch of a hot-path kernel, measured with a hipEvent pair on the solver's stream.
 // Kernels run in probe mode (no convergence logic; Kv with alpha = beta = 0) on the solver's live buffers; the
 // iterate state that KB/KA/Kv overwrite is saved and restored around the measurement.
+// probe 16: the phase records say "PCG iteration k0 of a chunk that never ends", the tolerance can never be met: the launches that follow
+// are the slot kernel's own F launches -- scalars from the fold, stopping test, record hand-over -- exactly as a solve runs them
+__global__ void k_slot_probe_f(int *slot, double *scal, int k0) {
+  for (int rec = 0; rec < 2; rec++) {
+    int *r = slot + rec * SR_WORDS;
+    r[SR_PHASE] = P_F; r[SR_K] = k0; r[SR_ADMM] = 0; r[SR_TARGET] = 1; r[SR_USED] = 0; r[SR_CONV] = 0; r[SR_CAP] = 1 << 20; r[SR_SEQ] = rec ? -1 : 0;
+  }
+  scal[S_TOL_NOW] = -1.0;
+}
+static void f1_probe_pair(Dev &d, int mode) {           // two consecutive F launches of the probe kernel (the double-buffered vectors alternate)
+  switch (d.f1.D) {
+    case 1: LAUNCH(k_f1_probe<1>, d, d, 2, mode); LAUNCH(k_f1_probe<1>, d, d, 3, mode); break;
+    case 2: LAUNCH(k_f1_probe<2>, d, d, 2, mode); LAUNCH(k_f1_probe<2>, d, d, 3, mode); break;
+    case 3: LAUNCH(k_f1_probe<3>, d, d, 2, mode); LAUNCH(k_f1_probe<3>, d, d, 3, mode); break;
+    default: LAUNCH(k_f1_probe<4>, d, d, 2, mode); LAUNCH(k_f1_probe<4>, d, d, 3, mode); break;
+  }
+}
 float time_kernel(Dev &d, int which, int reps) {
   HIP_CHECK(hipSetDevice(d.device));
   Impl &p = im(d);
@@ -2405,12 +2443,17 @@ float time_kernel(Dev &d, int which, int reps) {
       case 11: LAUNCH(k_k1f, d, d, 1); break;  // fused SpMV-A + vector update alone (alpha fixed by the stored history; drifts linearly, bounded)
       case 12: LAUNCH(k_k2f, d, d, 0); break;  // fused SpMV-B alone
       case 13: LAUNCH(k_k2f, d, d, 2); LAUNCH(k_k1f, d, d, 3); break;   // the same pair with the done flag set: what an early-exit pair costs
-      case 14: LAUNCH(k_f1_probe, d, d, 2, 1); LAUNCH(k_f1_probe, d, d, 3, 1); break;   // F1 form without the scalar fold at the head of the launch (two consecutive iterations)
-      case 15: LAUNCH(k_f1_probe, d, d, 2, 2); LAUNCH(k_f1_probe, d, d, 3, 2); break;   // F1 form: one PCG iteration = one launch; two consecutive iterations as a solve runs them (buffers alternate, fold included)
+      case 14: f1_probe_pair(d, 1); break;   // F1 form without the scalar fold at the head of the launch (two consecutive iterations)
+      case 16: slot_pair(d); break;           // two F launches of the slot kernel itself (records set up by k_slot_probe_f below): what a launch costs inside a solve
+      case 15: f1_probe_pair(d, 2); break;   // F1 form: one PCG iteration = one launch; two consecutive iterations as a solve runs them (buffers alternate, fold included)
       default: LAUNCH(k_k2f, d, d, 0); LAUNCH(k_k1f, d, d, 1); break;   // one FUSED PCG iteration (two kernels): repeated exact line-search steps, bounded
     }
   };
-  if (which >= 14 && !d.f1.on) return 0.f;
+  if (which >= 14 && which <= 16 && !d.f1.on) return 0.f;
+  if (which == 16) {
+    if (reps > 400) reps = 400;                 // (k advances by two per repetition; the alpha / gamma history holds kMaxCg entries)
+    hipLaunchKernelGGL(k_slot_probe_f, dim3(1), dim3(1), 0, st(d), d.slot, d.scal, 2);
+  }
   if (which >= 10) HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, which == 13 ? 1 : 0, sizeof(int), st(d)));   // (byte pattern 1 -> nonzero flag)
   for (int w = 0; w < 5; w++) launch();
   HIP_CHECK(hipEventRecord(p.ev0, st(d)));
