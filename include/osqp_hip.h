@@ -201,6 +201,10 @@ OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
    K2's time INSIDE the sequence, i.e. with the caches in the state a solve leaves them (a same-kernel repeat keeps the
    matrix L2-resident and flatters the kernel).  10 = one FUSED PCG iteration (k_k2f, k_k1f: the default form), 11 / 12 = each
    of the two alone, 13 = the pair with the converged flag set (eager-launch cost of an early-exit pair).
+   F1 form (one launch per PCG iteration; each of these times TWO consecutive launches, 0 when the form does not apply to the problem):
+   14 = the F-only probe kernel without the scalar fold at the head of the launch, 15 = with it (fixed alpha, beta, no stopping test),
+   16 = F launches of the slot kernel itself (phase record, scalars from the fold, a stopping test that never fires, record hand-over):
+   what a launch costs inside a solve.
    The kernels run in a side-effect-free "probe" mode or on saved-and-restored state; solver state is unchanged. */
 OSQPInt osqp_hip_time_kernel(OSQPSolver *solver, OSQPInt which, OSQPInt reps, double *mean_ms);
 
