@@ -108,3 +108,21 @@ def test_f1_form_is_not_taken_where_it_does_not_apply():
     _, r, s = _solve(P, q, A, l, u, True)
     assert int(s['pcg_fused']) == 1 and int(s['f1_replicas']) == 0
     assert r.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED
+
+
+@pytest.mark.parametrize('n,m,window,k,D', [(60000, 60000, 1, 1, 1), (40000, 80000, 20, 3, 2), (40000, 80000, 60, 5, 3), (50000, 100000, 100, 5, 4)])
+def test_every_replica_count_has_its_own_kernel_and_agrees_with_the_two_kernel_form(n, m, window, k, D, monkeypatch):
+    """The F1 kernels are templates on the replica count D (DevF1::D = how many row blocks apart two blocks must be for their column
+    windows not to overlap): one problem per value, each against the two-kernel form of the same engine (tools/f1_replica_sweep.py)."""
+    P, q, A, l, u = problems.banded_qp(n, m=m, window=window, nnz_per_row=k)
+    res = {}
+    for f1 in ('1', '0'):
+        monkeypatch.setenv('OSQP_HIP_F1', f1)
+        s = osqp_amd.OSQP(); s.setup(P, q, A, l, u, eps_abs=1e-6, eps_rel=1e-6, verbose=False, max_iter=20000)
+        r = s.solve(raise_error=True)
+        res[f1] = (r, s._solver.hip_stats())
+    (r1, s1), (r0, s0) = res['1'], res['0']
+    assert s1['f1_replicas'] == D and s1['pcg_fused'] == 2 and s0['f1_replicas'] == 0
+    assert abs(r1.info.iter - r0.info.iter) <= 0.1 * r0.info.iter + 25
+    assert np.abs(r1.x - r0.x).max() <= 2e-5 * (1 + np.abs(r0.x).max()) and np.abs(r1.y - r0.y).max() <= 1e-4 * (1 + np.abs(r0.y).max())
+    assert abs(r1.info.obj_val - r0.info.obj_val) <= 1e-6 * (1 + abs(r0.info.obj_val))
