@@ -95,13 +95,14 @@ def _cpu_baseline(P, q, A, l, u, settings, seconds_target, linsys):
     sample of iterations."""
     from oracle import Oracle, SOLVED
     t0 = time.time()
-    o = Oracle().setup(P, q, A, l, u, eps_abs=settings['eps_abs'], eps_rel=settings['eps_rel'], max_iter=20,
+    ncal = 20 if linsys == 0 else 2              # (the PCG fallback of a dense-block problem takes seconds per ADMM iteration on one core)
+    o = Oracle().setup(P, q, A, l, u, eps_abs=settings['eps_abs'], eps_rel=settings['eps_rel'], max_iter=ncal,
                        adaptive_rho_interval=settings['adaptive_rho_interval'], check_termination=settings['check_termination'],
                        linsys=linsys, **({'pcg_max_iter': 200, 'pcg_tol': 1e-7} if linsys else {}))
     t_setup = time.time() - t0
-    _, _, info = o.solve()                       # 20 iterations: calibrates the per-iteration cost
+    _, _, info = o.solve()                       # 20 (2) iterations: calibrates the per-iteration cost
     per_it = info.solve_time / max(info.iter, 1)
-    k = int(max(20, min(20000, seconds_target / max(per_it, 1e-9))))
+    k = int(max(ncal, min(20000, seconds_target / max(per_it, 1e-9))))
     o.update_settings(max_iter=k, warm_start=0)
     _, _, info = o.solve()
     done = info.status_val == SOLVED
