@@ -126,3 +126,37 @@ def test_every_replica_count_has_its_own_kernel_and_agrees_with_the_two_kernel_f
     assert abs(r1.info.iter - r0.info.iter) <= 0.1 * r0.info.iter + 25
     assert np.abs(r1.x - r0.x).max() <= 2e-5 * (1 + np.abs(r0.x).max()) and np.abs(r1.y - r0.y).max() <= 1e-4 * (1 + np.abs(r0.y).max())
     assert abs(r1.info.obj_val - r0.info.obj_val) <= 1e-6 * (1 + abs(r0.info.obj_val))
+
+
+def test_f1_form_follows_matrix_updates(monkeypatch):
+    """update(Px=, Ax=) on a handle that runs the F1 form: the packed copies the form keeps (P + sigma I in its own CSR) are refreshed with the
+    re-assembled matrices (re-scaled with the EXISTING scaling, as the reference does: _osqp.py:1443, :1463 -- so the iteration path is that
+    of an updated handle, not of a fresh one): same iterations as the two-kernel form after the same update, the solution of a fresh handle
+    on the new data."""
+    import scipy.sparse as sp
+    P, q, A, l, u = problems.banded_qp(20000, window=40)
+    rng = np.random.default_rng(7)
+    Pt = sp.triu(P, format='csc')
+    Px = Pt.data * (1 + 0.05 * rng.random(Pt.nnz))
+    Ax = A.data * (1 + 0.05 * rng.standard_normal(A.nnz))
+    kw = dict(eps_abs=1e-6, eps_rel=1e-6, verbose=False, max_iter=20000)
+    res = {}
+    for f1 in ('1', '0'):
+        monkeypatch.setenv('OSQP_HIP_F1', f1)
+        m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, **kw)
+        assert m._solver.hip_stats()['pcg_fused'] == (2 if f1 == '1' else 1)
+        r0 = m.solve(raise_error=True)
+        m.update(Px=Px, Ax=Ax)
+        m.update_settings(warm_starting=False, rho=0.1)
+        res[f1] = (r0, m.solve(raise_error=True))
+    monkeypatch.setenv('OSQP_HIP_F1', '1')
+    P2 = sp.csc_matrix((Px, Pt.indices, Pt.indptr), shape=P.shape)
+    A2 = sp.csc_matrix((Ax, A.indices, A.indptr), shape=A.shape)
+    f = osqp_amd.OSQP(); f.setup(P2, q, A2, l, u, **kw)
+    rf = f.solve(raise_error=True)
+    (r0, r1), (_, r1b) = res['1'], res['0']
+    assert abs(r1.info.iter - r1b.info.iter) <= 0.1 * r1b.info.iter + 25
+    for other in (r1b, rf):
+        assert _rel(r1.x, other.x) < 2e-5 and _rel(r1.y, other.y) < 1e-4
+        assert abs(r1.info.obj_val - other.info.obj_val) <= 1e-6 * (1 + abs(other.info.obj_val))
+    assert abs(r1.info.obj_val - r0.info.obj_val) > 1e-6 * (1 + abs(r0.info.obj_val))      # (the update did change the problem)
