@@ -24,6 +24,15 @@ print('dispatches %d, span %.2f ms, busy %.2f ms (%.1f %%), idle %.2f ms' % (len
 for lo_us, hi_us in ((0, 2), (2, 5), (5, 20), (20, 100), (100, 1000), (1000, 1e9)):
     sel = (gaps >= lo_us * 1e3) & (gaps < hi_us * 1e3)
     print('  gaps %6g - %6g us: %6d, total %.2f ms' % (lo_us, hi_us, sel.sum(), gaps[sel].sum() / 1e6))
+# the solves alone: maximal runs of dispatches without a gap above 200 us (what lies between them is the bench's own work: set-up of the next
+# step, the timing probes and their state copies), runs with fewer than 500 dispatches dropped
+cuts = np.where(gaps > 200e3)[0]
+bounds = np.concatenate([[0], cuts + 1, [len(st)]])
+runs = [(a, b) for a, b in zip(bounds[:-1], bounds[1:]) if b - a >= 500 and sum('k_slot' in nm for nm in names[a:b]) > 0.8 * (b - a)]
+if runs:
+    rb = sum((en[a:b] - st[a:b]).sum() for a, b in runs); rs = sum(en[a:b].max() - st[a] for a, b in runs)
+    print('  inside the %d solves (runs of >= 500 dispatches without a gap above 200 us): span %.2f ms, busy %.2f ms (%.1f %%), %d dispatches' % (
+        len(runs), rs / 1e6, rb / 1e6, 100.0 * rb / rs, sum(b - a for a, b in runs)))
 dur = en - st
 for key in ('k_slot_a', 'k_slot_b', 'k_slot1'):
     d = np.array([dur[i] for i, nm in enumerate(names) if key in nm])
