@@ -1113,6 +1113,15 @@ void Engine::exec_chunk_sync(int cnt, int lim, bool with_res, int kind, double *
 // stream (be::ctl_poll: no wait on the solve's stream) and keeps the queue a few slot pairs deep: most of what the chunk in flight
 // still needs at the rate observed so far; when little is left, the rest plus a boundary group plus the first part of the NEXT
 // chunk (by then the device has set it up itself).  Between polls the host sleeps.
+// A count of slot pairs that is ONE captured string (run_slots' unit sizes), at least `want` and at most `limit` -- or `want` itself when no
+// unit fits between the two.  Every replay boundary is a bubble (1-2 us; ~9 us under a profiler): where the chunk in flight will consume
+// the launches anyway, the next larger single string beats an exact count made of three.
+static int one_string(int want, int limit) {
+  static const int units[] = {2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
+  for (int u : units) if (u >= want) return u <= limit ? u : want;
+  return want;
+}
+
 int Engine::run_device_driven(double t0, double *res, int *flags) {
   Ctl &c = ctl_;
   c.status = CTL_RUNNING; c.chunk_done = 0; c.rho_flag = 0; c.stage2 = 0;
@@ -1142,7 +1151,8 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
   };
   // chunk in flight as of the last poll, and the progress counters at the first poll that saw it (rate estimate)
   { const int cnt = snap.ch_next - snap.iter;
-    const int np = std::max(2, (int)std::floor(pol_.poll_first * pairs_for(cnt, pred_for(snap, snap.ch_kind, snap.ch_tight))));
+    const double full = pairs_for(cnt, pred_for(snap, snap.ch_kind, snap.ch_tight));
+    const int np = one_string(std::max(2, (int)std::floor(pol_.poll_first * full)), (int)std::floor(0.95 * full));
     run_slots(0, np, 0); launched += np; }
   for (;;) {
     be::ctl_poll(d_, &snap, &seq, &done);
@@ -1159,7 +1169,7 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
     const double rate = done >= 2 ? std::min<double>(pairs_for(1, snap.budget[snap.ch_tight]), 0.5 * (double)std::max(0, seq - snap.seq_begin) / done) : 1.1 * pairs_for(1, pm);
     const int need = (int)std::ceil(rem * rate) + 2 - (int)ahead;
     if (need > kFinish) {                            // far from the chunk's end: most of what is missing
-      const int np = std::max(2, (int)std::ceil(pol_.poll_frac * need));
+      const int np = one_string(std::max(2, (int)std::ceil(pol_.poll_frac * need)), need - 2);      // (never beyond what the chunk still needs)
       run_slots(0, np, 0); launched += np;
       stats_.slot_topups += 1;
       cycle_done();
@@ -1173,7 +1183,8 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
       Ctl nx = snap; nx.iter = snap.ch_next; ctl_next_chunk(nx);
       const int ncnt = nx.ch_next - nx.iter;
       if (ncnt > 0) {
-        const int nq = std::max(2, (int)std::floor(pol_.poll_first * pairs_for(ncnt, pred_for(snap, nx.ch_kind, nx.ch_tight))));
+        const double full = pairs_for(ncnt, pred_for(snap, nx.ch_kind, nx.ch_tight));
+        const int nq = one_string(std::max(2, (int)std::floor(pol_.poll_first * full)), (int)std::floor(0.95 * full));
         run_slots(0, nq, 0); launched += nq;
       }
     }
