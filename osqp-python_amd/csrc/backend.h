@@ -293,7 +293,8 @@ bool wb_supported();
 bool wb_large_supported();                 // the dense solver libraries could be loaded                       // Woodbury preconditioner available (false: the host simulator)
 void wb_refresh(Dev &d);                   // wb.AL / ALT / WT values <- A.val (after assembly / equilibration / matrix updates)
 void wb_direct(Dev &d);                    // exact mode: x~ = x_g + M^-1 r_0 (after kb_rhs + wb_apply(0)); marks the solve as converged after one step
-void wb_apply(Dev &d, int parity);         // u = M^-1 r with the partials gamma = <r, u>, ||r||_inf in the slots of `parity` (after kb_rhs: 0, after kv(i): (i + 1) & 1)
+void wb_apply(Dev &d, int parity, int direct = 0);   // direct: exact mode -- the last of the three kernels also forms x~ = x_g + u and marks the solve as converged after one step
+//         // u = M^-1 r with the partials gamma = <r, u>, ||r||_inf in the slots of `parity` (after kb_rhs: 0, after kv(i): (i + 1) & 1)
 // ---- device-driven chunk boundaries (policy.h; backend_hip.hip "boundary kernels").  The host uploads the state block once per solve,
 // then only feeds launches: strings of slot launches and, after each chunk's worth, one boundary group -- conditional residual
 // kernels, k_decide (the rules of policy.h on the device: termination, rho, tolerance, budget, next chunk), conditional rho update.

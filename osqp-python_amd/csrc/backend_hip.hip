@@ -1835,11 +1835,13 @@ __global__ __launch_bounds__(kWbMaxRows) void k_wb_p2(Dev d) {             // h 
   w.h[a] = acc;
 }
 struct EWb3 {
-  const double *Dinv0, *r; double *uu; double g = 0, rn = 0, pr = 0, pd = 0;
-  __device__ __forceinline__ void prefetch(int j) { pr = r[j]; pd = Dinv0[j]; }
+  const double *Dinv0, *r; double *uu; double *xs;       // xs != nullptr: the direct mode -- u = K^-1 r_0 is added to x~ right here
+  double g = 0, rn = 0, pr = 0, pd = 0, px = 0;
+  __device__ __forceinline__ void prefetch(int j) { pr = r[j]; pd = Dinv0[j]; if (xs) px = xs[j]; }
   __device__ __forceinline__ void operator()(int j, const double (&s)[1]) {
     const double u = pd * (pr - s[0]);
     uu[j] = u; g += pr * u; rn = nanmax(rn, fabs(pr));
+    if (xs) xs[j] = px + u;
   }
 };
 __global__ __launch_bounds__(kBlock) void k_wb_direct(Dev d) {             // exact mode: x~ += u (u = K^-1 r_0); the PCG statistics see one iteration
@@ -1847,16 +1849,19 @@ __global__ __launch_bounds__(kBlock) void k_wb_direct(Dev d) {             // ex
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) d.xs[j] += d.uu[j];
   if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = 1; }
 }
-__global__ __launch_bounds__(kBlock) void k_wb_p3(Dev d, int parity) {     // u = D0^-1 (r - A_L' h); partials gamma = <r, u>, ||r||_inf
+// direct != 0 (exact mode, M = K): x~ = x_g + u in the same pass, and the PCG statistics see one iteration -- the flag is written by workgroup 0
+// at its END and not read by this launch (a workgroup that starts late must not take it for the previous solve's)
+__global__ __launch_bounds__(kBlock) void k_wb_p3(Dev d, int parity, int direct) {     // u = D0^-1 (r - A_L' h); partials gamma = <r, u>, ||r||_inf
   __shared__ StreamLds<1> lds;
-  if (d.flags[F_DONE]) return;
+  if (!direct && d.flags[F_DONE]) return;
   GVec g{d.wb.h};
-  EWb3 e{d.wb.Dinv0, d.r, d.uu};
+  EWb3 e{d.wb.Dinv0, d.r, d.uu, direct ? d.xs : nullptr};
   process_rows<1>(d.wb.ALT, g, e, lds);
   __syncthreads();
   double G = e.g, RN = e.rn;
   block_sum_max(G, RN, lds.red);
   put_partial(d.part, SL_GAMMA0 + parity, G); put_partial(d.part, SL_RN0 + parity, RN);
+  if (direct && blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = 1; }
 }
 
 // ---- many long rows (DevWb::large): dense S on the device
@@ -2169,11 +2174,11 @@ void wb_refresh(Dev &d) {
   if (d.wb.large) LAUNCH(k_wb_gather_large, d, d); else LAUNCH(k_wb_gather, d, d);
 }
 void wb_direct(Dev &d) { LAUNCH(k_wb_direct, d, d); }
-void wb_apply(Dev &d, int parity) {
+void wb_apply(Dev &d, int parity, int direct) {
   LAUNCH(k_wb_p1, d, d);
   if (d.wb.large) hipLaunchKernelGGL(k_wb_gemv, dim3(std::min(d.wb.r, 8 * kGrid)), dim3(kBlock), 0, st(d), d.wb.Sinv, d.wb.g, d.wb.h, d.wb.r, d.flags + F_DONE);
   else hipLaunchKernelGGL(k_wb_p2, dim3(1), dim3(kWbMaxRows), 0, st(d), d);
-  LAUNCH(k_wb_p3, d, d, parity);
+  LAUNCH(k_wb_p3, d, d, parity, direct);
 }
 
 bool wb_large_supported() { return dense_libs().ok; }

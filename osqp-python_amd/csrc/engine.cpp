@@ -814,13 +814,13 @@ void Engine::run_chunk(int niter, int budget) {
   auto enqueue = [&](int count) {
     for (int it = 0; it < count; it++) {
       be::kb_rhs(d_);
-      if (wb) be::wb_apply(d_, 0);
-      if (wb && d_.wb.exact) { be::wb_direct(d_); be::ka(d_, budget); continue; }      // M^-1 r_0 is the solve
+      if (wb) be::wb_apply(d_, 0, d_.wb.exact);
+      if (wb && d_.wb.exact) { be::ka(d_, budget); continue; }      // M^-1 r_0 is the solve (x~ formed by the last kernel of M^-1)
       for (int i = 0; i < budget; i++) { be::k1(d_, i); be::k2(d_, i); if (!fused || i == budget - 1) { be::kv(d_, i); if (wb) be::wb_apply(d_, (i + 1) & 1); } }
       be::ka(d_, budget);
     }
   };
-  stats_.kernel_launches += (double)niter * ((wb && d_.wb.exact) ? 6 : (fused ? 3 + 2 * budget : 2 + 3 * budget + (wb ? 3 * (budget + 1) : 0)));
+  stats_.kernel_launches += (double)niter * ((wb && d_.wb.exact) ? 5 : (fused ? 3 + 2 * budget : 2 + 3 * budget + (wb ? 3 * (budget + 1) : 0)));
   if (!(use_graph_ && be::graphs_supported())) { enqueue(niter); return; }
   // one executable graph per (ADMM iterations, PCG budget); graphs are kept below kMaxGraphNodes kernel nodes (a
   // check_termination = 0 solve would otherwise capture max_iter * (2 + 3*budget) nodes in one graph)
@@ -828,7 +828,7 @@ void Engine::run_chunk(int niter, int budget) {
   const int per = std::max(1, kMaxGraphNodes / (2 + 3 * budget + (wb ? 3 * (budget + 1) : 0)));
   for (int left = niter; left > 0;) {
     const int cnt = std::min(left, per);
-    auto key = std::make_pair(cnt, budget);
+    auto key = std::make_pair(cnt, budget | ((wb && d_.wb.exact) ? (1 << 24) : 0));      // (the direct mode is another launch sequence: it may come and go with rho in the large-rank form)
     auto it = graphs_.find(key);
     if (it == graphs_.end()) {
       be::graph_begin(d_);

@@ -50,7 +50,7 @@ void f1_refresh(Dev &) {}
 bool wb_supported() { return false; }
 bool wb_large_supported() { return false; }
 void wb_refresh(Dev &) {}
-void wb_apply(Dev &, int) {}
+void wb_apply(Dev &, int, int) {}
 void wb_direct(Dev &) {}
 bool ctl_supported(const Dev &) { return false; }
 void ctl_upload(Dev &, const Ctl &) {}
