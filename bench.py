@@ -55,8 +55,10 @@ def pmc_traffic(kernel, workload):
         files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_%s_%s.csv' % (workload, ctr))))
         if not files:
             return None
+        # (templated kernels appear with their arguments -- k_f1_probe<4> --, some rocprofv3 builds add the parameter list: match the bare name)
         for row in csv.DictReader(open(files[-1])):
-            if row['kernel'] == kernel and row['counter'] == ctr:
+            bare = row['kernel'].split('(')[0].split('<')[0].split(' ')[-1].split('::')[-1]
+            if bare == kernel and row['counter'] == ctr and float(row['active_dispatches']) > 0:
                 vals[ctr] = float(row['mean_active'])
     if len(vals) != 2:
         return None

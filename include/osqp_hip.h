@@ -226,7 +226,8 @@ OSQPInt osqp_hip_batch_solve(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat
 /* The same solve with EVERY array in device memory of this solver's device (e.g. torch ROCm tensors through data_ptr(); SURVEY 8f
  * rank 2: no PCIe round trip).  Asynchronous: the kernel is enqueued on `stream` (a hipStream_t; inputs must be ready on it and
  * the outputs are valid once it has drained -- the solver handle must not be used again before that); stream == NULL uses the
- * solver's own stream and waits for it.  l <= u is NOT validated on this path. */
+ * solver's own stream and waits for it.  l <= u is NOT validated on this path.  nbatch == 0 launches nothing and only answers whether the
+ * problem fits the batch kernel (OSQP_NO_ERROR / OSQP_FUNC_NOT_IMPLEMENTED): ranks with an empty share of a sharded batch ask this way. */
 OSQPInt osqp_hip_batch_solve_device(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat *q_dev, const OSQPFloat *l_dev, const OSQPFloat *u_dev,
                                     OSQPFloat *x_dev, OSQPFloat *y_dev, OSQPFloat *rec_dev, OSQPInt warm_start, void *stream);
 

@@ -49,17 +49,19 @@ std::vector<int> build_row_blocks_target(const std::vector<int> &rowptr, int nro
 }
 // Every kernel runs kGrid workgroups, so the number of row blocks is made a whole multiple k of kGrid with equal
 // nnz per block (a 1172-block matrix on a 1024-workgroup grid would otherwise cost two full rounds).
-std::vector<int> build_row_blocks(const std::vector<int> &rowptr, int nrows) {
+// cap: most entries of a block (kChunk for the CSR-stream kernels; kF1Chunk when the one-launch PCG form is wanted: a workgroup then
+// takes several blocks per launch on large problems)
+std::vector<int> build_row_blocks(const std::vector<int> &rowptr, int nrows, int cap = kChunk) {
   const long nnz = nrows > 0 ? rowptr[nrows] : 0;
-  long k = std::max<long>(1, (nnz + (long)kGrid * kChunk - 1) / ((long)kGrid * kChunk));
+  long k = std::max<long>(1, (nnz + (long)kGrid * cap - 1) / ((long)kGrid * cap));
   for (;; k++) {
     int target = (int)std::max<long>(128, (nnz + kGrid * k - 1) / (kGrid * k));
-    for (int attempt = 0; attempt < 40 && target <= kChunk; attempt++) {
+    for (int attempt = 0; attempt < 40 && target <= cap; attempt++) {
       std::vector<int> rb = build_row_blocks_target(rowptr, nrows, target);
       if ((long)rb.size() - 1 <= kGrid * k) return rb;
-      target = std::min<int>(kChunk + 1, target + std::max(1, target / 50));
+      target = std::min<int>(cap + 1, target + std::max(1, target / 50));
     }
-    if (k > 1024) return build_row_blocks_target(rowptr, nrows, kChunk);   // pathological (e.g. all rows long): accept
+    if (k > 1024) return build_row_blocks_target(rowptr, nrows, cap);   // pathological (e.g. all rows long): accept
   }
 }
 // block descriptors {first row, end row, first nnz, end nnz}; long rows also get their run table (see DevCsr::runinfo).  Slices are the
@@ -169,6 +171,13 @@ void Engine::drop_graphs() {
   graphs_.clear();
   for (auto &kv : sgraphs_) be::graph_free(d_, kv.second);
   sgraphs_.clear();
+}
+
+void Engine::sync_graph_scalars() {
+  const double sig[6] = {d_.theta, d_.alpha, d_.sigma, d_.rho_eq_factor, d_.rho_eq_mixed, (double)d_.eq_from_cnt};
+  if (std::memcmp(sig, graph_sig_, sizeof(sig)) == 0) return;
+  if (!graphs_.empty() || !sgraphs_.empty()) { be::sync(d_); drop_graphs(); }
+  std::memcpy(graph_sig_, sig, sizeof(sig));
 }
 
 void Engine::free_all() {
@@ -633,6 +642,21 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   lap("CSR(A), B structure, maps");
   std::vector<int> rbA = build_row_blocks(Arp, m), rbB = build_row_blocks(Brp, n);
   lap("row blocks");
+  d_.fused = pol_.pcg_fused ? 1 : 0;                 // 0 selects the 3-kernel sequence
+  prepare_wb(Arp, Arj);
+  if (d_.wb.on) d_.fused = 0;                        // (the Woodbury-corrected preconditioner lives in the three-kernel PCG form)
+  // One launch per PCG iteration (F1 form): wants row blocks of A of at most kF1Chunk entries -- on large problems (n = 1M: the default
+  // blocks hold ~2000 entries) A is re-blocked for it, a workgroup then loops over several blocks per launch; when the plan does not
+  // apply the default blocks stay
+  if (d_.fused && use_slots_ && pol_.window != 0) {
+    prepare_f1(rbA, Arp, Arj, Brp, Bj);
+    if (!d_.f1.on && (long)nzA > (long)kGrid * kF1Chunk) {
+      std::vector<int> rbF = build_row_blocks(Arp, m, kF1Chunk);
+      prepare_f1(rbF, Arp, Arj, Brp, Bj);
+      if (d_.f1.on) rbA.swap(rbF);
+    }
+  }
+  lap("F1 / Woodbury plans");
   // block descriptors; long rows also get their run table (see DevCsr::runinfo).  Slices are the fixed kChunk steps the kernels
   // take from the row's first entry (cutting them at run starts instead adds short slices that cost more than the saved
   // index bytes: lasso PCG pair 208 us vs 220 us)
@@ -703,11 +727,6 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   d_.Bdiag = up_i(bdiag);
   up_win(d_.A, rbA, Arp, Arj, n); up_win(d_.B, rbB, Brp, Bj, n);
   lap("upload structure");
-  d_.fused = pol_.pcg_fused ? 1 : 0;                 // 0 selects the 3-kernel sequence
-  prepare_wb(Arp, Arj);
-  if (d_.wb.on) d_.fused = 0;                        // (the Woodbury-corrected preconditioner lives in the three-kernel PCG form)
-  if (d_.fused && use_slots_ && d_.A.nwin == d_.A.nblk) prepare_f1(rbA, Arp, Arj, Brp, Bj);
-  lap("F1 / Woodbury plans");
   auto dv = [&](size_t cnt) { return dev_vec<double>(d_, cnt); };
   d_.q = dv(n); d_.l = dv(m); d_.u = dv(m); d_.D = dv(n); d_.Dinv = dv(n); d_.E = dv(m); d_.Einv = dv(m);
   d_.rho = dv(m); d_.rho_inv = dv(m); d_.ctype = dev_vec<int>(d_, m);
@@ -1007,7 +1026,16 @@ void Engine::ctl_setup() {
 void Engine::apply_rho(double rho) {
   rho_bar_ = rho; settings.rho = rho;
   be::set_rho(d_, rho_bar_);
-  be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  try { be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER); }
+  catch (const DeviceError &err) {
+    // a re-factorisation of the Woodbury correction failed in the middle of a solve (dense-library call, or S not positive definite at
+    // this rho): the handle continues with plain Jacobi, as setup does -- said loudly, visible in OSQPHipStats::woodbury_rows = 0
+    if (!d_.wb.on) throw;
+    std::fprintf(stderr, "osqp_hip: Woodbury correction switched off for this handle at rho = %.3e (%s)\n", rho, err.what());
+    d_.wb.on = 0; d_.wb.exact = 0;
+    be::sync(d_); drop_graphs();
+    be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  }
 }
 
 // info fields of the last check from the state block (+ the time integral of |gap|, accumulated where the host sees a check)
@@ -1219,6 +1247,7 @@ void Engine::run_group(int diagonal) {
 void Engine::admm_core(double t0, double *res) {
   Ctl &c = ctl_;
   ctl_setup();
+  sync_graph_scalars();
   be::zero(d_, d_.flags + F_STAT_SUM, sizeof(int) * (F_COUNT - F_STAT_SUM));      // (a device-driven solve leaves its last chunk's statistics behind)
   {
     double r0[R_COUNT];
@@ -1979,7 +2008,10 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
 // enqueued on the caller's stream and not waited for (stream == nullptr: the solver's stream, synchronous).
 int Engine::batch_solve_device(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, void *stream) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
-  if (nbatch <= 0 || !x || !y || !rec) return OSQP_DATA_VALIDATION_ERROR;
+  // nbatch == 0: the applicability query of a rank whose share of a sharded batch is empty -- the answer depends on (n, m) alone, so every
+  // rank of a job reaches the same decision before its first collective (osqp_amd/sharded.py)
+  if (nbatch == 0) return be::batch_lds_bytes(n, m) ? OSQP_NO_ERROR : OSQP_FUNC_NOT_IMPLEMENTED;
+  if (nbatch < 0 || !x || !y || !rec) return OSQP_DATA_VALIDATION_ERROR;
   if (!be::batch_lds_bytes(n, m)) return OSQP_FUNC_NOT_IMPLEMENTED;
   be::activate(d_);
   be::ext_wait(d_);                                 // the previous device-pointer call: its kernel reads the shared vectors and kp_val

@@ -144,6 +144,11 @@ class Engine {
   void polish();
   void apply_scaled_bounds(const std::vector<double> &ls, const std::vector<double> &us);
   void drop_graphs();
+  // Captured launches take Dev BY VALUE: its scalar fields (theta, alpha, sigma, the equality-weight rule k_set_rho reads) are frozen into
+  // every graph.  sync_graph_scalars() compares them with what the graphs were captured with and drops the graphs when they differ; called
+  // wherever launches may be replayed (admm_core, ls_solve).
+  double graph_sig_[6] = {0, 0, 0, 0, 0, 0};
+  void sync_graph_scalars();
   int check_termination(const double *res, bool approximate);
   void update_gap_info(const double *res, double t0);
   double gap_time_ = 0;

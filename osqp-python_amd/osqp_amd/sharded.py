@@ -113,10 +113,11 @@ def solve_batch_sharded_device(solver, q=None, l=None, u=None, rank=0, world=1):
     x = torch.empty((nb, solver.n), dtype=torch.float64, device=dev)
     y = torch.empty((nb, solver.m), dtype=torch.float64, device=dev)
     rec = torch.zeros((max(nb, 1), 12), dtype=torch.float64, device=dev)        # OSQP_HIP_BATCH_REC
-    if nb > 0:
-        ptr = lambda t: None if t is None else t.data_ptr()
-        solver._solver.hip_batch_solve_device(nb, ptr(ql), ptr(ll), ptr(ul), x.data_ptr(), y.data_ptr(), rec.data_ptr(), warm=False,
-                                              stream=torch.cuda.current_stream(dev).cuda_stream)
+    # (a rank with an EMPTY share calls too -- nbatch = 0 launches nothing and raises exactly when a non-empty share would: every rank takes
+    #  the same branch before the job's first collective)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    solver._solver.hip_batch_solve_device(nb, ptr(ql), ptr(ll), ptr(ul), x.data_ptr(), y.data_ptr(), rec.data_ptr(), warm=False,
+                                          stream=torch.cuda.current_stream(dev).cuda_stream)
     recs = torch.zeros((nb, len(RECORD_FIELDS)), dtype=torch.float64, device=dev)
     recs[:, 0] = torch.arange(lo, hi, dtype=torch.float64, device=dev)
     recs[:, 1:6] = rec[:nb, 0:5]                     # status_val, iter, obj_val, prim_res, dual_res
