@@ -95,7 +95,9 @@ def _cpu_baseline(P, q, A, l, u, settings, seconds_target, linsys):
     """Oracle (direct LDL', AMD ordering, 1 thread) on the same QP, cold-started, for at most ~seconds_target of ADMM
     iterations: run to convergence when that fits (then its iteration count and time-to-solution are reported), else a bounded
     sample of iterations."""
+    import oracle
     from oracle import Oracle, SOLVED
+    oracle.use_native()                          # -O3 -march=native, compiled on THIS host (BASELINE.md section 3); this is the timing child process
     t0 = time.time()
     ncal = 20 if linsys == 0 else 2              # (the PCG fallback of a dense-block problem takes seconds per ADMM iteration on one core)
     o = Oracle().setup(P, q, A, l, u, eps_abs=settings['eps_abs'], eps_rel=settings['eps_rel'], max_iter=ncal,
@@ -108,7 +110,7 @@ def _cpu_baseline(P, q, A, l, u, settings, seconds_target, linsys):
     o.update_settings(max_iter=k, warm_start=0)
     _, _, info = o.solve()
     done = info.status_val == SOLVED
-    out = {'value': info.iter / info.solve_time, 'unit': 'ADMM iter/s', 'cores': 1, 'kind': 'port',
+    out = {'value': info.iter / info.solve_time, 'unit': 'ADMM iter/s', 'cores': 1, 'kind': 'port', 'build': 'gcc -O3 -march=native -fno-fast-math, compiled on this host',
            'sample': '%d cold-started ADMM iterations of the same QP in %.1f s (%s); %s; setup %.1f s not included'
                      % (info.iter, info.solve_time, 'run to convergence' if done else 'bounded sample, not converged',
                         ('direct LDL\' KKT solve, own AMD ordering, nnz(L)=%.3g' % info.lnz) if linsys == 0 else
@@ -136,6 +138,9 @@ def main():
     ap.add_argument('--probe-reps', type=int, default=200)
     ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL, the production path) or 'gloo' (code-path test)")
     ap.add_argument('--single-device', action='store_true', help='test mode: every rank uses GPU 0 (one-GPU boxes)')
+    ap.add_argument('--batch', type=int, default=4096, help='BASELINE configs[4]: MPC QPs solved through the sharded batch path and reported as config.batch (0 disables)')
+    ap.add_argument('--batch-steps', type=int, default=5)
+    ap.add_argument('--batch-cpu', type=int, default=1, help='time the all-cores CPU baseline of the batch too (N = 1 only)')
     args = ap.parse_args()
     warnings.simplefilter('ignore')
 
@@ -223,6 +228,14 @@ def main():
     else:
         allrec = rec.cpu().numpy()[None, :]
     tmax = float(allrec[:, 5].max()); total_iters = float(allrec[:, 6].sum())
+
+    # BASELINE configs[4] through the sharded batch path -- the workload north_star really shards (one contiguous block of problems per GPU,
+    # one all_gather of the records) -- on every rank, at any N: `value` stays the replica metric, the batch travels as config.batch so that
+    # a scaling run of this script shows its strong-scaling curve (reference analogue: /root/reference/src/osqp/nn/torch.py:200-224)
+    batch_out = None
+    if args.batch > 0 and args.config == 'banded' and args.dist_backend == 'nccl':
+        import bench_batch
+        batch_out = bench_batch.measure_sharded_device(args.batch, args.batch_steps, 1, rank, world, local, use_dist)
 
     if rank == 0:
         nnzA, nnzB, mm = int(stats['nnzA']), int(stats['nnzB']), len(l)
@@ -331,6 +344,14 @@ def main():
             out['roofline']['streamed_bytes'] = streamed
             out['roofline']['frac_streamed'] = streamed / (pcg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             out['roofline']['replicas'] = f1_D
+        if batch_out is not None:
+            bdata = batch_out.pop('_data')
+            out['config']['batch'] = batch_out
+            if args.batch_cpu and args.cpu_seconds > 0 and world == 1:
+                import bench_batch
+                cb = bench_batch.cpu_batch_baseline(*bdata)
+                batch_out['cpu_baseline'] = cb
+                batch_out['gpu_over_cpu_all_cores'] = batch_out['QP_per_s'] / cb['value']
         if args.cpu_seconds > 0 and world == 1:          # (the CPU baseline is timed at N = 1 only: the other ranks would wait 40 s at the barrier)
             cb = cpu_baseline(P, q, A, l, u, settings, args.cpu_seconds)
             out['cpu_baseline'] = cb

@@ -20,8 +20,9 @@ _CPU = {}
 
 
 def _cpu_init(P, q, A, L, U):
-    from oracle import Oracle, lib
-    lib()                                              # load the library in the worker before the clock starts
+    import oracle
+    oracle.use_native()                                # -O3 -march=native, compiled on this host
+    oracle.lib()                                       # load the library in the worker before the clock starts
     _CPU['data'] = (P, q, A, L, U)
 
 
@@ -36,10 +37,78 @@ def _cpu_solve(span):
     return its, _t.perf_counter() - t0
 
 
+def cpu_batch_baseline(P, q, A, L, U, cores=None):
+    """The oracle over ALL host cores (SURVEY 8(d) / BASELINE.md section 3: 'an OpenMP-over-problems mode using all host cores'): the batch split
+    into one contiguous share per worker process, setup + solve per problem like the reference's per-element solver objects
+    (/root/reference/src/osqp/nn/torch.py:200-217).  Workers load the -march=native build made on this host."""
+    import multiprocessing as mp
+    B = len(L)
+    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))              # the cores this process may actually use
+    except (AttributeError, OSError):
+        pass
+    cores = max(1, min(int(cores or ncpu), B))
+    spans = [((B * w) // cores, (B * (w + 1)) // cores) for w in range(cores)]
+    import oracle
+    oracle.build_native()                                # compile once, in the parent
+    with mp.get_context('spawn').Pool(cores, initializer=_cpu_init, initargs=(P, q, A, L, U)) as pool:      # (spawn: the parent holds a HIP context)
+        pool.map(_cpu_solve, [(0, 1)] * cores)                                            # every worker has started and loaded the library
+        t0 = time.perf_counter()
+        parts = pool.map(_cpu_solve, spans, chunksize=1)
+        dt = time.perf_counter() - t0
+    its = sum(p[0] for p in parts); busy = max(p[1] for p in parts)
+    return {'value': B / dt, 'unit': 'QP/s', 'cores': cores, 'kind': 'port', 'build': 'gcc -O3 -march=native -fno-fast-math, compiled on this host',
+            'sample': 'all %d QPs split over %d worker processes (every core this process may use; os.cpu_count() = %d), oracle direct LDL\' (setup+solve per problem), '
+                      '%d ADMM iterations in %.2f s wall (slowest worker busy %.2f s)' % (B, cores, os.cpu_count() or 1, its, dt, busy)}
+
+
+def measure_sharded_device(B, steps, warmup, rank, world, local, use_dist):
+    """BASELINE configs[4] through the path a multi-GPU job runs (osqp_amd.sharded.solve_batch_sharded_device: this rank's contiguous
+    share in one batched launch by device pointer, then the job's ONE collective -- an all_gather of the 7-field records over RCCL -- INSIDE
+    the timed region).  Called by bench.py on every rank (any --gpus N, N = 1 included) so that the driver's scaling run carries the batch's
+    strong-scaling curve next to the replica metric.  Returns the dict bench.py prints as config.batch (rank 0) -- all ranks must call."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import osqp_amd
+    import problems
+    from osqp_amd import sharded
+    dev = torch.device('cuda', local)
+    P, q, A, L, U = problems.mpc_batch(B)
+    s = osqp_amd.OSQP(algebra='hip')
+    s.setup(P, q, A, L[0], U[0], eps_abs=1e-6, eps_rel=1e-6, verbose=False, max_iter=4000, device=local)
+    Ld, Ud = torch.tensor(L, device=dev), torch.tensor(U, device=dev)        # the whole batch resident on every rank; a rank solves its row block
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+    table = None
+    for _ in range(max(warmup, 1)):
+        table, x, y, span = sharded.solve_batch_sharded_device(s, l=Ld, u=Ud, rank=rank, world=world)
+    barrier(); t0 = time.perf_counter()
+    for _ in range(steps):
+        table, x, y, span = sharded.solve_batch_sharded_device(s, l=Ld, u=Ud, rank=rank, world=world)
+        ncheck = int((table[:, 1] == 1).sum().item())                            # (the host reads the gathered table: synchronises the step)
+    barrier(); el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = float(el.item())
+    tab = table.cpu().numpy()
+    owners = {int(i * world // B) for i in tab[:, 0].astype(int)} if world > 1 else {0}       # ranks whose records arrived (problem i lives on rank i * world // B)
+    return {'workload': 'BASELINE configs[4]: %d MPC QPs (n=120, m=240, problems.mpc_batch), eps 1e-6, contiguous blocks over %d rank(s), one batched launch per rank, '
+                        'one all_gather of the 7-field records (inside the timed region); bounds resident in HBM, x / y left in HBM' % (B, world),
+            'QP_per_s': B * steps / el, 'ms_per_batch': 1e3 * el / steps, 'steps': steps, 'solved': int((tab[:, 1] == 1).sum()), 'records': int(tab.shape[0]),
+            'n_ranks_seen': len(owners), 'scaling': 'strong', 'admm_iters_total': float(tab[:, 2].sum()),
+            'collective': 'all_gather (%s)' % ('RCCL' if use_dist else 'single process: none needed'), '_data': (P, q, A, L, U)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1); ap.add_argument('--steps', type=int, default=5); ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=4096); ap.add_argument('--cpu-sample', type=int, default=48)
+    ap.add_argument('--cpu-cores', type=int, default=0, help='worker processes of the CPU baseline (0 = every core this process may use)')
     args = ap.parse_args()
     warnings.simplefilter('ignore')
     import numpy as np
@@ -135,19 +204,8 @@ def main():
                                     'measured %.2f us (%.1f ADMM iterations per QP, %d QPs resident at a time, kernel %.2f ms)'
                                     % (2 * n_var, kChainCycles, 1e6 * floor_iter, 1e6 * t_iter, iters_per_qp, resident, 1e3 * kernel_s)}
         if args.cpu_sample > 0 and world == 1:
-            import multiprocessing as mp
-            cores = min(os.cpu_count() or 1, 64)       # worker processes (one contiguous share of the batch each)
-            sample = B
-            spans = [((sample * w) // cores, (sample * (w + 1)) // cores) for w in range(cores)]
-            with mp.get_context('spawn').Pool(cores, initializer=_cpu_init, initargs=(P, q, A, L, U)) as pool:      # (spawn: the parent holds a HIP context)
-                pool.map(_cpu_solve, [(0, 1)] * cores)                                            # every worker has started and loaded the library
-                t0 = time.perf_counter()
-                parts = pool.map(_cpu_solve, spans, chunksize=1)
-                dt = time.perf_counter() - t0
-            its = sum(p[0] for p in parts); busy = max(p[1] for p in parts)
-            out['cpu_baseline'] = {'value': sample / dt, 'unit': 'QP/s', 'cores': cores, 'kind': 'port',
-                                   'sample': 'all %d QPs split over %d worker processes (host has %d cores), oracle direct LDL\' (setup+solve per problem), '
-                                             '%d ADMM iterations in %.2f s wall (slowest worker busy %.2f s)' % (sample, cores, os.cpu_count() or 1, its, dt, busy)}
+            out['cpu_baseline'] = cpu_batch_baseline(P, q, A, L, U, cores=args.cpu_cores or None)
+            out['config']['gpu_over_cpu_all_cores'] = out['value'] / out['cpu_baseline']['value']
         print(json.dumps(out))
     if use_dist:
         dist.barrier(); dist.destroy_process_group()

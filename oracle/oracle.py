@@ -39,13 +39,39 @@ def build(force=False):
     return _LIB
 
 
+def build_native():
+    """The same source compiled `-O3 -march=native` FOR THE HOST IT RUNS ON (the CPU baseline's flags) -- used only by
+    the cpu_baseline legs of bench.py / bench_batch.py, which call use_native() in their timing processes.  The file name carries a hash
+    of this host's CPU flags: a build that travelled from another machine is never loaded (its instructions may not exist here)."""
+    import hashlib
+    try:
+        with open('/proc/cpuinfo') as f:
+            flags = next((ln for ln in f if ln.startswith('flags')), '')
+    except OSError:
+        flags = ''
+    out = os.path.join(_HERE, '_build', 'liboracle_native_%s.so' % hashlib.sha1(flags.encode()).hexdigest()[:10])
+    src = os.path.join(_HERE, 'osqp_oracle.c')
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call([os.environ.get('CC', 'gcc'), '-O3', '-march=native', '-fno-fast-math', '-shared', '-fPIC', '-o', out, src, '-lm'])
+    return out
+
+
 _lib = None
+_native = False
+
+
+def use_native(on=True):
+    """Route this PROCESS's oracle calls to the -march=native build (call before the first Oracle())."""
+    global _native, _lib
+    if bool(on) != _native:
+        _native, _lib = bool(on), None
 
 
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        _lib = C.CDLL(build_native() if _native else build())
         _lib.oracle_setup.restype = C.c_void_p
         _lib.oracle_solve.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.POINTER(Info)]
         for f in ('oracle_update_lin_cost', 'oracle_update_bounds', 'oracle_update_matrices', 'oracle_warm_start',

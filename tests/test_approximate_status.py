@@ -60,7 +60,7 @@ def oracle_window(name):
         prob, stg, inacc, exact = CASES[name]()
         win = []
         for K in range(1, 600):
-            _, _, info = Oracle().setup(*prob, max_iter=K, check_termination=1, adaptive_rho_interval=50, **stg).solve()
+            _, _, info = Oracle().setup(*prob, max_iter=K, check_termination=1, adaptive_rho=0, **stg).solve()
             if info.status_val == inacc:
                 win.append(K)
             elif info.status_val == exact:
@@ -85,7 +85,7 @@ def test_inaccurate_status_at_max_iter(backend, name):
     K = (win[0] + win[-1]) // 2
     with engine(backend):
         m = osqp_amd.OSQP(algebra='hip')
-        m.setup(*prob, max_iter=K, check_termination=1, adaptive_rho_interval=50, verbose=False, cg_max_iter=200, cg_tol_fraction=0.01, **stg)
+        m.setup(*prob, max_iter=K, check_termination=1, adaptive_rho=False, verbose=False, cg_max_iter=200, cg_tol_fraction=0.01, **stg)
         r = m.solve()
         assert r.info.status_val == inacc, (name, backend, K, win[0], win[-1], r.info.status, r.info.iter)   # (the enums agree: bindings.cpp.in:349-361)
         assert r.info.iter == K
@@ -112,7 +112,7 @@ def test_inaccurate_status_in_the_batch_kernel(name):
     P, q, A, l, u = prob
     K = (win[0] + win[-1]) // 2
     m = osqp_amd.OSQP(algebra='hip')
-    m.setup(P, q, A, l, u, max_iter=K, check_termination=1, adaptive_rho_interval=50, verbose=False, **stg)
+    m.setup(P, q, A, l, u, max_iter=K, check_termination=1, adaptive_rho=False, verbose=False, **stg)
     B = 6
     x, y, rec = m._solver.hip_batch_solve(q=np.tile(q, (B, 1)), nbatch=B)
     assert np.all(rec[:, 0] == inacc), rec[:, 0]

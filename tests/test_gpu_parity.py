@@ -17,7 +17,7 @@ import scipy.sparse as sp
 import osqp_amd
 import problems
 from oracle import Oracle, SOLVED
-from util import Fixture
+from util import Fixture, record_deviation
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -81,6 +81,8 @@ def test_solution_matches_oracle_direct(name, eps, atol):
     m, r = hip_solve(P, q, A, l, u, eps_abs=eps, eps_rel=eps, max_iter=100000)
     xo, yo, io = oracle_solve(P, q, A, l, u, eps_abs=1e-10, eps_rel=1e-10, max_iter=200000)
     assert r.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED and io.status_val == SOLVED
+    record_deviation('test_solution_matches_oracle_direct', '%s eps=%g' % (name, eps), dx_rel=np.abs(r.x - xo).max() / (1 + np.abs(xo).max()),
+                     dy_rel=np.abs(r.y - yo).max() / (1 + np.abs(yo).max()), atol=atol, iters=r.info.iter, oracle_iters_at_eps_1e_10=io.iter)
     npt.assert_allclose(r.x, xo, rtol=0, atol=atol * (1 + np.abs(xo).max()))
     npt.assert_allclose(r.y, yo, rtol=0, atol=atol * (1 + np.abs(yo).max()))
     assert abs(r.info.obj_val - io.obj_val) <= 10 * eps * (1 + abs(io.obj_val))

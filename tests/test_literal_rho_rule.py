@@ -1,0 +1,32 @@
+"""the reference's LITERAL adaptive-rho rule on the PCG path.  By default the indirect engine spends the setting
+`adaptive_rho_tolerance` on a square-root scale with a persistence test (an update costs it two small kernels, not
+a refactorisation); `set_policy(rho_tol_exp=1, rho_persist=0, rho_window=0)` restores the letter of
+/root/reference/src/osqppurepy/_osqp.py:910-930 (apply rho_new when it leaves [rho / tol, rho * tol]).  With that rule, the reference's
+1e3 equality weight and tight inner solves the multi-kernel PCG engine must count ADMM iterations like the pure-python reference on
+the five fixtures (tests/golden/make_fixtures.py: ref_iter) -- within one check interval on the GPU, exactly on the host simulator."""
+import warnings
+
+import pytest
+
+import osqp_amd
+from backend_param import engine
+from util import Fixture, record_deviation
+
+warnings.simplefilter('ignore')
+CASES = ['basic_QP', 'matrices_solve', 'config1_random_qp', 'warm_start', 'polish_random_admm']
+
+
+@pytest.mark.parametrize('backend', [pytest.param('hostsim'), pytest.param('hip-pcg', marks=pytest.mark.gpu)])
+@pytest.mark.parametrize('case', CASES)
+def test_pcg_path_with_the_literal_rho_rule_counts_iterations_like_the_reference(case, backend):
+    f = Fixture(case)
+    with engine(backend):
+        m = osqp_amd.OSQP(algebra='hip')
+        m.setup(f.P, f.q, f.A, f.l, f.u, **f.hip_settings(cg_max_iter=500, cg_tol_fraction=1e-3))
+        m._solver.set_policy(rho_tol_exp=1.0, rho_persist=0, rho_window=0, small_direct=0, rho_eq_factor=1e3)
+        r = m.solve()
+        if backend != 'hostsim':
+            assert m._solver.hip_stats()['kernel_launches'] > 1          # the multi-kernel engine ran, not the one-launch direct path
+        assert r.info.status_val == int(f['ref_status']) == 1
+        record_deviation('literal_rho_rule_iteration_counts', '%s %s' % (case, backend), iters=r.info.iter, ref_iters=int(f['ref_iter']), rho_updates=r.info.rho_updates)
+        assert abs(r.info.iter - int(f['ref_iter'])) <= (0 if backend == 'hostsim' else 25), (case, r.info.iter, int(f['ref_iter']))

@@ -95,3 +95,26 @@ def test_check_dualgap_on_a_small_problem_takes_the_host_driven_loop():
     r2 = m2.solve()
     assert m2._solver.hip_stats()['kernel_launches'] == 1
     assert np.abs(r.x - r2.x).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_scalars_frozen_into_captured_launches_follow_the_handle():
+    """Captured launches take the device struct by value: the equality-weight rule (k_set_rho inside the boundary group of a
+    device-driven solve) and the extrapolation weight are frozen into every graph.  Changing them on a handle that has already solved
+    must drop the graphs (Engine::sync_graph_scalars): the next solve equals, bit for bit, that of a fresh handle built with the value."""
+    P, q, A, l, u = problems.banded_qp(20000, window=40)
+    st = dict(eps_abs=1e-6, eps_rel=1e-6, max_iter=20000, check_termination=25, adaptive_rho_interval=50, verbose=False, warm_starting=False)
+    for field, value in (('rho_eq_factor', 50.0), ('extrap', 0.5)):
+        m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, **st)
+        r0 = m.solve()                                       # captures the slot strings and the boundary group with the defaults
+        assert r0.info.status_val == S.OSQP_SOLVED and r0.info.rho_updates >= 1
+        m._solver.set_policy(**{field: value})
+        m.update_settings(rho=0.1)
+        r1 = m.solve()
+        f = osqp_amd.OSQP(); f.setup(P, q, A, l, u, **st)
+        f._solver.set_policy(**{field: value})
+        r2 = f.solve()
+        assert r1.info.status_val == r2.info.status_val == S.OSQP_SOLVED
+        assert (r1.info.iter, r1.info.rho_updates) == (r2.info.iter, r2.info.rho_updates), (field, r1.info.iter, r2.info.iter)
+        assert np.array_equal(r1.x, r2.x) and np.array_equal(r1.y, r2.y), field
+        assert r1.info.iter != r0.info.iter or not np.array_equal(r1.x, r0.x)      # (the field does change the trajectory)

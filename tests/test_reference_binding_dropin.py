@@ -21,28 +21,41 @@ OUT = os.path.join(ROOT, 'tests', '_build', 'dropin')
 pytestmark = pytest.mark.skipif(not os.path.exists(SRC), reason='reference tree not present')
 
 
-@pytest.fixture(scope='module')
-def ext():
+def _build_binding(modname, lib):
+    """configure_file() + compile of the reference's binding source against include/compat, linked to `lib`"""
     import pybind11
-    import __graft_entry__ as g
-    g.build()
     os.makedirs(OUT, exist_ok=True)
-    cpp = os.path.join(OUT, 'bindings.cpp')
+    cpp = os.path.join(OUT, modname + '.cpp')
     with open(SRC) as f:
-        text = f.read().replace('@OSQP_EXT_MODULE_NAME@', 'osqp_hip_ext')       # configure_file(), CMakeLists.txt:39-40
+        text = f.read().replace('@OSQP_EXT_MODULE_NAME@', modname)       # configure_file(), CMakeLists.txt:39-40
     with open(cpp, 'w') as f:
         f.write(text)
-    so = os.path.join(OUT, 'osqp_hip_ext' + sysconfig.get_config_var('EXT_SUFFIX'))
-    libdir = os.path.join(ROOT, 'osqp-python_amd', 'osqp_amd')
+    so = os.path.join(OUT, modname + sysconfig.get_config_var('EXT_SUFFIX'))
     subprocess.check_call(['g++', '-O1', '-std=c++17', '-shared', '-fPIC', '-fvisibility=hidden', cpp, '-o', so,
                            '-I', os.path.join(ROOT, 'include', 'compat'), '-I', pybind11.get_include(), '-I', sysconfig.get_paths()['include'],
-                           os.path.join(libdir, 'libosqp_hip.so'), '-Wl,-rpath,' + libdir])
-    from osqp_amd import _lib
-    _lib.handle()                                        # torch's HIP runtime first
-    spec = importlib.util.spec_from_file_location('osqp_hip_ext', so)
+                           lib, '-Wl,-rpath,' + os.path.dirname(lib)])
+    spec = importlib.util.spec_from_file_location(modname, so)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+@pytest.fixture(scope='module')
+def ext():
+    import __graft_entry__ as g
+    g.build()
+    from osqp_amd import _lib
+    _lib.handle()                                        # torch's HIP runtime first (INTEGRATION.md §3)
+    return _build_binding('osqp_hip_ext', os.path.join(ROOT, 'osqp-python_amd', 'osqp_amd', 'libosqp_hip.so'))
+
+
+@pytest.fixture(scope='module')
+def ext_hostsim():
+    """The same binding source linked against the HOST-SIMULATOR build of the engine (tests/hostsim_build.py: the product's host driver
+    + api.cpp over plain-loop device ops): the whole call sequence of bindings.cpp.in:153-281 can then be executed in a container
+    without a GPU.  Test infrastructure; nothing of it travels or ships."""
+    import hostsim_build
+    return _build_binding('osqp_hostsim_ext', hostsim_build.build())
 
 
 def test_reference_binding_compiles_and_exposes_the_ext_surface(ext):
@@ -78,3 +91,67 @@ def test_reference_binding_drives_the_engine(ext):
     solver.solve()
     assert solver.info.status_val == 1
     np.testing.assert_allclose(solver.solution.x, [0.3, 0.7], atol=1e-5)
+
+
+def test_reference_binding_drives_a_whole_call_sequence_on_the_host_simulator(ext_hostsim):
+    """setup -> solve -> update_data_vec -> solve -> update_data_mat (by index) -> solve -> warm_start -> solve -> update_settings ->
+    update_rho -> solve, all through the reference's own binding (bindings.cpp.in:153 osqp_setup, :198 osqp_solve, :237 osqp_update_data_vec,
+    :280 osqp_update_data_mat, :193 osqp_warm_start, :204 osqp_update_settings, :213 osqp_update_rho), against the SAME sequence through
+    this repo's ctypes front-end on the same library: x, y, iteration counts and objective must agree bit for bit at every stage."""
+    import osqp_amd
+    from hostsim_util import hostsim
+    from util import Fixture
+    ext = ext_hostsim
+    f = Fixture('matrices_update_P_A')                      # update_matrices_test.py: n = 5, m = 8, new P / A values in the fixture
+    Pu = sp.triu(f.P, format='csc'); Pu.sort_indices()
+    A = f.A.copy(); A.sort_indices()
+    n, m = f.n, f.m
+    rng = np.random.default_rng(0)
+    q2 = f.q + 0.1 * rng.standard_normal(n)
+    l2, u2 = f.l - 0.05, f.u + 0.05
+    Px_idx = np.arange(0, Pu.nnz, 2, dtype=np.int32); Px_new = (Pu.data[Px_idx] * 1.1).copy()
+    Ax_idx = np.arange(1, A.nnz, 3, dtype=np.int32); Ax_new = (A.data[Ax_idx] * 0.9).copy()
+    stg = dict(eps_abs=1e-7, eps_rel=1e-7, max_iter=4000, check_termination=1, adaptive_rho_interval=25, scaling=10)
+
+    # ---- the reference binding
+    s = ext.OSQPSettings(); ext.osqp_set_default_settings(s); s.verbose = 0
+    for k, v in stg.items():
+        setattr(s, k, v)
+    Pc, Ac = ext.CSC(Pu), ext.CSC(A)
+    solver = ext.OSQPSolver(Pc, np.ascontiguousarray(f.q), Ac, np.ascontiguousarray(f.l), np.ascontiguousarray(f.u), m, n, s)
+    stages = []
+
+    def snap(tag):
+        assert solver.solve() == 0
+        info, sol = solver.info, solver.solution
+        stages.append((tag, np.array(sol.x), np.array(sol.y), int(info.iter), float(info.obj_val), int(info.status_val)))
+    snap('setup')
+    assert solver.update_data_vec(q2, l2, u2) == 0; snap('vec')
+    assert solver.update_data_mat(Px_new, Px_idx, Ax_new, Ax_idx) == 0; snap('mat')
+    assert solver.warm_start(np.zeros(n), None) == 0; snap('warm')
+    s2 = solver.get_settings(); s2.alpha = 1.4; s2.max_iter = 3000
+    assert solver.update_settings(s2) == 0
+    assert solver.update_rho(0.3) == 0; snap('settings')
+    with pytest.raises(ValueError, match='2'):              # OSQP_SETTINGS_VALIDATION_ERROR through py::value_error (:204-209)
+        bad = ext.OSQPSettings(); ext.osqp_set_default_settings(bad); bad.alpha = 3.0
+        solver.update_settings(bad)
+
+    # ---- the same sequence through this repo's front-end (ctypes) on the same library
+    with hostsim():
+        mdl = osqp_amd.OSQP(algebra='hip')
+        mdl.setup(Pu, f.q, A, f.l, f.u, verbose=False, **stg)
+        mine = []
+
+        def snap2(tag):
+            r = mdl.solve()
+            mine.append((tag, r.x.copy(), r.y.copy(), int(r.info.iter), float(r.info.obj_val), int(r.info.status_val)))
+        snap2('setup')
+        mdl.update(q=q2, l=l2, u=u2); snap2('vec')
+        mdl.update(Px=Px_new, Px_idx=Px_idx, Ax=Ax_new, Ax_idx=Ax_idx); snap2('mat')
+        mdl.warm_start(x=np.zeros(n)); snap2('warm')
+        mdl.update_settings(alpha=1.4, max_iter=3000, rho=0.3); snap2('settings')
+    for a, b in zip(stages, mine):
+        assert a[0] == b[0] and a[5] == 1 and b[5] == 1, (a[0], a[5], b[5])
+        assert a[3] == b[3], (a[0], a[3], b[3])
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[4] == b[4], a[0]
+    assert len({st[3] for st in stages}) > 1                # (the stages really are different solves)
