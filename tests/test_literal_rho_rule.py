@@ -3,7 +3,7 @@
 a refactorisation); `set_policy(rho_tol_exp=1, rho_persist=0, rho_window=0)` restores the letter of
 /root/reference/src/osqppurepy/_osqp.py:910-930 (apply rho_new when it leaves [rho / tol, rho * tol]).  With that rule, the reference's
 1e3 equality weight and tight inner solves the multi-kernel PCG engine must count ADMM iterations like the pure-python reference on
-the five fixtures (tests/golden/make_fixtures.py: ref_iter) -- within one check interval on the GPU, exactly on the host simulator."""
+the five fixtures (tests/golden/make_fixtures.py: ref_iter) -- exactly on the host simulator, within 5 iterations on the GPU (measured: equal on all five, profiles/r04b_parity_deviations_partial.json)."""
 import warnings
 
 import pytest
@@ -29,4 +29,4 @@ def test_pcg_path_with_the_literal_rho_rule_counts_iterations_like_the_reference
             assert m._solver.hip_stats()['kernel_launches'] > 1          # the multi-kernel engine ran, not the one-launch direct path
         assert r.info.status_val == int(f['ref_status']) == 1
         record_deviation('literal_rho_rule_iteration_counts', '%s %s' % (case, backend), iters=r.info.iter, ref_iters=int(f['ref_iter']), rho_updates=r.info.rho_updates)
-        assert abs(r.info.iter - int(f['ref_iter'])) <= (0 if backend == 'hostsim' else 25), (case, r.info.iter, int(f['ref_iter']))
+        assert abs(r.info.iter - int(f['ref_iter'])) <= (0 if backend == "hostsim" else 5), (case, r.info.iter, int(f['ref_iter']))
