@@ -130,8 +130,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--n', '--vars', dest='n', type=int, default=100000, help='variables (m = 2n, nnz(A) = 10n, nnz(P) = 2n); --vars: the spelling torch.distributed.run passes through')
     ap.add_argument('--carry-rho', action='store_true', help='keep the rho a solve ended with for the next step (the solver object\'s natural behaviour) instead of restarting every step from the setting')
-    ap.add_argument('--config', default='banded', choices=['banded', 'unstructured', 'lasso', 'portfolio'],
-                    help="banded = BASELINE configs[1] (the headline); unstructured = the same sizes with columns drawn from the whole row (GB/s only, "
+    ap.add_argument('--config', default='banded', choices=['banded', 'shuffled', 'unstructured', 'lasso', 'portfolio'],
+                    help="banded = BASELINE configs[1] (the headline); shuffled = the same QP with its variables and constraints randomly renumbered (the band is "
+                         "there but hidden: the engine has to find it, OSQPHipPolicy::reorder); unstructured = the same sizes with columns drawn from the whole row (GB/s only, "
                          "SURVEY 8d); lasso = configs[2] (5k features x 10k samples, dense data block); portfolio = configs[3] (10k assets, 100 factors)")
     ap.add_argument('--eps', type=float, default=1e-6)
     ap.add_argument('--cpu-seconds', type=float, default=40.0, help='CPU-baseline budget (0 disables)')
@@ -168,6 +169,11 @@ def main():
     if args.config == 'banded':
         P, q, A, l, u = problems.banded_qp(n, seed=12345); wl_tag = 'banded_n%d' % n
         wl_name = 'BASELINE configs[1]: single QP n=%d m=%d nnz(A)=%d nnz(P)=%d (problems.banded_qp, seed 12345)'
+    elif args.config == 'shuffled':
+        P, q, A, l, u = problems.banded_qp(n, seed=12345); wl_tag = 'shuffled_n%d' % n
+        _rng = np.random.default_rng(99); _pc, _pr = _rng.permutation(n), _rng.permutation(A.shape[0])
+        P = P[_pc][:, _pc].tocsc(); A = A[_pr][:, _pc].tocsc(); P.sort_indices(); A.sort_indices(); q, l, u = q[_pc], l[_pr], u[_pr]
+        wl_name = 'configs[1] with RANDOMLY RENUMBERED variables and constraints (hidden band): single QP n=%d m=%d nnz(A)=%d nnz(P)=%d (problems.banded_qp + permutation, seeds 12345 / 99)'
     elif args.config == 'unstructured':
         P, q, A, l, u = problems.banded_qp(n, window=n, seed=12345); wl_tag = 'unstructured_n%d' % n
         wl_name = 'configs[1] sizes with UNSTRUCTURED columns (SURVEY 8d: GB/s only): single QP n=%d m=%d nnz(A)=%d nnz(P)=%d (problems.banded_qp, window = n)'
@@ -314,7 +320,7 @@ def main():
             streamed = pcg_bytes; pcg_bytes = survey_pcg_bytes
         tts_ms = 1e3 * tmax / args.steps
         out = {
-            'metric': 'ADMM iterations/sec, n=%d m=%d nnz(A)=%d %s (indirect PCG)' % (n, mm, A.nnz, 'sparse QP' if args.config in ('banded', 'unstructured') else args.config + ' QP'),
+            'metric': 'ADMM iterations/sec, n=%d m=%d nnz(A)=%d %s (indirect PCG)' % (n, mm, A.nnz, 'sparse QP' if args.config in ('banded', 'shuffled', 'unstructured') else args.config + ' QP'),
             'value': total_iters / tmax, 'unit': 'ADMM iter/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * tmax / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
@@ -329,6 +335,7 @@ def main():
                        'pcg_iters_per_admm_iter': stats['pcg_iters_total'] / max(res.info.iter, 1), 'pcg_budget_limited_iters': int(stats['pcg_unconverged']),
                        'cg_cap_escalations': int(stats.get('cg_cap_escalations', 0)), 'slot_topups': int(stats.get('slot_topups', 0)),
                        'windowed_row_blocks': '%d of %d' % (int(stats.get('windowed_blocks', 0)), int(stats.get('row_blocks', 0))),
+                       'reordered': bool(stats.get('reordered', 0)), 'reorder_ms': stats.get('reorder_ms', 0.0),
                        'pcg_kernels_per_iteration': 1 if f1 else (2 if fused else 3), 'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
                        'setup_s': t_setup, 'per_rank': [{'status': int(r[0]), 'iter': int(r[1]), 'obj': r[2]} for r in allrec]},
             'roofline': {'bound': 'hbm', 'kernel': dom + (' -- in solves this body runs as the K2F phase of k_slot_b' if (fused and not f1) else ''), 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

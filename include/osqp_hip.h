@@ -190,6 +190,8 @@ typedef struct {
   double f1_replicas;         /* F1 form: replica vectors of the partial A' t (0: the form does not apply to this problem) */
   double woodbury_rows;       /* dense rows of A treated exactly in the preconditioner (0: plain Jacobi) */
   double woodbury_direct;     /* 1: that preconditioner is K^-1 for the current rho (the linear solves run without PCG iterations) */
+  double reordered;           /* 1: the engine works on a permuted copy of the problem (OSQPHipPolicy::reorder) */
+  double reorder_ms;          /* time setup spent looking for the permutation (0: not attempted) */
 } OSQPHipStats;
 OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
 
@@ -315,6 +317,9 @@ typedef struct {
   OSQPInt finish_pairs; OSQPInt poll_sleep_us;      /* device-driven chunks: a boundary group goes out when at most finish_pairs slot pairs are missing; pause between polls */
   /* diagnostics */
   OSQPInt slot_log, setup_timing, batch_timing, woodbury_log;
+  OSQPInt reorder;            /* 1 (default): when the one-launch PCG form does not apply to the matrices as numbered by the caller, look for a
+                                 bandwidth-reducing permutation of variables and constraints under which it does, and work on the permuted problem
+                                 (every vector crossing this API keeps the caller's numbering); 0: never; 2: always permute (tests)      [setup] */
 } OSQPHipPolicy;
 void    osqp_hip_default_policy(OSQPHipPolicy *policy);
 OSQPInt osqp_hip_set_policy(OSQPSolver *solver, const OSQPHipPolicy *policy);
@@ -332,6 +337,10 @@ OSQPInt osqp_hip_test_spmv(OSQPSolver *solver, OSQPInt which, const OSQPFloat *i
 OSQPInt osqp_hip_set_rho_eq_factor(OSQPSolver *solver, OSQPFloat factor);
 /* copy out internal scaling D (n), E (m), c */
 OSQPInt osqp_hip_get_scaling(OSQPSolver *solver, OSQPFloat *D, OSQPFloat *E, OSQPFloat *c);
+/* the permutation this handle works under (OSQPHipPolicy::reorder): perm_cols[k] (n) / perm_rows[k] (m) = the caller's index of the engine's
+   k-th variable / constraint; the identity when the problem was not reordered (OSQPHipStats::reordered = 0).  Diagnostic: nothing at this
+   API is expressed in the engine's numbering. */
+OSQPInt osqp_hip_get_reordering(OSQPSolver *solver, OSQPInt *perm_cols, OSQPInt *perm_rows);
 /* name of the compute backend compiled into this library: "hip-gfx950" for the product */
 const char *osqp_hip_backend(void);
 

@@ -105,6 +105,7 @@ OSQPInt osqp_hip_warm_start_device(OSQPSolver *s, const OSQPFloat *x, const OSQP
   return guarded(s, [&](Engine &e) { return e.warm_start_device(x, y, stream); });
 }
 OSQPInt osqp_hip_get_scaling(OSQPSolver *s, OSQPFloat *D, OSQPFloat *E, OSQPFloat *c) { return guarded(s, [&](Engine &e) { return e.get_scaling(D, E, c); }); }
+OSQPInt osqp_hip_get_reordering(OSQPSolver *s, OSQPInt *perm_cols, OSQPInt *perm_rows) { return guarded(s, [&](Engine &e) { return e.get_reordering(perm_cols, perm_rows); }); }
 
 }  // extern "C"
 

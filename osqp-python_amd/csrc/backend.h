@@ -356,6 +356,7 @@ bool device_vec_updates();               // false: the host simulator (the drive
 // dst (device) <- src, asynchronous on the solver's stream; src_on_device = 0: host memory (reusable when the call returns)
 void copy_in(Dev &d, void *dst, const void *src, size_t bytes, int src_on_device);
 void stream_wait(Dev &d, void *caller_stream);       // the solver's stream waits for everything queued on caller_stream so far
+void gather(Dev &d, double *dst_dev, const double *src_dev, const int *idx_dev, int cnt);   // dst[k] = src[idx[k]] (reordered problems: caller's numbering -> the engine's)
 void scale_q(Dev &d, double c);                       // q = c D qraw                                  (_osqp.py:1328)
 void scale_bounds(Dev &d, int rho_is_vec);            // l = E lraw, u = E uraw; ctype; cnt[0]       (:1357-1358, :505-518)
 int count_bad_bounds(Dev &d, const double *l_dev, const double *u_dev);   // rows with !(l <= u) (:1348-1349); synchronises

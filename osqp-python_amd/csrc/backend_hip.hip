@@ -1632,6 +1632,9 @@ __global__ __launch_bounds__(kBlock) void k_count_bad(int m, const double *l, co
   for (int o = 32; o > 0; o >>= 1) bad += __shfl_down(bad, o, 64);
   if ((threadIdx.x & 63) == 0 && bad) atomicAdd(&cnt[1], bad);
 }
+__global__ __launch_bounds__(kBlock) void k_gather(double *dst, const double *src, const int *idx, int cnt) {
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < cnt; k += gridDim.x * kBlock) dst[k] = src[idx[k]];
+}
 __global__ __launch_bounds__(kBlock) void k_scale_warm(Dev d, const double *xin, const double *yin, double c) {   // :1493-1545
   const int stride = gridDim.x * kBlock;
   if (xin) for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) d.x[j] = d.Dinv[j] * xin[j];
@@ -2325,6 +2328,7 @@ void stream_wait(Dev &d, void *caller_stream) {
   HIP_CHECK(hipEventRecord(im(d).ev_wait, static_cast<hipStream_t>(caller_stream)));      // (its own event: ev_ext may still mark a pending batch kernel)
   HIP_CHECK(hipStreamWaitEvent(st(d), im(d).ev_wait, 0));
 }
+void gather(Dev &d, double *dst, const double *src, const int *idx, int cnt) { if (cnt <= 0) return; HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_gather, d, dst, src, idx, cnt); }
 void scale_q(Dev &d, double c) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_scale_q, d, d, c); }
 void scale_bounds(Dev &d, int rho_is_vec) {
   HIP_CHECK(hipSetDevice(d.device));

@@ -47,6 +47,7 @@ class Engine {
   int test_spmv(int which, const double *in, double *out);
   int trace_read(unsigned long long *out, int count);
   int get_scaling(double *D, double *E, double *c);
+  int get_reordering(int *perm_cols, int *perm_rows) const;
   int set_rho_eq_factor(double f);
   int batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, double *zs_dev = nullptr);
   int batch_solve_device(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, void *stream);
@@ -106,7 +107,26 @@ class Engine {
   } bd_;
   void prepare_batch_direct();
   void prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj);
-  void prepare_f1(const std::vector<int> &rb, const std::vector<int> &Arp, const std::vector<int> &Arj, const std::vector<int> &Brp, const std::vector<int> &Bj);
+  struct F1Plan {                       // host image of backend.h DevF1 (plan_f1 builds it without touching the device; upload_f1 commits it)
+    bool ok = false; int D = 0, pnnz = 0;
+    std::vector<int> blk, prp, pcol, psrc; std::vector<unsigned int> ent; std::vector<unsigned short> cptr;
+  };
+  // ---- bandwidth-reducing reordering (Engine::compute_reorder): when the one-launch PCG form does not apply to the matrices as given but
+  // does after a symmetric permutation of the variables and a permutation of the constraints, the engine works on the PERMUTED problem
+  //   P' = P(pc, pc),  q' = q(pc),  A' = A(pr, pc),  l' = l(pr),  u' = u(pr)
+  // and every vector crossing the C API is permuted on the way (solutions, certificates, warm starts, data updates, scaling read-back).
+  bool reordered_ = false, no_reorder_ = false;
+  std::vector<int> pc_, pr_, ipc_, ipr_;     // pc_[new] = old column, ipc_[old] = new (rows: pr_, ipr_)
+  std::vector<int> PvalMap_, AvalMap_;       // caller's position in P.x / A.x -> position in the permuted CSC arrays (osqp_update_data_mat by index)
+  int *d_pc_ = nullptr, *d_pr_ = nullptr;    // device copies of pc_, pr_ (device-pointer updates: gathers)
+  double reorder_ms_ = 0;
+  void compute_reorder(const std::vector<int> &Arp, const std::vector<int> &Arj, const std::vector<int> &Brp, const std::vector<int> &Bj);
+  void apply_reorder();
+  void clear_reorder();
+  template <class T> std::vector<T> to_internal_n(const T *v) const { std::vector<T> o(n); for (int j = 0; j < n; j++) o[j] = v[pc_[j]]; return o; }
+  template <class T> std::vector<T> to_internal_m(const T *v) const { std::vector<T> o(m); for (int i = 0; i < m; i++) o[i] = v[pr_[i]]; return o; }
+  bool plan_f1(const std::vector<int> &rb, const std::vector<int> &Arp, const std::vector<int> &Arj, const std::vector<int> &Brp, const std::vector<int> &Bj, F1Plan &pl);
+  void upload_f1(const F1Plan &pl);
   bool small_direct_applicable();
   int solve_small_direct(double t0);
   void attach_batch_direct(BatchParams &p);

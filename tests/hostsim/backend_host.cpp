@@ -39,6 +39,7 @@ void stream_wait(Dev &, void *) {}
 void scale_q(Dev &, double) {}
 void scale_bounds(Dev &, int) {}
 int count_bad_bounds(Dev &, const double *, const double *) { return 0; }
+void gather(Dev &, double *dst, const double *src, const int *idx, int cnt) { for (int k = 0; k < cnt; k++) dst[k] = src[idx[k]]; }
 void scale_warm(Dev &, const double *, const double *, double) {}
 bool slots_supported(const Dev &) { return false; }
 void slot_begin(Dev &, int, int) {}
