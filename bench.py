@@ -336,6 +336,8 @@ def main():
                        'cg_cap_escalations': int(stats.get('cg_cap_escalations', 0)), 'slot_topups': int(stats.get('slot_topups', 0)),
                        'windowed_row_blocks': '%d of %d' % (int(stats.get('windowed_blocks', 0)), int(stats.get('row_blocks', 0))),
                        'reordered': bool(stats.get('reordered', 0)), 'reorder_ms': stats.get('reorder_ms', 0.0),
+                       'preconditioner': s.hip_preconditioner(), 'woodbury_factorisations_last_solve': int(stats.get('woodbury_factorisations', 0)),
+                       'woodbury_factor_ms_last_solve': stats.get('woodbury_factor_ms', 0.0),
                        'pcg_kernels_per_iteration': 1 if f1 else (2 if fused else 3), 'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
                        'setup_s': t_setup, 'per_rank': [{'status': int(r[0]), 'iter': int(r[1]), 'obj': r[2]} for r in allrec]},
             'roofline': {'bound': 'hbm', 'kernel': dom + (' -- in solves this body runs as the K2F phase of k_slot_b' if (fused and not f1) else ''), 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -351,6 +353,19 @@ def main():
             out['roofline']['streamed_bytes'] = streamed
             out['roofline']['frac_streamed'] = streamed / (pcg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             out['roofline']['replicas'] = f1_D
+        if int(stats.get('woodbury_rows', 0)) > 0:
+            # the figure with the reference's literal preconditioner next to it: the same QP, same settings, plain Jacobi (OSQPHipPolicy::woodbury = 0)
+            os.environ['OSQP_HIP_WOODBURY'] = '0'
+            try:
+                mj = osqp_amd.OSQP(algebra='hip'); mj.setup(P, q, A, l, u, **settings)
+                tj = time.perf_counter(); rj = mj.solve(); torch.cuda.synchronize(); tj = time.perf_counter() - tj
+                sj = mj._solver.hip_stats()
+                out['config']['jacobi_only'] = {'preconditioner': mj._solver.hip_preconditioner(), 'first_cold_solve_ms': 1e3 * tj, 'admm_iters': int(rj.info.iter), 'status': rj.info.status,
+                                                'pcg_iters_per_admm_iter': sj['pcg_iters_total'] / max(rj.info.iter, 1),
+                                                'note': 'to compare with config.first_cold_solve_ms (%.1f ms, %s)' % (first_ms or 0.0, s.hip_preconditioner())}
+                del mj
+            finally:
+                os.environ.pop('OSQP_HIP_WOODBURY', None)
         if batch_out is not None:
             bdata = batch_out.pop('_data')
             out['config']['batch'] = batch_out

@@ -190,9 +190,17 @@ typedef struct {
   double f1_replicas;         /* F1 form: replica vectors of the partial A' t (0: the form does not apply to this problem) */
   double woodbury_rows;       /* dense rows of A treated exactly in the preconditioner (0: plain Jacobi) */
   double woodbury_direct;     /* 1: that preconditioner is K^-1 for the current rho (the linear solves run without PCG iterations) */
+  double preconditioner;      /* OSQP_HIP_PRECOND_*: what the PCG is preconditioned with right now (below) */
+  double woodbury_factorisations, woodbury_factor_ms;   /* last solve: re-factorisations of the Woodbury system at rho updates, and their wall time */
   double reordered;           /* 1: the engine works on a permuted copy of the problem (OSQPHipPolicy::reorder) */
   double reorder_ms;          /* time setup spent looking for the permutation (0: not attempted) */
 } OSQPHipStats;
+/* OSQPHipStats::preconditioner.  `cg_precond = OSQP_DIAGONAL_PRECONDITIONER` (bindings.cpp.in:426, the reference's only preconditioner) selects the
+   Jacobi family: plain Jacobi M = diag(K), and -- this engine's addition, on by default, OSQPHipPolicy::woodbury / woodbury_large = 0 switch it
+   off -- the same diagonal with the rows of A that hold more than 128 entries treated exactly through the Woodbury identity (1..128 such rows:
+   r x r system inverted on the host; up to 16384 rows carrying most of A: formed, factorised and inverted on the device with rocBLAS / rocSOLVER,
+   which are loaded on demand).  Which one a handle runs is reported here, never implied. */
+enum { OSQP_HIP_PRECOND_NONE = 0, OSQP_HIP_PRECOND_JACOBI = 1, OSQP_HIP_PRECOND_JACOBI_WOODBURY = 2, OSQP_HIP_PRECOND_JACOBI_WOODBURY_DENSE = 3 };
 OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
 
 /* Re-launch one hot-path kernel `reps` times on the solver's stream with the solver's current device state and

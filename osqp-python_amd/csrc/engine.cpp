@@ -1139,6 +1139,7 @@ int Engine::solve() {
   }
   stats_.pcg_iters_total = stats_.pcg_iters_max = stats_.pcg_unconverged = 0;
   stats_.kernel_launches = stats_.graph_launches = 0; stats_.cg_cap_escalations = 0; stats_.slot_topups = 0;
+  stats_.woodbury_factorisations = 0; stats_.woodbury_factor_ms = 0;
   double res[R_COUNT];
   admm_core(t0, res);
   info.rho_estimate = rho_estimate(res);                                                 // :1275
@@ -1191,6 +1192,8 @@ void Engine::ctl_setup() {
 void Engine::apply_rho(double rho) {
   rho_bar_ = rho; settings.rho = rho;
   be::set_rho(d_, rho_bar_);
+  const double tf = d_.wb.on ? now_s() : 0.0;
+  struct Tally { Engine *e; double t0; ~Tally() { if (t0 > 0) { e->stats_.woodbury_factorisations += 1; e->stats_.woodbury_factor_ms += 1e3 * (now_s() - t0); } } } tally{this, tf};
   try { be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER); }
   catch (const DeviceError &err) {
     // a re-factorisation of the Woodbury correction failed in the middle of a solve (dense-library call, or S not positive definite at
@@ -2249,6 +2252,10 @@ int Engine::get_stats(OSQPHipStats *out) {
   out->woodbury_rows = d_.wb.on ? d_.wb.r : 0; out->woodbury_direct = (d_.wb.on && d_.wb.exact) ? 1 : 0;
   out->windowed_blocks = d_.A.nwin + d_.B.nwin; out->row_blocks = d_.A.nblk + d_.B.nblk;
   out->reordered = reordered_ ? 1.0 : 0.0; out->reorder_ms = reorder_ms_;
+  // which preconditioner the PCG of this handle runs with RIGHT NOW (the setting cg_precond = diagonal selects the Jacobi family; the
+  // Woodbury correction for dense rows is the engine's addition: OSQPHipPolicy::woodbury / woodbury_large switch it off)
+  out->preconditioner = settings.cg_precond != OSQP_DIAGONAL_PRECONDITIONER ? OSQP_HIP_PRECOND_NONE
+                        : !d_.wb.on ? OSQP_HIP_PRECOND_JACOBI : (d_.wb.large ? OSQP_HIP_PRECOND_JACOBI_WOODBURY_DENSE : OSQP_HIP_PRECOND_JACOBI_WOODBURY);
   return OSQP_NO_ERROR;
 }
 int Engine::time_kernel(int which, int reps, double *ms) {

@@ -223,10 +223,17 @@ class OSQPSolver:
         return self._lib.osqp_codegen(self._p, None, None, None)
 
     # ---- engine extensions ----
+    PRECONDITIONERS = {0: 'none', 1: 'jacobi', 2: 'jacobi + woodbury (dense rows, host-inverted system)',
+                       3: 'jacobi + woodbury (dense rows, system factorised on the device by rocBLAS / rocSOLVER)'}      # OSQP_HIP_PRECOND_*
+
     def hip_stats(self):
         s = _lib.StatsStruct()
         self._lib.osqp_hip_get_stats(self._p, C.byref(s))
         return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def hip_preconditioner(self):
+        """What this handle's PCG is preconditioned with right now, in words (OSQPHipStats::preconditioner)."""
+        return self.PRECONDITIONERS[int(self.hip_stats()['preconditioner'])]
 
     def get_policy(self):
         """This handle's engine policy (include/osqp_hip.h OSQPHipPolicy) as a dict."""
