@@ -241,7 +241,7 @@ def main():
     batch_out = None
     if args.batch > 0 and args.config == 'banded' and args.dist_backend == 'nccl':
         import bench_batch
-        batch_out = bench_batch.measure_sharded_device(args.batch, args.batch_steps, 1, rank, world, local, use_dist)
+        batch_out = bench_batch.measure_sharded_device(args.batch, args.batch_steps, 3, rank, world, local, use_dist)
 
     if rank == 0:
         nnzA, nnzB, mm = int(stats['nnzA']), int(stats['nnzB']), len(l)

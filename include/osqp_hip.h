@@ -189,7 +189,8 @@ typedef struct {
   double slot_topups;         /* last solve: chunks whose string of slot launches ended before the chunk did (more launches followed) */
   double f1_replicas;         /* F1 form: replica vectors of the partial A' t (0: the form does not apply to this problem) */
   double woodbury_rows;       /* dense rows of A treated exactly in the preconditioner (0: plain Jacobi) */
-  double woodbury_direct;     /* 1: that preconditioner is K^-1 for the current rho (the linear solves run without PCG iterations) */
+  double woodbury_direct;     /* 1: that preconditioner is K^-1 for the current rho (the linear solves run without PCG iterations); 2: ... and the ADMM
+                                 iteration runs as two launches (OSQPHipPolicy::woodbury_fused) */
   double preconditioner;      /* OSQP_HIP_PRECOND_*: what the PCG is preconditioned with right now (below) */
   double woodbury_factorisations, woodbury_factor_ms;   /* last solve: re-factorisations of the Woodbury system at rho updates, and their wall time */
   double reordered;           /* 1: the engine works on a permuted copy of the problem (OSQPHipPolicy::reorder) */
@@ -325,6 +326,8 @@ typedef struct {
   OSQPInt finish_pairs; OSQPInt poll_sleep_us;      /* device-driven chunks: a boundary group goes out when at most finish_pairs slot pairs are missing; pause between polls */
   /* diagnostics */
   OSQPInt slot_log, setup_timing, batch_timing, woodbury_log;
+  OSQPInt woodbury_fused;     /* the Woodbury direct mode as TWO launches per ADMM iteration where it applies (P diagonal, one-entry short rows,
+                                 n <= 16384; wbdirect_hip.hip) instead of five                                                      [setup] */
   OSQPInt reorder;            /* 1 (default): when the one-launch PCG form does not apply to the matrices as numbered by the caller, look for a
                                  bandwidth-reducing permutation of variables and constraints under which it does, and work on the permuted problem
                                  (every vector crossing this API keeps the caller's numbering); 0: never; 2: always permute (tests)      [setup] */

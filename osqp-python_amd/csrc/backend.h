@@ -109,6 +109,19 @@ constexpr int kWbMaxRows = 128;
 // mode is simply off), h = S^-1 g by a dense matrix-vector kernel (r^2 x 8 bytes per application).  Whether M = K (the direct mode) is
 // decided NUMERICALLY after every factorisation: M^-1 (K v) must reproduce a probe vector v to 1e-9.
 constexpr int kWbLargeMax = 16384;
+// The direct mode in TWO launches per ADMM iteration (wbdirect_hip.hip): P diagonal, every short row of A has exactly one entry, n <= kWbxMaxN.
+// A workgroup owns kWbxCols consecutive columns and keeps its dense r x kWbxCols tile of A_L in LDS; the two global reductions of the
+// iteration (g = A_L D0^-1 r_0, z~_L = A_L x~) travel as per-workgroup partials, summed in index order by every consumer.
+constexpr int kWbxCols = 64;
+constexpr int kWbxMaxN = 16384;           // at most 256 workgroups: every consumer folds all partials (G x kWbMaxRows doubles)
+struct DevWbx {
+  int on = 0, G = 0, nsc = 0;
+  double *tile = nullptr;                 // [G][kWbMaxRows][kWbxCols] A_L by column block, zero where A_L has no entry (rows >= r unused)
+  double *partG = nullptr, *partZ = nullptr;   // [G][kWbMaxRows] partial sums of the two reductions
+  double *ls0 = nullptr, *ls1 = nullptr;  // [3 r] {z, y, z~} of the long rows: read by X from ls0, written by X (workgroup 0) to ls1, handed over by Y
+  int *sc_ptr = nullptr, *sc_row = nullptr, *sc_src = nullptr;   // per column: its one-entry rows (CSR over columns) and where their values sit in A.val
+  double *sc_val = nullptr;
+};
 struct DevWb {
   int on = 0, r = 0;
   int large = 0;                 // r > kWbMaxRows: device-side dense factorisation; WT unused, W / colmap / ct in use
@@ -121,6 +134,7 @@ struct DevWb {
   int *info = nullptr;           // [2] status words of the factorisation / inversion
   int exact = 0;                 // K0 is diagonal (P diagonal, every short row of A has one entry): M = K, and M^-1 r_0 IS the solve -- no PCG iteration
                                  // (Engine::run_chunk: KB, the three kernels of M^-1, k_wb_direct, KA); cleared when S^-1 fails its accuracy check
+  DevWbx x;                      // exact mode in two launches per ADMM iteration (x.on)
   DevCsr AL, ALT;                // the long rows (r x n) and their transpose (n x r); values gathered from A.val through al_src / alt_src
   int *al_src = nullptr, *alt_src = nullptr;
   unsigned char *islong = nullptr;   // [m]
@@ -290,6 +304,10 @@ int slot_seq(Dev &d);                      // slots executed since slot_begin (c
 inline double slot_launches(const Dev &d, double pcg) { return d.f1.on ? pcg + 3.0 : 2.0 * (pcg + 2.0); }
 void f1_refresh(Dev &d);                   // f1.pval <- B.val (no-op without a plan)
 bool wb_supported();
+bool wbx_supported();                      // the two-launch direct mode exists (false: the host simulator)
+void wbx_init(Dev &d);                     // once per handle, after the plan is uploaded (LDS attribute of its kernels on d.device)
+void wbx_refresh(Dev &d);                  // tiles / one-entry-row values <- A.val
+void wbx_chunk(Dev &d, int niter);         // niter ADMM iterations: X(rhs), { Y, X } x (niter - 1), Y, X(update): 2 niter + 1 launches on d.stream
 bool wb_large_supported();                 // the dense solver libraries could be loaded                       // Woodbury preconditioner available (false: the host simulator)
 void wb_refresh(Dev &d);                   // wb.AL / ALT / WT values <- A.val (after assembly / equilibration / matrix updates)
 void wb_direct(Dev &d);                    // exact mode: x~ = x_g + M^-1 r_0 (after kb_rhs + wb_apply(0)); marks the solve as converged after one step

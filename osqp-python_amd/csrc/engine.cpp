@@ -118,6 +118,7 @@ void policy_from_env(OSQPHipPolicy &p, bool runtime_only) {
     for (int k = 1; k <= 5; k++) if (!std::strcmp(e, names[k])) p.batch_variant = k;
   }
   if (runtime_only) return;
+  on("OSQP_HIP_WOODBURY_FUSED", p.woodbury_fused);
   on("OSQP_HIP_WOODBURY", p.woodbury); on("OSQP_HIP_WOODBURY_DIRECT", p.woodbury_direct); on("OSQP_HIP_WOODBURY_LARGE", p.woodbury_large);
   num("OSQP_HIP_REORDER", p.reorder);
   on("OSQP_HIP_GRAPH", p.graph); on("OSQP_HIP_SLOTS", p.slots); on("OSQP_HIP_PCG_FUSED", p.pcg_fused); on("OSQP_HIP_F1", p.f1); on("OSQP_HIP_WINDOW", p.window);
@@ -137,7 +138,7 @@ void Engine::default_policy(OSQPHipPolicy *p) {
   p->polish_delta_floor = 1e-3; p->polish_pcg_tol = 1e-15; p->woodbury = 1; p->woodbury_direct = 1; p->woodbury_large = 1;
   p->slot_poll = 1; p->poll_low = 6; p->poll_first = 0.8; p->poll_frac = 0.75; p->poll_wait = 0.7;
   p->finish_pairs = 12; p->poll_sleep_us = 30;
-  p->reorder = 1;
+  p->reorder = 1; p->woodbury_fused = 1;
 }
 void Engine::set_default_policy(const OSQPHipPolicy *p) {
   g_default_policy_set = p != nullptr;
@@ -153,7 +154,7 @@ int Engine::set_policy(const OSQPHipPolicy *p) {
   const OSQPHipPolicy old = pol_;
   pol_ = *p; pol_explicit_ = true;
   // [setup] fields keep the value the handle was built with
-  pol_.slots = old.slots; pol_.pcg_fused = old.pcg_fused; pol_.f1 = old.f1; pol_.window = old.window; pol_.woodbury = old.woodbury; pol_.woodbury_direct = old.woodbury_direct; pol_.woodbury_large = old.woodbury_large; pol_.reorder = old.reorder;
+  pol_.slots = old.slots; pol_.pcg_fused = old.pcg_fused; pol_.f1 = old.f1; pol_.window = old.window; pol_.woodbury = old.woodbury; pol_.woodbury_direct = old.woodbury_direct; pol_.woodbury_large = old.woodbury_large; pol_.reorder = old.reorder; pol_.woodbury_fused = old.woodbury_fused;
   if (pol_.graph != old.graph) { use_graph_ = pol_.graph != 0; if (dev_ready_) { be::activate(d_); be::sync(d_); drop_graphs(); } }
   if (dev_ready_) d_.theta = pol_.extrap;
   if (dev_ready_ && pol_.rho_eq_factor >= 1.0 && pol_.rho_eq_factor != old.rho_eq_factor) return set_rho_eq_factor(pol_.rho_eq_factor);
@@ -198,7 +199,7 @@ void Engine::free_all() {
                   d_.dy, d_.xs, d_.xg, d_.xsp, d_.ztg, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.uu2, d_.ms, d_.part, d_.res,
                   d_.scal, d_.flags, d_.slot, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB,
                   d_.wb.AL.rowptr, d_.wb.AL.col, d_.wb.AL.blkdesc, d_.wb.AL.runinfo, d_.wb.AL.val, d_.wb.ALT.rowptr, d_.wb.ALT.col, d_.wb.ALT.blkdesc, d_.wb.ALT.runinfo, d_.wb.ALT.val,
-                  d_.wb.al_src, d_.wb.alt_src, d_.wb.islong, d_.wb.rows, d_.wb.WT, d_.wb.S, d_.wb.Sinv, d_.wb.g, d_.wb.h, d_.wb.Dinv0, d_.wb.colmap, d_.wb.W, d_.wb.pv, d_.wb.info,
+                  d_.wb.al_src, d_.wb.alt_src, d_.wb.islong, d_.wb.rows, d_.wb.WT, d_.wb.S, d_.wb.Sinv, d_.wb.g, d_.wb.h, d_.wb.Dinv0, d_.wb.colmap, d_.wb.W, d_.wb.pv, d_.wb.info, d_.wb.x.tile, d_.wb.x.partG, d_.wb.x.partZ, d_.wb.x.ls0, d_.wb.x.ls1, d_.wb.x.sc_ptr, d_.wb.x.sc_row, d_.wb.x.sc_src, d_.wb.x.sc_val,
                   d_.ctl, d_.f1.blk, d_.f1.ent, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.va, d_pc_, d_pr_};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   be::destroy(d_);
@@ -666,6 +667,27 @@ void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj
   // (large mode: decided numerically after every factorisation -- two-entry rows whose contributions to K0's off-diagonal cancel, as in
   //  the lasso's  -t <= x <= t , are as good as one-entry rows)
   if (large) { w.probe = pol_.woodbury_direct != 0; w.exact = 0; w.log = pol_.woodbury_log; }
+  // The direct mode in two launches per ADMM iteration (backend.h DevWbx): additionally every short row has EXACTLY one entry (an empty
+  // row would have no column to be updated with) and the problem is small enough for the per-workgroup partials (n <= kWbxMaxN)
+  if (w.exact && !large && pol_.woodbury_fused && be::wbx_supported() && n <= kWbxMaxN) {
+    bool ok = true;
+    for (int i = 0; i < m && ok; i++) if (!islong[i] && Arp[i + 1] - Arp[i] != 1) ok = false;
+    if (ok) {
+      std::vector<int> sc_ptr(n + 1, 0), sc_row, sc_src;
+      for (int j = 0; j < n; j++) {
+        for (int k = A_.p[j]; k < A_.p[j + 1]; k++) if (!islong[A_.i[k]]) { sc_row.push_back(A_.i[k]); sc_src.push_back(AmapA_[k]); }
+        sc_ptr[j + 1] = (int)sc_row.size();
+      }
+      DevWbx &x = w.x;
+      x.G = (n + kWbxCols - 1) / kWbxCols; x.nsc = (int)sc_row.size();
+      x.tile = dev_vec<double>(d_, (size_t)x.G * kWbMaxRows * kWbxCols);       // (zero-filled by the allocator: only the pattern's positions are ever written)
+      x.partG = dev_vec<double>(d_, (size_t)x.G * kWbMaxRows); x.partZ = dev_vec<double>(d_, (size_t)x.G * kWbMaxRows);
+      x.ls0 = dev_vec<double>(d_, 3 * (size_t)kWbMaxRows); x.ls1 = dev_vec<double>(d_, 3 * (size_t)kWbMaxRows);
+      x.sc_ptr = up_i(sc_ptr); x.sc_row = up_i(sc_row); x.sc_src = up_i(sc_src); x.sc_val = dev_vec<double>(d_, sc_row.size());
+      be::wbx_init(d_);
+      x.on = 1;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ setup
@@ -916,7 +938,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
     be::assemble(d_, 0, 1.0, 0);                                     // unscaled, sigma added after the equilibration
     c_ = be::ruiz(d_, settings.scaling);                             // _osqp.py:389-497
     cinv_ = 1.0 / c_;
-    be::f1_refresh(d_); be::wb_refresh(d_);
+    be::f1_refresh(d_); be::wb_refresh(d_); be::wbx_refresh(d_);
     D_.resize(n); E_.resize(m); Dinv_.resize(n); Einv_.resize(m);
     be::d2h(d_, D_.data(), d_.D, sizeof(double) * n); be::d2h(d_, Dinv_.data(), d_.Dinv, sizeof(double) * n);
     if (m > 0) { be::d2h(d_, E_.data(), d_.E, sizeof(double) * m); be::d2h(d_, Einv_.data(), d_.Einv, sizeof(double) * m); }
@@ -995,7 +1017,9 @@ void Engine::set_status(int st) {
 // hipGraph captured once per (niter, budget).
 void Engine::run_chunk(int niter, int budget) {
   const bool fused = be::pcg_fused(d_), wb = d_.wb.on != 0;
+  const bool xy = wb && d_.wb.exact && d_.wb.x.on;       // the direct mode in two launches per ADMM iteration (wbdirect_hip.hip)
   auto enqueue = [&](int count) {
+    if (xy) { be::wbx_chunk(d_, count); return; }
     for (int it = 0; it < count; it++) {
       be::kb_rhs(d_);
       if (wb) be::wb_apply(d_, 0, d_.wb.exact);
@@ -1004,7 +1028,7 @@ void Engine::run_chunk(int niter, int budget) {
       be::ka(d_, budget);
     }
   };
-  stats_.kernel_launches += (double)niter * ((wb && d_.wb.exact) ? 5 : (fused ? 3 + 2 * budget : 2 + 3 * budget + (wb ? 3 * (budget + 1) : 0)));
+  stats_.kernel_launches += xy ? 2.0 * niter + 1 : (double)niter * ((wb && d_.wb.exact) ? 5 : (fused ? 3 + 2 * budget : 2 + 3 * budget + (wb ? 3 * (budget + 1) : 0)));
   if (!(use_graph_ && be::graphs_supported())) { enqueue(niter); return; }
   // one executable graph per (ADMM iterations, PCG budget); graphs are kept below kMaxGraphNodes kernel nodes (a
   // check_termination = 0 solve would otherwise capture max_iter * (2 + 3*budget) nodes in one graph)
@@ -1012,7 +1036,7 @@ void Engine::run_chunk(int niter, int budget) {
   const int per = std::max(1, kMaxGraphNodes / (2 + 3 * budget + (wb ? 3 * (budget + 1) : 0)));
   for (int left = niter; left > 0;) {
     const int cnt = std::min(left, per);
-    auto key = std::make_pair(cnt, budget | ((wb && d_.wb.exact) ? (1 << 24) : 0));      // (the direct mode is another launch sequence: it may come and go with rho in the large-rank form)
+    auto key = std::make_pair(cnt, budget | ((wb && d_.wb.exact) ? (1 << 24) : 0) | (xy ? (1 << 25) : 0));      // (the direct mode is another launch sequence: it may come and go with rho in the large-rank form)
     auto it = graphs_.find(key);
     if (it == graphs_.end()) {
       be::graph_begin(d_);
@@ -1788,7 +1812,7 @@ int Engine::update_data_mat(const double *Px, const int *Px_idx, int P_n, const 
     if (Px) be::h2d(d_, d_.Praw, P_.x.data(), sizeof(double) * nzP);
     if (Ax) be::h2d(d_, d_.Araw, A_.x.data(), sizeof(double) * nzA);
     be::assemble(d_, 1, c_, 1);
-    be::f1_refresh(d_); be::wb_refresh(d_);
+    be::f1_refresh(d_); be::wb_refresh(d_); be::wbx_refresh(d_);
   } else {
     std::vector<double> Pxs, Axs;
     scale_matrix_values(Pxs, Axs);
@@ -2249,7 +2273,7 @@ int Engine::get_stats(OSQPHipStats *out) {
   if (!out) return OSQP_DATA_VALIDATION_ERROR;
   *out = stats_; out->pcg_fused = (d_.f1.on && use_slots_) ? 2.0 : (be::pcg_fused(d_) ? 1.0 : 0.0); out->batch_direct_bw = bd_.bw_symbolic;
   out->f1_replicas = d_.f1.on ? d_.f1.D : 0;
-  out->woodbury_rows = d_.wb.on ? d_.wb.r : 0; out->woodbury_direct = (d_.wb.on && d_.wb.exact) ? 1 : 0;
+  out->woodbury_rows = d_.wb.on ? d_.wb.r : 0; out->woodbury_direct = (d_.wb.on && d_.wb.exact) ? ((d_.wb.x.on) ? 2 : 1) : 0;
   out->windowed_blocks = d_.A.nwin + d_.B.nwin; out->row_blocks = d_.A.nblk + d_.B.nblk;
   out->reordered = reordered_ ? 1.0 : 0.0; out->reorder_ms = reorder_ms_;
   // which preconditioner the PCG of this handle runs with RIGHT NOW (the setting cg_precond = diagonal selects the Jacobi family; the

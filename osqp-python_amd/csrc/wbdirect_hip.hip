@@ -1,0 +1,280 @@
+// wbdirect_hip.hip -- the ADMM iteration of the Woodbury DIRECT mode in two launches (backend.h DevWbx).
+//
+// Problem class (portfolio, BASELINE configs[3]; Engine::prepare_wb decides): P diagonal, every row of A either LONG (more than kLongRow
+// entries; r <= kWbMaxRows of them: the factor-model rows and the budget row) or a ONE-entry row (the box on a variable), n <= kWbxMaxN.
+// Then  K = P + sigma I + A' diag(rho) A = D0 + A_L' diag(rho_L) A_L  with D0 diagonal, and the reduced KKT system of an ADMM iteration
+// (/root/reference/src/osqppurepy/_osqp.py:649-658 in its Schur-complement form) is solved exactly by the Woodbury identity
+//     K^-1 = D0^-1 - D0^-1 A_L' S^-1 A_L D0^-1 ,   S = diag(1 / rho_L) + A_L D0^-1 A_L'      (r x r, inverted at every rho update).
+// Round 3 ran that as FIVE launches per ADMM iteration (KB over B, three kernels of M^-1, KA over A), each a 1024-workgroup pass over
+// ~6 MB: launch latency, not bytes -- 8 us apiece, 1575 iterations, 85 ms for the portfolio QP.
+//
+// Here the iteration has the TWO global reductions the algebra really needs (g = A_L D0^-1 r_0 before h = S^-1 g; z~_L = A_L x~ before
+// the z / y update of the long rows), and a launch boundary at each:
+//     X:  [finish iteration k]   z~_L <- sum of the workgroups' partials;  z, y, v, t0 of the long rows (every workgroup, identically;
+//                                workgroup 0 stores them), of the one-entry rows of the own columns, x / dx / x_g of the own columns
+//                                                                                                       (_osqp.py:660-703)
+//         [start iteration k+1]  r_0 = sigma x - q - (P + sigma I) x_g + A' (v - t0)  on the own columns   (:649-650, reduced form,
+//                                start residual at the extrapolated x_g as in kb_rhs);  partial  g = A_L D0^-1 r_0
+//     Y:  g <- sum of partials;  h = S^-1 g;  x~ = x_g + D0^-1 (r_0 - A_L' h)  on the own columns;  partial  z~_L = A_L x~
+// A workgroup owns kWbxCols consecutive columns and keeps its dense r x kWbxCols tile of A_L in LDS for both passes of a launch (one
+// coalesced read of <= 64 KB; the zero entries of the tile cost bytes, not time: the launches are latency-bound).  Every sum has a
+// fixed order -- no atomics: results are reproducible run to run.  Same arithmetic as the five-launch form up to the order of the sums
+// (tests/test_gpu_woodbury.py compares the two).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <stdexcept>
+
+#include "../../include/osqp_hip.h"
+#include "backend.h"
+
+namespace osqp_hip {
+namespace be {
+
+#define WBX_CHECK(expr)                                                                                       \
+  do {                                                                                                        \
+    hipError_t e_ = (expr);                                                                                   \
+    if (e_ != hipSuccess) {                                                                                   \
+      char msg_[512];                                                                                         \
+      std::snprintf(msg_, sizeof(msg_), "osqp_hip: HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #expr); \
+      std::fprintf(stderr, "%s\n", msg_);                                                                     \
+      throw DeviceError(msg_);                                                                                \
+    }                                                                                                         \
+  } while (0)
+
+namespace {
+
+constexpr int kT = 256;                       // threads per workgroup
+constexpr int kR = kWbMaxRows;                // 128: rows of the tile (r of them in use)
+constexpr int kC = kWbxCols;                  // 64: columns a workgroup owns
+constexpr int kStride = kC + 1;               // LDS row stride of the tile (doubles): the row pass reads down a column of lanes
+static_assert(kT == 2 * kR && kT == 4 * kC, "thread layouts: (row, half) and (column, quarter)");
+
+struct XLds {
+  double tile[kR * kStride];                  // A_L[:, own columns], zero where A_L has no entry
+  double wv[kR];                              // X: v - t0 of the long rows;  Y: h = S^-1 g
+  double gv[kR];                              // Y: g
+  double col[kC];                             // X: D0^-1 r_0 of the own columns;  Y: x~ of the own columns
+  double red[4][kC];                          // column pass: one partial per quarter of the rows
+  double pz[2][kR];                           // row pass / partial sums: one partial per half
+};
+
+
+// tile <- global (r rows of kC doubles, contiguous per workgroup), coalesced 16-byte loads; rows r .. kR - 1 read as zero
+__device__ __forceinline__ void load_tile(const DevWbx &x, int r, XLds &L) {
+  const double2 *src = reinterpret_cast<const double2 *>(x.tile + (size_t)blockIdx.x * kR * kC);
+  const int cnt = r * kC / 2;
+  for (int e = threadIdx.x; e < kR * kC / 2; e += kT) {
+    const double2 v = e < cnt ? src[e] : make_double2(0.0, 0.0);
+    const int a = e / (kC / 2), c = 2 * (e - a * (kC / 2));
+    L.tile[a * kStride + c] = v.x; L.tile[a * kStride + c + 1] = v.y;
+  }
+}
+// out[a] = sum over the workgroups' partials part[w][a] in index order: two halves of the workgroups per row, then the halves
+__device__ __forceinline__ void fold_partials(const double *part, int G, XLds &L, double *out) {
+  const int a = threadIdx.x & (kR - 1), s = threadIdx.x >> 7;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+  int w = s;
+  for (; w + 6 < G; w += 8) {
+    const double p0 = part[(size_t)w * kR + a], p1 = part[(size_t)(w + 2) * kR + a], p2 = part[(size_t)(w + 4) * kR + a], p3 = part[(size_t)(w + 6) * kR + a];
+    acc0 += p0; acc1 += p1; acc2 += p2; acc3 += p3;
+  }
+  for (; w < G; w += 2) acc0 += part[(size_t)w * kR + a];
+  L.pz[s][a] = (acc0 + acc1) + (acc2 + acc3);
+  __syncthreads();
+  if (threadIdx.x < kR) out[a] = L.pz[0][a] + L.pz[1][a];
+  __syncthreads();
+}
+// column pass: sum_a tile[a][c] vec[a] for the own columns -> thread (c, quarter 0) returns the total
+__device__ __forceinline__ double column_pass(XLds &L, const double *vec) {
+  const int c = threadIdx.x & (kC - 1), q = threadIdx.x >> 6;
+  double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll 8
+  for (int a = q * (kR / 4); a < (q + 1) * (kR / 4); a += 2) { acc0 += L.tile[a * kStride + c] * vec[a]; acc1 += L.tile[(a + 1) * kStride + c] * vec[a + 1]; }
+  L.red[q][c] = acc0 + acc1;
+  __syncthreads();
+  return (L.red[0][c] + L.red[1][c]) + (L.red[2][c] + L.red[3][c]);
+}
+// row pass: part[blockIdx.x][a] = sum_c tile[a][c] col[c]
+__device__ __forceinline__ void row_pass(XLds &L, double *part) {
+  const int a = threadIdx.x & (kR - 1), s = threadIdx.x >> 7;
+  double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll 8
+  for (int c = s * (kC / 2); c < (s + 1) * (kC / 2); c += 2) { acc0 += L.tile[a * kStride + c] * L.col[c]; acc1 += L.tile[a * kStride + c + 1] * L.col[c + 1]; }
+  L.pz[s][a] = acc0 + acc1;
+  __syncthreads();
+  if (threadIdx.x < kR) part[(size_t)blockIdx.x * kR + a] = L.pz[0][a] + L.pz[1][a];
+}
+// the z / y update of one row (_osqp.py:682-703) and the quantities the next right-hand side needs; returns v - t0
+struct RowState { double z, y, zt; };
+__device__ __forceinline__ double row_update(const Dev &d, int i, double ztil, const RowState in, RowState &out, bool store) {
+  const double rho = d.rho[i], rinv = d.rho_inv[i], lo = d.l[i], up = d.u[i];
+  const double zr = d.alpha * ztil + (1.0 - d.alpha) * in.z;                  // :686-690
+  const double zn = fmin(fmax(zr + rinv * in.y, lo), up);                      // :674
+  const double dyi = rho * (zr - zn), yn = in.y + dyi;                         // :698-703
+  const double zg = ztil + d.theta * (ztil - in.zt);                           // A x_g (Dev::ztg)
+  const double v = rho * zn - yn, t0 = rho * zg;
+  out = RowState{zn, yn, ztil};
+  if (store) { d.y[i] = yn; d.dy[i] = dyi; d.z[i] = zn; d.zt[i] = ztil; d.v[i] = v; d.ztg[i] = zg; d.t0[i] = t0; }
+  return v - t0;
+}
+
+// X.  upd: finish an ADMM iteration (needs Y's partials);  rhs: start the next one
+template <bool UPD, bool RHS>
+__global__ __launch_bounds__(kT) void k_wbx_x(Dev d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XLds &L = *reinterpret_cast<XLds *>(smem);
+  const DevWbx &x = d.wb.x;
+  const int tid = threadIdx.x, r = d.wb.r, G = x.G, j0 = blockIdx.x * kC, n = d.n;
+  if (RHS) load_tile(x, r, L);
+  // ---- long rows
+  if (UPD) {
+    fold_partials(x.partZ, G, L, L.gv);                 // z~ of the long rows
+    if (tid < kR) {
+      double w = 0.0;
+      if (tid < r) {
+        const int i = d.wb.rows[tid];
+        const RowState in{x.ls0[3 * tid], x.ls0[3 * tid + 1], x.ls0[3 * tid + 2]};
+        RowState out;
+        w = row_update(d, i, L.gv[tid], in, out, blockIdx.x == 0);
+        if (blockIdx.x == 0) { x.ls1[3 * tid] = out.z; x.ls1[3 * tid + 1] = out.y; x.ls1[3 * tid + 2] = out.zt; }
+      }
+      L.wv[tid] = w;
+    }
+  } else if (tid < kR) {
+    double w = 0.0;
+    if (tid < r) {
+      const int i = d.wb.rows[tid];
+      w = d.v[i] - d.t0[i];
+      if (blockIdx.x == 0) { x.ls1[3 * tid] = d.z[i]; x.ls1[3 * tid + 1] = d.y[i]; x.ls1[3 * tid + 2] = d.zt[i]; }
+    }
+    L.wv[tid] = w;
+  }
+  // ---- own columns: one-entry rows and the x update (thread (c, quarter 0))
+  const int c = tid & (kC - 1), q = tid >> 6, j = j0 + c;
+  const bool own = q == 0 && j < n;
+  double ssum = 0.0, xj = 0.0, xgj = 0.0;
+  if (own) {
+    xj = d.x[j]; xgj = d.xg[j];
+    if (UPD) {
+      const double xt = d.xs[j], xn = d.alpha * xt + (1.0 - d.alpha) * xj;     // :664-668
+      d.dx[j] = xn - xj; d.x[j] = xn; xj = xn;
+      xgj = xt + d.theta * (xt - d.xsp[j]); d.xg[j] = xgj; d.xsp[j] = xt;       // next start (Dev::xg)
+      for (int k = x.sc_ptr[j]; k < x.sc_ptr[j + 1]; k++) {
+        const int i = x.sc_row[k]; const double av = x.sc_val[k];
+        const RowState in{d.z[i], d.y[i], d.zt[i]};
+        RowState out;
+        const double w = row_update(d, i, av * xt, in, out, true);
+        if (RHS) ssum += av * w;
+      }
+    } else if (RHS) {
+      for (int k = x.sc_ptr[j]; k < x.sc_ptr[j + 1]; k++) { const int i = x.sc_row[k]; ssum += x.sc_val[k] * (d.v[i] - d.t0[i]); }
+    }
+  }
+  if (UPD && blockIdx.x == 0 && tid == 0) {             // PCG statistics of the finished iteration: one exact step
+    d.flags[F_STAT_SUM] += 1; d.flags[F_STAT_SUMSQ] += 1; d.flags[F_STAT_N] += 1;
+    if (d.flags[F_STAT_MAX] < 1) d.flags[F_STAT_MAX] = 1;
+  }
+  if (!RHS) return;
+  __syncthreads();                                       // tile, wv
+  // ---- r_0 on the own columns, D0^-1 r_0, partial g
+  const double lsum = column_pass(L, L.wv);
+  if (q == 0) {
+    double yv = 0.0;
+    if (j < n) {
+      const double r0 = d.sigma * xj - d.q[j] - d.B.val[d.Bdiag[j]] * xgj + ssum + lsum;
+      d.r[j] = r0; yv = d.wb.Dinv0[j] * r0;
+    }
+    L.col[c] = yv;
+  }
+  __syncthreads();
+  row_pass(L, x.partG);
+}
+
+// Y
+__global__ __launch_bounds__(kT) void k_wbx_y(Dev d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XLds &L = *reinterpret_cast<XLds *>(smem);
+  const DevWbx &x = d.wb.x;
+  const int tid = threadIdx.x, r = d.wb.r, G = x.G, j0 = blockIdx.x * kC, n = d.n;
+  load_tile(x, r, L);
+  fold_partials(x.partG, G, L, L.gv);                    // g (rows >= r: zero partials)
+  if (tid < kR) {                                        // h = S^-1 g  (S^-1 symmetric: column a is read along a, coalesced)
+    double acc0 = 0.0, acc1 = 0.0;
+    if (tid < r) {
+      int b = 0;
+      for (; b + 1 < r; b += 2) { acc0 += d.wb.Sinv[(size_t)b * r + tid] * L.gv[b]; acc1 += d.wb.Sinv[(size_t)(b + 1) * r + tid] * L.gv[b + 1]; }
+      if (b < r) acc0 += d.wb.Sinv[(size_t)b * r + tid] * L.gv[b];
+    }
+    L.wv[tid] = acc0 + acc1;
+  }
+  __syncthreads();
+  const int c = tid & (kC - 1), q = tid >> 6, j = j0 + c;
+  const double s = column_pass(L, L.wv);                 // (A_L' h) on the own columns
+  if (q == 0) {
+    double xt = 0.0;
+    if (j < n) {
+      const double u = d.wb.Dinv0[j] * (d.r[j] - s);
+      xt = d.xg[j] + u;
+      d.xs[j] = xt; d.uu[j] = u;
+    }
+    L.col[c] = xt;
+  }
+  __syncthreads();
+  row_pass(L, x.partZ);                                  // partial z~ of the long rows
+  if (blockIdx.x == 0) {
+    if (tid < 3 * r) x.ls0[tid] = x.ls1[tid];            // the long rows' state X will read: handed over outside X (no workgroup of X reads what X writes)
+    if (tid + kT < 3 * r) x.ls0[tid + kT] = x.ls1[tid + kT];
+    if (tid == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = 1; }
+  }
+}
+
+// tiles and one-entry rows <- A.val (after assembly / equilibration / matrix updates)
+__global__ __launch_bounds__(kT) void k_wbx_fill(Dev d) {
+  const DevWbx &x = d.wb.x;
+  const DevCsr &AL = d.wb.AL;
+  const int stride = gridDim.x * kT;
+  for (int k = blockIdx.x * kT + threadIdx.x; k < AL.nnz; k += stride) {
+    // row of entry k: binary search in the r + 1 row pointers
+    int lo = 0, hi = d.wb.r;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (AL.rowptr[mid] <= k) lo = mid; else hi = mid; }
+    const int j = AL.col[k];
+    x.tile[((size_t)(j / kC) * kR + lo) * kC + (j % kC)] = d.A.val[d.wb.al_src[k]];
+  }
+  for (int k = blockIdx.x * kT + threadIdx.x; k < x.nsc; k += stride) x.sc_val[k] = d.A.val[x.sc_src[k]];
+}
+
+}  // namespace
+
+bool wbx_supported() { return true; }
+void wbx_refresh(Dev &d) {
+  if (!d.wb.on || !d.wb.x.on) return;
+  WBX_CHECK(hipSetDevice(d.device));
+  hipLaunchKernelGGL(k_wbx_fill, dim3(256), dim3(kT), 0, static_cast<hipStream_t>(d.stream), d);
+}
+void wbx_init(Dev &d) {                        // (more than the default 64 KB of dynamic LDS: gfx950 has 160 KB per CU, one workgroup per CU here)
+  WBX_CHECK(hipSetDevice(d.device));
+  const int lds = (int)sizeof(XLds);
+  WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_x<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_x<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_x<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_y), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+}
+// One chunk of `niter` ADMM iterations:  X(rhs), { Y, X(update + rhs) } x (niter - 1), Y, X(update)  -- 2 niter + 1 launches
+void wbx_chunk(Dev &d, int niter) {
+  if (niter <= 0) return;
+  WBX_CHECK(hipSetDevice(d.device));
+  hipStream_t s = static_cast<hipStream_t>(d.stream);
+  const size_t lds = sizeof(XLds);
+  const dim3 grid(d.wb.x.G), block(kT);
+  hipLaunchKernelGGL((k_wbx_x<false, true>), grid, block, lds, s, d);
+  for (int it = 1; it < niter; it++) {
+    hipLaunchKernelGGL(k_wbx_y, grid, block, lds, s, d);
+    hipLaunchKernelGGL((k_wbx_x<true, true>), grid, block, lds, s, d);
+  }
+  hipLaunchKernelGGL(k_wbx_y, grid, block, lds, s, d);
+  hipLaunchKernelGGL((k_wbx_x<true, false>), grid, block, lds, s, d);
+}
+
+}  // namespace be
+}  // namespace osqp_hip

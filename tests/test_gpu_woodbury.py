@@ -154,3 +154,31 @@ def test_large_rank_correction_with_dense_P_is_only_a_preconditioner():
     print('dense P: %d iterations, %.2f PCG each, rows %d direct %d, |dx| %.2e |dy| %.2e' % (r.info.iter, s['pcg_iters_total'] / r.info.iter, s['woodbury_rows'], s['woodbury_direct'], _rel(r.x, xo), _rel(r.y, yo)))
     assert s['woodbury_rows'] == 300 and s['woodbury_direct'] == 0
     assert _rel(r.x, xo) < 5e-5 and _rel(r.y, yo) < 2e-4
+
+
+@pytest.mark.parametrize('size', [(400, 20), (2000, 50), (10000, 100)])
+def test_direct_mode_in_two_launches_equals_the_five_launch_form(size):
+    """wbdirect_hip.hip (X / Y: two launches per ADMM iteration, the dense tile of the long rows in LDS, partial reductions folded in index
+    order) against the r03 form of the same direct mode (KB, three kernels of M^-1, KA): same algorithm, other summation order -- equal
+    ADMM iteration counts, x / y to 1e-9 of the solution's scale, the oracle's solution at the usual tolerance; updates of q / bounds, a rho
+    update and a warm start go through both."""
+    P, q, A, l, u = problems.portfolio_qp(*size)
+    rng = np.random.default_rng(5)
+    out = {}
+    for fused in (0, 1):
+        with _env(OSQP_HIP_WOODBURY_FUSED=str(fused)):
+            m, r, s = _solve(P, q, A, l, u, 1, 1)
+            assert r.info.status_val == 1 and s['woodbury_direct'] == (2 if fused else 1), (fused, s['woodbury_direct'])
+            q2 = q * (1.0 + 0.05 * np.sin(np.arange(len(q))))
+            m.update(q=q2); r2 = m.solve()
+            m.update_settings(rho=0.37); m.warm_start(x=0.5 * r.x, y=0.5 * r.y); r3 = m.solve()
+            out[fused] = (r, r2, r3, s, m._solver.hip_stats())
+    for k in range(3):
+        a, b = out[0][k], out[1][k]
+        assert a.info.status_val == b.info.status_val == 1, k
+        assert abs(a.info.iter - b.info.iter) <= 25, (k, a.info.iter, b.info.iter)
+        assert _rel(b.x, a.x) < 1e-7 and _rel(b.y, a.y) < 1e-6, (k, _rel(b.x, a.x), _rel(b.y, a.y))
+    assert out[1][3]['kernel_launches'] < 0.55 * out[0][3]['kernel_launches']
+    if size[0] <= 2000:
+        xo, yo, io = Oracle().setup(P, q, A, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000, adaptive_rho_interval=50).solve()
+        assert io.status_val == SOLVED and _rel(out[1][0].x, xo) < 5e-5 and _rel(out[1][0].y, yo) < 2e-4
