@@ -121,6 +121,7 @@ struct DevWbx {
   double *ls0 = nullptr, *ls1 = nullptr;  // [3 r] {z, y, z~} of the long rows: read by X from ls0, written by X (workgroup 0) to ls1, handed over by Y
   int *sc_ptr = nullptr, *sc_row = nullptr, *sc_src = nullptr;   // per column: its one-entry rows (CSR over columns) and where their values sit in A.val
   double *sc_val = nullptr;
+  double *bjj = nullptr;                  // [n] P_jj + sigma (the diagonal of B), refreshed with the tiles
 };
 struct DevWb {
   int on = 0, r = 0;

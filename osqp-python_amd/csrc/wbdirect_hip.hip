@@ -60,27 +60,40 @@ struct XLds {
 };
 
 
+// These launches are chains of memory round trips, not streams: every loop over global memory below first REQUESTS a batch of kBatch
+// values (clamped addresses, no branch around a load) and only then consumes it -- one latency per batch instead of one per value.
+constexpr int kBatch = 16;
 // tile <- global (r rows of kC doubles, contiguous per workgroup), coalesced 16-byte loads; rows r .. kR - 1 read as zero
-__device__ __forceinline__ void load_tile(const DevWbx &x, int r, XLds &L) {
+struct TileRegs { double2 v[kR * kC / 2 / kT]; };
+__device__ __forceinline__ TileRegs tile_issue(const DevWbx &x, int r) {
   const double2 *src = reinterpret_cast<const double2 *>(x.tile + (size_t)blockIdx.x * kR * kC);
   const int cnt = r * kC / 2;
-  for (int e = threadIdx.x; e < kR * kC / 2; e += kT) {
-    const double2 v = e < cnt ? src[e] : make_double2(0.0, 0.0);
-    const int a = e / (kC / 2), c = 2 * (e - a * (kC / 2));
-    L.tile[a * kStride + c] = v.x; L.tile[a * kStride + c + 1] = v.y;
+  TileRegs t;
+#pragma unroll
+  for (int u = 0; u < kR * kC / 2 / kT; u++) { const int e = threadIdx.x + u * kT; t.v[u] = src[min(e, cnt - 1)]; }
+  return t;
+}
+__device__ __forceinline__ void tile_store(const TileRegs &t, int r, XLds &L) {
+  const int cnt = r * kC / 2;
+#pragma unroll
+  for (int u = 0; u < kR * kC / 2 / kT; u++) {
+    const int e = threadIdx.x + u * kT, a = e / (kC / 2), c = 2 * (e - a * (kC / 2));
+    const bool ok = e < cnt;
+    L.tile[a * kStride + c] = ok ? t.v[u].x : 0.0; L.tile[a * kStride + c + 1] = ok ? t.v[u].y : 0.0;
   }
 }
 // out[a] = sum over the workgroups' partials part[w][a] in index order: two halves of the workgroups per row, then the halves
 __device__ __forceinline__ void fold_partials(const double *part, int G, XLds &L, double *out) {
   const int a = threadIdx.x & (kR - 1), s = threadIdx.x >> 7;
-  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-  int w = s;
-  for (; w + 6 < G; w += 8) {
-    const double p0 = part[(size_t)w * kR + a], p1 = part[(size_t)(w + 2) * kR + a], p2 = part[(size_t)(w + 4) * kR + a], p3 = part[(size_t)(w + 6) * kR + a];
-    acc0 += p0; acc1 += p1; acc2 += p2; acc3 += p3;
+  double acc = 0.0;
+  for (int w0 = s; w0 < G; w0 += 2 * kBatch) {
+    double p[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) p[k] = part[(size_t)min(w0 + 2 * k, G - 1) * kR + a];
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) acc += (w0 + 2 * k < G) ? p[k] : 0.0;
   }
-  for (; w < G; w += 2) acc0 += part[(size_t)w * kR + a];
-  L.pz[s][a] = (acc0 + acc1) + (acc2 + acc3);
+  L.pz[s][a] = acc;
   __syncthreads();
   if (threadIdx.x < kR) out[a] = L.pz[0][a] + L.pz[1][a];
   __syncthreads();
@@ -126,7 +139,8 @@ __global__ __launch_bounds__(kT) void k_wbx_x(Dev d) {
   XLds &L = *reinterpret_cast<XLds *>(smem);
   const DevWbx &x = d.wb.x;
   const int tid = threadIdx.x, r = d.wb.r, G = x.G, j0 = blockIdx.x * kC, n = d.n;
-  if (RHS) load_tile(x, r, L);
+  TileRegs tr;
+  if (RHS) tr = tile_issue(x, r);                        // requested first: consumed after the fold of the partials
   // ---- long rows
   if (UPD) {
     fold_partials(x.partZ, G, L, L.gv);                 // z~ of the long rows
@@ -153,9 +167,10 @@ __global__ __launch_bounds__(kT) void k_wbx_x(Dev d) {
   // ---- own columns: one-entry rows and the x update (thread (c, quarter 0))
   const int c = tid & (kC - 1), q = tid >> 6, j = j0 + c;
   const bool own = q == 0 && j < n;
-  double ssum = 0.0, xj = 0.0, xgj = 0.0;
+  double ssum = 0.0, xj = 0.0, xgj = 0.0, qj = 0.0, bjj = 0.0;
   if (own) {
     xj = d.x[j]; xgj = d.xg[j];
+    if (RHS) { qj = d.q[j]; bjj = x.bjj[j]; }
     if (UPD) {
       const double xt = d.xs[j], xn = d.alpha * xt + (1.0 - d.alpha) * xj;     // :664-668
       d.dx[j] = xn - xj; d.x[j] = xn; xj = xn;
@@ -176,13 +191,14 @@ __global__ __launch_bounds__(kT) void k_wbx_x(Dev d) {
     if (d.flags[F_STAT_MAX] < 1) d.flags[F_STAT_MAX] = 1;
   }
   if (!RHS) return;
+  tile_store(tr, r, L);
   __syncthreads();                                       // tile, wv
   // ---- r_0 on the own columns, D0^-1 r_0, partial g
   const double lsum = column_pass(L, L.wv);
   if (q == 0) {
     double yv = 0.0;
     if (j < n) {
-      const double r0 = d.sigma * xj - d.q[j] - d.B.val[d.Bdiag[j]] * xgj + ssum + lsum;
+      const double r0 = d.sigma * xj - qj - bjj * xgj + ssum + lsum;
       d.r[j] = r0; yv = d.wb.Dinv0[j] * r0;
     }
     L.col[c] = yv;
@@ -197,25 +213,38 @@ __global__ __launch_bounds__(kT) void k_wbx_y(Dev d) {
   XLds &L = *reinterpret_cast<XLds *>(smem);
   const DevWbx &x = d.wb.x;
   const int tid = threadIdx.x, r = d.wb.r, G = x.G, j0 = blockIdx.x * kC, n = d.n;
-  load_tile(x, r, L);
+  const TileRegs tr = tile_issue(x, r);
+  // S^-1 (symmetric: column a is read along a, coalesced): thread (a, half s) takes the rows b = s mod 2; requested ahead of the fold
+  const int ha = tid & (kR - 1), hs = tid >> 7, hac = min(ha, r - 1);
+  constexpr int kSb = kR / 2 / kBatch;                   // batches of S^-1 entries per thread (kR / 2 rows each)
+  double sv[kSb][kBatch];
+#pragma unroll
+  for (int bt = 0; bt < kSb; bt++)
+#pragma unroll
+    for (int k = 0; k < kBatch; k++) sv[bt][k] = d.wb.Sinv[(size_t)min(hs + 2 * (bt * kBatch + k), r - 1) * r + hac];
+  const int jy = j0 + (tid & (kC - 1));
+  double rj = 0.0, dj = 0.0, xgy = 0.0;
+  if ((tid >> 6) == 0 && jy < n) { rj = d.r[jy]; dj = d.wb.Dinv0[jy]; xgy = d.xg[jy]; }
   fold_partials(x.partG, G, L, L.gv);                    // g (rows >= r: zero partials)
-  if (tid < kR) {                                        // h = S^-1 g  (S^-1 symmetric: column a is read along a, coalesced)
-    double acc0 = 0.0, acc1 = 0.0;
-    if (tid < r) {
-      int b = 0;
-      for (; b + 1 < r; b += 2) { acc0 += d.wb.Sinv[(size_t)b * r + tid] * L.gv[b]; acc1 += d.wb.Sinv[(size_t)(b + 1) * r + tid] * L.gv[b + 1]; }
-      if (b < r) acc0 += d.wb.Sinv[(size_t)b * r + tid] * L.gv[b];
-    }
-    L.wv[tid] = acc0 + acc1;
+  tile_store(tr, r, L);
+  {
+    double acc = 0.0;
+#pragma unroll
+    for (int bt = 0; bt < kSb; bt++)
+#pragma unroll
+      for (int k = 0; k < kBatch; k++) { const int b = hs + 2 * (bt * kBatch + k); acc += b < r ? sv[bt][k] * L.gv[b] : 0.0; }
+    L.pz[hs][ha] = acc;
   }
+  __syncthreads();
+  if (tid < kR) L.wv[tid] = tid < r ? L.pz[0][tid] + L.pz[1][tid] : 0.0;      // h = S^-1 g
   __syncthreads();
   const int c = tid & (kC - 1), q = tid >> 6, j = j0 + c;
   const double s = column_pass(L, L.wv);                 // (A_L' h) on the own columns
   if (q == 0) {
     double xt = 0.0;
     if (j < n) {
-      const double u = d.wb.Dinv0[j] * (d.r[j] - s);
-      xt = d.xg[j] + u;
+      const double u = dj * (rj - s);
+      xt = xgy + u;
       d.xs[j] = xt; d.uu[j] = u;
     }
     L.col[c] = xt;
@@ -242,6 +271,7 @@ __global__ __launch_bounds__(kT) void k_wbx_fill(Dev d) {
     x.tile[((size_t)(j / kC) * kR + lo) * kC + (j % kC)] = d.A.val[d.wb.al_src[k]];
   }
   for (int k = blockIdx.x * kT + threadIdx.x; k < x.nsc; k += stride) x.sc_val[k] = d.A.val[x.sc_src[k]];
+  for (int j = blockIdx.x * kT + threadIdx.x; j < d.n; j += stride) x.bjj[j] = d.B.val[d.Bdiag[j]];      // P_jj + sigma (P is diagonal)
 }
 
 }  // namespace
