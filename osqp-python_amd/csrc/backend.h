@@ -116,6 +116,7 @@ constexpr int kWbxCols = 64;
 constexpr int kWbxMaxN = 16384;           // at most 256 workgroups: every consumer folds all partials (G x kWbMaxRows doubles)
 struct DevWbx {
   int on = 0, G = 0, nsc = 0;
+  double *tile2 = nullptr;                // [G][kWbMaxRows][kWbxCols] S^-1 A_L by column block (wbx_factor, after every inversion of S)
   double *tile = nullptr;                 // [G][kWbMaxRows][kWbxCols] A_L by column block, zero where A_L has no entry (rows >= r unused)
   double *partG = nullptr, *partZ = nullptr;   // [G][kWbMaxRows] partial sums of the two reductions
   double *ls0 = nullptr, *ls1 = nullptr;  // [3 r] {z, y, z~} of the long rows: read by X from ls0, written by X (workgroup 0) to ls1, handed over by Y
@@ -308,6 +309,7 @@ bool wb_supported();
 bool wbx_supported();                      // the two-launch direct mode exists (false: the host simulator)
 void wbx_init(Dev &d);                     // once per handle, after the plan is uploaded (LDS attribute of its kernels on d.device)
 void wbx_refresh(Dev &d);                  // tiles / one-entry-row values <- A.val
+void wbx_factor(Dev &d);                   // tile2 = S^-1 A_L (after S^-1 has changed)
 void wbx_chunk(Dev &d, int niter);         // niter ADMM iterations: X(rhs), { Y, X } x (niter - 1), Y, X(update): 2 niter + 1 launches on d.stream
 bool wb_large_supported();                 // the dense solver libraries could be loaded                       // Woodbury preconditioner available (false: the host simulator)
 void wb_refresh(Dev &d);                   // wb.AL / ALT / WT values <- A.val (after assembly / equilibration / matrix updates)

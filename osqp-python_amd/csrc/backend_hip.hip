@@ -2313,6 +2313,7 @@ static void wb_factor(Dev &d) {
   }
   HIP_CHECK(hipMemcpyAsync(w.Sinv, Si.data(), sizeof(double) * Si.size(), hipMemcpyHostToDevice, st(d)));
   HIP_CHECK(hipStreamSynchronize(st(d)));
+  wbx_factor(d);                                              // (two-launch direct mode: S^-1 A_L per column block)
 }
 void precond(Dev &d, int diagonal) {
   HIP_CHECK(hipSetDevice(d.device));

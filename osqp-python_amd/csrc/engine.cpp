@@ -199,7 +199,7 @@ void Engine::free_all() {
                   d_.dy, d_.xs, d_.xg, d_.xsp, d_.ztg, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.uu2, d_.ms, d_.part, d_.res,
                   d_.scal, d_.flags, d_.slot, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB,
                   d_.wb.AL.rowptr, d_.wb.AL.col, d_.wb.AL.blkdesc, d_.wb.AL.runinfo, d_.wb.AL.val, d_.wb.ALT.rowptr, d_.wb.ALT.col, d_.wb.ALT.blkdesc, d_.wb.ALT.runinfo, d_.wb.ALT.val,
-                  d_.wb.al_src, d_.wb.alt_src, d_.wb.islong, d_.wb.rows, d_.wb.WT, d_.wb.S, d_.wb.Sinv, d_.wb.g, d_.wb.h, d_.wb.Dinv0, d_.wb.colmap, d_.wb.W, d_.wb.pv, d_.wb.info, d_.wb.x.tile, d_.wb.x.partG, d_.wb.x.partZ, d_.wb.x.ls0, d_.wb.x.ls1, d_.wb.x.sc_ptr, d_.wb.x.sc_row, d_.wb.x.sc_src, d_.wb.x.sc_val, d_.wb.x.bjj,
+                  d_.wb.al_src, d_.wb.alt_src, d_.wb.islong, d_.wb.rows, d_.wb.WT, d_.wb.S, d_.wb.Sinv, d_.wb.g, d_.wb.h, d_.wb.Dinv0, d_.wb.colmap, d_.wb.W, d_.wb.pv, d_.wb.info, d_.wb.x.tile, d_.wb.x.tile2, d_.wb.x.partG, d_.wb.x.partZ, d_.wb.x.ls0, d_.wb.x.ls1, d_.wb.x.sc_ptr, d_.wb.x.sc_row, d_.wb.x.sc_src, d_.wb.x.sc_val, d_.wb.x.bjj,
                   d_.ctl, d_.f1.blk, d_.f1.ent, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.va, d_pc_, d_pr_};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   be::destroy(d_);
@@ -681,6 +681,7 @@ void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj
       DevWbx &x = w.x;
       x.G = (n + kWbxCols - 1) / kWbxCols; x.nsc = (int)sc_row.size();
       x.tile = dev_vec<double>(d_, (size_t)x.G * kWbMaxRows * kWbxCols);       // (zero-filled by the allocator: only the pattern's positions are ever written)
+      x.tile2 = dev_vec<double>(d_, (size_t)x.G * kWbMaxRows * kWbxCols);
       x.partG = dev_vec<double>(d_, (size_t)x.G * kWbMaxRows); x.partZ = dev_vec<double>(d_, (size_t)x.G * kWbMaxRows);
       x.ls0 = dev_vec<double>(d_, 3 * (size_t)kWbMaxRows); x.ls1 = dev_vec<double>(d_, 3 * (size_t)kWbMaxRows);
       x.sc_ptr = up_i(sc_ptr); x.sc_row = up_i(sc_row); x.sc_src = up_i(sc_src); x.sc_val = dev_vec<double>(d_, sc_row.size());

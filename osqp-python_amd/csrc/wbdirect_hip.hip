@@ -57,53 +57,61 @@ struct XLds {
   double col[kC];                             // X: D0^-1 r_0 of the own columns;  Y: x~ of the own columns
   double red[4][kC];                          // column pass: one partial per quarter of the rows
   double pz[2][kR];                           // row pass / partial sums: one partial per half
+  double pz4[4][kR / 2];                      // fold of the partials: odd rows, one partial per slice
 };
+static_assert(kC == kR / 2, "fold_partials keeps the even rows of a slice in red[s][0 .. kC)");
+struct YLds : XLds { double tile2[kR * kStride]; };      // Y also holds S^-1 A_L of its columns (refreshed at every rho update)
 
 
-// These launches are chains of memory round trips, not streams: every loop over global memory below first REQUESTS a batch of kBatch
-// values (clamped addresses, no branch around a load) and only then consumes it -- one latency per batch instead of one per value.
-constexpr int kBatch = 16;
+// These launches are chains of memory round trips, not streams: every loop over global memory below first REQUESTS a batch of
+// values (kFoldBatch, a whole tile; clamped addresses, no branch around a load) and only then consumes it -- one latency per batch instead of one per value.
 // tile <- global (r rows of kC doubles, contiguous per workgroup), coalesced 16-byte loads; rows r .. kR - 1 read as zero
 struct TileRegs { double2 v[kR * kC / 2 / kT]; };
-__device__ __forceinline__ TileRegs tile_issue(const DevWbx &x, int r) {
-  const double2 *src = reinterpret_cast<const double2 *>(x.tile + (size_t)blockIdx.x * kR * kC);
+__device__ __forceinline__ TileRegs tile_issue(const double *tiles, int r) {
+  const double2 *src = reinterpret_cast<const double2 *>(tiles + (size_t)blockIdx.x * kR * kC);
   const int cnt = r * kC / 2;
   TileRegs t;
 #pragma unroll
   for (int u = 0; u < kR * kC / 2 / kT; u++) { const int e = threadIdx.x + u * kT; t.v[u] = src[min(e, cnt - 1)]; }
   return t;
 }
-__device__ __forceinline__ void tile_store(const TileRegs &t, int r, XLds &L) {
+__device__ __forceinline__ void tile_store(const TileRegs &t, int r, double *dst) {
   const int cnt = r * kC / 2;
 #pragma unroll
   for (int u = 0; u < kR * kC / 2 / kT; u++) {
     const int e = threadIdx.x + u * kT, a = e / (kC / 2), c = 2 * (e - a * (kC / 2));
     const bool ok = e < cnt;
-    L.tile[a * kStride + c] = ok ? t.v[u].x : 0.0; L.tile[a * kStride + c + 1] = ok ? t.v[u].y : 0.0;
+    dst[a * kStride + c] = ok ? t.v[u].x : 0.0; dst[a * kStride + c + 1] = ok ? t.v[u].y : 0.0;
   }
 }
-// out[a] = sum over the workgroups' partials part[w][a] in index order: two halves of the workgroups per row, then the halves
+// out[a] = sum over the workgroups' partials part[w][a]: thread (row pair, slice s of four) takes the workgroups w = s mod 4 with 16-byte
+// loads, kFoldBatch of them in flight; the four slices are added in index order (fixed order throughout: deterministic)
+constexpr int kFoldBatch = 20;
 __device__ __forceinline__ void fold_partials(const double *part, int G, XLds &L, double *out) {
-  const int a = threadIdx.x & (kR - 1), s = threadIdx.x >> 7;
-  double acc = 0.0;
-  for (int w0 = s; w0 < G; w0 += 2 * kBatch) {
-    double p[kBatch];
+  const int a2 = threadIdx.x & (kR / 2 - 1), s = threadIdx.x >> 6;
+  const double2 *p2 = reinterpret_cast<const double2 *>(part);
+  double acc0 = 0.0, acc1 = 0.0;
+  for (int w0 = s; w0 < G; w0 += 4 * kFoldBatch) {
+    double2 p[kFoldBatch];
 #pragma unroll
-    for (int k = 0; k < kBatch; k++) p[k] = part[(size_t)min(w0 + 2 * k, G - 1) * kR + a];
+    for (int k = 0; k < kFoldBatch; k++) p[k] = p2[(size_t)min(w0 + 4 * k, G - 1) * (kR / 2) + a2];
 #pragma unroll
-    for (int k = 0; k < kBatch; k++) acc += (w0 + 2 * k < G) ? p[k] : 0.0;
+    for (int k = 0; k < kFoldBatch; k++) { const bool ok = w0 + 4 * k < G; acc0 += ok ? p[k].x : 0.0; acc1 += ok ? p[k].y : 0.0; }
   }
-  L.pz[s][a] = acc;
+  L.red[s][a2] = acc0; L.pz4[s][a2] = acc1;                  // (red: even rows, pz4: odd rows; kC = kR / 2 slots per slice)
   __syncthreads();
-  if (threadIdx.x < kR) out[a] = L.pz[0][a] + L.pz[1][a];
+  if (threadIdx.x < kR / 2) {
+    out[2 * a2] = (L.red[0][a2] + L.red[1][a2]) + (L.red[2][a2] + L.red[3][a2]);
+    out[2 * a2 + 1] = (L.pz4[0][a2] + L.pz4[1][a2]) + (L.pz4[2][a2] + L.pz4[3][a2]);
+  }
   __syncthreads();
 }
 // column pass: sum_a tile[a][c] vec[a] for the own columns -> thread (c, quarter 0) returns the total
-__device__ __forceinline__ double column_pass(XLds &L, const double *vec) {
+__device__ __forceinline__ double column_pass(XLds &L, const double *tile, const double *vec) {
   const int c = threadIdx.x & (kC - 1), q = threadIdx.x >> 6;
   double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll 8
-  for (int a = q * (kR / 4); a < (q + 1) * (kR / 4); a += 2) { acc0 += L.tile[a * kStride + c] * vec[a]; acc1 += L.tile[(a + 1) * kStride + c] * vec[a + 1]; }
+  for (int a = q * (kR / 4); a < (q + 1) * (kR / 4); a += 2) { acc0 += tile[a * kStride + c] * vec[a]; acc1 += tile[(a + 1) * kStride + c] * vec[a + 1]; }
   L.red[q][c] = acc0 + acc1;
   __syncthreads();
   return (L.red[0][c] + L.red[1][c]) + (L.red[2][c] + L.red[3][c]);
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(kT) void k_wbx_x(Dev d) {
   const DevWbx &x = d.wb.x;
   const int tid = threadIdx.x, r = d.wb.r, G = x.G, j0 = blockIdx.x * kC, n = d.n;
   TileRegs tr;
-  if (RHS) tr = tile_issue(x, r);                        // requested first: consumed after the fold of the partials
+  if (RHS) tr = tile_issue(x.tile, r);                        // requested first: consumed after the fold of the partials
   // ---- long rows
   if (UPD) {
     fold_partials(x.partZ, G, L, L.gv);                 // z~ of the long rows
@@ -191,10 +199,10 @@ __global__ __launch_bounds__(kT) void k_wbx_x(Dev d) {
     if (d.flags[F_STAT_MAX] < 1) d.flags[F_STAT_MAX] = 1;
   }
   if (!RHS) return;
-  tile_store(tr, r, L);
+  tile_store(tr, r, L.tile);
   __syncthreads();                                       // tile, wv
   // ---- r_0 on the own columns, D0^-1 r_0, partial g
-  const double lsum = column_pass(L, L.wv);
+  const double lsum = column_pass(L, L.tile, L.wv);
   if (q == 0) {
     double yv = 0.0;
     if (j < n) {
@@ -207,39 +215,20 @@ __global__ __launch_bounds__(kT) void k_wbx_x(Dev d) {
   row_pass(L, x.partG);
 }
 
-// Y
+// Y.  (A_L' S^-1 g is taken as (S^-1 A_L)' g with the second tile: no r x r product, no S^-1 traffic on the iteration's critical path)
 __global__ __launch_bounds__(kT) void k_wbx_y(Dev d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  XLds &L = *reinterpret_cast<XLds *>(smem);
+  YLds &L = *reinterpret_cast<YLds *>(smem);
   const DevWbx &x = d.wb.x;
   const int tid = threadIdx.x, r = d.wb.r, G = x.G, j0 = blockIdx.x * kC, n = d.n;
-  const TileRegs tr = tile_issue(x, r);
-  // S^-1 (symmetric: column a is read along a, coalesced): thread (a, half s) takes the rows b = s mod 2; requested ahead of the fold
-  const int ha = tid & (kR - 1), hs = tid >> 7, hac = min(ha, r - 1);
-  constexpr int kSb = kR / 2 / kBatch;                   // batches of S^-1 entries per thread (kR / 2 rows each)
-  double sv[kSb][kBatch];
-#pragma unroll
-  for (int bt = 0; bt < kSb; bt++)
-#pragma unroll
-    for (int k = 0; k < kBatch; k++) sv[bt][k] = d.wb.Sinv[(size_t)min(hs + 2 * (bt * kBatch + k), r - 1) * r + hac];
-  const int jy = j0 + (tid & (kC - 1));
-  double rj = 0.0, dj = 0.0, xgy = 0.0;
-  if ((tid >> 6) == 0 && jy < n) { rj = d.r[jy]; dj = d.wb.Dinv0[jy]; xgy = d.xg[jy]; }
-  fold_partials(x.partG, G, L, L.gv);                    // g (rows >= r: zero partials)
-  tile_store(tr, r, L);
-  {
-    double acc = 0.0;
-#pragma unroll
-    for (int bt = 0; bt < kSb; bt++)
-#pragma unroll
-      for (int k = 0; k < kBatch; k++) { const int b = hs + 2 * (bt * kBatch + k); acc += b < r ? sv[bt][k] * L.gv[b] : 0.0; }
-    L.pz[hs][ha] = acc;
-  }
-  __syncthreads();
-  if (tid < kR) L.wv[tid] = tid < r ? L.pz[0][tid] + L.pz[1][tid] : 0.0;      // h = S^-1 g
-  __syncthreads();
+  const TileRegs tr = tile_issue(x.tile, r), tr2 = tile_issue(x.tile2, r);
   const int c = tid & (kC - 1), q = tid >> 6, j = j0 + c;
-  const double s = column_pass(L, L.wv);                 // (A_L' h) on the own columns
+  double rj = 0.0, dj = 0.0, xgy = 0.0;
+  if (q == 0 && j < n) { rj = d.r[j]; dj = d.wb.Dinv0[j]; xgy = d.xg[j]; }
+  fold_partials(x.partG, G, L, L.gv);                    // g (rows >= r: zero partials)
+  tile_store(tr, r, L.tile); tile_store(tr2, r, L.tile2);
+  __syncthreads();
+  const double s = column_pass(L, L.tile2, L.gv);        // (A_L' S^-1 g) on the own columns
   if (q == 0) {
     double xt = 0.0;
     if (j < n) {
@@ -255,6 +244,25 @@ __global__ __launch_bounds__(kT) void k_wbx_y(Dev d) {
     if (tid < 3 * r) x.ls0[tid] = x.ls1[tid];            // the long rows' state X will read: handed over outside X (no workgroup of X reads what X writes)
     if (tid + kT < 3 * r) x.ls0[tid + kT] = x.ls1[tid + kT];
     if (tid == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = 1; }
+  }
+}
+
+// tile2 <- S^-1 tile (per column block; after every inversion of S): thread (c, quarter q) forms the rows a = q mod 4 of its column
+__global__ __launch_bounds__(kT) void k_wbx_t2(Dev d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XLds &L = *reinterpret_cast<XLds *>(smem);
+  const DevWbx &x = d.wb.x;
+  const int r = d.wb.r, c = threadIdx.x & (kC - 1), q = threadIdx.x >> 6;
+  tile_store(tile_issue(x.tile, r), r, L.tile);
+  __syncthreads();
+  double *out = x.tile2 + (size_t)blockIdx.x * kR * kC;
+  for (int a = q; a < r; a += 4) {
+    const double *srow = d.wb.Sinv + (size_t)a * r;      // (workgroup-uniform per a: scalar loads)
+    double acc0 = 0.0, acc1 = 0.0;
+    int b = 0;
+    for (; b + 1 < r; b += 2) { acc0 += srow[b] * L.tile[b * kStride + c]; acc1 += srow[b + 1] * L.tile[(b + 1) * kStride + c]; }
+    if (b < r) acc0 += srow[b] * L.tile[b * kStride + c];
+    out[(size_t)a * kC + c] = acc0 + acc1;
   }
 }
 
@@ -282,13 +290,19 @@ void wbx_refresh(Dev &d) {
   WBX_CHECK(hipSetDevice(d.device));
   hipLaunchKernelGGL(k_wbx_fill, dim3(256), dim3(kT), 0, static_cast<hipStream_t>(d.stream), d);
 }
+void wbx_factor(Dev &d) {                      // after S^-1 has changed (rho update): tile2 = S^-1 A_L
+  if (!d.wb.on || !d.wb.x.on) return;
+  WBX_CHECK(hipSetDevice(d.device));
+  hipLaunchKernelGGL(k_wbx_t2, dim3(d.wb.x.G), dim3(kT), sizeof(XLds), static_cast<hipStream_t>(d.stream), d);
+}
 void wbx_init(Dev &d) {                        // (more than the default 64 KB of dynamic LDS: gfx950 has 160 KB per CU, one workgroup per CU here)
   WBX_CHECK(hipSetDevice(d.device));
   const int lds = (int)sizeof(XLds);
   WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_x<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_x<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_x<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_y), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_t2), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_y), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(YLds)));
 }
 // One chunk of `niter` ADMM iterations:  X(rhs), { Y, X(update + rhs) } x (niter - 1), Y, X(update)  -- 2 niter + 1 launches
 void wbx_chunk(Dev &d, int niter) {
@@ -299,10 +313,10 @@ void wbx_chunk(Dev &d, int niter) {
   const dim3 grid(d.wb.x.G), block(kT);
   hipLaunchKernelGGL((k_wbx_x<false, true>), grid, block, lds, s, d);
   for (int it = 1; it < niter; it++) {
-    hipLaunchKernelGGL(k_wbx_y, grid, block, lds, s, d);
+    hipLaunchKernelGGL(k_wbx_y, grid, block, sizeof(YLds), s, d);
     hipLaunchKernelGGL((k_wbx_x<true, true>), grid, block, lds, s, d);
   }
-  hipLaunchKernelGGL(k_wbx_y, grid, block, lds, s, d);
+  hipLaunchKernelGGL(k_wbx_y, grid, block, sizeof(YLds), s, d);
   hipLaunchKernelGGL((k_wbx_x<true, false>), grid, block, lds, s, d);
 }
 
