@@ -326,6 +326,10 @@ typedef struct {
   OSQPInt finish_pairs; OSQPInt poll_sleep_us;      /* device-driven chunks: a boundary group goes out when at most finish_pairs slot pairs are missing; pause between polls */
   /* diagnostics */
   OSQPInt slot_log, setup_timing, batch_timing, woodbury_log;
+  OSQPFloat woodbury_direct_tol; /* device-factorised form: the direct mode (no confirming PCG iteration) is taken while the probe  max |M^-1 K v - v| / max |v|
+                                 measured after every factorisation stays below this (default 1e-6: every linear solve then reduces its residual a
+                                 millionfold -- orders beyond any tolerance the PCG would have been asked for; r03 demanded 1e-9, which the Woodbury
+                                 identity misses at 5k x 10k by a factor 4-40)                                                        [setup] */
   OSQPInt woodbury_fused;     /* the Woodbury direct mode as TWO launches per ADMM iteration where it applies (P diagonal, one-entry short rows,
                                  n <= 16384; wbdirect_hip.hip) instead of five                                                      [setup] */
   OSQPInt reorder;            /* 1 (default): when the one-launch PCG form does not apply to the matrices as numbered by the caller, look for a

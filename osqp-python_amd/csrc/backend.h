@@ -129,6 +129,7 @@ struct DevWb {
   int large = 0;                 // r > kWbMaxRows: device-side dense factorisation; WT unused, W / colmap / ct in use
   int ct = 0;                    // columns with an entry in a long row
   int probe = 0;                 // decide `exact` by the probe after every factorisation (large mode)
+  double exact_tol = 1e-6;       // ... the direct mode is on while  max |M^-1 K v - v| <= exact_tol max |v|  (OSQPHipPolicy::woodbury_direct_tol)
   int log = 0;                   // print the checks and the timing of every factorisation (OSQPHipPolicy::woodbury_log)
   int *colmap = nullptr;         // [n] column -> position among the ct touched ones (-1: untouched)
   double *W = nullptr;           // [r][ct] rows of A_L scaled by D0^-1/2 (zero where A_L has no entry)

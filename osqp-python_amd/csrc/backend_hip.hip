@@ -2258,7 +2258,7 @@ static void wb_factor_large(Dev &d) {
   HIP_CHECK(hipStreamSynchronize(st(d)));
   if (info[0] != 0 || info[1] != 0) throw DeviceError("osqp_hip: the Woodbury system of the preconditioner is not positive definite");
   const bool inv_ok = chk[0] <= 1e-8 * chk[1];
-  w.exact = (w.probe && inv_ok && chk[2] <= 1e-9 * chk[3]) ? 1 : 0;
+  w.exact = (w.probe && inv_ok && chk[2] <= w.exact_tol * chk[3]) ? 1 : 0;
   if (log) {
     lap(5);
     std::fprintf(stderr, "osqp_hip woodbury: r %d ct %d  |S S^-1 g - g| %.2e / %.2e   |M^-1 K v - v| %.2e / %.2e   direct %d;  D0 + W %.1f ms, GEMM %.1f ms, Cholesky %.1f ms, inverse %.1f ms, mirror + checks %.1f ms\n",
