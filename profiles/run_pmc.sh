@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 for ctr in FETCH_SIZE WRITE_SIZE; do
   out=/tmp/pmc_${tag}_$ctr; rm -rf $out; mkdir -p $out
-  (cd /tmp && rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -o pmc -- python $repo/bench.py --cpu-seconds 0 --probe-reps 5 "$@" > $out/stdout.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -o pmc -- python $repo/bench.py --cpu-seconds 0 --probe-reps 5 "$@" > $out/stdout.log 2>&1 < /dev/null)
   f=$(find $out -name '*counter_collection.csv' | head -1)
   echo "counter file: $f"
   if [ -n "$f" ]; then python $repo/profiles/summarize_pmc.py "$f" gpurun_out/${tag}_pmc_${wl}_$ctr.csv; else tail -5 $out/stdout.log; fi
