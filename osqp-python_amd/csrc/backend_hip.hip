@@ -17,1412 +17,12 @@
 //     reduced quantity (slot[blockIdx.x]) and the consumer kernel sums the kGrid partials in a fixed order
 //     (no atomics), so iteration counts are reproducible run to run;
 //   * launch batching with hipGraph (five captured strings of slot launches serve every chunk, see engine.cpp).
-#include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>          // types and prototypes only: the libraries are dlopen()ed (dense_libs)
-#include <rocsolver/rocsolver.h>
-#include <dlfcn.h>
-
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <algorithm>
-#include <chrono>
-#include <initializer_list>
-#include <mutex>
-#include <type_traits>
-#include <vector>
-#include <cmath>
-
-#include "../../include/osqp_hip.h"
-#include "backend.h"
-#include "policy.h"
+#include "hip_common.h"
 
 namespace osqp_hip {
 namespace be {
 
-#define HIP_CHECK(expr)                                                                                       \
-  do {                                                                                                        \
-    hipError_t e_ = (expr);                                                                                   \
-    if (e_ != hipSuccess) {                                                                                   \
-      char msg_[512];                                                                                         \
-      std::snprintf(msg_, sizeof(msg_), "osqp_hip: HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #expr); \
-      std::fprintf(stderr, "%s\n", msg_);                                                                     \
-      throw DeviceError(msg_);                                                                                \
-    }                                                                                                         \
-  } while (0)
-
 namespace {
-
-// partial-reduction slots inside Dev::part (each kGrid doubles)
-// Diagnostic build (-DOSQP_HIP_KTRACE, tools/ktrace.py): lane 0 of every workgroup stamps the 100 MHz wall clock at a few
-// phase boundaries; read back with be::ktrace_read.  Compiles to nothing in the product library.
-#ifdef OSQP_HIP_KTRACE
-constexpr int kTraceSlots = 16;
-__device__ unsigned long long g_ktrace[kGrid * kTraceSlots];
-#define KT(p) do { if (threadIdx.x == 0) g_ktrace[blockIdx.x * kTraceSlots + (p)] = wall_clock64(); } while (0)
-#else
-#define KT(p) do { } while (0)
-#endif
-// Ablation builds (-DOSQP_HIP_KNOCK=mask, timing experiments only -- results are WRONG): which phases of the windowed k_k2f cost what
-#ifndef OSQP_HIP_KNOCK
-#define OSQP_HIP_KNOCK 0
-#endif
-#define KNOCKED(bit) ((OSQP_HIP_KNOCK & (bit)) != 0)
-enum Slot { SL_GAMMA0 = 0, SL_GAMMA1, SL_RN0, SL_RN1, SL_BN, SL_DELTA, SL_DELTA1 /* F1 form: delta by parity (SL_DELTA + (k & 1)) */, SL_RES0 /* .. SL_RES0 + R_COUNT - 1 */ };
-static_assert(SL_RES0 + R_COUNT <= kPartSlots, "Dev::part is too small");
-
-struct Impl {
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_ext = nullptr, ev_wait = nullptr;      // ev_ext: end of a batch kernel on a caller's stream (ext_record / ext_wait); ev_wait: stream_wait
-  bool ext_pending = false;
-  double *pin_res = nullptr;
-  int *pin_flags = nullptr;      // [F_COUNT + 16]: the flags block followed by the two slot records
-  hipStream_t side = nullptr;    // slot_poll(): reads the slot records while the chunk's launches are still running on d.stream
-  int *pin_poll = nullptr;       // [kSlotInts]
-  Ctl *pin_ctl = nullptr, *pin_ctl2 = nullptr;   // staging of the state block (upload / poll + download)
-  int epoch = 0;                 // chunks begun (slot_begin); the device copy sits behind the two records
-  void *blas = nullptr;          // rocblas_handle of the large-rank Woodbury factorisation (created on first use)
-};
-inline Impl &im(Dev &d) { return *static_cast<Impl *>(d.impl); }
-inline hipStream_t st(Dev &d) { return static_cast<hipStream_t>(d.stream); }
-
-// ---------------------------------------------------------------------------------------------- device helpers
-__device__ __forceinline__ double nanmax(double r, double a) { return (a > r || a != a) ? a : r; }
-// Wave64 reductions with DPP moves (VALU rate).  HIP's __shfl_* compile to ds_bpermute_b32 -- an LDS round trip of ~100+ cycles
-// per 32-bit half and step: the three block reductions of a PCG kernel cost ~1 us each that way (tools/ktrace.py: 1.07 us in the
-// late hook of k_k2f, 0.9 us in k_k1f's exit).  dpp<CTRL, ROWS>(v): v of the DPP source lane, 0.0 where there is none / the row is
-// masked (0 = identity of the sums and of the maxima of magnitudes taken here).  The wave's result ends up in LANE 63.
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ double dpp(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-constexpr int kReduceLane = 63;          // the lane that holds a wave_sum / wave_max result
-__device__ __forceinline__ double wave_sum(double v) {
-  v += dpp<0xb1>(v);            // quad_perm [1,0,3,2]
-  v += dpp<0x4e>(v);            // quad_perm [2,3,0,1]: every lane holds its quad's total
-  v += dpp<0x114>(v);           // row_shr:4
-  v += dpp<0x118>(v);           // row_shr:8: lane 15 of every row of 16 holds the row's total
-  v += dpp<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
-  v += dpp<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's total
-  return v;
-}
-__device__ __forceinline__ double wave_max(double v) {                 // of non-negative values (or NaN)
-  v = nanmax(v, dpp<0xb1>(v)); v = nanmax(v, dpp<0x4e>(v)); v = nanmax(v, dpp<0x114>(v)); v = nanmax(v, dpp<0x118>(v));
-  v = nanmax(v, dpp<0x142, 0xa>(v)); v = nanmax(v, dpp<0x143, 0xc>(v));
-  return v;
-}
-constexpr int kWaves = kBlock / 64;      // block reductions: one value per wave through LDS; sred needs 2 * kWaves doubles
-__device__ __forceinline__ double sred_sum(const double *s) { double t = 0; for (int w = 0; w < kWaves; w += 2) t += s[w] + s[w + 1]; return t; }
-__device__ __forceinline__ double sred_max(const double *s) { double t = s[0]; for (int w = 1; w < kWaves; w++) t = nanmax(t, s[w]); return t; }
-// all threads receive the block total
-__device__ __forceinline__ double block_sum(double v, double *sred) {
-  v = wave_sum(v);
-  if ((threadIdx.x & 63) == kReduceLane) sred[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double t = sred_sum(sred);
-  __syncthreads();
-  return t;
-}
-__device__ __forceinline__ double block_max(double v, double *sred) {
-  v = wave_max(v);
-  if ((threadIdx.x & 63) == kReduceLane) sred[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double t = sred_max(sred);
-  __syncthreads();
-  return t;
-}
-// two quantities behind ONE barrier pair
-__device__ __forceinline__ void block_sum2(double &a, double &b, double *sred) {
-  a = wave_sum(a); b = wave_sum(b);
-  if ((threadIdx.x & 63) == kReduceLane) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; }
-  __syncthreads();
-  a = sred_sum(sred); b = sred_sum(sred + kWaves);
-  __syncthreads();
-}
-__device__ __forceinline__ void block_max2(double &a, double &b, double *sred) {
-  a = wave_max(a); b = wave_max(b);
-  if ((threadIdx.x & 63) == kReduceLane) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; }
-  __syncthreads();
-  a = sred_max(sred); b = sred_max(sred + kWaves);
-  __syncthreads();
-}
-// a = sum, b = max, ONE barrier pair
-__device__ __forceinline__ void block_sum_max(double &a, double &b, double *sred) {
-  a = wave_sum(a); b = wave_max(b);
-  if ((threadIdx.x & 63) == kReduceLane) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; }
-  __syncthreads();
-  a = sred_sum(sred); b = sred_max(sred + kWaves);
-  __syncthreads();
-}
-// per-thread slices of the kGrid partials of a slot: issue the loads early, reduce later.  Every lane reads kPart
-// CONSECUTIVE partials with 16-byte loads where it can (half the requests of strided 8-byte ones: +3.5 %); with fewer
-// partials than threads the first kGrid lanes read one each.
-constexpr int kPart = kGrid >= kBlock ? kGrid / kBlock : 1;
-static_assert(kGrid >= kBlock ? kGrid % kBlock == 0 : kBlock % kGrid == 0, "kGrid and kBlock must divide one another");
-static_assert(kWaves % 2 == 0, "block reductions pair the waves");
-struct PartRegs { double v[kPart]; };
-__device__ __forceinline__ PartRegs partial_load(const double *slot) {
-  PartRegs r;
-  if (kPart % 2 == 0) {
-    const double2 *s2 = reinterpret_cast<const double2 *>(slot) + (kPart / 2) * threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < kPart / 2; k++) { const double2 a = s2[k]; r.v[2 * k] = a.x; r.v[2 * k + 1] = a.y; }
-  } else {
-    r.v[0] = (kGrid >= kBlock || (int)threadIdx.x < kGrid) ? slot[threadIdx.x] : 0.0;     // 0: identity of both folds (maxima are of magnitudes)
-  }
-  return r;
-}
-__device__ __forceinline__ double partial_fold_sum(const PartRegs &r) { double v = 0; for (int k = 0; k < kPart; k++) v += r.v[k]; return v; }
-__device__ __forceinline__ double partial_fold_max(const PartRegs &r) { double v = 0; for (int k = 0; k < kPart; k++) v = nanmax(v, r.v[k]); return v; }
-__device__ __forceinline__ double partial_sum(const double *slot, double *sred) { return block_sum(partial_fold_sum(partial_load(slot)), sred); }
-__device__ __forceinline__ double partial_max(const double *slot, double *sred) { return block_max(partial_fold_max(partial_load(slot)), sred); }
-__device__ __forceinline__ void put_partial(double *part, int slot, double v) {
-  if (threadIdx.x == 0) part[slot * kGrid + blockIdx.x] = v;
-}
-
-// CSR-stream / CSR-vector row processing shared by every sparse kernel.
-//   G: gather functor   void operator()(int col, double val, double (&prod)[NS])
-//   E: row epilogue     void prefetch(int row)                                (optional loads issued before the barrier)
-//                       void operator()(int row, const double (&sum)[NS])    (called by exactly one lane per row)
-//   Pre: bool pre()     block-uniform hook run ONCE, after the first row block's streaming loads have been issued (so
-//                       whatever it waits for -- a reduction of partials, a flag -- overlaps those loads); returning
-//                       false abandons the kernel for this workgroup.
-template <int NS, int NBUF = (NS == 1 ? 2 : 1)>
-struct StreamLds { static constexpr int kBuf = NBUF; static constexpr bool kWin = false; double prod[NBUF][NS][kChunk]; double red[3 * kWaves]; };
-// Variant for kernels whose gather functor can stage a block's input-vector window in LDS (DevCsr::blkwin): single product
-// buffer + the window (T = what one column contributes: a double, or a 16-byte pair).  <= 40 KB: four workgroups per CU.
-template <int NS, class T>
-struct StreamLdsW { static constexpr int kBuf = 1; static constexpr bool kWin = true; double prod[1][NS][kChunk]; T win[kWinCap]; double red[3 * kWaves]; };
-struct NoPre { [[maybe_unused]] static constexpr int kTraceBase = 0; __device__ __forceinline__ bool operator()() const { return true; } };
-
-__device__ __forceinline__ bool wg_has_rows(const DevCsr &M) {      // same mapping as process_rows
-  const int per = (M.nblk + 7) >> 3;
-  const int sl = blockIdx.x >> 3;
-  return sl < per && (int)(blockIdx.x & 7) * per + sl < M.nblk;
-}
-// Optional two-phase forms (detected by a nested type), which let process_rows issue every load in the order it is needed
-// -- the memory counter retires loads in issue order, so a wait for a late-issued load drains everything before it:
-//   G:   using Ops;  Ops fetch(int col) const;                 the gathered operand(s), requested as soon as col arrives
-//                    void prod(const Ops &, double val, double (&prod)[NS]) const;   evaluated after the hook
-//   Pre: using Tok;  Tok begin() const;                        the hook's own loads, requested BEFORE the matrix loads
-//                    bool finish(const Tok &) const;           the rest of the hook (runs while the gathers are in flight)
-template <class T, class = void> struct has_ops : std::false_type {};
-template <class T> struct has_ops<T, std::void_t<typename T::Ops>> : std::true_type {};
-template <class T, class = void> struct has_tok : std::false_type {};
-template <class T> struct has_tok<T, std::void_t<typename T::Tok>> : std::true_type {};
-template <class G, bool = has_ops<G>::value> struct GatherOps {
-  struct Ops {};
-  static __device__ __forceinline__ Ops fetch(const G &, int) { return Ops(); }
-  template <int NS> static __device__ __forceinline__ void prod(const G &g, const Ops &, int c, double a, double (&pr)[NS]) { g(c, a, pr); }
-};
-template <class G> struct GatherOps<G, true> {
-  using Ops = typename G::Ops;
-  static __device__ __forceinline__ Ops fetch(const G &g, int c) { return g.fetch(c); }
-  template <int NS> static __device__ __forceinline__ void prod(const G &g, const Ops &o, int, double a, double (&pr)[NS]) { g.prod(o, a, pr); }
-};
-template <class P, bool = has_tok<P>::value> struct PreOps {
-  struct Tok {};
-  static __device__ __forceinline__ Tok begin(const P &) { return Tok(); }
-  static __device__ __forceinline__ bool finish(const P &p, const Tok &) { return p(); }
-};
-template <class P> struct PreOps<P, true> {
-  using Tok = typename P::Tok;
-  static __device__ __forceinline__ Tok begin(const P &p) { return p.begin(); }
-  static __device__ __forceinline__ bool finish(const P &p, const Tok &t) { return p.finish(t); }
-};
-// LATE hooks (static constexpr bool kLate = true): nothing the hook computes is needed before the row EPILOGUE, so its loads are
-// requested after the matrix stream and   bool finish(const Tok &, const double (&acc)[NS], bool owner)   runs once, between the
-// first block's row sums and its epilogue calls (acc: this lane's row sum, owner: this lane runs the epilogue of a row).  The
-// reductions of partials then cost no time at the front of the kernel (k_k2f: 1.8 of 7.6 us, tools/ablate.py).
-template <class T, class = void> struct is_late : std::false_type {};
-template <class T> struct is_late<T, std::void_t<decltype(T::kLate)>> : std::bool_constant<T::kLate> {};
-template <class P, bool = is_late<P>::value> struct LateOps {
-  static __device__ __forceinline__ typename PreOps<P>::Tok begin(const P &) { return typename PreOps<P>::Tok(); }
-  template <int NS> static __device__ __forceinline__ bool finish(const P &, const typename PreOps<P>::Tok &, const double (&)[NS], bool) { return true; }
-};
-template <class P> struct LateOps<P, true> {
-  static __device__ __forceinline__ typename P::Tok begin(const P &p) { return p.begin(); }
-  template <int NS> static __device__ __forceinline__ bool finish(const P &p, const typename P::Tok &t, const double (&acc)[NS], bool owner) { return p.finish(t, acc, owner); }
-};
-//   done:           optional device flag; when set the workgroup abandons the kernel.  It is read TOGETHER with the first
-//                   block descriptor (one wait for both scalar loads) instead of ahead of it.
-//   Windowed blocks (L::kWin, DevCsr::blkwin):  G additionally provides
-//                    using Win;  Win stage(int seg, int c) const;      element c of the input vector(s) of column segment seg
-//                    void wprod(const Win &, double val, double (&prod)[NS]) const;
-// The first row block's descriptors, loadable AHEAD of process_rows (the slot kernels request them together with the phase record
-// they branch on, so that the record's latency is not added to the kernel's dependent-load chain).
-struct FirstDesc { int4 ds, ws; };
-template <bool WIN>
-__device__ __forceinline__ FirstDesc first_desc(const DevCsr &M) {
-  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, per = (M.nblk + 7) >> 3;
-  const int b0 = xcd * per + slot0;
-  FirstDesc f{make_int4(0, 0, 0, 0), make_int4(0, -1, 0, 0)};
-  if (slot0 < per && b0 < M.nblk) {
-    f.ds = reinterpret_cast<const int4 *>(M.blkdesc)[b0];
-    if (WIN) f.ws = reinterpret_cast<const int4 *>(M.blkwin)[b0];
-  }
-  return f;
-}
-template <int NS, bool HAS_DONE, class G, class E, class Pre, class L>
-__device__ __forceinline__ bool process_rows_impl(const DevCsr &M, const G &g, E &e, L &lds, Pre pre, const int *done, const FirstDesc *fd = nullptr) {
-  int buf = 0;
-  const int4 *desc = reinterpret_cast<const int4 *>(M.blkdesc);
-  [[maybe_unused]] const int4 *wdesc = reinterpret_cast<const int4 *>(M.blkwin);
-  // XCD-contiguous mapping (speed only; correctness never depends on placement): workgroup id b is observed to run on
-  // XCD b % 8, so XCD x is given the contiguous row-block range [x*per, (x+1)*per).  Neighbouring row blocks gather
-  // overlapping windows of the input vector; on one XCD they share those lines in one L2 instead of every XCD's L2
-  // fetching (nearly) the whole vector.
-  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, slots = gridDim.x >> 3;
-  const int per = (M.nblk + 7) >> 3;
-  // The done flag and the first descriptor are requested back to back, ahead of any branch that depends on either, so
-  // the kernel's dependent-load chain is  {flag, descriptor} -> {col, val, rowptr} -> gather  (three levels, not five).
-  const int b0 = xcd * per + slot0;
-  const bool has0 = slot0 < per && b0 < M.nblk;
-  int dn = 0;
-  if (HAS_DONE) dn = *done;
-  int4 ds = make_int4(0, 0, 0, 0), ws = make_int4(0, -1, 0, 0);
-  if (fd) { ds = fd->ds; if constexpr (L::kWin) ws = fd->ws; }
-  else if (has0) { ds = desc[b0]; if constexpr (L::kWin) ws = wdesc[b0]; }
-  KT(Pre::kTraceBase + 1);      // flag + first descriptor arrived
-  if (dn) return false;
-  constexpr bool LATE = is_late<Pre>::value;
-  if (!has0) {      // a workgroup without rows still runs the hook (e.g. workgroup 0 owns the PCG flags)
-    if constexpr (LATE) { const double zero[NS] = {}; return LateOps<Pre>::template finish<NS>(pre, LateOps<Pre>::begin(pre), zero, false); }
-    else return PreOps<Pre>::finish(pre, PreOps<Pre>::begin(pre));
-  }
-  // One row block.  The first one (compile-time tag) also runs the hook; it is a separate instantiation so that no
-  // control-flow join sits between the hook's loads and the matrix loads (a join makes the compiler drain the counter).
-  auto block = [&](auto first_tag, const int4 ds, [[maybe_unused]] const int4 ws) -> bool {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    const int r0 = ds.x, k0 = ds.z, k1 = ds.w;
-    const int r1 = ds.y < 0 ? r0 + 1 : ds.y;                    // (ds.y < 0: a long row, -(1 + index of its run table))
-    const int cnt = k1 - k0;
-    if (ds.y < 0) {                                             // one long row: whole workgroup reduces it
-      const int *runs = M.runinfo - (1 + ds.y);
-      typename PreOps<Pre>::Tok ltok = typename PreOps<Pre>::Tok();
-      if constexpr (FIRST && !LATE) { if (!PreOps<Pre>::finish(pre, PreOps<Pre>::begin(pre))) return false; }
-      if (threadIdx.x == 0) e.prefetch(r0);                     // epilogue operands requested before the stream, not after it
-      if constexpr (FIRST && LATE) ltok = LateOps<Pre>::begin(pre);
-      double acc[NS];
-#pragma unroll
-      for (int s = 0; s < NS; s++) acc[s] = 0.0;
-      // kChunk entries per step, as in the short-row path: 8 index loads, 8 value loads, 8 gathers per lane in flight
-      // together (one load batch per lane and step reached 2.9 TB/s on dense 5000-entry rows; this form is the fix)
-      int c0 = runs[0];                                         // (requested one slice ahead: it gates the slice's first loads)
-      for (int base = k0, j = 0; base < k1; base += kChunk, j++) {
-        int cc[kChunk / kBlock];
-        double vv[kChunk / kBlock];
-        const int crun = c0;
-        if (base + kChunk < k1) c0 = runs[j + 1];
-        if (crun >= 0) {                                        // consecutive columns (dense block): no index loads for this slice
-#pragma unroll
-          for (int u = 0; u < kChunk / kBlock; u++) { const int k = base + (int)threadIdx.x + u * kBlock; cc[u] = k < k1 ? crun + (k - base) : -1; }
-        } else {
-#pragma unroll
-          for (int u = 0; u < kChunk / kBlock; u++) { const int k = base + (int)threadIdx.x + u * kBlock; cc[u] = k < k1 ? M.col[k] : -1; }
-        }
-#pragma unroll
-        for (int u = 0; u < kChunk / kBlock; u++) { const int k = base + (int)threadIdx.x + u * kBlock; vv[u] = k < k1 ? M.val[k] : 0.0; }
-        typename GatherOps<G>::Ops ops[kChunk / kBlock];
-#pragma unroll
-        for (int u = 0; u < kChunk / kBlock; u++) if (cc[u] >= 0) ops[u] = GatherOps<G>::fetch(g, cc[u]);
-#pragma unroll
-        for (int u = 0; u < kChunk / kBlock; u++) {
-          if (cc[u] < 0) continue;
-          double pr[NS];
-          GatherOps<G>::template prod<NS>(g, ops[u], cc[u], vv[u], pr);
-#pragma unroll
-          for (int s = 0; s < NS; s++) acc[s] += pr[s];
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < NS; s++) acc[s] = block_sum(acc[s], lds.red);
-      if constexpr (FIRST && LATE) { if (!LateOps<Pre>::template finish<NS>(pre, ltok, acc, threadIdx.x == 0)) return false; }
-      if (threadIdx.x == 0) e(r0, acc);
-      return true;
-    }
-    // many short rows: stage products in LDS
-    typename PreOps<Pre>::Tok tok = typename PreOps<Pre>::Tok();
-    if constexpr (FIRST && !LATE) tok = PreOps<Pre>::begin(pre);   // the hook's loads go out first: they are needed first
-    const int lpr = 2 * (r1 - r0) <= kBlock ? 2 : 1;
-    const int sub = lpr == 2 ? (int)(threadIdx.x & 1) : 0;
-    const int myr = r0 + (lpr == 2 ? (int)(threadIdx.x >> 1) : (int)threadIdx.x);   // the row this lane reduces in the first pass
-    int rp0 = 0, rp1 = 0;                                        // raw row pointers: not touched before the barrier
-    bool staged = false;
-    if constexpr (L::kWin) {
-      if (ws.y >= 0) {
-        // Windowed block: the window of the input vector(s) is fetched with coalesced loads (requested FIRST: it is needed
-        // first), written to LDS, and the per-entry gathers are LDS reads through 16-bit local indices.
-        // Instruction count matters as much as bytes here (the load-issue phase was ~700 instructions per wave with one exec-mask
-        // branch per load: 1.7 us of the kernel's 6.7): trip counts are BLOCK-UNIFORM (scalar branches), lanes past the end of the
-        // last partial batch re-read the last element (same cache line as their neighbours) instead of branching around the load.
-        using T = typename G::Win;
-        constexpr int CW = (kWinCap + kBlock - 1) / kBlock;
-        constexpr int CE = kChunk / kBlock;
-        const int wl = ws.y + ws.w;
-        const int nw = (wl + kBlock - 1) / kBlock, nu = (cnt + kBlock - 1) / kBlock;      // (cnt >= 1, wl >= 1 for a windowed block)
-        T we[CW];
-#pragma unroll
-        for (int u = 0; u < CW; u++) {
-          if (u < nw) {
-            const int p = min((int)threadIdx.x + u * kBlock, wl - 1);
-            we[u] = p < ws.y ? g.stage(0, ws.x + p) : g.stage(1, ws.z + (p - ws.y));
-          }
-        }
-        int lc[CE];
-        double vw[CE];
-        const unsigned short *lcp = M.lcol + k0;
-        const double *vp = M.val + k0;
-#pragma unroll
-        for (int u = 0; u < CE; u++) { if (u < nu) lc[u] = (int)lcp[min((int)threadIdx.x + u * kBlock, cnt - 1)]; }
-#pragma unroll
-        for (int u = 0; u < CE; u++) { if (u < nu) vw[u] = vp[min((int)threadIdx.x + u * kBlock, cnt - 1)]; }
-        if (myr < r1) { rp0 = M.rowptr[myr]; rp1 = M.rowptr[myr + 1]; if (sub == 0) e.prefetch(myr); }
-        if constexpr (FIRST && LATE) tok = LateOps<Pre>::begin(pre);            // a late hook's loads go out last
-        KT(Pre::kTraceBase + 2);
-#pragma unroll
-        for (int u = 0; u < CW; u++) { if (u < nw) lds.win[min((int)threadIdx.x + u * kBlock, wl - 1)] = we[u]; }     // (clamped lanes store the same value)
-        if constexpr (FIRST && !LATE) { if (!PreOps<Pre>::finish(pre, tok)) return false; KT(Pre::kTraceBase + 3); }
-        __syncthreads();
-        T gv[CE];
-#pragma unroll
-        for (int u = 0; u < CE; u++) { if (u < nu) gv[u] = lds.win[lc[u]]; }            // all LDS gathers in flight together
-#pragma unroll
-        for (int u = 0; u < CE; u++) {
-          if (u < nu) {
-            double pr[NS];
-            g.wprod(gv[u], vw[u], pr);         // (slots past cnt hold a copy of the last product: never read by the row sums)
-#pragma unroll
-            for (int s = 0; s < NS; s++) lds.prod[buf][s][threadIdx.x + u * kBlock] = pr[s];
-          }
-        }
-        staged = true;
-      }
-    }
-    if (!staged) {
-    int cc[kChunk / kBlock];
-    double vv[kChunk / kBlock];
-    // (masked, not clamped: a lane past the block's last entry issues nothing.  Re-reading the last entry instead makes the
-    // code branch-free but was measured 6 % slower -- row blocks are ~2/3 full, and the extra requests cost more than the branches)
-#pragma unroll
-    for (int u = 0; u < kChunk / kBlock; u++) { const int k = threadIdx.x + u * kBlock; cc[u] = k < cnt ? M.col[k0 + k] : -1; }     // indices first:
-#pragma unroll
-    for (int u = 0; u < kChunk / kBlock; u++) { const int k = threadIdx.x + u * kBlock; vv[u] = k < cnt ? M.val[k0 + k] : 0.0; }    // the gathers wait only for them
-    // Row sums: one lane per row, or -- when the block has at most kBlock/2 rows -- TWO lanes per row (even/odd entries,
-    // combined with one shuffle): halves the serial chain of LDS reads of the row-sum phase for matrices with ~100 rows of
-    // ~14 entries per block (B at config 2: k_k2f 7.9 -> 7.5 us back to back).
-    if (myr < r1) { rp0 = M.rowptr[myr]; rp1 = M.rowptr[myr + 1]; if (sub == 0) e.prefetch(myr); }
-    KT(Pre::kTraceBase + 2);
-    typename GatherOps<G>::Ops ops[kChunk / kBlock];
-#pragma unroll
-    for (int u = 0; u < kChunk / kBlock; u++) if (cc[u] >= 0) ops[u] = GatherOps<G>::fetch(g, cc[u]);   // gathers requested as the indices arrive
-    if constexpr (FIRST && LATE) tok = LateOps<Pre>::begin(pre);
-    if constexpr (FIRST && !LATE) { if (!PreOps<Pre>::finish(pre, tok)) return false; KT(Pre::kTraceBase + 3); }
-#pragma unroll
-    for (int u = 0; u < kChunk / kBlock; u++) {
-      if (cc[u] < 0) continue;
-      double pr[NS];
-      GatherOps<G>::template prod<NS>(g, ops[u], cc[u], vv[u], pr);
-#pragma unroll
-      for (int s = 0; s < NS; s++) lds.prod[buf][s][threadIdx.x + u * kBlock] = pr[s];
-    }
-    }  // !staged
-    __syncthreads();
-    KT(Pre::kTraceBase + 4);    // products staged
-    {
-      double acc[NS];
-#pragma unroll
-      for (int s = 0; s < NS; s++) acc[s] = 0.0;
-      const bool owner = myr < r1 && sub == 0;
-      if (KNOCKED(16)) { if (owner) for (int s = 0; s < NS; s++) acc[s] = lds.prod[buf][s][threadIdx.x]; }
-      else {
-        // The first kRowBatch entries of the lane's share are read with INDEPENDENT LDS loads (one latency, not one per entry:
-        // the variable-trip-count loop below serialised a ds_read + wait per entry, 0.75 us for the 12-entry rows of B at config
-        // 2) and added in entry order -- the same sum as the plain loop, since the masked slots add 0.0.
-        constexpr int kRowBatch = 8;
-        if (myr < r1) {
-          const int ra = rp0 - k0, rz = rp1 - k0;
-          double v[NS][kRowBatch];
-#pragma unroll
-          for (int b = 0; b < kRowBatch; b++) {
-            const int k = ra + sub + lpr * b;
-#pragma unroll
-            for (int s = 0; s < NS; s++) v[s][b] = k < rz ? lds.prod[buf][s][k] : 0.0;
-          }
-#pragma unroll
-          for (int b = 0; b < kRowBatch; b++) {
-#pragma unroll
-            for (int s = 0; s < NS; s++) acc[s] += v[s][b];
-          }
-          for (int k = ra + sub + lpr * kRowBatch; k < rz; k += lpr) {
-#pragma unroll
-            for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
-          }
-        }
-        if (lpr == 2) {
-#pragma unroll
-          for (int s = 0; s < NS; s++) acc[s] += dpp<0xb1>(acc[s]);            // lane ^ 1 (whole waves take this path: lpr is block-uniform)
-        }
-      }
-      if constexpr (FIRST && LATE) { KT(Pre::kTraceBase + 7); if (!LateOps<Pre>::template finish<NS>(pre, tok, acc, owner)) return false; KT(Pre::kTraceBase + 3); }
-      if (owner) e(myr, acc);
-    }
-    for (int r = myr + kBlock; lpr == 1 && r < r1; r += kBlock) {   // blocks with more than kBlock (mostly empty) rows
-      const int a = M.rowptr[r] - k0, z = M.rowptr[r + 1] - k0;
-      double acc[NS];
-#pragma unroll
-      for (int s = 0; s < NS; s++) acc[s] = 0.0;
-      for (int k = a; k < z; k++) {
-#pragma unroll
-        for (int s = 0; s < NS; s++) acc[s] += lds.prod[buf][s][k];
-      }
-      e.prefetch(r); e(r, acc);
-    }
-    KT(Pre::kTraceBase + 5);    // row sums + epilogue done
-    if (L::kBuf == 2) buf ^= 1;               // the next row block fills the other buffer: one barrier per block suffices
-    else __syncthreads();                      // single buffer (two-sum and windowed kernels): protect it before the next fill
-    return true;
-  };
-  if (!block(std::true_type(), ds, ws)) return false;
-  for (int sl = slot0 + slots; sl < per; sl += slots) {
-    const int b = xcd * per + sl;
-    if (b >= M.nblk) break;
-    int4 wn = make_int4(0, -1, 0, 0);
-    if constexpr (L::kWin) wn = wdesc[b];
-    block(std::false_type(), desc[b], wn);
-  }
-  return true;
-}
-template <int NS, class G, class E, class Pre, class L>
-__device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, L &lds, Pre pre) { return process_rows_impl<NS, false>(M, g, e, lds, pre, nullptr); }
-template <int NS, class G, class E, class Pre, class L>
-__device__ __forceinline__ bool process_rows(const DevCsr &M, const G &g, E &e, L &lds, Pre pre, const int *done) { return process_rows_impl<NS, true>(M, g, e, lds, pre, done); }
-template <int NS, class G, class E, class L>
-__device__ __forceinline__ void process_rows(const DevCsr &M, const G &g, E &e, L &lds) { process_rows_impl<NS, false>(M, g, e, lds, NoPre(), nullptr); }
-template <int NS, class G, class E, class Pre, class L>
-__device__ __forceinline__ bool process_rows_fd(const DevCsr &M, const G &g, E &e, L &lds, Pre pre, const FirstDesc &fd) { return process_rows_impl<NS, false>(M, g, e, lds, pre, nullptr, &fd); }
-struct NoPrefetch { __device__ __forceinline__ void prefetch(int) {} };
-
-// ---------------------------------------------------------------------------------------------- hot-path kernels
-// KB ------------------------------------------------------------------------------------------
-struct GKb {
-  const double *xg, *v, *t0; int n;      // (xg: the PCG start, Dev::xg; t0 = rho .* (A xg))
-  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[2]) const {
-    if (c < n) { pr[0] = 0.0; pr[1] = a * xg[c]; }
-    else { pr[0] = a * v[c - n]; pr[1] = a * t0[c - n]; }
-  }
-};
-struct EKb {
-  const double *x, *q, *Minv; double *r, *uu; double sigma; const double *xg; double *xs; double g = 0, rn = 0, bn = 0; double px = 0, pq = 0, pm = 0, pg = 0;
-  __device__ __forceinline__ void prefetch(int j) { px = x[j]; pq = q[j]; pm = Minv[j]; pg = xg[j]; }
-  __device__ __forceinline__ void operator()(int j, const double (&s)[2]) {
-    const double rhs = sigma * px - pq + s[0];
-    const double rr = rhs - s[1], u = pm * rr;
-    r[j] = rr; uu[j] = u; xs[j] = pg;           // x~ restarts from the extrapolated point (nobody gathers xs in this kernel)
-    g += rr * u; rn = nanmax(rn, fabs(rr)); bn = nanmax(bn, fabs(rhs));
-  }
-};
-__global__ __launch_bounds__(kBlock) void k_kb(Dev d) {
-  __shared__ StreamLds<2> lds;
-  GKb g{d.xg, d.v, d.t0, d.n};
-  EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma, d.xg, d.xs};
-  process_rows<2>(d.B, g, e, lds);
-  __syncthreads();
-  const double G = block_sum(e.g, lds.red);
-  double RN = e.rn, BN = e.bn;
-  block_max2(RN, BN, lds.red);
-  put_partial(d.part, SL_GAMMA0, G); put_partial(d.part, SL_RN0, RN); put_partial(d.part, SL_BN, BN);
-  if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
-}
-
-// K1 ------------------------------------------------------------------------------------------
-struct GVec {
-  const double *x;
-  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * x[c]; }
-  using Win = double;                                     // windowed row blocks: x's window staged in LDS
-  __device__ __forceinline__ Win stage(int, int c) const { return x[c]; }
-  __device__ __forceinline__ void wprod(const Win &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
-};
-struct EK1 {
-  const double *rho; double *t; double pr = 0;
-  __device__ __forceinline__ void prefetch(int i) { pr = rho[i]; }
-  __device__ __forceinline__ void operator()(int i, const double (&s)[1]) { t[i] = pr * s[0]; }
-};
-// PCG stopping test, run by every working workgroup (and workgroup 0) while its first matrix loads are in flight
-struct PreK1 {
-  [[maybe_unused]] static constexpr int kTraceBase = 0;
-  const Dev &d; int i, probe; double *red; int par = -1;      // par: parity of the ADMM iteration (slot form), -1: not recorded
-  __device__ __forceinline__ bool operator()() const {
-    if (probe == 1) return true;
-    // (No early exit on d.flags[F_DONE] here: in the slot form workgroup 0 of THIS launch may set the flag while other workgroups are
-    // still arriving, the waves of one workgroup then read different values, one skips the barriers of the reduction below and
-    // meets its siblings at the next __syncthreads() instead -- they fold its stale LDS slot.  Seen as run-to-run differences of
-    // solves running concurrently on several streams, 1-4 % of them (tools/thread_stress.py); every wave takes the reduction now.)
-    const PartRegs prn = partial_load(d.part + (SL_RN0 + (i & 1)) * kGrid), pbn = partial_load(d.part + SL_BN * kGrid);
-    double rn = partial_fold_max(prn), bn = partial_fold_max(pbn);
-    block_max2(rn, bn, red);
-    if (probe) { if (rn < -1.0) d.res[R_COUNT - 1] = bn; return true; }     // probe == 2: pay for the test, ignore it
-    const double tol = fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS]);
-    if (i == 0 && blockIdx.x == 0 && threadIdx.x == 0) { d.scal[S_TOL_NOW] = tol; d.scal[S_RN0] = rn; if (par >= 0) d.scal[S_RN0H + par] = rn; }   // fused PCG: later tests read the scalar
-    if (!(rn > tol)) {            // converged (a NaN residual also stops the inner loop; the ADMM residuals will flag it)
-      if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = i; }
-      return false;
-    }
-    return true;
-  }
-};
-__global__ __launch_bounds__(kBlock) void k_k1(Dev d, int i, int probe) {
-  __shared__ StreamLdsW<1, double> lds;
-  if (!wg_has_rows(d.A) && blockIdx.x != 0) return;               // nothing to do and not the flag owner
-  if (!probe && d.flags[F_DONE]) return;                          // PCG already converged: cheapest possible exit
-  GVec g{d.uu};
-  EK1 e{d.rho, d.t};
-  process_rows<1>(d.A, g, e, lds, PreK1{d, i, probe, lds.red});
-}
-
-// K2 ------------------------------------------------------------------------------------------
-struct GSplit {      // [pn; pm] indexed by a B column
-  const double *pn, *pm; int n;
-  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * (c < n ? pn[c] : pm[c - n]); }
-};
-struct EK2 {
-  const double *uu; double *w; double dl = 0, pu = 0;
-  __device__ __forceinline__ void prefetch(int j) { pu = uu[j]; }
-  __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { w[j] = s[0]; dl += s[0] * pu; }
-};
-__global__ __launch_bounds__(kBlock) void k_k2(Dev d, int probe) {
-  __shared__ StreamLds<1> lds;
-  if (!probe && d.flags[F_DONE]) return;
-  GSplit g{d.uu, d.t, d.n};
-  EK2 e{d.uu, d.w};
-  if (!process_rows<1>(d.B, g, e, lds, NoPre())) return;
-  __syncthreads();
-  const double DL = block_sum(e.dl, lds.red);
-  put_partial(d.part, SL_DELTA, DL);
-  KT(6);
-}
-
-// Kv ------------------------------------------------------------------------------------------
-// VEC = 2: one double2 per lane (large n); VEC = 1: one double per lane (keeps more workgroups busy at mid-size n)
-template <int VEC>
-__global__ __launch_bounds__(kBlock) void k_kv(Dev d, int i, int probe) {
-  __shared__ double sred[2 * kWaves];
-  const int nv = d.n / VEC;                                       // vector elements (tail handled by workgroup 0)
-  // XCD-contiguous chunks of kBlock elements, as in process_rows (each XCD keeps 'its' eighth of the PCG vectors)
-  const int nchunk = (nv + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3, slots = gridDim.x >> 3;
-  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
-  const int c0 = xcd * per + slot0;
-  const bool active = slot0 < per && c0 < nchunk;
-  const int j0 = c0 * kBlock + threadIdx.x;
-  if (!active && blockIdx.x != 0) {                                // idle workgroup: its partial slots must still read 0
-    if (!probe) { put_partial(d.part, SL_GAMMA0 + ((i + 1) & 1), 0.0); put_partial(d.part, SL_RN0 + ((i + 1) & 1), 0.0); }
-    return;
-  }
-  if (!probe && d.flags[F_DONE]) return;                           // PCG already converged
-  const bool first = (i == 0) && !probe;
-  typedef typename std::conditional<VEC == 2, double2, double>::type V;
-  // fused PCG (final update after the last budgeted iteration): s_i is already complete (k_k2 epilogue), w is not stored,
-  // u_i lives in the ping-pong buffer of parity i
-  const bool fz = d.fused && !probe;
-  const V *uin = reinterpret_cast<const V *>(fz && (i & 1) ? d.uu2 : d.uu);
-  V *uout = reinterpret_cast<V *>(fz && !(i & 1) ? d.uu2 : d.uu);
-  V *p2 = reinterpret_cast<V *>(d.p), *x2 = reinterpret_cast<V *>(d.xs), *r2 = reinterpret_cast<V *>(d.r), *s2 = reinterpret_cast<V *>(d.s);
-  const V *w2 = reinterpret_cast<const V *>(d.w), *m2 = reinterpret_cast<const V *>(d.Minv);
-  // issue this lane's first element loads, then fold the partials while they are in flight
-  const bool have = active && j0 < nv;
-  V u, w, x, r, mi, p, s;
-  if (have) { u = uin[j0]; x = x2[j0]; r = r2[j0]; mi = m2[j0]; if (fz) { s = s2[j0]; if (!first) p = p2[j0]; } else { w = w2[j0]; if (!first) { p = p2[j0]; s = s2[j0]; } } }
-  double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
-  double alpha = 0.0, beta = 0.0;
-  if (probe != 1) {
-    const PartRegs pg = partial_load(d.part + (SL_GAMMA0 + (i & 1)) * kGrid), pd = partial_load(d.part + SL_DELTA * kGrid);
-    double gamma = partial_fold_sum(pg), delta = partial_fold_sum(pd);
-    block_sum2(gamma, delta, sred);
-    if (probe) { if (gamma == -1.2345e300) d.res[R_COUNT - 1] = delta; }   // probe == 2: pay for the reduction, ignore it
-    else {
-      if (i == 0) { beta = 0.0; alpha = gamma / delta; }
-      else { beta = gamma / gam[i - 1]; alpha = gamma / (delta - beta * gamma / alp[i - 1]); }
-      if (blockIdx.x == 0 && threadIdx.x == 0) { gam[i] = gamma; alp[i] = alpha; }
-    }
-  }
-  double g = 0, rn = 0;
-  auto upd = [&](double &uu_, double ww_, double &xx_, double &rr_, double mm_, double &pp_, double &ss_) {
-    if (fz) { pp_ = first ? uu_ : uu_ + beta * pp_; }                 // ss_ is s_i already
-    else if (first) { pp_ = uu_; ss_ = ww_; } else { pp_ = uu_ + beta * pp_; ss_ = ww_ + beta * ss_; }
-    xx_ += alpha * pp_; rr_ -= alpha * ss_; uu_ = mm_ * rr_;
-    g += rr_ * uu_; rn = nanmax(rn, fabs(rr_));
-  };
-  for (int sl = slot0; active && sl < per; sl += slots) {
-    const int c = xcd * per + sl;
-    if (c >= nchunk) break;
-    const int j = c * kBlock + threadIdx.x;
-    if (j >= nv) break;
-    if (sl != slot0) { u = uin[j]; x = x2[j]; r = r2[j]; mi = m2[j]; if (fz) { s = s2[j]; if (!first) p = p2[j]; } else { w = w2[j]; if (!first) { p = p2[j]; s = s2[j]; } } }
-    if constexpr (VEC == 2) { upd(u.x, w.x, x.x, r.x, mi.x, p.x, s.x); upd(u.y, w.y, x.y, r.y, mi.y, p.y, s.y); }
-    else upd(u, w, x, r, mi, p, s);
-    p2[j] = p; if (!fz) s2[j] = s; x2[j] = x; r2[j] = r; uout[j] = u;
-  }
-  if (VEC == 2 && (d.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {      // odd tail element
-    const int j = d.n - 1;
-    const double *uin1 = reinterpret_cast<const double *>(uin); double *uout1 = reinterpret_cast<double *>(uout);
-    double uu_ = uin1[j], xx_ = d.xs[j], rr_ = d.r[j], pp_ = first ? 0.0 : d.p[j], ss_ = (first && !fz) ? 0.0 : d.s[j];
-    upd(uu_, fz ? 0.0 : d.w[j], xx_, rr_, d.Minv[j], pp_, ss_);
-    uout1[j] = uu_; d.xs[j] = xx_; d.r[j] = rr_; d.p[j] = pp_; if (!fz) d.s[j] = ss_;
-  }
-  block_sum_max(g, rn, sred);
-  if (!probe) { put_partial(d.part, SL_GAMMA0 + ((i + 1) & 1), g); put_partial(d.part, SL_RN0 + ((i + 1) & 1), rn); }
-}
-
-
-// Fused PCG (two kernels per iteration) --------------------------------------------------------------------------------
-// K2F_k :  stopping test on ||r_k||; beta_k = gamma_k / gamma_{k-1};  w = B [u_k; t_k];  delta_k = <w, u_k>;  and in the row
-//          epilogue  s_k = w + beta_k s_{k-1},  ms_k = Minv .* s_k   (w itself is never stored)
-// K1F_{k+1}: alpha_k = gamma_k / (delta_k - beta_k gamma_k / alpha_{k-1});
-//          (a) on this workgroup's chunk of the n-vectors:  p = u_k + beta_k p ; xs += alpha_k p ; r -= alpha_k s_k ;
-//              u_{k+1} = Minv r  (written to the OTHER u buffer) ; partials gamma_{k+1}, ||r_{k+1}||_inf
-//          (b) t_{k+1} = rho .* (A u_{k+1})  with u_{k+1}[c] = u_k[c] - alpha_k ms_k[c] recomputed at every gathered column
-//              (two gathers), so (b) never waits for (a) of another workgroup.
-struct GSplitU {
-  const double *pn, *pm; int n;
-  using Ops = double;
-  __device__ __forceinline__ Ops fetch(int c) const { return c < n ? pn[c] : pm[c - n]; }
-  __device__ __forceinline__ void prod(const Ops &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
-  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * fetch(c); }
-  using Win = double;
-  __device__ __forceinline__ Win stage(int seg, int c) const { return seg ? pm[c] : pn[c]; }
-  __device__ __forceinline__ void wprod(const Win &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
-};
-struct EK2F {
-  const double *u, *Minv; double *s, *ms; double beta = 0; int first = 0; double dl = 0, pu = 0, pm = 0, ps = 0;
-  __device__ __forceinline__ void prefetch(int j) { pu = u[j]; pm = Minv[j]; ps = s[j]; }
-  __device__ __forceinline__ void operator()(int j, const double (&sm)[1]) {
-    const double w = sm[0], sn = first ? w : w + beta * ps;
-    dl += w * pu;
-    if (KNOCKED(32)) { if (sn == -1.2345e300) s[j] = sn; return; }
-    s[j] = sn;
-    ms[j] = pm * sn;                                                       // Minv .* s_k: the vector k_k1f applies A to
-  }
-};
-// block reduction of three quantities (sum, max, sum) behind ONE barrier pair; sred needs 3 * kWaves doubles
-__device__ __forceinline__ void block_sum_max_sum(double &a, double &b, double &c, double *sred) {
-  a = wave_sum(a); b = wave_max(b); c = wave_sum(c);
-  if ((threadIdx.x & 63) == kReduceLane) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; sred[2 * kWaves + (threadIdx.x >> 6)] = c; }
-  __syncthreads();
-  a = sred_sum(sred); b = sred_max(sred + kWaves); c = sred_sum(sred + 2 * kWaves);
-  __syncthreads();
-}
-// LATE hook of k_k2f (runs between the row sums and the epilogue): folds gamma_k and ||r_k||_inf together with this
-// workgroup's share of delta_k = <w, u_k> (one barrier pair for all three), stopping test, beta_k.
-struct PreK2F {
-  [[maybe_unused]] static constexpr int kTraceBase = 0;
-  static constexpr bool kLate = true;
-  const Dev &d; int k; EK2F *e; double *red; double *dl_first;
-  struct Tok { PartRegs prn, pg; double tol, glast; };
-  __device__ __forceinline__ Tok begin() const {
-    Tok t;
-    if (KNOCKED(1)) { t.tol = 0; t.glast = 1; return t; }
-    if (KNOCKED(256)) { for (int q = 0; q < kPart; q++) { t.prn.v[q] = 1.0; t.pg.v[q] = 1.0; } }
-    else { t.prn = partial_load(d.part + (SL_RN0 + (k & 1)) * kGrid); t.pg = partial_load(d.part + (SL_GAMMA0 + (k & 1)) * kGrid); }
-    t.tol = d.scal[S_TOL_NOW]; t.glast = k == 0 ? 1.0 : d.scal[S_HIST + k - 1];
-    return t;
-  }
-  __device__ __forceinline__ bool finish(const Tok &t, const double (&acc)[1], bool owner) const {
-    if (KNOCKED(1)) { e->beta = 0.5; e->first = 0; *dl_first = 0; return true; }
-    double gamma = partial_fold_sum(t.pg), rn = partial_fold_max(t.prn);
-    const double dl0 = owner ? acc[0] * e->pu : 0.0;
-    double dls = dl0;
-    block_sum_max_sum(gamma, rn, dls, red);
-    double *gam = d.scal + S_HIST, *bet = d.scal + S_HIST + 2 * (kMaxCg + 1);
-    if (k > 0 && !(rn > t.tol)) {        // converged after k iterations (k == 0 was tested by k_k1)
-      if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = k; }
-      return false;
-    }
-    const double beta = k == 0 ? 0.0 : gamma / t.glast;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { gam[k] = gamma; bet[k] = beta; }
-    e->beta = beta; e->first = (k == 0);
-    e->dl = -dl0;                        // the epilogue adds this row's term again: e->dl then holds only LATER rows' terms
-    *dl_first = dls;
-    return true;
-  }
-};
-__global__ __launch_bounds__(kBlock) void k_k2f(Dev d, int k) {
-  __shared__ StreamLdsW<1, double> lds;
-  KT(0);
-  const double *u = (k & 1) ? d.uu2 : d.uu;
-  GSplitU g{u, d.t, d.n};
-  EK2F e{u, d.Minv, d.s, d.ms};
-  double dl_first = 0.0;
-  if (!process_rows<1>(d.B, g, e, lds, PreK2F{d, k, &e, lds.red, &dl_first}, d.flags + F_DONE)) return;
-  if (KNOCKED(64)) { if (e.dl == -1.2345e300) put_partial(d.part, SL_DELTA, e.dl); return; }
-  double DL = dl_first;
-  if (!d.B.single) { __syncthreads(); DL += block_sum(e.dl, lds.red); }    // rows beyond the first pass of the first block
-  put_partial(d.part, SL_DELTA, DL);
-  KT(6);
-}
-// K1F_{k+1}: S = A (Minv .* s_k) needs no scalar; alpha_k (from the delta partials) enters only the row epilogue
-//   t_{k+1} = t_k - alpha_k rho .* S      ( = rho .* A u_{k+1},  u_{k+1} = u_k - alpha_k Minv .* s_k )
-// and this workgroup's slice of the vector update, so the reduction of partials runs LATE, behind the matrix stream.
-struct GMs {
-  const double *ms;
-  using Ops = double;
-  __device__ __forceinline__ Ops fetch(int c) const { return ms[c]; }
-  __device__ __forceinline__ void prod(const Ops &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
-  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * ms[c]; }
-  using Win = double;
-  __device__ __forceinline__ Win stage(int, int c) const { return ms[c]; }
-  __device__ __forceinline__ void wprod(const Win &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
-};
-struct EK1F {
-  const double *rho; double *t; double alpha = 0, pr = 0, pt = 0;
-  __device__ __forceinline__ void prefetch(int i) { pr = rho[i]; pt = t[i]; }
-  __device__ __forceinline__ void operator()(int i, const double (&s)[1]) { t[i] = pt - alpha * pr * s[0]; }
-};
-struct PreK1F {
-  [[maybe_unused]] static constexpr int kTraceBase = 8;
-  static constexpr bool kLate = true;
-  const Dev &d; int k; bool has_vec; EK1F *e; double *red; double *g, *rn;
-  struct Tok { PartRegs pd; double gamma, beta, alast; double u0, p0, r0, s0, m0, x0; };
-  __device__ __forceinline__ int first_index() const {
-    const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3;
-    return (int)(((blockIdx.x & 7) * per + (blockIdx.x >> 3)) * kBlock + threadIdx.x);
-  }
-  __device__ __forceinline__ Tok begin() const {
-    const double *uin = (k & 1) ? d.uu2 : d.uu;
-    const double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1, *bet = d.scal + S_HIST + 2 * (kMaxCg + 1);
-    Tok t;
-    if (KNOCKED(512)) { for (int q = 0; q < kPart; q++) t.pd.v[q] = 1.0; } else t.pd = partial_load(d.part + SL_DELTA * kGrid);
-    t.gamma = gam[k]; t.beta = bet[k]; t.alast = k == 0 ? 1.0 : alp[k - 1];
-    const int j0 = first_index();
-    t.u0 = t.p0 = t.r0 = t.s0 = t.m0 = t.x0 = 0.0;
-    if (has_vec && j0 < d.n) { t.u0 = uin[j0]; t.p0 = k == 0 ? 0.0 : d.p[j0]; t.r0 = d.r[j0]; t.s0 = d.s[j0]; t.m0 = d.Minv[j0]; t.x0 = d.xs[j0]; }
-    return t;
-  }
-  __device__ __forceinline__ bool finish(const Tok &t, const double (&)[1], bool) const {
-    const double *uin = (k & 1) ? d.uu2 : d.uu;
-    double *uout = (k & 1) ? d.uu : d.uu2;
-    double *alp = d.scal + S_HIST + kMaxCg + 1;
-    const PartRegs &pd = t.pd;
-    const double gamma = t.gamma, beta = t.beta, alast = t.alast;
-    const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3, slots = gridDim.x >> 3;
-    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
-    const int j0 = first_index();
-    const bool live0 = has_vec && j0 < d.n;
-    const double u0 = t.u0, p0 = t.p0, r0 = t.r0, s0 = t.s0, m0 = t.m0, x0 = t.x0;
-    const double delta = block_sum(partial_fold_sum(pd), red);
-    const double alpha = k == 0 ? gamma / delta : gamma / (delta - beta * gamma / alast);
-    if (blockIdx.x == 0 && threadIdx.x == 0) alp[k] = alpha;
-    e->alpha = alpha;
-    double gg = 0, rr = 0;
-    if (live0) {
-      const double pp_ = k == 0 ? u0 : u0 + beta * p0;
-      const double rr_ = r0 - alpha * s0, un = m0 * rr_;
-      d.p[j0] = pp_; d.xs[j0] = x0 + alpha * pp_; d.r[j0] = rr_; uout[j0] = un;
-      gg += rr_ * un; rr = nanmax(rr, fabs(rr_));
-    }
-    if (has_vec) {
-      for (int sl = slot0 + slots; sl < per; sl += slots) {
-        const int c = xcd * per + sl;
-        if (c >= nchunk) break;
-        const int j = c * kBlock + threadIdx.x;
-        if (j >= d.n) break;
-        const double u = uin[j];
-        const double pp_ = k == 0 ? u : u + beta * d.p[j];
-        const double rr_ = d.r[j] - alpha * d.s[j], un = d.Minv[j] * rr_;
-        d.p[j] = pp_; d.xs[j] += alpha * pp_; d.r[j] = rr_; uout[j] = un;
-        gg += rr_ * un; rr = nanmax(rr, fabs(rr_));
-      }
-    }
-    *g = gg; *rn = rr;
-    return true;
-  }
-};
-__global__ __launch_bounds__(kBlock) void k_k1f(Dev d, int i) {          // i >= 1; performs the vector update of k = i - 1
-  __shared__ StreamLdsW<1, double> lds;
-  KT(8);
-  const int k = i - 1;
-  const bool has_rows = wg_has_rows(d.A);
-  const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3;
-  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
-  const bool has_vec = slot0 < per && xcd * per + slot0 < nchunk;
-  if (!has_rows && !has_vec && blockIdx.x != 0) {     // (partials of a finished PCG are never read: no flag test needed)
-    put_partial(d.part, SL_GAMMA0 + (i & 1), 0.0); put_partial(d.part, SL_RN0 + (i & 1), 0.0);
-    return;
-  }
-  double g = 0, rn = 0;
-  GMs gr{d.ms};
-  EK1F e{d.rho, d.t};
-  if (!process_rows<1>(d.A, gr, e, lds, PreK1F{d, k, has_vec, &e, lds.red, &g, &rn}, d.flags + F_DONE)) return;
-  __syncthreads();
-  block_sum_max(g, rn, lds.red);
-  put_partial(d.part, SL_GAMMA0 + (i & 1), g); put_partial(d.part, SL_RN0 + (i & 1), rn);
-  KT(14);
-}
-
-// KA ------------------------------------------------------------------------------------------
-struct EKa {
-  const double *l, *u, *rho, *rho_inv; double *z, *y, *zt, *t0, *v, *dy; double alpha; double *ztg; double theta;
-  double pl = 0, pu = 0, prho = 0, prinv = 0, pz = 0, py = 0, pzt = 0;
-  __device__ __forceinline__ void prefetch(int i) { pl = l[i]; pu = u[i]; prho = rho[i]; prinv = rho_inv[i]; pz = z[i]; py = y[i]; pzt = zt[i]; }
-  __device__ __forceinline__ void operator()(int i, const double (&s)[1]) {
-    const double ztil = s[0];
-    const double zr = alpha * ztil + (1.0 - alpha) * pz;                    // _osqp.py:686-690
-    const double zn = fmin(fmax(zr + prinv * py, pl), pu);                   // :674
-    const double dyi = prho * (zr - zn), yn = py + dyi;                      // :698-703
-    const double zg = ztil + theta * (ztil - pzt);                           // A xg (Dev::ztg)
-    y[i] = yn; dy[i] = dyi; z[i] = zn; zt[i] = ztil; v[i] = prho * zn - yn; ztg[i] = zg; t0[i] = prho * zg;
-  }
-};
-// The extrapolated PCG start is used after a solve that REACHED its tolerance -- and after a cut-off one only while the start
-// residuals keep falling (slot form, below).  A cut-off solve leaves an error that the few
-// iterations it was given barely touched in the slow modes of K; extrapolating along a step that contains it feeds that error, times
-// (1 + theta), to the next cut-off solve, and through z and y back into the next right-hand side: observed as iterates growing to
-// 1e12 within 25 ADMM iterations after a rho update had left five-iteration budgets on an ill-conditioned system (then 500
-// iterations of recovery; unstructured config 2 with cg_tol_fraction 0.1).  Limiting theta by the measured residual reduction of
-// the cut-off solve did not prevent it (the residual norm says little about the slow modes); starting from x~ itself does.
-// Every workgroup takes the same branch (conv / done come from an earlier launch); rn, bn of the last iterate are folded for
-// workgroup 0's statistics.
-__device__ __forceinline__ double cutoff_theta(const Dev &d, int slot, double *red, double &rn, double &bn, int admm = -1) {
-  rn = partial_fold_max(partial_load(d.part + (SL_RN0 + slot) * kGrid)); bn = partial_fold_max(partial_load(d.part + SL_BN * kGrid));
-  block_max2(rn, bn, red);
-  if (admm < 1) return 0.0;
-  // slot form: the start residuals of this and of the previous ADMM iteration are on record (written by earlier launches).  While they
-  // FALL the cut-off solves are keeping up and the extrapolation stays (config 2: budget-limited chunks are part of normal operation,
-  // 53 vs 65 ms); once the start residual grows, the next solve starts from x~ itself.
-  const double now = d.scal[S_RN0H + (admm & 1)], prev = d.scal[S_RN0H + ((admm + 1) & 1)];
-  return (now < prev) ? d.theta : 0.0;
-}
-__global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
-  __shared__ StreamLdsW<1, double> lds;
-  int done = d.flags[F_DONE];                       // (set by an earlier launch: the same value in every wave)
-  double theta = d.theta, rn_last = 0.0, bn_last = 0.0;
-  if (!done && budget > 0) { theta = cutoff_theta(d, budget & 1, lds.red, rn_last, bn_last); __syncthreads(); }
-  GVec g{d.xs};
-  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, theta};
-  process_rows<1>(d.A, g, e, lds);
-  const int stride = gridDim.x * kBlock;
-  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) {    // _osqp.py:664-668
-    const double xt = d.xs[j], xo = d.x[j], xn = d.alpha * xt + (1.0 - d.alpha) * xo;
-    d.dx[j] = xn - xo; d.x[j] = xn;
-    d.xg[j] = xt + theta * (xt - d.xsp[j]); d.xsp[j] = xt;                   // next PCG start (Dev::xg)
-  }
-  if (blockIdx.x == 0) {                                                     // PCG statistics of this ADMM iteration
-    if (!done && budget > 0) {            // did the last budgeted iteration reach the tolerance? (no K1 ran after it)
-      const double rn = rn_last, bn = bn_last;
-      done = !(rn > fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS])) ? 2 : 0;
-      if (!done && threadIdx.x == 0 && rn > 0.1 * d.scal[S_RN0]) d.flags[F_STAT_STAG] += 1;
-    }
-    if (threadIdx.x == 0) {
-      const int used = done == 1 ? d.flags[F_ITERS] : budget;
-      d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;
-      if (used > d.flags[F_STAT_MAX]) d.flags[F_STAT_MAX] = used;
-      if (!done) d.flags[F_STAT_UNCONV] += 1;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------- slot kernels
-// Device-side scheduling of the ADMM / PCG phases (no launch is wasted on a converged PCG).  A chunk of ADMM iterations is a fixed
-// string of launches  B A B A ...  ("slots"): a B slot streams B = [P + sigma I | A'] and runs whichever B-phase is due (KB, or
-// the K2F of the current PCG iteration), an A slot streams A and runs the A-phase that is due (the first K1, a K1F, or KA).  Which
-// phase is due is a small record in device memory: every slot reads the record its predecessor wrote (kernel boundary = ordering),
-// its workgroup 0 writes the successor's -- two records, so that no workgroup of a launch can observe its own launch's update.
-// The PCG of ADMM iteration j therefore takes exactly as many slot pairs as it has iterations (plus the pair that detects
-// convergence and runs KA), whatever the neighbouring iterations needed; only the few slots left over at the END of a chunk idle.
-enum SlotPhase { P_KB = 0, P_K1, P_K2F, P_K1F, P_KA, P_IDLE, P_F /* a PCG iteration of the F1 form (k_slot1) */ };
-enum SlotRec { SR_PHASE = 0, SR_K, SR_ADMM, SR_TARGET, SR_USED, SR_CONV, SR_CAP, SR_SEQ /* slots executed since k_slot_init: every slot adds one */, SR_WORDS = 8 };
-
-struct SlotState { int ph, k, admm, target, used, conv, cap, seq; };
-__device__ __forceinline__ SlotState slot_read(const int *r) { return SlotState{r[SR_PHASE], r[SR_K], r[SR_ADMM], r[SR_TARGET], r[SR_USED], r[SR_CONV], r[SR_CAP], r[SR_SEQ]}; }
-__device__ __forceinline__ void slot_write(int *w, const SlotState &s) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) { w[SR_PHASE] = s.ph; w[SR_K] = s.k; w[SR_ADMM] = s.admm; w[SR_TARGET] = s.target; w[SR_USED] = s.used; w[SR_CONV] = s.conv; w[SR_CAP] = s.cap; w[SR_SEQ] = s.seq + 1; }
-}
-__global__ void k_slot_init(int *slot, int target, int cap, int epoch) {      // (cap: PCG iterations per solve; in the record, not a kernel argument, so that captured strings of slots serve every chunk)
-  slot[SR_PHASE] = P_KB; slot[SR_K] = 0; slot[SR_ADMM] = 0; slot[SR_TARGET] = target; slot[SR_USED] = 0; slot[SR_CONV] = 0; slot[SR_CAP] = cap; slot[SR_SEQ] = 0;
-  slot[SR_WORDS + SR_SEQ] = 0; slot[SR_WORDS + SR_ADMM] = 0;        // (record B still holds the previous chunk's last state: slot_poll takes the newer record)
-  slot[2 * SR_WORDS] = epoch;                                        // which chunk the records belong to (slot_poll)
-}
-
-__global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
-  __shared__ union { StreamLds<2> kb; StreamLdsW<1, double> k2f; } lds;
-  const FirstDesc fd = first_desc<true>(d.B);          // (both B phases start from the same descriptors: requested before the branch)
-  SlotState st = slot_read(d.slot);                    // written by the previous A slot (or k_slot_init)
-  int *W = d.slot + SR_WORDS;
-  if (st.ph == P_KB) {
-    if (st.admm >= st.target) { st.ph = P_IDLE; slot_write(W, st); return; }
-    GKb g{d.xg, d.v, d.t0, d.n};
-    EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma, d.xg, d.xs};
-    process_rows_fd<2>(d.B, g, e, lds.kb, NoPre(), fd);
-    __syncthreads();
-    const double G = block_sum(e.g, lds.kb.red);
-    double RN = e.rn, BN = e.bn;
-    block_max2(RN, BN, lds.kb.red);
-    put_partial(d.part, SL_GAMMA0, G); put_partial(d.part, SL_RN0, RN); put_partial(d.part, SL_BN, BN);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
-    st.ph = P_K1; st.k = 0;
-  } else if (st.ph == P_K2F) {
-    const int k = st.k;
-    const double *u = (k & 1) ? d.uu2 : d.uu;
-    GSplitU g{u, d.t, d.n};
-    EK2F e{u, d.Minv, d.s, d.ms};
-    double dl_first = 0.0;
-    if (!process_rows_fd<1>(d.B, g, e, lds.k2f, PreK2F{d, k, &e, lds.k2f.red, &dl_first}, fd)) {   // converged after k iterations
-      st.ph = P_KA; st.used = k; st.conv = 1;
-      slot_write(W, st);
-      return;
-    }
-    double DL = dl_first;
-    if (!d.B.single) { __syncthreads(); DL += block_sum(e.dl, lds.k2f.red); }
-    put_partial(d.part, SL_DELTA, DL);
-    st.ph = P_K1F;
-  }
-  slot_write(W, st);                                   // (P_KA pending after a PCG that hit the cap, P_IDLE: passed through)
-}
-
-// KA with the PCG statistics taken from the slot record (used iterations; conv = 0: the PCG stopped at the cap -- did its last
-// iterate reach the tolerance anyway?)
-template <class L>
-__device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv, const FirstDesc &fd, int admm, int target, int rn_slot = -1) {
-  double theta = d.theta, rn_last = 0.0, bn_last = 0.0;
-  // (rn_slot: which of the two ||r|| partial buffers the last PCG launch wrote -- the parity of `used` in the two-kernel form, of the LAUNCH in the F1 form)
-  if (!conv) { theta = cutoff_theta(d, rn_slot >= 0 ? rn_slot : (used & 1), lds.red, rn_last, bn_last, admm); __syncthreads(); }      // (conv comes from the slot record: uniform)
-  GVec g{d.xs};
-  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, theta};
-  process_rows_fd<1>(d.A, g, e, lds, NoPre(), fd);
-  const int stride = gridDim.x * kBlock;
-  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) {    // _osqp.py:664-668
-    const double xt = d.xs[j], xo = d.x[j], xn = d.alpha * xt + (1.0 - d.alpha) * xo;
-    d.dx[j] = xn - xo; d.x[j] = xn;
-    d.xg[j] = xt + theta * (xt - d.xsp[j]); d.xsp[j] = xt;                   // next PCG start (Dev::xg)
-  }
-  if (blockIdx.x == 0) {
-    if (!conv) {
-      const double rn = rn_last, bn = bn_last;
-      conv = !(rn > fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS])) ? 2 : 0;
-      if (!conv && threadIdx.x == 0 && rn > 0.1 * d.scal[S_RN0]) d.flags[F_STAT_STAG] += 1;
-    }
-    if (threadIdx.x == 0) {
-      d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;
-      if (used > d.flags[F_STAT_MAX]) d.flags[F_STAT_MAX] = used;
-      if (!conv) d.flags[F_STAT_UNCONV] += 1;
-      if (d.ctl && admm + 1 >= target) d.ctl->chunk_done = 1;      // device-driven boundaries: the chunk's last ADMM iteration (read by LATER launches)
-    }
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_slot_a(Dev d) {
-  __shared__ union { StreamLdsW<1, double> k1; StreamLdsW<1, double> k1f; } lds;
-  const FirstDesc fd = first_desc<true>(d.A);
-  SlotState st = slot_read(d.slot + SR_WORDS);         // written by the previous B slot
-  int *W = d.slot;
-  if (st.ph == P_K1) {                                 // first A-apply of this ADMM iteration's PCG: stopping test on r_0, t_0 = rho .* (A u_0)
-    GVec g{d.uu};
-    EK1 e{d.rho, d.t};
-    if (process_rows_fd<1>(d.A, g, e, lds.k1, PreK1{d, 0, 0, lds.k1.red, st.admm & 1}, fd)) { st.ph = P_K2F; st.k = 0; }
-    else {                                             // the warm start already meets the tolerance: no PCG iteration, KA right here
-      __syncthreads();
-      slot_ka(d, lds.k1, 0, 1, fd, st.admm, st.target);
-      st.ph = P_KB; st.admm += 1;
-    }
-  } else if (st.ph == P_K1F) {
-    const int k = st.k, i = k + 1;
-    const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3;
-    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
-    const bool has_vec = slot0 < per && xcd * per + slot0 < nchunk;
-    if (!wg_has_rows(d.A) && !has_vec && blockIdx.x != 0) {
-      put_partial(d.part, SL_GAMMA0 + (i & 1), 0.0); put_partial(d.part, SL_RN0 + (i & 1), 0.0);
-    } else {
-      double g = 0, rn = 0;
-      GMs gr{d.ms};
-      EK1F e{d.rho, d.t};
-      process_rows_fd<1>(d.A, gr, e, lds.k1f, PreK1F{d, k, has_vec, &e, lds.k1f.red, &g, &rn}, fd);
-      __syncthreads();
-      block_sum_max(g, rn, lds.k1f.red);
-      put_partial(d.part, SL_GAMMA0 + (i & 1), g); put_partial(d.part, SL_RN0 + (i & 1), rn);
-    }
-    if (i >= st.cap) { st.ph = P_KA; st.used = i; st.conv = 0; }      // the PCG stops at the cap; the next A slot runs KA
-    else { st.ph = P_K2F; st.k = i; }
-  } else if (st.ph == P_KA) {
-    slot_ka(d, lds.k1, st.used, st.conv, fd, st.admm, st.target);
-    st.ph = P_KB; st.admm += 1;
-  }
-  slot_write(W, st);
-}
-
-
-// ---------------------------------------------------------------------------------------------- one launch per PCG iteration (F1)
-// backend.h DevF1.  Launch F_k of the PCG of one ADMM iteration (k = 0 .. iterations):
-//   scalars   k = 0:  ||r_0||, ||rhs|| (KB's partials) -> tolerance, stopping test
-//             k >= 1: gamma_{k-1}, delta_{k-1}, ||r_{k-1}|| (partials of F_{k-1}) -> stopping test (k >= 2), beta_{k-1}, alpha_{k-1}
-//   window    u_k[c] = Minv (r_{k-1} - alpha (w_{k-1} + beta s_{k-2}))[c],  w_{k-1} = sum_d rep_d = K u_{k-1}   (k = 0: Minv r_0)
-//             for every column c of the block's GATHER window (the columns its rows of A and its own rows of P touch) -- recomputed
-//             by every workgroup that gathers c, with the same instruction sequence as the owner's update (f1_upd): all copies
-//             are bit-identical.  The lane whose window column is one of the block's OWN columns also performs that column's
-//             vector update:  s_{k-1}, r_k, p_{k-1}, x~ += alpha p_{k-1}  stored;  partials gamma_k = <r_k, Minv r_k>, ||r_k||_inf
-//   SpMV      t = rho .* (A_g u_k)  (rows of the block, products staged in LDS, one lane per row),
-//             pu_k = (P + sigma I) u_k  on the own columns,  rep_{g mod D} = A_g' t (+ pu_k on the own columns)  per column of the block's
-//             SCATTER window (the columns of its rows of A, which include its own columns; second, column-ordered pass over the
-//             entries still held in registers),  partial delta_k = <t, A u_k> + <u_k, pu_k>_own = <u_k, K u_k>
-// r, s, rep are double-buffered by the parity of k: a workgroup reads what the PREVIOUS launch wrote while its neighbours
-// write this launch's values.  Four workgroup barriers per block, no global synchronisation inside the launch.
-// Template: D = replicas, FIRST = the launch F_0 (straight-line code: no run-time branch on either).
-struct F1Lds {
-  double win[kF1Win];            // u_k on the block's gather window
-  double prod[kF1Chunk];         // A products in row-major entry order, then val * t[row] in column-major order
-  double tvec[kF1MaxRows];       // t of the block's rows
-  double uown[kF1MaxOwn];        // u_k on the own columns
-  double puown[kF1MaxOwn];       // (P + sigma I) u_k on the own columns: added to the block's own slice of A' t (the own columns lie inside its scatter window)
-  double pprod[kF1PChunk];       // (P + sigma I) products of the own rows
-  double red[3 * kWaves];
-};
-struct F1Scal { double alpha, beta; int general; };       // general = 0: the first update (s_0 = w_0, p_0 = u_0: s_{-1}, p_{-1} are not used)
-template <int D>
-__device__ __forceinline__ double f1_w(const double (&rp)[D]) {     // w_{k-1} = K u_{k-1}: the replicas in index order (deterministic)
-  double w = rp[0];
-#pragma unroll
-  for (int q = 1; q < D; q++) w += rp[q];
-  return w;
-}
-__device__ __forceinline__ void f1_upd(const F1Scal &sc, double minv, double r, double w, double sp, double &sn, double &rn, double &un) {
-  sn = fma(sc.beta, sc.general ? sp : 0.0, w);           // (first update: beta = 0 and the stale s is masked, so s_0 = w_0 exactly)
-  rn = fma(-sc.alpha, sn, r);
-  un = minv * rn;
-}
-// sum of seg[a .. z): the first kB entries with independent LDS reads (as process_rows)
-template <int kB>
-__device__ __forceinline__ double f1_segsum(const double *seg, int a, int z) {
-  double v[kB];
-#pragma unroll
-  for (int q = 0; q < kB; q++) v[q] = a + q < z ? seg[a + q] : 0.0;
-  double acc = 0.0;
-#pragma unroll
-  for (int q = 0; q < kB; q++) acc += v[q];
-  for (int k = a + kB; k < z; k++) acc += seg[k];
-  return acc;
-}
-// The scalar part of launch F_k.  The per-workgroup partials (gamma, delta, ||r||) are double-buffered by the parity of the LAUNCH, not of k:
-// a launch reads what the previous launch of the string wrote -- KB: gamma_0, ||r_0||, ||rhs|| (in delta's slot); F_k: gamma_k, delta_k, ||r_k|| --
-// so the three loads depend on nothing but the kernel's `par` argument and leave at the very head of the launch (f1_fold_issue), next to
-// the phase record instead of behind it.  f1_fold_finish returns false when the PCG had already converged (the caller runs KA in this launch).
-struct F1Fold { PartRegs a, b, c; };
-__device__ __forceinline__ F1Fold f1_fold_issue(const Dev &d, const int par, const int probe) {
-  F1Fold f;
-#pragma unroll
-  for (int q = 0; q < kPart; q++) { f.a.v[q] = 0.0; f.b.v[q] = 0.0; f.c.v[q] = 0.0; }
-  if (probe == 1) return f;                                 // (probe == 2 pays for the fold like a solve's launch, then uses the fixed scalars)
-  const int prev = par ^ 1;
-  f.a = partial_load(d.part + (SL_GAMMA0 + prev) * kGrid); f.b = partial_load(d.part + (SL_DELTA + prev) * kGrid); f.c = partial_load(d.part + (SL_RN0 + prev) * kGrid);
-  return f;
-}
-__device__ __forceinline__ bool f1_fold_finish(const Dev &d, const int k, const int admm_par, const int probe, const F1Fold &f, double *red, F1Scal &sc) {
-  double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
-  const int tid = threadIdx.x;
-  sc = F1Scal{0.0, 0.0, k >= 2};
-  if (probe == 1) { sc.alpha = 1e-3; sc.beta = k >= 2 ? 0.5 : 0.0; return true; }
-  if (k == 0) {
-    double rn = partial_fold_max(f.c), bn = partial_fold_max(f.b);
-    block_max2(rn, bn, red);
-    const double tol = fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS]);
-    if (probe) { if (rn < -1.0) d.res[R_COUNT - 1] = bn + tol; return true; }
-    if (blockIdx.x == 0 && tid == 0) { d.scal[S_TOL_NOW] = tol; d.scal[S_RN0] = rn; d.scal[S_RN0H + admm_par] = rn; }
-    return rn > tol;                                        // false: the start already meets the tolerance (a NaN also ends the inner loop)
-  }
-  const double tol = d.scal[S_TOL_NOW], glast = k >= 2 ? gam[k - 2] : 1.0, alast = k >= 2 ? alp[k - 2] : 1.0;
-  double gamma = partial_fold_sum(f.a), rn = partial_fold_max(f.c), delta = partial_fold_sum(f.b);
-  block_sum_max_sum(gamma, rn, delta, red);
-  if (probe) {                                              // timing probe: the fold above was paid for; bounded, repeatable scalars instead of its result
-    if (rn < -1.0) d.res[R_COUNT - 1] = gamma + delta + tol + glast + alast;      // (never true: keeps the fold alive)
-    sc.alpha = 1e-3; sc.beta = k >= 2 ? 0.5 : 0.0;
-    return true;
-  }
-  if (k >= 2 && !(rn > tol)) return false;                  // converged after k - 1 iterations (r_0 was tested by F_0)
-  sc.beta = k >= 2 ? gamma / glast : 0.0;
-  sc.alpha = k >= 2 ? gamma / (delta - sc.beta * gamma / alast) : gamma / delta;
-  if (blockIdx.x == 0 && tid == 0) { gam[k - 1] = gamma; alp[k - 1] = sc.alpha; }
-  return true;
-}
-// base[idx] as int4 through the CONSTANT address space: with a wave-uniform index the compiler emits scalar loads
-__device__ __forceinline__ int4 sload_int4(const int *base, size_t idx) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef int __attribute__((ext_vector_type(4))) v4i;
-  typedef const v4i __attribute__((address_space(4))) *cptr;
-  const v4i v = ((cptr)(unsigned long long)base)[idx];
-  return make_int4(v.x, v.y, v.z, v.w);
-#else
-  return reinterpret_cast<const int4 *>(base)[idx];
-#endif
-}
-struct F1Rec { int4 ds, fa, fb, fc; };      // a block's record (DevF1::blk)
-__device__ __forceinline__ F1Rec f1_record(const DevF1 &f, int b) {
-  return F1Rec{sload_int4(f.blk, 4 * (size_t)b), sload_int4(f.blk, 4 * (size_t)b + 1), sload_int4(f.blk, 4 * (size_t)b + 2), sload_int4(f.blk, 4 * (size_t)b + 3)};
-}
-template <int D, bool FIRST>
-__device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool vec_only, const F1Scal sc, F1Lds &L, const F1Rec &rec0, const int par) {
-  const DevF1 &f = d.f1;
-  const int n = d.n, tid = threadIdx.x;
-  const int cur = (k + 1) & 1, nxt = k & 1;               // parity of k - 1 / of k
-  KT(1);
-  // every n-vector of the iteration lives in ONE arena (DevF1::va, stride ns): the addresses derive from one base pointer by scalar
-  // adds instead of a kernel-argument load per vector
-  const double *va = f.va; const size_t ns = f.ns;
-  const double *Minv = va, *xs_r = va + ns, *p_r = va + 2 * ns;
-  double *xs_w = f.va + ns, *p_w = f.va + 2 * ns;
-  const double *rread = va + (3 + ((FIRST || cur == 0) ? 0 : 1)) * ns;      // r_{k-1} (F_0: r_0)
-  double *rnxt = f.va + (3 + nxt) * ns;                     // r_k
-  const double *sprev = va + (5 + cur) * ns;                // s_{k-2}: stored next to r_{k-1}
-  double *snew = f.va + (5 + nxt) * ns;                     // s_{k-1}: stored next to r_k
-  const double *repcur = va + (7 + (size_t)cur * D) * ns;   // K u_{k-1} in D partial vectors
-  double *repnxt = f.va + (7 + (size_t)nxt * D) * ns;
-  double g_acc = 0.0, rn_acc = 0.0, dl_acc = 0.0;
-  // the vector update of one own column (operands in registers): stores s_{k-1}, r_k, p_{k-1}, x~; returns u_k
-  auto own_update = [&](int j, double mi, double r, double w, double sp, double pp, double x) -> double {
-    double sn, rn, un;
-    f1_upd(sc, mi, r, w, sp, sn, rn, un);
-    const double pn = fma(sc.beta, sc.general ? pp : 0.0, mi * r);
-    xs_w[j] = fma(sc.alpha, pn, x); p_w[j] = pn; snew[j] = sn; rnxt[j] = rn;
-    g_acc += rn * un; rn_acc = nanmax(rn_acc, fabs(rn));
-    return un;
-  };
-  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, slots = gridDim.x >> 3;
-  const int per = (d.A.nblk + 7) >> 3;
-  constexpr int CW = kF1Win / kBlock, CE = kF1Chunk / kBlock;
-  static_assert(kF1PChunk == kBlock, "one (P + sigma I) entry per lane");
-  for (int sl = slot0; sl < per; sl += slots) {
-    const int b = __builtin_amdgcn_readfirstlane(xcd * per + sl);
-    if (b >= d.A.nblk) break;
-    // the block's record: 16 words, one scalar load
-    // (read through the constant address space: the index is wave-uniform, so the four int4 become scalar loads behind ONE wait --
-    //  as generic-pointer loads inside this loop they were four vector loads, each waited for before the next was issued)
-    const F1Rec rec = sl == slot0 ? rec0 : f1_record(f, b);      // (the first block's record was requested before the scalar fold)
-    const int4 ds = rec.ds, fa = rec.fa, fb = rec.fb, fc = rec.fc;
-    const int r0 = ds.x, nrows = ds.y - ds.x, k0 = ds.z, cnt = ds.w - ds.z;
-    const int cov0 = fa.x, cov1 = fa.y, cs0 = fa.z, nown = fa.w - fa.z;
-    const int cpo = fb.x, pk0 = fb.y, pcnt = fb.z - fb.y;
-    const int g0 = fc.x, gl = vec_only ? 0 : fc.y, a0 = fc.z, wl = fc.w;      // gather window [g0, g0 + gl), scatter window [a0, a0 + wl)
-    const int nw = (gl + kBlock - 1) / kBlock, nu = (cnt + kBlock - 1) / kBlock, ns2 = (wl + kBlock - 1) / kBlock;
-    KT(2);
-    // ---- loads.  First the (P + sigma I) entry of this lane: its column decides whether the operand comes from the window or has
-    //      to be recomputed from its parts (columns outside the window), and those loads should leave with the window's, not after it
-    double pv = 0.0; int pc = g0;
-    const bool hasp = !vec_only && tid < pcnt;
-    if (!vec_only) { const int e = pk0 + max(0, min(tid, pcnt - 1)); pv = f.pval[e]; pc = f.pcol[e]; }
-    // ---- window parts (+ p, x~ where the window column is one of the block's own)
-    double wm[CW], wr[CW], wsv[CW], wq[CW][D], wpp[CW], wx[CW];
-    bool wown[CW];
-#pragma unroll
-    for (int u = 0; u < CW; u++) {
-      wown[u] = false;
-      if (u < nw) {
-        const int e = tid + u * kBlock, c = g0 + min(e, gl - 1);
-        wown[u] = e < gl && c >= cs0 && c - cs0 < nown;
-        wm[u] = Minv[c]; wr[u] = rread[c];
-        if (!FIRST) {
-#pragma unroll
-          for (int q = 0; q < D; q++) wq[u][q] = repcur[q * ns + c];
-          wsv[u] = sprev[c];
-          const int co = wown[u] ? c : g0;                  // (other lanes re-read one valid element: no branch around the loads)
-          wx[u] = xs_r[co]; wpp[u] = p_r[co];
-        }
-      }
-    }
-    // ---- matrix entries, row / column pointers
-    double vw[CE]; unsigned int en[CE];
-    int rp0 = 0, rp1 = 0; double rrho = 0.0;
-    int cp0[CW], cp1[CW];
-    int pp0 = 0, pp1 = 0;
-    if (!vec_only) {
-#pragma unroll
-      for (int u = 0; u < CE; u++) { if (u < nu) { const int e = k0 + min(tid + u * kBlock, cnt - 1); vw[u] = d.A.val[e]; en[u] = f.ent[e]; } }
-      { const int row = r0 + min(tid, nrows - 1); rp0 = d.A.rowptr[row]; rp1 = d.A.rowptr[row + 1]; rrho = d.rho[row]; }
-#pragma unroll
-      for (int u = 0; u < CW; u++) { if (u < ns2) { const int c = cpo + min(tid + u * kBlock, wl - 1); cp0[u] = f.cptr[c]; cp1[u] = f.cptr[c + 1]; } }
-      { const int j = min(cs0 + max(0, min(tid, nown - 1)), n - 1); pp0 = f.prp[j]; pp1 = f.prp[j + 1]; }
-    }
-    // ---- operand of a (P + sigma I) entry whose column lies outside the window: its parts, requested now
-    const int pcl = pc - g0;
-    const bool esc = hasp && !(pcl >= 0 && pcl < gl);
-    double em = 0, er = 0, es = 0, eq[D];
-#pragma unroll
-    for (int q = 0; q < D; q++) eq[q] = 0.0;
-    if (esc) {
-      em = Minv[pc]; er = rread[pc];
-      if (!FIRST) {
-        es = sprev[pc];
-#pragma unroll
-        for (int q = 0; q < D; q++) eq[q] = repcur[q * ns + pc];
-      }
-    }
-    KT(3);
-    // ---- u_k on the window -> LDS; the lane of an own column also performs that column's vector update
-#pragma unroll
-    for (int u = 0; u < CW; u++) {
-      if (u < nw) {
-        const int e = min(tid + u * kBlock, gl - 1);
-        double un;
-        if (FIRST) un = wm[u] * wr[u];
-        else {
-          const double w = f1_w<D>(wq[u]);
-          if (wown[u]) un = own_update(g0 + e, wm[u], wr[u], w, wsv[u], wpp[u], wx[u]);
-          else { double sn, rn; f1_upd(sc, wm[u], wr[u], w, wsv[u], sn, rn, un); }
-        }
-        if (wown[u]) L.uown[g0 + e - cs0] = un;
-        L.win[e] = un;                                      // (clamped lanes store the same value)
-      }
-    }
-    // ---- own columns outside the gather window (none on banded problems; all of them in the last budgeted update)
-    for (int jj = tid; jj < nown; jj += kBlock) {
-      const int j = cs0 + jj;
-      if (j >= g0 && j - g0 < gl) continue;
-      const double mi = Minv[j], r = rread[j];
-      double un = mi * r;
-      if (!FIRST) {
-        double rp[D];
-#pragma unroll
-        for (int q = 0; q < D; q++) rp[q] = repcur[q * ns + j];
-        un = own_update(j, mi, r, f1_w<D>(rp), sprev[j], p_r[j], xs_r[j]);
-      }
-      if (!vec_only) L.uown[jj] = un;
-    }
-    if (vec_only) continue;
-    KT(4);
-    __syncthreads();
-    // ---- products: A entries against the window; the (P + sigma I) entry against the window or its recomputed operand
-#pragma unroll
-    for (int u = 0; u < CE; u++) { if (u < nu) L.prod[tid + u * kBlock] = vw[u] * L.win[en[u] & 0x1ffu]; }
-    if (hasp) {
-      double uv;
-      if (!esc) uv = L.win[pcl];
-      else if (FIRST) uv = em * er;
-      else { double sn, rn; f1_upd(sc, em, er, f1_w<D>(eq), es, sn, rn, uv); }
-      L.pprod[tid] = pv * uv;
-    }
-    KT(5);
-    __syncthreads();
-    // ---- row sums: t = rho .* (A u) -> LDS
-    for (int row = tid; row < nrows; row += kBlock) {
-      if (row != tid) { rp0 = d.A.rowptr[r0 + row]; rp1 = d.A.rowptr[r0 + row + 1]; rrho = d.rho[r0 + row]; }
-      const double au = f1_segsum<6>(L.prod, rp0 - k0, rp1 - k0), t = rrho * au;
-      L.tvec[row] = t; dl_acc += t * au;
-    }
-    KT(6);
-    __syncthreads();
-    // ---- A_g' t: val * t[row] scattered to column-major order;  pu = (P + sigma I) u on the own columns -> global
-#pragma unroll
-    for (int u = 0; u < CE; u++) { if (u < nu) L.prod[en[u] >> 18] = vw[u] * L.tvec[(en[u] >> 9) & 0x1ffu]; }     // (clamped lanes repeat the last entry's store)
-    for (int jj = tid; jj < nown; jj += kBlock) {
-      if (jj != tid) { pp0 = f.prp[cs0 + jj]; pp1 = f.prp[cs0 + jj + 1]; }
-      const double pu = f1_segsum<4>(L.pprod, pp0 - pk0, pp1 - pk0);
-      L.puown[jj] = pu; dl_acc += L.uown[jj] * pu;
-    }
-    KT(7);
-    __syncthreads();
-    // ---- one lane per column of the scatter window
-    double *rout = repnxt + (size_t)(b % D) * ns;
-#pragma unroll
-    for (int u = 0; u < CW; u++) {
-      if (u < ns2) {
-        const int c = tid + u * kBlock;
-        if (c < wl) {
-          double v = f1_segsum<8>(L.prod, cp0[u], cp1[u]);
-          const int jo = a0 + c - cs0;
-          if (jo >= 0 && jo < nown) v += L.puown[jo];         // this block owns the column: + (P + sigma I) u
-          rout[a0 + c] = v;
-        }
-      }
-    }
-    for (int j = cov0 + tid; j < a0; j += kBlock) rout[j] = 0.0;             // the replica's gap up to the next window of this replica
-    for (int j = a0 + wl + tid; j < cov1; j += kBlock) rout[j] = 0.0;
-    KT(8);
-    if (sl + slots < per) __syncthreads();                  // (another block follows: the LDS arrays are reused)
-  }
-  __syncthreads();
-  block_sum_max_sum(g_acc, rn_acc, dl_acc, L.red);
-  if (!FIRST) { put_partial(d.part, SL_GAMMA0 + par, g_acc); put_partial(d.part, SL_RN0 + par, rn_acc); }
-  else if (tid == 0) {                                      // F_0 hands KB's gamma_0, ||r_0|| on: this workgroup's entries move to this launch's buffers
-    d.part[(SL_GAMMA0 + par) * kGrid + blockIdx.x] = d.part[(SL_GAMMA0 + (par ^ 1)) * kGrid + blockIdx.x];
-    d.part[(SL_RN0 + par) * kGrid + blockIdx.x] = d.part[(SL_RN0 + (par ^ 1)) * kGrid + blockIdx.x];
-  }
-  if (!vec_only) put_partial(d.part, SL_DELTA + par, dl_acc);
-  KT(9);
-}
-// returns false when the PCG had already converged (nothing done: the caller runs KA in this launch)
-// the record of the workgroup's first row block
-__device__ __forceinline__ F1Rec f1_first_record(const Dev &d) {
-  const int b0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * ((d.A.nblk + 7) >> 3) + (int)(blockIdx.x >> 3));
-  return f1_record(d.f1, min(b0, d.A.nblk - 1));
-}
-// D (the number of replica vectors, DevF1::D) is a TEMPLATE parameter of the kernels: a slot kernel that carries the bodies of all four
-// values pays for the three it never runs in every launch (the head of a launch is as long as the kernel's register / code footprint
-// makes it)
-template <int D>
-__device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const int cap, const int admm_par, const int probe, F1Lds &L, const F1Rec &rec0, const F1Fold &fold, const int par) {
-  KT(0);
-  F1Scal sc;
-  if (!f1_fold_finish(d, k, admm_par, probe, fold, L.red, sc)) return false;
-  const bool vec_only = !probe && k >= cap;                 // the last budgeted update: no operator apply follows
-  if (k == 0) f1_body<D, true>(d, k, vec_only, sc, L, rec0, par);
-  else f1_body<D, false>(d, k, vec_only, sc, L, rec0, par);
-  return true;
-}
-__global__ __launch_bounds__(kBlock) void k_f1_refresh(Dev d) {
-  for (int k = blockIdx.x * kBlock + threadIdx.x; k < d.f1.pnnz; k += gridDim.x * kBlock) d.f1.pval[k] = d.B.val[d.f1.psrc[k]];
-}
-// timing probe: one F launch as a solve runs it -- the scalar fold of the previous launch's partials included -- with fixed alpha, beta
-// and no stopping test (mode 2; mode 1 skips the fold: what the launch costs without it)
-template <int D>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_f1_probe(Dev d, int k, int mode) {
-  __shared__ F1Lds lds;
-  const int par = k & 1;
-  const F1Fold fold = f1_fold_issue(d, par, mode);
-  f1_iteration<D>(d, k, 1 << 30, 0, mode, lds, f1_first_record(d), fold, par);      // (the first block's record goes out ahead of the partials of the scalar fold: both latencies overlap)
-}
-
-// The slot kernel of the F1 form: every launch of a chunk's string is this kernel (par: which of the two phase records it reads);
-// the phase that is due -- KB (streams B), a PCG iteration F_k (streams A and P), KA (streams A) -- comes from the record.
-template <int D>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_slot1(Dev d, int par) {
-  __shared__ union { StreamLds<2> kb; StreamLdsW<1, double> ka; F1Lds f; } lds;
-  const int *R = d.slot + (par ? SR_WORDS : 0);
-  int *W = d.slot + (par ? 0 : SR_WORDS);
-  // The head of every launch is a chain of dependent scalar loads (kernel arguments -> phase record -> block record -> first vector loads):
-  // the arguments the F phase needs are pinned into registers HERE, behind one wait, and the block record is requested together with the
-  // phase record (most launches are F launches; KB / KA request their own descriptors after the branch)
-  const F1Fold fold = f1_fold_issue(d, par, 0);         // the previous launch's partials: their address depends on `par` alone
-  const F1Rec rec0 = f1_first_record(d);
-  SlotState st = slot_read(R);
-#if defined(__HIP_DEVICE_COMPILE__)
-  // both records, the partials and the phases' base pointers are in registers HERE: requested together, one wait
-  asm volatile("" :: "s"(st.ph), "s"(rec0.ds.x), "s"(rec0.fc.w), "s"(d.part), "s"(d.scal), "s"(d.f1.va), "s"(d.x), "s"(d.ztg), "s"(d.v), "s"(d.uu), "s"(d.n),
-               "v"(fold.a.v[0]), "v"(fold.a.v[kPart - 1]), "v"(fold.b.v[0]), "v"(fold.b.v[kPart - 1]), "v"(fold.c.v[0]), "v"(fold.c.v[kPart - 1]));
-#endif
-  if (st.ph == P_KB) {
-    if (st.admm >= st.target) { st.ph = P_IDLE; slot_write(W, st); return; }
-    GKb g{d.xg, d.v, d.t0, d.n};
-    EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma, d.xg, d.xs};
-    process_rows<2>(d.B, g, e, lds.kb);
-    __syncthreads();
-    const double G = block_sum(e.g, lds.kb.red);
-    double RN = e.rn, BN = e.bn;
-    block_max2(RN, BN, lds.kb.red);
-    put_partial(d.part, SL_GAMMA0 + par, G); put_partial(d.part, SL_RN0 + par, RN); put_partial(d.part, SL_DELTA + par, BN);      // (||rhs|| travels in delta's slot: f1_fold_finish, k = 0)
-    put_partial(d.part, SL_BN, BN);                        // (... and stays on record for the KA of a PCG that ran into its cap)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
-    st.ph = P_F; st.k = 0;
-  } else if (st.ph == P_F) {
-    if (f1_iteration<D>(d, st.k, st.cap, st.admm & 1, 0, lds.f, rec0, fold, par)) {
-      if (st.k >= st.cap) { st.ph = P_KA; st.used = st.k; st.conv = 0; }      // stopped at the cap: the next launch runs KA
-      else st.k += 1;
-    } else {                                             // converged: KA right here
-      __syncthreads();
-      slot_ka(d, lds.ka, st.k == 0 ? 0 : st.k - 1, 1, first_desc<true>(d.A), st.admm, st.target);
-      st.ph = P_KB; st.admm += 1;
-    }
-  } else if (st.ph == P_KA) {
-    slot_ka(d, lds.ka, st.used, st.conv, first_desc<true>(d.A), st.admm, st.target, par ^ 1);
-    st.ph = P_KB; st.admm += 1;
-  }
-  slot_write(W, st);
-}
 
 // ---------------------------------------------------------------------------------------------- residual kernels
 struct EKr1 : NoPrefetch {
@@ -1563,7 +163,6 @@ __global__ __launch_bounds__(kBlock) void k_set_rho(Dev d, double rho_bar, int c
   }
 }
 struct GPrec { const double *rho; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = c >= n ? rho[c - n] * a * a : 0.0; } };
-struct EPrec : NoPrefetch { const double *Bval; const int *Bdiag; double *Minv; __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { Minv[j] = 1.0 / (Bval[Bdiag[j]] + s[0]); } };
 __global__ __launch_bounds__(kBlock) void k_precond(Dev d, int cond) {
   __shared__ StreamLds<1> lds;
   if (cond && !d.ctl->rho_flag) return;
@@ -1641,20 +240,6 @@ __global__ __launch_bounds__(kBlock) void k_scale_warm(Dev d, const double *xin,
   if (yin) for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += stride) d.y[i] = c * d.Einv[i] * yin[i];
 }
 
-struct EStore : NoPrefetch { double *out; __device__ __forceinline__ void operator()(int r, const double (&s)[1]) { out[r] = s[0]; } };
-struct GVecSplit {           // one concatenated input vector; windowed blocks address its two column segments separately
-  const double *x; int split;
-  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * x[c]; }
-  using Win = double;
-  __device__ __forceinline__ Win stage(int seg, int c) const { return x[seg ? split + c : c]; }
-  __device__ __forceinline__ void wprod(const Win &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
-};
-__global__ __launch_bounds__(kBlock) void k_test_spmv(DevCsr M, const double *in, double *out) {     // the path the hot kernels take (windowed where the block is)
-  __shared__ StreamLdsW<1, double> lds;
-  GVecSplit g{in, M.split};
-  EStore e{{}, out};
-  process_rows<1>(M, g, e, lds);
-}
 
 
 // ---------------------------------------------------------------------------------------------- assembly and scaling
@@ -1787,202 +372,7 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, int stage) {
   for (int i = threadIdx.x; i < W; i += 64) go[i] = ci[i];
 }
 
-// ---------------------------------------------------------------------------------------------- Woodbury preconditioner (backend.h DevWb)
-__global__ __launch_bounds__(kBlock) void k_wb_gather(Dev d) {
-  const DevWb &w = d.wb;
-  const int stride = gridDim.x * kBlock;
-  for (int k = blockIdx.x * kBlock + threadIdx.x; k < w.AL.nnz; k += stride) w.AL.val[k] = d.A.val[w.al_src[k]];
-  for (int k = blockIdx.x * kBlock + threadIdx.x; k < w.ALT.nnz; k += stride) w.ALT.val[k] = d.A.val[w.alt_src[k]];
-  for (int a = 0; a < w.r; a++)                                            // dense transpose (pattern fixed: the other entries stay zero)
-    for (int k = w.AL.rowptr[a] + blockIdx.x * kBlock + threadIdx.x; k < w.AL.rowptr[a + 1]; k += stride) w.WT[(size_t)w.AL.col[k] * w.r + a] = d.A.val[w.al_src[k]];
-}
-// D0 = B_jj + sum over the SHORT rows of rho_i A_ij^2
-struct GPrecShort { const double *rho; const unsigned char *islong; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = (c >= n && !islong[c - n]) ? rho[c - n] * a * a : 0.0; } };
-__global__ __launch_bounds__(kBlock) void k_wb_diag(Dev d) {
-  __shared__ StreamLds<1> lds;
-  GPrecShort g{d.rho, d.wb.islong, d.n};
-  EPrec e{{}, d.B.val, d.Bdiag, d.wb.Dinv0};
-  process_rows<1>(d.B, g, e, lds);
-}
-// S_ab = sum_j A_L[a,j] A_L[b,j] / D0_j + (a == b) / rho_a : workgroup a, thread (slice s, b); column j of A_L is contiguous in WT.
-// The j loop is split over kWbSlices slices of the workgroup (j = s mod kWbSlices), four independent loads in flight per step, and the
-// slices are summed in index order (deterministic).  (r03: one thread per (a, b) walked all n columns with one dependent load chain --
-// 3.3 ms per rho update on the portfolio QP, a fifth of its solve.)
-constexpr int kWbSlices = 8;
-__global__ __launch_bounds__(kWbMaxRows * kWbSlices) void k_wb_S(Dev d) {
-  const DevWb &w = d.wb;
-  __shared__ double part[kWbSlices][kWbMaxRows];
-  const int a = blockIdx.x, b = threadIdx.x & (kWbMaxRows - 1), s = threadIdx.x / kWbMaxRows, r = w.r, n = d.n;
-  const int bb = b < r ? b : 0;
-  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-  int j = s;
-  for (; j + 3 * kWbSlices < n; j += 4 * kWbSlices) {
-    const size_t o0 = (size_t)j * r, o1 = (size_t)(j + kWbSlices) * r, o2 = (size_t)(j + 2 * kWbSlices) * r, o3 = (size_t)(j + 3 * kWbSlices) * r;
-    const double a0 = w.WT[o0 + a], a1 = w.WT[o1 + a], a2 = w.WT[o2 + a], a3 = w.WT[o3 + a];      // (workgroup-uniform)
-    const double b0 = w.WT[o0 + bb], b1 = w.WT[o1 + bb], b2 = w.WT[o2 + bb], b3 = w.WT[o3 + bb];
-    const double d0 = w.Dinv0[j], d1 = w.Dinv0[j + kWbSlices], d2 = w.Dinv0[j + 2 * kWbSlices], d3 = w.Dinv0[j + 3 * kWbSlices];
-    acc0 += a0 * d0 * b0; acc1 += a1 * d1 * b1; acc2 += a2 * d2 * b2; acc3 += a3 * d3 * b3;
-  }
-  for (; j < n; j += kWbSlices) acc0 += w.WT[(size_t)j * r + a] * w.Dinv0[j] * w.WT[(size_t)j * r + bb];
-  part[s][b] = (acc0 + acc1) + (acc2 + acc3);
-  __syncthreads();
-  if (s == 0 && b < r) {
-    double acc = 0.0;
-    for (int q = 0; q < kWbSlices; q++) acc += part[q][b];
-    if (a == b) acc += d.rho_inv[w.rows[a]];
-    w.S[(size_t)a * r + b] = acc;
-  }
-}
-struct GDr { const double *Dinv0, *r; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * Dinv0[c] * r[c]; } };
-__global__ __launch_bounds__(kBlock) void k_wb_p1(Dev d) {                 // g = A_L (D0^-1 r)
-  __shared__ StreamLds<1> lds;
-  if (d.flags[F_DONE]) return;
-  GDr g{d.wb.Dinv0, d.r};
-  EStore e{{}, d.wb.g};
-  process_rows<1>(d.wb.AL, g, e, lds);
-}
-__global__ __launch_bounds__(kWbMaxRows) void k_wb_p2(Dev d) {             // h = S^-1 g
-  const DevWb &w = d.wb;
-  if (d.flags[F_DONE]) return;
-  __shared__ double sg[kWbMaxRows];
-  const int a = threadIdx.x, r = w.r;
-  if (a < r) sg[a] = w.g[a];
-  __syncthreads();
-  if (a >= r) return;
-  double acc = 0.0;
-  for (int b = 0; b < r; b++) acc += w.Sinv[(size_t)a * r + b] * sg[b];
-  w.h[a] = acc;
-}
-struct EWb3 {
-  const double *Dinv0, *r; double *uu; double *xs;       // xs != nullptr: the direct mode -- u = K^-1 r_0 is added to x~ right here
-  double g = 0, rn = 0, pr = 0, pd = 0, px = 0;
-  __device__ __forceinline__ void prefetch(int j) { pr = r[j]; pd = Dinv0[j]; if (xs) px = xs[j]; }
-  __device__ __forceinline__ void operator()(int j, const double (&s)[1]) {
-    const double u = pd * (pr - s[0]);
-    uu[j] = u; g += pr * u; rn = nanmax(rn, fabs(pr));
-    if (xs) xs[j] = px + u;
-  }
-};
-__global__ __launch_bounds__(kBlock) void k_wb_direct(Dev d) {             // exact mode: x~ += u (u = K^-1 r_0); the PCG statistics see one iteration
-  const int stride = gridDim.x * kBlock;
-  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) d.xs[j] += d.uu[j];
-  if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = 1; }
-}
-// direct != 0 (exact mode, M = K): x~ = x_g + u in the same pass, and the PCG statistics see one iteration -- the flag is written by workgroup 0
-// at its END and not read by this launch (a workgroup that starts late must not take it for the previous solve's)
-__global__ __launch_bounds__(kBlock) void k_wb_p3(Dev d, int parity, int direct) {     // u = D0^-1 (r - A_L' h); partials gamma = <r, u>, ||r||_inf
-  __shared__ StreamLds<1> lds;
-  if (!direct && d.flags[F_DONE]) return;
-  GVec g{d.wb.h};
-  EWb3 e{d.wb.Dinv0, d.r, d.uu, direct ? d.xs : nullptr};
-  process_rows<1>(d.wb.ALT, g, e, lds);
-  __syncthreads();
-  double G = e.g, RN = e.rn;
-  block_sum_max(G, RN, lds.red);
-  put_partial(d.part, SL_GAMMA0 + parity, G); put_partial(d.part, SL_RN0 + parity, RN);
-  if (direct && blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = 1; }
-}
 
-// ---- many long rows (DevWb::large): dense S on the device
-// W[a][colmap[j]] = A_L[a, j] / sqrt(D0_j): workgroups stride over the long rows (the pattern is fixed, the other entries stay zero)
-__global__ __launch_bounds__(kBlock) void k_wb_fillW(Dev d) {
-  const DevWb &w = d.wb;
-  for (int a = blockIdx.x; a < w.r; a += gridDim.x)
-    for (int k = w.AL.rowptr[a] + threadIdx.x; k < w.AL.rowptr[a + 1]; k += kBlock) {
-      const int j = w.AL.col[k];
-      w.W[(size_t)a * w.ct + w.colmap[j]] = w.AL.val[k] * sqrt(w.Dinv0[j]);
-    }
-}
-__global__ __launch_bounds__(kBlock) void k_wb_gather_large(Dev d) {
-  const DevWb &w = d.wb;
-  const size_t stride = (size_t)gridDim.x * kBlock;
-  for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < (size_t)w.AL.nnz; k += stride) w.AL.val[k] = d.A.val[w.al_src[k]];
-  for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < (size_t)w.ALT.nnz; k += stride) w.ALT.val[k] = d.A.val[w.alt_src[k]];
-}
-__global__ __launch_bounds__(kBlock) void k_wb_adddiag(Dev d) {
-  const DevWb &w = d.wb;
-  for (int a = blockIdx.x * kBlock + threadIdx.x; a < w.r; a += gridDim.x * kBlock) w.S[(size_t)a * w.r + a] += d.rho_inv[w.rows[a]];
-}
-// the factorisation works on one triangle (entries M[c * r + q], q >= c): mirror it
-__global__ __launch_bounds__(kBlock) void k_wb_symm(double *M, int r) {
-  for (int c = blockIdx.x; c < r; c += gridDim.x)
-    for (int q = c + 1 + threadIdx.x; q < r; q += kBlock) M[(size_t)q * r + c] = M[(size_t)c * r + q];
-}
-// out = M in  (M: r x r, symmetric, full storage): one workgroup per row, 8 r^2 bytes per launch -- HBM-bound
-__global__ __launch_bounds__(kBlock) void k_wb_gemv(const double *M, const double *in, double *out, int r, const int *done) {
-  __shared__ double red[2 * kWaves];
-  if (done && *done) return;
-  for (int a = blockIdx.x; a < r; a += gridDim.x) {
-    const double *row = M + (size_t)a * r;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    int k = threadIdx.x;
-    for (; k + 3 * kBlock < r; k += 4 * kBlock) {
-      const double m0 = row[k], m1 = row[k + kBlock], m2 = row[k + 2 * kBlock], m3 = row[k + 3 * kBlock];
-      acc0 += m0 * in[k]; acc1 += m1 * in[k + kBlock]; acc2 += m2 * in[k + 2 * kBlock]; acc3 += m3 * in[k + 3 * kBlock];
-    }
-    for (; k < r; k += kBlock) acc0 += row[k] * in[k];
-    const double tot = block_sum((acc0 + acc1) + (acc2 + acc3), red);
-    if (threadIdx.x == 0) out[a] = tot;
-  }
-}
-// probe of the direct mode: v, rho .* (A v), comparison of M^-1 K v with v
-__global__ __launch_bounds__(kBlock) void k_wb_probe_init(Dev d) {
-  const DevWb &w = d.wb;
-  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += gridDim.x * kBlock) {
-    const double v = 0.5 + (double)((((unsigned)j * 2654435761u) >> 8) & 0xffffu) / 65536.0;
-    w.pv[j] = v; w.pv[(size_t)d.n + d.m + j] = v;
-  }
-}
-__global__ __launch_bounds__(kBlock) void k_wb_probe_rho(Dev d) {
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += gridDim.x * kBlock) d.wb.pv[(size_t)d.n + i] *= d.rho[i];
-}
-__global__ __launch_bounds__(kBlock) void k_wb_maxdiff(const double *a, const double *b, int cnt, double *out) {      // one workgroup: out[0] = max |a - b|, out[1] = max |b|
-  __shared__ double red[2 * kWaves];
-  double e = 0.0, s = 0.0;
-  for (int j = threadIdx.x; j < cnt; j += kBlock) { e = nanmax(e, fabs(a[j] - b[j])); s = nanmax(s, fabs(b[j])); }
-  block_max2(e, s, red);
-  if (threadIdx.x == 0) { out[0] = e; out[1] = s; }
-}
-__global__ void k_wb_seq(double *g, int r) { for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < r; a += gridDim.x * blockDim.x) g[a] = 1.0 + 0.25 * (a % 7); }
-
-#define LAUNCH(kernel, d, ...) hipLaunchKernelGGL(kernel, dim3(kGrid), dim3(kBlock), 0, st(d), __VA_ARGS__)
-
-}  // namespace
-
-// ---- dense solver libraries, loaded on first use (rocBLAS: fp64 GEMM; rocSOLVER: Cholesky factorisation and inverse).  Nothing of the
-// engine links against them: where they are missing the large-rank mode is off and such problems keep the Jacobi preconditioner.
-namespace {
-struct DenseLibs {
-  bool tried = false, ok = false;
-  void *hblas = nullptr, *hsolver = nullptr;
-  rocblas_status (*create)(rocblas_handle *) = nullptr;
-  rocblas_status (*destroy)(rocblas_handle) = nullptr;
-  rocblas_status (*set_stream)(rocblas_handle, hipStream_t) = nullptr;
-  rocblas_status (*dgemm)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const double *, const double *, rocblas_int,
-                          const double *, rocblas_int, const double *, double *, rocblas_int) = nullptr;
-  rocblas_status (*dpotrf)(rocblas_handle, const rocblas_fill, const rocblas_int, double *, const rocblas_int, rocblas_int *) = nullptr;
-  rocblas_status (*dpotri)(rocblas_handle, const rocblas_fill, const rocblas_int, double *, const rocblas_int, rocblas_int *) = nullptr;
-};
-DenseLibs &dense_libs() {
-  static DenseLibs L;
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
-  if (L.tried) return L;
-  L.tried = true;
-  auto open_any = [](std::initializer_list<const char *> names) -> void * { for (const char *nm : names) if (void *h = dlopen(nm, RTLD_NOW | RTLD_LOCAL)) return h; return nullptr; };
-  L.hblas = open_any({"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so"});
-  L.hsolver = open_any({"librocsolver.so.0", "librocsolver.so", "/opt/rocm/lib/librocsolver.so"});
-  if (!L.hblas || !L.hsolver) return L;
-  auto sym = [](void *h, const char *nm) { return dlsym(h, nm); };
-  L.create = reinterpret_cast<decltype(L.create)>(sym(L.hblas, "rocblas_create_handle"));
-  L.destroy = reinterpret_cast<decltype(L.destroy)>(sym(L.hblas, "rocblas_destroy_handle"));
-  L.set_stream = reinterpret_cast<decltype(L.set_stream)>(sym(L.hblas, "rocblas_set_stream"));
-  L.dgemm = reinterpret_cast<decltype(L.dgemm)>(sym(L.hblas, "rocblas_dgemm"));
-  L.dpotrf = reinterpret_cast<decltype(L.dpotrf)>(sym(L.hsolver, "rocsolver_dpotrf"));
-  L.dpotri = reinterpret_cast<decltype(L.dpotri)>(sym(L.hsolver, "rocsolver_dpotri"));
-  L.ok = L.create && L.destroy && L.set_stream && L.dgemm && L.dpotrf && L.dpotri;
-  return L;
-}
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- interface
@@ -2018,7 +408,7 @@ void destroy(Dev &d) {
   (void)hipEventDestroy(p.ev0); (void)hipEventDestroy(p.ev1); (void)hipEventDestroy(p.ev_ext); (void)hipEventDestroy(p.ev_wait); (void)hipHostFree(p.pin_res); (void)hipHostFree(p.pin_flags);
   (void)hipHostFree(p.pin_poll); if (p.side) (void)hipStreamDestroy(p.side);
   (void)hipHostFree(p.pin_ctl); (void)hipHostFree(p.pin_ctl2);
-  if (p.blas && dense_libs().ok) (void)dense_libs().destroy(static_cast<rocblas_handle>(p.blas));
+  if (p.blas) wb_release_blas(p.blas);                 // (woodbury_hip.hip: the rocBLAS handle of the device-factorised form)
   delete &p; d.impl = nullptr;
   if (d.stream) { (void)hipStreamDestroy(st(d)); d.stream = nullptr; }
 }
@@ -2056,47 +446,6 @@ void ext_wait(Dev &d) {
   HIP_CHECK(hipSetDevice(d.device));
   HIP_CHECK(hipEventSynchronize(im(d).ev_ext));
   im(d).ext_pending = false;
-}
-
-void kb_rhs(Dev &d) { LAUNCH(k_kb, d, d); }
-bool pcg_fused(const Dev &d) { return d.fused != 0; }
-void k1(Dev &d, int i) { if (d.fused && i > 0) LAUNCH(k_k1f, d, d, i); else LAUNCH(k_k1, d, d, i, 0); }
-void k2(Dev &d, int i) { if (d.fused) LAUNCH(k_k2f, d, d, i); else LAUNCH(k_k2, d, d, 0); }
-void kv(Dev &d, int i) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, i, 0); else LAUNCH(k_kv<1>, d, d, i, 0); }
-void ka(Dev &d, int budget) { LAUNCH(k_ka, d, d, budget); }
-bool slots_supported(const Dev &d) { return d.fused != 0 && d.slot != nullptr; }
-void slot_begin(Dev &d, int target, int cap) { HIP_CHECK(hipSetDevice(d.device)); hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(1), 0, st(d), d.slot, target, cap, ++im(d).epoch); }
-void slot_pair(Dev &d) {
-  if (d.f1.on) {
-    switch (d.f1.D) {
-      case 1: LAUNCH(k_slot1<1>, d, d, 0); LAUNCH(k_slot1<1>, d, d, 1); break;
-      case 2: LAUNCH(k_slot1<2>, d, d, 0); LAUNCH(k_slot1<2>, d, d, 1); break;
-      case 3: LAUNCH(k_slot1<3>, d, d, 0); LAUNCH(k_slot1<3>, d, d, 1); break;
-      default: LAUNCH(k_slot1<4>, d, d, 0); LAUNCH(k_slot1<4>, d, d, 1); break;
-    }
-  }
-  else { LAUNCH(k_slot_b, d, d); LAUNCH(k_slot_a, d, d); }
-}
-void f1_refresh(Dev &d) { if (d.f1.on) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_f1_refresh, d, d); } }
-int slot_seq(Dev &d) { return (im(d).pin_flags + F_COUNT)[SR_SEQ]; }      // slots executed since slot_begin, as of the last fetch (record A)
-int slot_done(Dev &d) {        // ADMM iterations completed by the chunk, as of the last fetch_flags / fetch_res_flags (record A: written by the last A slot)
-  const int *rec = im(d).pin_flags + F_COUNT;
-  return rec[SR_ADMM];
-}
-
-// Progress of the running chunk, read on a side stream WITHOUT waiting for d.stream: slots executed and ADMM iterations completed
-// according to the newer of the two records (a record is eight words written by one thread -- a read may mix two states of it, but
-// both counters only grow, so neither is ever ahead of the truth).  Scheduling information only: Engine::exec_chunk tops the chunk's
-// string of slot launches up before it runs dry; what the slots compute does not depend on how many of them are enqueued.
-void slot_poll(Dev &d, int *seq, int *done) {
-  HIP_CHECK(hipSetDevice(d.device));
-  Impl &p = im(d);
-  HIP_CHECK(hipMemcpyAsync(p.pin_poll, d.slot, sizeof(int) * kSlotInts, hipMemcpyDeviceToHost, p.side));
-  HIP_CHECK(hipStreamSynchronize(p.side));
-  if (p.pin_poll[2 * SR_WORDS] != p.epoch) { *seq = 0; *done = 0; return; }      // the chunk's first launch (k_slot_init) has not run yet
-  const int *ra = p.pin_poll, *rb = p.pin_poll + SR_WORDS;
-  const int *nw = ra[SR_SEQ] >= rb[SR_SEQ] ? ra : rb;
-  *seq = nw[SR_SEQ]; *done = nw[SR_ADMM];
 }
 
 bool ctl_supported(const Dev &d) { return d.ctl != nullptr && d.slot != nullptr; }
@@ -2186,135 +535,6 @@ void fetch_res_flags(Dev &d, double *hr, int *hf) {
 }
 
 void set_rho(Dev &d, double rho_bar) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_set_rho, d, d, rho_bar, 0); LAUNCH(k_init_guess, d, d, 0); }
-bool wb_supported() { return true; }
-void wb_refresh(Dev &d) {
-  if (!d.wb.on) return;
-  HIP_CHECK(hipSetDevice(d.device));
-  if (d.wb.large) LAUNCH(k_wb_gather_large, d, d); else LAUNCH(k_wb_gather, d, d);
-}
-void wb_direct(Dev &d) { LAUNCH(k_wb_direct, d, d); }
-void wb_apply(Dev &d, int parity, int direct) {
-  LAUNCH(k_wb_p1, d, d);
-  if (d.wb.large) hipLaunchKernelGGL(k_wb_gemv, dim3(std::min(d.wb.r, 8 * kGrid)), dim3(kBlock), 0, st(d), d.wb.Sinv, d.wb.g, d.wb.h, d.wb.r, d.flags + F_DONE);
-  else hipLaunchKernelGGL(k_wb_p2, dim3(1), dim3(kWbMaxRows), 0, st(d), d);
-  LAUNCH(k_wb_p3, d, d, parity, direct);
-}
-
-bool wb_large_supported() { return dense_libs().ok; }
-
-// D0, W, S = W W' + 1 / rho_L, S^-1 -- all on the device (r up to kWbLargeMax); then the two numerical checks
-static void wb_factor_large(Dev &d) {
-  DevWb &w = d.wb;
-  DenseLibs &L = dense_libs();
-  Impl &p = im(d);
-  if (!L.ok) throw DeviceError("osqp_hip: the dense solver libraries are not available");
-  if (!p.blas) {
-    rocblas_handle h = nullptr;
-    if (L.create(&h) != rocblas_status_success) throw DeviceError("osqp_hip: rocblas_create_handle failed");
-    p.blas = h;
-  }
-  rocblas_handle h = static_cast<rocblas_handle>(p.blas);
-  if (L.set_stream(h, st(d)) != rocblas_status_success) throw DeviceError("osqp_hip: rocblas_set_stream failed");
-  const int r = w.r, ct = w.ct;
-  const bool log = w.log != 0;
-  double tlap[6] = {0, 0, 0, 0, 0, 0};
-  auto lap = [&](int k) { if (log) { HIP_CHECK(hipStreamSynchronize(st(d))); tlap[k] = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); } };
-  lap(0);
-  LAUNCH(k_wb_diag, d, d);
-  LAUNCH(k_wb_fillW, d, d);
-  lap(1);
-  const double one = 1.0, zero = 0.0;
-  // W is r x ct row-major = ct x r column-major (ld ct): S = W' W in the library's convention
-  if (L.dgemm(h, rocblas_operation_transpose, rocblas_operation_none, r, r, ct, &one, w.W, ct, w.W, ct, &zero, w.S, r) != rocblas_status_success)
-    throw DeviceError("osqp_hip: rocblas_dgemm failed");
-  LAUNCH(k_wb_adddiag, d, d);
-  lap(2);
-  HIP_CHECK(hipMemcpyAsync(w.Sinv, w.S, sizeof(double) * (size_t)r * r, hipMemcpyDeviceToDevice, st(d)));
-  if (L.dpotrf(h, rocblas_fill_lower, r, w.Sinv, r, w.info) != rocblas_status_success) throw DeviceError("osqp_hip: rocsolver_dpotrf failed");
-  lap(3);
-  if (L.dpotri(h, rocblas_fill_lower, r, w.Sinv, r, w.info + 1) != rocblas_status_success) throw DeviceError("osqp_hip: rocsolver_dpotri failed");
-  lap(4);
-  hipLaunchKernelGGL(k_wb_symm, dim3(std::min(r, 8 * kGrid)), dim3(kBlock), 0, st(d), w.Sinv, r);
-  // S^-1 against S on a fixed vector:  S (S^-1 g) = g
-  double *out = w.pv + (size_t)d.n + d.m + d.n;                 // [4 + r] scratch behind the probe vectors
-  hipLaunchKernelGGL(k_wb_seq, dim3(64), dim3(256), 0, st(d), w.g, r);
-  hipLaunchKernelGGL(k_wb_gemv, dim3(std::min(r, 8 * kGrid)), dim3(kBlock), 0, st(d), w.Sinv, w.g, w.h, r, nullptr);
-  hipLaunchKernelGGL(k_wb_gemv, dim3(std::min(r, 8 * kGrid)), dim3(kBlock), 0, st(d), w.S, w.h, out + 4, r, nullptr);
-  hipLaunchKernelGGL(k_wb_maxdiff, dim3(1), dim3(kBlock), 0, st(d), out + 4, w.g, r, out);
-  // M^-1 (K v) = v ?   K v = B [v; rho .* (A v)]
-  if (w.probe) {
-    LAUNCH(k_wb_probe_init, d, d);
-    LAUNCH(k_test_spmv, d, d.A, w.pv, w.pv + d.n);
-    LAUNCH(k_wb_probe_rho, d, d);
-    LAUNCH(k_test_spmv, d, d.B, w.pv, d.r);
-    HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, 0, sizeof(int), st(d)));
-    wb_apply(d, 0);
-    hipLaunchKernelGGL(k_wb_maxdiff, dim3(1), dim3(kBlock), 0, st(d), d.uu, w.pv + (size_t)d.n + d.m, d.n, out + 2);
-  }
-  int info[2] = {0, 0};
-  double chk[4] = {0, 1, 0, 1};
-  HIP_CHECK(hipMemcpyAsync(info, w.info, sizeof(info), hipMemcpyDeviceToHost, st(d)));
-  HIP_CHECK(hipMemcpyAsync(chk, out, sizeof(double) * (w.probe ? 4 : 2), hipMemcpyDeviceToHost, st(d)));
-  HIP_CHECK(hipStreamSynchronize(st(d)));
-  if (info[0] != 0 || info[1] != 0) throw DeviceError("osqp_hip: the Woodbury system of the preconditioner is not positive definite");
-  const bool inv_ok = chk[0] <= 1e-8 * chk[1];
-  w.exact = (w.probe && inv_ok && chk[2] <= w.exact_tol * chk[3]) ? 1 : 0;
-  if (log) {
-    lap(5);
-    std::fprintf(stderr, "osqp_hip woodbury: r %d ct %d  |S S^-1 g - g| %.2e / %.2e   |M^-1 K v - v| %.2e / %.2e   direct %d;  D0 + W %.1f ms, GEMM %.1f ms, Cholesky %.1f ms, inverse %.1f ms, mirror + checks %.1f ms\n",
-                 r, ct, chk[0], chk[1], chk[2], chk[3], w.exact, 1e3 * (tlap[1] - tlap[0]), 1e3 * (tlap[2] - tlap[1]), 1e3 * (tlap[3] - tlap[2]), 1e3 * (tlap[4] - tlap[3]), 1e3 * (tlap[5] - tlap[4]));
-  }
-}
-// D0, S on the device; S^-1 on the host (r <= kWbMaxRows: a Cholesky factorisation of a few thousand entries, once per rho update)
-static void wb_factor(Dev &d) {
-  DevWb &w = d.wb;
-  if (w.large) { wb_factor_large(d); return; }
-  const int r = w.r;
-  LAUNCH(k_wb_diag, d, d);
-  hipLaunchKernelGGL(k_wb_S, dim3(r), dim3(kWbMaxRows * kWbSlices), 0, st(d), d);
-  std::vector<double> S((size_t)r * r), L((size_t)r * r, 0.0), Li((size_t)r * r, 0.0), Si((size_t)r * r, 0.0);
-  HIP_CHECK(hipMemcpyAsync(S.data(), w.S, sizeof(double) * S.size(), hipMemcpyDeviceToHost, st(d)));
-  HIP_CHECK(hipStreamSynchronize(st(d)));
-  for (int j = 0; j < r; j++) {                               // S = L L'
-    double dj = S[(size_t)j * r + j];
-    for (int k = 0; k < j; k++) dj -= L[(size_t)j * r + k] * L[(size_t)j * r + k];
-    if (!(dj > 0.0)) throw DeviceError("osqp_hip: the Woodbury system of the preconditioner is not positive definite");
-    const double ljj = std::sqrt(dj);
-    L[(size_t)j * r + j] = ljj;
-    for (int i = j + 1; i < r; i++) {
-      double v = S[(size_t)i * r + j];
-      for (int k = 0; k < j; k++) v -= L[(size_t)i * r + k] * L[(size_t)j * r + k];
-      L[(size_t)i * r + j] = v / ljj;
-    }
-  }
-  for (int c = 0; c < r; c++) {                               // Li = L^-1 (lower triangular), column by column
-    Li[(size_t)c * r + c] = 1.0 / L[(size_t)c * r + c];
-    for (int i = c + 1; i < r; i++) {
-      double v = 0.0;
-      for (int k = c; k < i; k++) v -= L[(size_t)i * r + k] * Li[(size_t)k * r + c];
-      Li[(size_t)i * r + c] = v / L[(size_t)i * r + i];
-    }
-  }
-  for (int a = 0; a < r; a++)                                 // S^-1 = Li' Li
-    for (int b = 0; b <= a; b++) {
-      double v = 0.0;
-      for (int k = a; k < r; k++) v += Li[(size_t)k * r + a] * Li[(size_t)k * r + b];
-      Si[(size_t)a * r + b] = Si[(size_t)b * r + a] = v;
-    }
-  if (w.exact) {                                              // the direct mode trusts S^-1: || S S^-1 - I ||_max must be at rounding level
-    double err = 0.0;
-    for (int a = 0; a < r; a++)
-      for (int b = 0; b < r; b++) {
-        double v = a == b ? -1.0 : 0.0;
-        for (int k = 0; k < r; k++) v += S[(size_t)a * r + k] * Si[(size_t)k * r + b];
-        err = std::max(err, std::fabs(v));
-      }
-    if (!(err < 1e-9)) w.exact = 0;
-  }
-  HIP_CHECK(hipMemcpyAsync(w.Sinv, Si.data(), sizeof(double) * Si.size(), hipMemcpyHostToDevice, st(d)));
-  HIP_CHECK(hipStreamSynchronize(st(d)));
-  wbx_factor(d);                                              // (two-launch direct mode: S^-1 A_L per column block)
-}
 void precond(Dev &d, int diagonal) {
   HIP_CHECK(hipSetDevice(d.device));
   if (diagonal) LAUNCH(k_precond, d, d, 0);
@@ -2414,102 +634,6 @@ void test_spmv(Dev &d, int which, const double *in, double *out) {
   LAUNCH(k_test_spmv, d, which == 0 ? d.A : d.B, in, out);
 }
 
-// Mean duration of one launch of a hot-path kernel, measured with a hipEvent pair on the solver's stream.
-// Kernels run in probe mode (no convergence logic; Kv with alpha = beta = 0) on the solver's live buffers; the
-// iterate state that KB/KA/Kv overwrite is saved and restored around the measurement.
-// probe 16: the phase records say "PCG iteration k0 of a chunk that never ends", the tolerance can never be met: the launches that follow
-// are the slot kernel's own F launches -- scalars from the fold, stopping test, record hand-over -- exactly as a solve runs them
-__global__ void k_slot_probe_f(int *slot, double *scal, int k0) {
-  for (int rec = 0; rec < 2; rec++) {
-    int *r = slot + rec * SR_WORDS;
-    r[SR_PHASE] = P_F; r[SR_K] = k0; r[SR_ADMM] = 0; r[SR_TARGET] = 1; r[SR_USED] = 0; r[SR_CONV] = 0; r[SR_CAP] = 1 << 20; r[SR_SEQ] = rec ? -1 : 0;
-  }
-  scal[S_TOL_NOW] = -1.0;
-}
-static void f1_probe_pair(Dev &d, int mode) {           // two consecutive F launches of the probe kernel (the double-buffered vectors alternate)
-  switch (d.f1.D) {
-    case 1: LAUNCH(k_f1_probe<1>, d, d, 2, mode); LAUNCH(k_f1_probe<1>, d, d, 3, mode); break;
-    case 2: LAUNCH(k_f1_probe<2>, d, d, 2, mode); LAUNCH(k_f1_probe<2>, d, d, 3, mode); break;
-    case 3: LAUNCH(k_f1_probe<3>, d, d, 2, mode); LAUNCH(k_f1_probe<3>, d, d, 3, mode); break;
-    default: LAUNCH(k_f1_probe<4>, d, d, 2, mode); LAUNCH(k_f1_probe<4>, d, d, 3, mode); break;
-  }
-}
-float time_kernel(Dev &d, int which, int reps) {
-  HIP_CHECK(hipSetDevice(d.device));
-  Impl &p = im(d);
-  struct Save { double *ptr; size_t cnt; double *bak; };
-  const size_t n = d.n, m = d.m;
-  Save sv[] = {{d.x, n, nullptr}, {d.z, m, nullptr}, {d.y, m, nullptr}, {d.xs, n, nullptr}, {d.zt, m, nullptr}, {d.t0, m, nullptr},
-               {d.v, m, nullptr}, {d.dx, n, nullptr}, {d.dy, m, nullptr}, {d.r, n, nullptr}, {d.uu, n, nullptr}, {d.p, n, nullptr},
-               {d.s, n, nullptr}, {d.w, n, nullptr}, {d.t, m, nullptr}, {d.uu2, n, nullptr}, {d.ms, 2 * n, nullptr},
-               {d.xg, n, nullptr}, {d.xsp, n, nullptr}, {d.ztg, m, nullptr}};
-  int flags_bak[F_COUNT];
-  HIP_CHECK(hipStreamSynchronize(st(d)));
-  HIP_CHECK(hipMemcpy(flags_bak, d.flags, sizeof(flags_bak), hipMemcpyDeviceToHost));
-  for (auto &s : sv) {
-    if (!s.cnt) continue;
-    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s.bak), s.cnt * sizeof(double)));
-    HIP_CHECK(hipMemcpy(s.bak, s.ptr, s.cnt * sizeof(double), hipMemcpyDeviceToDevice));
-  }
-  auto K1 = [&](int pr) { LAUNCH(k_k1, d, d, 1, pr); };
-  auto K2 = [&]() { LAUNCH(k_k2, d, d, 1); };
-  auto KV = [&](int pr) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, 1, pr); else LAUNCH(k_kv<1>, d, d, 1, pr); };
-  auto launch = [&]() {
-    switch (which) {
-      case 0: LAUNCH(k_k1, d, d, 1, 1); break;
-      case 1: LAUNCH(k_k2, d, d, 1); break;
-      case 2: if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, 1, 1); else LAUNCH(k_kv<1>, d, d, 1, 1); break;
-      case 3: LAUNCH(k_kb, d, d); break;
-      case 4: LAUNCH(k_ka, d, d, 0); break;
-      case 5: K1(1); K2(); KV(1); break;      // one PCG iteration, reductions of partials skipped
-      case 6: K1(2); K2(); KV(2); break;      // one PCG iteration as a solve executes it
-      case 7: K1(2); KV(2); break;            // ... without K2   (6 minus 7 = K2's time inside the sequence, L2-cold like in a solve)
-      case 8: K2(); KV(2); break;             // ... without K1
-      case 9: K1(2); K2(); break;             // ... without Kv
-      case 11: LAUNCH(k_k1f, d, d, 1); break;  // fused SpMV-A + vector update alone (alpha fixed by the stored history; drifts linearly, bounded)
-      case 12: LAUNCH(k_k2f, d, d, 0); break;  // fused SpMV-B alone
-      case 13: LAUNCH(k_k2f, d, d, 2); LAUNCH(k_k1f, d, d, 3); break;   // the same pair with the done flag set: what an early-exit pair costs
-      case 14: f1_probe_pair(d, 1); break;   // F1 form without the scalar fold at the head of the launch (two consecutive iterations)
-      case 16: slot_pair(d); break;           // two F launches of the slot kernel itself (records set up by k_slot_probe_f below): what a launch costs inside a solve
-      case 15: f1_probe_pair(d, 2); break;   // F1 form: one PCG iteration = one launch; two consecutive iterations as a solve runs them (buffers alternate, fold included)
-      default: LAUNCH(k_k2f, d, d, 0); LAUNCH(k_k1f, d, d, 1); break;   // one FUSED PCG iteration (two kernels): repeated exact line-search steps, bounded
-    }
-  };
-  if (which >= 14 && which <= 16 && !d.f1.on) return 0.f;
-  if (which == 16) {
-    if (reps > 400) reps = 400;                 // (k advances by two per repetition; the alpha / gamma history holds kMaxCg entries)
-    hipLaunchKernelGGL(k_slot_probe_f, dim3(1), dim3(1), 0, st(d), d.slot, d.scal, 2);
-  }
-  if (which >= 10) HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, which == 13 ? 1 : 0, sizeof(int), st(d)));   // (byte pattern 1 -> nonzero flag)
-  for (int w = 0; w < 5; w++) launch();
-  HIP_CHECK(hipEventRecord(p.ev0, st(d)));
-  for (int r = 0; r < reps; r++) launch();
-  HIP_CHECK(hipEventRecord(p.ev1, st(d)));
-  HIP_CHECK(hipEventSynchronize(p.ev1));
-  float ms = 0.f;
-  HIP_CHECK(hipEventElapsedTime(&ms, p.ev0, p.ev1));
-  for (auto &s : sv) {
-    if (!s.cnt) continue;
-    HIP_CHECK(hipMemcpy(s.ptr, s.bak, s.cnt * sizeof(double), hipMemcpyDeviceToDevice));
-    HIP_CHECK(hipFree(s.bak));
-  }
-  HIP_CHECK(hipMemcpy(d.flags, flags_bak, sizeof(flags_bak), hipMemcpyHostToDevice));
-  return ms / reps;
-}
-
-// Diagnostic: workgroup phase stamps of the last launches (count <= kGrid * 16); false when built without OSQP_HIP_KTRACE.
-bool ktrace_read(Dev &d, unsigned long long *out, int count) {
-#ifdef OSQP_HIP_KTRACE
-  HIP_CHECK(hipSetDevice(d.device));
-  HIP_CHECK(hipStreamSynchronize(st(d)));
-  if (count > kGrid * kTraceSlots) count = kGrid * kTraceSlots;
-  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ktrace), sizeof(unsigned long long) * count));
-  return true;
-#else
-  (void)d; (void)out; (void)count;
-  return false;
-#endif
-}
 
 }  // namespace be
 }  // namespace osqp_hip

@@ -1,0 +1,1059 @@
+// pcg_hip.hip -- the ADMM / PCG hot path of backend.h on gfx950: KB, K1, K2, Kv, the fused pair K2F / K1F, KA, the slot kernels (device-side
+// scheduling of the phases), the one-launch PCG iteration (F1 form, k_slot1) and the timing probes.  Design notes: backend_hip.hip (head of the
+// file) and DESIGN.md section 4.  Split out of backend_hip.hip in round 4; the shared device helpers are hip_common.h.
+#include "hip_common.h"
+
+namespace osqp_hip {
+namespace be {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- hot-path kernels
+// KB ------------------------------------------------------------------------------------------
+struct GKb {
+  const double *xg, *v, *t0; int n;      // (xg: the PCG start, Dev::xg; t0 = rho .* (A xg))
+  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[2]) const {
+    if (c < n) { pr[0] = 0.0; pr[1] = a * xg[c]; }
+    else { pr[0] = a * v[c - n]; pr[1] = a * t0[c - n]; }
+  }
+};
+struct EKb {
+  const double *x, *q, *Minv; double *r, *uu; double sigma; const double *xg; double *xs; double g = 0, rn = 0, bn = 0; double px = 0, pq = 0, pm = 0, pg = 0;
+  __device__ __forceinline__ void prefetch(int j) { px = x[j]; pq = q[j]; pm = Minv[j]; pg = xg[j]; }
+  __device__ __forceinline__ void operator()(int j, const double (&s)[2]) {
+    const double rhs = sigma * px - pq + s[0];
+    const double rr = rhs - s[1], u = pm * rr;
+    r[j] = rr; uu[j] = u; xs[j] = pg;           // x~ restarts from the extrapolated point (nobody gathers xs in this kernel)
+    g += rr * u; rn = nanmax(rn, fabs(rr)); bn = nanmax(bn, fabs(rhs));
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_kb(Dev d) {
+  __shared__ StreamLds<2> lds;
+  GKb g{d.xg, d.v, d.t0, d.n};
+  EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma, d.xg, d.xs};
+  process_rows<2>(d.B, g, e, lds);
+  __syncthreads();
+  const double G = block_sum(e.g, lds.red);
+  double RN = e.rn, BN = e.bn;
+  block_max2(RN, BN, lds.red);
+  put_partial(d.part, SL_GAMMA0, G); put_partial(d.part, SL_RN0, RN); put_partial(d.part, SL_BN, BN);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
+}
+
+// K1 ------------------------------------------------------------------------------------------
+struct EK1 {
+  const double *rho; double *t; double pr = 0;
+  __device__ __forceinline__ void prefetch(int i) { pr = rho[i]; }
+  __device__ __forceinline__ void operator()(int i, const double (&s)[1]) { t[i] = pr * s[0]; }
+};
+// PCG stopping test, run by every working workgroup (and workgroup 0) while its first matrix loads are in flight
+struct PreK1 {
+  [[maybe_unused]] static constexpr int kTraceBase = 0;
+  const Dev &d; int i, probe; double *red; int par = -1;      // par: parity of the ADMM iteration (slot form), -1: not recorded
+  __device__ __forceinline__ bool operator()() const {
+    if (probe == 1) return true;
+    // (No early exit on d.flags[F_DONE] here: in the slot form workgroup 0 of THIS launch may set the flag while other workgroups are
+    // still arriving, the waves of one workgroup then read different values, one skips the barriers of the reduction below and
+    // meets its siblings at the next __syncthreads() instead -- they fold its stale LDS slot.  Seen as run-to-run differences of
+    // solves running concurrently on several streams, 1-4 % of them (tools/thread_stress.py); every wave takes the reduction now.)
+    const PartRegs prn = partial_load(d.part + (SL_RN0 + (i & 1)) * kGrid), pbn = partial_load(d.part + SL_BN * kGrid);
+    double rn = partial_fold_max(prn), bn = partial_fold_max(pbn);
+    block_max2(rn, bn, red);
+    if (probe) { if (rn < -1.0) d.res[R_COUNT - 1] = bn; return true; }     // probe == 2: pay for the test, ignore it
+    const double tol = fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS]);
+    if (i == 0 && blockIdx.x == 0 && threadIdx.x == 0) { d.scal[S_TOL_NOW] = tol; d.scal[S_RN0] = rn; if (par >= 0) d.scal[S_RN0H + par] = rn; }   // fused PCG: later tests read the scalar
+    if (!(rn > tol)) {            // converged (a NaN residual also stops the inner loop; the ADMM residuals will flag it)
+      if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = i; }
+      return false;
+    }
+    return true;
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_k1(Dev d, int i, int probe) {
+  __shared__ StreamLdsW<1, double> lds;
+  if (!wg_has_rows(d.A) && blockIdx.x != 0) return;               // nothing to do and not the flag owner
+  if (!probe && d.flags[F_DONE]) return;                          // PCG already converged: cheapest possible exit
+  GVec g{d.uu};
+  EK1 e{d.rho, d.t};
+  process_rows<1>(d.A, g, e, lds, PreK1{d, i, probe, lds.red});
+}
+
+// K2 ------------------------------------------------------------------------------------------
+struct GSplit {      // [pn; pm] indexed by a B column
+  const double *pn, *pm; int n;
+  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * (c < n ? pn[c] : pm[c - n]); }
+};
+struct EK2 {
+  const double *uu; double *w; double dl = 0, pu = 0;
+  __device__ __forceinline__ void prefetch(int j) { pu = uu[j]; }
+  __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { w[j] = s[0]; dl += s[0] * pu; }
+};
+__global__ __launch_bounds__(kBlock) void k_k2(Dev d, int probe) {
+  __shared__ StreamLds<1> lds;
+  if (!probe && d.flags[F_DONE]) return;
+  GSplit g{d.uu, d.t, d.n};
+  EK2 e{d.uu, d.w};
+  if (!process_rows<1>(d.B, g, e, lds, NoPre())) return;
+  __syncthreads();
+  const double DL = block_sum(e.dl, lds.red);
+  put_partial(d.part, SL_DELTA, DL);
+  KT(6);
+}
+
+// Kv ------------------------------------------------------------------------------------------
+// VEC = 2: one double2 per lane (large n); VEC = 1: one double per lane (keeps more workgroups busy at mid-size n)
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_kv(Dev d, int i, int probe) {
+  __shared__ double sred[2 * kWaves];
+  const int nv = d.n / VEC;                                       // vector elements (tail handled by workgroup 0)
+  // XCD-contiguous chunks of kBlock elements, as in process_rows (each XCD keeps 'its' eighth of the PCG vectors)
+  const int nchunk = (nv + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3, slots = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+  const int c0 = xcd * per + slot0;
+  const bool active = slot0 < per && c0 < nchunk;
+  const int j0 = c0 * kBlock + threadIdx.x;
+  if (!active && blockIdx.x != 0) {                                // idle workgroup: its partial slots must still read 0
+    if (!probe) { put_partial(d.part, SL_GAMMA0 + ((i + 1) & 1), 0.0); put_partial(d.part, SL_RN0 + ((i + 1) & 1), 0.0); }
+    return;
+  }
+  if (!probe && d.flags[F_DONE]) return;                           // PCG already converged
+  const bool first = (i == 0) && !probe;
+  typedef typename std::conditional<VEC == 2, double2, double>::type V;
+  // fused PCG (final update after the last budgeted iteration): s_i is already complete (k_k2 epilogue), w is not stored,
+  // u_i lives in the ping-pong buffer of parity i
+  const bool fz = d.fused && !probe;
+  const V *uin = reinterpret_cast<const V *>(fz && (i & 1) ? d.uu2 : d.uu);
+  V *uout = reinterpret_cast<V *>(fz && !(i & 1) ? d.uu2 : d.uu);
+  V *p2 = reinterpret_cast<V *>(d.p), *x2 = reinterpret_cast<V *>(d.xs), *r2 = reinterpret_cast<V *>(d.r), *s2 = reinterpret_cast<V *>(d.s);
+  const V *w2 = reinterpret_cast<const V *>(d.w), *m2 = reinterpret_cast<const V *>(d.Minv);
+  // issue this lane's first element loads, then fold the partials while they are in flight
+  const bool have = active && j0 < nv;
+  V u, w, x, r, mi, p, s;
+  if (have) { u = uin[j0]; x = x2[j0]; r = r2[j0]; mi = m2[j0]; if (fz) { s = s2[j0]; if (!first) p = p2[j0]; } else { w = w2[j0]; if (!first) { p = p2[j0]; s = s2[j0]; } } }
+  double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
+  double alpha = 0.0, beta = 0.0;
+  if (probe != 1) {
+    const PartRegs pg = partial_load(d.part + (SL_GAMMA0 + (i & 1)) * kGrid), pd = partial_load(d.part + SL_DELTA * kGrid);
+    double gamma = partial_fold_sum(pg), delta = partial_fold_sum(pd);
+    block_sum2(gamma, delta, sred);
+    if (probe) { if (gamma == -1.2345e300) d.res[R_COUNT - 1] = delta; }   // probe == 2: pay for the reduction, ignore it
+    else {
+      if (i == 0) { beta = 0.0; alpha = gamma / delta; }
+      else { beta = gamma / gam[i - 1]; alpha = gamma / (delta - beta * gamma / alp[i - 1]); }
+      if (blockIdx.x == 0 && threadIdx.x == 0) { gam[i] = gamma; alp[i] = alpha; }
+    }
+  }
+  double g = 0, rn = 0;
+  auto upd = [&](double &uu_, double ww_, double &xx_, double &rr_, double mm_, double &pp_, double &ss_) {
+    if (fz) { pp_ = first ? uu_ : uu_ + beta * pp_; }                 // ss_ is s_i already
+    else if (first) { pp_ = uu_; ss_ = ww_; } else { pp_ = uu_ + beta * pp_; ss_ = ww_ + beta * ss_; }
+    xx_ += alpha * pp_; rr_ -= alpha * ss_; uu_ = mm_ * rr_;
+    g += rr_ * uu_; rn = nanmax(rn, fabs(rr_));
+  };
+  for (int sl = slot0; active && sl < per; sl += slots) {
+    const int c = xcd * per + sl;
+    if (c >= nchunk) break;
+    const int j = c * kBlock + threadIdx.x;
+    if (j >= nv) break;
+    if (sl != slot0) { u = uin[j]; x = x2[j]; r = r2[j]; mi = m2[j]; if (fz) { s = s2[j]; if (!first) p = p2[j]; } else { w = w2[j]; if (!first) { p = p2[j]; s = s2[j]; } } }
+    if constexpr (VEC == 2) { upd(u.x, w.x, x.x, r.x, mi.x, p.x, s.x); upd(u.y, w.y, x.y, r.y, mi.y, p.y, s.y); }
+    else upd(u, w, x, r, mi, p, s);
+    p2[j] = p; if (!fz) s2[j] = s; x2[j] = x; r2[j] = r; uout[j] = u;
+  }
+  if (VEC == 2 && (d.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {      // odd tail element
+    const int j = d.n - 1;
+    const double *uin1 = reinterpret_cast<const double *>(uin); double *uout1 = reinterpret_cast<double *>(uout);
+    double uu_ = uin1[j], xx_ = d.xs[j], rr_ = d.r[j], pp_ = first ? 0.0 : d.p[j], ss_ = (first && !fz) ? 0.0 : d.s[j];
+    upd(uu_, fz ? 0.0 : d.w[j], xx_, rr_, d.Minv[j], pp_, ss_);
+    uout1[j] = uu_; d.xs[j] = xx_; d.r[j] = rr_; d.p[j] = pp_; if (!fz) d.s[j] = ss_;
+  }
+  block_sum_max(g, rn, sred);
+  if (!probe) { put_partial(d.part, SL_GAMMA0 + ((i + 1) & 1), g); put_partial(d.part, SL_RN0 + ((i + 1) & 1), rn); }
+}
+
+
+// Fused PCG (two kernels per iteration) --------------------------------------------------------------------------------
+// K2F_k :  stopping test on ||r_k||; beta_k = gamma_k / gamma_{k-1};  w = B [u_k; t_k];  delta_k = <w, u_k>;  and in the row
+//          epilogue  s_k = w + beta_k s_{k-1},  ms_k = Minv .* s_k   (w itself is never stored)
+// K1F_{k+1}: alpha_k = gamma_k / (delta_k - beta_k gamma_k / alpha_{k-1});
+//          (a) on this workgroup's chunk of the n-vectors:  p = u_k + beta_k p ; xs += alpha_k p ; r -= alpha_k s_k ;
+//              u_{k+1} = Minv r  (written to the OTHER u buffer) ; partials gamma_{k+1}, ||r_{k+1}||_inf
+//          (b) t_{k+1} = rho .* (A u_{k+1})  with u_{k+1}[c] = u_k[c] - alpha_k ms_k[c] recomputed at every gathered column
+//              (two gathers), so (b) never waits for (a) of another workgroup.
+struct GSplitU {
+  const double *pn, *pm; int n;
+  using Ops = double;
+  __device__ __forceinline__ Ops fetch(int c) const { return c < n ? pn[c] : pm[c - n]; }
+  __device__ __forceinline__ void prod(const Ops &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
+  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * fetch(c); }
+  using Win = double;
+  __device__ __forceinline__ Win stage(int seg, int c) const { return seg ? pm[c] : pn[c]; }
+  __device__ __forceinline__ void wprod(const Win &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
+};
+struct EK2F {
+  const double *u, *Minv; double *s, *ms; double beta = 0; int first = 0; double dl = 0, pu = 0, pm = 0, ps = 0;
+  __device__ __forceinline__ void prefetch(int j) { pu = u[j]; pm = Minv[j]; ps = s[j]; }
+  __device__ __forceinline__ void operator()(int j, const double (&sm)[1]) {
+    const double w = sm[0], sn = first ? w : w + beta * ps;
+    dl += w * pu;
+    if (KNOCKED(32)) { if (sn == -1.2345e300) s[j] = sn; return; }
+    s[j] = sn;
+    ms[j] = pm * sn;                                                       // Minv .* s_k: the vector k_k1f applies A to
+  }
+};
+// block reduction of three quantities (sum, max, sum) behind ONE barrier pair; sred needs 3 * kWaves doubles
+__device__ __forceinline__ void block_sum_max_sum(double &a, double &b, double &c, double *sred) {
+  a = wave_sum(a); b = wave_max(b); c = wave_sum(c);
+  if ((threadIdx.x & 63) == kReduceLane) { sred[threadIdx.x >> 6] = a; sred[kWaves + (threadIdx.x >> 6)] = b; sred[2 * kWaves + (threadIdx.x >> 6)] = c; }
+  __syncthreads();
+  a = sred_sum(sred); b = sred_max(sred + kWaves); c = sred_sum(sred + 2 * kWaves);
+  __syncthreads();
+}
+// LATE hook of k_k2f (runs between the row sums and the epilogue): folds gamma_k and ||r_k||_inf together with this
+// workgroup's share of delta_k = <w, u_k> (one barrier pair for all three), stopping test, beta_k.
+struct PreK2F {
+  [[maybe_unused]] static constexpr int kTraceBase = 0;
+  static constexpr bool kLate = true;
+  const Dev &d; int k; EK2F *e; double *red; double *dl_first;
+  struct Tok { PartRegs prn, pg; double tol, glast; };
+  __device__ __forceinline__ Tok begin() const {
+    Tok t;
+    if (KNOCKED(1)) { t.tol = 0; t.glast = 1; return t; }
+    if (KNOCKED(256)) { for (int q = 0; q < kPart; q++) { t.prn.v[q] = 1.0; t.pg.v[q] = 1.0; } }
+    else { t.prn = partial_load(d.part + (SL_RN0 + (k & 1)) * kGrid); t.pg = partial_load(d.part + (SL_GAMMA0 + (k & 1)) * kGrid); }
+    t.tol = d.scal[S_TOL_NOW]; t.glast = k == 0 ? 1.0 : d.scal[S_HIST + k - 1];
+    return t;
+  }
+  __device__ __forceinline__ bool finish(const Tok &t, const double (&acc)[1], bool owner) const {
+    if (KNOCKED(1)) { e->beta = 0.5; e->first = 0; *dl_first = 0; return true; }
+    double gamma = partial_fold_sum(t.pg), rn = partial_fold_max(t.prn);
+    const double dl0 = owner ? acc[0] * e->pu : 0.0;
+    double dls = dl0;
+    block_sum_max_sum(gamma, rn, dls, red);
+    double *gam = d.scal + S_HIST, *bet = d.scal + S_HIST + 2 * (kMaxCg + 1);
+    if (k > 0 && !(rn > t.tol)) {        // converged after k iterations (k == 0 was tested by k_k1)
+      if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = k; }
+      return false;
+    }
+    const double beta = k == 0 ? 0.0 : gamma / t.glast;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { gam[k] = gamma; bet[k] = beta; }
+    e->beta = beta; e->first = (k == 0);
+    e->dl = -dl0;                        // the epilogue adds this row's term again: e->dl then holds only LATER rows' terms
+    *dl_first = dls;
+    return true;
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_k2f(Dev d, int k) {
+  __shared__ StreamLdsW<1, double> lds;
+  KT(0);
+  const double *u = (k & 1) ? d.uu2 : d.uu;
+  GSplitU g{u, d.t, d.n};
+  EK2F e{u, d.Minv, d.s, d.ms};
+  double dl_first = 0.0;
+  if (!process_rows<1>(d.B, g, e, lds, PreK2F{d, k, &e, lds.red, &dl_first}, d.flags + F_DONE)) return;
+  if (KNOCKED(64)) { if (e.dl == -1.2345e300) put_partial(d.part, SL_DELTA, e.dl); return; }
+  double DL = dl_first;
+  if (!d.B.single) { __syncthreads(); DL += block_sum(e.dl, lds.red); }    // rows beyond the first pass of the first block
+  put_partial(d.part, SL_DELTA, DL);
+  KT(6);
+}
+// K1F_{k+1}: S = A (Minv .* s_k) needs no scalar; alpha_k (from the delta partials) enters only the row epilogue
+//   t_{k+1} = t_k - alpha_k rho .* S      ( = rho .* A u_{k+1},  u_{k+1} = u_k - alpha_k Minv .* s_k )
+// and this workgroup's slice of the vector update, so the reduction of partials runs LATE, behind the matrix stream.
+struct GMs {
+  const double *ms;
+  using Ops = double;
+  __device__ __forceinline__ Ops fetch(int c) const { return ms[c]; }
+  __device__ __forceinline__ void prod(const Ops &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
+  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * ms[c]; }
+  using Win = double;
+  __device__ __forceinline__ Win stage(int, int c) const { return ms[c]; }
+  __device__ __forceinline__ void wprod(const Win &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
+};
+struct EK1F {
+  const double *rho; double *t; double alpha = 0, pr = 0, pt = 0;
+  __device__ __forceinline__ void prefetch(int i) { pr = rho[i]; pt = t[i]; }
+  __device__ __forceinline__ void operator()(int i, const double (&s)[1]) { t[i] = pt - alpha * pr * s[0]; }
+};
+struct PreK1F {
+  [[maybe_unused]] static constexpr int kTraceBase = 8;
+  static constexpr bool kLate = true;
+  const Dev &d; int k; bool has_vec; EK1F *e; double *red; double *g, *rn;
+  struct Tok { PartRegs pd; double gamma, beta, alast; double u0, p0, r0, s0, m0, x0; };
+  __device__ __forceinline__ int first_index() const {
+    const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3;
+    return (int)(((blockIdx.x & 7) * per + (blockIdx.x >> 3)) * kBlock + threadIdx.x);
+  }
+  __device__ __forceinline__ Tok begin() const {
+    const double *uin = (k & 1) ? d.uu2 : d.uu;
+    const double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1, *bet = d.scal + S_HIST + 2 * (kMaxCg + 1);
+    Tok t;
+    if (KNOCKED(512)) { for (int q = 0; q < kPart; q++) t.pd.v[q] = 1.0; } else t.pd = partial_load(d.part + SL_DELTA * kGrid);
+    t.gamma = gam[k]; t.beta = bet[k]; t.alast = k == 0 ? 1.0 : alp[k - 1];
+    const int j0 = first_index();
+    t.u0 = t.p0 = t.r0 = t.s0 = t.m0 = t.x0 = 0.0;
+    if (has_vec && j0 < d.n) { t.u0 = uin[j0]; t.p0 = k == 0 ? 0.0 : d.p[j0]; t.r0 = d.r[j0]; t.s0 = d.s[j0]; t.m0 = d.Minv[j0]; t.x0 = d.xs[j0]; }
+    return t;
+  }
+  __device__ __forceinline__ bool finish(const Tok &t, const double (&)[1], bool) const {
+    const double *uin = (k & 1) ? d.uu2 : d.uu;
+    double *uout = (k & 1) ? d.uu : d.uu2;
+    double *alp = d.scal + S_HIST + kMaxCg + 1;
+    const PartRegs &pd = t.pd;
+    const double gamma = t.gamma, beta = t.beta, alast = t.alast;
+    const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3, slots = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+    const int j0 = first_index();
+    const bool live0 = has_vec && j0 < d.n;
+    const double u0 = t.u0, p0 = t.p0, r0 = t.r0, s0 = t.s0, m0 = t.m0, x0 = t.x0;
+    const double delta = block_sum(partial_fold_sum(pd), red);
+    const double alpha = k == 0 ? gamma / delta : gamma / (delta - beta * gamma / alast);
+    if (blockIdx.x == 0 && threadIdx.x == 0) alp[k] = alpha;
+    e->alpha = alpha;
+    double gg = 0, rr = 0;
+    if (live0) {
+      const double pp_ = k == 0 ? u0 : u0 + beta * p0;
+      const double rr_ = r0 - alpha * s0, un = m0 * rr_;
+      d.p[j0] = pp_; d.xs[j0] = x0 + alpha * pp_; d.r[j0] = rr_; uout[j0] = un;
+      gg += rr_ * un; rr = nanmax(rr, fabs(rr_));
+    }
+    if (has_vec) {
+      for (int sl = slot0 + slots; sl < per; sl += slots) {
+        const int c = xcd * per + sl;
+        if (c >= nchunk) break;
+        const int j = c * kBlock + threadIdx.x;
+        if (j >= d.n) break;
+        const double u = uin[j];
+        const double pp_ = k == 0 ? u : u + beta * d.p[j];
+        const double rr_ = d.r[j] - alpha * d.s[j], un = d.Minv[j] * rr_;
+        d.p[j] = pp_; d.xs[j] += alpha * pp_; d.r[j] = rr_; uout[j] = un;
+        gg += rr_ * un; rr = nanmax(rr, fabs(rr_));
+      }
+    }
+    *g = gg; *rn = rr;
+    return true;
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_k1f(Dev d, int i) {          // i >= 1; performs the vector update of k = i - 1
+  __shared__ StreamLdsW<1, double> lds;
+  KT(8);
+  const int k = i - 1;
+  const bool has_rows = wg_has_rows(d.A);
+  const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3;
+  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+  const bool has_vec = slot0 < per && xcd * per + slot0 < nchunk;
+  if (!has_rows && !has_vec && blockIdx.x != 0) {     // (partials of a finished PCG are never read: no flag test needed)
+    put_partial(d.part, SL_GAMMA0 + (i & 1), 0.0); put_partial(d.part, SL_RN0 + (i & 1), 0.0);
+    return;
+  }
+  double g = 0, rn = 0;
+  GMs gr{d.ms};
+  EK1F e{d.rho, d.t};
+  if (!process_rows<1>(d.A, gr, e, lds, PreK1F{d, k, has_vec, &e, lds.red, &g, &rn}, d.flags + F_DONE)) return;
+  __syncthreads();
+  block_sum_max(g, rn, lds.red);
+  put_partial(d.part, SL_GAMMA0 + (i & 1), g); put_partial(d.part, SL_RN0 + (i & 1), rn);
+  KT(14);
+}
+
+// KA ------------------------------------------------------------------------------------------
+struct EKa {
+  const double *l, *u, *rho, *rho_inv; double *z, *y, *zt, *t0, *v, *dy; double alpha; double *ztg; double theta;
+  double pl = 0, pu = 0, prho = 0, prinv = 0, pz = 0, py = 0, pzt = 0;
+  __device__ __forceinline__ void prefetch(int i) { pl = l[i]; pu = u[i]; prho = rho[i]; prinv = rho_inv[i]; pz = z[i]; py = y[i]; pzt = zt[i]; }
+  __device__ __forceinline__ void operator()(int i, const double (&s)[1]) {
+    const double ztil = s[0];
+    const double zr = alpha * ztil + (1.0 - alpha) * pz;                    // _osqp.py:686-690
+    const double zn = fmin(fmax(zr + prinv * py, pl), pu);                   // :674
+    const double dyi = prho * (zr - zn), yn = py + dyi;                      // :698-703
+    const double zg = ztil + theta * (ztil - pzt);                           // A xg (Dev::ztg)
+    y[i] = yn; dy[i] = dyi; z[i] = zn; zt[i] = ztil; v[i] = prho * zn - yn; ztg[i] = zg; t0[i] = prho * zg;
+  }
+};
+// The extrapolated PCG start is used after a solve that REACHED its tolerance -- and after a cut-off one only while the start
+// residuals keep falling (slot form, below).  A cut-off solve leaves an error that the few
+// iterations it was given barely touched in the slow modes of K; extrapolating along a step that contains it feeds that error, times
+// (1 + theta), to the next cut-off solve, and through z and y back into the next right-hand side: observed as iterates growing to
+// 1e12 within 25 ADMM iterations after a rho update had left five-iteration budgets on an ill-conditioned system (then 500
+// iterations of recovery; unstructured config 2 with cg_tol_fraction 0.1).  Limiting theta by the measured residual reduction of
+// the cut-off solve did not prevent it (the residual norm says little about the slow modes); starting from x~ itself does.
+// Every workgroup takes the same branch (conv / done come from an earlier launch); rn, bn of the last iterate are folded for
+// workgroup 0's statistics.
+__device__ __forceinline__ double cutoff_theta(const Dev &d, int slot, double *red, double &rn, double &bn, int admm = -1) {
+  rn = partial_fold_max(partial_load(d.part + (SL_RN0 + slot) * kGrid)); bn = partial_fold_max(partial_load(d.part + SL_BN * kGrid));
+  block_max2(rn, bn, red);
+  if (admm < 1) return 0.0;
+  // slot form: the start residuals of this and of the previous ADMM iteration are on record (written by earlier launches).  While they
+  // FALL the cut-off solves are keeping up and the extrapolation stays (config 2: budget-limited chunks are part of normal operation,
+  // 53 vs 65 ms); once the start residual grows, the next solve starts from x~ itself.
+  const double now = d.scal[S_RN0H + (admm & 1)], prev = d.scal[S_RN0H + ((admm + 1) & 1)];
+  return (now < prev) ? d.theta : 0.0;
+}
+__global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
+  __shared__ StreamLdsW<1, double> lds;
+  int done = d.flags[F_DONE];                       // (set by an earlier launch: the same value in every wave)
+  double theta = d.theta, rn_last = 0.0, bn_last = 0.0;
+  if (!done && budget > 0) { theta = cutoff_theta(d, budget & 1, lds.red, rn_last, bn_last); __syncthreads(); }
+  GVec g{d.xs};
+  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, theta};
+  process_rows<1>(d.A, g, e, lds);
+  const int stride = gridDim.x * kBlock;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) {    // _osqp.py:664-668
+    const double xt = d.xs[j], xo = d.x[j], xn = d.alpha * xt + (1.0 - d.alpha) * xo;
+    d.dx[j] = xn - xo; d.x[j] = xn;
+    d.xg[j] = xt + theta * (xt - d.xsp[j]); d.xsp[j] = xt;                   // next PCG start (Dev::xg)
+  }
+  if (blockIdx.x == 0) {                                                     // PCG statistics of this ADMM iteration
+    if (!done && budget > 0) {            // did the last budgeted iteration reach the tolerance? (no K1 ran after it)
+      const double rn = rn_last, bn = bn_last;
+      done = !(rn > fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS])) ? 2 : 0;
+      if (!done && threadIdx.x == 0 && rn > 0.1 * d.scal[S_RN0]) d.flags[F_STAT_STAG] += 1;
+    }
+    if (threadIdx.x == 0) {
+      const int used = done == 1 ? d.flags[F_ITERS] : budget;
+      d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;
+      if (used > d.flags[F_STAT_MAX]) d.flags[F_STAT_MAX] = used;
+      if (!done) d.flags[F_STAT_UNCONV] += 1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- slot kernels
+// Device-side scheduling of the ADMM / PCG phases (no launch is wasted on a converged PCG).  A chunk of ADMM iterations is a fixed
+// string of launches  B A B A ...  ("slots"): a B slot streams B = [P + sigma I | A'] and runs whichever B-phase is due (KB, or
+// the K2F of the current PCG iteration), an A slot streams A and runs the A-phase that is due (the first K1, a K1F, or KA).  Which
+// phase is due is a small record in device memory: every slot reads the record its predecessor wrote (kernel boundary = ordering),
+// its workgroup 0 writes the successor's -- two records, so that no workgroup of a launch can observe its own launch's update.
+// The PCG of ADMM iteration j therefore takes exactly as many slot pairs as it has iterations (plus the pair that detects
+// convergence and runs KA), whatever the neighbouring iterations needed; only the few slots left over at the END of a chunk idle.
+__global__ void k_slot_init(int *slot, int target, int cap, int epoch) {      // (cap: PCG iterations per solve; in the record, not a kernel argument, so that captured strings of slots serve every chunk)
+  slot[SR_PHASE] = P_KB; slot[SR_K] = 0; slot[SR_ADMM] = 0; slot[SR_TARGET] = target; slot[SR_USED] = 0; slot[SR_CONV] = 0; slot[SR_CAP] = cap; slot[SR_SEQ] = 0;
+  slot[SR_WORDS + SR_SEQ] = 0; slot[SR_WORDS + SR_ADMM] = 0;        // (record B still holds the previous chunk's last state: slot_poll takes the newer record)
+  slot[2 * SR_WORDS] = epoch;                                        // which chunk the records belong to (slot_poll)
+}
+
+__global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
+  __shared__ union { StreamLds<2> kb; StreamLdsW<1, double> k2f; } lds;
+  const FirstDesc fd = first_desc<true>(d.B);          // (both B phases start from the same descriptors: requested before the branch)
+  SlotState st = slot_read(d.slot);                    // written by the previous A slot (or k_slot_init)
+  int *W = d.slot + SR_WORDS;
+  if (st.ph == P_KB) {
+    if (st.admm >= st.target) { st.ph = P_IDLE; slot_write(W, st); return; }
+    GKb g{d.xg, d.v, d.t0, d.n};
+    EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma, d.xg, d.xs};
+    process_rows_fd<2>(d.B, g, e, lds.kb, NoPre(), fd);
+    __syncthreads();
+    const double G = block_sum(e.g, lds.kb.red);
+    double RN = e.rn, BN = e.bn;
+    block_max2(RN, BN, lds.kb.red);
+    put_partial(d.part, SL_GAMMA0, G); put_partial(d.part, SL_RN0, RN); put_partial(d.part, SL_BN, BN);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
+    st.ph = P_K1; st.k = 0;
+  } else if (st.ph == P_K2F) {
+    const int k = st.k;
+    const double *u = (k & 1) ? d.uu2 : d.uu;
+    GSplitU g{u, d.t, d.n};
+    EK2F e{u, d.Minv, d.s, d.ms};
+    double dl_first = 0.0;
+    if (!process_rows_fd<1>(d.B, g, e, lds.k2f, PreK2F{d, k, &e, lds.k2f.red, &dl_first}, fd)) {   // converged after k iterations
+      st.ph = P_KA; st.used = k; st.conv = 1;
+      slot_write(W, st);
+      return;
+    }
+    double DL = dl_first;
+    if (!d.B.single) { __syncthreads(); DL += block_sum(e.dl, lds.k2f.red); }
+    put_partial(d.part, SL_DELTA, DL);
+    st.ph = P_K1F;
+  }
+  slot_write(W, st);                                   // (P_KA pending after a PCG that hit the cap, P_IDLE: passed through)
+}
+
+// KA with the PCG statistics taken from the slot record (used iterations; conv = 0: the PCG stopped at the cap -- did its last
+// iterate reach the tolerance anyway?)
+template <class L>
+__device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv, const FirstDesc &fd, int admm, int target, int rn_slot = -1) {
+  double theta = d.theta, rn_last = 0.0, bn_last = 0.0;
+  // (rn_slot: which of the two ||r|| partial buffers the last PCG launch wrote -- the parity of `used` in the two-kernel form, of the LAUNCH in the F1 form)
+  if (!conv) { theta = cutoff_theta(d, rn_slot >= 0 ? rn_slot : (used & 1), lds.red, rn_last, bn_last, admm); __syncthreads(); }      // (conv comes from the slot record: uniform)
+  GVec g{d.xs};
+  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, theta};
+  process_rows_fd<1>(d.A, g, e, lds, NoPre(), fd);
+  const int stride = gridDim.x * kBlock;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) {    // _osqp.py:664-668
+    const double xt = d.xs[j], xo = d.x[j], xn = d.alpha * xt + (1.0 - d.alpha) * xo;
+    d.dx[j] = xn - xo; d.x[j] = xn;
+    d.xg[j] = xt + theta * (xt - d.xsp[j]); d.xsp[j] = xt;                   // next PCG start (Dev::xg)
+  }
+  if (blockIdx.x == 0) {
+    if (!conv) {
+      const double rn = rn_last, bn = bn_last;
+      conv = !(rn > fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS])) ? 2 : 0;
+      if (!conv && threadIdx.x == 0 && rn > 0.1 * d.scal[S_RN0]) d.flags[F_STAT_STAG] += 1;
+    }
+    if (threadIdx.x == 0) {
+      d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;
+      if (used > d.flags[F_STAT_MAX]) d.flags[F_STAT_MAX] = used;
+      if (!conv) d.flags[F_STAT_UNCONV] += 1;
+      if (d.ctl && admm + 1 >= target) d.ctl->chunk_done = 1;      // device-driven boundaries: the chunk's last ADMM iteration (read by LATER launches)
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_slot_a(Dev d) {
+  __shared__ union { StreamLdsW<1, double> k1; StreamLdsW<1, double> k1f; } lds;
+  const FirstDesc fd = first_desc<true>(d.A);
+  SlotState st = slot_read(d.slot + SR_WORDS);         // written by the previous B slot
+  int *W = d.slot;
+  if (st.ph == P_K1) {                                 // first A-apply of this ADMM iteration's PCG: stopping test on r_0, t_0 = rho .* (A u_0)
+    GVec g{d.uu};
+    EK1 e{d.rho, d.t};
+    if (process_rows_fd<1>(d.A, g, e, lds.k1, PreK1{d, 0, 0, lds.k1.red, st.admm & 1}, fd)) { st.ph = P_K2F; st.k = 0; }
+    else {                                             // the warm start already meets the tolerance: no PCG iteration, KA right here
+      __syncthreads();
+      slot_ka(d, lds.k1, 0, 1, fd, st.admm, st.target);
+      st.ph = P_KB; st.admm += 1;
+    }
+  } else if (st.ph == P_K1F) {
+    const int k = st.k, i = k + 1;
+    const int nchunk = (d.n + kBlock - 1) / kBlock, per = (nchunk + 7) >> 3;
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+    const bool has_vec = slot0 < per && xcd * per + slot0 < nchunk;
+    if (!wg_has_rows(d.A) && !has_vec && blockIdx.x != 0) {
+      put_partial(d.part, SL_GAMMA0 + (i & 1), 0.0); put_partial(d.part, SL_RN0 + (i & 1), 0.0);
+    } else {
+      double g = 0, rn = 0;
+      GMs gr{d.ms};
+      EK1F e{d.rho, d.t};
+      process_rows_fd<1>(d.A, gr, e, lds.k1f, PreK1F{d, k, has_vec, &e, lds.k1f.red, &g, &rn}, fd);
+      __syncthreads();
+      block_sum_max(g, rn, lds.k1f.red);
+      put_partial(d.part, SL_GAMMA0 + (i & 1), g); put_partial(d.part, SL_RN0 + (i & 1), rn);
+    }
+    if (i >= st.cap) { st.ph = P_KA; st.used = i; st.conv = 0; }      // the PCG stops at the cap; the next A slot runs KA
+    else { st.ph = P_K2F; st.k = i; }
+  } else if (st.ph == P_KA) {
+    slot_ka(d, lds.k1, st.used, st.conv, fd, st.admm, st.target);
+    st.ph = P_KB; st.admm += 1;
+  }
+  slot_write(W, st);
+}
+
+
+// ---------------------------------------------------------------------------------------------- one launch per PCG iteration (F1)
+// backend.h DevF1.  Launch F_k of the PCG of one ADMM iteration (k = 0 .. iterations):
+//   scalars   k = 0:  ||r_0||, ||rhs|| (KB's partials) -> tolerance, stopping test
+//             k >= 1: gamma_{k-1}, delta_{k-1}, ||r_{k-1}|| (partials of F_{k-1}) -> stopping test (k >= 2), beta_{k-1}, alpha_{k-1}
+//   window    u_k[c] = Minv (r_{k-1} - alpha (w_{k-1} + beta s_{k-2}))[c],  w_{k-1} = sum_d rep_d = K u_{k-1}   (k = 0: Minv r_0)
+//             for every column c of the block's GATHER window (the columns its rows of A and its own rows of P touch) -- recomputed
+//             by every workgroup that gathers c, with the same instruction sequence as the owner's update (f1_upd): all copies
+//             are bit-identical.  The lane whose window column is one of the block's OWN columns also performs that column's
+//             vector update:  s_{k-1}, r_k, p_{k-1}, x~ += alpha p_{k-1}  stored;  partials gamma_k = <r_k, Minv r_k>, ||r_k||_inf
+//   SpMV      t = rho .* (A_g u_k)  (rows of the block, products staged in LDS, one lane per row),
+//             pu_k = (P + sigma I) u_k  on the own columns,  rep_{g mod D} = A_g' t (+ pu_k on the own columns)  per column of the block's
+//             SCATTER window (the columns of its rows of A, which include its own columns; second, column-ordered pass over the
+//             entries still held in registers),  partial delta_k = <t, A u_k> + <u_k, pu_k>_own = <u_k, K u_k>
+// r, s, rep are double-buffered by the parity of k: a workgroup reads what the PREVIOUS launch wrote while its neighbours
+// write this launch's values.  Four workgroup barriers per block, no global synchronisation inside the launch.
+// Template: D = replicas, FIRST = the launch F_0 (straight-line code: no run-time branch on either).
+struct F1Lds {
+  double win[kF1Win];            // u_k on the block's gather window
+  double prod[kF1Chunk];         // A products in row-major entry order, then val * t[row] in column-major order
+  double tvec[kF1MaxRows];       // t of the block's rows
+  double uown[kF1MaxOwn];        // u_k on the own columns
+  double puown[kF1MaxOwn];       // (P + sigma I) u_k on the own columns: added to the block's own slice of A' t (the own columns lie inside its scatter window)
+  double pprod[kF1PChunk];       // (P + sigma I) products of the own rows
+  double red[3 * kWaves];
+};
+struct F1Scal { double alpha, beta; int general; };       // general = 0: the first update (s_0 = w_0, p_0 = u_0: s_{-1}, p_{-1} are not used)
+template <int D>
+__device__ __forceinline__ double f1_w(const double (&rp)[D]) {     // w_{k-1} = K u_{k-1}: the replicas in index order (deterministic)
+  double w = rp[0];
+#pragma unroll
+  for (int q = 1; q < D; q++) w += rp[q];
+  return w;
+}
+__device__ __forceinline__ void f1_upd(const F1Scal &sc, double minv, double r, double w, double sp, double &sn, double &rn, double &un) {
+  sn = fma(sc.beta, sc.general ? sp : 0.0, w);           // (first update: beta = 0 and the stale s is masked, so s_0 = w_0 exactly)
+  rn = fma(-sc.alpha, sn, r);
+  un = minv * rn;
+}
+// sum of seg[a .. z): the first kB entries with independent LDS reads (as process_rows)
+template <int kB>
+__device__ __forceinline__ double f1_segsum(const double *seg, int a, int z) {
+  double v[kB];
+#pragma unroll
+  for (int q = 0; q < kB; q++) v[q] = a + q < z ? seg[a + q] : 0.0;
+  double acc = 0.0;
+#pragma unroll
+  for (int q = 0; q < kB; q++) acc += v[q];
+  for (int k = a + kB; k < z; k++) acc += seg[k];
+  return acc;
+}
+// The scalar part of launch F_k.  The per-workgroup partials (gamma, delta, ||r||) are double-buffered by the parity of the LAUNCH, not of k:
+// a launch reads what the previous launch of the string wrote -- KB: gamma_0, ||r_0||, ||rhs|| (in delta's slot); F_k: gamma_k, delta_k, ||r_k|| --
+// so the three loads depend on nothing but the kernel's `par` argument and leave at the very head of the launch (f1_fold_issue), next to
+// the phase record instead of behind it.  f1_fold_finish returns false when the PCG had already converged (the caller runs KA in this launch).
+struct F1Fold { PartRegs a, b, c; };
+__device__ __forceinline__ F1Fold f1_fold_issue(const Dev &d, const int par, const int probe) {
+  F1Fold f;
+#pragma unroll
+  for (int q = 0; q < kPart; q++) { f.a.v[q] = 0.0; f.b.v[q] = 0.0; f.c.v[q] = 0.0; }
+  if (probe == 1) return f;                                 // (probe == 2 pays for the fold like a solve's launch, then uses the fixed scalars)
+  const int prev = par ^ 1;
+  f.a = partial_load(d.part + (SL_GAMMA0 + prev) * kGrid); f.b = partial_load(d.part + (SL_DELTA + prev) * kGrid); f.c = partial_load(d.part + (SL_RN0 + prev) * kGrid);
+  return f;
+}
+__device__ __forceinline__ bool f1_fold_finish(const Dev &d, const int k, const int admm_par, const int probe, const F1Fold &f, double *red, F1Scal &sc) {
+  double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
+  const int tid = threadIdx.x;
+  sc = F1Scal{0.0, 0.0, k >= 2};
+  if (probe == 1) { sc.alpha = 1e-3; sc.beta = k >= 2 ? 0.5 : 0.0; return true; }
+  if (k == 0) {
+    double rn = partial_fold_max(f.c), bn = partial_fold_max(f.b);
+    block_max2(rn, bn, red);
+    const double tol = fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS]);
+    if (probe) { if (rn < -1.0) d.res[R_COUNT - 1] = bn + tol; return true; }
+    if (blockIdx.x == 0 && tid == 0) { d.scal[S_TOL_NOW] = tol; d.scal[S_RN0] = rn; d.scal[S_RN0H + admm_par] = rn; }
+    return rn > tol;                                        // false: the start already meets the tolerance (a NaN also ends the inner loop)
+  }
+  const double tol = d.scal[S_TOL_NOW], glast = k >= 2 ? gam[k - 2] : 1.0, alast = k >= 2 ? alp[k - 2] : 1.0;
+  double gamma = partial_fold_sum(f.a), rn = partial_fold_max(f.c), delta = partial_fold_sum(f.b);
+  block_sum_max_sum(gamma, rn, delta, red);
+  if (probe) {                                              // timing probe: the fold above was paid for; bounded, repeatable scalars instead of its result
+    if (rn < -1.0) d.res[R_COUNT - 1] = gamma + delta + tol + glast + alast;      // (never true: keeps the fold alive)
+    sc.alpha = 1e-3; sc.beta = k >= 2 ? 0.5 : 0.0;
+    return true;
+  }
+  if (k >= 2 && !(rn > tol)) return false;                  // converged after k - 1 iterations (r_0 was tested by F_0)
+  sc.beta = k >= 2 ? gamma / glast : 0.0;
+  sc.alpha = k >= 2 ? gamma / (delta - sc.beta * gamma / alast) : gamma / delta;
+  if (blockIdx.x == 0 && tid == 0) { gam[k - 1] = gamma; alp[k - 1] = sc.alpha; }
+  return true;
+}
+// base[idx] as int4 through the CONSTANT address space: with a wave-uniform index the compiler emits scalar loads
+__device__ __forceinline__ int4 sload_int4(const int *base, size_t idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef int __attribute__((ext_vector_type(4))) v4i;
+  typedef const v4i __attribute__((address_space(4))) *cptr;
+  const v4i v = ((cptr)(unsigned long long)base)[idx];
+  return make_int4(v.x, v.y, v.z, v.w);
+#else
+  return reinterpret_cast<const int4 *>(base)[idx];
+#endif
+}
+struct F1Rec { int4 ds, fa, fb, fc; };      // a block's record (DevF1::blk)
+__device__ __forceinline__ F1Rec f1_record(const DevF1 &f, int b) {
+  return F1Rec{sload_int4(f.blk, 4 * (size_t)b), sload_int4(f.blk, 4 * (size_t)b + 1), sload_int4(f.blk, 4 * (size_t)b + 2), sload_int4(f.blk, 4 * (size_t)b + 3)};
+}
+template <int D, bool FIRST>
+__device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool vec_only, const F1Scal sc, F1Lds &L, const F1Rec &rec0, const int par) {
+  const DevF1 &f = d.f1;
+  const int n = d.n, tid = threadIdx.x;
+  const int cur = (k + 1) & 1, nxt = k & 1;               // parity of k - 1 / of k
+  KT(1);
+  // every n-vector of the iteration lives in ONE arena (DevF1::va, stride ns): the addresses derive from one base pointer by scalar
+  // adds instead of a kernel-argument load per vector
+  const double *va = f.va; const size_t ns = f.ns;
+  const double *Minv = va, *xs_r = va + ns, *p_r = va + 2 * ns;
+  double *xs_w = f.va + ns, *p_w = f.va + 2 * ns;
+  const double *rread = va + (3 + ((FIRST || cur == 0) ? 0 : 1)) * ns;      // r_{k-1} (F_0: r_0)
+  double *rnxt = f.va + (3 + nxt) * ns;                     // r_k
+  const double *sprev = va + (5 + cur) * ns;                // s_{k-2}: stored next to r_{k-1}
+  double *snew = f.va + (5 + nxt) * ns;                     // s_{k-1}: stored next to r_k
+  const double *repcur = va + (7 + (size_t)cur * D) * ns;   // K u_{k-1} in D partial vectors
+  double *repnxt = f.va + (7 + (size_t)nxt * D) * ns;
+  double g_acc = 0.0, rn_acc = 0.0, dl_acc = 0.0;
+  // the vector update of one own column (operands in registers): stores s_{k-1}, r_k, p_{k-1}, x~; returns u_k
+  auto own_update = [&](int j, double mi, double r, double w, double sp, double pp, double x) -> double {
+    double sn, rn, un;
+    f1_upd(sc, mi, r, w, sp, sn, rn, un);
+    const double pn = fma(sc.beta, sc.general ? pp : 0.0, mi * r);
+    xs_w[j] = fma(sc.alpha, pn, x); p_w[j] = pn; snew[j] = sn; rnxt[j] = rn;
+    g_acc += rn * un; rn_acc = nanmax(rn_acc, fabs(rn));
+    return un;
+  };
+  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int per = (d.A.nblk + 7) >> 3;
+  constexpr int CW = kF1Win / kBlock, CE = kF1Chunk / kBlock;
+  static_assert(kF1PChunk == kBlock, "one (P + sigma I) entry per lane");
+  for (int sl = slot0; sl < per; sl += slots) {
+    const int b = __builtin_amdgcn_readfirstlane(xcd * per + sl);
+    if (b >= d.A.nblk) break;
+    // the block's record: 16 words, one scalar load
+    // (read through the constant address space: the index is wave-uniform, so the four int4 become scalar loads behind ONE wait --
+    //  as generic-pointer loads inside this loop they were four vector loads, each waited for before the next was issued)
+    const F1Rec rec = sl == slot0 ? rec0 : f1_record(f, b);      // (the first block's record was requested before the scalar fold)
+    const int4 ds = rec.ds, fa = rec.fa, fb = rec.fb, fc = rec.fc;
+    const int r0 = ds.x, nrows = ds.y - ds.x, k0 = ds.z, cnt = ds.w - ds.z;
+    const int cov0 = fa.x, cov1 = fa.y, cs0 = fa.z, nown = fa.w - fa.z;
+    const int cpo = fb.x, pk0 = fb.y, pcnt = fb.z - fb.y;
+    const int g0 = fc.x, gl = vec_only ? 0 : fc.y, a0 = fc.z, wl = fc.w;      // gather window [g0, g0 + gl), scatter window [a0, a0 + wl)
+    const int nw = (gl + kBlock - 1) / kBlock, nu = (cnt + kBlock - 1) / kBlock, ns2 = (wl + kBlock - 1) / kBlock;
+    KT(2);
+    // ---- loads.  First the (P + sigma I) entry of this lane: its column decides whether the operand comes from the window or has
+    //      to be recomputed from its parts (columns outside the window), and those loads should leave with the window's, not after it
+    double pv = 0.0; int pc = g0;
+    const bool hasp = !vec_only && tid < pcnt;
+    if (!vec_only) { const int e = pk0 + max(0, min(tid, pcnt - 1)); pv = f.pval[e]; pc = f.pcol[e]; }
+    // ---- window parts (+ p, x~ where the window column is one of the block's own)
+    double wm[CW], wr[CW], wsv[CW], wq[CW][D], wpp[CW], wx[CW];
+    bool wown[CW];
+#pragma unroll
+    for (int u = 0; u < CW; u++) {
+      wown[u] = false;
+      if (u < nw) {
+        const int e = tid + u * kBlock, c = g0 + min(e, gl - 1);
+        wown[u] = e < gl && c >= cs0 && c - cs0 < nown;
+        wm[u] = Minv[c]; wr[u] = rread[c];
+        if (!FIRST) {
+#pragma unroll
+          for (int q = 0; q < D; q++) wq[u][q] = repcur[q * ns + c];
+          wsv[u] = sprev[c];
+          const int co = wown[u] ? c : g0;                  // (other lanes re-read one valid element: no branch around the loads)
+          wx[u] = xs_r[co]; wpp[u] = p_r[co];
+        }
+      }
+    }
+    // ---- matrix entries, row / column pointers
+    double vw[CE]; unsigned int en[CE];
+    int rp0 = 0, rp1 = 0; double rrho = 0.0;
+    int cp0[CW], cp1[CW];
+    int pp0 = 0, pp1 = 0;
+    if (!vec_only) {
+#pragma unroll
+      for (int u = 0; u < CE; u++) { if (u < nu) { const int e = k0 + min(tid + u * kBlock, cnt - 1); vw[u] = d.A.val[e]; en[u] = f.ent[e]; } }
+      { const int row = r0 + min(tid, nrows - 1); rp0 = d.A.rowptr[row]; rp1 = d.A.rowptr[row + 1]; rrho = d.rho[row]; }
+#pragma unroll
+      for (int u = 0; u < CW; u++) { if (u < ns2) { const int c = cpo + min(tid + u * kBlock, wl - 1); cp0[u] = f.cptr[c]; cp1[u] = f.cptr[c + 1]; } }
+      { const int j = min(cs0 + max(0, min(tid, nown - 1)), n - 1); pp0 = f.prp[j]; pp1 = f.prp[j + 1]; }
+    }
+    // ---- operand of a (P + sigma I) entry whose column lies outside the window: its parts, requested now
+    const int pcl = pc - g0;
+    const bool esc = hasp && !(pcl >= 0 && pcl < gl);
+    double em = 0, er = 0, es = 0, eq[D];
+#pragma unroll
+    for (int q = 0; q < D; q++) eq[q] = 0.0;
+    if (esc) {
+      em = Minv[pc]; er = rread[pc];
+      if (!FIRST) {
+        es = sprev[pc];
+#pragma unroll
+        for (int q = 0; q < D; q++) eq[q] = repcur[q * ns + pc];
+      }
+    }
+    KT(3);
+    // ---- u_k on the window -> LDS; the lane of an own column also performs that column's vector update
+#pragma unroll
+    for (int u = 0; u < CW; u++) {
+      if (u < nw) {
+        const int e = min(tid + u * kBlock, gl - 1);
+        double un;
+        if (FIRST) un = wm[u] * wr[u];
+        else {
+          const double w = f1_w<D>(wq[u]);
+          if (wown[u]) un = own_update(g0 + e, wm[u], wr[u], w, wsv[u], wpp[u], wx[u]);
+          else { double sn, rn; f1_upd(sc, wm[u], wr[u], w, wsv[u], sn, rn, un); }
+        }
+        if (wown[u]) L.uown[g0 + e - cs0] = un;
+        L.win[e] = un;                                      // (clamped lanes store the same value)
+      }
+    }
+    // ---- own columns outside the gather window (none on banded problems; all of them in the last budgeted update)
+    for (int jj = tid; jj < nown; jj += kBlock) {
+      const int j = cs0 + jj;
+      if (j >= g0 && j - g0 < gl) continue;
+      const double mi = Minv[j], r = rread[j];
+      double un = mi * r;
+      if (!FIRST) {
+        double rp[D];
+#pragma unroll
+        for (int q = 0; q < D; q++) rp[q] = repcur[q * ns + j];
+        un = own_update(j, mi, r, f1_w<D>(rp), sprev[j], p_r[j], xs_r[j]);
+      }
+      if (!vec_only) L.uown[jj] = un;
+    }
+    if (vec_only) continue;
+    KT(4);
+    __syncthreads();
+    // ---- products: A entries against the window; the (P + sigma I) entry against the window or its recomputed operand
+#pragma unroll
+    for (int u = 0; u < CE; u++) { if (u < nu) L.prod[tid + u * kBlock] = vw[u] * L.win[en[u] & 0x1ffu]; }
+    if (hasp) {
+      double uv;
+      if (!esc) uv = L.win[pcl];
+      else if (FIRST) uv = em * er;
+      else { double sn, rn; f1_upd(sc, em, er, f1_w<D>(eq), es, sn, rn, uv); }
+      L.pprod[tid] = pv * uv;
+    }
+    KT(5);
+    __syncthreads();
+    // ---- row sums: t = rho .* (A u) -> LDS
+    for (int row = tid; row < nrows; row += kBlock) {
+      if (row != tid) { rp0 = d.A.rowptr[r0 + row]; rp1 = d.A.rowptr[r0 + row + 1]; rrho = d.rho[r0 + row]; }
+      const double au = f1_segsum<6>(L.prod, rp0 - k0, rp1 - k0), t = rrho * au;
+      L.tvec[row] = t; dl_acc += t * au;
+    }
+    KT(6);
+    __syncthreads();
+    // ---- A_g' t: val * t[row] scattered to column-major order;  pu = (P + sigma I) u on the own columns -> global
+#pragma unroll
+    for (int u = 0; u < CE; u++) { if (u < nu) L.prod[en[u] >> 18] = vw[u] * L.tvec[(en[u] >> 9) & 0x1ffu]; }     // (clamped lanes repeat the last entry's store)
+    for (int jj = tid; jj < nown; jj += kBlock) {
+      if (jj != tid) { pp0 = f.prp[cs0 + jj]; pp1 = f.prp[cs0 + jj + 1]; }
+      const double pu = f1_segsum<4>(L.pprod, pp0 - pk0, pp1 - pk0);
+      L.puown[jj] = pu; dl_acc += L.uown[jj] * pu;
+    }
+    KT(7);
+    __syncthreads();
+    // ---- one lane per column of the scatter window
+    double *rout = repnxt + (size_t)(b % D) * ns;
+#pragma unroll
+    for (int u = 0; u < CW; u++) {
+      if (u < ns2) {
+        const int c = tid + u * kBlock;
+        if (c < wl) {
+          double v = f1_segsum<8>(L.prod, cp0[u], cp1[u]);
+          const int jo = a0 + c - cs0;
+          if (jo >= 0 && jo < nown) v += L.puown[jo];         // this block owns the column: + (P + sigma I) u
+          rout[a0 + c] = v;
+        }
+      }
+    }
+    for (int j = cov0 + tid; j < a0; j += kBlock) rout[j] = 0.0;             // the replica's gap up to the next window of this replica
+    for (int j = a0 + wl + tid; j < cov1; j += kBlock) rout[j] = 0.0;
+    KT(8);
+    if (sl + slots < per) __syncthreads();                  // (another block follows: the LDS arrays are reused)
+  }
+  __syncthreads();
+  block_sum_max_sum(g_acc, rn_acc, dl_acc, L.red);
+  if (!FIRST) { put_partial(d.part, SL_GAMMA0 + par, g_acc); put_partial(d.part, SL_RN0 + par, rn_acc); }
+  else if (tid == 0) {                                      // F_0 hands KB's gamma_0, ||r_0|| on: this workgroup's entries move to this launch's buffers
+    d.part[(SL_GAMMA0 + par) * kGrid + blockIdx.x] = d.part[(SL_GAMMA0 + (par ^ 1)) * kGrid + blockIdx.x];
+    d.part[(SL_RN0 + par) * kGrid + blockIdx.x] = d.part[(SL_RN0 + (par ^ 1)) * kGrid + blockIdx.x];
+  }
+  if (!vec_only) put_partial(d.part, SL_DELTA + par, dl_acc);
+  KT(9);
+}
+// returns false when the PCG had already converged (nothing done: the caller runs KA in this launch)
+// the record of the workgroup's first row block
+__device__ __forceinline__ F1Rec f1_first_record(const Dev &d) {
+  const int b0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * ((d.A.nblk + 7) >> 3) + (int)(blockIdx.x >> 3));
+  return f1_record(d.f1, min(b0, d.A.nblk - 1));
+}
+// D (the number of replica vectors, DevF1::D) is a TEMPLATE parameter of the kernels: a slot kernel that carries the bodies of all four
+// values pays for the three it never runs in every launch (the head of a launch is as long as the kernel's register / code footprint
+// makes it)
+template <int D>
+__device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const int cap, const int admm_par, const int probe, F1Lds &L, const F1Rec &rec0, const F1Fold &fold, const int par) {
+  KT(0);
+  F1Scal sc;
+  if (!f1_fold_finish(d, k, admm_par, probe, fold, L.red, sc)) return false;
+  const bool vec_only = !probe && k >= cap;                 // the last budgeted update: no operator apply follows
+  if (k == 0) f1_body<D, true>(d, k, vec_only, sc, L, rec0, par);
+  else f1_body<D, false>(d, k, vec_only, sc, L, rec0, par);
+  return true;
+}
+__global__ __launch_bounds__(kBlock) void k_f1_refresh(Dev d) {
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < d.f1.pnnz; k += gridDim.x * kBlock) d.f1.pval[k] = d.B.val[d.f1.psrc[k]];
+}
+// timing probe: one F launch as a solve runs it -- the scalar fold of the previous launch's partials included -- with fixed alpha, beta
+// and no stopping test (mode 2; mode 1 skips the fold: what the launch costs without it)
+template <int D>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_f1_probe(Dev d, int k, int mode) {
+  __shared__ F1Lds lds;
+  const int par = k & 1;
+  const F1Fold fold = f1_fold_issue(d, par, mode);
+  f1_iteration<D>(d, k, 1 << 30, 0, mode, lds, f1_first_record(d), fold, par);      // (the first block's record goes out ahead of the partials of the scalar fold: both latencies overlap)
+}
+
+// The slot kernel of the F1 form: every launch of a chunk's string is this kernel (par: which of the two phase records it reads);
+// the phase that is due -- KB (streams B), a PCG iteration F_k (streams A and P), KA (streams A) -- comes from the record.
+template <int D>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_slot1(Dev d, int par) {
+  __shared__ union { StreamLds<2> kb; StreamLdsW<1, double> ka; F1Lds f; } lds;
+  const int *R = d.slot + (par ? SR_WORDS : 0);
+  int *W = d.slot + (par ? 0 : SR_WORDS);
+  // The head of every launch is a chain of dependent scalar loads (kernel arguments -> phase record -> block record -> first vector loads):
+  // the arguments the F phase needs are pinned into registers HERE, behind one wait, and the block record is requested together with the
+  // phase record (most launches are F launches; KB / KA request their own descriptors after the branch)
+  const F1Fold fold = f1_fold_issue(d, par, 0);         // the previous launch's partials: their address depends on `par` alone
+  const F1Rec rec0 = f1_first_record(d);
+  SlotState st = slot_read(R);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // both records, the partials and the phases' base pointers are in registers HERE: requested together, one wait
+  asm volatile("" :: "s"(st.ph), "s"(rec0.ds.x), "s"(rec0.fc.w), "s"(d.part), "s"(d.scal), "s"(d.f1.va), "s"(d.x), "s"(d.ztg), "s"(d.v), "s"(d.uu), "s"(d.n),
+               "v"(fold.a.v[0]), "v"(fold.a.v[kPart - 1]), "v"(fold.b.v[0]), "v"(fold.b.v[kPart - 1]), "v"(fold.c.v[0]), "v"(fold.c.v[kPart - 1]));
+#endif
+  if (st.ph == P_KB) {
+    if (st.admm >= st.target) { st.ph = P_IDLE; slot_write(W, st); return; }
+    GKb g{d.xg, d.v, d.t0, d.n};
+    EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma, d.xg, d.xs};
+    process_rows<2>(d.B, g, e, lds.kb);
+    __syncthreads();
+    const double G = block_sum(e.g, lds.kb.red);
+    double RN = e.rn, BN = e.bn;
+    block_max2(RN, BN, lds.kb.red);
+    put_partial(d.part, SL_GAMMA0 + par, G); put_partial(d.part, SL_RN0 + par, RN); put_partial(d.part, SL_DELTA + par, BN);      // (||rhs|| travels in delta's slot: f1_fold_finish, k = 0)
+    put_partial(d.part, SL_BN, BN);                        // (... and stays on record for the KA of a PCG that ran into its cap)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
+    st.ph = P_F; st.k = 0;
+  } else if (st.ph == P_F) {
+    if (f1_iteration<D>(d, st.k, st.cap, st.admm & 1, 0, lds.f, rec0, fold, par)) {
+      if (st.k >= st.cap) { st.ph = P_KA; st.used = st.k; st.conv = 0; }      // stopped at the cap: the next launch runs KA
+      else st.k += 1;
+    } else {                                             // converged: KA right here
+      __syncthreads();
+      slot_ka(d, lds.ka, st.k == 0 ? 0 : st.k - 1, 1, first_desc<true>(d.A), st.admm, st.target);
+      st.ph = P_KB; st.admm += 1;
+    }
+  } else if (st.ph == P_KA) {
+    slot_ka(d, lds.ka, st.used, st.conv, first_desc<true>(d.A), st.admm, st.target, par ^ 1);
+    st.ph = P_KB; st.admm += 1;
+  }
+  slot_write(W, st);
+}
+
+
+}  // namespace
+
+void kb_rhs(Dev &d) { LAUNCH(k_kb, d, d); }
+bool pcg_fused(const Dev &d) { return d.fused != 0; }
+void k1(Dev &d, int i) { if (d.fused && i > 0) LAUNCH(k_k1f, d, d, i); else LAUNCH(k_k1, d, d, i, 0); }
+void k2(Dev &d, int i) { if (d.fused) LAUNCH(k_k2f, d, d, i); else LAUNCH(k_k2, d, d, 0); }
+void kv(Dev &d, int i) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, i, 0); else LAUNCH(k_kv<1>, d, d, i, 0); }
+void ka(Dev &d, int budget) { LAUNCH(k_ka, d, d, budget); }
+bool slots_supported(const Dev &d) { return d.fused != 0 && d.slot != nullptr; }
+void slot_begin(Dev &d, int target, int cap) { HIP_CHECK(hipSetDevice(d.device)); hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(1), 0, st(d), d.slot, target, cap, ++im(d).epoch); }
+void slot_pair(Dev &d) {
+  if (d.f1.on) {
+    switch (d.f1.D) {
+      case 1: LAUNCH(k_slot1<1>, d, d, 0); LAUNCH(k_slot1<1>, d, d, 1); break;
+      case 2: LAUNCH(k_slot1<2>, d, d, 0); LAUNCH(k_slot1<2>, d, d, 1); break;
+      case 3: LAUNCH(k_slot1<3>, d, d, 0); LAUNCH(k_slot1<3>, d, d, 1); break;
+      default: LAUNCH(k_slot1<4>, d, d, 0); LAUNCH(k_slot1<4>, d, d, 1); break;
+    }
+  }
+  else { LAUNCH(k_slot_b, d, d); LAUNCH(k_slot_a, d, d); }
+}
+void f1_refresh(Dev &d) { if (d.f1.on) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_f1_refresh, d, d); } }
+int slot_seq(Dev &d) { return (im(d).pin_flags + F_COUNT)[SR_SEQ]; }      // slots executed since slot_begin, as of the last fetch (record A)
+int slot_done(Dev &d) {        // ADMM iterations completed by the chunk, as of the last fetch_flags / fetch_res_flags (record A: written by the last A slot)
+  const int *rec = im(d).pin_flags + F_COUNT;
+  return rec[SR_ADMM];
+}
+
+// Progress of the running chunk, read on a side stream WITHOUT waiting for d.stream: slots executed and ADMM iterations completed
+// according to the newer of the two records (a record is eight words written by one thread -- a read may mix two states of it, but
+// both counters only grow, so neither is ever ahead of the truth).  Scheduling information only: Engine::exec_chunk tops the chunk's
+// string of slot launches up before it runs dry; what the slots compute does not depend on how many of them are enqueued.
+void slot_poll(Dev &d, int *seq, int *done) {
+  HIP_CHECK(hipSetDevice(d.device));
+  Impl &p = im(d);
+  HIP_CHECK(hipMemcpyAsync(p.pin_poll, d.slot, sizeof(int) * kSlotInts, hipMemcpyDeviceToHost, p.side));
+  HIP_CHECK(hipStreamSynchronize(p.side));
+  if (p.pin_poll[2 * SR_WORDS] != p.epoch) { *seq = 0; *done = 0; return; }      // the chunk's first launch (k_slot_init) has not run yet
+  const int *ra = p.pin_poll, *rb = p.pin_poll + SR_WORDS;
+  const int *nw = ra[SR_SEQ] >= rb[SR_SEQ] ? ra : rb;
+  *seq = nw[SR_SEQ]; *done = nw[SR_ADMM];
+}
+
+// Mean duration of one launch of a hot-path kernel, measured with a hipEvent pair on the solver's stream.
+// Kernels run in probe mode (no convergence logic; Kv with alpha = beta = 0) on the solver's live buffers; the
+// iterate state that KB/KA/Kv overwrite is saved and restored around the measurement.
+// probe 16: the phase records say "PCG iteration k0 of a chunk that never ends", the tolerance can never be met: the launches that follow
+// are the slot kernel's own F launches -- scalars from the fold, stopping test, record hand-over -- exactly as a solve runs them
+__global__ void k_slot_probe_f(int *slot, double *scal, int k0) {
+  for (int rec = 0; rec < 2; rec++) {
+    int *r = slot + rec * SR_WORDS;
+    r[SR_PHASE] = P_F; r[SR_K] = k0; r[SR_ADMM] = 0; r[SR_TARGET] = 1; r[SR_USED] = 0; r[SR_CONV] = 0; r[SR_CAP] = 1 << 20; r[SR_SEQ] = rec ? -1 : 0;
+  }
+  scal[S_TOL_NOW] = -1.0;
+}
+static void f1_probe_pair(Dev &d, int mode) {           // two consecutive F launches of the probe kernel (the double-buffered vectors alternate)
+  switch (d.f1.D) {
+    case 1: LAUNCH(k_f1_probe<1>, d, d, 2, mode); LAUNCH(k_f1_probe<1>, d, d, 3, mode); break;
+    case 2: LAUNCH(k_f1_probe<2>, d, d, 2, mode); LAUNCH(k_f1_probe<2>, d, d, 3, mode); break;
+    case 3: LAUNCH(k_f1_probe<3>, d, d, 2, mode); LAUNCH(k_f1_probe<3>, d, d, 3, mode); break;
+    default: LAUNCH(k_f1_probe<4>, d, d, 2, mode); LAUNCH(k_f1_probe<4>, d, d, 3, mode); break;
+  }
+}
+float time_kernel(Dev &d, int which, int reps) {
+  HIP_CHECK(hipSetDevice(d.device));
+  Impl &p = im(d);
+  struct Save { double *ptr; size_t cnt; double *bak; };
+  const size_t n = d.n, m = d.m;
+  Save sv[] = {{d.x, n, nullptr}, {d.z, m, nullptr}, {d.y, m, nullptr}, {d.xs, n, nullptr}, {d.zt, m, nullptr}, {d.t0, m, nullptr},
+               {d.v, m, nullptr}, {d.dx, n, nullptr}, {d.dy, m, nullptr}, {d.r, n, nullptr}, {d.uu, n, nullptr}, {d.p, n, nullptr},
+               {d.s, n, nullptr}, {d.w, n, nullptr}, {d.t, m, nullptr}, {d.uu2, n, nullptr}, {d.ms, 2 * n, nullptr},
+               {d.xg, n, nullptr}, {d.xsp, n, nullptr}, {d.ztg, m, nullptr}};
+  int flags_bak[F_COUNT];
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  HIP_CHECK(hipMemcpy(flags_bak, d.flags, sizeof(flags_bak), hipMemcpyDeviceToHost));
+  for (auto &s : sv) {
+    if (!s.cnt) continue;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&s.bak), s.cnt * sizeof(double)));
+    HIP_CHECK(hipMemcpy(s.bak, s.ptr, s.cnt * sizeof(double), hipMemcpyDeviceToDevice));
+  }
+  auto K1 = [&](int pr) { LAUNCH(k_k1, d, d, 1, pr); };
+  auto K2 = [&]() { LAUNCH(k_k2, d, d, 1); };
+  auto KV = [&](int pr) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, 1, pr); else LAUNCH(k_kv<1>, d, d, 1, pr); };
+  auto launch = [&]() {
+    switch (which) {
+      case 0: LAUNCH(k_k1, d, d, 1, 1); break;
+      case 1: LAUNCH(k_k2, d, d, 1); break;
+      case 2: if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, 1, 1); else LAUNCH(k_kv<1>, d, d, 1, 1); break;
+      case 3: LAUNCH(k_kb, d, d); break;
+      case 4: LAUNCH(k_ka, d, d, 0); break;
+      case 5: K1(1); K2(); KV(1); break;      // one PCG iteration, reductions of partials skipped
+      case 6: K1(2); K2(); KV(2); break;      // one PCG iteration as a solve executes it
+      case 7: K1(2); KV(2); break;            // ... without K2   (6 minus 7 = K2's time inside the sequence, L2-cold like in a solve)
+      case 8: K2(); KV(2); break;             // ... without K1
+      case 9: K1(2); K2(); break;             // ... without Kv
+      case 11: LAUNCH(k_k1f, d, d, 1); break;  // fused SpMV-A + vector update alone (alpha fixed by the stored history; drifts linearly, bounded)
+      case 12: LAUNCH(k_k2f, d, d, 0); break;  // fused SpMV-B alone
+      case 13: LAUNCH(k_k2f, d, d, 2); LAUNCH(k_k1f, d, d, 3); break;   // the same pair with the done flag set: what an early-exit pair costs
+      case 14: f1_probe_pair(d, 1); break;   // F1 form without the scalar fold at the head of the launch (two consecutive iterations)
+      case 16: slot_pair(d); break;           // two F launches of the slot kernel itself (records set up by k_slot_probe_f below): what a launch costs inside a solve
+      case 15: f1_probe_pair(d, 2); break;   // F1 form: one PCG iteration = one launch; two consecutive iterations as a solve runs them (buffers alternate, fold included)
+      default: LAUNCH(k_k2f, d, d, 0); LAUNCH(k_k1f, d, d, 1); break;   // one FUSED PCG iteration (two kernels): repeated exact line-search steps, bounded
+    }
+  };
+  if (which >= 14 && which <= 16 && !d.f1.on) return 0.f;
+  if (which == 16) {
+    if (reps > 400) reps = 400;                 // (k advances by two per repetition; the alpha / gamma history holds kMaxCg entries)
+    hipLaunchKernelGGL(k_slot_probe_f, dim3(1), dim3(1), 0, st(d), d.slot, d.scal, 2);
+  }
+  if (which >= 10) HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, which == 13 ? 1 : 0, sizeof(int), st(d)));   // (byte pattern 1 -> nonzero flag)
+  for (int w = 0; w < 5; w++) launch();
+  HIP_CHECK(hipEventRecord(p.ev0, st(d)));
+  for (int r = 0; r < reps; r++) launch();
+  HIP_CHECK(hipEventRecord(p.ev1, st(d)));
+  HIP_CHECK(hipEventSynchronize(p.ev1));
+  float ms = 0.f;
+  HIP_CHECK(hipEventElapsedTime(&ms, p.ev0, p.ev1));
+  for (auto &s : sv) {
+    if (!s.cnt) continue;
+    HIP_CHECK(hipMemcpy(s.ptr, s.bak, s.cnt * sizeof(double), hipMemcpyDeviceToDevice));
+    HIP_CHECK(hipFree(s.bak));
+  }
+  HIP_CHECK(hipMemcpy(d.flags, flags_bak, sizeof(flags_bak), hipMemcpyHostToDevice));
+  return ms / reps;
+}
+
+// Diagnostic: workgroup phase stamps of the last launches (count <= kGrid * 16); false when built without OSQP_HIP_KTRACE.
+bool ktrace_read(Dev &d, unsigned long long *out, int count) {
+#ifdef OSQP_HIP_KTRACE
+  HIP_CHECK(hipSetDevice(d.device));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  if (count > kGrid * kTraceSlots) count = kGrid * kTraceSlots;
+  HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ktrace), sizeof(unsigned long long) * count));
+  return true;
+#else
+  (void)d; (void)out; (void)count;
+  return false;
+#endif
+}
+
+
+}  // namespace be
+}  // namespace osqp_hip

@@ -1,0 +1,348 @@
+// woodbury_hip.hip -- Woodbury-corrected Jacobi preconditioner for the dense rows of A (backend.h DevWb): the small form
+// (r <= 128 rows, S inverted on the host) and the device-factorised form (r <= 16384: one fp64 GEMM + Cholesky + inverse through rocBLAS / rocSOLVER,
+// loaded on demand).  Split out of backend_hip.hip in round 4.
+#include <rocblas/rocblas.h>          // types and prototypes only: the libraries are dlopen()ed (dense_libs)
+#include <rocsolver/rocsolver.h>
+#include <dlfcn.h>
+#include <initializer_list>
+#include <mutex>
+#include "hip_common.h"
+
+namespace osqp_hip {
+namespace be {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- Woodbury preconditioner (backend.h DevWb)
+__global__ __launch_bounds__(kBlock) void k_wb_gather(Dev d) {
+  const DevWb &w = d.wb;
+  const int stride = gridDim.x * kBlock;
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < w.AL.nnz; k += stride) w.AL.val[k] = d.A.val[w.al_src[k]];
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < w.ALT.nnz; k += stride) w.ALT.val[k] = d.A.val[w.alt_src[k]];
+  for (int a = 0; a < w.r; a++)                                            // dense transpose (pattern fixed: the other entries stay zero)
+    for (int k = w.AL.rowptr[a] + blockIdx.x * kBlock + threadIdx.x; k < w.AL.rowptr[a + 1]; k += stride) w.WT[(size_t)w.AL.col[k] * w.r + a] = d.A.val[w.al_src[k]];
+}
+// D0 = B_jj + sum over the SHORT rows of rho_i A_ij^2
+struct GPrecShort { const double *rho; const unsigned char *islong; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = (c >= n && !islong[c - n]) ? rho[c - n] * a * a : 0.0; } };
+__global__ __launch_bounds__(kBlock) void k_wb_diag(Dev d) {
+  __shared__ StreamLds<1> lds;
+  GPrecShort g{d.rho, d.wb.islong, d.n};
+  EPrec e{{}, d.B.val, d.Bdiag, d.wb.Dinv0};
+  process_rows<1>(d.B, g, e, lds);
+}
+// S_ab = sum_j A_L[a,j] A_L[b,j] / D0_j + (a == b) / rho_a : workgroup a, thread (slice s, b); column j of A_L is contiguous in WT.
+// The j loop is split over kWbSlices slices of the workgroup (j = s mod kWbSlices), four independent loads in flight per step, and the
+// slices are summed in index order (deterministic).  (r03: one thread per (a, b) walked all n columns with one dependent load chain --
+// 3.3 ms per rho update on the portfolio QP, a fifth of its solve.)
+constexpr int kWbSlices = 8;
+__global__ __launch_bounds__(kWbMaxRows * kWbSlices) void k_wb_S(Dev d) {
+  const DevWb &w = d.wb;
+  __shared__ double part[kWbSlices][kWbMaxRows];
+  const int a = blockIdx.x, b = threadIdx.x & (kWbMaxRows - 1), s = threadIdx.x / kWbMaxRows, r = w.r, n = d.n;
+  const int bb = b < r ? b : 0;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+  int j = s;
+  for (; j + 3 * kWbSlices < n; j += 4 * kWbSlices) {
+    const size_t o0 = (size_t)j * r, o1 = (size_t)(j + kWbSlices) * r, o2 = (size_t)(j + 2 * kWbSlices) * r, o3 = (size_t)(j + 3 * kWbSlices) * r;
+    const double a0 = w.WT[o0 + a], a1 = w.WT[o1 + a], a2 = w.WT[o2 + a], a3 = w.WT[o3 + a];      // (workgroup-uniform)
+    const double b0 = w.WT[o0 + bb], b1 = w.WT[o1 + bb], b2 = w.WT[o2 + bb], b3 = w.WT[o3 + bb];
+    const double d0 = w.Dinv0[j], d1 = w.Dinv0[j + kWbSlices], d2 = w.Dinv0[j + 2 * kWbSlices], d3 = w.Dinv0[j + 3 * kWbSlices];
+    acc0 += a0 * d0 * b0; acc1 += a1 * d1 * b1; acc2 += a2 * d2 * b2; acc3 += a3 * d3 * b3;
+  }
+  for (; j < n; j += kWbSlices) acc0 += w.WT[(size_t)j * r + a] * w.Dinv0[j] * w.WT[(size_t)j * r + bb];
+  part[s][b] = (acc0 + acc1) + (acc2 + acc3);
+  __syncthreads();
+  if (s == 0 && b < r) {
+    double acc = 0.0;
+    for (int q = 0; q < kWbSlices; q++) acc += part[q][b];
+    if (a == b) acc += d.rho_inv[w.rows[a]];
+    w.S[(size_t)a * r + b] = acc;
+  }
+}
+struct GDr { const double *Dinv0, *r; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * Dinv0[c] * r[c]; } };
+__global__ __launch_bounds__(kBlock) void k_wb_p1(Dev d) {                 // g = A_L (D0^-1 r)
+  __shared__ StreamLds<1> lds;
+  if (d.flags[F_DONE]) return;
+  GDr g{d.wb.Dinv0, d.r};
+  EStore e{{}, d.wb.g};
+  process_rows<1>(d.wb.AL, g, e, lds);
+}
+__global__ __launch_bounds__(kWbMaxRows) void k_wb_p2(Dev d) {             // h = S^-1 g
+  const DevWb &w = d.wb;
+  if (d.flags[F_DONE]) return;
+  __shared__ double sg[kWbMaxRows];
+  const int a = threadIdx.x, r = w.r;
+  if (a < r) sg[a] = w.g[a];
+  __syncthreads();
+  if (a >= r) return;
+  double acc = 0.0;
+  for (int b = 0; b < r; b++) acc += w.Sinv[(size_t)a * r + b] * sg[b];
+  w.h[a] = acc;
+}
+struct EWb3 {
+  const double *Dinv0, *r; double *uu; double *xs;       // xs != nullptr: the direct mode -- u = K^-1 r_0 is added to x~ right here
+  double g = 0, rn = 0, pr = 0, pd = 0, px = 0;
+  __device__ __forceinline__ void prefetch(int j) { pr = r[j]; pd = Dinv0[j]; if (xs) px = xs[j]; }
+  __device__ __forceinline__ void operator()(int j, const double (&s)[1]) {
+    const double u = pd * (pr - s[0]);
+    uu[j] = u; g += pr * u; rn = nanmax(rn, fabs(pr));
+    if (xs) xs[j] = px + u;
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_wb_direct(Dev d) {             // exact mode: x~ += u (u = K^-1 r_0); the PCG statistics see one iteration
+  const int stride = gridDim.x * kBlock;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) d.xs[j] += d.uu[j];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = 1; }
+}
+// direct != 0 (exact mode, M = K): x~ = x_g + u in the same pass, and the PCG statistics see one iteration -- the flag is written by workgroup 0
+// at its END and not read by this launch (a workgroup that starts late must not take it for the previous solve's)
+__global__ __launch_bounds__(kBlock) void k_wb_p3(Dev d, int parity, int direct) {     // u = D0^-1 (r - A_L' h); partials gamma = <r, u>, ||r||_inf
+  __shared__ StreamLds<1> lds;
+  if (!direct && d.flags[F_DONE]) return;
+  GVec g{d.wb.h};
+  EWb3 e{d.wb.Dinv0, d.r, d.uu, direct ? d.xs : nullptr};
+  process_rows<1>(d.wb.ALT, g, e, lds);
+  __syncthreads();
+  double G = e.g, RN = e.rn;
+  block_sum_max(G, RN, lds.red);
+  put_partial(d.part, SL_GAMMA0 + parity, G); put_partial(d.part, SL_RN0 + parity, RN);
+  if (direct && blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = 1; }
+}
+
+// ---- many long rows (DevWb::large): dense S on the device
+// W[a][colmap[j]] = A_L[a, j] / sqrt(D0_j): workgroups stride over the long rows (the pattern is fixed, the other entries stay zero)
+__global__ __launch_bounds__(kBlock) void k_wb_fillW(Dev d) {
+  const DevWb &w = d.wb;
+  for (int a = blockIdx.x; a < w.r; a += gridDim.x)
+    for (int k = w.AL.rowptr[a] + threadIdx.x; k < w.AL.rowptr[a + 1]; k += kBlock) {
+      const int j = w.AL.col[k];
+      w.W[(size_t)a * w.ct + w.colmap[j]] = w.AL.val[k] * sqrt(w.Dinv0[j]);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_wb_gather_large(Dev d) {
+  const DevWb &w = d.wb;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < (size_t)w.AL.nnz; k += stride) w.AL.val[k] = d.A.val[w.al_src[k]];
+  for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < (size_t)w.ALT.nnz; k += stride) w.ALT.val[k] = d.A.val[w.alt_src[k]];
+}
+__global__ __launch_bounds__(kBlock) void k_wb_adddiag(Dev d) {
+  const DevWb &w = d.wb;
+  for (int a = blockIdx.x * kBlock + threadIdx.x; a < w.r; a += gridDim.x * kBlock) w.S[(size_t)a * w.r + a] += d.rho_inv[w.rows[a]];
+}
+// the factorisation works on one triangle (entries M[c * r + q], q >= c): mirror it
+__global__ __launch_bounds__(kBlock) void k_wb_symm(double *M, int r) {
+  for (int c = blockIdx.x; c < r; c += gridDim.x)
+    for (int q = c + 1 + threadIdx.x; q < r; q += kBlock) M[(size_t)q * r + c] = M[(size_t)c * r + q];
+}
+// out = M in  (M: r x r, symmetric, full storage): one workgroup per row, 8 r^2 bytes per launch -- HBM-bound
+__global__ __launch_bounds__(kBlock) void k_wb_gemv(const double *M, const double *in, double *out, int r, const int *done) {
+  __shared__ double red[2 * kWaves];
+  if (done && *done) return;
+  for (int a = blockIdx.x; a < r; a += gridDim.x) {
+    const double *row = M + (size_t)a * r;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int k = threadIdx.x;
+    for (; k + 3 * kBlock < r; k += 4 * kBlock) {
+      const double m0 = row[k], m1 = row[k + kBlock], m2 = row[k + 2 * kBlock], m3 = row[k + 3 * kBlock];
+      acc0 += m0 * in[k]; acc1 += m1 * in[k + kBlock]; acc2 += m2 * in[k + 2 * kBlock]; acc3 += m3 * in[k + 3 * kBlock];
+    }
+    for (; k < r; k += kBlock) acc0 += row[k] * in[k];
+    const double tot = block_sum((acc0 + acc1) + (acc2 + acc3), red);
+    if (threadIdx.x == 0) out[a] = tot;
+  }
+}
+// probe of the direct mode: v, rho .* (A v), comparison of M^-1 K v with v
+__global__ __launch_bounds__(kBlock) void k_wb_probe_init(Dev d) {
+  const DevWb &w = d.wb;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += gridDim.x * kBlock) {
+    const double v = 0.5 + (double)((((unsigned)j * 2654435761u) >> 8) & 0xffffu) / 65536.0;
+    w.pv[j] = v; w.pv[(size_t)d.n + d.m + j] = v;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_wb_probe_rho(Dev d) {
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += gridDim.x * kBlock) d.wb.pv[(size_t)d.n + i] *= d.rho[i];
+}
+__global__ __launch_bounds__(kBlock) void k_wb_maxdiff(const double *a, const double *b, int cnt, double *out) {      // one workgroup: out[0] = max |a - b|, out[1] = max |b|
+  __shared__ double red[2 * kWaves];
+  double e = 0.0, s = 0.0;
+  for (int j = threadIdx.x; j < cnt; j += kBlock) { e = nanmax(e, fabs(a[j] - b[j])); s = nanmax(s, fabs(b[j])); }
+  block_max2(e, s, red);
+  if (threadIdx.x == 0) { out[0] = e; out[1] = s; }
+}
+__global__ void k_wb_seq(double *g, int r) { for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < r; a += gridDim.x * blockDim.x) g[a] = 1.0 + 0.25 * (a % 7); }
+
+}  // namespace
+
+// ---- dense solver libraries, loaded on first use (rocBLAS: fp64 GEMM; rocSOLVER: Cholesky factorisation and inverse).  Nothing of the
+// engine links against them: where they are missing the large-rank mode is off and such problems keep the Jacobi preconditioner.
+namespace {
+struct DenseLibs {
+  bool tried = false, ok = false;
+  void *hblas = nullptr, *hsolver = nullptr;
+  rocblas_status (*create)(rocblas_handle *) = nullptr;
+  rocblas_status (*destroy)(rocblas_handle) = nullptr;
+  rocblas_status (*set_stream)(rocblas_handle, hipStream_t) = nullptr;
+  rocblas_status (*dgemm)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const double *, const double *, rocblas_int,
+                          const double *, rocblas_int, const double *, double *, rocblas_int) = nullptr;
+  rocblas_status (*dpotrf)(rocblas_handle, const rocblas_fill, const rocblas_int, double *, const rocblas_int, rocblas_int *) = nullptr;
+  rocblas_status (*dpotri)(rocblas_handle, const rocblas_fill, const rocblas_int, double *, const rocblas_int, rocblas_int *) = nullptr;
+};
+DenseLibs &dense_libs() {
+  static DenseLibs L;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (L.tried) return L;
+  L.tried = true;
+  auto open_any = [](std::initializer_list<const char *> names) -> void * { for (const char *nm : names) if (void *h = dlopen(nm, RTLD_NOW | RTLD_LOCAL)) return h; return nullptr; };
+  L.hblas = open_any({"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so"});
+  L.hsolver = open_any({"librocsolver.so.0", "librocsolver.so", "/opt/rocm/lib/librocsolver.so"});
+  if (!L.hblas || !L.hsolver) return L;
+  auto sym = [](void *h, const char *nm) { return dlsym(h, nm); };
+  L.create = reinterpret_cast<decltype(L.create)>(sym(L.hblas, "rocblas_create_handle"));
+  L.destroy = reinterpret_cast<decltype(L.destroy)>(sym(L.hblas, "rocblas_destroy_handle"));
+  L.set_stream = reinterpret_cast<decltype(L.set_stream)>(sym(L.hblas, "rocblas_set_stream"));
+  L.dgemm = reinterpret_cast<decltype(L.dgemm)>(sym(L.hblas, "rocblas_dgemm"));
+  L.dpotrf = reinterpret_cast<decltype(L.dpotrf)>(sym(L.hsolver, "rocsolver_dpotrf"));
+  L.dpotri = reinterpret_cast<decltype(L.dpotri)>(sym(L.hsolver, "rocsolver_dpotri"));
+  L.ok = L.create && L.destroy && L.set_stream && L.dgemm && L.dpotrf && L.dpotri;
+  return L;
+}
+}  // namespace
+
+namespace {
+
+}  // namespace
+
+void wb_release_blas(void *handle) { if (handle && dense_libs().ok) (void)dense_libs().destroy(static_cast<rocblas_handle>(handle)); }
+bool wb_supported() { return true; }
+void wb_refresh(Dev &d) {
+  if (!d.wb.on) return;
+  HIP_CHECK(hipSetDevice(d.device));
+  if (d.wb.large) LAUNCH(k_wb_gather_large, d, d); else LAUNCH(k_wb_gather, d, d);
+}
+void wb_direct(Dev &d) { LAUNCH(k_wb_direct, d, d); }
+void wb_apply(Dev &d, int parity, int direct) {
+  LAUNCH(k_wb_p1, d, d);
+  if (d.wb.large) hipLaunchKernelGGL(k_wb_gemv, dim3(std::min(d.wb.r, 8 * kGrid)), dim3(kBlock), 0, st(d), d.wb.Sinv, d.wb.g, d.wb.h, d.wb.r, d.flags + F_DONE);
+  else hipLaunchKernelGGL(k_wb_p2, dim3(1), dim3(kWbMaxRows), 0, st(d), d);
+  LAUNCH(k_wb_p3, d, d, parity, direct);
+}
+
+bool wb_large_supported() { return dense_libs().ok; }
+
+// D0, W, S = W W' + 1 / rho_L, S^-1 -- all on the device (r up to kWbLargeMax); then the two numerical checks
+static void wb_factor_large(Dev &d) {
+  DevWb &w = d.wb;
+  DenseLibs &L = dense_libs();
+  Impl &p = im(d);
+  if (!L.ok) throw DeviceError("osqp_hip: the dense solver libraries are not available");
+  if (!p.blas) {
+    rocblas_handle h = nullptr;
+    if (L.create(&h) != rocblas_status_success) throw DeviceError("osqp_hip: rocblas_create_handle failed");
+    p.blas = h;
+  }
+  rocblas_handle h = static_cast<rocblas_handle>(p.blas);
+  if (L.set_stream(h, st(d)) != rocblas_status_success) throw DeviceError("osqp_hip: rocblas_set_stream failed");
+  const int r = w.r, ct = w.ct;
+  const bool log = w.log != 0;
+  double tlap[6] = {0, 0, 0, 0, 0, 0};
+  auto lap = [&](int k) { if (log) { HIP_CHECK(hipStreamSynchronize(st(d))); tlap[k] = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); } };
+  lap(0);
+  LAUNCH(k_wb_diag, d, d);
+  LAUNCH(k_wb_fillW, d, d);
+  lap(1);
+  const double one = 1.0, zero = 0.0;
+  // W is r x ct row-major = ct x r column-major (ld ct): S = W' W in the library's convention
+  if (L.dgemm(h, rocblas_operation_transpose, rocblas_operation_none, r, r, ct, &one, w.W, ct, w.W, ct, &zero, w.S, r) != rocblas_status_success)
+    throw DeviceError("osqp_hip: rocblas_dgemm failed");
+  LAUNCH(k_wb_adddiag, d, d);
+  lap(2);
+  HIP_CHECK(hipMemcpyAsync(w.Sinv, w.S, sizeof(double) * (size_t)r * r, hipMemcpyDeviceToDevice, st(d)));
+  if (L.dpotrf(h, rocblas_fill_lower, r, w.Sinv, r, w.info) != rocblas_status_success) throw DeviceError("osqp_hip: rocsolver_dpotrf failed");
+  lap(3);
+  if (L.dpotri(h, rocblas_fill_lower, r, w.Sinv, r, w.info + 1) != rocblas_status_success) throw DeviceError("osqp_hip: rocsolver_dpotri failed");
+  lap(4);
+  hipLaunchKernelGGL(k_wb_symm, dim3(std::min(r, 8 * kGrid)), dim3(kBlock), 0, st(d), w.Sinv, r);
+  // S^-1 against S on a fixed vector:  S (S^-1 g) = g
+  double *out = w.pv + (size_t)d.n + d.m + d.n;                 // [4 + r] scratch behind the probe vectors
+  hipLaunchKernelGGL(k_wb_seq, dim3(64), dim3(256), 0, st(d), w.g, r);
+  hipLaunchKernelGGL(k_wb_gemv, dim3(std::min(r, 8 * kGrid)), dim3(kBlock), 0, st(d), w.Sinv, w.g, w.h, r, nullptr);
+  hipLaunchKernelGGL(k_wb_gemv, dim3(std::min(r, 8 * kGrid)), dim3(kBlock), 0, st(d), w.S, w.h, out + 4, r, nullptr);
+  hipLaunchKernelGGL(k_wb_maxdiff, dim3(1), dim3(kBlock), 0, st(d), out + 4, w.g, r, out);
+  // M^-1 (K v) = v ?   K v = B [v; rho .* (A v)]
+  if (w.probe) {
+    LAUNCH(k_wb_probe_init, d, d);
+    LAUNCH(k_test_spmv, d, d.A, w.pv, w.pv + d.n);
+    LAUNCH(k_wb_probe_rho, d, d);
+    LAUNCH(k_test_spmv, d, d.B, w.pv, d.r);
+    HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, 0, sizeof(int), st(d)));
+    wb_apply(d, 0);
+    hipLaunchKernelGGL(k_wb_maxdiff, dim3(1), dim3(kBlock), 0, st(d), d.uu, w.pv + (size_t)d.n + d.m, d.n, out + 2);
+  }
+  int info[2] = {0, 0};
+  double chk[4] = {0, 1, 0, 1};
+  HIP_CHECK(hipMemcpyAsync(info, w.info, sizeof(info), hipMemcpyDeviceToHost, st(d)));
+  HIP_CHECK(hipMemcpyAsync(chk, out, sizeof(double) * (w.probe ? 4 : 2), hipMemcpyDeviceToHost, st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  if (info[0] != 0 || info[1] != 0) throw DeviceError("osqp_hip: the Woodbury system of the preconditioner is not positive definite");
+  const bool inv_ok = chk[0] <= 1e-8 * chk[1];
+  w.exact = (w.probe && inv_ok && chk[2] <= w.exact_tol * chk[3]) ? 1 : 0;
+  if (log) {
+    lap(5);
+    std::fprintf(stderr, "osqp_hip woodbury: r %d ct %d  |S S^-1 g - g| %.2e / %.2e   |M^-1 K v - v| %.2e / %.2e   direct %d;  D0 + W %.1f ms, GEMM %.1f ms, Cholesky %.1f ms, inverse %.1f ms, mirror + checks %.1f ms\n",
+                 r, ct, chk[0], chk[1], chk[2], chk[3], w.exact, 1e3 * (tlap[1] - tlap[0]), 1e3 * (tlap[2] - tlap[1]), 1e3 * (tlap[3] - tlap[2]), 1e3 * (tlap[4] - tlap[3]), 1e3 * (tlap[5] - tlap[4]));
+  }
+}
+// D0, S on the device; S^-1 on the host (r <= kWbMaxRows: a Cholesky factorisation of a few thousand entries, once per rho update)
+void wb_factor(Dev &d) {
+  DevWb &w = d.wb;
+  if (w.large) { wb_factor_large(d); return; }
+  const int r = w.r;
+  LAUNCH(k_wb_diag, d, d);
+  hipLaunchKernelGGL(k_wb_S, dim3(r), dim3(kWbMaxRows * kWbSlices), 0, st(d), d);
+  std::vector<double> S((size_t)r * r), L((size_t)r * r, 0.0), Li((size_t)r * r, 0.0), Si((size_t)r * r, 0.0);
+  HIP_CHECK(hipMemcpyAsync(S.data(), w.S, sizeof(double) * S.size(), hipMemcpyDeviceToHost, st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  for (int j = 0; j < r; j++) {                               // S = L L'
+    double dj = S[(size_t)j * r + j];
+    for (int k = 0; k < j; k++) dj -= L[(size_t)j * r + k] * L[(size_t)j * r + k];
+    if (!(dj > 0.0)) throw DeviceError("osqp_hip: the Woodbury system of the preconditioner is not positive definite");
+    const double ljj = std::sqrt(dj);
+    L[(size_t)j * r + j] = ljj;
+    for (int i = j + 1; i < r; i++) {
+      double v = S[(size_t)i * r + j];
+      for (int k = 0; k < j; k++) v -= L[(size_t)i * r + k] * L[(size_t)j * r + k];
+      L[(size_t)i * r + j] = v / ljj;
+    }
+  }
+  for (int c = 0; c < r; c++) {                               // Li = L^-1 (lower triangular), column by column
+    Li[(size_t)c * r + c] = 1.0 / L[(size_t)c * r + c];
+    for (int i = c + 1; i < r; i++) {
+      double v = 0.0;
+      for (int k = c; k < i; k++) v -= L[(size_t)i * r + k] * Li[(size_t)k * r + c];
+      Li[(size_t)i * r + c] = v / L[(size_t)i * r + i];
+    }
+  }
+  for (int a = 0; a < r; a++)                                 // S^-1 = Li' Li
+    for (int b = 0; b <= a; b++) {
+      double v = 0.0;
+      for (int k = a; k < r; k++) v += Li[(size_t)k * r + a] * Li[(size_t)k * r + b];
+      Si[(size_t)a * r + b] = Si[(size_t)b * r + a] = v;
+    }
+  if (w.exact) {                                              // the direct mode trusts S^-1: || S S^-1 - I ||_max must be at rounding level
+    double err = 0.0;
+    for (int a = 0; a < r; a++)
+      for (int b = 0; b < r; b++) {
+        double v = a == b ? -1.0 : 0.0;
+        for (int k = 0; k < r; k++) v += S[(size_t)a * r + k] * Si[(size_t)k * r + b];
+        err = std::max(err, std::fabs(v));
+      }
+    if (!(err < 1e-9)) w.exact = 0;
+  }
+  HIP_CHECK(hipMemcpyAsync(w.Sinv, Si.data(), sizeof(double) * Si.size(), hipMemcpyHostToDevice, st(d)));
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  wbx_factor(d);                                              // (two-launch direct mode: S^-1 A_L per column block)
+}
+
+}  // namespace be
+}  // namespace osqp_hip
