@@ -180,3 +180,22 @@ def test_reordered_handle_device_pointer_updates_equal_host_pointer_updates():
     xo, yo, io = o.solve()
     assert io.status_val == SOLVED
     assert np.abs(res[0].x - xo).max() <= 2e-5 * (1 + np.abs(xo).max()) and np.abs(res[0].y - yo).max() <= 2e-5 * (1 + np.abs(yo).max())
+
+
+@pytest.mark.gpu
+def test_polish_and_settings_updates_on_a_forced_reordered_handle(monkeypatch):
+    """polish (the refinement recurrence on the PCG path), update_settings and update_rho on a permuted handle: same polished solution as the
+    un-permuted handle (both polish to rounding-level residuals of the same reduced KKT system)."""
+    monkeypatch.setenv('OSQP_HIP_SMALL_DIRECT', '0')
+    P, q, A, l, u = problems.banded_qp(2000, window=40)
+    out = []
+    for mode in ('0', '2'):
+        monkeypatch.setenv('OSQP_HIP_REORDER', mode)
+        m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, eps_abs=1e-4, eps_rel=1e-4, max_iter=20000, verbose=False, polishing=True, adaptive_rho_interval=50)
+        assert bool(m._solver.hip_stats()['reordered']) == (mode == '2')
+        r = m.solve()
+        m.update_settings(rho=0.05, alpha=1.5); r2 = m.solve()
+        out.append((r, r2))
+    for a, b in zip(out[0], out[1]):
+        assert a.info.status_val == b.info.status_val == S.OSQP_SOLVED and a.info.status_polish == b.info.status_polish == 1
+        assert np.abs(a.x - b.x).max() <= 1e-8 * (1 + np.abs(a.x).max()) and np.abs(a.y - b.y).max() <= 1e-7 * (1 + np.abs(a.y).max())
