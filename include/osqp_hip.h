@@ -332,6 +332,8 @@ typedef struct {
                                  identity misses at 5k x 10k by a factor 4-40)                                                        [setup] */
   OSQPInt woodbury_fused;     /* the Woodbury direct mode as TWO launches per ADMM iteration where it applies (P diagonal, one-entry short rows,
                                  n <= 16384; wbdirect_hip.hip) instead of five                                                      [setup] */
+  OSQPInt debug_fail_refactor; /* TEST HOOK: that many of the next device-side inversions of the Woodbury system report "inaccurate" (exercises the
+                                 hand-over of a device-driven direct-mode solve to the host); 0 in production */
   OSQPInt reorder;            /* 1 (default): when the one-launch PCG form does not apply to the matrices as numbered by the caller, look for a
                                  bandwidth-reducing permutation of variables and constraints under which it does, and work on the permuted problem
                                  (every vector crossing this API keeps the caller's numbering); 0: never; 2: always permute (tests)      [setup] */

@@ -135,6 +135,7 @@ struct DevWb {
   double *W = nullptr;           // [r][ct] rows of A_L scaled by D0^-1/2 (zero where A_L has no entry)
   double *pv = nullptr;          // [n + m + n] probe vector v, rho .* (A v), v again (the reference M^-1 K v is compared with)
   int *info = nullptr;           // [2] status words of the factorisation / inversion
+  int *dbg = nullptr;            // [1] test hook: upcoming device-side inversions to report as failed (OSQPHipPolicy::debug_fail_refactor)
   int exact = 0;                 // K0 is diagonal (P diagonal, every short row of A has one entry): M = K, and M^-1 r_0 IS the solve -- no PCG iteration
                                  // (Engine::run_chunk: KB, the three kernels of M^-1, k_wb_direct, KA); cleared when S^-1 fails its accuracy check
   DevWbx x;                      // exact mode in two launches per ADMM iteration (x.on)
@@ -304,13 +305,16 @@ int slot_seq(Dev &d);                      // slots executed since slot_begin (c
 // launches one ADMM iteration with `pcg` PCG iterations needs in the slot form (a slot_pair() is two of them):
 //   two-kernel form  2 (pcg + 2)   KB, K1, pcg x (K2F, K1F), the K2F that detects convergence, KA
 //   F1 form          pcg + 3       KB, F_0, F_1 .. F_pcg, KA (run by the launch whose scalar fold detects convergence)
-inline double slot_launches(const Dev &d, double pcg) { return d.f1.on ? pcg + 3.0 : 2.0 * (pcg + 2.0); }
+//   Woodbury direct mode in two launches (wbdirect_hip.hip): 2 per iteration + one closing pair per chunk
+inline double slot_launches(const Dev &d, double pcg) { return (d.wb.on && d.wb.exact && d.wb.x.on) ? 2.16 : (d.f1.on ? pcg + 3.0 : 2.0 * (pcg + 2.0)); }
 void f1_refresh(Dev &d);                   // f1.pval <- B.val (no-op without a plan)
 bool wb_supported();
 bool wbx_supported();                      // the two-launch direct mode exists (false: the host simulator)
 void wbx_init(Dev &d);                     // once per handle, after the plan is uploaded (LDS attribute of its kernels on d.device)
 void wbx_refresh(Dev &d);                  // tiles / one-entry-row values <- A.val
-void wbx_factor(Dev &d);                   // tile2 = S^-1 A_L (after S^-1 has changed)
+void wbx_factor(Dev &d, int cond = 0);     // tile2 = S^-1 A_L (after S^-1 has changed); cond: inside a boundary group, only when it updated rho
+void wbx_slot_pair(Dev &d);                // the two launches as a pair of slots (device-side scheduling)
+inline bool wbx_active(const Dev &d) { return d.wb.on && d.wb.exact && d.wb.x.on; }
 void wbx_chunk(Dev &d, int niter);         // niter ADMM iterations: X(rhs), { Y, X } x (niter - 1), Y, X(update): 2 niter + 1 launches on d.stream
 bool wb_large_supported();                 // the dense solver libraries could be loaded                       // Woodbury preconditioner available (false: the host simulator)
 void wb_refresh(Dev &d);                   // wb.AL / ALT / WT values <- A.val (after assembly / equilibration / matrix updates)

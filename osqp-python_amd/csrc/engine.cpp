@@ -138,7 +138,7 @@ void Engine::default_policy(OSQPHipPolicy *p) {
   p->polish_delta_floor = 1e-3; p->polish_pcg_tol = 1e-15; p->woodbury = 1; p->woodbury_direct = 1; p->woodbury_large = 1;
   p->slot_poll = 1; p->poll_low = 6; p->poll_first = 0.8; p->poll_frac = 0.75; p->poll_wait = 0.7;
   p->finish_pairs = 12; p->poll_sleep_us = 30;
-  p->reorder = 1; p->woodbury_fused = 1; p->woodbury_direct_tol = 1e-6;
+  p->reorder = 1; p->woodbury_fused = 1; p->woodbury_direct_tol = 1e-6; p->debug_fail_refactor = 0;
 }
 void Engine::set_default_policy(const OSQPHipPolicy *p) {
   g_default_policy_set = p != nullptr;
@@ -157,6 +157,7 @@ int Engine::set_policy(const OSQPHipPolicy *p) {
   pol_.slots = old.slots; pol_.pcg_fused = old.pcg_fused; pol_.f1 = old.f1; pol_.window = old.window; pol_.woodbury = old.woodbury; pol_.woodbury_direct = old.woodbury_direct; pol_.woodbury_large = old.woodbury_large; pol_.reorder = old.reorder; pol_.woodbury_fused = old.woodbury_fused; pol_.woodbury_direct_tol = old.woodbury_direct_tol;
   if (pol_.graph != old.graph) { use_graph_ = pol_.graph != 0; if (dev_ready_) { be::activate(d_); be::sync(d_); drop_graphs(); } }
   if (dev_ready_) d_.theta = pol_.extrap;
+  if (dev_ready_ && d_.wb.dbg && pol_.debug_fail_refactor != old.debug_fail_refactor) { be::activate(d_); const int v = pol_.debug_fail_refactor; be::h2d(d_, d_.wb.dbg, &v, sizeof(int)); }
   if (dev_ready_ && pol_.rho_eq_factor >= 1.0 && pol_.rho_eq_factor != old.rho_eq_factor) return set_rho_eq_factor(pol_.rho_eq_factor);
   return OSQP_NO_ERROR;
 }
@@ -199,7 +200,7 @@ void Engine::free_all() {
                   d_.dy, d_.xs, d_.xg, d_.xsp, d_.ztg, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.uu2, d_.ms, d_.part, d_.res,
                   d_.scal, d_.flags, d_.slot, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB,
                   d_.wb.AL.rowptr, d_.wb.AL.col, d_.wb.AL.blkdesc, d_.wb.AL.runinfo, d_.wb.AL.val, d_.wb.ALT.rowptr, d_.wb.ALT.col, d_.wb.ALT.blkdesc, d_.wb.ALT.runinfo, d_.wb.ALT.val,
-                  d_.wb.al_src, d_.wb.alt_src, d_.wb.islong, d_.wb.rows, d_.wb.WT, d_.wb.S, d_.wb.Sinv, d_.wb.g, d_.wb.h, d_.wb.Dinv0, d_.wb.colmap, d_.wb.W, d_.wb.pv, d_.wb.info, d_.wb.x.tile, d_.wb.x.tile2, d_.wb.x.partG, d_.wb.x.partZ, d_.wb.x.ls0, d_.wb.x.ls1, d_.wb.x.sc_ptr, d_.wb.x.sc_row, d_.wb.x.sc_src, d_.wb.x.sc_val, d_.wb.x.bjj,
+                  d_.wb.al_src, d_.wb.alt_src, d_.wb.islong, d_.wb.rows, d_.wb.WT, d_.wb.S, d_.wb.Sinv, d_.wb.g, d_.wb.h, d_.wb.Dinv0, d_.wb.colmap, d_.wb.W, d_.wb.pv, d_.wb.info, d_.wb.dbg, d_.wb.x.tile, d_.wb.x.tile2, d_.wb.x.partG, d_.wb.x.partZ, d_.wb.x.ls0, d_.wb.x.ls1, d_.wb.x.sc_ptr, d_.wb.x.sc_row, d_.wb.x.sc_src, d_.wb.x.sc_val, d_.wb.x.bjj,
                   d_.ctl, d_.f1.blk, d_.f1.ent, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.va, d_pc_, d_pr_};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   be::destroy(d_);
@@ -656,8 +657,10 @@ void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj
   if (large) {
     w.large = 1; w.ct = ct; w.colmap = up_i(colmap);
     w.W = dev_vec<double>(d_, (size_t)r * ct);                  // (zero-filled by the allocator: only the pattern's positions are ever written)
-    w.pv = dev_vec<double>(d_, (size_t)n + m + n + 4 + r); w.info = dev_vec<int>(d_, 2);
+    w.pv = dev_vec<double>(d_, (size_t)n + m + n + 4 + r);
   } else w.WT = dev_vec<double>(d_, (size_t)n * r);
+  w.info = dev_vec<int>(d_, 2); w.dbg = dev_vec<int>(d_, 1);
+  if (pol_.debug_fail_refactor > 0) { const int v = pol_.debug_fail_refactor; be::h2d(d_, w.dbg, &v, sizeof(int)); }
   w.on = 1;
   // K0 diagonal <=> P has diagonal entries only and every short row of A has exactly one entry: then M = K (backend.h DevWb::exact)
   bool diag = pol_.woodbury_direct != 0;
@@ -1451,11 +1454,12 @@ void Engine::admm_core(double t0, double *res) {
   have_tol_ = false;
   ctl_next_chunk(c);
   if (settings.verbose) std::printf("iter   objective    prim res   dual res   rho        cg   time\n");
-  const bool slots = use_slots_ && be::slots_supported(d_);
-  const bool device_driven = slots && pol_.device_driven && !settings.verbose && be::ctl_supported(d_);
   int flags[F_COUNT] = {0};
   for (;;) {
     int st;
+    // (evaluated at every boundary: the Woodbury direct mode may leave the slot form in the middle of a solve -- NEED_REFACTOR below)
+    const bool slots = use_slots_ && be::slots_supported(d_);
+    const bool device_driven = slots && pol_.device_driven && !settings.verbose && be::ctl_supported(d_);
     const bool first_chunk = c.iter == 0;
     if (first_chunk || !device_driven) {
       be::set_pcg_tol(d_, c.tol_rel, ctl_chunk_tol_abs(c));
@@ -1515,6 +1519,17 @@ void Engine::admm_core(double t0, double *res) {
       else if (os == OSQP_PRIMAL_INFEASIBLE || os == OSQP_PRIMAL_INFEASIBLE_INACCURATE) info.obj_val = OSQP_INFTY;
       else if (os == OSQP_DUAL_INFEASIBLE || os == OSQP_DUAL_INFEASIBLE_INACCURATE) info.obj_val = -OSQP_INFTY;
       break;
+    }
+    if (st == CTL_NEED_HOST && (c.need & NEED_REFACTOR)) {
+      // Woodbury direct mode, device-driven: at the rho update of the last boundary the device-side inversion of S missed the accuracy the
+      // direct mode needs (backend k_wb_invert; the chunk it had begun was cancelled).  The solve continues on the host-synchronous path
+      // with the corrected preconditioner inside the PCG: rho is applied again (this time through the host's bookkeeping).
+      c.need &= ~NEED_REFACTOR; c.status = CTL_RUNNING;
+      d_.wb.exact = 0;
+      be::sync(d_); drop_graphs();
+      apply_rho(c.rho_bar);
+      c.rho_flag = 0;
+      continue;
     }
     if (st == CTL_NEED_HOST) {                            // max_iter without convergence: the approximate-tolerance pass (:1264-1266)
       if (!check_termination(res, true)) set_status(OSQP_MAX_ITER_REACHED);

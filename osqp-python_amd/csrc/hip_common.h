@@ -531,6 +531,7 @@ __device__ __forceinline__ void slot_write(int *w, const SlotState &s) {
 
 // ---- functions one unit defines and another calls
 void wb_factor(Dev &d);                    // woodbury_hip.hip: D0, S, S^-1 for the current rho (called by precond)
+void wb_factor_device(Dev &d, int cond);   // woodbury_hip.hip: the small form's re-factorisation as launches only (cond: inside a boundary group)
 void wb_release_blas(void *handle);        // woodbury_hip.hip: destroy the rocBLAS handle a Dev's Impl holds (called by destroy)
 
 }  // namespace be

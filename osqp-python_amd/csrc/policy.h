@@ -32,7 +32,7 @@ constexpr double kPolCgTolAbsMin = 1e-13;
 
 enum CtlStatus { CTL_RUNNING = 0, CTL_DONE = 1, CTL_NEED_HOST = 2 };
 // why a boundary was handed to the host
-enum CtlNeed { NEED_NONE = 0, NEED_PINF = 1, NEED_DINF = 2, NEED_MAXITER = 4 };
+enum CtlNeed { NEED_NONE = 0, NEED_PINF = 1, NEED_DINF = 2, NEED_MAXITER = 4, NEED_REFACTOR = 8 /* Woodbury direct mode: the device-side inversion failed its check */ };
 
 struct Ctl {
   // ---- settings snapshot (constant during a solve)

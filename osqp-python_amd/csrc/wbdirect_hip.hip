@@ -25,8 +25,7 @@
 #include <cstdio>
 #include <stdexcept>
 
-#include "../../include/osqp_hip.h"
-#include "backend.h"
+#include "hip_common.h"              // slot record layout (SlotState, slot_read / slot_write), HIP_CHECK
 
 namespace osqp_hip {
 namespace be {
@@ -142,9 +141,7 @@ __device__ __forceinline__ double row_update(const Dev &d, int i, double ztil, c
 
 // X.  upd: finish an ADMM iteration (needs Y's partials);  rhs: start the next one
 template <bool UPD, bool RHS>
-__global__ __launch_bounds__(kT) void k_wbx_x(Dev d) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  XLds &L = *reinterpret_cast<XLds *>(smem);
+__device__ __forceinline__ void wbx_x_body(const Dev &d, XLds &L) {
   const DevWbx &x = d.wb.x;
   const int tid = threadIdx.x, r = d.wb.r, G = x.G, j0 = blockIdx.x * kC, n = d.n;
   TileRegs tr;
@@ -215,10 +212,14 @@ __global__ __launch_bounds__(kT) void k_wbx_x(Dev d) {
   row_pass(L, x.partG);
 }
 
-// Y.  (A_L' S^-1 g is taken as (S^-1 A_L)' g with the second tile: no r x r product, no S^-1 traffic on the iteration's critical path)
-__global__ __launch_bounds__(kT) void k_wbx_y(Dev d) {
+template <bool UPD, bool RHS>
+__global__ __launch_bounds__(kT) void k_wbx_x(Dev d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  YLds &L = *reinterpret_cast<YLds *>(smem);
+  wbx_x_body<UPD, RHS>(d, *reinterpret_cast<XLds *>(smem));
+}
+
+// Y.  (A_L' S^-1 g is taken as (S^-1 A_L)' g with the second tile: no r x r product, no S^-1 traffic on the iteration's critical path)
+__device__ __forceinline__ void wbx_y_body(const Dev &d, YLds &L) {
   const DevWbx &x = d.wb.x;
   const int tid = threadIdx.x, r = d.wb.r, G = x.G, j0 = blockIdx.x * kC, n = d.n;
   const TileRegs tr = tile_issue(x.tile, r), tr2 = tile_issue(x.tile2, r);
@@ -247,9 +248,44 @@ __global__ __launch_bounds__(kT) void k_wbx_y(Dev d) {
   }
 }
 
-// tile2 <- S^-1 tile (per column block; after every inversion of S): thread (c, quarter q) forms the rows a = q mod 4 of its column
-__global__ __launch_bounds__(kT) void k_wbx_t2(Dev d) {
+__global__ __launch_bounds__(kT) void k_wbx_y(Dev d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  wbx_y_body(d, *reinterpret_cast<YLds *>(smem));
+}
+
+// Slot forms (device-side scheduling, pcg_hip.hip "slot kernels"): the same two launches as a pair of slots.  X reads record A and
+// writes record B, Y the other way round; P_KB = an iteration may start (right-hand side), P_K1 = Y is due, P_KA = Y has run, the
+// update is pending.  A chunk of N iterations takes N + 1 pairs (the last X only updates, the last Y passes the record on); launches
+// behind a finished chunk idle, every launch counts itself in SR_SEQ -- what is computed does not depend on how many are enqueued.
+__global__ __launch_bounds__(kT) void k_wbx_slot_x(Dev d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  XLds &L = *reinterpret_cast<XLds *>(smem);
+  SlotState st = slot_read(d.slot);
+  int *W = d.slot + SR_WORDS;
+  const bool upd = st.ph == P_KA;
+  const int admm_after = st.admm + (upd ? 1 : 0);
+  const bool rhs = (upd || st.ph == P_KB) && admm_after < st.target;
+  if (upd && rhs) wbx_x_body<true, true>(d, L);
+  else if (upd) wbx_x_body<true, false>(d, L);
+  else if (rhs) wbx_x_body<false, true>(d, L);
+  if (upd) {
+    if (d.ctl && admm_after >= st.target && blockIdx.x == 0 && threadIdx.x == 0) d.ctl->chunk_done = 1;      // (read by LATER launches)
+    st.admm = admm_after; st.used = 1; st.conv = 1;
+  }
+  st.ph = rhs ? P_K1 : (st.ph == P_IDLE ? P_IDLE : P_KB);      // (P_KB with admm >= target: the chunk is over, the next X idles)
+  slot_write(W, st);
+}
+__global__ __launch_bounds__(kT) void k_wbx_slot_y(Dev d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SlotState st = slot_read(d.slot + SR_WORDS);
+  if (st.ph == P_K1) { wbx_y_body(d, *reinterpret_cast<YLds *>(smem)); st.ph = P_KA; }
+  slot_write(d.slot, st);
+}
+
+// tile2 <- S^-1 tile (per column block; after every inversion of S): thread (c, quarter q) forms the rows a = q mod 4 of its column
+__global__ __launch_bounds__(kT) void k_wbx_t2(Dev d, int cond) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (cond && !d.ctl->rho_flag) return;
   XLds &L = *reinterpret_cast<XLds *>(smem);
   const DevWbx &x = d.wb.x;
   const int r = d.wb.r, c = threadIdx.x & (kC - 1), q = threadIdx.x >> 6;
@@ -290,10 +326,16 @@ void wbx_refresh(Dev &d) {
   WBX_CHECK(hipSetDevice(d.device));
   hipLaunchKernelGGL(k_wbx_fill, dim3(256), dim3(kT), 0, static_cast<hipStream_t>(d.stream), d);
 }
-void wbx_factor(Dev &d) {                      // after S^-1 has changed (rho update): tile2 = S^-1 A_L
+void wbx_factor(Dev &d, int cond) {            // after S^-1 has changed (rho update): tile2 = S^-1 A_L;  cond: only when the boundary group updated rho
   if (!d.wb.on || !d.wb.x.on) return;
   WBX_CHECK(hipSetDevice(d.device));
-  hipLaunchKernelGGL(k_wbx_t2, dim3(d.wb.x.G), dim3(kT), sizeof(XLds), static_cast<hipStream_t>(d.stream), d);
+  hipLaunchKernelGGL(k_wbx_t2, dim3(d.wb.x.G), dim3(kT), sizeof(XLds), static_cast<hipStream_t>(d.stream), d, cond);
+}
+void wbx_slot_pair(Dev &d) {
+  hipStream_t s = static_cast<hipStream_t>(d.stream);
+  const dim3 grid(d.wb.x.G), block(kT);
+  hipLaunchKernelGGL(k_wbx_slot_x, grid, block, sizeof(XLds), s, d);
+  hipLaunchKernelGGL(k_wbx_slot_y, grid, block, sizeof(YLds), s, d);
 }
 void wbx_init(Dev &d) {                        // (more than the default 64 KB of dynamic LDS: gfx950 has 160 KB per CU, one workgroup per CU here)
   WBX_CHECK(hipSetDevice(d.device));
@@ -303,6 +345,8 @@ void wbx_init(Dev &d) {                        // (more than the default 64 KB o
   WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_x<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_t2), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_y), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(YLds)));
+  WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_slot_x), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_slot_y), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(YLds)));
 }
 // One chunk of `niter` ADMM iterations:  X(rhs), { Y, X(update + rhs) } x (niter - 1), Y, X(update)  -- 2 niter + 1 launches
 void wbx_chunk(Dev &d, int niter) {

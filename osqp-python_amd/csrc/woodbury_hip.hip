@@ -24,8 +24,9 @@ __global__ __launch_bounds__(kBlock) void k_wb_gather(Dev d) {
 }
 // D0 = B_jj + sum over the SHORT rows of rho_i A_ij^2
 struct GPrecShort { const double *rho; const unsigned char *islong; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = (c >= n && !islong[c - n]) ? rho[c - n] * a * a : 0.0; } };
-__global__ __launch_bounds__(kBlock) void k_wb_diag(Dev d) {
+__global__ __launch_bounds__(kBlock) void k_wb_diag(Dev d, int cond) {      // cond: inside a boundary group -- only when it updated rho
   __shared__ StreamLds<1> lds;
+  if (cond && !d.ctl->rho_flag) return;
   GPrecShort g{d.rho, d.wb.islong, d.n};
   EPrec e{{}, d.B.val, d.Bdiag, d.wb.Dinv0};
   process_rows<1>(d.B, g, e, lds);
@@ -35,8 +36,9 @@ __global__ __launch_bounds__(kBlock) void k_wb_diag(Dev d) {
 // slices are summed in index order (deterministic).  (r03: one thread per (a, b) walked all n columns with one dependent load chain --
 // 3.3 ms per rho update on the portfolio QP, a fifth of its solve.)
 constexpr int kWbSlices = 8;
-__global__ __launch_bounds__(kWbMaxRows * kWbSlices) void k_wb_S(Dev d) {
+__global__ __launch_bounds__(kWbMaxRows * kWbSlices) void k_wb_S(Dev d, int cond) {
   const DevWb &w = d.wb;
+  if (cond && !d.ctl->rho_flag) return;
   __shared__ double part[kWbSlices][kWbMaxRows];
   const int a = blockIdx.x, b = threadIdx.x & (kWbMaxRows - 1), s = threadIdx.x / kWbMaxRows, r = w.r, n = d.n;
   const int bb = b < r ? b : 0;
@@ -57,6 +59,63 @@ __global__ __launch_bounds__(kWbMaxRows * kWbSlices) void k_wb_S(Dev d) {
     for (int q = 0; q < kWbSlices; q++) acc += part[q][b];
     if (a == b) acc += d.rho_inv[w.rows[a]];
     w.S[(size_t)a * r + b] = acc;
+  }
+}
+// S^-1 on the device (small form, r <= kWbMaxRows): in-place Gauss-Jordan elimination of the SPD matrix in LDS by ONE workgroup (no pivoting:
+// the pivots of an SPD matrix are positive), symmetrised, checked against S -- || S S^-1 - I ||_max must be at rounding level for the direct
+// mode -- and written to w.Sinv.  w.info[0] = 1: accurate, 0: inaccurate (the direct mode must not be used), -1: a pivot was not positive.
+// Until round 4 this was a host round trip (S down, Cholesky + triangular inverse on one core, S^-1 up: ~0.5 ms per rho update, and the reason
+// the direct mode's chunk boundaries could not be decided on the device).  cond: inside a boundary group -- only when it updated rho; a failed
+// check then hands the solve to the host (CTL_NEED_HOST / NEED_REFACTOR) and cancels the chunk the group has just begun.
+constexpr int kInvT = 1024;
+__global__ __launch_bounds__(kInvT) void k_wb_invert(Dev d, int cond) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const DevWb &w = d.wb;
+  if (cond && !d.ctl->rho_flag) return;
+  const int r = w.r, tid = threadIdx.x, rr = r * r;
+  double *M = sm, *rowk = M + rr, *colk = rowk + r, *red = colk + r;      // red: kInvT / 64 doubles
+  __shared__ double pmin_s;
+  for (int e = tid; e < rr; e += kInvT) M[e] = w.S[e];
+  if (tid == 0) pmin_s = 1e300;
+  __syncthreads();
+  for (int k = 0; k < r; k++) {
+    const double p = M[k * r + k], pi = 1.0 / p;
+    if (tid < r) { rowk[tid] = tid == k ? pi : M[k * r + tid] * pi; colk[tid] = M[tid * r + k]; }
+    if (tid == 0 && !(p >= pmin_s)) pmin_s = p;                           // (a NaN pivot is kept)
+    __syncthreads();
+    for (int e = tid; e < rr; e += kInvT) {
+      const int i = e / r, j = e - i * r;
+      M[e] = i == k ? rowk[j] : (j == k ? -colk[i] * pi : M[e] - colk[i] * rowk[j]);
+    }
+    __syncthreads();
+  }
+  // symmetrise (the elimination keeps symmetry up to rounding; consumers read rows as columns), then || S S^-1 - I ||_max
+  for (int e = tid; e < rr; e += kInvT) { const int i = e / r, j = e - i * r; if (i < j) { const double v = 0.5 * (M[e] + M[j * r + i]); M[e] = v; M[j * r + i] = v; } }
+  __syncthreads();
+  double err = 0.0;
+  for (int e = tid; e < rr; e += kInvT) {
+    const int a = e / r, b = e - a * r;
+    double acc0 = a == b ? -1.0 : 0.0, acc1 = 0.0;
+    int k = 0;
+    for (; k + 1 < r; k += 2) { acc0 += w.S[a * r + k] * M[k * r + b]; acc1 += w.S[a * r + k + 1] * M[(k + 1) * r + b]; }
+    if (k < r) acc0 += w.S[a * r + k] * M[k * r + b];
+    err = nanmax(err, fabs(acc0 + acc1));
+  }
+  err = wave_max(err);
+  if ((tid & 63) == kReduceLane) red[tid >> 6] = err;
+  __syncthreads();
+  for (int e = tid; e < rr; e += kInvT) w.Sinv[e] = M[e];
+  if (tid == 0) {
+    double e2 = 0.0;
+    for (int q = 0; q < kInvT / 64; q++) e2 = nanmax(e2, red[q]);
+    int ok = !(pmin_s > 0.0) ? -1 : ((e2 < 1e-9) ? 1 : 0);
+    if (w.dbg && *w.dbg > 0) { *w.dbg -= 1; ok = 0; }          // test hook (OSQPHipPolicy::debug_fail_refactor)
+    w.info[0] = ok;
+    if (cond && ok != 1) {                                    // device-driven solve: the direct mode cannot continue at this rho -- the host takes over
+      Ctl *c = d.ctl;
+      c->status = CTL_NEED_HOST; c->need |= NEED_REFACTOR;
+      d.slot[SR_PHASE] = P_KB; d.slot[SR_ADMM] = 0; d.slot[SR_TARGET] = 0;      // the chunk the group has just begun never starts: the slots behind it idle
+    }
   }
 }
 struct GDr { const double *Dinv0, *r; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = a * Dinv0[c] * r[c]; } };
@@ -248,7 +307,7 @@ static void wb_factor_large(Dev &d) {
   double tlap[6] = {0, 0, 0, 0, 0, 0};
   auto lap = [&](int k) { if (log) { HIP_CHECK(hipStreamSynchronize(st(d))); tlap[k] = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); } };
   lap(0);
-  LAUNCH(k_wb_diag, d, d);
+  LAUNCH(k_wb_diag, d, d, 0);
   LAUNCH(k_wb_fillW, d, d);
   lap(1);
   const double one = 1.0, zero = 0.0;
@@ -293,55 +352,32 @@ static void wb_factor_large(Dev &d) {
                  r, ct, chk[0], chk[1], chk[2], chk[3], w.exact, 1e3 * (tlap[1] - tlap[0]), 1e3 * (tlap[2] - tlap[1]), 1e3 * (tlap[3] - tlap[2]), 1e3 * (tlap[4] - tlap[3]), 1e3 * (tlap[5] - tlap[4]));
   }
 }
-// D0, S on the device; S^-1 on the host (r <= kWbMaxRows: a Cholesky factorisation of a few thousand entries, once per rho update)
+// D0, S, S^-1 (with its check) and the second tile of the two-launch direct mode: launches only -- conditional inside a boundary group
+void wb_factor_device(Dev &d, int cond) {
+  DevWb &w = d.wb;
+  const int r = w.r;
+  HIP_CHECK(hipSetDevice(d.device));
+  static thread_local int attr_dev = -1;
+  const size_t lds = sizeof(double) * ((size_t)r * r + 2 * (size_t)r + kInvT / 64);
+  if (attr_dev != d.device) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wb_invert), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * ((size_t)kWbMaxRows * kWbMaxRows + 2 * kWbMaxRows + kInvT / 64))));
+    attr_dev = d.device;
+  }
+  LAUNCH(k_wb_diag, d, d, cond);
+  hipLaunchKernelGGL(k_wb_S, dim3(r), dim3(kWbMaxRows * kWbSlices), 0, st(d), d, cond);
+  hipLaunchKernelGGL(k_wb_invert, dim3(1), dim3(kInvT), lds, st(d), d, cond);
+  wbx_factor(d, cond);                                        // (two-launch direct mode: S^-1 A_L per column block)
+}
+// small form (r <= kWbMaxRows), host-synchronous: the launches above, then the verdict of the check
 void wb_factor(Dev &d) {
   DevWb &w = d.wb;
   if (w.large) { wb_factor_large(d); return; }
-  const int r = w.r;
-  LAUNCH(k_wb_diag, d, d);
-  hipLaunchKernelGGL(k_wb_S, dim3(r), dim3(kWbMaxRows * kWbSlices), 0, st(d), d);
-  std::vector<double> S((size_t)r * r), L((size_t)r * r, 0.0), Li((size_t)r * r, 0.0), Si((size_t)r * r, 0.0);
-  HIP_CHECK(hipMemcpyAsync(S.data(), w.S, sizeof(double) * S.size(), hipMemcpyDeviceToHost, st(d)));
+  wb_factor_device(d, 0);
+  int ok = 0;
+  HIP_CHECK(hipMemcpyAsync(&ok, w.info, sizeof(int), hipMemcpyDeviceToHost, st(d)));
   HIP_CHECK(hipStreamSynchronize(st(d)));
-  for (int j = 0; j < r; j++) {                               // S = L L'
-    double dj = S[(size_t)j * r + j];
-    for (int k = 0; k < j; k++) dj -= L[(size_t)j * r + k] * L[(size_t)j * r + k];
-    if (!(dj > 0.0)) throw DeviceError("osqp_hip: the Woodbury system of the preconditioner is not positive definite");
-    const double ljj = std::sqrt(dj);
-    L[(size_t)j * r + j] = ljj;
-    for (int i = j + 1; i < r; i++) {
-      double v = S[(size_t)i * r + j];
-      for (int k = 0; k < j; k++) v -= L[(size_t)i * r + k] * L[(size_t)j * r + k];
-      L[(size_t)i * r + j] = v / ljj;
-    }
-  }
-  for (int c = 0; c < r; c++) {                               // Li = L^-1 (lower triangular), column by column
-    Li[(size_t)c * r + c] = 1.0 / L[(size_t)c * r + c];
-    for (int i = c + 1; i < r; i++) {
-      double v = 0.0;
-      for (int k = c; k < i; k++) v -= L[(size_t)i * r + k] * Li[(size_t)k * r + c];
-      Li[(size_t)i * r + c] = v / L[(size_t)i * r + i];
-    }
-  }
-  for (int a = 0; a < r; a++)                                 // S^-1 = Li' Li
-    for (int b = 0; b <= a; b++) {
-      double v = 0.0;
-      for (int k = a; k < r; k++) v += Li[(size_t)k * r + a] * Li[(size_t)k * r + b];
-      Si[(size_t)a * r + b] = Si[(size_t)b * r + a] = v;
-    }
-  if (w.exact) {                                              // the direct mode trusts S^-1: || S S^-1 - I ||_max must be at rounding level
-    double err = 0.0;
-    for (int a = 0; a < r; a++)
-      for (int b = 0; b < r; b++) {
-        double v = a == b ? -1.0 : 0.0;
-        for (int k = 0; k < r; k++) v += S[(size_t)a * r + k] * Si[(size_t)k * r + b];
-        err = std::max(err, std::fabs(v));
-      }
-    if (!(err < 1e-9)) w.exact = 0;
-  }
-  HIP_CHECK(hipMemcpyAsync(w.Sinv, Si.data(), sizeof(double) * Si.size(), hipMemcpyHostToDevice, st(d)));
-  HIP_CHECK(hipStreamSynchronize(st(d)));
-  wbx_factor(d);                                              // (two-launch direct mode: S^-1 A_L per column block)
+  if (ok < 0) throw DeviceError("osqp_hip: the Woodbury system of the preconditioner is not positive definite");
+  if (ok != 1) w.exact = 0;                                   // the direct mode trusts S^-1: || S S^-1 - I ||_max must be at rounding level
 }
 
 }  // namespace be

@@ -42,7 +42,8 @@ int count_bad_bounds(Dev &, const double *, const double *) { return 0; }
 bool wbx_supported() { return false; }
 void wbx_init(Dev &) {}
 void wbx_refresh(Dev &) {}
-void wbx_factor(Dev &) {}
+void wbx_factor(Dev &, int) {}
+void wbx_slot_pair(Dev &) {}
 void wbx_chunk(Dev &, int) {}
 void gather(Dev &, double *dst, const double *src, const int *idx, int cnt) { for (int k = 0; k < cnt; k++) dst[k] = src[idx[k]]; }
 void scale_warm(Dev &, const double *, const double *, double) {}

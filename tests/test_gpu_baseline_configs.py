@@ -16,7 +16,7 @@ from util import record_deviation
 pytestmark = pytest.mark.gpu
 warnings.simplefilter('ignore')
 EPS = 1e-6
-ATOL_1E6 = 2e-4        # x, y of two eps = 1e-6 iterates, relative to the solution's scale
+ATOL_1E6 = 2e-5        # x, y of two eps = 1e-6 iterates, relative to the solution's scale (measured on config 2 at full size: 2.4e-7 / 1.8e-6, profiles/r04f_parity_deviations.json)
 
 
 def certify(P, q, A, l, u, r, eps=EPS):
@@ -36,7 +36,7 @@ def test_config2_full_size_matches_oracle_direct_solution():
     direct-LDL' ADMM run to the same tolerance on the host (about a minute of CPU: 2 s ordering + factorisation, ~1300
     iterations of two triangular solves over nnz(L) = 2.7e7).  north_star's bar: agreement with the qdldl-direct CPU path
     within eps_abs = eps_rel = 1e-6; both iterates stop at residuals <= eps, so x, y are compared at 2e-4 relative to the
-    solution's scale and the objectives at 1e-6."""
+    solution's scale and the objectives at 1e-6.  (Round 4: 2e-5 -- ten times the measured deviation -- instead of 2e-4.)"""
     P, q, A, l, u = problems.banded_qp(100000)
     st = dict(eps_abs=EPS, eps_rel=EPS, max_iter=20000, adaptive_rho_interval=50, check_termination=25)
     m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, verbose=False, **st)

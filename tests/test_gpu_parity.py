@@ -72,9 +72,13 @@ def test_spmv_kernels_match_scipy(name):
     npt.assert_allclose(s.hip_test_spmv(1, vin), ref, rtol=1e-12, atol=1e-12)
 
 
-# measured on MI355X (round 1): at eps 1e-6 the worst case (portfolio) differs from the direct path by 4e-5 in x, 4e-4 in y
-# (both solvers only guarantee residuals <= eps); at eps 1e-8 by 3e-7 / 3e-6.  Tolerances = ~5x those.
-@pytest.mark.parametrize('eps,atol', [(1e-6, 2e-4), (1e-8, 2e-6)])
+# Tolerances = ~5x the deviations MEASURED on MI355X in round 4 (profiles/r04f_parity_deviations.json; both solvers only guarantee residuals
+# <= eps): eps 1e-6 -- portfolio 1.8e-5 in x / 3.3e-5 in y, banded_unaligned 5.6e-6 / 1.5e-5, the rest <= 1.1e-6 / 4.1e-6; eps 1e-8 -- worst
+# 1.8e-7 / 4.5e-7 (portfolio).  (Until round 4 the eps 1e-6 leg stood at 2e-4 for every problem: it would not have noticed a 10x regression.)
+ATOL_1E6 = {'portfolio': (1e-4, 2e-4), 'banded_unaligned': (3e-5, 8e-5)}       # (x, y); everything else (1e-5, 2e-5)
+
+
+@pytest.mark.parametrize('eps,atol', [(1e-6, None), (1e-8, 2e-6)])
 @pytest.mark.parametrize('name', list(GENS))
 def test_solution_matches_oracle_direct(name, eps, atol):
     P, q, A, l, u = GENS[name]()
@@ -82,9 +86,10 @@ def test_solution_matches_oracle_direct(name, eps, atol):
     xo, yo, io = oracle_solve(P, q, A, l, u, eps_abs=1e-10, eps_rel=1e-10, max_iter=200000)
     assert r.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED and io.status_val == SOLVED
     record_deviation('test_solution_matches_oracle_direct', '%s eps=%g' % (name, eps), dx_rel=np.abs(r.x - xo).max() / (1 + np.abs(xo).max()),
-                     dy_rel=np.abs(r.y - yo).max() / (1 + np.abs(yo).max()), atol=atol, iters=r.info.iter, oracle_iters_at_eps_1e_10=io.iter)
-    npt.assert_allclose(r.x, xo, rtol=0, atol=atol * (1 + np.abs(xo).max()))
-    npt.assert_allclose(r.y, yo, rtol=0, atol=atol * (1 + np.abs(yo).max()))
+                     dy_rel=np.abs(r.y - yo).max() / (1 + np.abs(yo).max()), atol=atol if atol is not None else list(ATOL_1E6.get(name, (1e-5, 2e-5))), iters=r.info.iter, oracle_iters_at_eps_1e_10=io.iter)
+    ax, ay = (atol, atol) if atol is not None else ATOL_1E6.get(name, (1e-5, 2e-5))
+    npt.assert_allclose(r.x, xo, rtol=0, atol=ax * (1 + np.abs(xo).max()))
+    npt.assert_allclose(r.y, yo, rtol=0, atol=ay * (1 + np.abs(yo).max()))
     assert abs(r.info.obj_val - io.obj_val) <= 10 * eps * (1 + abs(io.obj_val))
     EPS = eps
     k = problems.kkt_certificate(P, q, A, l, u, r.x, r.y)
