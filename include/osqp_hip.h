@@ -305,7 +305,8 @@ typedef struct {
   OSQPInt woodbury_direct;    /* ... and when the rest of K is diagonal, that preconditioner IS K^-1: the linear solve without PCG iterations [setup] */
   OSQPInt woodbury_large;     /* up to 16384 dense rows carrying most of A: the same correction with the r x r system formed, factorised and inverted on
                                  the device (rocBLAS / rocSOLVER, loaded on demand; off where they are missing)                    [setup] */
-  OSQPInt device_driven;      /* chunk boundaries (termination test, adaptive rho, PCG tolerance / budget) decided on the device */
+  OSQPInt device_driven;      /* chunk boundaries (termination test, adaptive rho, PCG tolerance / budget) decided on the device; 2: also for the Woodbury
+                                 direct mode in two launches (there the host-synchronous loop is the faster one and the default) */
   OSQPInt small_direct;       /* small QPs: the whole solve as ONE launch of the batch kernel's direct (banded LDL') variant */
   OSQPInt batch_reorder;      /* batch solves: launch the problems in the order of the previous call's iteration counts */
   OSQPInt batch_variant;      /* 0 automatic; 1 direct (one wave), 2 direct256, 3 w64 (PCG), 4 w256 (PCG), 5 generic -- if applicable */

@@ -116,6 +116,7 @@ constexpr int kWbxCols = 64;
 constexpr int kWbxMaxN = 16384;           // at most 256 workgroups: every consumer folds all partials (G x kWbMaxRows doubles)
 struct DevWbx {
   int on = 0, G = 0, nsc = 0;
+  int slots = 0;                          // run the two launches as device-scheduled slots (device-driven boundaries; OSQPHipPolicy::device_driven = 2) instead of captured strings of 2 N + 1 launches
   double *tile2 = nullptr;                // [G][kWbMaxRows][kWbxCols] S^-1 A_L by column block (wbx_factor, after every inversion of S)
   double *tile = nullptr;                 // [G][kWbMaxRows][kWbxCols] A_L by column block, zero where A_L has no entry (rows >= r unused)
   double *partG = nullptr, *partZ = nullptr;   // [G][kWbMaxRows] partial sums of the two reductions
@@ -306,7 +307,7 @@ int slot_seq(Dev &d);                      // slots executed since slot_begin (c
 //   two-kernel form  2 (pcg + 2)   KB, K1, pcg x (K2F, K1F), the K2F that detects convergence, KA
 //   F1 form          pcg + 3       KB, F_0, F_1 .. F_pcg, KA (run by the launch whose scalar fold detects convergence)
 //   Woodbury direct mode in two launches (wbdirect_hip.hip): 2 per iteration + one closing pair per chunk
-inline double slot_launches(const Dev &d, double pcg) { return (d.wb.on && d.wb.exact && d.wb.x.on) ? 2.16 : (d.f1.on ? pcg + 3.0 : 2.0 * (pcg + 2.0)); }
+inline double slot_launches(const Dev &d, double pcg) { return (d.wb.on && d.wb.exact && d.wb.x.on && d.wb.x.slots) ? 2.16 : (d.f1.on ? pcg + 3.0 : 2.0 * (pcg + 2.0)); }
 void f1_refresh(Dev &d);                   // f1.pval <- B.val (no-op without a plan)
 bool wb_supported();
 bool wbx_supported();                      // the two-launch direct mode exists (false: the host simulator)
@@ -315,6 +316,7 @@ void wbx_refresh(Dev &d);                  // tiles / one-entry-row values <- A.
 void wbx_factor(Dev &d, int cond = 0);     // tile2 = S^-1 A_L (after S^-1 has changed); cond: inside a boundary group, only when it updated rho
 void wbx_slot_pair(Dev &d);                // the two launches as a pair of slots (device-side scheduling)
 inline bool wbx_active(const Dev &d) { return d.wb.on && d.wb.exact && d.wb.x.on; }
+inline bool wbx_slots(const Dev &d) { return wbx_active(d) && d.wb.x.slots; }
 void wbx_chunk(Dev &d, int niter);         // niter ADMM iterations: X(rhs), { Y, X } x (niter - 1), Y, X(update): 2 niter + 1 launches on d.stream
 bool wb_large_supported();                 // the dense solver libraries could be loaded                       // Woodbury preconditioner available (false: the host simulator)
 void wb_refresh(Dev &d);                   // wb.AL / ALT / WT values <- A.val (after assembly / equilibration / matrix updates)

@@ -471,7 +471,7 @@ void ctl_group(Dev &d, int diagonal) {
   LAUNCH(k_set_rho, d, d, 0.0, 1);
   LAUNCH(k_init_guess, d, d, 1);
   if (diagonal) LAUNCH(k_precond, d, d, 1);
-  if (d.wb.on && !d.wb.large) wb_factor_device(d, 1);     // Woodbury direct mode in the slot form: D0, S, S^-1 (+ check), S^-1 A_L when rho changed
+  if (wbx_slots(d)) wb_factor_device(d, 1);               // Woodbury direct mode in the slot form: D0, S, S^-1 (+ check), S^-1 A_L when rho changed
 }
 void ctl_poll(Dev &d, Ctl *out, int *seq, int *done) {
   HIP_CHECK(hipSetDevice(d.device));

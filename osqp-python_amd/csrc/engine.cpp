@@ -99,7 +99,7 @@ void policy_from_env(OSQPHipPolicy &p, bool runtime_only) {
   auto on = [](const char *name, OSQPInt &v) { if (const char *e = std::getenv(name)) v = e[0] != '0'; };      // "0" switches off, anything else on
   auto num = [](const char *name, OSQPInt &v) { if (const char *e = std::getenv(name)) v = std::atoi(e); };
   auto real = [](const char *name, OSQPFloat &v) { if (const char *e = std::getenv(name)) v = std::atof(e); };
-  on("OSQP_HIP_SMALL_DIRECT", p.small_direct); on("OSQP_HIP_DEVICE_DRIVEN", p.device_driven); on("OSQP_HIP_BATCH_REORDER", p.batch_reorder);
+  on("OSQP_HIP_SMALL_DIRECT", p.small_direct); num("OSQP_HIP_DEVICE_DRIVEN", p.device_driven); on("OSQP_HIP_BATCH_REORDER", p.batch_reorder);
   num("OSQP_HIP_RHO_WINDOW", p.rho_window); real("OSQP_HIP_RHO_WINDOW_TOL", p.rho_window_tol); on("OSQP_HIP_RHO_PERSIST", p.rho_persist);
   if (const char *e = std::getenv("OSQP_HIP_RHO_TOL_EXP")) { const double v = std::atof(e); p.rho_tol_exp = v > 0 && v <= 1 ? v : 0.5; }
   real("OSQP_HIP_BUDGET_TOLERATE", p.budget_tolerate); real("OSQP_HIP_BUDGET_SIGMA", p.budget_sigma); num("OSQP_HIP_BUDGET_SLACK", p.budget_slack);
@@ -1458,6 +1458,10 @@ void Engine::admm_core(double t0, double *res) {
   for (;;) {
     int st;
     // (evaluated at every boundary: the Woodbury direct mode may leave the slot form in the middle of a solve -- NEED_REFACTOR below)
+    // (the Woodbury direct mode takes the slot form only when asked to, device_driven = 2: its two launches per ADMM iteration are so short
+    //  that a boundary group of sixteen launches costs what the host round trip it replaces costs, and the fixed captured strings of the
+    //  host-synchronous loop carry no idle launches -- 34 against 41 ms on the portfolio QP)
+    d_.wb.x.slots = (pol_.device_driven >= 2 && !settings.verbose) ? 1 : 0;
     const bool slots = use_slots_ && be::slots_supported(d_);
     const bool device_driven = slots && pol_.device_driven && !settings.verbose && be::ctl_supported(d_);
     const bool first_chunk = c.iter == 0;

@@ -922,10 +922,10 @@ void k1(Dev &d, int i) { if (d.fused && i > 0) LAUNCH(k_k1f, d, d, i); else LAUN
 void k2(Dev &d, int i) { if (d.fused) LAUNCH(k_k2f, d, d, i); else LAUNCH(k_k2, d, d, 0); }
 void kv(Dev &d, int i) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, i, 0); else LAUNCH(k_kv<1>, d, d, i, 0); }
 void ka(Dev &d, int budget) { LAUNCH(k_ka, d, d, budget); }
-bool slots_supported(const Dev &d) { return (d.fused != 0 || wbx_active(d)) && d.slot != nullptr; }
+bool slots_supported(const Dev &d) { return (d.fused != 0 || wbx_slots(d)) && d.slot != nullptr; }
 void slot_begin(Dev &d, int target, int cap) { HIP_CHECK(hipSetDevice(d.device)); hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(1), 0, st(d), d.slot, target, cap, ++im(d).epoch); }
 void slot_pair(Dev &d) {
-  if (wbx_active(d)) { wbx_slot_pair(d); return; }      // Woodbury direct mode: X, Y (wbdirect_hip.hip)
+  if (wbx_slots(d)) { wbx_slot_pair(d); return; }      // Woodbury direct mode: X, Y (wbdirect_hip.hip)
   if (d.f1.on) {
     switch (d.f1.D) {
       case 1: LAUNCH(k_slot1<1>, d, d, 0); LAUNCH(k_slot1<1>, d, d, 1); break;
