@@ -199,3 +199,31 @@ def test_polish_and_settings_updates_on_a_forced_reordered_handle(monkeypatch):
     for a, b in zip(out[0], out[1]):
         assert a.info.status_val == b.info.status_val == S.OSQP_SOLVED and a.info.status_polish == b.info.status_polish == 1
         assert np.abs(a.x - b.x).max() <= 1e-8 * (1 + np.abs(a.x).max()) and np.abs(a.y - b.y).max() <= 1e-7 * (1 + np.abs(a.y).max())
+
+
+@pytest.mark.gpu
+def test_matrix_updates_by_index_on_an_automatically_reordered_handle():
+    """osqp_update_data_mat with index lists in the CALLER's CSC order (bindings.cpp.in:240-281) on a handle the engine reordered by itself:
+    the updated handle must solve what a fresh handle built from the updated matrices solves."""
+    n = 50000
+    P, q, A, l, u = problems.banded_qp(n)
+    rng = np.random.default_rng(11)
+    pc, pr = rng.permutation(n), rng.permutation(2 * n)
+    Ps = sp.triu(P[pc][:, pc], format='csc'); Ps.sort_indices()
+    As = A[pr][:, pc].tocsc(); As.sort_indices()
+    qs, ls, us = q[pc], l[pr], u[pr]
+    st = dict(eps_abs=1e-8, eps_rel=1e-8, max_iter=50000, check_termination=25, adaptive_rho_interval=50, verbose=False)
+    m1 = osqp_amd.OSQP(); m1.setup(Ps, qs, As, ls, us, **st)
+    assert m1._solver.hip_stats()['reordered'] == 1 and m1._solver.hip_stats()['pcg_fused'] == 2
+    m1.solve()
+    Ax_idx = rng.permutation(As.nnz)[:As.nnz // 3].astype(np.int32); Ax_new = As.data[Ax_idx] * (1.0 + 0.05 * rng.standard_normal(Ax_idx.size))
+    Px_idx = np.flatnonzero(Ps.indices == np.repeat(np.arange(n), np.diff(Ps.indptr))).astype(np.int32)      # the diagonal entries: scaled up, P stays PSD
+    Px_new = Ps.data[Px_idx] * 1.1
+    m1.update(Px=Px_new, Px_idx=Px_idx, Ax=Ax_new, Ax_idx=Ax_idx)
+    m1.update_settings(rho=0.1); m1.warm_start(x=np.zeros(n), y=np.zeros(2 * n))
+    r1 = m1.solve()
+    P2 = Ps.copy(); P2.data[Px_idx] = Px_new
+    A2 = As.copy(); A2.data[Ax_idx] = Ax_new
+    m2 = osqp_amd.OSQP(); m2.setup(P2, qs, A2, ls, us, **st); r2 = m2.solve()
+    assert r1.info.status_val == r2.info.status_val == S.OSQP_SOLVED
+    assert np.abs(r1.x - r2.x).max() <= 2e-6 * (1 + np.abs(r2.x).max()) and np.abs(r1.y - r2.y).max() <= 2e-6 * (1 + np.abs(r2.y).max())
