@@ -1,0 +1,666 @@
+// engine_api.cpp -- the rest of the C-API surface of the engine: cold / warm start, data and settings updates, the LinSysSolver slot, the batch
+// and small-problem paths (one-workgroup-per-QP kernels), statistics and probes.  See engine.hpp.
+#include "engine_internal.hpp"
+
+namespace osqp_hip {
+
+// ------------------------------------------------------------------------------------------------ updates
+int Engine::cold_start() {                                                               // _osqp.py:636-642
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  be::zero(d_, d_.x, sizeof(double) * n); be::zero(d_, d_.z, sizeof(double) * m); be::zero(d_, d_.y, sizeof(double) * m);
+  be::init_iterates(d_, 1);
+  return OSQP_NO_ERROR;
+}
+
+int Engine::warm_start(const double *x, const double *y, bool keep_z) {                  // _osqp.py:1493-1545
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  settings.warm_starting = 1;
+  std::vector<double> xi, yi;
+  if (reordered_) { if (x) { xi = to_internal_n(x); x = xi.data(); } if (y) { yi = to_internal_m(y); y = yi.data(); } }
+  if (be::device_vec_updates()) {                      // raw vectors go up as they are; x = Dinv x, y = c Einv y on the device
+    double *sx = d_.w, *sy = d_.t;                     // PCG work vectors are free between solves
+    if (x) be::copy_in(d_, sx, x, sizeof(double) * n, 0);
+    if (y) be::copy_in(d_, sy, y, sizeof(double) * m, 0);
+    be::scale_warm(d_, x ? sx : nullptr, y ? sy : nullptr, c_);
+  } else {
+    if (x) {
+      std::vector<double> xs(n);
+      for (int j = 0; j < n; j++) xs[j] = x[j] * Dinv_[j];
+      be::h2d(d_, d_.x, xs.data(), sizeof(double) * n);
+    }
+    if (y) {
+      std::vector<double> ys(m);
+      for (int i = 0; i < m; i++) ys[i] = y[i] * Einv_[i] * c_;   // inverse of y = cinv E y_scaled (:1112); the C core includes c
+      be::h2d(d_, d_.y, ys.data(), sizeof(double) * m);
+    }
+  }
+  be::init_iterates(d_, keep_z ? 2 : 1);                            // z = A x (:1509); keep_z: the caller has put the z iterate in place
+  return OSQP_NO_ERROR;
+}
+
+int Engine::warm_start_device(const double *x, const double *y, void *stream) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (!be::device_vec_updates()) return OSQP_FUNC_NOT_IMPLEMENTED;
+  be::activate(d_);
+  be::ext_wait(d_);                                 // a batch kernel on a caller's stream may still read this solver's vectors
+  settings.warm_starting = 1;
+  be::stream_wait(d_, stream);
+  if (reordered_) {                                 // the caller's numbering -> the engine's, on the device (PCG work vectors are free between solves)
+    if (x) { be::gather(d_, d_.w, x, d_pc_, n); x = d_.w; }
+    if (y) { be::gather(d_, d_.t, y, d_pr_, m); y = d_.t; }
+  }
+  be::scale_warm(d_, x, y, c_);
+  be::init_iterates(d_, 1);
+  return OSQP_NO_ERROR;
+}
+
+int Engine::update_data_vec(const double *q, const double *l, const double *u) {          // _osqp.py:1312-1367
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  be::ext_wait(d_);                                 // a batch kernel on a caller's stream may still read the bounds / q
+  double t0 = now_s();
+  std::vector<double> qi, li_, ui_;
+  if (reordered_) {
+    if (q) { qi = to_internal_n(q); q = qi.data(); }
+    if (l) { li_ = to_internal_m(l); l = li_.data(); }
+    if (u) { ui_ = to_internal_m(u); u = ui_.data(); }
+  }
+  if (l || u) {
+    if (raw_stale_) ensure_host_vectors();
+    for (int i = 0; i < m; i++) {
+      double li = l ? l[i] : l0_[i], ui = u ? u[i] : u0_[i];
+      if (!(li <= ui)) return OSQP_DATA_VALIDATION_ERROR;                                // :1348-1349
+    }
+  }
+  const bool dev = be::device_vec_updates();
+  if (q) { q0_.assign(q, q + n); if (dev) be::copy_in(d_, d_.qraw, q, sizeof(double) * n, 0); else upload_q(); }
+  if (l) { l0_.assign(l, l + m); if (dev) be::copy_in(d_, d_.lraw, l, sizeof(double) * m, 0); }
+  if (u) { u0_.assign(u, u + m); if (dev) be::copy_in(d_, d_.uraw, u, sizeof(double) * m, 0); }
+  if (dev) device_scale_vectors(q != nullptr, l || u);
+  else if (l || u) upload_bounds_and_types();                                           // update_rho_vec :526-562
+  if (l || u) {
+    be::set_rho(d_, rho_bar_);
+    be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  }
+  set_status(OSQP_UNSOLVED);                                                             // reset_info :932-941
+  if (!dev) be::sync(d_);                           // (device path: everything is stream-ordered; the next solve waits for it)
+  update_time_acc_ += now_s() - t0;
+  return OSQP_NO_ERROR;
+}
+
+// q / l / u given by DEVICE pointer (parametric re-solve with the data produced on the GPU, nn/torch.py:136-140): one device-to-device
+// copy per vector, then the same kernels.  The bounds are validated on the device BEFORE anything changes (one 4-byte read-back).
+int Engine::update_data_vec_device(const double *q, const double *l, const double *u, void *stream) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (!be::device_vec_updates()) return OSQP_FUNC_NOT_IMPLEMENTED;
+  be::activate(d_);
+  be::ext_wait(d_);
+  double t0 = now_s();
+  be::stream_wait(d_, stream);
+  if (reordered_ && (l || u) && !(l && u)) {        // one bound in the caller's numbering against the resident other one: bring it over first
+    double *tmp = d_.t;                               // (a rejected call leaves the resident vectors untouched: staged in a PCG work vector)
+    be::gather(d_, tmp, l ? l : u, d_pr_, m);
+    if (be::count_bad_bounds(d_, l ? tmp : d_.lraw, u ? tmp : d_.uraw) > 0) return OSQP_DATA_VALIDATION_ERROR;
+  } else
+  if ((l || u) && be::count_bad_bounds(d_, l ? l : d_.lraw, u ? u : d_.uraw) > 0) return OSQP_DATA_VALIDATION_ERROR;
+  if (reordered_) {                                 // the resident raw vectors are kept in the engine's numbering: gathers instead of copies
+    if (q) be::gather(d_, d_.qraw, q, d_pc_, n);
+    if (l) be::gather(d_, d_.lraw, l, d_pr_, m);
+    if (u) be::gather(d_, d_.uraw, u, d_pr_, m);
+  } else {
+    if (q) be::copy_in(d_, d_.qraw, q, sizeof(double) * n, 1);
+    if (l) be::copy_in(d_, d_.lraw, l, sizeof(double) * m, 1);
+    if (u) be::copy_in(d_, d_.uraw, u, sizeof(double) * m, 1);
+  }
+  if (q || l || u) raw_stale_ = true;
+  device_scale_vectors(q != nullptr, l || u);
+  if (l || u) {
+    be::set_rho(d_, rho_bar_);
+    be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  }
+  set_status(OSQP_UNSOLVED);
+  update_time_acc_ += now_s() - t0;
+  return OSQP_NO_ERROR;
+}
+
+int Engine::update_data_mat(const double *Px, const int *Px_idx, int P_n, const double *Ax, const int *Ax_idx, int A_n) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  be::ext_wait(d_);
+  double t0 = now_s();
+  const int nzP = P_.nnz(), nzA = A_.nnz();
+  // bindings.cpp.in:240-281: idx == NULL means all entries in order.  Both arguments are validated BEFORE anything is changed:
+  // a rejected call leaves the host copies (and therefore the next upload) untouched.
+  if (Px) {
+    if (Px_idx) { for (int k = 0; k < P_n; k++) if (Px_idx[k] < 0 || Px_idx[k] >= nzP) return OSQP_DATA_VALIDATION_ERROR; }
+    else if (P_n != nzP && P_n != 0) return OSQP_DATA_VALIDATION_ERROR;
+  }
+  if (Ax) {
+    if (Ax_idx) { for (int k = 0; k < A_n; k++) if (Ax_idx[k] < 0 || Ax_idx[k] >= nzA) return OSQP_DATA_VALIDATION_ERROR; }
+    else if (A_n != nzA && A_n != 0) return OSQP_DATA_VALIDATION_ERROR;
+  }
+  // (reordered problem: the caller's positions in its own CSC arrays -> where those entries live in the permuted ones)
+  if (Px) for (int k = 0; k < (Px_idx ? P_n : nzP); k++) { const int c = Px_idx ? Px_idx[k] : k; P_.x[reordered_ ? PvalMap_[c] : c] = Px[k]; }
+  if (Ax) for (int k = 0; k < (Ax_idx ? A_n : nzA); k++) { const int c = Ax_idx ? Ax_idx[k] : k; A_.x[reordered_ ? AvalMap_[c] : c] = Ax[k]; }
+  if (be::device_assembly()) {                                                           // _osqp.py:1443,:1463 on the device
+    if (Px) be::h2d(d_, d_.Praw, P_.x.data(), sizeof(double) * nzP);
+    if (Ax) be::h2d(d_, d_.Araw, A_.x.data(), sizeof(double) * nzA);
+    be::assemble(d_, 1, c_, 1);
+    be::f1_refresh(d_); be::wb_refresh(d_); be::wbx_refresh(d_);
+  } else {
+    std::vector<double> Pxs, Axs;
+    scale_matrix_values(Pxs, Axs);
+    fill_matrix_values(Pxs, Axs);
+  }
+  be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);                   // the "refactor" of :1446,:1466,:1488
+  be::init_iterates(d_, 0);                                                              // z~, t0 depend on A; iterates untouched
+  set_status(OSQP_UNSOLVED);
+  be::sync(d_);
+  update_time_acc_ += now_s() - t0;
+  return OSQP_NO_ERROR;
+}
+
+int Engine::update_rho(double rho) {                                                     // _osqp.py:1579-1597
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  if (!(rho > 0)) return OSQP_SETTINGS_VALIDATION_ERROR;
+  rho_bar_ = clamp_rho(rho); settings.rho = rho_bar_;
+  be::set_rho(d_, rho_bar_);
+  be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  return OSQP_NO_ERROR;
+}
+
+int Engine::update_settings(const OSQPSettings *s) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  int err = validate_settings(s, false);
+  if (err) return err;
+  // settings that can change after setup (the reference: "These can be changed without running setup", _osqp.py:128-143)
+  settings.max_iter = s->max_iter; settings.eps_abs = s->eps_abs; settings.eps_rel = s->eps_rel;
+  settings.eps_prim_inf = s->eps_prim_inf; settings.eps_dual_inf = s->eps_dual_inf; settings.alpha = s->alpha;
+  settings.scaled_termination = s->scaled_termination; settings.check_termination = s->check_termination;
+  settings.check_dualgap = s->check_dualgap; settings.time_limit = s->time_limit; settings.warm_starting = s->warm_starting;
+  settings.verbose = s->verbose; settings.polishing = s->polishing; settings.delta = s->delta;
+  settings.polish_refine_iter = s->polish_refine_iter; settings.adaptive_rho = s->adaptive_rho;
+  settings.adaptive_rho_interval = s->adaptive_rho_interval; settings.adaptive_rho_fraction = s->adaptive_rho_fraction;
+  settings.adaptive_rho_tolerance = s->adaptive_rho_tolerance; settings.cg_max_iter = s->cg_max_iter;
+  settings.cg_tol_reduction = s->cg_tol_reduction; settings.cg_tol_fraction = s->cg_tol_fraction;
+  if (s->cg_precond != settings.cg_precond) { settings.cg_precond = s->cg_precond; be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER); }
+  if (d_.alpha != settings.alpha) { d_.alpha = settings.alpha; drop_graphs(); }     // alpha is baked into captured launches
+  have_tol_ = false; cg_budget_ = 0;
+  return OSQP_NO_ERROR;
+}
+
+// Batch of nbatch QPs that share this solver's (P, A, scaling, settings) and differ in q / l / u -- the reference's
+// update-style batching (nn/torch.py:136-164: update(q,l,u) + solve() per element) as ONE kernel launch.
+// q: nbatch x n, l/u: nbatch x m (row-major; NULL = this solver's current vector for every problem);
+// x: nbatch x n, y: nbatch x m (in: unscaled warm start if warm != 0; out: solution, or certificate for infeasible ones);
+// rec: nbatch x kBatchRec = {status_val, iter, obj_val, prim_res, dual_res, rho, rho_updates, pcg_iters, status_polish, polish_time, rho_estimate, reserved}.
+
+
+// ------------------------------------------------------------------------------------------------ LinSysSolver slot
+// The reduced-KKT PCG as a stand-alone linear solver (include/osqp_hip.h), built from the same backend
+// operations as the ADMM loop:  kb_rhs  forms  rhs = sigma x - q + A' v  and the PCG start residual, so with  x = 0,
+// q = -rhs_x,  v = rho .* rhs_z  it forms exactly the right-hand side of the reduced system;  k1/k2/kv  are the PCG
+// iterations (three-kernel form: a solve may be continued past its first budget);  init_iterates(0)  leaves  z~ = A x~.
+int Engine::ls_setup(const OSQPCscMatrix *P, const OSQPCscMatrix *A, const double *rho_vec, const OSQPSettings *s) {
+  if (!P || !A || !rho_vec || !s) return OSQP_DATA_VALIDATION_ERROR;
+  OSQPSettings st = *s;
+  st.scaling = 0; st.linsys_solver = OSQP_INDIRECT_SOLVER; st.verbose = 0; st.polishing = 0;   // the matrices arrive scaled
+  const int nn = P->n, mm = A->m;
+  std::vector<double> q(nn, 0.0), l(mm, -OSQP_INFTY), u(mm, OSQP_INFTY);
+  no_reorder_ = true;                                 // (the slot's vectors -- rhs, rho_vec, warm start -- are exchanged in the caller's numbering)
+  int err = setup(P, q.data(), A, l.data(), u.data(), mm, nn, &st);
+  if (err) return err;
+  d_.fused = 0; d_.f1.on = 0; d_.wb.on = 0;
+  return ls_set_rho_vec(rho_vec);
+}
+
+int Engine::ls_set_rho_vec(const double *rho_vec) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (!rho_vec) return OSQP_DATA_VALIDATION_ERROR;
+  be::activate(d_);
+  ls_rho_.assign(rho_vec, rho_vec + m);
+  std::vector<double> rinv(m);
+  for (int i = 0; i < m; i++) { if (!(ls_rho_[i] > 0)) return OSQP_DATA_VALIDATION_ERROR; rinv[i] = 1.0 / ls_rho_[i]; }
+  be::h2d(d_, d_.rho, ls_rho_.data(), sizeof(double) * m);
+  be::h2d(d_, d_.rho_inv, rinv.data(), sizeof(double) * m);
+  be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  be::init_iterates(d_, 0);                        // t0 = rho .* (A x~) must match the new rho
+  be::sync(d_);
+  return OSQP_NO_ERROR;
+}
+
+int Engine::ls_warm_start(const double *x) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (!x) return OSQP_DATA_VALIDATION_ERROR;
+  be::activate(d_);
+  be::h2d(d_, d_.xs, x, sizeof(double) * n);
+  be::init_iterates(d_, 0);
+  be::sync(d_);
+  return OSQP_NO_ERROR;
+}
+
+int Engine::ls_solve(double *b, double tol_rel, double tol_abs, int *iters) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (!b) return OSQP_DATA_VALIDATION_ERROR;
+  be::activate(d_);
+  std::vector<double> nq(n), v(m);
+  for (int j = 0; j < n; j++) nq[j] = -b[j];
+  for (int i = 0; i < m; i++) v[i] = ls_rho_[i] * b[n + i];
+  be::h2d(d_, d_.q, nq.data(), sizeof(double) * n);
+  be::h2d(d_, d_.v, v.data(), sizeof(double) * m);
+  be::zero(d_, d_.x, sizeof(double) * n);
+  be::set_pcg_tol(d_, tol_rel, tol_abs);
+  be::kb_rhs(d_);
+  const int cap = std::min(settings.cg_max_iter, kMaxCg);
+  int flags[F_COUNT] = {0};
+  int done = 0;
+  for (int i0 = 0; i0 < cap && !done;) {           // budget: what the previous solve needed + 2, then doubling
+    const int bud = std::min(cap - i0, std::max(4, i0 == 0 ? cg_budget_ + 2 : i0));
+    for (int i = i0; i < i0 + bud; i++) { be::k1(d_, i); be::k2(d_, i); be::kv(d_, i); }
+    i0 += bud;
+    be::k1(d_, i0 < cap ? i0 : cap);               // the stopping test of the last update (its SpMV is wasted only if the cap was hit)
+    be::fetch_flags(d_, flags);
+    done = flags[F_DONE];
+    if (!done && i0 >= cap) break;
+    if (!done) { be::k2(d_, i0); be::kv(d_, i0); i0++; }
+  }
+  cg_budget_ = done ? flags[F_ITERS] : cap;
+  if (iters) *iters = cg_budget_;
+  be::init_iterates(d_, 0);                        // z~ = A x~ ; t0 for the next solve's start residual
+  be::d2h(d_, b, d_.xs, sizeof(double) * n);
+  if (m > 0) be::d2h(d_, b + n, d_.zt, sizeof(double) * m);
+  return OSQP_NO_ERROR;
+}
+
+// ------------------------------------------------------------------------------------------------ batch path, direct solve
+// Symbolic preparation of the banded-Cholesky linear solve of the batch kernel (batch_hip.hip): the pattern of
+// K = P + sigma I + A' diag(rho) A, a reverse Cuthill-McKee ordering of it, the band slot of every P entry, and for
+// every band slot the list of products A_ia A_ib that rho_i multiplies.  The reference's builtin algebra factorises the
+// KKT matrix with QDLDL after an AMD ordering; for QPs small enough to live in one workgroup's LDS the
+// reduced matrix K (n x n, SPD) under a BANDWIDTH-reducing ordering is the better fit: no indirect addressing in the
+// factor, fixed trip counts.
+void Engine::free_batch_direct() {
+  void *ptrs[] = {bd_.perm, bd_.bp_slot, bd_.ke_slot, bd_.ke_ptr, bd_.kp_row, bd_.kp_a, bd_.kp_b, bd_.tri, bd_.kp_val};
+  for (void *p : ptrs) if (p) be::dfree(d_, p);
+  bd_ = BatchDirect();
+}
+
+void Engine::prepare_batch_direct() {
+  if (bd_.tried) return;
+  bd_.tried = true;
+  const int nzA = (int)Arj_.size(), nzB = (int)Bj_.size();
+  // adjacency of K (excluding the diagonal)
+  double pairs = 0;
+  for (int i = 0; i < m; i++) { const double len = Arp_[i + 1] - Arp_[i]; pairs += len * (len + 1) / 2; }
+  if (pairs > 4e6 || n > 4096) { bd_.bw_symbolic = -2; return; }   // dense rows: K would be (nearly) dense -- PCG path
+  std::vector<std::vector<int>> adj(n);
+  for (int j = 0; j < n; j++)
+    for (int k = Brp_[j]; k < Brp_[j + 1]; k++) { const int c = Bj_[k]; if (c < n && c != j) adj[j].push_back(c); }
+  for (int i = 0; i < m; i++)
+    for (int a = Arp_[i]; a < Arp_[i + 1]; a++)
+      for (int b = Arp_[i]; b < Arp_[i + 1]; b++) if (a != b) adj[Arj_[a]].push_back(Arj_[b]);
+  for (auto &v : adj) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+  // reverse Cuthill-McKee, component by component, each started from a pseudo-peripheral node
+  std::vector<int> order; order.reserve(n);
+  std::vector<char> seen(n, 0);
+  std::vector<int> level(n, -1), frontier, next;
+  auto bfs_far = [&](int start, int &ecc) {                  // farthest node of minimum degree from start (within its component)
+    std::vector<int> touched;
+    frontier.assign(1, start); level[start] = 0; touched.push_back(start);
+    int last = start; ecc = 0;
+    while (!frontier.empty()) {
+      next.clear();
+      int best = frontier[0];
+      for (int v : frontier) if (adj[v].size() < adj[best].size()) best = v;
+      last = best; ecc = level[best];
+      for (int v : frontier) for (int w : adj[v]) if (level[w] < 0) { level[w] = level[v] + 1; next.push_back(w); touched.push_back(w); }
+      frontier.swap(next);
+    }
+    for (int v : touched) level[v] = -1;
+    return last;
+  };
+  for (int s0 = 0; s0 < n; s0++) {
+    if (seen[s0]) continue;
+    int start = s0, ecc = -1;
+    for (int rounds = 0; rounds < 8; rounds++) {            // pseudo-peripheral node (George-Liu)
+      int e2; const int far = bfs_far(start, e2);
+      if (e2 <= ecc) break;
+      ecc = e2; start = far;
+    }
+    size_t head = order.size();
+    order.push_back(start); seen[start] = 1;
+    while (head < order.size()) {
+      const int v = order[head++];
+      std::vector<int> nb;
+      for (int w : adj[v]) if (!seen[w]) { seen[w] = 1; nb.push_back(w); }
+      std::sort(nb.begin(), nb.end(), [&](int a, int b) { return adj[a].size() != adj[b].size() ? adj[a].size() < adj[b].size() : a < b; });
+      order.insert(order.end(), nb.begin(), nb.end());
+    }
+  }
+  std::reverse(order.begin(), order.end());
+  std::vector<int> iperm(n);
+  for (int k = 0; k < n; k++) iperm[order[k]] = k;
+  int bw = 0;
+  for (int j = 0; j < n; j++) for (int c : adj[j]) bw = std::max(bw, std::abs(iperm[j] - iperm[c]));
+  bd_.bw_symbolic = bw;
+  const int W = bw + kBatchNB;                              // column stride of the padded band (batch_hip.hip)
+  if (bw > kBatchDirectMaxBw || !be::batch_direct_lds_bytes(n, m, std::max(nzA, nzB), bw)) return;
+  // band slot (column-major band: slot = col * W + (row - col), row >= col, permuted indices) of the P + sigma I entries of B
+  std::vector<int> bp_slot(nzB, -1);
+  for (int j = 0; j < n; j++)
+    for (int k = Brp_[j]; k < Brp_[j + 1]; k++) {
+      const int c = Bj_[k];
+      if (c >= n) continue;
+      const int pr = iperm[j], pc = iperm[c];
+      if (pr >= pc) bp_slot[k] = pc * W + (pr - pc);
+    }
+  // products of A' rho A, grouped by slot
+  struct Prod { int slot, row, a, b; };
+  std::vector<Prod> prods; prods.reserve((size_t)pairs);
+  for (int i = 0; i < m; i++)
+    for (int a = Arp_[i]; a < Arp_[i + 1]; a++)
+      for (int b = a; b < Arp_[i + 1]; b++) {
+        const int pa = iperm[Arj_[a]], pb = iperm[Arj_[b]];
+        const int r = std::max(pa, pb), c = std::min(pa, pb);
+        prods.push_back({c * W + (r - c), i, a, b});
+      }
+  std::stable_sort(prods.begin(), prods.end(), [](const Prod &x, const Prod &y) { return x.slot < y.slot; });
+  std::vector<int> ke_slot, ke_ptr, kp_row(prods.size()), kp_a(prods.size()), kp_b(prods.size());
+  for (size_t p = 0; p < prods.size(); p++) {
+    if (p == 0 || prods[p].slot != prods[p - 1].slot) { ke_slot.push_back(prods[p].slot); ke_ptr.push_back((int)p); }
+    kp_row[p] = prods[p].row; kp_a[p] = prods[p].a; kp_b[p] = prods[p].b;
+  }
+  ke_ptr.push_back((int)prods.size());
+  std::vector<int> tri;
+  for (int a = 1; a <= bw; a++) for (int b = a; b <= bw; b++) tri.push_back(a | (b << 8));
+  auto up = [&](const std::vector<int> &h) { int *p = dev_vec<int>(d_, h.size()); if (!h.empty()) be::h2d(d_, p, h.data(), sizeof(int) * h.size()); return p; };
+  bd_.perm = up(order); bd_.bp_slot = up(bp_slot); bd_.ke_slot = up(ke_slot); bd_.ke_ptr = up(ke_ptr);
+  bd_.kp_row = up(kp_row); bd_.kp_a = up(kp_a); bd_.kp_b = up(kp_b); bd_.tri = up(tri);
+  bd_.kp_val = dev_vec<double>(d_, prods.size());
+  bd_.bw = bw; bd_.nents = (int)ke_slot.size(); bd_.nprod = (int)prods.size(); bd_.ntri = (int)tri.size();
+  bd_.ok = true;
+}
+
+void Engine::fill_batch_params(BatchParams &p, int nbatch, int warm) {
+  p.n = n; p.m = m; p.nbatch = nbatch; p.A = d_.A; p.B = d_.B; p.D = d_.D; p.Dinv = d_.Dinv; p.E = d_.E; p.Einv = d_.Einv;
+  p.c = c_; p.cinv = cinv_; p.sigma = settings.sigma; p.alpha = settings.alpha; p.rho0 = clamp_rho(settings.rho); p.eq_factor = eq_factor_mixed_;
+  p.eps_abs = settings.eps_abs; p.eps_rel = settings.eps_rel; p.eps_pinf = settings.eps_prim_inf; p.eps_dinf = settings.eps_dual_inf;
+  p.cg_frac = settings.cg_tol_fraction; p.rho_tol = settings.adaptive_rho_tolerance;
+  p.max_iter = settings.max_iter; p.check = settings.check_termination; p.rho_interval = settings.adaptive_rho ? auto_rho_interval() : 0;
+  p.cg_max = settings.cg_max_iter; p.unscaled = settings.scaling && !settings.scaled_termination; p.scaling = settings.scaling;
+  p.precond = settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER; p.rho_is_vec = settings.rho_is_vec; p.warm = warm;
+  p.polish = settings.polishing; p.refine = settings.polish_refine_iter; p.delta = settings.delta;      // (honoured by the direct variants)
+  p.variant = pol_.batch_variant;
+}
+
+void Engine::attach_batch_direct(BatchParams &p) {
+  if (!bd_.ok) return;
+  p.eq_factor_direct = eq_factor_set_ ? eq_factor_mixed_ : 1e3;
+  p.bw = bd_.bw; p.nents = bd_.nents; p.ntri = bd_.ntri; p.perm = bd_.perm; p.bp_slot = bd_.bp_slot; p.ke_slot = bd_.ke_slot;
+  p.ke_ptr = bd_.ke_ptr; p.kp_row = bd_.kp_row; p.kp_val = bd_.kp_val; p.tri = bd_.tri;
+}
+
+// ------------------------------------------------------------------------------------------------ small problems
+// A QP small enough for the batch kernel's DIRECT variant (iterates, matrices and the banded LDL' factor of the reduced
+// KKT matrix in one workgroup's LDS) is solved by ONE launch of that kernel with a batch of one: the whole ADMM loop runs
+// on the device with exact linear solves and the reference's rho rule, i.e. the algorithm of the reference's direct path
+// (same iteration counts as the oracle), instead of thousands of graph-replayed multi-kernel iterations with inexact
+// inner solves -- on small LPs / rank-deficient QPs the latter can need 10x more ADMM iterations (fuzz).
+// With `polishing`, a SOLVED problem is polished in the same launch (reduced KKT system on the active set, factorised in LDS,
+// polish_refine_iter refinement steps: the reference's algorithm, _osqp.py:1710-1828).  Not taken with verbose
+// output (per-iteration printing lives in the host-driven loop), with a time limit, or when OSQP_HIP_SMALL_DIRECT=0.
+bool Engine::small_direct_applicable() {
+  if (!pol_.small_direct || !be::device_assembly() || settings.verbose || settings.time_limit < 1e9 || reordered_) return false;
+  if (settings.check_dualgap) return false;            // the one-launch kernel has no duality-gap test: the host-driven loop honours the setting
+  if (!be::batch_lds_bytes(n, m)) return false;
+  prepare_batch_direct();
+  if (!bd_.ok) return false;
+  BatchParams p{};
+  fill_batch_params(p, 1, 0);
+  attach_batch_direct(p);
+  return be::batch_direct_selected(p);
+}
+
+int Engine::solve_small_direct(double t0) {
+  const int warm = settings.warm_starting ? 1 : 0;
+  std::vector<double> x(n, 0.0), y(std::max(m, 1), 0.0);       // (m = 0: batch_solve still wants a non-null y)
+  if (warm) {                                                   // continue from the device iterates (x, y; z = A x as in warm_start)
+    be::d2h(d_, x.data(), d_.x, sizeof(double) * n);
+    if (m > 0) be::d2h(d_, y.data(), d_.y, sizeof(double) * m);
+    for (int j = 0; j < n; j++) x[j] *= D_[j];
+    for (int i = 0; i < m; i++) y[i] *= cinv_ * E_[i];
+  }
+  double rec[kBatchRec] = {0};
+  // (the handle's own scaled z goes in and out by device pointer: a continued solve keeps its z iterate, _osqp.py:1197-1204)
+  const int err = batch_solve(1, nullptr, nullptr, nullptr, x.data(), y.data(), rec, warm, m > 0 ? d_.z : nullptr);
+  if (err) return err;
+  const int st = (int)rec[0];
+  set_status(st);
+  info.iter = (int)rec[1]; info.obj_val = rec[2]; info.prim_res = rec[3]; info.dual_res = rec[4];
+  info.rho_updates = (int)rec[6]; info.rho_estimate = rec[10];                 // (_osqp.py:1275)
+  info.status_polish = (int)rec[8]; info.polish_time = rec[9];      // polished inside the kernel (reduced KKT on the factor in LDS)
+  if (rec[5] != rho_bar_) {                                     // adaptive rho moved: keep the handle's state in step (_osqp.py:923-930)
+    rho_bar_ = clamp_rho(rec[5]); settings.rho = rho_bar_;
+    be::set_rho(d_, rho_bar_);
+    be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  }
+  const bool pinf = st == OSQP_PRIMAL_INFEASIBLE || st == OSQP_PRIMAL_INFEASIBLE_INACCURATE;
+  const bool dinf = st == OSQP_DUAL_INFEASIBLE || st == OSQP_DUAL_INFEASIBLE_INACCURATE;
+  std::fill(sol_pc_.begin(), sol_pc_.end(), kNaN); std::fill(sol_dc_.begin(), sol_dc_.end(), kNaN);
+  const bool finite_xy = std::isfinite(rec[2]) && st != OSQP_NON_CVX;
+  if (!pinf && !dinf) {
+    std::copy(x.begin(), x.end(), sol_x_.begin()); std::copy(y.begin(), y.begin() + m, sol_y_.begin());   // (solution.x/y point into these)
+    if (finite_xy) {
+      const int keep = settings.warm_starting;
+      warm_start(x.data(), m > 0 ? y.data() : nullptr, /*keep_z=*/true);   // device x, y follow; z is the kernel's own (a later solve continues from them)
+      settings.warm_starting = keep;
+      // the v1 gap fields (update_gap_info) from the unscaled data on the host: a few hundred entries
+      ensure_host_vectors();
+      std::vector<double> px(n, 0.0), ax(m, 0.0), aty(n, 0.0);
+      for (int j = 0; j < n; j++)
+        for (int k = P_.p[j]; k < P_.p[j + 1]; k++) { const int i = P_.i[k]; px[i] += P_.x[k] * x[j]; if (i != j) px[j] += P_.x[k] * x[i]; }
+      for (int j = 0; j < n; j++)
+        for (int k = A_.p[j]; k < A_.p[j + 1]; k++) { ax[A_.i[k]] += A_.x[k] * x[j]; aty[j] += A_.x[k] * y[A_.i[k]]; }
+      double xpx = 0, sup = 0, nax = 0, nz = 0, npx = 0, naty = 0, nq = 0;
+      for (int j = 0; j < n; j++) { xpx += x[j] * px[j]; npx = std::max(npx, std::fabs(px[j])); naty = std::max(naty, std::fabs(aty[j])); nq = std::max(nq, std::fabs(q0_[j])); }
+      for (int i = 0; i < m; i++) {
+        if (y[i] > 0 && u0_[i] < OSQP_INFTY * kMinScaling) sup += u0_[i] * y[i];
+        else if (y[i] < 0 && l0_[i] > -OSQP_INFTY * kMinScaling) sup += l0_[i] * y[i];
+        nax = std::max(nax, std::fabs(ax[i])); nz = std::max(nz, std::fabs(std::min(std::max(ax[i], l0_[i]), u0_[i])));
+      }
+      info.dual_obj_val = -0.5 * xpx - sup;
+      info.duality_gap = info.obj_val - info.dual_obj_val;
+      const double tiny = 1e-10, gn = std::max(std::fabs(info.obj_val), std::fabs(info.dual_obj_val));
+      info.rel_kkt_error = std::max(std::max(m == 0 ? 0.0 : info.prim_res / (std::max(nax, nz) + tiny), info.dual_res / (std::max(std::max(npx, naty), nq) + tiny)),
+                                    std::fabs(info.duality_gap) / (gn + tiny));
+    } else {
+      cold_start();                                             // NaN iterates (non-convex problem) are no warm start
+      info.dual_obj_val = info.duality_gap = info.rel_kkt_error = kNaN;
+    }
+  } else {
+    std::fill(sol_x_.begin(), sol_x_.end(), kNaN); std::fill(sol_y_.begin(), sol_y_.end(), kNaN);
+    if (pinf) std::copy(y.begin(), y.begin() + m, sol_pc_.begin()); else std::copy(x.begin(), x.end(), sol_dc_.begin());                    // the kernel returns the certificate in place of y / x
+    cold_start();
+  }
+  stats_.pcg_iters_total = stats_.pcg_iters_max = stats_.pcg_unconverged = 0;
+  stats_.kernel_launches = 1; stats_.graph_launches = 0;
+  be::sync(d_);
+  info.solve_time = std::max(now_s() - t0 - info.polish_time, 0.0);
+  info.run_time = (first_run_ ? info.setup_time : info.update_time) + info.solve_time + info.polish_time;
+  first_run_ = false; clear_update_time_ = true;
+  return OSQP_NO_ERROR;
+}
+
+int Engine::batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, double *zs_dev) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (nbatch <= 0 || !x || !y || !rec) return OSQP_DATA_VALIDATION_ERROR;
+  prepare_batch_direct();                                     // (symbolic part runs on every backend: tests read the bandwidth)
+  if (!be::batch_lds_bytes(n, m) || reordered_) return OSQP_FUNC_NOT_IMPLEMENTED;      // (a reordered handle is a large single QP: the batch kernel is for QPs that fit one workgroup)
+  be::activate(d_);
+  be::ext_wait(d_);                                 // the scratch block may still be read by a kernel on a caller's stream
+  const bool timing = pol_.batch_timing != 0;
+  double tph[5]; tph[0] = now_s();
+  const size_t N = (size_t)nbatch * n, M = (size_t)nbatch * m;
+  if ((l || u) && !(l && u)) ensure_host_vectors();
+  for (int b = 0; b < nbatch && (l || u); b++)                                                       // _osqp.py:1348-1349
+    for (int i = 0; i < m; i++) {
+      const double li = l ? l[(size_t)b * m + i] : l0_[i], ui = u ? u[(size_t)b * m + i] : u0_[i];
+      if (!(li <= ui)) return OSQP_DATA_VALIDATION_ERROR;
+    }
+  tph[1] = now_s();
+  // one device scratch block, kept for the next call: [q | l | u | x | y | rec | q0 | l0 | u0]
+  const size_t need = 2 * N + 3 * M + (size_t)nbatch * kBatchRec + n + 2 * (size_t)m;
+  if (need > bbuf_cap_) { if (bbuf_) be::dfree(d_, bbuf_); bbuf_ = dev_vec<double>(d_, need); bbuf_cap_ = need; }
+  double *dq = bbuf_, *dl = dq + N, *du = dl + M, *dx = du + M, *dy = dx + N, *drec = dy + M, *dq0 = drec + (size_t)nbatch * kBatchRec, *dl0 = dq0 + n, *du0 = dl0 + m;
+  const bool devv = be::device_vec_updates();         // then the solver's own q, l, u are resident (unscaled): no upload for NULL arguments
+  if (q) be::h2d(d_, dq, q, sizeof(double) * N); else if (devv) dq0 = d_.qraw; else be::h2d(d_, dq0, q0_.data(), sizeof(double) * n);
+  if (l) be::h2d(d_, dl, l, sizeof(double) * M); else if (devv) dl0 = d_.lraw; else be::h2d(d_, dl0, l0_.data(), sizeof(double) * m);
+  if (u) be::h2d(d_, du, u, sizeof(double) * M); else if (devv) du0 = d_.uraw; else be::h2d(d_, du0, u0_.data(), sizeof(double) * m);
+  if (warm) { be::h2d(d_, dx, x, sizeof(double) * N); be::h2d(d_, dy, y, sizeof(double) * M); }
+  be::sync(d_); tph[2] = now_s();
+  BatchParams p{};
+  fill_batch_params(p, nbatch, warm);
+  p.q = q ? dq : nullptr; p.l = l ? dl : nullptr; p.u = u ? du : nullptr; p.q0 = dq0; p.l0 = dl0; p.u0 = du0; p.x = dx; p.y = dy; p.rec = drec;
+  p.zs = zs_dev;
+  // Launch order: the problems that took most iterations in the PREVIOUS call of the same size go first (parametric batches -- MPC
+  // steps, training epochs -- repeat their hard problems; with index order the last round of workgroups waits for stragglers:
+  // 4096 MPC QPs 13.3 -> 11 ms).  Scheduling only: every problem is solved by its own workgroup exactly as before.
+  const bool reorder = pol_.batch_reorder != 0;
+  if (reorder && nbatch > 1 && (int)batch_order_.size() == nbatch) {
+    if ((size_t)nbatch > batch_order_cap_) {
+      if (d_batch_order_) be::dfree(d_, d_batch_order_);
+      if (d_batch_iters_) { be::dfree(d_, d_batch_iters_); d_batch_iters_ = nullptr; d_batch_iters_n_ = 0; }
+      d_batch_order_ = dev_vec<int>(d_, nbatch); batch_order_cap_ = nbatch;
+    }
+    be::h2d(d_, d_batch_order_, batch_order_.data(), sizeof(int) * nbatch);
+    p.order = d_batch_order_;
+  }
+  d_batch_iters_n_ = 0;                            // (the device-pointer path's history does not describe this call)
+  prepare_batch_direct();
+  if (bd_.ok) {
+    be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);             // A's values may have changed since the last call
+    attach_batch_direct(p);
+  }
+  int err = be::batch_solve(d_, p);
+  tph[3] = now_s();
+  if (!err) {
+    be::d2h(d_, x, dx, sizeof(double) * N); be::d2h(d_, y, dy, sizeof(double) * M); be::d2h(d_, rec, drec, sizeof(double) * kBatchRec * nbatch);
+    if (reorder && nbatch > 1) {
+      batch_order_.resize(nbatch);
+      for (int b = 0; b < nbatch; b++) batch_order_[b] = b;
+      std::stable_sort(batch_order_.begin(), batch_order_.end(), [&](int a, int b) { return rec[(size_t)a * kBatchRec + 1] > rec[(size_t)b * kBatchRec + 1]; });
+    }
+  }
+  tph[4] = now_s();
+  stats_.gpu_solve_ms = 1e3 * (tph[3] - tph[2]);
+  if (timing) std::fprintf(stderr, "osqp_hip batch: validate %.2f ms, H2D %.2f ms, kernel %.2f ms, D2H %.2f ms\n", 1e3 * (tph[1] - tph[0]), 1e3 * (tph[2] - tph[1]), 1e3 * (tph[3] - tph[2]), 1e3 * (tph[4] - tph[3]));
+  return err;
+}
+
+
+// Device-resident variant: q, l, u, x, y, rec are device pointers on this solver's device; the kernel is
+// enqueued on the caller's stream and not waited for (stream == nullptr: the solver's stream, synchronous).
+int Engine::batch_solve_device(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, void *stream) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  // nbatch == 0: the applicability query of a rank whose share of a sharded batch is empty -- the answer depends on (n, m) alone, so every
+  // rank of a job reaches the same decision before its first collective (osqp_amd/sharded.py)
+  if (nbatch == 0) return (be::batch_lds_bytes(n, m) && !reordered_) ? OSQP_NO_ERROR : OSQP_FUNC_NOT_IMPLEMENTED;
+  if (nbatch < 0 || !x || !y || !rec) return OSQP_DATA_VALIDATION_ERROR;
+  if (!be::batch_lds_bytes(n, m) || reordered_) return OSQP_FUNC_NOT_IMPLEMENTED;
+  be::activate(d_);
+  be::ext_wait(d_);                                 // the previous device-pointer call: its kernel reads the shared vectors and kp_val
+  // shared vectors (for the arguments given as NULL): the solver's own resident unscaled q, l, u
+  double *dq0 = d_.qraw, *dl0 = d_.lraw, *du0 = d_.uraw;
+  BatchParams p{};
+  fill_batch_params(p, nbatch, warm);
+  p.q = q; p.l = l; p.u = u; p.q0 = dq0; p.l0 = dl0; p.u0 = du0; p.x = x; p.y = y; p.rec = rec;
+  // launch order as in batch_solve, entirely on the device: the kernel leaves every problem's iteration count, a rank kernel turns
+  // the previous call's counts into this call's order (both on the caller's stream: ordered with the batch kernels themselves)
+  const bool reorder = pol_.batch_reorder != 0;
+  if (reorder && nbatch > 1) {
+    if ((size_t)nbatch > batch_order_cap_) {           // (both buffers have the same capacity)
+      if (d_batch_order_) be::dfree(d_, d_batch_order_);
+      if (d_batch_iters_) be::dfree(d_, d_batch_iters_);
+      d_batch_order_ = dev_vec<int>(d_, nbatch); d_batch_iters_ = nullptr; batch_order_cap_ = nbatch; d_batch_iters_n_ = 0;
+    }
+    if (!d_batch_iters_) { d_batch_iters_ = dev_vec<int>(d_, batch_order_cap_); d_batch_iters_n_ = 0; }
+    be::sync(d_);                                    // (allocations / zero fills ran on the solver's stream)
+    if (d_batch_iters_n_ == nbatch) { be::batch_order(d_, nbatch, d_batch_iters_, d_batch_order_, stream); p.order = d_batch_order_; }
+    p.iters_out = d_batch_iters_;
+    d_batch_iters_n_ = nbatch;
+    batch_order_.clear();                            // (the host path's order does not describe this call)
+  }
+  prepare_batch_direct();
+  if (bd_.ok) {
+    be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);
+    attach_batch_direct(p);
+  }
+  be::sync(d_);                                   // the uploads and the product refresh ran on the solver's stream
+  const int err = be::batch_solve(d_, p, stream);
+  if (!err) be::ext_record(d_, stream);           // later calls that overwrite or free what this kernel reads wait for it (ext_wait)
+  return err;
+}
+
+int Engine::get_stats(OSQPHipStats *out) {
+  if (!out) return OSQP_DATA_VALIDATION_ERROR;
+  *out = stats_; out->pcg_fused = (d_.f1.on && use_slots_) ? 2.0 : (be::pcg_fused(d_) ? 1.0 : 0.0); out->batch_direct_bw = bd_.bw_symbolic;
+  out->f1_replicas = d_.f1.on ? d_.f1.D : 0;
+  out->woodbury_rows = d_.wb.on ? d_.wb.r : 0; out->woodbury_direct = (d_.wb.on && d_.wb.exact) ? ((d_.wb.x.on) ? 2 : 1) : 0;
+  out->windowed_blocks = d_.A.nwin + d_.B.nwin; out->row_blocks = d_.A.nblk + d_.B.nblk;
+  out->reordered = reordered_ ? 1.0 : 0.0; out->reorder_ms = reorder_ms_;
+  // which preconditioner the PCG of this handle runs with RIGHT NOW (the setting cg_precond = diagonal selects the Jacobi family; the
+  // Woodbury correction for dense rows is the engine's addition: OSQPHipPolicy::woodbury / woodbury_large switch it off)
+  out->preconditioner = settings.cg_precond != OSQP_DIAGONAL_PRECONDITIONER ? OSQP_HIP_PRECOND_NONE
+                        : !d_.wb.on ? OSQP_HIP_PRECOND_JACOBI : (d_.wb.large ? OSQP_HIP_PRECOND_JACOBI_WOODBURY_DENSE : OSQP_HIP_PRECOND_JACOBI_WOODBURY);
+  return OSQP_NO_ERROR;
+}
+int Engine::time_kernel(int which, int reps, double *ms) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  if (which < 0 || which > 16 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
+  *ms = be::time_kernel(d_, which, reps);
+  return OSQP_NO_ERROR;
+}
+int Engine::trace_read(unsigned long long *out, int count) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (!out || count <= 0) return OSQP_DATA_VALIDATION_ERROR;
+  return be::ktrace_read(d_, out, count) ? OSQP_NO_ERROR : OSQP_FUNC_NOT_IMPLEMENTED;
+}
+int Engine::test_spmv(int which, const double *in, double *out) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  be::activate(d_);
+  const int nin = which == 0 ? n : n + m, nout = which == 0 ? m : n;
+  double *din = dev_vec<double>(d_, nin), *dout = dev_vec<double>(d_, nout);
+  std::vector<double> hin(in, in + nin), hout(nout);
+  if (reordered_) {                                   // (vectors of the caller's numbering, like everything else at the API)
+    for (int j = 0; j < n; j++) hin[j] = in[pc_[j]];
+    if (which != 0) for (int i = 0; i < m; i++) hin[n + i] = in[n + pr_[i]];
+  }
+  be::h2d(d_, din, hin.data(), sizeof(double) * nin);
+  be::test_spmv(d_, which, din, dout);
+  be::d2h(d_, hout.data(), dout, sizeof(double) * nout);
+  for (int k = 0; k < nout; k++) out[reordered_ ? (which == 0 ? pr_[k] : pc_[k]) : k] = hout[k];
+  be::dfree(d_, din); be::dfree(d_, dout);
+  return OSQP_NO_ERROR;
+}
+int Engine::get_reordering(int *perm_cols, int *perm_rows) const {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  if (!perm_cols || (m > 0 && !perm_rows)) return OSQP_DATA_VALIDATION_ERROR;
+  for (int j = 0; j < n; j++) perm_cols[j] = reordered_ ? pc_[j] : j;
+  for (int i = 0; i < m; i++) perm_rows[i] = reordered_ ? pr_[i] : i;
+  return OSQP_NO_ERROR;
+}
+int Engine::get_scaling(double *D, double *E, double *c) {
+  if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
+  for (int j = 0; j < n; j++) D[reordered_ ? pc_[j] : j] = D_[j];
+  for (int i = 0; i < m; i++) E[reordered_ ? pr_[i] : i] = E_[i];
+  *c = c_;
+  return OSQP_NO_ERROR;
+}
+
+
+}  // namespace osqp_hip

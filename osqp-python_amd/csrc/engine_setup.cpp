@@ -1,0 +1,616 @@
+// engine_setup.cpp -- Engine::setup and what it plans: the bandwidth-reducing reordering (compute_reorder / apply_reorder), the plan of the
+// one-launch PCG form (plan_f1 / upload_f1), the plan of the Woodbury-corrected preconditioner and its two-launch direct mode (prepare_wb).
+// See engine.hpp; formulas cite /root/reference/src/osqppurepy/_osqp.py.
+#include "engine_internal.hpp"
+
+namespace osqp_hip {
+
+// ------------------------------------------------------------------------------------------------ reordering
+// A QP whose band structure is hidden by the order in which its variables and constraints happen to be numbered takes the slow
+// path (global gathers, two launches per PCG iteration) although a permutation would make it banded.  compute_reorder finds one:
+//   1. breadth-first order of the COLUMNS through the bipartite graph of A (column -> its rows -> their columns) joined with P's
+//      pattern, started from a pseudo-peripheral column (two sweeps), component by component (Cuthill-McKee levels);
+//   2. three barycentre sweeps -- a row sits at the mean rank of its columns, a column moves to the mean position of its rows,
+//      ranks are renewed by sorting -- which straighten the arbitrary order inside the BFS levels (measured on config 2 with shuffled
+//      rows and columns: window of a 1000-entry row block 287 columns as generated, 331 after the BFS, 286 after two sweeps);
+//   3. rows sorted by the middle of their (new) column range.
+// O(nnz) per sweep + two sorts of n / m keys; runs only when the natural order does not admit the one-launch form.
+void Engine::compute_reorder(const std::vector<int> &Arp, const std::vector<int> &Arj, const std::vector<int> &Brp, const std::vector<int> &Bj) {
+  std::vector<int> cstamp(n, 0), rstamp(m, 0), comp_done(n, 0), order, sweep, best;
+  order.reserve(n);
+  int stamp = 0;
+  auto bfs = [&](int start, std::vector<int> &out) {
+    out.clear(); stamp++;
+    out.push_back(start); cstamp[start] = stamp;
+    for (size_t h = 0; h < out.size(); h++) {
+      const int j = out[h];
+      for (int k = A_.p[j]; k < A_.p[j + 1]; k++) {
+        const int i = A_.i[k];
+        if (rstamp[i] == stamp) continue;
+        rstamp[i] = stamp;
+        for (int e = Arp[i]; e < Arp[i + 1]; e++) { const int c = Arj[e]; if (cstamp[c] != stamp) { cstamp[c] = stamp; out.push_back(c); } }
+      }
+      for (int k = Brp[j]; k < Brp[j + 1] && Bj[k] < n; k++) { const int c = Bj[k]; if (cstamp[c] != stamp) { cstamp[c] = stamp; out.push_back(c); } }
+    }
+  };
+  for (int s0 = 0; s0 < n; s0++) {
+    if (comp_done[s0]) continue;
+    bfs(s0, sweep);
+    if (sweep.size() > 2) { bfs(sweep.back(), best); bfs(best.back(), sweep); }      // pseudo-peripheral start: the far end of the far end
+    for (int c : sweep) { comp_done[c] = 1; order.push_back(c); }
+  }
+  std::vector<double> rank(n), prow(m), pcol(n);
+  for (int k = 0; k < n; k++) rank[order[k]] = k;
+  std::vector<int> idx(n);
+  for (int it = 0; it < 3; it++) {
+    for (int i = 0; i < m; i++) {
+      const int cnt = Arp[i + 1] - Arp[i];
+      double s = 0; for (int e = Arp[i]; e < Arp[i + 1]; e++) s += rank[Arj[e]];
+      prow[i] = cnt ? s / cnt : 0.0;
+    }
+    for (int j = 0; j < n; j++) {
+      const int cnt = A_.p[j + 1] - A_.p[j];
+      double s = 0; for (int k = A_.p[j]; k < A_.p[j + 1]; k++) s += prow[A_.i[k]];
+      pcol[j] = cnt ? s / cnt : rank[j];
+    }
+    for (int j = 0; j < n; j++) idx[j] = j;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return pcol[a] < pcol[b] || (pcol[a] == pcol[b] && rank[a] < rank[b]); });
+    for (int k = 0; k < n; k++) rank[idx[k]] = k;
+  }
+  pc_.assign(n, 0); ipc_.assign(n, 0);
+  for (int j = 0; j < n; j++) { ipc_[j] = (int)rank[j]; pc_[(int)rank[j]] = j; }
+  std::vector<long> key(m);
+  for (int i = 0; i < m; i++) {
+    int lo = INT32_MAX, hi = -1;
+    for (int e = Arp[i]; e < Arp[i + 1]; e++) { lo = std::min(lo, ipc_[Arj[e]]); hi = std::max(hi, ipc_[Arj[e]]); }
+    key[i] = hi >= 0 ? (long)lo + hi : 2L * n;                       // (empty rows last)
+  }
+  pr_.resize(m);
+  for (int i = 0; i < m; i++) pr_[i] = i;
+  std::stable_sort(pr_.begin(), pr_.end(), [&](int a, int b) { return key[a] < key[b]; });
+  ipr_.assign(m, 0);
+  for (int i = 0; i < m; i++) ipr_[pr_[i]] = i;
+}
+
+// P_, A_, q0_, l0_, u0_ <- the permuted problem; PvalMap_ / AvalMap_ = where each of the caller's stored entries went.  Entries keep the
+// caller's relative order inside a (row, column) pair (a CSC may repeat an entry), columns come out with ascending row indices.
+void Engine::apply_reorder() {
+  auto permute_csc = [&](HostCsc &M, const std::vector<int> &rmap, const std::vector<int> &cmap, bool upper, std::vector<int> &vmap) {
+    const int nz = M.nnz(), nr = M.nr, nc = M.nc;
+    std::vector<int> ri(nz), ci(nz);
+    for (int j = 0; j < nc; j++)
+      for (int k = M.p[j]; k < M.p[j + 1]; k++) {
+        int r = rmap[M.i[k]], c = cmap[j];
+        if (upper && r > c) std::swap(r, c);
+        ri[k] = r; ci[k] = c;
+      }
+    // stable counting sort by row, then by column: sorted by (column, row), ties in the caller's order
+    std::vector<int> byrow(nz), cnt(std::max(nr, nc) + 1, 0);
+    for (int k = 0; k < nz; k++) cnt[ri[k] + 1]++;
+    for (int r = 0; r < nr; r++) cnt[r + 1] += cnt[r];
+    for (int k = 0; k < nz; k++) byrow[cnt[ri[k]]++] = k;
+    HostCsc O; O.nr = nr; O.nc = nc; O.p.assign(nc + 1, 0); O.i.resize(nz); O.x.resize(nz);
+    for (int k = 0; k < nz; k++) O.p[ci[k] + 1]++;
+    for (int c = 0; c < nc; c++) O.p[c + 1] += O.p[c];
+    std::vector<int> cur(O.p.begin(), O.p.end() - 1);
+    vmap.assign(nz, 0);
+    for (int t = 0; t < nz; t++) { const int k = byrow[t], pos = cur[ci[k]]++; O.i[pos] = ri[k]; O.x[pos] = M.x[k]; vmap[k] = pos; }
+    M = std::move(O);
+  };
+  permute_csc(P_, ipc_, ipc_, true, PvalMap_);
+  permute_csc(A_, ipr_, ipc_, false, AvalMap_);
+  q0_ = to_internal_n(q0_.data()); l0_ = to_internal_m(l0_.data()); u0_ = to_internal_m(u0_.data());
+  reordered_ = true;
+}
+
+void Engine::clear_reorder() {
+  reordered_ = false;
+  pc_.clear(); pr_.clear(); ipc_.clear(); ipr_.clear(); PvalMap_.clear(); AvalMap_.clear();
+}
+
+// ------------------------------------------------------------------------------------------------ F1 plan
+// One launch per PCG iteration (backend.h DevF1): symbolic data, built once at setup from the row blocks of A.  The form applies when
+// every row block of A has a column window of at most kF1Win columns and at most kF1MaxRows rows, the windows of blocks g and g + D
+// never overlap for some D <= kF1MaxD (banded / block-banded A -- as given, or after Engine::reorder has found the band), and the
+// columns can be dealt out to the blocks as OWN columns -- consecutive ranges [cs[g], cs[g+1]) inside the block's window, at most
+// kF1MaxOwn of them with at most kF1PChunk entries of P + sigma I.  Anything else keeps the two-kernel form.  OSQPHipPolicy::f1 = 0
+// switches the plan off.  plan_f1 is host-only (no device state is touched: setup may try several row blockings / orderings).
+bool Engine::plan_f1(const std::vector<int> &rb, const std::vector<int> &Arp, const std::vector<int> &Arj,
+                     const std::vector<int> &Brp, const std::vector<int> &Bj, F1Plan &pl) {
+  pl = F1Plan();
+  if (!pol_.f1) return false;
+  const int nb = (int)rb.size() - 1;
+  if (!be::device_assembly() || m == 0 || nb < kGrid / 4) return false;      // (few blocks: most workgroups would idle in the vector update)
+  std::vector<int> a0(nb), wl(nb), lo0(nb), hi0(nb);
+  for (int b = 0; b < nb; b++) {
+    const int r0 = rb[b], r1 = rb[b + 1], k0 = Arp[r0], k1 = Arp[r1];
+    if (k1 == k0 || r1 - r0 > kF1MaxRows || k1 - k0 > kF1Chunk || (r1 - r0 == 1 && k1 - k0 > kLongRow)) return false;
+    int lo = INT32_MAX, hi = -1;
+    for (int k = k0; k < k1; k++) { lo = std::min(lo, Arj[k]); hi = std::max(hi, Arj[k]); }
+    if (hi - lo + 1 > kF1Win) return false;
+    lo0[b] = lo; hi0[b] = hi;
+  }
+  // own columns: cs[g] follows the rows (rb[g] n / m: on a band of slope n / m these are the columns under the block) and is clamped into
+  // what the neighbouring windows allow -- a column left of block g's window belongs to an earlier block, one right of block g - 1's
+  // window to a later one; a column no window holds goes to the block in front of the gap
+  std::vector<int> cs(nb + 1);
+  cs[0] = 0;
+  for (int g = 1; g < nb; g++) {
+    const int ideal = (int)((long)rb[g] * n / m);
+    const int lo = std::max(cs[g - 1], std::min(lo0[g], n)), up = hi0[g - 1] + 1;
+    cs[g] = lo <= up ? std::min(std::max(ideal, lo), up) : lo;
+    cs[g] = std::min(std::max(cs[g], cs[g - 1]), n);
+  }
+  cs[nb] = n;
+  for (int b = 0; b < nb; b++) {
+    // (the scatter window also covers the block's own columns: (P + sigma I) u of those joins the block's slice of A' t; a column
+    //  without entries of the block's rows simply has an empty segment)
+    int lo = lo0[b], hi = hi0[b];
+    if (cs[b + 1] > cs[b]) { lo = std::min(lo, cs[b]); hi = std::max(hi, cs[b + 1] - 1); }
+    if (hi - lo + 1 > kF1Win) return false;
+    a0[b] = lo; wl[b] = hi - lo + 1;
+  }
+  int D = 0;
+  for (int t = 1; t <= kF1MaxD && !D; t++) {
+    bool ok = true;
+    for (int g = 0; g + t < nb && ok; g++) ok = a0[g] + wl[g] <= a0[g + t];
+    if (ok) D = t;
+  }
+  if (!D) return false;
+  // the compact CSR of P + sigma I (row j of B up to its first A' entry)
+  std::vector<int> &prp = pl.prp; prp.assign(n + 1, 0);
+  for (int j = 0; j < n; j++) { int c = 0; for (int k = Brp[j]; k < Brp[j + 1] && Bj[k] < n; k++) c++; prp[j + 1] = prp[j] + c; }
+  const int pnnz = prp[n];
+  std::vector<int> &pcol = pl.pcol, &psrc = pl.psrc; pcol.assign(std::max(pnnz, 1), 0); psrc.assign(std::max(pnnz, 1), 0);
+  for (int j = 0; j < n; j++) for (int k = Brp[j], o = prp[j]; k < Brp[j + 1] && Bj[k] < n; k++, o++) { pcol[o] = Bj[k]; psrc[o] = k; }
+  std::vector<int> &blk = pl.blk; blk.assign(16 * (size_t)nb, 0);
+  std::vector<unsigned int> &ent = pl.ent; ent.assign(Arj.size(), 0u);
+  std::vector<unsigned short> &cptr = pl.cptr; cptr.clear();
+  std::vector<int> order, tpos;
+  for (int b = 0; b < nb; b++) {
+    if (cs[b + 1] - cs[b] > kF1MaxOwn || prp[cs[b + 1]] - prp[cs[b]] > kF1PChunk) return false;
+    const int r0 = rb[b], r1 = rb[b + 1], k0 = Arp[r0], k1 = Arp[r1], cnt = k1 - k0;
+    int *w = &blk[16 * (size_t)b];
+    w[0] = r0; w[1] = r1; w[2] = k0; w[3] = k1;
+    w[4] = b < D ? 0 : a0[b]; w[5] = b + D < nb ? a0[b + D] : n; w[6] = cs[b]; w[7] = cs[b + 1];
+    w[8] = (int)cptr.size(); w[9] = prp[cs[b]]; w[10] = prp[cs[b + 1]]; w[11] = 0;
+    // gather window: the columns of the block's rows of A, together with those of its own rows of P + sigma I when that widens the
+    // window by at most a quarter (every window column costs 4 + D vector loads; a P entry outside the window costs as many, once)
+    int g0 = a0[b], g1 = a0[b] + wl[b];
+    for (int k = prp[cs[b]]; k < prp[cs[b + 1]]; k++) { g0 = std::min(g0, pcol[k]); g1 = std::max(g1, pcol[k] + 1); }
+    if (g1 - g0 > kF1Win || 4 * (g1 - g0) > 5 * wl[b]) { g0 = a0[b]; g1 = a0[b] + wl[b]; }
+    w[12] = g0; w[13] = g1 - g0; w[14] = a0[b]; w[15] = wl[b];
+    // column-major order of the block's entries: stable by local column (rows ascending within a column)
+    order.resize(cnt);
+    for (int e = 0; e < cnt; e++) order[e] = e;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Arj[k0 + x] < Arj[k0 + y]; });
+    tpos.resize(cnt);
+    for (int t = 0; t < cnt; t++) tpos[order[t]] = t;
+    for (int r = r0; r < r1; r++)
+      for (int k = Arp[r]; k < Arp[r + 1]; k++)
+        ent[k] = (unsigned)(Arj[k] - g0) | ((unsigned)(r - r0) << 9) | ((unsigned)tpos[k - k0] << 18);
+    const size_t base = cptr.size();
+    cptr.resize(base + wl[b] + 1, 0);
+    for (int e = 0; e < cnt; e++) cptr[base + (Arj[k0 + e] - a0[b]) + 1]++;
+    for (int c = 0; c < wl[b]; c++) cptr[base + c + 1] = (unsigned short)(cptr[base + c + 1] + cptr[base + c]);
+  }
+  pl.D = D; pl.pnnz = pnnz; pl.ok = true;
+  return true;
+}
+
+void Engine::upload_f1(const F1Plan &pl) {
+  d_.f1 = DevF1();
+  if (!pl.ok) return;
+  auto up_i = [&](const std::vector<int> &h) { int *p = dev_vec<int>(d_, h.size()); if (!h.empty()) be::h2d(d_, p, h.data(), sizeof(int) * h.size()); return p; };
+  DevF1 &f = d_.f1;
+  f.D = pl.D; f.pnnz = pl.pnnz;
+  f.blk = up_i(pl.blk); f.prp = up_i(pl.prp); f.pcol = up_i(pl.pcol); f.psrc = up_i(pl.psrc);
+  f.ent = dev_vec<unsigned int>(d_, pl.ent.size()); be::h2d(d_, f.ent, pl.ent.data(), sizeof(unsigned int) * pl.ent.size());
+  f.cptr = dev_vec<unsigned short>(d_, pl.cptr.size()); be::h2d(d_, f.cptr, pl.cptr.data(), sizeof(unsigned short) * pl.cptr.size());
+  f.pval = dev_vec<double>(d_, pl.pnnz);
+  f.ns = ((size_t)n + 31) / 32 * 32;                       // 256-byte aligned vectors
+  f.va = dev_vec<double>(d_, (7 + 2 * (size_t)pl.D) * f.ns);
+  f.on = 1;
+}
+
+// ------------------------------------------------------------------------------------------------ Woodbury plan
+// backend.h DevWb: the rows of A with more than kLongRow entries, when there are between 1 and kWbMaxRows of them, are treated exactly
+// in the preconditioner.  Symbolic data: the long rows as their own CSR (r x n), its transpose (n x r), where each entry sits in A.val.
+void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj) {
+  d_.wb = DevWb();
+  if (!pol_.woodbury || !be::wb_supported() || settings.cg_precond != OSQP_DIAGONAL_PRECONDITIONER || m == 0) return;
+  std::vector<int> rows;
+  for (int i = 0; i < m; i++) if (Arp[i + 1] - Arp[i] > kLongRow) rows.push_back(i);
+  const int r = (int)rows.size();
+  if (r < 1) return;
+  // many long rows: dense S on the device (backend.h kWbLargeMax) -- when the libraries load, the dense blocks fit comfortably (W, S, S^-1:
+  // 8 (r ct + 2 r^2) bytes against a budget of 24 GiB of the 288) and the long rows carry most of A (else Jacobi is not the problem)
+  bool large = false;
+  std::vector<int> colmap;
+  int ct = 0;
+  if (r > kWbMaxRows) {
+    if (r > kWbLargeMax || !pol_.woodbury_large || !be::wb_large_supported()) return;
+    size_t nz_long = 0;
+    for (int i : rows) nz_long += (size_t)(Arp[i + 1] - Arp[i]);
+    if (2 * nz_long < (size_t)Arp[m]) return;
+    colmap.assign(n, -1);
+    for (int i : rows) for (int k = Arp[i]; k < Arp[i + 1]; k++) colmap[Arj[k]] = 0;
+    for (int j = 0; j < n; j++) if (colmap[j] == 0) colmap[j] = ct++;
+    if (8.0 * ((double)r * ct + 2.0 * (double)r * r) > 24.0 * 1024 * 1024 * 1024) return;
+    large = true;
+  }
+  std::vector<unsigned char> islong(m, 0);
+  std::vector<int> lrp(r + 1, 0), lcol, lsrc;
+  for (int a = 0; a < r; a++) {
+    const int i = rows[a]; islong[i] = 1;
+    for (int k = Arp[i]; k < Arp[i + 1]; k++) { lcol.push_back(Arj[k]); lsrc.push_back(k); }
+    lrp[a + 1] = (int)lcol.size();
+  }
+  std::vector<int> trp(n + 1, 0), tcol(lcol.size()), tsrc(lcol.size());
+  for (int c : lcol) trp[c + 1]++;
+  for (int j = 0; j < n; j++) trp[j + 1] += trp[j];
+  { std::vector<int> cur(trp.begin(), trp.end() - 1);
+    for (int a = 0; a < r; a++) for (int k = lrp[a]; k < lrp[a + 1]; k++) { const int pos = cur[lcol[k]]++; tcol[pos] = a; tsrc[pos] = lsrc[k]; } }
+  auto up_i = [&](const std::vector<int> &h) { int *p = dev_vec<int>(d_, h.size()); if (!h.empty()) be::h2d(d_, p, h.data(), sizeof(int) * h.size()); return p; };
+  auto up_csr = [&](DevCsr &M, int nr, int nc, const std::vector<int> &rp, const std::vector<int> &cj) {
+    std::vector<int> rb;
+    if (&M == &d_.wb.AL) { for (int a = 0; a <= nr; a++) rb.push_back(a); }      // every long row is a block of its own
+    else rb = build_row_blocks(rp, nr);
+    std::vector<int> runs;
+    M.nrows = nr; M.ncols = nc; M.nnz = (int)cj.size(); M.nblk = (int)rb.size() - 1; M.split = nc; M.single = 0; M.nwin = 0;
+    M.rowptr = up_i(rp); M.col = up_i(cj); M.blkdesc = up_i(block_descs(rb, rp, cj, runs)); M.runinfo = up_i(runs);
+    M.val = dev_vec<double>(d_, cj.size());
+  };
+  DevWb &w = d_.wb;
+  w.r = r;
+  up_csr(w.AL, r, n, lrp, lcol); up_csr(w.ALT, n, r, trp, tcol);
+  w.al_src = up_i(lsrc); w.alt_src = up_i(tsrc); w.rows = up_i(rows);
+  w.islong = dev_vec<unsigned char>(d_, m); be::h2d(d_, w.islong, islong.data(), m);
+  w.S = dev_vec<double>(d_, (size_t)r * r); w.Sinv = dev_vec<double>(d_, (size_t)r * r);
+  w.g = dev_vec<double>(d_, r); w.h = dev_vec<double>(d_, r); w.Dinv0 = dev_vec<double>(d_, n);
+  if (large) {
+    w.large = 1; w.ct = ct; w.colmap = up_i(colmap);
+    w.W = dev_vec<double>(d_, (size_t)r * ct);                  // (zero-filled by the allocator: only the pattern's positions are ever written)
+    w.pv = dev_vec<double>(d_, (size_t)n + m + n + 4 + r);
+  } else w.WT = dev_vec<double>(d_, (size_t)n * r);
+  w.info = dev_vec<int>(d_, 2); w.dbg = dev_vec<int>(d_, 1);
+  if (pol_.debug_fail_refactor > 0) { const int v = pol_.debug_fail_refactor; be::h2d(d_, w.dbg, &v, sizeof(int)); }
+  w.on = 1;
+  // K0 diagonal <=> P has diagonal entries only and every short row of A has exactly one entry: then M = K (backend.h DevWb::exact)
+  bool diag = pol_.woodbury_direct != 0;
+  for (int j = 0; j < n && diag; j++) for (int k = P_.p[j]; k < P_.p[j + 1]; k++) if (P_.i[k] != j) { diag = false; break; }
+  for (int i = 0; i < m && diag; i++) if (!islong[i] && Arp[i + 1] - Arp[i] > 1) diag = false;
+  w.exact = diag ? 1 : 0;
+  // (large mode: decided numerically after every factorisation -- two-entry rows whose contributions to K0's off-diagonal cancel, as in
+  //  the lasso's  -t <= x <= t , are as good as one-entry rows)
+  if (large) { w.probe = pol_.woodbury_direct != 0; w.exact = 0; w.log = pol_.woodbury_log; w.exact_tol = pol_.woodbury_direct_tol > 0 ? pol_.woodbury_direct_tol : 1e-6; }
+  // The direct mode in two launches per ADMM iteration (backend.h DevWbx): additionally every short row has EXACTLY one entry (an empty
+  // row would have no column to be updated with) and the problem is small enough for the per-workgroup partials (n <= kWbxMaxN)
+  if (w.exact && !large && pol_.woodbury_fused && be::wbx_supported() && n <= kWbxMaxN) {
+    bool ok = true;
+    for (int i = 0; i < m && ok; i++) if (!islong[i] && Arp[i + 1] - Arp[i] != 1) ok = false;
+    if (ok) {
+      std::vector<int> sc_ptr(n + 1, 0), sc_row, sc_src;
+      for (int j = 0; j < n; j++) {
+        for (int k = A_.p[j]; k < A_.p[j + 1]; k++) if (!islong[A_.i[k]]) { sc_row.push_back(A_.i[k]); sc_src.push_back(AmapA_[k]); }
+        sc_ptr[j + 1] = (int)sc_row.size();
+      }
+      DevWbx &x = w.x;
+      x.G = (n + kWbxCols - 1) / kWbxCols; x.nsc = (int)sc_row.size();
+      x.tile = dev_vec<double>(d_, (size_t)x.G * kWbMaxRows * kWbxCols);       // (zero-filled by the allocator: only the pattern's positions are ever written)
+      x.tile2 = dev_vec<double>(d_, (size_t)x.G * kWbMaxRows * kWbxCols);
+      x.partG = dev_vec<double>(d_, (size_t)x.G * kWbMaxRows); x.partZ = dev_vec<double>(d_, (size_t)x.G * kWbMaxRows);
+      x.ls0 = dev_vec<double>(d_, 3 * (size_t)kWbMaxRows); x.ls1 = dev_vec<double>(d_, 3 * (size_t)kWbMaxRows);
+      x.sc_ptr = up_i(sc_ptr); x.sc_row = up_i(sc_row); x.sc_src = up_i(sc_src); x.sc_val = dev_vec<double>(d_, sc_row.size());
+      x.bjj = dev_vec<double>(d_, n);
+      be::wbx_init(d_);
+      x.on = 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ setup
+int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *A, const double *l, const double *u,
+                  int m_, int n_, const OSQPSettings *s) {
+  double t0 = now_s();
+  const bool ptime = pol_.setup_timing != 0;
+  double tl = t0;
+  auto lap = [&](const char *what) { if (ptime) { double t = now_s(); std::fprintf(stderr, "[osqp_hip setup] %-28s %8.2f ms\n", what, 1e3 * (t - tl)); tl = t; } };
+  // ---- data validation (the C core's validate_data; error numbering bindings.cpp.in:364-375) ----
+  if (!P || !A || !q || n_ <= 0 || m_ < 0) return OSQP_DATA_VALIDATION_ERROR;
+  if (m_ > 0 && (!l || !u)) return OSQP_DATA_VALIDATION_ERROR;
+  if (P->m != n_ || P->n != n_ || A->m != m_ || A->n != n_) return OSQP_DATA_VALIDATION_ERROR;
+  auto csc_ok = [](const OSQPCscMatrix *M) {
+    if (!M->p) return false;
+    if (M->p[0] != 0) return false;
+    for (int j = 0; j < M->n; j++) if (M->p[j + 1] < M->p[j]) return false;
+    int nz = M->p[M->n];
+    if (nz > 0 && (!M->i || !M->x)) return false;
+    for (int k = 0; k < nz; k++) if (M->i[k] < 0 || M->i[k] >= M->m) return false;
+    return true;
+  };
+  if (!csc_ok(P) || !csc_ok(A)) return OSQP_DATA_VALIDATION_ERROR;
+  for (int j = 0; j < n_; j++)
+    for (int k = P->p[j]; k < P->p[j + 1]; k++) if (P->i[k] > j) return OSQP_DATA_VALIDATION_ERROR;   // upper triangular only
+  for (int i = 0; i < m_; i++) if (!(l[i] <= u[i])) return OSQP_DATA_VALIDATION_ERROR;
+  int err = validate_settings(s, true);
+  if (err) return err;
+
+  free_all();
+  n = n_; m = m_; settings = *s;
+  rho_bar_ = clamp_rho(settings.rho); settings.rho = rho_bar_;                            // _osqp.py:503
+  auto copy_csc = [](HostCsc &H, const OSQPCscMatrix *M) {
+    H.nr = M->m; H.nc = M->n; int nz = M->p[M->n];
+    H.p.assign(M->p, M->p + M->n + 1); H.i.assign(M->i, M->i + nz); H.x.assign(M->x, M->x + nz);
+  };
+  copy_csc(P_, P); copy_csc(A_, A);
+  q0_.assign(q, q + n); l0_.assign(l, l + m); u0_.assign(u, u + m);
+  lap("validate + copy");
+
+  // ---- device ----
+  err = be::init(d_, settings.device);
+  if (err) return err;
+  lap("device init");
+  dev_ready_ = true;
+  // ---- scaling: on the device once the matrices are assembled there; the test-only host simulator
+  //      keeps the driver's host restatement of _osqp.py:389-497 ----
+  const bool dev_asm = be::device_assembly();
+  std::vector<double> Px, Ax, qs;
+  d_.n = n; d_.m = m; d_.sigma = settings.sigma; d_.alpha = settings.alpha;
+
+  const int nzA = A_.nnz(), nzP = P_.nnz();
+  std::vector<int> Arp, Arj, Brp, Bj;
+  int nzB = 0;
+  // (a lambda: setup may build the structure twice -- as given, and for the reordered problem)
+  auto build_structure = [&]() {
+    // A as CSR (the incoming CSC is CSR(A')) + map CSC index -> CSR position
+    Arp.assign(m + 1, 0); Arj.assign(nzA, 0);
+    AmapA_.resize(nzA);
+    for (int k = 0; k < nzA; k++) Arp[A_.i[k] + 1]++;
+    for (int i = 0; i < m; i++) Arp[i + 1] += Arp[i];
+    {
+      std::vector<int> cur(Arp.begin(), Arp.end() - 1);
+      for (int j = 0; j < n; j++)
+        for (int k = A_.p[j]; k < A_.p[j + 1]; k++) { int pos = cur[A_.i[k]]++; Arj[pos] = j; AmapA_[k] = pos; }
+    }
+    // B = [P + sigma I | A'] as CSR with n rows; row j = (lower part of row j of P) (diag) (upper part) (column j of A)
+    Brp.assign(n + 1, 0);
+    std::vector<char> hasdiag(n, 0);
+    for (int j = 0; j < n; j++) {
+      Brp[j + 1] += 1 + (A_.p[j + 1] - A_.p[j]);
+      for (int k = P_.p[j]; k < P_.p[j + 1]; k++) {
+        int i = P_.i[k];
+        if (i == j) hasdiag[j] = 1; else { Brp[j + 1]++; Brp[i + 1]++; }
+      }
+    }
+    for (int j = 0; j < n; j++) Brp[j + 1] += Brp[j];
+    nzB = Brp[n];
+    Bj.assign(nzB, 0); std::vector<int> &bdiag = bdiag_; bdiag.assign(n, 0);
+    Pmap1_.assign(nzP, -1); Pmap2_.assign(nzP, -1); AmapB_.resize(nzA);
+    {
+      std::vector<int> cur(Brp.begin(), Brp.end() - 1);
+      for (int j = 0; j < n; j++) {
+        for (int k = P_.p[j]; k < P_.p[j + 1]; k++) {
+          int i = P_.i[k];
+          if (i == j) continue;
+          int p1 = cur[j]++; Bj[p1] = i; Pmap1_[k] = p1;      // (j, i): lower part of row j
+        }
+        bdiag[j] = cur[j]++; Bj[bdiag[j]] = j;
+        for (int k = P_.p[j]; k < P_.p[j + 1]; k++)           // every stored (j, j) entry -- valid CSC may repeat it -- adds into the one slot
+          if (P_.i[k] == j) Pmap1_[k] = bdiag[j];
+        for (int k = P_.p[j]; k < P_.p[j + 1]; k++) {
+          int i = P_.i[k];
+          if (i == j) continue;
+          int p2 = cur[i]++; Bj[p2] = j; Pmap2_[k] = p2;      // (i, j): upper part of row i (its diagonal is already placed)
+        }
+      }
+      for (int j = 0; j < n; j++)
+        for (int k = A_.p[j]; k < A_.p[j + 1]; k++) { int pos = cur[j]++; Bj[pos] = n + A_.i[k]; AmapB_[k] = pos; }
+    }
+  };
+  build_structure();
+  lap("CSR(A), B structure, maps");
+  std::vector<int> rbA = build_row_blocks(Arp, m), rbB = build_row_blocks(Brp, n);
+  lap("row blocks");
+  // One launch per PCG iteration (F1 form): wants row blocks of A of at most kF1Chunk entries -- on large problems (n = 1M: the default
+  // blocks hold ~2000 entries) A is re-blocked for it, a workgroup then loops over several blocks per launch; when the plan does not
+  // apply the default blocks stay
+  bool has_long = false;
+  for (int i = 0; i < m && !has_long; i++) has_long = Arp[i + 1] - Arp[i] > kLongRow;
+  const bool want_f1 = pol_.pcg_fused && use_slots_ && pol_.window != 0 && pol_.f1 && !has_long;
+  F1Plan plan;
+  auto try_plan = [&]() {
+    if (!want_f1) return false;
+    if (plan_f1(rbA, Arp, Arj, Brp, Bj, plan)) return true;
+    if ((long)nzA > (long)kGrid * kF1Chunk) {
+      std::vector<int> rbF = build_row_blocks(Arp, m, kF1Chunk);
+      if (plan_f1(rbF, Arp, Arj, Brp, Bj, plan)) { rbA.swap(rbF); return true; }
+    }
+    return false;
+  };
+  bool f1ok = try_plan();
+  // Reordering (OSQPHipPolicy::reorder; Engine::compute_reorder): 1 = when the one-launch form does not apply to the problem as given,
+  // look for a permutation under which it does and keep it only then; 2 = always work on the permuted problem (tests of the plumbing)
+  clear_reorder();
+  const int reorder = no_reorder_ ? 0 : pol_.reorder;
+  if (m > 0 && (reorder == 2 || (reorder == 1 && want_f1 && !f1ok && be::device_assembly() && (int)rbA.size() - 1 >= kGrid / 4))) {
+    const double tr = now_s();
+    compute_reorder(Arp, Arj, Brp, Bj);
+    HostCsc P0 = P_, A0 = A_; std::vector<double> q00 = q0_, l00 = l0_, u00 = u0_;
+    apply_reorder();
+    build_structure();
+    rbA = build_row_blocks(Arp, m); rbB = build_row_blocks(Brp, n);
+    f1ok = try_plan();
+    if (!f1ok && reorder != 2) {                     // no gain: the problem stays as the caller numbered it
+      P_ = std::move(P0); A_ = std::move(A0); q0_ = std::move(q00); l0_ = std::move(l00); u0_ = std::move(u00);
+      clear_reorder();
+      build_structure();
+      rbA = build_row_blocks(Arp, m); rbB = build_row_blocks(Brp, n);
+      f1ok = try_plan();
+    }
+    reorder_ms_ = 1e3 * (now_s() - tr);
+    lap("reordering");
+  }
+  if (!dev_asm) { Px = P_.x; Ax = A_.x; qs = q0_; compute_scaling(Px, Ax, qs); lap("Ruiz scaling (host)"); }
+  Arp_ = Arp; Arj_ = Arj; Brp_ = Brp; Bj_ = Bj;
+  d_.fused = pol_.pcg_fused ? 1 : 0;                 // 0 selects the 3-kernel sequence
+  prepare_wb(Arp, Arj);
+  if (d_.wb.on) d_.fused = 0;                        // (the Woodbury-corrected preconditioner lives in the three-kernel PCG form)
+  d_.f1 = DevF1();
+  if (d_.fused && f1ok) upload_f1(plan);
+  if (reordered_) {
+    d_pc_ = dev_vec<int>(d_, n); d_pr_ = dev_vec<int>(d_, m);
+    be::h2d(d_, d_pc_, pc_.data(), sizeof(int) * n); be::h2d(d_, d_pr_, pr_.data(), sizeof(int) * m);
+  }
+  lap("F1 / Woodbury plans");
+  // block descriptors; long rows also get their run table (see DevCsr::runinfo).  Slices are the fixed kChunk steps the kernels
+  // take from the row's first entry (cutting them at run starts instead adds short slices that cost more than the saved
+  // index bytes: lasso PCG pair 208 us vs 220 us)
+  auto descs = [](const std::vector<int> &rb, const std::vector<int> &rp, const std::vector<int> &cj, std::vector<int> &runs) {
+    std::vector<int> d; d.reserve(4 * rb.size());
+    runs.clear();
+    for (size_t b = 0; b + 1 < rb.size(); b++) {
+      const int r0 = rb[b], r1 = rb[b + 1], k0 = rp[r0], k1 = rp[r1];
+      int end_row = r1;
+      if (r1 - r0 == 1 && k1 - k0 > kLongRow) {
+        end_row = -(1 + (int)runs.size());
+        for (int base = k0; base < k1; base += kChunk) {
+          const int end = std::min(k1, base + kChunk);
+          bool run = true;
+          for (int k = base + 1; k < end && run; k++) run = cj[k] == cj[k - 1] + 1;
+          runs.push_back(run ? cj[base] : -1);
+        }
+      }
+      d.push_back(r0); d.push_back(end_row); d.push_back(k0); d.push_back(k1);
+    }
+    return d;
+  };
+
+  // column windows of the (short-row) blocks, see DevCsr::blkwin.  OSQPHipPolicy::window = 0 turns the windowed path off (A/B runs).
+  const bool win_on = pol_.window != 0;
+  auto windows = [win_on](const std::vector<int> &rb, const std::vector<int> &rp, const std::vector<int> &cj, int split,
+                    std::vector<int> &win, std::vector<unsigned short> &lcol) {
+    const size_t nb = rb.size() - 1;
+    win.assign(4 * nb, 0); lcol.assign(std::max<size_t>(cj.size(), 1), 0);
+    int nwin = 0;
+    for (size_t b = 0; b < nb; b++) {
+      const int r0 = rb[b], r1 = rb[b + 1], k0 = rp[r0], k1 = rp[r1];
+      win[4 * b + 1] = -1;
+      if (!win_on || (r1 - r0 == 1 && k1 - k0 > kLongRow) || k1 == k0) continue;
+      int lo0 = INT32_MAX, hi0 = -1, lo1 = INT32_MAX, hi1 = -1;
+      for (int k = k0; k < k1; k++) {
+        const int c = cj[k];
+        if (c < split) { lo0 = std::min(lo0, c); hi0 = std::max(hi0, c); } else { lo1 = std::min(lo1, c - split); hi1 = std::max(hi1, c - split); }
+      }
+      const long len0 = hi0 >= 0 ? (long)hi0 - lo0 + 1 : 0, len1 = hi1 >= 0 ? (long)hi1 - lo1 + 1 : 0;
+      if (len0 + len1 > kWinCap) continue;
+      if (len0 == 0) lo0 = 0;
+      if (len1 == 0) lo1 = 0;
+      win[4 * b] = lo0; win[4 * b + 1] = (int)len0; win[4 * b + 2] = lo1; win[4 * b + 3] = (int)len1;
+      for (int k = k0; k < k1; k++) {
+        const int c = cj[k];
+        lcol[k] = (unsigned short)(c < split ? c - lo0 : len0 + (c - split - lo1));
+      }
+      nwin++;
+    }
+    return nwin;
+  };
+  auto up_i = [&](const std::vector<int> &h) { int *p = dev_vec<int>(d_, h.size()); be::h2d(d_, p, h.data(), sizeof(int) * h.size()); return p; };
+  auto up_win = [&](DevCsr &M, const std::vector<int> &rb, const std::vector<int> &rp, const std::vector<int> &cj, int split) {
+    std::vector<int> win; std::vector<unsigned short> lcol;
+    M.split = split;
+    M.single = (int)rb.size() - 1 <= kGrid;
+    for (size_t b = 0; b + 1 < rb.size(); b++) if (rb[b + 1] - rb[b] > kBlock) M.single = 0;
+    M.nwin = windows(rb, rp, cj, split, win, lcol);
+    M.blkwin = up_i(win);
+    M.lcol = dev_vec<unsigned short>(d_, lcol.size());
+    be::h2d(d_, M.lcol, lcol.data(), sizeof(unsigned short) * lcol.size());
+  };
+  d_.A.nrows = m; d_.A.ncols = n; d_.A.nnz = nzA; d_.A.nblk = (int)rbA.size() - 1;
+  d_.A.rowptr = up_i(Arp); d_.A.col = up_i(Arj); { std::vector<int> runs; d_.A.blkdesc = up_i(descs(rbA, Arp, Arj, runs)); d_.A.runinfo = up_i(runs); } d_.A.val = dev_vec<double>(d_, nzA);
+  d_.B.nrows = n; d_.B.ncols = n + m; d_.B.nnz = nzB; d_.B.nblk = (int)rbB.size() - 1;
+  d_.B.rowptr = up_i(Brp); d_.B.col = up_i(Bj); { std::vector<int> runs; d_.B.blkdesc = up_i(descs(rbB, Brp, Bj, runs)); d_.B.runinfo = up_i(runs); } d_.B.val = dev_vec<double>(d_, nzB);
+  d_.Bdiag = up_i(bdiag_);
+  up_win(d_.A, rbA, Arp, Arj, n); up_win(d_.B, rbB, Brp, Bj, n);
+  lap("upload structure");
+  auto dv = [&](size_t cnt) { return dev_vec<double>(d_, cnt); };
+  d_.q = dv(n); d_.l = dv(m); d_.u = dv(m); d_.D = dv(n); d_.Dinv = dv(n); d_.E = dv(m); d_.Einv = dv(m);
+  d_.rho = dv(m); d_.rho_inv = dv(m); d_.ctype = dev_vec<int>(d_, m);
+  d_.x = dv(n); d_.z = dv(m); d_.y = dv(m); d_.dx = dv(n); d_.dy = dv(m); d_.zt = dv(m); d_.t0 = dv(m); d_.v = dv(m);
+  d_.xg = dv(n); d_.xsp = dv(n); d_.ztg = dv(m);
+  d_.theta = pol_.extrap;                            // PCG start extrapolation (backend.h Dev::xg)
+  d_.uu = dv(n); d_.w = dv(n); d_.t = dv(m); d_.uu2 = dv(n); d_.ms = dv(2 * (size_t)n);
+  if (d_.f1.on) { const size_t ns = d_.f1.ns; double *va = d_.f1.va; d_.Minv = va; d_.xs = va + ns; d_.p = va + 2 * ns; d_.r = va + 3 * ns; d_.s = va + 5 * ns; }   // backend.h DevF1::va
+  else { d_.r = dv(n); d_.p = dv(n); d_.s = dv(n); d_.Minv = dv(n); d_.xs = dv(n); }
+  d_.part = dv((size_t)kPartSlots * kGrid); d_.res = dv(R_COUNT); d_.scal = dv(S_HIST + 3 * (kMaxCg + 1)); d_.flags = dev_vec<int>(d_, F_COUNT); d_.slot = dev_vec<int>(d_, be::kSlotInts);
+  d_.ctl = be::device_assembly() ? static_cast<Ctl *>(be::alloc(d_, sizeof(Ctl))) : nullptr;      // (the host simulator processes every boundary on the host)
+  if (dev_asm) {
+    // the caller's values go up once, in their own (CSC) order; every later (re)assembly and the equilibration run on the device
+    std::vector<int> Pj(nzP), Aj(nzA);
+    for (int j = 0; j < n; j++) { for (int k = P_.p[j]; k < P_.p[j + 1]; k++) Pj[k] = j; for (int k = A_.p[j]; k < A_.p[j + 1]; k++) Aj[k] = j; }
+    d_.nzP = nzP; d_.nzA = nzA;
+    d_.Praw = dv(nzP); d_.Araw = dv(nzA); d_.cs = dv(2);
+    d_.Pi = up_i(P_.i); d_.Pj = up_i(Pj); d_.Pm1 = up_i(Pmap1_); d_.Pm2 = up_i(Pmap2_);
+    d_.Ai = up_i(A_.i); d_.Aj = up_i(Aj); d_.AmA = up_i(AmapA_); d_.AmB = up_i(AmapB_);
+    be::h2d(d_, d_.Praw, P_.x.data(), sizeof(double) * nzP); be::h2d(d_, d_.Araw, A_.x.data(), sizeof(double) * nzA);
+    be::h2d(d_, d_.q, q0_.data(), sizeof(double) * n);
+    be::assemble(d_, 0, 1.0, 0);                                     // unscaled, sigma added after the equilibration
+    c_ = be::ruiz(d_, settings.scaling);                             // _osqp.py:389-497
+    cinv_ = 1.0 / c_;
+    be::f1_refresh(d_); be::wb_refresh(d_); be::wbx_refresh(d_);
+    D_.resize(n); E_.resize(m); Dinv_.resize(n); Einv_.resize(m);
+    be::d2h(d_, D_.data(), d_.D, sizeof(double) * n); be::d2h(d_, Dinv_.data(), d_.Dinv, sizeof(double) * n);
+    if (m > 0) { be::d2h(d_, E_.data(), d_.E, sizeof(double) * m); be::d2h(d_, Einv_.data(), d_.Einv, sizeof(double) * m); }
+    lap("assembly + Ruiz scaling (device)");
+  } else {
+    Aval_.assign(nzA, 0.0); Bval_.assign(nzB, 0.0);
+    fill_matrix_values(Px, Ax);
+    be::h2d(d_, d_.D, D_.data(), sizeof(double) * n); be::h2d(d_, d_.Dinv, Dinv_.data(), sizeof(double) * n);
+    be::h2d(d_, d_.E, E_.data(), sizeof(double) * m); be::h2d(d_, d_.Einv, Einv_.data(), sizeof(double) * m);
+    lap("matrix values (host-scaled)");
+  }
+  d_.qraw = dv(n); d_.lraw = dv(m); d_.uraw = dv(m); d_.cnt = dev_vec<int>(d_, 2);
+  raw_stale_ = scaled_stale_ = false;
+  if (be::device_vec_updates()) {
+    be::copy_in(d_, d_.qraw, q0_.data(), sizeof(double) * n, 0);
+    be::copy_in(d_, d_.lraw, l0_.data(), sizeof(double) * m, 0); be::copy_in(d_, d_.uraw, u0_.data(), sizeof(double) * m, 0);
+    device_scale_vectors(true, true);
+  } else {
+    upload_q();
+    upload_bounds_and_types();
+  }
+  be::set_rho(d_, rho_bar_);                                       // _osqp.py:499-524
+  try { be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER); }
+  catch (const DeviceError &err) {
+    // the first device-side factorisation of the large-rank correction failed (a dense-library call, not this engine's kernels): the
+    // handle falls back to plain Jacobi -- said loudly, and visible in OSQPHipStats::woodbury_rows = 0
+    if (!(d_.wb.on && d_.wb.large)) throw;
+    std::fprintf(stderr, "osqp_hip: large-rank Woodbury correction switched off for this handle (%s)\n", err.what());
+    d_.wb.on = 0;
+    be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER);
+  }
+  be::init_iterates(d_, 1);
+
+  sol_x_.assign(n, kNaN); sol_y_.assign(m, kNaN); sol_pc_.assign(m, kNaN); sol_dc_.assign(n, kNaN);
+  solution.x = sol_x_.data(); solution.y = sol_y_.data(); solution.prim_inf_cert = sol_pc_.data(); solution.dual_inf_cert = sol_dc_.data();
+  std::memset(&info, 0, sizeof(info));
+  set_status(OSQP_UNSOLVED);
+  cg_budget_ = 0; have_tol_ = false; first_run_ = true; slot_pred_[0] = slot_pred_[1] = 6.0; slot_pred_[2] = 14.0;
+  stats_ = OSQPHipStats(); stats_.nnzA = nzA; stats_.nnzB = nzB;
+  be::sync(d_);
+  lap("vectors, rho, preconditioner");
+  info.setup_time = now_s() - t0;
+  if (settings.verbose) {
+    std::printf("-----------------------------------------------------------------\n");
+    std::printf("  OSQP ADMM engine for AMD MI355X (%s), indirect (PCG) solver\n", be::name());
+    std::printf("-----------------------------------------------------------------\n");
+    std::printf("problem:  variables n = %d, constraints m = %d\n          nnz(P) + nnz(A) = %d\n", n, m, nzP + nzA);
+    std::printf("settings: eps_abs = %.1e, eps_rel = %.1e, rho = %.2e%s, sigma = %.2e, alpha = %.2f,\n          max_iter = %d, scaling = %d, check_termination = %d, cg_max_iter = %d\n\n",
+                settings.eps_abs, settings.eps_rel, settings.rho, settings.adaptive_rho ? " (adaptive)" : "", settings.sigma,
+                settings.alpha, settings.max_iter, settings.scaling, settings.check_termination, settings.cg_max_iter);
+  }
+  return OSQP_NO_ERROR;
+}
+
+
+}  // namespace osqp_hip

@@ -7,8 +7,8 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'osqp-python_amd', 'csrc')
 OUT = os.path.join(ROOT, 'tests', '_build', 'libosqp_hostsim.so')
-SRCS = [os.path.join(CSRC, 'engine.cpp'), os.path.join(CSRC, 'api.cpp'), os.path.join(ROOT, 'tests', 'hostsim', 'backend_host.cpp')]
-DEPS = SRCS + [os.path.join(CSRC, 'engine.hpp'), os.path.join(CSRC, 'backend.h'), os.path.join(CSRC, 'policy.h'), os.path.join(ROOT, 'include', 'osqp_hip.h')]
+SRCS = [os.path.join(CSRC, 'engine.cpp'), os.path.join(CSRC, 'engine_setup.cpp'), os.path.join(CSRC, 'engine_api.cpp'), os.path.join(CSRC, 'api.cpp'), os.path.join(ROOT, 'tests', 'hostsim', 'backend_host.cpp')]
+DEPS = SRCS + [os.path.join(CSRC, 'engine.hpp'), os.path.join(CSRC, 'engine_internal.hpp'), os.path.join(CSRC, 'backend.h'), os.path.join(CSRC, 'policy.h'), os.path.join(ROOT, 'include', 'osqp_hip.h')]
 
 
 def build():
