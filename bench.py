@@ -142,6 +142,8 @@ def main():
     ap.add_argument('--batch', type=int, default=4096, help='BASELINE configs[4]: MPC QPs solved through the sharded batch path and reported as config.batch (0 disables)')
     ap.add_argument('--batch-steps', type=int, default=5)
     ap.add_argument('--batch-cpu', type=int, default=1, help='time the all-cores CPU baseline of the batch too (N = 1 only)')
+    ap.add_argument('--hbm-n', type=int, default=1000000, help='N = 1, headline config only: also time the dominant kernel on the same generator at this many variables '
+                                                               '(a working set beyond the 256 MiB Infinity Cache) and report it as roofline.hbm_resident (0 disables)')
     args = ap.parse_args()
     warnings.simplefilter('ignore')
 
@@ -353,6 +355,8 @@ def main():
             out['roofline']['streamed_bytes'] = streamed
             out['roofline']['frac_streamed'] = streamed / (pcg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             out['roofline']['replicas'] = f1_D
+            if out['roofline']['traffic']:
+                out['roofline']['frac_traffic'] = out['roofline']['traffic'] / (pcg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS      # by the bytes the PMC counters saw
         if int(stats.get('woodbury_rows', 0)) > 0:
             # the figure with the reference's literal preconditioner next to it: the same QP, same settings, plain Jacobi (OSQPHipPolicy::woodbury = 0)
             os.environ['OSQP_HIP_WOODBURY'] = '0'
@@ -374,6 +378,26 @@ def main():
                 cb = bench_batch.cpu_batch_baseline(*bdata)
                 batch_out['cpu_baseline'] = cb
                 batch_out['gpu_over_cpu_all_cores'] = batch_out['QP_per_s'] / cb['value']
+        if args.hbm_n > n and args.config == 'banded' and world == 1 and f1 and args.cpu_seconds > 0:      # (--cpu-seconds 0: the profiling runs -- no extra legs)
+            # The headline QP's working set (~50 MB) lives in the Infinity Cache: the fraction above is a cache-resident figure.  The same kernel on the
+            # same generator at hbm_n variables (n = 1M: ~0.5 GB of matrices and vectors per launch) is the HBM-resident point of the roofline.
+            Pb, qb, Ab, lb, ub = problems.banded_qp(args.hbm_n, seed=12345)
+            mb = osqp_amd.OSQP(algebra='hip'); mb.setup(Pb, qb, Ab, lb, ub, **settings)
+            rb = mb.solve(); sb = mb._solver; stb = sb.hip_stats()
+            if int(stb.get('pcg_fused', 0)) == 2:
+                nb_, mb_ = len(qb), len(lb)
+                nzA, nzB = int(stb['nnzA']), int(stb['nnzB']); nzP = nzB - nzA; Db = int(stb.get('f1_replicas', 0))
+                bytes_8d = spmv_bytes(nzP, nb_, nb_) + spmv_bytes(nzA, mb_, nb_) + spmv_bytes(nzA, nb_, mb_) + 104 * nb_
+                bytes_own = 12 * nzA + 4 * (mb_ + 1) + 8 * mb_ + 2 * Db * nb_ + 12 * nzP + 4 * (nb_ + 1) + 8 * nb_ * (4 + Db + 2 + 5 + Db)
+                ms_l = 0.5 * sb.hip_time_kernel(16, max(20, args.probe_reps // 4))
+                tr = pmc_traffic('k_f1_probe', 'banded_n%d' % nb_)
+                out['roofline']['hbm_resident'] = {
+                    'workload': 'the same generator at n=%d m=%d nnz(A)=%d (problems.banded_qp, seed 12345): %.0f MB per launch, beyond the 256 MiB Infinity Cache' % (nb_, mb_, Ab.nnz, bytes_own / 1e6),
+                    'kernel': dom, 'ms_per_launch': ms_l, 'bytes_per_launch': bytes_8d, 'achieved': bytes_8d / (ms_l * 1e-3) / 1e9, 'unit': 'GB/s',
+                    'frac': bytes_8d / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBS, 'streamed_bytes': bytes_own, 'frac_streamed': bytes_own / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'traffic': tr, 'frac_traffic': (tr / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None,
+                    'solve': {'status': rb.info.status, 'admm_iters': int(rb.info.iter), 'first_cold_solve_ms': 1e3 * rb.info.solve_time}}
+            del mb
         if args.cpu_seconds > 0 and world == 1:          # (the CPU baseline is timed at N = 1 only: the other ranks would wait 40 s at the barrier)
             cb = cpu_baseline(P, q, A, l, u, settings, args.cpu_seconds)
             out['cpu_baseline'] = cb

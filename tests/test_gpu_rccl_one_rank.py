@@ -29,7 +29,7 @@ def test_batch_bench_through_rccl_with_one_rank():
 
 
 def test_headline_bench_through_rccl_with_one_rank():
-    d = _run('bench.py', ['--steps', '1', '--warmup', '0', '--vars', '4000', '--cpu-seconds', '0', '--probe-reps', '5', '--batch', '96', '--batch-steps', '1'], 29532)
+    d = _run('bench.py', ['--steps', '1', '--warmup', '0', '--vars', '4000', '--cpu-seconds', '0', '--probe-reps', '5', '--batch', '96', '--batch-steps', '1', '--hbm-n', '0'], 29532)
     assert d['n_gpus'] == 1 and d['config']['status'] == 'solved' and d['value'] > 0
     b = d['config']['batch']                                # BASELINE configs[4] through the sharded device path, all_gather over RCCL in the timed region
     assert b['solved'] == b['records'] == 96 and b['n_ranks_seen'] == 1 and b['QP_per_s'] > 0 and 'RCCL' in b['collective']
