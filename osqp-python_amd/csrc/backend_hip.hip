@@ -264,12 +264,29 @@ __global__ __launch_bounds__(kBlock) void k_asm_scatter(Dev d, int scaled, doubl
   }
 }
 // out[r] = max |val| over the entries of row r with column < climit
+// Long rows (more than kLongRow entries: their own row block, DevCsr::blkdesc carries a negative end row) are walked by a whole workgroup,
+// the others by one thread each.  (Until round 4 every row was one thread's loop: the 5 000- and 10 000-entry rows of the lasso / portfolio
+// matrices made each of the ~70 equilibration launches of a setup take 1-12 ms.)
+template <class F>
+__device__ __forceinline__ void for_long_rows(const DevCsr &M, F &&f) {      // f(row, first entry, end entry), workgroup-uniform
+  const int4 *desc = reinterpret_cast<const int4 *>(M.blkdesc);
+  for (int b = blockIdx.x; b < M.nblk; b += gridDim.x) { const int4 ds = desc[b]; if (ds.y < 0) f(ds.x, ds.z, ds.w); }
+}
 __global__ __launch_bounds__(kBlock) void k_rowmax(DevCsr M, int climit, double *out) {
+  __shared__ double sred[2 * kWaves];
   for (int r = blockIdx.x * kBlock + threadIdx.x; r < M.nrows; r += gridDim.x * kBlock) {
+    const int k0 = M.rowptr[r], k1 = M.rowptr[r + 1];
+    if (k1 - k0 > kLongRow) continue;
     double mx = 0.0;
-    for (int k = M.rowptr[r]; k < M.rowptr[r + 1]; k++) if (M.col[k] < climit) mx = fmax(mx, fabs(M.val[k]));
+    for (int k = k0; k < k1; k++) if (M.col[k] < climit) mx = fmax(mx, fabs(M.val[k]));
     out[r] = mx;
   }
+  for_long_rows(M, [&](int r, int k0, int k1) {
+    double mx = 0.0;
+    for (int k = k0 + threadIdx.x; k < k1; k += kBlock) if (M.col[k] < climit) mx = fmax(mx, fabs(M.val[k]));
+    mx = block_max(mx, sred);
+    if (threadIdx.x == 0) out[r] = mx;
+  });
 }
 __global__ __launch_bounds__(kBlock) void k_ruiz_delta(double *v, int cnt) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < cnt; i += gridDim.x * kBlock) v[i] = 1.0 / sqrt(limit_scaling_dev(v[i]));
@@ -278,20 +295,31 @@ __global__ __launch_bounds__(kBlock) void k_ruiz_delta(double *v, int cnt) {
 __global__ __launch_bounds__(kBlock) void k_ruiz_scale_A(Dev d, const double *dt, const double *et) {
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += gridDim.x * kBlock) {
     const double ei = et[i];
-    for (int k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; k++) d.A.val[k] *= ei * dt[d.A.col[k]];
+    const int k0 = d.A.rowptr[i], k1 = d.A.rowptr[i + 1];
+    if (k1 - k0 <= kLongRow) for (int k = k0; k < k1; k++) d.A.val[k] *= ei * dt[d.A.col[k]];
     d.E[i] *= ei;
   }
+  for_long_rows(d.A, [&](int i, int k0, int k1) {
+    const double ei = et[i];
+    for (int k = k0 + threadIdx.x; k < k1; k += kBlock) d.A.val[k] *= ei * dt[d.A.col[k]];
+  });
 }
 // B = [P | A'] <- [diag(dt) P diag(dt) | diag(dt) A' diag(et)] ; q *= dt ; D *= dt
 __global__ __launch_bounds__(kBlock) void k_ruiz_scale_B(Dev d, const double *dt, const double *et) {
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += gridDim.x * kBlock) {
     const double dj = dt[j];
-    for (int k = d.B.rowptr[j]; k < d.B.rowptr[j + 1]; k++) {
-      const int c = d.B.col[k];
-      d.B.val[k] *= c < d.n ? dt[c] * dj : et[c - d.n] * dj;     // (same factor, same order of operands, as the entry's copy in A)
-    }
+    const int k0 = d.B.rowptr[j], k1 = d.B.rowptr[j + 1];
+    if (k1 - k0 <= kLongRow)
+      for (int k = k0; k < k1; k++) {
+        const int c = d.B.col[k];
+        d.B.val[k] *= c < d.n ? dt[c] * dj : et[c - d.n] * dj;     // (same factor, same order of operands, as the entry's copy in A)
+      }
     d.q[j] *= dj; d.D[j] *= dj;
   }
+  for_long_rows(d.B, [&](int j, int k0, int k1) {
+    const double dj = dt[j];
+    for (int k = k0 + threadIdx.x; k < k1; k += kBlock) { const int c = d.B.col[k]; d.B.val[k] *= c < d.n ? dt[c] * dj : et[c - d.n] * dj; }
+  });
 }
 // cost normalisation, one workgroup: ct = 1 / limit(max(limit(||q||_inf), mean_j ||P_:j||_inf)) ; c *= ct     (_osqp.py:443-448)
 __global__ __launch_bounds__(kBlock) void k_ruiz_cost(Dev d, const double *np) {
@@ -308,7 +336,7 @@ __global__ __launch_bounds__(kBlock) void k_ruiz_cost(Dev d, const double *np) {
 __global__ __launch_bounds__(kBlock) void k_ruiz_cost_apply(Dev d) {
   const double ct = d.cs[1];
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += gridDim.x * kBlock) {
-    for (int k = d.B.rowptr[j]; k < d.B.rowptr[j + 1]; k++) if (d.B.col[k] < d.n) d.B.val[k] *= ct;
+    for (int k = d.B.rowptr[j]; k < d.B.rowptr[j + 1] && d.B.col[k] < d.n; k++) d.B.val[k] *= ct;      // (the P part comes first in a row of B = [P | A'])
     d.q[j] *= ct;
   }
 }

@@ -425,6 +425,12 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
     if ((long)nzA > (long)kGrid * kF1Chunk) {
       std::vector<int> rbF = build_row_blocks(Arp, m, kF1Chunk);
       if (plan_f1(rbF, Arp, Arj, Brp, Bj, plan)) { rbA.swap(rbF); return true; }
+    } else {
+      // mid-size problems: the default blocking spreads A over all kGrid workgroups (n = 50k: 1024 blocks of ~490 entries) -- blocks half as
+      // tall as the band is wide need more than kF1MaxD replicas.  FULL blocks (fewer than kGrid of them: some workgroups idle in the F
+      // launches) keep the one-launch form applicable down to a quarter of the grid
+      std::vector<int> rbF = build_row_blocks_target(Arp, m, kF1Chunk - 24);
+      if ((int)rbF.size() - 1 >= kGrid / 4 && plan_f1(rbF, Arp, Arj, Brp, Bj, plan)) { rbA.swap(rbF); return true; }
     }
     return false;
   };
