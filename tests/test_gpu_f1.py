@@ -38,7 +38,8 @@ def _rel(a, b):
     return np.abs(a - b).max() / (1 + np.abs(b).max())
 
 
-@pytest.mark.parametrize('n,window', [(20000, 40), (100000, 200)])
+# (50 000: the plan needs FULL row blocks, fewer than the grid -- round 4; 1 000 000: A re-blocked to <= 1024 entries, ten blocks per workgroup -- round 4)
+@pytest.mark.parametrize('n,window', [(20000, 40), (50000, 200), (100000, 200), (1000000, 200)])
 def test_f1_form_matches_two_kernel_form_and_oracle(n, window):
     P, q, A, l, u = problems.banded_qp(n, window=window)
     m1, r1, s1 = _solve(P, q, A, l, u, True)

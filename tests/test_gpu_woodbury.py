@@ -209,3 +209,19 @@ def test_direct_mode_runs_device_driven_and_hands_over_when_a_refactorisation_fa
     assert r.info.status_val == 1 and r.info.rho_updates >= 1
     assert s['woodbury_direct'] == 0 and s['woodbury_rows'] > 0 and s['pcg_iters_total'] > 0      # finished by the PCG with the corrected preconditioner
     assert _rel(r.x, xo) < 5e-5 and _rel(r.y, yo) < 2e-4
+
+
+def test_two_launch_direct_mode_is_deterministic():
+    """every sum of wbdirect_hip.hip has a fixed order (partials folded in index order, no atomics): repeated cold solves on one handle and a
+    second handle give bit-identical x, y and iteration counts"""
+    P, q, A, l, u = problems.portfolio_qp(2000, 50)
+    got = []
+    for h in range(2):
+        m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, eps_abs=1e-7, eps_rel=1e-7, max_iter=50000, adaptive_rho_interval=50, check_termination=25, verbose=False, warm_starting=False)
+        for rep in range(3):
+            m.update_settings(rho=0.1)
+            r = m.solve()
+            assert r.info.status_val == 1 and m._solver.hip_stats()['woodbury_direct'] == 2
+            got.append((r.info.iter, r.info.rho_updates, r.x.copy(), r.y.copy()))
+    for g in got[1:]:
+        assert g[:2] == got[0][:2] and np.array_equal(g[2], got[0][2]) and np.array_equal(g[3], got[0][3])
