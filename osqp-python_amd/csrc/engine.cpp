@@ -995,9 +995,10 @@ void Engine::store_solution() {                                                 
     }
   }
   if (reordered_) {                                   // back to the caller's numbering of variables and constraints
-    auto back = [](std::vector<double> &v, const std::vector<int> &perm) { std::vector<double> o(v.size()); for (size_t k = 0; k < v.size(); k++) o[perm[k]] = v[k]; v.swap(o); };
+    // (in place: the buffers solution.x / y / *_inf_cert point to never move during a handle's life)
+    std::vector<double> o;
+    auto back = [&o](std::vector<double> &v, const std::vector<int> &perm) { o.resize(v.size()); for (size_t k = 0; k < v.size(); k++) o[perm[k]] = v[k]; std::copy(o.begin(), o.end(), v.begin()); };
     back(sol_x_, pc_); back(sol_dc_, pc_); back(sol_y_, pr_); back(sol_pc_, pr_);
-    solution.x = sol_x_.data(); solution.y = sol_y_.data(); solution.prim_inf_cert = sol_pc_.data(); solution.dual_inf_cert = sol_dc_.data();
   }
 }
 

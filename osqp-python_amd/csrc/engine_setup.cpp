@@ -437,7 +437,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   bool f1ok = try_plan();
   // Reordering (OSQPHipPolicy::reorder; Engine::compute_reorder): 1 = when the one-launch form does not apply to the problem as given,
   // look for a permutation under which it does and keep it only then; 2 = always work on the permuted problem (tests of the plumbing)
-  clear_reorder();
+  clear_reorder(); reorder_ms_ = 0;
   const int reorder = no_reorder_ ? 0 : pol_.reorder;
   if (m > 0 && (reorder == 2 || (reorder == 1 && want_f1 && !f1ok && be::device_assembly() && (int)rbA.size() - 1 >= kGrid / 4))) {
     const double tr = now_s();
