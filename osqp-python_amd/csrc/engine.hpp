@@ -120,7 +120,7 @@ class Engine {
   std::vector<int> PvalMap_, AvalMap_;       // caller's position in P.x / A.x -> position in the permuted CSC arrays (osqp_update_data_mat by index)
   int *d_pc_ = nullptr, *d_pr_ = nullptr;    // device copies of pc_, pr_ (device-pointer updates: gathers)
   double reorder_ms_ = 0;
-  void compute_reorder(const std::vector<int> &Arp, const std::vector<int> &Arj, const std::vector<int> &Brp, const std::vector<int> &Bj);
+  bool compute_reorder(const std::vector<int> &Arp, const std::vector<int> &Arj, const std::vector<int> &Brp, const std::vector<int> &Bj);
   void apply_reorder();
   void clear_reorder();
   template <class T> std::vector<T> to_internal_n(const T *v) const { std::vector<T> o(n); for (int j = 0; j < n; j++) o[j] = v[pc_[j]]; return o; }

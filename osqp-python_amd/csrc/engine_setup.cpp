@@ -15,14 +15,17 @@ namespace osqp_hip {
 //      rows and columns: window of a 1000-entry row block 287 columns as generated, 331 after the BFS, 286 after two sweeps);
 //   3. rows sorted by the middle of their (new) column range.
 // O(nnz) per sweep + two sorts of n / m keys; runs only when the natural order does not admit the one-launch form.
-void Engine::compute_reorder(const std::vector<int> &Arp, const std::vector<int> &Arj, const std::vector<int> &Brp, const std::vector<int> &Bj) {
+bool Engine::compute_reorder(const std::vector<int> &Arp, const std::vector<int> &Arj, const std::vector<int> &Brp, const std::vector<int> &Bj) {
   std::vector<int> cstamp(n, 0), rstamp(m, 0), comp_done(n, 0), order, sweep, best;
   order.reserve(n);
   int stamp = 0;
+  size_t widest = 0;                                 // widest BFS level seen (a lower bound of the bandwidth a level order can reach)
   auto bfs = [&](int start, std::vector<int> &out) {
     out.clear(); stamp++;
     out.push_back(start); cstamp[start] = stamp;
+    size_t level_end = 1;
     for (size_t h = 0; h < out.size(); h++) {
+      if (h == level_end) { widest = std::max(widest, out.size() - level_end); level_end = out.size(); }
       const int j = out[h];
       for (int k = A_.p[j]; k < A_.p[j + 1]; k++) {
         const int i = A_.i[k];
@@ -36,6 +39,9 @@ void Engine::compute_reorder(const std::vector<int> &Arp, const std::vector<int>
   for (int s0 = 0; s0 < n; s0++) {
     if (comp_done[s0]) continue;
     bfs(s0, sweep);
+    // An expander (columns drawn from everywhere) shows in the FIRST sweep: its levels explode, and no ordering of the levels can give row
+    // blocks a window of kF1Win columns -- stop before the remaining five sweeps (n = 100k unstructured: 97 ms of setup for nothing)
+    if (widest > 8u * kF1Win) return false;
     if (sweep.size() > 2) { bfs(sweep.back(), best); bfs(best.back(), sweep); }      // pseudo-peripheral start: the far end of the far end
     for (int c : sweep) { comp_done[c] = 1; order.push_back(c); }
   }
@@ -70,6 +76,7 @@ void Engine::compute_reorder(const std::vector<int> &Arp, const std::vector<int>
   std::stable_sort(pr_.begin(), pr_.end(), [&](int a, int b) { return key[a] < key[b]; });
   ipr_.assign(m, 0);
   for (int i = 0; i < m; i++) ipr_[pr_[i]] = i;
+  return true;
 }
 
 // P_, A_, q0_, l0_, u0_ <- the permuted problem; PvalMap_ / AvalMap_ = where each of the caller's stored entries went.  Entries keep the
@@ -441,18 +448,24 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   const int reorder = no_reorder_ ? 0 : pol_.reorder;
   if (m > 0 && (reorder == 2 || (reorder == 1 && want_f1 && !f1ok && be::device_assembly() && (int)rbA.size() - 1 >= kGrid / 4))) {
     const double tr = now_s();
-    compute_reorder(Arp, Arj, Brp, Bj);
-    HostCsc P0 = P_, A0 = A_; std::vector<double> q00 = q0_, l00 = l0_, u00 = u0_;
-    apply_reorder();
-    build_structure();
-    rbA = build_row_blocks(Arp, m); rbB = build_row_blocks(Brp, n);
-    f1ok = try_plan();
-    if (!f1ok && reorder != 2) {                     // no gain: the problem stays as the caller numbered it
-      P_ = std::move(P0); A_ = std::move(A0); q0_ = std::move(q00); l0_ = std::move(l00); u0_ = std::move(u00);
-      clear_reorder();
+    if (compute_reorder(Arp, Arj, Brp, Bj) || reorder == 2) {
+      if (pc_.empty()) {                             // (forced mode on a graph the search gave up on: the identity permutation exercises the plumbing just as well)
+        pc_.resize(n); ipc_.resize(n); pr_.resize(m); ipr_.resize(m);
+        for (int j = 0; j < n; j++) pc_[j] = ipc_[j] = j;
+        for (int i = 0; i < m; i++) pr_[i] = ipr_[i] = i;
+      }
+      HostCsc P0 = P_, A0 = A_; std::vector<double> q00 = q0_, l00 = l0_, u00 = u0_;
+      apply_reorder();
       build_structure();
       rbA = build_row_blocks(Arp, m); rbB = build_row_blocks(Brp, n);
       f1ok = try_plan();
+      if (!f1ok && reorder != 2) {                   // no gain: the problem stays as the caller numbered it
+        P_ = std::move(P0); A_ = std::move(A0); q0_ = std::move(q00); l0_ = std::move(l00); u0_ = std::move(u00);
+        clear_reorder();
+        build_structure();
+        rbA = build_row_blocks(Arp, m); rbB = build_row_blocks(Brp, n);
+        f1ok = try_plan();
+      }
     }
     reorder_ms_ = 1e3 * (now_s() - tr);
     lap("reordering");
