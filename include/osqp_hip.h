@@ -68,7 +68,7 @@ typedef struct {
   OSQPInt verbose;
   OSQPInt warm_starting;
   OSQPInt scaling;                        /* Ruiz iterations, 0 = off */
-  OSQPInt polishing;                      /* polish by re-running the ADMM on the guessed active set (engine.cpp polish()) */
+  OSQPInt polishing;                      /* polish by re-running the ADMM on the guessed active set (engine.cpp Engine::polish) */
   OSQPFloat rho;
   OSQPInt   rho_is_vec;
   OSQPFloat sigma;
@@ -350,7 +350,7 @@ OSQPInt osqp_hip_trace_read(OSQPSolver *solver, unsigned long long *out, OSQPInt
 /* Test hook (used by tests/ only): which = 0: out = A in (n -> m); 1: out = B [in_n; in_m] (n + m -> n), with the scaled device matrices. */
 OSQPInt osqp_hip_test_spmv(OSQPSolver *solver, OSQPInt which, const OSQPFloat *in, OSQPFloat *out);
 /* Weight of equality rows relative to inequality rows, rho_eq = factor * rho, used when equality and inequality rows are
-   mixed (default 10; the reference's 1e3 is kept when every active row is an equality).  See engine.cpp
+   mixed (default 10; the reference's 1e3 is kept when every active row is an equality).  See engine.cpp (Engine::classify_constraints)
    classify_constraints() for the rationale.  Takes effect immediately (rho vector + preconditioner are rebuilt). */
 OSQPInt osqp_hip_set_rho_eq_factor(OSQPSolver *solver, OSQPFloat factor);
 /* copy out internal scaling D (n), E (m), c */

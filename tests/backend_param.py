@@ -9,7 +9,7 @@ import pytest
 import os
 
 # 'hip'      small problems take the one-launch direct path (banded LDL' in LDS, batch_hip.hip) -- the default
-# 'hip-pcg'  OSQP_HIP_SMALL_DIRECT=0: the same problems through the multi-kernel PCG engine (backend_hip.hip), so that the
+# 'hip-pcg'  OSQP_HIP_SMALL_DIRECT=0: the same problems through the multi-kernel PCG engine (pcg_hip.hip), so that the
 #            reference's goldens pin BOTH kernels
 BACKENDS = [pytest.param('hostsim'), pytest.param('hip', marks=pytest.mark.gpu), pytest.param('hip-pcg', marks=pytest.mark.gpu)]
 

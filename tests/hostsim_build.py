@@ -1,4 +1,4 @@
-"""Builds tests/_build/libosqp_hostsim.so: the product's host driver (engine.cpp + api.cpp) linked against the
+"""Builds tests/_build/libosqp_hostsim.so: the product's host driver (engine*.cpp + api.cpp) linked against the
 plain-loop device-op simulator tests/hostsim/backend_host.cpp.  TEST INFRASTRUCTURE ONLY -- lets the CPU test tier
 exercise the driver / front-end without a GPU.  The package never loads this library."""
 import os

@@ -1,6 +1,6 @@
 """Valid CSC input with an entry stored twice: scipy does not sum duplicates on construction and neither does the
 reference's binding (bindings.cpp.in:12-62 hands the arrays through), so the C ABI must cope: every stored (j, j) entry of P adds
-into the one diagonal slot of B = [P + sigma I | A'] (engine.cpp setup, k_asm_scatter)."""
+into the one diagonal slot of B = [P + sigma I | A'] (engine_setup.cpp Engine::setup, k_asm_scatter)."""
 import warnings
 
 import numpy as np

@@ -105,7 +105,7 @@ def test_solution_matches_oracle_direct(name, eps, atol):
 def test_fixture_matches_python_reference(case, path, monkeypatch):
     """x, y, obj of the importable pure-python reference (ref_* in the fixtures), tightened settings on both sides -- through BOTH
     kernels: the one-launch direct path these small problems take by default (batch_hip.hip) and, with OSQP_HIP_SMALL_DIRECT=0,
-    the multi-kernel PCG engine (backend_hip.hip)."""
+    the multi-kernel PCG engine (pcg_hip.hip)."""
     monkeypatch.setenv('OSQP_HIP_SMALL_DIRECT', '1' if path == 'direct' else '0')
     f = Fixture(case)
     m = osqp_amd.OSQP(); m.setup(f.P, f.q, f.A, f.l, f.u, **f.hip_settings(cg_max_iter=100))
