@@ -36,6 +36,11 @@ for _p in (ROOT, os.path.join(ROOT, 'osqp-python_amd'), os.path.join(ROOT, 'orac
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def median(v):
+    v = sorted(v)
+    return None if not v else (v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]))
+
+
 def spmv_bytes(nnz, rows, cols):
     """Algorithmic bytes of one CSR SpMV: fp64 values + int32 column indices, row pointers, the input
     vector gathered once, the output written once."""
@@ -123,6 +128,100 @@ def _cpu_baseline(P, q, A, l, u, settings, seconds_target, linsys):
     return out
 
 
+def measure_roofline(s, stats, n, mm, args):
+    """Live timing of the hot-path kernels on the solver's own data (hipEvent pairs on the solver's stream, osqp_hip_time_kernel) against their
+    algorithmic bytes.  Returns (probes, kb, pcg_bytes, pcg_ms, dom, dom_kernel, survey_pcg_bytes, streamed, f1, fused, f1_D)."""
+    nnzA, nnzB = int(stats['nnzA']), int(stats['nnzB'])
+    fused = bool(stats.get('pcg_fused', 0))
+    f1 = int(stats.get('pcg_fused', 0)) == 2          # one launch per PCG iteration (DESIGN.md §4.5)
+    f1_D = int(stats.get('f1_replicas', 0))
+    sA, sB = spmv_bytes(nnzA, mm, n), spmv_bytes(nnzB, n, n + mm)
+    # SURVEY §8(d): B_pcg = B_P + B_A + B_At + 104 n  (the reference algorithm's PCG iteration: three SpMVs + 13 n-vector passes)
+    nnzP_full = nnzB - nnzA
+    survey_pcg_bytes = spmv_bytes(nnzP_full, n, n) + spmv_bytes(nnzA, mm, n) + spmv_bytes(nnzA, n, mm) + 104 * n
+    # algorithmic bytes per launch (DESIGN.md "Kernels"): SpMV formula + the fused epilogue / extra vectors
+    if f1:
+        # what the F1 kernel itself has to move: A once (8-byte values + one packed 32-bit index word per entry, row pointers, rho,
+        # 16-bit column pointers of the windows ~ 2 bytes per column and replica), P + sigma I once (CSR), and per column: Minv, r, pu,
+        # s, D replicas read; p, x~ read; s, r, p, x~, pu and D replicas written
+        f1_bytes = 12 * nnzA + 4 * (mm + 1) + 8 * mm + 2 * f1_D * n + 12 * nnzP_full + 4 * (n + 1) + 8 * n * (4 + f1_D + 2 + 5 + f1_D)
+        pcg_kernels = {'F1 one PCG iteration per launch (k_slot1 phase F)': (14, f1_bytes)}
+        seq_id, dom, dom_kernel = 16, 'F1 one PCG iteration per launch (k_slot1 phase F)', 'k_f1_probe'
+    elif fused:     # two kernels per PCG iteration
+        pcg_kernels = {
+            # SpMV(A) applied to Minv.*s (the gathered vector, counted in sA) with the epilogue t = t - alpha rho S (+ rho, t read:
+            # 16m; t written = sA's output), + the vector update: u p r s Minv x~ read, p x~ r u' written (10 x 8n)
+            'K1F spmv A + pcg vector update (k_k1f)': (11, sA + 2 * 8 * mm + 10 * 8 * n),
+            # SpMV(B) whose output is s (w is never stored), + s and Minv read (16n), + Minv.*s written (8n)
+            'K2F spmv B + s, Minv.*s, <s,u> (k_k2f)': (12, sB + 3 * 8 * n),
+        }
+        seq_id, dom, dom_kernel = 10, 'K2F spmv B + s, Minv.*s, <s,u> (k_k2f)', 'k_k2f'
+    else:
+        pcg_kernels = {
+            'K1 spmv A (t=rho.*(A u))': (0, sA + 8 * mm),
+            'K2 spmv B (w=B[u;t], <w,u>)': (1, sB),
+            'Kv pcg vector update': (2, 12 * 8 * n),
+        }
+        seq_id, dom, dom_kernel = 6, 'K2 spmv B (w=B[u;t], <w,u>)', 'k_k2'
+    other = {
+        # (+ the extrapolated PCG start: KB resets x~ to it (8n written); KA reads the previous z~ and x~_prev and writes
+        #  A xg, xg, x~_prev: 8m + 8n read, 8m + 16n written)
+        'KB rhs + pcg start': (3, sB + 8 * mm + 8 * (5 * n)),
+        'KA A x~ + z,y,x update + next PCG start': (4, sA + 8 * (11 * mm) + 8 * (6 * n)),
+    }
+    probes = {}
+    for name, (which, nbytes) in {**pcg_kernels, **other}.items():
+        probes[name] = {'ms_same_kernel_repeat': s.hip_time_kernel(which, args.probe_reps), 'bytes': nbytes}
+    # in-sequence times: T(one PCG iteration as a solve runs it) minus T(the sequence without the kernel); this is what
+    # a solve pays (the kernels evict each other's matrix from L2)
+    pcg_ms = s.hip_time_kernel(seq_id, args.probe_reps)
+    if f1:
+        # every probe = two consecutive iterations (the double-buffered vectors alternate as in a solve).  16: F launches of the SLOT KERNEL
+        # ITSELF (phase record, scalars from the fold of the previous launch's partials, stopping test that never fires): what a launch costs
+        # inside a solve -- the figure the roofline uses.  15: the same iteration in a kernel that holds nothing but the F phase, fixed
+        # scalars; 14: that kernel without the fold.
+        pcg_ms *= 0.5
+        probes[dom]['ms'] = pcg_ms
+        probes[dom]['ms_f_only_kernel'] = 0.5 * s.hip_time_kernel(15, args.probe_reps)
+        probes[dom]['ms_f_only_kernel_without_scalar_fold'] = 0.5 * probes[dom].pop('ms_same_kernel_repeat')
+    elif fused:   # the "sequence without the kernel" is the other kernel alone (L2-hot, so this is an upper bound)
+        names = list(pcg_kernels)
+        for name, other_name in zip(names, names[::-1]):
+            probes[name]['ms'] = max(pcg_ms - probes[other_name]['ms_same_kernel_repeat'], 1e-6)
+    else:
+        for name, which in zip(list(pcg_kernels), (8, 7, 9)):
+            probes[name]['ms'] = max(pcg_ms - s.hip_time_kernel(which, args.probe_reps), 1e-6)
+    for name in other:
+        probes[name]['ms'] = probes[name]['ms_same_kernel_repeat']
+    for name in probes:
+        probes[name]['GBps'] = probes[name]['bytes'] / (probes[name]['ms'] * 1e-3) / 1e9
+    kb = {name: probes[name]['bytes'] for name in probes}
+    pcg_bytes = sum(kb[k] for k in pcg_kernels)
+    if f1:
+        # one launch = one PCG iteration of the reference algorithm: the contract's algorithmic bytes per launch are SURVEY §8(d)'s
+        # B_pcg; the kernel's own (smaller) traffic model is reported next to it as streamed_bytes / frac_streamed
+        probes[dom]['streamed_bytes'] = kb[dom]; probes[dom]['GBps_streamed'] = probes[dom]['GBps']
+        kb[dom] = survey_pcg_bytes; probes[dom]['bytes'] = survey_pcg_bytes
+        probes[dom]['GBps'] = survey_pcg_bytes / (probes[dom]['ms'] * 1e-3) / 1e9
+        streamed = pcg_bytes; pcg_bytes = survey_pcg_bytes
+    return probes, kb, pcg_bytes, pcg_ms, dom, dom_kernel, survey_pcg_bytes, (streamed if f1 else None), f1, fused, f1_D
+
+
+def self_launch(ngpus, script=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks ourselves -- the same
+    torch.distributed.run command line the task statement gives, one process per GPU, rendezvous on 127.0.0.1 -- and hand its exit code on."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC only on this driver (RCCL / tensor sharing across processes)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ngpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), script or os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -144,8 +243,11 @@ def main():
     ap.add_argument('--batch-cpu', type=int, default=1, help='time the all-cores CPU baseline of the batch too (N = 1 only)')
     ap.add_argument('--hbm-n', type=int, default=1000000, help='N = 1, headline config only: also time the dominant kernel on the same generator at this many variables '
                                                                '(a working set beyond the 256 MiB Infinity Cache) and report it as roofline.hbm_resident (0 disables)')
+    ap.add_argument('--unstructured-leg', type=int, default=1, help='N = 1, headline config only: also solve the unstructured variant of the same sizes and report its PCG iteration as roofline.unstructured (0 disables)')
     args = ap.parse_args()
     warnings.simplefilter('ignore')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -154,12 +256,22 @@ def main():
     import problems
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    assert world == args.gpus, 'WORLD_SIZE = %d but --gpus %d' % (world, args.gpus)
     if args.single_device:
         local = 0
+    # OSQP_BENCH_HOSTSIM=1 (tests/test_bench_launch.py ONLY): the launch / sharding / gather logic of this script on a machine without a GPU --
+    # the engine's host driver linked to the plain-loop device simulator of tests/hostsim, CPU tensors, gloo.  Nothing it prints is a measurement
+    # (the line says so in `data`); the product path has no such switch: without it a missing HIP device fails in osqp_setup.
+    hostsim = bool(os.environ.get('OSQP_BENCH_HOSTSIM'))
+    if hostsim:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from hostsim_util import hostsim as _hostsim_ctx
+        _ctx = _hostsim_ctx(); _ctx.__enter__()
+        args.dist_backend = 'gloo'; args.cpu_seconds = 0.0; args.hbm_n = 0
     # OSQP_BENCH_FORCE_DIST=1: initialise the process group (RCCL) also for one rank -- exercises init / barrier / all_gather on a 1-GPU box
     use_dist = world > 1 or bool(os.environ.get('OSQP_BENCH_FORCE_DIST'))
-    torch.cuda.set_device(local)
+    if not hostsim:
+        torch.cuda.set_device(local)
     if use_dist:
         if args.dist_backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))     # backend "nccl" is RCCL on ROCm
@@ -196,7 +308,9 @@ def main():
     def barrier():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not hostsim:
+            torch.cuda.synchronize()
+    sync = (lambda: None) if hostsim else torch.cuda.synchronize
 
     # Every step is a TRUE cold solve: x, z, y restart from zero (warm_starting = False) and rho is put back to the setting's value
     # (the solver object, like the reference's -- adapt_rho writes settings.rho, _osqp.py:923-930 -- would otherwise carry the rho a
@@ -208,9 +322,9 @@ def main():
             m.update_settings(rho=rho0)
         return m.solve()
     first_ms, first_iters = None, None
-    step_iters, step_ms = [], []
+    step_iters, step_ms, step_event_ms = [], [], []
     for w in range(args.warmup):
-        tw = time.perf_counter(); rw = cold_solve(); torch.cuda.synchronize()
+        tw = time.perf_counter(); rw = cold_solve(); sync()
         if w == 0:
             first_ms, first_iters = 1e3 * (time.perf_counter() - tw), int(rw.info.iter)
     barrier()
@@ -222,13 +336,14 @@ def main():
         res = cold_solve()
         iters += res.info.iter
         step_iters.append(int(res.info.iter)); step_ms.append(1e3 * (time.perf_counter() - ts))
+        step_event_ms.append(m._solver.hip_stats()['gpu_solve_ms'])      # hipEvent pair on the solver's stream around osqp_solve
     barrier()
     elapsed = time.perf_counter() - t0
     stats = m._solver.hip_stats()
 
     # whole-job aggregate: total ADMM iterations / max-over-ranks time; final status/objective gather over RCCL
     rec = torch.tensor([float(res.info.status_val), float(res.info.iter), res.info.obj_val, res.info.prim_res, res.info.dual_res,
-                        elapsed, float(iters)], dtype=torch.float64, device='cuda' if args.dist_backend == 'nccl' else 'cpu')
+                        elapsed, float(iters)], dtype=torch.float64, device='cuda' if (args.dist_backend == 'nccl' and not hostsim) else 'cpu')
     if use_dist:
         allrec = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(allrec, rec)
@@ -241,91 +356,26 @@ def main():
     # one all_gather of the records) -- on every rank, at any N: `value` stays the replica metric, the batch travels as config.batch so that
     # a scaling run of this script shows its strong-scaling curve (reference analogue: /root/reference/src/osqp/nn/torch.py:200-224)
     batch_out = None
-    if args.batch > 0 and args.config == 'banded' and args.dist_backend == 'nccl':
+    if args.batch > 0 and args.config == 'banded' and (args.dist_backend == 'nccl' or hostsim):
         import bench_batch
-        batch_out = bench_batch.measure_sharded_device(args.batch, args.batch_steps, 3, rank, world, local, use_dist)
+        if hostsim:
+            batch_out = bench_batch.measure_sharded_host(args.batch, args.batch_steps, rank, world, use_dist)
+        else:
+            batch_out = bench_batch.measure_sharded_device(args.batch, args.batch_steps, 3, rank, world, local, use_dist)
 
     if rank == 0:
-        nnzA, nnzB, mm = int(stats['nnzA']), int(stats['nnzB']), len(l)
+        mm = len(l)
         s = m._solver
-        fused = bool(stats.get('pcg_fused', 0))
-        f1 = int(stats.get('pcg_fused', 0)) == 2          # one launch per PCG iteration
-        f1_D = int(stats.get('f1_replicas', 0))
-        sA, sB = spmv_bytes(nnzA, mm, n), spmv_bytes(nnzB, n, n + mm)
-        # B_pcg = B_P + B_A + B_At + 104 n  (the reference algorithm's PCG iteration: three SpMVs + 13 n-vector passes)
-        nnzP_full = nnzB - nnzA
-        survey_pcg_bytes = spmv_bytes(nnzP_full, n, n) + spmv_bytes(nnzA, mm, n) + spmv_bytes(nnzA, n, mm) + 104 * n
-        # algorithmic bytes per launch (DESIGN.md "Kernels"): SpMV formula + the fused epilogue / extra vectors
-        if f1:
-            # what the F1 kernel itself has to move: A once (8-byte values + one packed 32-bit index word per entry, row pointers, rho,
-            # 16-bit column pointers of the windows ~ 2 bytes per column and replica), P + sigma I once (CSR), and per column: Minv, r, pu,
-            # s, D replicas read; p, x~ read; s, r, p, x~, pu and D replicas written
-            f1_bytes = 12 * nnzA + 4 * (mm + 1) + 8 * mm + 2 * f1_D * n + 12 * nnzP_full + 4 * (n + 1) + 8 * n * (4 + f1_D + 2 + 5 + f1_D)
-            pcg_kernels = {'F1 one PCG iteration per launch (k_slot1 phase F)': (14, f1_bytes)}
-            seq_id, dom, dom_kernel = 16, 'F1 one PCG iteration per launch (k_slot1 phase F)', 'k_f1_probe'
-        elif fused:     # two kernels per PCG iteration
-            pcg_kernels = {
-                # SpMV(A) applied to Minv.*s (the gathered vector, counted in sA) with the epilogue t = t - alpha rho S (+ rho, t read:
-                # 16m; t written = sA's output), + the vector update: u p r s Minv x~ read, p x~ r u' written (10 x 8n)
-                'K1F spmv A + pcg vector update (k_k1f)': (11, sA + 2 * 8 * mm + 10 * 8 * n),
-                # SpMV(B) whose output is s (w is never stored), + s and Minv read (16n), + Minv.*s written (8n)
-                'K2F spmv B + s, Minv.*s, <s,u> (k_k2f)': (12, sB + 3 * 8 * n),
-            }
-            seq_id, dom, dom_kernel = 10, 'K2F spmv B + s, Minv.*s, <s,u> (k_k2f)', 'k_k2f'
+        if hostsim:
+            probes = kb = dom = dom_kernel = streamed = None; pcg_bytes = pcg_ms = survey_pcg_bytes = 0; f1 = fused = False; f1_D = 0
         else:
-            pcg_kernels = {
-                'K1 spmv A (t=rho.*(A u))': (0, sA + 8 * mm),
-                'K2 spmv B (w=B[u;t], <w,u>)': (1, sB),
-                'Kv pcg vector update': (2, 12 * 8 * n),
-            }
-            seq_id, dom, dom_kernel = 6, 'K2 spmv B (w=B[u;t], <w,u>)', 'k_k2'
-        other = {
-            # (+ the extrapolated PCG start: KB resets x~ to it (8n written); KA reads the previous z~ and x~_prev and writes
-            #  A xg, xg, x~_prev: 8m + 8n read, 8m + 16n written)
-            'KB rhs + pcg start': (3, sB + 8 * mm + 8 * (5 * n)),
-            'KA A x~ + z,y,x update + next PCG start': (4, sA + 8 * (11 * mm) + 8 * (6 * n)),
-        }
-        probes = {}
-        for name, (which, nbytes) in {**pcg_kernels, **other}.items():
-            probes[name] = {'ms_same_kernel_repeat': s.hip_time_kernel(which, args.probe_reps), 'bytes': nbytes}
-        # in-sequence times: T(one PCG iteration as a solve runs it) minus T(the sequence without the kernel); this is what
-        # a solve pays (the kernels evict each other's matrix from L2)
-        pcg_ms = s.hip_time_kernel(seq_id, args.probe_reps)
-        if f1:
-            # every probe = two consecutive iterations (the double-buffered vectors alternate as in a solve).  16: F launches of the SLOT KERNEL
-            # ITSELF (phase record, scalars from the fold of the previous launch's partials, stopping test that never fires): what a launch costs
-            # inside a solve -- the figure the roofline uses.  15: the same iteration in a kernel that holds nothing but the F phase, fixed
-            # scalars; 14: that kernel without the fold.
-            pcg_ms *= 0.5
-            probes[dom]['ms'] = pcg_ms
-            probes[dom]['ms_f_only_kernel'] = 0.5 * s.hip_time_kernel(15, args.probe_reps)
-            probes[dom]['ms_f_only_kernel_without_scalar_fold'] = 0.5 * probes[dom].pop('ms_same_kernel_repeat')
-        elif fused:   # the "sequence without the kernel" is the other kernel alone (L2-hot, so this is an upper bound)
-            names = list(pcg_kernels)
-            for name, other_name in zip(names, names[::-1]):
-                probes[name]['ms'] = max(pcg_ms - probes[other_name]['ms_same_kernel_repeat'], 1e-6)
-        else:
-            for name, which in zip(list(pcg_kernels), (8, 7, 9)):
-                probes[name]['ms'] = max(pcg_ms - s.hip_time_kernel(which, args.probe_reps), 1e-6)
-        for name in other:
-            probes[name]['ms'] = probes[name]['ms_same_kernel_repeat']
-        for name in probes:
-            probes[name]['GBps'] = probes[name]['bytes'] / (probes[name]['ms'] * 1e-3) / 1e9
-        kb = {name: probes[name]['bytes'] for name in probes}
-        pcg_bytes = sum(kb[k] for k in pcg_kernels)
-        if f1:
-            # one launch = one PCG iteration of the reference algorithm: the contract's algorithmic bytes per launch are SURVEY §8(d)'s
-            # B_pcg; the kernel's own (smaller) traffic model is reported next to it as streamed_bytes / frac_streamed
-            probes[dom]['streamed_bytes'] = kb[dom]; probes[dom]['GBps_streamed'] = probes[dom]['GBps']
-            kb[dom] = survey_pcg_bytes; probes[dom]['bytes'] = survey_pcg_bytes
-            probes[dom]['GBps'] = survey_pcg_bytes / (probes[dom]['ms'] * 1e-3) / 1e9
-            streamed = pcg_bytes; pcg_bytes = survey_pcg_bytes
+            probes, kb, pcg_bytes, pcg_ms, dom, dom_kernel, survey_pcg_bytes, streamed, f1, fused, f1_D = measure_roofline(s, stats, n, mm, args)
         tts_ms = 1e3 * tmax / args.steps
         out = {
             'metric': 'ADMM iterations/sec, n=%d m=%d nnz(A)=%d %s (indirect PCG)' % (n, mm, A.nnz, 'sparse QP' if args.config in ('banded', 'shuffled', 'unstructured') else args.config + ' QP'),
             'value': total_iters / tmax, 'unit': 'ADMM iter/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * tmax / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
+            'dtype': 'f64', 'data': 'synthetic' if not hostsim else 'synthetic -- HOST SIMULATOR (OSQP_BENCH_HOSTSIM test mode): launch logic only, NOT a measurement',
             'config': {'workload': (wl_name % (n, mm, A.nnz, P.nnz)) + ', eps_abs=eps_rel=%g, indirect PCG, one replica per GPU' % args.eps,
                        'time_to_solution_ms': tts_ms, 'admm_iters_per_solve': int(res.info.iter), 'status': res.info.status, 'obj_val': res.info.obj_val,
                        # what a step is, exactly: x, z, y restart from zero and rho restarts from the setting (see cold_solve above); the
@@ -333,6 +383,10 @@ def main():
                        'rho_carried_between_steps': bool(args.carry_rho), 'first_cold_solve_ms': first_ms, 'first_cold_solve_admm_iters': first_iters,
                        'mean_admm_iters_per_step': sum(step_iters) / max(len(step_iters), 1), 'admm_iters_per_step': step_iters,
                        'ms_per_step_each': [round(v, 3) for v in step_ms],
+                       # SURVEY 8(d)'s timing form next to the contract's wall-clock mean: a hipEvent pair on the solver's stream around every
+                       # osqp_solve (OSQPHipStats::gpu_solve_ms), median over the timed steps; and the wall-clock median / spread of the same steps
+                       'solve_ms_hipevent_median': median(step_event_ms), 'solve_ms_hipevent_each': [round(v, 3) for v in step_event_ms],
+                       'ms_per_step_median': median(step_ms), 'ms_per_step_max_minus_min': (max(step_ms) - min(step_ms)) if step_ms else None,
                        'prim_res': res.info.prim_res, 'dual_res': res.info.dual_res, 'rho_updates': int(res.info.rho_updates),
                        'pcg_iters_per_admm_iter': stats['pcg_iters_total'] / max(res.info.iter, 1), 'pcg_budget_limited_iters': int(stats['pcg_unconverged']),
                        'cg_cap_escalations': int(stats.get('cg_cap_escalations', 0)), 'slot_topups': int(stats.get('slot_topups', 0)),
@@ -342,7 +396,7 @@ def main():
                        'woodbury_factor_ms_last_solve': stats.get('woodbury_factor_ms', 0.0),
                        'pcg_kernels_per_iteration': 1 if f1 else (2 if fused else 3), 'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
                        'setup_s': t_setup, 'per_rank': [{'status': int(r[0]), 'iter': int(r[1]), 'obj': r[2]} for r in allrec]},
-            'roofline': {'bound': 'hbm', 'kernel': dom + (' -- in solves this body runs as the K2F phase of k_slot_b' if (fused and not f1) else ''), 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'roofline': None if hostsim else {'bound': 'hbm', 'kernel': dom + (' -- in solves this body runs as the K2F phase of k_slot_b' if (fused and not f1) else ''), 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': probes[dom]['GBps'] / HBM_PEAK_GBS, 'traffic': pmc_traffic(dom_kernel, wl_tag),
                          'bytes_per_launch': kb[dom], 'ms_per_launch': probes[dom]['ms'],
                          'pcg_iteration': {'bytes': pcg_bytes, 'ms': pcg_ms, 'GBps': pcg_bytes / (pcg_ms * 1e-3) / 1e9,
@@ -398,6 +452,31 @@ def main():
                     'traffic': tr, 'frac_traffic': (tr / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None,
                     'solve': {'status': rb.info.status, 'admm_iters': int(rb.info.iter), 'first_cold_solve_ms': 1e3 * rb.info.solve_time}}
             del mb
+        if args.unstructured_leg and args.config == 'banded' and world == 1 and not hostsim and args.cpu_seconds > 0:
+            # "also run an unstructured variant for GB/s only" -- the same sizes with every row's columns drawn from the
+            # whole range: no permutation gives its row blocks a compact window, so the PCG iteration runs as the two-kernel
+            # pair with global gathers.  One solve + the pair's launch time, in the driver's record next to the banded figure.
+            Pu, qu, Au, lu, uu_ = problems.banded_qp(n, window=n, seed=12345)
+            mu = osqp_amd.OSQP(algebra='hip'); mu.setup(Pu, qu, Au, lu, uu_, **settings)
+            tu = time.perf_counter(); ru = mu.solve(); torch.cuda.synchronize(); tu = time.perf_counter() - tu
+            tu2 = time.perf_counter(); mu.update_settings(rho=rho0); ru = mu.solve(); torch.cuda.synchronize(); tu2 = time.perf_counter() - tu2
+            su = mu._solver; stu = su.hip_stats()
+            form = int(stu.get('pcg_fused', 0))
+            nzA, nzB = int(stu['nnzA']), int(stu['nnzB']); nzP = nzB - nzA
+            b8d = spmv_bytes(nzP, n, n) + spmv_bytes(nzA, mm, n) + spmv_bytes(nzA, n, mm) + 104 * n
+            ms_it = (0.5 * su.hip_time_kernel(16, args.probe_reps)) if form == 2 else su.hip_time_kernel(10 if form == 1 else 6, args.probe_reps)
+            tru = None
+            if form == 1:
+                t1, t2 = pmc_traffic('k_k2f', 'unstructured_n%d' % n), pmc_traffic('k_k1f', 'unstructured_n%d' % n)
+                tru = (t1 + t2) if (t1 and t2) else None
+            out['roofline']['unstructured'] = {
+                'workload': 'configs[1] sizes, columns drawn from the whole row (problems.banded_qp, window = n, seed 12345): n=%d m=%d nnz(A)=%d' % (n, mm, Au.nnz),
+                'launches_per_pcg_iteration': {2: 1, 1: 2}.get(form, 3), 'ms_per_pcg_iteration': ms_it, 'bytes_per_pcg_iteration': b8d,
+                'achieved': b8d / (ms_it * 1e-3) / 1e9, 'unit': 'GB/s', 'frac': b8d / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                'traffic': tru, 'windowed_row_blocks': '%d of %d' % (int(stu.get('windowed_blocks', 0)), int(stu.get('row_blocks', 0))),
+                'solve': {'status': ru.info.status, 'admm_iters': int(ru.info.iter), 'first_cold_solve_ms': 1e3 * tu, 'second_cold_solve_ms': 1e3 * tu2,
+                          'pcg_iters_per_admm_iter': stu['pcg_iters_total'] / max(ru.info.iter, 1)}}
+            del mu
         if args.cpu_seconds > 0 and world == 1:          # (the CPU baseline is timed at N = 1 only: the other ranks would wait 40 s at the barrier)
             cb = cpu_baseline(P, q, A, l, u, settings, args.cpu_seconds)
             out['cpu_baseline'] = cb

@@ -63,6 +63,56 @@ def cpu_batch_baseline(P, q, A, L, U, cores=None):
                       '%d ADMM iterations in %.2f s wall (slowest worker busy %.2f s)' % (B, cores, os.cpu_count() or 1, its, dt, busy)}
 
 
+def sharded_kernel_only(s, Ld, Ud, rank, world):
+    """This rank's share as ONE batched launch on torch's current stream, nothing else (for the event-timed kernel figure)."""
+    import torch
+    from osqp_amd import sharded
+    B = Ld.shape[0]
+    lo, hi = sharded.shard_range(B, rank, world)
+    nb = hi - lo
+    x = torch.empty((nb, s.n), dtype=torch.float64, device=Ld.device); y = torch.empty((nb, s.m), dtype=torch.float64, device=Ld.device)
+    rec = torch.zeros((max(nb, 1), 12), dtype=torch.float64, device=Ld.device)
+    s._solver.hip_batch_solve_device(nb, None, Ld[lo:hi].data_ptr(), Ud[lo:hi].data_ptr(), x.data_ptr(), y.data_ptr(), rec.data_ptr(), warm=False,
+                                     stream=torch.cuda.current_stream(Ld.device).cuda_stream)
+    return x, y, rec
+
+
+def measure_sharded_host(B, steps, rank, world, use_dist):
+    """The same split through the HOST-array path (osqp_amd.sharded.solve_batch_sharded, all_gather on CPU tensors): what bench.py's test mode on
+    the host simulator runs (tests/test_bench_launch.py) -- the sharding arithmetic, the collective and the table are the product's, the
+    solves are the simulator's.  Returns the same dict shape as measure_sharded_device."""
+    import torch
+    import torch.distributed as dist
+    import osqp_amd
+    import problems
+    from osqp_amd import sharded
+    P, q, A, L, U = problems.mpc_batch(B, nx=3, nu=2, N=4)
+    s = osqp_amd.OSQP(algebra='hip')
+    s.setup(P, q, A, L[0], U[0], eps_abs=1e-6, eps_rel=1e-6, verbose=False, max_iter=4000)
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter(); ms_each = []
+    for _ in range(steps):
+        ts = time.perf_counter()
+        table, x, y, span = sharded.solve_batch_sharded(s, l=L, u=U, rank=rank, world=world)
+        ms_each.append(round(1e3 * (time.perf_counter() - ts), 3))
+    own = torch.tensor([sum(ms_each) / max(steps, 1)], dtype=torch.float64)
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    per_rank_ms = [float(own.item())]
+    if use_dist:
+        dist.barrier()
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        owns = [torch.empty_like(own) for _ in range(world)]
+        dist.all_gather(owns, own)
+        per_rank_ms = [float(o.item()) for o in owns]
+    el = float(el.item())
+    owners = {int(i * world // B) for i in table[:, 0].astype(int)} if world > 1 else {0}
+    return {'workload': '%d small MPC QPs, contiguous blocks over %d rank(s), host-array path on the HOST SIMULATOR (test mode)' % (B, world),
+            'QP_per_s': B * steps / el, 'ms_per_batch': 1e3 * el / steps, 'ms_each': ms_each, 'steps': steps, 'solved': int((table[:, 1] == 1).sum()), 'records': int(table.shape[0]),
+            'n_ranks_seen': len(owners), 'per_rank_ms': [round(v, 3) for v in per_rank_ms], 'scaling': 'strong', 'admm_iters_total': float(table[:, 2].sum()),
+            'collective': 'all_gather (%s)' % ('gloo' if use_dist else 'single process: none needed'), '_data': (P, q, A, L, U)}
+
+
 def measure_sharded_device(B, steps, warmup, rank, world, local, use_dist):
     """BASELINE configs[4] through the path a multi-GPU job runs (osqp_amd.sharded.solve_batch_sharded_device: this rank's contiguous
     share in one batched launch by device pointer, then the job's ONE collective -- an all_gather of the 7-field records over RCCL -- INSIDE
@@ -95,16 +145,38 @@ def measure_sharded_device(B, steps, warmup, rank, world, local, use_dist):
         table, x, y, span = sharded.solve_batch_sharded_device(s, l=Ld, u=Ud, rank=rank, world=world)
         ncheck = int((table[:, 1] == 1).sum().item())                            # (the host reads the gathered table: synchronises the step)
         ms_each.append(round(1e3 * (time.perf_counter() - ts), 3))
+    own = torch.tensor([1e3 * sum(ms_each) / max(steps, 1)], dtype=torch.float64, device=dev)      # this rank's own mean step (solve of its share + the gather)
     barrier(); el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    per_rank_ms = [float(own.item())]
     if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        owns = [torch.empty_like(own) for _ in range(world)]
+        dist.all_gather(owns, own)
+        per_rank_ms = [float(o.item()) for o in owns]
     el = float(el.item())
+    # the launch alone, this rank's share: HIP events around the batch kernel on its stream (no gather, no host read of the table)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); sharded_kernel_only(s, Ld, Ud, rank, world); e1.record(); e1.synchronize()
+    kernel_ms = e0.elapsed_time(e1)
+    share8 = None
+    if world == 1 and B >= 8:
+        # what ONE rank of an 8-GPU job would do: a contiguous eighth of the batch (512 of 4096 = one resident wave of workgroups) in one launch
+        # + the read of its table, on this GPU -- the number that predicts the 8-GPU curve (the slowest QP's chain bounds it, not throughput)
+        lo8, hi8 = sharded.shard_range(B, 0, 8)
+        t8 = []
+        for rep in range(steps + 1):
+            torch.cuda.synchronize(); ts = time.perf_counter()
+            tb8, _, _, _ = sharded.solve_batch_sharded_device(s, l=Ld[lo8:hi8], u=Ud[lo8:hi8], rank=0, world=1)
+            _ = int((tb8[:, 1] == 1).sum().item())
+            if rep:
+                t8.append(1e3 * (time.perf_counter() - ts))
+        share8 = sorted(t8)[len(t8) // 2]
     tab = table.cpu().numpy()
     owners = {int(i * world // B) for i in tab[:, 0].astype(int)} if world > 1 else {0}       # ranks whose records arrived (problem i lives on rank i * world // B)
     return {'workload': 'BASELINE configs[4]: %d MPC QPs (n=120, m=240, problems.mpc_batch), eps 1e-6, contiguous blocks over %d rank(s), one batched launch per rank, '
                         'one all_gather of the 7-field records (inside the timed region); bounds resident in HBM, x / y left in HBM' % (B, world),
             'QP_per_s': B * steps / el, 'ms_per_batch': 1e3 * el / steps, 'ms_each': ms_each, 'steps': steps, 'solved': int((tab[:, 1] == 1).sum()), 'records': int(tab.shape[0]),
-            'n_ranks_seen': len(owners), 'scaling': 'strong', 'admm_iters_total': float(tab[:, 2].sum()),
+            'n_ranks_seen': len(owners), 'per_rank_ms': [round(v, 3) for v in per_rank_ms], 'kernel_ms_rank0_share': kernel_ms, 'share_of_8_ms': share8, 'scaling': 'strong', 'admm_iters_total': float(tab[:, 2].sum()),
             'collective': 'all_gather (%s)' % ('RCCL' if use_dist else 'single process: none needed'), '_data': (P, q, A, L, U)}
 
 
@@ -115,6 +187,9 @@ def main():
     ap.add_argument('--cpu-cores', type=int, default=0, help='worker processes of the CPU baseline (0 = every core this process may use)')
     args = ap.parse_args()
     warnings.simplefilter('ignore')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:      # no launcher around us: start the ranks ourselves (as bench.py does)
+        import bench
+        sys.exit(bench.self_launch(args.gpus, os.path.abspath(__file__)))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -122,7 +197,7 @@ def main():
     import problems
     from osqp_amd import sharded
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
-    assert world == args.gpus
+    assert world == args.gpus, 'WORLD_SIZE = %d but --gpus %d' % (world, args.gpus)
     use_dist = world > 1 or bool(os.environ.get('OSQP_BENCH_FORCE_DIST'))     # (one-rank RCCL run: exercises init / barrier / all_reduce on a 1-GPU box)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)

@@ -272,6 +272,10 @@ void h2d(Dev &d, void *dst, const void *src, size_t bytes);
 void d2h(Dev &d, void *dst, const void *src, size_t bytes);   // synchronous w.r.t. the solver stream
 void zero(Dev &d, void *dst, size_t bytes);
 void sync(Dev &d);
+// hipEvent pair on the solver's stream around one osqp_solve ("hipEvent around solve"): mark(0) at its start, mark(1) at its end;
+// ev_ms waits for the second event and returns the elapsed milliseconds (host simulator: wall clock)
+void ev_mark(Dev &d, int which);
+double ev_ms(Dev &d);
 void activate(Dev &d);                  // make d.device current for the calling thread (HIP's current device is thread-local)
 // Work enqueued on a CALLER's stream that reads solver-owned memory (batch_solve with a stream): ext_record marks its end on that
 // stream, ext_wait makes the host wait for it before the solver overwrites or frees that memory (no-op when nothing is pending).

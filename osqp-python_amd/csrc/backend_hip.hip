@@ -419,7 +419,7 @@ int init(Dev &d, int device) {
   HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   d.stream = s;
   Impl *p = new Impl();
-  HIP_CHECK(hipEventCreate(&p->ev0)); HIP_CHECK(hipEventCreate(&p->ev1)); HIP_CHECK(hipEventCreateWithFlags(&p->ev_ext, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&p->ev_wait, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreate(&p->ev0)); HIP_CHECK(hipEventCreate(&p->ev1)); HIP_CHECK(hipEventCreate(&p->ev_s0)); HIP_CHECK(hipEventCreate(&p->ev_s1)); HIP_CHECK(hipEventCreateWithFlags(&p->ev_ext, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&p->ev_wait, hipEventDisableTiming));
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_res), sizeof(double) * R_COUNT, hipHostMallocDefault));
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_flags), sizeof(int) * (F_COUNT + 16), hipHostMallocDefault));
   HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p->pin_poll), sizeof(int) * kSlotInts, hipHostMallocDefault));
@@ -433,7 +433,7 @@ void destroy(Dev &d) {
   if (!d.impl) return;
   (void)hipSetDevice(d.device);
   Impl &p = im(d);
-  (void)hipEventDestroy(p.ev0); (void)hipEventDestroy(p.ev1); (void)hipEventDestroy(p.ev_ext); (void)hipEventDestroy(p.ev_wait); (void)hipHostFree(p.pin_res); (void)hipHostFree(p.pin_flags);
+  (void)hipEventDestroy(p.ev0); (void)hipEventDestroy(p.ev1); (void)hipEventDestroy(p.ev_s0); (void)hipEventDestroy(p.ev_s1); (void)hipEventDestroy(p.ev_ext); (void)hipEventDestroy(p.ev_wait); (void)hipHostFree(p.pin_res); (void)hipHostFree(p.pin_flags);
   (void)hipHostFree(p.pin_poll); if (p.side) (void)hipStreamDestroy(p.side);
   (void)hipHostFree(p.pin_ctl); (void)hipHostFree(p.pin_ctl2);
   if (p.blas) wb_release_blas(p.blas);                 // (woodbury_hip.hip: the rocBLAS handle of the device-factorised form)
@@ -462,6 +462,8 @@ void d2h(Dev &d, void *dst, const void *src, size_t b) {
 }
 void zero(Dev &d, void *dst, size_t b) { if (!b) return; HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipMemsetAsync(dst, 0, b, st(d))); }
 void sync(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); HIP_CHECK(hipStreamSynchronize(st(d))); }
+void ev_mark(Dev &d, int which) { HIP_CHECK(hipSetDevice(d.device)); Impl &p = im(d); HIP_CHECK(hipEventRecord(which ? p.ev_s1 : p.ev_s0, st(d))); }
+double ev_ms(Dev &d) { Impl &p = im(d); float ms = 0.f; HIP_CHECK(hipEventSynchronize(p.ev_s1)); HIP_CHECK(hipEventElapsedTime(&ms, p.ev_s0, p.ev_s1)); return (double)ms; }
 void activate(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); }
 void ext_record(Dev &d, void *stream) {
   if (!stream || !d.impl) return;

@@ -464,9 +464,18 @@ void Engine::update_gap_info(const double *res, double t0) {
   }
 }
 
+// osqp_solve: the solve proper between a hipEvent pair on the solver's stream ("hipEvent around solve"; OSQPHipStats::gpu_solve_ms)
 int Engine::solve() {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);
+  be::ev_mark(d_, 0);
+  const int err = solve_impl();
+  be::ev_mark(d_, 1);
+  stats_.gpu_solve_ms = be::ev_ms(d_);
+  return err;
+}
+
+int Engine::solve_impl() {
   const double t0 = now_s();
   if (!pol_explicit_) policy_from_env(pol_, true);
   if (clear_update_time_) { info.update_time = 0; }
@@ -566,6 +575,7 @@ void Engine::info_from_ctl(double t0) {
 // chunk is a string of slot launches sized from the PCG iterations the previous chunk of this kind needed; the host watches the
 // chunk's progress on a side stream and tops the string up before it runs dry.
 void Engine::exec_chunk_sync(int cnt, int lim, bool with_res, int kind, double *res, int *flags) {
+  sync_graph_scalars();                                // (captured strings freeze Dev's scalars: also checked here, where strings are replayed outside admm_core -- polish, ls_solve)
   const bool slots = use_slots_ && be::slots_supported(d_);
   if (!slots) {
     run_chunk(cnt, lim);

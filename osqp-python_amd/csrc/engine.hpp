@@ -29,6 +29,7 @@ class Engine {
   int setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *A, const double *l, const double *u, int m,
             int n, const OSQPSettings *s);
   int solve();
+  int solve_impl();
   int warm_start(const double *x, const double *y, bool keep_z = false);
   int cold_start();
   int update_data_vec(const double *q, const double *l, const double *u);
@@ -166,7 +167,7 @@ class Engine {
   void drop_graphs();
   // Captured launches take Dev BY VALUE: its scalar fields (theta, alpha, sigma, the equality-weight rule k_set_rho reads) are frozen into
   // every graph.  sync_graph_scalars() compares them with what the graphs were captured with and drops the graphs when they differ; called
-  // wherever launches may be replayed (admm_core, ls_solve).
+  // wherever launches may be replayed (admm_core, exec_chunk_sync -- hence polish; ls_solve launches eagerly and replays nothing).
   double graph_sig_[6] = {0, 0, 0, 0, 0, 0};
   void sync_graph_scalars();
   int check_termination(const double *res, bool approximate);

@@ -36,15 +36,24 @@ bool Engine::compute_reorder(const std::vector<int> &Arp, const std::vector<int>
       for (int k = Brp[j]; k < Brp[j + 1] && Bj[k] < n; k++) { const int c = Bj[k]; if (cstamp[c] != stamp) { cstamp[c] = stamp; out.push_back(c); } }
     }
   };
+  size_t ordered = 0;                                // columns of components whose level structure was worth ordering
   for (int s0 = 0; s0 < n; s0++) {
     if (comp_done[s0]) continue;
+    widest = 0;                                      // (per component: one expander among the components must not hide a band in the others)
     bfs(s0, sweep);
     // An expander (columns drawn from everywhere) shows in the FIRST sweep: its levels explode, and no ordering of the levels can give row
-    // blocks a window of kF1Win columns -- stop before the remaining five sweeps (n = 100k unstructured: 97 ms of setup for nothing)
-    if (widest > 8u * kF1Win) return false;
+    // blocks a window of kF1Win columns -- skip the two further sweeps (n = 100k unstructured: 97 ms of setup for nothing); the component
+    // keeps its natural order
+    if (widest > 8u * kF1Win) {
+      std::sort(sweep.begin(), sweep.end());
+      for (int c : sweep) { comp_done[c] = 1; order.push_back(c); }
+      continue;
+    }
     if (sweep.size() > 2) { bfs(sweep.back(), best); bfs(best.back(), sweep); }      // pseudo-peripheral start: the far end of the far end
     for (int c : sweep) { comp_done[c] = 1; order.push_back(c); }
+    ordered += sweep.size();
   }
+  if (2 * ordered < (size_t)n) return false;         // most of the problem is expander-like: no permutation will make the plan applicable
   std::vector<double> rank(n), prow(m), pcol(n);
   for (int k = 0; k < n; k++) rank[order[k]] = k;
   std::vector<int> idx(n);
@@ -285,6 +294,11 @@ void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj
   w.on = 1;
   // K0 diagonal <=> P has diagonal entries only and every short row of A has exactly one entry: then M = K (backend.h DevWb::exact)
   bool diag = pol_.woodbury_direct != 0;
+  // A long row that stores the same (row, column) twice (a valid CSC may: the engine keeps duplicates as separate CSR entries, and every SpMV
+  // sums them) has ONE cell in the dense tiles / the dense transpose, which the fill kernels ASSIGN: the tile would hold one of the two
+  // values.  As a preconditioner that is merely a slightly different M; as the direct mode (M taken for K) it would solve another system.
+  { std::vector<int> mark(n, -1);
+    for (int a = 0; a < r && diag; a++) for (int k = lrp[a]; k < lrp[a + 1]; k++) { if (mark[lcol[k]] == a) { diag = false; break; } mark[lcol[k]] = a; } }
   for (int j = 0; j < n && diag; j++) for (int k = P_.p[j]; k < P_.p[j + 1]; k++) if (P_.i[k] != j) { diag = false; break; }
   for (int i = 0; i < m && diag; i++) if (!islong[i] && Arp[i + 1] - Arp[i] > 1) diag = false;
   w.exact = diag ? 1 : 0;
@@ -443,10 +457,11 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   };
   bool f1ok = try_plan();
   // Reordering (OSQPHipPolicy::reorder; Engine::compute_reorder): 1 = when the one-launch form does not apply to the problem as given,
-  // look for a permutation under which it does and keep it only then; 2 = always work on the permuted problem (tests of the plumbing)
+  // look for a permutation under which it does and keep it only then -- never for a QP small enough for the batch kernel, which takes the
+  // caller's numbering only (a handle that serves batches keeps doing so); 2 = always work on the permuted problem (tests of the plumbing)
   clear_reorder(); reorder_ms_ = 0;
   const int reorder = no_reorder_ ? 0 : pol_.reorder;
-  if (m > 0 && (reorder == 2 || (reorder == 1 && want_f1 && !f1ok && be::device_assembly() && (int)rbA.size() - 1 >= kGrid / 4))) {
+  if (m > 0 && (reorder == 2 || (reorder == 1 && want_f1 && !f1ok && be::device_assembly() && (int)rbA.size() - 1 >= kGrid / 4 && !be::batch_lds_bytes(n, m)))) {
     const double tr = now_s();
     if (compute_reorder(Arp, Arj, Brp, Bj) || reorder == 2) {
       if (pc_.empty()) {                             // (forced mode on a graph the search gave up on: the identity permutation exercises the plumbing just as well)

@@ -59,6 +59,7 @@ static_assert(SL_RES0 + R_COUNT <= kPartSlots, "Dev::part is too small");
 
 struct Impl {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_ext = nullptr, ev_wait = nullptr;      // ev_ext: end of a batch kernel on a caller's stream (ext_record / ext_wait); ev_wait: stream_wait
+  hipEvent_t ev_s0 = nullptr, ev_s1 = nullptr;   // around one osqp_solve on the solver's stream (ev_mark / ev_ms)
   bool ext_pending = false;
   double *pin_res = nullptr;
   int *pin_flags = nullptr;      // [F_COUNT + 16]: the flags block followed by the two slot records

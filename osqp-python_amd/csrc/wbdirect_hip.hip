@@ -325,17 +325,20 @@ void wbx_refresh(Dev &d) {
   if (!d.wb.on || !d.wb.x.on) return;
   WBX_CHECK(hipSetDevice(d.device));
   hipLaunchKernelGGL(k_wbx_fill, dim3(256), dim3(kT), 0, static_cast<hipStream_t>(d.stream), d);
+  WBX_CHECK(hipGetLastError());
 }
 void wbx_factor(Dev &d, int cond) {            // after S^-1 has changed (rho update): tile2 = S^-1 A_L;  cond: only when the boundary group updated rho
   if (!d.wb.on || !d.wb.x.on) return;
   WBX_CHECK(hipSetDevice(d.device));
   hipLaunchKernelGGL(k_wbx_t2, dim3(d.wb.x.G), dim3(kT), sizeof(XLds), static_cast<hipStream_t>(d.stream), d, cond);
+  WBX_CHECK(hipGetLastError());                // (these kernels need 75-142 KB of dynamic LDS, granted by wbx_init: a refused launch must not pass silently)
 }
 void wbx_slot_pair(Dev &d) {
   hipStream_t s = static_cast<hipStream_t>(d.stream);
   const dim3 grid(d.wb.x.G), block(kT);
   hipLaunchKernelGGL(k_wbx_slot_x, grid, block, sizeof(XLds), s, d);
   hipLaunchKernelGGL(k_wbx_slot_y, grid, block, sizeof(YLds), s, d);
+  WBX_CHECK(hipGetLastError());
 }
 void wbx_init(Dev &d) {                        // (more than the default 64 KB of dynamic LDS: gfx950 has 160 KB per CU, one workgroup per CU here)
   WBX_CHECK(hipSetDevice(d.device));
@@ -362,6 +365,7 @@ void wbx_chunk(Dev &d, int niter) {
   }
   hipLaunchKernelGGL(k_wbx_y, grid, block, sizeof(YLds), s, d);
   hipLaunchKernelGGL((k_wbx_x<true, false>), grid, block, lds, s, d);
+  WBX_CHECK(hipGetLastError());
 }
 
 }  // namespace be

@@ -293,7 +293,7 @@ class OSQPSolver:
         st = self._lib.osqp_hip_batch_solve(self._p, B, _ptr(q, _lib.c_double_p), _ptr(l, _lib.c_double_p), _ptr(u, _lib.c_double_p),
                                             _ptr(x, _lib.c_double_p), _ptr(y, _lib.c_double_p), _ptr(rec, _lib.c_double_p), int(warm))
         if st:
-            raise ValueError(str(st))
+            raise self._batch_error(st)
         return x, y, rec
 
     def hip_batch_solve_device(self, nbatch, q_ptr, l_ptr, u_ptr, x_ptr, y_ptr, rec_ptr, warm=False, stream=None):
@@ -301,7 +301,17 @@ class OSQPSolver:
         rec: (B, BATCH_REC).  Enqueued on `stream` (hipStream_t handle as int; None: the solver's stream, synchronous)."""
         st = self._lib.osqp_hip_batch_solve_device(self._p, int(nbatch), q_ptr, l_ptr, u_ptr, x_ptr, y_ptr, rec_ptr, int(bool(warm)), stream)
         if st:
-            raise ValueError(str(st))
+            raise self._batch_error(st)
+
+    def _batch_error(self, st):
+        """ValueError(str(code)) as the pybind layer raises for a failed call (callers compare str(e) with the code); `.reason` says why
+        the batch kernel declined: OSQP_FUNC_NOT_IMPLEMENTED = the QP does not fit one workgroup's LDS, or this handle works on a
+        reordered copy of the problem (OSQPHipPolicy::reorder = 2; the automatic mode never reorders a problem the batch kernel takes)."""
+        e = ValueError(str(st))
+        e.code = int(st)
+        e.reason = ('the handle works on a reordered copy of the problem (OSQPHipPolicy::reorder): the batch kernel takes the caller\'s numbering only'
+                    if self.hip_stats().get('reordered') else 'the batch kernel declined (code %d): the QP does not fit one workgroup\'s LDS, or an argument is invalid' % int(st))
+        return e
 
     def hip_scaling(self):
         D, E, c = np.empty(self.n), np.empty(self.m), C.c_double()

@@ -4,6 +4,7 @@
 // host driver (engine.cpp, api.cpp) into tests/_build/libosqp_hostsim.so by tests/hostsim_build.py so the driver logic
 // can be exercised in CI containers that have no GPU.  The product library libosqp_hip.so links backend_hip.hip only,
 // has no CPU path, and never loads this file.
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -32,6 +33,9 @@ void h2d(Dev &, void *dst, const void *src, size_t b) { std::memcpy(dst, src, b)
 void d2h(Dev &, void *dst, const void *src, size_t b) { std::memcpy(dst, src, b); }
 void zero(Dev &, void *dst, size_t b) { std::memset(dst, 0, b); }
 void sync(Dev &) {}
+static thread_local double g_ev[2];
+void ev_mark(Dev &, int which) { g_ev[which ? 1 : 0] = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+double ev_ms(Dev &) { return 1e3 * (g_ev[1] - g_ev[0]); }
 void activate(Dev &) {}
 bool device_vec_updates() { return false; }
 void copy_in(Dev &, void *dst, const void *src, size_t bytes, int) { std::memcpy(dst, src, bytes); }

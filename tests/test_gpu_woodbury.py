@@ -225,3 +225,42 @@ def test_two_launch_direct_mode_is_deterministic():
             got.append((r.info.iter, r.info.rho_updates, r.x.copy(), r.y.copy()))
     for g in got[1:]:
         assert g[:2] == got[0][:2] and np.array_equal(g[2], got[0][2]) and np.array_equal(g[3], got[0][3])
+
+
+def test_duplicate_entry_in_a_dense_row_keeps_the_direct_mode_off():
+    """a valid CSC that stores one (row, column) of a DENSE row twice (the engine keeps the two as separate CSR entries; every SpMV
+    sums them) has one cell in the dense tiles of the Woodbury forms, which the fill kernels assign.  The direct mode (M taken for K) must then
+    stay off -- the solve goes through the PCG with the (slightly different) corrected preconditioner and still matches the oracle on the
+    matrix with the duplicates summed."""
+    import scipy.sparse as sp
+    P, q, A, l, u = problems.portfolio_qp(1500, 12)
+    A = A.tocsc(); A.sort_indices()
+    # duplicate one entry of the first dense row (the budget / factor rows hold hundreds of entries): (i, j) stored as 0.6 v and 0.4 v
+    counts = np.diff(A.tocsr().indptr); i = int(np.argmax(counts)); assert counts[i] > 128
+    j = int(A.tocsr().indices[A.tocsr().indptr[i] + 3])
+    indptr, indices, data = [0], [], []
+    for c in range(A.shape[1]):
+        for k in range(A.indptr[c], A.indptr[c + 1]):
+            if c == j and A.indices[k] == i:
+                indices += [i, i]; data += [0.6 * A.data[k], 0.4 * A.data[k]]
+            else:
+                indices.append(A.indices[k]); data.append(A.data[k])
+        indptr.append(len(indices))
+    Adup = sp.csc_matrix((np.array(data), np.array(indices), np.array(indptr)), shape=A.shape)
+    assert Adup.nnz == A.nnz + 1
+    ext = osqp_amd.interface._backend('hip')
+    st = ext.OSQPSettings(); ext.osqp_set_default_settings(st)
+    st.verbose = 0; st.eps_abs = st.eps_rel = 1e-7; st.max_iter = 50000; st.adaptive_rho_interval = 50
+    Pt = sp.triu(P).tocsc()
+    solver = ext.OSQPSolver(ext.CSC(Pt), q, ext.CSC(Adup), l, u, A.shape[0], A.shape[1], st)      # straight through the C ABI: no duplicate summing on the way
+    solver.solve()
+    s = solver.hip_stats()
+    assert solver.info.status_val == 1
+    assert s['woodbury_rows'] > 0 and s['woodbury_direct'] == 0          # preconditioner yes, direct mode no
+    xo, yo, io = Oracle().setup(P, q, A, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000, adaptive_rho_interval=50).solve()
+    assert io.status_val == SOLVED
+    assert _rel(np.array(solver.solution.x), xo) < 5e-5
+    # the same data without the duplicate takes the direct mode (the check above is not vacuous)
+    solver2 = ext.OSQPSolver(ext.CSC(Pt), q, ext.CSC(A), l, u, A.shape[0], A.shape[1], st)
+    solver2.solve()
+    assert solver2.hip_stats()['woodbury_direct'] >= 1
