@@ -359,6 +359,14 @@ OSQPInt osqp_hip_get_scaling(OSQPSolver *solver, OSQPFloat *D, OSQPFloat *E, OSQ
    k-th variable / constraint; the identity when the problem was not reordered (OSQPHipStats::reordered = 0).  Diagnostic: nothing at this
    API is expressed in the engine's numbering. */
 OSQPInt osqp_hip_get_reordering(OSQPSolver *solver, OSQPInt *perm_cols, OSQPInt *perm_rows);
+/* Where `verbose` output goes.  The reference's C core prints through c_print, which its Python binding maps to PySys_WriteStdout under the GIL
+   (/root/reference/cmake/printing.h:2-7) while solve() runs with the GIL released (bindings.cpp.in:197-199).  Here: every line of text a handle
+   prints is handed to ITS print function, or to stdout (fputs) when none is set.  osqp_hip_set_default_print installs the function handles
+   created AFTERWARDS start with (osqp_setup prints the problem header before the caller holds the handle) -- the Python layer installs one that
+   writes to sys.stdout (a ctypes callback takes the GIL itself); osqp_hip_set_print changes one handle's.  fn == NULL restores stdout. */
+typedef void (*osqp_hip_print_fn)(const char *text, void *user);
+void    osqp_hip_set_default_print(osqp_hip_print_fn fn, void *user);
+OSQPInt osqp_hip_set_print(OSQPSolver *solver, osqp_hip_print_fn fn, void *user);
 /* name of the compute backend compiled into this library: "hip-gfx950" for the product */
 const char *osqp_hip_backend(void);
 

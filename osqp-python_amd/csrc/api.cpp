@@ -26,6 +26,8 @@ OSQPInt guarded(OSQPSolver *s, F &&f) {
 extern "C" {
 
 const char *osqp_version(void) { return "1.0.0-hip.r1"; }
+void osqp_hip_set_default_print(osqp_hip_print_fn fn, void *user) { Engine::set_default_print(fn, user); }
+OSQPInt osqp_hip_set_print(OSQPSolver *s, osqp_hip_print_fn fn, void *user) { return guarded(s, [&](Engine &e) { e.set_print(fn, user); return (int)OSQP_NO_ERROR; }); }
 const char *osqp_hip_backend(void) { return osqp_hip::be::name(); }
 
 OSQPInt osqp_capabilities(void) { return OSQP_CAPABILITY_INDIRECT_SOLVER | OSQP_CAPABILITY_UPDATE_MATRICES; }

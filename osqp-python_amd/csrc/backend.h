@@ -44,6 +44,7 @@ constexpr int kF1PChunk = 256;     // most (P + sigma I) entries of a block's ow
 constexpr int kF1MaxOwn = 512;     // most own columns of a block
 constexpr int kF1MaxRows = 512;    // most rows of a block
 constexpr int kF1Chunk = 1024;     // most entries of a row block of A
+constexpr int kF1StreamBytes = kF1Chunk * 12;   // a block's slice of DevF1::stream: 8-byte values + 4-byte packed index words
 
 struct DevCsr {
   int nrows = 0, ncols = 0, nnz = 0, nblk = 0;
@@ -84,7 +85,13 @@ struct DevF1 {
                                  //   {offset of the block's column pointers in cptr, first and end entry of its own rows in the P arrays, 0}
                                  //   {g0, gl, a0, wl}: gather window [g0, g0 + gl) (columns of the block's rows of A -- plus those of its own
                                  //   rows of P if that widens it by at most a quarter), scatter window [a0, a0 + wl) (columns of its rows of A)
-  unsigned int *ent = nullptr;   // nnz(A): column relative to g0 (9 bits) | local row << 9 (9 bits) | position of the entry in the block's column-major order << 18 (11 bits)
+  // The matrix stream of a block, in the layout the kernel's LDS buffer has (pcg_hip.hip F1Stream): block b owns the kF1StreamBytes bytes at
+  // stream + b * kF1StreamBytes = { double val[kF1Chunk]; unsigned ent[kF1Chunk]; } -- the block's values of A (copied from A.val by be::f1_refresh)
+  // and one packed word per entry: column relative to g0 (9 bits) | local row << 9 (9 bits) | position of the entry in the block's
+  // column-major order << 18 (11 bits).  Fixed stride: the address depends on the block index alone, so a workgroup requests its first block's
+  // stream at the very head of a launch -- before any record has arrived -- and the NEXT block's stream while the current one is in its LDS
+  // phases, both as LDS-direct loads (global_load_lds_dwordx4: no VGPR destination).
+  unsigned char *stream = nullptr;
   unsigned short *cptr = nullptr;// per block: window length + 1 column pointers (block-local, column-major entry positions)
   int *prp = nullptr, *pcol = nullptr, *psrc = nullptr;   // compact CSR of P + sigma I (n rows): row pointers, columns, position of each entry in B.val
   double *pval = nullptr;        // values, refreshed from B.val by be::f1_refresh (after assembly / equilibration / matrix updates)

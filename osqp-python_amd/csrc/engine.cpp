@@ -4,6 +4,9 @@
 
 #include "engine_internal.hpp"
 
+#include <atomic>
+#include <cstdarg>
+
 namespace osqp_hip {
 
 // ------------------------------------------------------------------------------------------------ policy
@@ -81,7 +84,39 @@ int Engine::set_policy(const OSQPHipPolicy *p) {
   return OSQP_NO_ERROR;
 }
 
+// ---- verbose output.  The reference prints through c_print = PySys_WriteStdout under the GIL (/root/reference/cmake/printing.h:2-7); here every
+// piece of text goes to the handle's print function (include/osqp_hip.h osqp_hip_set_print; the Python layer installs one that writes to
+// sys.stdout), or to stdout when there is none.
+namespace {
+std::atomic<osqp_hip_print_fn> g_print_fn{nullptr};
+std::atomic<void *> g_print_user{nullptr};
+}
+void Engine::set_default_print(osqp_hip_print_fn fn, void *user) { g_print_user.store(user); g_print_fn.store(fn); }
+void Engine::say(const char *fmt, ...) const {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (print_fn_) print_fn_(buf, print_user_);
+  else { std::fputs(buf, stdout); std::fflush(stdout); }
+}
+// one line of the iteration table (_osqp.py:960-978; the time column is the run time so far, :964-967)
+void Engine::print_summary_line(int iter, double obj, double pri, double dua, double rho, double t0) const {
+  say("%4d  %11.4e   %8.2e   %8.2e   %8.2e  %8.2es\n", iter, obj, pri, dua, rho, (first_run_ ? info.setup_time : info.update_time) + (now_s() - t0));
+}
+// the checks the state block has logged since the last call (policy.h Ctl::log: every kCtlPrintInterval iterations, _osqp.py:1230-1231)
+void Engine::print_log(const Ctl &c, double t0) {
+  if (!settings.verbose) return;
+  if (c.nlog - log_printed_ > kCtlLog) log_printed_ = c.nlog - kCtlLog;      // (the host fell a whole ring behind: the oldest lines are gone)
+  for (; log_printed_ < c.nlog; log_printed_++) {
+    const double *e = c.log[log_printed_ % kCtlLog];
+    print_summary_line((int)e[0], e[1], e[2], e[3], e[4], t0);
+  }
+}
+
 Engine::Engine() {
+  print_fn_ = g_print_fn.load(); print_user_ = g_print_user.load();
   pub.settings = &settings; pub.solution = &solution; pub.info = &info; pub.work = reinterpret_cast<OSQPWorkspace *>(this);
   policy_from_env(pol_, false);
   use_graph_ = pol_.graph != 0; use_slots_ = pol_.slots != 0;
@@ -120,7 +155,7 @@ void Engine::free_all() {
                   d_.scal, d_.flags, d_.slot, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB,
                   d_.wb.AL.rowptr, d_.wb.AL.col, d_.wb.AL.blkdesc, d_.wb.AL.runinfo, d_.wb.AL.val, d_.wb.ALT.rowptr, d_.wb.ALT.col, d_.wb.ALT.blkdesc, d_.wb.ALT.runinfo, d_.wb.ALT.val,
                   d_.wb.al_src, d_.wb.alt_src, d_.wb.islong, d_.wb.rows, d_.wb.WT, d_.wb.S, d_.wb.Sinv, d_.wb.g, d_.wb.h, d_.wb.Dinv0, d_.wb.colmap, d_.wb.W, d_.wb.pv, d_.wb.info, d_.wb.dbg, d_.wb.x.tile, d_.wb.x.tile2, d_.wb.x.partG, d_.wb.x.partZ, d_.wb.x.ls0, d_.wb.x.ls1, d_.wb.x.sc_ptr, d_.wb.x.sc_row, d_.wb.x.sc_src, d_.wb.x.sc_val, d_.wb.x.bjj,
-                  d_.ctl, d_.f1.blk, d_.f1.ent, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.va, d_pc_, d_pr_};
+                  d_.ctl, d_.f1.blk, d_.f1.stream, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.va, d_pc_, d_pr_};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   be::destroy(d_);
   d_ = Dev(); d_pc_ = d_pr_ = nullptr;
@@ -499,11 +534,23 @@ int Engine::solve_impl() {
   be::sync(d_);
   info.run_time = (first_run_ ? info.setup_time : info.update_time) + info.solve_time + info.polish_time;   // :1284-1289
   first_run_ = false; clear_update_time_ = true;
-  if (settings.verbose)
-    std::printf("\nstatus:               %s\n%snumber of iterations: %d\noptimal objective:    %.4f\nrun time:             %.2es\noptimal rho estimate: %.2e\n\n",
-                info.status, info.status_polish == 1 ? "solution polish:      successful\n" : (info.status_polish == -1 ? "solution polish:      unsuccessful\n" : ""),
-                info.iter, info.obj_val, info.run_time, info.rho_estimate);
+  if (settings.verbose) print_footer();
   return OSQP_NO_ERROR;
+}
+
+// _osqp.py:1079-1096
+void Engine::print_footer() const {
+  say("\nstatus:               %s\n", info.status);
+  if (settings.polishing && info.status_val == OSQP_SOLVED) {
+    if (info.status_polish == 1) say("solution polish:      successful\n");
+    else if (info.status_polish == -1) say("solution polish:      unsuccessful\n");
+  }
+  say("number of iterations: %d\n", info.iter);
+  if (info.status_val == OSQP_SOLVED || info.status_val == OSQP_SOLVED_INACCURATE) {
+    say("optimal objective:    %.4f\n", info.obj_val);
+    say("run time:             %.2es\n", info.run_time);
+  }
+  say("optimal rho estimate: %.2e\n\n", info.rho_estimate);
 }
 
 // The ADMM loop proper (_osqp.py:1208-1266) on the current device iterates with the current settings; sets info.{iter,
@@ -563,6 +610,7 @@ void Engine::info_from_ctl(double t0) {
   info.dual_obj_val = c.dual_obj_val; info.duality_gap = c.duality_gap; info.rel_kkt_error = c.rel_kkt_error;
   info.rho_updates = c.rho_updates;
   if (c.rho_estimate > 0) info.rho_estimate = c.rho_estimate;
+  rho_at_last_check_ = rho_bar_;
   if (t0 >= 0) {
     const double t = now_s() - t0;
     info.primdual_int += std::fabs(info.duality_gap) * std::max(0.0, t - gap_time_);
@@ -703,6 +751,7 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
     run_slots(0, np, 0); launched += np; }
   for (;;) {
     be::ctl_poll(d_, &snap, &seq, &done);
+    print_log(snap, t0);
     if (snap.status != CTL_RUNNING) break;
     if (now_s() - t0 > settings.time_limit) { timed_out = true; break; }
     const long ahead = launched - seq / 2;           // pairs enqueued and not yet executed
@@ -775,7 +824,8 @@ void Engine::admm_core(double t0, double *res) {
   }
   have_tol_ = false;
   ctl_next_chunk(c);
-  if (settings.verbose) std::printf("iter   objective    prim res   dual res   rho        cg   time\n");
+  log_printed_ = 0;
+  if (settings.verbose) say("iter   objective    pri res    dua res    rho       time\n");      // _osqp.py:609-613
   int flags[F_COUNT] = {0};
   for (;;) {
     int st;
@@ -783,9 +833,10 @@ void Engine::admm_core(double t0, double *res) {
     // (the Woodbury direct mode takes the slot form only when asked to, device_driven = 2: its two launches per ADMM iteration are so short
     //  that a boundary group of sixteen launches costs what the host round trip it replaces costs, and the fixed captured strings of the
     //  host-synchronous loop carry no idle launches -- 34 against 41 ms on the portfolio QP)
-    d_.wb.x.slots = (pol_.device_driven >= 2 && !settings.verbose) ? 1 : 0;
+    d_.wb.x.slots = (pol_.device_driven >= 2) ? 1 : 0;
     const bool slots = use_slots_ && be::slots_supported(d_);
-    const bool device_driven = slots && pol_.device_driven && !settings.verbose && be::ctl_supported(d_);
+    // (`verbose` changes nothing about how a solve runs: the printed lines come from the state block's log, policy.h Ctl::log)
+    const bool device_driven = slots && pol_.device_driven && be::ctl_supported(d_);
     const bool first_chunk = c.iter == 0;
     if (first_chunk || !device_driven) {
       be::set_pcg_tol(d_, c.tol_rel, ctl_chunk_tol_abs(c));
@@ -826,16 +877,14 @@ void Engine::admm_core(double t0, double *res) {
       }
       if (was_check) {
         info_from_ctl(t0);
-        if (settings.verbose)
-          std::printf("%4d  %11.4e   %8.2e   %8.2e   %8.2e  %3d  %8.2es   (cg mean %.1f budget %d unconv %d; rho est %.2e)\n", c.iter, info.obj_val, info.prim_res,
-                      info.dual_res, rho_was, flags[F_STAT_MAX], now_s() - t0, flags[F_STAT_SUM] / (double)std::max(1, flags[F_STAT_N]), lim,
-                      flags[F_STAT_UNCONV], pol_rho_estimate(rho_was, res));
+        print_log(c, t0);
       }
-      (void)tight;
+      (void)tight; (void)rho_was;
       if (st == CTL_RUNNING && c.rho_flag) apply_rho(c.rho_bar);
     } else {
       st = run_device_driven(t0, res, flags);
       info_from_ctl(t0);
+      print_log(c, t0);
       if (st == -2) { set_status(OSQP_TIME_LIMIT_REACHED); break; }
     }
     if (st == CTL_DONE) {
@@ -863,6 +912,7 @@ void Engine::admm_core(double t0, double *res) {
     }
     if (now_s() - t0 > settings.time_limit) { set_status(OSQP_TIME_LIMIT_REACHED); break; }
   }
+  if (settings.verbose && info.iter % kCtlPrintInterval != 0) print_summary_line(info.iter, info.obj_val, info.prim_res, info.dual_res, rho_at_last_check_, t0);      // _osqp.py:1259-1261
   info.rho_updates = c.rho_updates;
   stats_.pcg_iters_total = c.pcg_total; stats_.pcg_iters_max = c.pcg_max; stats_.pcg_unconverged = c.pcg_unconv;
   stats_.cg_cap_escalations = c.escalations;
@@ -978,7 +1028,8 @@ void Engine::polish() {
   }
   be::init_iterates(d_, 0);
   info.polish_time = now_s() - tp;
-  if (settings.verbose) std::printf("plsh  %11.4e   %8.2e   %8.2e   --------  (%s)\n", pol_obj, pol_pri, pol_dua, ok ? "accepted" : "rejected");
+  if (settings.verbose) say("plsh  %11.4e   %8.2e   %8.2e   --------  %8.2es\n", pol_obj, pol_pri, pol_dua,
+                            (first_run_ ? info.setup_time : info.update_time) + info.solve_time + info.polish_time);      // _osqp.py:980-996
 }
 
 void Engine::store_solution() {                                                          // _osqp.py:1098-1115

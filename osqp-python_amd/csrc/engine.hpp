@@ -49,6 +49,9 @@ class Engine {
   int trace_read(unsigned long long *out, int count);
   int get_scaling(double *D, double *E, double *c);
   int get_reordering(int *perm_cols, int *perm_rows) const;
+  // verbose output (include/osqp_hip.h osqp_hip_set_print): one function per handle, the process default at construction
+  void set_print(osqp_hip_print_fn fn, void *user) { print_fn_ = fn; print_user_ = user; }
+  static void set_default_print(osqp_hip_print_fn fn, void *user);
   int set_rho_eq_factor(double f);
   int batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, double *zs_dev = nullptr);
   int batch_solve_device(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, void *stream);
@@ -68,6 +71,14 @@ class Engine {
   static int validate_settings(const OSQPSettings *s, bool at_setup);
 
  private:
+  osqp_hip_print_fn print_fn_ = nullptr; void *print_user_ = nullptr;
+  void say(const char *fmt, ...) const __attribute__((format(printf, 2, 3)));      // one piece of verbose text -> the handle's print function (stdout without one)
+  int log_printed_ = 0;                 // entries of Ctl::log already printed in this solve
+  void print_summary_line(int iter, double obj, double pri, double dua, double rho, double t0) const;
+  void print_log(const Ctl &c, double t0);
+  void print_footer() const;
+  void print_setup_header() const;
+  double rho_at_last_check_ = 0;        // rho_bar the last termination check ran with (the rho column of the last printed line)
   // ---- host copies ----
   HostCsc P_, A_;                       // P_: upper triangle
   std::vector<double> q0_, l0_, u0_;    // unscaled

@@ -411,10 +411,10 @@ void Engine::attach_batch_direct(BatchParams &p) {
 // (same iteration counts as the oracle), instead of thousands of graph-replayed multi-kernel iterations with inexact
 // inner solves -- on small LPs / rank-deficient QPs the latter can need 10x more ADMM iterations (fuzz).
 // With `polishing`, a SOLVED problem is polished in the same launch (reduced KKT system on the active set, factorised in LDS,
-// polish_refine_iter refinement steps: the reference's algorithm, _osqp.py:1710-1828).  Not taken with verbose
-// output (per-iteration printing lives in the host-driven loop), with a time limit, or when OSQP_HIP_SMALL_DIRECT=0.
+// polish_refine_iter refinement steps: the reference's algorithm, _osqp.py:1710-1828).  Not taken with a time limit or when
+// OSQP_HIP_SMALL_DIRECT=0.  `verbose` does not change the path: the whole loop is one launch, so the table holds its last line only.
 bool Engine::small_direct_applicable() {
-  if (!pol_.small_direct || !be::device_assembly() || settings.verbose || settings.time_limit < 1e9 || reordered_) return false;
+  if (!pol_.small_direct || !be::device_assembly() || settings.time_limit < 1e9 || reordered_) return false;
   if (settings.check_dualgap) return false;            // the one-launch kernel has no duality-gap test: the host-driven loop honours the setting
   if (!be::batch_lds_bytes(n, m)) return false;
   prepare_batch_direct();
@@ -491,6 +491,12 @@ int Engine::solve_small_direct(double t0) {
   be::sync(d_);
   info.solve_time = std::max(now_s() - t0 - info.polish_time, 0.0);
   info.run_time = (first_run_ ? info.setup_time : info.update_time) + info.solve_time + info.polish_time;
+  if (settings.verbose) {                          // (one launch ran the whole loop: the table holds its last line, _osqp.py:1259-1261)
+    say("iter   objective    pri res    dua res    rho       time\n");
+    print_summary_line(info.iter, info.obj_val, info.prim_res, info.dual_res, rho_bar_, t0);
+    if (info.status_polish) say("plsh  %11.4e   %8.2e   %8.2e   --------  %8.2es\n", info.obj_val, info.prim_res, info.dual_res, info.run_time);
+    print_footer();
+  }
   first_run_ = false; clear_update_time_ = true;
   return OSQP_NO_ERROR;
 }

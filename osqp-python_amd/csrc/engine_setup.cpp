@@ -221,7 +221,15 @@ void Engine::upload_f1(const F1Plan &pl) {
   DevF1 &f = d_.f1;
   f.D = pl.D; f.pnnz = pl.pnnz;
   f.blk = up_i(pl.blk); f.prp = up_i(pl.prp); f.pcol = up_i(pl.pcol); f.psrc = up_i(pl.psrc);
-  f.ent = dev_vec<unsigned int>(d_, pl.ent.size()); be::h2d(d_, f.ent, pl.ent.data(), sizeof(unsigned int) * pl.ent.size());
+  { // the blocks' matrix streams (backend.h DevF1::stream): the index words now, the values by be::f1_refresh once A.val is assembled
+    const size_t nb = pl.blk.size() / 16;
+    std::vector<unsigned char> hs(nb * (size_t)kF1StreamBytes, 0);
+    for (size_t b = 0; b < nb; b++) {
+      const int k0 = pl.blk[16 * b + 2], cnt = pl.blk[16 * b + 3] - k0;
+      std::memcpy(hs.data() + b * (size_t)kF1StreamBytes + sizeof(double) * kF1Chunk, pl.ent.data() + k0, sizeof(unsigned int) * (size_t)cnt);
+    }
+    f.stream = dev_vec<unsigned char>(d_, hs.size()); be::h2d(d_, f.stream, hs.data(), hs.size());
+  }
   f.cptr = dev_vec<unsigned short>(d_, pl.cptr.size()); be::h2d(d_, f.cptr, pl.cptr.data(), sizeof(unsigned short) * pl.cptr.size());
   f.pval = dev_vec<double>(d_, pl.pnnz);
   f.ns = ((size_t)n + 31) / 32 * 32;                       // 256-byte aligned vectors
@@ -634,17 +642,26 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   be::sync(d_);
   lap("vectors, rho, preconditioner");
   info.setup_time = now_s() - t0;
-  if (settings.verbose) {
-    std::printf("-----------------------------------------------------------------\n");
-    std::printf("  OSQP ADMM engine for AMD MI355X (%s), indirect (PCG) solver\n", be::name());
-    std::printf("-----------------------------------------------------------------\n");
-    std::printf("problem:  variables n = %d, constraints m = %d\n          nnz(P) + nnz(A) = %d\n", n, m, nzP + nzA);
-    std::printf("settings: eps_abs = %.1e, eps_rel = %.1e, rho = %.2e%s, sigma = %.2e, alpha = %.2f,\n          max_iter = %d, scaling = %d, check_termination = %d, cg_max_iter = %d\n\n",
-                settings.eps_abs, settings.eps_rel, settings.rho, settings.adaptive_rho ? " (adaptive)" : "", settings.sigma,
-                settings.alpha, settings.max_iter, settings.scaling, settings.check_termination, settings.cg_max_iter);
-  }
+  if (settings.verbose) print_setup_header();
   return OSQP_NO_ERROR;
 }
 
+// _osqp.py:564-607, with this engine's banner and linear-system line
+void Engine::print_setup_header() const {
+  say("-----------------------------------------------------------------\n");
+  say("           OSQP v%s  -  Operator Splitting QP Solver\n", "1.0.0-hip");
+  say("        ADMM engine for AMD MI355X (%s), C ABI of osqp v1\n", be::name());
+  say("-----------------------------------------------------------------\n");
+  say("problem:  variables n = %d, constraints m = %d\n", n, m);
+  say("          nnz(P) + nnz(A) = %d\n", P_.nnz() + A_.nnz());
+  say("settings: linear system solver = indirect (reduced-KKT PCG, %s),\n", settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER ? "diagonal preconditioner" : "no preconditioner");
+  say("          eps_abs = %.2e, eps_rel = %.2e,\n", settings.eps_abs, settings.eps_rel);
+  say("          eps_prim_inf = %.2e, eps_dual_inf = %.2e,\n", settings.eps_prim_inf, settings.eps_dual_inf);
+  say("          rho = %.2e %s\n", settings.rho, settings.adaptive_rho ? "(adaptive)" : "");
+  say("          sigma = %.2e, alpha = %.2f, max_iter = %d\n", settings.sigma, settings.alpha, settings.max_iter);
+  say("          check_termination: %s (interval %d), cg_max_iter = %d\n", settings.check_termination ? "on" : "off", settings.check_termination, settings.cg_max_iter);
+  say("          scaling: %s, scaled_termination: %s\n", settings.scaling ? "on" : "off", settings.scaled_termination ? "on" : "off");
+  say("          warm_start: %s, polish: %s\n\n", settings.warm_starting ? "on" : "off", settings.polishing ? "on" : "off");
+}
 
 }  // namespace osqp_hip

@@ -522,6 +522,20 @@ enum SlotRec { SR_PHASE = 0, SR_K, SR_ADMM, SR_TARGET, SR_USED, SR_CONV, SR_CAP,
 
 struct SlotState { int ph, k, admm, target, used, conv, cap, seq; };
 __device__ __forceinline__ SlotState slot_read(const int *r) { return SlotState{r[SR_PHASE], r[SR_K], r[SR_ADMM], r[SR_TARGET], r[SR_USED], r[SR_CONV], r[SR_CAP], r[SR_SEQ]}; }
+// The same record through the CONSTANT address space: two scalar loads (lgkmcnt) instead of eight vector loads (vmcnt).  The record was written by
+// the PREVIOUS launch (the scalar cache is invalidated at every kernel start) and this launch writes the OTHER record, so the value cannot change
+// under the kernel.  Used by the F1 slot kernel, whose head keeps LDS-direct transfers in flight: a wait on a vector load there would wait for
+// those transfers as well (the memory counter retires in issue order).
+__device__ __forceinline__ SlotState slot_read_scalar(const int *r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef int __attribute__((ext_vector_type(4))) v4i;
+  typedef const v4i __attribute__((address_space(4))) *cptr;
+  const v4i a = ((cptr)(unsigned long long)r)[0], b = ((cptr)(unsigned long long)r)[1];
+  return SlotState{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#else
+  return slot_read(r);
+#endif
+}
 __device__ __forceinline__ void slot_write(int *w, const SlotState &s) {
   if (blockIdx.x == 0 && threadIdx.x == 0) { w[SR_PHASE] = s.ph; w[SR_K] = s.k; w[SR_ADMM] = s.admm; w[SR_TARGET] = s.target; w[SR_USED] = s.used; w[SR_CONV] = s.conv; w[SR_CAP] = s.cap; w[SR_SEQ] = s.seq + 1; }
 }

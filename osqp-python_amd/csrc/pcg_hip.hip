@@ -564,6 +564,44 @@ struct F1Lds {
   double pprod[kF1PChunk];       // (P + sigma I) products of the own rows
   double red[3 * kWaves];
 };
+// A block's matrix stream in LDS: the image of its slice of DevF1::stream, filled by LDS-direct loads (no VGPR destination).
+struct F1Stream { double val[kF1Chunk]; unsigned int ent[kF1Chunk]; };
+static_assert(sizeof(F1Stream) == kF1StreamBytes, "LDS image and global layout of a block's stream must agree");
+static_assert(kF1StreamBytes % (kWaves * 1024) == 0, "every wave issues whole 1 KB pieces");
+// One 1 KB piece per wave instruction: lane l moves the 16 bytes at gsrc (its own address) to  LDS[lds_base + 16 l]  (lds_base wave-uniform, in
+// M0).  Inline asm: hipcc's builtin would make every later barrier drain the transfer (it counts it against vmcnt and waits before
+// __syncthreads); as asm the transfer is invisible to the compiler's wait insertion -- its own waits can only become stricter, never too weak
+// (it assumes fewer operations in flight than there are) -- and the consumer waits with f1_stream_wait.  M0 is saved and restored.
+__device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+#else
+  (void)gsrc; (void)lds_base;
+#endif
+}
+__device__ __forceinline__ unsigned lds_offset_of(const void *p) {       // byte offset of a __shared__ object inside the workgroup's LDS allocation
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void *)p;
+#else
+  (void)p; return 0u;
+#endif
+}
+// request block b's stream: kF1StreamBytes / (kWaves * 1024) pieces per wave, no register holds anything afterwards
+__device__ __forceinline__ void f1_stream_issue(const unsigned char *stream, int b, F1Stream &S) {
+  constexpr int kPieces = kF1StreamBytes / (kWaves * 1024);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned char *g = stream + (size_t)b * kF1StreamBytes + (size_t)wave * (kPieces * 1024) + (threadIdx.x & 63) * 16;
+  const unsigned l0 = lds_offset_of(&S) + (unsigned)wave * (kPieces * 1024);
+#pragma unroll
+  for (int q = 0; q < kPieces; q++) lds_dma16(g + q * 1024, __builtin_amdgcn_readfirstlane(l0 + q * 1024));
+}
+// everything this wave has requested has landed (its own pieces of the stream included); the workgroup barrier that follows publishes them
+__device__ __forceinline__ void f1_stream_wait() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
 struct F1Scal { double alpha, beta; int general; };       // general = 0: the first update (s_0 = w_0, p_0 = u_0: s_{-1}, p_{-1} are not used)
 template <int D>
 __device__ __forceinline__ double f1_w(const double (&rp)[D]) {     // w_{k-1} = K u_{k-1}: the replicas in index order (deterministic)
@@ -594,13 +632,13 @@ __device__ __forceinline__ double f1_segsum(const double *seg, int a, int z) {
 // so the three loads depend on nothing but the kernel's `par` argument and leave at the very head of the launch (f1_fold_issue), next to
 // the phase record instead of behind it.  f1_fold_finish returns false when the PCG had already converged (the caller runs KA in this launch).
 struct F1Fold { PartRegs a, b, c; };
-__device__ __forceinline__ F1Fold f1_fold_issue(const Dev &d, const int par, const int probe) {
+__device__ __forceinline__ F1Fold f1_fold_issue(const double *part, const int par, const int probe) {
   F1Fold f;
 #pragma unroll
   for (int q = 0; q < kPart; q++) { f.a.v[q] = 0.0; f.b.v[q] = 0.0; f.c.v[q] = 0.0; }
   if (probe == 1) return f;                                 // (probe == 2 pays for the fold like a solve's launch, then uses the fixed scalars)
   const int prev = par ^ 1;
-  f.a = partial_load(d.part + (SL_GAMMA0 + prev) * kGrid); f.b = partial_load(d.part + (SL_DELTA + prev) * kGrid); f.c = partial_load(d.part + (SL_RN0 + prev) * kGrid);
+  f.a = partial_load(part + (SL_GAMMA0 + prev) * kGrid); f.b = partial_load(part + (SL_DELTA + prev) * kGrid); f.c = partial_load(part + (SL_RN0 + prev) * kGrid);
   return f;
 }
 __device__ __forceinline__ bool f1_fold_finish(const Dev &d, const int k, const int admm_par, const int probe, const F1Fold &f, double *red, F1Scal &sc) {
@@ -646,7 +684,7 @@ __device__ __forceinline__ F1Rec f1_record(const DevF1 &f, int b) {
   return F1Rec{sload_int4(f.blk, 4 * (size_t)b), sload_int4(f.blk, 4 * (size_t)b + 1), sload_int4(f.blk, 4 * (size_t)b + 2), sload_int4(f.blk, 4 * (size_t)b + 3)};
 }
 template <int D, bool FIRST>
-__device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool vec_only, const F1Scal sc, F1Lds &L, const F1Rec &rec0, const int par) {
+__device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool vec_only, const F1Scal sc, F1Lds &L, F1Stream &S, const F1Rec &rec0, const int par) {
   const DevF1 &f = d.f1;
   const int n = d.n, tid = threadIdx.x;
   const int cur = (k + 1) & 1, nxt = k & 1;               // parity of k - 1 / of k
@@ -714,14 +752,11 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
         }
       }
     }
-    // ---- matrix entries, row / column pointers
-    double vw[CE]; unsigned int en[CE];
+    // ---- row / column pointers (the matrix entries themselves arrive in LDS: S, requested one block ahead)
     int rp0 = 0, rp1 = 0; double rrho = 0.0;
     int cp0[CW], cp1[CW];
     int pp0 = 0, pp1 = 0;
     if (!vec_only) {
-#pragma unroll
-      for (int u = 0; u < CE; u++) { if (u < nu) { const int e = k0 + min(tid + u * kBlock, cnt - 1); vw[u] = d.A.val[e]; en[u] = f.ent[e]; } }
       { const int row = r0 + min(tid, nrows - 1); rp0 = d.A.rowptr[row]; rp1 = d.A.rowptr[row + 1]; rrho = d.rho[row]; }
 #pragma unroll
       for (int u = 0; u < CW; u++) { if (u < ns2) { const int c = cpo + min(tid + u * kBlock, wl - 1); cp0[u] = f.cptr[c]; cp1[u] = f.cptr[c + 1]; } }
@@ -774,8 +809,20 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     }
     if (vec_only) continue;
     KT(4);
+    // ---- the block's stream has landed (this wave's pieces: the wait; everybody's: the barrier).  Every load this lane has requested so far is
+    //      complete as well -- pinned into registers HERE, so that the compiler places no wait of its own behind the request of the next block's
+    //      stream below (it cannot see that transfer: a later `s_waitcnt vmcnt(small)` for one of these values would wait for the stream too)
+    f1_stream_wait();
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" :: "v"(rp0), "v"(rp1), "v"(rrho), "v"(pp0), "v"(pp1), "v"(pv), "v"(pc), "v"(em), "v"(er), "v"(es), "v"(eq[0]), "v"(eq[D - 1]));
+#pragma unroll
+    for (int u = 0; u < CW; u++) { if (u < ns2) asm volatile("" :: "v"(cp0[u]), "v"(cp1[u])); }
+#endif
     __syncthreads();
     // ---- products: A entries against the window; the (P + sigma I) entry against the window or its recomputed operand
+    double vw[CE]; unsigned int en[CE];
+#pragma unroll
+    for (int u = 0; u < CE; u++) { if (u < nu) { const int e = min(tid + u * kBlock, cnt - 1); vw[u] = S.val[e]; en[u] = S.ent[e]; } }
 #pragma unroll
     for (int u = 0; u < CE; u++) { if (u < nu) L.prod[tid + u * kBlock] = vw[u] * L.win[en[u] & 0x1ffu]; }
     if (hasp) {
@@ -787,10 +834,22 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     }
     KT(5);
     __syncthreads();
+    // ---- every wave holds its entries in registers: the stream buffer is free -- the NEXT block's stream goes out now and lands during this
+    //      block's remaining LDS phases, its stores, and the next block's record / window loads
+    if (sl + slots < per) {
+      const int bn = __builtin_amdgcn_readfirstlane(xcd * per + sl + slots);
+      if (bn < d.A.nblk) f1_stream_issue(f.stream, bn, S);
+    }
     // ---- row sums: t = rho .* (A u) -> LDS
-    for (int row = tid; row < nrows; row += kBlock) {
-      if (row != tid) { rp0 = d.A.rowptr[r0 + row]; rp1 = d.A.rowptr[r0 + row + 1]; rrho = d.rho[r0 + row]; }
+    // (first pass peeled: its operands are in registers -- a shared loop body would carry the later passes' load waits, and any `s_waitcnt vmcnt`
+    //  executed here waits for the stream requested above as well)
+    if (tid < nrows) {
       const double au = f1_segsum<6>(L.prod, rp0 - k0, rp1 - k0), t = rrho * au;
+      L.tvec[tid] = t; dl_acc += t * au;
+    }
+    for (int row = tid + kBlock; row < nrows; row += kBlock) {
+      const int q0 = d.A.rowptr[r0 + row], q1 = d.A.rowptr[r0 + row + 1];
+      const double au = f1_segsum<6>(L.prod, q0 - k0, q1 - k0), t = d.rho[r0 + row] * au;
       L.tvec[row] = t; dl_acc += t * au;
     }
     KT(6);
@@ -798,9 +857,13 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     // ---- A_g' t: val * t[row] scattered to column-major order;  pu = (P + sigma I) u on the own columns -> global
 #pragma unroll
     for (int u = 0; u < CE; u++) { if (u < nu) L.prod[en[u] >> 18] = vw[u] * L.tvec[(en[u] >> 9) & 0x1ffu]; }     // (clamped lanes repeat the last entry's store)
-    for (int jj = tid; jj < nown; jj += kBlock) {
-      if (jj != tid) { pp0 = f.prp[cs0 + jj]; pp1 = f.prp[cs0 + jj + 1]; }
+    if (tid < nown) {
       const double pu = f1_segsum<4>(L.pprod, pp0 - pk0, pp1 - pk0);
+      L.puown[tid] = pu; dl_acc += L.uown[tid] * pu;
+    }
+    for (int jj = tid + kBlock; jj < nown; jj += kBlock) {
+      const int q0 = f.prp[cs0 + jj], q1 = f.prp[cs0 + jj + 1];
+      const double pu = f1_segsum<4>(L.pprod, q0 - pk0, q1 - pk0);
       L.puown[jj] = pu; dl_acc += L.uown[jj] * pu;
     }
     KT(7);
@@ -824,6 +887,8 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     KT(8);
     if (sl + slots < per) __syncthreads();                  // (another block follows: the LDS arrays are reused)
   }
+  if (vec_only) f1_stream_wait();                           // (a launch that applies no operator never consumed the stream its head requested: nothing may be in flight when the
+                                                            //  workgroup's LDS is released.  Not otherwise: the wait would also sit out every store of the body)
   __syncthreads();
   block_sum_max_sum(g_acc, rn_acc, dl_acc, L.red);
   if (!FIRST) { put_partial(d.part, SL_GAMMA0 + par, g_acc); put_partial(d.part, SL_RN0 + par, rn_acc); }
@@ -836,48 +901,66 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
 }
 // returns false when the PCG had already converged (nothing done: the caller runs KA in this launch)
 // the record of the workgroup's first row block
-__device__ __forceinline__ F1Rec f1_first_record(const Dev &d) {
-  const int b0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * ((d.A.nblk + 7) >> 3) + (int)(blockIdx.x >> 3));
-  return f1_record(d.f1, min(b0, d.A.nblk - 1));
+__device__ __forceinline__ F1Rec f1_first_record(const int *blk, int nblk) {
+  const int b0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * ((nblk + 7) >> 3) + (int)(blockIdx.x >> 3));
+  const size_t b = (size_t)min(b0, nblk - 1);
+  return F1Rec{sload_int4(blk, 4 * b), sload_int4(blk, 4 * b + 1), sload_int4(blk, 4 * b + 2), sload_int4(blk, 4 * b + 3)};
 }
 // D (the number of replica vectors, DevF1::D) is a TEMPLATE parameter of the kernels: a slot kernel that carries the bodies of all four
 // values pays for the three it never runs in every launch (the head of a launch is as long as the kernel's register / code footprint
 // makes it)
 template <int D>
-__device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const int cap, const int admm_par, const int probe, F1Lds &L, const F1Rec &rec0, const F1Fold &fold, const int par) {
+__device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const int cap, const int admm_par, const int probe, F1Lds &L, F1Stream &S, const F1Rec &rec0, const F1Fold &fold, const int par) {
   KT(0);
   F1Scal sc;
   if (!f1_fold_finish(d, k, admm_par, probe, fold, L.red, sc)) return false;
   const bool vec_only = !probe && k >= cap;                 // the last budgeted update: no operator apply follows
-  if (k == 0) f1_body<D, true>(d, k, vec_only, sc, L, rec0, par);
-  else f1_body<D, false>(d, k, vec_only, sc, L, rec0, par);
+  if (k == 0) f1_body<D, true>(d, k, vec_only, sc, L, S, rec0, par);
+  else f1_body<D, false>(d, k, vec_only, sc, L, S, rec0, par);
   return true;
+}
+// the stream of the workgroup's FIRST row block: its address depends on nothing but the block index, so it leaves at the head of the launch,
+// before the phase record, the block record or the partials have arrived
+__device__ __forceinline__ void f1_stream_first(const unsigned char *stream, int nblk, F1Stream &S) {
+  const int per = (nblk + 7) >> 3, slot0 = (int)(blockIdx.x >> 3);
+  const int b0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * per + slot0);
+  if (slot0 < per && b0 < nblk) f1_stream_issue(stream, b0, S);
 }
 __global__ __launch_bounds__(kBlock) void k_f1_refresh(Dev d) {
   for (int k = blockIdx.x * kBlock + threadIdx.x; k < d.f1.pnnz; k += gridDim.x * kBlock) d.f1.pval[k] = d.B.val[d.f1.psrc[k]];
+  // the value half of every block's stream <- A.val (entry e of block b sits at A.val[first entry of b + e])
+  for (int b = blockIdx.x; b < d.A.nblk; b += gridDim.x) {
+    const int k0 = d.f1.blk[16 * (size_t)b + 2], cnt = d.f1.blk[16 * (size_t)b + 3] - k0;
+    double *dst = reinterpret_cast<double *>(d.f1.stream + (size_t)b * kF1StreamBytes);
+    for (int e = threadIdx.x; e < cnt; e += kBlock) dst[e] = d.A.val[k0 + e];
+  }
 }
 // timing probe: one F launch as a solve runs it -- the scalar fold of the previous launch's partials included -- with fixed alpha, beta
 // and no stopping test (mode 2; mode 1 skips the fold: what the launch costs without it)
 template <int D>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_f1_probe(Dev d, int k, int mode) {
   __shared__ F1Lds lds;
+  __shared__ F1Stream sbuf;
   const int par = k & 1;
-  const F1Fold fold = f1_fold_issue(d, par, mode);
-  f1_iteration<D>(d, k, 1 << 30, 0, mode, lds, f1_first_record(d), fold, par);      // (the first block's record goes out ahead of the partials of the scalar fold: both latencies overlap)
+  f1_stream_first(d.f1.stream, d.A.nblk, sbuf);
+  const F1Fold fold = f1_fold_issue(d.part, par, mode);
+  f1_iteration<D>(d, k, 1 << 30, 0, mode, lds, sbuf, f1_first_record(d.f1.blk, d.A.nblk), fold, par);      // (the first block's record goes out ahead of the partials of the scalar fold: both latencies overlap)
 }
 
 // The slot kernel of the F1 form: every launch of a chunk's string is this kernel (par: which of the two phase records it reads);
 // the phase that is due -- KB (streams B), a PCG iteration F_k (streams A and P), KA (streams A) -- comes from the record.
 template <int D>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_slot1(Dev d, int par) {
-  __shared__ union { StreamLds<2> kb; StreamLdsW<1, double> ka; F1Lds f; } lds;
+  struct FS { F1Lds f; F1Stream s; };
+  __shared__ union { StreamLds<2> kb; StreamLdsW<1, double> ka; FS fs; } lds;
+  static_assert(sizeof(lds) <= 160 * 1024 / 4, "four workgroups per CU");
   const int *R = d.slot + (par ? SR_WORDS : 0);
   int *W = d.slot + (par ? 0 : SR_WORDS);
   // The head of every launch is a chain of dependent scalar loads (kernel arguments -> phase record -> block record -> first vector loads):
   // the arguments the F phase needs are pinned into registers HERE, behind one wait, and the block record is requested together with the
   // phase record (most launches are F launches; KB / KA request their own descriptors after the branch)
-  const F1Fold fold = f1_fold_issue(d, par, 0);         // the previous launch's partials: their address depends on `par` alone
-  const F1Rec rec0 = f1_first_record(d);
+  const F1Fold fold = f1_fold_issue(d.part, par, 0);    // the previous launch's partials: their address depends on `par` alone
+  const F1Rec rec0 = f1_first_record(d.f1.blk, d.A.nblk);
   SlotState st = slot_read(R);
 #if defined(__HIP_DEVICE_COMPILE__)
   // both records, the partials and the phases' base pointers are in registers HERE: requested together, one wait
@@ -898,10 +981,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
     st.ph = P_F; st.k = 0;
   } else if (st.ph == P_F) {
-    if (f1_iteration<D>(d, st.k, st.cap, st.admm & 1, 0, lds.f, rec0, fold, par)) {
+    // the first block's matrix stream: requested as soon as the phase is known (its address depends on the block index alone), lands in LDS
+    // while the scalar fold and the window loads run; nothing of it occupies a register
+    f1_stream_first(d.f1.stream, d.A.nblk, lds.fs.s);
+    if (f1_iteration<D>(d, st.k, st.cap, st.admm & 1, 0, lds.fs.f, lds.fs.s, rec0, fold, par)) {
       if (st.k >= st.cap) { st.ph = P_KA; st.used = st.k; st.conv = 0; }      // stopped at the cap: the next launch runs KA
       else st.k += 1;
     } else {                                             // converged: KA right here
+      f1_stream_wait();                                  // (the stream requested above was never consumed, and KA's LDS overlays its buffer)
       __syncthreads();
       slot_ka(d, lds.ka, st.k == 0 ? 0 : st.k - 1, 1, first_desc<true>(d.A), st.admm, st.target);
       st.ph = P_KB; st.admm += 1;

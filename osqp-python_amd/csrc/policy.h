@@ -58,7 +58,12 @@ struct Ctl {
   // ---- results of the last check
   double obj_val, prim_res, dual_res, dual_obj_val, duality_gap, rel_kkt_error, rho_estimate;
   double res[R_COUNT];            // the residual block the last check saw
+  // ---- verbose output: the checks whose iteration count is a multiple of kCtlPrintInterval (_osqp.py:32, :1230-1231), as a ring the host prints
+  // from -- the lines of a device-driven solve are then the same lines, whenever the host gets to read them
+  int nlog, log_pad;
+  double log[16][5];              // {iter, obj_val, prim_res, dual_res, rho_bar at the check}
 };
+constexpr int kCtlLog = 16, kCtlPrintInterval = 200;
 
 OSQP_HD inline int pol_imin(int a, int b) { return a < b ? a : b; }
 OSQP_HD inline int pol_imax(int a, int b) { return a > b ? a : b; }
@@ -249,6 +254,11 @@ OSQP_HD inline int ctl_boundary(Ctl &c, const double *res, const int *flags) {
   c.boundaries++;
   if (!c.ch_at_check) { ctl_budget_rule(c, flags); ctl_next_chunk(c); return CTL_RUNNING; }
   ctl_info(c, res);
+  if (c.iter % kCtlPrintInterval == 0) {
+    double *e = c.log[c.nlog % kCtlLog];
+    e[0] = c.iter; e[1] = c.obj_val; e[2] = c.prim_res; e[3] = c.dual_res; e[4] = c.rho_bar;
+    c.nlog++;
+  }
   const bool do_check = (c.ct > 0 && c.iter % c.ct == 0) || c.iter == c.max_iter;
   if (do_check) {
     const int st = ctl_stage1(c, res, false, nullptr, nullptr);

@@ -110,6 +110,8 @@ PROTOTYPES = {
     'osqp_adjoint_derivative_get_vec': (C.c_int, [SolverP, c_double_p, c_double_p, c_double_p]),
     'osqp_codegen': (C.c_int, [SolverP, C.c_char_p, C.c_char_p, C.c_void_p]),
     'osqp_set_default_codegen_defines': (None, [C.c_void_p]),
+    'osqp_hip_set_default_print': (None, [C.c_void_p, C.c_void_p]),
+    'osqp_hip_set_print': (C.c_int, [SolverP, C.c_void_p, C.c_void_p]),
     'osqp_hip_get_stats': (C.c_int, [SolverP, C.POINTER(StatsStruct)]),
     'osqp_hip_time_kernel': (C.c_int, [SolverP, C.c_int, C.c_int, c_double_p]),
     'osqp_hip_trace_read': (C.c_int, [SolverP, C.POINTER(C.c_ulonglong), C.c_int]),
@@ -131,11 +133,29 @@ PROTOTYPES = {
 }
 
 
+PRINT_FN = C.CFUNCTYPE(None, C.c_char_p, C.c_void_p)      # osqp_hip_print_fn
+
+
+def _py_print(text, _user):
+    """Where `verbose` output of every solver handle goes: sys.stdout, like the reference's c_print = PySys_WriteStdout under the GIL
+    (/root/reference/cmake/printing.h:2-7).  Called from inside osqp_setup / osqp_solve, which ctypes runs with the GIL released -- a ctypes
+    callback takes it for the duration of the call."""
+    import sys
+    try:
+        sys.stdout.write(text.decode('utf-8', 'replace'))
+    except Exception:                      # noqa: BLE001 -- a closed / replaced stdout must not take the solve down
+        pass
+
+
+_print_cb = PRINT_FN(_py_print)            # (module-level: must outlive every handle of the library)
+
+
 def _bind(lib):
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    lib.osqp_hip_set_default_print(C.cast(_print_cb, C.c_void_p), None)
     return lib
 
 
