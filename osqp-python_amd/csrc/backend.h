@@ -97,7 +97,8 @@ struct DevF1 {
   double *pval = nullptr;        // values, refreshed from B.val by be::f1_refresh (after assembly / equilibration / matrix updates)
   int pnnz = 0;
   // the n-vectors of the iteration in ONE arena, stride ns doubles: Minv, x~, p, r (parity 0 = Dev::r, 1), s (0 = Dev::s, 1),
-  // rep (parity 0: D vectors, parity 1: D vectors; their sum is K u_k: a block adds (P + sigma I) u_k of its own columns to its slice).
+  // rep (parity 0: D vectors, parity 1: D vectors; their sum is K u_k: a block adds (P + sigma I) u_k of its own columns to its slice), and a third
+  // set of D vectors: KA leaves the slices of rhs = sigma x - q + A' v in the parity-1 set and those of K x_g in the third (pcg_hip.hip f1_ka_body).
   // Dev::Minv / xs / p / r / s point into it.  r_k, s_{k-1} and rep_k (what launch F_k writes) live in parity k & 1.
   double *va = nullptr; size_t ns = 0;
 };
@@ -316,9 +317,10 @@ int slot_done(Dev &d);
 int slot_seq(Dev &d);                      // slots executed since slot_begin (consistency check of the record hand-over)
 // launches one ADMM iteration with `pcg` PCG iterations needs in the slot form (a slot_pair() is two of them):
 //   two-kernel form  2 (pcg + 2)   KB, K1, pcg x (K2F, K1F), the K2F that detects convergence, KA
-//   F1 form          pcg + 3       KB, F_0, F_1 .. F_pcg, KA (run by the launch whose scalar fold detects convergence)
+//   F1 form          pcg + 2       F_0, F_1 .. F_pcg, KA (run by the launch whose scalar fold detects convergence; it also leaves the slices F_0 builds
+//                                 r_0 from -- no KB launch) + one launch at the start of every chunk
 //   Woodbury direct mode in two launches (wbdirect_hip.hip): 2 per iteration + one closing pair per chunk
-inline double slot_launches(const Dev &d, double pcg) { return (d.wb.on && d.wb.exact && d.wb.x.on && d.wb.x.slots) ? 2.16 : (d.f1.on ? pcg + 3.0 : 2.0 * (pcg + 2.0)); }
+inline double slot_launches(const Dev &d, double pcg) { return (d.wb.on && d.wb.exact && d.wb.x.on && d.wb.x.slots) ? 2.16 : (d.f1.on ? pcg + 2.0 : 2.0 * (pcg + 2.0)); }
 void f1_refresh(Dev &d);                   // f1.pval <- B.val (no-op without a plan)
 bool wb_supported();
 bool wbx_supported();                      // the two-launch direct mode exists (false: the host simulator)

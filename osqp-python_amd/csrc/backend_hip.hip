@@ -437,6 +437,7 @@ void destroy(Dev &d) {
   (void)hipHostFree(p.pin_poll); if (p.side) (void)hipStreamDestroy(p.side);
   (void)hipHostFree(p.pin_ctl); (void)hipHostFree(p.pin_ctl2);
   if (p.blas) wb_release_blas(p.blas);                 // (woodbury_hip.hip: the rocBLAS handle of the device-factorised form)
+  dev_release(d);
   delete &p; d.impl = nullptr;
   if (d.stream) { (void)hipStreamDestroy(st(d)); d.stream = nullptr; }
 }
@@ -486,7 +487,7 @@ void ctl_upload(Dev &d, const Ctl &c) {
   HIP_CHECK(hipMemcpyAsync(d.ctl, p.pin_ctl, sizeof(Ctl), hipMemcpyHostToDevice, st(d)));
   HIP_CHECK(hipStreamSynchronize(st(d)));          // (the staging buffer is reused)
 }
-void ctl_begin(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); hipLaunchKernelGGL(k_ctl_begin, dim3(1), dim3(1), 0, st(d), d, ++im(d).epoch); }
+void ctl_begin(Dev &d) { HIP_CHECK(hipSetDevice(d.device)); dev_publish(d); hipLaunchKernelGGL(k_ctl_begin, dim3(1), dim3(1), 0, st(d), d, ++im(d).epoch); }
 void ctl_group(Dev &d, int diagonal) {
   LAUNCH(k_res_m, d, d, 1);
   LAUNCH(k_res_n, d, d, 1);

@@ -233,7 +233,7 @@ void Engine::upload_f1(const F1Plan &pl) {
   f.cptr = dev_vec<unsigned short>(d_, pl.cptr.size()); be::h2d(d_, f.cptr, pl.cptr.data(), sizeof(unsigned short) * pl.cptr.size());
   f.pval = dev_vec<double>(d_, pl.pnnz);
   f.ns = ((size_t)n + 31) / 32 * 32;                       // 256-byte aligned vectors
-  f.va = dev_vec<double>(d_, (7 + 2 * (size_t)pl.D) * f.ns);
+  f.va = dev_vec<double>(d_, (7 + 3 * (size_t)pl.D) * f.ns);
   f.on = 1;
 }
 

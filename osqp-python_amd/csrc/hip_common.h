@@ -68,11 +68,23 @@ struct Impl {
   Ctl *pin_ctl = nullptr, *pin_ctl2 = nullptr;   // staging of the state block (upload / poll + download)
   int epoch = 0;                 // chunks begun (slot_begin); the device copy sits behind the two records
   void *blas = nullptr;          // rocblas_handle of the large-rank Woodbury factorisation (created on first use)
+  // device-resident copy of Dev for the F1 slot kernel (pcg_hip.hip dev_publish): {head block, Dev}, and what was last uploaded
+  void *dev_block = nullptr; unsigned char *pin_block = nullptr; unsigned char *shadow_block = nullptr;
 };
 inline Impl &im(Dev &d) { return *static_cast<Impl *>(d.impl); }
 inline hipStream_t st(Dev &d) { return static_cast<hipStream_t>(d.stream); }
 
 // ---------------------------------------------------------------------------------------------- device helpers
+// A pointer that was LOADED from memory (the F1 slot kernel reads Dev from a device-resident copy) has no known address space: the compiler would
+// use flat_* instructions for every access through it (both memory counters, slower issue).  Every one of them points to device global memory:
+// gptr() says so in the TYPE -- a pointer into the global address space; indexing and arithmetic work as usual, the accesses are global_* ones.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OSQP_GLOBAL_AS __attribute__((address_space(1)))
+#else
+#define OSQP_GLOBAL_AS
+#endif
+template <class T> using gp = OSQP_GLOBAL_AS T *;
+template <class T> __device__ __forceinline__ gp<T> gptr(T *p) { return (gp<T>)p; }
 __device__ __forceinline__ double nanmax(double r, double a) { return (a > r || a != a) ? a : r; }
 // Wave64 reductions with DPP moves (VALU rate).  HIP's __shfl_* compile to ds_bpermute_b32 -- an LDS round trip of ~100+ cycles
 // per 32-bit half and step: the three block reductions of a PCG kernel cost ~1 us each that way (tools/ktrace.py: 1.07 us in the
@@ -149,10 +161,12 @@ constexpr int kPart = kGrid >= kBlock ? kGrid / kBlock : 1;
 static_assert(kGrid >= kBlock ? kGrid % kBlock == 0 : kBlock % kGrid == 0, "kGrid and kBlock must divide one another");
 static_assert(kWaves % 2 == 0, "block reductions pair the waves");
 struct PartRegs { double v[kPart]; };
-__device__ __forceinline__ PartRegs partial_load(const double *slot) {
+template <class P>
+__device__ __forceinline__ PartRegs partial_load(P slot) {      // P: const double * or its global-address-space form (gptr)
   PartRegs r;
   if (kPart % 2 == 0) {
-    const double2 *s2 = reinterpret_cast<const double2 *>(slot) + (kPart / 2) * threadIdx.x;
+    typedef typename std::conditional<std::is_same<P, gp<const double>>::value || std::is_same<P, gp<double>>::value, gp<const double2>, const double2 *>::type P2;
+    P2 s2 = (P2)slot + (kPart / 2) * threadIdx.x;
 #pragma unroll
     for (int k = 0; k < kPart / 2; k++) { const double2 a = s2[k]; r.v[2 * k] = a.x; r.v[2 * k + 1] = a.y; }
   } else {
@@ -164,7 +178,8 @@ __device__ __forceinline__ double partial_fold_sum(const PartRegs &r) { double v
 __device__ __forceinline__ double partial_fold_max(const PartRegs &r) { double v = 0; for (int k = 0; k < kPart; k++) v = nanmax(v, r.v[k]); return v; }
 __device__ __forceinline__ double partial_sum(const double *slot, double *sred) { return block_sum(partial_fold_sum(partial_load(slot)), sred); }
 __device__ __forceinline__ double partial_max(const double *slot, double *sred) { return block_max(partial_fold_max(partial_load(slot)), sred); }
-__device__ __forceinline__ void put_partial(double *part, int slot, double v) {
+template <class P>
+__device__ __forceinline__ void put_partial(P part, int slot, double v) {
   if (threadIdx.x == 0) part[slot * kGrid + blockIdx.x] = v;
 }
 
@@ -547,6 +562,8 @@ __device__ __forceinline__ void slot_write(int *w, const SlotState &s) {
 // ---- functions one unit defines and another calls
 void wb_factor(Dev &d);                    // woodbury_hip.hip: D0, S, S^-1 for the current rho (called by precond)
 void wb_factor_device(Dev &d, int cond);   // woodbury_hip.hip: the small form's re-factorisation as launches only (cond: inside a boundary group)
+void dev_publish(Dev &d);                  // pcg_hip.hip: bring the device copy of Dev the F1 slot kernel reads up to date (never inside a stream capture)
+void dev_release(Dev &d);                  // pcg_hip.hip: free it (called by destroy)
 void wb_release_blas(void *handle);        // woodbury_hip.hip: destroy the rocBLAS handle a Dev's Impl holds (called by destroy)
 
 }  // namespace be

@@ -380,13 +380,13 @@ struct EKa {
 // Every workgroup takes the same branch (conv / done come from an earlier launch); rn, bn of the last iterate are folded for
 // workgroup 0's statistics.
 __device__ __forceinline__ double cutoff_theta(const Dev &d, int slot, double *red, double &rn, double &bn, int admm = -1) {
-  rn = partial_fold_max(partial_load(d.part + (SL_RN0 + slot) * kGrid)); bn = partial_fold_max(partial_load(d.part + SL_BN * kGrid));
+  rn = partial_fold_max(partial_load(gptr(d.part) + (SL_RN0 + slot) * kGrid)); bn = partial_fold_max(partial_load(gptr(d.part) + SL_BN * kGrid));
   block_max2(rn, bn, red);
   if (admm < 1) return 0.0;
   // slot form: the start residuals of this and of the previous ADMM iteration are on record (written by earlier launches).  While they
   // FALL the cut-off solves are keeping up and the extrapolation stays (config 2: budget-limited chunks are part of normal operation,
   // 53 vs 65 ms); once the start residual grows, the next solve starts from x~ itself.
-  const double now = d.scal[S_RN0H + (admm & 1)], prev = d.scal[S_RN0H + ((admm + 1) & 1)];
+  const double now = gptr(d.scal)[S_RN0H + (admm & 1)], prev = gptr(d.scal)[S_RN0H + ((admm + 1) & 1)];
   return (now < prev) ? d.theta : 0.0;
 }
 __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
@@ -642,27 +642,28 @@ __device__ __forceinline__ F1Fold f1_fold_issue(const double *part, const int pa
   return f;
 }
 __device__ __forceinline__ bool f1_fold_finish(const Dev &d, const int k, const int admm_par, const int probe, const F1Fold &f, double *red, F1Scal &sc) {
-  double *gam = d.scal + S_HIST, *alp = d.scal + S_HIST + kMaxCg + 1;
+  double *gam = gptr(d.scal) + S_HIST, *alp = gptr(d.scal) + S_HIST + kMaxCg + 1;
   const int tid = threadIdx.x;
   sc = F1Scal{0.0, 0.0, k >= 2};
   if (probe == 1) { sc.alpha = 1e-3; sc.beta = k >= 2 ? 0.5 : 0.0; return true; }
-  if (k == 0) {
-    double rn = partial_fold_max(f.c), bn = partial_fold_max(f.b);
-    block_max2(rn, bn, red);
-    const double tol = fmax(d.scal[S_TOL_REL] * bn, d.scal[S_TOL_ABS]);
-    if (probe) { if (rn < -1.0) d.res[R_COUNT - 1] = bn + tol; return true; }
-    if (blockIdx.x == 0 && tid == 0) { d.scal[S_TOL_NOW] = tol; d.scal[S_RN0] = rn; d.scal[S_RN0H + admm_par] = rn; }
-    return rn > tol;                                        // false: the start already meets the tolerance (a NaN also ends the inner loop)
-  }
-  const double tol = d.scal[S_TOL_NOW], glast = k >= 2 ? gam[k - 2] : 1.0, alast = k >= 2 ? alp[k - 2] : 1.0;
+  if (k == 0) return true;                                  // F_0 builds r_0 itself (from the slices KA / the chunk's first launch left): nothing to fold yet
+  double tol = gptr(d.scal)[S_TOL_NOW];
+  const double glast = k >= 2 ? gam[k - 2] : 1.0, alast = k >= 2 ? alp[k - 2] : 1.0;
   double gamma = partial_fold_sum(f.a), rn = partial_fold_max(f.c), delta = partial_fold_sum(f.b);
   block_sum_max_sum(gamma, rn, delta, red);
+  if (k == 1 && probe == 0) {
+    // the tolerance of this ADMM iteration's PCG, from ||rhs|| (F_0's partials) -- and the test of the START: r_0 may already meet it
+    const double bn = block_max(partial_fold_max(partial_load(gptr(d.part) + SL_BN * kGrid)), red);
+    tol = fmax(gptr(d.scal)[S_TOL_REL] * bn, gptr(d.scal)[S_TOL_ABS]);
+    if (blockIdx.x == 0 && tid == 0) { gptr(d.scal)[S_TOL_NOW] = tol; gptr(d.scal)[S_RN0] = rn; gptr(d.scal)[S_RN0H + admm_par] = rn; }
+    if (!(rn > tol)) return false;                          // no PCG iteration (a NaN also ends the inner loop): the caller runs KA in this launch, x~ = the start
+  }
   if (probe) {                                              // timing probe: the fold above was paid for; bounded, repeatable scalars instead of its result
-    if (rn < -1.0) d.res[R_COUNT - 1] = gamma + delta + tol + glast + alast;      // (never true: keeps the fold alive)
+    if (rn < -1.0) gptr(d.res)[R_COUNT - 1] = gamma + delta + tol + glast + alast;      // (never true: keeps the fold alive)
     sc.alpha = 1e-3; sc.beta = k >= 2 ? 0.5 : 0.0;
     return true;
   }
-  if (k >= 2 && !(rn > tol)) return false;                  // converged after k - 1 iterations (r_0 was tested by F_0)
+  if (k >= 2 && !(rn > tol)) return false;                  // converged after k - 1 iterations
   sc.beta = k >= 2 ? gamma / glast : 0.0;
   sc.alpha = k >= 2 ? gamma / (delta - sc.beta * gamma / alast) : gamma / delta;
   if (blockIdx.x == 0 && tid == 0) { gam[k - 1] = gamma; alp[k - 1] = sc.alpha; }
@@ -691,16 +692,17 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
   KT(1);
   // every n-vector of the iteration lives in ONE arena (DevF1::va, stride ns): the addresses derive from one base pointer by scalar
   // adds instead of a kernel-argument load per vector
-  const double *va = f.va; const size_t ns = f.ns;
+  const double *va = gptr(f.va); const size_t ns = f.ns;
   const double *Minv = va, *xs_r = va + ns, *p_r = va + 2 * ns;
-  double *xs_w = f.va + ns, *p_w = f.va + 2 * ns;
-  const double *rread = va + (3 + ((FIRST || cur == 0) ? 0 : 1)) * ns;      // r_{k-1} (F_0: r_0)
-  double *rnxt = f.va + (3 + nxt) * ns;                     // r_k
+  double *xs_w = gptr(f.va) + ns, *p_w = gptr(f.va) + 2 * ns;
+  const double *rread = va + (3 + (cur == 0 ? 0 : 1)) * ns;                 // r_{k-1}
+  double *rnxt = gptr(f.va) + (3 + nxt) * ns;                     // r_k
   const double *sprev = va + (5 + cur) * ns;                // s_{k-2}: stored next to r_{k-1}
-  double *snew = f.va + (5 + nxt) * ns;                     // s_{k-1}: stored next to r_k
-  const double *repcur = va + (7 + (size_t)cur * D) * ns;   // K u_{k-1} in D partial vectors
-  double *repnxt = f.va + (7 + (size_t)nxt * D) * ns;
-  double g_acc = 0.0, rn_acc = 0.0, dl_acc = 0.0;
+  double *snew = gptr(f.va) + (5 + nxt) * ns;                     // s_{k-1}: stored next to r_k
+  const double *repcur = va + (7 + (size_t)cur * D) * ns;   // K u_{k-1} in D partial vectors  (F_0: the slices of r_0 = rhs - K x_g that f1_ka_body left)
+  const double *repV = va + (7 + (size_t)2 * D) * ns;       // F_0: the slices of rhs = sigma x - q + A' v alone (||rhs||_inf: read on the own columns only)
+  double *repnxt = gptr(f.va) + (7 + (size_t)nxt * D) * ns;
+  double g_acc = 0.0, rn_acc = 0.0, dl_acc = 0.0, bn_acc = 0.0;
   // the vector update of one own column (operands in registers): stores s_{k-1}, r_k, p_{k-1}, x~; returns u_k
   auto own_update = [&](int j, double mi, double r, double w, double sp, double pp, double x) -> double {
     double sn, rn, un;
@@ -732,7 +734,7 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     //      to be recomputed from its parts (columns outside the window), and those loads should leave with the window's, not after it
     double pv = 0.0; int pc = g0;
     const bool hasp = !vec_only && tid < pcnt;
-    if (!vec_only) { const int e = pk0 + max(0, min(tid, pcnt - 1)); pv = f.pval[e]; pc = f.pcol[e]; }
+    if (!vec_only) { const int e = pk0 + max(0, min(tid, pcnt - 1)); pv = gptr(f.pval)[e]; pc = gptr(f.pcol)[e]; }
     // ---- window parts (+ p, x~ where the window column is one of the block's own)
     double wm[CW], wr[CW], wsv[CW], wq[CW][D], wpp[CW], wx[CW];
     bool wown[CW];
@@ -742,14 +744,15 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
       if (u < nw) {
         const int e = tid + u * kBlock, c = g0 + min(e, gl - 1);
         wown[u] = e < gl && c >= cs0 && c - cs0 < nown;
-        wm[u] = Minv[c]; wr[u] = rread[c];
-        if (!FIRST) {
+        wm[u] = Minv[c];
 #pragma unroll
-          for (int q = 0; q < D; q++) wq[u][q] = repcur[q * ns + c];
+        for (int q = 0; q < D; q++) wq[u][q] = repcur[q * ns + c];
+        const int co = wown[u] ? c : g0;                    // (other lanes re-read one valid element: no branch around the loads)
+        if (!FIRST) {
+          wr[u] = rread[c];
           wsv[u] = sprev[c];
-          const int co = wown[u] ? c : g0;                  // (other lanes re-read one valid element: no branch around the loads)
           wx[u] = xs_r[co]; wpp[u] = p_r[co];
-        }
+        } else { wx[u] = xs_r[co]; wpp[u] = gptr(d.xg)[co]; }      // F_0: the own lane also moves x~ on (x~_prev <- x~, x~ <- x_g)
       }
     }
     // ---- row / column pointers (the matrix entries themselves arrive in LDS: S, requested one block ahead)
@@ -757,10 +760,10 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     int cp0[CW], cp1[CW];
     int pp0 = 0, pp1 = 0;
     if (!vec_only) {
-      { const int row = r0 + min(tid, nrows - 1); rp0 = d.A.rowptr[row]; rp1 = d.A.rowptr[row + 1]; rrho = d.rho[row]; }
+      { const int row = r0 + min(tid, nrows - 1); rp0 = gptr(d.A.rowptr)[row]; rp1 = gptr(d.A.rowptr)[row + 1]; rrho = gptr(d.rho)[row]; }
 #pragma unroll
-      for (int u = 0; u < CW; u++) { if (u < ns2) { const int c = cpo + min(tid + u * kBlock, wl - 1); cp0[u] = f.cptr[c]; cp1[u] = f.cptr[c + 1]; } }
-      { const int j = min(cs0 + max(0, min(tid, nown - 1)), n - 1); pp0 = f.prp[j]; pp1 = f.prp[j + 1]; }
+      for (int u = 0; u < CW; u++) { if (u < ns2) { const int c = cpo + min(tid + u * kBlock, wl - 1); cp0[u] = gptr(f.cptr)[c]; cp1[u] = gptr(f.cptr)[c + 1]; } }
+      { const int j = min(cs0 + max(0, min(tid, nown - 1)), n - 1); pp0 = gptr(f.prp)[j]; pp1 = gptr(f.prp)[j + 1]; }
     }
     // ---- operand of a (P + sigma I) entry whose column lies outside the window: its parts, requested now
     const int pcl = pc - g0;
@@ -769,12 +772,10 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
 #pragma unroll
     for (int q = 0; q < D; q++) eq[q] = 0.0;
     if (esc) {
-      em = Minv[pc]; er = rread[pc];
-      if (!FIRST) {
-        es = sprev[pc];
+      em = Minv[pc];
 #pragma unroll
-        for (int q = 0; q < D; q++) eq[q] = repcur[q * ns + pc];
-      }
+      for (int q = 0; q < D; q++) eq[q] = repcur[q * ns + pc];
+      if (!FIRST) { er = rread[pc]; es = sprev[pc]; }
     }
     KT(3);
     // ---- u_k on the window -> LDS; the lane of an own column also performs that column's vector update
@@ -783,9 +784,16 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
       if (u < nw) {
         const int e = min(tid + u * kBlock, gl - 1);
         double un;
-        if (FIRST) un = wm[u] * wr[u];
-        else {
-          const double w = f1_w<D>(wq[u]);
+        const double w = f1_w<D>(wq[u]);
+        if constexpr (FIRST) {
+          const double r0 = w;                              // rhs - K x_g: the slices' sum, the same expression in every workgroup that holds the column
+          un = wm[u] * r0;
+          if (wown[u]) {
+            const int j = g0 + e;
+            rnxt[j] = r0; gptr(d.xsp)[j] = wx[u]; xs_w[j] = wpp[u];
+            g_acc += r0 * un; rn_acc = nanmax(rn_acc, fabs(r0));
+          }
+        } else {
           if (wown[u]) un = own_update(g0 + e, wm[u], wr[u], w, wsv[u], wpp[u], wx[u]);
           else { double sn, rn; f1_upd(sc, wm[u], wr[u], w, wsv[u], sn, rn, un); }
         }
@@ -797,14 +805,17 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     for (int jj = tid; jj < nown; jj += kBlock) {
       const int j = cs0 + jj;
       if (j >= g0 && j - g0 < gl) continue;
-      const double mi = Minv[j], r = rread[j];
-      double un = mi * r;
-      if (!FIRST) {
-        double rp[D];
+      const double mi = Minv[j];
+      double rp[D];
 #pragma unroll
-        for (int q = 0; q < D; q++) rp[q] = repcur[q * ns + j];
-        un = own_update(j, mi, r, f1_w<D>(rp), sprev[j], p_r[j], xs_r[j]);
-      }
+      for (int q = 0; q < D; q++) rp[q] = repcur[q * ns + j];
+      double un;
+      if constexpr (FIRST) {
+        const double r0 = f1_w<D>(rp);
+        un = mi * r0;
+        rnxt[j] = r0; gptr(d.xsp)[j] = xs_r[j]; xs_w[j] = gptr(d.xg)[j];
+        g_acc += r0 * un; rn_acc = nanmax(rn_acc, fabs(r0));
+      } else un = own_update(j, mi, rread[j], f1_w<D>(rp), sprev[j], p_r[j], xs_r[j]);
       if (!vec_only) L.uown[jj] = un;
     }
     if (vec_only) continue;
@@ -819,6 +830,13 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     for (int u = 0; u < CW; u++) { if (u < ns2) asm volatile("" :: "v"(cp0[u]), "v"(cp1[u])); }
 #endif
     __syncthreads();
+    // F_0: ||rhs||_inf of the own columns from the slices of rhs alone (requested now that the window's registers are free, folded at the block's end)
+    [[maybe_unused]] double bv[D];
+    if constexpr (FIRST) {
+      const int j = cs0 + max(0, min(tid, nown - 1));
+#pragma unroll
+      for (int q = 0; q < D; q++) bv[q] = repV[q * ns + j];
+    }
     // ---- products: A entries against the window; the (P + sigma I) entry against the window or its recomputed operand
     double vw[CE]; unsigned int en[CE];
 #pragma unroll
@@ -828,7 +846,7 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     if (hasp) {
       double uv;
       if (!esc) uv = L.win[pcl];
-      else if (FIRST) uv = em * er;
+      else if constexpr (FIRST) uv = em * f1_w<D>(eq);
       else { double sn, rn; f1_upd(sc, em, er, f1_w<D>(eq), es, sn, rn, uv); }
       L.pprod[tid] = pv * uv;
     }
@@ -848,8 +866,8 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
       L.tvec[tid] = t; dl_acc += t * au;
     }
     for (int row = tid + kBlock; row < nrows; row += kBlock) {
-      const int q0 = d.A.rowptr[r0 + row], q1 = d.A.rowptr[r0 + row + 1];
-      const double au = f1_segsum<6>(L.prod, q0 - k0, q1 - k0), t = d.rho[r0 + row] * au;
+      const int q0 = gptr(d.A.rowptr)[r0 + row], q1 = gptr(d.A.rowptr)[r0 + row + 1];
+      const double au = f1_segsum<6>(L.prod, q0 - k0, q1 - k0), t = gptr(d.rho)[r0 + row] * au;
       L.tvec[row] = t; dl_acc += t * au;
     }
     KT(6);
@@ -862,7 +880,7 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
       L.puown[tid] = pu; dl_acc += L.uown[tid] * pu;
     }
     for (int jj = tid + kBlock; jj < nown; jj += kBlock) {
-      const int q0 = f.prp[cs0 + jj], q1 = f.prp[cs0 + jj + 1];
+      const int q0 = gptr(f.prp)[cs0 + jj], q1 = gptr(f.prp)[cs0 + jj + 1];
       const double pu = f1_segsum<4>(L.pprod, q0 - pk0, q1 - pk0);
       L.puown[jj] = pu; dl_acc += L.uown[jj] * pu;
     }
@@ -884,6 +902,15 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     }
     for (int j = cov0 + tid; j < a0; j += kBlock) rout[j] = 0.0;             // the replica's gap up to the next window of this replica
     for (int j = a0 + wl + tid; j < cov1; j += kBlock) rout[j] = 0.0;
+    if constexpr (FIRST) {
+      if (tid < nown) bn_acc = nanmax(bn_acc, fabs(f1_w<D>(bv)));
+      for (int jj = tid + kBlock; jj < nown; jj += kBlock) {
+        double rv[D];
+#pragma unroll
+        for (int q = 0; q < D; q++) rv[q] = repV[q * ns + cs0 + jj];
+        bn_acc = nanmax(bn_acc, fabs(f1_w<D>(rv)));
+      }
+    }
     KT(8);
     if (sl + slots < per) __syncthreads();                  // (another block follows: the LDS arrays are reused)
   }
@@ -891,12 +918,12 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
                                                             //  workgroup's LDS is released.  Not otherwise: the wait would also sit out every store of the body)
   __syncthreads();
   block_sum_max_sum(g_acc, rn_acc, dl_acc, L.red);
-  if (!FIRST) { put_partial(d.part, SL_GAMMA0 + par, g_acc); put_partial(d.part, SL_RN0 + par, rn_acc); }
-  else if (tid == 0) {                                      // F_0 hands KB's gamma_0, ||r_0|| on: this workgroup's entries move to this launch's buffers
-    d.part[(SL_GAMMA0 + par) * kGrid + blockIdx.x] = d.part[(SL_GAMMA0 + (par ^ 1)) * kGrid + blockIdx.x];
-    d.part[(SL_RN0 + par) * kGrid + blockIdx.x] = d.part[(SL_RN0 + (par ^ 1)) * kGrid + blockIdx.x];
+  put_partial(gptr(d.part), SL_GAMMA0 + par, g_acc); put_partial(gptr(d.part), SL_RN0 + par, rn_acc);
+  if constexpr (FIRST) {                                    // F_0 also owns ||rhs||_inf (the PCG tolerance of this ADMM iteration: f1_fold_finish, k = 1; KA of a capped PCG)
+    bn_acc = block_max(bn_acc, L.red);
+    put_partial(gptr(d.part), SL_BN, bn_acc);
   }
-  if (!vec_only) put_partial(d.part, SL_DELTA + par, dl_acc);
+  if (!vec_only) put_partial(gptr(d.part), SL_DELTA + par, dl_acc);
   KT(9);
 }
 // returns false when the PCG had already converged (nothing done: the caller runs KA in this launch)
@@ -926,6 +953,209 @@ __device__ __forceinline__ void f1_stream_first(const unsigned char *stream, int
   const int b0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * per + slot0);
   if (slot0 < per && b0 < nblk) f1_stream_issue(stream, b0, S);
 }
+
+// ---------------------------------------------------------------------------------------------- KA in the F1 form (no KB launch)
+// One launch does what KA and the following KB did in two ("k + 2 launches"):
+//   rows of block g     z~ = A_g x~ (window of x~ staged in LDS, products through the block's stream, one lane per row), the z / y update
+//                       (_osqp.py:682-703), v = rho z - y, z~, A x_g = z~ + theta (z~ - z~_prev), t0 = rho A x_g           -- what KA did
+//   own columns         x = alpha x~ + (1 - alpha) x, dx (_osqp.py:660-668), the next PCG start x_g = x~ + theta (x~ - x~_prev)  -- what KA did
+//   transposed passes   A_g' v and A_g' t0 per column of the block's scatter window (the same column-ordered pass as F's A_g' t, twice),
+//                       + sigma x - q resp. (P + sigma I) x_g on the own columns, written as the block's slices of two replica sets:
+//                         sum_d repR_d = r_0 = rhs - K x_g ,   sum_d repV_d = rhs = sigma x - q + A' v     (K x_g = (P + sigma I) x_g + A' t0)   -- what KB did
+// F_0 then forms r_0 column by column from the first set (f1_body<D, true>) and ||rhs|| on its own columns from the second, with gamma_0, ||r_0||.
+// SCATTER_ONLY: the first launch of a chunk -- v, t0, x, x_g are in memory (a rho update, a warm start or the previous chunk left them): only
+// the transposed passes and the own-column terms run.  x~_prev is NOT advanced here (F_0's own lanes do that): this launch reads it for the
+// operands of P at columns other workgroups own.
+template <int D, bool SCATTER_ONLY>
+__device__ __forceinline__ void f1_ka_body(const Dev &d, F1Lds &L, F1Stream &S, const F1Rec &rec0, const double theta) {
+  const DevF1 &f = d.f1;
+  const int tid = threadIdx.x;
+  const double *va = gptr(f.va); const size_t ns = f.ns;
+  const double *xs_r = va + ns;
+  double *repR = gptr(f.va) + (7 + (size_t)1 * D) * ns, *repV = gptr(f.va) + (7 + (size_t)2 * D) * ns;      // the parity-1 set (what F_0 reads as K u_{-1}'s place), the third set
+  const double alpha = d.alpha, sigma = d.sigma;
+  const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int per = (d.A.nblk + 7) >> 3;
+  constexpr int CW = kF1Win / kBlock, CE = kF1Chunk / kBlock;
+  for (int sl = slot0; sl < per; sl += slots) {
+    const int b = __builtin_amdgcn_readfirstlane(xcd * per + sl);
+    if (b >= d.A.nblk) break;
+    const F1Rec rec = sl == slot0 ? rec0 : f1_record(f, b);
+    const int4 ds = rec.ds, fa = rec.fa, fb = rec.fb, fc = rec.fc;
+    const int r0 = ds.x, nrows = ds.y - ds.x, k0 = ds.z, cnt = ds.w - ds.z;
+    const int cov0 = fa.x, cov1 = fa.y, cs0 = fa.z, nown = fa.w - fa.z;
+    const int cpo = fb.x, pk0 = fb.y, pcnt = fb.z - fb.y;
+    const int g0 = fc.x, gl = fc.y, a0 = fc.z, wl = fc.w;
+    const int nw = (gl + kBlock - 1) / kBlock, nu = (cnt + kBlock - 1) / kBlock, ns2 = (wl + kBlock - 1) / kBlock;
+    // ---- loads: the (P + sigma I) entry of this lane and its operand x_g[column]
+    double pv = 0.0; int pc = g0;
+    const bool hasp = tid < pcnt;
+    { const int e = pk0 + max(0, min(tid, pcnt - 1)); pv = gptr(f.pval)[e]; pc = gptr(f.pcol)[e]; }
+    const int pcl = pc - g0;
+    const bool pin = pcl >= 0 && pcl < gl;
+    double pxs = 0.0, pxp = 0.0;                             // x~[pc] (from the window when it is inside), x~_prev[pc]  -- or x_g[pc] itself (SCATTER_ONLY)
+    if (SCATTER_ONLY) pxs = gptr(d.xg)[pc];
+    else { pxp = gptr(d.xsp)[pc]; if (!pin) pxs = xs_r[pc]; }
+    // ---- window of x~ (rows' products) and the own columns' operands
+    double wx[CW], wxo[CW], wxp[CW], wq[CW];
+    bool wown[CW];
+#pragma unroll
+    for (int u = 0; u < CW; u++) {
+      wown[u] = false;
+      if (u < nw) {
+        const int e = tid + u * kBlock, c = g0 + min(e, gl - 1);
+        wown[u] = e < gl && c >= cs0 && c - cs0 < nown;
+        const int co = wown[u] ? c : g0;
+        if (!SCATTER_ONLY) { wx[u] = xs_r[c]; wxp[u] = gptr(d.xsp)[co]; }
+        wxo[u] = gptr(d.x)[co]; wq[u] = gptr(d.q)[co];
+      }
+    }
+    // ---- rows
+    int rp0 = 0, rp1 = 0;
+    double el = 0, eu = 0, erho = 0, erinv = 0, ez = 0, ey = 0, ezt = 0;      // (SCATTER_ONLY: ez = v, ey = t0 of the row)
+    { const int row = r0 + min(tid, nrows - 1);
+      if (SCATTER_ONLY) { ez = gptr(d.v)[row]; ey = gptr(d.t0)[row]; }
+      else { rp0 = gptr(d.A.rowptr)[row]; rp1 = gptr(d.A.rowptr)[row + 1]; el = gptr(d.l)[row]; eu = gptr(d.u)[row]; erho = gptr(d.rho)[row]; erinv = gptr(d.rho_inv)[row]; ez = gptr(d.z)[row]; ey = gptr(d.y)[row]; ezt = gptr(d.zt)[row]; } }
+    int cp0[CW], cp1[CW];
+#pragma unroll
+    for (int u = 0; u < CW; u++) { if (u < ns2) { const int c = cpo + min(tid + u * kBlock, wl - 1); cp0[u] = gptr(f.cptr)[c]; cp1[u] = gptr(f.cptr)[c + 1]; } }
+    int pp0 = 0, pp1 = 0;
+    { const int j = min(cs0 + max(0, min(tid, nown - 1)), d.n - 1); pp0 = gptr(f.prp)[j]; pp1 = gptr(f.prp)[j + 1]; }
+    // ---- window -> LDS; the own lane updates x and leaves  sigma x - q  for its column
+#pragma unroll
+    for (int u = 0; u < CW; u++) {
+      if (u < nw) {
+        const int e = min(tid + u * kBlock, gl - 1);
+        if (!SCATTER_ONLY) L.win[e] = wx[u];
+        if (wown[u]) {
+          const int j = g0 + e;
+          double xn = wxo[u];
+          if (!SCATTER_ONLY) {
+            const double xt = wx[u];
+            xn = alpha * xt + (1.0 - alpha) * wxo[u];                        // _osqp.py:664-668
+            gptr(d.dx)[j] = xn - wxo[u]; gptr(d.x)[j] = xn;
+            gptr(d.xg)[j] = xt + theta * (xt - wxp[u]);                            // next PCG start (Dev::xg); x~_prev moves on in F_0
+          }
+          L.uown[j - cs0] = sigma * xn - wq[u];
+        }
+      }
+    }
+    f1_stream_wait();
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" :: "v"(rp0), "v"(rp1), "v"(el), "v"(eu), "v"(erho), "v"(erinv), "v"(ez), "v"(ey), "v"(ezt), "v"(pp0), "v"(pp1), "v"(pv), "v"(pc), "v"(pxs), "v"(pxp));
+#pragma unroll
+    for (int u = 0; u < CW; u++) { if (u < ns2) asm volatile("" :: "v"(cp0[u]), "v"(cp1[u])); }
+#endif
+    __syncthreads();
+    double vw[CE]; unsigned int en[CE];
+#pragma unroll
+    for (int u = 0; u < CE; u++) { if (u < nu) { const int e = min(tid + u * kBlock, cnt - 1); vw[u] = S.val[e]; en[u] = S.ent[e]; } }
+    if (!SCATTER_ONLY) {
+#pragma unroll
+      for (int u = 0; u < CE; u++) { if (u < nu) L.prod[tid + u * kBlock] = vw[u] * L.win[en[u] & 0x1ffu]; }
+    }
+    if (hasp) {
+      double xg;
+      if (SCATTER_ONLY) xg = pxs;
+      else { const double xt = pin ? L.win[pcl] : pxs; xg = xt + theta * (xt - pxp); }
+      L.pprod[tid] = pv * xg;
+    }
+    __syncthreads();
+    if (sl + slots < per) {                                 // (every wave holds its entries in registers: the next block's stream goes out)
+      const int bn = __builtin_amdgcn_readfirstlane(xcd * per + sl + slots);
+      if (bn < d.A.nblk) f1_stream_issue(f.stream, bn, S);
+    }
+    // ---- rows: z~, the z / y update, v and t0 of the row (v -> LDS now, t0 kept for the second pass)
+    double t0r = 0.0;
+    if (tid < nrows) {
+      double vi;
+      if (SCATTER_ONLY) { vi = ez; t0r = ey; }
+      else {
+        const int i = r0 + tid;
+        const double ztil = f1_segsum<6>(L.prod, rp0 - k0, rp1 - k0);
+        const double zr = alpha * ztil + (1.0 - alpha) * ez;                 // _osqp.py:686-690
+        const double zn = fmin(fmax(zr + erinv * ey, el), eu);               // :674
+        const double dyi = erho * (zr - zn), yn = ey + dyi;                  // :698-703
+        const double zg = ztil + theta * (ztil - ezt);                       // A x_g
+        vi = erho * zn - yn; t0r = erho * zg;
+        gptr(d.y)[i] = yn; gptr(d.dy)[i] = dyi; gptr(d.z)[i] = zn; gptr(d.zt)[i] = ztil; gptr(d.v)[i] = vi; gptr(d.ztg)[i] = zg; gptr(d.t0)[i] = t0r;
+      }
+      L.tvec[tid] = vi;
+    }
+    for (int row = tid + kBlock; row < nrows; row += kBlock) {              // (blocks of more than kBlock rows; t0 of these rows is re-read from memory below)
+      const int i = r0 + row;
+      double vi;
+      if (SCATTER_ONLY) vi = gptr(d.v)[i];
+      else {
+        const int q0 = gptr(d.A.rowptr)[i], q1 = gptr(d.A.rowptr)[i + 1];
+        const double rho = gptr(d.rho)[i], zo = gptr(d.z)[i], yo = gptr(d.y)[i];
+        const double ztil = f1_segsum<6>(L.prod, q0 - k0, q1 - k0);
+        const double zr = alpha * ztil + (1.0 - alpha) * zo;
+        const double zn = fmin(fmax(zr + gptr(d.rho_inv)[i] * yo, gptr(d.l)[i]), gptr(d.u)[i]);
+        const double dyi = rho * (zr - zn), yn = yo + dyi;
+        const double zg = ztil + theta * (ztil - gptr(d.zt)[i]);
+        vi = rho * zn - yn;
+        gptr(d.y)[i] = yn; gptr(d.dy)[i] = dyi; gptr(d.z)[i] = zn; gptr(d.zt)[i] = ztil; gptr(d.v)[i] = vi; gptr(d.ztg)[i] = zg; gptr(d.t0)[i] = rho * zg;
+      }
+      L.tvec[row] = vi;
+    }
+    // ---- (P + sigma I) x_g on the own columns
+    if (tid < nown) L.puown[tid] = f1_segsum<4>(L.pprod, pp0 - pk0, pp1 - pk0);
+    for (int jj = tid + kBlock; jj < nown; jj += kBlock) { const int q0 = gptr(f.prp)[cs0 + jj], q1 = gptr(f.prp)[cs0 + jj + 1]; L.puown[jj] = f1_segsum<4>(L.pprod, q0 - pk0, q1 - pk0); }
+    __syncthreads();
+    // ---- first transposed pass: A_g' v
+#pragma unroll
+    for (int u = 0; u < CE; u++) { if (u < nu) L.prod[en[u] >> 18] = vw[u] * L.tvec[(en[u] >> 9) & 0x1ffu]; }
+    __syncthreads();
+    double cv[CW];
+#pragma unroll
+    for (int u = 0; u < CW; u++) { cv[u] = 0.0; if (u < ns2) { const int c = tid + u * kBlock; if (c < wl) cv[u] = f1_segsum<8>(L.prod, cp0[u], cp1[u]); } }
+    __syncthreads();
+    // ---- second pass: A_g' t0
+    if (tid < nrows) L.tvec[tid] = t0r;
+    for (int row = tid + kBlock; row < nrows; row += kBlock) L.tvec[row] = gptr(d.t0)[r0 + row];      // (written by this thread above, or by an earlier launch)
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < CE; u++) { if (u < nu) L.prod[en[u] >> 18] = vw[u] * L.tvec[(en[u] >> 9) & 0x1ffu]; }
+    __syncthreads();
+    double *routR = repR + (size_t)(b % D) * ns, *routV = repV + (size_t)(b % D) * ns;
+#pragma unroll
+    for (int u = 0; u < CW; u++) {
+      if (u < ns2) {
+        const int c = tid + u * kBlock;
+        if (c < wl) {
+          double tv = cv[u], tt = f1_segsum<8>(L.prod, cp0[u], cp1[u]);
+          const int jo = a0 + c - cs0;
+          if (jo >= 0 && jo < nown) { tv += L.uown[jo]; tt += L.puown[jo]; }      // this block owns the column: + sigma x - q  resp.  + (P + sigma I) x_g
+          routV[a0 + c] = tv; routR[a0 + c] = tv - tt;                             // slices of rhs, and of r_0 = rhs - K x_g
+        }
+      }
+    }
+    for (int j = cov0 + tid; j < a0; j += kBlock) { routV[j] = 0.0; routR[j] = 0.0; }      // the replicas' gaps up to the next window of this replica
+    for (int j = a0 + wl + tid; j < cov1; j += kBlock) { routV[j] = 0.0; routR[j] = 0.0; }
+    if (sl + slots < per) __syncthreads();
+  }
+}
+// KA of the slot machine in the F1 form: extrapolation weight, the body above, PCG statistics of the ADMM iteration that ends (as slot_ka)
+template <int D>
+__device__ __forceinline__ void f1_slot_ka(const Dev &d, F1Lds &L, F1Stream &S, const F1Rec &rec0, int used, int conv, int admm, int target, int rn_slot) {
+  double theta = d.theta, rn_last = 0.0, bn_last = 0.0;
+  if (!conv) { theta = cutoff_theta(d, rn_slot, L.red, rn_last, bn_last, admm); __syncthreads(); }      // (conv comes from the slot record: uniform)
+  f1_ka_body<D, false>(d, L, S, rec0, theta);
+  if (blockIdx.x == 0) {
+    if (!conv) {
+      const double rn = rn_last, bn = bn_last;
+      conv = !(rn > fmax(gptr(d.scal)[S_TOL_REL] * bn, gptr(d.scal)[S_TOL_ABS])) ? 2 : 0;
+      if (!conv && threadIdx.x == 0 && rn > 0.1 * gptr(d.scal)[S_RN0]) gptr(d.flags)[F_STAT_STAG] += 1;
+    }
+    if (threadIdx.x == 0) {
+      gptr(d.flags)[F_STAT_SUM] += used; gptr(d.flags)[F_STAT_SUMSQ] += used * used; gptr(d.flags)[F_STAT_N] += 1;
+      if (used > gptr(d.flags)[F_STAT_MAX]) gptr(d.flags)[F_STAT_MAX] = used;
+      if (!conv) gptr(d.flags)[F_STAT_UNCONV] += 1;
+      if (d.ctl && admm + 1 >= target) gptr(d.ctl)->chunk_done = 1;      // device-driven boundaries: the chunk's last ADMM iteration (read by LATER launches)
+    }
+  }
+}
 __global__ __launch_bounds__(kBlock) void k_f1_refresh(Dev d) {
   for (int k = blockIdx.x * kBlock + threadIdx.x; k < d.f1.pnnz; k += gridDim.x * kBlock) d.f1.pval[k] = d.B.val[d.f1.psrc[k]];
   // the value half of every block's stream <- A.val (entry e of block b sits at A.val[first entry of b + e])
@@ -943,60 +1173,65 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   __shared__ F1Stream sbuf;
   const int par = k & 1;
   f1_stream_first(d.f1.stream, d.A.nblk, sbuf);
-  const F1Fold fold = f1_fold_issue(d.part, par, mode);
+  const F1Fold fold = f1_fold_issue(gptr(d.part), par, mode);
   f1_iteration<D>(d, k, 1 << 30, 0, mode, lds, sbuf, f1_first_record(d.f1.blk, d.A.nblk), fold, par);      // (the first block's record goes out ahead of the partials of the scalar fold: both latencies overlap)
 }
 
-// The slot kernel of the F1 form: every launch of a chunk's string is this kernel (par: which of the two phase records it reads);
-// the phase that is due -- KB (streams B), a PCG iteration F_k (streams A and P), KA (streams A) -- comes from the record.
+// timing probes of the KA body above (time_kernel 17 / 18)
 template <int D>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_slot1(Dev d, int par) {
-  struct FS { F1Lds f; F1Stream s; };
-  __shared__ union { StreamLds<2> kb; StreamLdsW<1, double> ka; FS fs; } lds;
-  static_assert(sizeof(lds) <= 160 * 1024 / 4, "four workgroups per CU");
-  const int *R = d.slot + (par ? SR_WORDS : 0);
-  int *W = d.slot + (par ? 0 : SR_WORDS);
-  // The head of every launch is a chain of dependent scalar loads (kernel arguments -> phase record -> block record -> first vector loads):
-  // the arguments the F phase needs are pinned into registers HERE, behind one wait, and the block record is requested together with the
-  // phase record (most launches are F launches; KB / KA request their own descriptors after the branch)
-  const F1Fold fold = f1_fold_issue(d.part, par, 0);    // the previous launch's partials: their address depends on `par` alone
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_f1_ka_probe(Dev d, int scatter_only) {
+  __shared__ F1Lds lds;
+  __shared__ F1Stream sbuf;
+  f1_stream_first(d.f1.stream, d.A.nblk, sbuf);
   const F1Rec rec0 = f1_first_record(d.f1.blk, d.A.nblk);
-  SlotState st = slot_read(R);
-#if defined(__HIP_DEVICE_COMPILE__)
-  // both records, the partials and the phases' base pointers are in registers HERE: requested together, one wait
-  asm volatile("" :: "s"(st.ph), "s"(rec0.ds.x), "s"(rec0.fc.w), "s"(d.part), "s"(d.scal), "s"(d.f1.va), "s"(d.x), "s"(d.ztg), "s"(d.v), "s"(d.uu), "s"(d.n),
-               "v"(fold.a.v[0]), "v"(fold.a.v[kPart - 1]), "v"(fold.b.v[0]), "v"(fold.b.v[kPart - 1]), "v"(fold.c.v[0]), "v"(fold.c.v[kPart - 1]));
-#endif
+  if (scatter_only) f1_ka_body<D, true>(d, lds, sbuf, rec0, d.theta); else f1_ka_body<D, false>(d, lds, sbuf, rec0, d.theta);
+}
+
+// The slot kernel of the F1 form: every launch of a chunk's string is this kernel (par: which of the two phase records it reads).  Every phase is
+// built on the row blocks of A and their stream (no pass over B = [P + sigma I | A'] exists in this form):
+//   P_KB   the first launch of a chunk: the slices of rhs and K x_g from the vectors in memory (f1_ka_body, SCATTER_ONLY)
+//   P_F    PCG launch F_k; F_0 forms r_0 from the slices; the launch whose fold finds the PCG converged runs KA right there
+//   P_KA   KA after a PCG that stopped at its cap
+// An ADMM iteration with k PCG iterations is F_0 .. F_k + the launch that detects convergence and runs KA: k + 2 launches.
+// Dev reaches this kernel through MEMORY, not as a by-value argument: the compiler lowers a by-value struct into loads of every used field at
+// the kernel's entry -- some sixty here -- and, short of scalar registers, spills each batch to vector lanes before it fetches the next: ten
+// dependent load-wait-spill rounds in front of the first request of every launch (measured: +2 us per launch against the probe kernel that
+// holds one phase).  From memory the fields are fetched where the phase that runs needs them; the head's own six values sit in front of the
+// copy as one 48-byte block.  be::dev_publish keeps the copy current (slot_begin / ctl_begin: once per chunk, never inside a capture).
+struct F1Head { const unsigned char *stream; const int *blk; const double *part; const int *slot; int nblk, pad; };
+struct F1DevBlock { F1Head h; Dev d; };
+template <int D>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_slot1(const F1DevBlock *__restrict__ blk, int par) {
+  __shared__ F1Lds lds;
+  __shared__ F1Stream sbuf;
+  static_assert(sizeof(F1Lds) + sizeof(F1Stream) <= 160 * 1024 / 4, "four workgroups per CU");
+  const F1Head h = blk->h;
+  const Dev &d = blk->d;
+  const int *R = h.slot + (par ? SR_WORDS : 0);
+  int *W = gptr(d.slot) + (par ? 0 : SR_WORDS);
+  // every phase but the idle one consumes the first block's stream: requested before anything else has arrived
+  f1_stream_first(h.stream, h.nblk, sbuf);
+  const F1Fold fold = f1_fold_issue(gptr(h.part), par, 0);    // the previous launch's partials: their address depends on `par` alone
+  const F1Rec rec0 = f1_first_record(h.blk, h.nblk);
+  SlotState st = slot_read_scalar(R);
   if (st.ph == P_KB) {
-    if (st.admm >= st.target) { st.ph = P_IDLE; slot_write(W, st); return; }
-    GKb g{d.xg, d.v, d.t0, d.n};
-    EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma, d.xg, d.xs};
-    process_rows<2>(d.B, g, e, lds.kb);
-    __syncthreads();
-    const double G = block_sum(e.g, lds.kb.red);
-    double RN = e.rn, BN = e.bn;
-    block_max2(RN, BN, lds.kb.red);
-    put_partial(d.part, SL_GAMMA0 + par, G); put_partial(d.part, SL_RN0 + par, RN); put_partial(d.part, SL_DELTA + par, BN);      // (||rhs|| travels in delta's slot: f1_fold_finish, k = 0)
-    put_partial(d.part, SL_BN, BN);                        // (... and stays on record for the KA of a PCG that ran into its cap)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
+    if (st.admm >= st.target) { st.ph = P_IDLE; f1_stream_wait(); slot_write(W, st); return; }
+    f1_ka_body<D, true>(d, lds, sbuf, rec0, 0.0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { gptr(d.flags)[F_DONE] = 0; gptr(d.flags)[F_ITERS] = 0; }
     st.ph = P_F; st.k = 0;
   } else if (st.ph == P_F) {
-    // the first block's matrix stream: requested as soon as the phase is known (its address depends on the block index alone), lands in LDS
-    // while the scalar fold and the window loads run; nothing of it occupies a register
-    f1_stream_first(d.f1.stream, d.A.nblk, lds.fs.s);
-    if (f1_iteration<D>(d, st.k, st.cap, st.admm & 1, 0, lds.fs.f, lds.fs.s, rec0, fold, par)) {
+    if (f1_iteration<D>(d, st.k, st.cap, st.admm & 1, 0, lds, sbuf, rec0, fold, par)) {
       if (st.k >= st.cap) { st.ph = P_KA; st.used = st.k; st.conv = 0; }      // stopped at the cap: the next launch runs KA
       else st.k += 1;
-    } else {                                             // converged: KA right here
-      f1_stream_wait();                                  // (the stream requested above was never consumed, and KA's LDS overlays its buffer)
+    } else {                                             // converged after k - 1 iterations (k = 1: the start met the tolerance): KA right here
       __syncthreads();
-      slot_ka(d, lds.ka, st.k == 0 ? 0 : st.k - 1, 1, first_desc<true>(d.A), st.admm, st.target);
-      st.ph = P_KB; st.admm += 1;
+      f1_slot_ka<D>(d, lds, sbuf, rec0, st.k - 1, 1, st.admm, st.target, 0);
+      st.admm += 1; st.k = 0; st.ph = st.admm >= st.target ? P_IDLE : P_F;
     }
   } else if (st.ph == P_KA) {
-    slot_ka(d, lds.ka, st.used, st.conv, first_desc<true>(d.A), st.admm, st.target, par ^ 1);
-    st.ph = P_KB; st.admm += 1;
-  }
+    f1_slot_ka<D>(d, lds, sbuf, rec0, st.used, st.conv, st.admm, st.target, par ^ 1);
+    st.admm += 1; st.k = 0; st.ph = st.admm >= st.target ? P_IDLE : P_F;
+  } else f1_stream_wait();                               // (idle: nothing may be in flight when the workgroup's LDS is released)
   slot_write(W, st);
 }
 
@@ -1010,15 +1245,46 @@ void k2(Dev &d, int i) { if (d.fused) LAUNCH(k_k2f, d, d, i); else LAUNCH(k_k2, 
 void kv(Dev &d, int i) { if (d.n >= 2 * kGrid * kBlock) LAUNCH(k_kv<2>, d, d, i, 0); else LAUNCH(k_kv<1>, d, d, i, 0); }
 void ka(Dev &d, int budget) { LAUNCH(k_ka, d, d, budget); }
 bool slots_supported(const Dev &d) { return (d.fused != 0 || wbx_slots(d)) && d.slot != nullptr; }
-void slot_begin(Dev &d, int target, int cap) { HIP_CHECK(hipSetDevice(d.device)); hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(1), 0, st(d), d.slot, target, cap, ++im(d).epoch); }
+// The F1 slot kernel reads Dev from device memory (k_slot1): upload {head, Dev} when it differs from what was uploaded last.  Called where a chunk
+// begins (slot_begin, ctl_begin) and by the timing probe -- eager calls, never inside a stream capture (a copy node captured into a string of slots
+// would be replayed with every replay).  Stream-ordered: the launches that follow on d.stream see the new copy.
+void dev_publish(Dev &d) {
+  if (!d.f1.on) return;
+  Impl &p = im(d);
+  if (!p.dev_block) {
+    HIP_CHECK(hipMalloc(&p.dev_block, sizeof(F1DevBlock)));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p.pin_block), sizeof(F1DevBlock), hipHostMallocDefault));
+    p.shadow_block = static_cast<unsigned char *>(std::calloc(1, sizeof(F1DevBlock)));
+    std::memset(p.pin_block, 0, sizeof(F1DevBlock));
+    p.shadow_block[0] = 1;                               // (differs from any real block: the first call uploads)
+  }
+  F1DevBlock nb;
+  std::memset(static_cast<void *>(&nb), 0, sizeof(nb));
+  nb.h = F1Head{d.f1.stream, d.f1.blk, d.part, d.slot, d.A.nblk, 0};
+  std::memcpy(static_cast<void *>(&nb.d), static_cast<const void *>(&d), sizeof(Dev));
+  if (std::memcmp(&nb, p.shadow_block, sizeof(nb)) == 0) return;
+  // (the pinned staging block may still be the source of an upload in flight: drain the stream before rewriting it -- rare: a setting changed)
+  HIP_CHECK(hipStreamSynchronize(st(d)));
+  std::memcpy(p.shadow_block, &nb, sizeof(nb));
+  std::memcpy(p.pin_block, &nb, sizeof(nb));
+  HIP_CHECK(hipMemcpyAsync(p.dev_block, p.pin_block, sizeof(nb), hipMemcpyHostToDevice, st(d)));
+}
+void dev_release(Dev &d) {
+  Impl &p = im(d);
+  if (p.dev_block) { (void)hipFree(p.dev_block); p.dev_block = nullptr; }
+  if (p.pin_block) { (void)hipHostFree(p.pin_block); p.pin_block = nullptr; }
+  if (p.shadow_block) { std::free(p.shadow_block); p.shadow_block = nullptr; }
+}
+void slot_begin(Dev &d, int target, int cap) { HIP_CHECK(hipSetDevice(d.device)); dev_publish(d); hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(1), 0, st(d), d.slot, target, cap, ++im(d).epoch); }
 void slot_pair(Dev &d) {
   if (wbx_slots(d)) { wbx_slot_pair(d); return; }      // Woodbury direct mode: X, Y (wbdirect_hip.hip)
   if (d.f1.on) {
+    const F1DevBlock *db = static_cast<const F1DevBlock *>(im(d).dev_block);      // (current as of the chunk's slot_begin / ctl_begin: dev_publish)
     switch (d.f1.D) {
-      case 1: LAUNCH(k_slot1<1>, d, d, 0); LAUNCH(k_slot1<1>, d, d, 1); break;
-      case 2: LAUNCH(k_slot1<2>, d, d, 0); LAUNCH(k_slot1<2>, d, d, 1); break;
-      case 3: LAUNCH(k_slot1<3>, d, d, 0); LAUNCH(k_slot1<3>, d, d, 1); break;
-      default: LAUNCH(k_slot1<4>, d, d, 0); LAUNCH(k_slot1<4>, d, d, 1); break;
+      case 1: LAUNCH(k_slot1<1>, d, db, 0); LAUNCH(k_slot1<1>, d, db, 1); break;
+      case 2: LAUNCH(k_slot1<2>, d, db, 0); LAUNCH(k_slot1<2>, d, db, 1); break;
+      case 3: LAUNCH(k_slot1<3>, d, db, 0); LAUNCH(k_slot1<3>, d, db, 1); break;
+      default: LAUNCH(k_slot1<4>, d, db, 0); LAUNCH(k_slot1<4>, d, db, 1); break;
     }
   }
   else { LAUNCH(k_slot_b, d, d); LAUNCH(k_slot_a, d, d); }
@@ -1102,12 +1368,21 @@ float time_kernel(Dev &d, int which, int reps) {
       case 13: LAUNCH(k_k2f, d, d, 2); LAUNCH(k_k1f, d, d, 3); break;   // the same pair with the done flag set: what an early-exit pair costs
       case 14: f1_probe_pair(d, 1); break;   // F1 form without the scalar fold at the head of the launch (two consecutive iterations)
       case 16: slot_pair(d); break;           // two F launches of the slot kernel itself (records set up by k_slot_probe_f below): what a launch costs inside a solve
+      case 17: case 18:                      // KA of the F1 form (17) / the chunk's first launch, transposed passes only (18)
+        switch (d.f1.D) {
+          case 1: LAUNCH(k_f1_ka_probe<1>, d, d, which == 18); break;
+          case 2: LAUNCH(k_f1_ka_probe<2>, d, d, which == 18); break;
+          case 3: LAUNCH(k_f1_ka_probe<3>, d, d, which == 18); break;
+          default: LAUNCH(k_f1_ka_probe<4>, d, d, which == 18); break;
+        }
+        break;
       case 15: f1_probe_pair(d, 2); break;   // F1 form: one PCG iteration = one launch; two consecutive iterations as a solve runs them (buffers alternate, fold included)
       default: LAUNCH(k_k2f, d, d, 0); LAUNCH(k_k1f, d, d, 1); break;   // one FUSED PCG iteration (two kernels): repeated exact line-search steps, bounded
     }
   };
-  if (which >= 14 && which <= 16 && !d.f1.on) return 0.f;
+  if (which >= 14 && which <= 18 && !d.f1.on) return 0.f;
   if (which == 16) {
+    dev_publish(d);
     if (reps > 400) reps = 400;                 // (k advances by two per repetition; the alpha / gamma history holds kMaxCg entries)
     hipLaunchKernelGGL(k_slot_probe_f, dim3(1), dim3(1), 0, st(d), d.slot, d.scal, 2);
   }
