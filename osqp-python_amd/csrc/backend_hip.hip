@@ -389,6 +389,7 @@ __global__ __launch_bounds__(64) void k_decide(Dev d, int stage) {
     int st;
     if (stage == 1) {
       c.chunk_done = 0;
+      if (c.boundaries >= 0 && c.boundaries < kCtlHist) c.hist[c.boundaries] = c.seq_end - c.seq_begin;      // launches the chunk consumed (Engine::run_device_driven feeds the next solve from it)
       for (int q = 0; q < F_COUNT; q++) c.last_flags[q] = fl[q];
       st = ctl_boundary(c, res, fl);
     } else st = ctl_boundary_stage2(c, res, c.last_flags);

@@ -744,8 +744,26 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
     kLow = std::min(96, std::max<int>(pol_.poll_low, (int)std::ceil(3.0 * cycle_s / pair_s)));
     kFinish = std::max<int>(pol_.finish_pairs, 2 * kLow);
   };
+  // Feeding from HISTORY: the previous solve of this handle recorded how many slot launches each of its chunks consumed (Ctl::hist).  While this
+  // solve follows the same course -- a parametric re-solve, the steps of a benchmark -- every chunk gets exactly that string with its boundary
+  // group right behind it, two chunks ahead of the device: no idle launches, and nothing depends on when the host gets to poll.  The first chunk
+  // that outruns its string ends the mode (the polled top-ups below take over from whatever is queued); a chunk that needs less only idles.
+  bool use_hist = pol_.slot_poll != 0 && !feed_hist_.empty();
+  int fed = snap.boundaries;                         // chunks [.., fed) have their strings and groups enqueued
+  long fed_end_seq = 0;                              // slot launches enqueued up to the end of chunk fed - 1
+  auto feed_from_history = [&](int upto) {
+    while (use_hist && fed < upto) {
+      if (fed >= (int)feed_hist_.size() || feed_hist_[fed] <= 0) { use_hist = false; break; }
+      const int np = (feed_hist_[fed] + 1) / 2;
+      run_slots(0, np, 0); launched += np;
+      run_group(diagonal);
+      fed += 1; fed_end_seq = 2 * launched;
+    }
+  };
+  feed_from_history(snap.boundaries + 2);
   // chunk in flight as of the last poll, and the progress counters at the first poll that saw it (rate estimate)
-  { const int cnt = snap.ch_next - snap.iter;
+  if (!use_hist && launched == 0) {
+    const int cnt = snap.ch_next - snap.iter;
     const double full = pairs_for(cnt, pred_for(snap, snap.ch_kind, snap.ch_tight));
     const int np = one_string(std::max(2, (int)std::floor(pol_.poll_first * full)), (int)std::floor(0.95 * full));
     run_slots(0, np, 0); launched += np; }
@@ -754,6 +772,15 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
     print_log(snap, t0);
     if (snap.status != CTL_RUNNING) break;
     if (now_s() - t0 > settings.time_limit) { timed_out = true; break; }
+    if (use_hist) {
+      // (the device is in chunk snap.boundaries; all of it and of the next is queued.  Everything up to the end of chunk fed - 1 consumed and
+      //  the device still inside it: the course differs from the recorded one)
+      if (snap.boundaries < fed && seq >= fed_end_seq) use_hist = false;
+      else {
+        feed_from_history(snap.boundaries + 2);
+        if (use_hist) { std::this_thread::sleep_for(std::chrono::microseconds(std::max(pol_.poll_sleep_us, 100))); continue; }
+      }
+    }
     const long ahead = launched - seq / 2;           // pairs enqueued and not yet executed
     { const double t_now = now_s();
       if (seq - seq_rate >= 16) { pair_s = std::max(5e-6, 2.0 * (t_now - t_rate) / (double)(seq - seq_rate)); t_rate = t_now; seq_rate = seq; } }
@@ -793,6 +820,7 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
   for (int q = 0; q < R_COUNT; q++) res[q] = c.res[q];
   for (int q = 0; q < F_COUNT; q++) flags[q] = c.last_flags[q];
   for (int k = 0; k < 3; k++) if (c.kind_n[k] > 0) slot_pred_[k] = c.kind_sum[k] / c.kind_n[k];
+  feed_hist_.assign(c.hist, c.hist + std::min(std::max(c.boundaries, 0), (int)kCtlHist));      // (what the next solve of this handle is fed from)
   if (c.rho_bar != rho_bar_) { rho_bar_ = c.rho_bar; settings.rho = rho_bar_; }      // (applied on the device)
   if (timed_out && c.status == CTL_RUNNING) return -2;
   return c.status;

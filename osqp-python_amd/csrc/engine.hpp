@@ -173,6 +173,7 @@ class Engine {
   void exec_chunk_sync(int cnt, int lim, bool with_res, int kind, double *res, int *flags);
   int run_device_driven(double t0, double *res, int *flags);
   void run_group(int diagonal);
+  std::vector<int> feed_hist_;          // slot launches per chunk of the previous device-driven solve (Ctl::hist; index = boundaries processed when the chunk began)
   void polish();
   void apply_scaled_bounds(const std::vector<double> &ls, const std::vector<double> &us);
   void drop_graphs();

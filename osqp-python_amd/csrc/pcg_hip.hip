@@ -471,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
 // KA with the PCG statistics taken from the slot record (used iterations; conv = 0: the PCG stopped at the cap -- did its last
 // iterate reach the tolerance anyway?)
 template <class L>
-__device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv, const FirstDesc &fd, int admm, int target, int rn_slot = -1) {
+__device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv, const FirstDesc &fd, int admm, int target, int seq, int rn_slot = -1) {
   double theta = d.theta, rn_last = 0.0, bn_last = 0.0;
   // (rn_slot: which of the two ||r|| partial buffers the last PCG launch wrote -- the parity of `used` in the two-kernel form, of the LAUNCH in the F1 form)
   if (!conv) { theta = cutoff_theta(d, rn_slot >= 0 ? rn_slot : (used & 1), lds.red, rn_last, bn_last, admm); __syncthreads(); }      // (conv comes from the slot record: uniform)
@@ -494,7 +494,7 @@ __device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv
       d.flags[F_STAT_SUM] += used; d.flags[F_STAT_SUMSQ] += used * used; d.flags[F_STAT_N] += 1;
       if (used > d.flags[F_STAT_MAX]) d.flags[F_STAT_MAX] = used;
       if (!conv) d.flags[F_STAT_UNCONV] += 1;
-      if (d.ctl && admm + 1 >= target) d.ctl->chunk_done = 1;      // device-driven boundaries: the chunk's last ADMM iteration (read by LATER launches)
+      if (d.ctl && admm + 1 >= target) { d.ctl->seq_end = seq + 1; d.ctl->chunk_done = 1; }      // device-driven boundaries: the chunk's last ADMM iteration (read by LATER launches)
     }
   }
 }
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(kBlock) void k_slot_a(Dev d) {
     if (process_rows_fd<1>(d.A, g, e, lds.k1, PreK1{d, 0, 0, lds.k1.red, st.admm & 1}, fd)) { st.ph = P_K2F; st.k = 0; }
     else {                                             // the warm start already meets the tolerance: no PCG iteration, KA right here
       __syncthreads();
-      slot_ka(d, lds.k1, 0, 1, fd, st.admm, st.target);
+      slot_ka(d, lds.k1, 0, 1, fd, st.admm, st.target, st.seq);
       st.ph = P_KB; st.admm += 1;
     }
   } else if (st.ph == P_K1F) {
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kBlock) void k_slot_a(Dev d) {
     if (i >= st.cap) { st.ph = P_KA; st.used = i; st.conv = 0; }      // the PCG stops at the cap; the next A slot runs KA
     else { st.ph = P_K2F; st.k = i; }
   } else if (st.ph == P_KA) {
-    slot_ka(d, lds.k1, st.used, st.conv, fd, st.admm, st.target);
+    slot_ka(d, lds.k1, st.used, st.conv, fd, st.admm, st.target, st.seq);
     st.ph = P_KB; st.admm += 1;
   }
   slot_write(W, st);
@@ -1138,7 +1138,7 @@ __device__ __forceinline__ void f1_ka_body(const Dev &d, F1Lds &L, F1Stream &S, 
 }
 // KA of the slot machine in the F1 form: extrapolation weight, the body above, PCG statistics of the ADMM iteration that ends (as slot_ka)
 template <int D>
-__device__ __forceinline__ void f1_slot_ka(const Dev &d, F1Lds &L, F1Stream &S, const F1Rec &rec0, int used, int conv, int admm, int target, int rn_slot) {
+__device__ __forceinline__ void f1_slot_ka(const Dev &d, F1Lds &L, F1Stream &S, const F1Rec &rec0, int used, int conv, int admm, int target, int rn_slot, int seq) {
   double theta = d.theta, rn_last = 0.0, bn_last = 0.0;
   if (!conv) { theta = cutoff_theta(d, rn_slot, L.red, rn_last, bn_last, admm); __syncthreads(); }      // (conv comes from the slot record: uniform)
   f1_ka_body<D, false>(d, L, S, rec0, theta);
@@ -1152,7 +1152,7 @@ __device__ __forceinline__ void f1_slot_ka(const Dev &d, F1Lds &L, F1Stream &S, 
       gptr(d.flags)[F_STAT_SUM] += used; gptr(d.flags)[F_STAT_SUMSQ] += used * used; gptr(d.flags)[F_STAT_N] += 1;
       if (used > gptr(d.flags)[F_STAT_MAX]) gptr(d.flags)[F_STAT_MAX] = used;
       if (!conv) gptr(d.flags)[F_STAT_UNCONV] += 1;
-      if (d.ctl && admm + 1 >= target) gptr(d.ctl)->chunk_done = 1;      // device-driven boundaries: the chunk's last ADMM iteration (read by LATER launches)
+      if (d.ctl && admm + 1 >= target) { gptr(d.ctl)->seq_end = seq + 1; gptr(d.ctl)->chunk_done = 1; }      // device-driven boundaries: the chunk's last ADMM iteration (read by LATER launches)
     }
   }
 }
@@ -1225,11 +1225,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
       else st.k += 1;
     } else {                                             // converged after k - 1 iterations (k = 1: the start met the tolerance): KA right here
       __syncthreads();
-      f1_slot_ka<D>(d, lds, sbuf, rec0, st.k - 1, 1, st.admm, st.target, 0);
+      f1_slot_ka<D>(d, lds, sbuf, rec0, st.k - 1, 1, st.admm, st.target, 0, st.seq);
       st.admm += 1; st.k = 0; st.ph = st.admm >= st.target ? P_IDLE : P_F;
     }
   } else if (st.ph == P_KA) {
-    f1_slot_ka<D>(d, lds, sbuf, rec0, st.used, st.conv, st.admm, st.target, par ^ 1);
+    f1_slot_ka<D>(d, lds, sbuf, rec0, st.used, st.conv, st.admm, st.target, par ^ 1, st.seq);
     st.admm += 1; st.k = 0; st.ph = st.admm >= st.target ? P_IDLE : P_F;
   } else f1_stream_wait();                               // (idle: nothing may be in flight when the workgroup's LDS is released)
   slot_write(W, st);

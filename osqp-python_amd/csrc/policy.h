@@ -62,8 +62,13 @@ struct Ctl {
   // from -- the lines of a device-driven solve are then the same lines, whenever the host gets to read them
   int nlog, log_pad;
   double log[16][5];              // {iter, obj_val, prim_res, dual_res, rho_bar at the check}
+  // ---- how many slot launches every chunk of this solve consumed (device-driven solves; index = boundaries processed when the chunk began):
+  // the next solve of the handle is fed from it (Engine::run_device_driven) instead of from polled progress
+  int seq_end;                    // device: value of the slot counter when the chunk in flight completed its last ADMM iteration (written with chunk_done)
+  int hist_pad;
+  int hist[64];
 };
-constexpr int kCtlLog = 16, kCtlPrintInterval = 200;
+constexpr int kCtlLog = 16, kCtlPrintInterval = 200, kCtlHist = 64;
 
 OSQP_HD inline int pol_imin(int a, int b) { return a < b ? a : b; }
 OSQP_HD inline int pol_imax(int a, int b) { return a > b ? a : b; }

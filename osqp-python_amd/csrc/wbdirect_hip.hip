@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kT) void k_wbx_slot_x(Dev d) {
   else if (upd) wbx_x_body<true, false>(d, L);
   else if (rhs) wbx_x_body<false, true>(d, L);
   if (upd) {
-    if (d.ctl && admm_after >= st.target && blockIdx.x == 0 && threadIdx.x == 0) d.ctl->chunk_done = 1;      // (read by LATER launches)
+    if (d.ctl && admm_after >= st.target && blockIdx.x == 0 && threadIdx.x == 0) { d.ctl->seq_end = st.seq + 1; d.ctl->chunk_done = 1; }      // (read by LATER launches)
     st.admm = admm_after; st.used = 1; st.conv = 1;
   }
   st.ph = rhs ? P_K1 : (st.ph == P_IDLE ? P_IDLE : P_KB);      // (P_KB with admm >= target: the chunk is over, the next X idles)
