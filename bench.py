@@ -163,12 +163,24 @@ def measure_roofline(s, stats, n, mm, args):
             'Kv pcg vector update': (2, 12 * 8 * n),
         }
         seq_id, dom, dom_kernel = 6, 'K2 spmv B (w=B[u;t], <w,u>)', 'k_k2'
-    other = {
-        # (+ the extrapolated PCG start: KB resets x~ to it (8n written); KA reads the previous z~ and x~_prev and writes
-        #  A xg, xg, x~_prev: 8m + 8n read, 8m + 16n written)
-        'KB rhs + pcg start': (3, sB + 8 * mm + 8 * (5 * n)),
-        'KA A x~ + z,y,x update + next PCG start': (4, sA + 8 * (11 * mm) + 8 * (6 * n)),
-    }
+    if f1:
+        # F1 form, k + 2 launches per ADMM iteration: no pass over B.  KA streams A once (12 bytes per entry + row pointers), reads
+        # l, u, rho, rho_inv, z, y, z~_prev and writes y, dy, z, z~, v, A x_g, t0 per row (14 m-vector passes), reads x~ (window), x, x~_prev, q and
+        # writes x, dx, x_g per column, streams P + sigma I once, and leaves the slices of r_0 and of rhs (2 D n-vector passes written);
+        # the chunk's first launch runs its transposed passes only (v, t0, x, x_g, q read)
+        nzP = nnzB - nnzA
+        ka_bytes = 12 * nnzA + 4 * (mm + 1) + 8 * mm * 14 + 12 * nzP + 4 * (n + 1) + 8 * n * (4 + 3 + 2 * f1_D)
+        other = {
+            'KA z~ = A x~, z / y / x update, slices of r_0 and rhs (k_slot1 phase KA)': (17, ka_bytes),
+            'chunk start: slices of r_0 and rhs from the vectors in memory (k_slot1 phase KB)': (18, 12 * nnzA + 8 * mm * 2 + 12 * nzP + 4 * (n + 1) + 8 * n * (3 + 2 * f1_D)),
+        }
+    else:
+        other = {
+            # (+ the extrapolated PCG start: KB resets x~ to it (8n written); KA reads the previous z~ and x~_prev and writes
+            #  A xg, xg, x~_prev: 8m + 8n read, 8m + 16n written)
+            'KB rhs + pcg start': (3, sB + 8 * mm + 8 * (5 * n)),
+            'KA A x~ + z,y,x update + next PCG start': (4, sA + 8 * (11 * mm) + 8 * (6 * n)),
+        }
     probes = {}
     for name, (which, nbytes) in {**pcg_kernels, **other}.items():
         probes[name] = {'ms_same_kernel_repeat': s.hip_time_kernel(which, args.probe_reps), 'bytes': nbytes}
@@ -195,6 +207,28 @@ def measure_roofline(s, stats, n, mm, args):
         probes[name]['ms'] = probes[name]['ms_same_kernel_repeat']
     for name in probes:
         probes[name]['GBps'] = probes[name]['bytes'] / (probes[name]['ms'] * 1e-3) / 1e9
+    wdirect = int(stats.get('woodbury_direct', 0))
+    if wdirect:
+        # The Woodbury direct mode runs NO PCG iteration: what a solve launches per ADMM iteration is (2) the two-launch form k_wbx_x + k_wbx_y
+        # (portfolio: a dense r x 64 tile of A_L resp. S^-1 A_L per workgroup from LDS), or (1) KB, the three kernels of M^-1 = K^-1
+        # (k_wb_p1 over the long rows, k_wb_gemv with S^-1, k_wb_p3 over their transpose) and KA.  The roofline names THAT.
+        r = int(stats.get('woodbury_rows', 0))
+        if wdirect == 2:
+            G = (n + 63) // 64
+            wb_bytes = 2 * G * 128 * 64 * 8 + 8 * n * 12 + 8 * mm * 8          # both tiles as stored (zero-padded to 128 rows) + the n- and m-vector passes of X and Y
+            ms_it = s.hip_time_kernel(20, max(50, args.probe_reps))
+            name = 'Woodbury direct mode, one ADMM iteration = k_wbx_y + k_wbx_x (two launches)'
+            probes = {name: {'ms': ms_it, 'ms_same_kernel_repeat': ms_it, 'bytes': wb_bytes, 'GBps': wb_bytes / (ms_it * 1e-3) / 1e9, 'launches': 2}}
+            dom, dom_kernel = name, 'k_wbx_x'
+        else:
+            nzL = nnzA                                                         # (the long rows carry nearly all of A in this form)
+            wb_bytes = 8 * nzL + 8 * r * r + 8 * nzL + 8 * (4 * n + 2 * r)     # A_L once (values only: consecutive columns), S^-1, A_L' once, the vectors
+            ms_ch = s.hip_time_kernel(21, max(20, args.probe_reps // 4))
+            name = 'Woodbury direct mode, M^-1 = K^-1: k_wb_p1 + k_wb_gemv + k_wb_p3 (three launches per ADMM iteration)'
+            probes[name] = {'ms': ms_ch, 'ms_same_kernel_repeat': ms_ch, 'bytes': wb_bytes, 'GBps': wb_bytes / (ms_ch * 1e-3) / 1e9, 'launches': 3}
+            dom, dom_kernel = name, 'k_wb_gemv'
+        kb = {nm: probes[nm]['bytes'] for nm in probes}
+        return probes, kb, kb[dom], probes[dom]['ms'], dom, dom_kernel, survey_pcg_bytes, None, False, fused, 0
     kb = {name: probes[name]['bytes'] for name in probes}
     pcg_bytes = sum(kb[k] for k in pcg_kernels)
     if f1:
@@ -243,6 +277,7 @@ def main():
     ap.add_argument('--batch-cpu', type=int, default=1, help='time the all-cores CPU baseline of the batch too (N = 1 only)')
     ap.add_argument('--hbm-n', type=int, default=1000000, help='N = 1, headline config only: also time the dominant kernel on the same generator at this many variables '
                                                                '(a working set beyond the 256 MiB Infinity Cache) and report it as roofline.hbm_resident (0 disables)')
+    ap.add_argument('--jacobi-leg', type=int, default=1, help='lasso / portfolio: also solve once with the plain Jacobi preconditioner (config.jacobi_only); 0 for profiling runs, whose kernel statistics it would dominate')
     ap.add_argument('--unstructured-leg', type=int, default=1, help='N = 1, headline config only: also solve the unstructured variant of the same sizes and report its PCG iteration as roofline.unstructured (0 disables)')
     args = ap.parse_args()
     warnings.simplefilter('ignore')
@@ -394,6 +429,9 @@ def main():
                        'reordered': bool(stats.get('reordered', 0)), 'reorder_ms': stats.get('reorder_ms', 0.0),
                        'preconditioner': s.hip_preconditioner(), 'woodbury_factorisations_last_solve': int(stats.get('woodbury_factorisations', 0)),
                        'woodbury_factor_ms_last_solve': stats.get('woodbury_factor_ms', 0.0),
+                       # (rho updates of the last solve served by an inverse the handle had computed for the same rho_bar in an EARLIER solve -- every step of this
+                       #  bench restarts from the setting's rho and walks the same rho values; first_cold_solve_ms is the figure without any cached inverse)
+                       'woodbury_cache_hits_last_solve': int(stats.get('woodbury_cache_hits', 0)),
                        'pcg_kernels_per_iteration': 1 if f1 else (2 if fused else 3), 'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
                        'setup_s': t_setup, 'per_rank': [{'status': int(r[0]), 'iter': int(r[1]), 'obj': r[2]} for r in allrec]},
             'roofline': None if hostsim else {'bound': 'hbm', 'kernel': dom + (' -- in solves this body runs as the K2F phase of k_slot_b' if (fused and not f1) else ''), 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -411,7 +449,7 @@ def main():
             out['roofline']['replicas'] = f1_D
             if out['roofline']['traffic']:
                 out['roofline']['frac_traffic'] = out['roofline']['traffic'] / (pcg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS      # by the bytes the PMC counters saw
-        if int(stats.get('woodbury_rows', 0)) > 0:
+        if int(stats.get('woodbury_rows', 0)) > 0 and args.jacobi_leg:
             # the figure with the reference's literal preconditioner next to it: the same QP, same settings, plain Jacobi (OSQPHipPolicy::woodbury = 0)
             os.environ['OSQP_HIP_WOODBURY'] = '0'
             try:

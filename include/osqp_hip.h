@@ -195,6 +195,8 @@ typedef struct {
   double woodbury_factorisations, woodbury_factor_ms;   /* last solve: re-factorisations of the Woodbury system at rho updates, and their wall time */
   double reordered;           /* 1: the engine works on a permuted copy of the problem (OSQPHipPolicy::reorder) */
   double reorder_ms;          /* time setup spent looking for the permutation (0: not attempted) */
+  double woodbury_cache_hits; /* last solve: rho updates served by an inverse this handle had computed for the same rho_bar before (validated by the
+                                 numerical probe against the current matrices) -- woodbury_factorisations counts the others; woodbury_factor_ms covers both */
 } OSQPHipStats;
 /* OSQPHipStats::preconditioner.  `cg_precond = OSQP_DIAGONAL_PRECONDITIONER` (bindings.cpp.in:426, the reference's only preconditioner) selects the
    Jacobi family: plain Jacobi M = diag(K), and -- this engine's addition, on by default, OSQPHipPolicy::woodbury / woodbury_large = 0 switch it
@@ -215,7 +217,10 @@ OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
    F1 form (one launch per PCG iteration; each of these times TWO consecutive launches, 0 when the form does not apply to the problem):
    14 = the F-only probe kernel without the scalar fold at the head of the launch, 15 = with it (fixed alpha, beta, no stopping test),
    16 = F launches of the slot kernel itself (phase record, scalars from the fold, a stopping test that never fires, record hand-over):
-   what a launch costs inside a solve.
+   what a launch costs inside a solve; 17 = KA of the F1 form (z~ = A x~, z / y / x update, slices of r_0 and rhs), 18 = the first launch of a chunk
+   (those slices from the vectors in memory).
+   Woodbury direct mode (0 when it is not on): 20 = one ADMM iteration of the two-launch form (k_wbx_y + k_wbx_x; `reps` iterations as one chunk, time per
+   iteration), 21 = the three kernels of M^-1 = K^-1 of the five-launch form (k_wb_p1, k_wb_p2 / k_wb_gemv, k_wb_p3).
    The kernels run in a side-effect-free "probe" mode or on saved-and-restored state; solver state is unchanged. */
 OSQPInt osqp_hip_time_kernel(OSQPSolver *solver, OSQPInt which, OSQPInt reps, double *mean_ms);
 
@@ -338,6 +343,8 @@ typedef struct {
   OSQPInt reorder;            /* 1 (default): when the one-launch PCG form does not apply to the matrices as numbered by the caller, look for a
                                  bandwidth-reducing permutation of variables and constraints under which it does, and work on the permuted problem
                                  (every vector crossing this API keeps the caller's numbering); 0: never; 2: always permute (tests)      [setup] */
+  OSQPInt woodbury_cache;     /* 1 (default): the device-factorised Woodbury form keeps the last four inverses by rho_bar; a rho the handle has seen before is a
+                                 look-up + the numerical probe instead of an r^3 factorisation (OSQPHipStats::woodbury_cache_hits); 0: always factorise   [setup] */
 } OSQPHipPolicy;
 void    osqp_hip_default_policy(OSQPHipPolicy *policy);
 OSQPInt osqp_hip_set_policy(OSQPSolver *solver, const OSQPHipPolicy *policy);

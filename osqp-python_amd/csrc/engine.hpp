@@ -180,7 +180,7 @@ class Engine {
   // Captured launches take Dev BY VALUE: its scalar fields (theta, alpha, sigma, the equality-weight rule k_set_rho reads) are frozen into
   // every graph.  sync_graph_scalars() compares them with what the graphs were captured with and drops the graphs when they differ; called
   // wherever launches may be replayed (admm_core, exec_chunk_sync -- hence polish; ls_solve launches eagerly and replays nothing).
-  double graph_sig_[6] = {0, 0, 0, 0, 0, 0};
+  double graph_sig_[7] = {0, 0, 0, 0, 0, 0, 0};
   void sync_graph_scalars();
   int check_termination(const double *res, bool approximate);
   void update_gap_info(const double *res, double t0);

@@ -312,7 +312,7 @@ void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj
   w.exact = diag ? 1 : 0;
   // (large mode: decided numerically after every factorisation -- two-entry rows whose contributions to K0's off-diagonal cancel, as in
   //  the lasso's  -t <= x <= t , are as good as one-entry rows)
-  if (large) { w.probe = pol_.woodbury_direct != 0; w.exact = 0; w.log = pol_.woodbury_log; w.exact_tol = pol_.woodbury_direct_tol > 0 ? pol_.woodbury_direct_tol : 1e-6; }
+  if (large) { w.probe = pol_.woodbury_direct != 0; w.exact = 0; w.log = pol_.woodbury_log; w.cache_on = pol_.woodbury_cache != 0; w.exact_tol = pol_.woodbury_direct_tol > 0 ? pol_.woodbury_direct_tol : 1e-6; }
   // The direct mode in two launches per ADMM iteration (backend.h DevWbx): additionally every short row has EXACTLY one entry (an empty
   // row would have no column to be updated with) and the problem is small enough for the per-workgroup partials (n <= kWbxMaxN)
   if (w.exact && !large && pol_.woodbury_fused && be::wbx_supported() && n <= kWbxMaxN) {

@@ -1336,10 +1336,16 @@ float time_kernel(Dev &d, int which, int reps) {
   Impl &p = im(d);
   struct Save { double *ptr; size_t cnt; double *bak; };
   const size_t n = d.n, m = d.m;
+  if (which >= 14 && which <= 18 && !d.f1.on) return 0.f;
+  if (which == 20 && !wbx_active(d)) return 0.f;
+  if (which == 21 && !(d.wb.on && d.wb.exact)) return 0.f;
+  const bool wbx = which == 20;
+  const size_t r3 = wbx ? 3 * (size_t)d.wb.r : 0, gp_ = wbx ? (size_t)d.wb.x.G * kWbMaxRows : 0;
   Save sv[] = {{d.x, n, nullptr}, {d.z, m, nullptr}, {d.y, m, nullptr}, {d.xs, n, nullptr}, {d.zt, m, nullptr}, {d.t0, m, nullptr},
                {d.v, m, nullptr}, {d.dx, n, nullptr}, {d.dy, m, nullptr}, {d.r, n, nullptr}, {d.uu, n, nullptr}, {d.p, n, nullptr},
                {d.s, n, nullptr}, {d.w, n, nullptr}, {d.t, m, nullptr}, {d.uu2, n, nullptr}, {d.ms, 2 * n, nullptr},
-               {d.xg, n, nullptr}, {d.xsp, n, nullptr}, {d.ztg, m, nullptr}};
+               {d.xg, n, nullptr}, {d.xsp, n, nullptr}, {d.ztg, m, nullptr},
+               {d.wb.x.ls0, r3, nullptr}, {d.wb.x.ls1, r3, nullptr}, {d.wb.x.partG, gp_, nullptr}, {d.wb.x.partZ, gp_, nullptr}};
   int flags_bak[F_COUNT];
   HIP_CHECK(hipStreamSynchronize(st(d)));
   HIP_CHECK(hipMemcpy(flags_bak, d.flags, sizeof(flags_bak), hipMemcpyDeviceToHost));
@@ -1376,11 +1382,23 @@ float time_kernel(Dev &d, int which, int reps) {
           default: LAUNCH(k_f1_ka_probe<4>, d, d, which == 18); break;
         }
         break;
+      case 21: HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, 0, sizeof(int), st(d))); wb_apply(d, 0, 1); break;      // (the last kernel marks the solve as converged: cleared per repetition)     // Woodbury direct mode, device-factorised form: the three kernels of M^-1 = K^-1 (long rows, S^-1 product, transposed long rows + x~)
       case 15: f1_probe_pair(d, 2); break;   // F1 form: one PCG iteration = one launch; two consecutive iterations as a solve runs them (buffers alternate, fold included)
       default: LAUNCH(k_k2f, d, d, 0); LAUNCH(k_k1f, d, d, 1); break;   // one FUSED PCG iteration (two kernels): repeated exact line-search steps, bounded
     }
   };
-  if (which >= 14 && which <= 18 && !d.f1.on) return 0.f;
+  if (which == 20) {                              // the Woodbury direct mode in two launches: `reps` ADMM iterations as one chunk (X, {Y, X} x (reps - 1), Y, X); ms per ITERATION
+    wbx_chunk(d, 3);
+    HIP_CHECK(hipEventRecord(p.ev0, st(d)));
+    wbx_chunk(d, reps);
+    HIP_CHECK(hipEventRecord(p.ev1, st(d)));
+    HIP_CHECK(hipEventSynchronize(p.ev1));
+    float msx = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&msx, p.ev0, p.ev1));
+    for (auto &sx : sv) { if (!sx.cnt) continue; HIP_CHECK(hipMemcpy(sx.ptr, sx.bak, sx.cnt * sizeof(double), hipMemcpyDeviceToDevice)); HIP_CHECK(hipFree(sx.bak)); }
+    HIP_CHECK(hipMemcpy(d.flags, flags_bak, sizeof(flags_bak), hipMemcpyHostToDevice));
+    return msx / reps;
+  }
   if (which == 16) {
     dev_publish(d);
     if (reps > 400) reps = 400;                 // (k advances by two per repetition; the alpha / gamma history holds kMaxCg entries)

@@ -308,6 +308,47 @@ static void wb_factor_large(Dev &d) {
   auto lap = [&](int k) { if (log) { HIP_CHECK(hipStreamSynchronize(st(d))); tlap[k] = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); } };
   lap(0);
   LAUNCH(k_wb_diag, d, d, 0);
+  double *out = w.pv + (size_t)d.n + d.m + d.n;                 // [4 + r] scratch behind the probe vectors
+  // M^-1 (K v) = v ?   K v = B [v; rho .* (A v)]   -- the numerical test of "M is K" with the CURRENT matrices, rho vector and w.Sinv
+  auto probe = [&]() {
+    LAUNCH(k_wb_probe_init, d, d);
+    LAUNCH(k_test_spmv, d, d.A, w.pv, w.pv + d.n);
+    LAUNCH(k_wb_probe_rho, d, d);
+    LAUNCH(k_test_spmv, d, d.B, w.pv, d.r);
+    HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, 0, sizeof(int), st(d)));
+    wb_apply(d, 0);
+    hipLaunchKernelGGL(k_wb_maxdiff, dim3(1), dim3(kBlock), 0, st(d), d.uu, w.pv + (size_t)d.n + d.m, d.n, out + 2);
+  };
+  // ---- an inverse computed for this rho_bar before?  (backend.h DevWb::cache_buf)  Only with the probe on: it is what validates the entry
+  if (!w.cache_buf[0]) { w.cache_buf[0] = w.Sinv; w.cache_used = 0; w.cache_next = 0; }
+  if (w.probe && w.cache_on) {
+    for (int k = 0; k < w.cache_used; k++) {
+      if (w.cache_rho[k] != w.rho_key) continue;
+      w.Sinv = w.cache_buf[k];
+      probe();
+      double chk[2] = {1, 0};
+      HIP_CHECK(hipMemcpyAsync(chk, out + 2, sizeof(chk), hipMemcpyDeviceToHost, st(d)));
+      HIP_CHECK(hipStreamSynchronize(st(d)));
+      if (chk[0] <= w.exact_tol * chk[1]) {
+        w.exact = 1; w.cache_hits += 1;
+        if (log) std::fprintf(stderr, "osqp_hip woodbury: rho %.6e: cached inverse, |M^-1 K v - v| %.2e / %.2e\n", w.rho_key, chk[0], chk[1]);
+        return;
+      }
+      w.cache_rho[k] = -1.0;                                     // (the matrices or the rho vector have changed under the same rho_bar: the entry is dead)
+      break;
+    }
+  }
+  // the buffer this factorisation writes: a free one, else the oldest
+  { int slot = -1;
+    for (int k = 0; k < w.cache_used; k++) if (w.cache_rho[k] < 0) { slot = k; break; }
+    if (slot < 0 && w.cache_used < (w.cache_on ? DevWb::kCache : 1)) {
+      slot = w.cache_used;
+      if (!w.cache_buf[slot]) { void *b = nullptr; if (hipMalloc(&b, sizeof(double) * (size_t)w.r * w.r) != hipSuccess) { (void)hipGetLastError(); slot = -1; } else w.cache_buf[slot] = static_cast<double *>(b); }
+      if (slot >= 0) w.cache_used += 1;
+    }
+    if (slot < 0) { slot = w.cache_next % std::max(1, w.cache_used); w.cache_next += 1; }
+    w.Sinv = w.cache_buf[slot]; w.cache_rho[slot] = -1.0; w.cache_next = slot + 1;
+  }
   LAUNCH(k_wb_fillW, d, d);
   lap(1);
   const double one = 1.0, zero = 0.0;
@@ -323,21 +364,11 @@ static void wb_factor_large(Dev &d) {
   lap(4);
   hipLaunchKernelGGL(k_wb_symm, dim3(std::min(r, 8 * kGrid)), dim3(kBlock), 0, st(d), w.Sinv, r);
   // S^-1 against S on a fixed vector:  S (S^-1 g) = g
-  double *out = w.pv + (size_t)d.n + d.m + d.n;                 // [4 + r] scratch behind the probe vectors
   hipLaunchKernelGGL(k_wb_seq, dim3(64), dim3(256), 0, st(d), w.g, r);
   hipLaunchKernelGGL(k_wb_gemv, dim3(std::min(r, 8 * kGrid)), dim3(kBlock), 0, st(d), w.Sinv, w.g, w.h, r, nullptr);
   hipLaunchKernelGGL(k_wb_gemv, dim3(std::min(r, 8 * kGrid)), dim3(kBlock), 0, st(d), w.S, w.h, out + 4, r, nullptr);
   hipLaunchKernelGGL(k_wb_maxdiff, dim3(1), dim3(kBlock), 0, st(d), out + 4, w.g, r, out);
-  // M^-1 (K v) = v ?   K v = B [v; rho .* (A v)]
-  if (w.probe) {
-    LAUNCH(k_wb_probe_init, d, d);
-    LAUNCH(k_test_spmv, d, d.A, w.pv, w.pv + d.n);
-    LAUNCH(k_wb_probe_rho, d, d);
-    LAUNCH(k_test_spmv, d, d.B, w.pv, d.r);
-    HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, 0, sizeof(int), st(d)));
-    wb_apply(d, 0);
-    hipLaunchKernelGGL(k_wb_maxdiff, dim3(1), dim3(kBlock), 0, st(d), d.uu, w.pv + (size_t)d.n + d.m, d.n, out + 2);
-  }
+  if (w.probe) probe();
   int info[2] = {0, 0};
   double chk[4] = {0, 1, 0, 1};
   HIP_CHECK(hipMemcpyAsync(info, w.info, sizeof(info), hipMemcpyDeviceToHost, st(d)));
@@ -346,6 +377,7 @@ static void wb_factor_large(Dev &d) {
   if (info[0] != 0 || info[1] != 0) throw DeviceError("osqp_hip: the Woodbury system of the preconditioner is not positive definite");
   const bool inv_ok = chk[0] <= 1e-8 * chk[1];
   w.exact = (w.probe && inv_ok && chk[2] <= w.exact_tol * chk[3]) ? 1 : 0;
+  if (inv_ok) for (int k = 0; k < w.cache_used; k++) if (w.cache_buf[k] == w.Sinv) w.cache_rho[k] = w.rho_key;      // (the entry is valid from here on)
   if (log) {
     lap(5);
     std::fprintf(stderr, "osqp_hip woodbury: r %d ct %d  |S S^-1 g - g| %.2e / %.2e   |M^-1 K v - v| %.2e / %.2e   direct %d;  D0 + W %.1f ms, GEMM %.1f ms, Cholesky %.1f ms, inverse %.1f ms, mirror + checks %.1f ms\n",

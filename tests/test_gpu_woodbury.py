@@ -264,3 +264,31 @@ def test_duplicate_entry_in_a_dense_row_keeps_the_direct_mode_off():
     solver2 = ext.OSQPSolver(ext.CSC(Pt), q, ext.CSC(A), l, u, A.shape[0], A.shape[1], st)
     solver2.solve()
     assert solver2.hip_stats()['woodbury_direct'] >= 1
+
+
+def test_cached_inverses_serve_repeated_solves_and_die_with_the_matrices():
+    """backend.h DevWb::cache_buf: a handle that restarts from the setting's rho and walks the same rho values again finds its inverses by rho_bar
+    (validated by the numerical probe): the second solve factorises nothing and is bit-identical to the first.  After a matrix update the same
+    rho_bar values meet OTHER matrices: the probe rejects every entry, the solve factorises again and matches the oracle on the new data."""
+    import scipy.sparse as sp
+    P, q, A, l, u = problems.lasso_qp(300, 600)
+    st = dict(eps_abs=1e-7, eps_rel=1e-7, verbose=False, max_iter=50000, warm_starting=False)
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, **st)
+    r1 = m.solve(raise_error=True); s1 = m._solver.hip_stats()
+    m.update_settings(rho=0.1)
+    r2 = m.solve(raise_error=True); s2 = m._solver.hip_stats()
+    assert s1['woodbury_direct'] == 1 and s1['woodbury_cache_hits'] == 0
+    assert s1['woodbury_factorisations'] >= 1 and s2['woodbury_factorisations'] == 0 and s2['woodbury_cache_hits'] == s1['woodbury_factorisations']      # (the rho reset itself is a hit too, outside the solve's statistics)
+    assert r1.info.iter == r2.info.iter and np.array_equal(r1.x, r2.x) and np.array_equal(r1.y, r2.y)
+    rng = np.random.default_rng(5)
+    Ax = A.data * (1 + 0.05 * rng.standard_normal(A.nnz))
+    m.update(Ax=Ax); m.update_settings(rho=0.1)
+    r3 = m.solve(raise_error=True); s3 = m._solver.hip_stats()
+    assert s3['woodbury_cache_hits'] == 0 and s3['woodbury_factorisations'] >= 1
+    A2 = sp.csc_matrix((Ax, A.indices, A.indptr), shape=A.shape)
+    xo, yo, io = Oracle().setup(P, q, A2, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000).solve()
+    assert io.status_val == SOLVED and _rel(r3.x, xo) < 5e-5
+    with _env(OSQP_HIP_WOODBURY_CACHE='0'):                                   # the switch: every rho update factorises
+        m2 = osqp_amd.OSQP(); m2.setup(P, q, A, l, u, **st)
+        m2.solve(); m2.update_settings(rho=0.1); r4 = m2.solve(raise_error=True); s4 = m2._solver.hip_stats()
+    assert s4['woodbury_cache_hits'] == 0 and s4['woodbury_factorisations'] >= 1 and np.array_equal(r4.x, r1.x)
