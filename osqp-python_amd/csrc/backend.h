@@ -267,7 +267,15 @@ struct BatchParams {
   const int *kp_row = nullptr;  // per product: constraint row i (-> rho_i)
   const double *kp_val = nullptr;                    // per product: A_ia * A_ib (scaled values; refreshed before every batch call)
   const int *tri = nullptr;     // [ntri] (a | b << 8), 1 <= a <= b <= bw: the trailing-update pairs of one elimination step
+  // Spectral form of the direct solve (engine.hpp BatchSpectral; n <= kBatchSpecN): V [kBatchSpecN x kBatchSpecN, column-major, zero-padded], lambda [kBatchSpecN],
+  // the constraint classes and the equality weight they were built for.  nullptr: not available.  A problem whose own bounds give other classes is
+  // left to the banded kernel: the spectral launch marks its record (kBatchUnsolved in rec[0]), a second launch with only_marked solves the marked ones.
+  const double *sp_V = nullptr, *sp_lam = nullptr; const int *sp_ctype = nullptr;
+  double sp_rho_ref = 0.0, sp_eqf = 0.0;
+  int only_marked = 0;
 };
+constexpr int kBatchSpecN = 128;        // the spectral form keeps K^-1 in registers: row i = thread / 2, 64 columns per thread
+constexpr double kBatchUnsolved = -1000.0;
 
 namespace be {
 

@@ -150,8 +150,14 @@ __device__ __forceinline__ void dd_acc(double a, double v, double &hi, double &l
 // except the (prefetchable) column of L.
 // POLISH (direct variants): a separate instantiation that ends with the polish step, so that the plain kernel's register allocation
 // is not touched by code most launches never run.
-template <int kBB, int EA, int EB, bool DIRECT, bool POLISH = false, bool N128 = false>
-__global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) void k_batch_admm(BatchParams P) {
+// SPEC (256 threads, n <= kBatchSpecN, no polish): the direct solve in its SPECTRAL form (engine.hpp BatchSpectral).  K(rho)^-1 = V diag(1 / (1 + (rho -
+// rho_ref) lambda)) V' with V, lambda shared by the whole batch: the workgroup keeps K^-1 in REGISTERS (thread t: row t / 2, the 64 columns of half t % 2),
+// rebuilds it from V at a rho update (V streamed through LDS in chunks of columns; ~20 us, no factorisation) and solves with one dense product
+// (64 FMAs per thread against broadcast LDS reads + one lane exchange): the 240-pivot substitution chain of the banded form (9 of an iteration's 14 us)
+// becomes ~0.5 us, and no band lives in LDS.
+template <int kBB, int EA, int EB, bool DIRECT, bool POLISH = false, bool N128 = false, bool SPEC = false>
+__global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8 && !SPEC) ? 2 : 1) void k_batch_admm(BatchParams P) {
+  static_assert(!SPEC || (DIRECT && !POLISH && kBB == 256), "the spectral form: 256 threads, direct, no polish");
 #ifdef OSQP_HIP_KTRACE
   // diagnostic build: 100 MHz clock ticks spent in the phases; reported in rec[5..7] INSTEAD of rho / rho_updates / pcg_iters
   unsigned long long tk_all = wall_clock64(), tk_fact = 0, tk_solve = 0, tk0 = 0, tk1 = 0, tk_rhs = 0, tk_upd = 0, tk_fwd = 0, tk_res = 0;
@@ -169,6 +175,7 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
   const int n = P.n, m = P.m, tid = threadIdx.x;
   if ((int)blockIdx.x >= P.nbatch) return;
   const int b = P.order ? P.order[blockIdx.x] : (int)blockIdx.x;      // (workgroups are dispatched in index order: expected-longest problems first)
+  if (!SPEC && P.only_marked && P.rec[(size_t)b * kBatchRec] != kBatchUnsolved) return;      // (second launch behind the spectral one: only what that one left)
   // ---- LDS carve ----
   double *x = sm, *xs = x + n, *r = xs + n, *zv = r + n, *p = zv + n, *Kp = p + n, *q = Kp + n, *Minv = q + n, *dx = Minv + n, *tn = dx + n;
   double *z = tn + n, *y = z + m, *t = y + m, *l = t + m, *u = l + m, *rho = u + m, *zt = rho + m, *dy = zt + m;
@@ -250,6 +257,47 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
   const double n_ineq = red.sum((double)n_ineq_local);
   const double eqf = (n_ineq == 0.0) ? 1e3 : (DIRECT ? P.eq_factor_direct : P.eq_factor);  // engine.cpp classify_constraints()
   double rho_bar = P.rho0;
+  // SPEC: K^-1 of this problem, and the LDS the form needs (in the band's place): the zero-padded right-hand side, 1 / (1 + delta lambda)
+  [[maybe_unused]] double kin[SPEC ? 64 : 1];
+  [[maybe_unused]] double *sp_rhs = Lb, *sp_dk = Lb + kBatchSpecN + 2;
+  if constexpr (SPEC) {
+    // V was built for ONE set of constraint classes: a problem whose own bounds give other classes (or another equality weight) is not ours
+    double mism = (eqf != P.sp_eqf) ? 1.0 : 0.0;
+    for (int i = tid; i < m; i += kBB) {
+      const double li = l[i], ui = u[i];
+      int ty = (li < -OSQP_INFTY * 1e-4 && ui > OSQP_INFTY * 1e-4) ? -1 : ((ui - li < 1e-4) ? 1 : 0);
+      if (!P.rho_is_vec) ty = 0;
+      if (ty != P.sp_ctype[i]) mism = 1.0;
+    }
+    mism = red.sum(mism);
+    if (mism != 0.0) { if (tid == 0) P.rec[(size_t)b * kBatchRec] = kBatchUnsolved; return; }
+  }
+  // SPEC: K^-1 <- V diag(dk) V',  dk = 1 / (1 + (rb - rho_ref) lambda): V (column-major, kBatchSpecN rows per column) streamed through `prod` in chunks
+  [[maybe_unused]] auto update_kinv = [&](double rb) {
+    if constexpr (SPEC) {
+      const double dl = rb - P.sp_rho_ref;
+      if (tid < kBatchSpecN) sp_dk[tid] = 1.0 / (1.0 + dl * P.sp_lam[tid]);
+#pragma unroll
+      for (int c = 0; c < 64; c++) kin[c] = 0.0;
+      const int row = tid >> 1, half = tid & 1;
+      constexpr int kCol = kBatchSpecN + 2;                     // a staged column: rows 0..63, one double of padding, rows 64..127 (the two halves in different banks)
+      const int CH = prod_len / kCol;                           // columns of V per chunk (batch_solve requires >= 3)
+      for (int k0 = 0; k0 < n; k0 += CH) {
+        const int nk = min(CH, n - k0);
+        __syncthreads();
+        for (int e = tid; e < nk * kBatchSpecN; e += kBB) { const int kk = e / kBatchSpecN, r_ = e % kBatchSpecN; prod[kk * kCol + r_ + (r_ >= 64)] = P.sp_V[(size_t)k0 * kBatchSpecN + e]; }
+        __syncthreads();
+        for (int kk = 0; kk < nk; kk++) {
+          const double *vc = prod + kk * kCol;
+          const double a = vc[row + (row >= 64)] * sp_dk[k0 + kk];
+          const double *vh = vc + half * 65;                    // (8-byte broadcast reads: see ksolve)
+#pragma unroll
+          for (int c = 0; c < 64; c++) kin[c] = fma(a, vh[c], kin[c]);
+        }
+      }
+      __syncthreads();
+    }
+  };
   // DIRECT: assemble  K = (P + sigma I) + shift I + A' diag(rho) A  in the band and factorise it (shift = 0 for the ADMM system;
   // the polish step factorises P + delta I + A_act' (1/delta) A_act with shift = delta - sigma and rho = the active-row weights)
   [[maybe_unused]] auto factorize = [&](double shift) {
@@ -299,7 +347,8 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
       rho[i] = ty == -1 ? 1e-6 : (ty == 1 ? eqf * rb : rb);                                       // _osqp.py:520-522
     }
     __syncthreads();
-    if constexpr (DIRECT) factorize(0.0);
+    if constexpr (SPEC) update_kinv(rb);
+    else if constexpr (DIRECT) factorize(0.0);
     else {
       for (int j = tid; j < n; j += kBB) {                   // Jacobi preconditioner = 1/diag(K)
         double sacc = 0.0, dg = 0.0;
@@ -321,6 +370,27 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? 2 : 1) voi
   // broadcasts instead of a chain of 8) was tried and is slower, 12.6 vs 9.0 us per solve -- twice the broadcasts, and they do
   // not pipeline.
   auto ksolve = [&](const double *rhs, double *out) {
+    if constexpr (SPEC) {
+      // out = K^-1 rhs: thread (row, half) sums its 64 columns (the right-hand side is read as broadcasts: every thread of a half reads the same address),
+      // the two halves of a row meet through one lane exchange; fixed order, no atomics
+      if (tid < kBatchSpecN) sp_rhs[tid + (tid >= 64)] = tid < n ? rhs[tid] : 0.0;
+      __syncthreads();
+      BT2_BEGIN();
+      const int row = tid >> 1, half = tid & 1;
+      const double *rr = sp_rhs + half * 65;
+      // (8-byte reads: every thread of a half reads the SAME address, which the LDS serves as a broadcast -- a 16-byte read of one address by
+      //  all lanes is NOT broadcast: measured 250 cycles per ds_read_b128, 3.4 us per product; the second half sits 65 doubles on, in other banks)
+      double ac[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int c = 0; c < 64; c++) ac[c & 3] = fma(kin[c], rr[c], ac[c & 3]);
+      const double a0 = ac[0] + ac[2], a1 = ac[1] + ac[3];
+      double acc = a0 + a1;
+      acc += bdpp<0xb1>(acc);                                   // lane ^ 1: the other half of the row
+      if (half == 0 && row < n) out[row] = acc;
+      BT2_END(tk_fwd);
+      __syncthreads();
+      return;
+    }
     const double *__restrict__ Lr = Lb;
     double *__restrict__ buf = wbuf;
     constexpr int NB = kBatchNB;
@@ -825,6 +895,23 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
 #define BATCH_LAUNCH_DIRECT_N(TB, E, SMALL) do { if (p.polish) BATCH_LAUNCH_DIRECT_P(TB, E, true, SMALL); else BATCH_LAUNCH_DIRECT_P(TB, E, false, SMALL); } while (0)
   // (256-thread kernels: n <= 128 takes the instantiation whose substitutions keep every element in registers, ksolve)
 #define BATCH_LAUNCH_DIRECT(TB, E) do { if (TB == 256 && p.n <= 128) BATCH_LAUNCH_DIRECT_N(TB, E, (TB == 256)); else BATCH_LAUNCH_DIRECT_N(TB, E, false); } while (0)
+  // The spectral form of the direct solve where the engine has prepared it (BatchParams::sp_V): every problem whose constraint classes are the
+  // reference's is solved by this launch; the others are marked and left to the banded kernel launched right behind (only_marked).
+  bool spectral = false;
+  const int prod_len = ((p.A.nnz > p.B.nnz ? p.A.nnz : p.B.nnz) + 1) & ~1;
+  if (use_dir256 && p.sp_V && !p.polish && p.n <= kBatchSpecN && e256 <= 8 && prod_len >= 4 * (kBatchSpecN + 2) && !p.only_marked) {
+    const size_t lds_spec = lds_reg + sizeof(double) * (kBatchNB + 2 * kBatchSpecN + 4);
+#define BATCH_LAUNCH_SPEC(E) do { \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<256, E, E, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec) != hipSuccess) \
+      throw DeviceError("osqp_hip: cannot reserve LDS for the spectral batch kernel"); \
+    hipLaunchKernelGGL((k_batch_admm<256, E, E, true, false, false, true>), dim3(p.nbatch), dim3(256), lds_spec, st, p); } while (0)
+    if (e256 <= 2) BATCH_LAUNCH_SPEC(2); else if (e256 <= 4) BATCH_LAUNCH_SPEC(4); else if (e256 <= 6) BATCH_LAUNCH_SPEC(6); else BATCH_LAUNCH_SPEC(8);
+#undef BATCH_LAUNCH_SPEC
+    spectral = true;
+  }
+  BatchParams pm = p;
+  if (spectral) pm.only_marked = 1;
+#define p pm
   if (use_dir256) {
     if (e256 <= 2) BATCH_LAUNCH_DIRECT(256, 2); else if (e256 <= 4) BATCH_LAUNCH_DIRECT(256, 4); else if (e256 <= 6) BATCH_LAUNCH_DIRECT(256, 6); else if (e256 <= 8) BATCH_LAUNCH_DIRECT(256, 8); else BATCH_LAUNCH_DIRECT(256, 16);
   } else if (use_dir) {
@@ -838,6 +925,7 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
   } else {
     return OSQP_FUNC_NOT_IMPLEMENTED;
   }
+#undef p
 #undef BATCH_LAUNCH
 #undef BATCH_LAUNCH_DIRECT
 #undef BATCH_LAUNCH_DIRECT_P

@@ -148,7 +148,7 @@ void Engine::free_all() {
   if (d_batch_iters_) { be::dfree(d_, d_batch_iters_); d_batch_iters_ = nullptr; d_batch_iters_n_ = 0; }
   batch_order_.clear();
   if (ckpt_) { be::dfree(d_, ckpt_); ckpt_ = nullptr; }
-  free_batch_direct();
+  free_batch_direct(); free_batch_spectral();
   if (d_.f1.va) d_.Minv = d_.xs = d_.p = d_.r = d_.s = nullptr;      // (these point into the F1 arena, freed as one block below)
   if (d_.wb.cache_buf[0]) d_.wb.Sinv = d_.wb.cache_buf[0];      // (Sinv may point at one of the cached inverses: buffer 0 is this list's, the others are the backend's)
   void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag, d_.A.runinfo, d_.B.runinfo, d_.A.blkwin, d_.B.blkwin, d_.A.lcol, d_.B.lcol, d_.qraw, d_.lraw, d_.uraw, d_.cnt,

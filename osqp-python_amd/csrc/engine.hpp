@@ -118,6 +118,20 @@ class Engine {
     double *kp_val = nullptr;
   } bd_;
   void prepare_batch_direct();
+  // Spectral form of the batch path's direct solve (batch_hip.hip, SPEC): every problem of a batch shares P, A and the constraint classes, and
+  // rho enters K only through ONE scalar -- K(rho) = K_ref + (rho - rho_ref) M1, M1 = A' W A (W: 1 on inequality rows, the equality weight on
+  // equality rows).  With K_ref = L L', L^-1 M1 L^-T = Q Lambda Q' and V = L^-T Q:  K(rho)^-1 = V diag(1 / (1 + (rho - rho_ref) lambda)) V'.
+  // V and lambda are computed ONCE on the host (dense n <= 128: Cholesky + Jacobi eigenvalue sweeps) and shared by every problem; a workgroup
+  // keeps K(rho)^-1 in registers, rebuilds it from V at a rho update (no factorisation) and solves with one dense matrix-vector product.
+  struct BatchSpectral {
+    bool ok = false; int mat_epoch = -1;
+    double rho_ref = 0, eqf = 0, sigma = 0; int rho_is_vec = -1;
+    std::vector<int> ctype;          // the constraint classes V was built for (a problem of a batch whose own bounds give other classes takes the banded kernel)
+    double *V = nullptr, *lam = nullptr; int *d_ctype = nullptr;
+  } bs_;
+  int mat_epoch_ = 0;                // bumped by every change of P / A values
+  void prepare_batch_spectral(double rho_ref, double eqf);
+  void free_batch_spectral();
   void prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj);
   struct F1Plan {                       // host image of backend.h DevF1 (plan_f1 builds it without touching the device; upload_f1 commits it)
     bool ok = false; int D = 0, pnnz = 0;

@@ -142,6 +142,7 @@ int Engine::update_data_mat(const double *Px, const int *Px_idx, int P_n, const 
     else if (A_n != nzA && A_n != 0) return OSQP_DATA_VALIDATION_ERROR;
   }
   // (reordered problem: the caller's positions in its own CSC arrays -> where those entries live in the permuted ones)
+  mat_epoch_ += 1;
   if (Px) for (int k = 0; k < (Px_idx ? P_n : nzP); k++) { const int c = Px_idx ? Px_idx[k] : k; P_.x[reordered_ ? PvalMap_[c] : c] = Px[k]; }
   if (Ax) for (int k = 0; k < (Ax_idx ? A_n : nzA); k++) { const int c = Ax_idx ? Ax_idx[k] : k; A_.x[reordered_ ? AvalMap_[c] : c] = Ax[k]; }
   if (be::device_assembly()) {                                                           // _osqp.py:1443,:1463 on the device
@@ -289,6 +290,119 @@ void Engine::free_batch_direct() {
   bd_ = BatchDirect();
 }
 
+// ------------------------------------------------------------------------------------------------ batch path, spectral form of the direct solve
+// engine.hpp BatchSpectral.  Dense work on the host, n <= kBatchSpecN: the SCALED matrices (c D P D + sigma I, E A D: what the kernels hold) are
+// rebuilt from the host copies, K_ref and M1 assembled, K_ref = L L' (Cholesky), C = L^-1 M1 L^-T, C = Q Lambda Q' (cyclic Jacobi sweeps: C is
+// symmetric PSD with eigenvalues in [0, 1 / rho_ref]), V = L^-T Q.  Checked before use: || V' K_ref V - I ||_max and || V' M1 V - Lambda ||_max.
+void Engine::free_batch_spectral() {
+  void *ptrs[] = {bs_.V, bs_.lam, bs_.d_ctype};
+  for (void *p : ptrs) if (p) be::dfree(d_, p);
+  bs_ = BatchSpectral();
+}
+void Engine::prepare_batch_spectral(double rho_ref, double eqf) {
+  const int N = kBatchSpecN;
+  if (n > N || m == 0 || !be::device_assembly() || reordered_) { bs_.ok = false; return; }
+  // the reference classes: those of the solver's own bounds, classified as the kernel classifies a problem's (batch_hip.hip, _osqp.py:505-518)
+  std::vector<int> ct(m);
+  for (int i = 0; i < m; i++) {
+    const double li = E_[i] * std::max(l0_[i], -OSQP_INFTY), ui = E_[i] * std::min(u0_[i], OSQP_INFTY);
+    int ty = (li < -OSQP_INFTY * 1e-4 && ui > OSQP_INFTY * 1e-4) ? -1 : ((ui - li < 1e-4) ? 1 : 0);
+    if (!settings.rho_is_vec) ty = 0;
+    ct[i] = ty;
+  }
+  if (bs_.ok && bs_.mat_epoch == mat_epoch_ && bs_.eqf == eqf && bs_.sigma == settings.sigma && bs_.rho_is_vec == settings.rho_is_vec && bs_.ctype == ct) return;
+  const double rref = bs_.ok ? bs_.rho_ref : rho_ref;       // (any reference works: K(rho) = K_ref + (rho - rho_ref) M1; the first call's rho stays)
+  free_batch_spectral();
+  std::vector<double> K((size_t)n * n, 0.0), M1((size_t)n * n, 0.0);
+  for (int j = 0; j < n; j++) {
+    for (int k = P_.p[j]; k < P_.p[j + 1]; k++) {
+      const int i = P_.i[k];
+      const double v = c_ * D_[i] * P_.x[k] * D_[j];
+      K[(size_t)i * n + j] += v; if (i != j) K[(size_t)j * n + i] += v;
+    }
+    K[(size_t)j * n + j] += settings.sigma;
+  }
+  { // A' W A by rows of A (CSC -> per-row lists)
+    std::vector<std::vector<std::pair<int, double>>> rows(m);
+    for (int j = 0; j < n; j++) for (int k = A_.p[j]; k < A_.p[j + 1]; k++) rows[A_.i[k]].push_back({j, E_[A_.i[k]] * A_.x[k] * D_[j]});
+    for (int i = 0; i < m; i++) {
+      const int ty = ct[i];
+      for (auto &a : rows[i]) for (auto &b : rows[i]) {
+        const double v = a.second * b.second;
+        if (ty == -1) K[(size_t)a.first * n + b.first] += 1e-6 * v;                 // loose rows keep rho_i = 1e-6 whatever rho_bar is (_osqp.py:520)
+        else M1[(size_t)a.first * n + b.first] += (ty == 1 ? eqf : 1.0) * v;
+      }
+    }
+  }
+  std::vector<double> Kref(K);
+  for (size_t e = 0; e < Kref.size(); e++) Kref[e] += rref * M1[e];
+  // Cholesky Kref = L L' (lower, in place in Lm)
+  std::vector<double> Lm(Kref);
+  for (int c = 0; c < n; c++) {
+    double dg = Lm[(size_t)c * n + c];
+    for (int k = 0; k < c; k++) dg -= Lm[(size_t)c * n + k] * Lm[(size_t)c * n + k];
+    if (!(dg > 0.0)) { bs_.ok = false; return; }
+    dg = std::sqrt(dg); Lm[(size_t)c * n + c] = dg;
+    for (int r = c + 1; r < n; r++) {
+      double v = Lm[(size_t)r * n + c];
+      for (int k = 0; k < c; k++) v -= Lm[(size_t)r * n + k] * Lm[(size_t)c * n + k];
+      Lm[(size_t)r * n + c] = v / dg;
+    }
+  }
+  auto fwd = [&](std::vector<double> &X) {                    // X <- L^-1 X  (X: n x n row-major, column by column)
+    for (int col = 0; col < n; col++) for (int r = 0; r < n; r++) {
+      double v = X[(size_t)r * n + col];
+      for (int k = 0; k < r; k++) v -= Lm[(size_t)r * n + k] * X[(size_t)k * n + col];
+      X[(size_t)r * n + col] = v / Lm[(size_t)r * n + r];
+    }
+  };
+  auto transpose = [&](std::vector<double> &X) { for (int a = 0; a < n; a++) for (int b = a + 1; b < n; b++) std::swap(X[(size_t)a * n + b], X[(size_t)b * n + a]); };
+  std::vector<double> C(M1);
+  fwd(C); transpose(C); fwd(C);                              // L^-1 M1 L^-T  (symmetric)
+  for (int a = 0; a < n; a++) for (int b = a + 1; b < n; b++) { const double v = 0.5 * (C[(size_t)a * n + b] + C[(size_t)b * n + a]); C[(size_t)a * n + b] = C[(size_t)b * n + a] = v; }
+  // cyclic Jacobi: C = Q diag(lam) Q'
+  std::vector<double> Q((size_t)n * n, 0.0);
+  for (int a = 0; a < n; a++) Q[(size_t)a * n + a] = 1.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0.0, dsum = 0.0;
+    for (int a = 0; a < n; a++) { dsum += C[(size_t)a * n + a] * C[(size_t)a * n + a]; for (int b = a + 1; b < n; b++) off += C[(size_t)a * n + b] * C[(size_t)a * n + b]; }
+    if (off <= 1e-32 * (dsum + 1e-300)) break;
+    for (int p_ = 0; p_ < n - 1; p_++) for (int q_ = p_ + 1; q_ < n; q_++) {
+      const double apq = C[(size_t)p_ * n + q_];
+      if (apq == 0.0) continue;
+      const double theta = (C[(size_t)q_ * n + q_] - C[(size_t)p_ * n + p_]) / (2.0 * apq);
+      const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0)), cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+      for (int k = 0; k < n; k++) { const double ckp = C[(size_t)k * n + p_], ckq = C[(size_t)k * n + q_]; C[(size_t)k * n + p_] = cs * ckp - sn * ckq; C[(size_t)k * n + q_] = sn * ckp + cs * ckq; }
+      for (int k = 0; k < n; k++) { const double cpk = C[(size_t)p_ * n + k], cqk = C[(size_t)q_ * n + k]; C[(size_t)p_ * n + k] = cs * cpk - sn * cqk; C[(size_t)q_ * n + k] = sn * cpk + cs * cqk; }
+      for (int k = 0; k < n; k++) { const double qkp = Q[(size_t)k * n + p_], qkq = Q[(size_t)k * n + q_]; Q[(size_t)k * n + p_] = cs * qkp - sn * qkq; Q[(size_t)k * n + q_] = sn * qkp + cs * qkq; }
+    }
+  }
+  // V = L^-T Q  (back substitution per column)
+  std::vector<double> V(Q);
+  for (int col = 0; col < n; col++) for (int r = n - 1; r >= 0; r--) {
+    double v = V[(size_t)r * n + col];
+    for (int k = r + 1; k < n; k++) v -= Lm[(size_t)k * n + r] * V[(size_t)k * n + col];
+    V[(size_t)r * n + col] = v / Lm[(size_t)r * n + r];
+  }
+  std::vector<double> lam(n);
+  for (int k = 0; k < n; k++) lam[k] = std::max(C[(size_t)k * n + k], 0.0);
+  // check: V' Kref V = I, V' M1 V = Lambda
+  auto vtxv = [&](const std::vector<double> &X, int a, int b) { double s_ = 0; for (int i = 0; i < n; i++) { double t = 0; for (int j = 0; j < n; j++) t += X[(size_t)i * n + j] * V[(size_t)j * n + b]; s_ += V[(size_t)i * n + a] * t; } return s_; };
+  double err = 0.0;
+  for (int a = 0; a < n; a += std::max(1, n / 16)) for (int b = 0; b < n; b += std::max(1, n / 16)) {
+    err = std::max(err, std::fabs(vtxv(Kref, a, b) - (a == b ? 1.0 : 0.0)));
+    err = std::max(err, std::fabs(vtxv(M1, a, b) - (a == b ? lam[a] : 0.0)) / (1.0 + lam[a]));
+  }
+  if (!(err < 1e-9)) { bs_.ok = false; return; }
+  std::vector<double> Vp((size_t)N * N, 0.0), lp(N, 0.0);
+  for (int k = 0; k < n; k++) { lp[k] = lam[k]; for (int j = 0; j < n; j++) Vp[(size_t)k * N + j] = V[(size_t)j * n + k]; }      // column-major, zero-padded
+  bs_.V = dev_vec<double>(d_, Vp.size()); be::h2d(d_, bs_.V, Vp.data(), sizeof(double) * Vp.size());
+  bs_.lam = dev_vec<double>(d_, N); be::h2d(d_, bs_.lam, lp.data(), sizeof(double) * N);
+  bs_.d_ctype = dev_vec<int>(d_, m); be::h2d(d_, bs_.d_ctype, ct.data(), sizeof(int) * m);
+  bs_.ctype = ct; bs_.rho_ref = rref; bs_.eqf = eqf; bs_.sigma = settings.sigma; bs_.rho_is_vec = settings.rho_is_vec; bs_.mat_epoch = mat_epoch_;
+  bs_.ok = true;
+}
+
 void Engine::prepare_batch_direct() {
   if (bd_.tried) return;
   bd_.tried = true;
@@ -400,6 +514,18 @@ void Engine::fill_batch_params(BatchParams &p, int nbatch, int warm) {
 void Engine::attach_batch_direct(BatchParams &p) {
   if (!bd_.ok) return;
   p.eq_factor_direct = eq_factor_set_ ? eq_factor_mixed_ : 1e3;
+  // the spectral form of the same solve, where it applies (never with polish: that factorises another matrix in the band)
+  if (pol_.batch_variant == 0 && !settings.polishing && n <= kBatchSpecN) {
+    if (raw_stale_) ensure_host_vectors();             // (the solver's own bounds define the reference classes)
+    int n_ineq = 0;
+    for (int i = 0; i < m && settings.rho_is_vec; i++) {
+      const double li = E_[i] * std::max(l0_[i], -OSQP_INFTY), ui = E_[i] * std::min(u0_[i], OSQP_INFTY);
+      n_ineq += !((li < -OSQP_INFTY * 1e-4 && ui > OSQP_INFTY * 1e-4) || (ui - li < 1e-4));
+    }
+    if (!settings.rho_is_vec) n_ineq = m;
+    prepare_batch_spectral(p.rho0, n_ineq == 0 ? 1e3 : p.eq_factor_direct);
+    if (bs_.ok) { p.sp_V = bs_.V; p.sp_lam = bs_.lam; p.sp_ctype = bs_.d_ctype; p.sp_rho_ref = bs_.rho_ref; p.sp_eqf = bs_.eqf; }
+  }
   p.bw = bd_.bw; p.nents = bd_.nents; p.ntri = bd_.ntri; p.perm = bd_.perm; p.bp_slot = bd_.bp_slot; p.ke_slot = bd_.ke_slot;
   p.ke_ptr = bd_.ke_ptr; p.kp_row = bd_.kp_row; p.kp_val = bd_.kp_val; p.tri = bd_.tri;
 }
