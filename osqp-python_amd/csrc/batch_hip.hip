@@ -155,8 +155,12 @@ __device__ __forceinline__ void dd_acc(double a, double v, double &hi, double &l
 // rebuilds it from V at a rho update (V streamed through LDS in chunks of columns; ~20 us, no factorisation) and solves with one dense product
 // (64 FMAs per thread against broadcast LDS reads + one lane exchange): the 240-pivot substitution chain of the banded form (9 of an iteration's 14 us)
 // becomes ~0.5 us, and no band lives in LDS.
-template <int kBB, int EA, int EB, bool DIRECT, bool POLISH = false, bool N128 = false, bool SPEC = false>
-__global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8 && !SPEC) ? 2 : 1) void k_batch_admm(BatchParams P) {
+// SPW: workgroups per CU the spectral instantiation is compiled for.  1: K^-1 and everything else in registers (370 of the 512 a lone workgroup may
+// use) -- 5.0 us per ADMM iteration, the form for batches that fit the chip in two rounds (latency: 256 QPs 1.0 ms, 512 QPs 1.5 ms).  2: the 256
+// registers of two resident workgroups, ~150 of the kernel's values in scratch -- 8 us per iteration, but twice the problems in flight: 4096 QPs
+// 8.4 ms against 10.1 (and 10.6 for the banded form).  batch_solve picks by batch size.
+template <int kBB, int EA, int EB, bool DIRECT, bool POLISH = false, bool N128 = false, bool SPEC = false, int SPW = 1>
+__global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? (SPEC ? SPW : 2) : 1) void k_batch_admm(BatchParams P) {
   static_assert(!SPEC || (DIRECT && !POLISH && kBB == 256), "the spectral form: 256 threads, direct, no polish");
 #ifdef OSQP_HIP_KTRACE
   // diagnostic build: 100 MHz clock ticks spent in the phases; reported in rec[5..7] INSTEAD of rho / rho_updates / pcg_iters
@@ -901,12 +905,18 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
   const int prod_len = ((p.A.nnz > p.B.nnz ? p.A.nnz : p.B.nnz) + 1) & ~1;
   if (use_dir256 && p.sp_V && !p.polish && p.n <= kBatchSpecN && e256 <= 8 && prod_len >= 4 * (kBatchSpecN + 2) && !p.only_marked) {
     const size_t lds_spec = lds_reg + sizeof(double) * (kBatchNB + 2 * kBatchSpecN + 4);
-#define BATCH_LAUNCH_SPEC(E) do { \
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<256, E, E, true, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec) != hipSuccess) \
+#define BATCH_LAUNCH_SPEC_W(E, W) do { \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<256, E, E, true, false, false, true, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec) != hipSuccess) \
       throw DeviceError("osqp_hip: cannot reserve LDS for the spectral batch kernel"); \
-    hipLaunchKernelGGL((k_batch_admm<256, E, E, true, false, false, true>), dim3(p.nbatch), dim3(256), lds_spec, st, p); } while (0)
+    hipLaunchKernelGGL((k_batch_admm<256, E, E, true, false, false, true, W>), dim3(p.nbatch), dim3(256), lds_spec, st, p); } while (0)
+    // latency form up to three rounds of one workgroup per CU, throughput form (two per CU) beyond
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d.device);
+    const bool wide = p.nbatch > 3 * cus;
+#define BATCH_LAUNCH_SPEC(E) do { if (wide) BATCH_LAUNCH_SPEC_W(E, 2); else BATCH_LAUNCH_SPEC_W(E, 1); } while (0)
     if (e256 <= 2) BATCH_LAUNCH_SPEC(2); else if (e256 <= 4) BATCH_LAUNCH_SPEC(4); else if (e256 <= 6) BATCH_LAUNCH_SPEC(6); else BATCH_LAUNCH_SPEC(8);
 #undef BATCH_LAUNCH_SPEC
+#undef BATCH_LAUNCH_SPEC_W
     spectral = true;
   }
   BatchParams pm = p;
