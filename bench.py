@@ -128,6 +128,26 @@ def _cpu_baseline(P, q, A, l, u, settings, seconds_target, linsys):
     return out
 
 
+def upstream_osqp_line(P, q, A, l, u, settings):
+    """when the real `osqp` package (the reference's compiled C core) is importable on the timing host, time it on the same QP and label
+    it "upstream osqp x.y.z"; it is not part of this repo and not expected on the GPU box (no network): then the line says so."""
+    try:
+        import importlib
+        osqp = importlib.import_module('osqp')
+        if 'osqp_amd' in (getattr(osqp, '__file__', '') or ''):
+            raise ImportError('only this repo\'s own package answers to the name')
+    except Exception as e:                       # noqa: BLE001
+        return {'available': False, 'note': 'import osqp failed on this host (%s): the reference\'s C core is not installed; cpu_baseline is the oracle (kind = "port")' % type(e).__name__}
+    try:
+        import scipy.sparse as sp
+        m = osqp.OSQP()
+        m.setup(sp.triu(P).tocsc(), q, A, l, u, eps_abs=settings['eps_abs'], eps_rel=settings['eps_rel'], max_iter=settings['max_iter'], verbose=False)
+        t0 = time.perf_counter(); r = m.solve(); dt = time.perf_counter() - t0
+        return {'available': True, 'label': 'upstream osqp %s' % getattr(osqp, '__version__', '?'), 'status': r.info.status, 'iter': int(r.info.iter), 'solve_s': dt, 'it_per_s': r.info.iter / dt}
+    except Exception as e:                       # noqa: BLE001
+        return {'available': True, 'error': repr(e)}
+
+
 def measure_roofline(s, stats, n, mm, args):
     """Live timing of the hot-path kernels on the solver's own data (hipEvent pairs on the solver's stream, osqp_hip_time_kernel) against their
     algorithmic bytes.  Returns (probes, kb, pcg_bytes, pcg_ms, dom, dom_kernel, survey_pcg_bytes, streamed, f1, fused, f1_D)."""
@@ -263,7 +283,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--n', '--vars', dest='n', type=int, default=100000, help='variables (m = 2n, nnz(A) = 10n, nnz(P) = 2n); --vars: the spelling torch.distributed.run passes through')
     ap.add_argument('--carry-rho', action='store_true', help='keep the rho a solve ended with for the next step (the solver object\'s natural behaviour) instead of restarting every step from the setting')
-    ap.add_argument('--config', default='banded', choices=['banded', 'shuffled', 'unstructured', 'lasso', 'portfolio'],
+    ap.add_argument('--config', default='banded', choices=['banded', 'shuffled', 'unstructured', 'mixed', 'lasso', 'portfolio'],
                     help="banded = BASELINE configs[1] (the headline); shuffled = the same QP with its variables and constraints randomly renumbered (the band is "
                          "there but hidden: the engine has to find it, OSQPHipPolicy::reorder); unstructured = the same sizes with columns drawn from the whole row (GB/s only, "
                          "SURVEY 8d); lasso = configs[2] (5k features x 10k samples, dense data block); portfolio = configs[3] (10k assets, 100 factors)")
@@ -326,6 +346,9 @@ def main():
     elif args.config == 'unstructured':
         P, q, A, l, u = problems.banded_qp(n, window=n, seed=12345); wl_tag = 'unstructured_n%d' % n
         wl_name = 'configs[1] sizes with UNSTRUCTURED columns (SURVEY 8d: GB/s only): single QP n=%d m=%d nnz(A)=%d nnz(P)=%d (problems.banded_qp, window = n)'
+    elif args.config == 'mixed':
+        P, q, A, l, u = problems.banded_qp(n, seed=12345, long_range=0.02); wl_tag = 'mixed_n%d' % n
+        wl_name = 'configs[1] with 2 %% of the entries of A moved to columns drawn from the whole range (band + long-range couplings): single QP n=%d m=%d nnz(A)=%d nnz(P)=%d (problems.banded_qp, long_range = 0.02)'
     elif args.config == 'lasso':
         P, q, A, l, u = problems.lasso_qp(5000, 10000); wl_tag = 'lasso_5k_10k'
         wl_name = 'BASELINE configs[2]: lasso-as-QP, 5k features x 10k samples, dense data block: n=%d m=%d nnz(A)=%d nnz(P)=%d (problems.lasso_qp, seed 1)'
@@ -407,7 +430,7 @@ def main():
             probes, kb, pcg_bytes, pcg_ms, dom, dom_kernel, survey_pcg_bytes, streamed, f1, fused, f1_D = measure_roofline(s, stats, n, mm, args)
         tts_ms = 1e3 * tmax / args.steps
         out = {
-            'metric': 'ADMM iterations/sec, n=%d m=%d nnz(A)=%d %s (indirect PCG)' % (n, mm, A.nnz, 'sparse QP' if args.config in ('banded', 'shuffled', 'unstructured') else args.config + ' QP'),
+            'metric': 'ADMM iterations/sec, n=%d m=%d nnz(A)=%d %s (indirect PCG)' % (n, mm, A.nnz, 'sparse QP' if args.config in ('banded', 'shuffled', 'unstructured', 'mixed') else args.config + ' QP'),
             'value': total_iters / tmax, 'unit': 'ADMM iter/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * tmax / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic' if not hostsim else 'synthetic -- HOST SIMULATOR (OSQP_BENCH_HOSTSIM test mode): launch logic only, NOT a measurement',
@@ -517,6 +540,7 @@ def main():
             del mu
         if args.cpu_seconds > 0 and world == 1:          # (the CPU baseline is timed at N = 1 only: the other ranks would wait 40 s at the barrier)
             cb = cpu_baseline(P, q, A, l, u, settings, args.cpu_seconds)
+            cb['upstream_osqp'] = upstream_osqp_line(P, q, A, l, u, settings)      # "if `import osqp` happens to succeed on the box ..."; never required
             out['cpu_baseline'] = cb
             if cb.get('value'):
                 out['config']['gpu_over_cpu_iter_rate'] = (total_iters / tmax / world) / cb['value']

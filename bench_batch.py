@@ -261,27 +261,26 @@ def main():
                           'ms_per_step_median': float(sorted(step_ms)[len(step_ms) // 2]), 'kernel_ms_last_step': kernel_ms,
                           'solved': int((table[:, 1] == 1).sum()), 'admm_iters_total': float(table[:, 2].sum()),
                           'admm_iters_per_s': float(table[:, 2].sum()) * args.steps / el}}
-        # Roofline of the batch kernel (k_batch_admm<256, 6, 6, true>: six stored entries of A and of B per lane, one workgroup per QP, everything in LDS / registers): neither HBM
-        # (7.7 KB of vectors per QP in and out) nor MFMA applies.  What bounds it is the DEPENDENT chain of the two banded
-        # triangular substitutions of every ADMM iteration, which run on one wave: 2n pivots, each one broadcast (v_readlane pair)
-        # + one fp64 FMA that the next pivot depends on.  Floor = 2n pivots x kChainCycles at the 2.4 GHz peak clock with the CU's
-        # problems perfectly overlapped and nothing else in the iteration; achieved = ADMM iterations per second per resident
-        # problem.  Where the rest goes (tools/batch_trace.py, profiles/r02e_batch_trace.txt): per-block overhead of the substitutions
-        # (fetch of the next block of L, store / refill of finished elements), the two products, residual checks.  
-        n_var = P.shape[0]
-        kChainCycles = 43.5           # MEASURED cost of one pivot: two v_readlane_b32 (~14 cycles each, on or off a chain) + the dependent v_fma_f64
-                                      # (tools/lane_bcast_bench.hip, profiles/r02e_lane_bcast.txt)
+        # Roofline of the batch kernel (k_batch_admm<256, 6, 6, DIRECT, SPEC>: one workgroup per QP, iterates in LDS, the matrices and K^-1 in registers): neither
+        # HBM (7.7 KB of vectors per QP in and out) nor MFMA applies -- the kernel is a chain of short dependent phases.  Since round 5 the linear solve
+        # is the spectral form: one dense 128 x 128 fp64 product from registers (64 FMAs per thread: 256 issue cycles) instead
+        # of the 240-pivot substitution chain.  Floor of one ADMM iteration = what one workgroup cannot overlap with itself: 9 barrier-separated phases
+        # (t, B product, row sums, right-hand side copy, dense product, A product, row sums + z / y update, x update), each at least one LDS round trip
+        # + barrier (~170 cycles: 128 + 40), + the product's FMA issue: 9 x 170 + 256 = 1 786 cycles at 2.4 GHz = 0.74 us.  achieved = ADMM iterations per
+        # second per resident QP.  (The banded form's floor was the pivot chain: 2n x 43.5 cycles = 4.35 us; measured 13.9.)
         kernel_s = 1e-3 * kernel_ms
         iters_per_qp = float(table[:, 2].sum()) / B
-        resident = 2 * 256            # two problems per CU (69 KB of LDS each), 256 CUs
-        waves_of_qps = -(-int(B // world) // resident)
+        share = int(B // world)
+        per_cu = 2 if share > 3 * 256 else 1      # batch_hip.hip: one workgroup per CU (everything in registers) up to three rounds, two per CU (scratch) beyond
+        resident = per_cu * 256
+        waves_of_qps = -(-share // resident)
         t_iter = kernel_s / (waves_of_qps * iters_per_qp)              # wall time of one ADMM iteration of a resident QP
-        floor_iter = 2 * n_var * kChainCycles / 2.4e9
-        out['roofline'] = {'bound': 'latency', 'kernel': 'k_batch_admm<256,6,6,true,false,true>', 'unit': 'ADMM iter/s per resident QP',
+        floor_iter = (9 * 170 + 256) / 2.4e9
+        out['roofline'] = {'bound': 'latency', 'kernel': 'k_batch_admm<256,6,6,true,false,false,true,%d> (spectral direct solve)' % per_cu, 'unit': 'ADMM iter/s per resident QP',
                            'achieved': 1.0 / t_iter, 'peak': 1.0 / floor_iter, 'frac': floor_iter / t_iter, 'traffic': None,
-                           'model': 'dependent chain of the banded substitutions: 2n = %d pivots x %.1f cycles (broadcast + FMA, measured) at 2.4 GHz = %.2f us per ADMM iteration; '
-                                    'measured %.2f us (%.1f ADMM iterations per QP, %d QPs resident at a time, kernel %.2f ms)'
-                                    % (2 * n_var, kChainCycles, 1e6 * floor_iter, 1e6 * t_iter, iters_per_qp, resident, 1e3 * kernel_s)}
+                           'model': 'chain of 9 barrier-separated phases (LDS round trip + barrier ~170 cycles each) + 64 fp64 FMAs per thread of the dense product (256 issue cycles) '
+                                    '= %.2f us per ADMM iteration at 2.4 GHz; measured %.2f us (%.1f ADMM iterations per QP on average, %d QPs resident at a time in %d round(s), kernel %.2f ms)'
+                                    % (1e6 * floor_iter, 1e6 * t_iter, iters_per_qp, resident, waves_of_qps, 1e3 * kernel_s)}
         if args.cpu_sample > 0 and world == 1:
             out['cpu_baseline'] = cpu_batch_baseline(P, q, A, L, U, cores=args.cpu_cores or None)
             out['config']['gpu_over_cpu_all_cores'] = out['value'] / out['cpu_baseline']['value']

@@ -279,27 +279,58 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? (SPEC ? SP
   // SPEC: K^-1 <- V diag(dk) V',  dk = 1 / (1 + (rb - rho_ref) lambda): V (column-major, kBatchSpecN rows per column) streamed through `prod` in chunks
   [[maybe_unused]] auto update_kinv = [&](double rb) {
     if constexpr (SPEC) {
+      BT_BEGIN();
       const double dl = rb - P.sp_rho_ref;
       if (tid < kBatchSpecN) sp_dk[tid] = 1.0 / (1.0 + dl * P.sp_lam[tid]);
 #pragma unroll
       for (int c = 0; c < 64; c++) kin[c] = 0.0;
       const int row = tid >> 1, half = tid & 1;
       constexpr int kCol = kBatchSpecN + 2;                     // a staged column: rows 0..63, one double of padding, rows 64..127 (the two halves in different banks)
-      const int CH = prod_len / kCol;                           // columns of V per chunk (batch_solve requires >= 3)
+      constexpr int kChMax = 16;
+      const int CH = min(prod_len / kCol, kChMax);              // columns of V per chunk (batch_solve requires >= 3)
+      // the chunk after this one is fetched into registers while this one is consumed (kStage values per thread); inside a column the
+      // 64 broadcast reads run one block of 8 ahead of the multiply-adds that use them (left to itself the compiler keeps ONE read in flight)
+      constexpr int kStage = kChMax * kBatchSpecN / kBB;
+      double st[kStage];
+      auto fetch = [&](int k0) {
+        const int nk = min(CH, n - k0);
+#pragma unroll
+        for (int t = 0; t < kStage; t++) { const int e = tid + t * kBB; st[t] = (k0 < n && e < nk * kBatchSpecN) ? P.sp_V[(size_t)k0 * kBatchSpecN + e] : 0.0; }
+      };
+      fetch(0);
       for (int k0 = 0; k0 < n; k0 += CH) {
         const int nk = min(CH, n - k0);
         __syncthreads();
-        for (int e = tid; e < nk * kBatchSpecN; e += kBB) { const int kk = e / kBatchSpecN, r_ = e % kBatchSpecN; prod[kk * kCol + r_ + (r_ >= 64)] = P.sp_V[(size_t)k0 * kBatchSpecN + e]; }
+#pragma unroll
+        for (int t = 0; t < kStage; t++) { const int e = tid + t * kBB; if (e < nk * kBatchSpecN) { const int kk = e / kBatchSpecN, r_ = e % kBatchSpecN; prod[kk * kCol + r_ + (r_ >= 64)] = st[t]; } }
         __syncthreads();
+        fetch(k0 + CH);
         for (int kk = 0; kk < nk; kk++) {
           const double *vc = prod + kk * kCol;
           const double a = vc[row + (row >= 64)] * sp_dk[k0 + kk];
           const double *vh = vc + half * 65;                    // (8-byte broadcast reads: see ksolve)
+          double va[8], vb[8];
 #pragma unroll
-          for (int c = 0; c < 64; c++) kin[c] = fma(a, vh[c], kin[c]);
+          for (int c = 0; c < 8; c++) va[c] = vh[c];
+#pragma unroll
+          for (int blk = 0; blk < 8; blk += 2) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) vb[c] = vh[(blk + 1) * 8 + c];
+            asm volatile("" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]), "+v"(va[7]));
+#pragma unroll
+            for (int c = 0; c < 8; c++) kin[blk * 8 + c] = fma(a, va[c], kin[blk * 8 + c]);
+            if (blk + 2 < 8) {
+#pragma unroll
+              for (int c = 0; c < 8; c++) va[c] = vh[(blk + 2) * 8 + c];
+            }
+            asm volatile("" : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]), "+v"(vb[4]), "+v"(vb[5]), "+v"(vb[6]), "+v"(vb[7]));
+#pragma unroll
+            for (int c = 0; c < 8; c++) kin[(blk + 1) * 8 + c] = fma(a, vb[c], kin[(blk + 1) * 8 + c]);
+          }
         }
       }
       __syncthreads();
+      BT_END(tk_fact);
     }
   };
   // DIRECT: assemble  K = (P + sigma I) + shift I + A' diag(rho) A  in the band and factorise it (shift = 0 for the ADMM system;
@@ -384,9 +415,26 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? (SPEC ? SP
       const double *rr = sp_rhs + half * 65;
       // (8-byte reads: every thread of a half reads the SAME address, which the LDS serves as a broadcast -- a 16-byte read of one address by
       //  all lanes is NOT broadcast: measured 250 cycles per ds_read_b128, 3.4 us per product; the second half sits 65 doubles on, in other banks)
+      // (reads kept one block of 8 ahead of their multiply-adds by hand, as in update_kinv)
       double ac[4] = {0.0, 0.0, 0.0, 0.0};
+      double ra[8], rb_[8];
 #pragma unroll
-      for (int c = 0; c < 64; c++) ac[c & 3] = fma(kin[c], rr[c], ac[c & 3]);
+      for (int c = 0; c < 8; c++) ra[c] = rr[c];
+#pragma unroll
+      for (int blk = 0; blk < 8; blk += 2) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) rb_[c] = rr[(blk + 1) * 8 + c];
+        asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]));
+#pragma unroll
+        for (int c = 0; c < 8; c++) ac[c & 3] = fma(kin[blk * 8 + c], ra[c], ac[c & 3]);
+        if (blk + 2 < 8) {
+#pragma unroll
+          for (int c = 0; c < 8; c++) ra[c] = rr[(blk + 2) * 8 + c];
+        }
+        asm volatile("" : "+v"(rb_[0]), "+v"(rb_[1]), "+v"(rb_[2]), "+v"(rb_[3]), "+v"(rb_[4]), "+v"(rb_[5]), "+v"(rb_[6]), "+v"(rb_[7]));
+#pragma unroll
+        for (int c = 0; c < 8; c++) ac[c & 3] = fma(kin[(blk + 1) * 8 + c], rb_[c], ac[c & 3]);
+      }
       const double a0 = ac[0] + ac[2], a1 = ac[1] + ac[3];
       double acc = a0 + a1;
       acc += bdpp<0xb1>(acc);                                   // lane ^ 1: the other half of the row

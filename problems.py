@@ -13,11 +13,13 @@ def _distinct_sorted(rng, rows, k, w):
     return r + np.arange(k)[None, :]
 
 
-def banded_qp(n, m=None, nnz_per_row=5, window=200, eq_frac=0.1, seed=12345):
+def banded_qp(n, m=None, nnz_per_row=5, window=200, eq_frac=0.1, seed=12345, long_range=0.0):
     """BASELINE configs[1] ("Single QP n=100k m=200k nnz(A)=1M nnz(P)=200k"), SURVEY §8d config 2:
     A has exactly `nnz_per_row` N(0,1) entries per row in a random-within-a-band pattern (columns drawn from a window
     of `window` columns around i*n/m), P = diag(U(0.1,1.1)) + one symmetric off-diagonal pair per two rows inside the
-    band, the diagonal raised by the row's off-diagonal mass (strictly diagonally dominant: eigenvalues >= 0.1; stored full nnz(P) = 2n), 10 % equality rows; feasible by construction."""
+    band, the diagonal raised by the row's off-diagonal mass (strictly diagonally dominant: eigenvalues >= 0.1; stored full nnz(P) = 2n), 10 % equality rows; feasible by construction.
+    long_range > 0 (`bench.py --config mixed`): that fraction of A's entries gets its column redrawn from the WHOLE range -- a band plus a few
+    long-range couplings (drawn from a generator of their own: the banded part is the same matrix as with long_range = 0)."""
     rng = np.random.default_rng(seed)
     m = 2 * n if m is None else m
     k = min(nnz_per_row, n)
@@ -26,6 +28,13 @@ def banded_qp(n, m=None, nnz_per_row=5, window=200, eq_frac=0.1, seed=12345):
     lo = np.clip(centre - w // 2, 0, n - w)
     cols = lo[:, None] + _distinct_sorted(rng, m, k, w)
     vals = rng.standard_normal((m, k))
+    if long_range > 0:
+        r2 = np.random.default_rng(seed + 1)
+        pick = r2.random((m, k)) < long_range
+        far = r2.integers(0, n, size=(m, k))
+        cand = np.sort(np.where(pick, far, cols), axis=1)
+        dup = (np.diff(cand, axis=1) == 0).any(axis=1)          # (a redrawn column that hits another entry of its row: that row keeps its band)
+        cols = np.where(dup[:, None], cols, cand)
     A = sp.csr_matrix((vals.ravel(), cols.ravel().astype(np.int32), np.arange(0, m * k + 1, k, dtype=np.int32)), shape=(m, n)).tocsc()
     A.sort_indices()
     d = rng.uniform(0.1, 1.1, n)

@@ -161,3 +161,15 @@ def test_f1_form_follows_matrix_updates(monkeypatch):
         assert _rel(r1.x, other.x) < 2e-5 and _rel(r1.y, other.y) < 1e-4
         assert abs(r1.info.obj_val - other.info.obj_val) <= 1e-6 * (1 + abs(other.info.obj_val))
     assert abs(r1.info.obj_val - r0.info.obj_val) > 1e-6 * (1 + abs(r0.info.obj_val))      # (the update did change the problem)
+
+
+def test_band_plus_long_range_couplings_matches_the_oracle():
+    """`bench.py --config mixed`: 2 % of A's entries moved to columns drawn from the whole range.  The one-launch form does not apply to such a
+    matrix (a block with a far column has no compact window); whatever form the engine picks, the solution is the oracle's."""
+    P, q, A, l, u = problems.banded_qp(6000, window=60, long_range=0.02)
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, eps_abs=1e-8, eps_rel=1e-8, verbose=False, max_iter=50000, adaptive_rho_interval=50, check_termination=25)
+    r = m.solve()
+    xo, yo, io = Oracle().setup(P, q, A, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=100000, adaptive_rho_interval=50).solve()
+    assert r.info.status_val == 1 and io.status_val == SOLVED
+    assert np.abs(r.x - xo).max() <= 2e-6 * (1 + np.abs(xo).max()) and np.abs(r.y - yo).max() <= 4e-6 * (1 + np.abs(yo).max())
+    assert abs(r.info.obj_val - io.obj_val) <= 1e-7 * (1 + abs(io.obj_val))

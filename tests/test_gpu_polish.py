@@ -175,7 +175,7 @@ def test_polish_on_the_pcg_path_matches_the_oracle(n, window, eps):
 def test_polish_after_short_pcg_history_runs_to_the_end():
     """The polish's inner systems (relative tolerance 1e-15) take hundreds of PCG iterations where the ADMM chunks before them took two
     or three: the host must keep feeding the one long iteration (it used to give up after a number of top-ups sized by the prediction,
-    the solve came back with a device error and the handle kept the PREVIOUS solve's solution; tools/mt_debug3.py)."""
+    the solve came back with a device error and the handle kept the PREVIOUS solve's solution)."""
     seed = 72
     rng = np.random.default_rng(seed)
     P, q, A, l, u = problems.banded_qp(3000, window=60, seed=seed)
