@@ -197,6 +197,7 @@ typedef struct {
   double reorder_ms;          /* time setup spent looking for the permutation (0: not attempted) */
   double woodbury_cache_hits; /* last solve: rho updates served by an inverse this handle had computed for the same rho_bar before (validated by the
                                  numerical probe against the current matrices) -- woodbury_factorisations counts the others; woodbury_factor_ms covers both */
+  double f1_far_columns;      /* F1 form with per-block mixing: far columns (spill slots) over all row blocks of A (0: every block fits its window) */
 } OSQPHipStats;
 /* OSQPHipStats::preconditioner.  `cg_precond = OSQP_DIAGONAL_PRECONDITIONER` (bindings.cpp.in:426, the reference's only preconditioner) selects the
    Jacobi family: plain Jacobi M = diag(K), and -- this engine's addition, on by default, OSQPHipPolicy::woodbury / woodbury_large = 0 switch it
@@ -304,7 +305,8 @@ typedef struct {
   OSQPInt graph;              /* replay captured launch strings (hipGraph) instead of enqueuing them one by one                 [setup] */
   OSQPInt slots;              /* device-side scheduling of the ADMM / PCG phases ("slot" kernels)                               [setup] */
   OSQPInt pcg_fused;          /* 1: vector update fused into the SpMV kernels; 0: the three-kernel PCG iteration                [setup] */
-  OSQPInt f1;                 /* one launch per PCG iteration where the matrices allow it (banded A)                            [setup] */
+  OSQPInt f1;                 /* one launch per PCG iteration where the matrices allow it (banded A; 1: a block's few columns outside its
+                                 window are taken as far columns -- band + long-range couplings; 2: strict windows only)          [setup] */
   OSQPInt window;             /* windowed row blocks (16-bit local column indices, input window in LDS)                         [setup] */
   OSQPInt woodbury;           /* a few dense rows of A (1..128 rows with > 128 entries) are treated exactly in the preconditioner   [setup] */
   OSQPInt woodbury_direct;    /* ... and when the rest of K is diagonal, that preconditioner IS K^-1: the linear solve without PCG iterations [setup] */

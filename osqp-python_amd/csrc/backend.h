@@ -82,7 +82,7 @@ struct DevF1 {
   int *blk = nullptr;            // nblk(A) x 16 words, one scalar load per block:
                                  //   {first row, end row, first entry, end entry}  (the block's descriptor in A)
                                  //   {cov0, cov1, cs0, cs1}: replica coverage [cov0, cov1) (zero outside the window), own columns [cs0, cs1)
-                                 //   {offset of the block's column pointers in cptr, first and end entry of its own rows in the P arrays, 0}
+                                 //   {offset of the block's column pointers in cptr, first and end entry of its own rows in the P arrays, far columns (mix)}
                                  //   {g0, gl, a0, wl}: gather window [g0, g0 + gl) (columns of the block's rows of A -- plus those of its own
                                  //   rows of P if that widens it by at most a quarter), scatter window [a0, a0 + wl) (columns of its rows of A)
   // The matrix stream of a block, in the layout the kernel's LDS buffer has (pcg_hip.hip F1Stream): block b owns the kF1StreamBytes bytes at
@@ -101,7 +101,20 @@ struct DevF1 {
   // set of D vectors: KA leaves the slices of rhs = sigma x - q + A' v in the parity-1 set and those of K x_g in the third (pcg_hip.hip f1_ka_body).
   // Dev::Minv / xs / p / r / s point into it.  r_k, s_{k-1} and rep_k (what launch F_k writes) live in parity k & 1.
   double *va = nullptr; size_t ns = 0;
+  // Per-block mixing (mix = 1): a row block of A whose columns do not fit one window keeps a window of at most kF1Win - kF1MaxFar columns and
+  // treats the remaining columns -- at most kF1MaxFar distinct ones -- as FAR columns.  They occupy the LAST kF1MaxFar slots of the block's gather
+  // list (the same 4 + D vector loads at column fcol[.] instead of g0 + e; which lanes serve them does not depend on the block's record) and
+  // nfc more segments of its column-ordered pass.  A far column's sum goes to the block's SPILL SLOT for it instead of a replica: spill is
+  // ordered by (column, block), so whoever reconstructs column c adds its slots in index order to the replicas' sum -- written by launch F_k,
+  // read by F_{k+1}, three sets like the replicas (parity 0, parity 1 / r_0's slices, rhs's slices).  No atomics, fixed order: results do not
+  // depend on scheduling, and every workgroup that recomputes a column obtains the same bits.  blk word 11 = the block's number of far columns.
+  int mix = 0;
+  int *fcol = nullptr, *fq = nullptr;   // fixed stride kF1MaxFar per block: far columns (ascending) as pairs {column, spk[column]}, and the spill slot of each
+  int *sp_ptr = nullptr;         // [n + 1] spill slots by column (host-side order; kept for inspection)
+  int *spk = nullptr;            // [n] one packed word per column: first slot << 6 | count  (the plan refuses columns with more than 63 slots)
+  double *spill = nullptr; size_t nsp = 0;      // 3 x (nsp + 2): the sets are padded (a reader takes its first two slots unconditionally)
 };
+constexpr int kF1MaxFar = 128;     // most far columns of a row block
 
 // Woodbury correction of the Jacobi preconditioner for a FEW dense rows of A (portfolio: k + 1 rows with thousands of entries next to
 // n one-entry rows).  With L = the long rows (more than kLongRow entries; at most kWbMaxRows of them),

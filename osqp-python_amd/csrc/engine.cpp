@@ -43,7 +43,7 @@ void policy_from_env(OSQPHipPolicy &p, bool runtime_only) {
   on("OSQP_HIP_WOODBURY_FUSED", p.woodbury_fused); real("OSQP_HIP_WOODBURY_DIRECT_TOL", p.woodbury_direct_tol);
   on("OSQP_HIP_WOODBURY", p.woodbury); on("OSQP_HIP_WOODBURY_DIRECT", p.woodbury_direct); on("OSQP_HIP_WOODBURY_LARGE", p.woodbury_large);
   num("OSQP_HIP_REORDER", p.reorder); on("OSQP_HIP_WOODBURY_CACHE", p.woodbury_cache);
-  on("OSQP_HIP_GRAPH", p.graph); on("OSQP_HIP_SLOTS", p.slots); on("OSQP_HIP_PCG_FUSED", p.pcg_fused); on("OSQP_HIP_F1", p.f1); on("OSQP_HIP_WINDOW", p.window);
+  on("OSQP_HIP_GRAPH", p.graph); on("OSQP_HIP_SLOTS", p.slots); on("OSQP_HIP_PCG_FUSED", p.pcg_fused); num("OSQP_HIP_F1", p.f1); on("OSQP_HIP_WINDOW", p.window);
   real("OSQP_HIP_EXTRAP", p.extrap);
   if (const char *e = std::getenv("OSQP_HIP_RHO_EQ_FACTOR")) { const double v = std::atof(e); if (v >= 1.0) p.rho_eq_factor = v; }
   if (std::getenv("OSQP_HIP_SETUP_TIMING")) p.setup_timing = 1;

@@ -136,6 +136,7 @@ class Engine {
   struct F1Plan {                       // host image of backend.h DevF1 (plan_f1 builds it without touching the device; upload_f1 commits it)
     bool ok = false; int D = 0, pnnz = 0;
     std::vector<int> blk, prp, pcol, psrc; std::vector<unsigned int> ent; std::vector<unsigned short> cptr;
+    int mix = 0; size_t nsp = 0; std::vector<int> fcol, fq, sp_ptr;      // per-block mixing (backend.h DevF1::mix)
   };
   // ---- bandwidth-reducing reordering (Engine::compute_reorder): when the one-launch PCG form does not apply to the matrices as given but
   // does after a symmetric permutation of the variables and a permutation of the constraints, the engine works on the PERMUTED problem

@@ -744,6 +744,7 @@ int Engine::get_stats(OSQPHipStats *out) {
   out->woodbury_rows = d_.wb.on ? d_.wb.r : 0; out->woodbury_direct = (d_.wb.on && d_.wb.exact) ? ((d_.wb.x.on) ? 2 : 1) : 0;
   out->windowed_blocks = d_.A.nwin + d_.B.nwin; out->row_blocks = d_.A.nblk + d_.B.nblk;
   out->reordered = reordered_ ? 1.0 : 0.0; out->reorder_ms = reorder_ms_;
+  out->f1_far_columns = d_.f1.on && d_.f1.mix ? (double)d_.f1.nsp : 0.0;
   // which preconditioner the PCG of this handle runs with RIGHT NOW (the setting cg_precond = diagonal selects the Jacobi family; the
   // Woodbury correction for dense rows is the engine's addition: OSQPHipPolicy::woodbury / woodbury_large switch it off)
   out->preconditioner = settings.cg_precond != OSQP_DIAGONAL_PRECONDITIONER ? OSQP_HIP_PRECOND_NONE

@@ -126,7 +126,8 @@ void Engine::clear_reorder() {
 
 // ------------------------------------------------------------------------------------------------ F1 plan
 // One launch per PCG iteration (backend.h DevF1): symbolic data, built once at setup from the row blocks of A.  The form applies when
-// every row block of A has a column window of at most kF1Win columns and at most kF1MaxRows rows, the windows of blocks g and g + D
+// every row block of A has a column window of at most kF1Win columns (plus at most kF1MaxFar far columns outside it: per-block mixing,
+// backend.h DevF1::mix) and at most kF1MaxRows rows, the windows of blocks g and g + D
 // never overlap for some D <= kF1MaxD (banded / block-banded A -- as given, or after Engine::reorder has found the band), and the
 // columns can be dealt out to the blocks as OWN columns -- consecutive ranges [cs[g], cs[g+1]) inside the block's window, at most
 // kF1MaxOwn of them with at most kF1PChunk entries of P + sigma I.  Anything else keeps the two-kernel form.  OSQPHipPolicy::f1 = 0
@@ -135,21 +136,67 @@ bool Engine::plan_f1(const std::vector<int> &rb, const std::vector<int> &Arp, co
                      const std::vector<int> &Brp, const std::vector<int> &Bj, F1Plan &pl) {
   pl = F1Plan();
   if (!pol_.f1) return false;
+  auto fail = [&](const char *why, int b) { if (pol_.setup_timing) std::fprintf(stderr, "[osqp_hip] F1 plan: %s (row block %d of %d)\n", why, b, (int)rb.size() - 1); return false; };
+  const bool allow_mix = pol_.f1 != 2;                                        // (OSQPHipPolicy::f1 = 2: strict windows only, for A/B runs)
   const int nb = (int)rb.size() - 1;
-  if (!be::device_assembly() || m == 0 || nb < kGrid / 4) return false;      // (few blocks: most workgroups would idle in the vector update)
-  std::vector<int> a0(nb), wl(nb), lo0(nb), hi0(nb);
+  if (!be::device_assembly() || m == 0 || nb < kGrid / 4) return fail("too few row blocks", nb);      // (few blocks: most workgroups would idle in the vector update)
+  std::vector<int> a0(nb), wl(nb), lo0(nb), hi0(nb), nfar(nb, 0), cs(nb + 1);
+  std::vector<int> sc, dcols;
+  int D = 0;
+  // (up to three passes: 0 -- only blocks wider than kF1Win give columns away; 1 -- every block does (a block with ONE outlier 400 columns off fits
+  //  kF1Win, but its window then overlaps those of many neighbours: more than kF1MaxD replicas); 2 -- the same with the tight choice, far-column
+  //  cost 1 instead of 4: reaching out for near outliers keeps the far lists short but widens the windows)
+  for (int pass = 0; pass < (allow_mix ? 3 : 1); pass++) {
+  const int far_cost = pass == 2 ? 1 : 4;
+  pl.mix = 0; std::fill(nfar.begin(), nfar.end(), 0);
   for (int b = 0; b < nb; b++) {
     const int r0 = rb[b], r1 = rb[b + 1], k0 = Arp[r0], k1 = Arp[r1];
-    if (k1 == k0 || r1 - r0 > kF1MaxRows || k1 - k0 > kF1Chunk || (r1 - r0 == 1 && k1 - k0 > kLongRow)) return false;
+    if (k1 == k0 || r1 - r0 > kF1MaxRows || k1 - k0 > kF1Chunk || (r1 - r0 == 1 && k1 - k0 > kLongRow)) return fail("block shape", b);
     int lo = INT32_MAX, hi = -1;
     for (int k = k0; k < k1; k++) { lo = std::min(lo, Arj[k]); hi = std::max(hi, Arj[k]); }
-    if (hi - lo + 1 > kF1Win) return false;
+    if (hi - lo + 1 > kF1Win || pass >= 1) {
+      // per-block mixing (backend.h DevF1::mix): the densest window that leaves room for the columns outside it as far columns
+      if (!allow_mix) return fail("no window (strict)", b);
+      sc.assign(Arj.begin() + k0, Arj.begin() + k1);
+      std::sort(sc.begin(), sc.end());
+      bool found = false;
+      { // a far column costs about as much as kFarCost window columns (the same 4 + D loads, but scattered, behind a dependent index load, plus
+        // its spill slot on both sides): the window [d_i, d_j] over the block's distinct columns that minimises  width + kFarCost * (columns outside)
+        // = the maximum-sum run of  kFarCost + 1 - gap  over the gaps between neighbouring columns.  (Not "the window of kF1Win columns
+        // holding the most entries": that stretches every window towards its nearest outliers, and wide windows cost replicas and loads.)
+        const int kFarCost = far_cost;
+        std::vector<int> &dc = dcols; dc.assign(sc.begin(), sc.end());
+        dc.erase(std::unique(dc.begin(), dc.end()), dc.end());
+        const int U = (int)dc.size();
+        int bi = 0, bj = 0, ci = 0; long cur = 0, best = 0;
+        for (int t = 1; t < U; t++) {
+          cur += kFarCost + 1 - (dc[t] - dc[t - 1]);
+          if (cur < 0) { cur = 0; ci = t; }
+          else if (cur > best) { best = cur; bi = ci; bj = t; }
+        }
+        const int far = U - (bj - bi + 1);
+        if (far <= kF1MaxFar && dc[bj] - dc[bi] + 1 <= (far ? kF1Win - kF1MaxFar : kF1Win)) { found = true; lo = dc[bi]; hi = dc[bj]; nfar[b] = far; }
+      }
+      if (!found && hi - lo + 1 <= kF1Win) found = true;                     // (a block that fits as it is)
+      if (!found) {                                                            // ... or, failing that, the window of that width holding the most entries
+        const int width = kF1Win - kF1MaxFar;
+        int best = -1, bi = 0, bj = 0;
+        for (int i = 0, j = 0; i < (int)sc.size(); i++) {                     // entries sc[i .. j) lie in [sc[i], sc[i] + width)
+          while (j < (int)sc.size() && sc[j] - sc[i] < width) j++;
+          if (j - i > best) { best = j - i; bi = i; bj = j; }
+        }
+        int far = 0;
+        for (int i = 0; i < (int)sc.size(); i++) if ((i < bi || i >= bj) && (i == 0 || sc[i] != sc[i - 1])) far++;
+        if (far <= kF1MaxFar) { found = true; lo = sc[bi]; hi = sc[bj - 1]; nfar[b] = far; }
+      }
+      if (!found) return fail("too many far columns", b);
+      if (nfar[b]) pl.mix = 1;
+    }
     lo0[b] = lo; hi0[b] = hi;
   }
   // own columns: cs[g] follows the rows (rb[g] n / m: on a band of slope n / m these are the columns under the block) and is clamped into
   // what the neighbouring windows allow -- a column left of block g's window belongs to an earlier block, one right of block g - 1's
   // window to a later one; a column no window holds goes to the block in front of the gap
-  std::vector<int> cs(nb + 1);
   cs[0] = 0;
   for (int g = 1; g < nb; g++) {
     const int ideal = (int)((long)rb[g] * n / m);
@@ -163,16 +210,18 @@ bool Engine::plan_f1(const std::vector<int> &rb, const std::vector<int> &Arp, co
     //  without entries of the block's rows simply has an empty segment)
     int lo = lo0[b], hi = hi0[b];
     if (cs[b + 1] > cs[b]) { lo = std::min(lo, cs[b]); hi = std::max(hi, cs[b + 1] - 1); }
-    if (hi - lo + 1 > kF1Win) return false;
+    if (hi - lo + 1 > (nfar[b] ? kF1Win - kF1MaxFar : kF1Win)) return fail("window + own columns too wide", b);
     a0[b] = lo; wl[b] = hi - lo + 1;
   }
-  int D = 0;
+  D = 0;
   for (int t = 1; t <= kF1MaxD && !D; t++) {
     bool ok = true;
     for (int g = 0; g + t < nb && ok; g++) ok = a0[g] + wl[g] <= a0[g + t];
     if (ok) D = t;
   }
-  if (!D) return false;
+  if (D) break;
+  }
+  if (!D) return fail("windows of blocks g and g + 4 overlap", -1);
   // the compact CSR of P + sigma I (row j of B up to its first A' entry)
   std::vector<int> &prp = pl.prp; prp.assign(n + 1, 0);
   for (int j = 0; j < n; j++) { int c = 0; for (int k = Brp[j]; k < Brp[j + 1] && Bj[k] < n; k++) c++; prp[j + 1] = prp[j] + c; }
@@ -182,35 +231,75 @@ bool Engine::plan_f1(const std::vector<int> &rb, const std::vector<int> &Arp, co
   std::vector<int> &blk = pl.blk; blk.assign(16 * (size_t)nb, 0);
   std::vector<unsigned int> &ent = pl.ent; ent.assign(Arj.size(), 0u);
   std::vector<unsigned short> &cptr = pl.cptr; cptr.clear();
-  std::vector<int> order, tpos;
+  if (pl.mix) { pl.fcol.assign((size_t)nb * kF1MaxFar, -1); pl.fq.assign((size_t)nb * kF1MaxFar, 0); }
+  size_t nsp = 0;
+  std::vector<int> order, tpos, fc, slot;
   for (int b = 0; b < nb; b++) {
-    if (cs[b + 1] - cs[b] > kF1MaxOwn || prp[cs[b + 1]] - prp[cs[b]] > kF1PChunk) return false;
+    if (cs[b + 1] - cs[b] > kF1MaxOwn || prp[cs[b + 1]] - prp[cs[b]] > kF1PChunk) return fail("own columns", b);
     const int r0 = rb[b], r1 = rb[b + 1], k0 = Arp[r0], k1 = Arp[r1], cnt = k1 - k0;
     int *w = &blk[16 * (size_t)b];
     w[0] = r0; w[1] = r1; w[2] = k0; w[3] = k1;
     w[4] = b < D ? 0 : a0[b]; w[5] = b + D < nb ? a0[b + D] : n; w[6] = cs[b]; w[7] = cs[b + 1];
-    w[8] = (int)cptr.size(); w[9] = prp[cs[b]]; w[10] = prp[cs[b + 1]]; w[11] = 0;
+    w[8] = (int)cptr.size(); w[9] = prp[cs[b]]; w[10] = prp[cs[b + 1]]; w[11] = 0;      // (w[11]: far columns, below)
+    // far columns: whatever the final scatter window [a0, a0 + wl) does not hold (the own columns may have widened it over some)
+    fc.clear();
+    if (nfar[b]) {
+      for (int k = k0; k < k1; k++) if (Arj[k] < a0[b] || Arj[k] >= a0[b] + wl[b]) fc.push_back(Arj[k]);
+      std::sort(fc.begin(), fc.end()); fc.erase(std::unique(fc.begin(), fc.end()), fc.end());
+    }
+    const int nfc = (int)fc.size();
+    w[11] = nfc;
     // gather window: the columns of the block's rows of A, together with those of its own rows of P + sigma I when that widens the
     // window by at most a quarter (every window column costs 4 + D vector loads; a P entry outside the window costs as many, once)
     int g0 = a0[b], g1 = a0[b] + wl[b];
     for (int k = prp[cs[b]]; k < prp[cs[b + 1]]; k++) { g0 = std::min(g0, pcol[k]); g1 = std::max(g1, pcol[k] + 1); }
-    if (g1 - g0 > kF1Win || 4 * (g1 - g0) > 5 * wl[b]) { g0 = a0[b]; g1 = a0[b] + wl[b]; }
+    if (g1 - g0 > (nfc ? kF1Win - kF1MaxFar : kF1Win) || 4 * (g1 - g0) > 5 * wl[b]) { g0 = a0[b]; g1 = a0[b] + wl[b]; }
     w[12] = g0; w[13] = g1 - g0; w[14] = a0[b]; w[15] = wl[b];
-    // column-major order of the block's entries: stable by local column (rows ascending within a column)
+    // per entry: the slot of its column in the gather list (window columns first, then the far columns) and in the column-ordered pass
+    slot.resize(cnt);
+    for (int e = 0; e < cnt; e++) {
+      const int c = Arj[k0 + e];
+      if (c >= a0[b] && c < a0[b] + wl[b]) slot[e] = c - a0[b];
+      else slot[e] = wl[b] + (int)(std::lower_bound(fc.begin(), fc.end(), c) - fc.begin());
+    }
+    // column-major order of the block's entries: stable by slot (rows ascending within a column)
     order.resize(cnt);
     for (int e = 0; e < cnt; e++) order[e] = e;
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return Arj[k0 + x] < Arj[k0 + y]; });
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return slot[x] < slot[y]; });
     tpos.resize(cnt);
     for (int t = 0; t < cnt; t++) tpos[order[t]] = t;
+    const int gl = g1 - g0;
     for (int r = r0; r < r1; r++)
-      for (int k = Arp[r]; k < Arp[r + 1]; k++)
-        ent[k] = (unsigned)(Arj[k] - g0) | ((unsigned)(r - r0) << 9) | ((unsigned)tpos[k - k0] << 18);
+      for (int k = Arp[r]; k < Arp[r + 1]; k++) {
+        const int sl = slot[k - k0];
+        const unsigned gs = sl < wl[b] ? (unsigned)(Arj[k] - g0) : (unsigned)(kF1Win - kF1MaxFar + sl - wl[b]);      // (far columns: the last kF1MaxFar gather slots)
+        ent[k] = gs | ((unsigned)(r - r0) << 9) | ((unsigned)tpos[k - k0] << 18);
+      }
     const size_t base = cptr.size();
-    cptr.resize(base + wl[b] + 1, 0);
-    for (int e = 0; e < cnt; e++) cptr[base + (Arj[k0 + e] - a0[b]) + 1]++;
-    for (int c = 0; c < wl[b]; c++) cptr[base + c + 1] = (unsigned short)(cptr[base + c + 1] + cptr[base + c]);
+    cptr.resize(base + wl[b] + nfc + 1, 0);
+    for (int e = 0; e < cnt; e++) cptr[base + slot[e] + 1]++;
+    for (int c = 0; c < wl[b] + nfc; c++) cptr[base + c + 1] = (unsigned short)(cptr[base + c + 1] + cptr[base + c]);
+    if (pl.mix) { std::copy(fc.begin(), fc.end(), pl.fcol.begin() + (size_t)b * kF1MaxFar); nsp += (size_t)nfc; }
+  }
+  if (pol_.f1 == 3 && !pl.mix) { pl.mix = 1; pl.fcol.assign((size_t)nb * kF1MaxFar, -1); pl.fq.assign((size_t)nb * kF1MaxFar, 0); }      // (experiment: the mixing kernels on a matrix without far columns)
+  if (pl.mix && nsp >= (size_t)1 << 25) return fail("too many spill slots", -1);
+  if (pl.mix) {
+    // spill slots ordered by (column, block): blocks ascend within fcol, so a stable counting sort by column gives the order
+    pl.nsp = nsp;
+    pl.sp_ptr.assign((size_t)n + 1, 0);
+    for (int c : pl.fcol) if (c >= 0) pl.sp_ptr[c + 1]++;
+    for (int j = 0; j < n; j++) pl.sp_ptr[j + 1] += pl.sp_ptr[j];
+    std::vector<int> cur(pl.sp_ptr.begin(), pl.sp_ptr.end() - 1);
+    for (size_t i = 0; i < pl.fcol.size(); i++) if (pl.fcol[i] >= 0) pl.fq[i] = cur[pl.fcol[i]]++;
+    for (int j = 0; j < n; j++) if (pl.sp_ptr[j + 1] - pl.sp_ptr[j] > 63) return fail("a column is far for more than 63 row blocks", -1);
   }
   pl.D = D; pl.pnnz = pnnz; pl.ok = true;
+  if (pol_.setup_timing) {
+    double swl = 0, sgl = 0, sown = 0; int mwl = 0;
+    for (int b = 0; b < nb; b++) { swl += wl[b]; sgl += blk[16 * (size_t)b + 13]; sown += cs[b + 1] - cs[b]; mwl = std::max(mwl, wl[b]); }
+    std::fprintf(stderr, "[osqp_hip] F1 plan: %d row blocks, D = %d, scatter window %.1f columns on average (max %d), gather window %.1f, own columns %.1f, far columns %.2f per block\n",
+                 nb, D, swl / nb, mwl, sgl / nb, sown / nb, (double)pl.nsp / nb);
+  }
   return true;
 }
 
@@ -234,6 +323,13 @@ void Engine::upload_f1(const F1Plan &pl) {
   f.pval = dev_vec<double>(d_, pl.pnnz);
   f.ns = ((size_t)n + 31) / 32 * 32;                       // 256-byte aligned vectors
   f.va = dev_vec<double>(d_, (7 + 3 * (size_t)pl.D) * f.ns);
+  if (pl.mix) {
+    std::vector<int> spk((size_t)n), fc2(2 * pl.fcol.size(), 0);
+    for (int j = 0; j < n; j++) spk[j] = (pl.sp_ptr[j] << 6) | (pl.sp_ptr[j + 1] - pl.sp_ptr[j]);
+    for (size_t i = 0; i < pl.fcol.size(); i++) if (pl.fcol[i] >= 0) { fc2[2 * i] = pl.fcol[i]; fc2[2 * i + 1] = spk[pl.fcol[i]]; }
+    f.mix = 1; f.fcol = up_i(fc2); f.fq = up_i(pl.fq); f.sp_ptr = up_i(pl.sp_ptr); f.spk = up_i(spk);
+    f.nsp = pl.nsp; f.spill = dev_vec<double>(d_, 3 * (f.nsp + 2));
+  }
   f.on = 1;
 }
 

@@ -684,7 +684,34 @@ struct F1Rec { int4 ds, fa, fb, fc; };      // a block's record (DevF1::blk)
 __device__ __forceinline__ F1Rec f1_record(const DevF1 &f, int b) {
   return F1Rec{sload_int4(f.blk, 4 * (size_t)b), sload_int4(f.blk, 4 * (size_t)b + 1), sload_int4(f.blk, 4 * (size_t)b + 2), sload_int4(f.blk, 4 * (size_t)b + 3)};
 }
-template <int D, bool FIRST>
+// per-block mixing (backend.h DevF1::mix): what the far columns' spill slots hold for one column, summed in index order.  EVERY reconstruction of a
+// column is  f1_w(replicas) + f1_spill_sum(...)  -- the same expression in every workgroup that needs the column: all copies are bit-identical
+// A column's spill slots arrive as ONE packed word (DevF1::spk: first slot << 6 | count); the first two slots are requested together, behind the
+// packed word alone -- a loop would put one memory round trip per slot on the
+// block's critical path.  f1_spill_take: those two loads; f1_spill_sum: the sum.
+struct F1Spill { double v0, v1; };
+__device__ __forceinline__ F1Spill f1_spill_take(const double *sp, int word) {     // (lanes without slots request nothing)
+  const int q0 = word >> 6, cnt = word & 63;
+  F1Spill t{0.0, 0.0};
+  if (cnt > 0) t.v0 = sp[q0];
+  if (cnt > 1) t.v1 = sp[q0 + 1];
+  return t;
+}
+__device__ __forceinline__ double f1_spill_sum(const double *sp, int word, const F1Spill &t) {
+  const int q0 = word >> 6, cnt = word & 63;               // (the plan refuses columns with more than 63 slots)
+  double a = 0.0;
+  if (cnt > 0) a += t.v0;
+  if (cnt > 1) a += t.v1;
+  for (int q = q0 + 2; q < q0 + cnt; q++) a += sp[q];
+  return a;
+}
+__device__ __forceinline__ double f1_spill_sum(const double *sp, const int *spk, int c) {     // (columns off the fast path)
+  const int word = spk[c];
+  return f1_spill_sum(sp, word, f1_spill_take(sp, word));
+}
+// (Tried: the scalar fold INSIDE the body, behind the first block's vector requests, so that the two round trips overlap -- the fold's 24 partial
+//  registers on top of the window's cost 36 - 128 bytes of scratch per lane and the launch time did not move: 24.97 vs 24.66 us per pair.)
+template <int D, bool FIRST, bool MIX>
 __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool vec_only, const F1Scal sc, F1Lds &L, F1Stream &S, const F1Rec &rec0, const int par) {
   const DevF1 &f = d.f1;
   const int n = d.n, tid = threadIdx.x;
@@ -702,6 +729,10 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
   const double *repcur = va + (7 + (size_t)cur * D) * ns;   // K u_{k-1} in D partial vectors  (F_0: the slices of r_0 = rhs - K x_g that f1_ka_body left)
   const double *repV = va + (7 + (size_t)2 * D) * ns;       // F_0: the slices of rhs = sigma x - q + A' v alone (||rhs||_inf: read on the own columns only)
   double *repnxt = gptr(f.va) + (7 + (size_t)nxt * D) * ns;
+  // per-block mixing: the spill sets that go with the three replica sets, the spill slots by column
+  [[maybe_unused]] const double *spcur = MIX ? gptr(f.spill) + (size_t)cur * (f.nsp + 2) : nullptr, *spV = MIX ? gptr(f.spill) + 2 * (f.nsp + 2) : nullptr;
+  [[maybe_unused]] double *spnxt = MIX ? gptr(f.spill) + (size_t)nxt * (f.nsp + 2) : nullptr;
+  [[maybe_unused]] const int *spk = MIX ? gptr(f.spk) : nullptr;
   double g_acc = 0.0, rn_acc = 0.0, dl_acc = 0.0, bn_acc = 0.0;
   // the vector update of one own column (operands in registers): stores s_{k-1}, r_k, p_{k-1}, x~; returns u_k
   auto own_update = [&](int j, double mi, double r, double w, double sp, double pp, double x) -> double {
@@ -715,10 +746,16 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
   const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, slots = gridDim.x >> 3;
   const int per = (d.A.nblk + 7) >> 3;
   constexpr int CW = kF1Win / kBlock, CE = kF1Chunk / kBlock;
+  constexpr int kFB = kF1Win - kF1MaxFar;                   // first far slot
+  static_assert(kFB >= (CW - 1) * kBlock, "the far slots belong to the lanes' last window element");
   static_assert(kF1PChunk == kBlock, "one (P + sigma I) entry per lane");
   for (int sl = slot0; sl < per; sl += slots) {
     const int b = __builtin_amdgcn_readfirstlane(xcd * per + sl);
     if (b >= d.A.nblk) break;
+    // MIX: the far slots this lane serves -- {column, its packed spill word} for the gather, the spill slot for the column-ordered pass -- sit at a
+    // fixed stride per block: requested before the record (the window loads of those lanes wait for them, not for a second round trip)
+    [[maybe_unused]] int2 fcl = make_int2(0, 0); [[maybe_unused]] int fql = 0;
+    if constexpr (MIX) { if (tid >= kFB - (CW - 1) * kBlock) { const size_t i = (size_t)b * kF1MaxFar + (tid - (kFB - (CW - 1) * kBlock)); fcl = reinterpret_cast<const int2 *>(gptr(f.fcol))[i]; fql = gptr(f.fq)[i]; } }
     // the block's record: 16 words, one scalar load
     // (read through the constant address space: the index is wave-uniform, so the four int4 become scalar loads behind ONE wait --
     //  as generic-pointer loads inside this loop they were four vector loads, each waited for before the next was issued)
@@ -728,7 +765,10 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     const int cov0 = fa.x, cov1 = fa.y, cs0 = fa.z, nown = fa.w - fa.z;
     const int cpo = fb.x, pk0 = fb.y, pcnt = fb.z - fb.y;
     const int g0 = fc.x, gl = vec_only ? 0 : fc.y, a0 = fc.z, wl = fc.w;      // gather window [g0, g0 + gl), scatter window [a0, a0 + wl)
-    const int nw = (gl + kBlock - 1) / kBlock, nu = (cnt + kBlock - 1) / kBlock, ns2 = (wl + kBlock - 1) / kBlock;
+    // MIX: the block's far columns sit in the LAST kF1MaxFar slots of the gather list and of the column-ordered pass (slots kFB ..): which lanes
+    // serve them does not depend on the record (their loads were requested before it arrived)
+    const int nfc = MIX && !vec_only ? fb.w : 0;
+    const int nw = nfc ? CW : (gl + kBlock - 1) / kBlock, nu = (cnt + kBlock - 1) / kBlock, ns2 = nfc ? CW : (wl + kBlock - 1) / kBlock;
     KT(2);
     // ---- loads.  First the (P + sigma I) entry of this lane: its column decides whether the operand comes from the window or has
     //      to be recomputed from its parts (columns outside the window), and those loads should leave with the window's, not after it
@@ -738,11 +778,14 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     // ---- window parts (+ p, x~ where the window column is one of the block's own)
     double wm[CW], wr[CW], wsv[CW], wq[CW][D], wpp[CW], wx[CW];
     bool wown[CW];
+    [[maybe_unused]] int wsw[CW]; [[maybe_unused]] F1Spill wst[CW];      // MIX: the column's packed spill word, its first two slots
 #pragma unroll
     for (int u = 0; u < CW; u++) {
       wown[u] = false;
       if (u < nw) {
-        const int e = tid + u * kBlock, c = g0 + min(e, gl - 1);
+        const int e = tid + u * kBlock;
+        int c = g0 + min(e, gl - 1);
+        if constexpr (MIX) { const bool isfar = u == CW - 1 && e >= kFB && e - kFB < nfc; if (isfar) c = fcl.x; wsw[u] = isfar ? fcl.y : spk[c]; }
         wown[u] = e < gl && c >= cs0 && c - cs0 < nown;
         wm[u] = Minv[c];
 #pragma unroll
@@ -755,6 +798,10 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
         } else { wx[u] = xs_r[co]; wpp[u] = gptr(d.xg)[co]; }      // F_0: the own lane also moves x~ on (x~_prev <- x~, x~ <- x_g)
       }
     }
+    if constexpr (MIX) {                                     // the spill slots: behind the packed words alone (the first of this lane's requests to return)
+#pragma unroll
+      for (int u = 0; u < CW; u++) { if (u < nw) wst[u] = f1_spill_take(spcur, wsw[u]); }
+    }
     // ---- row / column pointers (the matrix entries themselves arrive in LDS: S, requested one block ahead)
     int rp0 = 0, rp1 = 0; double rrho = 0.0;
     int cp0[CW], cp1[CW];
@@ -762,29 +809,29 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     if (!vec_only) {
       { const int row = r0 + min(tid, nrows - 1); rp0 = gptr(d.A.rowptr)[row]; rp1 = gptr(d.A.rowptr)[row + 1]; rrho = gptr(d.rho)[row]; }
 #pragma unroll
-      for (int u = 0; u < CW; u++) { if (u < ns2) { const int c = cpo + min(tid + u * kBlock, wl - 1); cp0[u] = gptr(f.cptr)[c]; cp1[u] = gptr(f.cptr)[c + 1]; } }
+      for (int u = 0; u < CW; u++) {
+        if (u < ns2) {
+          int c = min(tid + u * kBlock, wl - 1);
+          if constexpr (MIX) { const int cf = tid + u * kBlock - kFB; if (u == CW - 1 && cf >= 0 && cf < nfc) c = wl + cf; }      // a far segment: behind the window's
+          cp0[u] = gptr(f.cptr)[cpo + c]; cp1[u] = gptr(f.cptr)[cpo + c + 1];
+        }
+      }
       { const int j = min(cs0 + max(0, min(tid, nown - 1)), n - 1); pp0 = gptr(f.prp)[j]; pp1 = gptr(f.prp)[j + 1]; }
     }
-    // ---- operand of a (P + sigma I) entry whose column lies outside the window: its parts, requested now
+    // ---- a (P + sigma I) entry whose column lies outside the window: its operand is recomputed from its parts in the product phase below (requested
+    //      THERE: held from here they would cost 7 + 2 D registers across the block's register peak for a case banded problems never meet)
     const int pcl = pc - g0;
     const bool esc = hasp && !(pcl >= 0 && pcl < gl);
-    double em = 0, er = 0, es = 0, eq[D];
-#pragma unroll
-    for (int q = 0; q < D; q++) eq[q] = 0.0;
-    if (esc) {
-      em = Minv[pc];
-#pragma unroll
-      for (int q = 0; q < D; q++) eq[q] = repcur[q * ns + pc];
-      if (!FIRST) { er = rread[pc]; es = sprev[pc]; }
-    }
     KT(3);
     // ---- u_k on the window -> LDS; the lane of an own column also performs that column's vector update
 #pragma unroll
     for (int u = 0; u < CW; u++) {
       if (u < nw) {
-        const int e = min(tid + u * kBlock, gl - 1);
+        int e = min(tid + u * kBlock, gl - 1);
+        if constexpr (MIX) { const int ef = tid + u * kBlock; if (u == CW - 1 && ef >= kFB && ef - kFB < nfc) e = ef; }
         double un;
-        const double w = f1_w<D>(wq[u]);
+        double w = f1_w<D>(wq[u]);
+        if constexpr (MIX) w += f1_spill_sum(spcur, wsw[u], wst[u]);
         if constexpr (FIRST) {
           const double r0 = w;                              // rhs - K x_g: the slices' sum, the same expression in every workgroup that holds the column
           un = wm[u] * r0;
@@ -810,12 +857,14 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
 #pragma unroll
       for (int q = 0; q < D; q++) rp[q] = repcur[q * ns + j];
       double un;
+      double wj = f1_w<D>(rp);
+      if constexpr (MIX) wj += f1_spill_sum(spcur, spk, j);
       if constexpr (FIRST) {
-        const double r0 = f1_w<D>(rp);
+        const double r0 = wj;
         un = mi * r0;
         rnxt[j] = r0; gptr(d.xsp)[j] = xs_r[j]; xs_w[j] = gptr(d.xg)[j];
         g_acc += r0 * un; rn_acc = nanmax(rn_acc, fabs(r0));
-      } else un = own_update(j, mi, rread[j], f1_w<D>(rp), sprev[j], p_r[j], xs_r[j]);
+      } else un = own_update(j, mi, rread[j], wj, sprev[j], p_r[j], xs_r[j]);
       if (!vec_only) L.uown[jj] = un;
     }
     if (vec_only) continue;
@@ -825,17 +874,20 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     //      stream below (it cannot see that transfer: a later `s_waitcnt vmcnt(small)` for one of these values would wait for the stream too)
     f1_stream_wait();
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" :: "v"(rp0), "v"(rp1), "v"(rrho), "v"(pp0), "v"(pp1), "v"(pv), "v"(pc), "v"(em), "v"(er), "v"(es), "v"(eq[0]), "v"(eq[D - 1]));
+    asm volatile("" :: "v"(rp0), "v"(rp1), "v"(rrho), "v"(pp0), "v"(pp1), "v"(pv), "v"(pc));
 #pragma unroll
     for (int u = 0; u < CW; u++) { if (u < ns2) asm volatile("" :: "v"(cp0[u]), "v"(cp1[u])); }
+    if constexpr (MIX) asm volatile("" :: "v"(fql));
 #endif
     __syncthreads();
     // F_0: ||rhs||_inf of the own columns from the slices of rhs alone (requested now that the window's registers are free, folded at the block's end)
     [[maybe_unused]] double bv[D];
+    [[maybe_unused]] int bsw = 0; [[maybe_unused]] F1Spill bst{0.0, 0.0};
     if constexpr (FIRST) {
       const int j = cs0 + max(0, min(tid, nown - 1));
 #pragma unroll
       for (int q = 0; q < D; q++) bv[q] = repV[q * ns + j];
+      if constexpr (MIX) bsw = spk[j];
     }
     // ---- products: A entries against the window; the (P + sigma I) entry against the window or its recomputed operand
     double vw[CE]; unsigned int en[CE];
@@ -846,8 +898,16 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     if (hasp) {
       double uv;
       if (!esc) uv = L.win[pcl];
-      else if constexpr (FIRST) uv = em * f1_w<D>(eq);
-      else { double sn, rn; f1_upd(sc, em, er, f1_w<D>(eq), es, sn, rn, uv); }
+      else {
+        double eq[D];
+#pragma unroll
+        for (int q = 0; q < D; q++) eq[q] = repcur[q * ns + pc];
+        const double em = Minv[pc];
+        double ew = f1_w<D>(eq);
+        if constexpr (MIX) ew += f1_spill_sum(spcur, spk, pc);
+        if constexpr (FIRST) uv = em * ew;
+        else { double sn, rn; f1_upd(sc, em, rread[pc], ew, sprev[pc], sn, rn, uv); }
+      }
       L.pprod[tid] = pv * uv;
     }
     KT(5);
@@ -897,18 +957,20 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
           const int jo = a0 + c - cs0;
           if (jo >= 0 && jo < nown) v += L.puown[jo];         // this block owns the column: + (P + sigma I) u
           rout[a0 + c] = v;
+        } else if constexpr (MIX) {
+          if (u == CW - 1 && c >= kFB && c - kFB < nfc) spnxt[fql] = f1_segsum<8>(L.prod, cp0[u], cp1[u]);      // a far column's sum: the block's spill slot for it
         }
       }
     }
     for (int j = cov0 + tid; j < a0; j += kBlock) rout[j] = 0.0;             // the replica's gap up to the next window of this replica
     for (int j = a0 + wl + tid; j < cov1; j += kBlock) rout[j] = 0.0;
     if constexpr (FIRST) {
-      if (tid < nown) bn_acc = nanmax(bn_acc, fabs(f1_w<D>(bv)));
+      if (tid < nown) bn_acc = nanmax(bn_acc, fabs(MIX ? f1_w<D>(bv) + f1_spill_sum(spV, bsw, f1_spill_take(spV, bsw)) : f1_w<D>(bv)));
       for (int jj = tid + kBlock; jj < nown; jj += kBlock) {
         double rv[D];
 #pragma unroll
         for (int q = 0; q < D; q++) rv[q] = repV[q * ns + cs0 + jj];
-        bn_acc = nanmax(bn_acc, fabs(f1_w<D>(rv)));
+        bn_acc = nanmax(bn_acc, fabs(MIX ? f1_w<D>(rv) + f1_spill_sum(spV, spk, cs0 + jj) : f1_w<D>(rv)));
       }
     }
     KT(8);
@@ -936,14 +998,14 @@ __device__ __forceinline__ F1Rec f1_first_record(const int *blk, int nblk) {
 // D (the number of replica vectors, DevF1::D) is a TEMPLATE parameter of the kernels: a slot kernel that carries the bodies of all four
 // values pays for the three it never runs in every launch (the head of a launch is as long as the kernel's register / code footprint
 // makes it)
-template <int D>
+template <int D, bool MIX>
 __device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const int cap, const int admm_par, const int probe, F1Lds &L, F1Stream &S, const F1Rec &rec0, const F1Fold &fold, const int par) {
   KT(0);
   F1Scal sc;
   if (!f1_fold_finish(d, k, admm_par, probe, fold, L.red, sc)) return false;
   const bool vec_only = !probe && k >= cap;                 // the last budgeted update: no operator apply follows
-  if (k == 0) f1_body<D, true>(d, k, vec_only, sc, L, S, rec0, par);
-  else f1_body<D, false>(d, k, vec_only, sc, L, S, rec0, par);
+  if (k == 0) f1_body<D, true, MIX>(d, k, vec_only, sc, L, S, rec0, par);
+  else f1_body<D, false, MIX>(d, k, vec_only, sc, L, S, rec0, par);
   return true;
 }
 // the stream of the workgroup's FIRST row block: its address depends on nothing but the block index, so it leaves at the head of the launch,
@@ -966,27 +1028,32 @@ __device__ __forceinline__ void f1_stream_first(const unsigned char *stream, int
 // SCATTER_ONLY: the first launch of a chunk -- v, t0, x, x_g are in memory (a rho update, a warm start or the previous chunk left them): only
 // the transposed passes and the own-column terms run.  x~_prev is NOT advanced here (F_0's own lanes do that): this launch reads it for the
 // operands of P at columns other workgroups own.
-template <int D, bool SCATTER_ONLY>
+template <int D, bool SCATTER_ONLY, bool MIX>
 __device__ __forceinline__ void f1_ka_body(const Dev &d, F1Lds &L, F1Stream &S, const F1Rec &rec0, const double theta) {
   const DevF1 &f = d.f1;
   const int tid = threadIdx.x;
   const double *va = gptr(f.va); const size_t ns = f.ns;
   const double *xs_r = va + ns;
   double *repR = gptr(f.va) + (7 + (size_t)1 * D) * ns, *repV = gptr(f.va) + (7 + (size_t)2 * D) * ns;      // the parity-1 set (what F_0 reads as K u_{-1}'s place), the third set
+  [[maybe_unused]] double *spR = MIX ? gptr(f.spill) + (f.nsp + 2) : nullptr, *spVw = MIX ? gptr(f.spill) + 2 * (f.nsp + 2) : nullptr;      // per-block mixing: the spill sets that go with them
   const double alpha = d.alpha, sigma = d.sigma;
   const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, slots = gridDim.x >> 3;
   const int per = (d.A.nblk + 7) >> 3;
   constexpr int CW = kF1Win / kBlock, CE = kF1Chunk / kBlock;
+  constexpr int kFB = kF1Win - kF1MaxFar;
   for (int sl = slot0; sl < per; sl += slots) {
     const int b = __builtin_amdgcn_readfirstlane(xcd * per + sl);
     if (b >= d.A.nblk) break;
+    [[maybe_unused]] int fcl = 0, fql = 0;                   // MIX: the far slot of this lane (f1_body): column, spill slot
+    if constexpr (MIX) { if (tid >= kFB - (CW - 1) * kBlock) { const size_t i = (size_t)b * kF1MaxFar + (tid - (kFB - (CW - 1) * kBlock)); fcl = gptr(f.fcol)[2 * i]; fql = gptr(f.fq)[i]; } }
     const F1Rec rec = sl == slot0 ? rec0 : f1_record(f, b);
     const int4 ds = rec.ds, fa = rec.fa, fb = rec.fb, fc = rec.fc;
     const int r0 = ds.x, nrows = ds.y - ds.x, k0 = ds.z, cnt = ds.w - ds.z;
     const int cov0 = fa.x, cov1 = fa.y, cs0 = fa.z, nown = fa.w - fa.z;
     const int cpo = fb.x, pk0 = fb.y, pcnt = fb.z - fb.y;
     const int g0 = fc.x, gl = fc.y, a0 = fc.z, wl = fc.w;
-    const int nw = (gl + kBlock - 1) / kBlock, nu = (cnt + kBlock - 1) / kBlock, ns2 = (wl + kBlock - 1) / kBlock;
+    const int nfc = MIX ? fb.w : 0;                          // MIX: far columns in the last kF1MaxFar slots (f1_body)
+    const int nw = nfc ? CW : (gl + kBlock - 1) / kBlock, nu = (cnt + kBlock - 1) / kBlock, ns2 = nfc ? CW : (wl + kBlock - 1) / kBlock;
     // ---- loads: the (P + sigma I) entry of this lane and its operand x_g[column]
     double pv = 0.0; int pc = g0;
     const bool hasp = tid < pcnt;
@@ -1003,7 +1070,9 @@ __device__ __forceinline__ void f1_ka_body(const Dev &d, F1Lds &L, F1Stream &S, 
     for (int u = 0; u < CW; u++) {
       wown[u] = false;
       if (u < nw) {
-        const int e = tid + u * kBlock, c = g0 + min(e, gl - 1);
+        const int e = tid + u * kBlock;
+        int c = g0 + min(e, gl - 1);
+        if constexpr (MIX) { if (u == CW - 1 && e >= kFB && e - kFB < nfc) c = fcl; }
         wown[u] = e < gl && c >= cs0 && c - cs0 < nown;
         const int co = wown[u] ? c : g0;
         if (!SCATTER_ONLY) { wx[u] = xs_r[c]; wxp[u] = gptr(d.xsp)[co]; }
@@ -1018,14 +1087,21 @@ __device__ __forceinline__ void f1_ka_body(const Dev &d, F1Lds &L, F1Stream &S, 
       else { rp0 = gptr(d.A.rowptr)[row]; rp1 = gptr(d.A.rowptr)[row + 1]; el = gptr(d.l)[row]; eu = gptr(d.u)[row]; erho = gptr(d.rho)[row]; erinv = gptr(d.rho_inv)[row]; ez = gptr(d.z)[row]; ey = gptr(d.y)[row]; ezt = gptr(d.zt)[row]; } }
     int cp0[CW], cp1[CW];
 #pragma unroll
-    for (int u = 0; u < CW; u++) { if (u < ns2) { const int c = cpo + min(tid + u * kBlock, wl - 1); cp0[u] = gptr(f.cptr)[c]; cp1[u] = gptr(f.cptr)[c + 1]; } }
+    for (int u = 0; u < CW; u++) {
+      if (u < ns2) {
+        int c = min(tid + u * kBlock, wl - 1);
+        if constexpr (MIX) { const int cf = tid + u * kBlock - kFB; if (u == CW - 1 && cf >= 0 && cf < nfc) c = wl + cf; }
+        cp0[u] = gptr(f.cptr)[cpo + c]; cp1[u] = gptr(f.cptr)[cpo + c + 1];
+      }
+    }
     int pp0 = 0, pp1 = 0;
     { const int j = min(cs0 + max(0, min(tid, nown - 1)), d.n - 1); pp0 = gptr(f.prp)[j]; pp1 = gptr(f.prp)[j + 1]; }
     // ---- window -> LDS; the own lane updates x and leaves  sigma x - q  for its column
 #pragma unroll
     for (int u = 0; u < CW; u++) {
       if (u < nw) {
-        const int e = min(tid + u * kBlock, gl - 1);
+        int e = min(tid + u * kBlock, gl - 1);
+        if constexpr (MIX) { const int ef = tid + u * kBlock; if (u == CW - 1 && ef >= kFB && ef - kFB < nfc) e = ef; }
         if (!SCATTER_ONLY) L.win[e] = wx[u];
         if (wown[u]) {
           const int j = g0 + e;
@@ -1045,6 +1121,7 @@ __device__ __forceinline__ void f1_ka_body(const Dev &d, F1Lds &L, F1Stream &S, 
     asm volatile("" :: "v"(rp0), "v"(rp1), "v"(el), "v"(eu), "v"(erho), "v"(erinv), "v"(ez), "v"(ey), "v"(ezt), "v"(pp0), "v"(pp1), "v"(pv), "v"(pc), "v"(pxs), "v"(pxp));
 #pragma unroll
     for (int u = 0; u < CW; u++) { if (u < ns2) asm volatile("" :: "v"(cp0[u]), "v"(cp1[u])); }
+    if constexpr (MIX) asm volatile("" :: "v"(fql));
 #endif
     __syncthreads();
     double vw[CE]; unsigned int en[CE];
@@ -1109,7 +1186,10 @@ __device__ __forceinline__ void f1_ka_body(const Dev &d, F1Lds &L, F1Stream &S, 
     __syncthreads();
     double cv[CW];
 #pragma unroll
-    for (int u = 0; u < CW; u++) { cv[u] = 0.0; if (u < ns2) { const int c = tid + u * kBlock; if (c < wl) cv[u] = f1_segsum<8>(L.prod, cp0[u], cp1[u]); } }
+    for (int u = 0; u < CW; u++) {
+      cv[u] = 0.0;
+      if (u < ns2) { const int c = tid + u * kBlock; if (c < wl || (MIX && u == CW - 1 && c >= kFB && c - kFB < nfc)) cv[u] = f1_segsum<8>(L.prod, cp0[u], cp1[u]); }
+    }
     __syncthreads();
     // ---- second pass: A_g' t0
     if (tid < nrows) L.tvec[tid] = t0r;
@@ -1128,6 +1208,8 @@ __device__ __forceinline__ void f1_ka_body(const Dev &d, F1Lds &L, F1Stream &S, 
           const int jo = a0 + c - cs0;
           if (jo >= 0 && jo < nown) { tv += L.uown[jo]; tt += L.puown[jo]; }      // this block owns the column: + sigma x - q  resp.  + (P + sigma I) x_g
           routV[a0 + c] = tv; routR[a0 + c] = tv - tt;                             // slices of rhs, and of r_0 = rhs - K x_g
+        } else if constexpr (MIX) {
+          if (u == CW - 1 && c >= kFB && c - kFB < nfc) { const double tv = cv[u], tt = f1_segsum<8>(L.prod, cp0[u], cp1[u]); spVw[fql] = tv; spR[fql] = tv - tt; }      // a far column: the block's spill slots
         }
       }
     }
@@ -1137,11 +1219,11 @@ __device__ __forceinline__ void f1_ka_body(const Dev &d, F1Lds &L, F1Stream &S, 
   }
 }
 // KA of the slot machine in the F1 form: extrapolation weight, the body above, PCG statistics of the ADMM iteration that ends (as slot_ka)
-template <int D>
+template <int D, bool MIX>
 __device__ __forceinline__ void f1_slot_ka(const Dev &d, F1Lds &L, F1Stream &S, const F1Rec &rec0, int used, int conv, int admm, int target, int rn_slot, int seq) {
   double theta = d.theta, rn_last = 0.0, bn_last = 0.0;
   if (!conv) { theta = cutoff_theta(d, rn_slot, L.red, rn_last, bn_last, admm); __syncthreads(); }      // (conv comes from the slot record: uniform)
-  f1_ka_body<D, false>(d, L, S, rec0, theta);
+  f1_ka_body<D, false, MIX>(d, L, S, rec0, theta);
   if (blockIdx.x == 0) {
     if (!conv) {
       const double rn = rn_last, bn = bn_last;
@@ -1167,24 +1249,24 @@ __global__ __launch_bounds__(kBlock) void k_f1_refresh(Dev d) {
 }
 // timing probe: one F launch as a solve runs it -- the scalar fold of the previous launch's partials included -- with fixed alpha, beta
 // and no stopping test (mode 2; mode 1 skips the fold: what the launch costs without it)
-template <int D>
+template <int D, bool MIX>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_f1_probe(Dev d, int k, int mode) {
   __shared__ F1Lds lds;
   __shared__ F1Stream sbuf;
   const int par = k & 1;
   f1_stream_first(d.f1.stream, d.A.nblk, sbuf);
   const F1Fold fold = f1_fold_issue(gptr(d.part), par, mode);
-  f1_iteration<D>(d, k, 1 << 30, 0, mode, lds, sbuf, f1_first_record(d.f1.blk, d.A.nblk), fold, par);      // (the first block's record goes out ahead of the partials of the scalar fold: both latencies overlap)
+  f1_iteration<D, MIX>(d, k, 1 << 30, 0, mode, lds, sbuf, f1_first_record(d.f1.blk, d.A.nblk), fold, par);      // (the first block's record goes out ahead of the partials of the scalar fold: both latencies overlap)
 }
 
 // timing probes of the KA body above (time_kernel 17 / 18)
-template <int D>
+template <int D, bool MIX>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_f1_ka_probe(Dev d, int scatter_only) {
   __shared__ F1Lds lds;
   __shared__ F1Stream sbuf;
   f1_stream_first(d.f1.stream, d.A.nblk, sbuf);
   const F1Rec rec0 = f1_first_record(d.f1.blk, d.A.nblk);
-  if (scatter_only) f1_ka_body<D, true>(d, lds, sbuf, rec0, d.theta); else f1_ka_body<D, false>(d, lds, sbuf, rec0, d.theta);
+  if (scatter_only) f1_ka_body<D, true, MIX>(d, lds, sbuf, rec0, d.theta); else f1_ka_body<D, false, MIX>(d, lds, sbuf, rec0, d.theta);
 }
 
 // The slot kernel of the F1 form: every launch of a chunk's string is this kernel (par: which of the two phase records it reads).  Every phase is
@@ -1200,7 +1282,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 // copy as one 48-byte block.  be::dev_publish keeps the copy current (slot_begin / ctl_begin: once per chunk, never inside a capture).
 struct F1Head { const unsigned char *stream; const int *blk; const double *part; const int *slot; int nblk, pad; };
 struct F1DevBlock { F1Head h; Dev d; };
-template <int D>
+template <int D, bool MIX>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_slot1(const F1DevBlock *__restrict__ blk, int par) {
   __shared__ F1Lds lds;
   __shared__ F1Stream sbuf;
@@ -1216,20 +1298,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   SlotState st = slot_read_scalar(R);
   if (st.ph == P_KB) {
     if (st.admm >= st.target) { st.ph = P_IDLE; f1_stream_wait(); slot_write(W, st); return; }
-    f1_ka_body<D, true>(d, lds, sbuf, rec0, 0.0);
+    f1_ka_body<D, true, MIX>(d, lds, sbuf, rec0, 0.0);
     if (blockIdx.x == 0 && threadIdx.x == 0) { gptr(d.flags)[F_DONE] = 0; gptr(d.flags)[F_ITERS] = 0; }
     st.ph = P_F; st.k = 0;
   } else if (st.ph == P_F) {
-    if (f1_iteration<D>(d, st.k, st.cap, st.admm & 1, 0, lds, sbuf, rec0, fold, par)) {
+    if (f1_iteration<D, MIX>(d, st.k, st.cap, st.admm & 1, 0, lds, sbuf, rec0, fold, par)) {
       if (st.k >= st.cap) { st.ph = P_KA; st.used = st.k; st.conv = 0; }      // stopped at the cap: the next launch runs KA
       else st.k += 1;
     } else {                                             // converged after k - 1 iterations (k = 1: the start met the tolerance): KA right here
       __syncthreads();
-      f1_slot_ka<D>(d, lds, sbuf, rec0, st.k - 1, 1, st.admm, st.target, 0, st.seq);
+      f1_slot_ka<D, MIX>(d, lds, sbuf, rec0, st.k - 1, 1, st.admm, st.target, 0, st.seq);
       st.admm += 1; st.k = 0; st.ph = st.admm >= st.target ? P_IDLE : P_F;
     }
   } else if (st.ph == P_KA) {
-    f1_slot_ka<D>(d, lds, sbuf, rec0, st.used, st.conv, st.admm, st.target, par ^ 1, st.seq);
+    f1_slot_ka<D, MIX>(d, lds, sbuf, rec0, st.used, st.conv, st.admm, st.target, par ^ 1, st.seq);
     st.admm += 1; st.k = 0; st.ph = st.admm >= st.target ? P_IDLE : P_F;
   } else f1_stream_wait();                               // (idle: nothing may be in flight when the workgroup's LDS is released)
   slot_write(W, st);
@@ -1275,17 +1357,27 @@ void dev_release(Dev &d) {
   if (p.pin_block) { (void)hipHostFree(p.pin_block); p.pin_block = nullptr; }
   if (p.shadow_block) { std::free(p.shadow_block); p.shadow_block = nullptr; }
 }
+// the F1 kernels are templates on D (replica vectors) and MIX (per-block mixing: far columns / spill slots, backend.h DevF1::mix)
+template <class F>
+static void f1_dispatch(const Dev &d, F &&f) {
+  auto with_d = [&](auto Dc) { if (d.f1.mix) f(Dc, std::true_type{}); else f(Dc, std::false_type{}); };
+  switch (d.f1.D) {
+    case 1: with_d(std::integral_constant<int, 1>{}); break;
+    case 2: with_d(std::integral_constant<int, 2>{}); break;
+    case 3: with_d(std::integral_constant<int, 3>{}); break;
+    default: with_d(std::integral_constant<int, 4>{}); break;
+  }
+}
 void slot_begin(Dev &d, int target, int cap) { HIP_CHECK(hipSetDevice(d.device)); dev_publish(d); hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(1), 0, st(d), d.slot, target, cap, ++im(d).epoch); }
 void slot_pair(Dev &d) {
   if (wbx_slots(d)) { wbx_slot_pair(d); return; }      // Woodbury direct mode: X, Y (wbdirect_hip.hip)
   if (d.f1.on) {
     const F1DevBlock *db = static_cast<const F1DevBlock *>(im(d).dev_block);      // (current as of the chunk's slot_begin / ctl_begin: dev_publish)
-    switch (d.f1.D) {
-      case 1: LAUNCH(k_slot1<1>, d, db, 0); LAUNCH(k_slot1<1>, d, db, 1); break;
-      case 2: LAUNCH(k_slot1<2>, d, db, 0); LAUNCH(k_slot1<2>, d, db, 1); break;
-      case 3: LAUNCH(k_slot1<3>, d, db, 0); LAUNCH(k_slot1<3>, d, db, 1); break;
-      default: LAUNCH(k_slot1<4>, d, db, 0); LAUNCH(k_slot1<4>, d, db, 1); break;
-    }
+    f1_dispatch(d, [&](auto Dc, auto Mc) {
+      constexpr int DD = decltype(Dc)::value; constexpr bool MM = decltype(Mc)::value;
+      hipLaunchKernelGGL((k_slot1<DD, MM>), dim3(kGrid), dim3(kBlock), 0, st(d), db, 0);
+      hipLaunchKernelGGL((k_slot1<DD, MM>), dim3(kGrid), dim3(kBlock), 0, st(d), db, 1);
+    });
   }
   else { LAUNCH(k_slot_b, d, d); LAUNCH(k_slot_a, d, d); }
 }
@@ -1324,12 +1416,11 @@ __global__ void k_slot_probe_f(int *slot, double *scal, int k0) {
   scal[S_TOL_NOW] = -1.0;
 }
 static void f1_probe_pair(Dev &d, int mode) {           // two consecutive F launches of the probe kernel (the double-buffered vectors alternate)
-  switch (d.f1.D) {
-    case 1: LAUNCH(k_f1_probe<1>, d, d, 2, mode); LAUNCH(k_f1_probe<1>, d, d, 3, mode); break;
-    case 2: LAUNCH(k_f1_probe<2>, d, d, 2, mode); LAUNCH(k_f1_probe<2>, d, d, 3, mode); break;
-    case 3: LAUNCH(k_f1_probe<3>, d, d, 2, mode); LAUNCH(k_f1_probe<3>, d, d, 3, mode); break;
-    default: LAUNCH(k_f1_probe<4>, d, d, 2, mode); LAUNCH(k_f1_probe<4>, d, d, 3, mode); break;
-  }
+  f1_dispatch(d, [&](auto Dc, auto Mc) {
+    constexpr int DD = decltype(Dc)::value; constexpr bool MM = decltype(Mc)::value;
+    hipLaunchKernelGGL((k_f1_probe<DD, MM>), dim3(kGrid), dim3(kBlock), 0, st(d), d, 2, mode);
+    hipLaunchKernelGGL((k_f1_probe<DD, MM>), dim3(kGrid), dim3(kBlock), 0, st(d), d, 3, mode);
+  });
 }
 float time_kernel(Dev &d, int which, int reps) {
   HIP_CHECK(hipSetDevice(d.device));
@@ -1375,12 +1466,10 @@ float time_kernel(Dev &d, int which, int reps) {
       case 14: f1_probe_pair(d, 1); break;   // F1 form without the scalar fold at the head of the launch (two consecutive iterations)
       case 16: slot_pair(d); break;           // two F launches of the slot kernel itself (records set up by k_slot_probe_f below): what a launch costs inside a solve
       case 17: case 18:                      // KA of the F1 form (17) / the chunk's first launch, transposed passes only (18)
-        switch (d.f1.D) {
-          case 1: LAUNCH(k_f1_ka_probe<1>, d, d, which == 18); break;
-          case 2: LAUNCH(k_f1_ka_probe<2>, d, d, which == 18); break;
-          case 3: LAUNCH(k_f1_ka_probe<3>, d, d, which == 18); break;
-          default: LAUNCH(k_f1_ka_probe<4>, d, d, which == 18); break;
-        }
+        f1_dispatch(d, [&](auto Dc, auto Mc) {
+          constexpr int DD = decltype(Dc)::value; constexpr bool MM = decltype(Mc)::value;
+          hipLaunchKernelGGL((k_f1_ka_probe<DD, MM>), dim3(kGrid), dim3(kBlock), 0, st(d), d, (int)(which == 18));
+        });
         break;
       case 21: HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, 0, sizeof(int), st(d))); wb_apply(d, 0, 1); break;      // (the last kernel marks the solve as converged: cleared per repetition)     // Woodbury direct mode, device-factorised form: the three kernels of M^-1 = K^-1 (long rows, S^-1 product, transposed long rows + x~)
       case 15: f1_probe_pair(d, 2); break;   // F1 form: one PCG iteration = one launch; two consecutive iterations as a solve runs them (buffers alternate, fold included)

@@ -163,13 +163,48 @@ def test_f1_form_follows_matrix_updates(monkeypatch):
     assert abs(r1.info.obj_val - r0.info.obj_val) > 1e-6 * (1 + abs(r0.info.obj_val))      # (the update did change the problem)
 
 
-def test_band_plus_long_range_couplings_matches_the_oracle():
-    """`bench.py --config mixed`: 2 % of A's entries moved to columns drawn from the whole range.  The one-launch form does not apply to such a
-    matrix (a block with a far column has no compact window); whatever form the engine picks, the solution is the oracle's."""
-    P, q, A, l, u = problems.banded_qp(6000, window=60, long_range=0.02)
-    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, eps_abs=1e-8, eps_rel=1e-8, verbose=False, max_iter=50000, adaptive_rho_interval=50, check_termination=25)
-    r = m.solve()
-    xo, yo, io = Oracle().setup(P, q, A, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=100000, adaptive_rho_interval=50).solve()
-    assert r.info.status_val == 1 and io.status_val == SOLVED
-    assert np.abs(r.x - xo).max() <= 2e-6 * (1 + np.abs(xo).max()) and np.abs(r.y - yo).max() <= 4e-6 * (1 + np.abs(yo).max())
-    assert abs(r.info.obj_val - io.obj_val) <= 1e-7 * (1 + abs(io.obj_val))
+def _solve_f1(P, q, A, l, u, f1, **kw):
+    old = os.environ.get('OSQP_HIP_F1')
+    os.environ['OSQP_HIP_F1'] = str(f1)
+    try:
+        st = dict(eps_abs=1e-6, eps_rel=1e-6, max_iter=20000, adaptive_rho_interval=50, check_termination=25, verbose=False)
+        st.update(kw)
+        m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, **st)
+        r = m.solve()
+        return m, r, m._solver.hip_stats()
+    finally:
+        if old is None:
+            os.environ.pop('OSQP_HIP_F1', None)
+        else:
+            os.environ['OSQP_HIP_F1'] = old
+
+
+@pytest.mark.parametrize('n,window,frac', [(20000, 40, 0.02), (20000, 40, 0.002), (100000, 200, 0.02)])
+def test_band_plus_long_range_couplings_run_the_one_launch_form(n, window, frac):
+    """`bench.py --config mixed`: a fraction of A's entries moved to columns drawn from the whole range.  Per-block mixing (backend.h DevF1::mix): a block
+    keeps its densest window and takes the other columns as far columns -- the one-launch form applies, with the same results as the two-kernel
+    form (OSQP_HIP_F1=2: strict windows, which such a matrix does not have) and as the oracle's direct solve."""
+    P, q, A, l, u = problems.banded_qp(n, window=window, long_range=frac)
+    m1, r1, s1 = _solve_f1(P, q, A, l, u, 1)
+    m0, r0, s0 = _solve_f1(P, q, A, l, u, 2)
+    assert int(s1['pcg_fused']) == 2 and 1 <= int(s1['f1_replicas']) <= 4 and s1['f1_far_columns'] > 0, s1
+    assert int(s0['pcg_fused']) == 1 and int(s0['f1_replicas']) == 0 and s0['f1_far_columns'] == 0
+    assert r1.info.status_val == r0.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED
+    print('n=%d long-range %.3f: %d far columns; mixing: %d iterations, %.1f PCG each, %d launches; two-kernel: %d iterations, %.1f PCG each, %d launches; |dx| %.2e |dy| %.2e'
+          % (n, frac, s1['f1_far_columns'], r1.info.iter, s1['pcg_iters_total'] / r1.info.iter, s1['kernel_launches'], r0.info.iter,
+             s0['pcg_iters_total'] / r0.info.iter, s0['kernel_launches'], _rel(r1.x, r0.x), _rel(r1.y, r0.y)))
+    assert _rel(r1.x, r0.x) < 1e-4 and _rel(r1.y, r0.y) < 1e-4
+    assert abs(r1.info.obj_val - r0.info.obj_val) <= 1e-6 * (1 + abs(r0.info.obj_val))
+    assert abs(r1.info.iter - r0.info.iter) <= 50
+    assert s1['kernel_launches'] < 0.75 * s0['kernel_launches']
+    _, rb, _ = _solve_f1(P, q, A, l, u, 1)               # deterministic: fixed summation order, no atomics
+    assert rb.info.iter == r1.info.iter and np.array_equal(rb.x, r1.x) and np.array_equal(rb.y, r1.y)
+    if n <= 20000:
+        kw = dict(eps_abs=1e-8, eps_rel=1e-8, max_iter=50000)
+        _, rt, st = _solve_f1(P, q, A, l, u, 1, **kw)
+        assert int(st['pcg_fused']) == 2 and st['f1_far_columns'] > 0
+        xo, yo, io = Oracle().setup(P, q, A, l, u, adaptive_rho_interval=50, check_termination=25, **kw).solve()
+        assert io.status_val == SOLVED and rt.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED
+        print('tight: engine %d iterations, oracle %d; |dx| %.2e |dy| %.2e' % (rt.info.iter, io.iter, _rel(rt.x, xo), _rel(rt.y, yo)))
+        assert _rel(rt.x, xo) < 2e-6 and _rel(rt.y, yo) < 4e-6
+        assert abs(rt.info.obj_val - io.obj_val) <= 1e-7 * (1 + abs(io.obj_val))
