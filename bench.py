@@ -455,7 +455,7 @@ def main():
                        # (rho updates of the last solve served by an inverse the handle had computed for the same rho_bar in an EARLIER solve -- every step of this
                        #  bench restarts from the setting's rho and walks the same rho values; first_cold_solve_ms is the figure without any cached inverse)
                        'woodbury_cache_hits_last_solve': int(stats.get('woodbury_cache_hits', 0)),
-                       'pcg_kernels_per_iteration': 1 if f1 else (2 if fused else 3), 'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
+                       'pcg_kernels_per_iteration': 1 if f1 else (2 if fused else 3), 'f1_replicas': int(stats.get('f1_replicas', 0)), 'f1_far_columns': int(stats.get('f1_far_columns', 0)), 'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
                        'setup_s': t_setup, 'per_rank': [{'status': int(r[0]), 'iter': int(r[1]), 'obj': r[2]} for r in allrec]},
             'roofline': None if hostsim else {'bound': 'hbm', 'kernel': dom + (' -- in solves this body runs as the K2F phase of k_slot_b' if (fused and not f1) else ''), 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': probes[dom]['GBps'] / HBM_PEAK_GBS, 'traffic': pmc_traffic(dom_kernel, wl_tag),

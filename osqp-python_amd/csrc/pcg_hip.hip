@@ -1282,6 +1282,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 // copy as one 48-byte block.  be::dev_publish keeps the copy current (slot_begin / ctl_begin: once per chunk, never inside a capture).
 struct F1Head { const unsigned char *stream; const int *blk; const double *part; const int *slot; int nblk, pad; };
 struct F1DevBlock { F1Head h; Dev d; };
+// (Per-block mixing, tried: the far lanes of the workgroup's first row block touching their lines at the head of the launch -- both parities, as LDS-direct
+//  loads into a scratch KB, so that the body's requests find them in this XCD's L2 instead of waiting for memory: the solve got SLOWER, 80 -> 95 ms on
+//  `bench.py --config mixed` (tools/mix_ab.py); the extra requests ahead of the fold's partials cost more than the late far lines do.)
 template <int D, bool MIX>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_slot1(const F1DevBlock *__restrict__ blk, int par) {
   __shared__ F1Lds lds;
