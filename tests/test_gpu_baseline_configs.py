@@ -109,6 +109,35 @@ def test_config3_lasso_full_size():
     print('lasso full: iter', r.info.iter, m._solver.hip_stats())
 
 
+def test_config3_lasso_full_size_duality_gap_at_1e_8():
+    """configs[2] at FULL size and eps 1e-8, certified without the oracle (its PCG path needs minutes per ADMM iteration here) and without the
+    engine's own multipliers: the classic lasso  min ||Ad x - b||^2 + lam ||x||_1  has the dual  max -1/4 ||nu||^2 - b' nu  s.t. ||Ad' nu||_inf <= lam.
+    From the returned x alone: nu = 2 (Ad x - b), scaled into the dual feasible set, bounds the optimal value from below; the primal value from
+    above.  A relative gap of 3e-7 pins the objective independently of every tolerance of the solver (the Woodbury direct mode's acceptance
+    threshold included); the subgradient conditions pin the support."""
+    nf, ns = 5000, 10000
+    P, q, A, l, u = problems.lasso_qp(nf, ns)
+    m = osqp_amd.OSQP(); m.setup(P, q, A, l, u, eps_abs=1e-8, eps_rel=1e-8, verbose=False, max_iter=50000)
+    r = m.solve()
+    certify(P, q, A, l, u, r, eps=1e-8)
+    Ad = A[:ns, :nf]; b = l[:ns]; lam = q[nf + ns]
+    x = r.x[:nf]
+    res = Ad @ x - b
+    g = 2.0 * (Ad.T @ res)
+    primal = float(res @ res + lam * np.abs(x).sum())
+    nu = 2.0 * res * min(1.0, lam / np.abs(g).max())
+    dual = float(-0.25 * (nu @ nu) - b @ nu)
+    gap = (primal - dual) / max(1.0, abs(primal))
+    on = np.abs(x) > 1e-7
+    viol_off = max(0.0, float(np.abs(g).max() / lam - 1.0))
+    viol_on = float(np.abs(g[on] + lam * np.sign(x[on])).max() / lam) if on.any() else 0.0
+    print('lasso full 1e-8: iter %d, %.0f ms, primal %.9e dual %.9e relative gap %.2e; support %d of %d; subgradient: |g| <= lam exceeded by %.2e, on the support off by %.2e; objective %.9e'
+          % (r.info.iter, m._solver.hip_stats()['gpu_solve_ms'], primal, dual, gap, int(on.sum()), nf, viol_off, viol_on, r.info.obj_val))
+    assert -1e-12 <= gap <= 3e-7                                            # (measured 5.6e-8)
+    assert viol_off <= 1e-7 and viol_on <= 1e-7                               # (measured 3.6e-9 / 3.8e-9)
+    assert abs(r.info.obj_val - primal) <= 1e-6 * (1 + abs(primal))       # (the QP's objective y'y + lam 1't at t = |x|, y = Ad x - b)
+
+
 def test_config4_portfolio_full_size():
     """Portfolio factor model n=10k assets, k=100 factors (block-sparse P, rho heterogeneity, one 10k-entry row)."""
     P, q, A, l, u = problems.portfolio_qp(10000, 100)
