@@ -18,7 +18,7 @@ PY
 }
 summ banded gpurun_out/${tag}_bench.json
 if [ "$mode" != quick ]; then
-  for cfg in shuffled unstructured portfolio lasso; do
+  for cfg in mixed shuffled unstructured portfolio lasso; do
     st=5; [ $cfg = lasso ] && st=2
     timeout 900 python bench.py --config $cfg --steps $st --warmup 1 --cpu-seconds 30 --batch 0 > gpurun_out/${tag}_bench_$cfg.json 2>> gpurun_out/${tag}_bench.err < /dev/null
     summ $cfg gpurun_out/${tag}_bench_$cfg.json
@@ -39,4 +39,10 @@ if [ "$mode" = big ]; then
   timeout 900 bash tools/prof_config.sh ${tag}_n1M --n 1000000 --steps 2 --warmup 1 < /dev/null | head -6
   timeout 900 bash profiles/run_pmc.sh $tag banded_n1000000 --n 1000000 --steps 1 --warmup 0 --batch 0 < /dev/null 2>&1 | grep -E "k_f1_probe|k_slot1" | head -4
   timeout 600 bash tools/prof_config.sh ${tag}_portfolio --config portfolio --steps 2 --warmup 1 < /dev/null | grep -E "k_wbx|k_wb_S"
+  timeout 600 bash tools/prof_config.sh ${tag}_mixed --config mixed --steps 2 --warmup 1 < /dev/null | grep -E "k_slot1" | head -3
+  # the batch path (configs[4]): bench line, where a problem's time goes, and the per-block mixing A/B + fuzz
+  timeout 600 python bench_batch.py --steps 10 > gpurun_out/${tag}_bench_batch.json 2>> gpurun_out/${tag}_bench.err < /dev/null; tail -c 300 gpurun_out/${tag}_bench_batch.json; echo
+  timeout 300 python tools/batch_trace.py 256 2>/dev/null | tail -4 > gpurun_out/${tag}_batch_trace.txt; timeout 300 python tools/batch_trace.py 4096 2>/dev/null | tail -4 >> gpurun_out/${tag}_batch_trace.txt
+  timeout 600 python tools/mix_ab.py 0.02 2>/dev/null | grep iters > gpurun_out/${tag}_mix_ab.txt; cat gpurun_out/${tag}_mix_ab.txt
+  timeout 900 python tools/mix_fuzz.py 15 2 2>/dev/null | grep -E "^ok|^BAD|cases" > gpurun_out/${tag}_mix_fuzz_seed2.txt; tail -1 gpurun_out/${tag}_mix_fuzz_seed2.txt
 fi
