@@ -712,7 +712,9 @@ __device__ __forceinline__ double f1_spill_sum(const double *sp, const int *spk,
 // (Tried: the scalar fold INSIDE the body, behind the first block's vector requests, so that the two round trips overlap -- the fold's 24 partial
 //  registers on top of the window's cost 36 - 128 bytes of scratch per lane and the launch time did not move: 24.97 vs 24.66 us per pair.  In two steps --
 //  the lane's share of the partials reduced to three doubles BEFORE the requests, the block reduction behind them -- no scratch, but the solve got
-//  slower: 44.3 -> 46.4 ms, 12.42 -> 13.03 us per F launch: the requests then wait for the partials instead of the other way round.)
+//  slower: 44.3 -> 46.4 ms, 12.42 -> 13.03 us per F launch: the requests then wait for the partials instead of the other way round.
+//  Also tried: the NEXT block's record and the first window element of every lane (3 + D values) requested during the current block, next to the next
+//  block's stream (n >= 1M, ten blocks per workgroup): 123 VGPRs, no scratch -- n = 1M unchanged (98.3 us per launch), n = 100k 12.5 -> 13.0 us.)
 template <int D, bool FIRST, bool MIX>
 __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool vec_only, const F1Scal sc, F1Lds &L, F1Stream &S, const F1Rec &rec0, const int par) {
   const DevF1 &f = d.f1;
