@@ -7,6 +7,7 @@ import warnings
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 import osqp_amd
 import problems
@@ -208,3 +209,36 @@ def test_band_plus_long_range_couplings_run_the_one_launch_form(n, window, frac)
         print('tight: engine %d iterations, oracle %d; |dx| %.2e |dy| %.2e' % (rt.info.iter, io.iter, _rel(rt.x, xo), _rel(rt.y, yo)))
         assert _rel(rt.x, xo) < 2e-6 and _rel(rt.y, yo) < 4e-6
         assert abs(rt.info.obj_val - io.obj_val) <= 1e-7 * (1 + abs(io.obj_val))
+
+
+def test_mixing_form_through_updates_warm_start_and_polish():
+    """The per-block mixing form behind the rest of the API: data updates (q, bounds, the values of A and P by index), a warm-started re-solve and the
+    polish step give what a fresh handle in the two-kernel form gives for the updated problem."""
+    n = 20000
+    P, q, A, l, u = problems.banded_qp(n, window=40, long_range=0.01)
+    m1, r1, s1 = _solve_f1(P, q, A, l, u, 1, polishing=True)
+    assert int(s1['pcg_fused']) == 2 and s1['f1_far_columns'] > 0
+    rng = np.random.default_rng(3)
+    q2 = q + 0.05 * rng.standard_normal(n); l2 = l - 0.1; u2 = u + 0.2
+    A2 = A.copy(); A2.data = A2.data * (1.0 + 0.05 * rng.standard_normal(A2.nnz))
+    P2 = P.copy(); P2.data = P2.data * 1.1
+    old = os.environ.get('OSQP_HIP_F1'); os.environ['OSQP_HIP_F1'] = '1'
+    try:
+        m1.update(q=q2, l=l2, u=u2)
+        m1.update(Ax=A2.data, Px=sp.triu(P2, format='csc').data)
+        rw = m1.solve()                                   # warm-started from the first solution
+    finally:
+        if old is None:
+            os.environ.pop('OSQP_HIP_F1', None)
+        else:
+            os.environ['OSQP_HIP_F1'] = old
+    sw = m1._solver.hip_stats()
+    assert int(sw['pcg_fused']) == 2 and sw['f1_far_columns'] == s1['f1_far_columns']
+    m0, r0, s0 = _solve_f1(P2, q2, A2, l2, u2, 2, polishing=True)
+    assert int(s0['pcg_fused']) == 1
+    assert rw.info.status_val == r0.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED
+    print('updated problem: mixing (warm) %d iterations, two-kernel (cold) %d; polish %d / %d; |dx| %.2e |dy| %.2e'
+          % (rw.info.iter, r0.info.iter, rw.info.status_polish, r0.info.status_polish, _rel(rw.x, r0.x), _rel(rw.y, r0.y)))
+    assert _rel(rw.x, r0.x) < 1e-4 and _rel(rw.y, r0.y) < 1e-4
+    assert abs(rw.info.obj_val - r0.info.obj_val) <= 1e-6 * (1 + abs(r0.info.obj_val))
+    assert rw.info.status_polish == r0.info.status_polish
