@@ -175,7 +175,9 @@ bool Engine::plan_f1(const std::vector<int> &rb, const std::vector<int> &Arp, co
           else if (cur > best) { best = cur; bi = ci; bj = t; }
         }
         const int far = U - (bj - bi + 1);
-        if (far <= kF1MaxFar && dc[bj] - dc[bi] + 1 <= (far ? kF1Win - kF1MaxFar : kF1Win)) { found = true; lo = dc[bi]; hi = dc[bj]; nfar[b] = far; }
+        // (a run that holds less than half of the block's entries is no window -- columns spread at a constant stride have no positive run at all)
+        const long inside = std::upper_bound(sc.begin(), sc.end(), dc[bj]) - std::lower_bound(sc.begin(), sc.end(), dc[bi]);
+        if (far <= kF1MaxFar && 2 * inside >= (long)sc.size() && dc[bj] - dc[bi] + 1 <= (far ? kF1Win - kF1MaxFar : kF1Win)) { found = true; lo = dc[bi]; hi = dc[bj]; nfar[b] = far; }
       }
       if (!found && hi - lo + 1 <= kF1Win) found = true;                     // (a block that fits as it is)
       if (!found) {                                                            // ... or, failing that, the window of that width holding the most entries

@@ -242,3 +242,32 @@ def test_mixing_form_through_updates_warm_start_and_polish():
     assert _rel(rw.x, r0.x) < 1e-4 and _rel(rw.y, r0.y) < 1e-4
     assert abs(rw.info.obj_val - r0.info.obj_val) <= 1e-6 * (1 + abs(r0.info.obj_val))
     assert rw.info.status_polish == r0.info.status_polish
+
+
+def test_mixing_plan_on_strided_columns_with_outliers():
+    """Columns at a constant stride of 8 inside the band (no run of neighbouring columns at all: the plan's window choice has to fall back to the
+    window holding the most entries) plus 1 % long-range entries: whatever form the plan arrives at, the solution is the two-kernel form's."""
+    n, m, k = 40000, 80000, 5
+    rng = np.random.default_rng(11)
+    centre = (np.arange(m, dtype=np.int64) * n) // m
+    base = np.clip((centre // 8) * 8 - 80, 0, n - 8 * 24)
+    pick = np.sort(np.argsort(rng.random((m, 24)), axis=1)[:, :k], axis=1)
+    cols = base[:, None] + 8 * pick
+    far = rng.random((m, k)) < 0.01
+    cols = np.where(far, rng.integers(0, n, size=(m, k)), cols)
+    cols.sort(axis=1)
+    dup = (np.diff(cols, axis=1) == 0).any(axis=1)
+    cols[dup] = (base[dup, None] + 8 * pick[dup])
+    A = sp.csr_matrix((rng.standard_normal(m * k), cols.ravel().astype(np.int32), np.arange(0, m * k + 1, k, dtype=np.int32)), shape=(m, n)).tocsc()
+    A.sort_indices()
+    P = sp.diags(rng.uniform(0.5, 1.5, n)).tocsc()
+    q = rng.standard_normal(n)
+    x0 = 0.1 * rng.standard_normal(n); ax0 = A @ x0
+    l = ax0 - rng.uniform(0, 1, m); u = ax0 + rng.uniform(0, 1, m)
+    m1, r1, s1 = _solve_f1(P, q, A, l, u, 1)
+    m0, r0, s0 = _solve_f1(P, q, A, l, u, 2)
+    print('strided: form %d, D %d, far %d; %d / %d iterations; |dx| %.2e |dy| %.2e; %.1f / %.1f ms'
+          % (s1['pcg_fused'], s1['f1_replicas'], s1['f1_far_columns'], r1.info.iter, r0.info.iter, _rel(r1.x, r0.x), _rel(r1.y, r0.y), s1['gpu_solve_ms'], s0['gpu_solve_ms']))
+    assert r1.info.status_val == r0.info.status_val == osqp_amd.SolverStatus.OSQP_SOLVED
+    assert _rel(r1.x, r0.x) < 1e-4 and _rel(r1.y, r0.y) < 1e-4
+    assert abs(r1.info.obj_val - r0.info.obj_val) <= 1e-6 * (1 + abs(r0.info.obj_val))
