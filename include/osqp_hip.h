@@ -306,7 +306,8 @@ typedef struct {
   OSQPInt slots;              /* device-side scheduling of the ADMM / PCG phases ("slot" kernels)                               [setup] */
   OSQPInt pcg_fused;          /* 1: vector update fused into the SpMV kernels; 0: the three-kernel PCG iteration                [setup] */
   OSQPInt f1;                 /* one launch per PCG iteration where the matrices allow it (banded A; 1: a block's few columns outside its
-                                 window are taken as far columns -- band + long-range couplings; 2: strict windows only)          [setup] */
+                                 window are taken as far columns -- band + long-range couplings; 2: strict windows only;
+                                 3: diagnostic -- the mixing kernels also on a matrix without far columns)                          [setup] */
   OSQPInt window;             /* windowed row blocks (16-bit local column indices, input window in LDS)                         [setup] */
   OSQPInt woodbury;           /* a few dense rows of A (1..128 rows with > 128 entries) are treated exactly in the preconditioner   [setup] */
   OSQPInt woodbury_direct;    /* ... and when the rest of K is diagonal, that preconditioner IS K^-1: the linear solve without PCG iterations [setup] */
