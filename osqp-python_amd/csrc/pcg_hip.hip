@@ -554,9 +554,12 @@ __global__ __launch_bounds__(kBlock) void k_slot_a(Dev d) {
 //             entries still held in registers),  partial delta_k = <t, A u_k> + <u_k, pu_k>_own = <u_k, K u_k>
 // r, s, rep are double-buffered by the parity of k: a workgroup reads what the PREVIOUS launch wrote while its neighbours
 // write this launch's values.  Four workgroup barriers per block, no global synchronisation inside the launch.
-// Template: D = replicas, FIRST = the launch F_0 (straight-line code: no run-time branch on either).
+// Template: D = replicas, FIRST = the launch F_0, MIX = per-block mixing (straight-line code: no run-time branch on any of them).  MIX (backend.h
+// DevF1::mix): the block's far columns -- columns of its rows outside its window -- take the LAST kF1MaxFar gather slots (lanes kBlock / 2 .. kBlock - 1
+// in their second window element: the same 4 + D loads at column fcol[.]) and nfc more segments of the column-ordered pass, whose sums go to the
+// block's spill slots; every reconstruction of a column is  f1_w(replicas) + f1_spill_sum(column's slots in index order).
 struct F1Lds {
-  double win[kF1Win];            // u_k on the block's gather window
+  double win[kF1Win];            // u_k on the block's gather window (MIX: far columns in the last kF1MaxFar slots)
   double prod[kF1Chunk];         // A products in row-major entry order, then val * t[row] in column-major order
   double tvec[kF1MaxRows];       // t of the block's rows
   double uown[kF1MaxOwn];        // u_k on the own columns
