@@ -717,7 +717,10 @@ __device__ __forceinline__ double f1_spill_sum(const double *sp, const int *spk,
 //  the lane's share of the partials reduced to three doubles BEFORE the requests, the block reduction behind them -- no scratch, but the solve got
 //  slower: 44.3 -> 46.4 ms, 12.42 -> 13.03 us per F launch: the requests then wait for the partials instead of the other way round.
 //  Also tried: the NEXT block's record and the first window element of every lane (3 + D values) requested during the current block, next to the next
-//  block's stream (n >= 1M, ten blocks per workgroup): 123 VGPRs, no scratch -- n = 1M unchanged (98.3 us per launch), n = 100k 12.5 -> 13.0 us.)
+//  block's stream (n >= 1M, ten blocks per workgroup): 123 VGPRs, no scratch -- n = 1M unchanged (98.3 us per launch), n = 100k 12.5 -> 13.0 us.
+//  And: everything the F body reads of Dev (24 pointers / sizes) as ONE block of three s_load_dwordx16 behind one wait, instead of the compiler's fetches
+//  at first use (nine s_load -> wait -> vector-load rounds in the ISA of the load phase): at the head of the launch 12.4 -> 14.2 us per F launch, at the
+//  start of the F phase 13.7 us -- the just-in-time fetches overlap the issue of the vector loads, the block does not; 104 spilled SGPRs, 126 VGPRs.)
 template <int D, bool FIRST, bool MIX>
 __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool vec_only, const F1Scal sc, F1Lds &L, F1Stream &S, const F1Rec &rec0, const int par) {
   const DevF1 &f = d.f1;
