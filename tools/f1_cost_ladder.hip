@@ -1,0 +1,106 @@
+// Where do the 12.5 us of an F launch go?  A ladder: one launch per iteration (1024 workgroups x 256 threads, block -> XCD mapping of the engine), starting
+// from the bare vector traffic of an F launch (8 vectors on a 300-column window read, 100 own columns x 7 + a 300-column replica slice written, four
+// workgroup barriers) and adding the engine's other ingredients one at a time (template bit mask):
+//   1  the scalar fold: 3 x 1024 partials of the previous launch read by every workgroup, block reduction, partials written at the end
+//   2  the phase record: 16 words read with scalar loads at the head, written by workgroup 0 at the end
+//   4  the block's matrix stream: 12 KB per block (values + index words) into LDS, consumed by the product phase
+//   8  pointers / P: row pointers + rho, column pointers, P row pointers, one P entry (value + column) per lane
+//  16  the LDS phases at their real size: 1000 products, row sums, 1000 transposed products, column sums
+//   hipcc --offload-arch=gfx950 -O3 tools/f1_cost_ladder.hip -o /tmp/ladder && timeout 120 /tmp/ladder
+#include <hip/hip_runtime.h>
+#include <cstdio>
+constexpr int C = 100, W = 300, NV = 8, G = 1024, ROWS = 200, ENT = 1000;
+template <int F>
+__global__ __launch_bounds__(256) void k_f(double *vec, size_t ns, int k, double *part, int *rec, const double *stream, const int *aux, double *out) {
+  __shared__ double win[512], prod[1024], tv[512], red[16];
+  __shared__ double sval[1024]; __shared__ unsigned sent[1024];
+  const int per = (G + 7) >> 3;
+  const int b = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  const int tid = threadIdx.x;
+  const int c0 = b * C, g0 = max(0, c0 - (W - C) / 2);
+  const int par = k & 1;
+  double alpha = 1e-3;
+  int phase = 1;
+  if (F & 2) { const int *R = rec + (par ? 16 : 0); phase = __builtin_nontemporal_load(R + 1) + __builtin_nontemporal_load(R + 5) * 0; }
+  if (F & 1) {                                               // fold of the previous launch's partials
+    const double *pp = part + (size_t)(par ^ 1) * 3 * G;
+    double a = 0, c = 0, m = 0;
+    for (int q = 0; q < G / 256; q++) { a += pp[tid * (G / 256) + q]; c += pp[G + tid * (G / 256) + q]; m = fmax(m, pp[2 * G + tid * (G / 256) + q]); }
+    for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o); c += __shfl_xor(c, o); m = fmax(m, __shfl_xor(m, o)); }
+    if ((tid & 63) == 0) { red[tid >> 6] = a; red[4 + (tid >> 6)] = c; red[8 + (tid >> 6)] = m; }
+    __syncthreads();
+    a = red[0] + red[1] + red[2] + red[3]; c = red[4] + red[5] + red[6] + red[7]; m = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
+    __syncthreads();
+    alpha = 1e-3 + 1e-12 * a / (1.0 + fabs(c) + m);
+  }
+  if (phase == 0) return;
+  // ---- loads
+  const double *src = vec + (size_t)((k - 1) & 1) * NV * ns; double *dst = vec + (size_t)(k & 1) * NV * ns;
+  double pv = 0; int pc = 0, rp0 = 0, rp1 = 0, cp[4] = {0, 0, 0, 0}, pp0 = 0, pp1 = 0; double rho = 1.0;
+  if (F & 8) { const int *ax = aux + (size_t)b * 2048; pv = src[(size_t)7 * ns + c0 + (tid % C)] * 1e-3; pc = ax[tid]; rp0 = ax[256 + min(tid, ROWS)]; rp1 = ax[257 + min(tid, ROWS)]; rho = src[(size_t)6 * ns + c0 + tid % C];
+               cp[0] = ax[600 + min(tid, W)]; cp[1] = ax[601 + min(tid, W)]; cp[2] = ax[600 + min(tid + 256, W)]; cp[3] = ax[601 + min(tid + 256, W)]; pp0 = ax[1000 + min(tid, C)]; pp1 = ax[1001 + min(tid, C)]; }
+  double acc[2] = {0.0, 0.0};
+  for (int u = 0; u < 2; u++) { const int e = tid + u * 256; if (e < W) { const int c = g0 + e; double w = 0; for (int v = 0; v < NV; v++) w += src[(size_t)v * ns + c]; acc[u] = w * alpha; win[e] = acc[u]; } }
+  double4 sv[3];
+  if (F & 4) { const double4 *st = reinterpret_cast<const double4 *>(stream + (size_t)b * 1536); for (int q = 0; q < 3; q++) sv[q] = st[tid + q * 256 < 384 ? tid + q * 256 : 0]; }
+  if (F & 4) { for (int q = 0; q < 3; q++) { const int i = tid + q * 256; if (i < 256) { sval[4 * i] = sv[q].x; sval[4 * i + 1] = sv[q].y; sval[4 * i + 2] = sv[q].z; sval[4 * i + 3] = sv[q].w; } else if (i < 384) { sent[8 * (i - 256)] = (unsigned)__double_as_longlong(sv[q].x); } } }
+  __syncthreads();
+  double s = 0.0;
+  if (F & 16) {
+    double vw[4]; unsigned en[4];
+    for (int u = 0; u < 4; u++) { const int e = min(tid + u * 256, ENT - 1); vw[u] = (F & 4) ? sval[e] + 1.0 : 1.0 + e * 1e-6; en[u] = (unsigned)((e * 7) % W) | ((unsigned)(e / 5) << 9) | ((unsigned)((e * 13) % ENT) << 18); }
+    for (int u = 0; u < 4; u++) prod[min(tid + u * 256, ENT - 1)] = vw[u] * win[en[u] & 511];
+    __syncthreads();
+    if (tid < ROWS) { double a = 0; for (int j = 0; j < 5; j++) a += prod[tid * 5 + j]; tv[tid] = rho * a; s += a; }
+    __syncthreads();
+    for (int u = 0; u < 4; u++) prod[en[u] >> 18] = vw[u] * tv[(en[u] >> 9) & 511];
+    __syncthreads();
+    for (int u = 0; u < 2; u++) { const int e = tid + u * 256; if (e < W) { double a = 0; for (int j = 0; j < 3; j++) a += prod[(e * 3 + j) % ENT]; acc[u] += 1e-9 * a; } }
+  } else {
+    for (int j = 0; j < 4; j++) s += win[(tid + j * 37) % W];
+    __syncthreads(); tv[tid] = s; __syncthreads();
+    s += tv[(tid * 3) % 256]; __syncthreads();
+  }
+  s += pv * 1e-9 + (pc + rp0 + rp1 + cp[0] + cp[1] + cp[2] + cp[3] + pp0 + pp1) * 1e-12;
+  if (tid < C) for (int v = 0; v < NV - 1; v++) dst[(size_t)v * ns + c0 + tid] = 1e-3 * s + v;
+  for (int u = 0; u < 2; u++) { const int e = tid + u * 256; if (e < W && (b % 4 == 0 || (g0 + e >= c0 && g0 + e < c0 + C))) dst[(size_t)(NV - 1) * ns + g0 + e] = 1e-3 * acc[u]; }
+  if (F & 1) {                                               // partials of this launch
+    double a = s, c = s * 0.5, m = fabs(s);
+    for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o); c += __shfl_xor(c, o); m = fmax(m, __shfl_xor(m, o)); }
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = a; red[4 + (tid >> 6)] = c; red[8 + (tid >> 6)] = m; }
+    __syncthreads();
+    if (tid == 0) { double *pw = part + (size_t)par * 3 * G; pw[blockIdx.x] = red[0] + red[1] + red[2] + red[3]; pw[G + blockIdx.x] = red[4] + red[5] + red[6] + red[7]; pw[2 * G + blockIdx.x] = fmax(fmax(red[8], red[9]), fmax(red[10], red[11])); }
+  }
+  if ((F & 2) && blockIdx.x == 0 && tid < 16) rec[(par ? 0 : 16) + tid] = tid == 1 ? 1 : k;
+  if (tid == 0 && s == 123.456) out[blockIdx.x] = s;
+}
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+template <int F> int run(const char *what, double *vec, size_t ns, double *part, int *rec, double *stream, int *aux, double *out) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int iters = 2000; float ms = 0;
+  for (int rep = 0; rep < 2; rep++) {
+    CK(hipEventRecord(e0));
+    for (int k = 1; k <= iters; k++) hipLaunchKernelGGL(k_f<F>, dim3(G), dim3(256), 0, 0, vec, ns, k, part, rec, stream, aux, out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+  }
+  std::printf("%-100s %6.2f us per launch\n", what, 1e3 * ms / iters);
+  return 0;
+}
+int main() {
+  const size_t ns = (size_t)G * C + 512;
+  double *vec, *part, *stream, *out; int *rec, *aux;
+  CK(hipMalloc(&vec, 8 * 2 * NV * ns)); CK(hipMemset(vec, 0, 8 * 2 * NV * ns)); CK(hipMalloc(&part, 8 * 2 * 3 * G)); CK(hipMemset(part, 0, 8 * 2 * 3 * G));
+  CK(hipMalloc(&stream, 8 * (size_t)G * 1536)); CK(hipMemset(stream, 0, 8 * (size_t)G * 1536)); CK(hipMalloc(&out, 8 * G)); CK(hipMalloc(&rec, 4 * 32)); CK(hipMalloc(&aux, 4 * (size_t)G * 2048)); CK(hipMemset(aux, 0, 4 * (size_t)G * 2048));
+  int one[32]; for (int i = 0; i < 32; i++) one[i] = 1; CK(hipMemcpy(rec, one, sizeof(one), hipMemcpyHostToDevice));
+  if (run<0>("vector traffic of an F launch + four barriers", vec, ns, part, rec, stream, aux, out)) return 1;
+  run<1>("+ scalar fold (3 x 1024 partials read by every workgroup, partials written)", vec, ns, part, rec, stream, aux, out);
+  run<3>("+ phase record (scalar loads at the head, written by workgroup 0)", vec, ns, part, rec, stream, aux, out);
+  run<7>("+ matrix stream (12 KB per block through LDS)", vec, ns, part, rec, stream, aux, out);
+  run<15>("+ row / column / P pointers, rho, one P entry per lane", vec, ns, part, rec, stream, aux, out);
+  run<31>("+ LDS phases at their real size (1000 products, row sums, transposed products, column sums)", vec, ns, part, rec, stream, aux, out);
+  run<30>("the same without the scalar fold", vec, ns, part, rec, stream, aux, out);
+  run<29>("the same without the phase record", vec, ns, part, rec, stream, aux, out);
+  run<27>("the same without the matrix stream", vec, ns, part, rec, stream, aux, out);
+  return 0;
+}
