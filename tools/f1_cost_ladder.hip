@@ -6,32 +6,61 @@
 //   4  the block's matrix stream: 12 KB per block (values + index words) into LDS, consumed by the product phase
 //   8  pointers / P: row pointers + rho, column pointers, P row pointers, one P entry (value + column) per lane
 //  16  the LDS phases at their real size: 1000 products, row sums, 1000 transposed products, column sums
+//  32  (with 1) the fold by wave 3 alone, while waves 0-2 request the window: the two round trips to memory overlap
 //   hipcc --offload-arch=gfx950 -O3 tools/f1_cost_ladder.hip -o /tmp/ladder && timeout 120 /tmp/ladder
 #include <hip/hip_runtime.h>
 #include <cstdio>
 constexpr int C = 100, W = 300, NV = 8, G = 1024, ROWS = 200, ENT = 1000;
-template <int F>
-__global__ __launch_bounds__(256) void k_f(double *vec, size_t ns, int k, double *part, int *rec, const double *stream, const int *aux, double *out) {
-  __shared__ double win[512], prod[1024], tv[512], red[16];
-  __shared__ double sval[1024]; __shared__ unsigned sent[1024];
+template <int F, int Q>
+__global__ __launch_bounds__(256 * Q) void k_f(double *vec, size_t ns, int k, double *part, int *rec, const double *stream, const int *aux, double *out) {
+  __shared__ double win_[Q][512], prod_[Q][1024], tv_[Q][512], red[64];
+  __shared__ double sval_[Q][1024]; __shared__ unsigned sent_[Q][1024];
+  const int sub = threadIdx.x >> 8;                          // Q sub-blocks of 256 threads per workgroup, one row block each
+  double *win = win_[sub], *prod = prod_[sub], *tv = tv_[sub], *sval = sval_[sub]; unsigned *sent = sent_[sub];
   const int per = (G + 7) >> 3;
-  const int b = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  const int tid = threadIdx.x;
+  const int vb = (int)blockIdx.x * Q + sub;                 // virtual 256-thread block
+  const int b = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) * Q + sub;
+  const int tid = threadIdx.x & 255;
   const int c0 = b * C, g0 = max(0, c0 - (W - C) / 2);
   const int par = k & 1;
   double alpha = 1e-3;
   int phase = 1;
   if (F & 2) { const int *R = rec + (par ? 16 : 0); phase = __builtin_nontemporal_load(R + 1) + __builtin_nontemporal_load(R + 5) * 0; }
-  if (F & 1) {                                               // fold of the previous launch's partials
+  double accp[2] = {0.0, 0.0}; bool pre = false;
+  if ((F & 1) && (F & 32) && Q == 1) {                                 // the fold by wave 3 ALONE while waves 0-2 request the window (192 lanes x 2 columns)
+    pre = true;
+    const double *src = vec + (size_t)((k - 1) & 1) * NV * ns;
+    if (tid >= 192) {
+      const double *pp = part + (size_t)(par ^ 1) * 3 * G; const int l = tid - 192;
+      double a = 0, c = 0, m = 0;
+      double va[G / 64], vc[G / 64], vm[G / 64];             // coalesced: lane l takes elements l, l + 64, ... (all requests out before the first add)
+#pragma unroll
+      for (int q = 0; q < G / 64; q++) { va[q] = pp[q * 64 + l]; vc[q] = pp[G + q * 64 + l]; vm[q] = pp[2 * G + q * 64 + l]; }
+#pragma unroll
+      for (int q = 0; q < G / 64; q++) { a += va[q]; c += vc[q]; m = fmax(m, vm[q]); }
+      for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o); c += __shfl_xor(c, o); m = fmax(m, __shfl_xor(m, o)); }
+      if (l == 0) { red[0] = a; red[1] = c; red[2] = m; }
+    } else {
+      for (int u = 0; u < 2; u++) { const int e = tid + u * 192; if (e < W) { const int c = g0 + e; double w = 0; for (int v = 0; v < NV; v++) w += src[(size_t)v * ns + c]; accp[u] = w; } }
+    }
+    __syncthreads();
+    alpha = 1e-3 + 1e-12 * red[0] / (1.0 + fabs(red[1]) + red[2]);
+  } else if (F & 1) {                                               // fold of the previous launch's partials (one slot per WORKGROUP: G / Q of them)
     const double *pp = part + (size_t)(par ^ 1) * 3 * G;
     double a = 0, c = 0, m = 0;
-    for (int q = 0; q < G / 256; q++) { a += pp[tid * (G / 256) + q]; c += pp[G + tid * (G / 256) + q]; m = fmax(m, pp[2 * G + tid * (G / 256) + q]); }
+    if (Q == 1) { for (int q = 0; q < G / 256; q++) { a += pp[tid * (G / 256) + q]; c += pp[G + tid * (G / 256) + q]; m = fmax(m, pp[2 * G + tid * (G / 256) + q]); } }
+    else if (threadIdx.x < G / Q) { a = pp[threadIdx.x]; c = pp[G + threadIdx.x]; m = pp[2 * G + threadIdx.x]; }
     for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o); c += __shfl_xor(c, o); m = fmax(m, __shfl_xor(m, o)); }
-    if ((tid & 63) == 0) { red[tid >> 6] = a; red[4 + (tid >> 6)] = c; red[8 + (tid >> 6)] = m; }
+    { const int wv = threadIdx.x >> 6; if ((threadIdx.x & 63) == 0) { red[wv] = a; red[16 + wv] = c; red[32 + wv] = m; } }
     __syncthreads();
-    a = red[0] + red[1] + red[2] + red[3]; c = red[4] + red[5] + red[6] + red[7]; m = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
+    a = 0; c = 0; m = 0; for (int w = 0; w < 4 * Q; w++) { a += red[w]; c += red[16 + w]; m = fmax(m, red[32 + w]); }
     __syncthreads();
     alpha = 1e-3 + 1e-12 * a / (1.0 + fabs(c) + m);
+  }
+  if (F & 64) {                                              // one dependent 8-byte read per lane at the head (2 KB per workgroup, written by the previous launch), no reduction
+    const double t = part[(size_t)(par ^ 1) * 3 * G + ((tid * 4 + (int)blockIdx.x) & (G - 1))];
+    if (F & 128) { red[tid >> 6] = t; __syncthreads(); alpha += 1e-12 * red[0]; __syncthreads(); }      // ... published through LDS behind a barrier
+    else alpha += 1e-12 * t;
   }
   if (phase == 0) return;
   // ---- loads
@@ -40,7 +69,8 @@ __global__ __launch_bounds__(256) void k_f(double *vec, size_t ns, int k, double
   if (F & 8) { const int *ax = aux + (size_t)b * 2048; pv = src[(size_t)7 * ns + c0 + (tid % C)] * 1e-3; pc = ax[tid]; rp0 = ax[256 + min(tid, ROWS)]; rp1 = ax[257 + min(tid, ROWS)]; rho = src[(size_t)6 * ns + c0 + tid % C];
                cp[0] = ax[600 + min(tid, W)]; cp[1] = ax[601 + min(tid, W)]; cp[2] = ax[600 + min(tid + 256, W)]; cp[3] = ax[601 + min(tid + 256, W)]; pp0 = ax[1000 + min(tid, C)]; pp1 = ax[1001 + min(tid, C)]; }
   double acc[2] = {0.0, 0.0};
-  for (int u = 0; u < 2; u++) { const int e = tid + u * 256; if (e < W) { const int c = g0 + e; double w = 0; for (int v = 0; v < NV; v++) w += src[(size_t)v * ns + c]; acc[u] = w * alpha; win[e] = acc[u]; } }
+  if (pre) { if (tid < 192) for (int u = 0; u < 2; u++) { const int e = tid + u * 192; if (e < W) { acc[u] = accp[u] * alpha; win[e] = acc[u]; } } }
+  else for (int u = 0; u < 2; u++) { const int e = tid + u * 256; if (e < W) { const int c = g0 + e; double w = 0; for (int v = 0; v < NV; v++) w += src[(size_t)v * ns + c]; acc[u] = w * alpha; win[e] = acc[u]; } }
   double4 sv[3];
   if (F & 4) { const double4 *st = reinterpret_cast<const double4 *>(stream + (size_t)b * 1536); for (int q = 0; q < 3; q++) sv[q] = st[tid + q * 256 < 384 ? tid + q * 256 : 0]; }
   if (F & 4) { for (int q = 0; q < 3; q++) { const int i = tid + q * 256; if (i < 256) { sval[4 * i] = sv[q].x; sval[4 * i + 1] = sv[q].y; sval[4 * i + 2] = sv[q].z; sval[4 * i + 3] = sv[q].w; } else if (i < 384) { sent[8 * (i - 256)] = (unsigned)__double_as_longlong(sv[q].x); } } }
@@ -63,25 +93,26 @@ __global__ __launch_bounds__(256) void k_f(double *vec, size_t ns, int k, double
   }
   s += pv * 1e-9 + (pc + rp0 + rp1 + cp[0] + cp[1] + cp[2] + cp[3] + pp0 + pp1) * 1e-12;
   if (tid < C) for (int v = 0; v < NV - 1; v++) dst[(size_t)v * ns + c0 + tid] = 1e-3 * s + v;
-  for (int u = 0; u < 2; u++) { const int e = tid + u * 256; if (e < W && (b % 4 == 0 || (g0 + e >= c0 && g0 + e < c0 + C))) dst[(size_t)(NV - 1) * ns + g0 + e] = 1e-3 * acc[u]; }
+  for (int u = 0; u < 2; u++) { const int e = pre ? (tid < 192 ? tid + u * 192 : W) : tid + u * 256; if (e < W && (b % 4 == 0 || (g0 + e >= c0 && g0 + e < c0 + C))) dst[(size_t)(NV - 1) * ns + g0 + e] = 1e-3 * acc[u]; }
   if (F & 1) {                                               // partials of this launch
     double a = s, c = s * 0.5, m = fabs(s);
     for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o); c += __shfl_xor(c, o); m = fmax(m, __shfl_xor(m, o)); }
     __syncthreads();
-    if ((tid & 63) == 0) { red[tid >> 6] = a; red[4 + (tid >> 6)] = c; red[8 + (tid >> 6)] = m; }
+    { const int wv = threadIdx.x >> 6; if ((threadIdx.x & 63) == 0) { red[wv] = a; red[16 + wv] = c; red[32 + wv] = m; } }
     __syncthreads();
-    if (tid == 0) { double *pw = part + (size_t)par * 3 * G; pw[blockIdx.x] = red[0] + red[1] + red[2] + red[3]; pw[G + blockIdx.x] = red[4] + red[5] + red[6] + red[7]; pw[2 * G + blockIdx.x] = fmax(fmax(red[8], red[9]), fmax(red[10], red[11])); }
+    if (threadIdx.x == 0) { double ra = 0, rc = 0, rm = 0; for (int w = 0; w < 4 * Q; w++) { ra += red[w]; rc += red[16 + w]; rm = fmax(rm, red[32 + w]); } double *pw = part + (size_t)par * 3 * G; pw[blockIdx.x] = ra; pw[G + blockIdx.x] = rc; pw[2 * G + blockIdx.x] = rm; }
   }
-  if ((F & 2) && blockIdx.x == 0 && tid < 16) rec[(par ? 0 : 16) + tid] = tid == 1 ? 1 : k;
+  if ((F & 64) && tid == 0) part[(size_t)par * 3 * G + blockIdx.x * Q + sub] = s;      // (one 8-byte store per block at the end)
+  if ((F & 2) && blockIdx.x == 0 && threadIdx.x < 16) rec[(par ? 0 : 16) + threadIdx.x] = threadIdx.x == 1 ? 1 : k;
   if (tid == 0 && s == 123.456) out[blockIdx.x] = s;
 }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
-template <int F> int run(const char *what, double *vec, size_t ns, double *part, int *rec, double *stream, int *aux, double *out) {
+template <int F, int Q = 1> int run(const char *what, double *vec, size_t ns, double *part, int *rec, double *stream, int *aux, double *out) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int iters = 2000; float ms = 0;
   for (int rep = 0; rep < 2; rep++) {
     CK(hipEventRecord(e0));
-    for (int k = 1; k <= iters; k++) hipLaunchKernelGGL(k_f<F>, dim3(G), dim3(256), 0, 0, vec, ns, k, part, rec, stream, aux, out);
+    for (int k = 1; k <= iters; k++) hipLaunchKernelGGL((k_f<F, Q>), dim3(G / Q), dim3(256 * Q), 0, 0, vec, ns, k, part, rec, stream, aux, out);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
   }
   std::printf("%-100s %6.2f us per launch\n", what, 1e3 * ms / iters);
@@ -102,5 +133,12 @@ int main() {
   run<30>("the same without the scalar fold", vec, ns, part, rec, stream, aux, out);
   run<29>("the same without the phase record", vec, ns, part, rec, stream, aux, out);
   run<27>("the same without the matrix stream", vec, ns, part, rec, stream, aux, out);
+  run<63>("everything, the fold by wave 3 alone while waves 0-2 request the window", vec, ns, part, rec, stream, aux, out);
+  run<33>("vector traffic + the fold by wave 3 alone under the window requests", vec, ns, part, rec, stream, aux, out);
+  run<64>("vector traffic + ONE dependent 8-byte read per lane at the head of what the previous launch wrote (no reduction)", vec, ns, part, rec, stream, aux, out);
+  run<192>("... the same, handed on through LDS behind a workgroup barrier", vec, ns, part, rec, stream, aux, out);
+  run<31, 4>("everything, as 256 workgroups x 1024 threads (four row blocks side by side, 256 partial slots)", vec, ns, part, rec, stream, aux, out);
+  run<30, 4>("the same without the scalar fold", vec, ns, part, rec, stream, aux, out);
+  run<31, 2>("everything, as 512 workgroups x 512 threads (two row blocks side by side, 512 partial slots)", vec, ns, part, rec, stream, aux, out);
   return 0;
 }
