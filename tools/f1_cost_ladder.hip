@@ -106,6 +106,59 @@ __global__ __launch_bounds__(256 * Q) void k_f(double *vec, size_t ns, int k, do
   if ((F & 2) && blockIdx.x == 0 && threadIdx.x < 16) rec[(par ? 0 : 16) + threadIdx.x] = threadIdx.x == 1 ? 1 : k;
   if (tid == 0 && s == 123.456) out[blockIdx.x] = s;
 }
+// Taller row blocks: 512 workgroups x 512 threads, one block of 400 rows / 2000 entries per workgroup -- own columns 200, window 400 (the band's 200 +
+// the rows' 200): every column's 8 values are gathered by 2.0 blocks instead of 2.9, half as many partial slots.  Everything of the ladder switched on.
+__global__ __launch_bounds__(512) void k_tall(double *vec, size_t ns, int k, double *part, int *rec, const double *stream, const int *aux, double *out) {
+  constexpr int G2 = G / 2, C2 = 2 * C, W2 = 400, ROWS2 = 2 * ROWS, ENT2 = 2 * ENT;
+  __shared__ double win[1024], prod[2048], tv[1024], red[64];
+  __shared__ double sval[2048]; __shared__ unsigned sent[2048];
+  const int per = (G2 + 7) >> 3;
+  const int b = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  const int tid = threadIdx.x;
+  const int c0 = b * C2, g0 = max(0, c0 - (W2 - C2) / 2);
+  const int par = k & 1;
+  double alpha = 1e-3;
+  const int *R = rec + (par ? 16 : 0); const int phase = __builtin_nontemporal_load(R + 1);
+  { const double *pp = part + (size_t)(par ^ 1) * 3 * G;
+    double a = pp[tid], c = pp[G + tid], m = pp[2 * G + tid];
+    for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o); c += __shfl_xor(c, o); m = fmax(m, __shfl_xor(m, o)); }
+    const int wv = tid >> 6; if ((tid & 63) == 0) { red[wv] = a; red[16 + wv] = c; red[32 + wv] = m; }
+    __syncthreads();
+    a = 0; c = 0; m = 0; for (int w = 0; w < 8; w++) { a += red[w]; c += red[16 + w]; m = fmax(m, red[32 + w]); }
+    __syncthreads();
+    alpha = 1e-3 + 1e-12 * a / (1.0 + fabs(c) + m); }
+  if (phase == 0) return;
+  const double *src = vec + (size_t)((k - 1) & 1) * NV * ns; double *dst = vec + (size_t)(k & 1) * NV * ns;
+  const int *ax = aux + (size_t)b * 4096;
+  const double pv = src[(size_t)7 * ns + c0 + (tid % C2)] * 1e-3; const int pc = ax[tid], rp0 = ax[512 + min(tid, ROWS2)], rp1 = ax[513 + min(tid, ROWS2)]; const double rho = src[(size_t)6 * ns + c0 + tid % C2];
+  const int cp0 = ax[1200 + min(tid, W2)], cp1 = ax[1201 + min(tid, W2)], pp0 = ax[2000 + min(tid, C2)], pp1 = ax[2001 + min(tid, C2)];
+  double acc = 0.0;
+  if (tid < W2) { const int c = g0 + tid; double w = 0; for (int v = 0; v < NV; v++) w += src[(size_t)v * ns + c]; acc = w * alpha; win[tid] = acc; }
+  { const double4 *st = reinterpret_cast<const double4 *>(stream + (size_t)b * 3072); double4 sv[2]; for (int q = 0; q < 2; q++) sv[q] = st[tid + q * 512 < 768 ? tid + q * 512 : 0];
+    for (int q = 0; q < 2; q++) { const int i = tid + q * 512; if (i < 512) { sval[4 * i] = sv[q].x; sval[4 * i + 1] = sv[q].y; sval[4 * i + 2] = sv[q].z; sval[4 * i + 3] = sv[q].w; } else if (i < 768) sent[8 * (i - 512)] = (unsigned)__double_as_longlong(sv[q].x); } }
+  __syncthreads();
+  double s = 0.0;
+  double vw[4]; unsigned en[4];
+  for (int u = 0; u < 4; u++) { const int e = min(tid + u * 512, ENT2 - 1); vw[u] = sval[e] + 1.0; en[u] = (unsigned)((e * 7) % W2) | ((unsigned)(e / 5) << 10) | ((unsigned)((e * 13) % ENT2) << 20); }
+  for (int u = 0; u < 4; u++) prod[min(tid + u * 512, ENT2 - 1)] = vw[u] * win[en[u] & 1023];
+  __syncthreads();
+  if (tid < ROWS2) { double a = 0; for (int j = 0; j < 5; j++) a += prod[tid * 5 + j]; tv[tid] = rho * a; s += a; }
+  __syncthreads();
+  for (int u = 0; u < 4; u++) prod[en[u] >> 20] = vw[u] * tv[(en[u] >> 10) & 1023];
+  __syncthreads();
+  if (tid < W2) { double a = 0; for (int j = 0; j < 5; j++) a += prod[(tid * 5 + j) % ENT2]; acc += 1e-9 * a; }
+  s += pv * 1e-9 + (pc + rp0 + rp1 + cp0 + cp1 + pp0 + pp1) * 1e-12;
+  if (tid < C2) for (int v = 0; v < NV - 1; v++) dst[(size_t)v * ns + c0 + tid] = 1e-3 * s + v;
+  if (tid < W2 && (b % 2 == 0 || (g0 + tid >= c0 && g0 + tid < c0 + C2))) dst[(size_t)(NV - 1) * ns + g0 + tid] = 1e-3 * acc;
+  { double a = s, c = s * 0.5, m = fabs(s);
+    for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o); c += __shfl_xor(c, o); m = fmax(m, __shfl_xor(m, o)); }
+    __syncthreads();
+    const int wv = tid >> 6; if ((tid & 63) == 0) { red[wv] = a; red[16 + wv] = c; red[32 + wv] = m; }
+    __syncthreads();
+    if (tid == 0) { double ra = 0, rc = 0, rm = 0; for (int w = 0; w < 8; w++) { ra += red[w]; rc += red[16 + w]; rm = fmax(rm, red[32 + w]); } double *pw = part + (size_t)par * 3 * G; pw[blockIdx.x] = ra; pw[G + blockIdx.x] = rc; pw[2 * G + blockIdx.x] = rm; } }
+  if (blockIdx.x == 0 && tid < 16) rec[(par ? 0 : 16) + tid] = tid == 1 ? 1 : k;
+  if (tid == 0 && s == 123.456) out[blockIdx.x] = s;
+}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 template <int F, int Q = 1> int run(const char *what, double *vec, size_t ns, double *part, int *rec, double *stream, int *aux, double *out) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -140,5 +193,8 @@ int main() {
   run<31, 4>("everything, as 256 workgroups x 1024 threads (four row blocks side by side, 256 partial slots)", vec, ns, part, rec, stream, aux, out);
   run<30, 4>("the same without the scalar fold", vec, ns, part, rec, stream, aux, out);
   run<31, 2>("everything, as 512 workgroups x 512 threads (two row blocks side by side, 512 partial slots)", vec, ns, part, rec, stream, aux, out);
+  { hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); float ms = 0; const int iters = 2000;
+    for (int rep = 0; rep < 2; rep++) { CK(hipEventRecord(e0)); for (int k = 1; k <= iters; k++) hipLaunchKernelGGL(k_tall, dim3(G / 2), dim3(512), 0, 0, vec, ns, k, part, rec, stream, aux, out); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); }
+    std::printf("%-100s %6.2f us per launch\n", "everything, TALL blocks: 512 workgroups x 512 threads, 400 rows / 2000 entries, window 400, own 200", 1e3 * ms / iters); }
   return 0;
 }
