@@ -782,9 +782,12 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     KT(2);
     // ---- loads.  First the (P + sigma I) entry of this lane: its column decides whether the operand comes from the window or has
     //      to be recomputed from its parts (columns outside the window), and those loads should leave with the window's, not after it
-    double pv = 0.0; int pc = g0;
+    // (every request of this stage is unconditional and its destination is written by nothing else: a default value assigned first makes the
+    //  compiler guard the register at the loop's head with `s_waitcnt vmcnt(0)` -- which also sits out the next block's stream and the previous
+    //  block's stores.  The last budgeted update (vec_only) requests a few values it does not use.)
     const bool hasp = !vec_only && tid < pcnt;
-    if (!vec_only) { const int e = pk0 + max(0, min(tid, pcnt - 1)); pv = gptr(f.pval)[e]; pc = gptr(f.pcol)[e]; }
+    const int pe = min(pk0 + max(0, min(tid, pcnt - 1)), f.pnnz - 1);
+    const double pv = gptr(f.pval)[pe]; const int pc = gptr(f.pcol)[pe];
     // ---- window parts (+ p, x~ where the window column is one of the block's own)
     double wm[CW], wr[CW], wsv[CW], wq[CW][D], wpp[CW], wx[CW];
     bool wown[CW];
@@ -813,21 +816,19 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
       for (int u = 0; u < CW; u++) { if (u < nw) wst[u] = f1_spill_take(spcur, wsw[u]); }
     }
     // ---- row / column pointers (the matrix entries themselves arrive in LDS: S, requested one block ahead)
-    int rp0 = 0, rp1 = 0; double rrho = 0.0;
     int cp0[CW], cp1[CW];
-    int pp0 = 0, pp1 = 0;
-    if (!vec_only) {
-      { const int row = r0 + min(tid, nrows - 1); rp0 = gptr(d.A.rowptr)[row]; rp1 = gptr(d.A.rowptr)[row + 1]; rrho = gptr(d.rho)[row]; }
+    const int prow = r0 + min(tid, nrows - 1);
+    const int rp0 = gptr(d.A.rowptr)[prow], rp1 = gptr(d.A.rowptr)[prow + 1]; const double rrho = gptr(d.rho)[prow];
 #pragma unroll
-      for (int u = 0; u < CW; u++) {
-        if (u < ns2) {
-          int c = min(tid + u * kBlock, wl - 1);
-          if constexpr (MIX) { const int cf = tid + u * kBlock - kFB; if (u == CW - 1 && cf >= 0 && cf < nfc) c = wl + cf; }      // a far segment: behind the window's
-          cp0[u] = gptr(f.cptr)[cpo + c]; cp1[u] = gptr(f.cptr)[cpo + c + 1];
-        }
+    for (int u = 0; u < CW; u++) {
+      if (u < ns2) {
+        int c = min(tid + u * kBlock, wl - 1);
+        if constexpr (MIX) { const int cf = tid + u * kBlock - kFB; if (u == CW - 1 && cf >= 0 && cf < nfc) c = wl + cf; }      // a far segment: behind the window's
+        cp0[u] = gptr(f.cptr)[cpo + c]; cp1[u] = gptr(f.cptr)[cpo + c + 1];
       }
-      { const int j = min(cs0 + max(0, min(tid, nown - 1)), n - 1); pp0 = gptr(f.prp)[j]; pp1 = gptr(f.prp)[j + 1]; }
     }
+    const int pj = min(cs0 + max(0, min(tid, nown - 1)), n - 1);
+    const int pp0 = gptr(f.prp)[pj], pp1 = gptr(f.prp)[pj + 1];
     // ---- a (P + sigma I) entry whose column lies outside the window: its operand is recomputed from its parts in the product phase below (requested
     //      THERE: held from here they would cost 7 + 2 D registers across the block's register peak for a case banded problems never meet)
     const int pcl = pc - g0;
