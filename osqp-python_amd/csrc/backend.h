@@ -285,6 +285,9 @@ struct BatchParams {
   // left to the banded kernel: the spectral launch marks its record (kBatchUnsolved in rec[0]), a second launch with only_marked solves the marked ones.
   const double *sp_V = nullptr, *sp_lam = nullptr; const int *sp_ctype = nullptr;
   double sp_rho_ref = 0.0, sp_eqf = 0.0;
+  // K^-1 for rho_bar = sp_K0_rho (the batch's starting rho: the same for every problem), built on the host with the kernel's own operation order and laid
+  // out as the threads hold it -- [64 columns][256 threads]: a problem LOADS its first K^-1 (coalesced, L2-resident) instead of rebuilding it from V
+  const double *sp_K0 = nullptr; double sp_K0_rho = 0.0;
   int only_marked = 0;
 };
 constexpr int kBatchSpecN = 128;        // the spectral form keeps K^-1 in registers: row i = thread / 2, 64 columns per thread

@@ -280,6 +280,13 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? (SPEC ? SP
   [[maybe_unused]] auto update_kinv = [&](double rb) {
     if constexpr (SPEC) {
       BT_BEGIN();
+      if (P.sp_K0 && rb == P.sp_K0_rho) {                      // the batch's starting rho: the host has formed this K^-1 once for everybody (same operations, same order)
+#pragma unroll
+        for (int c = 0; c < 64; c++) kin[c] = P.sp_K0[(size_t)c * kBB + tid];
+        __syncthreads();
+        BT_END(tk_fact);
+        return;
+      }
       const double dl = rb - P.sp_rho_ref;
       if (tid < kBatchSpecN) sp_dk[tid] = 1.0 / (1.0 + dl * P.sp_lam[tid]);
 #pragma unroll

@@ -128,7 +128,10 @@ class Engine {
     double rho_ref = 0, eqf = 0, sigma = 0; int rho_is_vec = -1;
     std::vector<int> ctype;          // the constraint classes V was built for (a problem of a batch whose own bounds give other classes takes the banded kernel)
     double *V = nullptr, *lam = nullptr; int *d_ctype = nullptr;
+    std::vector<double> Vh, lamh;    // host copies (padded, column-major) for K0
+    double *K0 = nullptr; double k0_rho = 0; bool k0_ok = false;      // K^-1 at the batch's starting rho (BatchParams::sp_K0)
   } bs_;
+  void prepare_batch_k0(double rho0);
   int mat_epoch_ = 0;                // bumped by every change of P / A values
   void prepare_batch_spectral(double rho_ref, double eqf);
   void free_batch_spectral();

@@ -295,7 +295,7 @@ void Engine::free_batch_direct() {
 // rebuilt from the host copies, K_ref and M1 assembled, K_ref = L L' (Cholesky), C = L^-1 M1 L^-T, C = Q Lambda Q' (cyclic Jacobi sweeps: C is
 // symmetric PSD with eigenvalues in [0, 1 / rho_ref]), V = L^-T Q.  Checked before use: || V' K_ref V - I ||_max and || V' M1 V - Lambda ||_max.
 void Engine::free_batch_spectral() {
-  void *ptrs[] = {bs_.V, bs_.lam, bs_.d_ctype};
+  void *ptrs[] = {bs_.V, bs_.lam, bs_.d_ctype, bs_.K0};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   bs_ = BatchSpectral();
 }
@@ -399,8 +399,32 @@ void Engine::prepare_batch_spectral(double rho_ref, double eqf) {
   bs_.V = dev_vec<double>(d_, Vp.size()); be::h2d(d_, bs_.V, Vp.data(), sizeof(double) * Vp.size());
   bs_.lam = dev_vec<double>(d_, N); be::h2d(d_, bs_.lam, lp.data(), sizeof(double) * N);
   bs_.d_ctype = dev_vec<int>(d_, m); be::h2d(d_, bs_.d_ctype, ct.data(), sizeof(int) * m);
+  bs_.Vh = Vp; bs_.lamh = lp; bs_.k0_ok = false;
   bs_.ctype = ct; bs_.rho_ref = rref; bs_.eqf = eqf; bs_.sigma = settings.sigma; bs_.rho_is_vec = settings.rho_is_vec; bs_.mat_epoch = mat_epoch_;
   bs_.ok = true;
+}
+
+// K^-1(rho0) = V diag(1 / (1 + (rho0 - rho_ref) lambda)) V' exactly as batch_hip.hip's update_kinv forms it -- thread (row, half) of 256, its 64 columns, the
+// columns of V in ascending order with one fused multiply-add each: the bits a problem would compute itself -- in the layout the threads load it in.
+void Engine::prepare_batch_k0(double rho0) {
+  if (!bs_.ok) return;
+  if (bs_.k0_ok && bs_.k0_rho == rho0) return;
+  const int N = kBatchSpecN, T = 256;
+  const double dl = rho0 - bs_.rho_ref;
+  std::vector<double> dk(N), K0((size_t)64 * T);
+  for (int k = 0; k < N; k++) dk[k] = 1.0 / (1.0 + dl * bs_.lamh[k]);
+  const double *V = bs_.Vh.data();                            // V[k * N + j] = V(j, k)
+  for (int tid = 0; tid < T; tid++) {
+    const int row = tid >> 1, half = tid & 1;
+    for (int c = 0; c < 64; c++) {
+      double acc = 0.0;
+      for (int k = 0; k < n; k++) { const double a = V[(size_t)k * N + row] * dk[k]; acc = std::fma(a, V[(size_t)k * N + half * 64 + c], acc); }
+      K0[(size_t)c * T + tid] = acc;
+    }
+  }
+  if (!bs_.K0) bs_.K0 = dev_vec<double>(d_, K0.size());
+  be::h2d(d_, bs_.K0, K0.data(), sizeof(double) * K0.size());
+  bs_.k0_rho = rho0; bs_.k0_ok = true;
 }
 
 void Engine::prepare_batch_direct() {
@@ -524,7 +548,11 @@ void Engine::attach_batch_direct(BatchParams &p) {
     }
     if (!settings.rho_is_vec) n_ineq = m;
     prepare_batch_spectral(p.rho0, n_ineq == 0 ? 1e3 : p.eq_factor_direct);
-    if (bs_.ok) { p.sp_V = bs_.V; p.sp_lam = bs_.lam; p.sp_ctype = bs_.d_ctype; p.sp_rho_ref = bs_.rho_ref; p.sp_eqf = bs_.eqf; }
+    if (bs_.ok) {
+      p.sp_V = bs_.V; p.sp_lam = bs_.lam; p.sp_ctype = bs_.d_ctype; p.sp_rho_ref = bs_.rho_ref; p.sp_eqf = bs_.eqf;
+      prepare_batch_k0(p.rho0);
+      if (bs_.k0_ok) { p.sp_K0 = bs_.K0; p.sp_K0_rho = bs_.k0_rho; }
+    }
   }
   p.bw = bd_.bw; p.nents = bd_.nents; p.ntri = bd_.ntri; p.perm = bd_.perm; p.bp_slot = bd_.bp_slot; p.ke_slot = bd_.ke_slot;
   p.ke_ptr = bd_.ke_ptr; p.kp_row = bd_.kp_row; p.kp_val = bd_.kp_val; p.tri = bd_.tri;
