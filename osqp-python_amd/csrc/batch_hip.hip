@@ -262,7 +262,10 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? (SPEC ? SP
   const double eqf = (n_ineq == 0.0) ? 1e3 : (DIRECT ? P.eq_factor_direct : P.eq_factor);  // engine.cpp classify_constraints()
   double rho_bar = P.rho0;
   // SPEC: K^-1 of this problem, and the LDS the form needs (in the band's place): the zero-padded right-hand side, 1 / (1 + delta lambda)
-  [[maybe_unused]] double kin[SPEC ? 64 : 1];
+  // SPEC: K^-1 in the register layout of the f64 matrix instruction's result (v_mfma_f64_16x16x4: lane l, register r of a 16 x 16 tile = element
+  // (l / 16 + 4 r, l % 16); tools/mfma_f64_layout.hip).  Wave w owns rows 32 w .. 32 w + 31: tiles kacc[tr * 8 + tc], tr = 0, 1 (16 rows each), tc = 0 .. 7.
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  [[maybe_unused]] v4d kacc[SPEC ? 16 : 1];
   [[maybe_unused]] double *sp_rhs = Lb, *sp_dk = Lb + kBatchSpecN + 2;
   if constexpr (SPEC) {
     // V was built for ONE set of constraint classes: a problem whose own bounds give other classes (or another equality weight) is not ours
@@ -280,9 +283,12 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? (SPEC ? SP
   [[maybe_unused]] auto update_kinv = [&](double rb) {
     if constexpr (SPEC) {
       BT_BEGIN();
-      if (P.sp_K0 && rb == P.sp_K0_rho) {                      // the batch's starting rho: the host has formed this K^-1 once for everybody (same operations, same order)
+      if (P.sp_K0 && rb == P.sp_K0_rho) {                      // the batch's starting rho: the host has formed this K^-1 once for everybody, in this layout
 #pragma unroll
-        for (int c = 0; c < 64; c++) kin[c] = P.sp_K0[(size_t)c * kBB + tid];
+        for (int t = 0; t < 16; t++) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) kacc[t][r] = P.sp_K0[(size_t)(t * 4 + r) * kBB + tid];
+        }
         __syncthreads();
         BT_END(tk_fact);
         return;
@@ -290,49 +296,41 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? (SPEC ? SP
       const double dl = rb - P.sp_rho_ref;
       if (tid < kBatchSpecN) sp_dk[tid] = 1.0 / (1.0 + dl * P.sp_lam[tid]);
 #pragma unroll
-      for (int c = 0; c < 64; c++) kin[c] = 0.0;
-      const int row = tid >> 1, half = tid & 1;
-      constexpr int kCol = kBatchSpecN + 2;                     // a staged column: rows 0..63, one double of padding, rows 64..127 (the two halves in different banks)
+      for (int t = 0; t < 16; t++) kacc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+      // K^-1 = (V diag(dk)) V' as a 128 x 128 x 128 product on the matrix cores: per step of four columns of V a wave issues 16 v_mfma_f64_16x16x4
+      // (its two row tiles against the eight column tiles); both operands are "V(16 t + l % 16, k + l / 16)" -- ten LDS reads per step.
+      const int lj = tid & 15, lk = (tid >> 4) & 3, wv = tid >> 6;
+      constexpr int kCol = kBatchSpecN + 2;                     // a staged column: rows 0..63, one double of padding, rows 64..127
       constexpr int kChMax = 16;
-      const int CH = min(prod_len / kCol, kChMax);              // columns of V per chunk (batch_solve requires >= 3)
-      // the chunk after this one is fetched into registers while this one is consumed (kStage values per thread); inside a column the
-      // 64 broadcast reads run one block of 8 ahead of the multiply-adds that use them (left to itself the compiler keeps ONE read in flight)
+      const int CH = min(prod_len / kCol, kChMax) & ~3;         // columns of V per chunk: a multiple of four (batch_solve requires >= 4)
       constexpr int kStage = kChMax * kBatchSpecN / kBB;
-      double st[kStage];
+      double st[kStage];                                        // the chunk after this one, fetched while this one is consumed
       auto fetch = [&](int k0) {
         const int nk = min(CH, n - k0);
 #pragma unroll
         for (int t = 0; t < kStage; t++) { const int e = tid + t * kBB; st[t] = (k0 < n && e < nk * kBatchSpecN) ? P.sp_V[(size_t)k0 * kBatchSpecN + e] : 0.0; }
       };
+      const int ra0 = 32 * wv + lj, ra1 = ra0 + 16;
+      const int oa0 = ra0 + (ra0 >= 64), oa1 = ra1 + (ra1 >= 64);
       fetch(0);
       for (int k0 = 0; k0 < n; k0 += CH) {
-        const int nk = min(CH, n - k0);
+        const int nk = min(CH, n - k0), nk4 = (nk + 3) & ~3;    // (columns nk .. nk4 are staged as zeros)
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < kStage; t++) { const int e = tid + t * kBB; if (e < nk * kBatchSpecN) { const int kk = e / kBatchSpecN, r_ = e % kBatchSpecN; prod[kk * kCol + r_ + (r_ >= 64)] = st[t]; } }
+        for (int t = 0; t < kStage; t++) { const int e = tid + t * kBB; if (e < nk4 * kBatchSpecN) { const int kk = e / kBatchSpecN, r_ = e % kBatchSpecN; prod[kk * kCol + r_ + (r_ >= 64)] = st[t]; } }
         __syncthreads();
         fetch(k0 + CH);
-        for (int kk = 0; kk < nk; kk++) {
-          const double *vc = prod + kk * kCol;
-          const double a = vc[row + (row >= 64)] * sp_dk[k0 + kk];
-          const double *vh = vc + half * 65;                    // (8-byte broadcast reads: see ksolve)
-          double va[8], vb[8];
+        for (int ks = 0; ks < nk4; ks += 4) {
+          const double *vc = prod + (ks + lk) * kCol;
+          const double dkv = sp_dk[min(k0 + ks + lk, kBatchSpecN - 1)];
+          double bb[8];
 #pragma unroll
-          for (int c = 0; c < 8; c++) va[c] = vh[c];
+          for (int tc = 0; tc < 8; tc++) bb[tc] = vc[16 * tc + lj + (tc >= 4)];
+          const double a0 = vc[oa0] * dkv, a1 = vc[oa1] * dkv;
 #pragma unroll
-          for (int blk = 0; blk < 8; blk += 2) {
-#pragma unroll
-            for (int c = 0; c < 8; c++) vb[c] = vh[(blk + 1) * 8 + c];
-            asm volatile("" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]), "+v"(va[7]));
-#pragma unroll
-            for (int c = 0; c < 8; c++) kin[blk * 8 + c] = fma(a, va[c], kin[blk * 8 + c]);
-            if (blk + 2 < 8) {
-#pragma unroll
-              for (int c = 0; c < 8; c++) va[c] = vh[(blk + 2) * 8 + c];
-            }
-            asm volatile("" : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]), "+v"(vb[4]), "+v"(vb[5]), "+v"(vb[6]), "+v"(vb[7]));
-#pragma unroll
-            for (int c = 0; c < 8; c++) kin[(blk + 1) * 8 + c] = fma(a, vb[c], kin[(blk + 1) * 8 + c]);
+          for (int tc = 0; tc < 8; tc++) {
+            kacc[tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bb[tc], kacc[tc], 0, 0, 0);
+            kacc[8 + tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bb[tc], kacc[8 + tc], 0, 0, 0);
           }
         }
       }
@@ -413,39 +411,42 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? (SPEC ? SP
   // not pipeline.
   auto ksolve = [&](const double *rhs, double *out) {
     if constexpr (SPEC) {
-      // out = K^-1 rhs: thread (row, half) sums its 64 columns (the right-hand side is read as broadcasts: every thread of a half reads the same address),
-      // the two halves of a row meet through one lane exchange; fixed order, no atomics
       if (tid < kBatchSpecN) sp_rhs[tid + (tid >= 64)] = tid < n ? rhs[tid] : 0.0;
       __syncthreads();
       BT2_BEGIN();
-      const int row = tid >> 1, half = tid & 1;
-      const double *rr = sp_rhs + half * 65;
-      // (8-byte reads: every thread of a half reads the SAME address, which the LDS serves as a broadcast -- a 16-byte read of one address by
-      //  all lanes is NOT broadcast: measured 250 cycles per ds_read_b128, 3.4 us per product; the second half sits 65 doubles on, in other banks)
-      // (reads kept one block of 8 ahead of their multiply-adds by hand, as in update_kinv)
-      double ac[4] = {0.0, 0.0, 0.0, 0.0};
-      double ra[8], rb_[8];
+      // out = K^-1 rhs in the tile layout: a lane multiplies its 64 elements by the right-hand side entries of ITS column (l % 16 of each of the eight
+      // column tiles: eight LDS reads, one line per wave instruction), sums over the tiles per row, and the sixteen lanes of a DPP row -- the sixteen
+      // columns of a tile -- are summed with row-local DPP moves.  Fixed order, no atomics.
+      const int lj = tid & 15, lk = (tid >> 4) & 3, wv = tid >> 6;
+      double bb[8];
 #pragma unroll
-      for (int c = 0; c < 8; c++) ra[c] = rr[c];
+      for (int tc = 0; tc < 8; tc++) bb[tc] = sp_rhs[16 * tc + lj + (tc >= 4)];
+      double pv[8];                                             // pv[tr * 4 + r]: this lane's share of row 32 wv + 16 tr + lk + 4 r
 #pragma unroll
-      for (int blk = 0; blk < 8; blk += 2) {
+      for (int tr = 0; tr < 2; tr++) {
 #pragma unroll
-        for (int c = 0; c < 8; c++) rb_[c] = rr[(blk + 1) * 8 + c];
-        asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]));
+        for (int r = 0; r < 4; r++) {
+          double a = kacc[tr * 8][r] * bb[0];
 #pragma unroll
-        for (int c = 0; c < 8; c++) ac[c & 3] = fma(kin[blk * 8 + c], ra[c], ac[c & 3]);
-        if (blk + 2 < 8) {
-#pragma unroll
-          for (int c = 0; c < 8; c++) ra[c] = rr[(blk + 2) * 8 + c];
+          for (int tc = 1; tc < 8; tc++) a = fma(kacc[tr * 8 + tc][r], bb[tc], a);
+          pv[tr * 4 + r] = a;
         }
-        asm volatile("" : "+v"(rb_[0]), "+v"(rb_[1]), "+v"(rb_[2]), "+v"(rb_[3]), "+v"(rb_[4]), "+v"(rb_[5]), "+v"(rb_[6]), "+v"(rb_[7]));
-#pragma unroll
-        for (int c = 0; c < 8; c++) ac[c & 3] = fma(kin[(blk + 1) * 8 + c], rb_[c], ac[c & 3]);
       }
-      const double a0 = ac[0] + ac[2], a1 = ac[1] + ac[3];
-      double acc = a0 + a1;
-      acc += bdpp<0xb1>(acc);                                   // lane ^ 1: the other half of the row
-      if (half == 0 && row < n) out[row] = acc;
+      // eight values per lane, each to be summed over the 16 lanes of its DPP row: two halving exchanges (lane ^ 1, lane ^ 2: a lane keeps the values
+      // whose index has its own low bits and hands the others over -- 4 + 2 exchanges instead of 8 + 8), then two rotations by 4 and 8 lanes on the two
+      // values left.  Lane lj < 4 ends with the complete sums of rows  16 i + lk + 4 lj,  i = 0, 1.
+      const bool b0 = tid & 1, b1 = tid & 2;
+      double w4[4], u2[2];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { const double keep = b0 ? pv[2 * i + 1] : pv[2 * i], send = b0 ? pv[2 * i] : pv[2 * i + 1]; w4[i] = keep + bdpp<0xb1>(send); }
+#pragma unroll
+      for (int i = 0; i < 2; i++) { const double keep = b1 ? w4[2 * i + 1] : w4[2 * i], send = b1 ? w4[2 * i] : w4[2 * i + 1]; u2[i] = keep + bdpp<0x4e>(send); }
+#pragma unroll
+      for (int i = 0; i < 2; i++) { u2[i] += bdpp<0x124>(u2[i]); u2[i] += bdpp<0x128>(u2[i]); }      // row_ror:4, row_ror:8
+      if (lj < 4) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) { const int row = 32 * wv + 16 * i + lk + 4 * lj; if (row < n) out[row] = u2[i]; }
+      }
       BT2_END(tk_fwd);
       __syncthreads();
       return;
@@ -964,10 +965,13 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<256, E, E, true, false, false, true, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec) != hipSuccess) \
       throw DeviceError("osqp_hip: cannot reserve LDS for the spectral batch kernel"); \
     hipLaunchKernelGGL((k_batch_admm<256, E, E, true, false, false, true, W>), dim3(p.nbatch), dim3(256), lds_spec, st, p); } while (0)
-    // latency form up to three rounds of one workgroup per CU, throughput form (two per CU) beyond
+    // One workgroup per CU (everything in registers) at every batch size: since K^-1 lives in the matrix instruction's result registers the two-per-CU
+    // form (256 registers, scratch) no longer wins on large batches either -- 4096 QPs 5.9 ms against 6.2 ms.  OSQP_HIP_BATCH_WIDE_ROUNDS=r selects it for
+    // batches of more than r rounds of one workgroup per CU (A/B runs).
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d.device);
-    const bool wide = p.nbatch > 3 * cus;
+    static const int wide_rounds = std::getenv("OSQP_HIP_BATCH_WIDE_ROUNDS") ? std::atoi(std::getenv("OSQP_HIP_BATCH_WIDE_ROUNDS")) : (1 << 20);
+    const bool wide = p.nbatch > wide_rounds * cus;
 #define BATCH_LAUNCH_SPEC(E) do { if (wide) BATCH_LAUNCH_SPEC_W(E, 2); else BATCH_LAUNCH_SPEC_W(E, 1); } while (0)
     if (e256 <= 2) BATCH_LAUNCH_SPEC(2); else if (e256 <= 4) BATCH_LAUNCH_SPEC(4); else if (e256 <= 6) BATCH_LAUNCH_SPEC(6); else BATCH_LAUNCH_SPEC(8);
 #undef BATCH_LAUNCH_SPEC

@@ -404,8 +404,8 @@ void Engine::prepare_batch_spectral(double rho_ref, double eqf) {
   bs_.ok = true;
 }
 
-// K^-1(rho0) = V diag(1 / (1 + (rho0 - rho_ref) lambda)) V' exactly as batch_hip.hip's update_kinv forms it -- thread (row, half) of 256, its 64 columns, the
-// columns of V in ascending order with one fused multiply-add each: the bits a problem would compute itself -- in the layout the threads load it in.
+// K^-1(rho0) = V diag(1 / (1 + (rho0 - rho_ref) lambda)) V' in the register layout batch_hip.hip's threads hold it in (the result layout of the f64 matrix
+// instruction), formed once for the whole batch: a problem loads its first K^-1 instead of building it.
 void Engine::prepare_batch_k0(double rho0) {
   if (!bs_.ok) return;
   if (bs_.k0_ok && bs_.k0_rho == rho0) return;
@@ -414,12 +414,14 @@ void Engine::prepare_batch_k0(double rho0) {
   std::vector<double> dk(N), K0((size_t)64 * T);
   for (int k = 0; k < N; k++) dk[k] = 1.0 / (1.0 + dl * bs_.lamh[k]);
   const double *V = bs_.Vh.data();                            // V[k * N + j] = V(j, k)
+  // (layout: batch_hip.hip kacc -- thread tid = 64 w + l holds, for tile t = tr * 8 + tc and register r, element (32 w + 16 tr + l / 16 + 4 r, 16 tc + l % 16))
   for (int tid = 0; tid < T; tid++) {
-    const int row = tid >> 1, half = tid & 1;
-    for (int c = 0; c < 64; c++) {
+    const int wv = tid >> 6, l = tid & 63, lj = l & 15, lk = l >> 4;
+    for (int t = 0; t < 16; t++) for (int r = 0; r < 4; r++) {
+      const int i = 32 * wv + 16 * (t / 8) + lk + 4 * r, j = 16 * (t % 8) + lj;
       double acc = 0.0;
-      for (int k = 0; k < n; k++) { const double a = V[(size_t)k * N + row] * dk[k]; acc = std::fma(a, V[(size_t)k * N + half * 64 + c], acc); }
-      K0[(size_t)c * T + tid] = acc;
+      for (int k = 0; k < n; k++) acc = std::fma(V[(size_t)k * N + i] * dk[k], V[(size_t)k * N + j], acc);
+      K0[(size_t)(t * 4 + r) * T + tid] = acc;
     }
   }
   if (!bs_.K0) bs_.K0 = dev_vec<double>(d_, K0.size());
