@@ -81,6 +81,31 @@ struct Red {
       return t;
     }
   }
+  // K maxima and S sums behind ONE pair of barriers (K + S <= 4: the 16 doubles of s): the same wave reductions and the same order over the waves as
+  // max() / sum() -- identical results; the residuals' 22 block reductions cost 44 barriers one at a time, 14 in groups of four
+  template <int K, int S>
+  __device__ __forceinline__ void max_sum_n(double (&mx)[K > 0 ? K : 1], double (&sm)[S > 0 ? S : 1]) const {
+    static_assert(NW * (K + S) <= 16, "scratch");
+    double *scr = s;
+    if constexpr (NW == 1) {
+#pragma unroll
+      for (int k = 0; k < K; k++) mx[k] = max(mx[k]);
+#pragma unroll
+      for (int k = 0; k < S; k++) sm[k] = sum(sm[k]);
+    } else {
+      const int w = threadIdx.x >> 6; const bool last = (threadIdx.x & 63) == 63;
+#pragma unroll
+      for (int k = 0; k < K; k++) { const double v = wmax63(mx[k]); if (last) scr[w * (K + S) + k] = v; }
+#pragma unroll
+      for (int k = 0; k < S; k++) { const double v = wsum63(sm[k]); if (last) scr[w * (K + S) + K + k] = v; }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < K; k++) { double t = 0.0; for (int q = 0; q < NW; q++) t = nmax(t, scr[q * (K + S) + k]); mx[k] = t; }
+#pragma unroll
+      for (int k = 0; k < S; k++) { double t = 0.0; for (int q = 0; q < NW; q++) t += scr[q * (K + S) + K + k]; sm[k] = t; }
+      __syncthreads();
+    }
+  }
   __device__ __forceinline__ void sum_max(double &a, double &b) const {   // a: sum, b: max
     if constexpr (NW == 1) { a = sum(a); b = max(b); }
     else {
@@ -637,8 +662,9 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? (SPEC ? SP
       a7 = nmax(a7, fabs(P.E[i] * dyi)); a8 = nmax(a8, fabs(dyi));
       s1 += u[i] * fmax(dyi, 0.0) + l[i] * fmin(dyi, 0.0);
     }
-    pri_u = red.max(a1); ax_u = red.max(a2); z_u = red.max(a3); pri_s = red.max(a4); ax_s = red.max(a5); z_s = red.max(a6);
-    dy_u = red.max(a7); dy_s = red.max(a8); pinf_lhs = red.sum(s1);
+    { double g1[4] = {a1, a2, a3, a4}, g2[4] = {a5, a6, a7, a8}, g3[1] = {s1}, none[1] = {0.0};
+      red.template max_sum_n<4, 0>(g1, none); red.template max_sum_n<4, 0>(g2, none); red.template max_sum_n<0, 1>(none, g3);
+      pri_u = g1[0]; ax_u = g1[1]; z_u = g1[2]; pri_s = g1[3]; ax_s = g2[0]; z_s = g2[1]; dy_u = g2[2]; dy_s = g2[3]; pinf_lhs = g3[0]; }
     double b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0, b8 = 0, b9 = 0, b10 = 0, t1 = 0, t2 = 0, t3 = 0;
     for (int j = tid; j < n; j += kBB) {
       double sp = 0.0, sa = 0.0;
@@ -649,9 +675,10 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? (SPEC ? SP
       b7 = nmax(b7, fabs(P.D[j] * dx[j])); b8 = nmax(b8, fabs(dx[j])); b9 = nmax(b9, fabs(q[j])); b10 = nmax(b10, fabs(di * q[j]));
       t1 += x[j] * px; t2 += q[j] * x[j]; t3 += q[j] * dx[j];
     }
-    dua_u = red.max(b1); px_u = red.max(b2); aty_u = red.max(b3); dua_s = red.max(b4); px_s = red.max(b5); aty_s = red.max(b6);
-    dxn_u = red.max(b7); dxn_s = red.max(b8); qn_s = red.max(b9); qn_u = red.max(b10);
-    xpx = red.sum(t1); qx = red.sum(t2); qdx = red.sum(t3);
+    { double g1[4] = {b1, b2, b3, b4}, g2[4] = {b5, b6, b7, b8}, g3[2] = {b9, b10}, sm[2] = {t1, t2}, g4[1] = {t3}, none[1] = {0.0};
+      red.template max_sum_n<4, 0>(g1, none); red.template max_sum_n<4, 0>(g2, none); red.template max_sum_n<2, 2>(g3, sm); red.template max_sum_n<0, 1>(none, g4);
+      dua_u = g1[0]; px_u = g1[1]; aty_u = g1[2]; dua_s = g1[3]; px_s = g2[0]; aty_s = g2[1]; dxn_u = g2[2]; dxn_s = g2[3]; qn_s = g3[0]; qn_u = g3[1];
+      xpx = sm[0]; qx = sm[1]; qdx = g4[0]; }
   };
 
   int status = OSQP_UNSOLVED, iter = 0, rho_updates = 0;
