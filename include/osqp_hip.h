@@ -180,7 +180,8 @@ typedef struct {
   double graph_launches;      /* hipGraphLaunch calls                                     */
   double gpu_solve_ms;        /* hipEvent time around the ADMM loop                       */
   double nnzA, nnzB;          /* stored entries of A (CSR) and B = [P+sigma I | A'] (CSR) */
-  double pcg_fused;           /* 2: ONE launch per PCG iteration (k_slot1, the F1 form); 1: two kernels (k_k2f, k_k1f); 0: three (k_k1, k_k2, k_kv) */
+  double pcg_fused;           /* 2: ONE launch per PCG iteration (k_slot1, the F1 form: banded A); 3: ONE launch per PCG iteration on the explicit reduced matrix
+                                 (k_slotk, the K form: any sparsity of moderate fill); 1: two kernels (k_k2f, k_k1f); 0: three (k_k1, k_k2, k_kv) */
   double batch_direct_bw;     /* half bandwidth of the reduced KKT matrix under the engine's RCM ordering (batch / small-QP direct
                                  solve); -1 before the first batch or small solve, -2 if the pattern is too dense to analyse */
   double cg_cap_escalations;  /* times the last solve doubled its PCG iteration cap because most solves of a chunk stagnated at it */
@@ -198,6 +199,7 @@ typedef struct {
   double woodbury_cache_hits; /* last solve: rho updates served by an inverse this handle had computed for the same rho_bar before (validated by the
                                  numerical probe against the current matrices) -- woodbury_factorisations counts the others; woodbury_factor_ms covers both */
   double f1_far_columns;      /* F1 form with per-block mixing: far columns (spill slots) over all row blocks of A (0: every block fits its window) */
+  double kform_nnz;           /* K form: stored entries of the explicit reduced matrix K = P + sigma I + A' diag(rho) A (0: the form is not in use) */
 } OSQPHipStats;
 /* OSQPHipStats::preconditioner.  `cg_precond = OSQP_DIAGONAL_PRECONDITIONER` (bindings.cpp.in:426, the reference's only preconditioner) selects the
    Jacobi family: plain Jacobi M = diag(K), and -- this engine's addition, on by default, OSQPHipPolicy::woodbury / woodbury_large = 0 switch it
@@ -348,6 +350,12 @@ typedef struct {
                                  (every vector crossing this API keeps the caller's numbering); 0: never; 2: always permute (tests)      [setup] */
   OSQPInt woodbury_cache;     /* 1 (default): the device-factorised Woodbury form keeps the last four inverses by rho_bar; a rho the handle has seen before is a
                                  look-up + the numerical probe instead of an r^3 factorisation (OSQPHipStats::woodbury_cache_hits); 0: always factorise   [setup] */
+  OSQPInt kform;              /* 1: where the one-launch form on A alone (f1) does not apply and no Woodbury mode is on, hold the reduced matrix
+                                 K = P + sigma I + A' diag(rho) A explicitly when its fill is moderate (sum of squared row lengths of A <= 8 nnz(A)) and run
+                                 ONE launch per PCG iteration on it (any sparsity pattern; k + 3 launches per ADMM iteration instead of 2 k + 4).
+                                 0 (default): the two-kernel form -- measured faster on MI355X: K needs nnz(K) random gathers per product (41 per row at
+                                 configs[1] sizes with unstructured columns: 4.1 M against the 2.2 M of the A / B pair), and a random 8..32-byte gather costs a
+                                 whole 128-byte line of L2 -> L1 traffic: 18-24 us per 4.2 M gathers alone (profiles/r06a_kform_gather_bench.txt)        [setup] */
 } OSQPHipPolicy;
 void    osqp_hip_default_policy(OSQPHipPolicy *policy);
 OSQPInt osqp_hip_set_policy(OSQPSolver *solver, const OSQPHipPolicy *policy);

@@ -116,6 +116,30 @@ struct DevF1 {
 };
 constexpr int kF1MaxFar = 128;     // most far columns of a row block
 
+// One launch per PCG iteration for ANY sparsity pattern ("K form", pcg_hip.hip k_slotk).  The reduced operator of the PCG,
+//     K = P + sigma I + A' diag(rho) A            (/root/reference/src/osqppurepy/_osqp.py:291-301 is the KKT matrix it is the Schur complement of)
+// is held EXPLICITLY as a CSR matrix (n x n, full symmetric pattern = pattern(P) + union over the rows i of A of cols(i) x cols(i)), so that one
+// PCG iteration is ONE sparse product instead of two dependent ones (t = rho .* (A u), then B [u; t]: two launches, each paying the launch boundary).
+// Symbolic part, once at setup (Engine::prepare_kf): every K entry owns a list of TERMS -- a copy of an entry of B.val (the P + sigma I part,
+// row < 0) or a product  rho_i A_ia A_ib  (row i, positions a, b in A.val); numeric part, k_kf_values: one streaming pass over the term lists
+// wherever rho or the matrix values change (be::precond), i.e. a rho update costs one more small kernel, not a re-assembly.  Chosen at setup when
+// neither the one-launch form on A alone (DevF1: banded A, 0.72 x the bytes) nor a Woodbury mode applies and the fill stays moderate
+// (sum_i nnz(row i)^2 <= kKfMaxFill nnz(A): configs[1] with unstructured columns: 41 entries per row, 49 MB; lasso / portfolio rows are dense: never).
+// The Chronopoulos-Gear recurrences fit the launch boundary as in the F1 form (pcg_hip.hip): launch F_k folds the previous launch's partials (gamma,
+// delta, ||r||), rebuilds  u_k[c] = Minv (r_{k-1} - alpha (w_{k-1} + beta s_{k-2}))[c]  at EVERY column c it gathers from the column's 32-byte
+// RECORD {Minv, r_{k-1}, w_{k-1}, s_{k-2}} (one aligned 32-byte gather per entry instead of four scattered ones; same instruction sequence as the
+// owner's update: all copies are bit-identical), updates its own rows' x~, p, r, s, applies K and leaves the next record + partials.  Records are
+// double-buffered by the parity of k.
+constexpr int kKfMaxFill = 8;
+struct DevKf {
+  int on = 0;
+  DevCsr K;
+  int *tptr = nullptr;           // [nnz(K) + 1] term ranges
+  int *trow = nullptr, *ta = nullptr, *tb = nullptr;   // per term: constraint row (< 0: copy of B.val[ta]), positions of A_ia, A_ib in A.val
+  int nterm = 0;
+  double *rec = nullptr;         // [2][n][4] records {Minv, r, w, s}: launch F_k reads parity (k + 1) & 1, writes parity k & 1 (KB writes parity 1)
+};
+
 // Woodbury correction of the Jacobi preconditioner for a FEW dense rows of A (portfolio: k + 1 rows with thousands of entries next to
 // n one-entry rows).  With L = the long rows (more than kLongRow entries; at most kWbMaxRows of them),
 //     K = K0 + A_L' diag(rho_L) A_L ,   M = D0 + A_L' diag(rho_L) A_L ,   D0 = diag(K0) = diag(P) + sigma + sum_{i not in L} rho_i A_ij^2
@@ -233,6 +257,7 @@ struct Dev {
   double *uu2 = nullptr, *ms = nullptr;  // fused PCG: u_k lives in (k&1 ? uu2 : uu); ms (2n) = interleaved pairs {u_k[j], (Minv .* s_k)[j]}
   int fused = 0;                 // 1: two kernels per PCG iteration (vector update k-1 fused into the SpMV-A kernel of iteration k)
   DevF1 f1;                      // one launch per PCG iteration (slot form only; f1.on)
+  DevKf kf;                      // one launch per PCG iteration on the explicit reduced matrix (slot form only; kf.on; never together with f1.on)
   DevWb wb;                      // Woodbury-corrected preconditioner for a few dense rows (three-kernel PCG form; wb.on)
   // reductions
   double *part = nullptr;        // [kPartSlots][kGrid] partial results, slots see backend implementation
@@ -352,7 +377,10 @@ int slot_seq(Dev &d);                      // slots executed since slot_begin (c
 //   F1 form          pcg + 2       F_0, F_1 .. F_pcg, KA (run by the launch whose scalar fold detects convergence; it also leaves the slices F_0 builds
 //                                 r_0 from -- no KB launch) + one launch at the start of every chunk
 //   Woodbury direct mode in two launches (wbdirect_hip.hip): 2 per iteration + one closing pair per chunk
-inline double slot_launches(const Dev &d, double pcg) { return (d.wb.on && d.wb.exact && d.wb.x.on && d.wb.x.slots) ? 2.16 : (d.f1.on ? pcg + 2.0 : 2.0 * (pcg + 2.0)); }
+//   K form           pcg + 3       KB (rhs and r_0 from B), F_0 .. F_pcg on the explicit K, KA (run by the launch whose fold detects convergence)
+inline double slot_launches(const Dev &d, double pcg) { return (d.wb.on && d.wb.exact && d.wb.x.on && d.wb.x.slots) ? 2.16 : (d.f1.on ? pcg + 2.0 : (d.kf.on ? pcg + 3.0 : 2.0 * (pcg + 2.0))); }
+bool kf_supported();                       // the K form exists (false: the host simulator)
+void kf_values(Dev &d, int cond = 0);      // K.val <- term lists with the current rho / A.val / B.val (no-op without the form; cond: inside a boundary group, only when it updated rho)
 void f1_refresh(Dev &d);                   // f1.pval <- B.val (no-op without a plan)
 bool wb_supported();
 bool wbx_supported();                      // the two-launch direct mode exists (false: the host simulator)

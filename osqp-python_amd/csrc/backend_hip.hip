@@ -504,6 +504,7 @@ void ctl_group(Dev &d, int diagonal) {
   LAUNCH(k_set_rho, d, d, 0.0, 1);
   LAUNCH(k_init_guess, d, d, 1);
   if (diagonal) LAUNCH(k_precond, d, d, 1);
+  kf_values(d, 1);                                        // K form: the explicit reduced matrix follows rho (no-op without the form)
   if (wbx_slots(d)) wb_factor_device(d, 1);               // Woodbury direct mode in the slot form: D0, S, S^-1 (+ check), S^-1 A_L when rho changed
 }
 void ctl_poll(Dev &d, Ctl *out, int *seq, int *done) {
@@ -573,6 +574,7 @@ void precond(Dev &d, int diagonal) {
   HIP_CHECK(hipSetDevice(d.device));
   if (diagonal) LAUNCH(k_precond, d, d, 0);
   else LAUNCH(k_fill, d, d.Minv, d.n, 1.0);
+  kf_values(d, 0);                                        // K form: K.val from the current rho / matrix values (every caller of precond has just changed one of them)
   if (d.wb.on) wb_factor(d);
 }
 void set_pcg_tol(Dev &d, double rel, double ab) {

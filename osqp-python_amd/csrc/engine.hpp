@@ -157,6 +157,7 @@ class Engine {
   template <class T> std::vector<T> to_internal_m(const T *v) const { std::vector<T> o(m); for (int i = 0; i < m; i++) o[i] = v[pr_[i]]; return o; }
   bool plan_f1(const std::vector<int> &rb, const std::vector<int> &Arp, const std::vector<int> &Arj, const std::vector<int> &Brp, const std::vector<int> &Bj, F1Plan &pl);
   void upload_f1(const F1Plan &pl);
+  void prepare_kf(const std::vector<int> &Arp, const std::vector<int> &Arj, const std::vector<int> &Brp, const std::vector<int> &Bj);      // backend.h DevKf
   bool small_direct_applicable();
   int solve_small_direct(double t0);
   void attach_batch_direct(BatchParams &p);

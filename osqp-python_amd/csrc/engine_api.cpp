@@ -215,7 +215,7 @@ int Engine::ls_setup(const OSQPCscMatrix *P, const OSQPCscMatrix *A, const doubl
   no_reorder_ = true;                                 // (the slot's vectors -- rhs, rho_vec, warm start -- are exchanged in the caller's numbering)
   int err = setup(P, q.data(), A, l.data(), u.data(), mm, nn, &st);
   if (err) return err;
-  d_.fused = 0; d_.f1.on = 0; d_.wb.on = 0;
+  d_.fused = 0; d_.f1.on = 0; d_.kf.on = 0; d_.wb.on = 0;
   return ls_set_rho_vec(rho_vec);
 }
 
@@ -769,8 +769,9 @@ int Engine::batch_solve_device(int nbatch, const double *q, const double *l, con
 
 int Engine::get_stats(OSQPHipStats *out) {
   if (!out) return OSQP_DATA_VALIDATION_ERROR;
-  *out = stats_; out->pcg_fused = (d_.f1.on && use_slots_) ? 2.0 : (be::pcg_fused(d_) ? 1.0 : 0.0); out->batch_direct_bw = bd_.bw_symbolic;
+  *out = stats_; out->pcg_fused = (d_.f1.on && use_slots_) ? 2.0 : ((d_.kf.on && use_slots_) ? 3.0 : (be::pcg_fused(d_) ? 1.0 : 0.0)); out->batch_direct_bw = bd_.bw_symbolic;
   out->f1_replicas = d_.f1.on ? d_.f1.D : 0;
+  out->kform_nnz = d_.kf.on ? (double)d_.kf.K.nnz : 0.0;
   out->woodbury_rows = d_.wb.on ? d_.wb.r : 0; out->woodbury_direct = (d_.wb.on && d_.wb.exact) ? ((d_.wb.x.on) ? 2 : 1) : 0;
   out->windowed_blocks = d_.A.nwin + d_.B.nwin; out->row_blocks = d_.A.nblk + d_.B.nblk;
   out->reordered = reordered_ ? 1.0 : 0.0; out->reorder_ms = reorder_ms_;

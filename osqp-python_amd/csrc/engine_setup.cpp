@@ -270,7 +270,6 @@ bool Engine::plan_f1(const std::vector<int> &rb, const std::vector<int> &Arp, co
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return slot[x] < slot[y]; });
     tpos.resize(cnt);
     for (int t = 0; t < cnt; t++) tpos[order[t]] = t;
-    const int gl = g1 - g0;
     for (int r = r0; r < r1; r++)
       for (int k = Arp[r]; k < Arp[r + 1]; k++) {
         const int sl = slot[k - k0];
@@ -333,6 +332,71 @@ void Engine::upload_f1(const F1Plan &pl) {
     f.nsp = pl.nsp; f.spill = dev_vec<double>(d_, 3 * (f.nsp + 2));
   }
   f.on = 1;
+}
+
+// ------------------------------------------------------------------------------------------------ K form
+// backend.h DevKf: the pattern of K = P + sigma I + A' diag(rho) A and, per entry, the list of its terms -- built once, row by row (Gustavson):
+// row j of K collects the (P + sigma I) entries of row j of B and, for every entry (i, j) of column j of A, the products A_ij A_ic over row i.
+// Terms of an entry are kept in that order (B entries first, then rows i ascending, row entries in CSR order): k_kf_values sums them in list
+// order, so K.val is a deterministic function of (rho, A.val, B.val).  A valid CSC may repeat an entry: every stored pair makes its own term.
+void Engine::prepare_kf(const std::vector<int> &Arp, const std::vector<int> &Arj, const std::vector<int> &Brp, const std::vector<int> &Bj) {
+  d_.kf = DevKf();
+  if (!pol_.kform || !be::kf_supported() || !be::device_assembly() || m == 0) return;
+  const double t0 = now_s();
+  const long nzA = Arp[m];
+  long nprod = 0;
+  for (int i = 0; i < m; i++) { const long len = Arp[i + 1] - Arp[i]; nprod += len * len; if (nprod > (long)kKfMaxFill * nzA + n) break; }
+  long npt = 0;
+  for (int j = 0; j < n; j++) for (int k = Brp[j]; k < Brp[j + 1] && Bj[k] < n; k++) npt++;
+  if (nprod > (long)kKfMaxFill * nzA + n || nprod + npt >= (1L << 30)) {
+    if (pol_.setup_timing) std::fprintf(stderr, "[osqp_hip] K form: fill too large (sum of squared row lengths > %d nnz(A))\n", kKfMaxFill);
+    return;
+  }
+  std::vector<int> Krp(n + 1, 0), Kj, tptr, trow, ta, tb;
+  Kj.reserve((size_t)(nprod + npt)); trow.reserve((size_t)(nprod + npt)); ta.reserve((size_t)(nprod + npt)); tb.reserve((size_t)(nprod + npt));
+  tptr.reserve((size_t)(nprod + npt) + 1);
+  std::vector<int> mark(n, -1), slot(n, 0), cols, cnt, order, newslot, start;
+  struct Term { int s, row, a, b; };
+  std::vector<Term> terms;
+  for (int j = 0; j < n; j++) {
+    cols.clear(); cnt.clear(); terms.clear();
+    auto add = [&](int c, int row, int a, int b) {
+      if (mark[c] != j) { mark[c] = j; slot[c] = (int)cols.size(); cols.push_back(c); cnt.push_back(0); }
+      cnt[slot[c]]++; terms.push_back(Term{slot[c], row, a, b});
+    };
+    for (int k = Brp[j]; k < Brp[j + 1] && Bj[k] < n; k++) add(Bj[k], -1, k, 0);
+    for (int k = A_.p[j]; k < A_.p[j + 1]; k++) {
+      const int i = A_.i[k], pa = AmapA_[k];
+      for (int e = Arp[i]; e < Arp[i + 1]; e++) add(Arj[e], i, pa, e);
+    }
+    const int nc = (int)cols.size();
+    order.resize(nc);
+    for (int q = 0; q < nc; q++) order[q] = q;
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return cols[x] < cols[y]; });
+    newslot.resize(nc); start.resize(nc + 1);
+    start[0] = 0;
+    for (int q = 0; q < nc; q++) { newslot[order[q]] = q; start[q + 1] = start[q] + cnt[order[q]]; }
+    const size_t tbase = trow.size();
+    for (int q = 0; q < nc; q++) { Kj.push_back(cols[order[q]]); tptr.push_back((int)tbase + start[q]); }
+    trow.resize(tbase + terms.size()); ta.resize(tbase + terms.size()); tb.resize(tbase + terms.size());
+    for (const Term &t : terms) { const size_t o = tbase + (size_t)start[newslot[t.s]]++; trow[o] = t.row; ta[o] = t.a; tb[o] = t.b; }      // (stable: terms of an entry keep their order)
+    Krp[j + 1] = (int)Kj.size();
+  }
+  tptr.push_back((int)trow.size());
+  const int nzK = (int)Kj.size();
+  std::vector<int> rb = build_row_blocks(Krp, n), runs;
+  auto up_i = [&](const std::vector<int> &h) { int *p = dev_vec<int>(d_, h.size()); if (!h.empty()) be::h2d(d_, p, h.data(), sizeof(int) * h.size()); return p; };
+  DevKf &f = d_.kf;
+  DevCsr &K = f.K;
+  K.nrows = n; K.ncols = n; K.nnz = nzK; K.nblk = (int)rb.size() - 1; K.split = n; K.nwin = 0;
+  K.single = (int)rb.size() - 1 <= kGrid;
+  for (size_t b = 0; b + 1 < rb.size(); b++) if (rb[b + 1] - rb[b] > kBlock) K.single = 0;
+  K.rowptr = up_i(Krp); K.col = up_i(Kj); K.blkdesc = up_i(block_descs(rb, Krp, Kj, runs)); K.runinfo = up_i(runs);
+  K.val = dev_vec<double>(d_, nzK);
+  f.tptr = up_i(tptr); f.trow = up_i(trow); f.ta = up_i(ta); f.tb = up_i(tb); f.nterm = (int)trow.size();
+  f.rec = dev_vec<double>(d_, 8 * (size_t)n);
+  f.on = 1;
+  if (pol_.setup_timing) std::fprintf(stderr, "[osqp_hip] K form: nnz(K) = %d (%.1f per row), %d terms, %d row blocks, %.1f ms\n", nzK, (double)nzK / n, f.nterm, K.nblk, 1e3 * (now_s() - t0));
 }
 
 // ------------------------------------------------------------------------------------------------ Woodbury plan
@@ -598,6 +662,8 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   if (d_.wb.on) d_.fused = 0;                        // (the Woodbury-corrected preconditioner lives in the three-kernel PCG form)
   d_.f1 = DevF1();
   if (d_.fused && f1ok) upload_f1(plan);
+  // (neither the one-launch form on A alone nor a Woodbury mode: the explicit reduced matrix, where its fill is moderate -- backend.h DevKf)
+  if (d_.fused && !d_.f1.on && use_slots_) prepare_kf(Arp, Arj, Brp, Bj);
   if (reordered_) {
     d_pc_ = dev_vec<int>(d_, n); d_pr_ = dev_vec<int>(d_, m);
     be::h2d(d_, d_pc_, pc_.data(), sizeof(int) * n); be::h2d(d_, d_pr_, pr_.data(), sizeof(int) * m);

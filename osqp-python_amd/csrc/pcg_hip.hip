@@ -1332,6 +1332,142 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 }
 
 
+// ---------------------------------------------------------------------------------------------- one launch per PCG iteration on the explicit K (K form)
+// backend.h DevKf.  Launch F_k of the PCG of one ADMM iteration (k = 0 .. iterations), exactly the F1 form's recurrences (above) with the operator
+// applied as ONE CSR product over K's row blocks (process_rows: any sparsity, no windows, no replicas):
+//   scalars   the previous launch's partials (f1_fold_issue / f1_fold_finish: stopping test, alpha_{k-1}, beta_{k-1}; k = 0: alpha = beta = 0)
+//   gather    u_k[c] = Minv (r_{k-1} - alpha (w_{k-1} + beta s_{k-2}))[c]  from column c's 32-byte record of parity (k + 1) & 1 -- two 16-byte loads
+//             of one aligned 32-byte line per entry, requested as the column indices arrive (GKf::fetch), evaluated behind the fold (GKf::prod)
+//   own rows  the same update from the row's own record (f1_upd: the owner's and every gatherer's u_k[j] are bit-identical), p_{k-1}, x~ += alpha p_{k-1},
+//             w_k[j] = (K u_k)_j  = the row sum, the record of parity k & 1 = {Minv, r_k, w_k, s_{k-1}}, partials gamma_k, ||r_k||, delta_k = <u_k, w_k>
+// KB (one pass over B = [P + sigma I | A'], as the two-kernel form's) leaves  {Minv, r_0, 0, 0}  in parity 1 and ||rhs|| in its partial slot, so F_0 is
+// the general launch with alpha = beta = 0.  An ADMM iteration with k PCG iterations = KB, F_0 .. F_k, [detect + KA] = k + 3 launches.
+struct KfOps { double2 a, b; };                      // a column's record: {Minv, r}, {w, s}
+struct GKf {
+  const double *rec; const F1Scal *sc;
+  using Ops = KfOps;
+  __device__ __forceinline__ Ops fetch(int c) const { const double2 *p = reinterpret_cast<const double2 *>(rec + 4 * (size_t)c); Ops o; o.a = p[0]; o.b = p[1]; return o; }
+  __device__ __forceinline__ void prod(const Ops &o, double a, double (&pr)[1]) const { double sn, rn, un; f1_upd(*sc, o.a.x, o.a.y, o.b.x, o.b.y, sn, rn, un); pr[0] = a * un; }
+  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { prod(fetch(c), a, pr); }
+};
+struct EKf {
+  const double *recr; double *recw, *p, *xs; const F1Scal *sc;
+  double g = 0, rn = 0, dl = 0;
+  double2 oa = make_double2(0, 0), ob = make_double2(0, 0); double pp = 0, px = 0;
+  __device__ __forceinline__ void prefetch(int j) { const double2 *q = reinterpret_cast<const double2 *>(recr + 4 * (size_t)j); oa = q[0]; ob = q[1]; pp = p[j]; px = xs[j]; }
+  // w: (K u_k)_j; with_w = false: the last budgeted update (no operator apply follows: w is not needed by anybody)
+  __device__ __forceinline__ void update(int j, double w, bool with_w) {
+    double sn, rnew, un;
+    f1_upd(*sc, oa.x, oa.y, ob.x, ob.y, sn, rnew, un);
+    const double pn = fma(sc->beta, sc->general ? pp : 0.0, oa.x * oa.y);
+    xs[j] = fma(sc->alpha, pn, px); p[j] = pn;
+    double2 *o = reinterpret_cast<double2 *>(recw + 4 * (size_t)j);
+    o[0] = make_double2(oa.x, rnew); o[1] = make_double2(w, sn);
+    g += rnew * un; rn = nanmax(rn, fabs(rnew)); if (with_w) dl += un * w;
+  }
+  __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { update(j, s[0], true); }
+};
+struct PreKf {
+  [[maybe_unused]] static constexpr int kTraceBase = 0;
+  const Dev &d; int k, admm_par, probe, par; double *red; F1Scal *sc;
+  using Tok = F1Fold;
+  __device__ __forceinline__ Tok begin() const { return f1_fold_issue(d.part, par, probe); }
+  __device__ __forceinline__ bool finish(const Tok &t) const { return f1_fold_finish(d, k, admm_par, probe, t, red, *sc); }
+};
+// returns false when the PCG had already converged (nothing done: the caller runs KA in this launch)
+template <class L>
+__device__ __forceinline__ bool kf_iteration(const Dev &d, const int k, const int cap, const int admm_par, const int probe, L &lds, const int par) {
+  F1Scal sc{0.0, 0.0, 0};
+  const int cur = (k + 1) & 1, nxt = k & 1;
+  const double *recr = d.kf.rec + (size_t)cur * 4 * (size_t)d.n;
+  double *recw = d.kf.rec + (size_t)nxt * 4 * (size_t)d.n;
+  const bool vec_only = !probe && k >= cap;                 // the last budgeted update: no operator apply follows
+  EKf e{recr, recw, d.p, d.xs, &sc};
+  if (vec_only) {
+    const F1Fold fold = f1_fold_issue(d.part, par, probe);
+    if (!f1_fold_finish(d, k, admm_par, probe, fold, lds.red, sc)) return false;
+    // the rows of this workgroup's row blocks of K (the same ownership as the operator launches)
+    const DevCsr &M = d.kf.K;
+    const int4 *desc = reinterpret_cast<const int4 *>(M.blkdesc);
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, slots = gridDim.x >> 3, per = (M.nblk + 7) >> 3;
+    for (int sl = slot0; sl < per; sl += slots) {
+      const int b = xcd * per + sl;
+      if (b >= M.nblk) break;
+      const int4 ds = desc[b];
+      const int r1 = ds.y < 0 ? ds.x + 1 : ds.y;
+      for (int j = ds.x + (int)threadIdx.x; j < r1; j += kBlock) { e.prefetch(j); e.update(j, 0.0, false); }
+    }
+  } else {
+    GKf g{recr, &sc};
+    if (!process_rows<1>(d.kf.K, g, e, lds, PreKf{d, k, admm_par, probe, par, lds.red, &sc})) return false;
+  }
+  __syncthreads();
+  block_sum_max_sum(e.g, e.rn, e.dl, lds.red);
+  put_partial(d.part, SL_GAMMA0 + par, e.g); put_partial(d.part, SL_RN0 + par, e.rn);
+  if (!vec_only) put_partial(d.part, SL_DELTA + par, e.dl);
+  return true;
+}
+struct EKbK {       // KB of the K form: rhs and r_0 as EKb; the start record {Minv, r_0, 0, 0} of parity 1 instead of r and u_0
+  const double *x, *q, *Minv; double *rec1; double sigma; const double *xg; double *xs; double bn = 0; double px = 0, pq = 0, pm = 0, pg = 0;
+  __device__ __forceinline__ void prefetch(int j) { px = x[j]; pq = q[j]; pm = Minv[j]; pg = xg[j]; }
+  __device__ __forceinline__ void operator()(int j, const double (&s)[2]) {
+    const double rhs = sigma * px - pq + s[0];
+    const double rr = rhs - s[1];
+    double2 *o = reinterpret_cast<double2 *>(rec1 + 4 * (size_t)j);
+    o[0] = make_double2(pm, rr); o[1] = make_double2(0.0, 0.0);
+    xs[j] = pg;                                              // x~ restarts from the extrapolated point (nobody gathers xs in this kernel)
+    bn = nanmax(bn, fabs(rhs));
+  }
+};
+// K.val <- the term lists (backend.h DevKf): copies of B.val entries (P + sigma I) and products rho_i A_ia A_ib, summed in list order
+__global__ __launch_bounds__(kBlock) void k_kf_values(Dev d, int cond) {
+  if (cond && !d.ctl->rho_flag) return;
+  const DevKf &f = d.kf;
+  const int stride = gridDim.x * kBlock;
+  for (int e = blockIdx.x * kBlock + threadIdx.x; e < f.K.nnz; e += stride) {
+    const int t0 = f.tptr[e], t1 = f.tptr[e + 1];
+    double v = 0.0;
+    for (int t = t0; t < t1; t++) { const int i = f.trow[t]; v += i < 0 ? d.B.val[f.ta[t]] : d.rho[i] * (d.A.val[f.ta[t]] * d.A.val[f.tb[t]]); }
+    f.K.val[e] = v;
+  }
+}
+// The slot kernel of the K form: every launch of a chunk's string is this kernel (par: which of the two phase records it reads).
+//   P_KB   rhs, r_0 and the start record from one pass over B (what the two-kernel form's KB does)
+//   P_F    PCG launch F_k on the explicit K; the launch whose fold finds the PCG converged runs KA right there
+//   P_KA   KA after a PCG that stopped at its cap
+__global__ __launch_bounds__(kBlock) void k_slotk(Dev d, int par) {
+  __shared__ union { StreamLds<2> kb; StreamLds<1> f; StreamLdsW<1, double> ka; } lds;
+  const int *R = d.slot + (par ? SR_WORDS : 0);
+  int *W = d.slot + (par ? 0 : SR_WORDS);
+  const FirstDesc fdA = first_desc<true>(d.A);          // (KA's first descriptors: requested with the phase record, as k_slot_a does)
+  SlotState st = slot_read(R);
+  if (st.ph == P_KB) {
+    if (st.admm >= st.target) { st.ph = P_IDLE; slot_write(W, st); return; }
+    GKb g{d.xg, d.v, d.t0, d.n};
+    EKbK e{d.x, d.q, d.Minv, d.kf.rec + 4 * (size_t)d.n, d.sigma, d.xg, d.xs};
+    process_rows<2>(d.B, g, e, lds.kb);
+    __syncthreads();
+    const double BN = block_max(e.bn, lds.kb.red);
+    put_partial(d.part, SL_BN, BN);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
+    st.ph = P_F; st.k = 0;
+  } else if (st.ph == P_F) {
+    if (kf_iteration(d, st.k, st.cap, st.admm & 1, 0, lds.f, par)) {
+      if (st.k >= st.cap) { st.ph = P_KA; st.used = st.k; st.conv = 0; }      // stopped at the cap: the next launch runs KA
+      else st.k += 1;
+    } else {                                             // converged after k - 1 iterations (k = 1: the start met the tolerance): KA right here
+      __syncthreads();
+      slot_ka(d, lds.ka, st.k - 1, 1, fdA, st.admm, st.target, st.seq);
+      st.admm += 1; st.k = 0; st.ph = P_KB;
+    }
+  } else if (st.ph == P_KA) {
+    slot_ka(d, lds.ka, st.used, st.conv, fdA, st.admm, st.target, st.seq, par ^ 1);
+    st.admm += 1; st.k = 0; st.ph = P_KB;
+  }
+  slot_write(W, st);
+}
+
+
 }  // namespace
 
 void kb_rhs(Dev &d) { LAUNCH(k_kb, d, d); }
@@ -1393,8 +1529,11 @@ void slot_pair(Dev &d) {
       hipLaunchKernelGGL((k_slot1<DD, MM>), dim3(kGrid), dim3(kBlock), 0, st(d), db, 1);
     });
   }
+  else if (d.kf.on) { LAUNCH(k_slotk, d, d, 0); LAUNCH(k_slotk, d, d, 1); }
   else { LAUNCH(k_slot_b, d, d); LAUNCH(k_slot_a, d, d); }
 }
+bool kf_supported() { return true; }
+void kf_values(Dev &d, int cond) { if (d.kf.on) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_kf_values, d, d, cond); } }
 void f1_refresh(Dev &d) { if (d.f1.on) { HIP_CHECK(hipSetDevice(d.device)); LAUNCH(k_f1_refresh, d, d); } }
 int slot_seq(Dev &d) { return (im(d).pin_flags + F_COUNT)[SR_SEQ]; }      // slots executed since slot_begin, as of the last fetch (record A)
 int slot_done(Dev &d) {        // ADMM iterations completed by the chunk, as of the last fetch_flags / fetch_res_flags (record A: written by the last A slot)
@@ -1441,7 +1580,7 @@ float time_kernel(Dev &d, int which, int reps) {
   Impl &p = im(d);
   struct Save { double *ptr; size_t cnt; double *bak; };
   const size_t n = d.n, m = d.m;
-  if (which >= 14 && which <= 18 && !d.f1.on) return 0.f;
+  if (which >= 14 && which <= 18 && !d.f1.on && !(which == 16 && d.kf.on)) return 0.f;
   if (which == 20 && !wbx_active(d)) return 0.f;
   if (which == 21 && !(d.wb.on && d.wb.exact)) return 0.f;
   const bool wbx = which == 20;
@@ -1449,7 +1588,7 @@ float time_kernel(Dev &d, int which, int reps) {
   Save sv[] = {{d.x, n, nullptr}, {d.z, m, nullptr}, {d.y, m, nullptr}, {d.xs, n, nullptr}, {d.zt, m, nullptr}, {d.t0, m, nullptr},
                {d.v, m, nullptr}, {d.dx, n, nullptr}, {d.dy, m, nullptr}, {d.r, n, nullptr}, {d.uu, n, nullptr}, {d.p, n, nullptr},
                {d.s, n, nullptr}, {d.w, n, nullptr}, {d.t, m, nullptr}, {d.uu2, n, nullptr}, {d.ms, 2 * n, nullptr},
-               {d.xg, n, nullptr}, {d.xsp, n, nullptr}, {d.ztg, m, nullptr},
+               {d.xg, n, nullptr}, {d.xsp, n, nullptr}, {d.ztg, m, nullptr}, {d.kf.rec, d.kf.on ? 8 * n : 0, nullptr},
                {d.wb.x.ls0, r3, nullptr}, {d.wb.x.ls1, r3, nullptr}, {d.wb.x.partG, gp_, nullptr}, {d.wb.x.partZ, gp_, nullptr}};
   int flags_bak[F_COUNT];
   HIP_CHECK(hipStreamSynchronize(st(d)));

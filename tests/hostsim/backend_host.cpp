@@ -58,6 +58,8 @@ int slot_done(Dev &) { return 0; }
 int slot_seq(Dev &) { return 0; }
 void slot_poll(Dev &, int *seq, int *done) { *seq = 0; *done = 0; }
 void f1_refresh(Dev &) {}
+bool kf_supported() { return false; }
+void kf_values(Dev &, int) {}
 bool wb_supported() { return false; }
 bool wb_large_supported() { return false; }
 void wb_refresh(Dev &) {}

@@ -7,6 +7,9 @@
 //   8  pointers / P: row pointers + rho, column pointers, P row pointers, one P entry (value + column) per lane
 //  16  the LDS phases at their real size: 1000 products, row sums, 1000 transposed products, column sums
 //  32  (with 1) the fold by wave 3 alone, while waves 0-2 request the window: the two round trips to memory overlap
+// 256  the fold as 64-bit INTEGER atomics (round 6): every workgroup adds its three fixed-point partials to three words (order-independent, hence
+//      deterministic), the next launch reads those three words with one scalar load instead of 24 KB of partials; three sets, the third zeroed by workgroup 0
+// 512  ... the same spread over 8 word triples (one per XCD = blockIdx.x & 7): eight times fewer adds per address, 24 words read at the head
 //   hipcc --offload-arch=gfx950 -O3 tools/f1_cost_ladder.hip -o /tmp/ladder && timeout 120 /tmp/ladder
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -62,6 +65,13 @@ __global__ __launch_bounds__(256 * Q) void k_f(double *vec, size_t ns, int k, do
     if (F & 128) { red[tid >> 6] = t; __syncthreads(); alpha += 1e-12 * red[0]; __syncthreads(); }      // ... published through LDS behind a barrier
     else alpha += 1e-12 * t;
   }
+  if (F & 256) {                                             // the three words the previous launch accumulated (spread: 8 triples)
+    const unsigned long long *acw = reinterpret_cast<const unsigned long long *>(part + 2 * 3 * G) + (size_t)((k + 2) % 3) * 32;
+    long long a = 0, c = 0; unsigned long long m = 0;
+    if (F & 512) { for (int x = 0; x < 8; x++) { a += (long long)acw[4 * x]; c += (long long)acw[4 * x + 1]; m = max(m, acw[4 * x + 2]); } }
+    else { a = (long long)acw[0]; c = (long long)acw[1]; m = acw[2]; }
+    alpha = 1e-3 + 1e-12 * (double)a / (1.0 + fabs((double)c) + (double)m);
+  }
   if (phase == 0) return;
   // ---- loads
   const double *src = vec + (size_t)((k - 1) & 1) * NV * ns; double *dst = vec + (size_t)(k & 1) * NV * ns;
@@ -101,6 +111,21 @@ __global__ __launch_bounds__(256 * Q) void k_f(double *vec, size_t ns, int k, do
     { const int wv = threadIdx.x >> 6; if ((threadIdx.x & 63) == 0) { red[wv] = a; red[16 + wv] = c; red[32 + wv] = m; } }
     __syncthreads();
     if (threadIdx.x == 0) { double ra = 0, rc = 0, rm = 0; for (int w = 0; w < 4 * Q; w++) { ra += red[w]; rc += red[16 + w]; rm = fmax(rm, red[32 + w]); } double *pw = part + (size_t)par * 3 * G; pw[blockIdx.x] = ra; pw[G + blockIdx.x] = rc; pw[2 * G + blockIdx.x] = rm; }
+  }
+  if (F & 256) {
+    double a = s, c = s * 0.5, m = fabs(s);
+    for (int o = 32; o; o >>= 1) { a += __shfl_xor(a, o); c += __shfl_xor(c, o); m = fmax(m, __shfl_xor(m, o)); }
+    __syncthreads();
+    { const int wv = threadIdx.x >> 6; if ((threadIdx.x & 63) == 0) { red[wv] = a; red[16 + wv] = c; red[32 + wv] = m; } }
+    __syncthreads();
+    unsigned long long *acb = reinterpret_cast<unsigned long long *>(part + 2 * 3 * G);
+    if (threadIdx.x < 3) {
+      double r = 0; for (int w = 0; w < 4 * Q; w++) r = threadIdx.x == 2 ? fmax(r, red[32 + w]) : r + red[16 * threadIdx.x + w];
+      unsigned long long *dstw = acb + (size_t)(k % 3) * 32 + ((F & 512) ? 4 * (blockIdx.x & 7) : 0) + threadIdx.x;
+      const long long fx = (long long)(r * 1048576.0);
+      if (threadIdx.x == 2) atomicMax(dstw, (unsigned long long)fx); else atomicAdd(dstw, (unsigned long long)fx);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 32) acb[(size_t)((k + 1) % 3) * 32 + threadIdx.x] = 0ull;
   }
   if ((F & 64) && tid == 0) part[(size_t)par * 3 * G + blockIdx.x * Q + sub] = s;      // (one 8-byte store per block at the end)
   if ((F & 2) && blockIdx.x == 0 && threadIdx.x < 16) rec[(par ? 0 : 16) + threadIdx.x] = threadIdx.x == 1 ? 1 : k;
@@ -174,7 +199,7 @@ template <int F, int Q = 1> int run(const char *what, double *vec, size_t ns, do
 int main() {
   const size_t ns = (size_t)G * C + 512;
   double *vec, *part, *stream, *out; int *rec, *aux;
-  CK(hipMalloc(&vec, 8 * 2 * NV * ns)); CK(hipMemset(vec, 0, 8 * 2 * NV * ns)); CK(hipMalloc(&part, 8 * 2 * 3 * G)); CK(hipMemset(part, 0, 8 * 2 * 3 * G));
+  CK(hipMalloc(&vec, 8 * 2 * NV * ns)); CK(hipMemset(vec, 0, 8 * 2 * NV * ns)); CK(hipMalloc(&part, 8 * (2 * 3 * G + 96))); CK(hipMemset(part, 0, 8 * (2 * 3 * G + 96)));
   CK(hipMalloc(&stream, 8 * (size_t)G * 1536)); CK(hipMemset(stream, 0, 8 * (size_t)G * 1536)); CK(hipMalloc(&out, 8 * G)); CK(hipMalloc(&rec, 4 * 32)); CK(hipMalloc(&aux, 4 * (size_t)G * 2048)); CK(hipMemset(aux, 0, 4 * (size_t)G * 2048));
   int one[32]; for (int i = 0; i < 32; i++) one[i] = 1; CK(hipMemcpy(rec, one, sizeof(one), hipMemcpyHostToDevice));
   if (run<0>("vector traffic of an F launch + four barriers", vec, ns, part, rec, stream, aux, out)) return 1;
@@ -186,6 +211,9 @@ int main() {
   run<30>("the same without the scalar fold", vec, ns, part, rec, stream, aux, out);
   run<29>("the same without the phase record", vec, ns, part, rec, stream, aux, out);
   run<27>("the same without the matrix stream", vec, ns, part, rec, stream, aux, out);
+  run<30 | 256>("everything, the fold as three 64-bit integer atomics per workgroup + one scalar read of three words at the head", vec, ns, part, rec, stream, aux, out);
+  run<30 | 256 | 512>("... the atomics spread over eight word triples (by blockIdx & 7)", vec, ns, part, rec, stream, aux, out);
+  run<256>("vector traffic + the atomic fold", vec, ns, part, rec, stream, aux, out);
   run<63>("everything, the fold by wave 3 alone while waves 0-2 request the window", vec, ns, part, rec, stream, aux, out);
   run<33>("vector traffic + the fold by wave 3 alone under the window requests", vec, ns, part, rec, stream, aux, out);
   run<64>("vector traffic + ONE dependent 8-byte read per lane at the head of what the previous launch wrote (no reduction)", vec, ns, part, rec, stream, aux, out);
