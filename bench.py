@@ -128,6 +128,93 @@ def _cpu_baseline(P, q, A, l, u, settings, seconds_target, linsys):
     return out
 
 
+def _cpu_sample_child(conn, P, q, A, l, u, settings, iters, linsys):
+    try:
+        import oracle
+        from oracle import Oracle, SOLVED
+        oracle.use_native()
+        t0 = time.time()
+        o = Oracle().setup(P, q, A, l, u, eps_abs=settings['eps_abs'], eps_rel=settings['eps_rel'], max_iter=iters, adaptive_rho_interval=settings['adaptive_rho_interval'],
+                           check_termination=settings['check_termination'], linsys=linsys, **({'pcg_max_iter': 200, 'pcg_tol': 1e-7} if linsys else {}))
+        ts = time.time() - t0
+        _, _, info = o.solve()
+        conn.send({'value': info.iter / info.solve_time, 'unit': 'ADMM iter/s', 'cores': 1, 'kind': 'port', 'setup_s': ts, 'converged': bool(info.status_val == SOLVED),
+                   'sample': '%d cold-started ADMM iterations in %.1f s (%s), %s' % (info.iter, info.solve_time, 'run to convergence' if info.status_val == SOLVED else 'bounded sample',
+                                                                                     'direct LDL\' KKT solve' if linsys == 0 else 'reduced-KKT Jacobi-PCG, %.1f PCG iterations per ADMM iteration' % (info.pcg_iters / max(info.iter, 1)))})
+    except Exception as e:          # noqa: BLE001
+        conn.send({'error': repr(e)})
+
+
+def cpu_sample(P, q, A, l, u, settings, iters, linsys, limit_s):
+    """A bounded sample of the oracle (iters ADMM iterations at most) in a child process with a hard time limit -- the CPU figure of an extra leg."""
+    import multiprocessing as mp
+    ctx = mp.get_context('fork')
+    parent, child = ctx.Pipe(duplex=False)
+    pr = ctx.Process(target=_cpu_sample_child, args=(child, P, q, A, l, u, settings, iters, linsys))
+    pr.start()
+    out = parent.recv() if parent.poll(limit_s) else None
+    if out is None:
+        pr.terminate()
+    pr.join(5.0)
+    return out if out is not None else {'value': None, 'sample': 'the oracle did not finish %d iterations within %.0f s' % (iters, limit_s)}
+
+
+def config_leg(which, args, settings, osqp_amd, problems, torch):
+    """BASELINE configs[2] (lasso) / configs[3] (portfolio) as a short leg of the DEFAULT line (the driver's record then carries them): first cold solve of
+    a fresh handle, a few steady cold steps (rho reset), the roofline of what those solves launch, a bounded CPU-oracle sample."""
+    import numpy as np
+    if which == 'lasso':
+        P, q, A, l, u = problems.lasso_qp(5000, 10000)
+        name = 'BASELINE configs[2]: lasso-as-QP, 5k features x 10k samples, dense data block (problems.lasso_qp, seed 1)'
+    else:
+        P, q, A, l, u = problems.portfolio_qp(10000, 100)
+        name = 'BASELINE configs[3]: portfolio factor model, 10k assets, 100 factors (problems.portfolio_qp, seed 1)'
+    st = dict(settings); st['max_iter'] = 50000
+    n, mm = len(q), len(l)
+    h = osqp_amd.OSQP(algebra='hip')
+    t0 = time.perf_counter(); h.setup(P, q, A, l, u, **st); t_setup = time.perf_counter() - t0
+    t0 = time.perf_counter(); r = h.solve(); torch.cuda.synchronize(); first_ms = 1e3 * (time.perf_counter() - t0)
+    s1 = h._solver.hip_stats()
+    steps = []
+    for _ in range(3):
+        h.update_settings(rho=0.1)
+        t0 = time.perf_counter(); r = h.solve(); torch.cuda.synchronize(); steps.append(1e3 * (time.perf_counter() - t0))
+    stats = h._solver.hip_stats()
+    probes, kb, pcg_bytes, pcg_ms, dom, dom_kernel, _, _, _, _, _ = measure_roofline(h._solver, stats, n, mm, args)
+    out = {'workload': name + ': n=%d m=%d nnz(A)=%d nnz(P)=%d, eps %g' % (n, mm, A.nnz, P.nnz, settings['eps_abs']),
+           'setup_s': t_setup, 'first_cold_solve_ms': first_ms, 'first_solve_woodbury_factorisations': int(s1.get('woodbury_factorisations', 0)),
+           'first_solve_woodbury_factor_ms': s1.get('woodbury_factor_ms', 0.0), 'ms_per_step': median(steps), 'ms_per_step_each': [round(v, 3) for v in steps],
+           'steady_step_woodbury_cache_hits': int(stats.get('woodbury_cache_hits', 0)), 'steady_step_woodbury_factorisations': int(stats.get('woodbury_factorisations', 0)),
+           'status': r.info.status, 'admm_iters': int(r.info.iter), 'obj_val': r.info.obj_val, 'preconditioner': h._solver.hip_preconditioner(),
+           'pcg_iters_per_admm_iter': stats['pcg_iters_total'] / max(r.info.iter, 1), 'kernel_launches_per_solve': stats['kernel_launches'],
+           'roofline': {'bound': 'hbm', 'kernel': dom, 'ms_per_launch_group': probes[dom]['ms'], 'launches': probes[dom].get('launches', 1), 'bytes': kb[dom],
+                        'achieved': probes[dom]['GBps'], 'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'frac': probes[dom]['GBps'] / HBM_PEAK_GBS}}
+    del h
+    # CPU oracle: portfolio converges in seconds on the direct path; the lasso's dense block does not factorise in the budget: two PCG-path iterations
+    out['cpu_baseline'] = cpu_sample(P, q, A, l, u, st, 20000, 0, 40.0) if which == 'portfolio' else cpu_sample(P, q, A, l, u, st, 2, 1, 40.0)
+    if out['cpu_baseline'].get('value'):
+        out['gpu_over_cpu_iter_rate'] = (r.info.iter / (median(steps) * 1e-3)) / out['cpu_baseline']['value']
+    return out
+
+
+def perturbed_resolves(m, q, l, u, steps, rho0, torch):
+    """What the reference's parametric use is (update(q, l, u) + solve(), /root/reference/src/osqp/nn/torch.py:136-140): before every cold solve q, l, u are
+    REDRAWN (q + 0.1 N(0,1); every row's interval shifted by 0.05 N(0,1): equality rows stay equalities, l <= u holds) and handed over with
+    update_data_vec.  The handle keeps its launch history and graphs; the course of the solve changes with the data."""
+    import numpy as np
+    rng = np.random.default_rng(2024)
+    upd, sol, its = [], [], []
+    for _ in range(steps):
+        qn = q + 0.1 * rng.standard_normal(len(q)); sh = 0.05 * rng.standard_normal(len(l))
+        t0 = time.perf_counter(); m.update(q=qn, l=l + sh, u=u + sh); m.update_settings(rho=rho0); torch.cuda.synchronize(); t1 = time.perf_counter()
+        r = m.solve(); torch.cuda.synchronize(); t2 = time.perf_counter()
+        upd.append(1e3 * (t1 - t0)); sol.append(1e3 * (t2 - t1)); its.append(int(r.info.iter))
+        assert r.info.status == 'solved', r.info.status
+    m.update(q=q, l=l, u=u); m.update_settings(rho=rho0)
+    return {'steps': steps, 'solve_ms_median': median(sol), 'solve_ms_mean': sum(sol) / len(sol), 'solve_ms_each': [round(v, 2) for v in sol], 'update_ms_median': median(upd),
+            'admm_iters_each': its, 'what': 'q, l, u redrawn before every cold solve (update_data_vec, rho reset); launch history and graphs of the handle kept'}
+
+
 def upstream_osqp_line(P, q, A, l, u, settings):
     """when the real `osqp` package (the reference's compiled C core) is importable on the timing host, time it on the same QP and label
     it "upstream osqp x.y.z"; it is not part of this repo and not expected on the GPU box (no network): then the line says so."""
@@ -298,6 +385,7 @@ def main():
     ap.add_argument('--hbm-n', type=int, default=1000000, help='N = 1, headline config only: also time the dominant kernel on the same generator at this many variables '
                                                                '(a working set beyond the 256 MiB Infinity Cache) and report it as roofline.hbm_resident (0 disables)')
     ap.add_argument('--jacobi-leg', type=int, default=1, help='lasso / portfolio: also solve once with the plain Jacobi preconditioner (config.jacobi_only); 0 for profiling runs, whose kernel statistics it would dominate')
+    ap.add_argument('--extra-legs', type=int, default=1, help='N = 1, headline config only: short legs of BASELINE configs[2] (lasso) and configs[3] (portfolio) reported as config.lasso / config.portfolio, and the perturbed re-solve of the headline QP (0 disables)')
     ap.add_argument('--unstructured-leg', type=int, default=1, help='N = 1, headline config only: also solve the unstructured variant of the same sizes and report its PCG iteration as roofline.unstructured (0 disables)')
     args = ap.parse_args()
     warnings.simplefilter('ignore')
@@ -537,7 +625,33 @@ def main():
                 'traffic': tru, 'windowed_row_blocks': '%d of %d' % (int(stu.get('windowed_blocks', 0)), int(stu.get('row_blocks', 0))),
                 'solve': {'status': ru.info.status, 'admm_iters': int(ru.info.iter), 'first_cold_solve_ms': 1e3 * tu, 'second_cold_solve_ms': 1e3 * tu2,
                           'pcg_iters_per_admm_iter': stu['pcg_iters_total'] / max(ru.info.iter, 1)}}
+            # the same matrix through the one-launch form on the explicit reduced matrix (OSQPHipPolicy::kform, off by default): in the record so that the
+            # choice is a measured one -- K needs nnz(K) random gathers per product where the A / B pair needs nnz(A) + nnz(B)
+            os.environ['OSQP_HIP_KFORM'] = '1'
+            try:
+                mk = osqp_amd.OSQP(algebra='hip'); tks = time.perf_counter(); mk.setup(Pu, qu, Au, lu, uu_, **settings); tks = time.perf_counter() - tks
+                mk.solve(); mk.update_settings(rho=rho0)
+                tk = time.perf_counter(); rk = mk.solve(); torch.cuda.synchronize(); tk = time.perf_counter() - tk
+                stk = mk._solver.hip_stats()
+                if int(stk.get('pcg_fused', 0)) == 3:
+                    ms_k = 0.5 * mk._solver.hip_time_kernel(16, args.probe_reps)
+                    out['roofline']['unstructured']['kform'] = {
+                        'what': 'one launch per PCG iteration on the explicit K = P + sigma I + A\' rho A (k_slotk): k + 3 launches per ADMM iteration instead of 2 k + 4',
+                        'nnz_K': int(stk.get('kform_nnz', 0)), 'launches_per_pcg_iteration': 1, 'ms_per_pcg_iteration': ms_k, 'frac': b8d / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        'second_cold_solve_ms': 1e3 * tk, 'admm_iters': int(rk.info.iter), 'status': rk.info.status, 'setup_s': tks, 'kernel_launches_per_solve': stk['kernel_launches'],
+                        'verdict': 'slower than the two-kernel pair: off by default (profiles/r06a_kform_gather_bench.txt: 4.2 M random gathers cost 18-24 us of L2 -> L1 line fills alone)'}
+                del mk
+            finally:
+                os.environ.pop('OSQP_HIP_KFORM', None)
             del mu
+        if args.extra_legs and args.config == 'banded' and world == 1 and not hostsim and args.cpu_seconds > 0:
+            out['config']['perturbed_resolve'] = perturbed_resolves(m, q, l, u, 20, rho0, torch)
+            out['config']['perturbed_resolve_ms'] = out['config']['perturbed_resolve']['solve_ms_median']
+            for leg in ('lasso', 'portfolio'):
+                try:
+                    out['config'][leg] = config_leg(leg, args, settings, osqp_amd, problems, torch)
+                except Exception as e:          # noqa: BLE001 -- an extra leg must not lose the headline line
+                    out['config'][leg] = {'error': repr(e)}
         if args.cpu_seconds > 0 and world == 1:          # (the CPU baseline is timed at N = 1 only: the other ranks would wait 40 s at the barrier)
             cb = cpu_baseline(P, q, A, l, u, settings, args.cpu_seconds)
             cb['upstream_osqp'] = upstream_osqp_line(P, q, A, l, u, settings)      # "if `import osqp` happens to succeed on the box ..."; never required

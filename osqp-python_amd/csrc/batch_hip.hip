@@ -994,10 +994,10 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
   const int prod_len = ((p.A.nnz > p.B.nnz ? p.A.nnz : p.B.nnz) + 1) & ~1;
   if (use_dir256 && p.sp_V && !p.polish && p.n <= kBatchSpecN && e256 <= 8 && prod_len >= 4 * (kBatchSpecN + 2) && !p.only_marked) {
     const size_t lds_spec = lds_reg + sizeof(double) * (kBatchNB + 2 * kBatchSpecN + 4);
+    // (a device that refuses the LDS reservation of this instantiation keeps the banded launch below for the whole batch)
 #define BATCH_LAUNCH_SPEC_W(E, W) do { \
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<256, E, E, true, false, false, true, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec) != hipSuccess) \
-      throw DeviceError("osqp_hip: cannot reserve LDS for the spectral batch kernel"); \
-    hipLaunchKernelGGL((k_batch_admm<256, E, E, true, false, false, true, W>), dim3(p.nbatch), dim3(256), lds_spec, st, p); } while (0)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<256, E, E, true, false, false, true, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec) != hipSuccess) { (void)hipGetLastError(); spectral = false; } \
+    else hipLaunchKernelGGL((k_batch_admm<256, E, E, true, false, false, true, W>), dim3(p.nbatch), dim3(256), lds_spec, st, p); } while (0)
     // One workgroup per CU (everything in registers) at every batch size: since K^-1 lives in the matrix instruction's result registers the two-per-CU
     // form (256 registers, scratch) no longer wins on large batches either -- 4096 QPs 5.9 ms against 6.2 ms.  OSQP_HIP_BATCH_WIDE_ROUNDS=r selects it for
     // batches of more than r rounds of one workgroup per CU (A/B runs).
@@ -1006,10 +1006,10 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
     static const int wide_rounds = std::getenv("OSQP_HIP_BATCH_WIDE_ROUNDS") ? std::atoi(std::getenv("OSQP_HIP_BATCH_WIDE_ROUNDS")) : (1 << 20);
     const bool wide = p.nbatch > wide_rounds * cus;
 #define BATCH_LAUNCH_SPEC(E) do { if (wide) BATCH_LAUNCH_SPEC_W(E, 2); else BATCH_LAUNCH_SPEC_W(E, 1); } while (0)
+    spectral = true;
     if (e256 <= 2) BATCH_LAUNCH_SPEC(2); else if (e256 <= 4) BATCH_LAUNCH_SPEC(4); else if (e256 <= 6) BATCH_LAUNCH_SPEC(6); else BATCH_LAUNCH_SPEC(8);
 #undef BATCH_LAUNCH_SPEC
 #undef BATCH_LAUNCH_SPEC_W
-    spectral = true;
   }
   BatchParams pm = p;
   if (spectral) pm.only_marked = 1;

@@ -253,6 +253,7 @@ void Engine::scale_matrix_values(std::vector<double> &Px, std::vector<double> &A
 // Hence: 1e3 (the reference's value) if no inequality row is active, eq_factor_mixed_ (10) otherwise.  The ADMM fixed
 // point, i.e. the solution, does not depend on it.  osqp_hip_set_rho_eq_factor() / OSQP_HIP_RHO_EQ_FACTOR override it.
 void Engine::classify_constraints(const std::vector<double> &ls, const std::vector<double> &us) {
+  const std::vector<int> before = ctype_;
   ctype_.resize(m);
   int n_ineq = 0;
   for (int i = 0; i < m; i++) {
@@ -266,6 +267,7 @@ void Engine::classify_constraints(const std::vector<double> &ls, const std::vect
   }
   d_.rho_eq_factor = (n_ineq == 0) ? 1e3 : mixed_eq_factor();
   d_.eq_from_cnt = 0;                                   // host classification: k_set_rho takes the factor from rho_eq_factor
+  if (before != ctype_) for (int k = 0; k < DevWb::kCache; k++) d_.wb.cache_rho[k] = -1.0;      // other classes, another rho vector under the same rho_bar: cached Woodbury inverses are dead
 }
 
 // Device-side counterpart of upload_q / upload_bounds_and_types: scaling and classification kernels over the resident raw vectors

@@ -125,6 +125,7 @@ class Engine {
   // keeps K(rho)^-1 in registers, rebuilds it from V at a rho update (no factorisation) and solves with one dense matrix-vector product.
   struct BatchSpectral {
     bool ok = false; int mat_epoch = -1;
+    bool failed = false;             // the decomposition was attempted for exactly this key (mat_epoch, eqf, sigma, rho_is_vec, ctype) and rejected: not retried
     double rho_ref = 0, eqf = 0, sigma = 0; int rho_is_vec = -1;
     std::vector<int> ctype;          // the constraint classes V was built for (a problem of a batch whose own bounds give other classes takes the banded kernel)
     double *V = nullptr, *lam = nullptr; int *d_ctype = nullptr;
@@ -133,7 +134,7 @@ class Engine {
   } bs_;
   void prepare_batch_k0(double rho0);
   int mat_epoch_ = 0;                // bumped by every change of P / A values
-  void prepare_batch_spectral(double rho_ref, double eqf);
+  bool prepare_batch_spectral(double rho_ref, double eqf, bool allow_build);      // true: the form is ready for the current key
   void free_batch_spectral();
   void prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj);
   struct F1Plan {                       // host image of backend.h DevF1 (plan_f1 builds it without touching the device; upload_f1 commits it)
@@ -160,7 +161,7 @@ class Engine {
   void prepare_kf(const std::vector<int> &Arp, const std::vector<int> &Arj, const std::vector<int> &Brp, const std::vector<int> &Bj);      // backend.h DevKf
   bool small_direct_applicable();
   int solve_small_direct(double t0);
-  void attach_batch_direct(BatchParams &p);
+  void attach_batch_direct(BatchParams &p, bool spectral);      // spectral: the caller is a batch large enough to pay for the host-side decomposition (or it exists already)
   void free_batch_direct();
   OSQPHipStats stats_{};
   double update_time_acc_ = 0;

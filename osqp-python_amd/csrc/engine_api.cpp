@@ -294,14 +294,15 @@ void Engine::free_batch_direct() {
 // engine.hpp BatchSpectral.  Dense work on the host, n <= kBatchSpecN: the SCALED matrices (c D P D + sigma I, E A D: what the kernels hold) are
 // rebuilt from the host copies, K_ref and M1 assembled, K_ref = L L' (Cholesky), C = L^-1 M1 L^-T, C = Q Lambda Q' (cyclic Jacobi sweeps: C is
 // symmetric PSD with eigenvalues in [0, 1 / rho_ref]), V = L^-T Q.  Checked before use: || V' K_ref V - I ||_max and || V' M1 V - Lambda ||_max.
+constexpr int kBatchSpectralMin = 32;      // smallest batch that has the spectral form prepared for it (Engine::attach_batch_direct)
 void Engine::free_batch_spectral() {
   void *ptrs[] = {bs_.V, bs_.lam, bs_.d_ctype, bs_.K0};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   bs_ = BatchSpectral();
 }
-void Engine::prepare_batch_spectral(double rho_ref, double eqf) {
+bool Engine::prepare_batch_spectral(double rho_ref, double eqf, bool allow_build) {
   const int N = kBatchSpecN;
-  if (n > N || m == 0 || !be::device_assembly() || reordered_) { bs_.ok = false; return; }
+  if (n > N || m == 0 || !be::device_assembly() || reordered_) { bs_.ok = false; return false; }
   // the reference classes: those of the solver's own bounds, classified as the kernel classifies a problem's (batch_hip.hip, _osqp.py:505-518)
   std::vector<int> ct(m);
   for (int i = 0; i < m; i++) {
@@ -310,9 +311,13 @@ void Engine::prepare_batch_spectral(double rho_ref, double eqf) {
     if (!settings.rho_is_vec) ty = 0;
     ct[i] = ty;
   }
-  if (bs_.ok && bs_.mat_epoch == mat_epoch_ && bs_.eqf == eqf && bs_.sigma == settings.sigma && bs_.rho_is_vec == settings.rho_is_vec && bs_.ctype == ct) return;
+  if ((bs_.ok || bs_.failed) && bs_.mat_epoch == mat_epoch_ && bs_.eqf == eqf && bs_.sigma == settings.sigma && bs_.rho_is_vec == settings.rho_is_vec && bs_.ctype == ct) return bs_.ok;
+  if (!allow_build) return false;                          // (what exists was built for other matrices / classes; this caller does not pay for a new one)
   const double rref = bs_.ok ? bs_.rho_ref : rho_ref;       // (any reference works: K(rho) = K_ref + (rho - rho_ref) M1; the first call's rho stays)
   free_batch_spectral();
+  // a rejected attempt (pivot <= 0, sweeps not converged, check missed) is remembered under the same key: every later call would redo O(n^3 x sweeps)
+  // host work for the same verdict.  Cleared by whatever changes the key (matrix update, other classes, sigma).
+  auto reject = [&]() { bs_.ok = false; bs_.failed = true; bs_.ctype = ct; bs_.eqf = eqf; bs_.sigma = settings.sigma; bs_.rho_is_vec = settings.rho_is_vec; bs_.mat_epoch = mat_epoch_; };
   std::vector<double> K((size_t)n * n, 0.0), M1((size_t)n * n, 0.0);
   for (int j = 0; j < n; j++) {
     for (int k = P_.p[j]; k < P_.p[j + 1]; k++) {
@@ -341,7 +346,7 @@ void Engine::prepare_batch_spectral(double rho_ref, double eqf) {
   for (int c = 0; c < n; c++) {
     double dg = Lm[(size_t)c * n + c];
     for (int k = 0; k < c; k++) dg -= Lm[(size_t)c * n + k] * Lm[(size_t)c * n + k];
-    if (!(dg > 0.0)) { bs_.ok = false; return; }
+    if (!(dg > 0.0)) { reject(); return false; }
     dg = std::sqrt(dg); Lm[(size_t)c * n + c] = dg;
     for (int r = c + 1; r < n; r++) {
       double v = Lm[(size_t)r * n + c];
@@ -363,10 +368,11 @@ void Engine::prepare_batch_spectral(double rho_ref, double eqf) {
   // cyclic Jacobi: C = Q diag(lam) Q'
   std::vector<double> Q((size_t)n * n, 0.0);
   for (int a = 0; a < n; a++) Q[(size_t)a * n + a] = 1.0;
+  bool jacobi_converged = false;
   for (int sweep = 0; sweep < 60; sweep++) {
     double off = 0.0, dsum = 0.0;
     for (int a = 0; a < n; a++) { dsum += C[(size_t)a * n + a] * C[(size_t)a * n + a]; for (int b = a + 1; b < n; b++) off += C[(size_t)a * n + b] * C[(size_t)a * n + b]; }
-    if (off <= 1e-32 * (dsum + 1e-300)) break;
+    if (off <= 1e-32 * (dsum + 1e-300)) { jacobi_converged = true; break; }
     for (int p_ = 0; p_ < n - 1; p_++) for (int q_ = p_ + 1; q_ < n; q_++) {
       const double apq = C[(size_t)p_ * n + q_];
       if (apq == 0.0) continue;
@@ -386,14 +392,18 @@ void Engine::prepare_batch_spectral(double rho_ref, double eqf) {
   }
   std::vector<double> lam(n);
   for (int k = 0; k < n; k++) lam[k] = std::max(C[(size_t)k * n + k], 0.0);
-  // check: V' Kref V = I, V' M1 V = Lambda
-  auto vtxv = [&](const std::vector<double> &X, int a, int b) { double s_ = 0; for (int i = 0; i < n; i++) { double t = 0; for (int j = 0; j < n; j++) t += X[(size_t)i * n + j] * V[(size_t)j * n + b]; s_ += V[(size_t)i * n + a] * t; } return s_; };
-  double err = 0.0;
-  for (int a = 0; a < n; a += std::max(1, n / 16)) for (int b = 0; b < n; b += std::max(1, n / 16)) {
-    err = std::max(err, std::fabs(vtxv(Kref, a, b) - (a == b ? 1.0 : 0.0)));
-    err = std::max(err, std::fabs(vtxv(M1, a, b) - (a == b ? lam[a] : 0.0)) / (1.0 + lam[a]));
-  }
-  if (!(err < 1e-9)) { bs_.ok = false; return; }
+  // check, EVERY entry (two n^3 products: cheap next to the sweeps): V' Kref V = I, V' M1 V = Lambda -- a V that is wrong anywhere would serve as K^-1 for a whole batch
+  double err = jacobi_converged ? 0.0 : 1.0;
+  { std::vector<double> T((size_t)n * n);
+    for (int pass = 0; pass < 2 && err < 1e-9; pass++) {
+      const std::vector<double> &X = pass ? M1 : Kref;
+      for (int i = 0; i < n; i++) for (int b = 0; b < n; b++) { double t = 0; for (int j = 0; j < n; j++) t += X[(size_t)i * n + j] * V[(size_t)j * n + b]; T[(size_t)i * n + b] = t; }      // T = X V
+      for (int a = 0; a < n; a++) for (int b = 0; b < n; b++) {
+        double s_ = 0; for (int i = 0; i < n; i++) s_ += V[(size_t)i * n + a] * T[(size_t)i * n + b];
+        err = std::max(err, pass ? std::fabs(s_ - (a == b ? lam[a] : 0.0)) / (1.0 + std::max(lam[a], lam[b])) : std::fabs(s_ - (a == b ? 1.0 : 0.0)));
+      }
+    } }
+  if (!(err < 1e-9)) { reject(); return false; }
   std::vector<double> Vp((size_t)N * N, 0.0), lp(N, 0.0);
   for (int k = 0; k < n; k++) { lp[k] = lam[k]; for (int j = 0; j < n; j++) Vp[(size_t)k * N + j] = V[(size_t)j * n + k]; }      // column-major, zero-padded
   bs_.V = dev_vec<double>(d_, Vp.size()); be::h2d(d_, bs_.V, Vp.data(), sizeof(double) * Vp.size());
@@ -402,6 +412,7 @@ void Engine::prepare_batch_spectral(double rho_ref, double eqf) {
   bs_.Vh = Vp; bs_.lamh = lp; bs_.k0_ok = false;
   bs_.ctype = ct; bs_.rho_ref = rref; bs_.eqf = eqf; bs_.sigma = settings.sigma; bs_.rho_is_vec = settings.rho_is_vec; bs_.mat_epoch = mat_epoch_;
   bs_.ok = true;
+  return true;
 }
 
 // K^-1(rho0) = V diag(1 / (1 + (rho0 - rho_ref) lambda)) V' in the register layout batch_hip.hip's threads hold it in (the result layout of the f64 matrix
@@ -537,10 +548,12 @@ void Engine::fill_batch_params(BatchParams &p, int nbatch, int warm) {
   p.variant = pol_.batch_variant;
 }
 
-void Engine::attach_batch_direct(BatchParams &p) {
+void Engine::attach_batch_direct(BatchParams &p, bool spectral) {
   if (!bd_.ok) return;
   p.eq_factor_direct = eq_factor_set_ ? eq_factor_mixed_ : 1e3;
-  // the spectral form of the same solve, where it applies (never with polish: that factorises another matrix in the band)
+  // the spectral form of the same solve, where it applies (never with polish: that factorises another matrix in the band) -- and where the caller is a
+  // batch that pays for the host-side decomposition (dense Cholesky + Jacobi sweeps: tens to hundreds of ms for a kernel that runs about one): a
+  // single osqp_solve of a small QP and small batches keep the banded kernel unless a batch has prepared the form for this key before
   if (pol_.batch_variant == 0 && !settings.polishing && n <= kBatchSpecN) {
     if (raw_stale_) ensure_host_vectors();             // (the solver's own bounds define the reference classes)
     int n_ineq = 0;
@@ -549,8 +562,7 @@ void Engine::attach_batch_direct(BatchParams &p) {
       n_ineq += !((li < -OSQP_INFTY * 1e-4 && ui > OSQP_INFTY * 1e-4) || (ui - li < 1e-4));
     }
     if (!settings.rho_is_vec) n_ineq = m;
-    prepare_batch_spectral(p.rho0, n_ineq == 0 ? 1e3 : p.eq_factor_direct);
-    if (bs_.ok) {
+    if (prepare_batch_spectral(p.rho0, n_ineq == 0 ? 1e3 : p.eq_factor_direct, spectral)) {
       p.sp_V = bs_.V; p.sp_lam = bs_.lam; p.sp_ctype = bs_.d_ctype; p.sp_rho_ref = bs_.rho_ref; p.sp_eqf = bs_.eqf;
       prepare_batch_k0(p.rho0);
       if (bs_.k0_ok) { p.sp_K0 = bs_.K0; p.sp_K0_rho = bs_.k0_rho; }
@@ -577,7 +589,7 @@ bool Engine::small_direct_applicable() {
   if (!bd_.ok) return false;
   BatchParams p{};
   fill_batch_params(p, 1, 0);
-  attach_batch_direct(p);
+  attach_batch_direct(p, false);
   return be::batch_direct_selected(p);
 }
 
@@ -705,7 +717,7 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   prepare_batch_direct();
   if (bd_.ok) {
     be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);             // A's values may have changed since the last call
-    attach_batch_direct(p);
+    attach_batch_direct(p, nbatch >= kBatchSpectralMin);
   }
   int err = be::batch_solve(d_, p);
   tph[3] = now_s();
@@ -759,7 +771,7 @@ int Engine::batch_solve_device(int nbatch, const double *q, const double *l, con
   prepare_batch_direct();
   if (bd_.ok) {
     be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);
-    attach_batch_direct(p);
+    attach_batch_direct(p, nbatch >= kBatchSpectralMin);
   }
   be::sync(d_);                                   // the uploads and the product refresh ran on the solver's stream
   const int err = be::batch_solve(d_, p, stream);

@@ -146,7 +146,9 @@ bool Engine::plan_f1(const std::vector<int> &rb, const std::vector<int> &Arp, co
   // (up to three passes: 0 -- only blocks wider than kF1Win give columns away; 1 -- every block does (a block with ONE outlier 400 columns off fits
   //  kF1Win, but its window then overlaps those of many neighbours: more than kF1MaxD replicas); 2 -- the same with the tight choice, far-column
   //  cost 1 instead of 4: reaching out for near outliers keeps the far lists short but widens the windows)
-  for (int pass = 0; pass < (allow_mix ? 3 : 1); pass++) {
+  const int npass = allow_mix ? 3 : 1;
+  for (int pass = 0; pass < npass; pass++) {
+  bool pass_failed = false;                              // (a block this pass cannot place: the next pass gives more columns away -- only the last pass's failure is final)
   const int far_cost = pass == 2 ? 1 : 4;
   pl.mix = 0; std::fill(nfar.begin(), nfar.end(), 0);
   for (int b = 0; b < nb; b++) {
@@ -191,11 +193,12 @@ bool Engine::plan_f1(const std::vector<int> &rb, const std::vector<int> &Arp, co
         for (int i = 0; i < (int)sc.size(); i++) if ((i < bi || i >= bj) && (i == 0 || sc[i] != sc[i - 1])) far++;
         if (far <= kF1MaxFar) { found = true; lo = sc[bi]; hi = sc[bj - 1]; nfar[b] = far; }
       }
-      if (!found) return fail("too many far columns", b);
+      if (!found) { if (pass + 1 < npass) { pass_failed = true; break; } return fail("too many far columns", b); }
       if (nfar[b]) pl.mix = 1;
     }
     lo0[b] = lo; hi0[b] = hi;
   }
+  if (pass_failed) continue;
   // own columns: cs[g] follows the rows (rb[g] n / m: on a band of slope n / m these are the columns under the block) and is clamped into
   // what the neighbouring windows allow -- a column left of block g's window belongs to an earlier block, one right of block g - 1's
   // window to a later one; a column no window holds goes to the block in front of the gap
@@ -212,9 +215,10 @@ bool Engine::plan_f1(const std::vector<int> &rb, const std::vector<int> &Arp, co
     //  without entries of the block's rows simply has an empty segment)
     int lo = lo0[b], hi = hi0[b];
     if (cs[b + 1] > cs[b]) { lo = std::min(lo, cs[b]); hi = std::max(hi, cs[b + 1] - 1); }
-    if (hi - lo + 1 > (nfar[b] ? kF1Win - kF1MaxFar : kF1Win)) return fail("window + own columns too wide", b);
+    if (hi - lo + 1 > (nfar[b] ? kF1Win - kF1MaxFar : kF1Win)) { if (pass + 1 < npass) { pass_failed = true; break; } return fail("window + own columns too wide", b); }
     a0[b] = lo; wl[b] = hi - lo + 1;
   }
+  if (pass_failed) continue;
   D = 0;
   for (int t = 1; t <= kF1MaxD && !D; t++) {
     bool ok = true;

@@ -278,6 +278,7 @@ void wb_refresh(Dev &d) {
   if (!d.wb.on) return;
   HIP_CHECK(hipSetDevice(d.device));
   if (d.wb.large) LAUNCH(k_wb_gather_large, d, d); else LAUNCH(k_wb_gather, d, d);
+  for (int k = 0; k < DevWb::kCache; k++) d.wb.cache_rho[k] = -1.0;      // new matrix values: no inverse computed for the old ones may be looked up (the probe would reject it; this saves the probe)
 }
 void wb_direct(Dev &d) { LAUNCH(k_wb_direct, d, d); }
 void wb_apply(Dev &d, int parity, int direct) {
@@ -341,7 +342,7 @@ static void wb_factor_large(Dev &d) {
   // the buffer this factorisation writes: a free one, else the oldest
   { int slot = -1;
     for (int k = 0; k < w.cache_used; k++) if (w.cache_rho[k] < 0) { slot = k; break; }
-    if (slot < 0 && w.cache_used < (w.cache_on ? DevWb::kCache : 1)) {
+    if (slot < 0 && w.cache_used < ((w.probe && w.cache_on) ? DevWb::kCache : 1)) {      // (without the probe no look-up can ever hit: one buffer)
       slot = w.cache_used;
       if (!w.cache_buf[slot]) { void *b = nullptr; if (hipMalloc(&b, sizeof(double) * (size_t)w.r * w.r) != hipSuccess) { (void)hipGetLastError(); slot = -1; } else w.cache_buf[slot] = static_cast<double *>(b); }
       if (slot >= 0) w.cache_used += 1;

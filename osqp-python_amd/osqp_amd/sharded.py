@@ -95,20 +95,23 @@ def gather_rows(rows_local, nproblems, device=None):
 
 
 # ---------------------------------------------------------------------------------------------------------------- device-resident
-def solve_batch_sharded_device(solver, q=None, l=None, u=None, rank=0, world=1):
+def solve_batch_sharded_device(solver, q=None, l=None, u=None, rank=0, world=1, total=None):
     """The same split with every array resident on the GPU (torch ROCm tensors, float64, shape (B, n) / (B, m); None = the solver's
     own vector): this rank's contiguous row block goes to osqp_hip_batch_solve_device by device pointer on torch's current stream --
     no host copy of q / l / u / x / y -- the 7-field records are assembled on the device, and the ONE all_gather (RCCL) runs on device
     tensors.  Returns (table[B, fields] device tensor, x_local, y_local device tensors, (lo, hi)).  Raises ValueError(str(code)) like
-    hip_batch_solve when the problem does not fit the batch kernel."""
+    hip_batch_solve when the problem does not fit the batch kernel.
+    total = B: the tensors hold ONLY this rank's row block [lo, hi) of a batch of B problems (a rank need not upload the rows of the others)."""
     import torch
     import torch.distributed as dist
     ref = next(a for a in (q, l, u) if a is not None)
     assert ref.is_cuda and all(a is None or (a.is_cuda and a.dtype == torch.float64 and a.dim() == 2) for a in (q, l, u))
-    B, dev = ref.shape[0], ref.device
+    B, dev = (ref.shape[0] if total is None else int(total)), ref.device
     lo, hi = shard_range(B, rank, world)
     nb = hi - lo
-    sl = lambda a: None if a is None else a[lo:hi].contiguous()          # (a row block of a contiguous tensor: a view, no copy)
+    if total is not None:
+        assert ref.shape[0] == nb, 'total=%d: rank %d of %d holds rows [%d, %d), got %d rows' % (B, rank, world, lo, hi, ref.shape[0])
+    sl = lambda a: None if a is None else (a if total is not None else a[lo:hi]).contiguous()          # (a row block of a contiguous tensor: a view, no copy)
     ql, ll, ul = sl(q), sl(l), sl(u)
     x = torch.empty((nb, solver.n), dtype=torch.float64, device=dev)
     y = torch.empty((nb, solver.m), dtype=torch.float64, device=dev)

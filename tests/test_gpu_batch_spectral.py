@@ -25,7 +25,7 @@ def _solver(P, q, A, l, u, banded=False, **kw):
     return s
 
 
-@pytest.mark.parametrize('B', [1, 64, 1100])
+@pytest.mark.parametrize('B', [1, 64, 1100])          # (B = 1: below kBatchSpectralMin both handles run the banded kernel -- the single-QP path of osqp_solve)
 def test_spectral_equals_banded(B):
     P, q, A, L, U = problems.mpc_batch(B)
     xs, ys, rs = _solver(P, q, A, L[0], U[0])._solver.hip_batch_solve(l=L, u=U)
@@ -56,7 +56,7 @@ def test_spectral_follows_matrix_updates():
 
 
 def test_problem_with_other_constraint_classes_takes_the_banded_kernel():
-    B = 24
+    B = 40                                                            # (>= 32: batches below that keep the banded kernel, engine_api.cpp kBatchSpectralMin)
     P, q, A, L, U = problems.mpc_batch(B)
     L = L.copy(); U = U.copy()
     m = L.shape[1]
@@ -67,7 +67,7 @@ def test_problem_with_other_constraint_classes_takes_the_banded_kernel():
     s = _solver(P, q, A, L[0], U[0])
     x, y, rec = s._solver.hip_batch_solve(l=L, u=U)
     assert (rec[:, 0] == 1).all()
-    for i in (0, 7, 11, 23):
+    for i in (0, 7, 11, 39):
         xo, yo, io = Oracle().setup(P, q, A, L[i], U[i], eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, adaptive_rho_interval=50, check_termination=25).solve()
         assert io.status_val == SOLVED and int(rec[i, 1]) == io.iter, (i, rec[i, 1], io.iter)
         assert np.abs(x[i] - xo).max() <= 1e-7 * (1 + np.abs(xo).max())

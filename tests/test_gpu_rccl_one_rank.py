@@ -9,14 +9,16 @@ import sys
 
 import pytest
 
+from util import free_port
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(script, extra, port):
+def _run(script, extra):
     env = dict(os.environ, OSQP_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, script), '--gpus', '1'] + extra
+           '--master-port', str(free_port()), os.path.join(ROOT, script), '--gpus', '1'] + extra
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1]
@@ -24,12 +26,12 @@ def _run(script, extra, port):
 
 
 def test_batch_bench_through_rccl_with_one_rank():
-    d = _run('bench_batch.py', ['--steps', '1', '--warmup', '1', '--batch', '96', '--cpu-sample', '0'], 29531)
+    d = _run('bench_batch.py', ['--steps', '1', '--warmup', '1', '--batch', '96', '--cpu-sample', '0'])
     assert d['n_gpus'] == 1 and d['config']['solved'] == 96 and d['value'] > 0 and d['scaling'] == 'strong'
 
 
 def test_headline_bench_through_rccl_with_one_rank():
-    d = _run('bench.py', ['--steps', '1', '--warmup', '0', '--vars', '4000', '--cpu-seconds', '0', '--probe-reps', '5', '--batch', '96', '--batch-steps', '1', '--hbm-n', '0'], 29532)
+    d = _run('bench.py', ['--steps', '1', '--warmup', '0', '--vars', '4000', '--cpu-seconds', '0', '--probe-reps', '5', '--batch', '96', '--batch-steps', '1', '--hbm-n', '0'])
     assert d['n_gpus'] == 1 and d['config']['status'] == 'solved' and d['value'] > 0
     b = d['config']['batch']                                # BASELINE configs[4] through the sharded device path, all_gather over RCCL in the timed region
     assert b['solved'] == b['records'] == 96 and b['n_ranks_seen'] == 1 and b['QP_per_s'] > 0 and 'RCCL' in b['collective']
@@ -41,7 +43,7 @@ def test_device_resident_sharded_batch_through_rccl_with_one_rank():
     2-rank split reproduce the full batch bit for bit."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
-           '--master-port', '29533', os.path.join(ROOT, 'tests', 'scripts', 'sharded_device_rccl.py')]
+           '--master-port', str(free_port()), os.path.join(ROOT, 'tests', 'scripts', 'sharded_device_rccl.py')]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])

@@ -3,7 +3,8 @@
 reference's CMakeLists.txt:39-41 does (module name substituted for @OSQP_EXT_MODULE_NAME@), compiled against
 include/compat/osqp_api_{functions,types}.h and linked to libosqp_hip.so.  The resulting extension module must expose the
 surface the reference front-end consumes with this engine's enum values, defaults and capabilities.
-Skipped when /root/reference is not present (e.g. on the GPU box); the build directory is git- and gpurun-ignored."""
+Skipped when /root/reference is not present (e.g. on the GPU box).  The configured source and the built module live in a pytest temporary
+directory (tmp_path_factory): nothing derived from the reference's source is ever written under the repository."""
 import importlib.util
 import os
 import subprocess
@@ -16,15 +17,14 @@ import scipy.sparse as sp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = '/root/reference/src/bindings.cpp.in'
-OUT = os.path.join(ROOT, 'tests', '_build', 'dropin')
 
 pytestmark = pytest.mark.skipif(not os.path.exists(SRC), reason='reference tree not present')
 
 
-def _build_binding(modname, lib):
-    """configure_file() + compile of the reference's binding source against include/compat, linked to `lib`"""
+def _build_binding(modname, lib, OUT):
+    """configure_file() + compile of the reference's binding source against include/compat, linked to `lib`; everything goes to OUT (a temp dir)"""
     import pybind11
-    os.makedirs(OUT, exist_ok=True)
+    OUT = str(OUT)
     cpp = os.path.join(OUT, modname + '.cpp')
     with open(SRC) as f:
         text = f.read().replace('@OSQP_EXT_MODULE_NAME@', modname)       # configure_file(), CMakeLists.txt:39-40
@@ -41,21 +41,21 @@ def _build_binding(modname, lib):
 
 
 @pytest.fixture(scope='module')
-def ext():
+def ext(tmp_path_factory):
     import __graft_entry__ as g
     g.build()
     from osqp_amd import _lib
     _lib.handle()                                        # torch's HIP runtime first
-    return _build_binding('osqp_hip_ext', os.path.join(ROOT, 'osqp-python_amd', 'osqp_amd', 'libosqp_hip.so'))
+    return _build_binding('osqp_hip_ext', os.path.join(ROOT, 'osqp-python_amd', 'osqp_amd', 'libosqp_hip.so'), tmp_path_factory.mktemp('dropin_hip'))
 
 
 @pytest.fixture(scope='module')
-def ext_hostsim():
+def ext_hostsim(tmp_path_factory):
     """The same binding source linked against the HOST-SIMULATOR build of the engine (tests/hostsim_build.py: the product's host driver
     + api.cpp over plain-loop device ops): the whole call sequence of bindings.cpp.in:153-281 can then be executed in a container
     without a GPU.  Test infrastructure; nothing of it travels or ships."""
     import hostsim_build
-    return _build_binding('osqp_hostsim_ext', hostsim_build.build())
+    return _build_binding('osqp_hostsim_ext', hostsim_build.build(), tmp_path_factory.mktemp('dropin_hostsim'))
 
 
 def test_reference_binding_compiles_and_exposes_the_ext_surface(ext):

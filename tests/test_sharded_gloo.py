@@ -6,6 +6,8 @@ import sys
 
 import numpy as np
 
+from util import free_port
+
 WORKER = r'''
 import os, sys, warnings
 warnings.simplefilter('ignore')
@@ -38,7 +40,7 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29517', WORLD_SIZE='2')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), WORLD_SIZE='2')
     procs = [subprocess.Popen([sys.executable, str(script), root, str(tmp_path)], env=dict(env, RANK=str(r))) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0
@@ -94,7 +96,7 @@ def test_torch_layer_two_rank_gloo(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'layer_worker.py'
     script.write_text(LAYER_WORKER)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29519', WORLD_SIZE='2')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), WORLD_SIZE='2')
     procs = [subprocess.Popen([sys.executable, str(script), root, str(tmp_path)], env=dict(env, RANK=str(r))) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0

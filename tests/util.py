@@ -46,6 +46,14 @@ class Fixture:
         return s
 
 
+def free_port():
+    """An ephemeral TCP port for a torch.distributed rendezvous on 127.0.0.1 (fixed numbers collide when tests run in parallel)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
 def record_deviation(test, case, **vals):
     """Measured deviations of a parity test (|dx|, |dy| relative to the solution's scale, iteration counts ...) appended to
     gpurun_out/parity_deviations.json -- the GPU run leaves the numbers behind even when pytest runs with -q (a copy of the round's
