@@ -250,6 +250,20 @@ OSQPInt osqp_hip_batch_solve(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat
 OSQPInt osqp_hip_batch_solve_device(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat *q_dev, const OSQPFloat *l_dev, const OSQPFloat *u_dev,
                                     OSQPFloat *x_dev, OSQPFloat *y_dev, OSQPFloat *rec_dev, OSQPInt warm_start, void *stream);
 
+/* The same batch with PER-PROBLEM MATRIX VALUES: the reference's forward accepts a P_val / A_val per batch element and solves the elements concurrently, one
+ * solver object each (/root/reference/src/osqp/nn/torch.py:128-157, 184-217).  Px: nbatch x nnz(P) (the upper triangle in the CSC order given at setup --
+ * what osqp_update_data_mat takes as Px with Px_idx = NULL, bindings.cpp.in:240-281), Ax: nbatch x nnz(A) (CSC order); NULL = this solver's own values
+ * for every problem.  Still ONE solve launch, one workgroup per problem: a launch in front of it assembles and equilibrates every problem's own matrices
+ * (the Ruiz scaling of /root/reference/src/osqppurepy/_osqp.py:389-497 with the problem's own P, q, A -- an element is scaled exactly as a solver set up
+ * with its data alone), the solve kernel then reads its problem's values; exact linear solves by the banded LDL' of the problem's own K (iteration
+ * counts equal the oracle's per element).  The sparsity pattern, the settings and the launch-order history are the handle's.  _device: every array in
+ * device memory, asynchronous on `stream` exactly like osqp_hip_batch_solve_device. */
+OSQPInt osqp_hip_batch_solve_mat(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat *Px, const OSQPFloat *Ax, const OSQPFloat *q, const OSQPFloat *l,
+                                 const OSQPFloat *u, OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm);
+OSQPInt osqp_hip_batch_solve_mat_device(OSQPSolver *solver, OSQPInt nbatch, const OSQPFloat *Px_dev, const OSQPFloat *Ax_dev, const OSQPFloat *q_dev,
+                                        const OSQPFloat *l_dev, const OSQPFloat *u_dev, OSQPFloat *x_dev, OSQPFloat *y_dev, OSQPFloat *rec_dev,
+                                        OSQPInt warm_start, void *stream);
+
 /* Parametric re-solve with the new data ALREADY ON THE GPU (the reference's update(q, l, u) + solve() loop,
  * src/osqp/nn/torch.py:136-140, /root/reference/src/osqppurepy/_osqp.py:1312-1367 and :1493-1545 restated as kernels):
  * q_dev / l_dev / u_dev / x_dev / y_dev are UNSCALED float64 arrays in device memory of this solver's device, NULL = unchanged.

@@ -97,6 +97,12 @@ OSQPInt osqp_hip_get_policy(OSQPSolver *s, OSQPHipPolicy *p) { return guarded(s,
 OSQPInt osqp_hip_batch_solve(OSQPSolver *s, OSQPInt nbatch, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u, OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm) {
   return guarded(s, [&](Engine &e) { return e.batch_solve(nbatch, q, l, u, x, y, rec, warm); });
 }
+OSQPInt osqp_hip_batch_solve_mat(OSQPSolver *s, OSQPInt nbatch, const OSQPFloat *Px, const OSQPFloat *Ax, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u, OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm) {
+  return guarded(s, [&](Engine &e) { return e.batch_solve(nbatch, q, l, u, x, y, rec, warm, nullptr, Px, Ax); });
+}
+OSQPInt osqp_hip_batch_solve_mat_device(OSQPSolver *s, OSQPInt nbatch, const OSQPFloat *Px, const OSQPFloat *Ax, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u, OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm, void *stream) {
+  return guarded(s, [&](Engine &e) { return e.batch_solve_device(nbatch, q, l, u, x, y, rec, warm, stream, Px, Ax); });
+}
 OSQPInt osqp_hip_batch_solve_device(OSQPSolver *s, OSQPInt nbatch, const OSQPFloat *q, const OSQPFloat *l, const OSQPFloat *u, OSQPFloat *x, OSQPFloat *y, OSQPFloat *rec, OSQPInt warm, void *stream) {
   return guarded(s, [&](Engine &e) { return e.batch_solve_device(nbatch, q, l, u, x, y, rec, warm, stream); });
 }

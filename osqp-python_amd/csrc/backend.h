@@ -314,6 +314,14 @@ struct BatchParams {
   // out as the threads hold it -- [64 columns][256 threads]: a problem LOADS its first K^-1 (coalesced, L2-resident) instead of rebuilding it from V
   const double *sp_K0 = nullptr; double sp_K0_rho = 0.0;
   int only_marked = 0;
+  // PER-PROBLEM MATRICES (the reference's forward with a P_val / A_val per batch element, /root/reference/src/osqp/nn/torch.py:128-157, 184-217: one
+  // solver object per element, each set up -- and therefore SCALED -- with its own matrices).  mat_on != 0: problem b reads its own scaled values
+  // Aval_b + b nnz(A), Bval_b + b nnz(B), its own equilibration D_b / Dinv_b (+ b n), E_b / Einv_b (+ b m), c_b[b] and, in the banded direct variant,
+  // its own products kp_val_b + b nprod -- all written by be::batch_prepare (k_batch_prepare: assembly + Ruiz equilibration of _osqp.py:389-497 per
+  // problem, one workgroup each, in LDS) right before the solve launch.  The spectral form (shared V) does not apply.
+  int mat_on = 0, nprod = 0;
+  double *Aval_b = nullptr, *Bval_b = nullptr, *D_b = nullptr, *Dinv_b = nullptr, *E_b = nullptr, *Einv_b = nullptr, *c_b = nullptr, *kp_val_b = nullptr;
+  const int *kp_a = nullptr, *kp_b = nullptr;   // per product: positions of A_ia, A_ib in A.val (the products are formed per problem)
 };
 constexpr int kBatchSpecN = 128;        // the spectral form keeps K^-1 in registers: row i = thread / 2, 64 columns per thread
 constexpr double kBatchUnsolved = -1000.0;
@@ -326,6 +334,10 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream = nullptr);
 size_t batch_direct_lds_bytes(int n, int m, int nnz, int bw); // 0 if the banded factor does not fit next to the iterates
 bool batch_direct_selected(const BatchParams &p);              // would batch_solve run a direct (banded LDL') variant for p?
 void batch_products(Dev &d, int nprod, const int *a, const int *b, double *out);   // out[p] = A.val[a[p]] * A.val[b[p]]
+// per-problem matrices: Px_b [nbatch][nnz(P as given at setup: upper triangle, CSC order)] / Ax_b [nbatch][nnz(A), CSC order], UNSCALED, device
+// pointers; nullptr = the solver's own values for every problem.  Fills p.Aval_b .. p.kp_val_b (allocated by the caller) on `stream` (nullptr: d.stream).
+// scaling_iters: the setting's `scaling`.  Returns OSQP_FUNC_NOT_IMPLEMENTED when a problem's matrices do not fit one workgroup's LDS.
+int batch_prepare(Dev &d, const BatchParams &p, const double *Px_b, const double *Ax_b, int scaling_iters, void *stream);
 void batch_order(Dev &d, int nbatch, const int *iters, int *order, void *stream);  // order = problems by descending iters (ties by index), on `stream`
 
 const char *name();

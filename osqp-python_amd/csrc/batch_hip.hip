@@ -205,6 +205,13 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? (SPEC ? SP
   if ((int)blockIdx.x >= P.nbatch) return;
   const int b = P.order ? P.order[blockIdx.x] : (int)blockIdx.x;      // (workgroups are dispatched in index order: expected-longest problems first)
   if (!SPEC && P.only_marked && P.rec[(size_t)b * kBatchRec] != kBatchUnsolved) return;      // (second launch behind the spectral one: only what that one left)
+  // per-problem matrices (BatchParams::mat_on): this workgroup's copy of the parameter block points at ITS problem's scaled values, equilibration and
+  // products -- everything below reads them through the same names as the shared case (block-uniform: scalar registers)
+  if (P.mat_on) {
+    P.A.val = P.Aval_b + (size_t)b * P.A.nnz; P.B.val = P.Bval_b + (size_t)b * P.B.nnz;
+    P.D = P.D_b + (size_t)b * P.n; P.Dinv = P.Dinv_b + (size_t)b * P.n; P.E = P.E_b + (size_t)b * P.m; P.Einv = P.Einv_b + (size_t)b * P.m;
+    P.c = P.c_b[b]; P.cinv = 1.0 / P.c; P.kp_val = P.kp_val_b + (size_t)b * P.nprod;
+  }
   // ---- LDS carve ----
   double *x = sm, *xs = x + n, *r = xs + n, *zv = r + n, *p = zv + n, *Kp = p + n, *q = Kp + n, *Minv = q + n, *dx = Minv + n, *tn = dx + n;
   double *z = tn + n, *y = z + m, *t = y + m, *l = t + m, *u = l + m, *rho = u + m, *zt = rho + m, *dy = zt + m;
@@ -949,6 +956,68 @@ void batch_products(Dev &d, int nprod, const int *a, const int *b, double *out) 
   if (nprod > 0) hipLaunchKernelGGL(k_batch_products, dim3((nprod + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(d.stream), d.A, nprod, a, b, out);
 }
 
+// ---- per-problem matrices: assembly + equilibration of every problem's own (P_b, A_b), one workgroup per problem, everything in LDS.
+// The same arithmetic, entry for entry, as the single-QP setup (backend_hip.hip k_asm_scatter, k_rowmax, k_ruiz_*: _osqp.py:389-497): an element of a
+// per-element batch is scaled exactly as a solver set up with its matrices alone would scale it -- the reference's forward builds one solver per
+// element (nn/torch.py:142-157).  Output: the scaled CSR values of A and B = [P + sigma I | A'], D, 1/D, E, 1/E, c and the banded variant's products.
+__device__ __forceinline__ double batch_limit_scaling(double v) { return v < 1e-4 ? 1.0 : (v > 1e4 ? 1e4 : v); }     // _osqp.py:363-387
+__global__ __launch_bounds__(256) void k_batch_prepare(BatchParams P, Dev d, const double *Px_b, const double *Ax_b, int iters) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int n = P.n, m = P.m, tid = threadIdx.x, b = blockIdx.x, nzA = P.A.nnz, nzB = P.B.nnz;
+  if (b >= P.nbatch) return;
+  double *Av = sm, *Bv = Av + ((nzA + 1) & ~1), *D = Bv + ((nzB + 1) & ~1), *E = D + n, *dt = E + m, *et = dt + n, *q = et + m, *np_ = q + n, *scr = np_ + n;
+  Red<4> red{scr};
+  const double *Ar = Ax_b ? Ax_b + (size_t)b * d.nzA : d.Araw, *Pr = Px_b ? Px_b + (size_t)b * d.nzP : d.Praw;
+  for (int k = tid; k < nzB; k += 256) Bv[k] = 0.0;
+  __syncthreads();
+  for (int k = tid; k < d.nzA; k += 256) { const double v = Ar[k]; Av[d.AmA[k]] = v; Bv[d.AmB[k]] = v; }
+  for (int k = tid; k < d.nzP; k += 256) {
+    const int i = d.Pi[k], j = d.Pj[k]; const double v = Pr[k];
+    if (i == j) atomicAdd(&Bv[d.Pm1[k]], v);            // (repeated (j, j) entries of a valid CSC sum up)
+    else { Bv[d.Pm1[k]] = v; Bv[d.Pm2[k]] = v; }
+  }
+  for (int j = tid; j < n; j += 256) { D[j] = 1.0; q[j] = P.q ? P.q[(size_t)b * n + j] : P.q0[j]; }
+  for (int i = tid; i < m; i += 256) E[i] = 1.0;
+  double c = 1.0;
+  __syncthreads();
+  const int *Arp = P.A.rowptr, *Ac = P.A.col, *Brp = P.B.rowptr, *Bc = P.B.col;
+  for (int it = 0; it < iters; it++) {
+    for (int j = tid; j < n; j += 256) { double mx = 0.0; for (int k = Brp[j]; k < Brp[j + 1]; k++) mx = fmax(mx, fabs(Bv[k])); dt[j] = 1.0 / sqrt(batch_limit_scaling(mx)); }      // KKT column j = row j of [P | A']
+    for (int i = tid; i < m; i += 256) { double mx = 0.0; for (int k = Arp[i]; k < Arp[i + 1]; k++) mx = fmax(mx, fabs(Av[k])); et[i] = 1.0 / sqrt(batch_limit_scaling(mx)); }
+    __syncthreads();
+    for (int i = tid; i < m; i += 256) { const double ei = et[i]; for (int k = Arp[i]; k < Arp[i + 1]; k++) Av[k] *= ei * dt[Ac[k]]; E[i] *= ei; }
+    for (int j = tid; j < n; j += 256) {
+      const double dj = dt[j];
+      for (int k = Brp[j]; k < Brp[j + 1]; k++) { const int cc = Bc[k]; Bv[k] *= cc < n ? dt[cc] * dj : et[cc - n] * dj; }
+      q[j] *= dj; D[j] *= dj;
+    }
+    __syncthreads();
+    double sum = 0.0, nq = 0.0;
+    for (int j = tid; j < n; j += 256) { double mx = 0.0; for (int k = Brp[j]; k < Brp[j + 1] && Bc[k] < n; k++) mx = fmax(mx, fabs(Bv[k])); sum += mx; nq = fmax(nq, fabs(q[j])); }
+    red.sum_max(sum, nq);
+    const double mean = sum / (double)(n > 0 ? n : 1);
+    const double ct = 1.0 / batch_limit_scaling(fmax(batch_limit_scaling(nq), mean));
+    c *= ct;
+    for (int j = tid; j < n; j += 256) { for (int k = Brp[j]; k < Brp[j + 1] && Bc[k] < n; k++) Bv[k] *= ct; q[j] *= ct; }
+    __syncthreads();
+  }
+  for (int j = tid; j < n; j += 256) { Bv[d.Bdiag[j]] += P.sigma; P.D_b[(size_t)b * n + j] = D[j]; P.Dinv_b[(size_t)b * n + j] = 1.0 / D[j]; }
+  for (int i = tid; i < m; i += 256) { P.E_b[(size_t)b * m + i] = E[i]; P.Einv_b[(size_t)b * m + i] = 1.0 / E[i]; }
+  if (tid == 0) P.c_b[b] = c;
+  __syncthreads();
+  for (int k = tid; k < nzA; k += 256) P.Aval_b[(size_t)b * nzA + k] = Av[k];
+  for (int k = tid; k < nzB; k += 256) P.Bval_b[(size_t)b * nzB + k] = Bv[k];
+  if (P.kp_val_b) for (int k = tid; k < P.nprod; k += 256) P.kp_val_b[(size_t)b * P.nprod + k] = Av[P.kp_a[k]] * Av[P.kp_b[k]];
+}
+int batch_prepare(Dev &d, const BatchParams &p, const double *Px_b, const double *Ax_b, int scaling_iters, void *stream) {
+  if (hipSetDevice(d.device) != hipSuccess) return OSQP_ALGEBRA_LOAD_ERROR;
+  const size_t lds = sizeof(double) * ((size_t)((p.A.nnz + 1) & ~1) + ((p.B.nnz + 1) & ~1) + 4 * (size_t)p.n + 2 * (size_t)p.m + 16);
+  if (lds > 144 * 1024) return OSQP_FUNC_NOT_IMPLEMENTED;
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_prepare), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return OSQP_FUNC_NOT_IMPLEMENTED; }
+  hipLaunchKernelGGL(k_batch_prepare, dim3(p.nbatch), dim3(256), lds, static_cast<hipStream_t>(stream ? stream : d.stream), p, d, Px_b, Ax_b, scaling_iters);
+  return OSQP_NO_ERROR;
+}
+
 namespace {
 struct BatchChoice { bool dir256, dir64, w64, w256, generic; int e64, e256; size_t lds_reg, lds_gen, lds_dir; };
 BatchChoice choose_batch_variant(const BatchParams &p) {
@@ -992,7 +1061,7 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
   // reference's is solved by this launch; the others are marked and left to the banded kernel launched right behind (only_marked).
   bool spectral = false;
   const int prod_len = ((p.A.nnz > p.B.nnz ? p.A.nnz : p.B.nnz) + 1) & ~1;
-  if (use_dir256 && p.sp_V && !p.polish && p.n <= kBatchSpecN && e256 <= 8 && prod_len >= 4 * (kBatchSpecN + 2) && !p.only_marked) {
+  if (use_dir256 && p.sp_V && !p.mat_on && !p.polish && p.n <= kBatchSpecN && e256 <= 8 && prod_len >= 4 * (kBatchSpecN + 2) && !p.only_marked) {
     const size_t lds_spec = lds_reg + sizeof(double) * (kBatchNB + 2 * kBatchSpecN + 4);
     // (a device that refuses the LDS reservation of this instantiation keeps the banded launch below for the whole batch)
 #define BATCH_LAUNCH_SPEC_W(E, W) do { \

@@ -144,6 +144,7 @@ void Engine::free_all() {
   try { be::activate(d_); be::ext_wait(d_); be::sync(d_); } catch (const DeviceError &) {}       // runs in the destructor: release what we can
   drop_graphs();
   if (bbuf_) { be::dfree(d_, bbuf_); bbuf_ = nullptr; bbuf_cap_ = 0; }
+  if (bmat_) { be::dfree(d_, bmat_); bmat_ = nullptr; bmat_cap_ = 0; }
   if (d_batch_order_) { be::dfree(d_, d_batch_order_); d_batch_order_ = nullptr; batch_order_cap_ = 0; }
   if (d_batch_iters_) { be::dfree(d_, d_batch_iters_); d_batch_iters_ = nullptr; d_batch_iters_n_ = 0; }
   batch_order_.clear();

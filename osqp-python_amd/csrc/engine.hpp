@@ -53,8 +53,11 @@ class Engine {
   void set_print(osqp_hip_print_fn fn, void *user) { print_fn_ = fn; print_user_ = user; }
   static void set_default_print(osqp_hip_print_fn fn, void *user);
   int set_rho_eq_factor(double f);
-  int batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, double *zs_dev = nullptr);
-  int batch_solve_device(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, void *stream);
+  // Px / Ax: optional PER-PROBLEM matrix values (nbatch x nnz(P upper triangle as given at setup) / nbatch x nnz(A), CSC order; nullptr = this solver's
+  // values for every problem) -- the reference's forward with a P_val / A_val per batch element (nn/torch.py:128-157): still ONE launch
+  int batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, double *zs_dev = nullptr, const double *Px = nullptr, const double *Ax = nullptr);
+  int batch_solve_device(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, void *stream, const double *Px = nullptr, const double *Ax = nullptr);
+  int attach_batch_matrices(BatchParams &p, const double *Px_dev, const double *Ax_dev, void *stream);      // per-problem matrices: scratch + be::batch_prepare
   void fill_batch_params(BatchParams &p, int nbatch, int warm);
   // LinSysSolver slot (include/osqp_hip.h): this Engine instance is then used ONLY as the reduced-KKT solver
   int ls_setup(const OSQPCscMatrix *P, const OSQPCscMatrix *A, const double *rho_vec, const OSQPSettings *s);
@@ -104,6 +107,7 @@ class Engine {
   bool use_graph_ = true;
   std::map<std::pair<int, int>, void *> graphs_;
   double *bbuf_ = nullptr; size_t bbuf_cap_ = 0;      // device scratch of batch_solve, kept across calls
+  double *bmat_ = nullptr; size_t bmat_cap_ = 0;      // per-problem matrices: scaled values, equilibration and products of every problem (BatchParams::Aval_b ..), kept across calls
   int *d_batch_iters_ = nullptr; int d_batch_iters_n_ = 0;      // device-pointer path: iteration counts of the previous call (its records never reach the host)
   std::vector<int> batch_order_; int *d_batch_order_ = nullptr; size_t batch_order_cap_ = 0;   // problems by descending iteration count of the previous batch call
   double *ckpt_ = nullptr;                            // device copy of (x, x~, z, y) taken before a solve's first chunk (cg cap escalation)

@@ -669,7 +669,20 @@ int Engine::solve_small_direct(double t0) {
   return OSQP_NO_ERROR;
 }
 
-int Engine::batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, double *zs_dev) {
+// Per-problem matrices (BatchParams::mat_on): one scratch block [Aval | Bval | D | Dinv | E | Einv | c | products], filled by be::batch_prepare on `stream`
+// (assembly + the reference's equilibration per problem).  The spectral form (one V for the whole batch) is switched off for such a call.
+int Engine::attach_batch_matrices(BatchParams &p, const double *Px_dev, const double *Ax_dev, void *stream) {
+  if (!be::device_assembly()) return OSQP_FUNC_NOT_IMPLEMENTED;
+  const size_t nb = (size_t)p.nbatch, nzA = (size_t)d_.A.nnz, nzB = (size_t)d_.B.nnz, np = bd_.ok ? (size_t)bd_.nprod : 0;
+  const size_t need = nb * (nzA + nzB + 2 * (size_t)n + 2 * (size_t)m + 1 + np);
+  if (need > bmat_cap_) { be::ext_wait(d_); if (bmat_) be::dfree(d_, bmat_); bmat_ = dev_vec<double>(d_, need); bmat_cap_ = need; be::sync(d_); }
+  p.Aval_b = bmat_; p.Bval_b = p.Aval_b + nb * nzA; p.D_b = p.Bval_b + nb * nzB; p.Dinv_b = p.D_b + nb * n; p.E_b = p.Dinv_b + nb * n; p.Einv_b = p.E_b + nb * m;
+  p.c_b = p.Einv_b + nb * m; p.kp_val_b = np ? p.c_b + nb : nullptr; p.nprod = (int)np; p.kp_a = bd_.kp_a; p.kp_b = bd_.kp_b;
+  p.mat_on = 1; p.sp_V = nullptr; p.sp_K0 = nullptr;
+  return be::batch_prepare(d_, p, Px_dev, Ax_dev, settings.scaling, stream);
+}
+
+int Engine::batch_solve(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, double *zs_dev, const double *Px, const double *Ax) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   if (nbatch <= 0 || !x || !y || !rec) return OSQP_DATA_VALIDATION_ERROR;
   prepare_batch_direct();                                     // (symbolic part runs on every backend: tests read the bandwidth)
@@ -687,9 +700,13 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
     }
   tph[1] = now_s();
   // one device scratch block, kept for the next call: [q | l | u | x | y | rec | q0 | l0 | u0]
-  const size_t need = 2 * N + 3 * M + (size_t)nbatch * kBatchRec + n + 2 * (size_t)m;
+  const size_t NP = Px ? (size_t)nbatch * P_.nnz() : 0, NA = Ax ? (size_t)nbatch * A_.nnz() : 0;
+  const size_t need = 2 * N + 3 * M + (size_t)nbatch * kBatchRec + n + 2 * (size_t)m + NP + NA;
   if (need > bbuf_cap_) { if (bbuf_) be::dfree(d_, bbuf_); bbuf_ = dev_vec<double>(d_, need); bbuf_cap_ = need; }
   double *dq = bbuf_, *dl = dq + N, *du = dl + M, *dx = du + M, *dy = dx + N, *drec = dy + M, *dq0 = drec + (size_t)nbatch * kBatchRec, *dl0 = dq0 + n, *du0 = dl0 + m;
+  double *dPx = du0 + m, *dAx = dPx + NP;
+  if (Px) be::h2d(d_, dPx, Px, sizeof(double) * NP);
+  if (Ax) be::h2d(d_, dAx, Ax, sizeof(double) * NA);
   const bool devv = be::device_vec_updates();         // then the solver's own q, l, u are resident (unscaled): no upload for NULL arguments
   if (q) be::h2d(d_, dq, q, sizeof(double) * N); else if (devv) dq0 = d_.qraw; else be::h2d(d_, dq0, q0_.data(), sizeof(double) * n);
   if (l) be::h2d(d_, dl, l, sizeof(double) * M); else if (devv) dl0 = d_.lraw; else be::h2d(d_, dl0, l0_.data(), sizeof(double) * m);
@@ -717,8 +734,9 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   prepare_batch_direct();
   if (bd_.ok) {
     be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);             // A's values may have changed since the last call
-    attach_batch_direct(p, nbatch >= kBatchSpectralMin);
+    attach_batch_direct(p, nbatch >= kBatchSpectralMin && !Px && !Ax);
   }
+  if (Px || Ax) { const int e2 = attach_batch_matrices(p, Px ? dPx : nullptr, Ax ? dAx : nullptr, nullptr); if (e2) return e2; }
   int err = be::batch_solve(d_, p);
   tph[3] = now_s();
   if (!err) {
@@ -738,7 +756,7 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
 
 // Device-resident variant: q, l, u, x, y, rec are device pointers on this solver's device; the kernel is
 // enqueued on the caller's stream and not waited for (stream == nullptr: the solver's stream, synchronous).
-int Engine::batch_solve_device(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, void *stream) {
+int Engine::batch_solve_device(int nbatch, const double *q, const double *l, const double *u, double *x, double *y, double *rec, int warm, void *stream, const double *Px, const double *Ax) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   // nbatch == 0: the applicability query of a rank whose share of a sharded batch is empty -- the answer depends on (n, m) alone, so every
   // rank of a job reaches the same decision before its first collective (osqp_amd/sharded.py)
@@ -771,9 +789,10 @@ int Engine::batch_solve_device(int nbatch, const double *q, const double *l, con
   prepare_batch_direct();
   if (bd_.ok) {
     be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);
-    attach_batch_direct(p, nbatch >= kBatchSpectralMin);
+    attach_batch_direct(p, nbatch >= kBatchSpectralMin && !Px && !Ax);
   }
   be::sync(d_);                                   // the uploads and the product refresh ran on the solver's stream
+  if (Px || Ax) { const int e2 = attach_batch_matrices(p, Px, Ax, stream); if (e2) return e2; }      // (on the caller's stream, in front of the solve launch)
   const int err = be::batch_solve(d_, p, stream);
   if (!err) be::ext_record(d_, stream);           // later calls that overwrite or free what this kernel reads wait for it (ext_wait)
   return err;

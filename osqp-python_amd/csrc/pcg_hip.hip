@@ -1452,7 +1452,9 @@ __global__ __launch_bounds__(kBlock) void k_slotk(Dev d, int par) {
     if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
     st.ph = P_F; st.k = 0;
   } else if (st.ph == P_F) {
-    if (kf_iteration(d, st.k, st.cap, st.admm & 1, 0, lds.f, par)) {
+    // (st.conv == 2 while the phase is P_F: the timing probe's records -- k_slot_probe_f -- the fold is paid for, then fixed scalars: a CG left running for
+    //  hundreds of iterations past convergence ends in 0 / 0, and a NaN residual reads as "converged")
+    if (kf_iteration(d, st.k, st.cap, st.admm & 1, st.conv == 2 ? 2 : 0, lds.f, par)) {
       if (st.k >= st.cap) { st.ph = P_KA; st.used = st.k; st.conv = 0; }      // stopped at the cap: the next launch runs KA
       else st.k += 1;
     } else {                                             // converged after k - 1 iterations (k = 1: the start met the tolerance): KA right here
@@ -1561,10 +1563,10 @@ void slot_poll(Dev &d, int *seq, int *done) {
 // iterate state that KB/KA/Kv overwrite is saved and restored around the measurement.
 // probe 16: the phase records say "PCG iteration k0 of a chunk that never ends", the tolerance can never be met: the launches that follow
 // are the slot kernel's own F launches -- scalars from the fold, stopping test, record hand-over -- exactly as a solve runs them
-__global__ void k_slot_probe_f(int *slot, double *scal, int k0) {
+__global__ void k_slot_probe_f(int *slot, double *scal, int k0, int conv) {
   for (int rec = 0; rec < 2; rec++) {
     int *r = slot + rec * SR_WORDS;
-    r[SR_PHASE] = P_F; r[SR_K] = k0; r[SR_ADMM] = 0; r[SR_TARGET] = 1; r[SR_USED] = 0; r[SR_CONV] = 0; r[SR_CAP] = 1 << 20; r[SR_SEQ] = rec ? -1 : 0;
+    r[SR_PHASE] = P_F; r[SR_K] = k0; r[SR_ADMM] = 0; r[SR_TARGET] = 1; r[SR_USED] = 0; r[SR_CONV] = conv; r[SR_CAP] = 1 << 20; r[SR_SEQ] = rec ? -1 : 0;
   }
   scal[S_TOL_NOW] = -1.0;
 }
@@ -1644,7 +1646,7 @@ float time_kernel(Dev &d, int which, int reps) {
   if (which == 16) {
     dev_publish(d);
     if (reps > 400) reps = 400;                 // (k advances by two per repetition; the alpha / gamma history holds kMaxCg entries)
-    hipLaunchKernelGGL(k_slot_probe_f, dim3(1), dim3(1), 0, st(d), d.slot, d.scal, 2);
+    hipLaunchKernelGGL(k_slot_probe_f, dim3(1), dim3(1), 0, st(d), d.slot, d.scal, 2, d.kf.on ? 2 : 0);
   }
   if (which >= 10) HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, which == 13 ? 1 : 0, sizeof(int), st(d)));   // (byte pattern 1 -> nonzero flag)
   for (int w = 0; w < 5; w++) launch();

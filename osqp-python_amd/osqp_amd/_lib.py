@@ -123,6 +123,8 @@ PROTOTYPES = {
     'osqp_hip_get_policy': (C.c_int, [SolverP, C.POINTER(PolicyStruct)]),
     'osqp_hip_batch_solve': (C.c_int, [SolverP, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),
     'osqp_hip_batch_solve_device': (C.c_int, [SolverP, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'osqp_hip_batch_solve_mat': (C.c_int, [SolverP, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),
+    'osqp_hip_batch_solve_mat_device': (C.c_int, [SolverP, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'osqp_hip_update_data_vec_device': (C.c_int, [SolverP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'osqp_hip_warm_start_device': (C.c_int, [SolverP, C.c_void_p, C.c_void_p, C.c_void_p]),
     'osqp_hip_get_scaling': (C.c_int, [SolverP, c_double_p, c_double_p, c_double_p]),

@@ -279,10 +279,11 @@ class OSQPSolver:
     BATCH_FIELDS = ('status_val', 'iter', 'obj_val', 'prim_res', 'dual_res', 'rho', 'rho_updates', 'pcg_iters', 'status_polish', 'polish_time', 'rho_estimate', 'reserved')
     BATCH_REC = len(BATCH_FIELDS)        # OSQP_HIP_BATCH_REC
 
-    def hip_batch_solve(self, q=None, l=None, u=None, x0=None, y0=None, nbatch=None):
+    def hip_batch_solve(self, q=None, l=None, u=None, x0=None, y0=None, nbatch=None, Px=None, Ax=None):
         """Solve a batch of QPs sharing this solver's P, A and settings (osqp_hip_batch_solve).  q: (B, n), l/u: (B, m).
-        Returns x (B, n), y (B, m), rec (B, BATCH_REC) with columns BATCH_FIELDS."""
-        arrs = [a for a in (q, l, u, x0, y0) if a is not None]
+        Px (B, nnz(triu P)) / Ax (B, nnz(A)): per-problem matrix values in the CSC order given at setup (osqp_hip_batch_solve_mat: the reference's
+        per-element P_val / A_val, nn/torch.py:128-157) -- still one launch.  Returns x (B, n), y (B, m), rec (B, BATCH_REC) with columns BATCH_FIELDS."""
+        arrs = [a for a in (q, l, u, x0, y0, Px, Ax) if a is not None]
         B = int(nbatch) if nbatch is not None else int(np.asarray(arrs[0]).shape[0])
         q, l, u = (None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(B, -1) for a in (q, l, u))
         warm = x0 is not None or y0 is not None      # a missing one starts from zero, like warm_start(x=None) / (y=None) of a single solver
@@ -290,16 +291,27 @@ class OSQPSolver:
         x = np.zeros((B, self.n)) if x0 is None else np.ascontiguousarray(x0, dtype=np.float64).reshape(B, self.n).copy()
         y = np.zeros((B, self.m)) if y0 is None else np.ascontiguousarray(y0, dtype=np.float64).reshape(B, self.m).copy()
         rec = np.zeros((B, self.BATCH_REC))
+        if Px is not None or Ax is not None:
+            Px, Ax = (None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(B, -1) for a in (Px, Ax))
+            st = self._lib.osqp_hip_batch_solve_mat(self._p, B, _ptr(Px, _lib.c_double_p), _ptr(Ax, _lib.c_double_p), _ptr(q, _lib.c_double_p), _ptr(l, _lib.c_double_p),
+                                                    _ptr(u, _lib.c_double_p), _ptr(x, _lib.c_double_p), _ptr(y, _lib.c_double_p), _ptr(rec, _lib.c_double_p), int(warm))
+            if st:
+                raise self._batch_error(st)
+            return x, y, rec
         st = self._lib.osqp_hip_batch_solve(self._p, B, _ptr(q, _lib.c_double_p), _ptr(l, _lib.c_double_p), _ptr(u, _lib.c_double_p),
                                             _ptr(x, _lib.c_double_p), _ptr(y, _lib.c_double_p), _ptr(rec, _lib.c_double_p), int(warm))
         if st:
             raise self._batch_error(st)
         return x, y, rec
 
-    def hip_batch_solve_device(self, nbatch, q_ptr, l_ptr, u_ptr, x_ptr, y_ptr, rec_ptr, warm=False, stream=None):
+    def hip_batch_solve_device(self, nbatch, q_ptr, l_ptr, u_ptr, x_ptr, y_ptr, rec_ptr, warm=False, stream=None, Px_ptr=None, Ax_ptr=None):
         """osqp_hip_batch_solve_device: raw device addresses (int or None) of float64 arrays laid out as in hip_batch_solve;
-        rec: (B, BATCH_REC).  Enqueued on `stream` (hipStream_t handle as int; None: the solver's stream, synchronous)."""
-        st = self._lib.osqp_hip_batch_solve_device(self._p, int(nbatch), q_ptr, l_ptr, u_ptr, x_ptr, y_ptr, rec_ptr, int(bool(warm)), stream)
+        rec: (B, BATCH_REC).  Enqueued on `stream` (hipStream_t handle as int; None: the solver's stream, synchronous).
+        Px_ptr / Ax_ptr: per-problem matrix values on the device (osqp_hip_batch_solve_mat_device)."""
+        if Px_ptr is not None or Ax_ptr is not None:
+            st = self._lib.osqp_hip_batch_solve_mat_device(self._p, int(nbatch), Px_ptr, Ax_ptr, q_ptr, l_ptr, u_ptr, x_ptr, y_ptr, rec_ptr, int(bool(warm)), stream)
+        else:
+            st = self._lib.osqp_hip_batch_solve_device(self._p, int(nbatch), q_ptr, l_ptr, u_ptr, x_ptr, y_ptr, rec_ptr, int(bool(warm)), stream)
         if st:
             raise self._batch_error(st)
 

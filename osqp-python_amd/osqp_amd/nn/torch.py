@@ -11,7 +11,9 @@ threads.  Here one persistent engine handle plays that role:
     stream (``osqp_hip_batch_solve_device``) and the solution is produced on the device;
   * with ``torch.distributed`` initialised (world size > 1) the batch is block-partitioned over the ranks, every rank solves its
     share on its own GPU, and the rows are all-gathered (``osqp_amd.sharded``) -- the multi-GPU form of the reference's thread pool;
-  * per-element P_val / A_val (2-D tensors): one single-QP handle, re-used through update(Px, Ax, q, l, u) (:136-140).
+  * per-element P_val / A_val (2-D tensors, :128-157, 184-217): the SAME single launch -- every workgroup reads its own element's matrix values, assembled
+    and equilibrated per element by a launch in front of it (osqp_hip_batch_solve_mat); only a problem too large for one workgroup falls back to the
+    single-QP handle, one element after the other.
 
 Like the reference, a batch element that is not solved raises RuntimeError (:158-162).  Backward (adjoint derivatives,
 :233-290) is out of scope of this engine: the returned tensor carries no grad_fn.
@@ -109,7 +111,21 @@ class OSQP(Module):
                 x, rec = self._loop(Pn, qn, An, ln, un, nb, batched, dev_index)
         else:
             dev_index = (device.index or 0) if q_val.is_cuda else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
-            x, rec = self._loop(Pn, qn, An, ln, un, nb, batched, dev_index)
+            x = rec = None
+            if world == 1:                                                              # per-element matrices: one launch (osqp_hip_batch_solve_mat)
+                # (the handle's OWN matrices matter only for the side that is shared; a batched side keeps what the handle holds -- no re-assembly per forward)
+                have = self._solver is not None and self._device == dev_index
+                s = self._handle((self._Pv if have else Pn[0]) if batched[0] else Pn, (self._Av if have else An[0]) if batched[2] else An, qn[0], ln[0], un[0], device=dev_index)
+                try:
+                    x, y, rec = s._solver.hip_batch_solve(q=qn, l=ln, u=un, Px=(Pn[:, self._triu_pick] if batched[0] else None), Ax=(An if batched[2] else None), nbatch=nb)
+                    self.last_dual = y
+                    self.mat_batch_launches = getattr(self, 'mat_batch_launches', 0) + 1
+                except ValueError as e:
+                    if str(e) != str(int(osqp_amd.SolverError.OSQP_FUNC_NOT_IMPLEMENTED)):
+                        raise
+                    x = rec = None
+            if x is None:
+                x, rec = self._loop(Pn, qn, An, ln, un, nb, batched, dev_index)
         bad = np.nonzero(rec[:, 0] != int(osqp_amd.SolverStatus.OSQP_SOLVED))[0]
         if bad.size:
             raise RuntimeError('Unable to solve QP, status: %d (batch element %d)' % (int(rec[bad[0], 0]), int(bad[0])))

@@ -266,6 +266,7 @@ size_t batch_direct_lds_bytes(int, int, int, int) { return 0; }
 bool batch_direct_selected(const BatchParams &) { return false; }
 void batch_products(Dev &, int, const int *, const int *, double *) {}
 void batch_order(Dev &, int, const int *, int *, void *) {}
+int batch_prepare(Dev &, const BatchParams &, const double *, const double *, int, void *) { return OSQP_FUNC_NOT_IMPLEMENTED; }
 int batch_solve(Dev &, const BatchParams &, void *) { return OSQP_FUNC_NOT_IMPLEMENTED; }   // GPU-only feature
 
 bool pcg_fused(const Dev &) { return false; }
