@@ -329,11 +329,14 @@ def measure_roofline(s, stats, n, mm, args):
             dom, dom_kernel = name, 'k_wbx_x'
         else:
             nzL = nnzA                                                         # (the long rows carry nearly all of A in this form)
-            wb_bytes = 8 * nzL + 8 * r * r + 8 * nzL + 8 * (4 * n + 2 * r)     # A_L once (values only: consecutive columns), S^-1, A_L' once, the vectors
+            cd = int(stats.get('woodbury_dual_cols', 0))                       # column-space form: the dense system is cd x cd (OSQPHipPolicy::woodbury_dual)
+            order = cd or r
+            wb_bytes = 8 * nzL + 8 * order * order + 8 * nzL + 8 * (4 * n + 2 * r)     # A_L once (values only: consecutive columns), the inverse, A_L' once, the vectors
             ms_ch = s.hip_time_kernel(21, max(20, args.probe_reps // 4))
-            name = 'Woodbury direct mode, M^-1 = K^-1: k_wb_p1 + k_wb_gemv + k_wb_p3 (three launches per ADMM iteration)'
-            probes[name] = {'ms': ms_ch, 'ms_same_kernel_repeat': ms_ch, 'bytes': wb_bytes, 'GBps': wb_bytes / (ms_ch * 1e-3) / 1e9, 'launches': 3}
-            dom, dom_kernel = name, 'k_wb_gemv'
+            name = ('Woodbury direct mode in column space, M^-1 = K^-1: k_wbd_beta + k_wbd_g + k_wbd_gemv (T^-1, %d x %d) + k_wbd_t + k_wbd_fin (five launches per ADMM iteration)' % (cd, cd)) if cd else \
+                   'Woodbury direct mode, M^-1 = K^-1: k_wb_p1 + k_wb_gemv + k_wb_p3 (three launches per ADMM iteration)'
+            probes[name] = {'ms': ms_ch, 'ms_same_kernel_repeat': ms_ch, 'bytes': wb_bytes, 'GBps': wb_bytes / (ms_ch * 1e-3) / 1e9, 'launches': 5 if cd else 3}
+            dom, dom_kernel = name, ('k_wbd_gemv' if cd else 'k_wb_gemv')
         kb = {nm: probes[nm]['bytes'] for nm in probes}
         return probes, kb, kb[dom], probes[dom]['ms'], dom, dom_kernel, survey_pcg_bytes, None, False, fused, 0
     kb = {name: probes[name]['bytes'] for name in probes}

@@ -199,6 +199,7 @@ typedef struct {
   double woodbury_cache_hits; /* last solve: rho updates served by an inverse this handle had computed for the same rho_bar before (validated by the
                                  numerical probe against the current matrices) -- woodbury_factorisations counts the others; woodbury_factor_ms covers both */
   double f1_far_columns;      /* F1 form with per-block mixing: far columns (spill slots) over all row blocks of A (0: every block fits its window) */
+  double woodbury_dual_cols;  /* device-factorised Woodbury form in column space (OSQPHipPolicy::woodbury_dual): order of its dense system = dense columns (0: row space) */
   double kform_nnz;           /* K form: stored entries of the explicit reduced matrix K = P + sigma I + A' diag(rho) A (0: the form is not in use) */
 } OSQPHipStats;
 /* OSQPHipStats::preconditioner.  `cg_precond = OSQP_DIAGONAL_PRECONDITIONER` (bindings.cpp.in:426, the reference's only preconditioner) selects the
@@ -370,6 +371,13 @@ typedef struct {
                                  0 (default): the two-kernel form -- measured faster on MI355X: K needs nnz(K) random gathers per product (41 per row at
                                  configs[1] sizes with unstructured columns: 4.1 M against the 2.2 M of the A / B pair), and a random 8..32-byte gather costs a
                                  whole 128-byte line of L2 -> L1 traffic: 18-24 us per 4.2 M gathers alone (profiles/r06a_kform_gather_bench.txt)        [setup] */
+  OSQPInt woodbury_dual;      /* 1 (default): the device-factorised Woodbury form works in COLUMN space where that is the smaller system -- the columns the dense rows touch
+                                 split into dense columns (two or more entries) and singletons (one: the lasso's -y_i); with fewer dense columns than 3/4 of the dense
+                                 rows, the cd x cd system  T = D0_C + A_d' diag(w) A_d  on the dense columns replaces the r x r system S (lasso 5k x 10k: 5 000 against
+                                 10 000: an eighth of the factorisation, a quarter of the inverse); 0: always the row-space form                                [setup] */
+  OSQPInt woodbury_vendor;    /* 0 (default): the dense system of the device-factorised Woodbury form is formed and inverted by this engine's own kernels on the fp64 matrix
+                                 cores (dense_hip.hip: a strided MFMA GEMM + block Gauss-Jordan inversion); 1: rocBLAS dgemm + rocSOLVER dpotrf / dpotri, loaded on
+                                 demand (the route of rounds 3-5, kept for A/B runs; without the libraries osqp_setup falls back to plain Jacobi)            [setup] */
 } OSQPHipPolicy;
 void    osqp_hip_default_policy(OSQPHipPolicy *policy);
 OSQPInt osqp_hip_set_policy(OSQPSolver *solver, const OSQPHipPolicy *policy);

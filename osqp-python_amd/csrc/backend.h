@@ -154,6 +154,7 @@ constexpr int kWbMaxRows = 128;
 // mode is simply off), h = S^-1 g by a dense matrix-vector kernel (r^2 x 8 bytes per application).  Whether M = K (the direct mode) is
 // decided NUMERICALLY after every factorisation: M^-1 (K v) must reproduce a probe vector v to 1e-9.
 constexpr int kWbLargeMax = 16384;
+inline size_t wb_inverse_work(int n) { return (size_t)n * 64 * 2 + 64 * 64 + 8; }      // dense_hip.hip dense_spd_inverse: column panel, row panel, pivot block
 // The direct mode in TWO launches per ADMM iteration (wbdirect_hip.hip): P diagonal, every short row of A has exactly one entry, n <= kWbxMaxN.
 // A workgroup owns kWbxCols consecutive columns and keeps its dense r x kWbxCols tile of A_L in LDS; the two global reductions of the
 // iteration (g = A_L D0^-1 r_0, z~_L = A_L x~) travel as per-workgroup partials, summed in index order by every consumer.
@@ -199,8 +200,27 @@ struct DevWb {
   double rho_key = 0.0;          // rho_bar of the last be::set_rho
   double *cache_buf[kCache] = {nullptr, nullptr, nullptr, nullptr}; double cache_rho[kCache] = {0, 0, 0, 0}; int cache_used = 0, cache_next = 0;
   int cache_hits = 0, cache_on = 1;
-  double *g = nullptr, *h = nullptr;      // [r]
+  double *g = nullptr, *h = nullptr;      // [r]  (dual form: [max(r, cd)])
   double *Dinv0 = nullptr;       // [n]  1 / D0
+  // COLUMN-SPACE ("dual") form of the device-factorised correction (large only; Engine::prepare_wb takes it when it is the smaller system).  The columns
+  // the long rows touch split into DENSE columns (two or more long-row entries: cd of them) and SINGLETON columns (exactly one: the lasso's -y_i of
+  // the rows  y = A_d x - b).  Eliminating the singletons of every row a (Sherman-Morrison on its block  diag(D0_j) + rho_a s_a s_a') leaves, on the
+  // dense columns C,
+  //     T = D0_C + A_d' diag(w) A_d ,   w_a = rho_a / (1 + rho_a sigma_a) ,   sigma_a = sum_{j singleton of a} A_aj^2 / D0_j        (cd x cd, SPD)
+  // and  M^-1 r  is:  beta_a = sum_{j singleton of a} A_aj r_j / D0_j ;  x_C = T^-1 (r_C - A_d' (w .* beta)) ;  t_a = (beta_a + A_d[a] x_C) / (1 + rho_a sigma_a) ;
+  // x_j = (r_j - rho_a A_aj t_a) / D0_j on a singleton column of row a,  x_j = r_j / D0_j on the columns no long row touches.  Exactly the same M as the
+  // row-space form (S = 1 / rho_L + A_L D0^-1 A_L', r x r) -- with cd x cd instead of r x r to form, factorise, invert and stream per application:
+  // lasso 5k x 10k: cd = 5 000 against r = 10 000 -- an eighth of the factorisation's flops, a quarter of the inverse's bytes.
+  // In this form: ct = cd, colmap = index among the dense columns, W [r][cd] = sqrt(w_a) A_d, S = T, Sinv = T^-1 (cd x cd).
+  int vendor = 0;                // 1: form / factorise / invert the dense system with rocBLAS + rocSOLVER (A/B switch, OSQPHipPolicy::woodbury_vendor); 0: dense_hip.hip
+  double *gjwork = nullptr;      // [wb_inverse_work(order) + 1] panels of the block Gauss-Jordan inverse, the smallest pivot behind them
+  int dual = 0, cd = 0;
+  int *kind = nullptr;           // [n] 0: no long row touches the column, 1: dense, 2: singleton
+  int *dcol = nullptr;           // [cd] the dense columns, ascending
+  int *srow = nullptr, *ssrc = nullptr; double *sval = nullptr;      // [n] singleton column -> index a of its long row, position of its entry in A.val, the entry (wb_refresh)
+  int *sg_ptr = nullptr, *sg_col = nullptr;                          // per long row: its singleton columns (CSR over the r rows; sums run in list order)
+  double *wv = nullptr, *den = nullptr, *beta = nullptr, *wbeta = nullptr, *rt = nullptr;      // [r] w_a, 1 + rho_a sigma_a, beta_a, w_a beta_a, rho_a t_a
+  double *uz = nullptr;          // [n] x_C scattered to its columns, ZERO everywhere else (only dense positions are ever written): the vector the row pass gathers
 };
 
 // indices into Dev::res (results of the residual kernels, reduced on the device)

@@ -1,0 +1,174 @@
+// dense_hip.hip -- the dense fp64 work of the device-factorised Woodbury correction (backend.h DevWb::large), hand-written for gfx950's matrix cores:
+// forming the system (S = W W' / T = W' W: one GEMM) and inverting it (SPD, order up to kWbLargeMax).  Until round 5 this was rocBLAS dgemm +
+// rocSOLVER dpotrf / dpotri, loaded on demand (woodbury_hip.hip keeps that route as an A/B switch, OSQPHipPolicy::woodbury_vendor).
+//
+//   dense_gemm      C = beta C + alpha A B  on v_mfma_f64_16x16x4 (operand layout: tools/mfma_f64_layout.hip -- A: lane l holds A(l % 16, l / 16),
+//                   B: B(l / 16, l % 16), result register r of lane l = C(l / 16 + 4 r, l % 16)).  A workgroup of four waves owns a 64 x 64 tile of C
+//                   (a wave: 32 x 32 = 2 x 2 instruction tiles); K advances in chunks of 16 through two LDS buffers (the next chunk is fetched into
+//                   registers while the current one feeds the matrix cores).  Operands are addressed by strides: each of A, B may be contiguous along
+//                   K or along its free index; the LDS image of an operand is laid out so that both its coalesced fill and the instruction's operand
+//                   reads are bank-conflict free (free-index-major rows of 80 doubles when the free index is contiguous in memory, K-major rows of 17
+//                   doubles when K is).  fp64 MFMA issues one 16x16x4 per 64 cycles and SIMD: the loop is bound by the matrix cores, not by LDS or L2.
+//   dense_spd_inverse   in-place inverse of an SPD matrix by BLOCK Gauss-Jordan elimination without pivoting (the pivots of an SPD matrix are positive):
+//                   per block step k (64 columns):  P = A_kk^-1 (one workgroup, Gauss-Jordan in LDS);  R = P A_k: ;  A_ij -= A_ik R_j  (i, j outside
+//                   block k: ONE rank-64 GEMM over the whole matrix -- the panels' block-k parts are zeroed in their copies);  A_ik = -A_ik P;
+//                   A_k: = R, A_kk = P.  All of the n^3 work is dense_gemm; 2 n^3 flops (no use of symmetry), ~6 launches per block step.
+#include "hip_common.h"
+
+namespace osqp_hip {
+namespace be {
+
+namespace {
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int kGT = 64, kGK = 16;
+constexpr int kLdI = kGT + 16;      // free-index-contiguous operand: LDS image [k][i], 80 doubles per k (rows k and k + 1 fall on the two bank halves)
+constexpr int kLdK = kGK + 1;       // K-contiguous operand: LDS image [i][k], 17 doubles per i
+constexpr int kOpDoubles = (kGK * kLdI > kGT * kLdK) ? kGK * kLdI : kGT * kLdK;
+struct GemmArgs { int M, N, K; double alpha, beta; const double *A; long as_i, as_k; const double *B; long bs_k, bs_j; double *C; long cs_i, cs_j; };
+
+// AK / BK: the operand is contiguous along K in memory (else along its free index)
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256) void k_dgemm(GemmArgs g) {
+  __shared__ double As[2][kOpDoubles], Bs[2][kOpDoubles];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int i0 = blockIdx.y * kGT, j0 = blockIdx.x * kGT;
+  const int rb = 32 * (w >> 1), cb = 32 * (w & 1), lj = l & 15, lk = l >> 4;
+  v4d acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+  double ra[4], rbv[4];
+  // element (f, k) of a 64 x 16 operand chunk this thread moves in round q: coalesced along the operand's contiguous direction
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      { const int f = AK ? (tid >> 4) + 16 * q : (tid & 63), k = AK ? (tid & 15) : (tid >> 6) + 4 * q;
+        const int gi = i0 + f, gk = k0 + k;
+        ra[q] = (gi < g.M && gk < g.K) ? g.A[(long)gi * g.as_i + (long)gk * g.as_k] : 0.0; }
+      { const int f = BK ? (tid >> 4) + 16 * q : (tid & 63), k = BK ? (tid & 15) : (tid >> 6) + 4 * q;
+        const int gj = j0 + f, gk = k0 + k;
+        rbv[q] = (gj < g.N && gk < g.K) ? g.B[(long)gk * g.bs_k + (long)gj * g.bs_j] : 0.0; }
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      { const int f = AK ? (tid >> 4) + 16 * q : (tid & 63), k = AK ? (tid & 15) : (tid >> 6) + 4 * q; As[buf][AK ? f * kLdK + k : k * kLdI + f] = ra[q]; }
+      { const int f = BK ? (tid >> 4) + 16 * q : (tid & 63), k = BK ? (tid & 15) : (tid >> 6) + 4 * q; Bs[buf][BK ? f * kLdK + k : k * kLdI + f] = rbv[q]; }
+    }
+  };
+  fetch(0);
+  stage(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < g.K; k0 += kGK) {
+    const bool more = k0 + kGK < g.K;
+    if (more) fetch(k0 + kGK);                              // (in flight while this chunk feeds the matrix cores)
+    const double *as = As[buf], *bs = Bs[buf];
+#pragma unroll
+    for (int ks = 0; ks < kGK; ks += 4) {
+      const int kk = ks + lk;
+      const double a0 = AK ? as[(rb + lj) * kLdK + kk] : as[kk * kLdI + rb + lj], a1 = AK ? as[(rb + 16 + lj) * kLdK + kk] : as[kk * kLdI + rb + 16 + lj];
+      const double b0 = BK ? bs[(cb + lj) * kLdK + kk] : bs[kk * kLdI + cb + lj], b1 = BK ? bs[(cb + 16 + lj) * kLdK + kk] : bs[kk * kLdI + cb + 16 + lj];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) { stage(buf ^ 1); __syncthreads(); buf ^= 1; }      // (the other buffer: nobody reads it in this iteration; one barrier per chunk)
+  }
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int gi = i0 + rb + 16 * a + lk + 4 * r, gj = j0 + cb + 16 * b + lj;
+        if (gi < g.M && gj < g.N) {
+          double *c = g.C + (long)gi * g.cs_i + (long)gj * g.cs_j;
+          *c = g.beta == 0.0 ? g.alpha * acc[a][b][r] : g.beta * *c + g.alpha * acc[a][b][r];
+        }
+      }
+}
+
+constexpr int kGjNb = 64;
+// P = (A_kk)^-1 by Gauss-Jordan elimination in LDS, no pivoting; the smallest pivot seen goes to info (<= 0 or NaN: not positive definite)
+__global__ __launch_bounds__(256) void k_gj_pivot(const double *A, long ld, int k0, int nb, double *P, double *minpiv) {
+  __shared__ double M[kGjNb * (kGjNb + 1)], rowk[kGjNb], colk[kGjNb];
+  __shared__ double pmin;
+  const int tid = threadIdx.x, S = kGjNb + 1;
+  for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e - i * nb; M[i * S + j] = A[(long)(k0 + i) * ld + k0 + j]; }
+  if (tid == 0) pmin = 1e300;
+  __syncthreads();
+  for (int k = 0; k < nb; k++) {
+    const double p = M[k * S + k], pi = 1.0 / p;
+    if (tid < nb) { rowk[tid] = tid == k ? pi : M[k * S + tid] * pi; colk[tid] = M[tid * S + k]; }
+    if (tid == 0 && !(p >= pmin)) pmin = p;
+    __syncthreads();
+    for (int e = tid; e < nb * nb; e += 256) {
+      const int i = e / nb, j = e - i * nb;
+      M[i * S + j] = i == k ? rowk[j] : (j == k ? -colk[i] * pi : M[i * S + j] - colk[i] * rowk[j]);
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e - i * nb; P[i * kGjNb + j] = M[i * S + j]; }
+  if (tid == 0 && !(pmin >= *minpiv)) *minpiv = pmin;
+}
+// Ck (n x 64, row-major) <- the column panel A[:, k0 .. k0 + nb) with the rows of block k zeroed
+__global__ __launch_bounds__(256) void k_gj_colpanel(const double *A, long ld, int n, int k0, int nb, double *Ck) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)n * kGjNb; e += (long)gridDim.x * 256) {
+    const int i = (int)(e / kGjNb), j = (int)(e - (long)i * kGjNb);
+    Ck[e] = (j < nb && (i < k0 || i >= k0 + nb)) ? A[(long)i * ld + k0 + j] : 0.0;
+  }
+}
+// R's columns of block k <- 0 (the rank-nb update must leave block column k alone), after a copy of nothing: R holds P A_k: already
+__global__ __launch_bounds__(256) void k_gj_zero_cols(double *R, long ldr, int k0, int nb) {
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < nb * nb; e += gridDim.x * 256) { const int i = e / nb, j = e - i * nb; R[(long)i * ldr + k0 + j] = 0.0; }
+}
+// row panel: A[k0 + i][j] = R[i][j] outside block k, = P[i][j - k0] inside
+__global__ __launch_bounds__(256) void k_gj_rowpanel(double *A, long ld, int n, int k0, int nb, const double *R, long ldr, const double *P) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)nb * n; e += (long)gridDim.x * 256) {
+    const int i = (int)(e / n), j = (int)(e - (long)i * n);
+    A[(long)(k0 + i) * ld + j] = (j >= k0 && j < k0 + nb) ? P[i * kGjNb + (j - k0)] : R[(long)i * ldr + j];
+  }
+}
+__global__ void k_set1(double *p, double v) { *p = v; }
+
+template <bool AK, bool BK>
+void launch_gemm(hipStream_t s, const GemmArgs &g) {
+  hipLaunchKernelGGL((k_dgemm<AK, BK>), dim3((g.N + kGT - 1) / kGT, (g.M + kGT - 1) / kGT), dim3(256), 0, s, g);
+}
+}  // namespace
+
+// C (M x N) = beta C + alpha A B with A(i, k) = A[i as_i + k as_k], B(k, j) = B[k bs_k + j bs_j], C(i, j) = C[i cs_i + j cs_j]; each of A, B must have one unit stride
+void dense_gemm(void *stream, int M, int N, int K, double alpha, const double *A, long as_i, long as_k, const double *B, long bs_k, long bs_j, double beta, double *C, long cs_i, long cs_j) {
+  if (M <= 0 || N <= 0) return;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const GemmArgs g{M, N, K, alpha, beta, A, as_i, as_k, B, bs_k, bs_j, C, cs_i, cs_j};
+  const bool ak = as_k == 1, bk = bs_k == 1;
+  if (!(ak || as_i == 1) || !(bk || bs_j == 1)) throw DeviceError("osqp_hip: dense_gemm needs a unit stride in every operand");
+  if (ak && bk) launch_gemm<true, true>(s, g); else if (ak) launch_gemm<true, false>(s, g); else if (bk) launch_gemm<false, true>(s, g); else launch_gemm<false, false>(s, g);
+}
+// A (n x n, row-major, leading dimension ld, SPD) <- A^-1 in place; work: n x 64 + 64 x n + 64 x 64 + 1 doubles (device); *(work + that) ... see the
+// header of this file.  The smallest pivot any block saw is left in minpiv[0] (device): <= 0 (or NaN) means the matrix was not positive definite.
+size_t dense_spd_inverse_work(int n) { return (size_t)n * kGjNb * 2 + (size_t)kGjNb * kGjNb + 8; }
+void dense_spd_inverse(void *stream, double *A, long ld, int n, double *work, double *minpiv) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double *Ck = work, *R = Ck + (size_t)n * kGjNb, *P = R + (size_t)n * kGjNb;
+  hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, s, minpiv, 1e300);
+  const int gridp = std::min(4 * kGrid, (int)(((long)n * kGjNb + 255) / 256));
+  for (int k0 = 0; k0 < n; k0 += kGjNb) {
+    const int nb = std::min(kGjNb, n - k0);
+    hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(256), 0, s, A, ld, k0, nb, P, minpiv);
+    hipLaunchKernelGGL(k_gj_colpanel, dim3(gridp), dim3(256), 0, s, A, ld, n, k0, nb, Ck);
+    dense_gemm(s, nb, n, nb, 1.0, P, kGjNb, 1, A + (long)k0 * ld, ld, 1, 0.0, R, n, 1);                  // R = P A_k:
+    hipLaunchKernelGGL(k_gj_zero_cols, dim3(16), dim3(256), 0, s, R, (long)n, k0, nb);
+    dense_gemm(s, n, n, nb, -1.0, Ck, kGjNb, 1, R, n, 1, 1.0, A, ld, 1);                                  // A_ij -= A_ik R_j outside block row / column k
+    dense_gemm(s, n, nb, nb, -1.0, Ck, kGjNb, 1, P, kGjNb, 1, 0.0, A + k0, ld, 1);                        // A_ik = -A_ik P  (block k's own rows: zero, rewritten below)
+    hipLaunchKernelGGL(k_gj_rowpanel, dim3(gridp), dim3(256), 0, s, A, ld, n, k0, nb, R, (long)n, P);
+  }
+}
+
+}  // namespace be
+}  // namespace osqp_hip

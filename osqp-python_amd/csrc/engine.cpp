@@ -42,7 +42,7 @@ void policy_from_env(OSQPHipPolicy &p, bool runtime_only) {
   if (runtime_only) return;
   on("OSQP_HIP_WOODBURY_FUSED", p.woodbury_fused); real("OSQP_HIP_WOODBURY_DIRECT_TOL", p.woodbury_direct_tol);
   on("OSQP_HIP_WOODBURY", p.woodbury); on("OSQP_HIP_WOODBURY_DIRECT", p.woodbury_direct); on("OSQP_HIP_WOODBURY_LARGE", p.woodbury_large);
-  num("OSQP_HIP_REORDER", p.reorder); on("OSQP_HIP_WOODBURY_CACHE", p.woodbury_cache); on("OSQP_HIP_KFORM", p.kform);
+  num("OSQP_HIP_REORDER", p.reorder); on("OSQP_HIP_WOODBURY_CACHE", p.woodbury_cache); on("OSQP_HIP_KFORM", p.kform); on("OSQP_HIP_WOODBURY_DUAL", p.woodbury_dual); on("OSQP_HIP_WOODBURY_VENDOR", p.woodbury_vendor);
   on("OSQP_HIP_GRAPH", p.graph); on("OSQP_HIP_SLOTS", p.slots); on("OSQP_HIP_PCG_FUSED", p.pcg_fused); num("OSQP_HIP_F1", p.f1); on("OSQP_HIP_WINDOW", p.window);
   real("OSQP_HIP_EXTRAP", p.extrap);
   if (const char *e = std::getenv("OSQP_HIP_RHO_EQ_FACTOR")) { const double v = std::atof(e); if (v >= 1.0) p.rho_eq_factor = v; }
@@ -60,7 +60,7 @@ void Engine::default_policy(OSQPHipPolicy *p) {
   p->polish_delta_floor = 1e-3; p->polish_pcg_tol = 1e-15; p->woodbury = 1; p->woodbury_direct = 1; p->woodbury_large = 1; p->woodbury_cache = 1;
   p->slot_poll = 1; p->poll_low = 6; p->poll_first = 0.8; p->poll_frac = 0.75; p->poll_wait = 0.7;
   p->finish_pairs = 12; p->poll_sleep_us = 30;
-  p->reorder = 1; p->kform = 0; p->woodbury_fused = 1; p->woodbury_direct_tol = 1e-6; p->debug_fail_refactor = 0;
+  p->reorder = 1; p->kform = 0; p->woodbury_dual = 1; p->woodbury_vendor = 0; p->woodbury_fused = 1; p->woodbury_direct_tol = 1e-6; p->debug_fail_refactor = 0;
 }
 void Engine::set_default_policy(const OSQPHipPolicy *p) {
   g_default_policy_set = p != nullptr;
@@ -76,7 +76,7 @@ int Engine::set_policy(const OSQPHipPolicy *p) {
   const OSQPHipPolicy old = pol_;
   pol_ = *p; pol_explicit_ = true;
   // [setup] fields keep the value the handle was built with
-  pol_.slots = old.slots; pol_.pcg_fused = old.pcg_fused; pol_.f1 = old.f1; pol_.window = old.window; pol_.woodbury = old.woodbury; pol_.woodbury_direct = old.woodbury_direct; pol_.woodbury_large = old.woodbury_large; pol_.reorder = old.reorder; pol_.woodbury_cache = old.woodbury_cache; pol_.woodbury_fused = old.woodbury_fused; pol_.woodbury_direct_tol = old.woodbury_direct_tol; pol_.kform = old.kform;
+  pol_.slots = old.slots; pol_.pcg_fused = old.pcg_fused; pol_.f1 = old.f1; pol_.window = old.window; pol_.woodbury = old.woodbury; pol_.woodbury_direct = old.woodbury_direct; pol_.woodbury_large = old.woodbury_large; pol_.reorder = old.reorder; pol_.woodbury_cache = old.woodbury_cache; pol_.woodbury_fused = old.woodbury_fused; pol_.woodbury_direct_tol = old.woodbury_direct_tol; pol_.kform = old.kform; pol_.woodbury_dual = old.woodbury_dual; pol_.woodbury_vendor = old.woodbury_vendor;
   if (pol_.graph != old.graph) { use_graph_ = pol_.graph != 0; if (dev_ready_) { be::activate(d_); be::sync(d_); drop_graphs(); } }
   if (dev_ready_) d_.theta = pol_.extrap;
   if (dev_ready_ && d_.wb.dbg && pol_.debug_fail_refactor != old.debug_fail_refactor) { be::activate(d_); const int v = pol_.debug_fail_refactor; be::h2d(d_, d_.wb.dbg, &v, sizeof(int)); }
@@ -159,6 +159,7 @@ void Engine::free_all() {
                   d_.wb.AL.rowptr, d_.wb.AL.col, d_.wb.AL.blkdesc, d_.wb.AL.runinfo, d_.wb.AL.val, d_.wb.ALT.rowptr, d_.wb.ALT.col, d_.wb.ALT.blkdesc, d_.wb.ALT.runinfo, d_.wb.ALT.val,
                   d_.wb.al_src, d_.wb.alt_src, d_.wb.islong, d_.wb.rows, d_.wb.WT, d_.wb.S, d_.wb.Sinv, d_.wb.g, d_.wb.h, d_.wb.Dinv0, d_.wb.colmap, d_.wb.W, d_.wb.pv, d_.wb.info, d_.wb.dbg, d_.wb.x.tile, d_.wb.x.tile2, d_.wb.x.partG, d_.wb.x.partZ, d_.wb.x.ls0, d_.wb.x.ls1, d_.wb.x.sc_ptr, d_.wb.x.sc_row, d_.wb.x.sc_src, d_.wb.x.sc_val, d_.wb.x.bjj,
                   d_.ctl, d_.f1.blk, d_.f1.stream, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.va, d_.f1.fcol, d_.f1.fq, d_.f1.sp_ptr, d_.f1.spk, d_.f1.spill, d_pc_, d_pr_,
+                  d_.wb.gjwork, d_.wb.kind, d_.wb.dcol, d_.wb.srow, d_.wb.ssrc, d_.wb.sval, d_.wb.sg_ptr, d_.wb.sg_col, d_.wb.wv, d_.wb.den, d_.wb.beta, d_.wb.wbeta, d_.wb.rt, d_.wb.uz,
                   d_.kf.K.rowptr, d_.kf.K.col, d_.kf.K.blkdesc, d_.kf.K.runinfo, d_.kf.K.val, d_.kf.tptr, d_.kf.trow, d_.kf.ta, d_.kf.tb, d_.kf.rec};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   be::destroy(d_);

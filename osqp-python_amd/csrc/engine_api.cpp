@@ -803,6 +803,7 @@ int Engine::get_stats(OSQPHipStats *out) {
   *out = stats_; out->pcg_fused = (d_.f1.on && use_slots_) ? 2.0 : ((d_.kf.on && use_slots_) ? 3.0 : (be::pcg_fused(d_) ? 1.0 : 0.0)); out->batch_direct_bw = bd_.bw_symbolic;
   out->f1_replicas = d_.f1.on ? d_.f1.D : 0;
   out->kform_nnz = d_.kf.on ? (double)d_.kf.K.nnz : 0.0;
+  out->woodbury_dual_cols = (d_.wb.on && d_.wb.dual) ? (double)d_.wb.cd : 0.0;
   out->woodbury_rows = d_.wb.on ? d_.wb.r : 0; out->woodbury_direct = (d_.wb.on && d_.wb.exact) ? ((d_.wb.x.on) ? 2 : 1) : 0;
   out->windowed_blocks = d_.A.nwin + d_.B.nwin; out->row_blocks = d_.A.nblk + d_.B.nblk;
   out->reordered = reordered_ ? 1.0 : 0.0; out->reorder_ms = reorder_ms_;

@@ -415,9 +415,9 @@ void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj
   if (r < 1) return;
   // many long rows: dense S on the device (backend.h kWbLargeMax) -- when the libraries load, the dense blocks fit comfortably (W, S, S^-1:
   // 8 (r ct + 2 r^2) bytes against a budget of 24 GiB of the 288) and the long rows carry most of A (else Jacobi is not the problem)
-  bool large = false;
-  std::vector<int> colmap;
-  int ct = 0;
+  bool large = false, dual = false;
+  std::vector<int> colmap, cntL;
+  int ct = 0, cd = 0;
   if (r > kWbMaxRows) {
     if (r > kWbLargeMax || !pol_.woodbury_large || !be::wb_large_supported()) return;
     size_t nz_long = 0;
@@ -426,7 +426,14 @@ void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj
     colmap.assign(n, -1);
     for (int i : rows) for (int k = Arp[i]; k < Arp[i + 1]; k++) colmap[Arj[k]] = 0;
     for (int j = 0; j < n; j++) if (colmap[j] == 0) colmap[j] = ct++;
-    if (8.0 * ((double)r * ct + 2.0 * (double)r * r) > 24.0 * 1024 * 1024 * 1024) return;
+    // column-space ("dual") form (backend.h DevWb::dual): the touched columns split into dense ones (two or more long-row entries) and singletons (one);
+    // when the dense columns are fewer than the long rows the cd x cd system on them is the smaller one to form, factorise, invert and stream
+    cntL.assign(n, 0);
+    for (int i : rows) for (int k = Arp[i]; k < Arp[i + 1]; k++) cntL[Arj[k]]++;
+    for (int j = 0; j < n; j++) cd += cntL[j] >= 2;
+    dual = pol_.woodbury_dual != 0 && cd >= 1 && 4 * (long)cd <= 3 * (long)r;
+    const double order = dual ? cd : r, width = dual ? cd : ct;
+    if (8.0 * ((double)r * width + 2.0 * order * order) > 24.0 * 1024 * 1024 * 1024) return;
     large = true;
   }
   std::vector<unsigned char> islong(m, 0);
@@ -456,14 +463,30 @@ void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj
   up_csr(w.AL, r, n, lrp, lcol); up_csr(w.ALT, n, r, trp, tcol);
   w.al_src = up_i(lsrc); w.alt_src = up_i(tsrc); w.rows = up_i(rows);
   w.islong = dev_vec<unsigned char>(d_, m); be::h2d(d_, w.islong, islong.data(), m);
-  w.S = dev_vec<double>(d_, (size_t)r * r); w.Sinv = dev_vec<double>(d_, (size_t)r * r);
+  const size_t ord = dual ? (size_t)cd : (size_t)r;           // order of the dense system (backend.h DevWb: S / T)
+  w.S = dev_vec<double>(d_, ord * ord); w.Sinv = dev_vec<double>(d_, ord * ord);
   w.g = dev_vec<double>(d_, r); w.h = dev_vec<double>(d_, r); w.Dinv0 = dev_vec<double>(d_, n);
-  if (large) {
+  if (large && dual) {
+    // dense columns get the positions 0 .. cd - 1 of W / T; every singleton column knows its long row and where its entry sits in A.val
+    std::vector<int> kind(n, 0), dcol, srow(n, 0), ssrc(n, 0), sg_ptr(r + 1, 0), sg_col;
+    for (int j = 0; j < n; j++) { colmap[j] = -1; if (cntL[j] >= 2) { kind[j] = 1; colmap[j] = (int)dcol.size(); dcol.push_back(j); } else if (cntL[j] == 1) kind[j] = 2; }
+    for (int a = 0; a < r; a++) {
+      for (int k = lrp[a]; k < lrp[a + 1]; k++) if (kind[lcol[k]] == 2) { srow[lcol[k]] = a; ssrc[lcol[k]] = lsrc[k]; sg_col.push_back(lcol[k]); }
+      sg_ptr[a + 1] = (int)sg_col.size();
+    }
+    w.large = 1; w.dual = 1; w.cd = cd; w.ct = cd; w.colmap = up_i(colmap);
+    w.kind = up_i(kind); w.dcol = up_i(dcol); w.srow = up_i(srow); w.ssrc = up_i(ssrc); w.sg_ptr = up_i(sg_ptr); w.sg_col = up_i(sg_col);
+    w.sval = dev_vec<double>(d_, n); w.uz = dev_vec<double>(d_, n);
+    w.wv = dev_vec<double>(d_, r); w.den = dev_vec<double>(d_, r); w.beta = dev_vec<double>(d_, r); w.wbeta = dev_vec<double>(d_, r); w.rt = dev_vec<double>(d_, r);
+    w.W = dev_vec<double>(d_, (size_t)r * cd);                  // (zero-filled by the allocator: only the pattern's positions are ever written)
+    w.pv = dev_vec<double>(d_, (size_t)n + m + n + 4 + r);
+  } else if (large) {
     w.large = 1; w.ct = ct; w.colmap = up_i(colmap);
     w.W = dev_vec<double>(d_, (size_t)r * ct);                  // (zero-filled by the allocator: only the pattern's positions are ever written)
     w.pv = dev_vec<double>(d_, (size_t)n + m + n + 4 + r);
   } else w.WT = dev_vec<double>(d_, (size_t)n * r);
   w.info = dev_vec<int>(d_, 2); w.dbg = dev_vec<int>(d_, 1);
+  if (large) { w.vendor = pol_.woodbury_vendor != 0; w.gjwork = dev_vec<double>(d_, wb_inverse_work((int)ord) + 1); }
   if (pol_.debug_fail_refactor > 0) { const int v = pol_.debug_fail_refactor; be::h2d(d_, w.dbg, &v, sizeof(int)); }
   w.on = 1;
   // K0 diagonal <=> P has diagonal entries only and every short row of A has exactly one entry: then M = K (backend.h DevWb::exact)

@@ -564,6 +564,9 @@ void wb_factor(Dev &d);                    // woodbury_hip.hip: D0, S, S^-1 for 
 void wb_factor_device(Dev &d, int cond);   // woodbury_hip.hip: the small form's re-factorisation as launches only (cond: inside a boundary group)
 void dev_publish(Dev &d);                  // pcg_hip.hip: bring the device copy of Dev the F1 slot kernel reads up to date (never inside a stream capture)
 void dev_release(Dev &d);                  // pcg_hip.hip: free it (called by destroy)
+// dense_hip.hip: the dense fp64 building blocks of the device-factorised Woodbury correction on the matrix cores (strided operands; SPD inverse in place)
+void dense_gemm(void *stream, int M, int N, int K, double alpha, const double *A, long as_i, long as_k, const double *B, long bs_k, long bs_j, double beta, double *C, long cs_i, long cs_j);
+void dense_spd_inverse(void *stream, double *A, long ld, int n, double *work, double *minpiv);
 void wb_release_blas(void *handle);        // woodbury_hip.hip: destroy the rocBLAS handle a Dev's Impl holds (called by destroy)
 
 }  // namespace be

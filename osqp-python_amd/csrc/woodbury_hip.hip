@@ -228,6 +228,101 @@ __global__ __launch_bounds__(kBlock) void k_wb_maxdiff(const double *a, const do
   block_max2(e, s, red);
   if (threadIdx.x == 0) { out[0] = e; out[1] = s; }
 }
+// ---- column-space ("dual") form (backend.h DevWb::dual)
+__global__ __launch_bounds__(kBlock) void k_wbd_gather(Dev d) {            // the singleton entries' values <- A.val
+  const DevWb &w = d.wb;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += gridDim.x * kBlock) if (w.kind[j] == 2) w.sval[j] = d.A.val[w.ssrc[j]];
+}
+__global__ __launch_bounds__(kBlock) void k_wbd_weights(Dev d) {           // sigma_a, 1 + rho_a sigma_a, w_a  (one thread per long row; its singletons in list order)
+  const DevWb &w = d.wb;
+  for (int a = blockIdx.x * kBlock + threadIdx.x; a < w.r; a += gridDim.x * kBlock) {
+    double sg = 0.0;
+    for (int k = w.sg_ptr[a]; k < w.sg_ptr[a + 1]; k++) { const int j = w.sg_col[k]; const double v = w.sval[j]; sg += v * v * w.Dinv0[j]; }
+    const double rho = d.rho[w.rows[a]], dn = 1.0 + rho * sg;
+    w.den[a] = dn; w.wv[a] = rho / dn;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_wbd_fillW(Dev d) {             // W[a][colmap[j]] = sqrt(w_a) A_L[a, j] on the dense columns
+  const DevWb &w = d.wb;
+  for (int a = blockIdx.x; a < w.r; a += gridDim.x) {
+    const double sw = sqrt(w.wv[a]);
+    for (int k = w.AL.rowptr[a] + threadIdx.x; k < w.AL.rowptr[a + 1]; k += kBlock) {
+      const int c = w.colmap[w.AL.col[k]];
+      if (c >= 0) w.W[(size_t)a * w.cd + c] = w.AL.val[k] * sw;
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_wbd_adddiag(Dev d) {           // T_kk += D0 of the k-th dense column
+  const DevWb &w = d.wb;
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < w.cd; k += gridDim.x * kBlock) w.S[(size_t)k * w.cd + k] += 1.0 / w.Dinv0[w.dcol[k]];
+}
+__global__ __launch_bounds__(kBlock) void k_wbd_beta(Dev d) {              // beta_a, w_a beta_a
+  const DevWb &w = d.wb;
+  if (d.flags[F_DONE]) return;
+  for (int a = blockIdx.x * kBlock + threadIdx.x; a < w.r; a += gridDim.x * kBlock) {
+    double b = 0.0;
+    for (int k = w.sg_ptr[a]; k < w.sg_ptr[a + 1]; k++) { const int j = w.sg_col[k]; b += w.sval[j] * w.Dinv0[j] * d.r[j]; }
+    w.beta[a] = b; w.wbeta[a] = w.wv[a] * b;
+  }
+}
+struct EWbdG : NoPrefetch {                                                // g_C = r_C - A_d' (w .* beta): rows of the transpose = columns; only the dense ones have an equation in T
+  const int *kind, *colmap; const double *r; double *gc;
+  __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { if (kind[j] == 1) gc[colmap[j]] = r[j] - s[0]; }
+};
+__global__ __launch_bounds__(kBlock) void k_wbd_g(Dev d) {
+  __shared__ StreamLds<1> lds;
+  if (d.flags[F_DONE]) return;
+  GVec g{d.wb.wbeta};
+  EWbdG e{{}, d.wb.kind, d.wb.colmap, d.r, d.wb.g};
+  process_rows<1>(d.wb.ALT, g, e, lds);
+}
+// x_C = T^-1 g_C, written straight to its columns of uz (one workgroup per row of T^-1; 8 cd^2 bytes per launch)
+__global__ __launch_bounds__(kBlock) void k_wbd_gemv(Dev d) {
+  __shared__ double red[2 * kWaves];
+  const DevWb &w = d.wb;
+  if (d.flags[F_DONE]) return;
+  const int cd = w.cd;
+  for (int a = blockIdx.x; a < cd; a += gridDim.x) {
+    const double *row = w.Sinv + (size_t)a * cd;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int k = threadIdx.x;
+    for (; k + 3 * kBlock < cd; k += 4 * kBlock) {
+      const double m0 = row[k], m1 = row[k + kBlock], m2 = row[k + 2 * kBlock], m3 = row[k + 3 * kBlock];
+      acc0 += m0 * w.g[k]; acc1 += m1 * w.g[k + kBlock]; acc2 += m2 * w.g[k + 2 * kBlock]; acc3 += m3 * w.g[k + 3 * kBlock];
+    }
+    for (; k < cd; k += kBlock) acc0 += row[k] * w.g[k];
+    const double tot = block_sum((acc0 + acc1) + (acc2 + acc3), red);
+    if (threadIdx.x == 0) w.uz[w.dcol[a]] = tot;
+  }
+}
+struct EWbdT : NoPrefetch {                                                // rho_a t_a = rho_a (beta_a + A_d[a] x_C) / (1 + rho_a sigma_a) = w_a (beta_a + A_d[a] x_C)
+  const double *beta, *wv; double *rt;
+  __device__ __forceinline__ void operator()(int a, const double (&s)[1]) { rt[a] = wv[a] * (beta[a] + s[0]); }
+};
+__global__ __launch_bounds__(kBlock) void k_wbd_t(Dev d) {
+  __shared__ StreamLds<1> lds;
+  if (d.flags[F_DONE]) return;
+  GVec g{d.wb.uz};                                       // (zero on every column that is not dense: the singleton entries of a row drop out of the product)
+  EWbdT e{{}, d.wb.beta, d.wb.wv, d.wb.rt};
+  process_rows<1>(d.wb.AL, g, e, lds);
+}
+// u = M^-1 r column by column; partials gamma = <r, u>, ||r||_inf; direct: x~ += u and the PCG statistics see one iteration (as k_wb_p3)
+__global__ __launch_bounds__(kBlock) void k_wbd_fin(Dev d, int parity, int direct) {
+  __shared__ double red[2 * kWaves];
+  const DevWb &w = d.wb;
+  if (!direct && d.flags[F_DONE]) return;
+  double g = 0.0, rn = 0.0;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += gridDim.x * kBlock) {
+    const int kd = w.kind[j];
+    const double rj = d.r[j];
+    const double u = kd == 1 ? w.uz[j] : (kd == 2 ? (rj - w.sval[j] * w.rt[w.srow[j]]) * w.Dinv0[j] : rj * w.Dinv0[j]);
+    d.uu[j] = u; g += rj * u; rn = nanmax(rn, fabs(rj));
+    if (direct) d.xs[j] += u;
+  }
+  block_sum_max(g, rn, red);
+  put_partial(d.part, SL_GAMMA0 + parity, g); put_partial(d.part, SL_RN0 + parity, rn);
+  if (direct && blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = 1; }
+}
 __global__ void k_wb_seq(double *g, int r) { for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < r; a += gridDim.x * blockDim.x) g[a] = 1.0 + 0.25 * (a % 7); }
 
 }  // namespace
@@ -278,37 +373,54 @@ void wb_refresh(Dev &d) {
   if (!d.wb.on) return;
   HIP_CHECK(hipSetDevice(d.device));
   if (d.wb.large) LAUNCH(k_wb_gather_large, d, d); else LAUNCH(k_wb_gather, d, d);
+  if (d.wb.dual) LAUNCH(k_wbd_gather, d, d);
   for (int k = 0; k < DevWb::kCache; k++) d.wb.cache_rho[k] = -1.0;      // new matrix values: no inverse computed for the old ones may be looked up (the probe would reject it; this saves the probe)
 }
 void wb_direct(Dev &d) { LAUNCH(k_wb_direct, d, d); }
 void wb_apply(Dev &d, int parity, int direct) {
+  if (d.wb.dual) {                                          // column-space form: five launches, 8 (2 nnz(A_L) + cd^2) bytes
+    hipLaunchKernelGGL(k_wbd_beta, dim3((d.wb.r + kBlock - 1) / kBlock), dim3(kBlock), 0, st(d), d);
+    LAUNCH(k_wbd_g, d, d);
+    hipLaunchKernelGGL(k_wbd_gemv, dim3(std::min(d.wb.cd, 8 * kGrid)), dim3(kBlock), 0, st(d), d);
+    LAUNCH(k_wbd_t, d, d);
+    LAUNCH(k_wbd_fin, d, d, parity, direct);
+    return;
+  }
   LAUNCH(k_wb_p1, d, d);
   if (d.wb.large) hipLaunchKernelGGL(k_wb_gemv, dim3(std::min(d.wb.r, 8 * kGrid)), dim3(kBlock), 0, st(d), d.wb.Sinv, d.wb.g, d.wb.h, d.wb.r, d.flags + F_DONE);
   else hipLaunchKernelGGL(k_wb_p2, dim3(1), dim3(kWbMaxRows), 0, st(d), d);
   LAUNCH(k_wb_p3, d, d, parity, direct);
 }
 
-bool wb_large_supported() { return dense_libs().ok; }
+bool wb_large_supported() { return true; }      // (own kernels: dense_hip.hip; the vendor route needs the libraries, checked where it is asked for)
 
 // D0, W, S = W W' + 1 / rho_L, S^-1 -- all on the device (r up to kWbLargeMax); then the two numerical checks
 static void wb_factor_large(Dev &d) {
   DevWb &w = d.wb;
-  DenseLibs &L = dense_libs();
   Impl &p = im(d);
-  if (!L.ok) throw DeviceError("osqp_hip: the dense solver libraries are not available");
-  if (!p.blas) {
-    rocblas_handle h = nullptr;
-    if (L.create(&h) != rocblas_status_success) throw DeviceError("osqp_hip: rocblas_create_handle failed");
-    p.blas = h;
+  rocblas_handle h = nullptr;
+  static DenseLibs none;
+  DenseLibs &L = w.vendor ? dense_libs() : none;             // (the libraries are touched only on the vendor route)
+  if (w.vendor) {
+    if (!L.ok) throw DeviceError("osqp_hip: the dense solver libraries are not available");
+    if (!p.blas) {
+      rocblas_handle hh = nullptr;
+      if (L.create(&hh) != rocblas_status_success) throw DeviceError("osqp_hip: rocblas_create_handle failed");
+      p.blas = hh;
+    }
+    h = static_cast<rocblas_handle>(p.blas);
+    if (L.set_stream(h, st(d)) != rocblas_status_success) throw DeviceError("osqp_hip: rocblas_set_stream failed");
   }
-  rocblas_handle h = static_cast<rocblas_handle>(p.blas);
-  if (L.set_stream(h, st(d)) != rocblas_status_success) throw DeviceError("osqp_hip: rocblas_set_stream failed");
-  const int r = w.r, ct = w.ct;
+  const int ct = w.ct;
+  const int r = w.dual ? w.cd : w.r;                         // order of the dense system: S (row space, r x r) or T (column space, cd x cd)
   const bool log = w.log != 0;
   double tlap[6] = {0, 0, 0, 0, 0, 0};
   auto lap = [&](int k) { if (log) { HIP_CHECK(hipStreamSynchronize(st(d))); tlap[k] = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); } };
   lap(0);
   LAUNCH(k_wb_diag, d, d, 0);
+  // (column-space form: the row weights w_a = rho_a / (1 + rho_a sigma_a) belong to the APPLICATION of M^-1 as much as to T -- they follow rho here, ahead of the
+  //  look-up of a cached inverse, whose probe applies M^-1 with them)
+  if (w.dual) hipLaunchKernelGGL(k_wbd_weights, dim3((w.r + kBlock - 1) / kBlock), dim3(kBlock), 0, st(d), d);
   double *out = w.pv + (size_t)d.n + d.m + d.n;                 // [4 + r] scratch behind the probe vectors
   // M^-1 (K v) = v ?   K v = B [v; rho .* (A v)]   -- the numerical test of "M is K" with the CURRENT matrices, rho vector and w.Sinv
   auto probe = [&]() {
@@ -344,25 +456,43 @@ static void wb_factor_large(Dev &d) {
     for (int k = 0; k < w.cache_used; k++) if (w.cache_rho[k] < 0) { slot = k; break; }
     if (slot < 0 && w.cache_used < ((w.probe && w.cache_on) ? DevWb::kCache : 1)) {      // (without the probe no look-up can ever hit: one buffer)
       slot = w.cache_used;
-      if (!w.cache_buf[slot]) { void *b = nullptr; if (hipMalloc(&b, sizeof(double) * (size_t)w.r * w.r) != hipSuccess) { (void)hipGetLastError(); slot = -1; } else w.cache_buf[slot] = static_cast<double *>(b); }
+      if (!w.cache_buf[slot]) { void *b = nullptr; if (hipMalloc(&b, sizeof(double) * (size_t)r * r) != hipSuccess) { (void)hipGetLastError(); slot = -1; } else w.cache_buf[slot] = static_cast<double *>(b); }
       if (slot >= 0) w.cache_used += 1;
     }
     if (slot < 0) { slot = w.cache_next % std::max(1, w.cache_used); w.cache_next += 1; }
     w.Sinv = w.cache_buf[slot]; w.cache_rho[slot] = -1.0; w.cache_next = slot + 1;
   }
+  const double one = 1.0, zero = 0.0;
+  if (w.dual) {
+    LAUNCH(k_wbd_fillW, d, d);
+    lap(1);
+    // W is r x cd row-major = cd x r column-major (ld cd): T = W_cm W_cm' (cd x cd, inner dimension r)
+    if (!w.vendor) dense_gemm(st(d), r, r, w.r, 1.0, w.W, 1, r, w.W, r, 1, 0.0, w.S, r, 1);      // T(i, j) = sum_a W[a][i] W[a][j]
+    else if (L.dgemm(h, rocblas_operation_none, rocblas_operation_transpose, r, r, w.r, &one, w.W, r, w.W, r, &zero, w.S, r) != rocblas_status_success)
+      throw DeviceError("osqp_hip: rocblas_dgemm failed");
+    LAUNCH(k_wbd_adddiag, d, d);
+  } else {
   LAUNCH(k_wb_fillW, d, d);
   lap(1);
-  const double one = 1.0, zero = 0.0;
   // W is r x ct row-major = ct x r column-major (ld ct): S = W' W in the library's convention
-  if (L.dgemm(h, rocblas_operation_transpose, rocblas_operation_none, r, r, ct, &one, w.W, ct, w.W, ct, &zero, w.S, r) != rocblas_status_success)
+  if (!w.vendor) dense_gemm(st(d), r, r, ct, 1.0, w.W, ct, 1, w.W, 1, ct, 0.0, w.S, r, 1);        // S(a, b) = sum_j W[a][j] W[b][j]
+  else if (L.dgemm(h, rocblas_operation_transpose, rocblas_operation_none, r, r, ct, &one, w.W, ct, w.W, ct, &zero, w.S, r) != rocblas_status_success)
     throw DeviceError("osqp_hip: rocblas_dgemm failed");
   LAUNCH(k_wb_adddiag, d, d);
+  }
   lap(2);
   HIP_CHECK(hipMemcpyAsync(w.Sinv, w.S, sizeof(double) * (size_t)r * r, hipMemcpyDeviceToDevice, st(d)));
+  double *minpiv = w.gjwork + wb_inverse_work(r);
+  if (!w.vendor) {
+    HIP_CHECK(hipMemsetAsync(w.info, 0, 2 * sizeof(int), st(d)));
+    dense_spd_inverse(st(d), w.Sinv, r, r, w.gjwork, minpiv);      // block Gauss-Jordan on the matrix cores (dense_hip.hip)
+    lap(3); lap(4);
+  } else {
   if (L.dpotrf(h, rocblas_fill_lower, r, w.Sinv, r, w.info) != rocblas_status_success) throw DeviceError("osqp_hip: rocsolver_dpotrf failed");
   lap(3);
   if (L.dpotri(h, rocblas_fill_lower, r, w.Sinv, r, w.info + 1) != rocblas_status_success) throw DeviceError("osqp_hip: rocsolver_dpotri failed");
   lap(4);
+  }
   hipLaunchKernelGGL(k_wb_symm, dim3(std::min(r, 8 * kGrid)), dim3(kBlock), 0, st(d), w.Sinv, r);
   // S^-1 against S on a fixed vector:  S (S^-1 g) = g
   hipLaunchKernelGGL(k_wb_seq, dim3(64), dim3(256), 0, st(d), w.g, r);
@@ -371,18 +501,19 @@ static void wb_factor_large(Dev &d) {
   hipLaunchKernelGGL(k_wb_maxdiff, dim3(1), dim3(kBlock), 0, st(d), out + 4, w.g, r, out);
   if (w.probe) probe();
   int info[2] = {0, 0};
-  double chk[4] = {0, 1, 0, 1};
+  double chk[4] = {0, 1, 0, 1}, piv = 1.0;
+  if (!w.vendor) HIP_CHECK(hipMemcpyAsync(&piv, minpiv, sizeof(double), hipMemcpyDeviceToHost, st(d)));
   HIP_CHECK(hipMemcpyAsync(info, w.info, sizeof(info), hipMemcpyDeviceToHost, st(d)));
   HIP_CHECK(hipMemcpyAsync(chk, out, sizeof(double) * (w.probe ? 4 : 2), hipMemcpyDeviceToHost, st(d)));
   HIP_CHECK(hipStreamSynchronize(st(d)));
-  if (info[0] != 0 || info[1] != 0) throw DeviceError("osqp_hip: the Woodbury system of the preconditioner is not positive definite");
+  if (info[0] != 0 || info[1] != 0 || !(piv > 0.0)) throw DeviceError("osqp_hip: the Woodbury system of the preconditioner is not positive definite");
   const bool inv_ok = chk[0] <= 1e-8 * chk[1];
   w.exact = (w.probe && inv_ok && chk[2] <= w.exact_tol * chk[3]) ? 1 : 0;
   if (inv_ok) for (int k = 0; k < w.cache_used; k++) if (w.cache_buf[k] == w.Sinv) w.cache_rho[k] = w.rho_key;      // (the entry is valid from here on)
   if (log) {
     lap(5);
-    std::fprintf(stderr, "osqp_hip woodbury: r %d ct %d  |S S^-1 g - g| %.2e / %.2e   |M^-1 K v - v| %.2e / %.2e   direct %d;  D0 + W %.1f ms, GEMM %.1f ms, Cholesky %.1f ms, inverse %.1f ms, mirror + checks %.1f ms\n",
-                 r, ct, chk[0], chk[1], chk[2], chk[3], w.exact, 1e3 * (tlap[1] - tlap[0]), 1e3 * (tlap[2] - tlap[1]), 1e3 * (tlap[3] - tlap[2]), 1e3 * (tlap[4] - tlap[3]), 1e3 * (tlap[5] - tlap[4]));
+    std::fprintf(stderr, "osqp_hip woodbury (%s): order %d ct %d  |S S^-1 g - g| %.2e / %.2e   |M^-1 K v - v| %.2e / %.2e   direct %d;  D0 + W %.1f ms, GEMM %.1f ms, Cholesky %.1f ms, inverse %.1f ms, mirror + checks %.1f ms\n",
+                 w.dual ? "column space" : "row space", r, ct, chk[0], chk[1], chk[2], chk[3], w.exact, 1e3 * (tlap[1] - tlap[0]), 1e3 * (tlap[2] - tlap[1]), 1e3 * (tlap[3] - tlap[2]), 1e3 * (tlap[4] - tlap[3]), 1e3 * (tlap[5] - tlap[4]));
   }
 }
 // D0, S, S^-1 (with its check) and the second tile of the two-launch direct mode: launches only -- conditional inside a boundary group

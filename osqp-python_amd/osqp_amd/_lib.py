@@ -57,7 +57,7 @@ class SolverStruct(C.Structure):
 class StatsStruct(C.Structure):
     _fields_ = [(k, C.c_double) for k in ('pcg_iters_total', 'pcg_iters_max', 'pcg_unconverged', 'kernel_launches',
                                           'graph_launches', 'gpu_solve_ms', 'nnzA', 'nnzB', 'pcg_fused', 'batch_direct_bw',
-                                          'cg_cap_escalations', 'windowed_blocks', 'row_blocks', 'slot_topups', 'f1_replicas', 'woodbury_rows', 'woodbury_direct', 'preconditioner', 'woodbury_factorisations', 'woodbury_factor_ms', 'reordered', 'reorder_ms', 'woodbury_cache_hits', 'f1_far_columns', 'kform_nnz')]
+                                          'cg_cap_escalations', 'windowed_blocks', 'row_blocks', 'slot_topups', 'f1_replicas', 'woodbury_rows', 'woodbury_direct', 'preconditioner', 'woodbury_factorisations', 'woodbury_factor_ms', 'reordered', 'reorder_ms', 'woodbury_cache_hits', 'f1_far_columns', 'woodbury_dual_cols', 'kform_nnz')]
 
 
 class PolicyStruct(C.Structure):       # OSQPHipPolicy, include/osqp_hip.h (same order)
@@ -66,7 +66,7 @@ class PolicyStruct(C.Structure):       # OSQPHipPolicy, include/osqp_hip.h (same
                  ('rho_tol_exp', C.c_double), ('budget_tolerate', C.c_double), ('budget_sigma', C.c_double), ('budget_slack', C.c_int), ('budget_full', C.c_int),
                  ('cg_escalate', C.c_int), ('stall', C.c_int), ('polish_delta_floor', C.c_double), ('polish_pcg_tol', C.c_double), ('slot_poll', C.c_int), ('poll_low', C.c_int), ('poll_first', C.c_double),
                  ('poll_frac', C.c_double), ('poll_wait', C.c_double), ('finish_pairs', C.c_int), ('poll_sleep_us', C.c_int),
-                 ('slot_log', C.c_int), ('setup_timing', C.c_int), ('batch_timing', C.c_int), ('woodbury_log', C.c_int), ('woodbury_direct_tol', C.c_double), ('woodbury_fused', C.c_int), ('debug_fail_refactor', C.c_int), ('reorder', C.c_int), ('woodbury_cache', C.c_int), ('kform', C.c_int)])
+                 ('slot_log', C.c_int), ('setup_timing', C.c_int), ('batch_timing', C.c_int), ('woodbury_log', C.c_int), ('woodbury_direct_tol', C.c_double), ('woodbury_fused', C.c_int), ('debug_fail_refactor', C.c_int), ('reorder', C.c_int), ('woodbury_cache', C.c_int), ('kform', C.c_int), ('woodbury_dual', C.c_int), ('woodbury_vendor', C.c_int)])
 
 
 SolverP = C.POINTER(SolverStruct)

@@ -223,8 +223,8 @@ class OSQPSolver:
         return self._lib.osqp_codegen(self._p, None, None, None)
 
     # ---- engine extensions ----
-    PRECONDITIONERS = {0: 'none', 1: 'jacobi', 2: 'jacobi + woodbury (dense rows, host-inverted system)',
-                       3: 'jacobi + woodbury (dense rows, system factorised on the device by rocBLAS / rocSOLVER)'}      # OSQP_HIP_PRECOND_*
+    PRECONDITIONERS = {0: 'none', 1: 'jacobi', 2: 'jacobi + woodbury (dense rows, system inverted in one workgroup\'s LDS)',
+                       3: 'jacobi + woodbury (dense rows, dense system formed and inverted on the fp64 matrix cores)'}      # OSQP_HIP_PRECOND_*
 
     def hip_stats(self):
         s = _lib.StatsStruct()
@@ -233,7 +233,14 @@ class OSQPSolver:
 
     def hip_preconditioner(self):
         """What this handle's PCG is preconditioned with right now, in words (OSQPHipStats::preconditioner)."""
-        return self.PRECONDITIONERS[int(self.hip_stats()['preconditioner'])]
+        st = self.hip_stats()
+        name = self.PRECONDITIONERS[int(st['preconditioner'])]
+        if int(st['preconditioner']) == 3:
+            cd = int(st.get('woodbury_dual_cols', 0))
+            name += (', column space (%d x %d)' % (cd, cd)) if cd else ', row space'
+            if self.get_policy().get('woodbury_vendor'):
+                name += ' -- vendor route (rocBLAS / rocSOLVER)'
+        return name
 
     def get_policy(self):
         """This handle's engine policy (include/osqp_hip.h OSQPHipPolicy) as a dict."""

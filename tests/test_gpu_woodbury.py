@@ -292,3 +292,51 @@ def test_cached_inverses_serve_repeated_solves_and_die_with_the_matrices():
         m2 = osqp_amd.OSQP(); m2.setup(P, q, A, l, u, **st)
         m2.solve(); m2.update_settings(rho=0.1); r4 = m2.solve(raise_error=True); s4 = m2._solver.hip_stats()
     assert s4['woodbury_cache_hits'] == 0 and s4['woodbury_factorisations'] >= 1 and np.array_equal(r4.x, r1.x)
+
+
+def test_column_space_form_equals_the_row_space_form():
+    """backend.h DevWb::dual (OSQPHipPolicy::woodbury_dual): with fewer dense columns than 3/4 of the dense rows the device-factorised correction works on
+    the cd x cd system of the dense columns (lasso 300 x 600: cd = 300 against r = 600; the -y_i entries are singletons).  The same M as the row-space
+    form: same direct mode, same solution as that form and as the oracle."""
+    P, q, A, l, u = problems.lasso_qp(300, 600)
+    xo, yo, io = Oracle().setup(P, q, A, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000).solve()
+    assert io.status_val == SOLVED
+    out = {}
+    for name, env in (('dual', {'OSQP_HIP_WOODBURY_DUAL': '1'}), ('row', {'OSQP_HIP_WOODBURY_DUAL': '0'})):
+        with _env(**env):
+            m = osqp_amd.OSQP()
+            m.setup(P, q, A, l, u, eps_abs=1e-8, eps_rel=1e-8, verbose=False, max_iter=50000)
+            r = m.solve(raise_error=True)
+            out[name] = (r, m._solver.hip_stats())
+    (rd, sd), (rr, sr) = out['dual'], out['row']
+    assert sd['woodbury_dual_cols'] == 300 and sr['woodbury_dual_cols'] == 0 and sd['woodbury_rows'] == sr['woodbury_rows'] == 600
+    assert sd['woodbury_direct'] == 1 and sr['woodbury_direct'] == 1
+    print('column space: %d iterations, row space: %d; |dx| %.2e |dy| %.2e; vs oracle |dx| %.2e' % (rd.info.iter, rr.info.iter, _rel(rd.x, rr.x), _rel(rd.y, rr.y), _rel(rd.x, xo)))
+    assert rd.info.iter == rr.info.iter
+    assert _rel(rd.x, rr.x) < 1e-7 and _rel(rd.y, rr.y) < 1e-6
+    assert _rel(rd.x, xo) < 5e-6 and _rel(rd.y, yo) < 2e-5
+
+
+def test_column_space_form_with_several_singletons_per_row():
+    """Rows  A_d x - y1 + 0.5 y2 = b : TWO singleton columns per dense row (the per-row Sherman-Morrison elimination in its general form, sigma_a = sum of two
+    terms), P diagonal, one-entry short rows: the correction is exact (direct mode) and the solution is the oracle's."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(11)
+    nf, ns = 150, 400
+    Ad = sp.csc_matrix(rng.standard_normal((ns, nf)))
+    b = rng.standard_normal(ns)
+    n = nf + 2 * ns
+    P = sp.diags(np.concatenate([0.01 * np.ones(nf), 2.0 * np.ones(ns), 1.0 * np.ones(ns)]), format='csc')
+    q = np.concatenate([0.1 * rng.standard_normal(nf), np.zeros(2 * ns)])
+    A = sp.vstack([sp.hstack([Ad, -sp.eye(ns), 0.5 * sp.eye(ns)]), sp.hstack([sp.eye(nf), sp.csc_matrix((nf, 2 * ns))])], format='csc')
+    l = np.concatenate([b, -np.ones(nf)]); u = np.concatenate([b, np.ones(nf)])
+    xo, yo, io = Oracle().setup(P, q, A, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000).solve()
+    assert io.status_val == SOLVED
+    m = osqp_amd.OSQP()
+    m.setup(P, q, A, l, u, eps_abs=1e-8, eps_rel=1e-8, verbose=False, max_iter=50000)
+    r = m.solve(raise_error=True)
+    s = m._solver.hip_stats()
+    print('two singletons per row: %d iterations, %.2f PCG each, rows %d, dense columns %d, direct %d; |dx| %.2e |dy| %.2e' %
+          (r.info.iter, s['pcg_iters_total'] / r.info.iter, s['woodbury_rows'], s['woodbury_dual_cols'], s['woodbury_direct'], _rel(r.x, xo), _rel(r.y, yo)))
+    assert s['woodbury_rows'] == ns and s['woodbury_dual_cols'] == nf and s['woodbury_direct'] == 1
+    assert _rel(r.x, xo) < 5e-6 and _rel(r.y, yo) < 2e-5
