@@ -332,6 +332,15 @@ def measure_roofline(s, stats, n, mm, args):
             cd = int(stats.get('woodbury_dual_cols', 0))                       # column-space form: the dense system is cd x cd (OSQPHipPolicy::woodbury_dual)
             order = cd or r
             wb_bytes = 8 * nzL + 8 * order * order + 8 * nzL + 8 * (4 * n + 2 * r)     # A_L once (values only: consecutive columns), the inverse, A_L' once, the vectors
+            if int(stats.get('woodbury_fused_iteration', 0)):
+                # the fused iteration: A_L streamed twice (transposed pass with the combined vector, row pass that also updates z / y of the dense rows), T^-1 once,
+                # the m- and n-vector passes of the seven launches -- a whole ADMM iteration, no KB / KA launch beside it
+                wb_bytes = 2 * 8 * nzL + 8 * order * order + 8 * (12 * n + 16 * mm)
+                ms_it = s.hip_time_kernel(23, max(20, args.probe_reps // 4))
+                name = 'Woodbury direct mode in column space, FUSED ADMM iteration: k_wbf_r + k_wbf_beta + k_wbf_g + k_wbd_gemv (T^-1, %d x %d) + k_wbf_t + k_wbf_x + k_wbf_s (seven launches, no KB / KA)' % (cd, cd)
+                probes = {name: {'ms': ms_it, 'ms_same_kernel_repeat': ms_it, 'bytes': wb_bytes, 'GBps': wb_bytes / (ms_it * 1e-3) / 1e9, 'launches': 7}}
+                kb = {name: wb_bytes}
+                return probes, kb, wb_bytes, ms_it, name, 'k_wbf_g', survey_pcg_bytes, None, False, fused, 0
             ms_ch = s.hip_time_kernel(21, max(20, args.probe_reps // 4))
             name = ('Woodbury direct mode in column space, M^-1 = K^-1: k_wbd_beta + k_wbd_g + k_wbd_gemv (T^-1, %d x %d) + k_wbd_t + k_wbd_fin (five launches per ADMM iteration)' % (cd, cd)) if cd else \
                    'Woodbury direct mode, M^-1 = K^-1: k_wb_p1 + k_wb_gemv + k_wb_p3 (three launches per ADMM iteration)'

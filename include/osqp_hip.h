@@ -200,6 +200,7 @@ typedef struct {
                                  numerical probe against the current matrices) -- woodbury_factorisations counts the others; woodbury_factor_ms covers both */
   double f1_far_columns;      /* F1 form with per-block mixing: far columns (spill slots) over all row blocks of A (0: every block fits its window) */
   double woodbury_dual_cols;  /* device-factorised Woodbury form in column space (OSQPHipPolicy::woodbury_dual): order of its dense system = dense columns (0: row space) */
+  double woodbury_fused_iteration; /* 1: the column-space direct mode runs its ADMM iteration fused -- seven launches, the dense block of A streamed twice instead of four times (no KB / KA launch) */
   double kform_nnz;           /* K form: stored entries of the explicit reduced matrix K = P + sigma I + A' diag(rho) A (0: the form is not in use) */
 } OSQPHipStats;
 /* OSQPHipStats::preconditioner.  `cg_precond = OSQP_DIAGONAL_PRECONDITIONER` (bindings.cpp.in:426, the reference's only preconditioner) selects the
@@ -224,7 +225,8 @@ OSQPInt osqp_hip_get_stats(OSQPSolver *solver, OSQPHipStats *out);
    what a launch costs inside a solve; 17 = KA of the F1 form (z~ = A x~, z / y / x update, slices of r_0 and rhs), 18 = the first launch of a chunk
    (those slices from the vectors in memory).
    Woodbury direct mode (0 when it is not on): 20 = one ADMM iteration of the two-launch form (k_wbx_y + k_wbx_x; `reps` iterations as one chunk, time per
-   iteration), 21 = the three kernels of M^-1 = K^-1 of the five-launch form (k_wb_p1, k_wb_p2 / k_wb_gemv, k_wb_p3).
+   iteration), 21 = the kernels of M^-1 = K^-1 of the unfused form (k_wb_p1, k_wb_p2 / k_wb_gemv, k_wb_p3; column space: the five k_wbd_* launches),
+   23 = one ADMM iteration of the fused column-space direct mode (seven launches: k_wbf_r, k_wbf_beta, k_wbf_g, k_wbd_gemv, k_wbf_t, k_wbf_x, k_wbf_s).
    The kernels run in a side-effect-free "probe" mode or on saved-and-restored state; solver state is unchanged. */
 OSQPInt osqp_hip_time_kernel(OSQPSolver *solver, OSQPInt which, OSQPInt reps, double *mean_ms);
 

@@ -221,6 +221,16 @@ struct DevWb {
   int *sg_ptr = nullptr, *sg_col = nullptr;                          // per long row: its singleton columns (CSR over the r rows; sums run in list order)
   double *wv = nullptr, *den = nullptr, *beta = nullptr, *wbeta = nullptr, *rt = nullptr;      // [r] w_a, 1 + rho_a sigma_a, beta_a, w_a beta_a, rho_a t_a
   double *uz = nullptr;          // [n] x_C scattered to its columns, ZERO everywhere else (only dense positions are ever written): the vector the row pass gathers
+  // FUSED ADMM iteration of the column-space direct mode (fused = 1; woodbury_hip.hip wbf_iteration): the dense block of A is streamed TWICE per ADMM
+  // iteration instead of four times (KB's A' v, the g pass, the t pass, KA's A x~).  With c = v - t0 (v = rho z - y, t0 = rho A x_g):
+  //   r_0 = sigma x - q - (P + sigma I) x_g + A' c,   so   g_C = [sigma x - q - (P + sigma I) x_g]_C + A_C' (c - w .* beta on the dense rows):
+  // ONE transposed pass with the combined vector cc does KB's and the g pass's work; and since x~ = x_g + u,  z~ = A x_g + A u  on a dense row a is
+  // ztg_a + (A_d[a] u_C + beta_a - rho_a t_a sigma_a): the t pass already holds A_d[a] u_C, so it also performs KA's z / y update of the dense rows.
+  int fused = 0;
+  DevCsr Bd, Bn, As;             // views of B / A (same arrays, other block lists): row blocks of B holding a dense column / a column that is not dense; row blocks of A holding a short row
+  double *cc = nullptr;          // [m] v - t0 (- w_a beta_a on dense row a)
+  int *lidx = nullptr;           // [m] constraint row -> its index among the dense rows (rows[lidx[i]] = i; 0 on short rows)
+  double *sig = nullptr;         // [r] sigma_a
 };
 
 // indices into Dev::res (results of the residual kernels, reduced on the device)
@@ -426,6 +436,8 @@ void wbx_chunk(Dev &d, int niter);         // niter ADMM iterations: X(rhs), { Y
 bool wb_large_supported();                 // the dense solver libraries could be loaded                       // Woodbury preconditioner available (false: the host simulator)
 void wb_refresh(Dev &d);                   // wb.AL / ALT / WT values <- A.val (after assembly / equilibration / matrix updates)
 void wb_direct(Dev &d);                    // exact mode: x~ = x_g + M^-1 r_0 (after kb_rhs + wb_apply(0)); marks the solve as converged after one step
+inline bool wbf_active(const Dev &d) { return d.wb.on && d.wb.exact && d.wb.dual && d.wb.fused; }
+void wbf_iteration(Dev &d);                // one ADMM iteration of the fused column-space direct mode: seven launches (no KB, no KA)
 void wb_apply(Dev &d, int parity, int direct = 0);   // direct: exact mode -- the last of the three kernels also forms x~ = x_g + u and marks the solve as converged after one step
 //         // u = M^-1 r with the partials gamma = <r, u>, ||r||_inf in the slots of `parity` (after kb_rhs: 0, after kv(i): (i + 1) & 1)
 // ---- device-driven chunk boundaries (policy.h; backend_hip.hip "boundary kernels").  The host uploads the state block once per solve,

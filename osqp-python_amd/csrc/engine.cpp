@@ -159,7 +159,7 @@ void Engine::free_all() {
                   d_.wb.AL.rowptr, d_.wb.AL.col, d_.wb.AL.blkdesc, d_.wb.AL.runinfo, d_.wb.AL.val, d_.wb.ALT.rowptr, d_.wb.ALT.col, d_.wb.ALT.blkdesc, d_.wb.ALT.runinfo, d_.wb.ALT.val,
                   d_.wb.al_src, d_.wb.alt_src, d_.wb.islong, d_.wb.rows, d_.wb.WT, d_.wb.S, d_.wb.Sinv, d_.wb.g, d_.wb.h, d_.wb.Dinv0, d_.wb.colmap, d_.wb.W, d_.wb.pv, d_.wb.info, d_.wb.dbg, d_.wb.x.tile, d_.wb.x.tile2, d_.wb.x.partG, d_.wb.x.partZ, d_.wb.x.ls0, d_.wb.x.ls1, d_.wb.x.sc_ptr, d_.wb.x.sc_row, d_.wb.x.sc_src, d_.wb.x.sc_val, d_.wb.x.bjj,
                   d_.ctl, d_.f1.blk, d_.f1.stream, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.va, d_.f1.fcol, d_.f1.fq, d_.f1.sp_ptr, d_.f1.spk, d_.f1.spill, d_pc_, d_pr_,
-                  d_.wb.gjwork, d_.wb.kind, d_.wb.dcol, d_.wb.srow, d_.wb.ssrc, d_.wb.sval, d_.wb.sg_ptr, d_.wb.sg_col, d_.wb.wv, d_.wb.den, d_.wb.beta, d_.wb.wbeta, d_.wb.rt, d_.wb.uz,
+                  d_.wb.gjwork, d_.wb.cc, d_.wb.sig, d_.wb.lidx, d_.wb.Bd.blkdesc, d_.wb.Bn.blkdesc, d_.wb.As.blkdesc, d_.wb.kind, d_.wb.dcol, d_.wb.srow, d_.wb.ssrc, d_.wb.sval, d_.wb.sg_ptr, d_.wb.sg_col, d_.wb.wv, d_.wb.den, d_.wb.beta, d_.wb.wbeta, d_.wb.rt, d_.wb.uz,
                   d_.kf.K.rowptr, d_.kf.K.col, d_.kf.K.blkdesc, d_.kf.K.runinfo, d_.kf.K.val, d_.kf.tptr, d_.kf.trow, d_.kf.ta, d_.kf.tb, d_.kf.rec};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   be::destroy(d_);
@@ -380,6 +380,7 @@ void Engine::run_chunk(int niter, int budget) {
   auto enqueue = [&](int count) {
     if (xy) { be::wbx_chunk(d_, count); return; }
     for (int it = 0; it < count; it++) {
+      if (be::wbf_active(d_)) { be::wbf_iteration(d_); continue; }      // column-space direct mode, fused: seven launches, the dense block streamed twice (backend.h DevWb::fused)
       be::kb_rhs(d_);
       if (wb) be::wb_apply(d_, 0, d_.wb.exact);
       if (wb && d_.wb.exact) { be::ka(d_, budget); continue; }      // M^-1 r_0 is the solve (x~ formed by the last kernel of M^-1)
@@ -387,7 +388,7 @@ void Engine::run_chunk(int niter, int budget) {
       be::ka(d_, budget);
     }
   };
-  stats_.kernel_launches += xy ? 2.0 * niter + 1 : (double)niter * ((wb && d_.wb.exact) ? 5 : (fused ? 3 + 2 * budget : 2 + 3 * budget + (wb ? 3 * (budget + 1) : 0)));
+  stats_.kernel_launches += xy ? 2.0 * niter + 1 : (double)niter * ((wb && d_.wb.exact) ? (d_.wb.dual ? 7 : 5) : (fused ? 3 + 2 * budget : 2 + 3 * budget + (wb ? 3 * (budget + 1) : 0)));
   if (!(use_graph_ && be::graphs_supported())) { enqueue(niter); return; }
   // one executable graph per (ADMM iterations, PCG budget); graphs are kept below kMaxGraphNodes kernel nodes (a
   // check_termination = 0 solve would otherwise capture max_iter * (2 + 3*budget) nodes in one graph)
@@ -395,7 +396,7 @@ void Engine::run_chunk(int niter, int budget) {
   const int per = std::max(1, kMaxGraphNodes / (2 + 3 * budget + (wb ? 3 * (budget + 1) : 0)));
   for (int left = niter; left > 0;) {
     const int cnt = std::min(left, per);
-    auto key = std::make_pair(cnt, budget | ((wb && d_.wb.exact) ? (1 << 24) : 0) | (xy ? (1 << 25) : 0));      // (the direct mode is another launch sequence: it may come and go with rho in the large-rank form)
+    auto key = std::make_pair(cnt, budget | ((wb && d_.wb.exact) ? (1 << 24) : 0) | (xy ? (1 << 25) : 0) | (be::wbf_active(d_) ? (1 << 26) : 0));      // (the direct mode is another launch sequence: it may come and go with rho in the large-rank form)
     auto it = graphs_.find(key);
     if (it == graphs_.end()) {
       be::graph_begin(d_);

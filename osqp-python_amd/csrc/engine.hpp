@@ -141,6 +141,8 @@ class Engine {
   bool prepare_batch_spectral(double rho_ref, double eqf, bool allow_build);      // true: the form is ready for the current key
   void free_batch_spectral();
   void prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj);
+  std::vector<int> wb_kind_;            // column kinds of the column-space Woodbury form (backend.h DevWb::kind), kept for the block views built after the upload
+  void build_wbf_views(const std::vector<int> &rbA, const std::vector<int> &rbB, const std::vector<int> &Arp, const std::vector<int> &Arj, const std::vector<int> &Brp, const std::vector<int> &Bj);
   struct F1Plan {                       // host image of backend.h DevF1 (plan_f1 builds it without touching the device; upload_f1 commits it)
     bool ok = false; int D = 0, pnnz = 0;
     std::vector<int> blk, prp, pcol, psrc; std::vector<unsigned int> ent; std::vector<unsigned short> cptr;

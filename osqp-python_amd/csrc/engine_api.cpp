@@ -804,6 +804,7 @@ int Engine::get_stats(OSQPHipStats *out) {
   out->f1_replicas = d_.f1.on ? d_.f1.D : 0;
   out->kform_nnz = d_.kf.on ? (double)d_.kf.K.nnz : 0.0;
   out->woodbury_dual_cols = (d_.wb.on && d_.wb.dual) ? (double)d_.wb.cd : 0.0;
+  out->woodbury_fused_iteration = be::wbf_active(d_) ? 1.0 : 0.0;
   out->woodbury_rows = d_.wb.on ? d_.wb.r : 0; out->woodbury_direct = (d_.wb.on && d_.wb.exact) ? ((d_.wb.x.on) ? 2 : 1) : 0;
   out->windowed_blocks = d_.A.nwin + d_.B.nwin; out->row_blocks = d_.A.nblk + d_.B.nblk;
   out->reordered = reordered_ ? 1.0 : 0.0; out->reorder_ms = reorder_ms_;
@@ -817,7 +818,7 @@ int Engine::get_stats(OSQPHipStats *out) {
 int Engine::time_kernel(int which, int reps, double *ms) {
   if (!dev_ready_) return OSQP_WORKSPACE_NOT_INIT_ERROR;
   be::activate(d_);
-  if (which < 0 || which > 21 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
+  if (which < 0 || which > 23 || reps <= 0 || !ms) return OSQP_DATA_VALIDATION_ERROR;
   *ms = be::time_kernel(d_, which, reps);
   return OSQP_NO_ERROR;
 }

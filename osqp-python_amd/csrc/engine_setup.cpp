@@ -480,6 +480,11 @@ void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj
     w.wv = dev_vec<double>(d_, r); w.den = dev_vec<double>(d_, r); w.beta = dev_vec<double>(d_, r); w.wbeta = dev_vec<double>(d_, r); w.rt = dev_vec<double>(d_, r);
     w.W = dev_vec<double>(d_, (size_t)r * cd);                  // (zero-filled by the allocator: only the pattern's positions are ever written)
     w.pv = dev_vec<double>(d_, (size_t)n + m + n + 4 + r);
+    // fused ADMM iteration of the direct mode (backend.h DevWb::fused): per-row tables now, the block views of A / B once those are uploaded (build_wbf_views)
+    { std::vector<int> lidx(m, 0); for (int a = 0; a < r; a++) lidx[rows[a]] = a; w.lidx = up_i(lidx); }
+    w.cc = dev_vec<double>(d_, m); w.sig = dev_vec<double>(d_, r);
+    w.fused = (pol_.woodbury_fused != 0 && pol_.woodbury_direct != 0) ? 1 : 0;
+    wb_kind_ = kind;
   } else if (large) {
     w.large = 1; w.ct = ct; w.colmap = up_i(colmap);
     w.W = dev_vec<double>(d_, (size_t)r * ct);                  // (zero-filled by the allocator: only the pattern's positions are ever written)
@@ -525,6 +530,30 @@ void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj
       x.on = 1;
     }
   }
+}
+
+// Block views for the fused column-space iteration (backend.h DevWb::Bd / Bn / As): the same CSR arrays as d_.B / d_.A with a filtered block list --
+// row blocks of B that hold a dense column, row blocks of B that hold a column that is not dense (a mixed block is in both: the epilogues filter by
+// kind), row blocks of A that hold a short row.  A long row's descriptor keeps its offset into the run table.
+void Engine::build_wbf_views(const std::vector<int> &rbA, const std::vector<int> &rbB, const std::vector<int> &Arp, const std::vector<int> &Arj, const std::vector<int> &Brp, const std::vector<int> &Bj) {
+  DevWb &w = d_.wb;
+  if (!(w.on && w.dual && w.fused)) return;
+  std::vector<int> runs, dB = block_descs(rbB, Brp, Bj, runs), dA = block_descs(rbA, Arp, Arj, runs);
+  std::vector<int> bd, bn, as;
+  for (size_t b = 0; b + 1 < rbB.size(); b++) {
+    bool dense = false, other = false;
+    for (int j = rbB[b]; j < rbB[b + 1]; j++) { if (wb_kind_[j] == 1) dense = true; else other = true; }
+    if (dense) bd.insert(bd.end(), dB.begin() + 4 * b, dB.begin() + 4 * b + 4);
+    if (other) bn.insert(bn.end(), dB.begin() + 4 * b, dB.begin() + 4 * b + 4);
+  }
+  for (size_t b = 0; b + 1 < rbA.size(); b++) {
+    bool shortrow = false;
+    for (int i = rbA[b]; i < rbA[b + 1]; i++) if (Arp[i + 1] - Arp[i] <= kLongRow) shortrow = true;
+    if (shortrow) as.insert(as.end(), dA.begin() + 4 * b, dA.begin() + 4 * b + 4);
+  }
+  auto up_i = [&](const std::vector<int> &h) { int *p = dev_vec<int>(d_, h.size()); if (!h.empty()) be::h2d(d_, p, h.data(), sizeof(int) * h.size()); return p; };
+  auto view = [&](const DevCsr &M, const std::vector<int> &desc) { DevCsr V = M; V.blkdesc = up_i(desc); V.nblk = (int)desc.size() / 4; V.blkwin = nullptr; V.lcol = nullptr; V.nwin = 0; V.single = 0; return V; };
+  w.Bd = view(d_.B, bd); w.Bn = view(d_.B, bn); w.As = view(d_.A, as);
 }
 
 // ------------------------------------------------------------------------------------------------ setup
@@ -765,6 +794,7 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   d_.B.rowptr = up_i(Brp); d_.B.col = up_i(Bj); { std::vector<int> runs; d_.B.blkdesc = up_i(descs(rbB, Brp, Bj, runs)); d_.B.runinfo = up_i(runs); } d_.B.val = dev_vec<double>(d_, nzB);
   d_.Bdiag = up_i(bdiag_);
   up_win(d_.A, rbA, Arp, Arj, n); up_win(d_.B, rbB, Brp, Bj, n);
+  build_wbf_views(rbA, rbB, Arp, Arj, Brp, Bj);
   lap("upload structure");
   auto dv = [&](size_t cnt) { return dev_vec<double>(d_, cnt); };
   d_.q = dv(n); d_.l = dv(m); d_.u = dv(m); d_.D = dv(n); d_.Dinv = dv(n); d_.E = dv(m); d_.Einv = dv(m);

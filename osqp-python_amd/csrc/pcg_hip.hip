@@ -1585,6 +1585,7 @@ float time_kernel(Dev &d, int which, int reps) {
   if (which >= 14 && which <= 18 && !d.f1.on && !(which == 16 && d.kf.on)) return 0.f;
   if (which == 20 && !wbx_active(d)) return 0.f;
   if (which == 21 && !(d.wb.on && d.wb.exact)) return 0.f;
+  if (which == 23 && !wbf_active(d)) return 0.f;
   const bool wbx = which == 20;
   const size_t r3 = wbx ? 3 * (size_t)d.wb.r : 0, gp_ = wbx ? (size_t)d.wb.x.G * kWbMaxRows : 0;
   Save sv[] = {{d.x, n, nullptr}, {d.z, m, nullptr}, {d.y, m, nullptr}, {d.xs, n, nullptr}, {d.zt, m, nullptr}, {d.t0, m, nullptr},
@@ -1627,6 +1628,7 @@ float time_kernel(Dev &d, int which, int reps) {
         });
         break;
       case 21: HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, 0, sizeof(int), st(d))); wb_apply(d, 0, 1); break;      // (the last kernel marks the solve as converged: cleared per repetition)     // Woodbury direct mode, device-factorised form: the three kernels of M^-1 = K^-1 (long rows, S^-1 product, transposed long rows + x~)
+      case 23: wbf_iteration(d); break;       // one ADMM iteration of the fused column-space direct mode (seven launches; the iterates move on: state saved and restored around the measurement)
       case 15: f1_probe_pair(d, 2); break;   // F1 form: one PCG iteration = one launch; two consecutive iterations as a solve runs them (buffers alternate, fold included)
       default: LAUNCH(k_k2f, d, d, 0); LAUNCH(k_k1f, d, d, 1); break;   // one FUSED PCG iteration (two kernels): repeated exact line-search steps, bounded
     }

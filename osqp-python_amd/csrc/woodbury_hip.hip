@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void k_wbd_weights(Dev d) {           // si
     double sg = 0.0;
     for (int k = w.sg_ptr[a]; k < w.sg_ptr[a + 1]; k++) { const int j = w.sg_col[k]; const double v = w.sval[j]; sg += v * v * w.Dinv0[j]; }
     const double rho = d.rho[w.rows[a]], dn = 1.0 + rho * sg;
-    w.den[a] = dn; w.wv[a] = rho / dn;
+    w.den[a] = dn; w.wv[a] = rho / dn; if (w.sig) w.sig[a] = sg;
   }
 }
 __global__ __launch_bounds__(kBlock) void k_wbd_fillW(Dev d) {             // W[a][colmap[j]] = sqrt(w_a) A_L[a, j] on the dense columns
@@ -323,6 +323,99 @@ __global__ __launch_bounds__(kBlock) void k_wbd_fin(Dev d, int parity, int direc
   put_partial(d.part, SL_GAMMA0 + parity, g); put_partial(d.part, SL_RN0 + parity, rn);
   if (direct && blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 1; d.flags[F_ITERS] = 1; }
 }
+// ---- fused ADMM iteration of the column-space direct mode (backend.h DevWb::fused).  Formulas of the iteration: _osqp.py:644-703; x~ = x_g + K^-1 r_0.
+struct GWbf {                                              // row j of B = [P + sigma I | A']: sum 0 = ((P + sigma I) x_g)_j, sum 1 = (A' c)_j with c given as a - b (- nothing) or as one vector
+  const double *xg, *ca, *cb; int n;
+  __device__ __forceinline__ void operator()(int c, double a, double (&pr)[2]) const {
+    if (c < n) { pr[0] = a * xg[c]; pr[1] = 0.0; }
+    else { pr[0] = 0.0; pr[1] = a * (cb ? ca[c - n] - cb[c - n] : ca[c - n]); }
+  }
+};
+struct EWbfR {                                             // non-dense columns: r_0j = sigma x_j - q_j - ((P + sigma I) x_g)_j + (A' c)_j
+  const int *kind; const double *x, *q; double *r; double sigma; double px = 0, pq = 0;
+  __device__ __forceinline__ void prefetch(int j) { px = x[j]; pq = q[j]; }
+  __device__ __forceinline__ void operator()(int j, const double (&s)[2]) { if (kind[j] != 1) r[j] = sigma * px - pq - s[0] + s[1]; }
+};
+__global__ __launch_bounds__(kBlock) void k_wbf_r(Dev d) {
+  __shared__ StreamLds<2> lds;
+  GWbf g{d.xg, d.v, d.t0, d.n};
+  EWbfR e{d.wb.kind, d.x, d.q, d.r, d.sigma};
+  process_rows<2>(d.wb.Bn, g, e, lds);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
+}
+__global__ __launch_bounds__(kBlock) void k_wbf_beta(Dev d) {                // per constraint row: cc = v - t0 (- w_a beta_a on dense row a); beta_a from r_0 at the row's singleton columns
+  const DevWb &w = d.wb;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += gridDim.x * kBlock) {
+    double c = d.v[i] - d.t0[i];
+    if (w.islong[i]) {
+      const int a = w.lidx[i];
+      double b = 0.0;
+      for (int k = w.sg_ptr[a]; k < w.sg_ptr[a + 1]; k++) { const int j = w.sg_col[k]; b += w.sval[j] * w.Dinv0[j] * d.r[j]; }
+      w.beta[a] = b; c -= w.wv[a] * b;
+    }
+    w.cc[i] = c;
+  }
+}
+struct EWbfG {                                             // dense columns: g_C = [sigma x - q - (P + sigma I) x_g]_C + A_C' cc
+  const int *kind, *colmap; const double *x, *q; double *gc; double sigma; double px = 0, pq = 0;
+  __device__ __forceinline__ void prefetch(int j) { px = x[j]; pq = q[j]; }
+  __device__ __forceinline__ void operator()(int j, const double (&s)[2]) { if (kind[j] == 1) gc[colmap[j]] = sigma * px - pq - s[0] + s[1]; }
+};
+__global__ __launch_bounds__(kBlock) void k_wbf_g(Dev d) {
+  __shared__ StreamLds<2> lds;
+  GWbf g{d.xg, d.wb.cc, nullptr, d.n};
+  EWbfG e{d.wb.kind, d.wb.colmap, d.x, d.q, d.wb.g, d.sigma};
+  process_rows<2>(d.wb.Bd, g, e, lds);
+}
+// the z / y update of one constraint row from z~_i (_osqp.py:682-703), the next PCG start's A x_g by linearity and what the next right-hand side reads (as pcg_hip.hip EKa)
+struct WbfRowUpd {
+  const double *l, *u, *rho, *rho_inv; double *z, *y, *zt, *t0, *v, *dy, *ztg; double alpha, theta;
+  __device__ __forceinline__ void operator()(int i, double ztil) const {
+    const double prho = rho[i], pz = z[i], py = y[i], pzt = zt[i];
+    const double zr = alpha * ztil + (1.0 - alpha) * pz;
+    const double zn = fmin(fmax(zr + rho_inv[i] * py, l[i]), u[i]);
+    const double dyi = prho * (zr - zn), yn = py + dyi;
+    const double zg = ztil + theta * (ztil - pzt);
+    y[i] = yn; dy[i] = dyi; z[i] = zn; zt[i] = ztil; v[i] = prho * zn - yn; ztg[i] = zg; t0[i] = prho * zg;
+  }
+};
+struct EWbfT : NoPrefetch {                                // dense row a: rho_a t_a, then z~ = A x_g + A u with A u = A_d[a] u_C + beta_a - rho_a t_a sigma_a
+  const double *beta, *wv, *sig; double *rt; const int *rows; WbfRowUpd up;
+  __device__ __forceinline__ void operator()(int a, const double (&s)[1]) {
+    const double t = wv[a] * (beta[a] + s[0]);
+    rt[a] = t;
+    const int i = rows[a];
+    up(i, up.ztg[i] + (s[0] + beta[a] - t * sig[a]));
+  }
+};
+__global__ __launch_bounds__(kBlock) void k_wbf_t(Dev d) {
+  __shared__ StreamLds<1> lds;
+  GVec g{d.wb.uz};
+  EWbfT e{{}, d.wb.beta, d.wb.wv, d.wb.sig, d.wb.rt, d.wb.rows, WbfRowUpd{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.ztg, d.alpha, d.theta}};
+  process_rows<1>(d.wb.AL, g, e, lds);
+}
+__global__ __launch_bounds__(kBlock) void k_wbf_x(Dev d) {                   // u column by column, x~ = x_g + u, the x update (_osqp.py:660-668), the next PCG start
+  const DevWb &w = d.wb;
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += gridDim.x * kBlock) {
+    const int kd = w.kind[j];
+    const double u = kd == 1 ? w.uz[j] : (kd == 2 ? (d.r[j] - w.sval[j] * w.rt[w.srow[j]]) * w.Dinv0[j] : d.r[j] * w.Dinv0[j]);
+    const double xt = d.xg[j] + u, xo = d.x[j], xn = d.alpha * xt + (1.0 - d.alpha) * xo;
+    d.uu[j] = u; d.xs[j] = xt; d.dx[j] = xn - xo; d.x[j] = xn;
+    d.xg[j] = xt + d.theta * (xt - d.xsp[j]); d.xsp[j] = xt;
+  }
+}
+struct EWbfS : NoPrefetch { WbfRowUpd up; const unsigned char *islong; __device__ __forceinline__ void operator()(int i, const double (&s)[1]) { if (!islong[i]) up(i, s[0]); } };
+__global__ __launch_bounds__(kBlock) void k_wbf_s(Dev d) {                   // the short rows: z~ = A x~ and their z / y update; the PCG statistics see one iteration
+  __shared__ StreamLds<1> lds;
+  GVec g{d.xs};
+  EWbfS e{{}, WbfRowUpd{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.ztg, d.alpha, d.theta}, d.wb.islong};
+  process_rows<1>(d.wb.As, g, e, lds);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    d.flags[F_DONE] = 1; d.flags[F_ITERS] = 1;
+    d.flags[F_STAT_SUM] += 1; d.flags[F_STAT_SUMSQ] += 1; d.flags[F_STAT_N] += 1;
+    if (d.flags[F_STAT_MAX] < 1) d.flags[F_STAT_MAX] = 1;
+  }
+}
 __global__ void k_wb_seq(double *g, int r) { for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < r; a += gridDim.x * blockDim.x) g[a] = 1.0 + 0.25 * (a % 7); }
 
 }  // namespace
@@ -392,7 +485,16 @@ void wb_apply(Dev &d, int parity, int direct) {
   LAUNCH(k_wb_p3, d, d, parity, direct);
 }
 
-bool wb_large_supported() { return true; }      // (own kernels: dense_hip.hip; the vendor route needs the libraries, checked where it is asked for)
+bool wb_large_supported() { return true; }
+void wbf_iteration(Dev &d) {
+  LAUNCH(k_wbf_r, d, d);
+  hipLaunchKernelGGL(k_wbf_beta, dim3((d.m + kBlock - 1) / kBlock), dim3(kBlock), 0, st(d), d);
+  LAUNCH(k_wbf_g, d, d);
+  hipLaunchKernelGGL(k_wbd_gemv, dim3(std::min(d.wb.cd, 8 * kGrid)), dim3(kBlock), 0, st(d), d);
+  LAUNCH(k_wbf_t, d, d);
+  hipLaunchKernelGGL(k_wbf_x, dim3(std::min((d.n + kBlock - 1) / kBlock, kGrid)), dim3(kBlock), 0, st(d), d);
+  LAUNCH(k_wbf_s, d, d);
+}      // (own kernels: dense_hip.hip; the vendor route needs the libraries, checked where it is asked for)
 
 // D0, W, S = W W' + 1 / rho_L, S^-1 -- all on the device (r up to kWbLargeMax); then the two numerical checks
 static void wb_factor_large(Dev &d) {

@@ -59,6 +59,7 @@ int slot_seq(Dev &) { return 0; }
 void slot_poll(Dev &, int *seq, int *done) { *seq = 0; *done = 0; }
 void f1_refresh(Dev &) {}
 bool kf_supported() { return false; }
+void wbf_iteration(Dev &) {}
 void kf_values(Dev &, int) {}
 bool wb_supported() { return false; }
 bool wb_large_supported() { return false; }

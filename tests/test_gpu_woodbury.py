@@ -340,3 +340,32 @@ def test_column_space_form_with_several_singletons_per_row():
           (r.info.iter, s['pcg_iters_total'] / r.info.iter, s['woodbury_rows'], s['woodbury_dual_cols'], s['woodbury_direct'], _rel(r.x, xo), _rel(r.y, yo)))
     assert s['woodbury_rows'] == ns and s['woodbury_dual_cols'] == nf and s['woodbury_direct'] == 1
     assert _rel(r.x, xo) < 5e-6 and _rel(r.y, yo) < 2e-5
+
+
+def test_fused_column_space_iteration_equals_the_unfused_one():
+    """backend.h DevWb::fused: the ADMM iteration of the column-space direct mode as seven launches that stream the dense block twice (no KB / KA launch)
+    against the unfused sequence KB, five M^-1 launches, KA (OSQP_HIP_WOODBURY_FUSED=0): the same iteration in another order of operations -- equal
+    iteration counts, x / y to 1e-9, both equal to the oracle; warm-started re-solve and polish go through the same kernels."""
+    P, q, A, l, u = problems.lasso_qp(300, 600)
+    xo, yo, io = Oracle().setup(P, q, A, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000).solve()
+    out = {}
+    for name, env in (('fused', {'OSQP_HIP_WOODBURY_FUSED': '1'}), ('unfused', {'OSQP_HIP_WOODBURY_FUSED': '0'})):
+        with _env(**env):
+            m = osqp_amd.OSQP()
+            m.setup(P, q, A, l, u, eps_abs=1e-8, eps_rel=1e-8, verbose=False, max_iter=50000, polishing=True)
+            r = m.solve(raise_error=True)
+            out[name] = (m, r, m._solver.hip_stats())
+    (mf, rf, sf), (mu, ru, su) = out['fused'], out['unfused']
+    assert sf['woodbury_fused_iteration'] == 1 and su['woodbury_fused_iteration'] == 0 and sf['woodbury_dual_cols'] == su['woodbury_dual_cols'] == 300
+    print('fused %d iterations (%d launches), unfused %d (%d); |dx| %.2e |dy| %.2e; vs oracle %.2e' % (rf.info.iter, sf['kernel_launches'], ru.info.iter, su['kernel_launches'], _rel(rf.x, ru.x), _rel(rf.y, ru.y), _rel(rf.x, xo)))
+    assert rf.info.iter == ru.info.iter and rf.info.status_polish == ru.info.status_polish
+    assert _rel(rf.x, ru.x) < 1e-9 and _rel(rf.y, ru.y) < 1e-8
+    assert _rel(rf.x, xo) < 5e-6 and _rel(rf.y, yo) < 2e-5
+    # a parametric re-solve on the fused handle: new q / bounds, warm start
+    rng = np.random.default_rng(1)
+    q2 = q * (1 + 0.1 * rng.standard_normal(len(q)))
+    with _env(OSQP_HIP_WOODBURY_FUSED='1'):
+        mf.update(q=q2); mf.update_settings(warm_starting=True)
+        r2 = mf.solve(raise_error=True)
+    x2, y2, i2 = Oracle().setup(P, q2, A, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000).solve()
+    assert _rel(r2.x, x2) < 5e-6 and abs(r2.info.obj_val - i2.obj_val) <= 1e-6 * (1 + abs(i2.obj_val))
