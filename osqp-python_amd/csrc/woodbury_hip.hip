@@ -356,16 +356,20 @@ __global__ __launch_bounds__(kBlock) void k_wbf_beta(Dev d) {                // 
     w.cc[i] = c;
   }
 }
-struct EWbfG {                                             // dense columns: g_C = [sigma x - q - (P + sigma I) x_g]_C + A_C' cc
+// (one sum, single product buffer: 16 KB of LDS and <= 64 registers -- EIGHT workgroups per CU, launched as 2 kGrid workgroups: these two passes stream
+//  the 400 MB dense block; with four workgroups per CU the bytes in flight per CU did not cover the memory latency: 115 us per pass)
+struct GWbf1 { const double *xg, *cc; int n; __device__ __forceinline__ void operator()(int c, double a, double (&pr)[1]) const { pr[0] = c < n ? -(a * xg[c]) : a * cc[c - n]; } };
+struct EWbfG1 {
   const int *kind, *colmap; const double *x, *q; double *gc; double sigma; double px = 0, pq = 0;
   __device__ __forceinline__ void prefetch(int j) { px = x[j]; pq = q[j]; }
-  __device__ __forceinline__ void operator()(int j, const double (&s)[2]) { if (kind[j] == 1) gc[colmap[j]] = sigma * px - pq - s[0] + s[1]; }
+  __device__ __forceinline__ void operator()(int j, const double (&s)[1]) { if (kind[j] == 1) gc[colmap[j]] = sigma * px - pq + s[0]; }
 };
+constexpr int kWbfGrid = 2 * kGrid;
 __global__ __launch_bounds__(kBlock) void k_wbf_g(Dev d) {
-  __shared__ StreamLds<2> lds;
-  GWbf g{d.xg, d.wb.cc, nullptr, d.n};
-  EWbfG e{d.wb.kind, d.wb.colmap, d.x, d.q, d.wb.g, d.sigma};
-  process_rows<2>(d.wb.Bd, g, e, lds);
+  __shared__ StreamLds<1, 1> lds;
+  GWbf1 g{d.xg, d.wb.cc, d.n};
+  EWbfG1 e{d.wb.kind, d.wb.colmap, d.x, d.q, d.wb.g, d.sigma};
+  process_rows<1>(d.wb.Bd, g, e, lds);
 }
 // the z / y update of one constraint row from z~_i (_osqp.py:682-703), the next PCG start's A x_g by linearity and what the next right-hand side reads (as pcg_hip.hip EKa)
 struct WbfRowUpd {
@@ -389,7 +393,7 @@ struct EWbfT : NoPrefetch {                                // dense row a: rho_a
   }
 };
 __global__ __launch_bounds__(kBlock) void k_wbf_t(Dev d) {
-  __shared__ StreamLds<1> lds;
+  __shared__ StreamLds<1, 1> lds;
   GVec g{d.wb.uz};
   EWbfT e{{}, d.wb.beta, d.wb.wv, d.wb.sig, d.wb.rt, d.wb.rows, WbfRowUpd{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.ztg, d.alpha, d.theta}};
   process_rows<1>(d.wb.AL, g, e, lds);
@@ -489,9 +493,9 @@ bool wb_large_supported() { return true; }
 void wbf_iteration(Dev &d) {
   LAUNCH(k_wbf_r, d, d);
   hipLaunchKernelGGL(k_wbf_beta, dim3((d.m + kBlock - 1) / kBlock), dim3(kBlock), 0, st(d), d);
-  LAUNCH(k_wbf_g, d, d);
+  hipLaunchKernelGGL(k_wbf_g, dim3(kWbfGrid), dim3(kBlock), 0, st(d), d);
   hipLaunchKernelGGL(k_wbd_gemv, dim3(std::min(d.wb.cd, 8 * kGrid)), dim3(kBlock), 0, st(d), d);
-  LAUNCH(k_wbf_t, d, d);
+  hipLaunchKernelGGL(k_wbf_t, dim3(kWbfGrid), dim3(kBlock), 0, st(d), d);
   hipLaunchKernelGGL(k_wbf_x, dim3(std::min((d.n + kBlock - 1) / kBlock, kGrid)), dim3(kBlock), 0, st(d), d);
   LAUNCH(k_wbf_s, d, d);
 }      // (own kernels: dense_hip.hip; the vendor route needs the libraries, checked where it is asked for)
