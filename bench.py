@@ -324,9 +324,12 @@ def measure_roofline(s, stats, n, mm, args):
             G = (n + 63) // 64
             wb_bytes = 2 * G * 128 * 64 * 8 + 8 * n * 12 + 8 * mm * 8          # both tiles as stored (zero-padded to 128 rows) + the n- and m-vector passes of X and Y
             ms_it = s.hip_time_kernel(20, max(50, args.probe_reps))
-            name = 'Woodbury direct mode, one ADMM iteration = k_wbx_y + k_wbx_x (two launches)'
-            probes = {name: {'ms': ms_it, 'ms_same_kernel_repeat': ms_it, 'bytes': wb_bytes, 'GBps': wb_bytes / (ms_it * 1e-3) / 1e9, 'launches': 2}}
-            dom, dom_kernel = name, 'k_wbx_x'
+            one = int(stats.get('woodbury_one_launch', 0))
+            if one:      # one launch per ADMM iteration: the tile of A_L once (no S^-1 A_L tile), S^-1 (128 x 128 padded) per workgroup, the vector passes
+                wb_bytes = G * 128 * 64 * 8 + G * 128 * 128 * 8 + 8 * n * 12 + 8 * mm * 8
+            name = 'Woodbury direct mode, one ADMM iteration = ONE launch (k_wbz: fold of g, h = S^-1 g from registers, long rows, own columns, next right-hand side)' if one else 'Woodbury direct mode, one ADMM iteration = k_wbx_y + k_wbx_x (two launches)'
+            probes = {name: {'ms': ms_it, 'ms_same_kernel_repeat': ms_it, 'bytes': wb_bytes, 'GBps': wb_bytes / (ms_it * 1e-3) / 1e9, 'launches': 1 if one else 2}}
+            dom, dom_kernel = name, ('k_wbz' if one else 'k_wbx_x')
         else:
             nzL = nnzA                                                         # (the long rows carry nearly all of A in this form)
             cd = int(stats.get('woodbury_dual_cols', 0))                       # column-space form: the dense system is cd x cd (OSQPHipPolicy::woodbury_dual)

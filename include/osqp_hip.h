@@ -201,6 +201,7 @@ typedef struct {
   double f1_far_columns;      /* F1 form with per-block mixing: far columns (spill slots) over all row blocks of A (0: every block fits its window) */
   double woodbury_dual_cols;  /* device-factorised Woodbury form in column space (OSQPHipPolicy::woodbury_dual): order of its dense system = dense columns (0: row space) */
   double woodbury_fused_iteration; /* 1: the column-space direct mode runs its ADMM iteration fused -- seven launches, the dense block of A streamed twice instead of four times (no KB / KA launch) */
+  double woodbury_one_launch; /* 1: the Woodbury direct mode of a few dense rows runs ONE launch per ADMM iteration (k_wbz; woodbury_direct = 2 and OSQPHipPolicy::woodbury_fused = 1) */
   double kform_nnz;           /* K form: stored entries of the explicit reduced matrix K = P + sigma I + A' diag(rho) A (0: the form is not in use) */
 } OSQPHipStats;
 /* OSQPHipStats::preconditioner.  `cg_precond = OSQP_DIAGONAL_PRECONDITIONER` (bindings.cpp.in:426, the reference's only preconditioner) selects the
@@ -358,8 +359,10 @@ typedef struct {
                                  measured after every factorisation stays below this (default 1e-6: every linear solve then reduces its residual a
                                  millionfold -- orders beyond any tolerance the PCG would have been asked for; r03 demanded 1e-9, which the Woodbury
                                  identity misses at 5k x 10k by a factor 4-40)                                                        [setup] */
-  OSQPInt woodbury_fused;     /* the Woodbury direct mode as TWO launches per ADMM iteration where it applies (P diagonal, one-entry short rows,
-                                 n <= 16384; wbdirect_hip.hip) instead of five                                                      [setup] */
+  OSQPInt woodbury_fused;     /* 1 (default): the Woodbury direct mode in its fused forms where they apply -- a few dense rows (P diagonal, one-entry short rows,
+                                 n <= 16384; wbdirect_hip.hip): ONE launch per ADMM iteration (round 6; rounds 3-5: two); many dense rows in column space: seven
+                                 launches that stream the dense block twice (woodbury_hip.hip wbf_iteration).  2: the two-launch form of rounds 3-5 (A/B runs);
+                                 0: KB, the kernels of M^-1, KA                                                                                    [setup] */
   OSQPInt debug_fail_refactor; /* TEST HOOK: that many of the next device-side inversions of the Woodbury system report "inaccurate" (exercises the
                                  hand-over of a device-driven direct-mode solve to the host); 0 in production */
   OSQPInt reorder;            /* 1 (default): when the one-launch PCG form does not apply to the matrices as numbered by the caller, look for a

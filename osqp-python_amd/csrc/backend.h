@@ -167,6 +167,15 @@ struct DevWbx {
   double *tile = nullptr;                 // [G][kWbMaxRows][kWbxCols] A_L by column block, zero where A_L has no entry (rows >= r unused)
   double *partG = nullptr, *partZ = nullptr;   // [G][kWbMaxRows] partial sums of the two reductions
   double *ls0 = nullptr, *ls1 = nullptr;  // [3 r] {z, y, z~} of the long rows: read by X from ls0, written by X (workgroup 0) to ls1, handed over by Y
+  // ONE launch per ADMM iteration (one = 1; wbdirect_hip.hip k_wbz; round 6).  The second global reduction of the two-launch form is not needed:
+  //   z~_L = A_L x~ = A_L x_g + A_L D0^-1 r_0 - (A_L D0^-1 A_L') S^-1 g = A_L x_g + g - (S - diag(1 / rho_L)) h = A_L x_g + h ./ rho_L ,   h = S^-1 g,
+  // and A_L x_g is carried along by linearity (Dev::ztg) -- so a launch folds the previous launch's partials of g, forms h with S^-1 held in registers
+  // (sinvp: rows padded to kWbMaxRows, loaded at the head of the launch), updates the long rows, its own columns and one-entry rows, builds the next
+  // right-hand side and leaves the next partials of g.  The partials alternate between partG and partZ, the long rows' state {z, y, z~, A x_g}
+  // between lz0 and lz1, by the parity of the launch (no workgroup reads what its own launch writes).
+  int one = 0;
+  double *sinvp = nullptr;                // [kWbMaxRows][kWbMaxRows] S^-1, zero-padded (wbx_factor)
+  double *lz0 = nullptr, *lz1 = nullptr;  // [4 kWbMaxRows] {z, y, z~, A x_g} of the long rows
   int *sc_ptr = nullptr, *sc_row = nullptr, *sc_src = nullptr;   // per column: its one-entry rows (CSR over columns) and where their values sit in A.val
   double *sc_val = nullptr;
   double *bjj = nullptr;                  // [n] P_jj + sigma (the diagonal of B), refreshed with the tiles

@@ -40,7 +40,7 @@ void policy_from_env(OSQPHipPolicy &p, bool runtime_only) {
     for (int k = 1; k <= 5; k++) if (!std::strcmp(e, names[k])) p.batch_variant = k;
   }
   if (runtime_only) return;
-  on("OSQP_HIP_WOODBURY_FUSED", p.woodbury_fused); real("OSQP_HIP_WOODBURY_DIRECT_TOL", p.woodbury_direct_tol);
+  num("OSQP_HIP_WOODBURY_FUSED", p.woodbury_fused); real("OSQP_HIP_WOODBURY_DIRECT_TOL", p.woodbury_direct_tol);
   on("OSQP_HIP_WOODBURY", p.woodbury); on("OSQP_HIP_WOODBURY_DIRECT", p.woodbury_direct); on("OSQP_HIP_WOODBURY_LARGE", p.woodbury_large);
   num("OSQP_HIP_REORDER", p.reorder); on("OSQP_HIP_WOODBURY_CACHE", p.woodbury_cache); on("OSQP_HIP_KFORM", p.kform); on("OSQP_HIP_WOODBURY_DUAL", p.woodbury_dual); on("OSQP_HIP_WOODBURY_VENDOR", p.woodbury_vendor);
   on("OSQP_HIP_GRAPH", p.graph); on("OSQP_HIP_SLOTS", p.slots); on("OSQP_HIP_PCG_FUSED", p.pcg_fused); num("OSQP_HIP_F1", p.f1); on("OSQP_HIP_WINDOW", p.window);
@@ -157,7 +157,7 @@ void Engine::free_all() {
                   d_.dy, d_.xs, d_.xg, d_.xsp, d_.ztg, d_.zt, d_.t0, d_.v, d_.r, d_.uu, d_.p, d_.s, d_.w, d_.t, d_.Minv, d_.uu2, d_.ms, d_.part, d_.res,
                   d_.scal, d_.flags, d_.slot, d_.Praw, d_.Araw, d_.cs, d_.Pi, d_.Pj, d_.Pm1, d_.Pm2, d_.Ai, d_.Aj, d_.AmA, d_.AmB,
                   d_.wb.AL.rowptr, d_.wb.AL.col, d_.wb.AL.blkdesc, d_.wb.AL.runinfo, d_.wb.AL.val, d_.wb.ALT.rowptr, d_.wb.ALT.col, d_.wb.ALT.blkdesc, d_.wb.ALT.runinfo, d_.wb.ALT.val,
-                  d_.wb.al_src, d_.wb.alt_src, d_.wb.islong, d_.wb.rows, d_.wb.WT, d_.wb.S, d_.wb.Sinv, d_.wb.g, d_.wb.h, d_.wb.Dinv0, d_.wb.colmap, d_.wb.W, d_.wb.pv, d_.wb.info, d_.wb.dbg, d_.wb.x.tile, d_.wb.x.tile2, d_.wb.x.partG, d_.wb.x.partZ, d_.wb.x.ls0, d_.wb.x.ls1, d_.wb.x.sc_ptr, d_.wb.x.sc_row, d_.wb.x.sc_src, d_.wb.x.sc_val, d_.wb.x.bjj,
+                  d_.wb.al_src, d_.wb.alt_src, d_.wb.islong, d_.wb.rows, d_.wb.WT, d_.wb.S, d_.wb.Sinv, d_.wb.g, d_.wb.h, d_.wb.Dinv0, d_.wb.colmap, d_.wb.W, d_.wb.pv, d_.wb.info, d_.wb.dbg, d_.wb.x.tile, d_.wb.x.tile2, d_.wb.x.partG, d_.wb.x.partZ, d_.wb.x.ls0, d_.wb.x.ls1, d_.wb.x.lz0, d_.wb.x.lz1, d_.wb.x.sinvp, d_.wb.x.sc_ptr, d_.wb.x.sc_row, d_.wb.x.sc_src, d_.wb.x.sc_val, d_.wb.x.bjj,
                   d_.ctl, d_.f1.blk, d_.f1.stream, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.va, d_.f1.fcol, d_.f1.fq, d_.f1.sp_ptr, d_.f1.spk, d_.f1.spill, d_pc_, d_pr_,
                   d_.wb.gjwork, d_.wb.cc, d_.wb.sig, d_.wb.lidx, d_.wb.Bd.blkdesc, d_.wb.Bn.blkdesc, d_.wb.As.blkdesc, d_.wb.kind, d_.wb.dcol, d_.wb.srow, d_.wb.ssrc, d_.wb.sval, d_.wb.sg_ptr, d_.wb.sg_col, d_.wb.wv, d_.wb.den, d_.wb.beta, d_.wb.wbeta, d_.wb.rt, d_.wb.uz,
                   d_.kf.K.rowptr, d_.kf.K.col, d_.kf.K.blkdesc, d_.kf.K.runinfo, d_.kf.K.val, d_.kf.tptr, d_.kf.trow, d_.kf.ta, d_.kf.tb, d_.kf.rec};
@@ -388,7 +388,7 @@ void Engine::run_chunk(int niter, int budget) {
       be::ka(d_, budget);
     }
   };
-  stats_.kernel_launches += xy ? 2.0 * niter + 1 : (double)niter * ((wb && d_.wb.exact) ? (d_.wb.dual ? 7 : 5) : (fused ? 3 + 2 * budget : 2 + 3 * budget + (wb ? 3 * (budget + 1) : 0)));
+  stats_.kernel_launches += xy ? ((d_.wb.x.one && !d_.wb.x.slots) ? niter + 1.0 : 2.0 * niter + 1) : (double)niter * ((wb && d_.wb.exact) ? (d_.wb.dual ? 7 : 5) : (fused ? 3 + 2 * budget : 2 + 3 * budget + (wb ? 3 * (budget + 1) : 0)));
   if (!(use_graph_ && be::graphs_supported())) { enqueue(niter); return; }
   // one executable graph per (ADMM iterations, PCG budget); graphs are kept below kMaxGraphNodes kernel nodes (a
   // check_termination = 0 solve would otherwise capture max_iter * (2 + 3*budget) nodes in one graph)

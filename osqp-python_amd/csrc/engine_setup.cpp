@@ -524,6 +524,8 @@ void Engine::prepare_wb(const std::vector<int> &Arp, const std::vector<int> &Arj
       x.tile2 = dev_vec<double>(d_, (size_t)x.G * kWbMaxRows * kWbxCols);
       x.partG = dev_vec<double>(d_, (size_t)x.G * kWbMaxRows); x.partZ = dev_vec<double>(d_, (size_t)x.G * kWbMaxRows);
       x.ls0 = dev_vec<double>(d_, 3 * (size_t)kWbMaxRows); x.ls1 = dev_vec<double>(d_, 3 * (size_t)kWbMaxRows);
+      x.lz0 = dev_vec<double>(d_, 4 * (size_t)kWbMaxRows); x.lz1 = dev_vec<double>(d_, 4 * (size_t)kWbMaxRows); x.sinvp = dev_vec<double>(d_, (size_t)kWbMaxRows * kWbMaxRows);
+      x.one = pol_.woodbury_fused == 1 ? 1 : 0;          // (OSQPHipPolicy::woodbury_fused = 2: the two-launch form of rounds 3-5, for A/B runs)
       x.sc_ptr = up_i(sc_ptr); x.sc_row = up_i(sc_row); x.sc_src = up_i(sc_src); x.sc_val = dev_vec<double>(d_, sc_row.size());
       x.bjj = dev_vec<double>(d_, n);
       be::wbx_init(d_);

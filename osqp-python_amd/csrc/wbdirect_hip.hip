@@ -86,16 +86,17 @@ __device__ __forceinline__ void tile_store(const TileRegs &t, int r, double *dst
 // out[a] = sum over the workgroups' partials part[w][a]: thread (row pair, slice s of four) takes the workgroups w = s mod 4 with 16-byte
 // loads, kFoldBatch of them in flight; the four slices are added in index order (fixed order throughout: deterministic)
 constexpr int kFoldBatch = 20;
+template <int kFB = kFoldBatch>
 __device__ __forceinline__ void fold_partials(const double *part, int G, XLds &L, double *out) {
   const int a2 = threadIdx.x & (kR / 2 - 1), s = threadIdx.x >> 6;
   const double2 *p2 = reinterpret_cast<const double2 *>(part);
   double acc0 = 0.0, acc1 = 0.0;
-  for (int w0 = s; w0 < G; w0 += 4 * kFoldBatch) {
-    double2 p[kFoldBatch];
+  for (int w0 = s; w0 < G; w0 += 4 * kFB) {
+    double2 p[kFB];
 #pragma unroll
-    for (int k = 0; k < kFoldBatch; k++) p[k] = p2[(size_t)min(w0 + 4 * k, G - 1) * (kR / 2) + a2];
+    for (int k = 0; k < kFB; k++) p[k] = p2[(size_t)min(w0 + 4 * k, G - 1) * (kR / 2) + a2];
 #pragma unroll
-    for (int k = 0; k < kFoldBatch; k++) { const bool ok = w0 + 4 * k < G; acc0 += ok ? p[k].x : 0.0; acc1 += ok ? p[k].y : 0.0; }
+    for (int k = 0; k < kFB; k++) { const bool ok = w0 + 4 * k < G; acc0 += ok ? p[k].x : 0.0; acc1 += ok ? p[k].y : 0.0; }
   }
   L.red[s][a2] = acc0; L.pz4[s][a2] = acc1;                  // (red: even rows, pz4: odd rows; kC = kR / 2 slots per slice)
   __syncthreads();
@@ -166,6 +167,7 @@ __device__ __forceinline__ void wbx_x_body(const Dev &d, XLds &L) {
       const int i = d.wb.rows[tid];
       w = d.v[i] - d.t0[i];
       if (blockIdx.x == 0) { x.ls1[3 * tid] = d.z[i]; x.ls1[3 * tid + 1] = d.y[i]; x.ls1[3 * tid + 2] = d.zt[i]; }
+      if (blockIdx.x == 0 && x.one) { x.lz0[4 * tid] = d.z[i]; x.lz0[4 * tid + 1] = d.y[i]; x.lz0[4 * tid + 2] = d.zt[i]; x.lz0[4 * tid + 3] = d.ztg[i]; }      // (one-launch form: what its first launch reads)
     }
     L.wv[tid] = w;
   }
@@ -253,6 +255,103 @@ __global__ __launch_bounds__(kT) void k_wbx_y(Dev d) {
   wbx_y_body(d, *reinterpret_cast<YLds *>(smem));
 }
 
+// Z: ONE launch per ADMM iteration (backend.h DevWbx::one).  par: parity of the launch in its chunk -- partials of g are read from (par ? partZ : partG)
+// and written to the other, the long rows' state is read from (par ? lz1 : lz0) and written to the other.  RHS = false: the chunk's last launch.
+struct ZLds : XLds { double hv[kR]; };
+struct SinvRegs { double2 v[kR / 4]; };                      // thread (row a = tid mod kR, half = tid / kR): 64 entries of row a of S^-1
+__device__ __forceinline__ SinvRegs sinv_issue(const double *sinvp) {
+  const int a = threadIdx.x & (kR - 1), hf = threadIdx.x >> 7;
+  const double2 *src = reinterpret_cast<const double2 *>(sinvp + (size_t)a * kR + hf * (kR / 2));
+  SinvRegs s;
+#pragma unroll
+  for (int u = 0; u < kR / 4; u++) s.v[u] = src[u];
+  return s;
+}
+template <bool RHS>
+__device__ __forceinline__ void wbz_body(const Dev &d, ZLds &L, const int par) {
+  const DevWbx &x = d.wb.x;
+  const int tid = threadIdx.x, r = d.wb.r, G = x.G, j0 = blockIdx.x * kC, n = d.n;
+  const double *pin = par ? x.partZ : x.partG; double *pout = par ? x.partG : x.partZ;
+  const double *lin = par ? x.lz1 : x.lz0; double *lout = par ? x.lz0 : x.lz1;
+  const TileRegs tr = tile_issue(x.tile, r);                  // requested first: consumed after the fold
+  const SinvRegs sr = sinv_issue(x.sinvp);
+  const int c = tid & (kC - 1), q = tid >> 6, j = j0 + c;
+  const bool own = q == 0 && j < n;
+  double rj = 0.0, dj = 0.0, xgj = 0.0, xj = 0.0, xspj = 0.0, qj = 0.0, bjj = 0.0;
+  if (own) { rj = d.r[j]; dj = d.wb.Dinv0[j]; xgj = d.xg[j]; xj = d.x[j]; xspj = d.xsp[j]; if (RHS) { qj = d.q[j]; bjj = x.bjj[j]; } }
+  fold_partials(pin, G, L, L.gv);                             // g (rows >= r: zero partials)
+  { // h = S^-1 g: two half rows per row, S^-1 from registers, g broadcast from LDS
+    const int a = tid & (kR - 1), hf = tid >> 7;
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < kR / 4; u++) { acc0 += sr.v[u].x * L.gv[hf * (kR / 2) + 2 * u]; acc1 += sr.v[u].y * L.gv[hf * (kR / 2) + 2 * u + 1]; }
+    L.pz[hf][a] = acc0 + acc1;
+  }
+  __syncthreads();
+  if (tid < kR) {                                             // the long rows, identically in every workgroup (workgroup 0 stores)
+    double w = 0.0, h = 0.0;
+    if (tid < r) {
+      h = L.pz[0][tid] + L.pz[1][tid];
+      const int i = d.wb.rows[tid];
+      const RowState in{lin[4 * tid], lin[4 * tid + 1], lin[4 * tid + 2]};
+      const double ztil = lin[4 * tid + 3] + h * d.rho_inv[i];      // z~ = A x_g + h / rho
+      RowState out;
+      w = row_update(d, i, ztil, in, out, blockIdx.x == 0);
+      if (blockIdx.x == 0) { lout[4 * tid] = out.z; lout[4 * tid + 1] = out.y; lout[4 * tid + 2] = out.zt; lout[4 * tid + 3] = ztil + d.theta * (ztil - in.zt); }
+    }
+    L.wv[tid] = w; L.hv[tid] = h;
+  }
+  tile_store(tr, r, L.tile);
+  __syncthreads();                                            // tile, wv, hv
+  const double s = column_pass(L, L.tile, L.hv);              // (A_L' h) on the own columns
+  double ssum = 0.0, xn = xj, xgn = xgj;
+  if (own) {
+    const double u = dj * (rj - s), xt = xgj + u;             // x~ = x_g + D0^-1 (r_0 - A_L' h)
+    d.xs[j] = xt; d.uu[j] = u;
+    xn = d.alpha * xt + (1.0 - d.alpha) * xj;                 // :664-668
+    d.dx[j] = xn - xj; d.x[j] = xn;
+    xgn = xt + d.theta * (xt - xspj); d.xg[j] = xgn; d.xsp[j] = xt;
+    // (tried: the long rows' and the first one-entry row's constants and state requested at the head, under the fold's round trips: 11.8 -> 12.3 us;
+    //  all 160 partials of the fold in flight at once: scratch, 11.9 us -- the launch is bound by its barriers and the fold's two round trips)
+    for (int k = x.sc_ptr[j]; k < x.sc_ptr[j + 1]; k++) {
+      const int i = x.sc_row[k]; const double av = x.sc_val[k];
+      const RowState in{d.z[i], d.y[i], d.zt[i]};
+      RowState out;
+      const double w = row_update(d, i, av * xt, in, out, true);
+      if (RHS) ssum += av * w;
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) {                          // PCG statistics of the finished iteration: one exact step
+    d.flags[F_STAT_SUM] += 1; d.flags[F_STAT_SUMSQ] += 1; d.flags[F_STAT_N] += 1;
+    if (d.flags[F_STAT_MAX] < 1) d.flags[F_STAT_MAX] = 1;
+    d.flags[F_DONE] = 1; d.flags[F_ITERS] = 1;
+  }
+  if (!RHS) return;
+  __syncthreads();                                            // (column_pass reuses its partial buffer)
+  const double lsum = column_pass(L, L.tile, L.wv);           // (A_L' (v - t0)) on the own columns
+  if (q == 0) {
+    double yv = 0.0;
+    if (j < n) {
+      const double r0 = d.sigma * xn - qj - bjj * xgn + ssum + lsum;
+      d.r[j] = r0; yv = dj * r0;
+    }
+    L.col[c] = yv;
+  }
+  __syncthreads();
+  row_pass(L, pout);
+}
+template <bool RHS>
+__global__ __launch_bounds__(kT) void k_wbz(Dev d, int par) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  wbz_body<RHS>(d, *reinterpret_cast<ZLds *>(smem), par);
+}
+// sinvp <- S^-1, rows padded to kR (after every inversion of S)
+__global__ __launch_bounds__(kT) void k_wbz_pad(Dev d, int cond) {
+  if (cond && !d.ctl->rho_flag) return;
+  const int r = d.wb.r;
+  for (int e = blockIdx.x * kT + threadIdx.x; e < kR * kR; e += gridDim.x * kT) { const int a = e / kR, b = e - a * kR; d.wb.x.sinvp[e] = (a < r && b < r) ? d.wb.Sinv[(size_t)a * r + b] : 0.0; }
+}
+
 // Slot forms (device-side scheduling, pcg_hip.hip "slot kernels"): the same two launches as a pair of slots.  X reads record A and
 // writes record B, Y the other way round; P_KB = an iteration may start (right-hand side), P_K1 = Y is due, P_KA = Y has run, the
 // update is pending.  A chunk of N iterations takes N + 1 pairs (the last X only updates, the last Y passes the record on); launches
@@ -331,6 +430,7 @@ void wbx_factor(Dev &d, int cond) {            // after S^-1 has changed (rho up
   if (!d.wb.on || !d.wb.x.on) return;
   WBX_CHECK(hipSetDevice(d.device));
   hipLaunchKernelGGL(k_wbx_t2, dim3(d.wb.x.G), dim3(kT), sizeof(XLds), static_cast<hipStream_t>(d.stream), d, cond);
+  if (d.wb.x.one) hipLaunchKernelGGL(k_wbz_pad, dim3(16), dim3(kT), 0, static_cast<hipStream_t>(d.stream), d, cond);
   WBX_CHECK(hipGetLastError());                // (these kernels need 75-142 KB of dynamic LDS, granted by wbx_init: a refused launch must not pass silently)
 }
 void wbx_slot_pair(Dev &d) {
@@ -349,9 +449,11 @@ void wbx_init(Dev &d) {                        // (more than the default 64 KB o
   WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_t2), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_y), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(YLds)));
   WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_slot_x), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbz<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZLds)));
+  WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbz<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ZLds)));
   WBX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wbx_slot_y), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(YLds)));
 }
-// One chunk of `niter` ADMM iterations:  X(rhs), { Y, X(update + rhs) } x (niter - 1), Y, X(update)  -- 2 niter + 1 launches
+// One chunk of `niter` ADMM iterations:  X(rhs), { Y, X(update + rhs) } x (niter - 1), Y, X(update)  -- 2 niter + 1 launches (two-launch form)
 void wbx_chunk(Dev &d, int niter) {
   if (niter <= 0) return;
   WBX_CHECK(hipSetDevice(d.device));
@@ -359,6 +461,12 @@ void wbx_chunk(Dev &d, int niter) {
   const size_t lds = sizeof(XLds);
   const dim3 grid(d.wb.x.G), block(kT);
   hipLaunchKernelGGL((k_wbx_x<false, true>), grid, block, lds, s, d);
+  if (d.wb.x.one && !d.wb.x.slots) {             // one launch per ADMM iteration: X(rhs), Z x (niter - 1), Z(last) -- niter + 1 launches
+    for (int it = 1; it < niter; it++) hipLaunchKernelGGL((k_wbz<true>), grid, block, sizeof(ZLds), s, d, (it - 1) & 1);
+    hipLaunchKernelGGL((k_wbz<false>), grid, block, sizeof(ZLds), s, d, (niter - 1) & 1);
+    WBX_CHECK(hipGetLastError());
+    return;
+  }
   for (int it = 1; it < niter; it++) {
     hipLaunchKernelGGL(k_wbx_y, grid, block, sizeof(YLds), s, d);
     hipLaunchKernelGGL((k_wbx_x<true, true>), grid, block, lds, s, d);
