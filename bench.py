@@ -55,13 +55,24 @@ def pmc_traffic(kernel, workload):
     this workload (same generator, same size) is present -- a figure measured on another problem size is not reported."""
     import csv
     import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('pcg_hip.hip', 'hip_common.h'):
+        with open(os.path.join(ROOT, 'osqp-python_amd', 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    sha = h.hexdigest()[:16]
     vals = {}
     for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
         files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_%s_%s.csv' % (workload, ctr))))
         if not files:
             return None
+        rows = list(csv.DictReader(open(files[-1])))
+        # a summary is used only if it was taken of THESE kernel sources (profiles/summarize_pmc.py stamps the hash of pcg_hip.hip + hip_common.h as its
+        # last row): counters of an earlier state of the kernel are not reported as this run's traffic
+        if not any(r['kernel'] == '__source__' and r['counter'] == sha for r in rows):
+            return None
         # (templated kernels appear with their arguments -- k_f1_probe<4> --, some rocprofv3 builds add the parameter list: match the bare name)
-        for row in csv.DictReader(open(files[-1])):
+        for row in rows:
             bare = row['kernel'].split('(')[0].split('<')[0].split(' ')[-1].split('::')[-1]
             if bare == kernel and row['counter'] == ctr and float(row['active_dispatches']) > 0:
                 vals[ctr] = float(row['mean_active'])

@@ -2,9 +2,22 @@
 """Aggregate a rocprofv3 --pmc counter_collection CSV per kernel: mean counter value per dispatch, split into 'active'
 dispatches and early-exit (no-op) ones by a duration-free criterion (counter value above 1% of the kernel's max)."""
 import csv
+import hashlib
+import os
 import re
 import collections
 import sys
+
+
+def source_sha16():
+    """what the counters describe: the hot-path kernel sources as they are in this tree (bench.py pmc_traffic refuses a summary taken of other code)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ('pcg_hip.hip', 'hip_common.h'):
+        with open(os.path.join(root, 'osqp-python_amd', 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
 
 path, out = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -24,4 +37,5 @@ with open(out, 'w') as g:
             mx = max(v)
             act = [x for x in v if x > 0.01 * mx] if mx > 0 else []
             g.write('%s,%s,%d,%.6g,%d,%.6g,%.6g\n' % (k, c, len(v), sum(v) / len(v), len(act), (sum(act) / len(act)) if act else 0.0, mx))
+    g.write('__source__,%s,0,0,0,0,0\n' % source_sha16())      # (last row: which kernel sources were measured)
 print(open(out).read())
