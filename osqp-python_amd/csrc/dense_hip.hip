@@ -15,7 +15,7 @@
 //                   A_k: = R, A_kk = P.  All of the n^3 work is dense_gemm; 2 n^3 flops (no use of symmetry), ~6 launches per block step.
 //                   Measured (MI355X, round 6): the GEMM forms the lasso's systems at 40 TFLOP/s (order 5 000, inner dimension 10 000: 12 ms) and 54 TFLOP/s
 //                   (order 10 000, inner 15 000: 55 ms; rocBLAS: 8.4 / 43 ms); the inverse takes 28.5 ms at order 5 000 and 121 ms at 10 000 (rocSOLVER
-//                   potrf + potri: 23 / 84 ms) -- bound by the serial pivot block and ~500 dependent launches, not by the matrix cores.  Block steps of 128
+//                   potrf + potri: 23 / 84 ms) with the pivot block inverted in LDS (221 us per block: 17.5 of the 28.5 ms) -- see k_gj_pivot for its register form.  Block steps of 128
 //                   columns: 30.6 / 103 ms (the 128-step pivot chain costs what the halved traffic of the rank update saves at order 5 000).
 //                   Accuracy: Gauss-Jordan without pivoting loses about three digits against the Cholesky route on an ill-conditioned system (row-space S of
 //                   the lasso at rho = 0.1: |M^-1 K v - v| 2.5e-6 against 5e-9) -- the correction is then used as a preconditioner only (the direct mode
@@ -101,26 +101,40 @@ __global__ __launch_bounds__(256) void k_dgemm(GemmArgs g) {
 }
 
 constexpr int kGjNb = 64;
-// P = (A_kk)^-1 by Gauss-Jordan elimination in LDS, no pivoting; the smallest pivot seen goes to info (<= 0 or NaN: not positive definite)
+// P = (A_kk)^-1 by Gauss-Jordan elimination, no pivoting; the smallest pivot seen goes to minpiv (<= 0 or NaN: not positive definite).
+// The 64 x 64 block lives in REGISTERS: thread (column j = tid mod 64, row group g = tid / 64) holds rows g, g + 4, .. of its column; a step publishes
+// row k and column k through LDS (two buffers alternating by the parity of k: ONE barrier per step) and every thread updates its sixteen
+// elements (row k's register is picked by a select chain: the compiler refuses to unroll all 64 steps).  A block of fewer than 64 columns is padded
+// with the identity.  (First version: the block in LDS, sixteen elements per thread addressed through an integer division, two barriers per step --
+// 221 us per block, 17.5 of the 28.5 ms of an inversion of order 5 000: profiles/r06k_lasso_kernel_stats_before_pivot.csv.)
 __global__ __launch_bounds__(256) void k_gj_pivot(const double *A, long ld, int k0, int nb, double *P, double *minpiv) {
-  __shared__ double M[kGjNb * (kGjNb + 1)], rowk[kGjNb], colk[kGjNb];
-  __shared__ double pmin;
-  const int tid = threadIdx.x, S = kGjNb + 1;
-  for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e - i * nb; M[i * S + j] = A[(long)(k0 + i) * ld + k0 + j]; }
-  if (tid == 0) pmin = 1e300;
-  __syncthreads();
-  for (int k = 0; k < nb; k++) {
-    const double p = M[k * S + k], pi = 1.0 / p;
-    if (tid < nb) { rowk[tid] = tid == k ? pi : M[k * S + tid] * pi; colk[tid] = M[tid * S + k]; }
-    if (tid == 0 && !(p >= pmin)) pmin = p;
-    __syncthreads();
-    for (int e = tid; e < nb * nb; e += 256) {
-      const int i = e / nb, j = e - i * nb;
-      M[i * S + j] = i == k ? rowk[j] : (j == k ? -colk[i] * pi : M[i * S + j] - colk[i] * rowk[j]);
+  static_assert(kGjNb == 64, "thread layout: 64 columns x 4 row groups");
+  __shared__ double rowb[2][kGjNb], colb[2][kGjNb];
+  const int tid = threadIdx.x, j = tid & 63, g = tid >> 6;
+  double m[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) { const int i = g + 4 * q; m[q] = (i < nb && j < nb) ? A[(long)(k0 + i) * ld + k0 + j] : (i == j ? 1.0 : 0.0); }
+  double pmin = 1e300;
+#pragma unroll 4
+  for (int k = 0; k < kGjNb; k++) {
+    const int b = k & 1, gk = k & 3, qk = k >> 2;
+    if (g == gk) rowb[b][j] = m[qk];
+    if (j == k) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) colb[b][g + 4 * q] = m[q];
     }
     __syncthreads();
+    const double p = rowb[b][k], pi = 1.0 / p;
+    if (!(p >= pmin)) pmin = p;                            // (a NaN pivot is kept)
+    const double rk = (j == k) ? pi : rowb[b][j] * pi;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const double ck = colb[b][g + 4 * q];
+      m[q] = (g == gk && q == qk) ? rk : ((j == k) ? -ck * pi : m[q] - ck * rk);
+    }
   }
-  for (int e = tid; e < nb * nb; e += 256) { const int i = e / nb, j = e - i * nb; P[i * kGjNb + j] = M[i * S + j]; }
+#pragma unroll
+  for (int q = 0; q < 16; q++) { const int i = g + 4 * q; if (i < nb && j < nb) P[i * kGjNb + j] = m[q]; }
   if (tid == 0 && !(pmin >= *minpiv)) *minpiv = pmin;
 }
 // Ck (n x 64, row-major) <- the column panel A[:, k0 .. k0 + nb) with the rows of block k zeroed
