@@ -383,6 +383,9 @@ typedef struct {
   OSQPInt woodbury_vendor;    /* 0 (default): the dense system of the device-factorised Woodbury form is formed and inverted by this engine's own kernels on the fp64 matrix
                                  cores (dense_hip.hip: a strided MFMA GEMM + block Gauss-Jordan inversion); 1: rocBLAS dgemm + rocSOLVER dpotrf / dpotri, loaded on
                                  demand (the route of rounds 3-5, kept for A/B runs; without the libraries osqp_setup falls back to plain Jacobi)            [setup] */
+  OSQPInt batch_wave;         /* batch solves in the spectral form: 1 = one WAVE per problem, eight problems in flight per CU (batch_hip.hip k_batch_wave); 0 (default)
+                                 = one workgroup per problem.  Opt-in: measured slower end to end on the MPC batch (a problem's own latency is 4-6x higher on one
+                                 wave, and a batch ends with its slowest problem -- DESIGN.md section 8) */
 } OSQPHipPolicy;
 void    osqp_hip_default_policy(OSQPHipPolicy *policy);
 OSQPInt osqp_hip_set_policy(OSQPSolver *solver, const OSQPHipPolicy *policy);

@@ -361,7 +361,19 @@ struct BatchParams {
   int mat_on = 0, nprod = 0;
   double *Aval_b = nullptr, *Bval_b = nullptr, *D_b = nullptr, *Dinv_b = nullptr, *E_b = nullptr, *Einv_b = nullptr, *c_b = nullptr, *kp_val_b = nullptr;
   const int *kp_a = nullptr, *kp_b = nullptr;   // per product: positions of A_ia, A_ib in A.val (the products are formed per problem)
+  // ONE WAVE PER PROBLEM, spectral form (batch_hip.hip k_batch_wave; built by Engine::prepare_batch_wave).  A workgroup of kBatchWaveW waves keeps V and
+  // the shared matrices' values in LDS once for all of them; a wave keeps its problem's iterates in registers, rows spread over the lanes: row r of A' (and
+  // of every n-vector) belongs to lane r % 64, slot r / 64; the rows of A are sorted by length (descending) first and the sorted position decides
+  // lane and slot (wv_row: position -> row, -1 = none), so that the rows one ELL step treats together have similar lengths.  ELL steps of a group of 64 rows:
+  // [wv_aend[g - 1], wv_aend[g]); entry (step s, lane l): value A.val[wv_Aidx[s 64 + l]] (index -1: padding, value 0), column wv_Acol[s 64 + l].
+  // A' the same over B's entries with column >= n (wv_Tcol = the constraint ROW, original numbering).
+  int wv_on = 0;
+  int wv_aend[4] = {0, 0, 0, 0}, wv_tend[2] = {0, 0};
+  const int *wv_Aidx = nullptr, *wv_Acol = nullptr, *wv_Tidx = nullptr, *wv_Tcol = nullptr, *wv_row = nullptr;
+  int *wv_queue = nullptr;       // device counter: the next position of the launch order not yet taken by a wave (zeroed before the launch)
 };
+constexpr int kBatchWaveW = 8;          // waves (= problems in flight) per workgroup of the wave-per-problem kernel; one workgroup per CU
+constexpr int kBatchWaveSA = 32, kBatchWaveST = 24;   // ELL steps of A / A' the kernel has registers for
 constexpr int kBatchSpecN = 128;        // the spectral form keeps K^-1 in registers: row i = thread / 2, 64 columns per thread
 constexpr double kBatchUnsolved = -1000.0;
 
@@ -372,6 +384,7 @@ size_t batch_lds_bytes(int n, int m);                       // 0 if a problem do
 int batch_solve(Dev &d, const BatchParams &p, void *stream = nullptr);
 size_t batch_direct_lds_bytes(int n, int m, int nnz, int bw); // 0 if the banded factor does not fit next to the iterates
 bool batch_direct_selected(const BatchParams &p);              // would batch_solve run a direct (banded LDL') variant for p?
+size_t batch_wave_lds_bytes(int n, int m, int steps);          // LDS of the wave-per-problem kernel (V + `steps` ELL steps of values + one staging vector per wave); 0: does not fit
 void batch_products(Dev &d, int nprod, const int *a, const int *b, double *out);   // out[p] = A.val[a[p]] * A.val[b[p]]
 // per-problem matrices: Px_b [nbatch][nnz(P as given at setup: upper triangle, CSC order)] / Ax_b [nbatch][nnz(A), CSC order], UNSCALED, device
 // pointers; nullptr = the solver's own values for every problem.  Fills p.Aval_b .. p.kp_val_b (allocated by the caller) on `stream` (nullptr: d.stream).

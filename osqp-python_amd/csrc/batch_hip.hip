@@ -12,6 +12,7 @@
 // /root/reference/src/osqppurepy/_osqp.py.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -914,6 +915,378 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? (SPEC ? SP
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- one WAVE per problem, spectral form
+// k_batch_admm gives a problem a whole workgroup -- and, in its spectral form, the whole register file of a CU for K^-1: ONE problem in flight per CU,
+// 3.7 us per ADMM iteration of which the dense product is 0.6 (profiles/r06_batch_trace.txt).  Here a problem is ONE WAVE and a CU runs kBatchWaveW of
+// them at once, with what they share kept once:
+//   * V (the batch's common eigenvectors, engine.hpp BatchSpectral) in LDS, row-major with an odd row stride -- 116 KB at n = 120.  A solve is
+//     x~ = V (d . (V' rhs)),  d_k = 1 / (1 + (rho - rho_ref) lambda_k):  two passes over V by the wave itself (lane k reads column k of row j for V' rhs --
+//     consecutive words; lane i reads row i for V t -- stride 121 doubles: conflict-free), the vector entries broadcast with v_readlane from the lane
+//     that owns them.  No K^-1 exists: a rho update is two divisions per lane (the workgroup kernel rebuilds K^-1 from V: ~20 us).
+//   * the matrices' values once in LDS as well, in ELL steps with one lane per row (BatchParams::wv_*: groups of 64 rows, A's rows sorted by length so
+//     that a step's rows are about equally long -- 26 KB for the MPC pattern); every wave keeps its lanes' column indices in registers (two per
+//     register) and gathers through one staged vector of its own in LDS.  (Values in registers -- 112 more per lane -- was the first form: 185 of them
+//     spilled at eight waves per CU.)
+//   * every iterate in registers (n <= 128: two slots per lane, m <= 256: four); reductions are DPP moves + v_readlane.  No barrier after the prologue:
+//     a wave takes the next position of the launch order from a device counter when its problem is done (longest-expected problems first, as before).
+// Same arithmetic as k_batch_admm's direct path up to the order of the sums (FMA chains per row here, products summed in entry order there; the two-stage
+// solve instead of K^-1 times rhs): iteration counts agree, iterates to ~1e-12 (tests/test_gpu_batch_wave.py).
+#ifdef OSQP_HIP_KTRACE
+#define WT_MARK(v) const unsigned long long v = wall_clock64()
+#define WT_ADD(acc, d) (acc += (d))
+#else
+#define WT_MARK(v) ((void)0)
+#define WT_ADD(acc, d) ((void)0)
+#endif
+template <int SA, int ST, int N8>
+__global__ __launch_bounds__(64 * kBatchWaveW, 1) void k_batch_wave(BatchParams P) {
+  static_assert(N8 % 8 == 0 && N8 <= kBatchSpecN, "rows / columns of V in LDS (n rounded up; zero beyond n): compile-time -- the dense products are straight-line code");
+  constexpr int S = N8 + 1;                            // row stride: odd (conflict-free column walks)
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int n = P.n, m = P.m, tid = threadIdx.x, L = tid & 63, wv = tid >> 6;
+  constexpr int n8 = N8;                               // (>= n: batch_solve picks the instantiation)
+  double *Vl = sm;
+  const int stg_len = ((n > m ? n : m) + 1) & ~1;
+  const int ae0 = P.wv_aend[0], ae1 = P.wv_aend[1], ae2 = P.wv_aend[2], ae3 = P.wv_aend[3], te0 = P.wv_tend[0], te1 = P.wv_tend[1];
+  double *eA = sm + (((size_t)n8 * S + 1) & ~(size_t)1), *eT = eA + (size_t)ae3 * 64;
+  double *stage = eT + (size_t)te1 * 64 + (size_t)wv * stg_len;
+  unsigned short *kA = reinterpret_cast<unsigned short *>(eT + (size_t)te1 * 64 + (size_t)kBatchWaveW * stg_len), *kT = kA + (size_t)ae3 * 64;
+  for (int e = tid; e < n8 * S; e += 64 * kBatchWaveW) Vl[e] = 0.0;
+  for (int e = tid; e < ae3 * 64; e += 64 * kBatchWaveW) { const int ix = P.wv_Aidx[e]; eA[e] = ix >= 0 ? P.A.val[ix] : 0.0; kA[e] = (unsigned short)P.wv_Acol[e]; }
+  for (int e = tid; e < te1 * 64; e += 64 * kBatchWaveW) { const int ix = P.wv_Tidx[e]; eT[e] = ix >= 0 ? P.B.val[ix] : 0.0; kT[e] = (unsigned short)P.wv_Tcol[e]; }
+  __syncthreads();
+  for (int e = tid; e < n * kBatchSpecN; e += 64 * kBatchWaveW) { const int k = e / kBatchSpecN, j = e % kBatchSpecN; if (j < n) Vl[j * S + k] = P.sp_V[e]; }      // V(j, k)
+  __syncthreads();                                       // (the last barrier of the kernel)
+  const DevCsr &B = P.B;
+  // ---- the matrices: ELL values and columns (16 bits) in LDS, one copy for the eight waves ----
+  int rowm[4]; bool vm[4], vn[2];
+#pragma unroll
+  for (int s = 0; s < 4; s++) { rowm[s] = (s * 64 + L < 256) ? P.wv_row[s * 64 + L] : -1; vm[s] = rowm[s] >= 0; if (!vm[s]) rowm[s] = 0; }
+#pragma unroll
+  for (int s = 0; s < 2; s++) vn[s] = s * 64 + L < n;
+  const int jn[2] = {min(L, n - 1), min(64 + L, n - 1)};          // (clamped: lanes without an element read a valid one and drop the result)
+  const double lam0 = P.sp_lam[jn[0]], lam1 = P.sp_lam[jn[1]];
+  auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+  auto wsum = [&](double v) { return readlane_f64(wsum63(v), 63); };
+  auto wmax = [&](double v) { return readlane_f64(wmax63(v), 63); };
+  auto stage_n = [&](const double (&v)[2]) {
+    wave_sync();
+#pragma unroll
+    for (int s = 0; s < 2; s++) if (vn[s]) stage[s * 64 + L] = v[s];
+    wave_sync();
+  };
+  auto stage_m = [&](const double (&v)[4]) {
+    wave_sync();
+#pragma unroll
+    for (int s = 0; s < 4; s++) if (vm[s]) stage[rowm[s]] = v[s];
+    wave_sync();
+  };
+  // out[slot] = (A v)_row for the n-vector v staged in LDS
+  auto mulA = [&](double (&out)[4]) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+    for (int h = 0; h < SA; h += 8) {
+      if (h < ae3) {
+        double pv[8], av[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) { const bool on = h + s < ae3; pv[s] = stage[on ? kA[(h + s) * 64 + L] : 0]; av[s] = on ? eA[(h + s) * 64 + L] : 0.0; }
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+          const int g = h + s;
+          if (g < ae0) a0 = fma(av[s], pv[s], a0); else if (g < ae1) a1 = fma(av[s], pv[s], a1); else if (g < ae2) a2 = fma(av[s], pv[s], a2); else if (g < ae3) a3 = fma(av[s], pv[s], a3);
+        }
+      }
+    }
+    out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
+  };
+  // out[slot] = (A' w)_j for the m-vector w staged in LDS (original row numbering)
+  auto mulT = [&](double (&out)[2]) {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int h = 0; h < ST; h += 8) {
+      if (h < te1) {
+        double pv[8], av[8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) { const bool on = h + s < te1; pv[s] = stage[on ? kT[(h + s) * 64 + L] : 0]; av[s] = on ? eT[(h + s) * 64 + L] : 0.0; }
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+          const int g = h + s;
+          if (g < te0) a0 = fma(av[s], pv[s], a0); else if (g < te1) a1 = fma(av[s], pv[s], a1);
+        }
+      }
+    }
+    out[0] = a0; out[1] = a1;
+  };
+  // out[slot] = ((P + sigma I) v)_j for the n-vector staged in LDS: B's entries with column < n, from memory (residuals and certificates only)
+  auto mulP = [&](double (&out)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      double a = 0.0;
+      if (vn[s]) { const int j = s * 64 + L; for (int k = B.rowptr[j]; k < B.rowptr[j + 1]; k++) { const int c = B.col[k]; if (c < n) a = fma(B.val[k], stage[c], a); } }
+      out[s] = a;
+    }
+  };
+  // The two dense products of a solve, x~ = V (d . (V' rhs)), fully unrolled, straight-line code (the size n8 of the LDS copy is a template parameter): every
+  // LDS offset and every v_readlane lane index is then an immediate -- per step one or two reads, two v_readlane, two FMAs.  (First form: a runtime loop,
+  // indices in registers: a v_add per read, an s_add + wait states per v_readlane -- 2 250 instructions per solve, 10 of an iteration's 23 us with eight
+  // waves per CU.  Rows / columns n .. n8 of the LDS copy are zero.)
+  // (Every block of eight steps sits behind a uniform branch on an OPAQUE copy of n8: the branch is never taken, but it keeps the compiler from treating a
+  //  product as one straight line -- it then hoists all 240 reads and the v_readlanes in front of the FMAs and spills 500 - 1 000 registers, with or
+  //  without scheduling barriers between hand-pipelined blocks: 12.5 ms per batch instead of 4.9.)
+  // w = V' rhs: lane = column k (and k + 64), step = row j;  rhs_j from lane j % 64 of rhs[j / 64]
+  auto vt_mul = [&](const double (&rhs)[2], double &o0, double &o1) {
+    const double *vc = Vl + L;
+    int n8r = N8;
+    asm volatile("" : "+s"(n8r));
+    double a0[2] = {0.0, 0.0}, a1[2] = {0.0, 0.0};
+#pragma unroll
+    for (int j0 = 0; j0 < N8; j0 += 8) {
+      if (j0 < n8r) {
+        double va[8], vb[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) { va[jj] = vc[(j0 + jj) * S]; vb[jj] = vc[(j0 + jj) * S + 64]; }
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) { const double r = readlane_f64(rhs[j0 >> 6], (j0 & 63) + jj); a0[jj & 1] = fma(va[jj], r, a0[jj & 1]); a1[jj & 1] = fma(vb[jj], r, a1[jj & 1]); }
+      }
+    }
+    o0 = a0[0] + a0[1]; o1 = a1[0] + a1[1];
+  };
+  // x = V t: lane = row i (and i + 64), step = column k
+  auto v_mul = [&](double t0, double t1, double &o0, double &o1) {
+    const double *vr0 = Vl + jn[0] * S, *vr1 = Vl + jn[1] * S;
+    int n8r = N8;
+    asm volatile("" : "+s"(n8r));
+    double a0[2] = {0.0, 0.0}, a1[2] = {0.0, 0.0};
+#pragma unroll
+    for (int k0 = 0; k0 < N8; k0 += 8) {
+      if (k0 < n8r) {
+        double va[8], vb[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) { va[kk] = vr0[k0 + kk]; vb[kk] = vr1[k0 + kk]; }
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) { const double r = readlane_f64(k0 < 64 ? t0 : t1, (k0 & 63) + kk); a0[kk & 1] = fma(va[kk], r, a0[kk & 1]); a1[kk & 1] = fma(vb[kk], r, a1[kk & 1]); }
+      }
+    }
+    o0 = a0[0] + a0[1]; o1 = a1[0] + a1[1];
+  };
+  auto ksolve = [&](const double (&rhs)[2], double dk0, double dk1, double (&out)[2]) {
+    double w0, w1;
+    vt_mul(rhs, w0, w1);
+    v_mul(vn[0] ? dk0 * w0 : 0.0, vn[1] ? dk1 * w1 : 0.0, out[0], out[1]);
+  };
+  const bool unsc = P.unscaled != 0;
+  bool first = true;
+
+  while (true) {
+    // ---- the next problem of the launch order ----
+    // The first problem of a wave is position (wave index) x (workgroups) + (workgroup): the longest-expected problems land one per CU.  Later ones
+    // come from the device counter.  (EVERY lane adds one -- the compiler folds that into a single atomic per wave -- and the counter runs in units of
+    //  64.  The obvious form, lane 0 alone behind `if (L == 0)`, hangs: the loop is then compiled with a second version for the lanes that never run the
+    //  atomic, whose position stays 0.)
+    int pos;
+    if (first) { pos = __builtin_amdgcn_readfirstlane(wv) * (int)gridDim.x + (int)blockIdx.x; first = false; }
+    else pos = (int)gridDim.x * kBatchWaveW + (__builtin_amdgcn_readfirstlane(atomicAdd(P.wv_queue, 1)) >> 6);
+    if (pos >= P.nbatch) break;
+    const int b = P.order ? P.order[pos] : pos;
+    double x[2], q[2], dx[2], xs[2], z[4], y[4], l[4], u[4], dy[4];
+    int ty[4];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const int j = jn[s];
+      q[s] = vn[s] ? P.c * P.D[j] * (P.q ? P.q[(size_t)b * n + j] : P.q0[j]) : 0.0;
+      x[s] = (vn[s] && P.warm) ? P.x[(size_t)b * n + j] * P.Dinv[j] : 0.0; dx[s] = 0.0; xs[s] = 0.0;
+    }
+    double n_ineq_l = 0.0, mism = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int i = rowm[s];
+      const double li = P.E[i] * fmax(P.l ? P.l[(size_t)b * m + i] : P.l0[i], -OSQP_INFTY), ui = P.E[i] * fmin(P.u ? P.u[(size_t)b * m + i] : P.u0[i], OSQP_INFTY);
+      l[s] = vm[s] ? li : 0.0; u[s] = vm[s] ? ui : 0.0;
+      y[s] = (vm[s] && P.warm) ? P.y[(size_t)b * m + i] * P.Einv[i] * P.c : 0.0; dy[s] = 0.0; z[s] = 0.0;
+      int t_ = (li < -OSQP_INFTY * 1e-4 && ui > OSQP_INFTY * 1e-4) ? -1 : ((ui - li < 1e-4) ? 1 : 0);   // _osqp.py:505-518
+      if (!P.rho_is_vec) t_ = 0;
+      ty[s] = t_;
+      if (vm[s]) { n_ineq_l += (t_ == 0); if (t_ != P.sp_ctype[i]) mism = 1.0; }
+    }
+    const double n_ineq = wsum(n_ineq_l);
+    const double eqf = (n_ineq == 0.0) ? 1e3 : P.eq_factor_direct;                      // engine.cpp classify_constraints()
+    // V was built for ONE set of constraint classes: a problem whose own bounds give other classes (or another equality weight) is the banded kernel's
+    mism = wsum(mism) + (eqf != P.sp_eqf ? 1.0 : 0.0);
+    if (mism != 0.0) { if (L == 0) P.rec[(size_t)b * kBatchRec] = kBatchUnsolved; continue; }
+    double rho_bar = P.rho0, rho_eq = 0.0, dk0 = 0.0, dk1 = 0.0;
+    auto rho_of = [&](int s) { return ty[s] == -1 ? 1e-6 : (ty[s] == 1 ? rho_eq : rho_bar); };             // _osqp.py:520-522 (three values: not kept per row)
+    auto set_rho = [&](double rb) {
+      rho_eq = eqf * rb;
+      const double dl = rb - P.sp_rho_ref;
+      dk0 = 1.0 / (1.0 + dl * lam0); dk1 = 1.0 / (1.0 + dl * lam1);
+    };
+    set_rho(rho_bar);
+    // z = A x   (_osqp.py:1509 / cold start); a continued solve keeps its z iterate
+    stage_n(x);
+    mulA(z);
+    if (P.zs && P.warm) {
+#pragma unroll
+      for (int s = 0; s < 4; s++) if (vm[s]) z[s] = P.zs[(size_t)b * m + rowm[s]];
+    }
+    double pri_u = 0, ax_u = 0, z_u = 0, pri_s = 0, ax_s = 0, z_s = 0, dy_u = 0, dy_s = 0, pinf_lhs = 0, dua_u = 0, px_u = 0, aty_u = 0, dua_s = 0, px_s = 0, aty_s = 0,
+           dxn_u = 0, dxn_s = 0, xpx = 0, qx = 0, qdx = 0, qn_s = 0, qn_u = 0;
+    auto residuals = [&]() {
+      double a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0, s1 = 0;
+      stage_n(x);
+      double ax[4], sp[2], sa[2];
+      mulA(ax); mulP(sp);
+#pragma unroll
+      for (int s = 0; s < 4; s++) if (vm[s]) {
+        const int i = rowm[s];
+        const double pr = ax[s] - z[s], ei = P.Einv[i], dyi = dy[s];
+        a1 = nmax(a1, fabs(ei * pr)); a2 = nmax(a2, fabs(ei * ax[s])); a3 = nmax(a3, fabs(ei * z[s]));
+        a4 = nmax(a4, fabs(pr)); a5 = nmax(a5, fabs(ax[s])); a6 = nmax(a6, fabs(z[s]));
+        a7 = nmax(a7, fabs(P.E[i] * dyi)); a8 = nmax(a8, fabs(dyi));
+        s1 += u[s] * fmax(dyi, 0.0) + l[s] * fmin(dyi, 0.0);
+      }
+      pri_u = wmax(a1); ax_u = wmax(a2); z_u = wmax(a3); pri_s = wmax(a4); ax_s = wmax(a5); z_s = wmax(a6); dy_u = wmax(a7); dy_s = wmax(a8); pinf_lhs = wsum(s1);
+      stage_m(y);
+      mulT(sa);
+      double b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0, b8 = 0, b9 = 0, b10 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+      for (int s = 0; s < 2; s++) if (vn[s]) {
+        const int j = s * 64 + L;
+        const double px = sp[s] - P.sigma * x[s], dr = px + q[s] + sa[s], di = P.Dinv[j];
+        b1 = nmax(b1, fabs(di * dr)); b2 = nmax(b2, fabs(di * px)); b3 = nmax(b3, fabs(di * sa[s]));
+        b4 = nmax(b4, fabs(dr)); b5 = nmax(b5, fabs(px)); b6 = nmax(b6, fabs(sa[s]));
+        b7 = nmax(b7, fabs(P.D[j] * dx[s])); b8 = nmax(b8, fabs(dx[s])); b9 = nmax(b9, fabs(q[s])); b10 = nmax(b10, fabs(di * q[s]));
+        t1 += x[s] * px; t2 += q[s] * x[s]; t3 += q[s] * dx[s];
+      }
+      dua_u = wmax(b1); px_u = wmax(b2); aty_u = wmax(b3); dua_s = wmax(b4); px_s = wmax(b5); aty_s = wmax(b6); dxn_u = wmax(b7); dxn_s = wmax(b8); qn_s = wmax(b9); qn_u = wmax(b10);
+      xpx = wsum(t1); qx = wsum(t2); qdx = wsum(t3);
+    };
+    int status = OSQP_UNSOLVED, iter = 0, rho_updates = 0;
+    double obj = 0, prim_res = 0, dual_res = 0;
+#ifdef OSQP_HIP_KTRACE
+    unsigned long long tkT = 0, tkS = 0, tkA = 0, tkR = 0;
+#endif
+    WT_MARK(tk0);
+    if (P.max_iter <= 0) residuals();
+    while (true) {
+      iter++;
+      // ---- rhs = sigma x - q + A'(rho z - y);  x~ = K^-1 rhs   (_osqp.py:649-650, :307-311 in reduced form) ----
+      double t[4], rhs[2], sA[2];
+      WT_MARK(c0);
+#pragma unroll
+      for (int s = 0; s < 4; s++) t[s] = rho_of(s) * z[s] - y[s];
+      stage_m(t);
+      mulT(sA);
+      WT_MARK(c1); WT_ADD(tkT, c1 - c0);
+#pragma unroll
+      for (int s = 0; s < 2; s++) rhs[s] = vn[s] ? P.sigma * x[s] - q[s] + sA[s] : 0.0;
+      ksolve(rhs, dk0, dk1, xs);
+      WT_MARK(c2); WT_ADD(tkS, c2 - c1);
+      // ---- z~ = A x~; x, z, y update (_osqp.py:660-703) ----
+      stage_n(xs);
+      double zt[4];
+      mulA(zt);
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const double rh = rho_of(s), yi = y[s];
+        const double zr = P.alpha * zt[s] + (1.0 - P.alpha) * z[s];
+        const double zn = fmin(fmax(zr + yi / rh, l[s]), u[s]);
+        const double dyi = rh * (zr - zn);
+        y[s] = yi + dyi; dy[s] = dyi; z[s] = zn;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; s++) { const double xo = x[s], xn = P.alpha * xs[s] + (1.0 - P.alpha) * xo; dx[s] = xn - xo; x[s] = xn; }
+      WT_MARK(c3); WT_ADD(tkA, c3 - c2);
+      const bool at_check = (P.check > 0 && iter % P.check == 0) || iter >= P.max_iter;
+      const bool at_rho = P.rho_interval > 0 && iter % P.rho_interval == 0;
+      if (!at_check && !at_rho) continue;
+      WT_MARK(c4);
+      residuals();
+      WT_MARK(c5); WT_ADD(tkR, c5 - c4);
+      obj = (0.5 * xpx + qx) * (P.scaling ? P.cinv : 1.0);                               // _osqp.py:705-712
+      prim_res = m == 0 ? 0.0 : (unsc ? pri_u : pri_s);
+      dual_res = unsc ? P.cinv * dua_u : dua_s;
+      bool stop = false;
+      for (int approx = 0; approx < 2 && !stop && at_check; approx++) {                  // _osqp.py:998-1077, :1264-1266
+        if (approx && iter < P.max_iter) break;
+        const double f = approx ? 10.0 : 1.0;
+        const double ea = f * P.eps_abs, er = f * P.eps_rel, epi = f * P.eps_pinf, edi = f * P.eps_dinf;
+        if (prim_res > OSQP_INFTY || dual_res > OSQP_INFTY || prim_res != prim_res || dual_res != dual_res) { status = OSQP_NON_CVX; obj = NAN; stop = true; break; }
+        bool pri_ok = false, dua_ok = false, pinf = false, dinf = false;
+        if (m == 0) pri_ok = true;
+        else if (prim_res < ea + er * (unsc ? fmax(ax_u, z_u) : fmax(ax_s, z_s))) pri_ok = true;
+        else {                                                                          // is_primal_infeasible :796-820
+          const double nd = unsc ? dy_u : dy_s;
+          if (nd > epi && pinf_lhs < -epi * nd) {
+            double sa[2], mu = 0, ms = 0;
+            stage_m(dy); mulT(sa);
+#pragma unroll
+            for (int s = 0; s < 2; s++) if (vn[s]) { mu = nmax(mu, fabs(P.Dinv[s * 64 + L] * sa[s])); ms = nmax(ms, fabs(sa[s])); }
+            mu = wmax(mu); ms = wmax(ms);
+            pinf = (unsc ? mu : ms) < epi * nd;
+          }
+        }
+        const double mx = unsc ? P.cinv * fmax(fmax(aty_u, px_u), qn_u) : fmax(fmax(aty_s, px_s), qn_s);
+        if (dual_res < ea + er * mx) dua_ok = true;
+        else {                                                                          // is_dual_infeasible :822-878
+          const double nd = unsc ? dxn_u : dxn_s, sc = unsc ? P.c : 1.0;
+          if (nd > edi && qdx < -sc * edi * nd) {
+            double sp[2], mu = 0, ms = 0, viol = 0;
+            stage_n(dx); mulP(sp);
+#pragma unroll
+            for (int s = 0; s < 2; s++) if (vn[s]) { const double v = sp[s] - P.sigma * dx[s]; mu = nmax(mu, fabs(P.Dinv[s * 64 + L] * v)); ms = nmax(ms, fabs(v)); }
+            mu = wmax(mu); ms = wmax(ms);
+            if ((unsc ? mu : ms) < sc * edi * nd) {
+              double adx[4];
+              mulA(adx);
+#pragma unroll
+              for (int s = 0; s < 4; s++) if (vm[s]) {
+                double a = adx[s];
+                if (unsc) a *= P.Einv[rowm[s]];
+                if ((u[s] < OSQP_INFTY * 1e-4 && a > edi * nd) || (l[s] > -OSQP_INFTY * 1e-4 && a < -edi * nd)) viol += 1.0;
+              }
+              viol = wsum(viol);
+              dinf = viol == 0.0;
+            }
+          }
+        }
+        if (pri_ok && dua_ok) { status = approx ? OSQP_SOLVED_INACCURATE : OSQP_SOLVED; stop = true; }
+        else if (pinf) { status = approx ? OSQP_PRIMAL_INFEASIBLE_INACCURATE : OSQP_PRIMAL_INFEASIBLE; obj = OSQP_INFTY; stop = true; }
+        else if (dinf) { status = approx ? OSQP_DUAL_INFEASIBLE_INACCURATE : OSQP_DUAL_INFEASIBLE; obj = -OSQP_INFTY; stop = true; }
+      }
+      if (stop) break;
+      if (iter >= P.max_iter) { status = OSQP_MAX_ITER_REACHED; break; }
+      if (at_rho) {                                                                      // adapt_rho :880-930
+        const double pr = pri_s / (fmax(ax_s, z_s) + 1e-10), du = dua_s / (fmax(fmax(aty_s, px_s), qn_s) + 1e-10);
+        double rn_ = rho_bar * sqrt(pr / (du + 1e-10));
+        rn_ = fmin(fmax(rn_, 1e-6), 1e6);
+        if (rn_ > P.rho_tol * rho_bar || rn_ < rho_bar / P.rho_tol) { rho_bar = rn_; set_rho(rho_bar); rho_updates++; }
+      }
+    }
+    const double rho_est = fmin(fmax(rho_bar * sqrt((pri_s / (fmax(ax_s, z_s) + 1e-10)) / (dua_s / (fmax(fmax(aty_s, px_s), qn_s) + 1e-10) + 1e-10)), 1e-6), 1e6);
+    // ---- store: x = D x, y = cinv E y (_osqp.py:1110-1112); certificates in place of x / y for infeasible problems ----
+    const bool pinf = status == OSQP_PRIMAL_INFEASIBLE || status == OSQP_PRIMAL_INFEASIBLE_INACCURATE;
+    const bool dinf = status == OSQP_DUAL_INFEASIBLE || status == OSQP_DUAL_INFEASIBLE_INACCURATE;
+#pragma unroll
+    for (int s = 0; s < 2; s++) if (vn[s]) { const int j = s * 64 + L; P.x[(size_t)b * n + j] = dinf ? (unsc ? P.D[j] * dx[s] : dx[s]) : (pinf ? NAN : (P.scaling ? P.D[j] * x[s] : x[s])); }
+#pragma unroll
+    for (int s = 0; s < 4; s++) if (vm[s]) {
+      const int i = rowm[s];
+      if (P.zs) P.zs[(size_t)b * m + i] = z[s];
+      P.y[(size_t)b * m + i] = pinf ? (unsc ? P.E[i] * dy[s] : dy[s]) : (dinf ? NAN : (P.scaling ? P.cinv * P.E[i] * y[s] : y[s]));
+    }
+    if (L == 0) {
+      double *rc = P.rec + (size_t)b * kBatchRec;
+      rc[0] = status; rc[1] = iter; rc[2] = obj; rc[3] = prim_res; rc[4] = dual_res; rc[5] = rho_bar; rc[6] = rho_updates; rc[7] = 0.0;
+      rc[8] = 0.0; rc[9] = 0.0; rc[10] = rho_est; rc[11] = 0.0;
+#ifdef OSQP_HIP_KTRACE
+      rc[7] = (double)tkT; rc[8] = (double)tkS; rc[9] = (double)tkA; rc[11] = (double)tkR; rc[10] = (double)(wall_clock64() - tk0);      // 100 MHz ticks per phase (tools/batch_wave_probe.py)
+#endif
+      if (P.iters_out) P.iters_out[b] = iter;
+    }
+  }
+}
+
 }  // namespace
 
 // LDS needed per problem (bytes); 0 if the problem does not fit one workgroup's LDS.  nnz > 0 adds the product buffer of
@@ -1041,6 +1414,15 @@ BatchChoice choose_batch_variant(const BatchParams &p) {
 }
 }  // namespace
 bool batch_direct_selected(const BatchParams &p) { const BatchChoice c = choose_batch_variant(p); return c.dir256 || c.dir64; }
+// rows / columns of V in the wave kernel's LDS: compile-time, two instantiations (n <= 120: the MPC batch's 116 KB; n <= 128)
+static int batch_wave_n8(int n) { return n <= 120 ? 120 : 128; }
+size_t batch_wave_lds_bytes(int n, int m, int steps) {
+  if (n < 1 || n > kBatchSpecN || m < 1 || m > 256) return 0;
+  const size_t n8 = (size_t)batch_wave_n8(n), S = n8 + 1, stg = (size_t)((n > m ? n : m) + 1) & ~(size_t)1;
+  const size_t b = sizeof(double) * (((n8 * S + 1) & ~(size_t)1) + (size_t)steps * 64 + (size_t)kBatchWaveW * stg) + sizeof(unsigned short) * (size_t)steps * 64;
+  // (V t reads row min(64 + lane, n - 1) and V' rhs reads 64 words past a row's start: both stay inside V + staging)
+  return b <= 160 * 1024 ? b : 0;
+}
 
 int batch_solve(Dev &d, const BatchParams &p, void *stream) {
   if (hipSetDevice(d.device) != hipSuccess) return OSQP_ALGEBRA_LOAD_ERROR;
@@ -1061,7 +1443,7 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
   // reference's is solved by this launch; the others are marked and left to the banded kernel launched right behind (only_marked).
   bool spectral = false;
   const int prod_len = ((p.A.nnz > p.B.nnz ? p.A.nnz : p.B.nnz) + 1) & ~1;
-  if (use_dir256 && p.sp_V && !p.mat_on && !p.polish && p.n <= kBatchSpecN && e256 <= 8 && prod_len >= 4 * (kBatchSpecN + 2) && !p.only_marked) {
+  if (use_dir256 && p.sp_V && !p.wv_on && !p.mat_on && !p.polish && p.n <= kBatchSpecN && e256 <= 8 && prod_len >= 4 * (kBatchSpecN + 2) && !p.only_marked) {
     const size_t lds_spec = lds_reg + sizeof(double) * (kBatchNB + 2 * kBatchSpecN + 4);
     // (a device that refuses the LDS reservation of this instantiation keeps the banded launch below for the whole batch)
 #define BATCH_LAUNCH_SPEC_W(E, W) do { \
@@ -1079,6 +1461,20 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
     if (e256 <= 2) BATCH_LAUNCH_SPEC(2); else if (e256 <= 4) BATCH_LAUNCH_SPEC(4); else if (e256 <= 6) BATCH_LAUNCH_SPEC(6); else BATCH_LAUNCH_SPEC(8);
 #undef BATCH_LAUNCH_SPEC
 #undef BATCH_LAUNCH_SPEC_W
+  }
+  // ... one WAVE per problem where the engine has prepared that form (wv_on: large batches): eight problems in flight per CU
+  if (use_dir256 && p.sp_V && p.wv_on && !p.mat_on && !p.polish && !p.only_marked) {
+    const size_t lds_w = batch_wave_lds_bytes(p.n, p.m, p.wv_aend[3] + p.wv_tend[1]);
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d.device);
+    auto launch = [&](auto kern) {
+      if (!lds_w || hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w) != hipSuccess) { (void)hipGetLastError(); return; }
+      if (hipMemsetAsync(p.wv_queue, 0, sizeof(int), st) != hipSuccess) throw DeviceError("osqp_hip: batch queue reset failed");
+      const int wgs = std::min(cus, p.nbatch);            // (fewer problems than CUs: one wave per workgroup gets one)
+      hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * kBatchWaveW), lds_w, st, p);
+      spectral = true;
+    };
+    if (batch_wave_n8(p.n) == 120) launch(&k_batch_wave<kBatchWaveSA, kBatchWaveST, 120>); else launch(&k_batch_wave<kBatchWaveSA, kBatchWaveST, 128>);
   }
   BatchParams pm = p;
   if (spectral) pm.only_marked = 1;

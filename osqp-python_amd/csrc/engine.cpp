@@ -22,6 +22,7 @@ void policy_from_env(OSQPHipPolicy &p, bool runtime_only) {
   auto num = [](const char *name, OSQPInt &v) { if (const char *e = std::getenv(name)) v = std::atoi(e); };
   auto real = [](const char *name, OSQPFloat &v) { if (const char *e = std::getenv(name)) v = std::atof(e); };
   on("OSQP_HIP_SMALL_DIRECT", p.small_direct); num("OSQP_HIP_DEVICE_DRIVEN", p.device_driven); on("OSQP_HIP_BATCH_REORDER", p.batch_reorder);
+  num("OSQP_HIP_BATCH_WAVE", p.batch_wave);
   num("OSQP_HIP_RHO_WINDOW", p.rho_window); real("OSQP_HIP_RHO_WINDOW_TOL", p.rho_window_tol); on("OSQP_HIP_RHO_PERSIST", p.rho_persist);
   if (const char *e = std::getenv("OSQP_HIP_RHO_TOL_EXP")) { const double v = std::atof(e); p.rho_tol_exp = v > 0 && v <= 1 ? v : 0.5; }
   real("OSQP_HIP_BUDGET_TOLERATE", p.budget_tolerate); real("OSQP_HIP_BUDGET_SIGMA", p.budget_sigma); num("OSQP_HIP_BUDGET_SLACK", p.budget_slack);
@@ -60,7 +61,7 @@ void Engine::default_policy(OSQPHipPolicy *p) {
   p->polish_delta_floor = 1e-3; p->polish_pcg_tol = 1e-15; p->woodbury = 1; p->woodbury_direct = 1; p->woodbury_large = 1; p->woodbury_cache = 1;
   p->slot_poll = 1; p->poll_low = 6; p->poll_first = 0.8; p->poll_frac = 0.75; p->poll_wait = 0.7;
   p->finish_pairs = 12; p->poll_sleep_us = 30;
-  p->reorder = 1; p->kform = 0; p->woodbury_dual = 1; p->woodbury_vendor = 0; p->woodbury_fused = 1; p->woodbury_direct_tol = 1e-6; p->debug_fail_refactor = 0;
+  p->reorder = 1; p->kform = 0; p->woodbury_dual = 1; p->woodbury_vendor = 0; p->woodbury_fused = 1; p->woodbury_direct_tol = 1e-6; p->debug_fail_refactor = 0; p->batch_wave = 0;
 }
 void Engine::set_default_policy(const OSQPHipPolicy *p) {
   g_default_policy_set = p != nullptr;
@@ -70,7 +71,7 @@ int Engine::get_policy(OSQPHipPolicy *p) const { if (!p) return OSQP_DATA_VALIDA
 int Engine::set_policy(const OSQPHipPolicy *p) {
   if (!p) return OSQP_DATA_VALIDATION_ERROR;
   if (!(p->extrap >= 0 && p->extrap <= 2) || p->rho_window < 0 || !(p->rho_window_tol > 0) || !(p->rho_tol_exp > 0 && p->rho_tol_exp <= 1) ||
-      !(p->budget_sigma >= 0) || p->finish_pairs < 1 || p->batch_variant < 0 || p->batch_variant > 5 ||
+      !(p->budget_sigma >= 0) || p->finish_pairs < 1 || p->batch_variant < 0 || p->batch_variant > 5 || p->batch_wave < 0 || p->batch_wave > 1 ||
       !(p->rho_eq_factor == 0 || p->rho_eq_factor >= 1) || p->reorder < 0 || p->reorder > 2 || !(p->woodbury_direct_tol > 0 && p->woodbury_direct_tol < 1) || !(p->polish_delta_floor > 0) || !(p->polish_pcg_tol > 0 && p->polish_pcg_tol < 1))
     return OSQP_SETTINGS_VALIDATION_ERROR;
   const OSQPHipPolicy old = pol_;
@@ -149,7 +150,7 @@ void Engine::free_all() {
   if (d_batch_iters_) { be::dfree(d_, d_batch_iters_); d_batch_iters_ = nullptr; d_batch_iters_n_ = 0; }
   batch_order_.clear();
   if (ckpt_) { be::dfree(d_, ckpt_); ckpt_ = nullptr; }
-  free_batch_direct(); free_batch_spectral();
+  free_batch_direct(); free_batch_spectral(); free_batch_wave();
   if (d_.f1.va) d_.Minv = d_.xs = d_.p = d_.r = d_.s = nullptr;      // (these point into the F1 arena, freed as one block below)
   if (d_.wb.cache_buf[0]) d_.wb.Sinv = d_.wb.cache_buf[0];      // (Sinv may point at one of the cached inverses: buffer 0 is this list's, the others are the backend's)
   void *ptrs[] = {d_.A.rowptr, d_.A.col, d_.A.blkdesc, d_.A.val, d_.B.rowptr, d_.B.col, d_.B.blkdesc, d_.B.val, d_.Bdiag, d_.A.runinfo, d_.B.runinfo, d_.A.blkwin, d_.B.blkwin, d_.A.lcol, d_.B.lcol, d_.qraw, d_.lraw, d_.uraw, d_.cnt,

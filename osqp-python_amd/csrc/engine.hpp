@@ -122,6 +122,16 @@ class Engine {
     double *kp_val = nullptr;
   } bd_;
   void prepare_batch_direct();
+  // one wave per problem (backend.h BatchParams::wv_*, batch_hip.hip k_batch_wave): the ELL row layout of A (rows sorted by length) and A', built once per
+  // pattern; the values are read from the device matrices at every launch
+  struct BatchWave {
+    bool tried = false, ok = false;
+    int aend[4] = {0, 0, 0, 0}, tend[2] = {0, 0};
+    int *Aidx = nullptr, *Acol = nullptr, *Tidx = nullptr, *Tcol = nullptr, *row = nullptr, *queue = nullptr;
+  } bwv_;
+  void prepare_batch_wave();
+  void free_batch_wave();
+  void attach_batch_wave(BatchParams &p, int nbatch);
   // Spectral form of the batch path's direct solve (batch_hip.hip, SPEC): every problem of a batch shares P, A and the constraint classes, and
   // rho enters K only through ONE scalar -- K(rho) = K_ref + (rho - rho_ref) M1, M1 = A' W A (W: 1 on inequality rows, the equality weight on
   // equality rows).  With K_ref = L L', L^-1 M1 L^-T = Q Lambda Q' and V = L^-T Q:  K(rho)^-1 = V diag(1 / (1 + (rho - rho_ref) lambda)) V'.

@@ -290,6 +290,60 @@ void Engine::free_batch_direct() {
   bd_ = BatchDirect();
 }
 
+// ------------------------------------------------------------------------------------------------ batch path, one wave per problem
+// engine.hpp BatchWave / backend.h BatchParams::wv_*.  Rows of A sorted by length (descending, stable): sorted position p -> lane p % 64, slot p / 64; a group
+// of 64 positions takes as many ELL steps as its longest (= first) row has entries.  A' (B's entries with column >= n) in the natural order of the variables.
+void Engine::free_batch_wave() {
+  void *ptrs[] = {bwv_.Aidx, bwv_.Acol, bwv_.Tidx, bwv_.Tcol, bwv_.row, bwv_.queue};
+  for (void *p : ptrs) if (p) be::dfree(d_, p);
+  bwv_ = BatchWave();
+}
+void Engine::prepare_batch_wave() {
+  if (bwv_.tried) return;
+  bwv_.tried = true;
+  if (n < 1 || n > kBatchSpecN || m < 1 || m > 256 || reordered_) return;
+  std::vector<int> pos(m);
+  for (int i = 0; i < m; i++) pos[i] = i;
+  std::stable_sort(pos.begin(), pos.end(), [&](int a, int b) { return Arp_[a + 1] - Arp_[a] > Arp_[b + 1] - Arp_[b]; });
+  int aend[4] = {0, 0, 0, 0}, tend[2] = {0, 0}, acc = 0;
+  for (int g = 0; g < 4; g++) { if (g * 64 < m) { const int r = pos[g * 64]; acc += Arp_[r + 1] - Arp_[r]; } aend[g] = acc; }
+  if (acc > kBatchWaveSA) return;
+  std::vector<int> Aidx((size_t)std::max(acc, 1) * 64, -1), Acol((size_t)std::max(acc, 1) * 64, 0), row(256, -1);
+  for (int p = 0; p < m; p++) {
+    const int r = pos[p], lane = p % 64, g = p / 64, s0 = g ? aend[g - 1] : 0;
+    row[p] = r;
+    for (int k = Arp_[r]; k < Arp_[r + 1]; k++) { Aidx[(size_t)(s0 + k - Arp_[r]) * 64 + lane] = k; Acol[(size_t)(s0 + k - Arp_[r]) * 64 + lane] = Arj_[k]; }
+  }
+  int tacc = 0;
+  std::vector<int> tcnt(n, 0);
+  for (int j = 0; j < n; j++) for (int k = Brp_[j]; k < Brp_[j + 1]; k++) tcnt[j] += Bj_[k] >= n;
+  for (int g = 0; g < 2; g++) { int mx = 0; for (int j = g * 64; j < std::min(n, g * 64 + 64); j++) mx = std::max(mx, tcnt[j]); tacc += mx; tend[g] = tacc; }
+  if (tacc > kBatchWaveST) return;
+  std::vector<int> Tidx((size_t)std::max(tacc, 1) * 64, -1), Tcol((size_t)std::max(tacc, 1) * 64, 0);
+  for (int j = 0; j < n; j++) {
+    const int lane = j % 64, g = j / 64, s0 = g ? tend[g - 1] : 0;
+    int e = 0;
+    for (int k = Brp_[j]; k < Brp_[j + 1]; k++) if (Bj_[k] >= n) { Tidx[(size_t)(s0 + e) * 64 + lane] = k; Tcol[(size_t)(s0 + e) * 64 + lane] = Bj_[k] - n; e++; }
+  }
+  if (!be::batch_wave_lds_bytes(n, m, acc + tacc)) return;
+  auto up = [&](const std::vector<int> &v) { int *dptr = dev_vec<int>(d_, v.size()); be::h2d(d_, dptr, v.data(), sizeof(int) * v.size()); return dptr; };
+  bwv_.Aidx = up(Aidx); bwv_.Acol = up(Acol); bwv_.Tidx = up(Tidx); bwv_.Tcol = up(Tcol); bwv_.row = up(row);
+  bwv_.queue = dev_vec<int>(d_, 1);
+  for (int g = 0; g < 4; g++) bwv_.aend[g] = aend[g];
+  bwv_.tend[0] = tend[0]; bwv_.tend[1] = tend[1];
+  bwv_.ok = true;
+}
+// (behind attach_batch_direct: the form needs the spectral decomposition)
+void Engine::attach_batch_wave(BatchParams &p, int /*nbatch*/) {
+  if (!p.sp_V || pol_.batch_wave != 1 || p.mat_on || p.polish) return;      // (opt-in: OSQPHipPolicy::batch_wave)
+  prepare_batch_wave();
+  if (!bwv_.ok) return;
+  p.wv_on = 1;
+  for (int g = 0; g < 4; g++) p.wv_aend[g] = bwv_.aend[g];
+  p.wv_tend[0] = bwv_.tend[0]; p.wv_tend[1] = bwv_.tend[1];
+  p.wv_Aidx = bwv_.Aidx; p.wv_Acol = bwv_.Acol; p.wv_Tidx = bwv_.Tidx; p.wv_Tcol = bwv_.Tcol; p.wv_row = bwv_.row; p.wv_queue = bwv_.queue;
+}
+
 // ------------------------------------------------------------------------------------------------ batch path, spectral form of the direct solve
 // engine.hpp BatchSpectral.  Dense work on the host, n <= kBatchSpecN: the SCALED matrices (c D P D + sigma I, E A D: what the kernels hold) are
 // rebuilt from the host copies, K_ref and M1 assembled, K_ref = L L' (Cholesky), C = L^-1 M1 L^-T, C = Q Lambda Q' (cyclic Jacobi sweeps: C is
@@ -735,6 +789,7 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
   if (bd_.ok) {
     be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);             // A's values may have changed since the last call
     attach_batch_direct(p, nbatch >= kBatchSpectralMin && !Px && !Ax);
+    if (!Px && !Ax) attach_batch_wave(p, nbatch);
   }
   if (Px || Ax) { const int e2 = attach_batch_matrices(p, Px ? dPx : nullptr, Ax ? dAx : nullptr, nullptr); if (e2) return e2; }
   int err = be::batch_solve(d_, p);
@@ -790,6 +845,7 @@ int Engine::batch_solve_device(int nbatch, const double *q, const double *l, con
   if (bd_.ok) {
     be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);
     attach_batch_direct(p, nbatch >= kBatchSpectralMin && !Px && !Ax);
+    if (!Px && !Ax) attach_batch_wave(p, nbatch);
   }
   be::sync(d_);                                   // the uploads and the product refresh ran on the solver's stream
   if (Px || Ax) { const int e2 = attach_batch_matrices(p, Px, Ax, stream); if (e2) return e2; }      // (on the caller's stream, in front of the solve launch)

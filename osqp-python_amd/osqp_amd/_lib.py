@@ -66,7 +66,7 @@ class PolicyStruct(C.Structure):       # OSQPHipPolicy, include/osqp_hip.h (same
                  ('rho_tol_exp', C.c_double), ('budget_tolerate', C.c_double), ('budget_sigma', C.c_double), ('budget_slack', C.c_int), ('budget_full', C.c_int),
                  ('cg_escalate', C.c_int), ('stall', C.c_int), ('polish_delta_floor', C.c_double), ('polish_pcg_tol', C.c_double), ('slot_poll', C.c_int), ('poll_low', C.c_int), ('poll_first', C.c_double),
                  ('poll_frac', C.c_double), ('poll_wait', C.c_double), ('finish_pairs', C.c_int), ('poll_sleep_us', C.c_int),
-                 ('slot_log', C.c_int), ('setup_timing', C.c_int), ('batch_timing', C.c_int), ('woodbury_log', C.c_int), ('woodbury_direct_tol', C.c_double), ('woodbury_fused', C.c_int), ('debug_fail_refactor', C.c_int), ('reorder', C.c_int), ('woodbury_cache', C.c_int), ('kform', C.c_int), ('woodbury_dual', C.c_int), ('woodbury_vendor', C.c_int)])
+                 ('slot_log', C.c_int), ('setup_timing', C.c_int), ('batch_timing', C.c_int), ('woodbury_log', C.c_int), ('woodbury_direct_tol', C.c_double), ('woodbury_fused', C.c_int), ('debug_fail_refactor', C.c_int), ('reorder', C.c_int), ('woodbury_cache', C.c_int), ('kform', C.c_int), ('woodbury_dual', C.c_int), ('woodbury_vendor', C.c_int), ('batch_wave', C.c_int)])
 
 
 SolverP = C.POINTER(SolverStruct)

@@ -265,6 +265,7 @@ void project_normalcone(Dev &d) {
 size_t batch_lds_bytes(int, int) { return 0; }
 size_t batch_direct_lds_bytes(int, int, int, int) { return 0; }
 bool batch_direct_selected(const BatchParams &) { return false; }
+size_t batch_wave_lds_bytes(int, int, int) { return 0; }
 void batch_products(Dev &, int, const int *, const int *, double *) {}
 void batch_order(Dev &, int, const int *, int *, void *) {}
 int batch_prepare(Dev &, const BatchParams &, const double *, const double *, int, void *) { return OSQP_FUNC_NOT_IMPLEMENTED; }
