@@ -308,7 +308,21 @@ def main():
         waves_of_qps = -(-share // resident)
         t_iter = kernel_s / (waves_of_qps * iters_per_qp)              # wall time of one ADMM iteration of a resident QP
         floor_iter = (9 * 170 + 256) / 2.4e9
-        out['roofline'] = {'bound': 'latency', 'kernel': 'k_batch_admm<256,6,6,true,false,false,true,%d> (spectral direct solve)' % per_cu, 'unit': 'ADMM iter/s per resident QP',
+        split = int(s._solver.hip_stats().get('batch_wave_split', -1))
+        if split >= 0:
+            # the wave-per-problem kernel (batch_hip.hip k_batch_wave: V and the matrices in LDS once per CU, a problem = one wave, eight in flight per CU).  Its
+            # bound is VALU issue: a problem's solve is two dense n x n products by ONE wave -- 2 n^2 FMAs, each with its v_readlane broadcast and LDS read --
+            # and the ELL products; floor = the FMAs of the two products alone at the CU's fp64 rate (4 SIMDs x 16 lanes): 2 x 120^2 / 64 cycles per QP-iteration.
+            cus = 256
+            t_cu = kernel_s / (float(table[:, 2].sum()) / cus)            # CU time per (problem, ADMM iteration)
+            floor_cu = 2 * 120 * 120 / 64.0 / 2.4e9
+            out['roofline'] = {'bound': 'valu', 'kernel': 'k_batch_wave<32,24,120> (one wave per QP, eight QPs in flight per CU; the %d longest-expected QPs on k_batch_admm beside it)' % split,
+                               'unit': 'ADMM iter/s per CU', 'achieved': 1.0 / t_cu, 'peak': 1.0 / floor_cu, 'frac': floor_cu / t_cu, 'traffic': None,
+                               'model': 'fp64 FMAs of the two dense products of a solve (2 x 120^2) at 64 FMAs per cycle per CU = %.2f us per QP-iteration; measured %.2f us '
+                                        '(%.1f ADMM iterations per QP on average, kernel %.2f ms; ~4 500 wave instructions per QP-iteration: v_readlane broadcasts, LDS reads, ELL products, updates)'
+                                        % (1e6 * floor_cu, 1e6 * t_cu, iters_per_qp, 1e3 * kernel_s)}
+        else:
+          out['roofline'] = {'bound': 'latency', 'kernel': 'k_batch_admm<256,6,6,true,false,false,true,%d> (spectral direct solve)' % per_cu, 'unit': 'ADMM iter/s per resident QP',
                            'achieved': 1.0 / t_iter, 'peak': 1.0 / floor_iter, 'frac': floor_iter / t_iter, 'traffic': None,
                            'model': 'chain of 9 barrier-separated phases (LDS round trip + barrier ~170 cycles each) + 64 fp64 FMAs per thread of the dense product (256 issue cycles) '
                                     '= %.2f us per ADMM iteration at 2.4 GHz; measured %.2f us (%.1f ADMM iterations per QP on average, %d QPs resident at a time in %d round(s), kernel %.2f ms)'

@@ -203,6 +203,8 @@ typedef struct {
   double woodbury_fused_iteration; /* 1: the column-space direct mode runs its ADMM iteration fused -- seven launches, the dense block of A streamed twice instead of four times (no KB / KA launch) */
   double woodbury_one_launch; /* 1: the Woodbury direct mode of a few dense rows runs ONE launch per ADMM iteration (k_wbz; woodbury_direct = 2 and OSQPHipPolicy::woodbury_fused = 1) */
   double kform_nnz;           /* K form: stored entries of the explicit reduced matrix K = P + sigma I + A' diag(rho) A (0: the form is not in use) */
+  double batch_wave_split;    /* last batch solve: -1 = workgroup-per-problem kernels only; >= 0 = the wave-per-problem kernel ran, with this many of the
+                                 longest-expected problems on the workgroup kernel beside it (0: no launch order yet) */
 } OSQPHipStats;
 /* OSQPHipStats::preconditioner.  `cg_precond = OSQP_DIAGONAL_PRECONDITIONER` (bindings.cpp.in:426, the reference's only preconditioner) selects the
    Jacobi family: plain Jacobi M = diag(K), and -- this engine's addition, on by default, OSQPHipPolicy::woodbury / woodbury_large = 0 switch it
@@ -383,9 +385,10 @@ typedef struct {
   OSQPInt woodbury_vendor;    /* 0 (default): the dense system of the device-factorised Woodbury form is formed and inverted by this engine's own kernels on the fp64 matrix
                                  cores (dense_hip.hip: a strided MFMA GEMM + block Gauss-Jordan inversion); 1: rocBLAS dgemm + rocSOLVER dpotrf / dpotri, loaded on
                                  demand (the route of rounds 3-5, kept for A/B runs; without the libraries osqp_setup falls back to plain Jacobi)            [setup] */
-  OSQPInt batch_wave;         /* batch solves in the spectral form: 1 = one WAVE per problem, eight problems in flight per CU (batch_hip.hip k_batch_wave); 0 (default)
-                                 = one workgroup per problem.  Opt-in: measured slower end to end on the MPC batch (a problem's own latency is 4-6x higher on one
-                                 wave, and a batch ends with its slowest problem -- DESIGN.md section 8) */
+  OSQPInt batch_wave;         /* batch solves in the spectral form: one WAVE per problem, eight problems in flight per CU, the longest-expected problems on the
+                                 workgroup kernel beside it (batch_hip.hip k_batch_wave).  0 (default): for batches of at least 3072 problems, or 1536 with a
+                                 launch order from a previous call (measured, MPC batch: 4096 QPs 3.5 ms against 5.7, 2048 2.2 against 3.0 with history, 1024
+                                 2.1 against 1.6 -- below that a problem's own latency on one wave decides); 1: at every batch size; -1: never */
 } OSQPHipPolicy;
 void    osqp_hip_default_policy(OSQPHipPolicy *policy);
 OSQPInt osqp_hip_set_policy(OSQPSolver *solver, const OSQPHipPolicy *policy);

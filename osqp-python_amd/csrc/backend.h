@@ -305,6 +305,7 @@ struct Dev {
   int *flags = nullptr;          // [F_COUNT]
   int *slot = nullptr;           // [16] the two phase records of the slot kernels (backend_hip.hip "slot kernels"); nullptr: not used
   void *stream = nullptr;        // hipStream_t (product) / unused (host simulator)
+  void *bside = nullptr, *bev0 = nullptr, *bev1 = nullptr;      // batch path: second stream + fork / join events (batch_hip.hip, created on first use)
   void *impl = nullptr;          // backend private (events, graphs, pinned staging)
 };
 
@@ -370,6 +371,8 @@ struct BatchParams {
   int wv_on = 0;
   int wv_aend[4] = {0, 0, 0, 0}, wv_tend[2] = {0, 0};
   const int *wv_Aidx = nullptr, *wv_Acol = nullptr, *wv_Tidx = nullptr, *wv_Tcol = nullptr, *wv_row = nullptr;
+  int wv_first = 0;              // positions [0, wv_first) of the launch order are not the wave kernel's (be::batch_solve sends them to the workgroup kernel)
+  int wv_split = 0;              // how many of the first positions the engine wants treated that way (0: none; needs a launch order)
   int *wv_queue = nullptr;       // device counter: the next position of the launch order not yet taken by a wave (zeroed before the launch)
 };
 constexpr int kBatchWaveW = 8;          // waves (= problems in flight) per workgroup of the wave-per-problem kernel; one workgroup per CU
@@ -384,6 +387,7 @@ size_t batch_lds_bytes(int n, int m);                       // 0 if a problem do
 int batch_solve(Dev &d, const BatchParams &p, void *stream = nullptr);
 size_t batch_direct_lds_bytes(int n, int m, int nnz, int bw); // 0 if the banded factor does not fit next to the iterates
 bool batch_direct_selected(const BatchParams &p);              // would batch_solve run a direct (banded LDL') variant for p?
+void batch_release(Dev &d);                                    // the batch path's second stream and events
 size_t batch_wave_lds_bytes(int n, int m, int steps);          // LDS of the wave-per-problem kernel (V + `steps` ELL steps of values + one staging vector per wave); 0: does not fit
 void batch_products(Dev &d, int nprod, const int *a, const int *b, double *out);   // out[p] = A.val[a[p]] * A.val[b[p]]
 // per-problem matrices: Px_b [nbatch][nnz(P as given at setup: upper triangle, CSC order)] / Ax_b [nbatch][nnz(A), CSC order], UNSCALED, device

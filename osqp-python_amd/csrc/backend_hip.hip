@@ -438,6 +438,7 @@ void destroy(Dev &d) {
   (void)hipHostFree(p.pin_poll); if (p.side) (void)hipStreamDestroy(p.side);
   (void)hipHostFree(p.pin_ctl); (void)hipHostFree(p.pin_ctl2);
   if (p.blas) wb_release_blas(p.blas);                 // (woodbury_hip.hip: the rocBLAS handle of the device-factorised form)
+  batch_release(d);
   for (int k = 1; k < DevWb::kCache; k++) if (d.wb.cache_buf[k]) { (void)hipFree(d.wb.cache_buf[k]); d.wb.cache_buf[k] = nullptr; }      // (buffer 0 is the engine's own Sinv allocation)
   dev_release(d);
   delete &p; d.impl = nullptr;

@@ -1085,8 +1085,8 @@ __global__ __launch_bounds__(64 * kBatchWaveW, 1) void k_batch_wave(BatchParams 
     //  64.  The obvious form, lane 0 alone behind `if (L == 0)`, hangs: the loop is then compiled with a second version for the lanes that never run the
     //  atomic, whose position stays 0.)
     int pos;
-    if (first) { pos = __builtin_amdgcn_readfirstlane(wv) * (int)gridDim.x + (int)blockIdx.x; first = false; }
-    else pos = (int)gridDim.x * kBatchWaveW + (__builtin_amdgcn_readfirstlane(atomicAdd(P.wv_queue, 1)) >> 6);
+    if (first) { pos = P.wv_first + __builtin_amdgcn_readfirstlane(wv) * (int)gridDim.x + (int)blockIdx.x; first = false; }
+    else pos = P.wv_first + (int)gridDim.x * kBatchWaveW + (__builtin_amdgcn_readfirstlane(atomicAdd(P.wv_queue, 1)) >> 6);
     if (pos >= P.nbatch) break;
     const int b = P.order ? P.order[pos] : pos;
     double x[2], q[2], dx[2], xs[2], z[4], y[4], l[4], u[4], dy[4];
@@ -1413,6 +1413,11 @@ BatchChoice choose_batch_variant(const BatchParams &p) {
   return c;
 }
 }  // namespace
+void batch_release(Dev &d) {
+  if (d.bside) { (void)hipStreamDestroy(static_cast<hipStream_t>(d.bside)); d.bside = nullptr; }
+  if (d.bev0) { (void)hipEventDestroy(static_cast<hipEvent_t>(d.bev0)); d.bev0 = nullptr; }
+  if (d.bev1) { (void)hipEventDestroy(static_cast<hipEvent_t>(d.bev1)); d.bev1 = nullptr; }
+}
 bool batch_direct_selected(const BatchParams &p) { const BatchChoice c = choose_batch_variant(p); return c.dir256 || c.dir64; }
 // rows / columns of V in the wave kernel's LDS: compile-time, two instantiations (n <= 120: the MPC batch's 116 KB; n <= 128)
 static int batch_wave_n8(int n) { return n <= 120 ? 120 : 128; }
@@ -1443,38 +1448,61 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
   // reference's is solved by this launch; the others are marked and left to the banded kernel launched right behind (only_marked).
   bool spectral = false;
   const int prod_len = ((p.A.nnz > p.B.nnz ? p.A.nnz : p.B.nnz) + 1) & ~1;
-  if (use_dir256 && p.sp_V && !p.wv_on && !p.mat_on && !p.polish && p.n <= kBatchSpecN && e256 <= 8 && prod_len >= 4 * (kBatchSpecN + 2) && !p.only_marked) {
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d.device);
+  const bool spec_ok = use_dir256 && p.sp_V && !p.mat_on && !p.polish && p.n <= kBatchSpecN && e256 <= 8 && prod_len >= 4 * (kBatchSpecN + 2) && !p.only_marked;
+  // workgroup-per-problem spectral launch of the first q.nbatch positions of the launch order, on stream s; false: the device refused the LDS reservation
+  // (the banded launch below then takes the whole batch)
+  auto spec_launch = [&](const BatchParams &q, hipStream_t s) -> bool {
     const size_t lds_spec = lds_reg + sizeof(double) * (kBatchNB + 2 * kBatchSpecN + 4);
-    // (a device that refuses the LDS reservation of this instantiation keeps the banded launch below for the whole batch)
+    bool ok = true;
 #define BATCH_LAUNCH_SPEC_W(E, W) do { \
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<256, E, E, true, false, false, true, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec) != hipSuccess) { (void)hipGetLastError(); spectral = false; } \
-    else hipLaunchKernelGGL((k_batch_admm<256, E, E, true, false, false, true, W>), dim3(p.nbatch), dim3(256), lds_spec, st, p); } while (0)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_batch_admm<256, E, E, true, false, false, true, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spec) != hipSuccess) { (void)hipGetLastError(); ok = false; } \
+    else hipLaunchKernelGGL((k_batch_admm<256, E, E, true, false, false, true, W>), dim3(q.nbatch), dim3(256), lds_spec, s, q); } while (0)
     // One workgroup per CU (everything in registers) at every batch size: since K^-1 lives in the matrix instruction's result registers the two-per-CU
     // form (256 registers, scratch) no longer wins on large batches either -- 4096 QPs 5.9 ms against 6.2 ms.  OSQP_HIP_BATCH_WIDE_ROUNDS=r selects it for
     // batches of more than r rounds of one workgroup per CU (A/B runs).
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d.device);
     static const int wide_rounds = std::getenv("OSQP_HIP_BATCH_WIDE_ROUNDS") ? std::atoi(std::getenv("OSQP_HIP_BATCH_WIDE_ROUNDS")) : (1 << 20);
-    const bool wide = p.nbatch > wide_rounds * cus;
+    const bool wide = q.nbatch > wide_rounds * cus;
 #define BATCH_LAUNCH_SPEC(E) do { if (wide) BATCH_LAUNCH_SPEC_W(E, 2); else BATCH_LAUNCH_SPEC_W(E, 1); } while (0)
-    spectral = true;
     if (e256 <= 2) BATCH_LAUNCH_SPEC(2); else if (e256 <= 4) BATCH_LAUNCH_SPEC(4); else if (e256 <= 6) BATCH_LAUNCH_SPEC(6); else BATCH_LAUNCH_SPEC(8);
 #undef BATCH_LAUNCH_SPEC
 #undef BATCH_LAUNCH_SPEC_W
-  }
-  // ... one WAVE per problem where the engine has prepared that form (wv_on: large batches): eight problems in flight per CU
-  if (use_dir256 && p.sp_V && p.wv_on && !p.mat_on && !p.polish && !p.only_marked) {
+    return ok;
+  };
+  if (spec_ok && !p.wv_on) spectral = spec_launch(p, st);
+  // ... one WAVE per problem where the engine has prepared that form (wv_on): eight problems in flight per CU.  A problem on one wave takes ~12 us per ADMM
+  // iteration against 3.7 for a workgroup, and a batch ends with its slowest problem: with a launch order (longest-expected first) the first wv_split
+  // positions -- the outliers, 38 of the MPC batch's 4096 problems take 200 .. 375 iterations against a mean of 95 -- go to the workgroup kernel on a second
+  // stream, one CU each, while the wave kernel runs on the other CUs.
+  if (spec_ok && p.wv_on) {
     const size_t lds_w = batch_wave_lds_bytes(p.n, p.m, p.wv_aend[3] + p.wv_tend[1]);
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d.device);
+    const int split = (p.order && p.wv_split > 0 && p.nbatch >= 8 * p.wv_split && cus > 2 * p.wv_split) ? p.wv_split : 0;
     auto launch = [&](auto kern) {
       if (!lds_w || hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w) != hipSuccess) { (void)hipGetLastError(); return; }
+      BatchParams pw = p;
+      hipStream_t side = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+      if (split) {
+        if (!d.bside) {
+          hipStream_t s2; hipEvent_t a, b;
+          if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess)
+            throw DeviceError("osqp_hip: cannot create the batch path's second stream");
+          d.bside = s2; d.bev0 = a; d.bev1 = b;
+        }
+        side = static_cast<hipStream_t>(d.bside); ev0 = static_cast<hipEvent_t>(d.bev0); ev1 = static_cast<hipEvent_t>(d.bev1);
+        BatchParams ph = p; ph.nbatch = split; ph.wv_on = 0;
+        if (hipEventRecord(ev0, st) != hipSuccess || hipStreamWaitEvent(side, ev0, 0) != hipSuccess) throw DeviceError("osqp_hip: batch stream fork failed");
+        if (spec_launch(ph, side)) pw.wv_first = split;               // (refused: the wave kernel takes them as well)
+        if (hipEventRecord(ev1, side) != hipSuccess) throw DeviceError("osqp_hip: batch stream join failed");
+      }
       if (hipMemsetAsync(p.wv_queue, 0, sizeof(int), st) != hipSuccess) throw DeviceError("osqp_hip: batch queue reset failed");
-      const int wgs = std::min(cus, p.nbatch);            // (fewer problems than CUs: one wave per workgroup gets one)
-      hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * kBatchWaveW), lds_w, st, p);
+      const int wgs = std::max(1, std::min(cus - pw.wv_first, p.nbatch - pw.wv_first));      // (fewer problems than CUs: one wave per workgroup gets one)
+      hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * kBatchWaveW), lds_w, st, pw);
+      if (split && hipStreamWaitEvent(st, ev1, 0) != hipSuccess) throw DeviceError("osqp_hip: batch stream join failed");
       spectral = true;
     };
     if (batch_wave_n8(p.n) == 120) launch(&k_batch_wave<kBatchWaveSA, kBatchWaveST, 120>); else launch(&k_batch_wave<kBatchWaveSA, kBatchWaveST, 128>);
+    if (!spectral) spectral = spec_launch(p, st);       // (no room for the wave form's LDS: the workgroup form)
   }
   BatchParams pm = p;
   if (spectral) pm.only_marked = 1;

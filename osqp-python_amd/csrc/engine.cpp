@@ -71,7 +71,7 @@ int Engine::get_policy(OSQPHipPolicy *p) const { if (!p) return OSQP_DATA_VALIDA
 int Engine::set_policy(const OSQPHipPolicy *p) {
   if (!p) return OSQP_DATA_VALIDATION_ERROR;
   if (!(p->extrap >= 0 && p->extrap <= 2) || p->rho_window < 0 || !(p->rho_window_tol > 0) || !(p->rho_tol_exp > 0 && p->rho_tol_exp <= 1) ||
-      !(p->budget_sigma >= 0) || p->finish_pairs < 1 || p->batch_variant < 0 || p->batch_variant > 5 || p->batch_wave < 0 || p->batch_wave > 1 ||
+      !(p->budget_sigma >= 0) || p->finish_pairs < 1 || p->batch_variant < 0 || p->batch_variant > 5 || p->batch_wave < -1 || p->batch_wave > 1 ||
       !(p->rho_eq_factor == 0 || p->rho_eq_factor >= 1) || p->reorder < 0 || p->reorder > 2 || !(p->woodbury_direct_tol > 0 && p->woodbury_direct_tol < 1) || !(p->polish_delta_floor > 0) || !(p->polish_pcg_tol > 0 && p->polish_pcg_tol < 1))
     return OSQP_SETTINGS_VALIDATION_ERROR;
   const OSQPHipPolicy old = pol_;

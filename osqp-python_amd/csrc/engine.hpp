@@ -132,6 +132,7 @@ class Engine {
   void prepare_batch_wave();
   void free_batch_wave();
   void attach_batch_wave(BatchParams &p, int nbatch);
+  int batch_wave_last_ = -1;            // OSQPHipStats::batch_wave_split
   // Spectral form of the batch path's direct solve (batch_hip.hip, SPEC): every problem of a batch shares P, A and the constraint classes, and
   // rho enters K only through ONE scalar -- K(rho) = K_ref + (rho - rho_ref) M1, M1 = A' W A (W: 1 on inequality rows, the equality weight on
   // equality rows).  With K_ref = L L', L^-1 M1 L^-T = Q Lambda Q' and V = L^-T Q:  K(rho)^-1 = V diag(1 / (1 + (rho - rho_ref) lambda)) V'.

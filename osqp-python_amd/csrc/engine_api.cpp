@@ -293,6 +293,7 @@ void Engine::free_batch_direct() {
 // ------------------------------------------------------------------------------------------------ batch path, one wave per problem
 // engine.hpp BatchWave / backend.h BatchParams::wv_*.  Rows of A sorted by length (descending, stable): sorted position p -> lane p % 64, slot p / 64; a group
 // of 64 positions takes as many ELL steps as its longest (= first) row has entries.  A' (B's entries with column >= n) in the natural order of the variables.
+constexpr int kBatchWaveMin = 3072, kBatchWaveMinOrdered = 1536;      // smallest batches that take the wave-per-problem kernel by default (without / with a launch order)
 void Engine::free_batch_wave() {
   void *ptrs[] = {bwv_.Aidx, bwv_.Acol, bwv_.Tidx, bwv_.Tcol, bwv_.row, bwv_.queue};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
@@ -334,13 +335,16 @@ void Engine::prepare_batch_wave() {
   bwv_.ok = true;
 }
 // (behind attach_batch_direct: the form needs the spectral decomposition)
-void Engine::attach_batch_wave(BatchParams &p, int /*nbatch*/) {
-  if (!p.sp_V || pol_.batch_wave != 1 || p.mat_on || p.polish) return;      // (opt-in: OSQPHipPolicy::batch_wave)
+void Engine::attach_batch_wave(BatchParams &p, int nbatch) {
+  // OSQPHipPolicy::batch_wave; automatic = where it measured faster (tools/batch_size_sweep.py): large batches, smaller ones only with a launch order
+  if (!p.sp_V || pol_.batch_wave < 0 || p.mat_on || p.polish) return;
+  if (pol_.batch_wave == 0 && nbatch < (p.order ? kBatchWaveMinOrdered : kBatchWaveMin)) return;
   prepare_batch_wave();
   if (!bwv_.ok) return;
   p.wv_on = 1;
   for (int g = 0; g < 4; g++) p.wv_aend[g] = bwv_.aend[g];
   p.wv_tend[0] = bwv_.tend[0]; p.wv_tend[1] = bwv_.tend[1];
+  p.wv_split = std::min(64, std::max(8, nbatch / 128));      // (the longest-expected problems to the workgroup kernel; be::batch_solve applies it when there is a launch order)
   p.wv_Aidx = bwv_.Aidx; p.wv_Acol = bwv_.Acol; p.wv_Tidx = bwv_.Tidx; p.wv_Tcol = bwv_.Tcol; p.wv_row = bwv_.row; p.wv_queue = bwv_.queue;
 }
 
@@ -790,6 +794,7 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
     be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);             // A's values may have changed since the last call
     attach_batch_direct(p, nbatch >= kBatchSpectralMin && !Px && !Ax);
     if (!Px && !Ax) attach_batch_wave(p, nbatch);
+    batch_wave_last_ = p.wv_on ? ((p.order && nbatch >= 8 * p.wv_split) ? p.wv_split : 0) : -1;
   }
   if (Px || Ax) { const int e2 = attach_batch_matrices(p, Px ? dPx : nullptr, Ax ? dAx : nullptr, nullptr); if (e2) return e2; }
   int err = be::batch_solve(d_, p);
@@ -846,6 +851,7 @@ int Engine::batch_solve_device(int nbatch, const double *q, const double *l, con
     be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);
     attach_batch_direct(p, nbatch >= kBatchSpectralMin && !Px && !Ax);
     if (!Px && !Ax) attach_batch_wave(p, nbatch);
+    batch_wave_last_ = p.wv_on ? ((p.order && nbatch >= 8 * p.wv_split) ? p.wv_split : 0) : -1;
   }
   be::sync(d_);                                   // the uploads and the product refresh ran on the solver's stream
   if (Px || Ax) { const int e2 = attach_batch_matrices(p, Px, Ax, stream); if (e2) return e2; }      // (on the caller's stream, in front of the solve launch)
@@ -859,6 +865,7 @@ int Engine::get_stats(OSQPHipStats *out) {
   *out = stats_; out->pcg_fused = (d_.f1.on && use_slots_) ? 2.0 : ((d_.kf.on && use_slots_) ? 3.0 : (be::pcg_fused(d_) ? 1.0 : 0.0)); out->batch_direct_bw = bd_.bw_symbolic;
   out->f1_replicas = d_.f1.on ? d_.f1.D : 0;
   out->kform_nnz = d_.kf.on ? (double)d_.kf.K.nnz : 0.0;
+  out->batch_wave_split = (double)batch_wave_last_;
   out->woodbury_dual_cols = (d_.wb.on && d_.wb.dual) ? (double)d_.wb.cd : 0.0;
   out->woodbury_fused_iteration = be::wbf_active(d_) ? 1.0 : 0.0;
   out->woodbury_one_launch = (be::wbx_active(d_) && d_.wb.x.one && !d_.wb.x.slots) ? 1.0 : 0.0;

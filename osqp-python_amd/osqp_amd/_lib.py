@@ -57,7 +57,7 @@ class SolverStruct(C.Structure):
 class StatsStruct(C.Structure):
     _fields_ = [(k, C.c_double) for k in ('pcg_iters_total', 'pcg_iters_max', 'pcg_unconverged', 'kernel_launches',
                                           'graph_launches', 'gpu_solve_ms', 'nnzA', 'nnzB', 'pcg_fused', 'batch_direct_bw',
-                                          'cg_cap_escalations', 'windowed_blocks', 'row_blocks', 'slot_topups', 'f1_replicas', 'woodbury_rows', 'woodbury_direct', 'preconditioner', 'woodbury_factorisations', 'woodbury_factor_ms', 'reordered', 'reorder_ms', 'woodbury_cache_hits', 'f1_far_columns', 'woodbury_dual_cols', 'woodbury_fused_iteration', 'woodbury_one_launch', 'kform_nnz')]
+                                          'cg_cap_escalations', 'windowed_blocks', 'row_blocks', 'slot_topups', 'f1_replicas', 'woodbury_rows', 'woodbury_direct', 'preconditioner', 'woodbury_factorisations', 'woodbury_factor_ms', 'reordered', 'reorder_ms', 'woodbury_cache_hits', 'f1_far_columns', 'woodbury_dual_cols', 'woodbury_fused_iteration', 'woodbury_one_launch', 'kform_nnz', 'batch_wave_split')]
 
 
 class PolicyStruct(C.Structure):       # OSQPHipPolicy, include/osqp_hip.h (same order)

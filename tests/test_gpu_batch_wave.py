@@ -1,6 +1,6 @@
 """GPU tier: the batch path's wave-per-problem kernel (batch_hip.hip k_batch_wave: V and the matrices once per CU in LDS, a problem's iterates in the registers
-of ONE wave, eight problems in flight per CU; opt-in, OSQPHipPolicy::batch_wave = 1) against the workgroup-per-problem spectral kernel (the default)
-and the banded LDL' kernel: the same algorithm with the same rho rule -- equal
+of ONE wave, eight problems in flight per CU; OSQPHipPolicy::batch_wave: 1 forces it at any batch size, -1 switches it off, 0 = large batches only) against
+the workgroup-per-problem spectral kernel and the banded LDL' kernel: the same algorithm with the same rho rule -- equal
 iteration counts, x / y to 1e-9 -- also for warm starts, after a matrix update, for a problem with other constraint classes (left to the banded kernel),
 for infeasible problems (certificates) and against the CPU oracle per problem."""
 import warnings
@@ -30,28 +30,30 @@ def _solver(P, q, A, l, u, wave=1, banded=False, **kw):
 def test_wave_equals_workgroup_forms(B):
     P, q, A, L, U = problems.mpc_batch(B)
     xw, yw, rw = _solver(P, q, A, L[0], U[0], wave=1)._solver.hip_batch_solve(l=L, u=U)
-    xs, ys, rs = _solver(P, q, A, L[0], U[0], wave=0)._solver.hip_batch_solve(l=L, u=U)
+    xs, ys, rs = _solver(P, q, A, L[0], U[0], wave=-1)._solver.hip_batch_solve(l=L, u=U)
     assert (rw[:, 0] == 1).all() and (rs[:, 0] == 1).all()
     assert np.array_equal(rw[:, 1], rs[:, 1]) and np.array_equal(rw[:, 6], rs[:, 6])          # iterations, rho updates
     assert np.abs(xw - xs).max() <= 1e-9 * (1 + np.abs(xs).max()) and np.abs(yw - ys).max() <= 1e-9 * (1 + np.abs(ys).max())
     assert np.abs(rw[:, 2] - rs[:, 2]).max() <= 1e-9 * (1 + np.abs(rs[:, 2]).max())           # objective
     if B <= 700:
-        xb, yb, rb = _solver(P, q, A, L[0], U[0], wave=0, banded=True)._solver.hip_batch_solve(l=L, u=U)
+        xb, yb, rb = _solver(P, q, A, L[0], U[0], wave=-1, banded=True)._solver.hip_batch_solve(l=L, u=U)
         assert np.array_equal(rw[:, 1], rb[:, 1]) and np.abs(xw - xb).max() <= 1e-9 * (1 + np.abs(xb).max())
 
 
-def test_wave_is_opt_in_and_repeats_bit_identically():
+def test_wave_default_rule_and_repeats():
     B = 1024
     P, q, A, L, U = problems.mpc_batch(B)
     s = osqp_amd.OSQP(); s.setup(P, q, A, L[0], U[0], **ST)
     assert s._solver.get_policy()['batch_wave'] == 0
     xd, yd, rd = s._solver.hip_batch_solve(l=L, u=U)
-    x0, y0, r0 = _solver(P, q, A, L[0], U[0], wave=0)._solver.hip_batch_solve(l=L, u=U)
-    assert np.array_equal(xd, x0) and np.array_equal(rd[:, :7], r0[:, :7])                      # the default IS the workgroup kernel
+    x0, y0, r0 = _solver(P, q, A, L[0], U[0], wave=-1)._solver.hip_batch_solve(l=L, u=U)
+    assert np.array_equal(xd, x0) and np.array_equal(rd[:, :7], r0[:, :7])                      # 1024 problems: the default is the workgroup kernel
     sw = _solver(P, q, A, L[0], U[0], wave=1)
-    x1, y1, r1 = sw._solver.hip_batch_solve(l=L, u=U)
-    x2, y2, r2 = sw._solver.hip_batch_solve(l=L, u=U)           # (second call: launch order from the first call's iteration counts, other waves get other problems)
-    assert np.array_equal(x1, x2) and np.array_equal(y1, y2) and np.array_equal(r1[:, :7], r2[:, :7])
+    x1, y1, r1 = sw._solver.hip_batch_solve(l=L, u=U)           # (no launch order yet: every problem on the wave kernel)
+    x2, y2, r2 = sw._solver.hip_batch_solve(l=L, u=U)           # (launch order from the first call's iteration counts: other waves get other problems, and the
+    x3, y3, r3 = sw._solver.hip_batch_solve(l=L, u=U)           #  32 longest-expected ones go to the workgroup kernel on the second stream -- batch_hip.hip batch_solve)
+    assert np.array_equal(x2, x3) and np.array_equal(y2, y3) and np.array_equal(r2[:, :7], r3[:, :7])      # same order, same routing: bit-identical
+    assert np.array_equal(r1[:, 1], r2[:, 1]) and np.abs(x1 - x2).max() <= 1e-9 * (1 + np.abs(x2).max())  # another routing: the kernels agree to rounding
     assert np.array_equal(r1[:, 1], rd[:, 1]) and np.abs(x1 - xd).max() <= 1e-9 * (1 + np.abs(xd).max())
 
 
@@ -72,7 +74,7 @@ def test_wave_warm_start_and_per_problem_q():
     P, q, A, L, U = problems.mpc_batch(B)
     rng = np.random.default_rng(2)
     Q = q[None, :] + 0.05 * rng.standard_normal((B, q.size))
-    sw, ss = _solver(P, q, A, L[0], U[0], wave=1), _solver(P, q, A, L[0], U[0], wave=0)
+    sw, ss = _solver(P, q, A, L[0], U[0], wave=1), _solver(P, q, A, L[0], U[0], wave=-1)
     xw, yw, rw = sw._solver.hip_batch_solve(q=Q, l=L, u=U)
     xs, ys, rs = ss._solver.hip_batch_solve(q=Q, l=L, u=U)
     assert (rw[:, 0] == 1).all() and np.array_equal(rw[:, 1], rs[:, 1])
@@ -110,7 +112,7 @@ def test_wave_leaves_other_constraint_classes_to_the_banded_kernel():
     L[7, box] = U[7, box] = 0.0
     L[11, box] = -1e30; U[11, box] = 1e30
     x, y, rec = _solver(P, q, A, L[0], U[0], wave=1)._solver.hip_batch_solve(l=L, u=U)
-    xb, yb, rb = _solver(P, q, A, L[0], U[0], wave=0, banded=True)._solver.hip_batch_solve(l=L, u=U)
+    xb, yb, rb = _solver(P, q, A, L[0], U[0], wave=-1, banded=True)._solver.hip_batch_solve(l=L, u=U)
     assert (rec[:, 0] == 1).all() and np.array_equal(rec[:, 1], rb[:, 1])
     assert np.array_equal(x[7], xb[7]) and np.array_equal(x[11], xb[11])                        # those two WERE solved by the banded kernel: bit-identical
 
@@ -123,9 +125,18 @@ def test_wave_infeasible_problem_in_the_batch():
     box = np.flatnonzero(U[0] - L[0] > 1.0)
     L[3, box[:4]] = 50.0; U[3, box[:4]] = 60.0
     xw, yw, rw = _solver(P, q, A, L[0], U[0], wave=1)._solver.hip_batch_solve(l=L, u=U)
-    xs, ys, rs = _solver(P, q, A, L[0], U[0], wave=0)._solver.hip_batch_solve(l=L, u=U)
+    xs, ys, rs = _solver(P, q, A, L[0], U[0], wave=-1)._solver.hip_batch_solve(l=L, u=U)
     assert np.array_equal(rw[:, 0], rs[:, 0]) and np.array_equal(rw[:, 1], rs[:, 1])
     ok = rw[:, 0] == 1
     assert ok.sum() >= B - 1 and np.abs(xw[ok] - xs[ok]).max() <= 1e-9 * (1 + np.abs(xs[ok]).max())
     if not ok[3]:
         assert np.allclose(yw[3], ys[3], rtol=1e-6, atol=1e-9, equal_nan=True)
+
+
+def test_wave_is_the_default_for_large_batches():
+    B = 4096
+    P, q, A, L, U = problems.mpc_batch(B)
+    s = osqp_amd.OSQP(); s.setup(P, q, A, L[0], U[0], **ST)
+    xd, yd, rd = s._solver.hip_batch_solve(l=L, u=U)
+    xw, yw, rw = _solver(P, q, A, L[0], U[0], wave=1)._solver.hip_batch_solve(l=L, u=U)
+    assert (rd[:, 0] == 1).all() and np.array_equal(xd, xw) and np.array_equal(yd, yw) and np.array_equal(rd[:, :7], rw[:, :7])

@@ -9,7 +9,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 mi = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
 P, q, A, L, U = problems.mpc_batch(B)
 out = {}
-for w in (0, 1):
+for w in (-1, 1):
     s = osqp_amd.OSQP(); s.setup(P, q, A, L[0], U[0], eps_abs=1e-6, eps_rel=1e-6, verbose=False, max_iter=mi)
     s._solver.set_policy(batch_wave=w)
     print('wave', w, 'launching', flush=True)
@@ -17,7 +17,7 @@ for w in (0, 1):
     t2 = time.time(); x, y, r = s._solver.hip_batch_solve(l=L, u=U); t3 = time.time()
     print('wave', w, 'status', np.unique(r[:, 0]), 'iters mean %.1f max %d' % (r[:, 1].mean(), r[:, 1].max()), 'first %.1f ms second %.2f ms' % (1e3 * (t1 - t0), 1e3 * (t3 - t2)), flush=True)
     out[w] = (x, y, r)
-xs, ys, rs = out[0]; xw, yw, rw = out[1]
+xs, ys, rs = out[-1]; xw, yw, rw = out[1]
 print('iters equal', np.array_equal(rs[:, 1], rw[:, 1]), 'dx %.2e dy %.2e' % (np.abs(xs - xw).max(), np.abs(ys - yw).max()), 'iter diff', np.flatnonzero(rs[:, 1] != rw[:, 1])[:10])
 import os
 if os.environ.get('OSQP_HIP_LIBRARY', '').endswith('trace.so'):          # (make TRACE=1 build: rec[7..11] hold 100 MHz ticks per phase)
