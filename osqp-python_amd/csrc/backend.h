@@ -373,6 +373,7 @@ struct BatchParams {
   const int *wv_Aidx = nullptr, *wv_Acol = nullptr, *wv_Tidx = nullptr, *wv_Tcol = nullptr, *wv_row = nullptr;
   int wv_first = 0;              // positions [0, wv_first) of the launch order are not the wave kernel's (be::batch_solve sends them to the workgroup kernel)
   int wv_split = 0;              // how many of the first positions the engine wants treated that way (0: none; needs a launch order)
+  int wv_cus = 0;                // ... and on how many CUs (the wave kernel's grid leaves them free; wv_split > wv_cus: several problems per CU, one after the other)
   int *wv_queue = nullptr;       // device counter: the next position of the launch order not yet taken by a wave (zeroed before the launch)
 };
 constexpr int kBatchWaveW = 8;          // waves (= problems in flight) per workgroup of the wave-per-problem kernel; one workgroup per CU

@@ -1477,7 +1477,7 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
   // stream, one CU each, while the wave kernel runs on the other CUs.
   if (spec_ok && p.wv_on) {
     const size_t lds_w = batch_wave_lds_bytes(p.n, p.m, p.wv_aend[3] + p.wv_tend[1]);
-    const int split = (p.order && p.wv_split > 0 && p.nbatch >= 8 * p.wv_split && cus > 2 * p.wv_split) ? p.wv_split : 0;
+    const int split = (p.order && p.wv_split > 0 && p.wv_cus > 0 && p.nbatch >= 8 * p.wv_split && cus > 2 * p.wv_cus) ? p.wv_split : 0;
     auto launch = [&](auto kern) {
       if (!lds_w || hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w) != hipSuccess) { (void)hipGetLastError(); return; }
       BatchParams pw = p;
@@ -1496,7 +1496,7 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
         if (hipEventRecord(ev1, side) != hipSuccess) throw DeviceError("osqp_hip: batch stream join failed");
       }
       if (hipMemsetAsync(p.wv_queue, 0, sizeof(int), st) != hipSuccess) throw DeviceError("osqp_hip: batch queue reset failed");
-      const int wgs = std::max(1, std::min(cus - pw.wv_first, p.nbatch - pw.wv_first));      // (fewer problems than CUs: one wave per workgroup gets one)
+      const int wgs = std::max(1, std::min(cus - (pw.wv_first ? p.wv_cus : 0), p.nbatch - pw.wv_first));      // (fewer problems than CUs: one wave per workgroup gets one)
       hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * kBatchWaveW), lds_w, st, pw);
       if (split && hipStreamWaitEvent(st, ev1, 0) != hipSuccess) throw DeviceError("osqp_hip: batch stream join failed");
       spectral = true;

@@ -344,7 +344,14 @@ void Engine::attach_batch_wave(BatchParams &p, int nbatch) {
   p.wv_on = 1;
   for (int g = 0; g < 4; g++) p.wv_aend[g] = bwv_.aend[g];
   p.wv_tend[0] = bwv_.tend[0]; p.wv_tend[1] = bwv_.tend[1];
-  p.wv_split = std::min(64, std::max(8, nbatch / 128));      // (the longest-expected problems to the workgroup kernel; be::batch_solve applies it when there is a launch order)
+  // the longest-expected problems to the workgroup kernel (be::batch_solve applies it when there is a launch order): wv_cus CUs are left free for it
+  // and take wv_split problems, several each, one after the other
+  static const int env_split = std::getenv("OSQP_HIP_WAVE_SPLIT") ? std::atoi(std::getenv("OSQP_HIP_WAVE_SPLIT")) : -1;
+  static const int env_cus = std::getenv("OSQP_HIP_WAVE_CUS") ? std::atoi(std::getenv("OSQP_HIP_WAVE_CUS")) : -1;
+  // (tools/batch_size_sweep.py under OSQP_HIP_WAVE_SPLIT / OSQP_HIP_WAVE_CUS, MPC batch: 2048 QPs 2.21 ms with 32 / 32, 2.84 with 64 / 16; 4096 QPs 3.26 ms
+  //  with 48 / 16, 3.41 with 32 / 32; 8192 QPs 5.66 against 6.18 -- a large batch is bound by the wave kernel's throughput and wants its CUs back)
+  p.wv_cus = env_cus >= 0 ? env_cus : (nbatch < 3072 ? 32 : 16);
+  p.wv_split = env_split >= 0 ? env_split : (nbatch < 3072 ? 32 : 48);
   p.wv_Aidx = bwv_.Aidx; p.wv_Acol = bwv_.Acol; p.wv_Tidx = bwv_.Tidx; p.wv_Tcol = bwv_.Tcol; p.wv_row = bwv_.row; p.wv_queue = bwv_.queue;
 }
 
@@ -794,7 +801,7 @@ int Engine::batch_solve(int nbatch, const double *q, const double *l, const doub
     be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);             // A's values may have changed since the last call
     attach_batch_direct(p, nbatch >= kBatchSpectralMin && !Px && !Ax);
     if (!Px && !Ax) attach_batch_wave(p, nbatch);
-    batch_wave_last_ = p.wv_on ? ((p.order && nbatch >= 8 * p.wv_split) ? p.wv_split : 0) : -1;
+    batch_wave_last_ = p.wv_on ? ((p.order && p.wv_cus > 0 && nbatch >= 8 * p.wv_split) ? p.wv_split : 0) : -1;
   }
   if (Px || Ax) { const int e2 = attach_batch_matrices(p, Px ? dPx : nullptr, Ax ? dAx : nullptr, nullptr); if (e2) return e2; }
   int err = be::batch_solve(d_, p);
@@ -851,7 +858,7 @@ int Engine::batch_solve_device(int nbatch, const double *q, const double *l, con
     be::batch_products(d_, bd_.nprod, bd_.kp_a, bd_.kp_b, bd_.kp_val);
     attach_batch_direct(p, nbatch >= kBatchSpectralMin && !Px && !Ax);
     if (!Px && !Ax) attach_batch_wave(p, nbatch);
-    batch_wave_last_ = p.wv_on ? ((p.order && nbatch >= 8 * p.wv_split) ? p.wv_split : 0) : -1;
+    batch_wave_last_ = p.wv_on ? ((p.order && p.wv_cus > 0 && nbatch >= 8 * p.wv_split) ? p.wv_split : 0) : -1;
   }
   be::sync(d_);                                   // the uploads and the product refresh ran on the solver's stream
   if (Px || Ax) { const int e2 = attach_batch_matrices(p, Px, Ax, stream); if (e2) return e2; }      // (on the caller's stream, in front of the solve launch)

@@ -51,7 +51,7 @@ def test_wave_default_rule_and_repeats():
     sw = _solver(P, q, A, L[0], U[0], wave=1)
     x1, y1, r1 = sw._solver.hip_batch_solve(l=L, u=U)           # (no launch order yet: every problem on the wave kernel)
     x2, y2, r2 = sw._solver.hip_batch_solve(l=L, u=U)           # (launch order from the first call's iteration counts: other waves get other problems, and the
-    x3, y3, r3 = sw._solver.hip_batch_solve(l=L, u=U)           #  32 longest-expected ones go to the workgroup kernel on the second stream -- batch_hip.hip batch_solve)
+    x3, y3, r3 = sw._solver.hip_batch_solve(l=L, u=U)           #  longest-expected ones go to the workgroup kernel on the second stream -- batch_hip.hip batch_solve)
     assert np.array_equal(x2, x3) and np.array_equal(y2, y3) and np.array_equal(r2[:, :7], r3[:, :7])      # same order, same routing: bit-identical
     assert np.array_equal(r1[:, 1], r2[:, 1]) and np.abs(x1 - x2).max() <= 1e-9 * (1 + np.abs(x2).max())  # another routing: the kernels agree to rounding
     assert np.array_equal(r1[:, 1], rd[:, 1]) and np.abs(x1 - xd).max() <= 1e-9 * (1 + np.abs(xd).max())
