@@ -982,42 +982,30 @@ __global__ __launch_bounds__(64 * kBatchWaveW, 1) void k_batch_wave(BatchParams 
     for (int s = 0; s < 4; s++) if (vm[s]) stage[rowm[s]] = v[s];
     wave_sync();
   };
+  // one group of 64 rows: steps [s0, s1) of an ELL array (values ev, 16-bit columns kv; a lane's entries beyond its row are padding: value 0, column 0)
+  // against the vector staged in LDS.  A runtime loop per group with nothing but loads and one FMA chain in it (first form: one unrolled sequence over
+  // all groups with the group picked by uniform branches per step -- the compiler turned that into a branch and two dependent LDS round trips per step,
+  // 6 of an iteration's 12 us).
+  auto ell_group = [&](const double *ev, const unsigned short *kv, int s0, int s1) {
+    // (blocks of four steps: four column reads and four value reads, then the four gathers, then the FMAs -- two LDS round trips per block; written as a
+    //  plain loop the compiler serialises column read -> gather -> FMA per step.  The steps of a last, partial block re-read the group's last step with
+    //  the value replaced by zero.)
+    double acc = 0.0;
+    for (int b0 = s0; b0 < s1; b0 += 4) {
+      int c[4]; double v[4], pv[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { const bool on = b0 + j < s1; const int si = on ? b0 + j : s1 - 1; c[j] = kv[si * 64 + L]; v[j] = ev[si * 64 + L]; v[j] = on ? v[j] : 0.0; }
+#pragma unroll
+      for (int j = 0; j < 4; j++) pv[j] = stage[c[j]];
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc = fma(v[j], pv[j], acc);
+    }
+    return acc;
+  };
   // out[slot] = (A v)_row for the n-vector v staged in LDS
-  auto mulA = [&](double (&out)[4]) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-    for (int h = 0; h < SA; h += 8) {
-      if (h < ae3) {
-        double pv[8], av[8];
-#pragma unroll
-        for (int s = 0; s < 8; s++) { const bool on = h + s < ae3; pv[s] = stage[on ? kA[(h + s) * 64 + L] : 0]; av[s] = on ? eA[(h + s) * 64 + L] : 0.0; }
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-          const int g = h + s;
-          if (g < ae0) a0 = fma(av[s], pv[s], a0); else if (g < ae1) a1 = fma(av[s], pv[s], a1); else if (g < ae2) a2 = fma(av[s], pv[s], a2); else if (g < ae3) a3 = fma(av[s], pv[s], a3);
-        }
-      }
-    }
-    out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
-  };
+  auto mulA = [&](double (&out)[4]) { out[0] = ell_group(eA, kA, 0, ae0); out[1] = ell_group(eA, kA, ae0, ae1); out[2] = ell_group(eA, kA, ae1, ae2); out[3] = ell_group(eA, kA, ae2, ae3); };
   // out[slot] = (A' w)_j for the m-vector w staged in LDS (original row numbering)
-  auto mulT = [&](double (&out)[2]) {
-    double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-    for (int h = 0; h < ST; h += 8) {
-      if (h < te1) {
-        double pv[8], av[8];
-#pragma unroll
-        for (int s = 0; s < 8; s++) { const bool on = h + s < te1; pv[s] = stage[on ? kT[(h + s) * 64 + L] : 0]; av[s] = on ? eT[(h + s) * 64 + L] : 0.0; }
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-          const int g = h + s;
-          if (g < te0) a0 = fma(av[s], pv[s], a0); else if (g < te1) a1 = fma(av[s], pv[s], a1);
-        }
-      }
-    }
-    out[0] = a0; out[1] = a1;
-  };
+  auto mulT = [&](double (&out)[2]) { out[0] = ell_group(eT, kT, 0, te0); out[1] = ell_group(eT, kT, te0, te1); };
   // out[slot] = ((P + sigma I) v)_j for the n-vector staged in LDS: B's entries with column < n, from memory (residuals and certificates only)
   auto mulP = [&](double (&out)[2]) {
 #pragma unroll
