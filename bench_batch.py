@@ -319,7 +319,7 @@ def main():
             out['roofline'] = {'bound': 'valu', 'kernel': 'k_batch_wave<32,24,120> (one wave per QP, eight QPs in flight per CU; the %d longest-expected QPs on k_batch_admm beside it)' % split,
                                'unit': 'ADMM iter/s per CU', 'achieved': 1.0 / t_cu, 'peak': 1.0 / floor_cu, 'frac': floor_cu / t_cu, 'traffic': None,
                                'model': 'fp64 FMAs of the two dense products of a solve (2 x 120^2) at 64 FMAs per cycle per CU = %.2f us per QP-iteration; measured %.2f us '
-                                        '(%.1f ADMM iterations per QP on average, kernel %.2f ms; ~4 500 wave instructions per QP-iteration: v_readlane broadcasts, LDS reads, ELL products, updates)'
+                                        '(%.1f ADMM iterations per QP on average, kernel %.2f ms; ~3 500 wave instructions per QP-iteration: v_readlane broadcasts, LDS reads, ELL products, updates)'
                                         % (1e6 * floor_cu, 1e6 * t_cu, iters_per_qp, 1e3 * kernel_s)}
         else:
           out['roofline'] = {'bound': 'latency', 'kernel': 'k_batch_admm<256,6,6,true,false,false,true,%d> (spectral direct solve)' % per_cu, 'unit': 'ADMM iter/s per resident QP',

@@ -386,9 +386,10 @@ typedef struct {
                                  cores (dense_hip.hip: a strided MFMA GEMM + block Gauss-Jordan inversion); 1: rocBLAS dgemm + rocSOLVER dpotrf / dpotri, loaded on
                                  demand (the route of rounds 3-5, kept for A/B runs; without the libraries osqp_setup falls back to plain Jacobi)            [setup] */
   OSQPInt batch_wave;         /* batch solves in the spectral form: one WAVE per problem, eight problems in flight per CU, the longest-expected problems on the
-                                 workgroup kernel beside it (batch_hip.hip k_batch_wave).  0 (default): for batches of at least 3072 problems, or 1536 with a
-                                 launch order from a previous call (measured, MPC batch: 4096 QPs 3.5 ms against 5.7, 2048 2.2 against 3.0 with history, 1024
-                                 2.1 against 1.6 -- below that a problem's own latency on one wave decides); 1: at every batch size; -1: never */
+                                 workgroup kernel beside it (batch_hip.hip k_batch_wave).  0 (default): for batches of at least 2048 problems, or 1280 with a
+                                 launch order from a previous call (measured, MPC batch, with a launch order: 4096 QPs 2.8 ms against 5.7, 2048 1.8 against
+                                 3.0, 1280 1.7 against 1.9, 1024 1.7 against 1.6; without: 2048 3.5 against 3.6, 1536 3.5 against 3.1 -- below that a
+                                 problem's own latency on one wave decides); 1: at every batch size; -1: never */
 } OSQPHipPolicy;
 void    osqp_hip_default_policy(OSQPHipPolicy *policy);
 OSQPInt osqp_hip_set_policy(OSQPSolver *solver, const OSQPHipPolicy *policy);

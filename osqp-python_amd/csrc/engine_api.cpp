@@ -293,7 +293,7 @@ void Engine::free_batch_direct() {
 // ------------------------------------------------------------------------------------------------ batch path, one wave per problem
 // engine.hpp BatchWave / backend.h BatchParams::wv_*.  Rows of A sorted by length (descending, stable): sorted position p -> lane p % 64, slot p / 64; a group
 // of 64 positions takes as many ELL steps as its longest (= first) row has entries.  A' (B's entries with column >= n) in the natural order of the variables.
-constexpr int kBatchWaveMin = 3072, kBatchWaveMinOrdered = 1536;      // smallest batches that take the wave-per-problem kernel by default (without / with a launch order)
+constexpr int kBatchWaveMin = 2048, kBatchWaveMinOrdered = 1280;      // smallest batches that take the wave-per-problem kernel by default (without / with a launch order)
 void Engine::free_batch_wave() {
   void *ptrs[] = {bwv_.Aidx, bwv_.Acol, bwv_.Tidx, bwv_.Tcol, bwv_.row, bwv_.queue};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
