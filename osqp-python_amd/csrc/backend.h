@@ -240,6 +240,13 @@ struct DevWb {
   double *cc = nullptr;          // [m] v - t0 (- w_a beta_a on dense row a)
   int *lidx = nullptr;           // [m] constraint row -> its index among the dense rows (rows[lidx[i]] = i; 0 on short rows)
   double *sig = nullptr;         // [r] sigma_a
+  // ... with the dense block held DENSE (dense = 1: cd even, the block at least half full): Ad [r][cd] row-major = A_d, zeros where A has no entry
+  // (filled by wb_refresh).  The two passes over the block are then plain dense kernels -- 8 bytes per entry, 16-byte loads, no index stream, no row
+  // slices: k_wbf_gd (column sums by row blocks into gp, fixed order) + k_wbf_gr (their sum + the short rows' and P's part from the small lists bq_*)
+  // in place of k_wbf_g, and k_wbf_td (two rows per workgroup against ud) in place of k_wbf_t.
+  int dense = 0, grb = 0;        // grb: row blocks of the column-sum pass
+  double *Ad = nullptr, *ud = nullptr, *ccd = nullptr, *gp = nullptr;     // ud [cd] = x_C compact (k_wbd_gemv), ccd [r] = cc on the dense rows, gp [grb][cd] partial column sums
+  int *bq_ptr = nullptr, *bq_idx = nullptr, *bq_col = nullptr;            // per dense column: its entries of B outside the dense rows (position in B.val, column of B)
 };
 
 // indices into Dev::res (results of the residual kernels, reduced on the device)

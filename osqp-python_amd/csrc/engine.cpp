@@ -160,7 +160,7 @@ void Engine::free_all() {
                   d_.wb.AL.rowptr, d_.wb.AL.col, d_.wb.AL.blkdesc, d_.wb.AL.runinfo, d_.wb.AL.val, d_.wb.ALT.rowptr, d_.wb.ALT.col, d_.wb.ALT.blkdesc, d_.wb.ALT.runinfo, d_.wb.ALT.val,
                   d_.wb.al_src, d_.wb.alt_src, d_.wb.islong, d_.wb.rows, d_.wb.WT, d_.wb.S, d_.wb.Sinv, d_.wb.g, d_.wb.h, d_.wb.Dinv0, d_.wb.colmap, d_.wb.W, d_.wb.pv, d_.wb.info, d_.wb.dbg, d_.wb.x.tile, d_.wb.x.tile2, d_.wb.x.partG, d_.wb.x.partZ, d_.wb.x.ls0, d_.wb.x.ls1, d_.wb.x.lz0, d_.wb.x.lz1, d_.wb.x.sinvp, d_.wb.x.sc_ptr, d_.wb.x.sc_row, d_.wb.x.sc_src, d_.wb.x.sc_val, d_.wb.x.bjj,
                   d_.ctl, d_.f1.blk, d_.f1.stream, d_.f1.cptr, d_.f1.prp, d_.f1.pcol, d_.f1.psrc, d_.f1.pval, d_.f1.va, d_.f1.fcol, d_.f1.fq, d_.f1.sp_ptr, d_.f1.spk, d_.f1.spill, d_pc_, d_pr_,
-                  d_.wb.gjwork, d_.wb.cc, d_.wb.sig, d_.wb.lidx, d_.wb.Bd.blkdesc, d_.wb.Bn.blkdesc, d_.wb.As.blkdesc, d_.wb.kind, d_.wb.dcol, d_.wb.srow, d_.wb.ssrc, d_.wb.sval, d_.wb.sg_ptr, d_.wb.sg_col, d_.wb.wv, d_.wb.den, d_.wb.beta, d_.wb.wbeta, d_.wb.rt, d_.wb.uz,
+                  d_.wb.gjwork, d_.wb.cc, d_.wb.sig, d_.wb.lidx, d_.wb.Ad, d_.wb.ud, d_.wb.ccd, d_.wb.gp, d_.wb.bq_ptr, d_.wb.bq_idx, d_.wb.bq_col, d_.wb.Bd.blkdesc, d_.wb.Bn.blkdesc, d_.wb.As.blkdesc, d_.wb.kind, d_.wb.dcol, d_.wb.srow, d_.wb.ssrc, d_.wb.sval, d_.wb.sg_ptr, d_.wb.sg_col, d_.wb.wv, d_.wb.den, d_.wb.beta, d_.wb.wbeta, d_.wb.rt, d_.wb.uz,
                   d_.kf.K.rowptr, d_.kf.K.col, d_.kf.K.blkdesc, d_.kf.K.runinfo, d_.kf.K.val, d_.kf.tptr, d_.kf.trow, d_.kf.ta, d_.kf.tb, d_.kf.rec};
   for (void *p : ptrs) if (p) be::dfree(d_, p);
   be::destroy(d_);

@@ -556,6 +556,22 @@ void Engine::build_wbf_views(const std::vector<int> &rbA, const std::vector<int>
   auto up_i = [&](const std::vector<int> &h) { int *p = dev_vec<int>(d_, h.size()); if (!h.empty()) be::h2d(d_, p, h.data(), sizeof(int) * h.size()); return p; };
   auto view = [&](const DevCsr &M, const std::vector<int> &desc) { DevCsr V = M; V.blkdesc = up_i(desc); V.nblk = (int)desc.size() / 4; V.blkwin = nullptr; V.lcol = nullptr; V.nwin = 0; V.single = 0; return V; };
   w.Bd = view(d_.B, bd); w.Bn = view(d_.B, bn); w.As = view(d_.A, as);
+  // the dense block held dense (backend.h DevWb::dense): OSQPHipPolicy::woodbury_fused = 2 keeps the CSR passes (A/B runs)
+  long nzd = 0;
+  for (int i = 0; i < m; i++) if (Arp[i + 1] - Arp[i] > kLongRow) for (int k = Arp[i]; k < Arp[i + 1]; k++) nzd += wb_kind_[Arj[k]] == 1;
+  const size_t cells = (size_t)w.r * w.cd;
+  if (pol_.woodbury_fused == 1 && w.cd % 2 == 0 && w.cd >= 512 && cells <= ((size_t)1 << 29) && 2 * (size_t)nzd >= cells) {
+    std::vector<int> qp(w.cd + 1, 0), qi, qc;
+    int c = 0;
+    for (int j = 0; j < n; j++) if (wb_kind_[j] == 1) {
+      for (int k = Brp[j]; k < Brp[j + 1]; k++) { const int col = Bj[k]; if (col >= n && Arp[col - n + 1] - Arp[col - n] > kLongRow) continue; qi.push_back(k); qc.push_back(col); }
+      qp[++c] = (int)qi.size();
+    }
+    w.bq_ptr = up_i(qp); w.bq_idx = up_i(qi); w.bq_col = up_i(qc);
+    w.grb = std::max(1, std::min(128, (w.r + 63) / 64));
+    w.Ad = dev_vec<double>(d_, cells); w.ud = dev_vec<double>(d_, w.cd); w.ccd = dev_vec<double>(d_, w.r); w.gp = dev_vec<double>(d_, (size_t)w.grb * w.cd);
+    w.dense = 1;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ setup

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void k_wbd_gemv(Dev d) {
     }
     for (; k < cd; k += kBlock) acc0 += row[k] * w.g[k];
     const double tot = block_sum((acc0 + acc1) + (acc2 + acc3), red);
-    if (threadIdx.x == 0) w.uz[w.dcol[a]] = tot;
+    if (threadIdx.x == 0) { w.uz[w.dcol[a]] = tot; if (w.ud) w.ud[a] = tot; }
   }
 }
 struct EWbdT : NoPrefetch {                                                // rho_a t_a = rho_a (beta_a + A_d[a] x_C) / (1 + rho_a sigma_a) = w_a (beta_a + A_d[a] x_C)
@@ -352,6 +352,7 @@ __global__ __launch_bounds__(kBlock) void k_wbf_beta(Dev d) {                // 
       double b = 0.0;
       for (int k = w.sg_ptr[a]; k < w.sg_ptr[a + 1]; k++) { const int j = w.sg_col[k]; b += w.sval[j] * w.Dinv0[j] * d.r[j]; }
       w.beta[a] = b; c -= w.wv[a] * b;
+      if (w.ccd) w.ccd[a] = c;
     }
     w.cc[i] = c;
   }
@@ -397,6 +398,83 @@ __global__ __launch_bounds__(kBlock) void k_wbf_t(Dev d) {
   GVec g{d.wb.uz};
   EWbfT e{{}, d.wb.beta, d.wb.wv, d.wb.sig, d.wb.rt, d.wb.rows, WbfRowUpd{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.ztg, d.alpha, d.theta}};
   process_rows<1>(d.wb.AL, g, e, lds);
+}
+// ---- the same two passes with the dense block held dense (backend.h DevWb::dense).  Ad [r][cd] row-major, cd even: every load is 16 bytes.
+typedef double wb_d2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(kBlock) void k_wbd_fillAd(Dev d) {            // Ad[a][colmap[j]] = A_L[a, j] on the dense columns
+  const DevWb &w = d.wb;
+  for (int a = blockIdx.x; a < w.r; a += gridDim.x)
+    for (int k = w.AL.rowptr[a] + threadIdx.x; k < w.AL.rowptr[a + 1]; k += kBlock) { const int c = w.colmap[w.AL.col[k]]; if (c >= 0) w.Ad[(size_t)a * w.cd + c] = w.AL.val[k]; }
+}
+// partial column sums  gp[rb][c] = sum over the rows a of block rb of Ad[a][c] cc_a:  workgroup (column tile of 2 kBlock columns, row block); a thread owns
+// two adjacent columns and walks the block's rows, eight 16-byte loads in flight; the row's weight is a uniform (scalar) load.  Rows in ascending order:
+// the sums do not depend on the launch geometry of anything else.
+constexpr int kWbGdRows = 8;
+__global__ __launch_bounds__(kBlock) void k_wbf_gd(Dev d) {
+  const DevWb &w = d.wb;
+  const int cd = w.cd, c0 = (blockIdx.x * kBlock + threadIdx.x) * 2, rb = blockIdx.y;
+  const int per = (w.r + w.grb - 1) / w.grb, a0 = rb * per, a1 = min(w.r, a0 + per);
+  if (c0 >= cd) return;
+  const double *col = w.Ad + c0;
+  double s0 = 0.0, s1 = 0.0;
+  int a = a0;
+  for (; a + kWbGdRows <= a1; a += kWbGdRows) {
+    wb_d2 v[kWbGdRows];
+#pragma unroll
+    for (int k = 0; k < kWbGdRows; k++) v[k] = *reinterpret_cast<const wb_d2 *>(col + (size_t)(a + k) * cd);
+#pragma unroll
+    for (int k = 0; k < kWbGdRows; k++) { const double c = w.ccd[a + k]; s0 = fma(v[k].x, c, s0); s1 = fma(v[k].y, c, s1); }
+  }
+  for (; a < a1; a++) { const wb_d2 v = *reinterpret_cast<const wb_d2 *>(col + (size_t)a * cd); const double c = w.ccd[a]; s0 = fma(v.x, c, s0); s1 = fma(v.y, c, s1); }
+  *reinterpret_cast<wb_d2 *>(w.gp + (size_t)rb * cd + c0) = wb_d2{s0, s1};
+}
+// g_C[c] = sigma x_j - q_j + (the entries of B's row j outside the dense rows: -(P + sigma I) x_g and the short rows' A' cc) + the row blocks' partial sums.
+// 64 columns per workgroup, four threads per column (row blocks rb = q, q + 4, ..; thread 0 of a column also takes the small list), summed in a fixed order.
+__global__ __launch_bounds__(kBlock) void k_wbf_gr(Dev d) {
+  static_assert(kBlock == 256, "four threads per column, 64 columns");
+  __shared__ double part[4][64];
+  const DevWb &w = d.wb;
+  const int cx = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + cx;
+  double s = 0.0;
+  if (c < w.cd) {
+    for (int rb = q; rb < w.grb; rb += 4) s += w.gp[(size_t)rb * w.cd + c];
+    if (q == 0) {
+      const int j = w.dcol[c];
+      double b = d.sigma * d.x[j] - d.q[j];
+      for (int k = w.bq_ptr[c]; k < w.bq_ptr[c + 1]; k++) { const int col = w.bq_col[k]; const double a = d.B.val[w.bq_idx[k]]; b += col < d.n ? -(a * d.xg[col]) : a * w.cc[col - d.n]; }
+      s += b;
+    }
+  }
+  part[q][cx] = s;
+  __syncthreads();
+  if (q == 0 && c < w.cd) w.g[c] = (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]);
+}
+// rho_a t_a and the z / y update of the dense rows (EWbfT) from  s_a = Ad[a] . x_C:  two rows per workgroup against one read of x_C
+__global__ __launch_bounds__(kBlock) void k_wbf_td(Dev d) {
+  __shared__ double red[2 * kWaves];
+  const DevWb &w = d.wb;
+  const int cd = w.cd;
+  EWbfT e{{}, w.beta, w.wv, w.sig, w.rt, w.rows, WbfRowUpd{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.ztg, d.alpha, d.theta}};
+  for (int a0 = blockIdx.x * 2; a0 < w.r; a0 += gridDim.x * 2) {
+    const bool two = a0 + 1 < w.r;
+    const double *r0 = w.Ad + (size_t)a0 * cd, *r1 = w.Ad + (size_t)(two ? a0 + 1 : a0) * cd;
+    double s0 = 0.0, s1 = 0.0;
+    int k = threadIdx.x * 2;
+    for (; k + 3 * 2 * kBlock < cd; k += 4 * 2 * kBlock) {
+      wb_d2 u[4], p[4], q[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) { u[t] = *reinterpret_cast<const wb_d2 *>(w.ud + k + t * 2 * kBlock); p[t] = *reinterpret_cast<const wb_d2 *>(r0 + k + t * 2 * kBlock); q[t] = *reinterpret_cast<const wb_d2 *>(r1 + k + t * 2 * kBlock); }
+#pragma unroll
+      for (int t = 0; t < 4; t++) { s0 = fma(p[t].x, u[t].x, s0); s0 = fma(p[t].y, u[t].y, s0); s1 = fma(q[t].x, u[t].x, s1); s1 = fma(q[t].y, u[t].y, s1); }
+    }
+    for (; k < cd; k += 2 * kBlock) {
+      const wb_d2 u = *reinterpret_cast<const wb_d2 *>(w.ud + k), p = *reinterpret_cast<const wb_d2 *>(r0 + k), q = *reinterpret_cast<const wb_d2 *>(r1 + k);
+      s0 = fma(p.x, u.x, s0); s0 = fma(p.y, u.y, s0); s1 = fma(q.x, u.x, s1); s1 = fma(q.y, u.y, s1);
+    }
+    const double t0 = block_sum(s0, red), t1 = block_sum(s1, red);
+    if (threadIdx.x == 0) { const double one[1] = {t0}; e(a0, one); }
+    if (threadIdx.x == 64 && two) { const double one[1] = {t1}; e(a0 + 1, one); }
+  }
 }
 __global__ __launch_bounds__(kBlock) void k_wbf_x(Dev d) {                   // u column by column, x~ = x_g + u, the x update (_osqp.py:660-668), the next PCG start
   const DevWb &w = d.wb;
@@ -471,6 +549,7 @@ void wb_refresh(Dev &d) {
   HIP_CHECK(hipSetDevice(d.device));
   if (d.wb.large) LAUNCH(k_wb_gather_large, d, d); else LAUNCH(k_wb_gather, d, d);
   if (d.wb.dual) LAUNCH(k_wbd_gather, d, d);
+  if (d.wb.dense) LAUNCH(k_wbd_fillAd, d, d);
   for (int k = 0; k < DevWb::kCache; k++) d.wb.cache_rho[k] = -1.0;      // new matrix values: no inverse computed for the old ones may be looked up (the probe would reject it; this saves the probe)
 }
 void wb_direct(Dev &d) { LAUNCH(k_wb_direct, d, d); }
@@ -493,9 +572,13 @@ bool wb_large_supported() { return true; }
 void wbf_iteration(Dev &d) {
   LAUNCH(k_wbf_r, d, d);
   hipLaunchKernelGGL(k_wbf_beta, dim3((d.m + kBlock - 1) / kBlock), dim3(kBlock), 0, st(d), d);
-  hipLaunchKernelGGL(k_wbf_g, dim3(kWbfGrid), dim3(kBlock), 0, st(d), d);
+  if (d.wb.dense) {
+    hipLaunchKernelGGL(k_wbf_gd, dim3((d.wb.cd / 2 + kBlock - 1) / kBlock, d.wb.grb), dim3(kBlock), 0, st(d), d);
+    hipLaunchKernelGGL(k_wbf_gr, dim3((d.wb.cd + 63) / 64), dim3(kBlock), 0, st(d), d);
+  } else hipLaunchKernelGGL(k_wbf_g, dim3(kWbfGrid), dim3(kBlock), 0, st(d), d);
   hipLaunchKernelGGL(k_wbd_gemv, dim3(std::min(d.wb.cd, 8 * kGrid)), dim3(kBlock), 0, st(d), d);
-  hipLaunchKernelGGL(k_wbf_t, dim3(kWbfGrid), dim3(kBlock), 0, st(d), d);
+  if (d.wb.dense) hipLaunchKernelGGL(k_wbf_td, dim3(std::min((d.wb.r + 1) / 2, 2 * kWbfGrid)), dim3(kBlock), 0, st(d), d);
+  else hipLaunchKernelGGL(k_wbf_t, dim3(kWbfGrid), dim3(kBlock), 0, st(d), d);
   hipLaunchKernelGGL(k_wbf_x, dim3(std::min((d.n + kBlock - 1) / kBlock, kGrid)), dim3(kBlock), 0, st(d), d);
   LAUNCH(k_wbf_s, d, d);
 }      // (own kernels: dense_hip.hip; the vendor route needs the libraries, checked where it is asked for)

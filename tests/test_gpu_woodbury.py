@@ -369,3 +369,35 @@ def test_fused_column_space_iteration_equals_the_unfused_one():
         r2 = mf.solve(raise_error=True)
     x2, y2, i2 = Oracle().setup(P, q2, A, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000).solve()
     assert _rel(r2.x, x2) < 5e-6 and abs(r2.info.obj_val - i2.obj_val) <= 1e-6 * (1 + abs(i2.obj_val))
+
+
+def test_fused_iteration_with_the_dense_block_held_dense():
+    """backend.h DevWb::dense: from 512 dense columns on (even count, block at least half full) the fused iteration's two passes over the dense block are
+    dense kernels on a row-major copy (k_wbf_gd + k_wbf_gr, k_wbf_td; OSQPHipStats::woodbury_fused_iteration = 2) instead of CSR passes
+    (OSQP_HIP_WOODBURY_FUSED=2 keeps those): the same iteration -- equal iteration counts, x / y to 1e-9, both equal to the oracle; the copy follows
+    osqp_update_data_mat."""
+    P, q, A, l, u = problems.lasso_qp(600, 1200)
+    xo, yo, io = Oracle().setup(P, q, A, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000).solve()
+    out = {}
+    for name, env in (('dense', {'OSQP_HIP_WOODBURY_FUSED': '1'}), ('csr', {'OSQP_HIP_WOODBURY_FUSED': '2'}), ('unfused', {'OSQP_HIP_WOODBURY_FUSED': '0'})):
+        with _env(**env):
+            m = osqp_amd.OSQP()
+            m.setup(P, q, A, l, u, eps_abs=1e-8, eps_rel=1e-8, verbose=False, max_iter=50000)
+            r = m.solve(raise_error=True)
+            out[name] = (m, r, m._solver.hip_stats())
+    (md, rd, sd), (mc, rc, sc), (mu, ru, su) = out['dense'], out['csr'], out['unfused']
+    assert sd['woodbury_fused_iteration'] == 2 and sc['woodbury_fused_iteration'] == 1 and su['woodbury_fused_iteration'] == 0 and sd['woodbury_dual_cols'] == 600
+    print('dense %d iterations (%d launches), csr %d (%d), unfused %d; |dx| %.2e %.2e' % (rd.info.iter, sd['kernel_launches'], rc.info.iter, sc['kernel_launches'], ru.info.iter, _rel(rd.x, rc.x), _rel(rd.x, ru.x)))
+    assert rd.info.iter == rc.info.iter == ru.info.iter
+    assert _rel(rd.x, rc.x) < 1e-9 and _rel(rd.y, rc.y) < 1e-8 and _rel(rd.x, ru.x) < 1e-9
+    assert _rel(rd.x, xo) < 5e-6 and _rel(rd.y, yo) < 2e-5
+    # new matrix values: the dense copy is refilled
+    rng = np.random.default_rng(3)
+    Ax = A.data * (1 + 0.02 * rng.standard_normal(A.nnz) * (np.abs(np.abs(A.data) - 1.0) > 1e-12))
+    import scipy.sparse as sp
+    A2 = sp.csc_matrix((Ax, A.indices, A.indptr), shape=A.shape)
+    with _env(OSQP_HIP_WOODBURY_FUSED='1'):
+        md.update(Ax=Ax)
+        r2 = md.solve(raise_error=True)
+    x2, y2, i2 = Oracle().setup(P, q, A2, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000).solve()
+    assert r2.info.status_val == 1 and _rel(r2.x, x2) < 5e-6 and abs(r2.info.obj_val - i2.obj_val) <= 1e-6 * (1 + abs(i2.obj_val))
