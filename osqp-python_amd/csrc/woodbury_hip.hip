@@ -282,6 +282,30 @@ __global__ __launch_bounds__(kBlock) void k_wbd_gemv(Dev d) {
   const DevWb &w = d.wb;
   if (d.flags[F_DONE]) return;
   const int cd = w.cd;
+  if ((cd & 1) == 0) {                                   // two rows per workgroup against one read of g, 16-byte loads (one row, 8-byte loads: 44.9 us at cd = 5 000)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    for (int a0 = blockIdx.x * 2; a0 < cd; a0 += gridDim.x * 2) {
+      const bool two = a0 + 1 < cd;
+      const double *r0 = w.Sinv + (size_t)a0 * cd, *r1 = w.Sinv + (size_t)(two ? a0 + 1 : a0) * cd;
+      double s0 = 0.0, s1 = 0.0;
+      int k = threadIdx.x * 2;
+      for (; k + 3 * 2 * kBlock < cd; k += 4 * 2 * kBlock) {
+        d2 u[4], p[4], q[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) { u[t] = *reinterpret_cast<const d2 *>(w.g + k + t * 2 * kBlock); p[t] = *reinterpret_cast<const d2 *>(r0 + k + t * 2 * kBlock); q[t] = *reinterpret_cast<const d2 *>(r1 + k + t * 2 * kBlock); }
+#pragma unroll
+        for (int t = 0; t < 4; t++) { s0 = fma(p[t].x, u[t].x, s0); s0 = fma(p[t].y, u[t].y, s0); s1 = fma(q[t].x, u[t].x, s1); s1 = fma(q[t].y, u[t].y, s1); }
+      }
+      for (; k < cd; k += 2 * kBlock) {
+        const d2 u = *reinterpret_cast<const d2 *>(w.g + k), p = *reinterpret_cast<const d2 *>(r0 + k), q = *reinterpret_cast<const d2 *>(r1 + k);
+        s0 = fma(p.x, u.x, s0); s0 = fma(p.y, u.y, s0); s1 = fma(q.x, u.x, s1); s1 = fma(q.y, u.y, s1);
+      }
+      const double t0 = block_sum(s0, red), t1 = block_sum(s1, red);
+      if (threadIdx.x == 0) { w.uz[w.dcol[a0]] = t0; if (w.ud) w.ud[a0] = t0; }
+      if (threadIdx.x == 64 && two) { w.uz[w.dcol[a0 + 1]] = t1; if (w.ud) w.ud[a0 + 1] = t1; }
+    }
+    return;
+  }
   for (int a = blockIdx.x; a < cd; a += gridDim.x) {
     const double *row = w.Sinv + (size_t)a * cd;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
@@ -429,15 +453,16 @@ __global__ __launch_bounds__(kBlock) void k_wbf_gd(Dev d) {
   *reinterpret_cast<wb_d2 *>(w.gp + (size_t)rb * cd + c0) = wb_d2{s0, s1};
 }
 // g_C[c] = sigma x_j - q_j + (the entries of B's row j outside the dense rows: -(P + sigma I) x_g and the short rows' A' cc) + the row blocks' partial sums.
-// 64 columns per workgroup, four threads per column (row blocks rb = q, q + 4, ..; thread 0 of a column also takes the small list), summed in a fixed order.
+// 16 columns per workgroup, sixteen threads per column (row blocks rb = q, q + 16, ..; thread 0 of a column also takes the small list), summed in a fixed
+// order.  (64 columns x 4 threads: 79 workgroups for 5 000 columns, 13.8 us.)
 __global__ __launch_bounds__(kBlock) void k_wbf_gr(Dev d) {
-  static_assert(kBlock == 256, "four threads per column, 64 columns");
-  __shared__ double part[4][64];
+  static_assert(kBlock == 256, "sixteen threads per column, 16 columns");
+  __shared__ double part[16][17];
   const DevWb &w = d.wb;
-  const int cx = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + cx;
+  const int cx = threadIdx.x & 15, q = threadIdx.x >> 4, c = blockIdx.x * 16 + cx;
   double s = 0.0;
   if (c < w.cd) {
-    for (int rb = q; rb < w.grb; rb += 4) s += w.gp[(size_t)rb * w.cd + c];
+    for (int rb = q; rb < w.grb; rb += 16) s += w.gp[(size_t)rb * w.cd + c];
     if (q == 0) {
       const int j = w.dcol[c];
       double b = d.sigma * d.x[j] - d.q[j];
@@ -447,7 +472,12 @@ __global__ __launch_bounds__(kBlock) void k_wbf_gr(Dev d) {
   }
   part[q][cx] = s;
   __syncthreads();
-  if (q == 0 && c < w.cd) w.g[c] = (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]);
+  if (q == 0 && c < w.cd) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += part[k][cx];
+    w.g[c] = t;
+  }
 }
 // rho_a t_a and the z / y update of the dense rows (EWbfT) from  s_a = Ad[a] . x_C:  two rows per workgroup against one read of x_C
 __global__ __launch_bounds__(kBlock) void k_wbf_td(Dev d) {
@@ -574,7 +604,7 @@ void wbf_iteration(Dev &d) {
   hipLaunchKernelGGL(k_wbf_beta, dim3((d.m + kBlock - 1) / kBlock), dim3(kBlock), 0, st(d), d);
   if (d.wb.dense) {
     hipLaunchKernelGGL(k_wbf_gd, dim3((d.wb.cd / 2 + kBlock - 1) / kBlock, d.wb.grb), dim3(kBlock), 0, st(d), d);
-    hipLaunchKernelGGL(k_wbf_gr, dim3((d.wb.cd + 63) / 64), dim3(kBlock), 0, st(d), d);
+    hipLaunchKernelGGL(k_wbf_gr, dim3((d.wb.cd + 15) / 16), dim3(kBlock), 0, st(d), d);
   } else hipLaunchKernelGGL(k_wbf_g, dim3(kWbfGrid), dim3(kBlock), 0, st(d), d);
   hipLaunchKernelGGL(k_wbd_gemv, dim3(std::min(d.wb.cd, 8 * kGrid)), dim3(kBlock), 0, st(d), d);
   if (d.wb.dense) hipLaunchKernelGGL(k_wbf_td, dim3(std::min((d.wb.r + 1) / 2, 2 * kWbfGrid)), dim3(kBlock), 0, st(d), d);
