@@ -316,7 +316,7 @@ def main():
             cus = 256
             t_cu = kernel_s / (float(table[:, 2].sum()) / cus)            # CU time per (problem, ADMM iteration)
             floor_cu = 2 * 120 * 120 / 64.0 / 2.4e9
-            out['roofline'] = {'bound': 'valu', 'kernel': 'k_batch_wave<32,24,120> (one wave per QP, eight QPs in flight per CU; the %d longest-expected QPs on k_batch_admm beside it)' % split,
+            out['roofline'] = {'bound': 'valu', 'kernel': 'k_batch_wave<120> (one wave per QP, eight QPs in flight per CU; the %d longest-expected QPs on k_batch_admm beside it)' % split,
                                'unit': 'ADMM iter/s per CU', 'achieved': 1.0 / t_cu, 'peak': 1.0 / floor_cu, 'frac': floor_cu / t_cu, 'traffic': None,
                                'model': 'fp64 FMAs of the two dense products of a solve (2 x 120^2) at 64 FMAs per cycle per CU = %.2f us per QP-iteration; measured %.2f us '
                                         '(%.1f ADMM iterations per QP on average, kernel %.2f ms; ~3 500 wave instructions per QP-iteration: v_readlane broadcasts, LDS reads, ELL products, updates)'

@@ -384,7 +384,7 @@ struct BatchParams {
   int *wv_queue = nullptr;       // device counter: the next position of the launch order not yet taken by a wave (zeroed before the launch)
 };
 constexpr int kBatchWaveW = 8;          // waves (= problems in flight) per workgroup of the wave-per-problem kernel; one workgroup per CU
-constexpr int kBatchWaveSA = 32, kBatchWaveST = 24;   // ELL steps of A / A' the kernel has registers for
+constexpr int kBatchWaveSA = 128, kBatchWaveST = 128;   // most ELL steps of A / A' (what decides is the LDS they take: be::batch_wave_lds_bytes)
 constexpr int kBatchSpecN = 128;        // the spectral form keeps K^-1 in registers: row i = thread / 2, 64 columns per thread
 constexpr double kBatchUnsolved = -1000.0;
 

@@ -939,7 +939,7 @@ __global__ __launch_bounds__(kBB, (DIRECT && kBB == 256 && EA <= 8) ? (SPEC ? SP
 #define WT_MARK(v) ((void)0)
 #define WT_ADD(acc, d) ((void)0)
 #endif
-template <int SA, int ST, int N8>
+template <int N8>
 __global__ __launch_bounds__(64 * kBatchWaveW, 1) void k_batch_wave(BatchParams P) {
   static_assert(N8 % 8 == 0 && N8 <= kBatchSpecN, "rows / columns of V in LDS (n rounded up; zero beyond n): compile-time -- the dense products are straight-line code");
   constexpr int S = N8 + 1;                            // row stride: odd (conflict-free column walks)
@@ -1407,8 +1407,8 @@ void batch_release(Dev &d) {
   if (d.bev1) { (void)hipEventDestroy(static_cast<hipEvent_t>(d.bev1)); d.bev1 = nullptr; }
 }
 bool batch_direct_selected(const BatchParams &p) { const BatchChoice c = choose_batch_variant(p); return c.dir256 || c.dir64; }
-// rows / columns of V in the wave kernel's LDS: compile-time, two instantiations (n <= 120: the MPC batch's 116 KB; n <= 128)
-static int batch_wave_n8(int n) { return n <= 120 ? 120 : 128; }
+// rows / columns of V in the wave kernel's LDS: compile-time, three instantiations (n <= 64: 33 KB; n <= 120: the MPC batch's 116 KB; n <= 128)
+static int batch_wave_n8(int n) { return n <= 64 ? 64 : (n <= 120 ? 120 : 128); }
 size_t batch_wave_lds_bytes(int n, int m, int steps) {
   if (n < 1 || n > kBatchSpecN || m < 1 || m > 256) return 0;
   const size_t n8 = (size_t)batch_wave_n8(n), S = n8 + 1, stg = (size_t)((n > m ? n : m) + 1) & ~(size_t)1;
@@ -1489,7 +1489,7 @@ int batch_solve(Dev &d, const BatchParams &p, void *stream) {
       if (split && hipStreamWaitEvent(st, ev1, 0) != hipSuccess) throw DeviceError("osqp_hip: batch stream join failed");
       spectral = true;
     };
-    if (batch_wave_n8(p.n) == 120) launch(&k_batch_wave<kBatchWaveSA, kBatchWaveST, 120>); else launch(&k_batch_wave<kBatchWaveSA, kBatchWaveST, 128>);
+    if (batch_wave_n8(p.n) == 64) launch(&k_batch_wave<64>); else if (batch_wave_n8(p.n) == 120) launch(&k_batch_wave<120>); else launch(&k_batch_wave<128>);
     if (!spectral) spectral = spec_launch(p, st);       // (no room for the wave form's LDS: the workgroup form)
   }
   BatchParams pm = p;

@@ -140,3 +140,34 @@ def test_wave_is_the_default_for_large_batches():
     xd, yd, rd = s._solver.hip_batch_solve(l=L, u=U)
     xw, yw, rw = _solver(P, q, A, L[0], U[0], wave=1)._solver.hip_batch_solve(l=L, u=U)
     assert (rd[:, 0] == 1).all() and np.array_equal(xd, xw) and np.array_equal(yd, yw) and np.array_equal(rd[:, :7], rw[:, :7])
+
+
+@pytest.mark.parametrize('shape', ['random30', 'banded60', 'mpc_small'])
+def test_wave_on_other_patterns(shape):
+    """other sizes and sparsity patterns than the MPC batch: n far below the padded size of the LDS copy of V, fewer rows than lane slots, rows of A of
+    mixed lengths (the ELL groups), per-problem q -- against the workgroup kernel and the oracle"""
+    B = 48
+    rng = np.random.default_rng(11)
+    if shape == 'mpc_small':
+        P, q, A, L, U = problems.mpc_batch(B, nx=3, nu=2, N=4)
+        Q = np.repeat(q[None, :], B, axis=0)
+    else:
+        P, q, A, l, u = problems.random_qp(30, 50, density=0.15, seed=5) if shape == 'random30' else problems.banded_qp(60, window=8, seed=5)
+        n, m = P.shape[0], A.shape[0]
+        l = np.maximum(l, -1e3); u = np.minimum(u, 1e3)
+        ineq = (u - l > 1e-3)[None, :]                                     # (equality rows stay equalities: the classes V was built for)
+        L = l[None, :] - 0.3 * rng.random((B, m)) * ineq; U = u[None, :] + 0.3 * rng.random((B, m)) * ineq
+        Q = q[None, :] + 0.1 * rng.standard_normal((B, n))
+    sw, ss = _solver(P, q, A, L[0], U[0], wave=1), _solver(P, q, A, L[0], U[0], wave=-1)
+    xw, yw, rw = sw._solver.hip_batch_solve(q=Q, l=L, u=U)
+    xs, ys, rs = ss._solver.hip_batch_solve(q=Q, l=L, u=U)
+    assert sw._solver.hip_stats()['batch_wave_split'] >= 0, 'the wave form does not apply to this pattern: the test would compare a kernel with itself'
+    assert ss._solver.hip_stats()['batch_wave_split'] == -1
+    assert np.array_equal(rw[:, 0], rs[:, 0]) and (rw[:, 0] == 1).all()
+    assert np.array_equal(rw[:, 1], rs[:, 1]) and np.array_equal(rw[:, 6], rs[:, 6])
+    assert np.abs(xw - xs).max() <= 1e-9 * (1 + np.abs(xs).max()) and np.abs(yw - ys).max() <= 1e-9 * (1 + np.abs(ys).max())
+    for i in (0, 17, 47):
+        xo, yo, io = Oracle().setup(P, Q[i], A, L[i], U[i], eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, adaptive_rho_interval=50, check_termination=25).solve()
+        # (the kernels' common trajectory may pass a termination check the oracle's misses by rounding, or the other way round: one check interval apart)
+        assert io.status_val == SOLVED and abs(int(rw[i, 1]) - io.iter) <= 25, (i, rw[i, 1], io.iter)
+        assert np.abs(xw[i] - xo).max() <= 1e-4 * (1 + np.abs(xo).max()) and abs(rw[i, 2] - io.obj_val) <= 1e-5 * (1 + abs(io.obj_val))
