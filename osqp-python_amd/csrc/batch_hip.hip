@@ -1028,15 +1028,20 @@ __global__ __launch_bounds__(64 * kBatchWaveW, 1) void k_batch_wave(BatchParams 
     int n8r = N8;
     asm volatile("" : "+s"(n8r));
     double a0[2] = {0.0, 0.0}, a1[2] = {0.0, 0.0};
+    double va[8], vb[8], na[8], nb[8];
+    auto load = [&](int j0, double (&ua)[8], double (&ub)[8]) {
 #pragma unroll
-    for (int j0 = 0; j0 < N8; j0 += 8) {
-      if (j0 < n8r) {
-        double va[8], vb[8];
+      for (int jj = 0; jj < 8; jj++) { ua[jj] = vc[(j0 + jj) * S]; ub[jj] = vc[(j0 + jj) * S + 64]; }
+    };
+    auto compute = [&](int j0, const double (&ua)[8], const double (&ub)[8]) {
 #pragma unroll
-        for (int jj = 0; jj < 8; jj++) { va[jj] = vc[(j0 + jj) * S]; vb[jj] = vc[(j0 + jj) * S + 64]; }
+      for (int jj = 0; jj < 8; jj++) { const double r = readlane_f64(rhs[j0 >> 6], (j0 & 63) + jj); a0[jj & 1] = fma(ua[jj], r, a0[jj & 1]); a1[jj & 1] = fma(ub[jj], r, a1[jj & 1]); }
+    };
+    load(0, va, vb);
 #pragma unroll
-        for (int jj = 0; jj < 8; jj++) { const double r = readlane_f64(rhs[j0 >> 6], (j0 & 63) + jj); a0[jj & 1] = fma(va[jj], r, a0[jj & 1]); a1[jj & 1] = fma(vb[jj], r, a1[jj & 1]); }
-      }
+    for (int j0 = 0; j0 < N8; j0 += 16) {
+      if (j0 < n8r) { if (j0 + 8 < N8) load(j0 + 8, na, nb); compute(j0, va, vb); }            // (the block's reads are the NEXT block's: one LDS latency behind eight steps of FMAs)
+      if (j0 + 8 < N8 && j0 + 8 < n8r) { if (j0 + 16 < N8) load(j0 + 16, va, vb); compute(j0 + 8, na, nb); }
     }
     o0 = a0[0] + a0[1]; o1 = a1[0] + a1[1];
   };
@@ -1046,15 +1051,20 @@ __global__ __launch_bounds__(64 * kBatchWaveW, 1) void k_batch_wave(BatchParams 
     int n8r = N8;
     asm volatile("" : "+s"(n8r));
     double a0[2] = {0.0, 0.0}, a1[2] = {0.0, 0.0};
+    double va[8], vb[8], na[8], nb[8];
+    auto load = [&](int k0, double (&ua)[8], double (&ub)[8]) {
 #pragma unroll
-    for (int k0 = 0; k0 < N8; k0 += 8) {
-      if (k0 < n8r) {
-        double va[8], vb[8];
+      for (int kk = 0; kk < 8; kk++) { ua[kk] = vr0[k0 + kk]; ub[kk] = vr1[k0 + kk]; }
+    };
+    auto compute = [&](int k0, const double (&ua)[8], const double (&ub)[8]) {
 #pragma unroll
-        for (int kk = 0; kk < 8; kk++) { va[kk] = vr0[k0 + kk]; vb[kk] = vr1[k0 + kk]; }
+      for (int kk = 0; kk < 8; kk++) { const double r = readlane_f64(k0 < 64 ? t0 : t1, (k0 & 63) + kk); a0[kk & 1] = fma(ua[kk], r, a0[kk & 1]); a1[kk & 1] = fma(ub[kk], r, a1[kk & 1]); }
+    };
+    load(0, va, vb);
 #pragma unroll
-        for (int kk = 0; kk < 8; kk++) { const double r = readlane_f64(k0 < 64 ? t0 : t1, (k0 & 63) + kk); a0[kk & 1] = fma(va[kk], r, a0[kk & 1]); a1[kk & 1] = fma(vb[kk], r, a1[kk & 1]); }
-      }
+    for (int k0 = 0; k0 < N8; k0 += 16) {
+      if (k0 < n8r) { if (k0 + 8 < N8) load(k0 + 8, na, nb); compute(k0, va, vb); }
+      if (k0 + 8 < N8 && k0 + 8 < n8r) { if (k0 + 16 < N8) load(k0 + 16, va, vb); compute(k0 + 8, na, nb); }
     }
     o0 = a0[0] + a0[1]; o1 = a1[0] + a1[1];
   };
