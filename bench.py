@@ -351,10 +351,12 @@ def measure_roofline(s, stats, n, mm, args):
                 # the m- and n-vector passes of the seven launches -- a whole ADMM iteration, no KB / KA launch beside it
                 wb_bytes = 2 * 8 * nzL + 8 * order * order + 8 * (12 * n + 16 * mm)
                 ms_it = s.hip_time_kernel(23, max(20, args.probe_reps // 4))
-                dense = int(stats.get('woodbury_fused_iteration', 0)) == 2
-                name = ('Woodbury direct mode in column space, FUSED ADMM iteration, dense block held dense: k_wbf_r + k_wbf_beta + k_wbf_gd + k_wbf_gr + k_wbd_gemv (T^-1, %d x %d) + k_wbf_td + k_wbf_x + k_wbf_s (eight launches, no KB / KA)' % (cd, cd)) if dense else \
+                fmode = int(stats.get('woodbury_fused_iteration', 0))
+                dense = fmode >= 2
+                name = ('Woodbury direct mode in column space, FUSED ADMM iteration, dense block held dense: k_wbf_rb + k_wbf_gd + k_wbf_gr + k_wbd_gemv (T^-1, %d x %d) + k_wbf_td + k_wbf_x + k_wbf_s2 (seven launches, no KB / KA)' % (cd, cd)) if fmode == 3 else \
+                       ('Woodbury direct mode in column space, FUSED ADMM iteration, dense block held dense: k_wbf_r + k_wbf_beta + k_wbf_gd + k_wbf_gr + k_wbd_gemv (T^-1, %d x %d) + k_wbf_td + k_wbf_x + k_wbf_s (eight launches, no KB / KA)' % (cd, cd)) if dense else \
                        ('Woodbury direct mode in column space, FUSED ADMM iteration: k_wbf_r + k_wbf_beta + k_wbf_g + k_wbd_gemv (T^-1, %d x %d) + k_wbf_t + k_wbf_x + k_wbf_s (seven launches, no KB / KA)' % (cd, cd))
-                probes = {name: {'ms': ms_it, 'ms_same_kernel_repeat': ms_it, 'bytes': wb_bytes, 'GBps': wb_bytes / (ms_it * 1e-3) / 1e9, 'launches': 8 if dense else 7}}
+                probes = {name: {'ms': ms_it, 'ms_same_kernel_repeat': ms_it, 'bytes': wb_bytes, 'GBps': wb_bytes / (ms_it * 1e-3) / 1e9, 'launches': 8 if fmode == 2 else 7}}
                 kb = {name: wb_bytes}
                 return probes, kb, wb_bytes, ms_it, name, 'k_wbf_g', survey_pcg_bytes, None, False, fused, 0
             ms_ch = s.hip_time_kernel(21, max(20, args.probe_reps // 4))

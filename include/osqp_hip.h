@@ -201,7 +201,8 @@ typedef struct {
   double f1_far_columns;      /* F1 form with per-block mixing: far columns (spill slots) over all row blocks of A (0: every block fits its window) */
   double woodbury_dual_cols;  /* device-factorised Woodbury form in column space (OSQPHipPolicy::woodbury_dual): order of its dense system = dense columns (0: row space) */
   double woodbury_fused_iteration; /* 1: the column-space direct mode runs its ADMM iteration fused -- seven launches, the dense block of A streamed twice instead of four times (no KB / KA launch);
-                                 2: ... with the block held dense (eight launches: the two passes are dense kernels without an index stream) */
+                                 2: ... with the block held dense (eight launches: the two passes are dense kernels without an index stream);
+                                 3: ... and the short rows / columns by one thread each (k_wbf_rb, k_wbf_s2: seven launches) */
   double woodbury_one_launch; /* 1: the Woodbury direct mode of a few dense rows runs ONE launch per ADMM iteration (k_wbz; woodbury_direct = 2 and OSQPHipPolicy::woodbury_fused = 1) */
   double kform_nnz;           /* K form: stored entries of the explicit reduced matrix K = P + sigma I + A' diag(rho) A (0: the form is not in use) */
   double batch_wave_split;    /* last batch solve: -1 = workgroup-per-problem kernels only; >= 0 = the wave-per-problem kernel ran, with this many of the

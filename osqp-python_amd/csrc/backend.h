@@ -245,6 +245,7 @@ struct DevWb {
   // slices: k_wbf_gd (column sums by row blocks into gp, fixed order) + k_wbf_gr (their sum + the short rows' and P's part from the small lists bq_*)
   // in place of k_wbf_g, and k_wbf_td (two rows per workgroup against ud) in place of k_wbf_t.
   int dense = 0, grb = 0;        // grb: row blocks of the column-sum pass
+  int thin = 0;                  // every row of B of a column that is not dense and every short row of A has <= 64 entries: k_wbf_rb / k_wbf_s2 (one thread per row)
   double *Ad = nullptr, *ud = nullptr, *ccd = nullptr, *gp = nullptr;     // ud [cd] = x_C compact (k_wbd_gemv), ccd [r] = cc on the dense rows, gp [grb][cd] partial column sums
   int *bq_ptr = nullptr, *bq_idx = nullptr, *bq_col = nullptr;            // per dense column: its entries of B outside the dense rows (position in B.val, column of B)
 };

@@ -874,7 +874,7 @@ int Engine::get_stats(OSQPHipStats *out) {
   out->kform_nnz = d_.kf.on ? (double)d_.kf.K.nnz : 0.0;
   out->batch_wave_split = (double)batch_wave_last_;
   out->woodbury_dual_cols = (d_.wb.on && d_.wb.dual) ? (double)d_.wb.cd : 0.0;
-  out->woodbury_fused_iteration = be::wbf_active(d_) ? (d_.wb.dense ? 2.0 : 1.0) : 0.0;
+  out->woodbury_fused_iteration = be::wbf_active(d_) ? (d_.wb.dense ? (d_.wb.thin ? 3.0 : 2.0) : 1.0) : 0.0;
   out->woodbury_one_launch = (be::wbx_active(d_) && d_.wb.x.one && !d_.wb.x.slots) ? 1.0 : 0.0;
   out->woodbury_rows = d_.wb.on ? d_.wb.r : 0; out->woodbury_direct = (d_.wb.on && d_.wb.exact) ? ((d_.wb.x.on) ? 2 : 1) : 0;
   out->windowed_blocks = d_.A.nwin + d_.B.nwin; out->row_blocks = d_.A.nblk + d_.B.nblk;

@@ -556,6 +556,10 @@ void Engine::build_wbf_views(const std::vector<int> &rbA, const std::vector<int>
   auto up_i = [&](const std::vector<int> &h) { int *p = dev_vec<int>(d_, h.size()); if (!h.empty()) be::h2d(d_, p, h.data(), sizeof(int) * h.size()); return p; };
   auto view = [&](const DevCsr &M, const std::vector<int> &desc) { DevCsr V = M; V.blkdesc = up_i(desc); V.nblk = (int)desc.size() / 4; V.blkwin = nullptr; V.lcol = nullptr; V.nwin = 0; V.single = 0; return V; };
   w.Bd = view(d_.B, bd); w.Bn = view(d_.B, bn); w.As = view(d_.A, as);
+  { int mx = 0;
+    for (int j = 0; j < n; j++) if (wb_kind_[j] != 1) mx = std::max(mx, Brp[j + 1] - Brp[j]);
+    for (int i = 0; i < m; i++) if (Arp[i + 1] - Arp[i] <= kLongRow) mx = std::max(mx, Arp[i + 1] - Arp[i]);
+    w.thin = (pol_.woodbury_fused == 1 && mx <= 64) ? 1 : 0; }
   // the dense block held dense (backend.h DevWb::dense): OSQPHipPolicy::woodbury_fused = 2 keeps the CSR passes (A/B runs)
   long nzd = 0;
   for (int i = 0; i < m; i++) if (Arp[i + 1] - Arp[i] > kLongRow) for (int k = Arp[i]; k < Arp[i + 1]; k++) nzd += wb_kind_[Arj[k]] == 1;

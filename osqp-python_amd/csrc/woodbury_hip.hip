@@ -528,6 +528,48 @@ __global__ __launch_bounds__(kBlock) void k_wbf_s(Dev d) {                   // 
     if (d.flags[F_STAT_MAX] < 1) d.flags[F_STAT_MAX] = 1;
   }
 }
+// ---- thin forms (DevWb::thin: every row of B of a column that is not dense and every short row of A has at most 64 entries): one thread per row, no LDS
+// staging -- the process_rows launches these replace cost their fixed ~12 us each for a few entries per row.  k_wbf_rb = k_wbf_r + k_wbf_beta in one
+// launch: a singleton column belongs to exactly one dense row, whose thread forms r_0 there itself.
+__device__ __forceinline__ double wbf_rcol(const Dev &d, int j) {
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = d.B.rowptr[j]; k < d.B.rowptr[j + 1]; k++) { const int c = d.B.col[k]; const double a = d.B.val[k]; if (c < d.n) s0 = fma(a, d.xg[c], s0); else s1 = fma(a, d.v[c - d.n] - d.t0[c - d.n], s1); }
+  return d.sigma * d.x[j] - d.q[j] - s0 + s1;
+}
+__global__ __launch_bounds__(kBlock) void k_wbf_rb(Dev d) {
+  const DevWb &w = d.wb;
+  const int top = d.n > d.m ? d.n : d.m;
+  for (int t = blockIdx.x * kBlock + threadIdx.x; t < top; t += gridDim.x * kBlock) {
+    if (t < d.n && w.kind[t] == 0) d.r[t] = wbf_rcol(d, t);
+    if (t < d.m) {
+      double c = d.v[t] - d.t0[t];
+      if (w.islong[t]) {
+        const int a = w.lidx[t];
+        double b = 0.0;
+        for (int k = w.sg_ptr[a]; k < w.sg_ptr[a + 1]; k++) { const int j = w.sg_col[k]; const double rj = wbf_rcol(d, j); d.r[j] = rj; b += w.sval[j] * w.Dinv0[j] * rj; }
+        w.beta[a] = b; c -= w.wv[a] * b;
+        if (w.ccd) w.ccd[a] = c;
+      }
+      w.cc[t] = c;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { d.flags[F_DONE] = 0; d.flags[F_ITERS] = 0; }
+}
+__global__ __launch_bounds__(kBlock) void k_wbf_s2(Dev d) {
+  const DevWb &w = d.wb;
+  WbfRowUpd up{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.ztg, d.alpha, d.theta};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < d.m; i += gridDim.x * kBlock) {
+    if (w.islong[i]) continue;
+    double s = 0.0;
+    for (int k = d.A.rowptr[i]; k < d.A.rowptr[i + 1]; k++) s = fma(d.A.val[k], d.xs[d.A.col[k]], s);
+    up(i, s);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    d.flags[F_DONE] = 1; d.flags[F_ITERS] = 1;
+    d.flags[F_STAT_SUM] += 1; d.flags[F_STAT_SUMSQ] += 1; d.flags[F_STAT_N] += 1;
+    if (d.flags[F_STAT_MAX] < 1) d.flags[F_STAT_MAX] = 1;
+  }
+}
 __global__ void k_wb_seq(double *g, int r) { for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < r; a += gridDim.x * blockDim.x) g[a] = 1.0 + 0.25 * (a % 7); }
 
 }  // namespace
@@ -600,8 +642,12 @@ void wb_apply(Dev &d, int parity, int direct) {
 
 bool wb_large_supported() { return true; }
 void wbf_iteration(Dev &d) {
-  LAUNCH(k_wbf_r, d, d);
-  hipLaunchKernelGGL(k_wbf_beta, dim3((d.m + kBlock - 1) / kBlock), dim3(kBlock), 0, st(d), d);
+  const int top = d.n > d.m ? d.n : d.m;
+  if (d.wb.thin) hipLaunchKernelGGL(k_wbf_rb, dim3(std::min((top + kBlock - 1) / kBlock, 4 * kGrid)), dim3(kBlock), 0, st(d), d);
+  else {
+    LAUNCH(k_wbf_r, d, d);
+    hipLaunchKernelGGL(k_wbf_beta, dim3((d.m + kBlock - 1) / kBlock), dim3(kBlock), 0, st(d), d);
+  }
   if (d.wb.dense) {
     hipLaunchKernelGGL(k_wbf_gd, dim3((d.wb.cd / 2 + kBlock - 1) / kBlock, d.wb.grb), dim3(kBlock), 0, st(d), d);
     hipLaunchKernelGGL(k_wbf_gr, dim3((d.wb.cd + 15) / 16), dim3(kBlock), 0, st(d), d);
@@ -610,7 +656,8 @@ void wbf_iteration(Dev &d) {
   if (d.wb.dense) hipLaunchKernelGGL(k_wbf_td, dim3(std::min((d.wb.r + 1) / 2, 2 * kWbfGrid)), dim3(kBlock), 0, st(d), d);
   else hipLaunchKernelGGL(k_wbf_t, dim3(kWbfGrid), dim3(kBlock), 0, st(d), d);
   hipLaunchKernelGGL(k_wbf_x, dim3(std::min((d.n + kBlock - 1) / kBlock, kGrid)), dim3(kBlock), 0, st(d), d);
-  LAUNCH(k_wbf_s, d, d);
+  if (d.wb.thin) hipLaunchKernelGGL(k_wbf_s2, dim3(std::min((d.m + kBlock - 1) / kBlock, 4 * kGrid)), dim3(kBlock), 0, st(d), d);
+  else LAUNCH(k_wbf_s, d, d);
 }      // (own kernels: dense_hip.hip; the vendor route needs the libraries, checked where it is asked for)
 
 // D0, W, S = W W' + 1 / rho_L, S^-1 -- all on the device (r up to kWbLargeMax); then the two numerical checks

@@ -373,7 +373,8 @@ def test_fused_column_space_iteration_equals_the_unfused_one():
 
 def test_fused_iteration_with_the_dense_block_held_dense():
     """backend.h DevWb::dense: from 512 dense columns on (even count, block at least half full) the fused iteration's two passes over the dense block are
-    dense kernels on a row-major copy (k_wbf_gd + k_wbf_gr, k_wbf_td; OSQPHipStats::woodbury_fused_iteration = 2) instead of CSR passes
+    dense kernels on a row-major copy (k_wbf_gd + k_wbf_gr, k_wbf_td) and the short rows / columns take one thread each (k_wbf_rb, k_wbf_s2;
+    OSQPHipStats::woodbury_fused_iteration = 3) instead of CSR passes
     (OSQP_HIP_WOODBURY_FUSED=2 keeps those): the same iteration -- equal iteration counts, x / y to 1e-9, both equal to the oracle; the copy follows
     osqp_update_data_mat."""
     P, q, A, l, u = problems.lasso_qp(600, 1200)
@@ -386,7 +387,7 @@ def test_fused_iteration_with_the_dense_block_held_dense():
             r = m.solve(raise_error=True)
             out[name] = (m, r, m._solver.hip_stats())
     (md, rd, sd), (mc, rc, sc), (mu, ru, su) = out['dense'], out['csr'], out['unfused']
-    assert sd['woodbury_fused_iteration'] == 2 and sc['woodbury_fused_iteration'] == 1 and su['woodbury_fused_iteration'] == 0 and sd['woodbury_dual_cols'] == 600
+    assert sd['woodbury_fused_iteration'] == 3 and sc['woodbury_fused_iteration'] == 1 and su['woodbury_fused_iteration'] == 0 and sd['woodbury_dual_cols'] == 600
     print('dense %d iterations (%d launches), csr %d (%d), unfused %d; |dx| %.2e %.2e' % (rd.info.iter, sd['kernel_launches'], rc.info.iter, sc['kernel_launches'], ru.info.iter, _rel(rd.x, rc.x), _rel(rd.x, ru.x)))
     assert rd.info.iter == rc.info.iter == ru.info.iter
     assert _rel(rd.x, rc.x) < 1e-9 and _rel(rd.y, rc.y) < 1e-8 and _rel(rd.x, ru.x) < 1e-9
