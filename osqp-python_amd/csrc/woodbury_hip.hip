@@ -10,6 +10,8 @@
 
 namespace osqp_hip {
 namespace be {
+// dense_hip.hip (declared here: hip_common.h is one of the two files the committed PMC summaries are stamped with)
+void dense_gemm_sym(void *stream, int N, int K, double alpha, const double *A, long as_i, long as_k, const double *B, long bs_k, long bs_j, double *C, long ld);
 
 namespace {
 
@@ -733,7 +735,7 @@ static void wb_factor_large(Dev &d) {
     LAUNCH(k_wbd_fillW, d, d);
     lap(1);
     // W is r x cd row-major = cd x r column-major (ld cd): T = W_cm W_cm' (cd x cd, inner dimension r)
-    if (!w.vendor) dense_gemm(st(d), r, r, w.r, 1.0, w.W, 1, r, w.W, r, 1, 0.0, w.S, r, 1);      // T(i, j) = sum_a W[a][i] W[a][j]
+    if (!w.vendor) dense_gemm_sym(st(d), r, w.r, 1.0, w.W, 1, r, w.W, r, 1, w.S, r);             // T(i, j) = sum_a W[a][i] W[a][j]: one triangle on the matrix cores, mirrored
     else if (L.dgemm(h, rocblas_operation_none, rocblas_operation_transpose, r, r, w.r, &one, w.W, r, w.W, r, &zero, w.S, r) != rocblas_status_success)
       throw DeviceError("osqp_hip: rocblas_dgemm failed");
     LAUNCH(k_wbd_adddiag, d, d);
@@ -741,7 +743,7 @@ static void wb_factor_large(Dev &d) {
   LAUNCH(k_wb_fillW, d, d);
   lap(1);
   // W is r x ct row-major = ct x r column-major (ld ct): S = W' W in the library's convention
-  if (!w.vendor) dense_gemm(st(d), r, r, ct, 1.0, w.W, ct, 1, w.W, 1, ct, 0.0, w.S, r, 1);        // S(a, b) = sum_j W[a][j] W[b][j]
+  if (!w.vendor) dense_gemm_sym(st(d), r, ct, 1.0, w.W, ct, 1, w.W, 1, ct, w.S, r);               // S(a, b) = sum_j W[a][j] W[b][j]
   else if (L.dgemm(h, rocblas_operation_transpose, rocblas_operation_none, r, r, ct, &one, w.W, ct, w.W, ct, &zero, w.S, r) != rocblas_status_success)
     throw DeviceError("osqp_hip: rocblas_dgemm failed");
   LAUNCH(k_wb_adddiag, d, d);
