@@ -56,6 +56,9 @@ def pmc_traffic(kernel, workload):
     import csv
     import glob
     import hashlib
+    if '+' in kernel:                                   # a launch group (the lasso's fused iteration): the sum over its kernels, None if any is missing
+        parts = [pmc_traffic(k, workload) for k in kernel.split('+')]
+        return None if any(p is None for p in parts) else float(sum(parts))
     h = hashlib.sha256()
     for f in ('pcg_hip.hip', 'hip_common.h'):
         with open(os.path.join(ROOT, 'osqp-python_amd', 'csrc', f), 'rb') as fh:
@@ -358,7 +361,8 @@ def measure_roofline(s, stats, n, mm, args):
                        ('Woodbury direct mode in column space, FUSED ADMM iteration: k_wbf_r + k_wbf_beta + k_wbf_g + k_wbd_gemv (T^-1, %d x %d) + k_wbf_t + k_wbf_x + k_wbf_s (seven launches, no KB / KA)' % (cd, cd))
                 probes = {name: {'ms': ms_it, 'ms_same_kernel_repeat': ms_it, 'bytes': wb_bytes, 'GBps': wb_bytes / (ms_it * 1e-3) / 1e9, 'launches': 8 if fmode == 2 else 7}}
                 kb = {name: wb_bytes}
-                return probes, kb, wb_bytes, ms_it, name, 'k_wbf_g', survey_pcg_bytes, None, False, fused, 0
+                group = 'k_wbf_rb+k_wbf_gd+k_wbf_gr+k_wbd_gemv+k_wbf_td+k_wbf_x+k_wbf_s2' if fmode == 3 else 'k_wbf_g'      # (roofline.traffic: PMC bytes summed over the launch group)
+                return probes, kb, wb_bytes, ms_it, name, group, survey_pcg_bytes, None, False, fused, 0
             ms_ch = s.hip_time_kernel(21, max(20, args.probe_reps // 4))
             name = ('Woodbury direct mode in column space, M^-1 = K^-1: k_wbd_beta + k_wbd_g + k_wbd_gemv (T^-1, %d x %d) + k_wbd_t + k_wbd_fin (five launches per ADMM iteration)' % (cd, cd)) if cd else \
                    'Woodbury direct mode, M^-1 = K^-1: k_wb_p1 + k_wb_gemv + k_wb_p3 (three launches per ADMM iteration)'
