@@ -202,7 +202,8 @@ def config_leg(which, args, settings, osqp_amd, problems, torch):
            'status': r.info.status, 'admm_iters': int(r.info.iter), 'obj_val': r.info.obj_val, 'preconditioner': h._solver.hip_preconditioner(),
            'pcg_iters_per_admm_iter': stats['pcg_iters_total'] / max(r.info.iter, 1), 'kernel_launches_per_solve': stats['kernel_launches'],
            'roofline': {'bound': 'hbm', 'kernel': dom, 'ms_per_launch_group': probes[dom]['ms'], 'launches': probes[dom].get('launches', 1), 'bytes': kb[dom],
-                        'achieved': probes[dom]['GBps'], 'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'frac': probes[dom]['GBps'] / HBM_PEAK_GBS}}
+                        'achieved': probes[dom]['GBps'], 'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'frac': probes[dom]['GBps'] / HBM_PEAK_GBS,
+                        'traffic': pmc_traffic(dom_kernel, 'lasso_5k_10k' if which == 'lasso' else 'portfolio_10k_100')}}      # (PMC bytes per launch group: profiles/*_pmc_<workload>_*)
     del h
     # CPU oracle: portfolio converges in seconds on the direct path; the lasso's dense block does not factorise in the budget: two PCG-path iterations
     out['cpu_baseline'] = cpu_sample(P, q, A, l, u, st, 20000, 0, 40.0) if which == 'portfolio' else cpu_sample(P, q, A, l, u, st, 2, 1, 40.0)
