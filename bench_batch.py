@@ -175,11 +175,14 @@ def measure_sharded_device(B, steps, warmup, rank, world, local, use_dist):
         per_rank_ms = [float(o.item()) for o in owns]
     el = float(el.item())
     # PERTURBED batches: every step solves NEW problems (x0 redrawn: other dynamics bounds) -- the launch order comes from the previous, different batch
-    pert = []; pert_solved = []
+    pert = []; pert_solved = []; pert_other = []
     for k in range(steps):
         _, _, _, Lk, Uk = problems.mpc_batch(B, seed=1000 + k)
         Lk_d, Uk_d = torch.tensor(Lk[lo:hi], device=dev), torch.tensor(Uk[lo:hi], device=dev)
         barrier(); tf = time.perf_counter(); tbk, okk = step(Lk_d, Uk_d); pert.append(1e3 * (time.perf_counter() - tf)); pert_solved.append(okk)
+        if okk < B:                                                              # (random x0 can make an MPC QP infeasible: e.g. seed 1004, problem 3251 -- the oracle says primal infeasible too)
+            st = tbk[:, 1].cpu().numpy().astype(int)
+            pert_other.append({'step': k, 'status_counts': {str(v): int((st == v).sum()) for v in sorted(set(st.tolist())) if v != 1}})
     # the launch alone, this rank's share: HIP events around the batch kernel on its stream (no gather, no host read of the table)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); sharded_kernel_only(s, Ld, Ud, rank, world); e1.record(); e1.synchronize()
@@ -207,7 +210,7 @@ def measure_sharded_device(B, steps, warmup, rank, world, local, use_dist):
             'n_ranks_seen': len(owners), 'per_rank_ms': [round(v, 3) for v in per_rank_ms], 'kernel_ms_rank0_share': kernel_ms, 'share_of_8_ms': share8, 'share_of_4_ms': shares.get(4), 'share_of_2_ms': shares.get(2),
             'first_call_ms': first_call_ms, 'first_batch_ms': sorted(nohist)[len(nohist) // 2], 'first_batch_ms_each': [round(v, 3) for v in nohist],
             'first_batch_what': 'warm handle, NO launch-order history (batch_reorder = 0: index order); first_call_ms = the handle\'s very first call, host-side preparation of the spectral form included',
-            'perturbed_ms': sorted(pert)[len(pert) // 2], 'perturbed_ms_each': [round(v, 3) for v in pert], 'perturbed_solved': pert_solved,
+            'perturbed_ms': sorted(pert)[len(pert) // 2], 'perturbed_ms_each': [round(v, 3) for v in pert], 'perturbed_solved': pert_solved, 'perturbed_other_statuses': pert_other,
             'perturbed_what': 'every step a batch of NEW problems (x0 redrawn, seeds 1000 + k); the launch order is the previous, different batch\'s', 'scaling': 'strong', 'admm_iters_total': float(tab[:, 2].sum()),
             'collective': 'all_gather (%s)' % ('RCCL' if use_dist else 'single process: none needed'), '_data': (P, q, A, L, U)}
 
