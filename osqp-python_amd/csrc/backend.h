@@ -154,7 +154,7 @@ constexpr int kWbMaxRows = 128;
 // mode is simply off), h = S^-1 g by a dense matrix-vector kernel (r^2 x 8 bytes per application).  Whether M = K (the direct mode) is
 // decided NUMERICALLY after every factorisation: M^-1 (K v) must reproduce a probe vector v to 1e-9.
 constexpr int kWbLargeMax = 16384;
-inline size_t wb_inverse_work(int n) { return (size_t)n * 64 * 2 + 64 * 64 + 8; }      // dense_hip.hip dense_spd_inverse: column panel, row panel, pivot block
+inline size_t wb_inverse_work(int n) { return (size_t)n * 64 * 3 + 2 * 64 * 64 + 8; }      // dense_hip.hip dense_spd_inverse: column panel, row panel, R, two pivot blocks
 // The direct mode in TWO launches per ADMM iteration (wbdirect_hip.hip): P diagonal, every short row of A has exactly one entry, n <= kWbxMaxN.
 // A workgroup owns kWbxCols consecutive columns and keeps its dense r x kWbxCols tile of A_L in LDS; the two global reductions of the
 // iteration (g = A_L D0^-1 r_0, z~_L = A_L x~) travel as per-workgroup partials, summed in index order by every consumer.

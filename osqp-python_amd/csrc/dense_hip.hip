@@ -10,9 +10,10 @@
 //                   reads are bank-conflict free (free-index-major rows of 80 doubles when the free index is contiguous in memory, K-major rows of 17
 //                   doubles when K is).  fp64 MFMA issues one 16x16x4 per 64 cycles and SIMD: the loop is bound by the matrix cores, not by LDS or L2.
 //   dense_spd_inverse   in-place inverse of an SPD matrix by BLOCK Gauss-Jordan elimination without pivoting (the pivots of an SPD matrix are positive):
-//                   per block step k (64 columns):  P = A_kk^-1 (one workgroup, Gauss-Jordan in LDS);  R = P A_k: ;  A_ij -= A_ik R_j  (i, j outside
-//                   block k: ONE rank-64 GEMM over the whole matrix -- the panels' block-k parts are zeroed in their copies);  A_ik = -A_ik P;
-//                   A_k: = R, A_kk = P.  All of the n^3 work is dense_gemm; 2 n^3 flops (no use of symmetry), ~6 launches per block step.
+//                   per block step k (64 columns):  P = A_kk^-1 (one workgroup, Gauss-Jordan in registers);  R = P A_k: ;  A_ij -= A_ik R_j  (i, j outside
+//                   block k: ONE rank-64 GEMM -- the panels' block-k parts are zeroed in their copies);  A_ik = -A_ik P;  A_k: = R, A_kk = P.  All of the
+//                   n^3 work is dense_gemm.  Second form (end of round 6): only the tiles on and above the diagonal are kept current (n^3 flops, half the
+//                   bytes) and the next pivot block is inverted on a second stream under the rank update: 17.3 -> 12.1 ms at order 5 000 (see the function).
 //                   Measured (MI355X, round 6): the GEMM forms the lasso's systems at 40 TFLOP/s (order 5 000, inner dimension 10 000: 12 ms) and 54 TFLOP/s
 //                   (order 10 000, inner 15 000: 55 ms; rocBLAS: 8.4 / 43 ms); the inverse takes 28.5 ms at order 5 000 and 121 ms at 10 000 (rocSOLVER
 //                   potrf + potri: 23 / 84 ms) with the pivot block inverted in LDS (221 us per block: 17.5 of the 28.5 ms) -- see k_gj_pivot for its register form.  Block steps of 128
@@ -32,7 +33,7 @@ constexpr int kGT = 64, kGK = 16;
 constexpr int kLdI = kGT + 16;      // free-index-contiguous operand: LDS image [k][i], 80 doubles per k (rows k and k + 1 fall on the two bank halves)
 constexpr int kLdK = kGK + 1;       // K-contiguous operand: LDS image [i][k], 17 doubles per i
 constexpr int kOpDoubles = (kGK * kLdI > kGT * kLdK) ? kGK * kLdI : kGT * kLdK;
-struct GemmArgs { int M, N, K; double alpha, beta; const double *A; long as_i, as_k; const double *B; long bs_k, bs_j; double *C; long cs_i, cs_j; int upper = 0; };      // upper: only the tiles on and above the diagonal (a symmetric product: dense_gemm_sym mirrors them)
+struct GemmArgs { int M, N, K; double alpha, beta; const double *A; long as_i, as_k; const double *B; long bs_k, bs_j; double *C; long cs_i, cs_j; int upper = 0; int skip = -1; };      // skip: the diagonal tile (skip, skip) is left alone (dense_spd_inverse updates it ahead of the others)      // upper: only the tiles on and above the diagonal (a symmetric product: dense_gemm_sym mirrors them)
 
 // AK / BK: the operand is contiguous along K in memory (else along its free index)
 template <bool AK, bool BK>
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(256) void k_dgemm(GemmArgs g) {
   __shared__ double As[2][kOpDoubles], Bs[2][kOpDoubles];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   if (g.upper && blockIdx.y > blockIdx.x) return;
+  if ((int)blockIdx.x == g.skip && (int)blockIdx.y == g.skip) return;
   const int i0 = blockIdx.y * kGT, j0 = blockIdx.x * kGT;
   const int rb = 32 * (w >> 1), cb = 32 * (w & 1), lj = l & 15, lk = l >> 4;
   v4d acc[2][2];
@@ -138,22 +140,42 @@ __global__ __launch_bounds__(256) void k_gj_pivot(const double *A, long ld, int 
   for (int q = 0; q < 16; q++) { const int i = g + 4 * q; if (i < nb && j < nb) P[i * kGjNb + j] = m[q]; }
   if (tid == 0 && !(pmin >= *minpiv)) *minpiv = pmin;
 }
-// Ck (n x 64, row-major) <- the column panel A[:, k0 .. k0 + nb) with the rows of block k zeroed
-__global__ __launch_bounds__(256) void k_gj_colpanel(const double *A, long ld, int n, int k0, int nb, double *Ck) {
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)n * kGjNb; e += (long)gridDim.x * 256) {
-    const int i = (int)(e / kGjNb), j = (int)(e - (long)i * kGjNb);
-    Ck[e] = (j < nb && (i < k0 || i >= k0 + nb)) ? A[(long)i * ld + k0 + j] : 0.0;
+// The panels of block step k, built from the UPPER triangle alone (tiles (i, j), i <= j, are the only ones the inverse keeps current; see dense_spd_inverse):
+//   Ck (n x 64, row-major)  = the column panel A[:, k0 .. k0 + nb) with block k's own rows zeroed: rows above the block are read where they lie, rows below it
+//                             are the transposed row panel (both blocks still unswept: the trailing matrix is symmetric);
+//   Rw (64 x n, row-major)  = the row panel A[k0 .. k0 + nb, :]: right of the block where it lies, left of it MINUS the transposed column panel (Gauss-Jordan
+//                             without pivoting keeps A_us = -A_su' between a swept block s and an unswept block u); block k's own columns zero.
+// One workgroup per 64 rows of Ck: the 64 x 64 tile goes through LDS so that the read and both writes are coalesced.
+__global__ __launch_bounds__(256) void k_gj_panels(const double *A, long ld, int n, int k0, int nb, double *Ck, double *Rw) {
+  __shared__ double T[kGjNb][kGjNb + 1];
+  const int tid = threadIdx.x, lo = tid & 63, hi = tid >> 6;
+  const int i0 = blockIdx.x * kGjNb, kb = k0 / kGjNb, t = blockIdx.x;
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const int h = hi + 4 * q;
+    if (t < kb) { const int il = h, j = lo; T[il][j] = (j < nb) ? A[(long)(i0 + il) * ld + k0 + j] : 0.0; }                              // (i0 + il < k0 <= n)
+    else if (t > kb) { const int il = lo, j = h; T[il][j] = (j < nb && i0 + il < n) ? A[(long)(k0 + j) * ld + i0 + il] : 0.0; }
+    else T[h][lo] = 0.0;
+  }
+  __syncthreads();
+  const double sg = t < kb ? -1.0 : 1.0;
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const int h = hi + 4 * q;
+    if (i0 + h < n) Ck[(long)(i0 + h) * kGjNb + lo] = T[h][lo];
+    if (i0 + lo < n) Rw[(long)h * n + i0 + lo] = sg * T[lo][h];
   }
 }
-// R's columns of block k <- 0 (the rank-nb update must leave block column k alone), after a copy of nothing: R holds P A_k: already
+// R's columns of block k <- 0 (the rank-nb update must leave block column k alone)
 __global__ __launch_bounds__(256) void k_gj_zero_cols(double *R, long ldr, int k0, int nb) {
   for (int e = blockIdx.x * 256 + threadIdx.x; e < nb * nb; e += gridDim.x * 256) { const int i = e / nb, j = e - i * nb; R[(long)i * ldr + k0 + j] = 0.0; }
 }
-// row panel: A[k0 + i][j] = R[i][j] outside block k, = P[i][j - k0] inside
+// row panel, the part in the upper triangle: A[k0 + i][j] = P[i][j - k0] inside block k, = R[i][j] right of it
 __global__ __launch_bounds__(256) void k_gj_rowpanel(double *A, long ld, int n, int k0, int nb, const double *R, long ldr, const double *P) {
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)nb * n; e += (long)gridDim.x * 256) {
-    const int i = (int)(e / n), j = (int)(e - (long)i * n);
-    A[(long)(k0 + i) * ld + j] = (j >= k0 && j < k0 + nb) ? P[i * kGjNb + (j - k0)] : R[(long)i * ldr + j];
+  const int w = n - k0;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)nb * w; e += (long)gridDim.x * 256) {
+    const int i = (int)(e / w), j = k0 + (int)(e - (long)i * w);
+    A[(long)(k0 + i) * ld + j] = (j < k0 + nb) ? P[i * kGjNb + (j - k0)] : R[(long)i * ldr + j];
   }
 }
 __global__ void k_set1(double *p, double v) { *p = v; }
@@ -193,24 +215,68 @@ void dense_gemm_sym(void *stream, int N, int K, double alpha, const double *A, l
   if (ak && bk) launch_gemm<true, true>(s, g); else if (ak) launch_gemm<true, false>(s, g); else if (bk) launch_gemm<false, true>(s, g); else launch_gemm<false, false>(s, g);
   hipLaunchKernelGGL(k_sym_mirror, dim3((N + 31) / 32, (N + 31) / 32), dim3(256), 0, s, C, ld, N);
 }
-// A (n x n, row-major, leading dimension ld, SPD) <- A^-1 in place; work: n x 64 + 64 x n + 64 x 64 + 1 doubles (device); *(work + that) ... see the
-// header of this file.  The smallest pivot any block saw is left in minpiv[0] (device): <= 0 (or NaN) means the matrix was not positive definite.
-size_t dense_spd_inverse_work(int n) { return (size_t)n * kGjNb * 2 + (size_t)kGjNb * kGjNb + 8; }
+// A (n x n, row-major, leading dimension ld, SPD) <- A^-1 in place; work: dense_spd_inverse_work(n) doubles (device).  The smallest pivot any block saw is
+// left in minpiv[0] (device): <= 0 (or NaN) means the matrix was not positive definite.
+//
+// Round 6, second form: ONE TRIANGLE and a pivot that runs AHEAD.  Gauss-Jordan without pivoting on a symmetric matrix keeps, between the swept blocks S and
+// the unswept blocks U,  A_SS and A_UU symmetric and A_US = -A_SU'  -- so the tiles on and above the diagonal determine the matrix at every step.  A block
+// step builds its two panels from those tiles (k_gj_panels), the rank-64 update touches the upper tiles only (half the flops, half the 2 x 8 n^2 bytes a step
+// moves -- the update is bandwidth-bound: 8 flop / byte), the lower triangle is mirrored once at the end (everything swept: symmetric).  The next pivot
+// block (k + 1, k + 1) gets its share of the update FIRST, in a launch of its own; its inversion (one workgroup, a chain of 64 dependent steps: 78 us)
+// then runs on a second stream UNDER the rank update of the other tiles instead of in front of the next step.  Pivot blocks alternate between two buffers.
+// (First form: full matrix, pivot in line: 17.3 ms at order 5 000, profiles/r06k_*.)
+size_t dense_spd_inverse_work(int n) { return (size_t)n * kGjNb * 3 + (size_t)kGjNb * kGjNb * 2 + 8; }
+namespace {
+struct GjAux { int dev = -1; hipStream_t s2 = nullptr; hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr}; };
+GjAux &gj_aux() {
+  static thread_local GjAux a;
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  if (a.dev != dev) {                                       // (one auxiliary stream + four events per host thread and device; never inside a capture: the factorisation is host-driven)
+    HIP_CHECK(hipStreamCreateWithFlags(&a.s2, hipStreamNonBlocking));
+    for (int q = 0; q < 2; q++) { HIP_CHECK(hipEventCreateWithFlags(&a.ready[q], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&a.done[q], hipEventDisableTiming)); }
+    a.dev = dev;
+  }
+  return a;
+}
+}  // namespace
 void dense_spd_inverse(void *stream, double *A, long ld, int n, double *work, double *minpiv) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  double *Ck = work, *R = Ck + (size_t)n * kGjNb, *P = R + (size_t)n * kGjNb;
+  double *Ck = work, *Rw = Ck + (size_t)n * kGjNb, *R = Rw + (size_t)n * kGjNb, *Pb = R + (size_t)n * kGjNb;
+  static const bool lookahead = []() { const char *e = std::getenv("OSQP_HIP_GJ_LOOKAHEAD"); return !(e && e[0] == '0'); }();
+  GjAux *aux = lookahead ? &gj_aux() : nullptr;
   hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, s, minpiv, 1e300);
-  const int gridp = std::min(4 * kGrid, (int)(((long)n * kGjNb + 255) / 256));
-  for (int k0 = 0; k0 < n; k0 += kGjNb) {
-    const int nb = std::min(kGjNb, n - k0);
-    hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(256), 0, s, A, ld, k0, nb, P, minpiv);
-    hipLaunchKernelGGL(k_gj_colpanel, dim3(gridp), dim3(256), 0, s, A, ld, n, k0, nb, Ck);
-    dense_gemm(s, nb, n, nb, 1.0, P, kGjNb, 1, A + (long)k0 * ld, ld, 1, 0.0, R, n, 1);                  // R = P A_k:
+  const int nblk = (n + kGjNb - 1) / kGjNb;
+  hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(256), 0, s, A, ld, 0, std::min(kGjNb, n), Pb, minpiv);
+  for (int kb = 0; kb < nblk; kb++) {
+    const int k0 = kb * kGjNb, nb = std::min(kGjNb, n - k0);
+    double *P = Pb + (size_t)(kb & 1) * kGjNb * kGjNb;
+    hipLaunchKernelGGL(k_gj_panels, dim3(nblk), dim3(256), 0, s, A, ld, n, k0, nb, Ck, Rw);
+    if (kb > 0 && aux) HIP_CHECK(hipStreamWaitEvent(s, aux->done[kb & 1], 0));                           // P of this block: inverted under the previous step's update
+    dense_gemm(s, nb, n, nb, 1.0, P, kGjNb, 1, Rw, n, 1, 0.0, R, n, 1);                                    // R = P A_k:
     hipLaunchKernelGGL(k_gj_zero_cols, dim3(16), dim3(256), 0, s, R, (long)n, k0, nb);
-    dense_gemm(s, n, n, nb, -1.0, Ck, kGjNb, 1, R, n, 1, 1.0, A, ld, 1);                                  // A_ij -= A_ik R_j outside block row / column k
-    dense_gemm(s, n, nb, nb, -1.0, Ck, kGjNb, 1, P, kGjNb, 1, 0.0, A + k0, ld, 1);                        // A_ik = -A_ik P  (block k's own rows: zero, rewritten below)
-    hipLaunchKernelGGL(k_gj_rowpanel, dim3(gridp), dim3(256), 0, s, A, ld, n, k0, nb, R, (long)n, P);
+    int skip = -1;
+    if (kb + 1 < nblk) {
+      // the next pivot block first, then its inversion beside the update of the rest
+      const int k1 = k0 + kGjNb, nb1 = std::min(kGjNb, n - k1);
+      double *Pn = Pb + (size_t)((kb + 1) & 1) * kGjNb * kGjNb;
+      dense_gemm(s, nb1, nb1, nb, -1.0, Ck + (size_t)k1 * kGjNb, kGjNb, 1, R + k1, n, 1, 1.0, A + (long)k1 * ld + k1, ld, 1);
+      skip = kb + 1;
+      if (aux) {
+        HIP_CHECK(hipEventRecord(aux->ready[kb & 1], s));
+        HIP_CHECK(hipStreamWaitEvent(aux->s2, aux->ready[kb & 1], 0));
+        hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(256), 0, aux->s2, A, ld, k1, nb1, Pn, minpiv);
+        HIP_CHECK(hipEventRecord(aux->done[(kb + 1) & 1], aux->s2));
+      } else hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(256), 0, s, A, ld, k1, nb1, Pn, minpiv);
+    }
+    { GemmArgs g{n, n, nb, -1.0, 1.0, Ck, kGjNb, 1, R, (long)n, 1, A, ld, 1};                             // A_ij -= A_ik R_j on the upper tiles outside block row / column k
+      g.upper = 1; g.skip = skip;
+      launch_gemm<true, false>(s, g); }
+    dense_gemm(s, k0, nb, nb, -1.0, Ck, kGjNb, 1, P, kGjNb, 1, 0.0, A + k0, ld, 1);                       // A_ik = -A_ik P  above the block
+    const int gridr = std::max(1, std::min(4 * kGrid, (int)(((long)nb * (n - k0) + 255) / 256)));
+    hipLaunchKernelGGL(k_gj_rowpanel, dim3(gridr), dim3(256), 0, s, A, ld, n, k0, nb, R, (long)n, P);
   }
+  hipLaunchKernelGGL(k_sym_mirror, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, s, A, ld, n);
 }
 
 }  // namespace be
