@@ -110,15 +110,41 @@ constexpr int kGjNb = 64;
 // elements (row k's register is picked by a select chain: the compiler refuses to unroll all 64 steps).  A block of fewer than 64 columns is padded
 // with the identity.  (First version: the block in LDS, sixteen elements per thread addressed through an integer division, two barriers per step --
 // 221 us per block, 17.5 of the 28.5 ms of an inversion of order 5 000: profiles/r06k_lasso_kernel_stats_before_pivot.csv.)
-__global__ __launch_bounds__(256) void k_gj_pivot(const double *A, long ld, int k0, int nb, double *P, double *minpiv) {
+// upd != 0: the block first receives its share of the CURRENT step's rank update,  A_kk -= Ck[k0 .., :] R[:, k0 ..]  (kc columns of the panel), in registers --
+// nothing else needs the updated block (the next step's panels leave block k out, its row panel write replaces it by P): the block's inversion then
+// depends on R alone and runs beside the rank update of the other tiles (dense_spd_inverse).  The wave priority is raised: the workgroup shares its CU
+// with GEMM waves, and its chain of 64 dependent steps is the critical path of a block step.
+__global__ __launch_bounds__(256) void k_gj_pivot(const double *A, long ld, int k0, int nb, double *P, double *minpiv, int upd, const double *Ck, const double *R, long ldr, int kc) {
   static_assert(kGjNb == 64, "thread layout: 64 columns x 4 row groups");
   __shared__ double rowb[2][kGjNb], colb[2][kGjNb];
   const int tid = threadIdx.x, j = tid & 63, g = tid >> 6;
   double m[16];
 #pragma unroll
   for (int q = 0; q < 16; q++) { const int i = g + 4 * q; m[q] = (i < nb && j < nb) ? A[(long)(k0 + i) * ld + k0 + j] : (i == j ? 1.0 : 0.0); }
+  if (upd) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ double sA[kGjNb][17], sB[16][kGjNb];
+    for (int c0 = 0; c0 < kc; c0 += 16) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int e = tid + 256 * q;
+        { const int il = e >> 4, cc = e & 15; sA[il][cc] = (il < nb && c0 + cc < kc) ? Ck[(long)(k0 + il) * kGjNb + c0 + cc] : 0.0; }
+        { const int cc = e >> 6, jj = e & 63; sB[cc][jj] = (jj < nb && c0 + cc < kc) ? R[(long)(c0 + cc) * ldr + k0 + jj] : 0.0; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int cc = 0; cc < 16; cc++) {
+        const double rv = sB[cc][j];
+#pragma unroll
+        for (int q = 0; q < 16; q++) m[q] = fma(-sA[g + 4 * q][cc], rv, m[q]);
+      }
+      __syncthreads();
+    }
+  }
   double pmin = 1e300;
-#pragma unroll 4
+  // (all 64 steps unrolled: the register that holds row k's element is then a compile-time index -- with the loop rolled it was picked, and written back,
+  //  through a 16-way select chain in every step: 78 us per block)
+#pragma clang loop unroll(full)
   for (int k = 0; k < kGjNb; k++) {
     const int b = k & 1, gk = k & 3, qk = k >> 2;
     if (g == gk) rowb[b][j] = m[qk];
@@ -133,8 +159,9 @@ __global__ __launch_bounds__(256) void k_gj_pivot(const double *A, long ld, int 
 #pragma unroll
     for (int q = 0; q < 16; q++) {
       const double ck = colb[b][g + 4 * q];
-      m[q] = (g == gk && q == qk) ? rk : ((j == k) ? -ck * pi : m[q] - ck * rk);
+      m[q] = (j == k) ? -ck * pi : m[q] - ck * rk;
     }
+    if (g == gk) m[qk] = rk;
   }
 #pragma unroll
   for (int q = 0; q < 16; q++) { const int i = g + 4 * q; if (i < nb && j < nb) P[i * kGjNb + j] = m[q]; }
@@ -165,10 +192,6 @@ __global__ __launch_bounds__(256) void k_gj_panels(const double *A, long ld, int
     if (i0 + h < n) Ck[(long)(i0 + h) * kGjNb + lo] = T[h][lo];
     if (i0 + lo < n) Rw[(long)h * n + i0 + lo] = sg * T[lo][h];
   }
-}
-// R's columns of block k <- 0 (the rank-nb update must leave block column k alone)
-__global__ __launch_bounds__(256) void k_gj_zero_cols(double *R, long ldr, int k0, int nb) {
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < nb * nb; e += gridDim.x * 256) { const int i = e / nb, j = e - i * nb; R[(long)i * ldr + k0 + j] = 0.0; }
 }
 // row panel, the part in the upper triangle: A[k0 + i][j] = P[i][j - k0] inside block k, = R[i][j] right of it
 __global__ __launch_bounds__(256) void k_gj_rowpanel(double *A, long ld, int n, int k0, int nb, const double *R, long ldr, const double *P) {
@@ -222,8 +245,8 @@ void dense_gemm_sym(void *stream, int N, int K, double alpha, const double *A, l
 // the unswept blocks U,  A_SS and A_UU symmetric and A_US = -A_SU'  -- so the tiles on and above the diagonal determine the matrix at every step.  A block
 // step builds its two panels from those tiles (k_gj_panels), the rank-64 update touches the upper tiles only (half the flops, half the 2 x 8 n^2 bytes a step
 // moves -- the update is bandwidth-bound: 8 flop / byte), the lower triangle is mirrored once at the end (everything swept: symmetric).  The next pivot
-// block (k + 1, k + 1) gets its share of the update FIRST, in a launch of its own; its inversion (one workgroup, a chain of 64 dependent steps: 78 us)
-// then runs on a second stream UNDER the rank update of the other tiles instead of in front of the next step.  Pivot blocks alternate between two buffers.
+// block (k + 1, k + 1) takes its share of the update inside the launch that inverts it (one workgroup, raised priority, a chain of 64 dependent steps) --
+// on a second stream, UNDER the rank update of the other tiles instead of in front of the next step.  Pivot blocks alternate between two buffers.
 // (First form: full matrix, pivot in line: 17.3 ms at order 5 000, profiles/r06k_*.)
 size_t dense_spd_inverse_work(int n) { return (size_t)n * kGjNb * 3 + (size_t)kGjNb * kGjNb * 2 + 8; }
 namespace {
@@ -247,27 +270,27 @@ void dense_spd_inverse(void *stream, double *A, long ld, int n, double *work, do
   GjAux *aux = lookahead ? &gj_aux() : nullptr;
   hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, s, minpiv, 1e300);
   const int nblk = (n + kGjNb - 1) / kGjNb;
-  hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(256), 0, s, A, ld, 0, std::min(kGjNb, n), Pb, minpiv);
+  hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(256), 0, s, A, ld, 0, std::min(kGjNb, n), Pb, minpiv, 0, nullptr, nullptr, 0L, 0);
   for (int kb = 0; kb < nblk; kb++) {
     const int k0 = kb * kGjNb, nb = std::min(kGjNb, n - k0);
     double *P = Pb + (size_t)(kb & 1) * kGjNb * kGjNb;
-    hipLaunchKernelGGL(k_gj_panels, dim3(nblk), dim3(256), 0, s, A, ld, n, k0, nb, Ck, Rw);
     if (kb > 0 && aux) HIP_CHECK(hipStreamWaitEvent(s, aux->done[kb & 1], 0));                           // P of this block: inverted under the previous step's update
-    dense_gemm(s, nb, n, nb, 1.0, P, kGjNb, 1, Rw, n, 1, 0.0, R, n, 1);                                    // R = P A_k:
-    hipLaunchKernelGGL(k_gj_zero_cols, dim3(16), dim3(256), 0, s, R, (long)n, k0, nb);
+    hipLaunchKernelGGL(k_gj_panels, dim3(nblk), dim3(256), 0, s, A, ld, n, k0, nb, Ck, Rw);              //  (behind the wait: that launch read the previous Ck and R)
+    dense_gemm(s, nb, n, nb, 1.0, P, kGjNb, 1, Rw, n, 1, 0.0, R, n, 1);                                    // R = P A_k:   (block k's own columns: zero, as in Rw)
     int skip = -1;
     if (kb + 1 < nblk) {
-      // the next pivot block first, then its inversion beside the update of the rest
+      // the next pivot block: updated and inverted by one workgroup beside the update of the rest
       const int k1 = k0 + kGjNb, nb1 = std::min(kGjNb, n - k1);
       double *Pn = Pb + (size_t)((kb + 1) & 1) * kGjNb * kGjNb;
-      dense_gemm(s, nb1, nb1, nb, -1.0, Ck + (size_t)k1 * kGjNb, kGjNb, 1, R + k1, n, 1, 1.0, A + (long)k1 * ld + k1, ld, 1);
       skip = kb + 1;
+      hipStream_t sp = s;
       if (aux) {
         HIP_CHECK(hipEventRecord(aux->ready[kb & 1], s));
         HIP_CHECK(hipStreamWaitEvent(aux->s2, aux->ready[kb & 1], 0));
-        hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(256), 0, aux->s2, A, ld, k1, nb1, Pn, minpiv);
-        HIP_CHECK(hipEventRecord(aux->done[(kb + 1) & 1], aux->s2));
-      } else hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(256), 0, s, A, ld, k1, nb1, Pn, minpiv);
+        sp = aux->s2;
+      }
+      hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(256), 0, sp, A, ld, k1, nb1, Pn, minpiv, 1, Ck, R, (long)n, nb);
+      if (aux) HIP_CHECK(hipEventRecord(aux->done[(kb + 1) & 1], aux->s2));
     }
     { GemmArgs g{n, n, nb, -1.0, 1.0, Ck, kGjNb, 1, R, (long)n, 1, A, ld, 1};                             // A_ij -= A_ik R_j on the upper tiles outside block row / column k
       g.upper = 1; g.skip = skip;
