@@ -47,6 +47,17 @@ def spmv_bytes(nnz, rows, cols):
     return 12 * nnz + 4 * (rows + 1) + 8 * cols + 8 * rows
 
 
+def pmc_sources(workload):
+    """The kernel sources a PMC summary of `workload` describes (profiles/summarize_pmc.py stamps their hash, pmc_traffic compares it): the PCG kernels and
+    the shared helpers always; the Woodbury forms' files for the configurations whose solves launch them."""
+    files = ['pcg_hip.hip', 'hip_common.h']
+    if workload.startswith('lasso'):
+        files.append('woodbury_hip.hip')
+    if workload.startswith('portfolio'):
+        files.append('wbdirect_hip.hip')
+    return files
+
+
 def pmc_traffic(kernel, workload):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summaries of THIS workload (profiles/*_pmc_<workload>_
     FETCH_SIZE.csv and ..._WRITE_SIZE.csv, produced by profiles/run_pmc.sh with one pass per counter -- PMC passes cannot run inside
@@ -60,7 +71,7 @@ def pmc_traffic(kernel, workload):
         parts = [pmc_traffic(k, workload) for k in kernel.split('+')]
         return None if any(p is None for p in parts) else float(sum(parts))
     h = hashlib.sha256()
-    for f in ('pcg_hip.hip', 'hip_common.h'):
+    for f in pmc_sources(workload):
         with open(os.path.join(ROOT, 'osqp-python_amd', 'csrc', f), 'rb') as fh:
             h.update(fh.read())
     sha = h.hexdigest()[:16]
@@ -70,7 +81,7 @@ def pmc_traffic(kernel, workload):
         if not files:
             return None
         rows = list(csv.DictReader(open(files[-1])))
-        # a summary is used only if it was taken of THESE kernel sources (profiles/summarize_pmc.py stamps the hash of pcg_hip.hip + hip_common.h as its
+        # a summary is used only if it was taken of THESE kernel sources (profiles/summarize_pmc.py stamps the hash of pmc_sources(workload) as its
         # last row): counters of an earlier state of the kernel are not reported as this run's traffic
         if not any(r['kernel'] == '__source__' and r['counter'] == sha for r in rows):
             return None

@@ -9,11 +9,17 @@ import collections
 import sys
 
 
-def source_sha16():
-    """what the counters describe: the hot-path kernel sources as they are in this tree (bench.py pmc_traffic refuses a summary taken of other code)"""
+def source_sha16(workload):
+    """what the counters describe: the kernel sources of this workload as they are in this tree (bench.py pmc_sources / pmc_traffic: a summary taken of other
+    code is refused)"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = ['pcg_hip.hip', 'hip_common.h']
+    if workload.startswith('lasso'):
+        files.append('woodbury_hip.hip')
+    if workload.startswith('portfolio'):
+        files.append('wbdirect_hip.hip')
     h = hashlib.sha256()
-    for f in ('pcg_hip.hip', 'hip_common.h'):
+    for f in files:
         with open(os.path.join(root, 'osqp-python_amd', 'csrc', f), 'rb') as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -37,5 +43,6 @@ with open(out, 'w') as g:
             mx = max(v)
             act = [x for x in v if x > 0.01 * mx] if mx > 0 else []
             g.write('%s,%s,%d,%.6g,%d,%.6g,%.6g\n' % (k, c, len(v), sum(v) / len(v), len(act), (sum(act) / len(act)) if act else 0.0, mx))
-    g.write('__source__,%s,0,0,0,0,0\n' % source_sha16())      # (last row: which kernel sources were measured)
+    wl = re.search(r'_pmc_(.+)_(FETCH_SIZE|WRITE_SIZE)\.csv$', os.path.basename(out))
+    g.write('__source__,%s,0,0,0,0,0\n' % source_sha16(wl.group(1) if wl else ''))      # (last row: which kernel sources were measured)
 print(open(out).read())
