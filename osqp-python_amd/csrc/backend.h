@@ -109,6 +109,7 @@ struct DevF1 {
   // read by F_{k+1}, three sets like the replicas (parity 0, parity 1 / r_0's slices, rhs's slices).  No atomics, fixed order: results do not
   // depend on scheduling, and every workgroup that recomputes a column obtains the same bits.  blk word 11 = the block's number of far columns.
   int mix = 0;
+  int wt = 0;                    // the launches' results are written through the XCD's L2 (pcg_hip.hip gst_): set while the working set fits the Infinity Cache
   int *fcol = nullptr, *fq = nullptr;   // fixed stride kF1MaxFar per block: far columns (ascending) as pairs {column, spk[column]}, and the spill slot of each
   int *sp_ptr = nullptr;         // [n + 1] spill slots by column (host-side order; kept for inspection)
   int *spk = nullptr;            // [n] one packed word per column: first slot << 6 | count  (the plan refuses columns with more than 63 slots)

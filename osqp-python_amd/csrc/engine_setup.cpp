@@ -335,6 +335,11 @@ void Engine::upload_f1(const F1Plan &pl) {
     f.mix = 1; f.fcol = up_i(fc2); f.fq = up_i(pl.fq); f.sp_ptr = up_i(pl.sp_ptr); f.spk = up_i(spk);
     f.nsp = pl.nsp; f.spill = dev_vec<double>(d_, 3 * (f.nsp + 2));
   }
+  { // write-through stores (DevF1::wt) while what a launch touches stays in the 256 MiB Infinity Cache: stream + vector arena + the m-vectors KA writes
+    const double mb = ((double)(pl.blk.size() / 16) * kF1StreamBytes + 8.0 * (7 + 3 * (double)pl.D) * (double)f.ns + 8.0 * 10 * (double)m) / (1024.0 * 1024.0);
+    const char *e = std::getenv("OSQP_HIP_F1_WT");
+    f.wt = e ? (e[0] != '0') : (mb <= 160.0);
+  }
   f.on = 1;
 }
 

@@ -721,7 +721,17 @@ __device__ __forceinline__ double f1_spill_sum(const double *sp, const int *spk,
 //  And: everything the F body reads of Dev (24 pointers / sizes) as ONE block of three s_load_dwordx16 behind one wait, instead of the compiler's fetches
 //  at first use (nine s_load -> wait -> vector-load rounds in the ISA of the load phase): at the head of the launch 12.4 -> 14.2 us per F launch, at the
 //  start of the F phase 13.7 us -- the just-in-time fetches overlap the issue of the vector loads, the block does not; 104 spilled SGPRs, 126 VGPRs.)
-template <int D, bool FIRST, bool MIX>
+// Stores of a launch's results.  What a launch writes is read by the NEXT launch on other XCDs, i.e. through memory, never from this XCD's L2 -- and the
+// end of a kernel waits until its dirty lines have been written back.  WT: relaxed agent-scope stores (global_store ... sc1: written through the L2 as they are
+// produced), so that the kernel's end finds nothing to write back: KA launch 12.8 -> 10.9 us, F launch 12.7 -> 12.4 us, configs[1] 44.5 -> 43.0 ms per cold solve.
+// Only while the working set sits in the Infinity Cache (DevF1::wt, Engine::upload_f1): at n = 1M, where the launch is bound by HBM bandwidth, the same
+// stores cost 4 - 6 us per launch (95 -> 100 us).  (Non-temporal stores -- the nt bit -- changed nothing: 12.55 us.)
+template <bool WT>
+__device__ __forceinline__ void gst_(double *p, double v) {
+  if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+#define gst gst_<WT>
+template <int D, bool FIRST, bool MIX, bool WT>
 __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool vec_only, const F1Scal sc, F1Lds &L, F1Stream &S, const F1Rec &rec0, const int par) {
   const DevF1 &f = d.f1;
   const int n = d.n, tid = threadIdx.x;
@@ -749,7 +759,7 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     double sn, rn, un;
     f1_upd(sc, mi, r, w, sp, sn, rn, un);
     const double pn = fma(sc.beta, sc.general ? pp : 0.0, mi * r);
-    xs_w[j] = fma(sc.alpha, pn, x); p_w[j] = pn; snew[j] = sn; rnxt[j] = rn;
+    gst(xs_w + j, fma(sc.alpha, pn, x)); gst(p_w + j, pn); gst(snew + j, sn); gst(rnxt + j, rn);
     g_acc += rn * un; rn_acc = nanmax(rn_acc, fabs(rn));
     return un;
   };
@@ -848,7 +858,7 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
           un = wm[u] * r0;
           if (wown[u]) {
             const int j = g0 + e;
-            rnxt[j] = r0; gptr(d.xsp)[j] = wx[u]; xs_w[j] = wpp[u];
+            gst(rnxt + j, r0); gst(gptr(d.xsp) + j, wx[u]); gst(xs_w + j, wpp[u]);
             g_acc += r0 * un; rn_acc = nanmax(rn_acc, fabs(r0));
           }
         } else {
@@ -873,7 +883,7 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
       if constexpr (FIRST) {
         const double r0 = wj;
         un = mi * r0;
-        rnxt[j] = r0; gptr(d.xsp)[j] = xs_r[j]; xs_w[j] = gptr(d.xg)[j];
+        gst(rnxt + j, r0); gst(gptr(d.xsp) + j, xs_r[j]); gst(xs_w + j, gptr(d.xg)[j]);
         g_acc += r0 * un; rn_acc = nanmax(rn_acc, fabs(r0));
       } else un = own_update(j, mi, rread[j], wj, sprev[j], p_r[j], xs_r[j]);
       if (!vec_only) L.uown[jj] = un;
@@ -967,14 +977,14 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
           double v = f1_segsum<8>(L.prod, cp0[u], cp1[u]);
           const int jo = a0 + c - cs0;
           if (jo >= 0 && jo < nown) v += L.puown[jo];         // this block owns the column: + (P + sigma I) u
-          rout[a0 + c] = v;
+          gst(rout + a0 + c, v);
         } else if constexpr (MIX) {
-          if (u == CW - 1 && c >= kFB && c - kFB < nfc) spnxt[fql] = f1_segsum<8>(L.prod, cp0[u], cp1[u]);      // a far column's sum: the block's spill slot for it
+          if (u == CW - 1 && c >= kFB && c - kFB < nfc) gst(spnxt + fql, f1_segsum<8>(L.prod, cp0[u], cp1[u]));      // a far column's sum: the block's spill slot for it
         }
       }
     }
-    for (int j = cov0 + tid; j < a0; j += kBlock) rout[j] = 0.0;             // the replica's gap up to the next window of this replica
-    for (int j = a0 + wl + tid; j < cov1; j += kBlock) rout[j] = 0.0;
+    for (int j = cov0 + tid; j < a0; j += kBlock) gst(rout + j, 0.0);             // the replica's gap up to the next window of this replica
+    for (int j = a0 + wl + tid; j < cov1; j += kBlock) gst(rout + j, 0.0);
     if constexpr (FIRST) {
       if (tid < nown) bn_acc = nanmax(bn_acc, fabs(MIX ? f1_w<D>(bv) + f1_spill_sum(spV, bsw, f1_spill_take(spV, bsw)) : f1_w<D>(bv)));
       for (int jj = tid + kBlock; jj < nown; jj += kBlock) {
@@ -1009,14 +1019,14 @@ __device__ __forceinline__ F1Rec f1_first_record(const int *blk, int nblk) {
 // D (the number of replica vectors, DevF1::D) is a TEMPLATE parameter of the kernels: a slot kernel that carries the bodies of all four
 // values pays for the three it never runs in every launch (the head of a launch is as long as the kernel's register / code footprint
 // makes it)
-template <int D, bool MIX>
+template <int D, bool MIX, bool WT>
 __device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const int cap, const int admm_par, const int probe, F1Lds &L, F1Stream &S, const F1Rec &rec0, const F1Fold &fold, const int par) {
   KT(0);
   F1Scal sc;
   if (!f1_fold_finish(d, k, admm_par, probe, fold, L.red, sc)) return false;
   const bool vec_only = !probe && k >= cap;                 // the last budgeted update: no operator apply follows
-  if (k == 0) f1_body<D, true, MIX>(d, k, vec_only, sc, L, S, rec0, par);
-  else f1_body<D, false, MIX>(d, k, vec_only, sc, L, S, rec0, par);
+  if (k == 0) f1_body<D, true, MIX, WT>(d, k, vec_only, sc, L, S, rec0, par);
+  else f1_body<D, false, MIX, WT>(d, k, vec_only, sc, L, S, rec0, par);
   return true;
 }
 // the stream of the workgroup's FIRST row block: its address depends on nothing but the block index, so it leaves at the head of the launch,
@@ -1039,7 +1049,7 @@ __device__ __forceinline__ void f1_stream_first(const unsigned char *stream, int
 // SCATTER_ONLY: the first launch of a chunk -- v, t0, x, x_g are in memory (a rho update, a warm start or the previous chunk left them): only
 // the transposed passes and the own-column terms run.  x~_prev is NOT advanced here (F_0's own lanes do that): this launch reads it for the
 // operands of P at columns other workgroups own.
-template <int D, bool SCATTER_ONLY, bool MIX>
+template <int D, bool SCATTER_ONLY, bool MIX, bool WT>
 __device__ __forceinline__ void f1_ka_body(const Dev &d, F1Lds &L, F1Stream &S, const F1Rec &rec0, const double theta) {
   const DevF1 &f = d.f1;
   const int tid = threadIdx.x;
@@ -1120,8 +1130,8 @@ __device__ __forceinline__ void f1_ka_body(const Dev &d, F1Lds &L, F1Stream &S, 
           if (!SCATTER_ONLY) {
             const double xt = wx[u];
             xn = alpha * xt + (1.0 - alpha) * wxo[u];                        // _osqp.py:664-668
-            gptr(d.dx)[j] = xn - wxo[u]; gptr(d.x)[j] = xn;
-            gptr(d.xg)[j] = xt + theta * (xt - wxp[u]);                            // next PCG start (Dev::xg); x~_prev moves on in F_0
+            gst(gptr(d.dx) + j, xn - wxo[u]); gst(gptr(d.x) + j, xn);
+            gst(gptr(d.xg) + j, xt + theta * (xt - wxp[u]));                            // next PCG start (Dev::xg); x~_prev moves on in F_0
           }
           L.uown[j - cs0] = sigma * xn - wq[u];
         }
@@ -1166,7 +1176,7 @@ __device__ __forceinline__ void f1_ka_body(const Dev &d, F1Lds &L, F1Stream &S, 
         const double dyi = erho * (zr - zn), yn = ey + dyi;                  // :698-703
         const double zg = ztil + theta * (ztil - ezt);                       // A x_g
         vi = erho * zn - yn; t0r = erho * zg;
-        gptr(d.y)[i] = yn; gptr(d.dy)[i] = dyi; gptr(d.z)[i] = zn; gptr(d.zt)[i] = ztil; gptr(d.v)[i] = vi; gptr(d.ztg)[i] = zg; gptr(d.t0)[i] = t0r;
+        gst(gptr(d.y) + i, yn); gst(gptr(d.dy) + i, dyi); gst(gptr(d.z) + i, zn); gst(gptr(d.zt) + i, ztil); gst(gptr(d.v) + i, vi); gst(gptr(d.ztg) + i, zg); gst(gptr(d.t0) + i, t0r);
       }
       L.tvec[tid] = vi;
     }
@@ -1183,7 +1193,7 @@ __device__ __forceinline__ void f1_ka_body(const Dev &d, F1Lds &L, F1Stream &S, 
         const double dyi = rho * (zr - zn), yn = yo + dyi;
         const double zg = ztil + theta * (ztil - gptr(d.zt)[i]);
         vi = rho * zn - yn;
-        gptr(d.y)[i] = yn; gptr(d.dy)[i] = dyi; gptr(d.z)[i] = zn; gptr(d.zt)[i] = ztil; gptr(d.v)[i] = vi; gptr(d.ztg)[i] = zg; gptr(d.t0)[i] = rho * zg;
+        gst(gptr(d.y) + i, yn); gst(gptr(d.dy) + i, dyi); gst(gptr(d.z) + i, zn); gst(gptr(d.zt) + i, ztil); gst(gptr(d.v) + i, vi); gst(gptr(d.ztg) + i, zg); gst(gptr(d.t0) + i, rho * zg);
       }
       L.tvec[row] = vi;
     }
@@ -1218,23 +1228,23 @@ __device__ __forceinline__ void f1_ka_body(const Dev &d, F1Lds &L, F1Stream &S, 
           double tv = cv[u], tt = f1_segsum<8>(L.prod, cp0[u], cp1[u]);
           const int jo = a0 + c - cs0;
           if (jo >= 0 && jo < nown) { tv += L.uown[jo]; tt += L.puown[jo]; }      // this block owns the column: + sigma x - q  resp.  + (P + sigma I) x_g
-          routV[a0 + c] = tv; routR[a0 + c] = tv - tt;                             // slices of rhs, and of r_0 = rhs - K x_g
+          gst(routV + a0 + c, tv); gst(routR + a0 + c, tv - tt);                             // slices of rhs, and of r_0 = rhs - K x_g
         } else if constexpr (MIX) {
-          if (u == CW - 1 && c >= kFB && c - kFB < nfc) { const double tv = cv[u], tt = f1_segsum<8>(L.prod, cp0[u], cp1[u]); spVw[fql] = tv; spR[fql] = tv - tt; }      // a far column: the block's spill slots
+          if (u == CW - 1 && c >= kFB && c - kFB < nfc) { const double tv = cv[u], tt = f1_segsum<8>(L.prod, cp0[u], cp1[u]); gst(spVw + fql, tv); gst(spR + fql, tv - tt); }      // a far column: the block's spill slots
         }
       }
     }
-    for (int j = cov0 + tid; j < a0; j += kBlock) { routV[j] = 0.0; routR[j] = 0.0; }      // the replicas' gaps up to the next window of this replica
-    for (int j = a0 + wl + tid; j < cov1; j += kBlock) { routV[j] = 0.0; routR[j] = 0.0; }
+    for (int j = cov0 + tid; j < a0; j += kBlock) { gst(routV + j, 0.0); gst(routR + j, 0.0); }      // the replicas' gaps up to the next window of this replica
+    for (int j = a0 + wl + tid; j < cov1; j += kBlock) { gst(routV + j, 0.0); gst(routR + j, 0.0); }
     if (sl + slots < per) __syncthreads();
   }
 }
 // KA of the slot machine in the F1 form: extrapolation weight, the body above, PCG statistics of the ADMM iteration that ends (as slot_ka)
-template <int D, bool MIX>
+template <int D, bool MIX, bool WT>
 __device__ __forceinline__ void f1_slot_ka(const Dev &d, F1Lds &L, F1Stream &S, const F1Rec &rec0, int used, int conv, int admm, int target, int rn_slot, int seq) {
   double theta = d.theta, rn_last = 0.0, bn_last = 0.0;
   if (!conv) { theta = cutoff_theta(d, rn_slot, L.red, rn_last, bn_last, admm); __syncthreads(); }      // (conv comes from the slot record: uniform)
-  f1_ka_body<D, false, MIX>(d, L, S, rec0, theta);
+  f1_ka_body<D, false, MIX, WT>(d, L, S, rec0, theta);
   if (blockIdx.x == 0) {
     if (!conv) {
       const double rn = rn_last, bn = bn_last;
@@ -1260,24 +1270,24 @@ __global__ __launch_bounds__(kBlock) void k_f1_refresh(Dev d) {
 }
 // timing probe: one F launch as a solve runs it -- the scalar fold of the previous launch's partials included -- with fixed alpha, beta
 // and no stopping test (mode 2; mode 1 skips the fold: what the launch costs without it)
-template <int D, bool MIX>
+template <int D, bool MIX, bool WT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_f1_probe(Dev d, int k, int mode) {
   __shared__ F1Lds lds;
   __shared__ F1Stream sbuf;
   const int par = k & 1;
   f1_stream_first(d.f1.stream, d.A.nblk, sbuf);
   const F1Fold fold = f1_fold_issue(gptr(d.part), par, mode);
-  f1_iteration<D, MIX>(d, k, 1 << 30, 0, mode, lds, sbuf, f1_first_record(d.f1.blk, d.A.nblk), fold, par);      // (the first block's record goes out ahead of the partials of the scalar fold: both latencies overlap)
+  f1_iteration<D, MIX, WT>(d, k, 1 << 30, 0, mode, lds, sbuf, f1_first_record(d.f1.blk, d.A.nblk), fold, par);      // (the first block's record goes out ahead of the partials of the scalar fold: both latencies overlap)
 }
 
 // timing probes of the KA body above (time_kernel 17 / 18)
-template <int D, bool MIX>
+template <int D, bool MIX, bool WT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_f1_ka_probe(Dev d, int scatter_only) {
   __shared__ F1Lds lds;
   __shared__ F1Stream sbuf;
   f1_stream_first(d.f1.stream, d.A.nblk, sbuf);
   const F1Rec rec0 = f1_first_record(d.f1.blk, d.A.nblk);
-  if (scatter_only) f1_ka_body<D, true, MIX>(d, lds, sbuf, rec0, d.theta); else f1_ka_body<D, false, MIX>(d, lds, sbuf, rec0, d.theta);
+  if (scatter_only) f1_ka_body<D, true, MIX, WT>(d, lds, sbuf, rec0, d.theta); else f1_ka_body<D, false, MIX, WT>(d, lds, sbuf, rec0, d.theta);
 }
 
 // The slot kernel of the F1 form: every launch of a chunk's string is this kernel (par: which of the two phase records it reads).  Every phase is
@@ -1296,7 +1306,7 @@ struct F1DevBlock { F1Head h; Dev d; };
 // (Per-block mixing, tried: the far lanes of the workgroup's first row block touching their lines at the head of the launch -- both parities, as LDS-direct
 //  loads into a scratch KB, so that the body's requests find them in this XCD's L2 instead of waiting for memory: the solve got SLOWER, 80 -> 95 ms on
 //  `bench.py --config mixed` (tools/mix_ab.py); the extra requests ahead of the fold's partials cost more than the late far lines do.)
-template <int D, bool MIX>
+template <int D, bool MIX, bool WT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_slot1(const F1DevBlock *__restrict__ blk, int par) {
   __shared__ F1Lds lds;
   __shared__ F1Stream sbuf;
@@ -1312,26 +1322,27 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   SlotState st = slot_read_scalar(R);
   if (st.ph == P_KB) {
     if (st.admm >= st.target) { st.ph = P_IDLE; f1_stream_wait(); slot_write(W, st); return; }
-    f1_ka_body<D, true, MIX>(d, lds, sbuf, rec0, 0.0);
+    f1_ka_body<D, true, MIX, WT>(d, lds, sbuf, rec0, 0.0);
     if (blockIdx.x == 0 && threadIdx.x == 0) { gptr(d.flags)[F_DONE] = 0; gptr(d.flags)[F_ITERS] = 0; }
     st.ph = P_F; st.k = 0;
   } else if (st.ph == P_F) {
-    if (f1_iteration<D, MIX>(d, st.k, st.cap, st.admm & 1, 0, lds, sbuf, rec0, fold, par)) {
+    if (f1_iteration<D, MIX, WT>(d, st.k, st.cap, st.admm & 1, 0, lds, sbuf, rec0, fold, par)) {
       if (st.k >= st.cap) { st.ph = P_KA; st.used = st.k; st.conv = 0; }      // stopped at the cap: the next launch runs KA
       else st.k += 1;
     } else {                                             // converged after k - 1 iterations (k = 1: the start met the tolerance): KA right here
       __syncthreads();
-      f1_slot_ka<D, MIX>(d, lds, sbuf, rec0, st.k - 1, 1, st.admm, st.target, 0, st.seq);
+      f1_slot_ka<D, MIX, WT>(d, lds, sbuf, rec0, st.k - 1, 1, st.admm, st.target, 0, st.seq);
       st.admm += 1; st.k = 0; st.ph = st.admm >= st.target ? P_IDLE : P_F;
     }
   } else if (st.ph == P_KA) {
-    f1_slot_ka<D, MIX>(d, lds, sbuf, rec0, st.used, st.conv, st.admm, st.target, par ^ 1, st.seq);
+    f1_slot_ka<D, MIX, WT>(d, lds, sbuf, rec0, st.used, st.conv, st.admm, st.target, par ^ 1, st.seq);
     st.admm += 1; st.k = 0; st.ph = st.admm >= st.target ? P_IDLE : P_F;
   } else f1_stream_wait();                               // (idle: nothing may be in flight when the workgroup's LDS is released)
   slot_write(W, st);
 }
 
 
+#undef gst
 // ---------------------------------------------------------------------------------------------- one launch per PCG iteration on the explicit K (K form)
 // backend.h DevKf.  Launch F_k of the PCG of one ADMM iteration (k = 0 .. iterations), exactly the F1 form's recurrences (above) with the operator
 // applied as ONE CSR product over K's row blocks (process_rows: any sparsity, no windows, no replicas):
@@ -1512,7 +1523,8 @@ void dev_release(Dev &d) {
 // the F1 kernels are templates on D (replica vectors) and MIX (per-block mixing: far columns / spill slots, backend.h DevF1::mix)
 template <class F>
 static void f1_dispatch(const Dev &d, F &&f) {
-  auto with_d = [&](auto Dc) { if (d.f1.mix) f(Dc, std::true_type{}); else f(Dc, std::false_type{}); };
+  auto with_m = [&](auto Dc, auto Mc) { if (d.f1.wt) f(Dc, Mc, std::true_type{}); else f(Dc, Mc, std::false_type{}); };
+  auto with_d = [&](auto Dc) { if (d.f1.mix) with_m(Dc, std::true_type{}); else with_m(Dc, std::false_type{}); };
   switch (d.f1.D) {
     case 1: with_d(std::integral_constant<int, 1>{}); break;
     case 2: with_d(std::integral_constant<int, 2>{}); break;
@@ -1525,10 +1537,10 @@ void slot_pair(Dev &d) {
   if (wbx_slots(d)) { wbx_slot_pair(d); return; }      // Woodbury direct mode: X, Y (wbdirect_hip.hip)
   if (d.f1.on) {
     const F1DevBlock *db = static_cast<const F1DevBlock *>(im(d).dev_block);      // (current as of the chunk's slot_begin / ctl_begin: dev_publish)
-    f1_dispatch(d, [&](auto Dc, auto Mc) {
-      constexpr int DD = decltype(Dc)::value; constexpr bool MM = decltype(Mc)::value;
-      hipLaunchKernelGGL((k_slot1<DD, MM>), dim3(kGrid), dim3(kBlock), 0, st(d), db, 0);
-      hipLaunchKernelGGL((k_slot1<DD, MM>), dim3(kGrid), dim3(kBlock), 0, st(d), db, 1);
+    f1_dispatch(d, [&](auto Dc, auto Mc, auto Wc) {
+      constexpr int DD = decltype(Dc)::value; constexpr bool MM = decltype(Mc)::value, WW = decltype(Wc)::value;
+      hipLaunchKernelGGL((k_slot1<DD, MM, WW>), dim3(kGrid), dim3(kBlock), 0, st(d), db, 0);
+      hipLaunchKernelGGL((k_slot1<DD, MM, WW>), dim3(kGrid), dim3(kBlock), 0, st(d), db, 1);
     });
   }
   else if (d.kf.on) { LAUNCH(k_slotk, d, d, 0); LAUNCH(k_slotk, d, d, 1); }
@@ -1571,10 +1583,10 @@ __global__ void k_slot_probe_f(int *slot, double *scal, int k0, int conv) {
   scal[S_TOL_NOW] = -1.0;
 }
 static void f1_probe_pair(Dev &d, int mode) {           // two consecutive F launches of the probe kernel (the double-buffered vectors alternate)
-  f1_dispatch(d, [&](auto Dc, auto Mc) {
-    constexpr int DD = decltype(Dc)::value; constexpr bool MM = decltype(Mc)::value;
-    hipLaunchKernelGGL((k_f1_probe<DD, MM>), dim3(kGrid), dim3(kBlock), 0, st(d), d, 2, mode);
-    hipLaunchKernelGGL((k_f1_probe<DD, MM>), dim3(kGrid), dim3(kBlock), 0, st(d), d, 3, mode);
+  f1_dispatch(d, [&](auto Dc, auto Mc, auto Wc) {
+    constexpr int DD = decltype(Dc)::value; constexpr bool MM = decltype(Mc)::value, WW = decltype(Wc)::value;
+    hipLaunchKernelGGL((k_f1_probe<DD, MM, WW>), dim3(kGrid), dim3(kBlock), 0, st(d), d, 2, mode);
+    hipLaunchKernelGGL((k_f1_probe<DD, MM, WW>), dim3(kGrid), dim3(kBlock), 0, st(d), d, 3, mode);
   });
 }
 float time_kernel(Dev &d, int which, int reps) {
@@ -1622,9 +1634,9 @@ float time_kernel(Dev &d, int which, int reps) {
       case 14: f1_probe_pair(d, 1); break;   // F1 form without the scalar fold at the head of the launch (two consecutive iterations)
       case 16: slot_pair(d); break;           // two F launches of the slot kernel itself (records set up by k_slot_probe_f below): what a launch costs inside a solve
       case 17: case 18:                      // KA of the F1 form (17) / the chunk's first launch, transposed passes only (18)
-        f1_dispatch(d, [&](auto Dc, auto Mc) {
-          constexpr int DD = decltype(Dc)::value; constexpr bool MM = decltype(Mc)::value;
-          hipLaunchKernelGGL((k_f1_ka_probe<DD, MM>), dim3(kGrid), dim3(kBlock), 0, st(d), d, (int)(which == 18));
+        f1_dispatch(d, [&](auto Dc, auto Mc, auto Wc) {
+          constexpr int DD = decltype(Dc)::value; constexpr bool MM = decltype(Mc)::value, WW = decltype(Wc)::value;
+          hipLaunchKernelGGL((k_f1_ka_probe<DD, MM, WW>), dim3(kGrid), dim3(kBlock), 0, st(d), d, (int)(which == 18));
         });
         break;
       case 21: HIP_CHECK(hipMemsetAsync(d.flags + F_DONE, 0, sizeof(int), st(d))); wb_apply(d, 0, 1); break;      // (the last kernel marks the solve as converged: cleared per repetition)     // Woodbury direct mode, device-factorised form: the three kernels of M^-1 = K^-1 (long rows, S^-1 product, transposed long rows + x~)
