@@ -296,6 +296,7 @@ struct Dev {
   // PCG start of the NEXT ADMM iteration: x~ extrapolated along the last step, xg = x~ + theta (x~ - x~_prev) (KA writes it, KB gathers it
   // and resets xs to it); ztg = A xg by linearity = z~ + theta (z~ - z~_prev), so that t0 = rho .* ztg keeps K xg = B [xg; t0] exact.
   double *xg = nullptr, *xsp = nullptr, *ztg = nullptr;
+  int wt = 0;                    // two-kernel form: results written through the XCD's L2 (pcg_hip.hip stw) -- set while matrices + vectors fit the Infinity Cache
   double theta = 0.9;            // extrapolation weight (OSQP_HIP_EXTRAP; 0 = start from the previous x~)
   double *zt = nullptr;          // z~ = A x~
   double *t0 = nullptr;          // rho .* z~  (so K x~ = B [x~; t0] needs no extra SpMV)

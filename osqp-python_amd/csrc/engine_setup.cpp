@@ -829,6 +829,11 @@ int Engine::setup(const OSQPCscMatrix *P, const double *q, const OSQPCscMatrix *
   d_.x = dv(n); d_.z = dv(m); d_.y = dv(m); d_.dx = dv(n); d_.dy = dv(m); d_.zt = dv(m); d_.t0 = dv(m); d_.v = dv(m);
   d_.xg = dv(n); d_.xsp = dv(n); d_.ztg = dv(m);
   d_.theta = pol_.extrap;                            // PCG start extrapolation (backend.h Dev::xg)
+  { // write-through result stores of the two-kernel form (Dev::wt): while A, B and the vectors of an iteration stay in the 256 MiB Infinity Cache
+    const double mb = (12.0 * ((double)d_.A.nnz + (double)d_.B.nnz) + 8.0 * (14.0 * n + 12.0 * m)) / (1024.0 * 1024.0);
+    const char *ev = std::getenv("OSQP_HIP_WT");
+    d_.wt = ev ? (ev[0] != '0') : (mb <= 160.0);
+  }
   d_.uu = dv(n); d_.w = dv(n); d_.t = dv(m); d_.uu2 = dv(n); d_.ms = dv(2 * (size_t)n);
   if (d_.f1.on) { const size_t ns = d_.f1.ns; double *va = d_.f1.va; d_.Minv = va; d_.xs = va + ns; d_.p = va + 2 * ns; d_.r = va + 3 * ns; d_.s = va + 5 * ns; }   // backend.h DevF1::va
   else { d_.r = dv(n); d_.p = dv(n); d_.s = dv(n); d_.Minv = dv(n); d_.xs = dv(n); }

@@ -9,6 +9,11 @@ namespace be {
 namespace {
 
 // ---------------------------------------------------------------------------------------------- hot-path kernels
+// A result store of the two-kernel form: written through the XCD's L2 (relaxed agent-scope store) when Dev::wt says the working set sits in the Infinity
+// Cache -- see gst_ below (F1 form, where the switch is a template parameter); here a wave-uniform branch per store.
+__device__ __forceinline__ void stw(int wt, double *p, double v) {
+  if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
 // KB ------------------------------------------------------------------------------------------
 struct GKb {
   const double *xg, *v, *t0; int n;      // (xg: the PCG start, Dev::xg; t0 = rho .* (A xg))
@@ -18,19 +23,19 @@ struct GKb {
   }
 };
 struct EKb {
-  const double *x, *q, *Minv; double *r, *uu; double sigma; const double *xg; double *xs; double g = 0, rn = 0, bn = 0; double px = 0, pq = 0, pm = 0, pg = 0;
+  const double *x, *q, *Minv; double *r, *uu; double sigma; const double *xg; double *xs; double g = 0, rn = 0, bn = 0; double px = 0, pq = 0, pm = 0, pg = 0; int wt = 0;
   __device__ __forceinline__ void prefetch(int j) { px = x[j]; pq = q[j]; pm = Minv[j]; pg = xg[j]; }
   __device__ __forceinline__ void operator()(int j, const double (&s)[2]) {
     const double rhs = sigma * px - pq + s[0];
     const double rr = rhs - s[1], u = pm * rr;
-    r[j] = rr; uu[j] = u; xs[j] = pg;           // x~ restarts from the extrapolated point (nobody gathers xs in this kernel)
+    stw(wt, r + j, rr); stw(wt, uu + j, u); stw(wt, xs + j, pg);           // x~ restarts from the extrapolated point (nobody gathers xs in this kernel)
     g += rr * u; rn = nanmax(rn, fabs(rr)); bn = nanmax(bn, fabs(rhs));
   }
 };
 __global__ __launch_bounds__(kBlock) void k_kb(Dev d) {
   __shared__ StreamLds<2> lds;
   GKb g{d.xg, d.v, d.t0, d.n};
-  EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma, d.xg, d.xs};
+  EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma, d.xg, d.xs}; e.wt = d.wt;
   process_rows<2>(d.B, g, e, lds);
   __syncthreads();
   const double G = block_sum(e.g, lds.red);
@@ -191,14 +196,14 @@ struct GSplitU {
   __device__ __forceinline__ void wprod(const Win &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
 };
 struct EK2F {
-  const double *u, *Minv; double *s, *ms; double beta = 0; int first = 0; double dl = 0, pu = 0, pm = 0, ps = 0;
+  const double *u, *Minv; double *s, *ms; double beta = 0; int first = 0; double dl = 0, pu = 0, pm = 0, ps = 0; int wt = 0;
   __device__ __forceinline__ void prefetch(int j) { pu = u[j]; pm = Minv[j]; ps = s[j]; }
   __device__ __forceinline__ void operator()(int j, const double (&sm)[1]) {
     const double w = sm[0], sn = first ? w : w + beta * ps;
     dl += w * pu;
     if (KNOCKED(32)) { if (sn == -1.2345e300) s[j] = sn; return; }
-    s[j] = sn;
-    ms[j] = pm * sn;                                                       // Minv .* s_k: the vector k_k1f applies A to
+    stw(wt, s + j, sn);
+    stw(wt, ms + j, pm * sn);                                                       // Minv .* s_k: the vector k_k1f applies A to
   }
 };
 // block reduction of three quantities (sum, max, sum) behind ONE barrier pair; sred needs 3 * kWaves doubles
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void k_k2f(Dev d, int k) {
   KT(0);
   const double *u = (k & 1) ? d.uu2 : d.uu;
   GSplitU g{u, d.t, d.n};
-  EK2F e{u, d.Minv, d.s, d.ms};
+  EK2F e{u, d.Minv, d.s, d.ms}; e.wt = d.wt;
   double dl_first = 0.0;
   if (!process_rows<1>(d.B, g, e, lds, PreK2F{d, k, &e, lds.red, &dl_first}, d.flags + F_DONE)) return;
   if (KNOCKED(64)) { if (e.dl == -1.2345e300) put_partial(d.part, SL_DELTA, e.dl); return; }
@@ -271,9 +276,9 @@ struct GMs {
   __device__ __forceinline__ void wprod(const Win &o, double a, double (&pr)[1]) const { pr[0] = a * o; }
 };
 struct EK1F {
-  const double *rho; double *t; double alpha = 0, pr = 0, pt = 0;
+  const double *rho; double *t; double alpha = 0, pr = 0, pt = 0; int wt = 0;
   __device__ __forceinline__ void prefetch(int i) { pr = rho[i]; pt = t[i]; }
-  __device__ __forceinline__ void operator()(int i, const double (&s)[1]) { t[i] = pt - alpha * pr * s[0]; }
+  __device__ __forceinline__ void operator()(int i, const double (&s)[1]) { stw(wt, t + i, pt - alpha * pr * s[0]); }
 };
 struct PreK1F {
   [[maybe_unused]] static constexpr int kTraceBase = 8;
@@ -314,7 +319,7 @@ struct PreK1F {
     if (live0) {
       const double pp_ = k == 0 ? u0 : u0 + beta * p0;
       const double rr_ = r0 - alpha * s0, un = m0 * rr_;
-      d.p[j0] = pp_; d.xs[j0] = x0 + alpha * pp_; d.r[j0] = rr_; uout[j0] = un;
+      stw(d.wt, d.p + j0, pp_); stw(d.wt, d.xs + j0, x0 + alpha * pp_); stw(d.wt, d.r + j0, rr_); stw(d.wt, uout + j0, un);
       gg += rr_ * un; rr = nanmax(rr, fabs(rr_));
     }
     if (has_vec) {
@@ -326,7 +331,7 @@ struct PreK1F {
         const double u = uin[j];
         const double pp_ = k == 0 ? u : u + beta * d.p[j];
         const double rr_ = d.r[j] - alpha * d.s[j], un = d.Minv[j] * rr_;
-        d.p[j] = pp_; d.xs[j] += alpha * pp_; d.r[j] = rr_; uout[j] = un;
+        stw(d.wt, d.p + j, pp_); stw(d.wt, d.xs + j, d.xs[j] + alpha * pp_); stw(d.wt, d.r + j, rr_); stw(d.wt, uout + j, un);
         gg += rr_ * un; rr = nanmax(rr, fabs(rr_));
       }
     }
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void k_k1f(Dev d, int i) {          // i >=
   }
   double g = 0, rn = 0;
   GMs gr{d.ms};
-  EK1F e{d.rho, d.t};
+  EK1F e{d.rho, d.t}; e.wt = d.wt;
   if (!process_rows<1>(d.A, gr, e, lds, PreK1F{d, k, has_vec, &e, lds.red, &g, &rn}, d.flags + F_DONE)) return;
   __syncthreads();
   block_sum_max(g, rn, lds.red);
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(kBlock) void k_k1f(Dev d, int i) {          // i >=
 
 // KA ------------------------------------------------------------------------------------------
 struct EKa {
-  const double *l, *u, *rho, *rho_inv; double *z, *y, *zt, *t0, *v, *dy; double alpha; double *ztg; double theta;
+  const double *l, *u, *rho, *rho_inv; double *z, *y, *zt, *t0, *v, *dy; double alpha; double *ztg; double theta; int wt = 0;
   double pl = 0, pu = 0, prho = 0, prinv = 0, pz = 0, py = 0, pzt = 0;
   __device__ __forceinline__ void prefetch(int i) { pl = l[i]; pu = u[i]; prho = rho[i]; prinv = rho_inv[i]; pz = z[i]; py = y[i]; pzt = zt[i]; }
   __device__ __forceinline__ void operator()(int i, const double (&s)[1]) {
@@ -367,7 +372,7 @@ struct EKa {
     const double zn = fmin(fmax(zr + prinv * py, pl), pu);                   // :674
     const double dyi = prho * (zr - zn), yn = py + dyi;                      // :698-703
     const double zg = ztil + theta * (ztil - pzt);                           // A xg (Dev::ztg)
-    y[i] = yn; dy[i] = dyi; z[i] = zn; zt[i] = ztil; v[i] = prho * zn - yn; ztg[i] = zg; t0[i] = prho * zg;
+    stw(wt, y + i, yn); stw(wt, dy + i, dyi); stw(wt, z + i, zn); stw(wt, zt + i, ztil); stw(wt, v + i, prho * zn - yn); stw(wt, ztg + i, zg); stw(wt, t0 + i, prho * zg);
   }
 };
 // The extrapolated PCG start is used after a solve that REACHED its tolerance -- and after a cut-off one only while the start
@@ -395,13 +400,13 @@ __global__ __launch_bounds__(kBlock) void k_ka(Dev d, int budget) {
   double theta = d.theta, rn_last = 0.0, bn_last = 0.0;
   if (!done && budget > 0) { theta = cutoff_theta(d, budget & 1, lds.red, rn_last, bn_last); __syncthreads(); }
   GVec g{d.xs};
-  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, theta};
+  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, theta}; e.wt = d.wt;
   process_rows<1>(d.A, g, e, lds);
   const int stride = gridDim.x * kBlock;
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) {    // _osqp.py:664-668
     const double xt = d.xs[j], xo = d.x[j], xn = d.alpha * xt + (1.0 - d.alpha) * xo;
-    d.dx[j] = xn - xo; d.x[j] = xn;
-    d.xg[j] = xt + theta * (xt - d.xsp[j]); d.xsp[j] = xt;                   // next PCG start (Dev::xg)
+    stw(d.wt, d.dx + j, xn - xo); stw(d.wt, d.x + j, xn);
+    stw(d.wt, d.xg + j, xt + theta * (xt - d.xsp[j])); stw(d.wt, d.xsp + j, xt);                   // next PCG start (Dev::xg)
   }
   if (blockIdx.x == 0) {                                                     // PCG statistics of this ADMM iteration
     if (!done && budget > 0) {            // did the last budgeted iteration reach the tolerance? (no K1 ran after it)
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
   if (st.ph == P_KB) {
     if (st.admm >= st.target) { st.ph = P_IDLE; slot_write(W, st); return; }
     GKb g{d.xg, d.v, d.t0, d.n};
-    EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma, d.xg, d.xs};
+    EKb e{d.x, d.q, d.Minv, d.r, d.uu, d.sigma, d.xg, d.xs}; e.wt = d.wt;
     process_rows_fd<2>(d.B, g, e, lds.kb, NoPre(), fd);
     __syncthreads();
     const double G = block_sum(e.g, lds.kb.red);
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(kBlock) void k_slot_b(Dev d) {
     const int k = st.k;
     const double *u = (k & 1) ? d.uu2 : d.uu;
     GSplitU g{u, d.t, d.n};
-    EK2F e{u, d.Minv, d.s, d.ms};
+    EK2F e{u, d.Minv, d.s, d.ms}; e.wt = d.wt;
     double dl_first = 0.0;
     if (!process_rows_fd<1>(d.B, g, e, lds.k2f, PreK2F{d, k, &e, lds.k2f.red, &dl_first}, fd)) {   // converged after k iterations
       st.ph = P_KA; st.used = k; st.conv = 1;
@@ -476,13 +481,13 @@ __device__ __forceinline__ void slot_ka(const Dev &d, L &lds, int used, int conv
   // (rn_slot: which of the two ||r|| partial buffers the last PCG launch wrote -- the parity of `used` in the two-kernel form, of the LAUNCH in the F1 form)
   if (!conv) { theta = cutoff_theta(d, rn_slot >= 0 ? rn_slot : (used & 1), lds.red, rn_last, bn_last, admm); __syncthreads(); }      // (conv comes from the slot record: uniform)
   GVec g{d.xs};
-  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, theta};
+  EKa e{d.l, d.u, d.rho, d.rho_inv, d.z, d.y, d.zt, d.t0, d.v, d.dy, d.alpha, d.ztg, theta}; e.wt = d.wt;
   process_rows_fd<1>(d.A, g, e, lds, NoPre(), fd);
   const int stride = gridDim.x * kBlock;
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < d.n; j += stride) {    // _osqp.py:664-668
     const double xt = d.xs[j], xo = d.x[j], xn = d.alpha * xt + (1.0 - d.alpha) * xo;
-    d.dx[j] = xn - xo; d.x[j] = xn;
-    d.xg[j] = xt + theta * (xt - d.xsp[j]); d.xsp[j] = xt;                   // next PCG start (Dev::xg)
+    stw(d.wt, d.dx + j, xn - xo); stw(d.wt, d.x + j, xn);
+    stw(d.wt, d.xg + j, xt + theta * (xt - d.xsp[j])); stw(d.wt, d.xsp + j, xt);                   // next PCG start (Dev::xg)
   }
   if (blockIdx.x == 0) {
     if (!conv) {
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(kBlock) void k_slot_a(Dev d) {
     } else {
       double g = 0, rn = 0;
       GMs gr{d.ms};
-      EK1F e{d.rho, d.t};
+      EK1F e{d.rho, d.t}; e.wt = d.wt;
       process_rows_fd<1>(d.A, gr, e, lds.k1f, PreK1F{d, k, has_vec, &e, lds.k1f.red, &g, &rn}, fd);
       __syncthreads();
       block_sum_max(g, rn, lds.k1f.red);
