@@ -178,6 +178,12 @@ __device__ __forceinline__ double partial_fold_sum(const PartRegs &r) { double v
 __device__ __forceinline__ double partial_fold_max(const PartRegs &r) { double v = 0; for (int k = 0; k < kPart; k++) v = nanmax(v, r.v[k]); return v; }
 __device__ __forceinline__ double partial_sum(const double *slot, double *sred) { return block_sum(partial_fold_sum(partial_load(slot)), sred); }
 __device__ __forceinline__ double partial_max(const double *slot, double *sred) { return block_max(partial_fold_max(partial_load(slot)), sred); }
+// A result store of a latency-bound launch (two-kernel form, one-launch Woodbury form): written through the XCD's L2 (relaxed agent-scope store) when Dev::wt says the working set sits in the Infinity
+// Cache -- pcg_hip.hip gst_ (F1 form, where the switch is a template parameter); here a wave-uniform branch per store.
+__device__ __forceinline__ void stw(int wt, double *p, double v) {
+  if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+// KB ------------------------------------------------------------------------------------------
 template <class P>
 __device__ __forceinline__ void put_partial(P part, int slot, double v) {
   if (threadIdx.x == 0) part[slot * kGrid + blockIdx.x] = v;

@@ -9,12 +9,6 @@ namespace be {
 namespace {
 
 // ---------------------------------------------------------------------------------------------- hot-path kernels
-// A result store of the two-kernel form: written through the XCD's L2 (relaxed agent-scope store) when Dev::wt says the working set sits in the Infinity
-// Cache -- see gst_ below (F1 form, where the switch is a template parameter); here a wave-uniform branch per store.
-__device__ __forceinline__ void stw(int wt, double *p, double v) {
-  if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
-}
-// KB ------------------------------------------------------------------------------------------
 struct GKb {
   const double *xg, *v, *t0; int n;      // (xg: the PCG start, Dev::xg; t0 = rho .* (A xg))
   __device__ __forceinline__ void operator()(int c, double a, double (&pr)[2]) const {
