@@ -47,6 +47,30 @@ def spmv_bytes(nnz, rows, cols):
     return 12 * nnz + 4 * (rows + 1) + 8 * cols + 8 * rows
 
 
+def device_state(local):
+    """What the bench saw of the GPU right behind its timed region (box-to-box drift of a few per cent shows up in the launch times: round-5 verdict, item 7):
+    the device's name / CU count / nominal clock from the runtime, and the current clocks, performance level and power from rocm-smi (None where the tool is
+    absent or says nothing parseable).  Reporting only: nothing is set."""
+    import shutil
+    import subprocess
+    out = {}
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(local)
+        out.update({'name': p.name, 'cus': int(p.multi_processor_count), 'nominal_clock_mhz': getattr(p, 'clock_rate', 0) / 1e3 or None, 'hbm_gib': round(p.total_memory / 2**30, 1)})
+    except Exception as e:          # noqa: BLE001
+        out['error'] = repr(e)
+    smi = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+    try:
+        r = subprocess.run([smi, '-d', str(local), '--showclocks', '--showperflevel', '--showpower', '--json'], capture_output=True, text=True, timeout=20)
+        js = json.loads(r.stdout[r.stdout.index('{'):]) if '{' in r.stdout else {}
+        card = next(iter(js.values())) if js else {}
+        out['rocm_smi'] = {k: v for k, v in card.items() if any(t in k.lower() for t in ('sclk', 'mclk', 'fclk', 'socclk', 'performance', 'power'))} or None
+    except Exception as e:          # noqa: BLE001
+        out['rocm_smi'] = None; out['rocm_smi_error'] = repr(e)[:120]
+    return out
+
+
 def pmc_sources(workload):
     """The kernel sources a PMC summary of `workload` describes (profiles/summarize_pmc.py stamps their hash, pmc_traffic compares it): the PCG kernels and
     the shared helpers always; the Woodbury forms' files for the configurations whose solves launch them."""
@@ -558,6 +582,7 @@ def main():
     if rank == 0:
         mm = len(l)
         s = m._solver
+        dev_state = None if hostsim else device_state(local)
         if hostsim:
             probes = kb = dom = dom_kernel = streamed = None; pcg_bytes = pcg_ms = survey_pcg_bytes = 0; f1 = fused = False; f1_D = 0
         else:
@@ -591,6 +616,7 @@ def main():
                        'woodbury_cache_hits_last_solve': int(stats.get('woodbury_cache_hits', 0)),
                        'pcg_kernels_per_iteration': 1 if f1 else (2 if fused else 3), 'f1_replicas': int(stats.get('f1_replicas', 0)), 'f1_far_columns': int(stats.get('f1_far_columns', 0)), 'kernel_launches_per_solve': stats['kernel_launches'], 'graph_launches_per_solve': stats['graph_launches'],
                        'setup_s': t_setup, 'per_rank': [{'status': int(r[0]), 'iter': int(r[1]), 'obj': r[2]} for r in allrec]},
+            'device': dev_state,
             'roofline': None if hostsim else {'bound': 'hbm', 'kernel': dom + (' -- in solves this body runs as the K2F phase of k_slot_b' if (fused and not f1) else ''), 'achieved': probes[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': probes[dom]['GBps'] / HBM_PEAK_GBS, 'traffic': pmc_traffic(dom_kernel, wl_tag),
                          'bytes_per_launch': kb[dom], 'ms_per_launch': probes[dom]['ms'],
