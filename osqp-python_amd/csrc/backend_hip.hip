@@ -511,8 +511,10 @@ void ctl_group(Dev &d, int diagonal) {
 void ctl_poll(Dev &d, Ctl *out, int *seq, int *done) {
   HIP_CHECK(hipSetDevice(d.device));
   Impl &p = im(d);
-  HIP_CHECK(hipMemcpyAsync(p.pin_ctl2, d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, p.side));
+  // (the slot records FIRST: the state block is then at least as new as the launch count -- a count that says "the chunk's string is consumed" comes with
+  //  the chunk_done flag its last KA set, Engine::run_device_driven's test of a chunk that outran its string)
   HIP_CHECK(hipMemcpyAsync(p.pin_poll, d.slot, sizeof(int) * kSlotInts, hipMemcpyDeviceToHost, p.side));
+  HIP_CHECK(hipMemcpyAsync(p.pin_ctl2, d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, p.side));
   HIP_CHECK(hipStreamSynchronize(p.side));
   std::memcpy(out, p.pin_ctl2, sizeof(Ctl));
   if (p.pin_poll[2 * SR_WORDS] != p.epoch) { *seq = 0; *done = 0; out->status = CTL_RUNNING; return; }      // k_ctl_begin has not run yet

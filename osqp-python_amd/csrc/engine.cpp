@@ -763,13 +763,16 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
   long fed_end_seq = 0;                              // slot launches enqueued up to the end of chunk fed - 1
   auto feed_from_history = [&](int upto) {
     while (use_hist && fed < upto) {
-      if (fed >= (int)feed_hist_.size() || feed_hist_[fed] <= 0) { use_hist = false; break; }
+      if (fed >= (int)feed_hist_.size()) break;      // every recorded chunk is queued: the solve ends there if it follows the recorded course (the poll loop below waits for that,
+                                                     //  or for the device to begin a chunk beyond the record) -- topping up here would queue launches and groups behind the last boundary
+      if (feed_hist_[fed] <= 0) { use_hist = false; break; }
       const int np = (feed_hist_[fed] + 1) / 2;
       run_slots(0, np, 0); launched += np;
       run_group(diagonal);
       fed += 1; fed_end_seq = 2 * launched;
     }
   };
+  if (pol_.slot_log) { std::fprintf(stderr, "feed: history of %zu chunks:", feed_hist_.size()); for (int h : feed_hist_) std::fprintf(stderr, " %d", h); std::fprintf(stderr, "\n"); }
   feed_from_history(snap.boundaries + 2);
   // chunk in flight as of the last poll, and the progress counters at the first poll that saw it (rate estimate)
   if (!use_hist && launched == 0) {
@@ -785,7 +788,10 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
     if (use_hist) {
       // (the device is in chunk snap.boundaries; all of it and of the next is queued.  Everything up to the end of chunk fed - 1 consumed and
       //  the device still inside it: the course differs from the recorded one)
-      if (snap.boundaries < fed && seq >= fed_end_seq) use_hist = false;
+      if ((snap.boundaries < fed && seq >= fed_end_seq && !snap.chunk_done) || (fed >= (int)feed_hist_.size() && snap.boundaries >= fed)) {      // (chunk_done: the chunk HAS finished with its string, only its boundary group has not run yet)      // (... or past the last recorded chunk and still running)
+        use_hist = false;
+        if (pol_.slot_log) std::fprintf(stderr, "feed: history mode ends: device in chunk %d (iter %d, %d of its iterations done), chunks fed %d, launches executed %d of %ld fed\n", snap.boundaries, snap.iter, done, fed, seq, fed_end_seq);
+      }
       else {
         feed_from_history(snap.boundaries + 2);
         if (use_hist) { std::this_thread::sleep_for(std::chrono::microseconds(std::max(pol_.poll_sleep_us, 100))); continue; }
@@ -831,6 +837,7 @@ int Engine::run_device_driven(double t0, double *res, int *flags) {
   for (int q = 0; q < F_COUNT; q++) flags[q] = c.last_flags[q];
   for (int k = 0; k < 3; k++) if (c.kind_n[k] > 0) slot_pred_[k] = c.kind_sum[k] / c.kind_n[k];
   feed_hist_.assign(c.hist, c.hist + std::min(std::max(c.boundaries, 0), (int)kCtlHist));      // (what the next solve of this handle is fed from)
+  if (pol_.slot_log) { std::fprintf(stderr, "feed: this solve's chunks consumed:"); for (int h : feed_hist_) std::fprintf(stderr, " %d", h); std::fprintf(stderr, "  (boundaries %d, launches enqueued %ld)\n", c.boundaries, 2 * launched); }
   if (c.rho_bar != rho_bar_) { rho_bar_ = c.rho_bar; settings.rho = rho_bar_; }      // (applied on the device)
   if (timed_out && c.status == CTL_RUNNING) return -2;
   return c.status;
