@@ -574,10 +574,15 @@ static_assert(kF1StreamBytes % (kWaves * 1024) == 0, "every wave issues whole 1 
 // M0).  Inline asm: hipcc's builtin would make every later barrier drain the transfer (it counts it against vmcnt and waits before
 // __syncthreads); as asm the transfer is invisible to the compiler's wait insertion -- its own waits can only become stricter, never too weak
 // (it assumes fewer operations in flight than there are) -- and the consumer waits with f1_stream_wait.  M0 is saved and restored.
+// NT: the load carries the non-temporal bit -- the matrix stream is read once per launch and, beyond the Infinity Cache (n = 1M: 126 of the 320 MB a launch
+// moves), only evicts the window vectors its neighbours are about to gather: 96 -> 85 us per launch there; at n = 100k (everything cache-resident) it costs
+// 0.15 us, so the bit follows the write-through switch (WT = false: the HBM-resident regime).
+template <bool NT>
 __device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_base) {
 #if defined(__HIP_DEVICE_COMPILE__)
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+  if constexpr (NT) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+  else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
 #else
   (void)gsrc; (void)lds_base;
 #endif
@@ -590,13 +595,14 @@ __device__ __forceinline__ unsigned lds_offset_of(const void *p) {       // byte
 #endif
 }
 // request block b's stream: kF1StreamBytes / (kWaves * 1024) pieces per wave, no register holds anything afterwards
+template <bool NT>
 __device__ __forceinline__ void f1_stream_issue(const unsigned char *stream, int b, F1Stream &S) {
   constexpr int kPieces = kF1StreamBytes / (kWaves * 1024);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned char *g = stream + (size_t)b * kF1StreamBytes + (size_t)wave * (kPieces * 1024) + (threadIdx.x & 63) * 16;
   const unsigned l0 = lds_offset_of(&S) + (unsigned)wave * (kPieces * 1024);
 #pragma unroll
-  for (int q = 0; q < kPieces; q++) lds_dma16(g + q * 1024, __builtin_amdgcn_readfirstlane(l0 + q * 1024));
+  for (int q = 0; q < kPieces; q++) lds_dma16<NT>(g + q * 1024, __builtin_amdgcn_readfirstlane(l0 + q * 1024));
 }
 // everything this wave has requested has landed (its own pieces of the stream included); the workgroup barrier that follows publishes them
 __device__ __forceinline__ void f1_stream_wait() {
@@ -936,7 +942,7 @@ __device__ __forceinline__ void f1_body(const Dev &d, const int k, const bool ve
     //      block's remaining LDS phases, its stores, and the next block's record / window loads
     if (sl + slots < per) {
       const int bn = __builtin_amdgcn_readfirstlane(xcd * per + sl + slots);
-      if (bn < d.A.nblk) f1_stream_issue(f.stream, bn, S);
+      if (bn < d.A.nblk) f1_stream_issue<!WT>(f.stream, bn, S);
     }
     // ---- row sums: t = rho .* (A u) -> LDS
     // (first pass peeled: its operands are in registers -- a shared loop body would carry the later passes' load waits, and any `s_waitcnt vmcnt`
@@ -1030,10 +1036,11 @@ __device__ __forceinline__ bool f1_iteration(const Dev &d, const int k, const in
 }
 // the stream of the workgroup's FIRST row block: its address depends on nothing but the block index, so it leaves at the head of the launch,
 // before the phase record, the block record or the partials have arrived
+template <bool NT>
 __device__ __forceinline__ void f1_stream_first(const unsigned char *stream, int nblk, F1Stream &S) {
   const int per = (nblk + 7) >> 3, slot0 = (int)(blockIdx.x >> 3);
   const int b0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * per + slot0);
-  if (slot0 < per && b0 < nblk) f1_stream_issue(stream, b0, S);
+  if (slot0 < per && b0 < nblk) f1_stream_issue<NT>(stream, b0, S);
 }
 
 // ---------------------------------------------------------------------------------------------- KA in the F1 form (no KB launch)
@@ -1160,7 +1167,7 @@ __device__ __forceinline__ void f1_ka_body(const Dev &d, F1Lds &L, F1Stream &S, 
     __syncthreads();
     if (sl + slots < per) {                                 // (every wave holds its entries in registers: the next block's stream goes out)
       const int bn = __builtin_amdgcn_readfirstlane(xcd * per + sl + slots);
-      if (bn < d.A.nblk) f1_stream_issue(f.stream, bn, S);
+      if (bn < d.A.nblk) f1_stream_issue<!WT>(f.stream, bn, S);
     }
     // ---- rows: z~, the z / y update, v and t0 of the row (v -> LDS now, t0 kept for the second pass)
     double t0r = 0.0;
@@ -1274,7 +1281,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   __shared__ F1Lds lds;
   __shared__ F1Stream sbuf;
   const int par = k & 1;
-  f1_stream_first(d.f1.stream, d.A.nblk, sbuf);
+  f1_stream_first<!WT>(d.f1.stream, d.A.nblk, sbuf);
   const F1Fold fold = f1_fold_issue(gptr(d.part), par, mode);
   f1_iteration<D, MIX, WT>(d, k, 1 << 30, 0, mode, lds, sbuf, f1_first_record(d.f1.blk, d.A.nblk), fold, par);      // (the first block's record goes out ahead of the partials of the scalar fold: both latencies overlap)
 }
@@ -1284,7 +1291,7 @@ template <int D, bool MIX, bool WT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_f1_ka_probe(Dev d, int scatter_only) {
   __shared__ F1Lds lds;
   __shared__ F1Stream sbuf;
-  f1_stream_first(d.f1.stream, d.A.nblk, sbuf);
+  f1_stream_first<!WT>(d.f1.stream, d.A.nblk, sbuf);
   const F1Rec rec0 = f1_first_record(d.f1.blk, d.A.nblk);
   if (scatter_only) f1_ka_body<D, true, MIX, WT>(d, lds, sbuf, rec0, d.theta); else f1_ka_body<D, false, MIX, WT>(d, lds, sbuf, rec0, d.theta);
 }
@@ -1315,7 +1322,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   const int *R = h.slot + (par ? SR_WORDS : 0);
   int *W = gptr(d.slot) + (par ? 0 : SR_WORDS);
   // every phase but the idle one consumes the first block's stream: requested before anything else has arrived
-  f1_stream_first(h.stream, h.nblk, sbuf);
+  f1_stream_first<!WT>(h.stream, h.nblk, sbuf);
   const F1Fold fold = f1_fold_issue(gptr(h.part), par, 0);    // the previous launch's partials: their address depends on `par` alone
   const F1Rec rec0 = f1_first_record(h.blk, h.nblk);
   SlotState st = slot_read_scalar(R);
