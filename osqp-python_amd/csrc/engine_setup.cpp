@@ -338,7 +338,11 @@ void Engine::upload_f1(const F1Plan &pl) {
   { // write-through stores (DevF1::wt) while what a launch touches stays in the 256 MiB Infinity Cache: stream + vector arena + the m-vectors KA writes
     const double mb = ((double)(pl.blk.size() / 16) * kF1StreamBytes + 8.0 * (7 + 3 * (double)pl.D) * (double)f.ns + 8.0 * 10 * (double)m) / (1024.0 * 1024.0);
     const char *e = std::getenv("OSQP_HIP_F1_WT");
-    f.wt = e ? (e[0] != '0') : (mb <= 160.0);
+    // (measured, F launch in us with the results written through / with plain stores and a non-temporal matrix stream -- the kernels' two states:
+    //  n = 250k (110 MB by this estimate) 26.8 / 28.7;  400k (175 MB) 34.9 / 37.8;  550k (241 MB) 47.8 / 51.3;  750k (328 MB) 62.8 / 66.3;  1M (438 MB) 98.0 / 82.1.
+    //  Plain stores WITHOUT the non-temporal stream would be the best of three at 550k - 750k (47.1 / 59.9 us), but a third instantiation of every F1 kernel
+    //  cost the n = 100k solve 0.25 ms in the same-box A/B -- not kept)
+    f.wt = e ? (e[0] != '0') : (mb <= 380.0);
   }
   f.on = 1;
 }
